@@ -1,0 +1,125 @@
+"""Pin the CPU oracle (oracle/usflows_oracle.py) against
+ (a) golden vectors generated from the real reference (tests/golden/*.npz), fp32 and fp64,
+ (b) the reference's own known-answer tests (tests/veriflow/transforms_test.py:5-19, 35-51),
+ (c) -- only where /root/reference exists -- a live re-run of the reference."""
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import usflows_oracle as orc
+from golden_util import case_names, load_case
+
+SMALL = case_names(small_only=True)
+ALL = case_names()
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs() / b.double().abs().clamp_min(1e-30)).max().item()
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_fp64_matches_reference_fp64(name):
+    spec, sd, a = load_case(name)
+    sd64 = orc.to_dtype(sd, torch.float64)
+    ctx = a.get("context")
+    ctx64 = ctx.double() if ctx is not None else None
+    lp = orc.flow_log_prob(sd64, spec, a["x"].double(), ctx64)
+    assert _rel(lp, a["log_prob64"]) < 1e-11
+    z = orc.flow_backward(sd64, spec, a["x"].double(), ctx64)
+    assert torch.allclose(z, a["backward64"], rtol=1e-10, atol=1e-10)
+    xf = orc.flow_forward(sd64, spec, a["zin"].double(), ctx64)
+    assert torch.allclose(xf, a["forward64"], rtol=1e-10, atol=1e-10)
+    assert abs(float(orc.total_ladj(sd64, spec)) - float(a["total_ladj64"])) < 1e-9 * max(1.0, abs(float(a["total_ladj64"])))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_oracle_fp32_matches_reference_fp32(name):
+    """Same ops in the same order -> the fp32 oracle reproduces the fp32 reference to rounding
+    noise (bitwise on most cases; threaded BLAS reductions may differ in the last ulp)."""
+    spec, sd, a = load_case(name)
+    ctx = a.get("context")
+    lp = orc.flow_log_prob(sd, spec, a["x"], ctx)
+    assert _rel(lp, a["log_prob32"]) < 2e-6
+    # and both sit within the reference's own fp32 noise of the fp64 truth
+    assert _rel(lp, a["log_prob64"]) < 2e-5
+    z = orc.flow_backward(sd, spec, a["x"], ctx)
+    scale = a["backward64"].abs().max().item()
+    assert (z.double() - a["backward64"]).abs().max().item() < 2e-5 * scale
+    xf = orc.flow_forward(sd, spec, a["zin"], ctx)
+    scale = a["forward64"].abs().max().item()
+    assert (xf.double() - a["forward64"]).abs().max().item() < 2e-5 * scale
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", [n for n in ALL if "d784" in n])
+def test_oracle_cfg2_model(name):
+    """BASELINE cfg2 model (D=784, K=32, h=[256,256]): state dict regenerated from the seed."""
+    spec, sd, a = load_case(name)
+    lp = orc.flow_log_prob(sd, spec, a["x"])
+    assert _rel(lp, a["log_prob32"]) < 5e-6
+    assert _rel(lp, a["log_prob64"]) < 1e-5
+
+
+def test_udl_property_constant_jacobian():
+    """log_prob(x) - base.log_prob(f^-1(x)) is ONE constant (= -sum ladj): the uniformly-scaling
+    property the reference exists for (README.md:7-12)."""
+    spec, sd, a = load_case("synth_d16_k4_hh2_conj_laplace")
+    sd64 = orc.to_dtype(sd, torch.float64)
+    x = a["x"].double()
+    z, ld = orc.flow_backward(sd64, spec, x, return_logdet=True)
+    assert (ld - ld[0]).abs().max() == 0
+    assert abs(ld[0].item() + float(orc.total_ladj(sd64, spec))) < 1e-10
+
+
+# ---- the reference's own known-answer tests, restated on the oracle's primitives -----------
+def test_kat_scale_transform():
+    """tests/veriflow/transforms_test.py:5-19: scale==2 -> y=2x, exact inverse, ladj = 10 log 2."""
+    dim = 10
+    s = torch.ones(dim) * 2
+    x = torch.ones(dim)
+    y = x * s
+    assert (y == 2 * x).all()
+    assert (y / s == x).all()
+    assert s.abs().log().sum() == dim * torch.log(torch.tensor(2.0))
+
+
+def test_kat_lu_transform():
+    """tests/veriflow/transforms_test.py:35-51: L=tril(ones), U=I, b=0 -> y = arange+1, exact
+    inverse, ladj 0."""
+    dim = 10
+    L_raw, U_raw, b = torch.tril(torch.ones(dim, dim)), torch.eye(dim), torch.zeros(dim)
+    x = torch.ones(dim)
+    y = torch.nn.functional.linear(x, orc.lu_matrix(L_raw, U_raw), b)
+    assert (y == torch.arange(dim) + 1.0).all()
+    xb = torch.nn.functional.linear(y - b, orc.lu_inverse_matrix(L_raw, U_raw))
+    assert (xb == x).all()
+    assert orc.lu_ladj(U_raw) == 0
+
+
+def test_checkerboard_mask():
+    m = orc.checkerboard_mask(7)
+    assert m.shape == (1, 7) and m.flatten().tolist() == [0, 1, 0, 1, 0, 1, 0]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/usflows"), reason="reference not present")
+def test_oracle_vs_live_reference():
+    """Build container only: rerun the real reference now and compare with the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import ref_shim
+    flows, transforms, networks, distributions = ref_shim.install()
+    torch.manual_seed(7)
+    D = 12
+    flow = flows.USFlow(torch.distributions.Laplace(torch.zeros(D), torch.ones(D)), [D], 3,
+                        networks.ConditionalDenseNN,
+                        dict(input_dim=D, context_dim=1, hidden_dims=[20, 20], out_dim=D,
+                             nonlinearity=torch.nn.LeakyReLU(0.01)),
+                        householder=1, affine_conjugation=True)
+    spec = orc.FlowSpec(D, 3, [20, 20], householder=1, affine_conjugation=True)
+    sd = {k: v.detach() for k, v in flow.state_dict().items()}
+    x = torch.rand(9, D)
+    with torch.no_grad():
+        ref = flow.log_prob(x)
+    assert _rel(orc.flow_log_prob(sd, spec, x), ref) < 2e-6
