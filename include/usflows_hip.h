@@ -1,0 +1,176 @@
+/*
+ * usflows_hip.h -- C ABI of libusflows_hip.so: the MI355X (gfx950) kernels behind the USFlows
+ * coupling-flow hot path (Flow.log_prob / Flow.sample / Flow.backward / Flow._forward).
+ *
+ * Boundary contract:
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; sizes are int64_t;
+ *   - nothing is allocated inside; the caller owns every buffer for the duration of the call;
+ *   - work is enqueued on the given hipStream_t (pass torch's current stream) and the call
+ *     returns immediately; no host synchronisation, safe to capture into a hipGraph;
+ *   - return value: 0 = ok, negative = argument error, positive = hipError_t of the launch;
+ *     usf_last_error() gives a human-readable message for the calling thread. No exceptions
+ *     cross the ABI.
+ *
+ * The reference (aai-institute/USFlows) has no native layer: each entry point below replaces a
+ * sequence of ATen ops issued by the cited reference lines (paths relative to /root/reference).
+ */
+#ifndef USFLOWS_HIP_H
+#define USFLOWS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* usf_stream_t; /* hipStream_t */
+
+#define USF_ABI_VERSION 1
+
+/* activation ids (conditioner nonlinearity, networks.py:717,737) */
+#define USF_ACT_NONE 0
+#define USF_ACT_LEAKY_RELU 1 /* slope 0 == ReLU */
+
+/* base distribution ids */
+#define USF_BASE_LAPLACE 0 /* torch Laplace.log_prob summed over D (Independent, distributions.py:709-728) */
+#define USF_BASE_NORMAL 1  /* torch Normal.log_prob summed over D */
+#define USF_BASE_LPNORM1 2 /* r = ||z-loc||_1  (RadialDistribution.log_prob, distributions.py:501-505) */
+#define USF_BASE_LPNORM2 3 /* r = ||z-loc||_2 */
+#define USF_BASE_LPNORMINF 4 /* r = ||z-loc||_inf */
+
+/*
+ * Fused dense layer:   C = epilogue( prologue(A) @ W^T )        (row-major, fp32, exact-f32 MFMA)
+ *
+ *   prologue(A)[m,k] = (A[m,k] / pre_div[k]) - pre_sub[k]       (each optional)
+ *   acc[m,n]         = sum_k prologue(A)[m,k] * W[n,k]
+ *   v                = act(acc + bias[n])                       (bias optional)
+ *   v                = residual[m,n] + res_sign * v             (residual optional)
+ *   C[m,n]           = v * post_mul[n]                          (post_mul optional)
+ *
+ * replaces, depending on the flags:
+ *   BlockAffineTransform.backward  y=(y-b)@Minv^T        transforms.py:936-962 (pre_sub=b, W=Minv)
+ *   ... preceded by ScaleTransform.backward x/scale      transforms.py:116-125 (pre_div=scale)
+ *   BlockAffineTransform.forward   y=x@M^T+b             transforms.py:913-934 (bias=b, W=M)
+ *   ... followed by ScaleTransform.forward x*scale       transforms.py:105-114 (post_mul=scale)
+ *   one nn.Linear (+LeakyReLU) of the conditioner MLP    networks.py:739-751
+ *   the masked residual of MaskedCoupling                transforms.py:285-290, 301-306
+ *     (mask-aware: A/W/C are the pass-through / transformed column segments)
+ * Requirements: K % 4 == 0, lda/ldw/ldc/ldr % 4 == 0, all base pointers 16-byte aligned.
+ */
+typedef struct usf_linear_desc {
+  const float* A;        int64_t lda;   /* [M,K] activations */
+  const float* W;        int64_t ldw;   /* [N,K] weight, K contiguous (torch nn.Linear layout) */
+  const float* bias;                    /* [N] or NULL */
+  const float* pre_div;                 /* [K] or NULL */
+  const float* pre_sub;                 /* [K] or NULL */
+  const float* residual; int64_t ldr;   /* [M,N] or NULL */
+  const float* post_mul;                /* [N] or NULL */
+  float*       C;        int64_t ldc;   /* [M,N] */
+  int64_t M, N, K;
+  float res_sign;                       /* +1 (coupling forward) / -1 (coupling backward) */
+  float slope;                          /* LeakyReLU negative slope */
+  int32_t act;                          /* USF_ACT_* */
+  int32_t reserved;
+} usf_linear_desc;
+
+int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream);
+
+/*
+ * Fused additive coupling layer (MaskedCoupling.forward/backward, transforms.py:277-306) with a
+ * dense (leaky-)ReLU conditioner (ConditionalDenseNN networks.py:739-751 / pyro DenseNN):
+ *
+ *   out[:, pass]  = z[:, pass]                                   (only if out != z)
+ *   out[:, trans] = z[:, trans] + sign * MLP(z[:, pass] [, context])
+ *
+ * Mask-aware: W_in holds only the columns of layers[0].weight that multiply pass-through
+ * features (the others meet x*mask == 0), W_out/b_out only the rows that produce transformed
+ * features (the others are multiplied by (1-mask) == 0).  Hidden activations never leave the
+ * CU (registers/LDS).  n_hidden in [1, USF_MAX_HIDDEN]; every hidden width <= usf_coupling_max_width().
+ */
+#define USF_MAX_HIDDEN 4
+typedef struct usf_coupling_desc {
+  const float* z;   int64_t ldz;        /* [M, >= off_pass+n_pass, off_trans+n_trans] */
+  float*       out; int64_t ldo;        /* may alias z (in place on the transformed half) */
+  int64_t M;
+  int64_t off_pass, n_pass;             /* conditioning (mask==1) column segment */
+  int64_t off_trans, n_trans;           /* transformed (mask==0) column segment */
+  int32_t n_hidden;
+  int32_t hidden[USF_MAX_HIDDEN];
+  const float* W_in;   int64_t ldw_in;  /* [hidden[0], n_pass] */
+  const float* b_in;                    /* [hidden[0]] */
+  const float* W_hid[USF_MAX_HIDDEN];   /* W_hid[i]: [hidden[i+1], hidden[i]], i < n_hidden-1 */
+  const float* b_hid[USF_MAX_HIDDEN];
+  int64_t      ldw_hid[USF_MAX_HIDDEN];
+  const float* W_out;  int64_t ldw_out; /* [n_trans, hidden[last]] */
+  const float* b_out;                   /* [n_trans] */
+  const float* context;                 /* [M] (context_dim == 1, flows.py:188-191,564) or NULL */
+  const float* W_ctx;                   /* [hidden[0]] (layers[1].weight[:,0]) or NULL */
+  const float* b_ctx;                   /* [hidden[0]] or NULL */
+  const float* post_sub;                /* [n_trans]+[n_pass] reserved, must be NULL */
+  float sign;                           /* +1 forward, -1 backward */
+  float slope;
+  int32_t act;
+  int32_t reserved;
+} usf_coupling_desc;
+
+int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream);
+int usf_coupling_max_width(void);       /* widest hidden layer the fused kernel accepts */
+
+/*
+ * Tail of Flow.log_prob (flows.py:245): per-sample reduction over the feature axis.
+ *   LAPLACE/NORMAL: logp[m] = sum_d base_d(z[m,d]) + logdet_const
+ *   LPNORM*:        logp[m] = ||z[m,:] - loc||_p   (the caller finishes RadialDistribution.log_prob
+ *                             on the [M] vector: distributions.py:506-511)
+ * loc/scale: [D] (scale unused for LPNORM*). If sum_out != NULL, sum_out[0] += sum_m logp[m] and
+ * sum_out[1] += M (fp64 accumulators, for the data-parallel mean: one RCCL all-reduce of 2 scalars).
+ */
+int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base,
+                         const float* loc, const float* scale, float logdet_const,
+                         float* logp, double* sum_out, usf_stream_t stream);
+
+/*
+ * Head of Flow.sample (flows.py:258): z ~ base, counter-based Philox4x32-10 RNG.
+ *   LAPLACE: u~U(eps-1,1); z = loc - scale*sign(u)*log1p(-|u|)   (torch Laplace.rsample)
+ *   NORMAL : Box-Muller;   z = loc + scale*n
+ * Element (m,d) always consumes counter (m*D+d)/4 of stream (seed, offset): results do not
+ * depend on the launch geometry, and ranks draw disjoint substreams via `row_offset`.
+ */
+int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base,
+                        const float* loc, const float* scale, uint64_t seed, uint64_t offset,
+                        int64_t row_offset, usf_stream_t stream);
+
+/* ScaleTransform.forward / backward as a standalone layer (transforms.py:105-125): y = x*s or x/s */
+int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D,
+                  const float* s, int32_t divide, usf_stream_t stream);
+
+/* column gather/scatter between the user's natural layout and the engine's segment layout:
+ * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */
+int usf_gather_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t n,
+                        const int32_t* idx, usf_stream_t stream);
+
+/*
+ * Run a prebuilt list of ops with ONE call (the whole flow: ~2K+2 launches). op.kind selects the
+ * member of the union; pointers inside may be patched by the caller between calls.
+ */
+#define USF_OP_LINEAR 1
+#define USF_OP_COUPLING 2
+typedef struct usf_op {
+  int32_t kind;
+  int32_t reserved;
+  union {
+    usf_linear_desc linear;
+    usf_coupling_desc coupling;
+  } u;
+} usf_op;
+
+int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream);
+
+int usf_abi_version(void);
+int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op) for kind 1|2|0: binding self-check */
+const char* usf_last_error(void);
+const char* usf_build_info(void);       /* "gfx950 ..." */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USFLOWS_HIP_H */

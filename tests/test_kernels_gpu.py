@@ -1,0 +1,187 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (usflows_amd._ext -> libusflows_hip.so).
+Reference for each op = the torch-CPU expression the oracle uses (fp32), plus fp64 for error bars."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ext():
+    from usflows_amd import _ext
+    _ext.load()
+    return _ext
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test needs a GPU"
+    return torch.device("cuda:0")
+
+
+def _linear_ref(A, W, bias, pre_div, pre_sub, residual, post_mul, res_sign, slope, act, dtype):
+    a = A.to(dtype)
+    if pre_div is not None:
+        a = a / pre_div.to(dtype)
+    if pre_sub is not None:
+        a = a - pre_sub.to(dtype)
+    v = a @ W.to(dtype).t()
+    if bias is not None:
+        v = v + bias.to(dtype)
+    if act:
+        v = torch.nn.functional.leaky_relu(v, slope)
+    if residual is not None:
+        v = residual.to(dtype) + res_sign * v
+    if post_mul is not None:
+        v = v * post_mul.to(dtype)
+    return v
+
+
+CASES = [
+    # M, N, K, flags
+    (1, 1, 4, {}),
+    (5, 3, 8, dict(bias=True)),
+    (48, 7, 8, dict(bias=True, pre_sub=True)),
+    (65, 33, 36, dict(bias=True, act=True)),
+    (64, 64, 64, dict(bias=True, residual=True, res_sign=-1.0)),
+    (130, 160, 52, dict(pre_div=True, pre_sub=True)),
+    (257, 161, 100, dict(bias=True, post_mul=True)),
+    (300, 784, 784, dict(pre_sub=True)),
+    (513, 256, 392, dict(bias=True, act=True)),
+    (256, 392, 256, dict(bias=True, residual=True, res_sign=1.0)),
+    (1000, 129, 260, dict(bias=True, act=True, slope=0.0)),
+    (2048, 800, 784, dict(bias=True)),
+]
+
+
+@pytest.mark.parametrize("M,N,K,flags", CASES)
+def test_linear_parity(M, N, K, flags):
+    ext, dev = _ext(), _dev()
+    g = torch.Generator().manual_seed(M * 1000003 + N * 1009 + K)
+    lda, ldw, ldc = K + 4, K, N + 3
+    A = torch.randn(M, lda, generator=g)
+    W = torch.randn(N, ldw, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) if flags.get("bias") else None
+    pre_div = (torch.rand(K, generator=g) + 0.5) * torch.where(torch.rand(K, generator=g) < 0.5, -1.0, 1.0) \
+        if flags.get("pre_div") else None
+    pre_sub = torch.randn(K, generator=g) if flags.get("pre_sub") else None
+    residual = torch.randn(M, N + 5, generator=g) if flags.get("residual") else None
+    post_mul = torch.randn(N, generator=g) if flags.get("post_mul") else None
+    act = 1 if flags.get("act") else 0
+    slope = flags.get("slope", 0.01)
+    res_sign = flags.get("res_sign", 1.0)
+
+    d = lambda t: None if t is None else t.to(dev)
+    C = torch.full((M, ldc), float("nan"), device=dev)
+    ext.linear(d(A), d(W), C, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=d(bias), pre_div=d(pre_div),
+               pre_sub=d(pre_sub), residual=d(residual), ldr=(N + 5), post_mul=d(post_mul), res_sign=res_sign,
+               act=act, slope=slope)
+    torch.cuda.synchronize()
+    out = C.cpu()
+    res = None if residual is None else residual[:, :N]
+    ref64 = _linear_ref(A[:, :K], W, bias, pre_div, pre_sub, res, post_mul, res_sign, slope, act, torch.float64)
+    ref32 = _linear_ref(A[:, :K], W, bias, pre_div, pre_sub, res, post_mul, res_sign, slope, act, torch.float32)
+    assert torch.isnan(out[:, N:]).all(), "kernel wrote outside its N columns"
+    got = out[:, :N].double()
+    scale = ref64.abs().max().item() + 1e-30
+    err = (got - ref64).abs().max().item() / scale
+    err_ref = (ref32.double() - ref64).abs().max().item() / scale
+    # fp32 fma-chain GEMM: same error class as the CPU sgemm (tolerance: 1e-5 relative, north_star)
+    assert err < max(4 * err_ref, 2e-6), (err, err_ref)
+    assert err < 1e-5
+
+
+def test_linear_rejects_bad_args():
+    ext, dev = _ext(), _dev()
+    A = torch.zeros(4, 6, device=dev)
+    W = torch.zeros(4, 6, device=dev)
+    C = torch.zeros(4, 4, device=dev)
+    with pytest.raises(RuntimeError):
+        ext.linear(A, W, C, M=4, N=4, K=6, lda=6, ldw=6, ldc=4)   # K % 4 != 0
+
+
+@pytest.mark.parametrize("base", ["laplace", "normal", "l1", "l2", "linf"])
+@pytest.mark.parametrize("M,D", [(1, 1), (7, 5), (100, 784), (1000, 33)])
+def test_base_logprob(base, M, D):
+    ext, dev = _ext(), _dev()
+    g = torch.Generator().manual_seed(M * 31 + D)
+    ld = D + (4 - D % 4) % 4
+    z = torch.randn(M, ld, generator=g) * 3
+    loc = torch.randn(D, generator=g)
+    sc = torch.rand(D, generator=g) + 0.5
+    const = -12.5
+    out = torch.empty(M, device=dev)
+    acc = torch.zeros(2, dtype=torch.float64, device=dev)
+    ids = dict(laplace=ext.BASE_LAPLACE, normal=ext.BASE_NORMAL, l1=ext.BASE_LPNORM1, l2=ext.BASE_LPNORM2,
+               linf=ext.BASE_LPNORMINF)
+    ext.base_logprob(z.to(dev), ld, M, D, ids[base], loc.to(dev), sc.to(dev), const, out, acc)
+    torch.cuda.synchronize()
+    zz = z[:, :D].double()
+    l64, s64 = loc.double(), sc.double()
+    if base == "laplace":
+        ref = torch.distributions.Laplace(l64, s64).log_prob(zz).sum(-1) + const
+    elif base == "normal":
+        ref = torch.distributions.Normal(l64, s64).log_prob(zz).sum(-1) + const
+    elif base == "l1":
+        ref = (zz - l64).norm(p=1, dim=-1)
+    elif base == "l2":
+        ref = (zz - l64).norm(p=2, dim=-1)
+    else:
+        ref = (zz - l64).norm(p=math.inf, dim=-1)
+    got = out.cpu().double()
+    assert ((got - ref).abs() / ref.abs().clamp_min(1e-3)).max().item() < 2e-6
+    a = acc.cpu()
+    assert abs(a[0].item() - got.sum().item()) < 1e-6 * max(1.0, abs(got.sum().item()))
+    assert a[1].item() == M
+
+
+def test_scale_and_gather():
+    ext, dev = _ext(), _dev()
+    M, D = 37, 21
+    x = torch.randn(M, D)
+    s = torch.randn(D) + 2
+    y = torch.empty(M, D, device=dev)
+    ext.scale(x.to(dev), D, y, D, M, D, s.to(dev), 1)
+    assert torch.equal(y.cpu(), x / s)
+    ext.scale(x.to(dev), D, y, D, M, D, s.to(dev), 0)
+    assert torch.equal(y.cpu(), x * s)
+    idx = torch.tensor([3, 0, -1, 20, 5], dtype=torch.int32)
+    out = torch.empty(M, 8, device=dev).fill_(7.0)
+    ext.gather_cols(x.to(dev), D, out, 8, M, 5, idx.to(dev))
+    o = out.cpu()
+    assert torch.equal(o[:, 0], x[:, 3]) and torch.equal(o[:, 1], x[:, 0]) and (o[:, 2] == 0).all()
+    assert torch.equal(o[:, 3], x[:, 20]) and (o[:, 5:] == 7).all()
+
+
+@pytest.mark.parametrize("base", ["laplace", "normal"])
+def test_base_sample_statistics_and_determinism(base):
+    ext, dev = _ext(), _dev()
+    M, D = 20000, 20
+    loc = torch.linspace(-1, 1, D)
+    sc = torch.linspace(0.5, 2.0, D)
+    bid = ext.BASE_LAPLACE if base == "laplace" else ext.BASE_NORMAL
+    z1 = torch.empty(M, D, device=dev)
+    z2 = torch.empty(M, D, device=dev)
+    ext.base_sample(z1, D, M, D, bid, loc.to(dev), sc.to(dev), 1234, 0)
+    ext.base_sample(z2, D, M, D, bid, loc.to(dev), sc.to(dev), 1234, 0)
+    assert torch.equal(z1, z2)
+    # rank substreams: rows [M/2, M) drawn with row_offset reproduce the tail of the full draw
+    z3 = torch.empty(M // 2, D, device=dev)
+    ext.base_sample(z3, D, M // 2, D, bid, loc.to(dev), sc.to(dev), 1234, 0, row_offset=M // 2)
+    assert torch.equal(z3, z1[M // 2:])
+    ext.base_sample(z2, D, M, D, bid, loc.to(dev), sc.to(dev), 1235, 0)
+    assert not torch.equal(z1, z2)
+    z = z1.cpu().double()
+    assert torch.isfinite(z).all()
+    mean, std = z.mean(0), z.std(0)
+    true_std = sc.double() * (math.sqrt(2.0) if base == "laplace" else 1.0)
+    assert ((mean - loc.double()).abs() < 5 * true_std / math.sqrt(M)).all()
+    assert ((std - true_std).abs() / true_std < 0.05).all()
+    # distribution check (KS against the analytic CDF) on one column
+    col = ((z[:, 3] - loc[3].double()) / sc[3].double()).sort().values
+    if base == "laplace":
+        cdf = torch.where(col < 0, 0.5 * torch.exp(col), 1 - 0.5 * torch.exp(-col))
+    else:
+        cdf = 0.5 * (1 + torch.erf(col / math.sqrt(2.0)))
+    emp = (torch.arange(1, M + 1, dtype=torch.float64)) / M
+    assert (cdf - emp).abs().max().item() < 1.7 / math.sqrt(M)

@@ -1,0 +1,176 @@
+"""ctypes binding of ``libusflows_hip.so`` (C ABI in ``include/usflows_hip.h``).
+
+The library is built in-tree by ``usflows_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+for gfx950.  There is NO fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised -- the product path never silently degrades to eager PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  -- must be imported first: the .so binds to torch's HIP runtime instance
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libusflows_hip.so")
+
+USF_ABI_VERSION = 1
+USF_MAX_HIDDEN = 4
+
+ACT_NONE, ACT_LEAKY_RELU = 0, 1
+BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
+OP_LINEAR, OP_COUPLING = 1, 2
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [
+        ("A", _fp), ("lda", C.c_int64),
+        ("W", _fp), ("ldw", C.c_int64),
+        ("bias", _fp), ("pre_div", _fp), ("pre_sub", _fp),
+        ("residual", _fp), ("ldr", C.c_int64),
+        ("post_mul", _fp),
+        ("C", _fp), ("ldc", C.c_int64),
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("res_sign", C.c_float), ("slope", C.c_float),
+        ("act", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class CouplingDesc(C.Structure):
+    _fields_ = [
+        ("z", _fp), ("ldz", C.c_int64),
+        ("out", _fp), ("ldo", C.c_int64),
+        ("M", C.c_int64),
+        ("off_pass", C.c_int64), ("n_pass", C.c_int64),
+        ("off_trans", C.c_int64), ("n_trans", C.c_int64),
+        ("n_hidden", C.c_int32), ("hidden", C.c_int32 * USF_MAX_HIDDEN),
+        ("W_in", _fp), ("ldw_in", C.c_int64), ("b_in", _fp),
+        ("W_hid", _fp * USF_MAX_HIDDEN), ("b_hid", _fp * USF_MAX_HIDDEN), ("ldw_hid", C.c_int64 * USF_MAX_HIDDEN),
+        ("W_out", _fp), ("ldw_out", C.c_int64), ("b_out", _fp),
+        ("context", _fp), ("W_ctx", _fp), ("b_ctx", _fp),
+        ("post_sub", _fp),
+        ("sign", C.c_float), ("slope", C.c_float),
+        ("act", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("u", _OpUnion)]
+
+
+# every symbol include/usflows_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "usf_abi_version": (C.c_int, []),
+    "usf_sizeof_desc": (C.c_int, [C.c_int32]),
+    "usf_last_error": (C.c_char_p, []),
+    "usf_build_info": (C.c_char_p, []),
+    "usf_linear_f32": (C.c_int, [C.POINTER(LinearDesc), C.c_void_p]),
+    "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
+    "usf_coupling_max_width": (C.c_int, []),
+    "usf_base_logprob_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_float,
+                                       _fp, _fp, C.c_void_p]),
+    "usf_base_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
+                                      C.c_uint64, C.c_int64, C.c_void_p]),
+    "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
+    "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
+    "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_exists() -> bool:
+    return os.path.isfile(LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once). Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not lib_exists():
+        raise RuntimeError(
+            f"usflows_amd: HIP extension not built ({LIB_PATH} missing). Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C usflows_amd/csrc`. "
+            "There is no CPU/eager fallback for the device path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.usf_abi_version() != USF_ABI_VERSION:
+        raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
+    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op)):
+        if lib.usf_sizeof_desc(kind) != C.sizeof(st):
+            raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
+                               f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().usf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"usflows_amd HIP call failed ({what}, rc={rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+# ---- thin typed wrappers (each enqueues on torch's current stream) ---------------------------
+def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_sub=None, residual=None,
+           ldr=0, post_mul=None, res_sign=1.0, act=ACT_NONE, slope=0.0, a_off=0, c_off=0, r_off=0):
+    """usf_linear_f32 on raw tensors; *_off are element offsets into A/C/residual."""
+    d = LinearDesc()
+    d.A = A.data_ptr() + 4 * a_off
+    d.lda = lda
+    d.W = W.data_ptr()
+    d.ldw = ldw
+    d.bias = ptr(bias)
+    d.pre_div = ptr(pre_div)
+    d.pre_sub = ptr(pre_sub)
+    d.residual = None if residual is None else residual.data_ptr() + 4 * r_off
+    d.ldr = ldr
+    d.post_mul = ptr(post_mul)
+    d.C = C_out.data_ptr() + 4 * c_off
+    d.ldc = ldc
+    d.M, d.N, d.K = M, N, K
+    d.res_sign, d.slope, d.act = res_sign, slope, act
+    check(load().usf_linear_f32(C.byref(d), current_stream(A.device)), "usf_linear_f32")
+
+
+def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):
+    check(load().usf_base_logprob_f32(z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), float(logdet_const),
+                                      out.data_ptr(), ptr(sum_out), current_stream(z.device)),
+          "usf_base_logprob_f32")
+
+
+def base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset=0):
+    check(load().usf_base_sample_f32(z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), seed, offset,
+                                     row_offset, current_stream(z.device)), "usf_base_sample_f32")
+
+
+def scale(x, ldx, y, ldy, M, D, s, divide):
+    check(load().usf_scale_f32(x.data_ptr(), ldx, y.data_ptr(), ldy, M, D, s.data_ptr(), int(divide),
+                               current_stream(x.device)), "usf_scale_f32")
+
+
+def gather_cols(src, lds, dst, ldd, M, n, idx):
+    check(load().usf_gather_cols_f32(src.data_ptr(), lds, dst.data_ptr(), ldd, M, n, idx.data_ptr(),
+                                     current_stream(src.device)), "usf_gather_cols_f32")
+
+
+def run_ops(ops_array, n, device=None):
+    check(load().usf_run_ops(ops_array, n, current_stream(device)), "usf_run_ops")

@@ -1,0 +1,90 @@
+// extern "C" surface of libusflows_hip.so (declared in include/usflows_hip.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include "usf_common.h"
+
+namespace usf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int linear_dispatch(const usf_linear_desc* d, hipStream_t stream);
+int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
+int coupling_max_width();
+int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
+                 const float* scale, float logdet_const, float* logp, double* sum_out, hipStream_t stream);
+int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* scale,
+                uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream);
+int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s, int32_t divide,
+          hipStream_t stream);
+int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
+                hipStream_t stream);
+
+}  // namespace usf
+
+extern "C" {
+
+int usf_abi_version(void) { return USF_ABI_VERSION; }
+int usf_sizeof_desc(int32_t kind) {
+  switch (kind) {
+    case USF_OP_LINEAR: return (int)sizeof(usf_linear_desc);
+    case USF_OP_COUPLING: return (int)sizeof(usf_coupling_desc);
+    case 0: return (int)sizeof(usf_op);
+    default: return -1;
+  }
+}
+const char* usf_last_error(void) { return usf::g_err; }
+const char* usf_build_info(void) { return "libusflows_hip gfx950 f32-mfma (" __DATE__ " " __TIME__ ")"; }
+
+int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream) {
+  return usf::linear_dispatch(d, (hipStream_t)stream);
+}
+
+int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream) {
+  return usf::coupling_dispatch(d, (hipStream_t)stream);
+}
+
+int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
+
+int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
+                         const float* scale, float logdet_const, float* logp, double* sum_out, usf_stream_t stream) {
+  return usf::base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, logp, sum_out, (hipStream_t)stream);
+}
+
+int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
+                        const float* scale, uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream) {
+  return usf::base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset, (hipStream_t)stream);
+}
+
+int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s,
+                  int32_t divide, usf_stream_t stream) {
+  return usf::scale(x, ldx, y, ldy, M, D, s, divide, (hipStream_t)stream);
+}
+
+int usf_gather_cols_f32(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n,
+                        const int32_t* idx, usf_stream_t stream) {
+  return usf::gather_cols(src, lds_, dst, ldd, M, n, idx, (hipStream_t)stream);
+}
+
+int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {
+  if (n_ops < 0 || (n_ops > 0 && !ops)) { usf::set_error("usf_run_ops: bad op list"); return -1; }
+  for (int32_t i = 0; i < n_ops; ++i) {
+    int rc;
+    switch (ops[i].kind) {
+      case USF_OP_LINEAR: rc = usf::linear_dispatch(&ops[i].u.linear, (hipStream_t)stream); break;
+      case USF_OP_COUPLING: rc = usf::coupling_dispatch(&ops[i].u.coupling, (hipStream_t)stream); break;
+      default: usf::set_error("usf_run_ops: op %d has unknown kind %d", i, ops[i].kind); return -2;
+    }
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

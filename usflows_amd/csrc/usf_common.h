@@ -1,0 +1,46 @@
+// Shared device/host helpers for libusflows_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/usflows_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define USF_WAVE 64
+
+namespace usf {
+
+void set_error(const char* fmt, ...);
+
+static inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// leaky_relu exactly as ATen: x > 0 ? x : x * slope
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  return (act == USF_ACT_LEAKY_RELU) ? (v > 0.0f ? v : v * slope) : v;
+}
+
+// 64-lane sum via DPP-friendly shuffles (wavefront = 64 on gfx950)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace usf

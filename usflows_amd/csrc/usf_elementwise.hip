@@ -1,0 +1,231 @@
+// HBM-bound kernels of the path: base-density tail (per-sample wave reduction), base sampling
+// head (Philox), standalone scale layer, column gather.  One wave per row, 16-B lane accesses.
+#include "usf_common.h"
+
+namespace usf {
+
+// ------------------------------------------------------------------------------------------
+// tail: logp[m] = sum_d f(z[m,d]) + c    |   r[m] = ||z[m,:]-loc||_p
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float base_term(float z, float loc, float scale, int base) {
+  switch (base) {
+    case USF_BASE_LAPLACE:   // torch Laplace.log_prob: -log(2*scale) - |v-loc|/scale
+      return -logf(2.0f * scale) - fabsf(z - loc) / scale;
+    case USF_BASE_NORMAL: {  // torch Normal.log_prob: -((v-loc)^2)/(2 var) - log(scale) - log(sqrt(2 pi))
+      const float d = z - loc;
+      return -(d * d) / (2.0f * (scale * scale)) - logf(scale) - 0.91893853320467274178f;
+    }
+    case USF_BASE_LPNORM1:   return fabsf(z - loc);
+    case USF_BASE_LPNORM2: { const float d = z - loc; return d * d; }
+    default:                 return fabsf(z - loc);   // LPNORMINF (max-reduced)
+  }
+}
+
+template <int BASE>
+__global__ __launch_bounds__(256) void base_logprob_kernel(const float* __restrict__ z, int64_t ldz, int M, int D,
+                                                           const float* __restrict__ loc,
+                                                           const float* __restrict__ scale, float logdet_const,
+                                                           float* __restrict__ logp, double* __restrict__ sum_out) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  double block_sum = 0.0;
+  const bool vec = ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15u) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(loc) & 15u) == 0) &&
+                   (scale == nullptr || (reinterpret_cast<uintptr_t>(scale) & 15u) == 0);
+  const int D4 = vec ? (D & ~3) : 0;
+  for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave_in_block; row < M;
+       row += (int64_t)gridDim.x * waves_per_block) {
+    const float* zr = z + row * ldz;
+    float acc = 0.f;
+    for (int d = lane * 4; d < D4; d += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zr + d);
+      const f32x4 l = *reinterpret_cast<const f32x4*>(loc + d);
+      f32x4 s = {1.f, 1.f, 1.f, 1.f};
+      if (BASE == USF_BASE_LAPLACE || BASE == USF_BASE_NORMAL) s = *reinterpret_cast<const f32x4*>(scale + d);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = base_term(v[j], l[j], s[j], BASE);
+        acc = (BASE == USF_BASE_LPNORMINF) ? fmaxf(acc, t) : acc + t;
+      }
+    }
+    for (int d = D4 + lane; d < D; d += 64) {
+      const float s = (BASE == USF_BASE_LAPLACE || BASE == USF_BASE_NORMAL) ? scale[d] : 1.f;
+      const float t = base_term(zr[d], loc[d], s, BASE);
+      acc = (BASE == USF_BASE_LPNORMINF) ? fmaxf(acc, t) : acc + t;
+    }
+    acc = (BASE == USF_BASE_LPNORMINF) ? wave_max(acc) : wave_sum(acc);
+    float out;
+    if (BASE == USF_BASE_LPNORM2) out = sqrtf(acc);
+    else if (BASE == USF_BASE_LAPLACE || BASE == USF_BASE_NORMAL) out = acc + logdet_const;
+    else out = acc;
+    if (lane == 0) {
+      logp[row] = out;
+      block_sum += (double)out;
+    }
+  }
+  if (sum_out != nullptr) {
+    __shared__ double part[4];
+    if (lane == 0) part[wave_in_block] = block_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < waves_per_block; ++w) t += part[w];
+      if (t != 0.0) atomicAdd(&sum_out[0], t);
+    }
+  }
+}
+
+__global__ void add_count_kernel(double* sum_out, double n) { sum_out[1] += n; }
+
+int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
+                 const float* scale, float logdet_const, float* logp, double* sum_out, hipStream_t stream) {
+  if (M < 0 || D <= 0 || M > 0x7fffffff || D > 0x7fffffff || ldz < D) { set_error("usf_base_logprob_f32: bad sizes"); return -2; }
+  if (M == 0) return 0;
+  if (!z || !loc || !logp) { set_error("usf_base_logprob_f32: null pointer"); return -1; }
+  if ((base == USF_BASE_LAPLACE || base == USF_BASE_NORMAL) && !scale) { set_error("usf_base_logprob_f32: scale required"); return -1; }
+  const int wpb = 4;
+  int64_t blocks = (M + wpb - 1) / wpb;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  dim3 g((unsigned)blocks), b(256);
+#define USF_LAUNCH_BASE(B) \
+  hipLaunchKernelGGL((base_logprob_kernel<B>), g, b, 0, stream, z, ldz, (int)M, (int)D, loc, scale, logdet_const, logp, sum_out)
+  switch (base) {
+    case USF_BASE_LAPLACE: USF_LAUNCH_BASE(USF_BASE_LAPLACE); break;
+    case USF_BASE_NORMAL: USF_LAUNCH_BASE(USF_BASE_NORMAL); break;
+    case USF_BASE_LPNORM1: USF_LAUNCH_BASE(USF_BASE_LPNORM1); break;
+    case USF_BASE_LPNORM2: USF_LAUNCH_BASE(USF_BASE_LPNORM2); break;
+    case USF_BASE_LPNORMINF: USF_LAUNCH_BASE(USF_BASE_LPNORMINF); break;
+    default: set_error("usf_base_logprob_f32: unknown base %d", base); return -2;
+  }
+#undef USF_LAUNCH_BASE
+  int rc = check_launch("usf_base_logprob_f32");
+  if (rc) return rc;
+  if (sum_out) {
+    hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, sum_out, (double)M);
+    rc = check_launch("usf_base_logprob_f32(count)");
+  }
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// head: Philox4x32-10 counter RNG -> Laplace / Normal
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+}
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t stream_id, uint64_t seed, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+// uniform in (0,1): 24 random bits, never 0 or 1
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void base_sample_kernel(float* __restrict__ z, int64_t ldz, int64_t M, int D,
+                                                          int base, const float* __restrict__ loc,
+                                                          const float* __restrict__ scale, uint64_t seed,
+                                                          uint64_t offset, int64_t row_offset) {
+  const int64_t groups_per_row = (D + 3) / 4;
+  const int64_t total = M * groups_per_row;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = g / groups_per_row;
+    const int d0 = (int)(g % groups_per_row) * 4;
+    uint32_t rnd[4];
+    philox4x32_10((uint64_t)((m + row_offset) * groups_per_row + d0 / 4), offset, seed, rnd);
+    float v[4];
+    if (base == USF_BASE_LAPLACE) {
+      // torch Laplace.rsample: u ~ U(eps-1, 1); loc - scale*sign(u)*log1p(-|u|)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = 2.0f * u01(rnd[j]) - 1.0f;
+        const float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
+        v[j] = -sgn * log1pf(-fabsf(u));
+      }
+    } else {
+      const float r0 = sqrtf(-2.0f * logf(u01(rnd[0]))), r1 = sqrtf(-2.0f * logf(u01(rnd[2])));
+      float s0, c0, s1, c1;
+      sincosf(6.28318530717958647692f * u01(rnd[1]), &s0, &c0);
+      sincosf(6.28318530717958647692f * u01(rnd[3]), &s1, &c1);
+      v[0] = r0 * c0; v[1] = r0 * s0; v[2] = r1 * c1; v[3] = r1 * s1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = d0 + j;
+      if (d < D) z[m * ldz + d] = loc[d] + scale[d] * v[j];
+    }
+  }
+}
+
+int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* scale,
+                uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream) {
+  if (M < 0 || D <= 0 || D > 0x7fffffff || ldz < D) { set_error("usf_base_sample_f32: bad sizes"); return -2; }
+  if (M == 0) return 0;
+  if (!z || !loc || !scale) { set_error("usf_base_sample_f32: null pointer"); return -1; }
+  if (base != USF_BASE_LAPLACE && base != USF_BASE_NORMAL) { set_error("usf_base_sample_f32: base %d not sampled on device", base); return -2; }
+  const int64_t total = M * ((D + 3) / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(base_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, ldz, M, (int)D, base, loc,
+                     scale, seed, offset, row_offset);
+  return check_launch("usf_base_sample_f32");
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone scale layer and column gather
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                    int64_t ldy, int64_t M, int D, const float* __restrict__ s,
+                                                    int divide) {
+  const int64_t total = M * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / D;
+    const int d = (int)(i % D);
+    const float v = x[m * ldx + d];
+    y[m * ldy + d] = divide ? v / s[d] : v * s[d];
+  }
+}
+
+int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s, int32_t divide,
+          hipStream_t stream) {
+  if (M < 0 || D <= 0 || D > 0x7fffffff || ldx < D || ldy < D) { set_error("usf_scale_f32: bad sizes"); return -2; }
+  if (M == 0) return 0;
+  if (!x || !y || !s) { set_error("usf_scale_f32: null pointer"); return -1; }
+  int64_t blocks = (M * D + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, ldx, y, ldy, M, (int)D, s, divide);
+  return check_launch("usf_scale_f32");
+}
+
+__global__ __launch_bounds__(256) void gather_cols_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                          int64_t ldd, int64_t M, int n, const int32_t* __restrict__ idx) {
+  const int64_t total = M * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / n;
+    const int j = (int)(i % n);
+    const int c = idx[j];
+    dst[m * ldd + j] = (c >= 0) ? src[m * lds_ + c] : 0.f;
+  }
+}
+
+int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
+                hipStream_t stream) {
+  if (M < 0 || n <= 0 || n > 0x7fffffff || ldd < n) { set_error("usf_gather_cols_f32: bad sizes"); return -2; }
+  if (M == 0) return 0;
+  if (!src || !dst || !idx) { set_error("usf_gather_cols_f32: null pointer"); return -1; }
+  int64_t blocks = (M * n + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, lds_, dst, ldd, M, (int)n, idx);
+  return check_launch("usf_gather_cols_f32");
+}
+
+}  // namespace usf
