@@ -43,7 +43,7 @@ typedef void* usf_stream_t; /* hipStream_t */
  *
  *   prologue(A)[m,k] = (A[m,k] / pre_div[k]) - pre_sub[k]       (each optional)
  *   acc[m,n]         = sum_k prologue(A)[m,k] * W[n,k]
- *   v                = act(acc + bias[n])                       (bias optional)
+ *   v                = act(acc + bias[n] + addend[m,n])         (bias, addend optional)
  *   v                = residual[m,n] + res_sign * v             (residual optional)
  *   C[m,n]           = v * post_mul[n]                          (post_mul optional)
  *
@@ -64,6 +64,8 @@ typedef struct usf_linear_desc {
   const float* pre_div;                 /* [K] or NULL */
   const float* pre_sub;                 /* [K] or NULL */
   const float* residual; int64_t ldr;   /* [M,N] or NULL */
+  const float* addend;   int64_t ldadd; /* [M,N] or NULL: added BEFORE the activation (context branch
+                                           h + layers[1](context), networks.py:741-743) */
   const float* post_mul;                /* [N] or NULL */
   float*       C;        int64_t ldc;   /* [M,N] */
   int64_t M, N, K;

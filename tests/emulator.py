@@ -1,0 +1,163 @@
+"""CPU emulation of the device op list (test infrastructure).
+
+Interprets the ctypes op array a ``FlowEngine`` builds -- the very descriptors the HIP library
+would receive -- with torch-CPU arithmetic, by mapping raw pointers back onto the engine's CPU
+tensors.  This lets the `-m "not gpu"` suite check the engine's layout permutation, mask-aware
+weight slicing, fusion and pointer arithmetic against the golden vectors without a GPU.
+It implements the *documented semantics* of ``usf_linear_f32`` / ``usf_coupling_additive_f32``
+(include/usflows_hip.h), not the kernels."""
+import ctypes as C
+
+import torch
+
+from usflows_amd import _ext
+
+
+class PtrMap:
+    def __init__(self):
+        self.tensors = []
+
+    def add(self, t):
+        if t is not None and torch.is_tensor(t) and t.numel() > 0:
+            self.tensors.append(t)
+
+    def view(self, ptr, rows, cols, ld, dtype=torch.float32):
+        """strided [rows, cols] view (row stride ld) at raw address ptr"""
+        for t in self.tensors:
+            base, nbytes = t.data_ptr(), t.numel() * t.element_size()
+            if base <= ptr < base + nbytes:
+                off = (ptr - base) // t.element_size()
+                flat = t.view(-1)
+                assert off + (rows - 1) * ld + cols <= flat.numel(), "descriptor reads past its tensor"
+                return torch.as_strided(flat, (rows, cols), (ld, 1), off)
+        raise KeyError(f"pointer {ptr:#x} not inside any known tensor")
+
+    def vec(self, ptr, n):
+        return self.view(ptr, 1, n, n)[0]
+
+
+def emulate_linear(d, pm: PtrMap, dtype=torch.float32):
+    M, N, K = d.M, d.N, d.K
+    A = pm.view(d.A, M, K, d.lda).to(dtype)
+    W = pm.view(d.W, N, K, d.ldw).to(dtype)
+    if d.pre_div:
+        A = A / pm.vec(d.pre_div, K).to(dtype)
+    if d.pre_sub:
+        A = A - pm.vec(d.pre_sub, K).to(dtype)
+    v = A @ W.t()
+    if d.bias:
+        v = v + pm.vec(d.bias, N).to(dtype)
+    if d.addend:
+        v = v + pm.view(d.addend, M, N, d.ldadd).to(dtype)
+    if d.act == _ext.ACT_LEAKY_RELU:
+        v = torch.where(v > 0, v, v * d.slope)
+    if d.residual:
+        v = pm.view(d.residual, M, N, d.ldr).to(dtype) + d.res_sign * v
+    if d.post_mul:
+        v = v * pm.vec(d.post_mul, N).to(dtype)
+    pm.view(d.C, M, N, d.ldc).copy_(v.to(torch.float32))
+
+
+def emulate_coupling(d, pm: PtrMap, dtype=torch.float32):
+    M = d.M
+    zp = pm.view(d.z + 4 * d.off_pass, M, d.n_pass, d.ldz).to(dtype)
+    h = zp @ pm.view(d.W_in, d.hidden[0], d.n_pass, d.ldw_in).to(dtype).t() + pm.vec(d.b_in, d.hidden[0]).to(dtype)
+    if d.context:
+        ctx = pm.vec(d.context, M).to(dtype)
+        h = h + (ctx[:, None] * pm.view(d.W_ctx, d.hidden[0], 1, 4).to(dtype).t() + pm.vec(d.b_ctx, d.hidden[0]).to(dtype))
+    act = lambda v: torch.where(v > 0, v, v * d.slope) if d.act == _ext.ACT_LEAKY_RELU else v
+    h = act(h)
+    for j in range(d.n_hidden - 1):
+        W = pm.view(d.W_hid[j], d.hidden[j + 1], d.hidden[j], d.ldw_hid[j]).to(dtype)
+        h = act(h @ W.t() + pm.vec(d.b_hid[j], d.hidden[j + 1]).to(dtype))
+    Wo = pm.view(d.W_out, d.n_trans, d.hidden[d.n_hidden - 1], d.ldw_out).to(dtype)
+    t = h @ Wo.t() + pm.vec(d.b_out, d.n_trans).to(dtype)
+    zt = pm.view(d.z + 4 * d.off_trans, M, d.n_trans, d.ldz).to(dtype)
+    pm.view(d.out + 4 * d.off_trans, M, d.n_trans, d.ldo).copy_((zt + d.sign * t).to(torch.float32))
+    if d.out != d.z:
+        pm.view(d.out + 4 * d.off_pass, M, d.n_pass, d.ldo).copy_(pm.view(d.z + 4 * d.off_pass, M, d.n_pass, d.ldz))
+
+
+def _gather(src, dst, idx):
+    out = torch.zeros(src.shape[0], idx.numel())
+    ok = idx >= 0
+    out[:, ok] = src[:, idx[ok].long()]
+    dst.copy_(out)
+
+
+def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
+    """CPU stand-in for FlowEngine._execute."""
+    ws, pk = plan["ws"], plan["pk"]
+    pm = PtrMap()
+    for t in ws.values():
+        pm.add(t)
+    for group in ("mats", "vecs"):
+        for t in pk[group].values():
+            pm.add(t)
+    for cp in pk["coupling"].values():
+        for W, b in cp["layers"]:
+            pm.add(W), pm.add(b)
+        pm.add(cp["W_out"]), pm.add(cp["b_out"])
+        if cp["has_ctx"]:
+            pm.add(cp["W_ctx4"]), pm.add(cp["b_ctx"])
+    pm.add(x)
+    pm.add(out)
+    B = x.shape[0]
+    if context is not None:
+        ws["ctx4"][:, 0].copy_(context.reshape(B))
+        ws["ctx"].copy_(context.reshape(B))
+    arr = plan["arr"]
+    for idx in plan["patch_in"]:
+        arr[idx].u.linear.A = x.data_ptr()
+    for idx in plan["patch_out"]:
+        arr[idx].u.linear.C = out.data_ptr()
+    pos = 0
+
+    def run_until(end):
+        nonlocal pos
+        while pos < end:
+            op = arr[pos]
+            if op.kind == _ext.OP_LINEAR:
+                emulate_linear(op.u.linear, pm, dtype)
+            else:
+                emulate_coupling(op.u.coupling, pm, dtype)
+            pos += 1
+
+    for g in plan["side"]:
+        run_until(g[1])
+        if g[0] == "scale":
+            _, _, buf, ld, sc, divide, ncols = g
+            ws[buf][:, :ncols] = ws[buf][:, :ncols] / sc if divide else ws[buf][:, :ncols] * sc
+        else:
+            _, _, src, dst_name, dst_layout = g
+            src_t = x if src[0] == "user_in" else ws[src[0]]
+            _gather(src_t, ws[dst_name], eng._gather_index(src[1], dst_layout, x.device))
+    run_until(plan["n"])
+    fg = plan["final_gather"]
+    if fg is not None:
+        src, dst_name = fg
+        if dst_name == "user_out":
+            _gather(ws[src[0]], out, eng._gather_index(src[1], "user", x.device))
+        else:
+            _gather(ws[src[0]], ws[dst_name], eng._gather_index(src[1], "nat", x.device))
+
+
+def engine_transform(eng, x, direction, context=None, fused=False):
+    eng.use_fused_coupling = fused
+    if fused:
+        eng._fused_ok = lambda cp: len(cp["hidden"]) <= _ext.USF_MAX_HIDDEN
+    B = x.shape[0]
+    out = torch.empty(B, eng.D)
+    plan = eng._plan(direction, B, x.device, context is not None, "user")
+    run_plan(eng, plan, x.contiguous(), out, context)
+    return out
+
+
+def engine_latent(eng, x, context=None, fused=False):
+    eng.use_fused_coupling = fused
+    if fused:
+        eng._fused_ok = lambda cp: len(cp["hidden"]) <= _ext.USF_MAX_HIDDEN
+    plan = eng._plan("backward", x.shape[0], x.device, context is not None, "nat")
+    run_plan(eng, plan, x.contiguous(), None, context)
+    buf = plan["ws"][plan["out_buf"][0]]
+    return buf[:, : eng.D].clone(), -plan["pk"]["ladj_total"]

@@ -1,0 +1,65 @@
+"""Engine logic on CPU: the op lists FlowEngine builds, interpreted by tests/emulator.py, must
+reproduce the golden vectors (layout permutation, mask-aware slicing, fusion, pointer math)."""
+import pytest
+import torch
+
+from golden_util import case_names, load_case
+from model_util import build_flow
+from usflows_amd.engine import FlowEngine
+import emulator
+from oracle import usflows_oracle as orc
+
+SMALL = case_names(small_only=True)
+
+
+def _tol(ref64):
+    return 3e-5 * max(1.0, ref64.abs().max().item())
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", SMALL)
+def test_engine_ops_reproduce_golden(name, fused):
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd)
+    eng = FlowEngine(flow.layers)
+    ctx = a.get("context")
+    z = emulator.engine_transform(eng, a["x"], "backward", ctx, fused)
+    assert (z.double() - a["backward64"]).abs().max().item() < _tol(a["backward64"])
+    xf = emulator.engine_transform(eng, a["zin"], "forward", ctx, fused)
+    assert (xf.double() - a["forward64"]).abs().max().item() < _tol(a["forward64"])
+    # log_prob path: soft-trained flows get an implicit zero context (flows.py:559-565)
+    ctx_lp = ctx
+    if ctx_lp is None and spec.soft_training:
+        ctx_lp = torch.zeros(a["x"].shape[0], 1)
+    zl, logdet = emulator.engine_latent(eng, a["x"], ctx_lp, fused)
+    assert abs(logdet + float(a["total_ladj64"])) < 1e-9 * max(1.0, abs(float(a["total_ladj64"])))
+    lp = orc.base_log_prob(spec, zl.double()) + logdet
+    rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
+    assert rel < 2e-5, rel
+
+
+def test_single_layer_engines():
+    """every layer type as a one-layer engine (what layer.forward/backward dispatch to)"""
+    spec, sd, a = load_case("synth_d7_k3_hh1_conj_normal")
+    flow = build_flow(spec, sd)
+    x = a["x"]
+    with torch.no_grad():
+        for layer in flow.layers:
+            eng = FlowEngine([layer])
+            for direction in ("forward", "backward"):
+                ref = layer.forward(x) if direction == "forward" else layer.backward(x)
+                got = emulator.engine_transform(eng, x, direction)
+                assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5), (type(layer).__name__, direction)
+
+
+def test_pack_cache_invalidation():
+    spec, sd, a = load_case("synth_d7_k3_hh0_laplace")
+    flow = build_flow(spec, sd)
+    eng = FlowEngine(flow.layers)
+    p1 = eng.pack(torch.device("cpu"))
+    assert eng.pack(torch.device("cpu")) is p1
+    with torch.no_grad():
+        flow.layers[-1].scale.mul_(2.0)          # in-place update bumps the version counter
+    p2 = eng.pack(torch.device("cpu"))
+    assert p2 is not p1
+    assert abs((p2["ladj_total"] - p1["ladj_total"]) - 7 * torch.log(torch.tensor(2.0)).item()) < 1e-6

@@ -31,6 +31,7 @@ class LinearDesc(C.Structure):
         ("W", _fp), ("ldw", C.c_int64),
         ("bias", _fp), ("pre_div", _fp), ("pre_sub", _fp),
         ("residual", _fp), ("ldr", C.c_int64),
+        ("addend", _fp), ("ldadd", C.c_int64),
         ("post_mul", _fp),
         ("C", _fp), ("ldc", C.c_int64),
         ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
@@ -131,7 +132,8 @@ def current_stream(device=None) -> int:
 
 # ---- thin typed wrappers (each enqueues on torch's current stream) ---------------------------
 def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_sub=None, residual=None,
-           ldr=0, post_mul=None, res_sign=1.0, act=ACT_NONE, slope=0.0, a_off=0, c_off=0, r_off=0):
+           ldr=0, post_mul=None, res_sign=1.0, act=ACT_NONE, slope=0.0, a_off=0, c_off=0, r_off=0,
+           addend=None, ldadd=0):
     """usf_linear_f32 on raw tensors; *_off are element offsets into A/C/residual."""
     d = LinearDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -144,6 +146,8 @@ def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_
     d.residual = None if residual is None else residual.data_ptr() + 4 * r_off
     d.ldr = ldr
     d.post_mul = ptr(post_mul)
+    d.addend = ptr(addend)
+    d.ldadd = ldadd
     d.C = C_out.data_ptr() + 4 * c_off
     d.ldc = ldc
     d.M, d.N, d.K = M, N, K

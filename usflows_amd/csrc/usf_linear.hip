@@ -18,8 +18,8 @@ namespace usf {
 
 struct LinArgs {
   const float* A; const float* W; const float* bias; const float* pre_div; const float* pre_sub;
-  const float* residual; const float* post_mul; float* C;
-  int64_t lda, ldw, ldr, ldc;
+  const float* residual; const float* addend; const float* post_mul; float* C;
+  int64_t lda, ldw, ldr, ldadd, ldc;
   int M, N, K;
   int nbm, nbn;
   float res_sign, slope;
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
         const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < p.M) {
           float v = acc[tm][tn][r] + bv;
+          if (p.addend) v = v + p.addend[(int64_t)row * p.ldadd + col];
           v = act_apply(v, p.act, p.slope);
           if (p.residual) v = p.residual[(int64_t)row * p.ldr + col] + p.res_sign * v;
           if (p.post_mul) v = v * pm;
@@ -214,7 +215,7 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (d->M == 0) return 0;
   if (!d->A || !d->W || !d->C) { set_error("usf_linear_f32: null A/W/C"); return -1; }
   if ((d->K & 3) || (d->lda & 3) || (d->ldw & 3) || d->lda < d->K || d->ldw < d->K || d->ldc < d->N ||
-      (d->residual && d->ldr < d->N)) {
+      (d->residual && d->ldr < d->N) || (d->addend && d->ldadd < d->N)) {
     set_error("usf_linear_f32: K/lda/ldw must be multiples of 4 and strides >= extents "
               "(K=%lld lda=%lld ldw=%lld ldc=%lld)", (long long)d->K, (long long)d->lda, (long long)d->ldw,
               (long long)d->ldc);
@@ -228,8 +229,8 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_linear_f32: bad act"); return -2; }
   LinArgs a;
   a.A = d->A; a.W = d->W; a.bias = d->bias; a.pre_div = d->pre_div; a.pre_sub = d->pre_sub;
-  a.residual = d->residual; a.post_mul = d->post_mul; a.C = d->C;
-  a.lda = d->lda; a.ldw = d->ldw; a.ldr = d->ldr; a.ldc = d->ldc;
+  a.residual = d->residual; a.addend = d->addend; a.post_mul = d->post_mul; a.C = d->C;
+  a.lda = d->lda; a.ldw = d->ldw; a.ldr = d->ldr; a.ldadd = d->ldadd; a.ldc = d->ldc;
   a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K;
   a.nbm = a.nbn = 0;
   a.res_sign = d->res_sign; a.slope = d->slope; a.act = d->act;

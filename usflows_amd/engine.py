@@ -1,0 +1,655 @@
+"""Device engine: compiles a list of USFlows layers into a chain of HIP kernel launches.
+
+What it does, per flow (see DESIGN.md for the rationale):
+
+* **parameter pack** (cached per parameter version): for every affine block the dense ``M``,
+  ``M^-1`` (triangular solves in fp64 on the device, rounded once to fp32), bias and
+  ``sum log|diag U|``; for every coupling the mask-aware slices of the conditioner weights.  The
+  reference re-derives all of this on every ``log_prob`` call (transforms.py:1289-1293, 795-809).
+* **segment layout**: between layers the activation matrix is stored ``[mask==0 features |
+  mask==1 features]`` (each segment padded to 4 floats), so a coupling layer's conditioning half
+  and transformed half are *contiguous* column ranges -- no strided gathers, and the ``x*mask`` /
+  ``(1-mask)*NN`` zeros of the reference are never multiplied.  The permutation is folded into
+  the rows/columns of the neighbouring affine matrices at pack time, i.e. it is free.
+* **op list**: fused linear ops (``usf_linear_f32``: scale / bias prologue + GEMM + bias /
+  LeakyReLU / residual / scale epilogue), optionally the fused coupling kernel, then the base
+  density tail (``usf_base_logprob_f32``).  The whole list is launched by ONE ``usf_run_ops``
+  call on torch's current stream.
+
+No arithmetic of the device path is done by torch ops, except the (cached, batch-independent)
+parameter prep and the O(B) finishing formula of the radial density.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _ext
+from . import transforms as T
+from .networks import ConditionalDenseNN, DenseNN
+
+
+class EngineUnsupported(Exception):
+    """The layer list contains something the fused device path cannot express."""
+
+
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def _activation_of(f) -> Optional[Tuple[int, float]]:
+    if isinstance(f, nn.LeakyReLU):
+        return _ext.ACT_LEAKY_RELU, float(f.negative_slope)
+    if isinstance(f, nn.ReLU):
+        return _ext.ACT_LEAKY_RELU, 0.0
+    return None
+
+
+def conditioner_supported(cond: nn.Module) -> bool:
+    if isinstance(cond, ConditionalDenseNN):
+        return cond.context_dim == 1 and _activation_of(cond.f) is not None
+    if isinstance(cond, DenseNN):
+        return cond.count_params == 1 and _activation_of(cond.f) is not None
+    return False
+
+
+@dataclass
+class _Step:
+    kind: str            # 'scale' | 'affine' | 'coupling'
+    module: nn.Module    # ScaleTransform | AffineTransform block | MaskedCoupling
+    inverted: bool       # wrapped in InverseTransform
+
+
+def _analyze(layers: Sequence[nn.Module]) -> List[_Step]:
+    steps = []
+    for l in layers:
+        inv = False
+        while isinstance(l, T.InverseTransform):
+            inv = not inv
+            l = l.transform
+        if isinstance(l, T.ScaleTransform) and l.scale.dim() == 1:
+            steps.append(_Step("scale", l, inv))
+        elif isinstance(l, T.BlockAffineTransform):
+            steps.append(_Step("affine", l.block_transform, inv))
+        elif isinstance(l, (T.LUTransform, T.HouseholderTransform, T.SequentialAffineTransform)):
+            steps.append(_Step("affine", l, inv))
+        elif isinstance(l, T.MaskedCoupling) and l.mask.dim() == 2 and conditioner_supported(l.conditioner):
+            steps.append(_Step("coupling", l, inv))
+        else:
+            raise EngineUnsupported(f"layer {type(l).__name__} has no fused device form")
+    if not steps:
+        raise EngineUnsupported("empty layer list")
+    return steps
+
+
+# ---------------------------------------------------------------------------------------------
+# fp64 parameter prep (device torch ops; batch independent; cached)
+# ---------------------------------------------------------------------------------------------
+def _affine_mats64(blk) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(M, M^-1, bias, ladj) of an affine block in fp64, following the reference's definitions."""
+    if isinstance(blk, T.LUTransform):
+        d = blk.dim
+        dev = blk.L_raw.device
+        eye = torch.eye(d, dtype=torch.float64, device=dev)
+        L = blk.L_raw.detach().double().tril(-1) + eye          # transforms.py:1271-1274
+        U = blk.U_raw.detach().double().triu()                  # :1276-1279
+        M = L @ U                                               # :1281-1283
+        Linv = torch.linalg.solve_triangular(L, eye, upper=False, unitriangular=True)
+        Minv = torch.linalg.solve_triangular(U, Linv, upper=True)   # U^-1 L^-1, :1289-1293
+        ladj = U.diagonal().abs().log().sum()                   # :1303-1320
+        return M, Minv, blk.bias_vector.detach().double(), ladj
+    if isinstance(blk, T.HouseholderTransform):
+        w = blk.w_0.detach().double()
+        for vk in blk.vk_householder.detach().double():         # :795-809 as rank-1 updates
+            w = w - 2.0 * torch.outer(w @ vk, vk) / torch.dot(vk, vk)
+        zero = torch.zeros(blk.dim, dtype=torch.float64, device=w.device)
+        return w, w.t().contiguous(), zero, zero.sum()
+    if isinstance(blk, T.SequentialAffineTransform):
+        parts = [_affine_mats64(t) for t in blk.transforms]
+        dev = parts[0][0].device
+        M = torch.eye(blk.dim, dtype=torch.float64, device=dev)
+        Minv = torch.eye(blk.dim, dtype=torch.float64, device=dev)
+        b = torch.zeros(blk.dim, dtype=torch.float64, device=dev)
+        ladj = torch.zeros((), dtype=torch.float64, device=dev)
+        for m, _, bi, la in parts:                              # :1457-1462, :1471-1476
+            M = M @ m
+            b = b @ m + bi
+            ladj = ladj + la
+        for _, mi, _, _ in parts[::-1]:                         # :1464-1469
+            Minv = Minv @ mi
+        return M, Minv, b, ladj
+    raise EngineUnsupported(type(blk).__name__)
+
+
+class FlowEngine:
+    """Compiled device form of ``layers`` (a whole ``Flow`` or a single layer)."""
+
+    def __init__(self, layers: Sequence[nn.Module]):
+        self.steps = _analyze(layers)
+        self.D = self._infer_dim()
+        self._pack = None
+        self._pack_key = None
+        self._plans: Dict[tuple, dict] = {}
+        self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
+        self.op_timing = None          # set to a list to record (tag, start_event, end_event) per op (bench.py)
+        self.use_fused_coupling = True
+        self._layout_from_masks()
+
+    # ---- static structure ---------------------------------------------------------------------
+    def _infer_dim(self) -> int:
+        for s in self.steps:
+            if s.kind == "scale":
+                return int(s.module.scale.shape[0])
+            if s.kind == "affine":
+                return int(s.module.dim)
+            if s.kind == "coupling":
+                return int(s.module.mask.shape[-1])
+        raise EngineUnsupported("cannot infer dimension")
+
+    def _layout_from_masks(self):
+        D = self.D
+        base = None
+        self._flip = {}
+        for i, s in enumerate(self.steps):
+            if s.kind != "coupling":
+                continue
+            m = s.module.mask.detach().flatten().cpu()
+            if m.numel() != D or not bool(((m == 0) | (m == 1)).all()):
+                raise EngineUnsupported("coupling mask must be a 0/1 vector of length D")
+            if base is None:
+                base = m
+            if torch.equal(m, base):
+                self._flip[i] = False
+            elif torch.equal(m, 1 - base):
+                self._flip[i] = True
+            else:
+                raise EngineUnsupported("coupling masks must alternate between m and 1-m")
+        if base is None:
+            idx0 = torch.arange(D)
+            idx1 = torch.zeros(0, dtype=torch.long)
+        else:
+            idx0 = torch.nonzero(base == 0).flatten()
+            idx1 = torch.nonzero(base == 1).flatten()
+        self.n0, self.n1 = int(idx0.numel()), int(idx1.numel())
+        self.n0a, self.n1a = _round_up(self.n0, 4), _round_up(self.n1, 4)
+        self.LD = max(self.n0a + self.n1a, 4)
+        seg = torch.full((self.LD,), -1, dtype=torch.long)
+        seg[: self.n0] = idx0
+        seg[self.n0a: self.n0a + self.n1] = idx1
+        self.seg_idx = seg
+        self.LDn = _round_up(D, 4)
+        nat = torch.full((self.LDn,), -1, dtype=torch.long)
+        nat[:D] = torch.arange(D)
+        self.nat_idx = nat
+        self.hmax = 4
+        for s in self.steps:
+            if s.kind == "coupling":
+                self.hmax = max(self.hmax, max(_round_up(int(h), 4) for h in s.module.conditioner.hidden_dims))
+
+    def _params(self):
+        seen, out = set(), []
+        for s in self.steps:
+            for p in s.module.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+        return out
+
+    # ---- parameter pack -----------------------------------------------------------------------
+    def _version_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self._params())
+
+    def refresh(self):
+        """Drop the cached parameter pack (it is also rebuilt automatically when a parameter's
+        version counter or storage changes)."""
+        self._pack, self._pack_key = None, None
+        self._plans.clear()
+
+    def _idx(self, layout: str) -> torch.Tensor:
+        return self.seg_idx if layout == "seg" else self.nat_idx
+
+    @staticmethod
+    def _perm_mat(mat64: torch.Tensor, out_idx: torch.Tensor, in_idx: torch.Tensor) -> torch.Tensor:
+        dev = mat64.device
+        oi, ii = out_idx.to(dev), in_idx.to(dev)
+        W = torch.zeros(oi.numel(), ii.numel(), dtype=torch.float64, device=dev)
+        ro, ci = torch.nonzero(oi >= 0).flatten(), torch.nonzero(ii >= 0).flatten()
+        W[ro[:, None], ci[None, :]] = mat64[oi[ro][:, None], ii[ci][None, :]]
+        return W.float().contiguous()
+
+    @staticmethod
+    def _perm_vec(v64: torch.Tensor, idx: torch.Tensor, pad: float) -> torch.Tensor:
+        idx = idx.to(v64.device)
+        out = torch.full((idx.numel(),), pad, dtype=torch.float64, device=v64.device)
+        ok = idx >= 0
+        out[ok] = v64[idx[ok]]
+        return out.float().contiguous()
+
+    def pack(self, device) -> dict:
+        key = self._version_key(device)
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}}
+        ladj_total = torch.zeros((), dtype=torch.float64, device=device)
+        with torch.no_grad():
+            for i, s in enumerate(self.steps):
+                if s.kind == "affine":
+                    if id(s.module) not in pk["affine"]:
+                        M, Minv, b, ladj = _affine_mats64(s.module)
+                        pk["affine"][id(s.module)] = dict(M=M.to(device), Minv=Minv.to(device), b=b.to(device),
+                                                          ladj=ladj.to(device))
+                    la = pk["affine"][id(s.module)]["ladj"]
+                    ladj_total = ladj_total + (-la if s.inverted else la)
+                elif s.kind == "scale":
+                    sc = s.module.scale.detach().double().to(device)
+                    pk["scale"][id(s.module)] = sc
+                    la = sc.abs().log().sum()
+                    ladj_total = ladj_total + (-la if s.inverted else la)
+                elif s.kind == "coupling":
+                    pk["coupling"][i] = self._pack_coupling(i, s.module, device)
+        pk["ladj_total"] = float(ladj_total.item())
+        self._pack, self._pack_key = pk, key
+        self._plans.clear()
+        return pk
+
+    def _pack_coupling(self, i: int, layer, device) -> dict:
+        cond = layer.conditioner
+        flip = self._flip[i]
+        # mask==1 features condition, mask==0 features are transformed (transforms.py:285-290)
+        if not flip:      # layer mask == base mask: pass = segment 1, transformed = segment 0
+            pass_off, pass_n, pass_idx = self.n0a, self.n1a, self.seg_idx[self.n0a: self.n0a + self.n1a]
+            tr_off, tr_n, tr_idx = 0, self.n0, self.seg_idx[: self.n0]
+        else:
+            pass_off, pass_n, pass_idx = 0, self.n0a, self.seg_idx[: self.n0a]
+            tr_off, tr_n, tr_idx = self.n0a, self.n1, self.seg_idx[self.n0a: self.n0a + self.n1]
+        act, slope = _activation_of(cond.f)
+        lin = list(cond.layers)
+        has_ctx = isinstance(cond, ConditionalDenseNN)
+        first = lin[0]
+        ctx_l = lin[1] if has_ctx else None
+        hidden = lin[2:-1] if has_ctx else lin[1:-1]
+        last = lin[-1]
+        f64 = lambda t: t.detach().double().to(device)
+
+        def pad_rows(W, b, n_pad):
+            Wp = torch.zeros(n_pad, W.shape[1], dtype=W.dtype, device=W.device)
+            Wp[: W.shape[0]] = W
+            bp = torch.zeros(n_pad, dtype=b.dtype, device=b.device)
+            bp[: b.shape[0]] = b
+            return Wp, bp
+
+        def pad_cols(W, k_pad):
+            Wp = torch.zeros(W.shape[0], k_pad, dtype=W.dtype, device=W.device)
+            Wp[:, : W.shape[1]] = W
+            return Wp
+
+        h = [int(x) for x in cond.hidden_dims]
+        hp = [_round_up(x, 4) for x in h]
+        W_in = self._perm_mat(f64(first.weight), torch.arange(h[0]), pass_idx).double()   # [h0, pass_n]
+        W_in, b_in = pad_rows(W_in, f64(first.bias), hp[0])
+        layers = [(W_in.float().contiguous(), b_in.float().contiguous())]
+        for j, l in enumerate(hidden):
+            W, b = pad_rows(pad_cols(f64(l.weight), hp[j]), f64(l.bias), hp[j + 1])
+            layers.append((W.float().contiguous(), b.float().contiguous()))
+        W_out = pad_cols(f64(last.weight)[tr_idx.to(device)], hp[-1])                     # [tr_n, h_last_pad]
+        b_out = f64(last.bias)[tr_idx.to(device)]
+        d = dict(pass_off=pass_off, pass_n=pass_n, tr_off=tr_off, tr_n=tr_n, act=act, slope=slope,
+                 hidden=hp, layers=layers, W_out=W_out.float().contiguous(), b_out=b_out.float().contiguous(),
+                 has_ctx=has_ctx)
+        if has_ctx:
+            Wc = torch.zeros(hp[0], 4, dtype=torch.float64, device=device)
+            Wc[: h[0], 0] = f64(ctx_l.weight)[:, 0]
+            bc = torch.zeros(hp[0], dtype=torch.float64, device=device)
+            bc[: h[0]] = f64(ctx_l.bias)
+            d["W_ctx4"] = Wc.float().contiguous()      # [h0, 4]: context rides in column 0 of a 4-wide K
+            d["b_ctx"] = bc.float().contiguous()
+        return d
+
+    def _mat(self, pk, blk, which: str, out_layout: str, in_layout: str) -> torch.Tensor:
+        key = (id(blk), which, out_layout, in_layout)
+        if key not in pk["mats"]:
+            pk["mats"][key] = self._perm_mat(pk["affine"][id(blk)][which], self._idx(out_layout), self._idx(in_layout))
+        return pk["mats"][key]
+
+    def _vec(self, pk, name, v64, layout: str, pad: float) -> torch.Tensor:
+        key = (name, layout, pad)
+        if key not in pk["vecs"]:
+            pk["vecs"][key] = self._perm_vec(v64, self._idx(layout), pad)
+        return pk["vecs"][key]
+
+    # ---- workspace ----------------------------------------------------------------------------
+    def _workspace(self, B: int, device) -> Dict[str, torch.Tensor]:
+        key = (B, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 4:
+                self._ws.clear()
+                self._plans.clear()
+            z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=device)
+            ws = dict(zA=z(B, self.LD), zB=z(B, self.LD), nat=z(B, self.LDn), H1=z(B, self.hmax),
+                      H2=z(B, self.hmax), P=z(B, self.hmax), ctx4=z(B, 4), ctx=z(B),
+                      sum=torch.zeros(2, dtype=torch.float64, device=device))
+            self._ws[key] = ws
+        return ws
+
+    # ---- plan construction --------------------------------------------------------------------
+    def _primitive_ops(self, direction: str):
+        """[(prim, step_index)] with prim in scale_mul/scale_div/affine_fwd/affine_bwd/coupling_fwd/coupling_bwd"""
+        seq = list(enumerate(self.steps))
+        if direction == "backward":
+            seq = seq[::-1]
+        prims = []
+        for i, s in seq:
+            fwd = (direction == "forward") != s.inverted
+            if s.kind == "scale":
+                prims.append(("scale_mul" if fwd else "scale_div", i))
+            elif s.kind == "affine":
+                prims.append(("affine_fwd" if fwd else "affine_bwd", i))
+            else:
+                prims.append(("coupling_fwd" if fwd else "coupling_bwd", i))
+        return prims
+
+    def _build_plan(self, direction: str, B: int, device, has_ctx: bool, final: str) -> dict:
+        """final: 'user' (last op writes the caller's [B,D] tensor) or 'nat' (workspace buffer, for the tail).
+
+        Returns the ctypes op array plus the few launches that are not usf_run_ops ops
+        (layout gathers at the ends, stand-alone scale layers), each tagged with the op index
+        before which it runs."""
+        pk = self.pack(device)
+        ws = self._workspace(B, device)
+        prims = self._primitive_ops(direction)
+        ops: List[_ext.Op] = []
+        patch_in: List[int] = []       # ops whose A is the caller's input tensor
+        patch_out: List[int] = []      # ops whose C is the caller's output tensor
+        side: List[tuple] = []         # ("gather", at, src_cur, dst_name, dst_layout) | ("scale", at, buf, ld, vec, divide, ncols)
+        cur = ("user_in", "nat", self.D)     # (buffer name, layout, row stride)
+        free = ["zA", "zB"]
+
+        def take():
+            return free.pop(0)
+
+        def release(name):
+            if name in ("zA", "zB") and name not in free:
+                free.append(name)
+
+        def lin_op(**kw) -> _ext.Op:
+            op = _ext.Op()
+            op.kind = _ext.OP_LINEAR
+            for k_, v_ in kw.items():
+                setattr(op.u.linear, k_, v_)
+            return op
+
+        def nat2():
+            if "nat2" not in ws:
+                ws["nat2"] = torch.zeros(B, self.LDn, dtype=torch.float32, device=device)
+            return ws["nat2"]
+
+        n = len(prims)
+        k = 0
+        while k < n:
+            prim, i = prims[k]
+            s = self.steps[i]
+            nxt = prims[k + 1] if k + 1 < n else None
+            # ---- affine (optionally with the scale layer fused on its outer side) ---------------
+            if prim in ("affine_fwd", "affine_bwd") or (prim == "scale_div" and nxt and nxt[0] == "affine_bwd"):
+                if cur[0] == "user_in" and self.D % 4 != 0:
+                    # rows of the caller's tensor are not 16-B aligned: stage through a padded copy
+                    side.append(("gather", len(ops), cur, "nat", "nat"))
+                    cur = ("nat", "nat", self.LDn)
+                in_layout = cur[1]
+                kw = {}
+                if prim == "scale_div":
+                    sc64 = pk["scale"][id(s.module)]
+                    kw["pre_div"] = self._vec(pk, ("scale", id(s.module)), sc64, in_layout, 1.0).data_ptr()
+                    k += 1
+                    prim, i = prims[k]
+                    s = self.steps[i]
+                    nxt = prims[k + 1] if k + 1 < n else None
+                blk = s.module
+                a = pk["affine"][id(blk)]
+                fuse_post = prim == "affine_fwd" and nxt is not None and nxt[0] == "scale_mul"
+                is_last = (k == n - 1) or (fuse_post and k == n - 2)
+                out_layout = "nat" if is_last else "seg"
+                Kdim = self.LD if in_layout == "seg" else self.LDn
+                if prim == "affine_bwd":
+                    W = self._mat(pk, blk, "Minv", out_layout, in_layout)
+                    kw["pre_sub"] = self._vec(pk, ("b", id(blk)), a["b"], in_layout, 0.0).data_ptr()
+                else:
+                    W = self._mat(pk, blk, "M", out_layout, in_layout)
+                    kw["bias"] = self._vec(pk, ("b", id(blk)), a["b"], out_layout, 0.0).data_ptr()
+                    if fuse_post:
+                        s2 = self.steps[nxt[1]]
+                        kw["post_mul"] = self._vec(pk, ("scale", id(s2.module)), pk["scale"][id(s2.module)],
+                                                   out_layout, 1.0).data_ptr()
+                        k += 1
+                assert W.shape[1] == Kdim
+                if out_layout == "seg":
+                    dst = take()
+                    Ndim, ldc, cptr = self.LD, self.LD, ws[dst].data_ptr()
+                elif final == "user":
+                    dst, Ndim, ldc, cptr = "user_out", self.D, self.D, 0
+                else:
+                    dst, Ndim, ldc, cptr = "nat2", self.D, self.LDn, nat2().data_ptr()
+                if cur[0] == "user_in":
+                    patch_in.append(len(ops))
+                if dst == "user_out":
+                    patch_out.append(len(ops))
+                ops.append(lin_op(A=(0 if cur[0] == "user_in" else ws[cur[0]].data_ptr()), lda=cur[2],
+                                  W=W.data_ptr(), ldw=W.shape[1], C=cptr, ldc=ldc, M=B, N=Ndim, K=Kdim,
+                                  res_sign=1.0, slope=0.0, act=_ext.ACT_NONE, **kw))
+                release(cur[0])
+                cur = (dst, out_layout, ldc)
+                k += 1
+                continue
+            # ---- stand-alone scale layer: elementwise kernel, in place on a workspace buffer -----
+            if prim in ("scale_mul", "scale_div"):
+                if cur[0] == "user_in":
+                    side.append(("gather", len(ops), cur, "nat", "nat"))
+                    cur = ("nat", "nat", self.LDn)
+                sc = self._vec(pk, ("scale", id(s.module)), pk["scale"][id(s.module)], cur[1], 1.0)
+                side.append(("scale", len(ops), cur[0], cur[2], sc, prim == "scale_div",
+                             self.LD if cur[1] == "seg" else self.LDn))
+                k += 1
+                continue
+            # ---- coupling (in place on a segment-layout buffer) -----------------------------------
+            if cur[1] != "seg" or cur[0] in ("user_in", "nat", "nat2"):
+                dst = take()
+                side.append(("gather", len(ops), cur, dst, "seg"))
+                release(cur[0])
+                cur = (dst, "seg", self.LD)
+            cp = pk["coupling"][i]
+            sign = 1.0 if prim == "coupling_fwd" else -1.0
+            zptr = ws[cur[0]].data_ptr()
+            use_ctx = has_ctx and cp["has_ctx"]
+            if self.use_fused_coupling and self._fused_ok(cp):
+                ops.append(self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None))
+            else:
+                hbufs = ["H1", "H2"]
+                src_ptr, src_ld, src_K = zptr + 4 * cp["pass_off"], self.LD, cp["pass_n"]
+                for j, (W, b) in enumerate(cp["layers"]):
+                    hb = ws[hbufs[j % 2]]
+                    kw = {}
+                    if j == 0 and use_ctx:
+                        # P = ctx * Wc + bc as a K=4 GEMM (context in column 0 of a zero-padded [B,4] operand);
+                        # added to (acc + b_in) before the activation, as networks.py:741-745 does
+                        ops.append(lin_op(A=ws["ctx4"].data_ptr(), lda=4, W=cp["W_ctx4"].data_ptr(), ldw=4,
+                                          bias=cp["b_ctx"].data_ptr(), C=ws["P"].data_ptr(), ldc=self.hmax,
+                                          M=B, N=cp["hidden"][0], K=4, res_sign=1.0, slope=0.0, act=_ext.ACT_NONE))
+                        kw = dict(addend=ws["P"].data_ptr(), ldadd=self.hmax)
+                    ops.append(lin_op(A=src_ptr, lda=src_ld, W=W.data_ptr(), ldw=W.shape[1], bias=b.data_ptr(),
+                                      C=hb.data_ptr(), ldc=self.hmax, M=B, N=W.shape[0], K=src_K, res_sign=1.0,
+                                      slope=cp["slope"], act=cp["act"], **kw))
+                    src_ptr, src_ld, src_K = hb.data_ptr(), self.hmax, W.shape[0]
+                tptr = zptr + 4 * cp["tr_off"]
+                ops.append(lin_op(A=src_ptr, lda=src_ld, W=cp["W_out"].data_ptr(), ldw=cp["W_out"].shape[1],
+                                  bias=cp["b_out"].data_ptr(), residual=tptr, ldr=self.LD, C=tptr, ldc=self.LD,
+                                  M=B, N=cp["tr_n"], K=src_K, res_sign=sign, slope=0.0, act=_ext.ACT_NONE))
+            k += 1
+
+        # ---- final layout fix-up ------------------------------------------------------------------
+        final_gather = None
+        if final == "user" and cur[0] != "user_out":
+            final_gather = (cur, "user_out")
+        elif final == "nat" and cur[1] != "nat":
+            nat2()
+            final_gather = (cur, "nat2")
+            cur = ("nat2", "nat", self.LDn)
+        arr = (_ext.Op * max(len(ops), 1))(*ops)
+        return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=side,
+                    final_gather=final_gather, out_buf=cur, ws=ws, pk=pk)
+
+    # fused coupling kernel availability (filled in when the kernel is present)
+    def _fused_ok(self, cp) -> bool:
+        lib = _ext.load()
+        wmax = lib.usf_coupling_max_width()
+        return wmax > 0 and len(cp["hidden"]) <= _ext.USF_MAX_HIDDEN and max(cp["hidden"]) <= wmax
+
+    def _coupling_op(self, cp, zptr, B, sign, ws_ctx) -> _ext.Op:
+        op = _ext.Op()
+        op.kind = _ext.OP_COUPLING
+        d = op.u.coupling
+        d.z, d.ldz, d.out, d.ldo, d.M = zptr, self.LD, zptr, self.LD, B
+        d.off_pass, d.n_pass, d.off_trans, d.n_trans = cp["pass_off"], cp["pass_n"], cp["tr_off"], cp["tr_n"]
+        d.n_hidden = len(cp["hidden"])
+        for j, hh in enumerate(cp["hidden"]):
+            d.hidden[j] = hh
+        W, b = cp["layers"][0]
+        d.W_in, d.ldw_in, d.b_in = W.data_ptr(), W.shape[1], b.data_ptr()
+        for j, (W, b) in enumerate(cp["layers"][1:]):
+            d.W_hid[j], d.b_hid[j], d.ldw_hid[j] = W.data_ptr(), b.data_ptr(), W.shape[1]
+        d.W_out, d.ldw_out, d.b_out = cp["W_out"].data_ptr(), cp["W_out"].shape[1], cp["b_out"].data_ptr()
+        if ws_ctx is not None:
+            d.context = ws_ctx["ctx"].data_ptr()
+            d.W_ctx, d.b_ctx = cp["W_ctx4"].data_ptr(), cp["b_ctx"].data_ptr()
+        d.sign, d.slope, d.act = sign, cp["slope"], cp["act"]
+        return op
+
+    # ---- execution ----------------------------------------------------------------------------
+    def _plan(self, direction, B, device, has_ctx, final):
+        pk = self.pack(device)   # may invalidate plans
+        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._build_plan(direction, B, device, has_ctx, final)
+            self._plans[key] = plan
+        return plan
+
+    def _execute(self, plan, x: torch.Tensor, out: Optional[torch.Tensor], context):
+        ws = plan["ws"]
+        B = x.shape[0]
+        dev = x.device
+        if context is not None:
+            c = context.reshape(B).to(torch.float32)
+            ws["ctx4"][:, 0].copy_(c)
+            ws["ctx"].copy_(c)
+        arr = plan["arr"]
+        for idx in plan["patch_in"]:
+            arr[idx].u.linear.A = x.data_ptr()
+        for idx in plan["patch_out"]:
+            arr[idx].u.linear.C = out.data_ptr()
+        lib = _ext.load()
+        stream = _ext.current_stream(dev)
+        pos = 0
+
+        def run_until(end):
+            nonlocal pos
+            if end > pos and self.op_timing is not None:
+                # instrumented mode: one launch per call, bracketed by HIP events on the launch stream
+                for j in range(pos, end):
+                    op = arr[j]
+                    if op.kind == _ext.OP_LINEAR:
+                        tag = ("linear", op.u.linear.M, op.u.linear.N, op.u.linear.K)
+                    else:
+                        tag = ("coupling", op.u.coupling.M, op.u.coupling.n_trans, op.u.coupling.n_pass)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    sub = C.cast(C.byref(arr, j * C.sizeof(_ext.Op)), C.POINTER(_ext.Op))
+                    _ext.check(lib.usf_run_ops(sub, 1, stream), "usf_run_ops")
+                    e1.record()
+                    self.op_timing.append((tag, e0, e1))
+                self.launch_count += 1
+                pos = end
+            elif end > pos:
+                sub = C.cast(C.byref(arr, pos * C.sizeof(_ext.Op)), C.POINTER(_ext.Op))
+                _ext.check(lib.usf_run_ops(sub, end - pos, stream), "usf_run_ops")
+                self.launch_count += 1
+                pos = end
+
+        for g in plan["side"]:           # already in op order (stable)
+            run_until(g[1])
+            if g[0] == "scale":
+                _, _, buf, ld, sc, divide, ncols = g
+                _ext.scale(ws[buf], ld, ws[buf], ld, B, ncols, sc, divide)
+                self.launch_count += 1
+            else:
+                _, _, src, dst_name, dst_layout = g
+                src_t = x if src[0] == "user_in" else ws[src[0]]
+                idx = self._gather_index(src[1], dst_layout, dev)
+                dst_t = ws[dst_name]
+                _ext.gather_cols(src_t, src[2], dst_t, dst_t.shape[1], B, dst_t.shape[1], idx)
+                self.launch_count += 1
+        run_until(plan["n"])
+        fg = plan["final_gather"]
+        if fg is not None:
+            src, dst_name = fg
+            src_t = ws[src[0]]
+            if dst_name == "user_out":
+                _ext.gather_cols(src_t, src[2], out, self.D, B, self.D, self._gather_index(src[1], "user", dev))
+            else:
+                _ext.gather_cols(src_t, src[2], ws[dst_name], self.LDn, B, self.LDn,
+                                 self._gather_index(src[1], "nat", dev))
+            self.launch_count += 1
+
+    def _gather_index(self, src_layout: str, dst_layout: str, device) -> torch.Tensor:
+        """int32 index: dst column j <- src column idx[j] (or -1 -> 0)."""
+        key = ("gidx", src_layout, dst_layout, str(device))
+        cache = self.__dict__.setdefault("_gidx", {})
+        if key not in cache:
+            src_idx = self._idx(src_layout)
+            pos = {int(f): c for c, f in enumerate(src_idx.tolist()) if f >= 0}   # feature -> src column
+            if dst_layout == "user":
+                feats = list(range(self.D))
+            else:
+                feats = self._idx(dst_layout).tolist()
+            cache[key] = torch.tensor([pos[f] if f >= 0 else -1 for f in feats], dtype=torch.int32, device=device)
+        return cache[key]
+
+    # ---- public API ---------------------------------------------------------------------------
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("FlowEngine runs on ROCm devices only")
+        if x.dim() != 2 or x.shape[1] != self.D:
+            raise ValueError(f"expected input of shape [B, {self.D}], got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            x = x.float()
+        if not x.is_contiguous() or (x.data_ptr() % 16) != 0:
+            x = x.contiguous().clone() if (x.data_ptr() % 16) != 0 else x.contiguous()
+        return x
+
+    def transform(self, x: torch.Tensor, direction: str, context: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Flow._forward / Flow.backward on the device: natural layout in, natural layout out."""
+        x = self._check_input(x)
+        B = x.shape[0]
+        out = torch.empty(B, self.D, dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out
+        plan = self._plan(direction, B, x.device, context is not None, "user")
+        self._execute(plan, x, out, context)
+        return out
+
+    def latent(self, x: torch.Tensor, context=None) -> Tuple[torch.Tensor, int, float]:
+        """backward pass into the workspace: (z buffer [B, ldn], ldn, -sum ladj)."""
+        x = self._check_input(x)
+        plan = self._plan("backward", x.shape[0], x.device, context is not None, "nat")
+        self._execute(plan, x, None, context)
+        buf = plan["ws"][plan["out_buf"][0]]
+        return buf, plan["out_buf"][2], -plan["pk"]["ladj_total"]
+
+    def ladj_total(self, device) -> float:
+        return self.pack(device)["ladj_total"]

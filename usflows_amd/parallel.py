@@ -1,0 +1,49 @@
+"""Data-parallel use of the hot path: one process per GPU, the sample batch sharded row-wise,
+parameters replicated, and exactly ONE collective per batch -- an all-reduce (RCCL over xGMI when
+the backend is "nccl") of two fp64 scalars [sum log_prob, count] for the mean log-likelihood.
+
+The reference has no distributed code; this is the multi-GPU row of the scope
+table (section 8e).  Sampling needs no collective: ranks draw disjoint Philox substreams
+(``row_offset``)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """contiguous row range [lo, hi) of ``rank`` (first ``n_rows % world_size`` ranks get one extra)"""
+    base, rem = divmod(n_rows, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def mean_log_prob(flow, x_shard: torch.Tensor, context: Optional[torch.Tensor] = None, group=None,
+                  acc: Optional[torch.Tensor] = None):
+    """(mean log_prob over ALL ranks' rows as a 0-dim fp64 tensor, this rank's per-sample log_prob).
+
+    No host synchronisation: the sums are accumulated on the device by the tail kernel and the
+    all-reduce is enqueued behind it."""
+    dev = x_shard.device
+    if acc is None:
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+    else:
+        acc.zero_()
+    with torch.no_grad():
+        if x_shard.is_cuda and flow._on_device_fast_path(x_shard, context):
+            lp = flow._log_prob_device(x_shard, context, sum_out=acc)
+        else:
+            lp = flow.log_prob(x_shard, context) if context is not None else flow.log_prob(x_shard)
+            acc[0] = lp.double().sum()
+            acc[1] = float(lp.numel())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return acc[0] / acc[1], lp
+
+
+def sample_sharded(flow, n_total: int, seed: int, rank: int, world_size: int) -> torch.Tensor:
+    """this rank's rows of a global draw of ``n_total`` samples (same result for any world size)"""
+    lo, hi = shard_rows(n_total, rank, world_size)
+    return flow.sample([hi - lo], seed=seed, row_offset=lo)

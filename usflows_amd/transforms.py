@@ -1,0 +1,534 @@
+"""Bijective layers of the USFlows hot path -- host-side mirror of the reference's
+``src/usflows/transforms.py`` (same class names, constructor signatures, parameter names and
+state-dict keys) with the device arithmetic routed to hand-written gfx950 kernels.
+
+Dispatch rule (every layer, every call):
+  * tensors on a ROCm device and no autograd graph needed (``torch.no_grad()`` or nothing
+    requires grad)  ->  HIP kernels through ``usflows_amd.engine`` / the C ABI.  If the HIP
+    library is missing this raises; there is no eager fallback on that branch.
+  * autograd needed (``Flow.fit``) or CPU tensors  ->  the differentiable *composite*
+    formulation below, written with torch ops exactly as the math in the reference reads.
+    (HIP backward kernels are SURVEY row N2, "next".)
+
+Only flat inputs (``in_dims=[D]``) are in scope: the 1x1-conv form of
+``BlockAffineTransform`` for image-shaped inputs is not built.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Iterable, List, Optional
+
+import torch
+from torch import nn
+from torch.distributions import constraints
+from torch.nn import functional as F
+from torch.nn import init
+
+
+class TransformModule(torch.distributions.Transform, nn.Module):
+    """``torch.distributions.Transform`` that is also an ``nn.Module`` (what the reference takes
+    from ``pyro.distributions.TransformModule``; re-stated here so pyro is not a dependency)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+    def __hash__(self):
+        return nn.Module.__hash__(self)
+
+
+def _needs_grad(module: nn.Module, *tensors) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
+def use_hip(module: nn.Module, x: torch.Tensor, *more) -> bool:
+    """True when this call must run on the HIP kernels."""
+    return x.is_cuda and x.dtype == torch.float32 and not _needs_grad(module, x, *more)
+
+
+class BaseTransform(TransformModule):
+    """Layer protocol of the reference (transforms.py:23-69): forward / backward /
+    log_abs_det_jacobian (+ feasibility helpers)."""
+
+    bijective = True
+    domain = constraints.real_vector
+    codomain = constraints.real_vector
+
+    def __init__(self, *args, **kwargs):
+        # the reference skips TransformModule.__init__ and initialises nn.Module + Transform
+        nn.Module.__init__(self)
+        self._cache_size = 0
+        self._inv = None
+        self._engine = None
+
+    def is_feasible(self) -> bool:
+        return True
+
+    def jitter(self, jitter: float = 1e-6) -> None:
+        pass
+
+    def add_jitter(self, jitter: float = 1e-6) -> None:
+        pass
+
+    def forward(self, x: torch.Tensor, context: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def backward(self, y: torch.Tensor, context: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        raise NotImplementedError()
+
+    def _call(self, x):
+        return self.forward(x)
+
+    def _inverse(self, y):
+        return self.backward(y)
+
+    def log_prior(self):
+        return 0.0
+
+    def simplify(self):
+        return self
+
+    def sign(self):
+        return 1
+
+    # -- HIP dispatch for a stand-alone layer call: a one-layer engine -------------------------
+    def _hip(self, direction: str, x: torch.Tensor, context=None) -> torch.Tensor:
+        from .engine import FlowEngine
+        if self._engine is None:
+            self._engine = FlowEngine([self])
+        return self._engine.transform(x, direction, context)
+
+
+class ScaleTransform(BaseTransform):
+    """y = scale * x  (transforms.py:73-171)."""
+
+    def __init__(self, in_dims, prior_scale: float = 1.0, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.in_dims = in_dims
+        self.prior_scale = prior_scale
+        self.dim = math.prod(in_dims) if isinstance(in_dims, Iterable) else in_dims
+        self.scale = nn.Parameter(torch.empty(in_dims))
+        self.init_params()
+
+    def init_params(self):
+        bound = 1 / math.sqrt(self.dim) if self.dim > 0 else 0
+        init.uniform_(self.scale, -bound, bound)
+
+    def forward(self, x, context=None):
+        if x.dim() == 2 and self.scale.dim() == 1 and use_hip(self, x):
+            return self._hip("forward", x)
+        return x * self.scale
+
+    def backward(self, x, context=None):
+        if x.dim() == 2 and self.scale.dim() == 1 and use_hip(self, x):
+            return self._hip("backward", x)
+        return x / self.scale
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        return self.scale.abs().log().sum()
+
+    def sign(self) -> int:
+        return 1 if (self.scale < 0).int().sum() % 2 == 0 else -1
+
+    def is_feasible(self) -> bool:
+        return (self.scale != 0).all()
+
+    def add_jitter(self, jitter: float = 1e-6) -> None:
+        # (the reference's version refers to a non-existent U_raw, transforms.py:154-157)
+        with torch.no_grad():
+            self.scale.add_(torch.randn(self.scale.shape, device=self.scale.device) * jitter)
+
+    def log_prior(self):
+        return 0
+
+
+class MaskedCoupling(BaseTransform):
+    """Additive coupling  y = x + (1-mask) * conditioner(x*mask)  (transforms.py:254-347).
+    ``log_abs_det_jacobian`` is the python float 0.0: the Jacobian is unit-triangular."""
+
+    def __init__(self, mask: torch.Tensor, conditioner: nn.Module, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.mask = mask
+        self.conditioner = conditioner
+        self.input_shape = mask.shape
+
+    def _hip_ok(self, x, context) -> bool:
+        from .engine import conditioner_supported
+        return x.dim() == 2 and self.mask.dim() == 2 and conditioner_supported(self.conditioner) \
+            and use_hip(self, x, context)
+
+    def forward(self, x, context=None):
+        if self._hip_ok(x, context):
+            return self._hip("forward", x, context)
+        x_masked = x * self.mask
+        if context is None:
+            return x + (1 - self.mask) * self.conditioner(x_masked)
+        return x + (1 - self.mask) * self.conditioner(x_masked, context)
+
+    def backward(self, y, context=None):
+        if self._hip_ok(y, context):
+            return self._hip("backward", y, context)
+        y_masked = y * self.mask
+        if context is None:
+            return y - (1 - self.mask) * self.conditioner(y_masked)
+        return y - (1 - self.mask) * self.conditioner(y_masked, context)
+
+    def log_abs_det_jacobian(self, x, y, context=None) -> float:
+        return 0.0
+
+    def sign(self):
+        return 1.0
+
+    def to(self, device):
+        self.mask = self.mask.to(device)
+        return super().to(device)
+
+
+class InverseTransform(BaseTransform):
+    """Swaps forward/backward of the wrapped (shared) transform (transforms.py:349-414)."""
+
+    def __init__(self, transform, *args, **kwargs):
+        super().__init__()
+        self.transform = transform
+        self.bijective = transform.bijective
+        self.args = args
+        self.kwargs = kwargs
+
+    def forward(self, x, context=None):
+        return self.transform.backward(x, context)
+
+    def backward(self, y, context=None):
+        return self.transform.forward(y, context)
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        return -self.transform.log_abs_det_jacobian(x, y, context)
+
+    def sign(self):
+        return self.transform.sign()
+
+    def is_feasible(self):
+        return self.transform.is_feasible()
+
+    def simplify(self):
+        return InverseTransform(self.transform.simplify(), *self.args, **self.kwargs)
+
+
+class AffineTransform(BaseTransform):
+    """Interface: matrix() / inverse_matrix() / bias() of y = A x + b (transforms.py:697-750)."""
+
+    def __init__(self, dim: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.dim = dim
+        self.input_shape = dim
+
+    def matrix(self) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def bias(self) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def inverse_matrix(self) -> torch.Tensor:
+        raise NotImplementedError()
+
+    def _to_plane_linear(self):
+        return PlaneBijectiveLinearTransform(self.dim, self.matrix(), self.bias(), self.inverse_matrix())
+
+    def simplify(self):
+        return self._to_plane_linear()
+
+
+class PlaneBijectiveLinearTransform(BaseTransform):
+    """Frozen dense form of an affine layer, used by ``simplify()`` (transforms.py:618-695)."""
+
+    def __init__(self, dim, m, bias, m_inv=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.dim = dim
+        self.bias_vector = bias
+        self.forth = nn.Linear(dim, dim, bias=True)
+        self.forth.weight = nn.Parameter(m)
+        self.forth.bias = nn.Parameter(bias)
+        self.back = nn.Linear(dim, dim, bias=True)
+        self.back.weight = nn.Parameter(m_inv)
+        self.back.bias = nn.Parameter(-torch.matmul(m_inv, bias))
+        self.m_inv = m_inv
+        with torch.no_grad():
+            self.ladj = torch.linalg.slogdet(m)[1]
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        return self.ladj
+
+    def forward(self, x, context=None):
+        return self.forth(x)
+
+    def backward(self, y, context=None):
+        return self.back(y)
+
+    def matrix(self):
+        return self.forth.weight
+
+    def inverse_matrix(self):
+        return self.back.weight
+
+    def bias(self):
+        return self.forth.bias
+
+
+class HouseholderTransform(AffineTransform):
+    """w_0 @ prod_k (I - 2 v_k v_k^T / v_k.v_k), w_0 a fixed random permutation
+    (transforms.py:752-872)."""
+
+    sign = 1
+    ladj = 0
+
+    def __init__(self, dim: int, nvs: int = 1, device="cpu", *args, **kwargs) -> None:
+        super().__init__(dim, *args, **kwargs)
+        self.nvs = nvs
+        self.dim = dim
+        indices = torch.randperm(dim)
+        w = torch.zeros((dim, dim))
+        w[torch.arange(dim), indices] = 1.0
+        self.vk_householder = nn.Parameter(0.2 * torch.randn(nvs, dim), requires_grad=True)
+        self.w_0 = nn.Parameter(w.to(torch.float32), requires_grad=False)
+        self.to(device)
+
+    def _construct_householder_permutation(self) -> torch.Tensor:
+        w = self.w_0
+        eye = torch.eye(self.dim, dtype=w.dtype, device=w.device)
+        for vk in self.vk_householder:
+            w = torch.mm(w, eye - 2 * torch.outer(vk, vk) / torch.dot(vk, vk))
+        return w
+
+    def forward(self, x, context=None):
+        return torch.matmul(x, self._construct_householder_permutation().transpose(0, 1).contiguous())
+
+    def backward(self, y, context=None):
+        return torch.matmul(y, self._construct_householder_permutation().T)
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        return self.ladj
+
+    def matrix(self):
+        return self._construct_householder_permutation()
+
+    def inverse_matrix(self):
+        return self._construct_householder_permutation().transpose(0, 1).contiguous()
+
+    def bias(self):
+        return torch.zeros(self.dim, device=self.vk_householder.device)
+
+
+class LUTransform(AffineTransform):
+    """y = (L U) x + b with unit-lower L and upper U (transforms.py:1178-1379)."""
+
+    volume_preserving = False
+
+    def __init__(self, dim: int, prior_scale: float = 1.0, *args, **kwargs):
+        super().__init__(dim, *args, **kwargs)
+        self.L_raw = nn.Parameter(torch.empty(dim, dim))
+        self.U_raw = nn.Parameter(torch.empty(dim, dim))
+        self.bias_vector = nn.Parameter(torch.empty(dim))
+        self.dim = dim
+        self.prior_scale = prior_scale
+        self.init_params()
+        self.input_shape = dim
+        self.L_mask = torch.tril(torch.ones(dim, dim), diagonal=-1)
+        self.U_mask = torch.triu(torch.ones(dim, dim), diagonal=0)
+        # keep the structural zeros: gradients outside the triangles are masked
+        self.L_raw.register_hook(lambda grad: grad * self.L_mask)
+        self.U_raw.register_hook(lambda grad: grad * self.U_mask)
+
+    def init_params(self):
+        d = self.dim
+        init.kaiming_uniform_(self.L_raw, nonlinearity="relu")
+        with torch.no_grad():
+            self.L_raw.copy_(self.L_raw.tril(diagonal=-1).fill_diagonal_(1))
+        init.kaiming_uniform_(self.U_raw, nonlinearity="relu")
+        with torch.no_grad():
+            self.U_raw.fill_diagonal_(0)
+            sign = -torch.ones(d) + 2 * torch.bernoulli(0.5 * torch.ones(d))
+            scale = self.prior_scale * torch.ones(d) * 1 / d if self.prior_scale is not None else torch.ones(d)
+            self.U_raw += sign * torch.normal(torch.zeros(d), scale).exp().diag()
+            self.U_raw.copy_(self.U_raw.triu())
+        bound = 1 / math.sqrt(d) if d > 0 else 0
+        init.uniform_(self.bias_vector, -bound, bound)
+
+    @property
+    def L(self):
+        return self.L_raw.tril(-1) + torch.eye(self.dim, dtype=self.L_raw.dtype, device=self.L_raw.device)
+
+    @property
+    def U(self):
+        return self.U_raw.triu()
+
+    def matrix(self):
+        return torch.matmul(self.L, self.U)
+
+    def bias(self):
+        return self.bias_vector
+
+    def inverse_matrix(self):
+        return torch.matmul(torch.inverse(self.U), torch.inverse(self.L))
+
+    def forward(self, x, context=None):
+        return F.linear(x, self.matrix(), self.bias())
+
+    def backward(self, y, context=None):
+        x = y - self.bias_vector
+        x = F.linear(x, torch.inverse(self.L))
+        return F.linear(x, torch.inverse(self.U))
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        # sum log|diag U| in the reference's diag()-free (ONNX-friendly) form, transforms.py:1313-1320
+        U = self.U
+        dU = U - U.triu(1) + (torch.ones_like(U) - torch.eye(self.dim, dtype=U.dtype, device=U.device))
+        return dU.abs().log().sum()
+
+    def sign(self):
+        return self.L.diag().prod().sign() * self.U.diag().prod().sign()
+
+    def to(self, device):
+        self.L_mask = self.L_mask.to(device)
+        self.U_mask = self.U_mask.to(device)
+        self.device = device
+        return super().to(device)
+
+    def is_feasible(self) -> bool:
+        return (self.U_raw.diag() != 0).all()
+
+    def add_jitter(self, jitter: float = 1e-6) -> None:
+        perturbation = torch.randn(self.dim, device=self.U_raw.device) * jitter
+        with torch.no_grad():
+            self.U_raw.copy_(self.U_raw + perturbation * torch.eye(self.dim, device=self.U_raw.device))
+
+    def log_prior(self):
+        x = self.U.diag().abs().log()
+        return -(x * x).sum() / (2 * self.prior_scale ** 2) - x.sum()
+
+
+class SequentialAffineTransform(AffineTransform):
+    """Composition of affine transforms, row-vector convention of the reference
+    (transforms.py:1381-1486): matrix = M_1 M_2 ..., bias = (..(0 M_1 + b_1) M_2 + b_2 ..)."""
+
+    def __init__(self, transforms: Iterable[AffineTransform], *args, **kwargs) -> None:
+        transforms = list(transforms)
+        dim = transforms[0].dim
+        if any(t.dim != dim for t in transforms):
+            raise ValueError("All transforms must have the same dimension")
+        super().__init__(dim, *args, **kwargs)
+        self.transforms = nn.ModuleList(transforms)
+        self.device = "cpu"
+
+    def _dev(self):
+        for p in self.parameters():
+            return p.device
+        return torch.device(self.device)
+
+    def forward(self, x, context=None):
+        for t in self.transforms:
+            x = t(x, context)
+        return x
+
+    def backward(self, y, context=None):
+        for t in self.transforms[::-1]:
+            y = t.backward(y, context)
+        return y
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        return sum(t.log_abs_det_jacobian(x, y, context) for t in self.transforms)
+
+    def sign(self):
+        return math.prod(t.sign() if callable(t.sign) else t.sign for t in self.transforms)
+
+    def matrix(self):
+        M = torch.eye(self.dim, device=self._dev())
+        for t in self.transforms:
+            M = torch.matmul(M, t.matrix())
+        return M
+
+    def inverse_matrix(self):
+        M = torch.eye(self.dim, device=self._dev())
+        for t in self.transforms[::-1]:
+            M = torch.matmul(M, t.inverse_matrix())
+        return M
+
+    def bias(self):
+        b = torch.zeros(self.dim, device=self._dev())
+        for t in self.transforms:
+            b = torch.matmul(b, t.matrix()) + t.bias()
+        return b
+
+    def is_feasible(self):
+        return all(t.is_feasible() for t in self.transforms)
+
+    def add_jitter(self, jitter: float = 1e-6):
+        for t in self.transforms:
+            t.add_jitter(jitter)
+
+    def log_prior(self):
+        return sum(t.log_prior() for t in self.transforms)
+
+    def to(self, device):
+        for t in self.transforms:
+            t.to(device)
+        self.device = device
+        return super().to(device)
+
+
+class BlockAffineTransform(BaseTransform):
+    """y = A x + b applied to flat inputs with ``F.linear`` (transforms.py:874-1029);
+    ``n_blocks`` = prod(in_dims[1:]) = 1 for the in-scope flat case."""
+
+    def __init__(self, in_dims: Iterable[int], block_transform: AffineTransform, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.in_dims = in_dims
+        if block_transform.dim != in_dims[0]:
+            raise ValueError("block_transform dim must match input dim")
+        if len(in_dims) != 1:
+            raise NotImplementedError(
+                "usflows_amd: image-shaped in_dims (1x1-conv BlockAffineTransform) are out of scope "
+                "(SURVEY.md section 8a/N4); use flat in_dims=[D]")
+        self.block_size = in_dims[0]
+        self.input_rank = len(in_dims) - 1
+        self.n_blocks = math.prod(in_dims[1:])
+        self.block_transform = block_transform
+
+    def forward(self, x, context=None):
+        if x.dim() == 2 and use_hip(self, x):
+            return self._hip("forward", x)
+        return F.linear(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device))
+
+    def backward(self, y, context=None):
+        if y.dim() == 2 and use_hip(self, y):
+            return self._hip("backward", y)
+        w = self.block_transform.inverse_matrix().to(y.device)
+        b = self.block_transform.bias().to(y.device)
+        return F.linear(y - b, w)
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        return self.block_transform.log_abs_det_jacobian(x, y, context) * self.n_blocks
+
+    def sign(self):
+        s = self.block_transform.sign
+        return (s() if callable(s) else s) ** self.n_blocks
+
+    def is_feasible(self):
+        return self.block_transform.is_feasible()
+
+    def add_jitter(self, jitter: float = 1e-6):
+        self.block_transform.add_jitter(jitter)
+
+    def log_prior(self):
+        return self.block_transform.log_prior()
+
+    def simplify(self):
+        return BlockAffineTransform(self.in_dims, self.block_transform._to_plane_linear())
+
+    def to(self, device):
+        self.block_transform.to(device)
+        return super().to(device)
