@@ -26,7 +26,7 @@ struct LinArgs {
   int act;
 };
 
-template <int TM, int TN, int WM, int BK>
+template <int TM, int TN, int WM, int BK, bool PRO, int EPI>
 __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   constexpr int NT = WM * 64;
   constexpr int BM = WM * TM * 32;
@@ -37,7 +37,9 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   constexpr int NWV = (BN * WCH + NT - 1) / NT;  // float4 staged per thread per slab
   static_assert((LDS_LD / 4) % 2 == 1, "row stride must be an odd number of 16-B slots");
 
-  __shared__ __attribute__((aligned(16))) float lds[2][BN * LDS_LD];
+  constexpr int BN_LDS = (NWV * NT) / WCH;   // >= BN: every thread stages exactly NWV float4, no guards
+  static_assert((NWV * NT) % WCH == 0 && BN_LDS >= BN, "staging shape");
+  __shared__ __attribute__((aligned(16))) float lds[2][BN_LDS * LDS_LD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -56,39 +58,38 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   const int n0 = bn * BN;
 
   // ---- per-lane activation fragment sources -----------------------------------------------
+  // All global loads below are UNCONDITIONAL (clamped addresses + selects): a branch around a
+  // load makes hipcc drain vmcnt(0) in front of the MFMA block and the prefetch is lost.
   const float* aptr[TM];
-  bool avalid[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const int r = row0 + tm * 32 + li;
-    avalid[tm] = r < p.M;
-    aptr[tm] = p.A + (int64_t)(avalid[tm] ? r : 0) * p.lda + 4 * lh;
+    const int r = min(row0 + tm * 32 + li, p.M - 1);     // rows >= M: valid garbage, never stored
+    aptr[tm] = p.A + (int64_t)r * p.lda;
   }
-  const bool has_pro = (p.pre_div != nullptr) || (p.pre_sub != nullptr);
+  const float* pdiv = p.pre_div ? p.pre_div : p.pre_sub;   // PRO only: at least one is non-null
+  const float* psub = p.pre_sub ? p.pre_sub : p.pre_div;
+  const bool has_div = p.pre_div != nullptr, has_sub = p.pre_sub != nullptr;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 
   auto load_a = [&](int k0, f32x4 (&dst)[TM][QS]) {
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
       const int k = k0 + 8 * q + 4 * lh;
       const bool kin = k < p.K;
+      const int kc = min(k, p.K - 4);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kin && avalid[tm]) v = *reinterpret_cast<const f32x4*>(aptr[tm] + k0 + 8 * q);
-        dst[tm][q] = v;
+      for (int tm = 0; tm < TM; ++tm) dst[tm][q] = *reinterpret_cast<const f32x4*>(aptr[tm] + kc);
+      if (PRO) {
+        f32x4 d = *reinterpret_cast<const f32x4*>(pdiv + kc);
+        f32x4 sb = *reinterpret_cast<const f32x4*>(psub + kc);
+        d = has_div ? d : one4;
+        sb = has_sub ? sb : zero4;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) dst[tm][q] = dst[tm][q] / d - sb;
       }
-      if (has_pro && kin) {
-        if (p.pre_div) {
-          const f32x4 d = *reinterpret_cast<const f32x4*>(p.pre_div + k);
 #pragma unroll
-          for (int tm = 0; tm < TM; ++tm) dst[tm][q] = dst[tm][q] / d;
-        }
-        if (p.pre_sub) {
-          const f32x4 s = *reinterpret_cast<const f32x4*>(p.pre_sub + k);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm) dst[tm][q] = dst[tm][q] - s;
-        }
-      }
+      for (int tm = 0; tm < TM; ++tm) dst[tm][q] = kin ? dst[tm][q] : zero4;
     }
   };
 
@@ -99,12 +100,10 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
       const int idx = tid + i * NT;
       const int r = idx / WCH;
       const int c = idx % WCH;
-      const int n = n0 + r;
+      const int n = min(n0 + r, p.N - 1);                  // columns >= N: garbage, never stored
       const int k = k0 + 4 * c;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < BN * WCH && n < p.N && k < p.K)
-        v = *reinterpret_cast<const f32x4*>(p.W + (int64_t)n * p.ldw + k);
-      dst[i] = v;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.W + (int64_t)n * p.ldw + min(k, p.K - 4));
+      dst[i] = (k < p.K) ? v : zero4;
     }
   };
   auto store_w = [&](int buf, const f32x4 (&src)[NWV]) {
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
       const int idx = tid + i * NT;
       const int r = idx / WCH;
       const int c = idx % WCH;
-      if (idx < BN * WCH) *reinterpret_cast<f32x4*>(&lds[buf][r * LDS_LD + 4 * c]) = src[i];
+      *reinterpret_cast<f32x4*>(&lds[buf][r * LDS_LD + 4 * c]) = src[i];
     }
   };
 
@@ -134,17 +133,12 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   store_w(0, wst);
   __syncthreads();
 
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    const bool more = (s + 1) < nslab;
-    if (more) {
-      load_w((s + 1) * BK, wst);
-      load_a((s + 1) * BK, a_nxt);
-    }
-    const float* wl = &lds[buf][li * LDS_LD + 4 * lh];
+  const float* wl0 = &lds[0][li * LDS_LD + 4 * lh];
+  auto compute = [&](int buf, int qn) {
+    const float* wl = wl0 + buf * (BN_LDS * LDS_LD);
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
-      if (s * BK + 8 * q < p.K) {           // uniform: skip all-zero 8-k steps of the K tail
+      if (q < qn) {
         f32x4 b[TN];
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
@@ -158,36 +152,62 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
               acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[tm][q][t], b[tn][t], acc[tm][tn], 0, 0, 0);
       }
     }
-    if (more) {
-      store_w(buf ^ 1, wst);
+  };
+
+  // steady state: every slab but the last prefetches its successor (no branch around the loads)
+  for (int s = 0; s + 1 < nslab; ++s) {
+    const int buf = s & 1;
+    load_w((s + 1) * BK, wst);
+    load_a((s + 1) * BK, a_nxt);
+    compute(buf, QS);
+    store_w(buf ^ 1, wst);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int q = 0; q < QS; ++q) a_cur[tm][q] = a_nxt[tm][q];
-    }
+      for (int q = 0; q < QS; ++q) a_cur[tm][q] = a_nxt[tm][q];
     __syncthreads();
   }
+  // last slab: skip the all-zero 8-k steps of the K tail (uniform)
+  compute((nslab - 1) & 1, (p.K - (nslab - 1) * BK + 7) / 8);
 
   // ---- epilogue: C layout of 32x32 f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
+  // Loads (bias / post_mul / residual / addend) are unconditional with clamped indices; only the
+  // stores are predicated.
+  int row0e = row0;                       // opaque copy: keeps the epilogue's address math from being
+  asm volatile("" : "+v"(row0e));         // hoisted above the K loop (it would live across it and spill)
+  const bool has_bias = p.bias != nullptr, has_pm = p.post_mul != nullptr;
+  const float* biasp = has_bias ? p.bias : p.W;           // any valid address
+  const float* pmp = has_pm ? p.post_mul : p.W;
+  const float* extra = (EPI == 1) ? p.residual : p.addend;
+  const int64_t ldx = (EPI == 1) ? p.ldr : p.ldadd;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int col = n0 + tn * 32 + li;
-    if (col >= p.N) continue;
-    const float bv = p.bias ? p.bias[col] : 0.f;
-    const float pm = p.post_mul ? p.post_mul[col] : 1.f;
+    const int colc = min(col, p.N - 1);
+    float bv = biasp[has_bias ? colc : 0];
+    float pm = pmp[has_pm ? colc : 0];
+    bv = has_bias ? bv : 0.f;
+    pm = has_pm ? pm : 1.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      float ex[16];
+      if (EPI != 0) {
+        __builtin_amdgcn_sched_barrier(0);    // keep the 16 loads of ONE tile in flight, not of all tiles (spills)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0e + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
+          ex[r] = extra[(int64_t)row * ldx + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < p.M) {
-          float v = acc[tm][tn][r] + bv;
-          if (p.addend) v = v + p.addend[(int64_t)row * p.ldadd + col];
-          v = act_apply(v, p.act, p.slope);
-          if (p.residual) v = p.residual[(int64_t)row * p.ldr + col] + p.res_sign * v;
-          if (p.post_mul) v = v * pm;
-          p.C[(int64_t)row * p.ldc + col] = v;
-        }
+        const int row = row0e + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = acc[tm][tn][r] + bv;
+        if (EPI == 2) v = v + ex[r];
+        v = act_apply(v, p.act, p.slope);
+        if (EPI == 1) v = ex[r] + p.res_sign * v;
+        v = v * pm;
+        if (row < p.M && col < p.N) p.C[(int64_t)row * p.ldc + col] = v;
       }
     }
   }
@@ -195,6 +215,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
 
 template <int TM, int TN, int WM, int BK>
 static int launch_linear(const LinArgs& a0, hipStream_t stream) {
+  const bool pro = a0.pre_div != nullptr || a0.pre_sub != nullptr;
   LinArgs a = a0;
   constexpr int BM = WM * TM * 32, BN = TN * 32;
   a.nbm = (a.M + BM - 1) / BM;
@@ -202,7 +223,15 @@ static int launch_linear(const LinArgs& a0, hipStream_t stream) {
   const int64_t panels8 = ((int64_t)(a.nbm + 7) / 8) * 8;
   const int64_t grid = panels8 * a.nbn;
   if (grid > 0x7fffffffLL) { set_error("usf_linear_f32: grid too large"); return -3; }
-  hipLaunchKernelGGL((linear_kernel<TM, TN, WM, BK>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  const int epi = a.residual ? 1 : (a.addend ? 2 : 0);
+  const dim3 g((unsigned)grid), b(WM * 64);
+#define USF_LIN(P, E) hipLaunchKernelGGL((linear_kernel<TM, TN, WM, BK, P, E>), g, b, 0, stream, a)
+  if (pro) {
+    if (epi == 0) USF_LIN(true, 0); else if (epi == 1) USF_LIN(true, 1); else USF_LIN(true, 2);
+  } else {
+    if (epi == 0) USF_LIN(false, 0); else if (epi == 1) USF_LIN(false, 1); else USF_LIN(false, 2);
+  }
+#undef USF_LIN
   return check_launch("usf_linear_f32");
 }
 
@@ -227,6 +256,7 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
     return -2;
   }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_linear_f32: bad act"); return -2; }
+  if (d->residual && d->addend) { set_error("usf_linear_f32: residual and addend are mutually exclusive"); return -2; }
   LinArgs a;
   a.A = d->A; a.W = d->W; a.bias = d->bias; a.pre_div = d->pre_div; a.pre_sub = d->pre_sub;
   a.residual = d->residual; a.addend = d->addend; a.post_mul = d->post_mul; a.C = d->C;
