@@ -64,7 +64,7 @@ def emulate_coupling(d, pm: PtrMap, dtype=torch.float32):
     h = zp @ pm.view(d.W_in, d.hidden[0], d.n_pass, d.ldw_in).to(dtype).t() + pm.vec(d.b_in, d.hidden[0]).to(dtype)
     if d.context:
         ctx = pm.vec(d.context, M).to(dtype)
-        h = h + (ctx[:, None] * pm.view(d.W_ctx, d.hidden[0], 1, 4).to(dtype).t() + pm.vec(d.b_ctx, d.hidden[0]).to(dtype))
+        h = h + (ctx[:, None] * pm.vec(d.W_ctx, d.hidden[0]).to(dtype)[None, :] + pm.vec(d.b_ctx, d.hidden[0]).to(dtype))
     act = lambda v: torch.where(v > 0, v, v * d.slope) if d.act == _ext.ACT_LEAKY_RELU else v
     h = act(h)
     for j in range(d.n_hidden - 1):
@@ -99,7 +99,7 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
             pm.add(W), pm.add(b)
         pm.add(cp["W_out"]), pm.add(cp["b_out"])
         if cp["has_ctx"]:
-            pm.add(cp["W_ctx4"]), pm.add(cp["b_ctx"])
+            pm.add(cp["W_ctx4"]), pm.add(cp["W_ctx1"]), pm.add(cp["b_ctx"])
     pm.add(x)
     pm.add(out)
     B = x.shape[0]

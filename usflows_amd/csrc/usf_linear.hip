@@ -72,19 +72,29 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 
-  auto load_a = [&](int k0, f32x4 (&dst)[TM][QS]) {
+  // Loads are split in two halves so that the ISSUE can be pinned in front of the MFMA block
+  // (sched_barrier) and everything that consumes the data (selects, prologue math, LDS stores)
+  // behind it: left alone, hipcc sinks the loads to the end of the block and waits for them there.
+  constexpr int NPRO = PRO ? QS : 1;
+  auto issue_a = [&](int k0, f32x4 (&dst)[TM][QS], f32x4 (&dv)[NPRO], f32x4 (&sv)[NPRO]) {
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
-      const int k = k0 + 8 * q + 4 * lh;
-      const bool kin = k < p.K;
-      const int kc = min(k, p.K - 4);
+      const int kc = min(k0 + 8 * q + 4 * lh, p.K - 4);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) dst[tm][q] = *reinterpret_cast<const f32x4*>(aptr[tm] + kc);
       if (PRO) {
-        f32x4 d = *reinterpret_cast<const f32x4*>(pdiv + kc);
-        f32x4 sb = *reinterpret_cast<const f32x4*>(psub + kc);
-        d = has_div ? d : one4;
-        sb = has_sub ? sb : zero4;
+        dv[q] = *reinterpret_cast<const f32x4*>(pdiv + kc);
+        sv[q] = *reinterpret_cast<const f32x4*>(psub + kc);
+      }
+    }
+  };
+  auto finish_a = [&](int k0, f32x4 (&dst)[TM][QS], const f32x4 (&dv)[NPRO], const f32x4 (&sv)[NPRO]) {
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      const bool kin = (k0 + 8 * q + 4 * lh) < p.K;
+      if (PRO) {
+        const f32x4 d = has_div ? dv[q] : one4;
+        const f32x4 sb = has_sub ? sv[q] : zero4;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) dst[tm][q] = dst[tm][q] / d - sb;
       }
@@ -94,25 +104,23 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   };
 
   // ---- weight slab staging (global -> regs -> LDS) ----------------------------------------
-  auto load_w = [&](int k0, f32x4 (&dst)[NWV]) {
+  auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
       const int idx = tid + i * NT;
       const int r = idx / WCH;
       const int c = idx % WCH;
       const int n = min(n0 + r, p.N - 1);                  // columns >= N: garbage, never stored
-      const int k = k0 + 4 * c;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p.W + (int64_t)n * p.ldw + min(k, p.K - 4));
-      dst[i] = (k < p.K) ? v : zero4;
+      dst[i] = *reinterpret_cast<const f32x4*>(p.W + (int64_t)n * p.ldw + min(k0 + 4 * c, p.K - 4));
     }
   };
-  auto store_w = [&](int buf, const f32x4 (&src)[NWV]) {
+  auto store_w = [&](int buf, int k0, const f32x4 (&src)[NWV]) {
 #pragma unroll
     for (int i = 0; i < NWV; ++i) {
       const int idx = tid + i * NT;
       const int r = idx / WCH;
       const int c = idx % WCH;
-      *reinterpret_cast<f32x4*>(&lds[buf][r * LDS_LD + 4 * c]) = src[i];
+      *reinterpret_cast<f32x4*>(&lds[buf][r * LDS_LD + 4 * c]) = (k0 + 4 * c < p.K) ? src[i] : zero4;
     }
   };
 
@@ -125,12 +133,14 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
   f32x4 a_cur[TM][QS], a_nxt[TM][QS];
+  f32x4 dvr[NPRO], svr[NPRO];
   f32x4 wst[NWV];
 
   const int nslab = (p.K + BK - 1) / BK;
-  load_w(0, wst);
-  load_a(0, a_cur);
-  store_w(0, wst);
+  issue_w(0, wst);
+  issue_a(0, a_cur, dvr, svr);
+  finish_a(0, a_cur, dvr, svr);
+  store_w(0, 0, wst);
   __syncthreads();
 
   const float* wl0 = &lds[0][li * LDS_LD + 4 * lh];
@@ -157,10 +167,14 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   // steady state: every slab but the last prefetches its successor (no branch around the loads)
   for (int s = 0; s + 1 < nslab; ++s) {
     const int buf = s & 1;
-    load_w((s + 1) * BK, wst);
-    load_a((s + 1) * BK, a_nxt);
+    const int k1 = (s + 1) * BK;
+    issue_w(k1, wst);
+    issue_a(k1, a_nxt, dvr, svr);
+    __builtin_amdgcn_sched_barrier(0);
     compute(buf, QS);
-    store_w(buf ^ 1, wst);
+    __builtin_amdgcn_sched_barrier(0);
+    store_w(buf ^ 1, k1, wst);
+    finish_a(k1, a_nxt, dvr, svr);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

@@ -308,6 +308,7 @@ class FlowEngine:
             bc = torch.zeros(hp[0], dtype=torch.float64, device=device)
             bc[: h[0]] = f64(ctx_l.bias)
             d["W_ctx4"] = Wc.float().contiguous()      # [h0, 4]: context rides in column 0 of a 4-wide K
+            d["W_ctx1"] = Wc[:, 0].float().contiguous()  # [h0]: form the fused coupling kernel takes
             d["b_ctx"] = bc.float().contiguous()
         return d
 
@@ -419,7 +420,15 @@ class FlowEngine:
                 Kdim = self.LD if in_layout == "seg" else self.LDn
                 if prim == "affine_bwd":
                     W = self._mat(pk, blk, "Minv", out_layout, in_layout)
-                    kw["pre_sub"] = self._vec(pk, ("b", id(blk)), a["b"], in_layout, 0.0).data_ptr()
+                    if "pre_div" in kw:
+                        # first layer of log_prob: (x / s - b) @ Minv^T, prologue in the operand registers
+                        kw["pre_sub"] = self._vec(pk, ("b", id(blk)), a["b"], in_layout, 0.0).data_ptr()
+                    else:
+                        # (y - b) @ Minv^T == y @ Minv^T + c with c = -(Minv b), c formed in fp64 at pack
+                        # time: keeps the bias out of the K loop's registers ("bias folding")
+                        if "c" not in a:
+                            a["c"] = -(a["Minv"] @ a["b"])
+                        kw["bias"] = self._vec(pk, ("c", id(blk)), a["c"], out_layout, 0.0).data_ptr()
                 else:
                     W = self._mat(pk, blk, "M", out_layout, in_layout)
                     kw["bias"] = self._vec(pk, ("b", id(blk)), a["b"], out_layout, 0.0).data_ptr()
@@ -526,7 +535,7 @@ class FlowEngine:
         d.W_out, d.ldw_out, d.b_out = cp["W_out"].data_ptr(), cp["W_out"].shape[1], cp["b_out"].data_ptr()
         if ws_ctx is not None:
             d.context = ws_ctx["ctx"].data_ptr()
-            d.W_ctx, d.b_ctx = cp["W_ctx4"].data_ptr(), cp["b_ctx"].data_ptr()
+            d.W_ctx, d.b_ctx = cp["W_ctx1"].data_ptr(), cp["b_ctx"].data_ptr()
         d.sign, d.slope, d.act = sign, cp["slope"], cp["act"]
         return op
 
