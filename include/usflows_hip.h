@@ -87,7 +87,13 @@ int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream);
  * Mask-aware: W_in holds only the columns of layers[0].weight that multiply pass-through
  * features (the others meet x*mask == 0), W_out/b_out only the rows that produce transformed
  * features (the others are multiplied by (1-mask) == 0).  Hidden activations never leave the
- * CU (registers/LDS).  n_hidden in [1, USF_MAX_HIDDEN]; every hidden width <= usf_coupling_max_width().
+ * CU (registers).  The fused kernel takes n_hidden in [1, 3] and hidden widths <= usf_coupling_max_width().
+ *
+ * Padding contract (lets the kernel load weights without clamps or selects): with
+ * Hp = usf_coupling_padded_width(max hidden width), Kp = ceil32(n_pass), Np = ceil32(n_trans):
+ *   W_in  readable as [Hp, Kp] (ldw_in  >= Kp), W_hid[i] as [Hp, Hp] (ldw_hid >= Hp),
+ *   W_out readable as [Np, Hp] (ldw_out >= Hp), b_in / b_hid[i] / W_ctx / b_ctx as [Hp], b_out as [Np],
+ * all ZERO outside their true extents.  z/out: in place (out == z, ldo == ldz).
  */
 #define USF_MAX_HIDDEN 4
 typedef struct usf_coupling_desc {
@@ -117,6 +123,7 @@ typedef struct usf_coupling_desc {
 
 int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream);
 int usf_coupling_max_width(void);       /* widest hidden layer the fused kernel accepts */
+int usf_coupling_padded_width(int h);   /* Hp of the padding contract for hidden width h (-1 if unsupported) */
 
 /*
  * Tail of Flow.log_prob (flows.py:245): per-sample reduction over the feature axis.

@@ -98,6 +98,12 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
         for W, b in cp["layers"]:
             pm.add(W), pm.add(b)
         pm.add(cp["W_out"]), pm.add(cp["b_out"])
+        if "fused" in cp:
+            f = cp["fused"]
+            for t in (f["W_in"], f["b_in"], f["W_out"], f["b_out"], f.get("W_ctx"), f.get("b_ctx")):
+                pm.add(t)
+            for W, b in f["hid"]:
+                pm.add(W), pm.add(b)
         if cp["has_ctx"]:
             pm.add(cp["W_ctx4"]), pm.add(cp["W_ctx1"]), pm.add(cp["b_ctx"])
     pm.add(x)
@@ -145,7 +151,7 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
 def engine_transform(eng, x, direction, context=None, fused=False):
     eng.use_fused_coupling = fused
     if fused:
-        eng._fused_ok = lambda cp: len(cp["hidden"]) <= _ext.USF_MAX_HIDDEN
+        eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     B = x.shape[0]
     out = torch.empty(B, eng.D)
     plan = eng._plan(direction, B, x.device, context is not None, "user")
@@ -156,7 +162,7 @@ def engine_transform(eng, x, direction, context=None, fused=False):
 def engine_latent(eng, x, context=None, fused=False):
     eng.use_fused_coupling = fused
     if fused:
-        eng._fused_ok = lambda cp: len(cp["hidden"]) <= _ext.USF_MAX_HIDDEN
+        eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     plan = eng._plan("backward", x.shape[0], x.device, context is not None, "nat")
     run_plan(eng, plan, x.contiguous(), None, context)
     buf = plan["ws"][plan["out_buf"][0]]

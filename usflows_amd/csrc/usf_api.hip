@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 int linear_dispatch(const usf_linear_desc* d, hipStream_t stream);
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 int coupling_max_width();
+int coupling_padded_width(int h);
 int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                  const float* scale, float logdet_const, float* logp, double* sum_out, hipStream_t stream);
 int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* scale,
@@ -52,6 +53,7 @@ int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream) {
 }
 
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
+int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }
 
 int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                          const float* scale, float logdet_const, float* logp, double* sum_out, usf_stream_t stream) {

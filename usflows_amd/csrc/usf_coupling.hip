@@ -5,35 +5,33 @@
 //   out[:, trans] = z[:, trans] + sign * ( W_out . act( W_h . act( W_in . z[:, pass] + b_in [+ ctx] ) + b_h ) + b_out )
 //
 // Design (DESIGN.md "fused coupling kernel"):
-//  * One wave owns 32 batch rows for the whole layer; a 256-thread block = 128 rows.
+//  * One wave owns 16 batch rows for the whole layer (v_mfma_f32_16x16x4_f32); a 256-thread block
+//    = 64 rows, two blocks per CU (<= 256 VGPRs, 64 KB LDS each) so that one block's barriers and
+//    load waits are covered by the other block's MFMAs.
 //  * The MLP is evaluated TRANSPOSED: X1 = W_in . Z^T, X2 = W_h . X1, ... so that every hidden
 //    activation tile is an MFMA *accumulator* with the batch row on the lane and the hidden unit in
-//    the register index.  On gfx950 the 32x32 f32 accumulator layout (row = (r&3) + 8*(r>>2) +
-//    4*(lane>>5)) is exactly the k-permutation this library feeds its f32 MFMAs with (lane half h
-//    owns k = 8q+4h..+3), so an accumulator register IS the next layer's B operand: no LDS round
-//    trip, no shuffles, no conversion.  The last product flips orientation (X as the A operand)
-//    so that its output has the feature on the lane -> coalesced residual read-modify-write.
-//  * Only the weights travel through LDS: a unified stream of 32 KB stages (a [H x 32] k-slab of
-//    W_in / W_h, or a [32 x H] n-tile of W_out), register-staged and double-buffered, the loads
-//    of stage g+1 pinned in front of the MFMA block of stage g.
+//    the register index.  On gfx950 the 16x16 f32 accumulator layout (row = 4*(lane>>4) + r) is
+//    exactly the k-permutation this library feeds its f32 MFMAs with (lane group g owns
+//    k = 16q+4g..+3), so an accumulator register IS the next layer's B operand: no LDS round trip,
+//    no shuffles, no conversion.  The last product flips orientation (X as the A operand) so that
+//    its output has the feature on the lane -> coalesced residual read-modify-write.
+//  * Only the weights travel through LDS: a unified stream of 32 KB stages (a [256 x 32] k-slab of
+//    W_in / W_h, or a [32 x 256] n-tile of W_out), register-staged and double-buffered, the loads
+//    of stage g+1 pinned in front of the MFMA block of stage g.  LDS image is k-chunk-major
+//    (slot = chunk * rows + row): fragment reads and staging writes are both conflict-free.
 //  * z fragments (phase 1) and residual values (phase 3) go global -> registers directly; each
 //    element is needed by exactly one wave.
 #include "usf_common.h"
 
 namespace usf {
 
-constexpr int CPL_HT = 8;                  // hidden tiles of 32 -> hidden widths up to 256
 constexpr int CPL_BK = 32;                 // k per weight slab
-constexpr int CPL_LDW = CPL_BK + 4;        // slab row stride (odd number of 16-B slots)
-constexpr int CPL_H = CPL_HT * 32;
-constexpr int CPL_LDW3 = CPL_H + 4;        // n-tile row stride
-constexpr int CPL_BUF = (CPL_H * CPL_LDW > 32 * CPL_LDW3) ? CPL_H * CPL_LDW : 32 * CPL_LDW3;
-constexpr int CPL_NST = 8;                 // float4 staged per thread per stage (2048 / 256)
+constexpr int CPL_ROWS = 64;               // batch rows per block (4 waves x 16)
+constexpr int CPL_HMAX = 256;              // widest hidden layer the kernel is instantiated for
 
 struct CplArgs {
   const float* z; float* out; int64_t ldz;
   int M, off_pass, n_pass, off_trans, n_trans;
-  int nh; int h[USF_MAX_HIDDEN];
   const float* W_in; int64_t ldw_in; const float* b_in;
   const float* W_hid[2]; const float* b_hid[2]; int64_t ldw_hid[2];
   const float* W_out; int64_t ldw_out; const float* b_out;
@@ -41,238 +39,274 @@ struct CplArgs {
   float sign, slope; int act;
 };
 
-template <int NH>
-__global__ __launch_bounds__(256, 1) void coupling_kernel(const CplArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[2][CPL_BUF];
+// NH = number of hidden layers, T = hidden tiles of 16 kept in registers: every hidden layer is
+// treated as Hp = 16*T wide (the caller zero-pads the weights to that width, see the header), so
+//  * no per-tile branches: each MFMA block is straight-line code and the LDS fragment reads are
+//    software-pipelined two tiles ahead of the MFMAs that consume them;
+//  * no clamps / selects on the weight loads: a thread's NST loads of a stage sit at constant
+//    strides from one per-thread pointer.
+template <int NH, int T>
+__global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
+  constexpr int HP = 16 * T;               // padded hidden width
+  constexpr int NST = T / 2;               // float4 staged per thread per stage (HP*32/4/256)
+  constexpr int BUF = HP * CPL_BK;         // floats per stage buffer
+  __shared__ __attribute__((aligned(16))) float lds[2][BUF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int li = lane & 31;
-  const int lh = lane >> 5;
-  const int wrow0 = blockIdx.x * 128 + wave * 32;
-  const int rowc = min(wrow0 + li, p.M - 1);           // rows >= M: valid garbage, never stored
+  const int lj = lane & 15;
+  const int lg = lane >> 4;
+  const int wrow0 = blockIdx.x * CPL_ROWS + wave * 16;
+  const int rowc = min(wrow0 + lj, p.M - 1);           // rows >= M: valid garbage, never stored
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  // ---- unified weight-stage stream --------------------------------------------------------
+  // ---- weight stages ---------------------------------------------------------------------------
+  // LDS image: slot(row, chunk) = chunk * nr + row (16-B slots).  k-slab: nr = HP rows x 8 chunks;
+  // n-tile: nr = 32 rows x NCH chunks.  Thread -> (row, chunk): 8 consecutive lanes take 8 consecutive
+  // rows of one chunk (conflict-free ds_write_b128); a wave covers 8 rows x 8 chunks = 8 whole 128-B
+  // lines of the weight matrix (coalesced).  Load i of a thread is at a constant stride from load 0.
+  // The per-load address is re-derived from ONE live pointer (opaque bump) -- left to itself hipcc
+  // precomputes all NST 64-bit addresses of every weight matrix, keeps them live across the whole
+  // kernel and spills inside the MFMA loops.
+  const int kr0 = (tid & 7) + 8 * (tid >> 6), kc = (tid >> 3) & 7;          // k-slab: row = kr0 + 32 i
+  auto issue_k = [&](const float* W, int64_t ld, int k0, f32x4 (&st)[NST]) {
+    int64_t off = (int64_t)kr0 * ld + (k0 + 4 * kc);       // opaque OFFSET (an opaque pointer would turn
+    const int64_t step = 32 * ld;                          // the loads into flat_load: lgkmcnt + vmcnt)
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      st[i] = *reinterpret_cast<const f32x4*>(W + off);
+      off += step;
+      asm volatile("" : "+v"(off));
+    }
+  };
+  auto store_k = [&](int buf, const f32x4 (&st)[NST]) {
+    float* dst = &lds[buf][4 * (kc * HP + kr0)];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<f32x4*>(dst + 4 * 32 * i) = st[i];
+  };
+  // n-tile: idx = tid + 256 i -> row = (idx & 7) + 8 * (idx / (8 * NCH)), chunk = (idx >> 3) % NCH, which
+  // separates into a per-thread base and a compile-time function of i:
+  //   T=4 : row = (tid&7) + 8*(tid>>7) + 16 i, chunk = (tid>>3)&15
+  //   T=8 : row = (tid&7) + 8 i,               chunk = (tid>>3)
+  //   T=16: row = (tid&7) + 8 (i>>1),          chunk = (tid>>3) + 32 (i&1)
+  const int nr0 = (T == 4) ? (tid & 7) + 8 * (tid >> 7) : (tid & 7);
+  const int nc0 = (T == 4) ? ((tid >> 3) & 15) : (tid >> 3);
+  auto n_drow = [](int i) { return (T == 4) ? 16 * i : ((T == 8) ? 8 * i : 8 * (i >> 1)); };
+  auto n_dchunk = [](int i) { return (T == 16) ? 32 * (i & 1) : 0; };
+  auto issue_n = [&](const float* W, int64_t ld, int n0, f32x4 (&st)[NST]) {
+    int64_t off = (int64_t)(n0 + nr0) * ld + 4 * nc0;
+    asm volatile("" : "+v"(off));
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+      st[i] = *reinterpret_cast<const f32x4*>(W + off + (int64_t)n_drow(i) * ld + 4 * n_dchunk(i));
+  };
+  auto store_n = [&](int buf, const f32x4 (&st)[NST]) {
+    float* dst = &lds[buf][4 * (nc0 * 32 + nr0)];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) *reinterpret_cast<f32x4*>(dst + 4 * (n_dchunk(i) * 32 + n_drow(i))) = st[i];
+  };
+
   const int nS1 = (p.n_pass + CPL_BK - 1) / CPL_BK;
-  int nS2[2] = {0, 0};
-#pragma unroll
-  for (int l = 0; l + 1 < NH; ++l) nS2[l] = (p.h[l] + 31) / 32;
   const int nS3 = (p.n_trans + 31) / 32;
-  const int g2 = nS1;                                   // first stage of hidden layer 0 -> 1
-  const int g2b = g2 + nS2[0];                          // first stage of hidden layer 1 -> 2
-  const int g3 = g2b + nS2[1];                          // first stage of the output product
-  const int G = g3 + nS3;
 
-  struct Src { const float* base; int64_t ld; int nrows, ncols, row0, k0, shift; };
-  auto stage_src = [&](int g) -> Src {
-    g = min(g, G - 1);
-    Src s;
-    if (g < g2) {                 // W_in k-slab: rows = hidden units, cols = pass-through features
-      s.base = p.W_in; s.ld = p.ldw_in; s.nrows = p.h[0]; s.ncols = p.n_pass; s.row0 = 0; s.k0 = g * CPL_BK; s.shift = 3;
-    } else if (g < g2b) {
-      s.base = p.W_hid[0]; s.ld = p.ldw_hid[0]; s.nrows = p.h[NH > 1 ? 1 : 0]; s.ncols = p.h[0]; s.row0 = 0;
-      s.k0 = (g - g2) * CPL_BK; s.shift = 3;
-    } else if (g < g3) {
-      s.base = p.W_hid[1]; s.ld = p.ldw_hid[1]; s.nrows = p.h[NH > 2 ? 2 : 0]; s.ncols = p.h[NH > 1 ? 1 : 0]; s.row0 = 0;
-      s.k0 = (g - g2b) * CPL_BK; s.shift = 3;
-    } else {                      // W_out n-tile: 32 output features x all of the last hidden layer
-      s.base = p.W_out; s.ld = p.ldw_out; s.nrows = p.n_trans; s.ncols = p.h[NH - 1]; s.row0 = (g - g3) * 32;
-      s.k0 = 0; s.shift = 6;
-    }
-    return s;
-  };
-  // loads are unconditional (clamped); the zero-fill happens at LDS-store time
-  auto issue_stage = [&](int g, f32x4 (&st)[CPL_NST]) {
-    const Src s = stage_src(g);
-    const int cmask = (1 << s.shift) - 1;
+  f32x4 X1[T], X2[T];
 #pragma unroll
-    for (int i = 0; i < CPL_NST; ++i) {
-      const int idx = tid + i * 256;
-      const int row = min(s.row0 + (idx >> s.shift), s.nrows - 1);
-      const int k = min(s.k0 + 4 * (idx & cmask), s.ncols - 4);
-      st[i] = *reinterpret_cast<const f32x4*>(s.base + (int64_t)row * s.ld + k);
-    }
-  };
-  auto store_stage = [&](int g, int buf, const f32x4 (&st)[CPL_NST]) {
-    const Src s = stage_src(g);
-    const int cmask = (1 << s.shift) - 1;
-    const int ldl = (s.shift == 3) ? CPL_LDW : CPL_LDW3;
-#pragma unroll
-    for (int i = 0; i < CPL_NST; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx >> s.shift, c = idx & cmask;
-      const bool ok = (s.row0 + r < s.nrows) && (s.k0 + 4 * c < s.ncols);
-      *reinterpret_cast<f32x4*>(&lds[buf][r * ldl + 4 * c]) = ok ? st[i] : zero4;
-    }
-  };
+  for (int t = 0; t < T; ++t) X1[t] = zero4;
 
-  f32x16 X1[CPL_HT], X2[CPL_HT];
-#pragma unroll
-  for (int t = 0; t < CPL_HT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) X1[t][r] = 0.f;
-
-  f32x4 st[CPL_NST];
-  f32x4 zc[4], zn[4];
+  f32x4 st[NST];
+  f32x4 zc[2], zn[2];
   const float* zrow = p.z + (int64_t)rowc * p.ldz + p.off_pass;
-  auto issue_z = [&](int k0, f32x4 (&dst)[4]) {
+  auto issue_z = [&](int k0, f32x4 (&dst)[2]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4*>(zrow + min(k0 + 8 * q + 4 * lh, p.n_pass - 4));
+    for (int q = 0; q < 2; ++q) dst[q] = *reinterpret_cast<const f32x4*>(zrow + min(k0 + 16 * q + 4 * lg, p.n_pass - 4));
   };
-  auto finish_z = [&](int k0, f32x4 (&dst)[4]) {
+  auto finish_z = [&](int k0, f32x4 (&dst)[2]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = (k0 + 8 * q + 4 * lh < p.n_pass) ? dst[q] : zero4;
+    for (int q = 0; q < 2; ++q) dst[q] = (k0 + 16 * q + 4 * lg < p.n_pass) ? dst[q] : zero4;
   };
 
-  int g = 0;                                            // current stage
-  issue_stage(0, st);
+  // One 16-k step over all hidden tiles: X[ht] += Wfrag(ht) (x) B.  Tiles go in pairs (two
+  // independent accumulators back to back: 16x16x4 has a 40-cycle dependent latency on a 32-cycle
+  // issue) and the fragments of the next pair are read while the current pair multiplies.
+  auto mfma_block = [&](const float* wq, f32x4 (&X)[T], const f32x4 bop) {
+    f32x4 a[T];
+#pragma unroll
+    for (int ht = 0; ht < T; ++ht) a[ht] = *reinterpret_cast<const f32x4*>(wq + 4 * (ht * 16));
+#pragma unroll
+    for (int ht = 0; ht < T; ht += 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        X[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ht][t], bop[t], X[ht], 0, 0, 0);
+        X[ht + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ht + 1][t], bop[t], X[ht + 1], 0, 0, 0);
+      }
+    }
+    // schedule: 4 fragment reads up front, then {8 MFMA, 2 reads} -- reads run two tile pairs ahead
+    __builtin_amdgcn_sched_group_barrier(0x100, (T >= 4) ? 4 : T, 0);
+#pragma unroll
+    for (int i = 0; i < T / 2 - 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+  };
+  // first stage of the phase that follows hidden layer `l` input (compile-time kind)
+  auto issue_after_input = [&](f32x4 (&s_)[NST]) {
+    if (NH >= 2) issue_k(p.W_hid[0], p.ldw_hid[0], 0, s_); else issue_n(p.W_out, p.ldw_out, 0, s_);
+  };
+  auto store_after_input = [&](int buf, const f32x4 (&s_)[NST]) {
+    if (NH >= 2) store_k(buf, s_); else store_n(buf, s_);
+  };
+
+  int g = 0;                                            // stage counter: buffer = g & 1
+  issue_k(p.W_in, p.ldw_in, 0, st);
   issue_z(0, zc);
-  store_stage(0, 0, st);
+  store_k(0, st);
   finish_z(0, zc);
   __syncthreads();
 
   // ================= phase 1: X1[h][row] += W_in[h][k] * z[row][k] ============================
-  const int nht0 = (p.h[0] + 31) / 32;
-  for (int s = 0; s < nS1; ++s, ++g) {
+  auto phase1_compute = [&](int buf, int s) {
+    const float* wl = &lds[buf][4 * (lg * HP + lj)];
+    const int nq = min(2, (p.n_pass - s * CPL_BK + 15) / 16);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q < nq) mfma_block(wl + 4 * (q * 4 * HP), X1, zc[q]);     // uniform, per 16-k step
+    }
+  };
+  for (int s = 0; s + 1 < nS1; ++s, ++g) {
     const int buf = g & 1;
-    issue_stage(g + 1, st);
+    issue_k(p.W_in, p.ldw_in, (s + 1) * CPL_BK, st);
     issue_z((s + 1) * CPL_BK, zn);
     __builtin_amdgcn_sched_barrier(0);
-    const float* wl = &lds[buf][li * CPL_LDW + 4 * lh];
-    const int nq = min(4, (p.n_pass - s * CPL_BK + 7) / 8);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < nq) {
-#pragma unroll
-        for (int ht = 0; ht < CPL_HT; ++ht) {
-          if (ht < nht0) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(wl + ht * 32 * CPL_LDW + 8 * q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) X1[ht] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], zc[q][t], X1[ht], 0, 0, 0);
-          }
-        }
-      }
-    }
+    phase1_compute(buf, s);
     __builtin_amdgcn_sched_barrier(0);
-    store_stage(g + 1, buf ^ 1, st);
+    store_k(buf ^ 1, st);
     finish_z((s + 1) * CPL_BK, zn);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) zc[q] = zn[q];
+    for (int q = 0; q < 2; ++q) zc[q] = zn[q];
     __syncthreads();
   }
+  {   // last k-slab of W_in: prefetch the first stage of the next phase
+    const int buf = g & 1;
+    issue_after_input(st);
+    __builtin_amdgcn_sched_barrier(0);
+    phase1_compute(buf, nS1 - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_after_input(buf ^ 1, st);
+    __syncthreads();
+    ++g;
+  }
 
-  // bias (+ context branch) + activation on an accumulator array, in registers
-  auto bias_act = [&](f32x16 (&X)[CPL_HT], const float* bias, int h, bool with_ctx) {
+  // bias (+ context branch) + activation on an accumulator array, in registers:
+  // X[ht][t] of lane (j, g) is hidden unit ht*16 + 4g + t of batch row j
+  auto bias_act = [&](f32x4 (&X)[T], const float* bias, bool with_ctx) {
     const float cv = with_ctx ? p.ctx[rowc] : 0.f;
 #pragma unroll
-    for (int ht = 0; ht < CPL_HT; ++ht) {
-      __builtin_amdgcn_sched_barrier(0);               // one tile's bias loads in flight at a time
+    for (int ht = 0; ht < T; ++ht) {
+      const int hi = ht * 16 + 4 * lg;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + hi);
+      f32x4 wc = zero4, bc = zero4;
+      if (with_ctx) {
+        wc = *reinterpret_cast<const f32x4*>(p.W_ctx + hi);
+        bc = *reinterpret_cast<const f32x4*>(p.b_ctx + hi);
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int hi = min(ht * 32 + 8 * q + 4 * lh, h - 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + hi);
-        f32x4 wc = zero4, bc = zero4;
-        if (with_ctx) {
-          wc = *reinterpret_cast<const f32x4*>(p.W_ctx + hi);
-          bc = *reinterpret_cast<const f32x4*>(p.b_ctx + hi);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          float v = X[ht][4 * q + t] + b[t];                  // layers[0](x)
-          if (with_ctx) v = v + (cv * wc[t] + bc[t]);         // + layers[1](context), networks.py:741-743
-          X[ht][4 * q + t] = act_apply(v, p.act, p.slope);
-        }
+      for (int t = 0; t < 4; ++t) {
+        float v = X[ht][t] + b[t];                          // layers[0](x)
+        if (with_ctx) v = v + (cv * wc[t] + bc[t]);         // + layers[1](context), networks.py:741-743
+        X[ht][t] = act_apply(v, p.act, p.slope);
       }
     }
   };
-  bias_act(X1, p.b_in, p.h[0], p.ctx != nullptr);
+  bias_act(X1, p.b_in, p.ctx != nullptr);
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1] * Xin[h1][row] ====================
-  auto hidden_layer = [&](f32x16 (&Xin)[CPL_HT], f32x16 (&Xout)[CPL_HT], int l) {
-    const int nkt = (p.h[l] + 31) / 32;
-    const int nho = (p.h[l + 1] + 31) / 32;
+  auto hidden_layer = [&](f32x4 (&Xin)[T], f32x4 (&Xout)[T], int l) {
 #pragma unroll
-    for (int kt = 0; kt < CPL_HT; ++kt) {
-      if (kt < nkt) {
-        const int buf = g & 1;
-        issue_stage(g + 1, st);
-        __builtin_amdgcn_sched_barrier(0);
-        const float* wl = &lds[buf][li * CPL_LDW + 4 * lh];
+    for (int ks = 0; ks < T / 2; ++ks) {
+      const int buf = g & 1;
+      const bool last = (ks + 1 == T / 2);
+      const bool next_is_hidden = (l + 2 < NH);
+      if (!last) issue_k(p.W_hid[l], p.ldw_hid[l], (ks + 1) * CPL_BK, st);
+      else if (next_is_hidden) issue_k(p.W_hid[l + 1], p.ldw_hid[l + 1], 0, st);
+      else issue_n(p.W_out, p.ldw_out, 0, st);
+      __builtin_amdgcn_sched_barrier(0);
+      const float* wl = &lds[buf][4 * (lg * HP + lj)];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int ht = 0; ht < CPL_HT; ++ht) {
-            if (ht < nho) {
-              const f32x4 a = *reinterpret_cast<const f32x4*>(wl + ht * 32 * CPL_LDW + 8 * q);
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                Xout[ht] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], Xin[kt][4 * q + t], Xout[ht], 0, 0, 0);
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        store_stage(g + 1, buf ^ 1, st);
-        __syncthreads();
-        ++g;
-      }
+      for (int q = 0; q < 2; ++q) mfma_block(wl + 4 * (q * 4 * HP), Xout, Xin[2 * ks + q]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!last || next_is_hidden) store_k(buf ^ 1, st); else store_n(buf ^ 1, st);
+      __syncthreads();
+      ++g;
     }
-    bias_act(Xout, p.b_hid[l], p.h[l + 1], false);
+    bias_act(Xout, p.b_hid[l], false);
   };
   if (NH >= 2) {
 #pragma unroll
-    for (int t = 0; t < CPL_HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) X2[t][r] = 0.f;
+    for (int t = 0; t < T; ++t) X2[t] = zero4;
     hidden_layer(X1, X2, 0);
   }
   if (NH >= 3) {
 #pragma unroll
-    for (int t = 0; t < CPL_HT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) X1[t][r] = 0.f;
+    for (int t = 0; t < T; ++t) X1[t] = zero4;
     hidden_layer(X2, X1, 1);
   }
 
   // ================= phase 3: T[row][n] = sum_h Xlast[h][row] * W_out[n][h]; residual ==========
-  auto output_layer = [&](f32x16 (&X)[CPL_HT]) {
-    const int nkt = (p.h[NH - 1] + 31) / 32;
+  // two 16-wide n tiles per stage, interleaved (16x16x4 needs 2 independent accumulators)
+  auto output_layer = [&](f32x4 (&X)[T]) {
     for (int nt = 0; nt < nS3; ++nt, ++g) {
       const int buf = g & 1;
-      issue_stage(g + 1, st);
-      const int col = nt * 32 + li;
-      const int colc = min(col, p.n_trans - 1);
-      float res[16];
+      issue_n(p.W_out, p.ldw_out, min(nt + 1, nS3 - 1) * 32, st);
+      int col[2];
+      float res[2][4], bo[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
-        res[r] = p.z[(int64_t)row * p.ldz + p.off_trans + colc];
+      for (int u = 0; u < 2; ++u) {
+        col[u] = nt * 32 + u * 16 + lj;
+        const int colc = min(col[u], p.n_trans - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(wrow0 + 4 * lg + r, p.M - 1);
+          res[u][r] = p.z[(int64_t)row * p.ldz + p.off_trans + colc];
+        }
+        bo[u] = p.b_out[col[u]];                            // b_out is padded to 32 * nS3
       }
-      const float bo = p.b_out[colc];
       __builtin_amdgcn_sched_barrier(0);
-      f32x16 acc;
+      f32x4 acc0 = zero4, acc1 = zero4;
+      const float* wl = &lds[buf][4 * (lg * 32 + lj)];
+      f32x4 b0[T], b1[T];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* wl = &lds[buf][li * CPL_LDW3 + 4 * lh];
+      for (int kt = 0; kt < T; ++kt) {
+        b0[kt] = *reinterpret_cast<const f32x4*>(wl + 4 * (kt * 4 * 32));
+        b1[kt] = *reinterpret_cast<const f32x4*>(wl + 4 * (kt * 4 * 32 + 16));
+      }
 #pragma unroll
-      for (int kt = 0; kt < CPL_HT; ++kt) {
-        if (kt < nkt) {
+      for (int kt = 0; kt < T; ++kt) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(wl + kt * 32 + 8 * q);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[kt][4 * q + t], b[t], acc, 0, 0, 0);
-          }
+        for (int t = 0; t < 4; ++t) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(X[kt][t], b0[kt][t], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(X[kt][t], b1[kt][t], acc1, 0, 0, 0);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      store_stage(g + 1, buf ^ 1, st);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = res[r] + p.sign * (acc[r] + bo);
-        if (row < p.M && col < p.n_trans) p.out[(int64_t)row * p.ldz + p.off_trans + col] = v;
+      for (int i = 0; i < T - 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      store_n(buf ^ 1, st);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wrow0 + 4 * lg + r;
+          const float a = (u == 0) ? acc0[r] : acc1[r];
+          const float v = res[u][r] + p.sign * (a + bo[u]);
+          if (row < p.M && col[u] < p.n_trans) p.out[(int64_t)row * p.ldz + p.off_trans + col[u]] = v;
+        }
       }
       __syncthreads();
     }
@@ -280,7 +314,11 @@ __global__ __launch_bounds__(256, 1) void coupling_kernel(const CplArgs p) {
   if (NH == 2) output_layer(X2); else output_layer(X1);
 }
 
-int coupling_max_width() { return CPL_H; }
+static int padded_width(int h) { return h <= 64 ? 64 : (h <= 128 ? 128 : 256); }
+
+int coupling_padded_width(int h) { return (h < 1 || h > CPL_HMAX) ? -1 : padded_width(h); }
+
+int coupling_max_width() { return CPL_HMAX; }
 
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_additive_f32: null descriptor"); return -1; }
@@ -301,13 +339,20 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   CplArgs a;
   a.z = d->z; a.out = d->out; a.ldz = d->ldz;
   a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans;
-  a.nh = d->n_hidden;
-  for (int i = 0; i < USF_MAX_HIDDEN; ++i) a.h[i] = (i < d->n_hidden) ? d->hidden[i] : 4;
+  int hmax = 0;
   for (int i = 0; i < d->n_hidden; ++i) {
-    if (a.h[i] < 4 || (a.h[i] & 3) || a.h[i] > CPL_H) {
-      set_error("usf_coupling_additive_f32: hidden width %d must be a multiple of 4 in [4, %d]", a.h[i], CPL_H);
+    if (d->hidden[i] < 1 || d->hidden[i] > CPL_HMAX) {
+      set_error("usf_coupling_additive_f32: hidden width %d must be in [1, %d]", d->hidden[i], CPL_HMAX);
       return -2;
     }
+    hmax = d->hidden[i] > hmax ? d->hidden[i] : hmax;
+  }
+  const int hp = padded_width(hmax);
+  const int64_t kp = ((d->n_pass + 31) / 32) * 32;
+  if (d->ldw_in < kp || d->ldw_out < hp) {
+    set_error("usf_coupling_additive_f32: padding contract violated (ldw_in %lld < %lld or ldw_out %lld < %d)",
+              (long long)d->ldw_in, (long long)kp, (long long)d->ldw_out, hp);
+    return -2;
   }
   a.W_in = d->W_in; a.ldw_in = d->ldw_in; a.b_in = d->b_in;
   for (int i = 0; i < 2; ++i) {
@@ -315,7 +360,8 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
     a.W_hid[i] = used ? d->W_hid[i] : d->W_in;
     a.b_hid[i] = used ? d->b_hid[i] : d->b_in;
     a.ldw_hid[i] = used ? d->ldw_hid[i] : d->ldw_in;
-    if (used && (!d->W_hid[i] || !d->b_hid[i] || (d->ldw_hid[i] & 3) || !aligned16(d->W_hid[i]) || !aligned16(d->b_hid[i]))) {
+    if (used && (!d->W_hid[i] || !d->b_hid[i] || (d->ldw_hid[i] & 3) || d->ldw_hid[i] < hp || !aligned16(d->W_hid[i]) ||
+                 !aligned16(d->b_hid[i]))) {
       set_error("usf_coupling_additive_f32: bad hidden layer %d", i);
       return -2;
     }
@@ -324,12 +370,16 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   a.ctx = d->context; a.W_ctx = d->W_ctx; a.b_ctx = d->b_ctx;
   if (a.ctx && (!a.W_ctx || !a.b_ctx || !aligned16(a.b_ctx) || !aligned16(a.W_ctx))) { set_error("usf_coupling_additive_f32: context needs W_ctx and b_ctx"); return -1; }
   a.sign = d->sign; a.slope = d->slope; a.act = d->act;
-  const dim3 grid((unsigned)((d->M + 127) / 128)), block(256);
+  const dim3 grid((unsigned)((d->M + CPL_ROWS - 1) / CPL_ROWS)), block(256);
+#define USF_CPL(NHV, TV) hipLaunchKernelGGL((coupling_kernel<NHV, TV>), grid, block, 0, stream, a)
+#define USF_CPL_T(NHV) do { if (hmax <= 64) USF_CPL(NHV, 4); else if (hmax <= 128) USF_CPL(NHV, 8); else USF_CPL(NHV, 16); } while (0)
   switch (d->n_hidden) {
-    case 1: hipLaunchKernelGGL((coupling_kernel<1>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((coupling_kernel<2>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((coupling_kernel<3>), grid, block, 0, stream, a); break;
+    case 1: USF_CPL_T(1); break;
+    case 2: USF_CPL_T(2); break;
+    default: USF_CPL_T(3); break;
   }
+#undef USF_CPL_T
+#undef USF_CPL
   return check_launch("usf_coupling_additive_f32");
 }
 

@@ -517,9 +517,39 @@ class FlowEngine:
     def _fused_ok(self, cp) -> bool:
         lib = _ext.load()
         wmax = lib.usf_coupling_max_width()
-        return wmax > 0 and len(cp["hidden"]) <= _ext.USF_MAX_HIDDEN and max(cp["hidden"]) <= wmax
+        return wmax > 0 and len(cp["hidden"]) <= 3 and max(cp["hidden"]) <= wmax
+
+    def _fused_pack(self, cp) -> dict:
+        """weights re-laid out for the fused kernel's padding contract (include/usflows_hip.h)"""
+        if "fused" in cp:
+            return cp["fused"]
+        lib = _ext.load()
+        Hp = lib.usf_coupling_padded_width(max(cp["hidden"]))
+        Kp = _round_up(cp["pass_n"], 32)
+        Np = _round_up(cp["tr_n"], 32)
+
+        def pad2(W, rows, cols):
+            out = torch.zeros(rows, cols, dtype=torch.float32, device=W.device)
+            out[: W.shape[0], : W.shape[1]] = W
+            return out
+
+        def pad1(v, n):
+            out = torch.zeros(n, dtype=torch.float32, device=v.device)
+            out[: v.shape[0]] = v
+            return out
+
+        W0, b0 = cp["layers"][0]
+        f = dict(Hp=Hp, W_in=pad2(W0, Hp, Kp), b_in=pad1(b0, Hp),
+                 hid=[(pad2(W, Hp, Hp), pad1(b, Hp)) for W, b in cp["layers"][1:]],
+                 W_out=pad2(cp["W_out"], Np, Hp), b_out=pad1(cp["b_out"], Np))
+        if cp["has_ctx"]:
+            f["W_ctx"] = pad1(cp["W_ctx1"], Hp)
+            f["b_ctx"] = pad1(cp["b_ctx"], Hp)
+        cp["fused"] = f
+        return f
 
     def _coupling_op(self, cp, zptr, B, sign, ws_ctx) -> _ext.Op:
+        f = self._fused_pack(cp)
         op = _ext.Op()
         op.kind = _ext.OP_COUPLING
         d = op.u.coupling
@@ -528,14 +558,13 @@ class FlowEngine:
         d.n_hidden = len(cp["hidden"])
         for j, hh in enumerate(cp["hidden"]):
             d.hidden[j] = hh
-        W, b = cp["layers"][0]
-        d.W_in, d.ldw_in, d.b_in = W.data_ptr(), W.shape[1], b.data_ptr()
-        for j, (W, b) in enumerate(cp["layers"][1:]):
+        d.W_in, d.ldw_in, d.b_in = f["W_in"].data_ptr(), f["W_in"].shape[1], f["b_in"].data_ptr()
+        for j, (W, b) in enumerate(f["hid"]):
             d.W_hid[j], d.b_hid[j], d.ldw_hid[j] = W.data_ptr(), b.data_ptr(), W.shape[1]
-        d.W_out, d.ldw_out, d.b_out = cp["W_out"].data_ptr(), cp["W_out"].shape[1], cp["b_out"].data_ptr()
+        d.W_out, d.ldw_out, d.b_out = f["W_out"].data_ptr(), f["W_out"].shape[1], f["b_out"].data_ptr()
         if ws_ctx is not None:
             d.context = ws_ctx["ctx"].data_ptr()
-            d.W_ctx, d.b_ctx = cp["W_ctx1"].data_ptr(), cp["b_ctx"].data_ptr()
+            d.W_ctx, d.b_ctx = f["W_ctx"].data_ptr(), f["b_ctx"].data_ptr()
         d.sign, d.slope, d.act = sign, cp["slope"], cp["act"]
         return op
 
