@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="run couplings as 3 linear ops instead of the fused kernel")
     ap.add_argument("--cpu-rows", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,8 +126,18 @@ def main():
             name = "coupling_kernel (fused additive coupling)"
         ach = flops / (avg_ms * 1e-3) / 1e12
         share = tot[dom] / sum(tot.values())
+        # HBM bytes per launch of that kernel: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 runs of this
+        # same command) committed under profiles/; null when the profile does not cover this kernel/shape
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            key = "linear_kernel<2,5,4,16,false,0>" if dom[0] == "linear" else "coupling_kernel<2,16>"
+            if B == 65536 and D == 784 and list(args.hidden) == [256, 256]:
+                traffic = prof["kernels"][key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": name,
+                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": name,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(classes[dom]),
                     "share_of_gpu_time": round(share, 3),
                     "algorithmic_flops_per_launch": flops,
@@ -143,6 +154,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         rows = min(args.cpu_rows, B)
         xc = x[:rows].cpu()
+        # 16 threads is the fastest setting for this workload on the GPU box's 2 x EPYC 9575F (probed with
+        # tools/cpu_threads_probe.py: 8 -> 1860, 16 -> 2403, 32 -> 1362, 64 -> 651, 128 (torch default) -> 203 samples/s)
+        torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
         with torch.no_grad():
             orc.flow_log_prob(sd, spec, xc[: min(64, rows)])        # warm-up (thread pool, allocator)
             n_it, t_cpu0 = 0, time.perf_counter()

@@ -1,0 +1,59 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/usflows_hip.h declares
+(no compute calls here: there is no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "usflows_hip.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(usf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared_functions()
+    for must in ("usf_linear_f32", "usf_coupling_additive_f32", "usf_base_logprob_f32", "usf_base_sample_f32",
+                 "usf_scale_f32", "usf_gather_cols_f32", "usf_run_ops", "usf_abi_version", "usf_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from usflows_amd import _ext
+    if not _ext.lib_exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_ext.LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    # and the python binding knows every one of them
+    assert set(_declared_functions()) == set(_ext.SYMBOLS)
+
+
+def test_binding_struct_layout_matches_c():
+    from usflows_amd import _ext
+    lib = _ext.load()          # load() itself cross-checks sizeof() of every descriptor
+    assert lib.usf_abi_version() == _ext.USF_ABI_VERSION
+    assert lib.usf_sizeof_desc(_ext.OP_LINEAR) == ctypes.sizeof(_ext.LinearDesc)
+    assert lib.usf_sizeof_desc(_ext.OP_COUPLING) == ctypes.sizeof(_ext.CouplingDesc)
+    assert lib.usf_coupling_max_width() == 256
+    assert [lib.usf_coupling_padded_width(h) for h in (1, 64, 65, 128, 200, 256, 257)] == [64, 64, 128, 128, 256, 256, -1]
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """descriptor validation runs before any launch: bad arguments -> negative rc + message"""
+    from usflows_amd import _ext
+    lib = _ext.load()
+    d = _ext.LinearDesc()
+    d.M, d.N, d.K = 4, 4, 6            # K % 4 != 0
+    d.A = d.W = d.C = 16
+    d.lda = d.ldw = 8
+    d.ldc = 4
+    rc = lib.usf_linear_f32(ctypes.byref(d), None)
+    assert rc < 0 and b"multiples of 4" in lib.usf_last_error()
+    assert lib.usf_run_ops(None, 3, None) < 0

@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference API on CPU: constructor surface, state-dict layout, composite
+(autograd) path vs the golden vectors, feasibility helpers, fit()."""
+import math
+
+import pytest
+import torch
+
+from golden_util import case_names, load_case
+from model_util import build_flow
+from oracle import usflows_oracle as orc
+from usflows_amd.flows import Flow, USFlow
+from usflows_amd.networks import ConditionalDenseNN, DenseNN
+from usflows_amd import transforms as T
+from usflows_amd import distributions as D
+
+SMALL = case_names(small_only=True)
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs() / b.double().abs().clamp_min(1e-30)).max().item()
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_composite_path_matches_golden(name):
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd)
+    ctx = a.get("context")
+    with torch.no_grad():
+        lp = flow.log_prob(a["x"], context=ctx) if ctx is not None else flow.log_prob(a["x"])
+    assert _rel(lp, a["log_prob64"]) < 2e-5
+    assert _rel(lp, a["log_prob32"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_state_dict_keys_match_reference_layout(name):
+    """strict key-for-key equality with the state dict the REFERENCE model produced (fixture)"""
+    spec, sd, _ = load_case(name)
+    flow = build_flow(spec)
+    ours = set(flow.state_dict().keys())
+    theirs = set(sd.keys())
+    assert ours == theirs, (sorted(ours - theirs)[:5], sorted(theirs - ours)[:5])
+    for k, v in flow.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+
+
+def test_layer_order_matches_reference():
+    f = USFlow(torch.distributions.Laplace(torch.zeros(6), torch.ones(6)), [6], 2, ConditionalDenseNN,
+               dict(input_dim=6, context_dim=1, hidden_dims=[8], out_dim=6), affine_conjugation=True, householder=1)
+    names = [type(l).__name__ for l in f.layers]
+    assert names == ["BlockAffineTransform", "MaskedCoupling", "InverseTransform"] * 2 + ["BlockAffineTransform", "ScaleTransform"]
+    assert f.layers[2].transform is f.layers[0]                 # InverseTransform shares the block
+    assert f.layers[1].mask.flatten().tolist() == [0, 1, 0, 1, 0, 1]
+    assert f.layers[4].mask.flatten().tolist() == [1, 0, 1, 0, 1, 0]
+    f2 = USFlow(torch.distributions.Laplace(torch.zeros(6), torch.ones(6)), [6], 2, ConditionalDenseNN,
+                dict(input_dim=6, context_dim=1, hidden_dims=[8], out_dim=6), householder=0)
+    assert [type(l).__name__ for l in f2.layers] == ["BlockAffineTransform", "MaskedCoupling"] * 2 + \
+        ["BlockAffineTransform", "ScaleTransform"]
+
+
+def test_constructor_errors():
+    base = torch.distributions.Laplace(torch.zeros(4), torch.ones(4))
+    args = dict(input_dim=4, context_dim=1, hidden_dims=[8], out_dim=4)
+    with pytest.raises(ValueError):
+        USFlow(base, [4], 1, ConditionalDenseNN, args, masktype="diagonal")
+    with pytest.raises(ValueError):
+        USFlow(base, [4], 1, ConditionalDenseNN, args, lu_transform=-1)
+    with pytest.raises(ValueError):
+        USFlow(base, [4], 1, ConditionalDenseNN, args, householder=-1)
+    with pytest.raises(ValueError):
+        T.BlockAffineTransform([5], T.LUTransform(4))
+    with pytest.raises(ValueError):
+        T.SequentialAffineTransform([T.LUTransform(4), T.LUTransform(5)])
+    with pytest.raises(NotImplementedError):
+        T.BlockAffineTransform([4, 2, 2], T.LUTransform(4))
+
+
+def test_reference_known_answer_tests_on_product_layers():
+    """tests/veriflow/transforms_test.py:5-19 and :35-51 restated on usflows_amd's layers"""
+    dim = 10
+    st = T.ScaleTransform([dim])
+    with torch.no_grad():
+        st.scale.copy_(torch.ones(dim) * 2)
+    x = torch.ones(dim)
+    y = st(x)
+    assert (y == 2 * x).all() and (st.backward(y) == x).all()
+    assert st.log_abs_det_jacobian(x, y) == dim * torch.log(torch.tensor(2.0))
+    lu = T.LUTransform(dim)
+    with torch.no_grad():
+        lu.L_raw.copy_(torch.tril(torch.ones(dim, dim)))
+        lu.U_raw.copy_(torch.eye(dim))
+        lu.bias_vector.copy_(torch.zeros(dim))
+    y = lu(x)
+    assert (y == torch.arange(dim) + 1.0).all()
+    assert (lu.backward(y) == x).all()
+    assert lu.log_abs_det_jacobian(x, y) == 0
+
+
+def test_feasibility_and_jitter():
+    spec, sd, _ = load_case("synth_d7_k3_hh0_laplace")
+    flow = build_flow(spec, sd)
+    assert flow.is_feasible()
+    with torch.no_grad():
+        flow.layers[0].block_transform.transforms[0].U_raw[2, 2] = 0.0
+    assert not flow.is_feasible()
+    flow.add_jitter(1e-3)
+    assert flow.is_feasible()
+
+
+def test_fit_runs_and_reduces_loss_on_cpu():
+    torch.manual_seed(0)
+    D_ = 4
+    flow = USFlow(torch.distributions.Laplace(torch.zeros(D_), torch.ones(D_)), [D_], 2, ConditionalDenseNN,
+                  dict(input_dim=D_, context_dim=1, hidden_dims=[16], out_dim=D_, nonlinearity=torch.nn.LeakyReLU(0.01)),
+                  householder=0)
+    with torch.no_grad():        # tame the reference's default init
+        flow.layers[-1].scale.copy_(torch.ones(D_))
+    data = torch.randn(512, D_) * 0.5 + 1.0
+    ds = torch.utils.data.TensorDataset(data)
+    losses = flow.fit(ds, optim=torch.optim.Adam, optim_params=dict(lr=1e-2), batch_size=64, epochs=6,
+                      device=torch.device("cpu"))
+    assert len(losses) == 6 and losses[-1] < losses[0]
+
+
+def test_soft_training_fit_step():
+    torch.manual_seed(0)
+    D_ = 4
+    flow = USFlow(torch.distributions.Laplace(torch.zeros(D_), torch.ones(D_)), [D_], 1, ConditionalDenseNN,
+                  dict(input_dim=D_, context_dim=1, hidden_dims=[8], out_dim=D_), householder=0, soft_training=True,
+                  training_noise_prior=torch.distributions.Uniform(1e-20, 0.01))
+    with torch.no_grad():
+        flow.layers[-1].scale.copy_(torch.ones(D_))
+    ds = torch.utils.data.TensorDataset(torch.randn(64, D_))
+    losses = flow.fit(ds, optim=torch.optim.SGD, optim_params=dict(lr=1e-4), batch_size=32, epochs=1,
+                      device=torch.device("cpu"))
+    assert math.isfinite(losses[0])
+    assert flow.log_prob(torch.randn(5, D_)).shape == (5,)      # implicit zero context
+
+
+def test_forward_export_modes_and_sample_shape():
+    spec, sd, a = load_case("synth_d7_k3_hh0_laplace")
+    flow = build_flow(spec, sd)
+    with torch.no_grad():
+        flow.export = "log_prob"
+        assert torch.equal(flow(a["x"]), flow.log_prob(a["x"]))
+        flow.export = "backward"
+        assert torch.equal(flow(a["x"]), flow.backward(a["x"]))
+        flow.export = "forward"
+        assert torch.equal(flow(a["x"]), flow._forward(a["x"]))
+        flow.export = "nope"
+        with pytest.raises(ValueError):
+            flow(a["x"])
+        assert flow.sample([5]).shape == (5, 7) and flow.sample().shape == (1, 7)
+
+
+def test_densenn_matches_conditional_densenn_without_context():
+    torch.manual_seed(1)
+    a = ConditionalDenseNN(6, 1, [8, 8], 6, torch.nn.LeakyReLU(0.01))
+    b = DenseNN(6, [8, 8], [6], torch.nn.LeakyReLU(0.01))
+    with torch.no_grad():
+        b.layers[0].load_state_dict(a.layers[0].state_dict())
+        b.layers[1].load_state_dict(a.layers[2].state_dict())
+        b.layers[2].load_state_dict(a.layers[3].state_dict())
+    x = torch.randn(9, 6)
+    assert torch.equal(a(x), b(x))
+
+
+def test_radial_distribution_matches_oracle():
+    spec, sd, a = load_case("synth_d16_k4_hh0_conj_radial1")
+    flow = build_flow(spec, sd)
+    z = a["backward32"]
+    assert _rel(flow.base_distribution.log_prob(z), orc.base_log_prob(spec, z)) < 1e-6
+    s = flow.base_distribution.sample([100])
+    assert s.shape == (100, 16) and torch.isfinite(s).all()
+
+
+def test_simplify_is_equivalent():
+    spec, sd, a = load_case("synth_d7_k3_hh1_conj_normal")
+    flow = build_flow(spec, sd)
+    with torch.no_grad():
+        simple = flow.simplify()
+        assert torch.allclose(simple.log_prob(a["x"]), flow.log_prob(a["x"]), rtol=1e-4, atol=1e-4)

@@ -1,0 +1,74 @@
+"""Multi-process data-parallel path on CPU (gloo, world_size 2): batch sharding + the single scalar
+all-reduce reproduce the single-process mean log_prob; sharded sampling geometry."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from golden_util import load_case
+        from model_util import build_flow
+        from usflows_amd.parallel import mean_log_prob, shard_rows
+        spec, sd, a = load_case("synth_d16_k4_hh2_conj_laplace")
+        flow = build_flow(spec, sd)
+        x = a["x"]                                   # 48 rows -> uneven-friendly split below
+        lo, hi = shard_rows(x.shape[0] - 1, rank, world)      # 47 rows: 24 + 23
+        mean, lp = mean_log_prob(flow, x[lo:hi])
+        q.put((rank, float(mean), lp.double().sum().item(), hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mean_log_prob_allreduce_world2():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import load_case
+    _, _, a = load_case("synth_d16_k4_hh2_conj_laplace")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = sum(r[3] for r in res)
+    assert n == 47 and [r[3] for r in res] == [24, 23]
+    expect = a["log_prob64"][:47].mean().item()
+    for _, mean, _, _ in res:                        # every rank holds the global mean
+        assert abs(mean - expect) < 1e-5 * abs(expect)
+    assert abs(sum(r[2] for r in res) / n - expect) < 1e-5 * abs(expect)
+
+
+def test_shard_rows_partition():
+    from usflows_amd.parallel import shard_rows
+    for n in (0, 1, 7, 8, 65536, 1000003):
+        for w in (1, 2, 3, 8):
+            parts = [shard_rows(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1

@@ -32,6 +32,16 @@ class _NoCache:
         pass
 
 
+class TransformedDistribution(tdist.TransformedDistribution):
+    """torch's TransformedDistribution plus the ``clear_cache()`` that ``Flow.fit`` calls after every
+    optimiser step (flows.py:207; a pyro extension of the torch class)."""
+
+    def clear_cache(self):
+        for t in self.transforms:
+            if getattr(t, "_cache_size", 0) == 1:
+                t._cached_x_y = None, None
+
+
 class Flow(torch.nn.Module):
     """Base flow: a list of bijective layers over a base distribution (flows.py:22-378)."""
 
@@ -58,7 +68,7 @@ class Flow(torch.nn.Module):
         if len(batch_shape) > 0:
             self.base_distribution = Independent(self.base_distribution, len(batch_shape))
         try:
-            self.transform = tdist.TransformedDistribution(self.base_distribution, layers)
+            self.transform = TransformedDistribution(self.base_distribution, layers)
         except Exception:
             self.transform = _NoCache()
 
