@@ -13,7 +13,7 @@ from typing import Optional
 import torch  # noqa: F401  -- must be imported first: the .so binds to torch's HIP runtime instance
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libusflows_hip.so")
+LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
 USF_ABI_VERSION = 1
 USF_MAX_HIDDEN = 4

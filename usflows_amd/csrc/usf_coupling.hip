@@ -13,8 +13,8 @@
 //    the register index.  On gfx950 the 16x16 f32 accumulator layout (row = 4*(lane>>4) + r) is
 //    exactly the k-permutation this library feeds its f32 MFMAs with (lane group g owns
 //    k = 16q+4g..+3), so an accumulator register IS the next layer's B operand: no LDS round trip,
-//    no shuffles, no conversion.  The last product flips orientation (X as the A operand) so that
-//    its output has the feature on the lane -> coalesced residual read-modify-write.
+//    no shuffles, no conversion.  The output product keeps that orientation: a lane ends up with 4
+//    consecutive output features of its row -> one 16-byte residual load and one 16-byte store.
 //  * Only the weights travel through LDS: a unified stream of 32 KB stages (a [256 x 32] k-slab of
 //    W_in / W_h, or a [32 x 256] n-tile of W_out), register-staged and double-buffered, the loads
 //    of stage g+1 pinned in front of the MFMA block of stage g.  LDS image is k-chunk-major
@@ -31,7 +31,7 @@ constexpr int CPL_HMAX = 256;              // widest hidden layer the kernel is 
 
 struct CplArgs {
   const float* z; float* out; int64_t ldz;
-  int M, off_pass, n_pass, off_trans, n_trans;
+  int M, off_pass, n_pass, off_trans, n_trans, n_trans4;
   const float* W_in; int64_t ldw_in; const float* b_in;
   const float* W_hid[2]; const float* b_hid[2]; int64_t ldw_hid[2];
   const float* W_out; int64_t ldw_out; const float* b_out;
@@ -259,18 +259,16 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
     for (int nt = 0; nt < nS3; ++nt, ++g) {
       const int buf = g & 1;
       issue_n(p.W_out, p.ldw_out, min(nt + 1, nS3 - 1) * 32, st);
+      // output tile u (16 features) of this stage: lane (j, g) ends up with features 4g..4g+3 of row j
+      const int orow = min(wrow0 + lj, p.M - 1);
       int col[2];
-      float res[2][4], bo[2];
+      f32x4 res[2], bo[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        col[u] = nt * 32 + u * 16 + lj;
-        const int colc = min(col[u], p.n_trans - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = min(wrow0 + 4 * lg + r, p.M - 1);
-          res[u][r] = p.z[(int64_t)row * p.ldz + p.off_trans + colc];
-        }
-        bo[u] = p.b_out[col[u]];                            // b_out is padded to 32 * nS3
+        col[u] = nt * 32 + u * 16 + 4 * lg;
+        // rows of z are padded to 4 floats and n_trans segments start 16-B aligned: a float4 never straddles the buffer
+        res[u] = *reinterpret_cast<const f32x4*>(p.z + (int64_t)orow * p.ldz + p.off_trans + min(col[u], p.n_trans4 - 4));
+        bo[u] = *reinterpret_cast<const f32x4*>(p.b_out + col[u]);     // b_out is padded to 32 * nS3
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x4 acc0 = zero4, acc1 = zero4;
@@ -285,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
       for (int kt = 0; kt < T; ++kt) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(X[kt][t], b0[kt][t], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(X[kt][t], b1[kt][t], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[kt][t], X[kt][t], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[kt][t], X[kt][t], acc1, 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -300,12 +298,19 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
       store_n(buf ^ 1, st);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
+        const f32x4 a = (u == 0) ? acc0 : acc1;
+        f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wrow0 + 4 * lg + r;
-          const float a = (u == 0) ? acc0[r] : acc1[r];
-          const float v = res[u][r] + p.sign * (a + bo[u]);
-          if (row < p.M && col[u] < p.n_trans) p.out[(int64_t)row * p.ldz + p.off_trans + col[u]] = v;
+        for (int r = 0; r < 4; ++r) v[r] = res[u][r] + p.sign * (a[r] + bo[u][r]);
+        float* dst = p.out + (int64_t)(wrow0 + lj) * p.ldz + p.off_trans + col[u];
+        if (wrow0 + lj < p.M) {
+          if (col[u] + 3 < p.n_trans) {
+            *reinterpret_cast<f32x4*>(dst) = v;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (col[u] + r < p.n_trans) dst[r] = v[r];
+          }
         }
       }
       __syncthreads();
@@ -330,7 +335,7 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (d->M == 0) return 0;
   if (!d->z || !d->out || !d->W_in || !d->b_in || !d->W_out || !d->b_out) { set_error("usf_coupling_additive_f32: null pointer"); return -1; }
   if (d->out != d->z || d->ldo != d->ldz) { set_error("usf_coupling_additive_f32: this version works in place (out == z)"); return -2; }
-  if ((d->n_pass & 3) || (d->off_pass & 3) || (d->ldz & 3) || (d->ldw_in & 3) || (d->ldw_out & 3) || !aligned16(d->z) ||
+  if ((d->n_pass & 3) || (d->off_pass & 3) || (d->off_trans & 3) || (d->ldz & 3) || d->off_trans + ((d->n_trans + 3) / 4) * 4 > d->ldz || (d->ldw_in & 3) || (d->ldw_out & 3) || !aligned16(d->z) ||
       !aligned16(d->W_in) || !aligned16(d->W_out) || !aligned16(d->b_in)) {
     set_error("usf_coupling_additive_f32: n_pass/off_pass/ldz/ldw must be multiples of 4 and pointers 16-byte aligned");
     return -2;
@@ -338,7 +343,7 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_coupling_additive_f32: bad act"); return -2; }
   CplArgs a;
   a.z = d->z; a.out = d->out; a.ldz = d->ldz;
-  a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans;
+  a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans; a.n_trans4 = (int)((d->n_trans + 3) / 4 * 4);
   int hmax = 0;
   for (int i = 0; i < d->n_hidden; ++i) {
     if (d->hidden[i] < 1 || d->hidden[i] > CPL_HMAX) {

@@ -21,7 +21,7 @@ struct LinArgs {
   const float* residual; const float* addend; const float* post_mul; float* C;
   int64_t lda, ldw, ldr, ldadd, ldc;
   int M, N, K;
-  int nbm, nbn;
+  int nbm, nbn, vec_ok, bias_vec;
   float res_sign, slope;
   int act;
 };
@@ -124,13 +124,33 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
     }
   };
 
+  // MFMA-A = weights (i = output feature), MFMA-B = activations (j = batch row): the accumulator holds
+  // C^T -- batch row = lane&31, output feature = (r&3) + 8*(r>>2) + 4*(lane>>5) -- i.e. every group of 4
+  // registers is 4 consecutive output features of one row.  Accumulators start at the bias (all bias
+  // loads of the tile in flight together, landing under the first slab).
+  const bool has_bias = p.bias != nullptr, has_pm = p.post_mul != nullptr;
+  const float* biasp = has_bias ? p.bias : p.W;           // any valid address
+  const float* pmp = has_pm ? p.post_mul : p.W;
   f32x16 acc[TM][TN];
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
+      f32x4 bv = zero4;
+      if (has_bias) {
+        if (p.bias_vec) {                                // uniform: bias 16-B aligned and N % 4 == 0
+          bv = *reinterpret_cast<const f32x4*>(biasp + min(col, p.N - 4));
+        } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+          for (int j = 0; j < 4; ++j) bv[j] = biasp[min(col + j, p.N - 1)];
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tm][tn][4 * g4 + j] = bv[j];
+    }
 
   f32x4 a_cur[TM][QS], a_nxt[TM][QS];
   f32x4 dvr[NPRO], svr[NPRO];
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[tm][q][t], b[tn][t], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[tn][t], a_cur[tm][q][t], acc[tm][tn], 0, 0, 0);
       }
     }
   };
@@ -184,44 +204,92 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
   // last slab: skip the all-zero 8-k steps of the K tail (uniform)
   compute((nslab - 1) & 1, (p.K - (nslab - 1) * BK + 7) / 8);
 
-  // ---- epilogue: C layout of 32x32 f32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) --
-  // Loads (bias / post_mul / residual / addend) are unconditional with clamped indices; only the
-  // stores are predicated.
+  // ---- epilogue -------------------------------------------------------------------------------
   int row0e = row0;                       // opaque copy: keeps the epilogue's address math from being
   asm volatile("" : "+v"(row0e));         // hoisted above the K loop (it would live across it and spill)
-  const bool has_bias = p.bias != nullptr, has_pm = p.post_mul != nullptr;
-  const float* biasp = has_bias ? p.bias : p.W;           // any valid address
-  const float* pmp = has_pm ? p.post_mul : p.W;
   const float* extra = (EPI == 1) ? p.residual : p.addend;
   const int64_t ldx = (EPI == 1) ? p.ldr : p.ldadd;
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-    const int col = n0 + tn * 32 + li;
-    const int colc = min(col, p.N - 1);
-    float bv = biasp[has_bias ? colc : 0];
-    float pm = pmp[has_pm ? colc : 0];
-    bv = has_bias ? bv : 0.f;
-    pm = has_pm ? pm : 1.f;
+  if (EPI == 0 && p.vec_ok) {
+    // no per-element loads: transpose each 32x32 tile through a per-wave LDS scratch (the weight
+    // staging buffers are dead by now) so that one store instruction writes 8 rows x 128 contiguous
+    // bytes = whole cache lines (the store issue rate bounds this phase)
+    constexpr int TLD = 36;               // odd number of 16-B slots per scratch row
+    static_assert(2 * BN_LDS * LDS_LD >= WM * 32 * TLD, "transpose scratch must fit the staging buffers");
+    float* tw = &lds[0][0] + wave * (32 * TLD);
+    const int rr = lane >> 3, cc = 4 * (lane & 7);
+    __syncthreads();                      // every wave is done reading the last weight slab
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      float ex[16];
-      if (EPI != 0) {
-        __builtin_amdgcn_sched_barrier(0);    // keep the 16 loads of ONE tile in flight, not of all tiles (spills)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(row0e + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.M - 1);
-          ex[r] = extra[(int64_t)row * ldx + colc];
+      for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = act_apply(acc[tm][tn][4 * g4 + j], p.act, p.slope);
+            if (has_pm) x = x * pmp[min(col + j, p.N - 1)];
+            v[j] = x;
+          }
+          *reinterpret_cast<f32x4*>(tw + li * TLD + 8 * g4 + 4 * lh) = v;       // [row = lane&31][col in tile]
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                    // same wave wrote and reads: no barrier needed
+          const int r = rr + 8 * i;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * TLD + cc);
+          const int row = row0e + tm * 32 + r;
+          const int col = n0 + tn * 32 + cc;
+          float* dst = p.C + (int64_t)row * p.ldc + col;
+          if (row < p.M) {
+            if (col + 3 < p.N) {
+              *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (col + j < p.N) dst[j] = v[j];
+            }
+          }
         }
       }
+    }
+    return;
+  }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0e + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float v = acc[tm][tn][r] + bv;
-        if (EPI == 2) v = v + ex[r];
-        v = act_apply(v, p.act, p.slope);
-        if (EPI == 1) v = ex[r] + p.res_sign * v;
-        v = v * pm;
-        if (row < p.M && col < p.N) p.C[(int64_t)row * p.ldc + col] = v;
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = row0e + tm * 32 + li;
+    const int rowc = min(row, p.M - 1);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
+        float pm[4], ex[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c2 = min(col + j, p.N - 1);
+          pm[j] = has_pm ? pmp[c2] : 1.f;
+          ex[j] = (EPI != 0) ? extra[(int64_t)rowc * ldx + c2] : 0.f;
+        }
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = acc[tm][tn][4 * g4 + j];
+          if (EPI == 2) x = x + ex[j];
+          x = act_apply(x, p.act, p.slope);
+          if (EPI == 1) x = ex[j] + p.res_sign * x;
+          v[j] = x * pm[j];
+        }
+        float* dst = p.C + (int64_t)row * p.ldc + col;
+        if (row < p.M) {
+          if (p.vec_ok && col + 3 < p.N) {
+            *reinterpret_cast<f32x4*>(dst) = v;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < p.N) dst[j] = v[j];
+          }
+        }
       }
     }
   }
@@ -277,6 +345,8 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   a.lda = d->lda; a.ldw = d->ldw; a.ldr = d->ldr; a.ldadd = d->ldadd; a.ldc = d->ldc;
   a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K;
   a.nbm = a.nbn = 0;
+  a.vec_ok = ((d->ldc & 3) == 0 && aligned16(d->C)) ? 1 : 0;   // 16-byte row stores possible
+  a.bias_vec = (d->bias && aligned16(d->bias) && (d->N & 3) == 0) ? 1 : 0;
   a.res_sign = d->res_sign; a.slope = d->slope; a.act = d->act;
 
   // tile choice: 256-row panels; 160- or 128-wide column blocks, whichever pads N less
