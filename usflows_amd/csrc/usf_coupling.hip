@@ -37,6 +37,7 @@ struct CplArgs {
   const float* W_out; int64_t ldw_out; const float* b_out;
   const float* ctx; const float* W_ctx; const float* b_ctx;
   float sign, slope; int act;
+  unsigned long long* dbg;              // tuning builds only (USF_STAMP)
 };
 
 // NH = number of hidden layers, T = hidden tiles of 16 kept in registers: every hidden layer is
@@ -110,9 +111,16 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
   const int nS1 = (p.n_pass + CPL_BK - 1) / CPL_BK;
   const int nS3 = (p.n_trans + 31) / 32;
 
+  // Accumulators start at the layer's bias (bias + sum_k): the bias loads are issued at kernel start and
+  // land under the first weight stages; loading them between the phases exposed a memory latency (and,
+  // at the register limit, spills) while both co-resident blocks sat idle -- 16 % of the kernel.
+  // X[ht][t] of lane (j, g) is hidden unit ht*16 + 4g + t of batch row j.
   f32x4 X1[T], X2[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) X1[t] = zero4;
+  for (int t = 0; t < T; ++t) {
+    X1[t] = *reinterpret_cast<const f32x4*>(p.b_in + t * 16 + 4 * lg);
+    if (NH >= 2) X2[t] = *reinterpret_cast<const f32x4*>(p.b_hid[0] + t * 16 + 4 * lg);
+  }
 
   f32x4 st[NST];
   f32x4 zc[2], zn[2];
@@ -165,6 +173,12 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
   finish_z(0, zc);
   __syncthreads();
 
+#ifdef USF_STAMP
+#define CSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define CSTAMP(v)
+#endif
+  CSTAMP(c0);
   // ================= phase 1: X1[h][row] += W_in[h][k] * z[row][k] ============================
   auto phase1_compute = [&](int buf, int s) {
     const float* wl = &lds[buf][4 * (lg * HP + lj)];
@@ -198,28 +212,27 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
     ++g;
   }
 
-  // bias (+ context branch) + activation on an accumulator array, in registers:
-  // X[ht][t] of lane (j, g) is hidden unit ht*16 + 4g + t of batch row j
-  auto bias_act = [&](f32x4 (&X)[T], const float* bias, bool with_ctx) {
+  // (context branch +) activation on an accumulator array, in registers
+  auto ctx_act = [&](f32x4 (&X)[T], bool with_ctx) {
     const float cv = with_ctx ? p.ctx[rowc] : 0.f;
 #pragma unroll
     for (int ht = 0; ht < T; ++ht) {
-      const int hi = ht * 16 + 4 * lg;
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + hi);
       f32x4 wc = zero4, bc = zero4;
       if (with_ctx) {
-        wc = *reinterpret_cast<const f32x4*>(p.W_ctx + hi);
-        bc = *reinterpret_cast<const f32x4*>(p.b_ctx + hi);
+        wc = *reinterpret_cast<const f32x4*>(p.W_ctx + ht * 16 + 4 * lg);
+        bc = *reinterpret_cast<const f32x4*>(p.b_ctx + ht * 16 + 4 * lg);
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float v = X[ht][t] + b[t];                          // layers[0](x)
+        float v = X[ht][t];                                 // layers[0](x): bias already inside
         if (with_ctx) v = v + (cv * wc[t] + bc[t]);         // + layers[1](context), networks.py:741-743
         X[ht][t] = act_apply(v, p.act, p.slope);
       }
     }
   };
-  bias_act(X1, p.b_in, p.ctx != nullptr);
+  CSTAMP(c1);
+  ctx_act(X1, p.ctx != nullptr);
+  CSTAMP(c2);
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1] * Xin[h1][row] ====================
   auto hidden_layer = [&](f32x4 (&Xin)[T], f32x4 (&Xout)[T], int l) {
@@ -240,19 +253,16 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
       __syncthreads();
       ++g;
     }
-    bias_act(Xout, p.b_hid[l], false);
+    ctx_act(Xout, false);
   };
-  if (NH >= 2) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) X2[t] = zero4;
-    hidden_layer(X1, X2, 0);
-  }
+  if (NH >= 2) hidden_layer(X1, X2, 0);
   if (NH >= 3) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) X1[t] = zero4;
+    for (int t = 0; t < T; ++t) X1[t] = *reinterpret_cast<const f32x4*>(p.b_hid[1] + t * 16 + 4 * lg);
     hidden_layer(X2, X1, 1);
   }
 
+  CSTAMP(c3);
   // ================= phase 3: T[row][n] = sum_h Xlast[h][row] * W_out[n][h]; residual ==========
   // two 16-wide n tiles per stage, interleaved (16x16x4 needs 2 independent accumulators)
   auto output_layer = [&](f32x4 (&X)[T]) {
@@ -317,7 +327,18 @@ __global__ __launch_bounds__(256, 2) void coupling_kernel(const CplArgs p) {
     }
   };
   if (NH == 2) output_layer(X2); else output_layer(X1);
+#ifdef USF_STAMP
+  CSTAMP(c4);
+  if (p.dbg && lane == 0) {
+    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 1024) * 4 + wave) * 8;
+    o[0] = c1 - c0; o[1] = c2 - c1; o[2] = c3 - c2; o[3] = c4 - c3; o[4] = c4 - c0; o[5] = 1;
+  }
+#endif
 }
+
+#ifdef USF_STAMP
+unsigned long long* g_cdbg = nullptr;
+#endif
 
 static int padded_width(int h) { return h <= 64 ? 64 : (h <= 128 ? 128 : 256); }
 
@@ -375,6 +396,10 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   a.ctx = d->context; a.W_ctx = d->W_ctx; a.b_ctx = d->b_ctx;
   if (a.ctx && (!a.W_ctx || !a.b_ctx || !aligned16(a.b_ctx) || !aligned16(a.W_ctx))) { set_error("usf_coupling_additive_f32: context needs W_ctx and b_ctx"); return -1; }
   a.sign = d->sign; a.slope = d->slope; a.act = d->act;
+  a.dbg = nullptr;
+#ifdef USF_STAMP
+  a.dbg = g_cdbg;
+#endif
   const dim3 grid((unsigned)((d->M + CPL_ROWS - 1) / CPL_ROWS)), block(256);
 #define USF_CPL(NHV, TV) hipLaunchKernelGGL((coupling_kernel<NHV, TV>), grid, block, 0, stream, a)
 #define USF_CPL_T(NHV) do { if (hmax <= 64) USF_CPL(NHV, 4); else if (hmax <= 128) USF_CPL(NHV, 8); else USF_CPL(NHV, 16); } while (0)
