@@ -37,6 +37,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run couplings as 3 linear ops instead of the fused kernel")
+    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=None,
+                    help="affine GEMM arithmetic: bf16x3 = 3-way split on the bf16 MFMA (default), f32 = exact-f32 MFMA")
+    ap.add_argument("--mode", choices=["log_prob", "sample"], default="log_prob",
+                    help="sample: time Flow.sample (Philox head + forward pass), BASELINE cfg5 per GPU")
     ap.add_argument("--cpu-rows", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -63,12 +67,18 @@ def main():
     flow = build_flow(spec, sd, device=str(dev))
     eng = flow.engine()
     eng.use_fused_coupling = not args.unfused
+    if args.gemm:
+        eng.gemm_mode = args.gemm
     B, D = args.batch, args.dim
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand(B, D, generator=g).to(dev)               # this rank's shard, resident in HBM
     acc = torch.zeros(2, dtype=torch.float64, device=dev)
 
     def step():
+        if args.mode == "sample":
+            with torch.no_grad():
+                xs = flow.sample([B], seed=1234, row_offset=rank * B)
+            return xs[0, 0].double(), xs[:, 0]
         return mean_log_prob(flow, x, acc=acc)
 
     t_prep0 = time.perf_counter()
@@ -151,7 +161,7 @@ def main():
 
     # ---- CPU baseline: the oracle (op-for-op torch-CPU restatement of the reference), bounded sample ----
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.mode == "log_prob":
         rows = min(args.cpu_rows, B)
         xc = x[:rows].cpu()
         # 16 threads is the fastest setting for this workload on the GPU box's 2 x EPYC 9575F (probed with
@@ -173,7 +183,10 @@ def main():
                          f"per-call parameter prep the reference performs), {cpu_s:.1f} s",
                "host_cpus": os.cpu_count(), "parity_max_rel_vs_cpu_fp32": rel}
 
-    out = {"metric": "log_prob samples/sec (whole node), 32-layer 784-dim flow, batch 65536",
+    if args.mode == "sample":
+        cpu = None
+    out = {"metric": ("log_prob samples/sec (whole node), 32-layer 784-dim flow, batch 65536" if args.mode == "log_prob"
+                      else "sample() samples/sec (whole node), 32-layer 784-dim flow"),
            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

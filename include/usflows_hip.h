@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 1
+#define USF_ABI_VERSION 2
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -73,6 +73,11 @@ typedef struct usf_linear_desc {
   float slope;                          /* LeakyReLU negative slope */
   int32_t act;                          /* USF_ACT_* */
   int32_t reserved;
+  /* Optional split-precision copy of W for the bf16x3 path (fp32-equivalent accuracy on the bf16 matrix
+   * cores): three bf16 planes W1+W2+W3 == W (round-to-nearest residual split), plane p at
+   * W_split + p*split_plane_stride, each [N, ldw_split] bf16 with ldw_split >= ceil32(K), zero-padded.
+   * Used when non-NULL and the op has no prologue / residual / addend and K % 8 == 0; W must still be given. */
+  const void* W_split; int64_t ldw_split; int64_t split_plane_stride;
 } usf_linear_desc;
 
 int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream);

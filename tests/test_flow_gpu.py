@@ -55,6 +55,22 @@ def test_golden_parity(name, fused):
         assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2e-5 * s
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("name", [n for n in case_names() if "d64" in n or "d784" in n or "d33" in n])
+def test_golden_parity_gemm_modes(name, mode):
+    """affine GEMMs on the bf16 matrix cores with the 3-way split (default) or on exact-f32 MFMA: same 1e-5 gate"""
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd, device=DEV)
+    flow.engine().gemm_mode = mode
+    with torch.no_grad():
+        lp = flow.log_prob(a["x"].to(DEV))
+        xf = flow._forward(a["zin"].to(DEV))
+    assert _rel(lp, a["log_prob64"]) < RTOL, name
+    assert _rel(lp, a["log_prob32"]) < RTOL, name
+    s = max(1.0, a["forward64"].abs().max().item())
+    assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2e-5 * s
+
+
 @pytest.mark.parametrize("B", [0, 1, 3, 64, 65, 257, 1000])
 def test_ragged_batch_sizes_vs_oracle(B):
     spec = orc.FlowSpec(20, 3, [24, 12], householder=1, affine_conjugation=True)
@@ -110,6 +126,33 @@ def test_udl_preservation_and_roundtrip_full_batch():
         lp64 = flow.log_prob(a["x"].to(DEV))
     assert _rel(lp64, a["log_prob64"]) < RTOL
     assert _rel(lp64, a["log_prob32"]) < RTOL
+
+
+def test_wide_conditioner_unfused_path_cfg4_like():
+    """BASELINE cfg4 shape class (D = 3072, hidden 1024 > the fused kernel's 256): the coupling runs as a
+    chain of usf_linear_f32 launches; parity vs the fp64 oracle."""
+    spec = orc.FlowSpec(3072, 2, [1024, 1024], householder=0)
+    sd = orc.synth_state_dict(spec, seed=4, alpha=0.05)
+    flow = build_flow(spec, sd, device=DEV)
+    x = torch.rand(96, 3072, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV))
+        z = flow.backward(x.to(DEV))
+        xr = flow._forward(z)
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x.double())
+    assert _rel(lp, ref) < RTOL
+    assert (xr.cpu() - x).abs().max().item() < 2e-4
+
+
+def test_three_hidden_layers_and_narrow_widths_fused():
+    spec = orc.FlowSpec(40, 3, [48, 20, 136], householder=1, affine_conjugation=True, negative_slope=0.0)
+    sd = orc.synth_state_dict(spec, seed=8)
+    flow = build_flow(spec, sd, device=DEV)
+    x = torch.rand(333, 40, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV))
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x.double())
+    assert _rel(lp, ref) < RTOL
 
 
 def test_linearity_of_affine_layer():

@@ -91,6 +91,29 @@ def test_linear_parity(M, N, K, flags):
     assert err < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(65, 65, 8), (200, 160, 40), (257, 784, 784), (1000, 392, 256), (4096, 800, 784)])
+def test_linear_bf16x3_split_precision(M, N, K):
+    """bf16x3 path: three-way residual split of both operands on the bf16 MFMA; must carry fp32-class error"""
+    ext, dev = _ext(), _dev()
+    from usflows_amd.engine import FlowEngine
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * 3
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    Wd = W.to(dev)
+    planes = FlowEngine._split_planes({"mats": {}}, Wd)
+    assert torch.equal(planes.float().sum(0)[:, :K], Wd) or (planes.float().sum(0)[:, :K] - Wd).abs().max() < 1e-9
+    C = torch.full((M, N), float("nan"), device=dev)
+    ext.linear(A.to(dev), Wd, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.to(dev), W_split=planes)
+    torch.cuda.synchronize()
+    ref64 = A.double() @ W.double().t() + bias.double()
+    ref32 = A @ W.t() + bias
+    scale = ref64.abs().max().item()
+    err = (C.cpu().double() - ref64).abs().max().item() / scale
+    err32 = (ref32.double() - ref64).abs().max().item() / scale
+    assert err < max(4 * err32, 1e-6), (err, err32)
+
+
 def test_linear_rejects_bad_args():
     ext, dev = _ext(), _dev()
     A = torch.zeros(4, 6, device=dev)

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 1
+USF_ABI_VERSION = 2
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -37,6 +37,7 @@ class LinearDesc(C.Structure):
         ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
         ("res_sign", C.c_float), ("slope", C.c_float),
         ("act", C.c_int32), ("reserved", C.c_int32),
+        ("W_split", _fp), ("ldw_split", C.c_int64), ("split_plane_stride", C.c_int64),
     ]
 
 
@@ -134,7 +135,7 @@ def current_stream(device=None) -> int:
 # ---- thin typed wrappers (each enqueues on torch's current stream) ---------------------------
 def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_sub=None, residual=None,
            ldr=0, post_mul=None, res_sign=1.0, act=ACT_NONE, slope=0.0, a_off=0, c_off=0, r_off=0,
-           addend=None, ldadd=0):
+           addend=None, ldadd=0, W_split=None):
     """usf_linear_f32 on raw tensors; *_off are element offsets into A/C/residual."""
     d = LinearDesc()
     d.A = A.data_ptr() + 4 * a_off
@@ -149,6 +150,10 @@ def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_
     d.post_mul = ptr(post_mul)
     d.addend = ptr(addend)
     d.ldadd = ldadd
+    if W_split is not None:            # [3, N, ceil32(K)] bf16 planes (see include/usflows_hip.h)
+        d.W_split = W_split.data_ptr()
+        d.ldw_split = W_split.shape[2]
+        d.split_plane_stride = W_split.shape[1] * W_split.shape[2]
     d.C = C_out.data_ptr() + 4 * c_off
     d.ldc = ldc
     d.M, d.N, d.K = M, N, K

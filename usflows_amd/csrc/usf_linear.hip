@@ -317,6 +317,9 @@ static int launch_linear(const LinArgs& a0, hipStream_t stream) {
   return check_launch("usf_linear_f32");
 }
 
+bool linear_bf16x3_eligible(const usf_linear_desc* d);
+int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream);
+
 int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_linear_f32: null descriptor"); return -1; }
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || d->M > 0x7fffffff || d->N > 0x7fffffff || d->K > 0x7fffffff) {
@@ -339,6 +342,7 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_linear_f32: bad act"); return -2; }
   if (d->residual && d->addend) { set_error("usf_linear_f32: residual and addend are mutually exclusive"); return -2; }
+  if (linear_bf16x3_eligible(d)) return linear_bf16x3_dispatch(d, stream);
   LinArgs a;
   a.A = d->A; a.W = d->W; a.bias = d->bias; a.pre_div = d->pre_div; a.pre_sub = d->pre_sub;
   a.residual = d->residual; a.addend = d->addend; a.post_mul = d->post_mul; a.C = d->C;

@@ -1,0 +1,247 @@
+// Split-precision variant of the fused dense layer:  C = A @ W^T + bias  with fp32-equivalent accuracy on
+// the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate).
+//
+// Every fp32 operand is written as the exact sum of three bf16 numbers (round-to-nearest residual split:
+// x = x1 + x2 + x3, 8 + 8 + 8 significant bits) and the product is expanded, keeping the six terms whose
+// weight is >= 2^-16 of the leading one:
+//      a.w ~= a1 w1 + (a1 w2 + a2 w1) + (a1 w3 + a2 w2 + a3 w1)            (dropped: 2^-24 relative)
+// Products of bf16 numbers are exact in fp32 and the MFMA accumulates in fp32, so the result carries the
+// same error class as an fp32 FMA chain (measured through the whole 65-layer cfg2 flow: 6.9e-7 vs 6.7e-7 max
+// relative error against the fp64 reference) at 16/6 = 2.7x the f32-MFMA throughput.
+//   * W is split once at parameter-pack time (three bf16 planes, K padded to 32 with zeros).
+//   * A stays fp32 in HBM (the coupling kernels read/write it); each wave splits its own operand
+//     fragments in registers (v_cvt_pk_bf16_f32 + subtracts) -- VALU work that runs beside the MFMAs.
+//   * Same tiling idioms as usf_linear.hip: waves tile M only, activation fragments global -> registers,
+//     weight planes through LDS (k-chunk-major image, register-staged, double-buffered), XCD-aware block
+//     map, bias in the accumulator init, LDS-transposed whole-cache-line stores.
+#include "usf_common.h"
+
+namespace usf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Lin3Args {
+  const float* A; const __bf16* Wp; const float* bias; const float* post_mul; float* C;
+  int64_t lda, ldc, ldwp, plane_stride;
+  int M, N, K, nbm, nbn;
+  float slope; int act;
+  int bias_vec;
+};
+
+__device__ __forceinline__ void split3(const f32x4 x0, const f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = (j < 4) ? x0[j & 3] : x1[j & 3];
+    const __bf16 h = (__bf16)x;
+    const float r = x - (float)h;              // exact
+    const __bf16 m = (__bf16)r;
+    const float r2 = r - (float)m;             // exact
+    p1[j] = h; p2[j] = m; p3[j] = (__bf16)r2;
+  }
+}
+
+template <int TN, int WM>
+__global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Args p) {
+  constexpr int NT = WM * 64;
+  constexpr int BM = WM * 32;
+  constexpr int BN = TN * 32;
+  constexpr int BK = 32;                       // two 16-k MFMA steps per slab
+  constexpr int RSTEP = NT / 4;                // rows between a thread's consecutive staged chunks (4 chunks/row)
+  constexpr int NWV = (BN + RSTEP - 1) / RSTEP;
+  constexpr int NR = NWV * RSTEP;              // LDS rows per plane (>= BN, multiple of 16)
+  static_assert(NR % 16 == 0 && RSTEP % 8 == 0, "staging shape");
+  // LDS image: slot(plane, chunk, row) = (plane * 4 + chunk) * NR + row, 16-byte slots (8 bf16 of one row)
+  __shared__ __attribute__((aligned(16))) float lds[2][3 * 4 * NR * 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
+  const int panel = (seq / p.nbn) * 8 + xcd;
+  const int bn = seq % p.nbn;
+  if (panel >= p.nbm) return;
+  const int row0 = panel * BM + wave * 32;
+  const int n0 = bn * BN;
+
+  const float* arow = p.A + (int64_t)min(row0 + li, p.M - 1) * p.lda;
+  // activation fragment of 16-k step s: 8 consecutive fp32 A[row][k0 + 16 s + 8 h .. +7]
+  auto issue_a = [&](int k0, f32x4 (&dst)[4]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        dst[2 * s + u] = *reinterpret_cast<const f32x4*>(arow + min(k0 + 16 * s + 8 * lh + 4 * u, p.K - 4));
+  };
+  auto finish_a = [&](int k0, f32x4 (&dst)[4]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        dst[2 * s + u] = (k0 + 16 * s + 8 * lh + 4 * u < p.K) ? dst[2 * s + u] : zero4;
+  };
+  // weight planes: thread -> (row, chunk): row = (tid & 7) + 8 * (tid >> 5) + RSTEP * i, chunk = (tid >> 3) & 3
+  const int wr0 = (tid & 7) + 8 * (tid >> 5);
+  const int wc = (tid >> 3) & 3;
+  auto issue_w = [&](int k0, f32x4 (&dst)[3][NWV]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < NWV; ++i) {
+        const int n = min(n0 + wr0 + RSTEP * i, p.N - 1);
+        dst[pl][i] = *reinterpret_cast<const f32x4*>(p.Wp + pl * p.plane_stride + (int64_t)n * p.ldwp + k0 + 8 * wc);
+      }
+  };
+  auto store_w = [&](int buf, const f32x4 (&src)[3][NWV]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int i = 0; i < NWV; ++i)
+        *reinterpret_cast<f32x4*>(&lds[buf][4 * ((pl * 4 + wc) * NR + wr0 + RSTEP * i)]) = src[pl][i];
+  };
+
+  // accumulators (C^T: batch row on the lane, 4 consecutive output features per register group) start at the bias
+  const bool has_bias = p.bias != nullptr, has_pm = p.post_mul != nullptr;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
+      f32x4 bv = zero4;
+      if (has_bias) {
+        if (p.bias_vec) {
+          bv = *reinterpret_cast<const f32x4*>(p.bias + min(col, p.N - 4));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[j] = p.bias[min(col + j, p.N - 1)];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[tn][4 * g4 + j] = bv[j];
+    }
+
+  f32x4 a_cur[4], a_nxt[4];
+  f32x4 wst[3][NWV];
+  const int nslab = (p.K + BK - 1) / BK;
+  issue_w(0, wst);
+  issue_a(0, a_cur);
+  finish_a(0, a_cur);
+  store_w(0, wst);
+  __syncthreads();
+
+  auto compute = [&](int buf) {
+    const float* wl = &lds[buf][4 * (lh * NR + li)];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a1, a2, a3;
+      split3(a_cur[2 * s], a_cur[2 * s + 1], a1, a2, a3);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4 + 2 * s) * NR + tn * 32));
+        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4 + 2 * s) * NR + tn * 32));
+        const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4 + 2 * s) * NR + tn * 32));
+        // smallest terms first
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, a1, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a2, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a3, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a1, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a2, acc[tn], 0, 0, 0);
+        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[tn], 0, 0, 0);
+      }
+    }
+  };
+
+  for (int s = 0; s + 1 < nslab; ++s) {
+    const int buf = s & 1;
+    const int k1 = (s + 1) * BK;
+    issue_w(k1, wst);
+    issue_a(k1, a_nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    store_w(buf ^ 1, wst);
+    finish_a(k1, a_nxt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    __syncthreads();
+  }
+  compute((nslab - 1) & 1);          // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
+
+  // ---- epilogue: transpose each 32x32 tile through a per-wave LDS scratch -> whole-cache-line stores ----
+  constexpr int TLD = 36;
+  static_assert(2 * 3 * 4 * NR * 4 >= WM * 32 * TLD, "transpose scratch must fit the staging buffers");
+  float* tw = &lds[0][0] + wave * (32 * TLD);
+  const int rr = lane >> 3, cc = 4 * (lane & 7);
+  __syncthreads();                   // every wave is done reading the last weight slab
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = act_apply(acc[tn][4 * g4 + j], p.act, p.slope);
+        if (has_pm) x = x * p.post_mul[min(col + j, p.N - 1)];
+        v[j] = x;
+      }
+      *reinterpret_cast<f32x4*>(tw + li * TLD + 8 * g4 + 4 * lh) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rr + 8 * i;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * TLD + cc);
+      const int row = row0 + r;
+      const int col = n0 + tn * 32 + cc;
+      float* dst = p.C + (int64_t)row * p.ldc + col;
+      if (row < p.M) {
+        if (col + 3 < p.N) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < p.N) dst[j] = v[j];
+        }
+      }
+    }
+  }
+}
+
+template <int TN, int WM>
+static int launch3(Lin3Args a, hipStream_t stream) {
+  constexpr int BM = WM * 32, BN = TN * 32;
+  a.nbm = (a.M + BM - 1) / BM;
+  a.nbn = (a.N + BN - 1) / BN;
+  const int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
+  if (grid > 0x7fffffffLL) { set_error("usf_linear_f32(bf16x3): grid too large"); return -3; }
+  hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  return check_launch("usf_linear_f32(bf16x3)");
+}
+
+// true when this descriptor can take the split-precision kernel
+bool linear_bf16x3_eligible(const usf_linear_desc* d) {
+  return d->W_split != nullptr && !d->pre_div && !d->pre_sub && !d->residual && !d->addend && (d->K & 7) == 0 &&
+         (d->ldc & 3) == 0 && aligned16(d->C) && aligned16(d->W_split) && (d->ldw_split & 7) == 0 &&
+         d->ldw_split >= ((d->K + 31) / 32) * 32 && d->M > 64 && d->N > 64;
+}
+
+int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
+  Lin3Args a;
+  a.A = d->A; a.Wp = reinterpret_cast<const __bf16*>(d->W_split); a.bias = d->bias; a.post_mul = d->post_mul; a.C = d->C;
+  a.lda = d->lda; a.ldc = d->ldc; a.ldwp = d->ldw_split; a.plane_stride = d->split_plane_stride;
+  a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K; a.nbm = a.nbn = 0;
+  a.slope = d->slope; a.act = d->act;
+  a.bias_vec = (d->bias && aligned16(d->bias) && (d->N & 3) == 0) ? 1 : 0;
+  const int pad160 = ((a.N + 159) / 160) * 160 - a.N;
+  const int pad128 = ((a.N + 127) / 128) * 128 - a.N;
+  if (pad160 < pad128) return launch3<5, 4>(a, stream);
+  return launch3<4, 4>(a, stream);
+}
+
+}  // namespace usf

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -139,6 +140,10 @@ class FlowEngine:
         self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
         self.op_timing = None          # set to a list to record (tag, start_event, end_event) per op (bench.py)
         self.use_fused_coupling = True
+        # "bf16x3" (default): the D x D affine GEMMs run on the bf16 matrix cores with a 3-way residual split of
+        # both operands (fp32-equivalent accuracy); "f32": exact-f32 MFMA everywhere
+        # (USFLOWS_AMD_GEMM=f32 or engine.gemm_mode = "f32")
+        self.gemm_mode = os.environ.get("USFLOWS_AMD_GEMM", "bf16x3")
         self._layout_from_masks()
 
     # ---- static structure ---------------------------------------------------------------------
@@ -318,6 +323,22 @@ class FlowEngine:
             pk["mats"][key] = self._perm_mat(pk["affine"][id(blk)][which], self._idx(out_layout), self._idx(in_layout))
         return pk["mats"][key]
 
+    @staticmethod
+    def _split_planes(pk, W: torch.Tensor) -> torch.Tensor:
+        """[3, N, ceil32(K)] bf16 planes with W1 + W2 + W3 == W (round-to-nearest residual split)"""
+        key = ("planes", W.data_ptr())
+        if key not in pk["mats"]:
+            N, K = W.shape
+            Kp = _round_up(K, 32)
+            hi = W.to(torch.bfloat16)
+            r = W - hi.float()
+            mid = r.to(torch.bfloat16)
+            lo = (r - mid.float()).to(torch.bfloat16)
+            planes = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=W.device)
+            planes[0, :, :K], planes[1, :, :K], planes[2, :, :K] = hi, mid, lo
+            pk["mats"][key] = planes
+        return pk["mats"][key]
+
     def _vec(self, pk, name, v64, layout: str, pad: float) -> torch.Tensor:
         key = (name, layout, pad)
         if key not in pk["vecs"]:
@@ -438,6 +459,11 @@ class FlowEngine:
                                                    out_layout, 1.0).data_ptr()
                         k += 1
                 assert W.shape[1] == Kdim
+                if self.gemm_mode == "bf16x3" and "pre_div" not in kw and Kdim % 8 == 0:
+                    planes = self._split_planes(pk, W)
+                    kw["W_split"] = planes.data_ptr()
+                    kw["ldw_split"] = planes.shape[2]
+                    kw["split_plane_stride"] = planes.shape[1] * planes.shape[2]
                 if out_layout == "seg":
                     dst = take()
                     Ndim, ldc, cptr = self.LD, self.LD, ws[dst].data_ptr()
@@ -571,7 +597,7 @@ class FlowEngine:
     # ---- execution ----------------------------------------------------------------------------
     def _plan(self, direction, B, device, has_ctx, final):
         pk = self.pack(device)   # may invalidate plans
-        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling)
+        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final)
