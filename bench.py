@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -50,7 +51,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
@@ -89,26 +91,26 @@ def main():
         step()
     if not args.no_kernel_timing:
         eng.op_timing = []
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         mean, lp = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timing, eng.op_timing = eng.op_timing, None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
 
     if rank != 0:
-        if world > 1:
+        if distributed:
             dist.destroy_process_group()
         return
 
@@ -122,7 +124,8 @@ def main():
         dom = max(tot, key=tot.get)
         avg_ms = tot[dom] / len(classes[dom])
         hs = [((h + 3) // 4) * 4 for h in args.hidden]
-        if dom[0] == "linear":
+        peak, peak_note = F32_MFMA_PEAK_TFLOPS, "dense f32 MFMA (v_mfma_f32_32x32x2_f32)"
+        if dom[0] in ("linear", "linear_bf16x3"):
             _, M, N, K = dom
             if N >= D and K >= D:                        # the D x D affine layer
                 flops = 2.0 * M * D * D
@@ -130,6 +133,11 @@ def main():
             else:
                 flops = 2.0 * M * min(N, D) * min(K, D)
                 name = f"linear_kernel (conditioner layer N={N} K={K})"
+            if dom[0] == "linear_bf16x3":
+                # fp32-equivalent GEMM on the bf16 matrix cores: 6 bf16 MFMA products per fp32 product, so the
+                # roof for ALGORITHMIC (fp32) flops is the dense bf16 peak / 6
+                name = name.replace("linear_kernel<2,5,4,16>", "linear_bf16x3_kernel<5,4>")
+                peak, peak_note = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
         else:
             _, M, ntr, npass = dom
             flops = 2.0 * M * (npass * hs[0] + sum(a * b for a, b in zip(hs[:-1], hs[1:])) + hs[-1] * ntr)
@@ -141,13 +149,14 @@ def main():
         traffic = None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            key = "linear_kernel<2,5,4,16,false,0>" if dom[0] == "linear" else "coupling_kernel<2,16>"
+            key = {"linear": "linear_kernel<2,5,4,16,false,0>", "linear_bf16x3": "linear_bf16x3_kernel<5,4>"}.get(
+                dom[0], "coupling_kernel<2,16>")
             if B == 65536 and D == 784 and list(args.hidden) == [256, 256]:
                 traffic = prof["kernels"][key]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": name,
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "kernel": name, "peak_is": peak_note,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(classes[dom]),
                     "share_of_gpu_time": round(share, 3),
                     "algorithmic_flops_per_launch": flops,
@@ -189,19 +198,21 @@ def main():
                       else "sample() samples/sec (whole node), 32-layer 784-dim flow"),
            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if eng.gemm_mode == "f32" else "f32 (D x D GEMMs as bf16x3 split on the bf16 MFMA, fp32-equivalent)",
+           "data": "synthetic",
            "config": {"workload": f"BASELINE cfg2: USFlow in_dims=[{D}], {args.blocks} additive coupling blocks, "
                                   f"ConditionalDenseNN{list(args.hidden)}+LeakyReLU(0.01), lu_transform=1, householder=0, "
                                   f"Laplace(0,1) base; log_prob of {B} rows per GPU resident in HBM; conditioned "
                                   f"synthetic parameters (seed 100, alpha 0.1)",
                       "rows_per_gpu": B, "global_rows": B * world, "parallelism": f"dp{world} (batch sharded, "
-                      "one RCCL all-reduce of 2 fp64 scalars per step)", "fused_coupling": not args.unfused},
+                      "one RCCL all-reduce of 2 fp64 scalars per step)", "fused_coupling": not args.unfused, "gemm_mode": eng.gemm_mode},
            "flow_algorithmic_tflops_per_gpu": round(flow_tflops, 2),
            "flow_frac_of_f32_mfma_peak": round(flow_tflops / F32_MFMA_PEAK_TFLOPS, 4),
            "param_prep_first_call_s": round(prep_s, 3), "mean_log_prob": float(mean.item()),
            "roofline": roofline, "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

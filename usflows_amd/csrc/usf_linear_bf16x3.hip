@@ -26,6 +26,7 @@ struct Lin3Args {
   int M, N, K, nbm, nbn;
   float slope; int act;
   int bias_vec;
+  unsigned long long* dbg;              // tuning builds only (USF_STAMP)
 };
 
 __device__ __forceinline__ void split3(const f32x4 x0, const f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -126,53 +127,94 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       for (int j = 0; j < 4; ++j) acc[tn][4 * g4 + j] = bv[j];
     }
 
-  f32x4 a_cur[4], a_nxt[4];
+#ifdef USF_STAMP
+#define BSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define BSTAMP(v)
+#endif
+  BSTAMP(b0);
+  // operand planes of the current slab (2 steps x 3 planes) are kept split; the NEXT slab's fp32 fragments
+  // are split while the second 16-k step of the current slab multiplies (VALU beside MFMA in one wave)
+  bf16x8 pc[2][3], pn[2][3];
+  f32x4 a_nxt[4];
   f32x4 wst[3][NWV];
   const int nslab = (p.K + BK - 1) / BK;
   issue_w(0, wst);
-  issue_a(0, a_cur);
-  finish_a(0, a_cur);
+  issue_a(0, a_nxt);
+  finish_a(0, a_nxt);
+  split3(a_nxt[0], a_nxt[1], pc[0][0], pc[0][1], pc[0][2]);
+  split3(a_nxt[2], a_nxt[3], pc[1][0], pc[1][1], pc[1][2]);
   store_w(0, wst);
   __syncthreads();
 
-  auto compute = [&](int buf) {
+  auto compute_step = [&](int buf, int s) {
     const float* wl = &lds[buf][4 * (lh * NR + li)];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a1, a2, a3;
-      split3(a_cur[2 * s], a_cur[2 * s + 1], a1, a2, a3);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4 + 2 * s) * NR + tn * 32));
-        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4 + 2 * s) * NR + tn * 32));
-        const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4 + 2 * s) * NR + tn * 32));
-        // smallest terms first
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, a1, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a2, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a3, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a1, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a2, acc[tn], 0, 0, 0);
-        acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[tn], 0, 0, 0);
-      }
+    for (int tn = 0; tn < TN; ++tn) {
+#if defined(USF_ABL3) && (USF_ABL3 & 1)      // tuning: no LDS fragment reads
+      const bf16x8 w1 = pc[s][0], w2 = pc[s][1], w3 = pc[s][2];
+#else
+      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4 + 2 * s) * NR + tn * 32));
+      const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4 + 2 * s) * NR + tn * 32));
+      const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4 + 2 * s) * NR + tn * 32));
+#endif
+      // smallest terms first
+      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, pc[s][0], acc[tn], 0, 0, 0);
+      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, pc[s][1], acc[tn], 0, 0, 0);
+      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][2], acc[tn], 0, 0, 0);
+      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, pc[s][0], acc[tn], 0, 0, 0);
+      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][1], acc[tn], 0, 0, 0);
+      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][0], acc[tn], 0, 0, 0);
     }
   };
+  // reads one tile ahead of the MFMAs that use them; VALU = the next slab's operand split, spread between tiles
+#define USF_PIN_STEP(VALU_PER_TILE)                                                   \
+  do {                                                                                \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                \
+    _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_) {                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                              \
+      if (tn_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);            \
+      if ((VALU_PER_TILE) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (VALU_PER_TILE), 0); \
+    }                                                                                 \
+  } while (0)
 
+  BSTAMP(b1);
   for (int s = 0; s + 1 < nslab; ++s) {
     const int buf = s & 1;
     const int k1 = (s + 1) * BK;
+#if !(defined(USF_ABL3) && (USF_ABL3 & 4))   // tuning: no global loads in the loop
     issue_w(k1, wst);
     issue_a(k1, a_nxt);
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    compute(buf);
+    compute_step(buf, 0);
+    USF_PIN_STEP(0);
+    __builtin_amdgcn_sched_barrier(0);
+#if defined(USF_ABL3) && (USF_ABL3 & 2)      // tuning: no operand split in the loop
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) pn[q][pl] = pc[q][pl];
+#else
+    finish_a(k1, a_nxt);
+    split3(a_nxt[0], a_nxt[1], pn[0][0], pn[0][1], pn[0][2]);
+    split3(a_nxt[2], a_nxt[3], pn[1][0], pn[1][1], pn[1][2]);
+#endif
+    compute_step(buf, 1);
+    USF_PIN_STEP(24);
     __builtin_amdgcn_sched_barrier(0);
     store_w(buf ^ 1, wst);
-    finish_a(k1, a_nxt);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) pc[q][pl] = pn[q][pl];
     __syncthreads();
   }
-  compute((nslab - 1) & 1);          // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
+  BSTAMP(b2);
+  compute_step((nslab - 1) & 1, 0);  // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
+  compute_step((nslab - 1) & 1, 1);
 
+  BSTAMP(b3);
   // ---- epilogue: transpose each 32x32 tile through a per-wave LDS scratch -> whole-cache-line stores ----
   constexpr int TLD = 36;
   static_assert(2 * 3 * 4 * NR * 4 >= WM * 32 * TLD, "transpose scratch must fit the staging buffers");
@@ -211,7 +253,18 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       }
     }
   }
+#ifdef USF_STAMP
+  BSTAMP(b4);
+  if (p.dbg && lane == 0) {
+    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 1024) * WM + wave) * 8;
+    o[0] = b1 - b0; o[1] = b2 - b1; o[2] = b3 - b2; o[3] = b4 - b3; o[4] = b4 - b0; o[5] = 1;
+  }
+#endif
 }
+
+#ifdef USF_STAMP
+unsigned long long* g_bdbg = nullptr;
+#endif
 
 template <int TN, int WM>
 static int launch3(Lin3Args a, hipStream_t stream) {
@@ -238,6 +291,10 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K; a.nbm = a.nbn = 0;
   a.slope = d->slope; a.act = d->act;
   a.bias_vec = (d->bias && aligned16(d->bias) && (d->N & 3) == 0) ? 1 : 0;
+  a.dbg = nullptr;
+#ifdef USF_STAMP
+  a.dbg = g_bdbg;
+#endif
   const int pad160 = ((a.N + 159) / 160) * 160 - a.N;
   const int pad128 = ((a.N + 127) / 128) * 128 - a.N;
   if (pad160 < pad128) return launch3<5, 4>(a, stream);

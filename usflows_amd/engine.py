@@ -628,7 +628,8 @@ class FlowEngine:
                 for j in range(pos, end):
                     op = arr[j]
                     if op.kind == _ext.OP_LINEAR:
-                        tag = ("linear", op.u.linear.M, op.u.linear.N, op.u.linear.K)
+                        kind = "linear_bf16x3" if (op.u.linear.W_split and not op.u.linear.pre_div) else "linear"
+                        tag = (kind, op.u.linear.M, op.u.linear.N, op.u.linear.K)
                     else:
                         tag = ("coupling", op.u.coupling.M, op.u.coupling.n_trans, op.u.coupling.n_pass)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
