@@ -124,6 +124,14 @@ typedef struct usf_coupling_desc {
   float slope;
   int32_t act;
   int32_t reserved;
+  /* Optional split-precision copies of the (padded) weights for the bf16x3 path: three bf16 planes each,
+   * plane q at base + q*plane (elements), rows/ld as in the padding contract above with ld >= the padded K.
+   * split_hid / split_out additionally have their K (hidden-unit) axis permuted inside every block of 32:
+   * position 8g+j holds unit 4g+j (j<4) or 16+4g+(j-4) (j>=4), the order in which the kernel's accumulators
+   * present the previous layer.  Used when all needed planes are given, hidden width in (128, 256], M >= 1024. */
+  const void* split_in;  int64_t split_in_ld,  split_in_plane;
+  const void* split_hid[USF_MAX_HIDDEN]; int64_t split_hid_ld, split_hid_plane;
+  const void* split_out; int64_t split_out_ld, split_out_plane;
 } usf_coupling_desc;
 
 int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream);

@@ -56,6 +56,9 @@ class CouplingDesc(C.Structure):
         ("post_sub", _fp),
         ("sign", C.c_float), ("slope", C.c_float),
         ("act", C.c_int32), ("reserved", C.c_int32),
+        ("split_in", _fp), ("split_in_ld", C.c_int64), ("split_in_plane", C.c_int64),
+        ("split_hid", _fp * USF_MAX_HIDDEN), ("split_hid_ld", C.c_int64), ("split_hid_plane", C.c_int64),
+        ("split_out", _fp), ("split_out_ld", C.c_int64), ("split_out_plane", C.c_int64),
     ]
 
 

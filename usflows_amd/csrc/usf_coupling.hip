@@ -346,6 +346,9 @@ int coupling_padded_width(int h) { return (h < 1 || h > CPL_HMAX) ? -1 : padded_
 
 int coupling_max_width() { return CPL_HMAX; }
 
+bool coupling_bf16x3_eligible(const usf_coupling_desc* d);
+int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream);
+
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_additive_f32: null descriptor"); return -1; }
   if (d->M < 0 || d->M > 0x7fffffff || d->n_pass <= 0 || d->n_trans <= 0 || d->n_hidden < 1 || d->n_hidden > 3) {
@@ -362,6 +365,7 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
     return -2;
   }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_coupling_additive_f32: bad act"); return -2; }
+  if (coupling_bf16x3_eligible(d)) return coupling_bf16x3_dispatch(d, stream);
   CplArgs a;
   a.z = d->z; a.out = d->out; a.ldz = d->ldz;
   a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans; a.n_trans4 = (int)((d->n_trans + 3) / 4 * 4);

@@ -592,7 +592,42 @@ class FlowEngine:
             d.context = ws_ctx["ctx"].data_ptr()
             d.W_ctx, d.b_ctx = f["W_ctx"].data_ptr(), f["b_ctx"].data_ptr()
         d.sign, d.slope, d.act = sign, cp["slope"], cp["act"]
+        if self.gemm_mode == "bf16x3" and f["Hp"] == 256:
+            s3 = self._fused_split(f)
+            d.split_in, d.split_in_ld, d.split_in_plane = s3["in"].data_ptr(), s3["in"].shape[2], s3["in"].shape[1] * s3["in"].shape[2]
+            for j, P in enumerate(s3["hid"]):
+                d.split_hid[j] = P.data_ptr()
+            if s3["hid"]:
+                d.split_hid_ld, d.split_hid_plane = s3["hid"][0].shape[2], s3["hid"][0].shape[1] * s3["hid"][0].shape[2]
+            d.split_out, d.split_out_ld, d.split_out_plane = s3["out"].data_ptr(), s3["out"].shape[2], s3["out"].shape[1] * s3["out"].shape[2]
         return op
+
+    @staticmethod
+    def _fused_split(f: dict) -> dict:
+        """bf16x3 planes of the fused kernel's padded weights; hidden (K) axes of the hidden / output layers in
+        the accumulator order of the kernel (include/usflows_hip.h)"""
+        if "split" in f:
+            return f["split"]
+        Hp = f["Hp"]
+        dev = f["W_in"].device
+        g, j = torch.arange(4, device=dev)[:, None], torch.arange(8, device=dev)[None, :]
+        within = torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4)).reshape(-1)          # [32]
+        perm = (torch.arange(0, Hp, 32, device=dev)[:, None] + within[None, :]).reshape(-1)
+
+        def planes(W):
+            N, K = W.shape
+            Kp = _round_up(K, 32)
+            hi = W.to(torch.bfloat16)
+            r = W - hi.float()
+            mid = r.to(torch.bfloat16)
+            lo = (r - mid.float()).to(torch.bfloat16)
+            out = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=W.device)
+            out[0, :, :K], out[1, :, :K], out[2, :, :K] = hi, mid, lo
+            return out
+
+        f["split"] = dict(**{"in": planes(f["W_in"])}, hid=[planes(W[:, perm]) for W, _ in f["hid"]],
+                          out=planes(f["W_out"][:, perm]))
+        return f["split"]
 
     # ---- execution ----------------------------------------------------------------------------
     def _plan(self, direction, B, device, has_ctx, final):
