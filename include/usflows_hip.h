@@ -76,7 +76,7 @@ typedef struct usf_linear_desc {
   /* Optional split-precision copy of W for the bf16x3 path (fp32-equivalent accuracy on the bf16 matrix
    * cores): three bf16 planes W1+W2+W3 == W (round-to-nearest residual split), plane p at
    * W_split + p*split_plane_stride, each [N, ldw_split] bf16 with ldw_split >= ceil32(K), zero-padded.
-   * Used when non-NULL and the op has no prologue / residual / addend and K % 8 == 0; W must still be given. */
+   * Used when non-NULL and the op has no residual / addend and K % 8 == 0; W must still be given. */
   const void* W_split; int64_t ldw_split; int64_t split_plane_stride;
 } usf_linear_desc;
 

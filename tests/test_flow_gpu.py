@@ -155,6 +155,24 @@ def test_three_hidden_layers_and_narrow_widths_fused():
     assert _rel(lp, ref) < RTOL
 
 
+@pytest.mark.parametrize("hidden,soft", [([256], False), ([256, 256, 256], False), ([200, 256], True), ([256, 160], False)])
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_wide_hidden_variants_both_gemm_modes(hidden, soft, mode):
+    """hidden widths in (128, 256] with M >= 1024 take the bf16x3 fused coupling kernel in bf16x3 mode:
+    1 / 2 / 3 hidden layers, ragged widths, soft-training context"""
+    spec = orc.FlowSpec(72, 2, hidden, householder=0, soft_training=soft)
+    sd = orc.synth_state_dict(spec, seed=21)
+    flow = build_flow(spec, sd, device=DEV)
+    flow.engine().gemm_mode = mode
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1500, 72, generator=g)
+    ctx = torch.rand(1500, 1, generator=g) if soft else None
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV), context=ctx.to(DEV)) if soft else flow.log_prob(x.to(DEV))
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x.double(), ctx.double() if soft else None)
+    assert _rel(lp, ref) < RTOL, (hidden, soft, mode)
+
+
 def test_linearity_of_affine_layer():
     """BlockAffineTransform.backward is affine: f(a x1 + (1-a) x2) = a f(x1) + (1-a) f(x2)."""
     spec = orc.FlowSpec(64, 1, [8], householder=1)

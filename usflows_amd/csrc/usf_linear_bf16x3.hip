@@ -22,6 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Lin3Args {
   const float* A; const __bf16* Wp; const float* bias; const float* post_mul; float* C;
+  const float* pre_div; const float* pre_sub;
   int64_t lda, ldc, ldwp, plane_stride;
   int M, N, K, nbm, nbn;
   float slope; int act;
@@ -41,7 +42,7 @@ __device__ __forceinline__ void split3(const f32x4 x0, const f32x4 x1, bf16x8& p
   }
 }
 
-template <int TN, int WM>
+template <int TN, int WM, bool PRO>
 __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Args p) {
   constexpr int NT = WM * 64;
   constexpr int BM = WM * 32;
@@ -72,19 +73,35 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 
   const float* arow = p.A + (int64_t)min(row0 + li, p.M - 1) * p.lda;
   // activation fragment of 16-k step s: 8 consecutive fp32 A[row][k0 + 16 s + 8 h .. +7]
+  // PRO: A' = A / pre_div - pre_sub in the operand registers, before the split (ScaleTransform.backward +
+  // bias of the tail affine layer, transforms.py:116-125, 960)
+  const float* pdiv = p.pre_div ? p.pre_div : p.pre_sub;
+  const float* psub = p.pre_sub ? p.pre_sub : p.pre_div;
+  const bool has_div = p.pre_div != nullptr, has_sub = p.pre_sub != nullptr;
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+  constexpr int NPRO = PRO ? 4 : 1;
+  f32x4 dvr[NPRO], svr[NPRO];
   auto issue_a = [&](int k0, f32x4 (&dst)[4]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        dst[2 * s + u] = *reinterpret_cast<const f32x4*>(arow + min(k0 + 16 * s + 8 * lh + 4 * u, p.K - 4));
+      for (int u = 0; u < 2; ++u) {
+        const int kc = min(k0 + 16 * s + 8 * lh + 4 * u, p.K - 4);
+        dst[2 * s + u] = *reinterpret_cast<const f32x4*>(arow + kc);
+        if (PRO) {
+          dvr[2 * s + u] = *reinterpret_cast<const f32x4*>(pdiv + kc);
+          svr[2 * s + u] = *reinterpret_cast<const f32x4*>(psub + kc);
+        }
+      }
   };
   auto finish_a = [&](int k0, f32x4 (&dst)[4]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) {
+        if (PRO) dst[2 * s + u] = dst[2 * s + u] / (has_div ? dvr[2 * s + u] : one4) - (has_sub ? svr[2 * s + u] : zero4);
         dst[2 * s + u] = (k0 + 16 * s + 8 * lh + 4 * u < p.K) ? dst[2 * s + u] : zero4;
+      }
   };
   // weight planes: thread -> (row, chunk): row = (tid & 7) + 8 * (tid >> 5) + RSTEP * i, chunk = (tid >> 3) & 3
   const int wr0 = (tid & 7) + 8 * (tid >> 5);
@@ -268,18 +285,21 @@ unsigned long long* g_bdbg = nullptr;
 
 template <int TN, int WM>
 static int launch3(Lin3Args a, hipStream_t stream) {
+  const bool pro = a.pre_div != nullptr || a.pre_sub != nullptr;
   constexpr int BM = WM * 32, BN = TN * 32;
   a.nbm = (a.M + BM - 1) / BM;
   a.nbn = (a.N + BN - 1) / BN;
   const int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
   if (grid > 0x7fffffffLL) { set_error("usf_linear_f32(bf16x3): grid too large"); return -3; }
-  hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  if (pro) hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, true>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  else hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, false>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
   return check_launch("usf_linear_f32(bf16x3)");
 }
 
 // true when this descriptor can take the split-precision kernel
 bool linear_bf16x3_eligible(const usf_linear_desc* d) {
-  return d->W_split != nullptr && !d->pre_div && !d->pre_sub && !d->residual && !d->addend && (d->K & 7) == 0 &&
+  return d->W_split != nullptr && !d->residual && !d->addend && (d->K & 7) == 0 &&
+         (!d->pre_div || aligned16(d->pre_div)) && (!d->pre_sub || aligned16(d->pre_sub)) &&
          (d->ldc & 3) == 0 && aligned16(d->C) && aligned16(d->W_split) && (d->ldw_split & 7) == 0 &&
          d->ldw_split >= ((d->K + 31) / 32) * 32 && d->M > 64 && d->N > 64;
 }
@@ -287,6 +307,7 @@ bool linear_bf16x3_eligible(const usf_linear_desc* d) {
 int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   Lin3Args a;
   a.A = d->A; a.Wp = reinterpret_cast<const __bf16*>(d->W_split); a.bias = d->bias; a.post_mul = d->post_mul; a.C = d->C;
+  a.pre_div = d->pre_div; a.pre_sub = d->pre_sub;
   a.lda = d->lda; a.ldc = d->ldc; a.ldwp = d->ldw_split; a.plane_stride = d->split_plane_stride;
   a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K; a.nbm = a.nbn = 0;
   a.slope = d->slope; a.act = d->act;

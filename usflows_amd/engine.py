@@ -459,7 +459,7 @@ class FlowEngine:
                                                    out_layout, 1.0).data_ptr()
                         k += 1
                 assert W.shape[1] == Kdim
-                if self.gemm_mode == "bf16x3" and "pre_div" not in kw and Kdim % 8 == 0:
+                if self.gemm_mode == "bf16x3" and Kdim % 8 == 0:
                     planes = self._split_planes(pk, W)
                     kw["W_split"] = planes.data_ptr()
                     kw["ldw_split"] = planes.shape[2]
@@ -663,7 +663,7 @@ class FlowEngine:
                 for j in range(pos, end):
                     op = arr[j]
                     if op.kind == _ext.OP_LINEAR:
-                        kind = "linear_bf16x3" if (op.u.linear.W_split and not op.u.linear.pre_div) else "linear"
+                        kind = "linear_bf16x3" if op.u.linear.W_split else "linear"
                         tag = (kind, op.u.linear.M, op.u.linear.N, op.u.linear.K)
                     else:
                         tag = ("coupling", op.u.coupling.M, op.u.coupling.n_trans, op.u.coupling.n_pass)
