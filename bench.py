@@ -149,8 +149,9 @@ def main():
         traffic = None
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            key = {"linear": "linear_kernel<2,5,4,16,false,0>", "linear_bf16x3": "linear_bf16x3_kernel<5,4>"}.get(
-                dom[0], "coupling_kernel<2,16>")
+            key = {"linear": "linear_kernel<2,5,4,16,false,0> (gemm_mode f32, earlier pass)",
+                   "linear_bf16x3": "linear_bf16x3_kernel<5,4>"}.get(
+                dom[0], "coupling_bf16x3_kernel<2,16>" if eng.gemm_mode == "bf16x3" else "coupling_kernel<2,16> (gemm_mode f32, earlier pass)")
             if B == 65536 and D == 784 and list(args.hidden) == [256, 256]:
                 traffic = prof["kernels"][key]["hbm_bytes_per_launch"]
         except Exception:
