@@ -19,7 +19,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense bf16 MFMA peak
@@ -59,14 +58,13 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
-    from oracle import usflows_oracle as orc          # generator of the synthetic state dict + cpu_baseline
-    from model_util import build_flow
+    from usflows_amd.synth import ModelSpec, synth_state_dict, build_usflow
     from usflows_amd.parallel import mean_log_prob
 
-    spec = orc.FlowSpec(args.dim, args.blocks, list(args.hidden), householder=0, affine_conjugation=False,
+    spec = ModelSpec(args.dim, args.blocks, list(args.hidden), householder=0, affine_conjugation=False,
                         negative_slope=0.01, conditioner="ConditionalDenseNN", base="laplace")
-    sd = orc.synth_state_dict(spec, seed=100, alpha=0.1)     # same parameters on every rank
-    flow = build_flow(spec, sd, device=str(dev))
+    sd = synth_state_dict(spec, seed=100, alpha=0.1)         # same parameters on every rank
+    flow = build_usflow(spec, sd, device=str(dev))
     eng = flow.engine()
     eng.use_fused_coupling = not args.unfused
     if args.gemm:
@@ -172,6 +170,7 @@ def main():
     # ---- CPU baseline: the oracle (op-for-op torch-CPU restatement of the reference), bounded sample ----
     cpu = None
     if world == 1 and not args.no_cpu_baseline and args.mode == "log_prob":
+        from oracle import usflows_oracle as orc      # the CPU oracle: this leg only
         rows = min(args.cpu_rows, B)
         xc = x[:rows].cpu()
         # 16 threads is the fastest setting for this workload on the GPU box's 2 x EPYC 9575F (probed with

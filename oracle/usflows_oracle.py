@@ -8,7 +8,10 @@ What it is: an op-for-op restatement, in plain torch-CPU tensor ops, of what the
 computes on the path named by BASELINE.json (reference = /root/reference, aai-institute/USFlows
 @2025-09-12).  It is *functional*: it consumes a reference-layout ``state_dict`` plus a small
 ``FlowSpec`` and never instantiates reference or product modules, so it cannot accidentally
-share code with either.  Each function cites the reference lines it follows.
+share arithmetic with either.  (The only thing it shares with the product is plain data: the
+``ModelSpec`` dataclass, the layer-order list and the synthetic-parameter generator of
+``usflows_amd/synth.py`` -- so that fixtures, oracle and device path see the same parameters.)
+Each function cites the reference lines it follows.
 
 Pinning: checked (a) against the reference's own known-answer tests
 (tests/veriflow/transforms_test.py:5-19 Scale, :35-51 LU) restated in tests/test_oracle.py,
@@ -36,27 +39,7 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------------------
 # spec
 # --------------------------------------------------------------------------------------
-@dataclass
-class FlowSpec:
-    """Everything about a reference ``USFlow`` that is not in its state dict."""
-
-    dim: int                              # in_dims=[dim] (flat inputs only: SURVEY section 8a)
-    coupling_blocks: int
-    hidden_dims: Sequence[int]
-    lu_transform: int = 1                 # flows.py:401
-    householder: int = 1                  # flows.py:402 (ctor default)
-    affine_conjugation: bool = False      # flows.py:399
-    negative_slope: float = 0.01          # LeakyReLU slope; 0.0 == ReLU
-    conditioner: str = "ConditionalDenseNN"   # or "DenseNN" (pyro layout: no context layer)
-    base: str = "laplace"                 # "laplace" | "normal" | "radial"
-    base_loc: Optional[torch.Tensor] = None
-    base_scale: Optional[torch.Tensor] = None
-    radial_p: float = 1.0                 # RadialDistribution p (1, 2, inf)
-    radial_norm: str = "lognormal"        # norm_distribution family
-    radial_norm_loc: float = 0.0
-    radial_norm_scale: float = 1.0        # (already soft-plussed) sigma
-    soft_training: bool = False
-    extra: dict = field(default_factory=dict)
+from usflows_amd.synth import ModelSpec as FlowSpec, layer_plan  # noqa: E402  (plain dataclass + layer order, no arithmetic)
 
 
 def checkerboard_mask(dim: int, dtype=torch.float32) -> torch.Tensor:
@@ -217,33 +200,8 @@ def coupling_backward(sd, prefix, spec, mask, y, context=None):
 
 
 # --------------------------------------------------------------------------------------
-# layer list (USFlow.__init__, flows.py:434-482)
+# layer list (USFlow.__init__, flows.py:434-482): usflows_amd.synth.layer_plan
 # --------------------------------------------------------------------------------------
-def layer_plan(spec: FlowSpec):
-    """[(kind, trainable_layers prefix, mask)] in ``Flow.layers`` order.
-
-    kinds: 'affine' (BlockAffineTransform), 'coupling', 'inv_affine' (InverseTransform sharing
-    the block's parameters; its state-dict alias is '<idx>.transform.'), 'scale'."""
-    has_affine = spec.lu_transform > 0 or spec.householder > 0
-    plan = []
-    idx = 0
-    for i in range(spec.coupling_blocks):
-        a_idx = None
-        if has_affine:
-            a_idx = idx
-            plan.append(("affine", f"trainable_layers.{idx}.block_transform.", None, True))
-            idx += 1
-        plan.append(("coupling", f"trainable_layers.{idx}.", i % 2, None))
-        idx += 1
-        if spec.affine_conjugation and has_affine:
-            plan.append(("inv_affine", f"trainable_layers.{a_idx}.block_transform.", None, True))
-            idx += 1
-    plan.append(("affine", f"trainable_layers.{idx}.block_transform.", None, False))
-    idx += 1
-    plan.append(("scale", f"trainable_layers.{idx}.", None, None))
-    return plan
-
-
 def _mask_for(spec, flip, dtype):
     m = checkerboard_mask(spec.dim, dtype)
     return 1 - m if flip else m            # flows.py:472 alternates after every block
@@ -364,80 +322,7 @@ def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
 
 
 # --------------------------------------------------------------------------------------
-# deterministic, well-conditioned synthetic parameters
+# deterministic synthetic parameters: pure data generation shared with bench.py / smoke (no flow
+# arithmetic); lives in usflows_amd/synth.py, re-exported here for the tests
 # --------------------------------------------------------------------------------------
-def synth_state_dict(spec: FlowSpec, seed: int = 0, alpha: float = 0.1) -> Dict[str, torch.Tensor]:
-    """Reference-layout state dict with the reference's init *distributions* followed by the
-    documented conditioning transform (L <- I + alpha*tril(L,-1); U <- alpha*triu(U,1) +
-    diag(sign*U[0.75,1.25]); scale <- sign*U[0.5,1.5]).  The default init of the reference
-    explodes at depth (|z| ~ 7e22 at D=784,K=32); these parameters keep |z| = O(10)."""
-    g = torch.Generator().manual_seed(seed)
-    D = spec.dim
-    sd: Dict[str, torch.Tensor] = {}
-
-    def ku(shape, fan_in, gain=math.sqrt(2.0)):      # kaiming_uniform_(nonlinearity="relu")
-        bound = gain * math.sqrt(3.0 / fan_in)
-        return (torch.rand(shape, generator=g) * 2 - 1) * bound
-
-    def lu_params(prefix):
-        L = torch.eye(D) + alpha * ku((D, D), D).tril(-1)
-        sign = torch.where(torch.rand(D, generator=g) < 0.5, -1.0, 1.0)
-        diag = sign * (0.75 + 0.5 * torch.rand(D, generator=g))
-        U = alpha * ku((D, D), D).triu(1) + torch.diag(diag)
-        sd[prefix + "L_raw"] = L
-        sd[prefix + "U_raw"] = U
-        sd[prefix + "bias_vector"] = (torch.rand(D, generator=g) * 2 - 1) / math.sqrt(D)
-
-    def linear(prefix, out_f, in_f):                  # nn.Linear default init
-        bound = 1.0 / math.sqrt(in_f)
-        sd[prefix + "weight"] = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound
-        sd[prefix + "bias"] = (torch.rand(out_f, generator=g) * 2 - 1) * bound
-
-    done = set()
-    for kind, prefix, flip, seq in layer_plan(spec):
-        if prefix in done:
-            continue
-        done.add(prefix)
-        if kind in ("affine", "inv_affine"):
-            if not seq:
-                lu_params(prefix)
-                continue
-            j = 0
-            for _ in range(spec.lu_transform):
-                lu_params(f"{prefix}transforms.{j}.")
-                j += 1
-            if spec.householder > 0:
-                q = f"{prefix}transforms.{j}."
-                sd[q + "vk_householder"] = 0.2 * torch.randn(spec.householder, D, generator=g)
-                w = torch.zeros(D, D)
-                w[torch.arange(D), torch.randperm(D, generator=g)] = 1.0
-                sd[q + "w_0"] = w
-        elif kind == "coupling":
-            c = prefix + "conditioner."
-            hs = list(spec.hidden_dims)
-            if spec.conditioner == "ConditionalDenseNN":
-                linear(c + "layers.0.", hs[0], D)
-                linear(c + "layers.1.", hs[0], 1)
-                idx = 2
-                for i in range(1, len(hs)):
-                    linear(c + f"layers.{idx}.", hs[i], hs[i - 1])
-                    idx += 1
-                linear(c + f"layers.{idx}.", D, hs[-1])
-            else:
-                linear(c + "layers.0.", hs[0], D)
-                for i in range(1, len(hs)):
-                    linear(c + f"layers.{i}.", hs[i], hs[i - 1])
-                linear(c + f"layers.{len(hs)}.", D, hs[-1])
-        elif kind == "scale":
-            sign = torch.where(torch.rand(D, generator=g) < 0.5, -1.0, 1.0)
-            sd[prefix + "scale"] = sign * (0.5 + torch.rand(D, generator=g))
-    # InverseTransform aliases (same tensors under '<idx>.transform.block_transform.')
-    if spec.affine_conjugation:
-        idx = 0
-        for i in range(spec.coupling_blocks):
-            a = idx
-            inv = idx + 2
-            for k in [k for k in sd if k.startswith(f"trainable_layers.{a}.block_transform.")]:
-                sd[k.replace(f"trainable_layers.{a}.", f"trainable_layers.{inv}.transform.")] = sd[k]
-            idx += 3
-    return sd
+from usflows_amd.synth import synth_state_dict  # noqa: E402,F401
