@@ -114,6 +114,37 @@ def test_linear_bf16x3_split_precision(M, N, K):
     assert err < max(4 * err32, 1e-6), (err, err32)
 
 
+@pytest.mark.parametrize("flags", [dict(act=True), dict(residual=True, res_sign=-1.0), dict(addend=True, act=True),
+                                   dict(pre=True), dict(post_mul=True)])
+def test_linear_bf16x3_epilogues(flags):
+    ext, dev = _ext(), _dev()
+    from usflows_amd.engine import FlowEngine
+    M, N, K = 777, 392, 256
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g) if flags.get("residual") else None
+    add = torch.randn(M, N, generator=g) if flags.get("addend") else None
+    pdiv = (torch.rand(K, generator=g) + 0.5) if flags.get("pre") else None
+    psub = torch.randn(K, generator=g) if flags.get("pre") else None
+    pm = torch.randn(N, generator=g) if flags.get("post_mul") else None
+    d = lambda t: None if t is None else t.to(dev)
+    planes = FlowEngine._split_planes({"mats": {}}, W.to(dev))
+    C = torch.full((M, N), float("nan"), device=dev)
+    ext.linear(d(A), d(W), C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=d(bias), residual=d(res), ldr=N, addend=d(add),
+               ldadd=N, pre_div=d(pdiv), pre_sub=d(psub), post_mul=d(pm), res_sign=flags.get("res_sign", 1.0),
+               act=1 if flags.get("act") else 0, slope=0.01, W_split=planes)
+    torch.cuda.synchronize()
+    ref = _linear_ref(A, W, bias, pdiv, psub, res, pm, flags.get("res_sign", 1.0), 0.01, 1 if flags.get("act") else 0,
+                      torch.float64) if add is None else None
+    if add is not None:
+        v = A.double() @ W.double().t() + bias.double() + add.double()
+        ref = torch.nn.functional.leaky_relu(v, 0.01)
+    err = (C.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+
+
 def test_linear_rejects_bad_args():
     ext, dev = _ext(), _dev()
     A = torch.zeros(4, 6, device=dev)

@@ -25,6 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Lin3Args {
   const float* A; const __bf16* Wp; const float* bias; const float* post_mul; float* C;
   const float* pre_div; const float* pre_sub;
+  const float* residual; const float* addend; int64_t ldr, ldadd; float res_sign;
   int64_t lda, ldc, ldwp, plane_stride;
   int M, N, K, nbm, nbn;
   float slope; int act;
@@ -244,22 +245,25 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
       f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = act_apply(acc[tn][4 * g4 + j], p.act, p.slope);
-        if (has_pm) x = x * p.post_mul[min(col + j, p.N - 1)];
-        v[j] = x;
-      }
+      for (int j = 0; j < 4; ++j) v[j] = acc[tn][4 * g4 + j];
       *reinterpret_cast<f32x4*>(tw + li * TLD + 8 * g4 + 4 * lh) = v;
     }
+    // everything element-wise happens after the transpose, where a lane owns 4 consecutive features of a
+    // row and the wave touches whole cache lines (addend / residual are read the same way)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 8 * i;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * TLD + cc);
+      f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * TLD + cc);
       const int row = row0 + r;
       const int col = n0 + tn * 32 + cc;
+      const int rowc = min(row, p.M - 1), colc = min(col, p.N - 4);
+      if (p.addend) v = v + *reinterpret_cast<const f32x4*>(p.addend + (int64_t)rowc * p.ldadd + colc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act, p.slope);
+      if (p.residual) v = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rowc * p.ldr + colc) + p.res_sign * v;
+      if (has_pm) v = v * *reinterpret_cast<const f32x4*>(p.post_mul + colc);
       float* dst = p.C + (int64_t)row * p.ldc + col;
       if (row < p.M) {
         if (col + 3 < p.N) {
@@ -300,7 +304,10 @@ static int launch3(Lin3Args a, hipStream_t stream) {
 
 // true when this descriptor can take the split-precision kernel
 bool linear_bf16x3_eligible(const usf_linear_desc* d) {
-  return d->W_split != nullptr && !d->residual && !d->addend && (d->K & 7) == 0 &&
+  return d->W_split != nullptr && (d->K & 7) == 0 && (d->N & 3) == 0 &&
+         (!d->residual || (aligned16(d->residual) && (d->ldr & 3) == 0)) &&
+         (!d->addend || (aligned16(d->addend) && (d->ldadd & 3) == 0)) && !(d->residual && d->addend) &&
+         (!d->post_mul || aligned16(d->post_mul)) &&
          (!d->pre_div || aligned16(d->pre_div)) && (!d->pre_sub || aligned16(d->pre_sub)) &&
          (d->ldc & 3) == 0 && aligned16(d->C) && aligned16(d->W_split) && (d->ldw_split & 7) == 0 &&
          d->ldw_split >= ((d->K + 31) / 32) * 32 && d->M > 64 && d->N > 64;
@@ -310,6 +317,7 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   Lin3Args a;
   a.A = d->A; a.Wp = reinterpret_cast<const __bf16*>(d->W_split); a.bias = d->bias; a.post_mul = d->post_mul; a.C = d->C;
   a.pre_div = d->pre_div; a.pre_sub = d->pre_sub;
+  a.residual = d->residual; a.addend = d->addend; a.ldr = d->ldr; a.ldadd = d->ldadd; a.res_sign = d->res_sign;
   a.lda = d->lda; a.ldc = d->ldc; a.ldwp = d->ldw_split; a.plane_stride = d->split_plane_stride;
   a.M = (int)d->M; a.N = (int)d->N; a.K = (int)d->K; a.nbm = a.nbn = 0;
   a.slope = d->slope; a.act = d->act;

@@ -323,6 +323,14 @@ class FlowEngine:
             pk["mats"][key] = self._perm_mat(pk["affine"][id(blk)][which], self._idx(out_layout), self._idx(in_layout))
         return pk["mats"][key]
 
+    def _split_kw(self, pk, W: torch.Tensor, K: int) -> dict:
+        """descriptor fields that hand the bf16x3 planes of W to usf_linear_f32 (empty in f32 mode)"""
+        if self.gemm_mode != "bf16x3" or K % 8 != 0 or W.shape[0] <= 64:
+            return {}
+        planes = self._split_planes(pk, W)
+        return dict(W_split=planes.data_ptr(), ldw_split=planes.shape[2],
+                    split_plane_stride=planes.shape[1] * planes.shape[2])
+
     @staticmethod
     def _split_planes(pk, W: torch.Tensor) -> torch.Tensor:
         """[3, N, ceil32(K)] bf16 planes with W1 + W2 + W3 == W (round-to-nearest residual split)"""
@@ -459,11 +467,7 @@ class FlowEngine:
                                                    out_layout, 1.0).data_ptr()
                         k += 1
                 assert W.shape[1] == Kdim
-                if self.gemm_mode == "bf16x3" and Kdim % 8 == 0:
-                    planes = self._split_planes(pk, W)
-                    kw["W_split"] = planes.data_ptr()
-                    kw["ldw_split"] = planes.shape[2]
-                    kw["split_plane_stride"] = planes.shape[1] * planes.shape[2]
+                kw.update(self._split_kw(pk, W, Kdim))
                 if out_layout == "seg":
                     dst = take()
                     Ndim, ldc, cptr = self.LD, self.LD, ws[dst].data_ptr()
@@ -517,6 +521,7 @@ class FlowEngine:
                                           bias=cp["b_ctx"].data_ptr(), C=ws["P"].data_ptr(), ldc=self.hmax,
                                           M=B, N=cp["hidden"][0], K=4, res_sign=1.0, slope=0.0, act=_ext.ACT_NONE))
                         kw = dict(addend=ws["P"].data_ptr(), ldadd=self.hmax)
+                    kw.update(self._split_kw(pk, W, src_K))
                     ops.append(lin_op(A=src_ptr, lda=src_ld, W=W.data_ptr(), ldw=W.shape[1], bias=b.data_ptr(),
                                       C=hb.data_ptr(), ldc=self.hmax, M=B, N=W.shape[0], K=src_K, res_sign=1.0,
                                       slope=cp["slope"], act=cp["act"], **kw))
@@ -524,7 +529,8 @@ class FlowEngine:
                 tptr = zptr + 4 * cp["tr_off"]
                 ops.append(lin_op(A=src_ptr, lda=src_ld, W=cp["W_out"].data_ptr(), ldw=cp["W_out"].shape[1],
                                   bias=cp["b_out"].data_ptr(), residual=tptr, ldr=self.LD, C=tptr, ldc=self.LD,
-                                  M=B, N=cp["tr_n"], K=src_K, res_sign=sign, slope=0.0, act=_ext.ACT_NONE))
+                                  M=B, N=cp["tr_n"], K=src_K, res_sign=sign, slope=0.0, act=_ext.ACT_NONE,
+                                  **self._split_kw(pk, cp["W_out"], src_K)))
             k += 1
 
         # ---- final layout fix-up ------------------------------------------------------------------
