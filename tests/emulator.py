@@ -150,6 +150,7 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
 
 def engine_transform(eng, x, direction, context=None, fused=False):
     eng.use_fused_coupling = fused
+    eng.fused_min_rows = 0
     if fused:
         eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     B = x.shape[0]
@@ -161,6 +162,7 @@ def engine_transform(eng, x, direction, context=None, fused=False):
 
 def engine_latent(eng, x, context=None, fused=False):
     eng.use_fused_coupling = fused
+    eng.fused_min_rows = 0
     if fused:
         eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     plan = eng._plan("backward", x.shape[0], x.device, context is not None, "nat")

@@ -35,6 +35,7 @@ def test_golden_parity(name, fused):
     eng = flow.engine()
     assert eng is not None
     eng.use_fused_coupling = fused
+    eng.fused_min_rows = 0             # small fixtures: force the fused kernel when asked for
     ctx = a.get("context")
     x, zin = a["x"].to(DEV), a["zin"].to(DEV)
     n0 = eng.launch_count
@@ -62,6 +63,7 @@ def test_golden_parity_gemm_modes(name, mode):
     spec, sd, a = load_case(name)
     flow = build_flow(spec, sd, device=DEV)
     flow.engine().gemm_mode = mode
+    flow.engine().fused_min_rows = 0
     with torch.no_grad():
         lp = flow.log_prob(a["x"].to(DEV))
         xf = flow._forward(a["zin"].to(DEV))
@@ -148,6 +150,7 @@ def test_three_hidden_layers_and_narrow_widths_fused():
     spec = orc.FlowSpec(40, 3, [48, 20, 136], householder=1, affine_conjugation=True, negative_slope=0.0)
     sd = orc.synth_state_dict(spec, seed=8)
     flow = build_flow(spec, sd, device=DEV)
+    flow.engine().fused_min_rows = 0
     x = torch.rand(333, 40, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():
         lp = flow.log_prob(x.to(DEV))
@@ -164,6 +167,7 @@ def test_wide_hidden_variants_both_gemm_modes(hidden, soft, mode):
     sd = orc.synth_state_dict(spec, seed=21)
     flow = build_flow(spec, sd, device=DEV)
     flow.engine().gemm_mode = mode
+    flow.engine().fused_min_rows = 0
     g = torch.Generator().manual_seed(5)
     x = torch.rand(1500, 72, generator=g)
     ctx = torch.rand(1500, 1, generator=g) if soft else None

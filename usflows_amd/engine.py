@@ -140,6 +140,7 @@ class FlowEngine:
         self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
         self.op_timing = None          # set to a list to record (tag, start_event, end_event) per op (bench.py)
         self.use_fused_coupling = True
+        self.fused_min_rows = 24576    # measured cross-over on MI355X at D=784, hidden 256 (bench.py --batch sweep)
         # "bf16x3" (default): the D x D affine GEMMs run on the bf16 matrix cores with a 3-way residual split of
         # both operands (fp32-equivalent accuracy); "f32": exact-f32 MFMA everywhere
         # (USFLOWS_AMD_GEMM=f32 or engine.gemm_mode = "f32")
@@ -506,7 +507,9 @@ class FlowEngine:
             sign = 1.0 if prim == "coupling_fwd" else -1.0
             zptr = ws[cur[0]].data_ptr()
             use_ctx = has_ctx and cp["has_ctx"]
-            if self.use_fused_coupling and self._fused_ok(cp):
+            # the fused kernel keeps a wave on 16 rows for the whole MLP: unbeatable when the chip is full, but
+            # its latency is one wave's serial MFMA chain; small batches run the MLP as 3 short linear launches
+            if self.use_fused_coupling and self._fused_ok(cp) and B >= self.fused_min_rows:
                 ops.append(self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None))
             else:
                 hbufs = ["H1", "H2"]
@@ -638,7 +641,7 @@ class FlowEngine:
     # ---- execution ----------------------------------------------------------------------------
     def _plan(self, direction, B, device, has_ctx, final):
         pk = self.pack(device)   # may invalidate plans
-        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode)
+        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final)
