@@ -51,12 +51,18 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   constexpr int BM = WM * 32;
   constexpr int BN = TN * 32;
   constexpr int BK = 32;                       // two 16-k MFMA steps per slab
-  constexpr int RSTEP = NT / 4;                // rows between a thread's consecutive staged chunks (4 chunks/row)
-  constexpr int NWV = (BN + RSTEP - 1) / RSTEP;
-  constexpr int NR = NWV * RSTEP;              // LDS rows per plane (>= BN, multiple of 16)
-  static_assert(NR % 16 == 0 && RSTEP % 8 == 0, "staging shape");
-  // LDS image: slot(plane, chunk, row) = (plane * 4 + chunk) * NR + row, 16-byte slots (8 bf16 of one row)
-  __shared__ __attribute__((aligned(16))) float lds[2][3 * 4 * NR * 4];
+  // weight stage = 3 planes x 4 k-chunks x BN rows of 16-byte slots, LDS image slot(plane, chunk, row) =
+  // (plane * 4 + chunk) * BN + row.  The slots are dealt to the threads in image order (8 consecutive lanes =
+  // 8 consecutive rows of one chunk: conflict-free ds_write_b128, whole 64-B row pieces per 4 lanes' worth
+  // of chunks on the global side); only the last round of the deal is partial.
+  constexpr int NSLOT = 3 * 4 * BN;
+  constexpr int NWV = (NSLOT + NT - 1) / NT;   // float4 staged per thread per slab
+  constexpr int NR = BN;
+  static_assert(NR % 16 == 0, "fragment reads need the chunk stride to be a multiple of 16 slots");
+  constexpr int TLD_ = 36;
+  constexpr int STG = NSLOT * 4;               // floats per staging buffer
+  constexpr int BUFF = (2 * STG >= WM * 32 * TLD_) ? STG : (WM * 32 * TLD_ + 1) / 2;   // room for the transpose scratch
+  __shared__ __attribute__((aligned(16))) float lds[2][BUFF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -106,24 +112,31 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
         dst[2 * s + u] = (k0 + 16 * s + 8 * lh + 4 * u < p.K) ? dst[2 * s + u] : zero4;
       }
   };
-  // weight planes: thread -> (row, chunk): row = (tid & 7) + 8 * (tid >> 5) + RSTEP * i, chunk = (tid >> 3) & 3
-  const int wr0 = (tid & 7) + 8 * (tid >> 5);
-  const int wc = (tid >> 3) & 3;
-  auto issue_w = [&](int k0, f32x4 (&dst)[3][NWV]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-      for (int i = 0; i < NWV; ++i) {
-        const int n = min(n0 + wr0 + RSTEP * i, p.N - 1);
-        dst[pl][i] = *reinterpret_cast<const f32x4*>(p.Wp + pl * p.plane_stride + (int64_t)n * p.ldwp + k0 + 8 * wc);
-      }
+  // deal: 32 consecutive lanes take 8 rows x 4 chunks (64 contiguous bytes per row on the global side; 8
+  // consecutive lanes = 8 consecutive rows of one chunk on the LDS side); groups run over (plane, 8-row group)
+  constexpr int NRG = BN / 8;                  // 8-row groups per plane
+  auto slot_of = [&](int idx, int& plane, int& chunk, int& row) {
+    const int g32 = idx >> 5;
+    plane = g32 / NRG;
+    row = (g32 % NRG) * 8 + (idx & 7);
+    chunk = (idx >> 3) & 3;
   };
-  auto store_w = [&](int buf, const f32x4 (&src)[3][NWV]) {
+  auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int i = 0; i < NWV; ++i) {
+      int pl, ch, r;
+      slot_of(min(tid + NT * i, NSLOT - 1), pl, ch, r);    // (last round: duplicates, never stored)
+      const int n = min(n0 + r, p.N - 1);
+      dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + pl * p.plane_stride + (int64_t)n * p.ldwp + k0 + 8 * ch);
+    }
+  };
+  auto store_w = [&](int buf, const f32x4 (&src)[NWV]) {
 #pragma unroll
-      for (int i = 0; i < NWV; ++i)
-        *reinterpret_cast<f32x4*>(&lds[buf][4 * ((pl * 4 + wc) * NR + wr0 + RSTEP * i)]) = src[pl][i];
+    for (int i = 0; i < NWV; ++i) {
+      int pl, ch, r;
+      slot_of(tid + NT * i, pl, ch, r);
+      if (tid + NT * i < NSLOT) *reinterpret_cast<f32x4*>(&lds[buf][4 * ((pl * 4 + ch) * BN + r)]) = src[i];
+    }
   };
 
   // accumulators (C^T: batch row on the lane, 4 consecutive output features per register group) start at the bias
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   // are split while the second 16-k step of the current slab multiplies (VALU beside MFMA in one wave)
   bf16x8 pc[2][3], pn[2][3];
   f32x4 a_nxt[4];
-  f32x4 wst[3][NWV];
+  f32x4 wst[NWV];
   const int nslab = (p.K + BK - 1) / BK;
   issue_w(0, wst);
   issue_a(0, a_nxt);
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   BSTAMP(b3);
   // ---- epilogue: transpose each 32x32 tile through a per-wave LDS scratch -> whole-cache-line stores ----
   constexpr int TLD = 36;
-  static_assert(2 * 3 * 4 * NR * 4 >= WM * 32 * TLD, "transpose scratch must fit the staging buffers");
+  static_assert(2 * BUFF >= WM * 32 * TLD && TLD == TLD_, "transpose scratch must fit the staging buffers");
   float* tw = &lds[0][0] + wave * (32 * TLD);
   const int rr = lane >> 3, cc = 4 * (lane & 7);
   __syncthreads();                   // every wave is done reading the last weight slab
