@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do
+USFLOWS_AMD_LIB=$GRAFT_REPO_ROOT/usflows_amd/csrc/libusflows_base.so python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('BASE', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('NEW ', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"
+done

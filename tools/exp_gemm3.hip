@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   d.A = A; d.lda = K; d.W = W; d.ldw = K; d.bias = bias; d.C = C; d.ldc = N; d.M = M; d.N = N; d.K = K; d.res_sign = 1.f;
   d.W_split = P; d.ldw_split = Kp; d.split_plane_stride = N * Kp;
 #ifdef USF_STAMP
-  unsigned long long* dbg; hipMalloc(&dbg, 4096 * 8 * 8); hipMemset(dbg, 0, 4096 * 8 * 8); usf::g_bdbg = dbg;
+  unsigned long long* dbg; hipMalloc(&dbg, 2 * 8192 * 8 * 8); hipMemset(dbg, 0, 2 * 8192 * 8 * 8); usf::g_bdbg = dbg;
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) usf::linear_bf16x3_dispatch(&d, 0);
@@ -38,10 +38,13 @@ int main(int argc, char** argv) {
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
   printf("bf16x3 M=%lld N=%lld K=%lld: %.3f ms  %.1f TF/s (fp32-equivalent)\n", (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
 #ifdef USF_STAMP
-  std::vector<unsigned long long> hd(4096 * 8);
-  hipMemcpy(hd.data(), dbg, 4096 * 8 * 8, hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> hd(2 * 8192 * 8);
+  hipMemcpy(hd.data(), dbg, 2 * 8192 * 8 * 8, hipMemcpyDeviceToHost);
   double sm[6] = {0, 0, 0, 0, 0, 0}; int nw = 0;
-  for (int w = 0; w < 4096; ++w) if (hd[w * 8 + 5]) { for (int j = 0; j < 6; ++j) sm[j] += hd[w * 8 + j]; ++nw; }
+  for (int w = 0; w < 8192; ++w) if (hd[w * 8 + 5]) { for (int j = 0; j < 6; ++j) sm[j] += hd[w * 8 + j]; ++nw; }
+  { double pq[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 8192; ++w) if (hd[w * 8 + 5]) for (int j = 0; j < 5; ++j) pq[j] += hd[8192 * 8 + w * 8 + j];
+    printf("  loop phases per wave: issue %.0f step0 %.0f step1+split %.0f store %.0f barrier %.0f\n", pq[0] / nw, pq[1] / nw, pq[2] / nw, pq[3] / nw, pq[4] / nw); }
   printf("  waves %d: cycles per wave: prologue %.0f loop %.0f last %.0f epilogue %.0f total %.0f\n", nw, sm[0] / nw, sm[1] / nw, sm[2] / nw, sm[3] / nw, sm[4] / nw);
 #endif
   return 0;

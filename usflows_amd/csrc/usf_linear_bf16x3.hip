@@ -60,7 +60,10 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   constexpr int NR = BN;
   static_assert(NR % 16 == 0, "fragment reads need the chunk stride to be a multiple of 16 slots");
   constexpr int TLD_ = 36;
-  constexpr int STG = NSLOT * 4;               // floats per staging buffer
+  // the last round of the deal is partial: its surplus threads store (duplicates of the last slot) into a
+  // tail of the buffer nobody reads, so the K loop stays ONE basic block (a branch around the store lets the
+  // compiler sink the operand split behind it, out of the MFMA shadow)
+  constexpr int STG = NWV * NT * 4;            // floats per staging buffer
   constexpr int BUFF = (2 * STG >= WM * 32 * TLD_) ? STG : (WM * 32 * TLD_ + 1) / 2;   // room for the transpose scratch
   __shared__ __attribute__((aligned(16))) float lds[2][BUFF];
 
@@ -135,7 +138,8 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     for (int i = 0; i < NWV; ++i) {
       int pl, ch, r;
       slot_of(tid + NT * i, pl, ch, r);
-      if (tid + NT * i < NSLOT) *reinterpret_cast<f32x4*>(&lds[buf][4 * ((pl * 4 + ch) * BN + r)]) = src[i];
+      const int sl = (tid + NT * i < NSLOT) ? (pl * 4 + ch) * BN + r : tid + NT * i;
+      *reinterpret_cast<f32x4*>(&lds[buf][4 * sl]) = src[i];
     }
   };
 
@@ -211,18 +215,43 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     }                                                                                 \
   } while (0)
 
+  // step 0: as above, plus VMEM reads dealt over the tiles
+  constexpr int NLD = NWV + (PRO ? 12 : 4);
+  constexpr int LPT = (NLD + TN - 1) / TN;
+#define USF_PIN_STEP0()                                                               \
+  do {                                                                                \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                \
+    _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_) {                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                              \
+      if (tn_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);            \
+      __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);                            \
+    }                                                                                 \
+  } while (0)
+
   BSTAMP(b1);
+#ifdef USF_STAMP
+  unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#define LSTAMP(v) BSTAMP(v)
+#define LACC(i, a, b) ph[i] += (b) - (a)
+#else
+#define LSTAMP(v)
+#define LACC(i, a, b)
+#endif
   for (int s = 0; s + 1 < nslab; ++s) {
     const int buf = s & 1;
     const int k1 = (s + 1) * BK;
+    LSTAMP(l0);
+    // the next slab's global loads are dealt out between the tiles of step 0 (activation fragments first:
+    // the split in step 1 wants them): issued as one burst behind the barrier, the 8 waves' 64 loads queue
+    // in the address unit for ~2000 cycles during which no wave reaches its first MFMA
 #if !(defined(USF_ABL3) && (USF_ABL3 & 4))   // tuning: no global loads in the loop
-    issue_w(k1, wst);
     issue_a(k1, a_nxt);
+    issue_w(k1, wst);
 #endif
-    __builtin_amdgcn_sched_barrier(0);
     compute_step(buf, 0);
-    USF_PIN_STEP(0);
+    USF_PIN_STEP0();
     __builtin_amdgcn_sched_barrier(0);
+    LSTAMP(l2);
 #if defined(USF_ABL3) && (USF_ABL3 & 2)      // tuning: no operand split in the loop
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -236,12 +265,17 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     compute_step(buf, 1);
     USF_PIN_STEP(24);
     __builtin_amdgcn_sched_barrier(0);
+    LSTAMP(l3);
     store_w(buf ^ 1, wst);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) pc[q][pl] = pn[q][pl];
+    __builtin_amdgcn_sched_barrier(0);
+    LSTAMP(l4);
     __syncthreads();
+    LSTAMP(l5);
+    LACC(1, l0, l2); LACC(2, l2, l3); LACC(3, l3, l4); LACC(4, l4, l5);
   }
   BSTAMP(b2);
   compute_step((nslab - 1) & 1, 0);  // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
@@ -294,6 +328,8 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   if (p.dbg && lane == 0) {
     unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 1024) * WM + wave) * 8;
     o[0] = b1 - b0; o[1] = b2 - b1; o[2] = b3 - b2; o[3] = b4 - b3; o[4] = b4 - b0; o[5] = 1;
+    unsigned long long* o2 = p.dbg + 8192 * 8 + (size_t)((blockIdx.x % 1024) * WM + wave) * 8;
+    for (int i = 0; i < 5; ++i) o2[i] = ph[i];
   }
 #endif
 }
