@@ -206,6 +206,82 @@ static void run(const float* src, float* out, unsigned long long* clk, int iters
          tf / 6, cyc / rt * 100.0);
 }
 
+// same output tile per wave (32 batch rows x 160 features), v_mfma_f32_16x16x32_bf16: 10 x 2 tiles, 6 terms each
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_mix16(const float* __restrict__ src, float* __restrict__ out, int iters,
+                                                     unsigned long long* clk) {
+  __shared__ __attribute__((aligned(16))) float lds[7680];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 7680; i += 512) lds[i] = src[(i * 7 + blockIdx.x) & 0xffff];
+  __syncthreads();
+  f32x4 a[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(src + ((tid * 16 + i * 4 + blockIdx.x * 64) & 0xfff0));
+  bf16x8 pc[2][3], w[3];
+  split3(a[0], a[1], pc[0][0], pc[0][1], pc[0][2]);
+  split3(a[2], a[3], pc[1][0], pc[1][1], pc[1][2]);
+  split3(a[1], a[2], w[0], w[1], w[2]);
+  f32x4 acc[10][2];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      bf16x8 w1 = w[0], w2 = w[1], w3 = w[2];
+      if (MODE >= 2) {
+        const float* wl = lds + 4 * ((lane >> 4) * 160 + (lane & 15));
+        w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 640 + t * 16));
+        w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 640 + t * 16));
+        w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 640 + t * 16));
+      }
+#define M16(W, P) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[0][P], acc[t][0], 0, 0, 0); acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[1][P], acc[t][1], 0, 0, 0)
+      M16(w3, 0); M16(w2, 1); M16(w1, 2); M16(w2, 0); M16(w1, 1); M16(w1, 0);
+    }
+    if (MODE >= 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[i][j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a[i][j]) ^ (unsigned)(it & 255));
+      split3(a[0], a[1], pc[0][0], pc[0][1], pc[0][2]);
+      split3(a[2], a[3], pc[1][0], pc[1][1], pc[1][2]);
+    }
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 10; ++t) s4 = s4 + acc[t][0] + acc[t][1];
+  out[blockIdx.x * 512 + tid] = s4[0] + s4[1] + s4[2] + s4[3];
+  if (tid == 0 && blockIdx.x < 512) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = t1 - t0; }
+}
+
+template <int MODE>
+static void run16(const float* src, float* out, unsigned long long* clk, int iters, int dyn) {
+  hipFuncSetAttribute((const void*)mfma_mix16<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int blocks = 512;
+  for (int i = 0; i < 30; ++i) hipLaunchKernelGGL((mfma_mix16<MODE>), dim3(blocks), dim3(512), dyn, 0, src, out, iters, clk);
+  hipEventRecord(e0);
+  const int reps = 30;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((mfma_mix16<MODE>), dim3(blocks), dim3(512), dyn, 0, src, out, iters, clk);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  ms /= reps;
+  std::vector<unsigned long long> h(1024);
+  hipMemcpy(h.data(), clk, 1024 * 8, hipMemcpyDeviceToHost);
+  double cyc = 0, rt = 0;
+  for (int i = 0; i < 512; ++i) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
+  const double flops = (double)blocks * 8 * iters * 20 * 6 * 2.0 * 16 * 16 * 32;
+  const double tf = flops / (ms * 1e-3) / 1e12;
+  printf("16x16x32 mode=%d dynLDS=%d  %.3f ms  %.1f TF bf16 (%.1f fp32-equiv)  clock ~ %.0f MHz\n", MODE, dyn, ms, tf, tf / 6, cyc / rt * 100.0);
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 400;
   float *src, *out; unsigned long long* clk;
@@ -220,13 +296,13 @@ int main(int argc, char** argv) {
   for (size_t o = 0; o < abytes; o += 65536 * 4) hipMemcpy((char*)Abig + o, h.data(), std::min((size_t)65536 * 4, abytes - o), hipMemcpyHostToDevice);
   for (size_t o = 0; o < wbytes; o += 65536 * 4) hipMemcpy((char*)Wp + o, h.data(), std::min((size_t)65536 * 4, wbytes - o), hipMemcpyHostToDevice);
   const int big = 36000;   // dynamic LDS that leaves room for one block per CU only
-  run<5, 3>(src, out, clk, iters, Abig, Wp, 0, big);
-  run<5, 4>(src, out, clk, iters, Abig, Wp, 0, big);
-  run<5, 5>(src, out, clk, iters, Abig, Wp, 0, big);
-  run<5, 6>(src, out, clk, iters, Abig, Wp, 0, big);
-  run<5, 6>(src, out, clk, iters, Abig, Wp, 1, big);
-  run<5, 6>(src, out, clk, iters, Abig, Wp, 2, big);
-  run<5, 7>(src, out, clk, iters, Abig, Wp, 0, big);
-  run<5, 8>(src, out, clk, iters, Abig, Wp, 0, 0);
+  for (int rep = 0; rep < 2; ++rep) {
+    run<5, 0>(src, out, clk, iters, Abig, Wp, 0, big);
+    run16<0>(src, out, clk, iters, big);
+    run<5, 2>(src, out, clk, iters, Abig, Wp, 0, big);
+    run16<2>(src, out, clk, iters, big);
+    run<5, 2>(src, out, clk, iters, Abig, Wp, 0, 0);
+    run16<2>(src, out, clk, iters, 0);
+  }
   return 0;
 }

@@ -51,21 +51,28 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   constexpr int BM = WM * 32;
   constexpr int BN = TN * 32;
   constexpr int BK = 32;                       // two 16-k MFMA steps per slab
-  // weight stage = 3 planes x 4 k-chunks x BN rows of 16-byte slots, LDS image slot(plane, chunk, row) =
-  // (plane * 4 + chunk) * BN + row.  The slots are dealt to the threads in image order (8 consecutive lanes =
-  // 8 consecutive rows of one chunk: conflict-free ds_write_b128, whole 64-B row pieces per 4 lanes' worth
-  // of chunks on the global side); only the last round of the deal is partial.
+  // Weight stage = 3 planes x 4 k-chunks x BN rows of 16-byte slots; LDS image slot(plane, chunk, row) =
+  // (plane * 4 + chunk) * CS + row with the chunk stride CS = BN + 4 slots (= 64 B mod 256 B).  The slots are
+  // dealt to the threads row-major (4 consecutive lanes = the 4 chunks = 64 contiguous bytes of one row; a
+  // 16-lane group = 4 rows = 4 cache lines on the global side and, thanks to the chunk stride, 16 different
+  // 16-B bank groups on the LDS side).  Fragment reads stay 32 lanes x 16 B contiguous.
+  // The last round of the deal is partial: its surplus threads repeat the first slots of the deal (same
+  // source, same destination, same bytes as the owner writes), so the K loop stays ONE basic block (a
+  // branch around the store lets the compiler sink the operand split behind it, out of the MFMA shadow).
+  constexpr int CS = BN + 4;
   constexpr int NSLOT = 3 * 4 * BN;
   constexpr int NWV = (NSLOT + NT - 1) / NT;   // float4 staged per thread per slab
-  constexpr int NR = BN;
-  static_assert(NR % 16 == 0, "fragment reads need the chunk stride to be a multiple of 16 slots");
-  constexpr int TLD_ = 36;
-  // the last round of the deal is partial: its surplus threads store (duplicates of the last slot) into a
-  // tail of the buffer nobody reads, so the K loop stays ONE basic block (a branch around the store lets the
-  // compiler sink the operand split behind it, out of the MFMA shadow)
-  constexpr int STG = NWV * NT * 4;            // floats per staging buffer
-  constexpr int BUFF = (2 * STG >= WM * 32 * TLD_) ? STG : (WM * 32 * TLD_ + 1) / 2;   // room for the transpose scratch
-  __shared__ __attribute__((aligned(16))) float lds[2][BUFF];
+  constexpr int IMG = 12 * CS;
+  static_assert(NWV * NT - NSLOT <= NSLOT, "surplus threads wrap once");
+  static_assert(BN % 16 == 0, "chunk stride arithmetic assumes 16-row multiples");
+  constexpr int STG = IMG * 4;                 // floats per staging buffer
+  // Three LDS objects, so the compiler can tell their accesses apart (reads of one weight buffer, the stores
+  // into the other and the scratch traffic are free to interleave): two weight slabs, and per wave a 32 x 32
+  // fp32 scratch.  Activation slabs are fetched in whole 128-B lines (8 lanes per row) and turned into MFMA
+  // operand fragments through the scratch; the epilogue sends the output tiles the other way.
+  __shared__ __attribute__((aligned(16))) float wbuf0[STG];
+  __shared__ __attribute__((aligned(16))) float wbuf1[STG];
+  __shared__ __attribute__((aligned(16))) float ascr[WM * 1024];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -83,64 +90,67 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   const int row0 = panel * BM + wave * 32;
   const int n0 = bn * BN;
 
-  const float* arow = p.A + (int64_t)min(row0 + li, p.M - 1) * p.lda;
-  // activation fragment of 16-k step s: 8 consecutive fp32 A[row][k0 + 16 s + 8 h .. +7]
-  // PRO: A' = A / pre_div - pre_sub in the operand registers, before the split (ScaleTransform.backward +
-  // bias of the tail affine layer, transforms.py:116-125, 960)
+  // ---- activations: lane = (row ar + 8 i, 16-B chunk ac) of the wave's 32 x 32 slab, i = 0..3 ----
+  const int ar = lane >> 3, ac = lane & 7;
+  const float* arow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) arow[i] = p.A + (int64_t)min(row0 + ar + 8 * i, p.M - 1) * p.lda;
+  // PRO: A' = A / pre_div - pre_sub before the split (ScaleTransform.backward + bias of the tail affine
+  // layer, transforms.py:116-125, 960); one k-chunk per lane serves its four rows
   const float* pdiv = p.pre_div ? p.pre_div : p.pre_sub;
   const float* psub = p.pre_sub ? p.pre_sub : p.pre_div;
   const bool has_div = p.pre_div != nullptr, has_sub = p.pre_sub != nullptr;
   const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
-  constexpr int NPRO = PRO ? 4 : 1;
-  f32x4 dvr[NPRO], svr[NPRO];
+  f32x4 dvr = one4, svr = zero4;
   auto issue_a = [&](int k0, f32x4 (&dst)[4]) {
+    const int kc = min(k0 + 4 * ac, p.K - 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc);
+    if (PRO) {
+      dvr = *reinterpret_cast<const f32x4*>(pdiv + kc);
+      svr = *reinterpret_cast<const f32x4*>(psub + kc);
+    }
+  };
+  // scratch image: row r = 32 floats, its 16-B chunk c stored at position c ^ ((r >> 1) & 7): the line-shaped
+  // writes (8 lanes per row) and the fragment-shaped reads (one row per lane) are both bank-conflict free
+  float* const scr = ascr + wave * 1024;
+  auto transpose_a = [&](int k0, f32x4 (&src)[4], f32x4 (&frag)[4]) {
+    const bool live = k0 + 4 * ac < p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = src[i];
+      if (PRO) v = v / (has_div ? dvr : one4) - (has_sub ? svr : zero4);
+      v = live ? v : zero4;
+      const int r = ar + 8 * i;
+      *reinterpret_cast<f32x4*>(scr + r * 32 + 4 * (ac ^ ((r >> 1) & 7))) = v;
+    }
+    // fragment of 16-k step s: k = 16 s + 8 lh + (0..7) = chunks 4 s + 2 lh + u
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int kc = min(k0 + 16 * s + 8 * lh + 4 * u, p.K - 4);
-        dst[2 * s + u] = *reinterpret_cast<const f32x4*>(arow + kc);
-        if (PRO) {
-          dvr[2 * s + u] = *reinterpret_cast<const f32x4*>(pdiv + kc);
-          svr[2 * s + u] = *reinterpret_cast<const f32x4*>(psub + kc);
-        }
-      }
+      for (int u = 0; u < 2; ++u)
+        frag[2 * s + u] = *reinterpret_cast<const f32x4*>(scr + li * 32 + 4 * ((4 * s + 2 * lh + u) ^ ((li >> 1) & 7)));
   };
-  auto finish_a = [&](int k0, f32x4 (&dst)[4]) {
+
+  // ---- weights ----
+  const __bf16* wsrc[NWV];
+  int wdst[NWV];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (PRO) dst[2 * s + u] = dst[2 * s + u] / (has_div ? dvr[2 * s + u] : one4) - (has_sub ? svr[2 * s + u] : zero4);
-        dst[2 * s + u] = (k0 + 16 * s + 8 * lh + 4 * u < p.K) ? dst[2 * s + u] : zero4;
-      }
-  };
-  // deal: 32 consecutive lanes take 8 rows x 4 chunks (64 contiguous bytes per row on the global side; 8
-  // consecutive lanes = 8 consecutive rows of one chunk on the LDS side); groups run over (plane, 8-row group)
-  constexpr int NRG = BN / 8;                  // 8-row groups per plane
-  auto slot_of = [&](int idx, int& plane, int& chunk, int& row) {
-    const int g32 = idx >> 5;
-    plane = g32 / NRG;
-    row = (g32 % NRG) * 8 + (idx & 7);
-    chunk = (idx >> 3) & 3;
-  };
+  for (int i = 0; i < NWV; ++i) {
+    const int idx = tid + NT * i;
+    const int idc = (idx < NSLOT) ? idx : idx - NSLOT;
+    const int pl = idc / (4 * BN), rem = idc % (4 * BN);
+    const int r = rem >> 2, ch = rem & 3;
+    wsrc[i] = p.Wp + pl * p.plane_stride + (int64_t)min(n0 + r, p.N - 1) * p.ldwp + 8 * ch;
+    wdst[i] = 4 * ((pl * 4 + ch) * CS + r);
+  }
   auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) {
-      int pl, ch, r;
-      slot_of(min(tid + NT * i, NSLOT - 1), pl, ch, r);    // (last round: duplicates, never stored)
-      const int n = min(n0 + r, p.N - 1);
-      dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + pl * p.plane_stride + (int64_t)n * p.ldwp + k0 + 8 * ch);
-    }
+    for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
   };
-  auto store_w = [&](int buf, const f32x4 (&src)[NWV]) {
+  auto store_w = [&](float* wb, const f32x4 (&src)[NWV]) {
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) {
-      int pl, ch, r;
-      slot_of(tid + NT * i, pl, ch, r);
-      const int sl = (tid + NT * i < NSLOT) ? (pl * 4 + ch) * BN + r : tid + NT * i;
-      *reinterpret_cast<f32x4*>(&lds[buf][4 * sl]) = src[i];
-    }
+    for (int i = 0; i < NWV; ++i) *reinterpret_cast<f32x4*>(wb + wdst[i]) = src[i];
   };
 
   // accumulators (C^T: batch row on the lane, 4 consecutive output features per register group) start at the bias
@@ -170,31 +180,31 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 #define BSTAMP(v)
 #endif
   BSTAMP(b0);
-  // operand planes of the current slab (2 steps x 3 planes) are kept split; the NEXT slab's fp32 fragments
-  // are split while the second 16-k step of the current slab multiplies (VALU beside MFMA in one wave)
+  // Pipeline: weights of slab s+1 are fetched during step 0 of slab s and stored behind its step 1; the
+  // activation lines of slab s+2 are fetched during step 1 of slab s, right after the lines of slab s+1 went
+  // through the scratch -- a full slab of latency cover; slab s+1's operand planes are split (VALU) in the
+  // shadow of step 1's MFMAs.
   bf16x8 pc[2][3], pn[2][3];
-  f32x4 a_nxt[4];
+  f32x4 a_nxt[4], af[4];
   f32x4 wst[NWV];
   const int nslab = (p.K + BK - 1) / BK;
   issue_w(0, wst);
   issue_a(0, a_nxt);
-  finish_a(0, a_nxt);
-  split3(a_nxt[0], a_nxt[1], pc[0][0], pc[0][1], pc[0][2]);
-  split3(a_nxt[2], a_nxt[3], pc[1][0], pc[1][1], pc[1][2]);
-  store_w(0, wst);
+  transpose_a(0, a_nxt, af);
+  __builtin_amdgcn_sched_barrier(0);
+  issue_a(BK, a_nxt);
+  split3(af[0], af[1], pc[0][0], pc[0][1], pc[0][2]);
+  split3(af[2], af[3], pc[1][0], pc[1][1], pc[1][2]);
+  store_w(wbuf0, wst);
   __syncthreads();
 
-  auto compute_step = [&](int buf, int s) {
-    const float* wl = &lds[buf][4 * (lh * NR + li)];
+  auto compute_step = [&](const float* rb, int s) {
+    const float* wl = rb + 4 * (lh * CS + li);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-#if defined(USF_ABL3) && (USF_ABL3 & 1)      // tuning: no LDS fragment reads
-      const bf16x8 w1 = pc[s][0], w2 = pc[s][1], w3 = pc[s][2];
-#else
-      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4 + 2 * s) * NR + tn * 32));
-      const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4 + 2 * s) * NR + tn * 32));
-      const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4 + 2 * s) * NR + tn * 32));
-#endif
+      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4 + 2 * s) * CS + tn * 32));
+      const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4 + 2 * s) * CS + tn * 32));
+      const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4 + 2 * s) * CS + tn * 32));
       // smallest terms first
       acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, pc[s][0], acc[tn], 0, 0, 0);
       acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, pc[s][1], acc[tn], 0, 0, 0);
@@ -204,28 +214,39 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][0], acc[tn], 0, 0, 0);
     }
   };
-  // reads one tile ahead of the MFMAs that use them; VALU = the next slab's operand split, spread between tiles
-#define USF_PIN_STEP(VALU_PER_TILE)                                                   \
-  do {                                                                                \
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                \
-    _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_) {                            \
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                              \
-      if (tn_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);            \
-      if ((VALU_PER_TILE) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (VALU_PER_TILE), 0); \
-    }                                                                                 \
+  // Issue order pins (masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write).
+  // Weight fragments are read one tile ahead of the MFMAs that use them.
+  //  * step 0 carries the next slab's weight loads, dealt over its tiles (issued as one burst behind the
+  //    barrier the block's loads queue in the address unit for ~2000 cycles while no wave reaches an MFMA),
+  //    the scratch round trip of the next activation slab and, once that has freed the registers, the
+  //    activation loads of the slab after it (a full slab of latency cover);
+  //  * step 1 carries the operand split of the next slab (VALU in the MFMA shadow).
+  constexpr int LPT0 = (NWV + TN - 1) / TN;
+  constexpr int T_SW = (TN >= 4) ? 1 : 0;                        // tile that carries the scratch writes
+  constexpr int T_SR = T_SW + 1;                                 // ... the scratch fragment reads
+  constexpr int T_LA = (T_SR + 1 < TN) ? T_SR + 1 : T_SR;        // ... the activation loads
+  constexpr int NLA = PRO ? 6 : 4;
+  constexpr int VPT = (120 + TN - 1) / TN;
+#define USF_PIN_STEP0()                                                                           \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
+    _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                          \
+      if (f_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
+      __builtin_amdgcn_sched_group_barrier(0x020, LPT0, 0);                                       \
+      if (f_ == T_SW) __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);                          \
+      if (f_ == T_SR) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                          \
+      if (f_ == T_LA) __builtin_amdgcn_sched_group_barrier(0x020, NLA, 0);                        \
+    }                                                                                             \
   } while (0)
-
-  // step 0: as above, plus VMEM reads dealt over the tiles
-  constexpr int NLD = NWV + (PRO ? 12 : 4);
-  constexpr int LPT = (NLD + TN - 1) / TN;
-#define USF_PIN_STEP0()                                                               \
-  do {                                                                                \
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                \
-    _Pragma("unroll") for (int tn_ = 0; tn_ < TN; ++tn_) {                            \
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                              \
-      if (tn_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);            \
-      __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);                            \
-    }                                                                                 \
+#define USF_PIN_STEP1()                                                                           \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
+    _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                          \
+      if (f_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
+      __builtin_amdgcn_sched_group_barrier(0x002, VPT, 0);                                        \
+    }                                                                                             \
   } while (0)
 
   BSTAMP(b1);
@@ -237,36 +258,22 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 #define LSTAMP(v)
 #define LACC(i, a, b)
 #endif
-  for (int s = 0; s + 1 < nslab; ++s) {
-    const int buf = s & 1;
-    const int k1 = (s + 1) * BK;
+  auto slab = [&](const float* rb, float* wb, int k1) {
     LSTAMP(l0);
-    // the next slab's global loads are dealt out between the tiles of step 0 (activation fragments first:
-    // the split in step 1 wants them): issued as one burst behind the barrier, the 8 waves' 64 loads queue
-    // in the address unit for ~2000 cycles during which no wave reaches its first MFMA
-#if !(defined(USF_ABL3) && (USF_ABL3 & 4))   // tuning: no global loads in the loop
-    issue_a(k1, a_nxt);
     issue_w(k1, wst);
-#endif
-    compute_step(buf, 0);
+    compute_step(rb, 0);
+    transpose_a(k1, a_nxt, af);
+    issue_a(k1 + BK, a_nxt);
     USF_PIN_STEP0();
     __builtin_amdgcn_sched_barrier(0);
     LSTAMP(l2);
-#if defined(USF_ABL3) && (USF_ABL3 & 2)      // tuning: no operand split in the loop
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) pn[q][pl] = pc[q][pl];
-#else
-    finish_a(k1, a_nxt);
-    split3(a_nxt[0], a_nxt[1], pn[0][0], pn[0][1], pn[0][2]);
-    split3(a_nxt[2], a_nxt[3], pn[1][0], pn[1][1], pn[1][2]);
-#endif
-    compute_step(buf, 1);
-    USF_PIN_STEP(24);
+    split3(af[0], af[1], pn[0][0], pn[0][1], pn[0][2]);
+    split3(af[2], af[3], pn[1][0], pn[1][1], pn[1][2]);
+    compute_step(rb, 1);
+    USF_PIN_STEP1();
     __builtin_amdgcn_sched_barrier(0);
     LSTAMP(l3);
-    store_w(buf ^ 1, wst);
+    store_w(wb, wst);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -276,18 +283,22 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     __syncthreads();
     LSTAMP(l5);
     LACC(1, l0, l2); LACC(2, l2, l3); LACC(3, l3, l4); LACC(4, l4, l5);
+  };
+  int s = 0;
+  for (; s + 2 < nslab; s += 2) {
+    slab(wbuf0, wbuf1, (s + 1) * BK);
+    slab(wbuf1, wbuf0, (s + 2) * BK);
   }
+  if (s + 1 < nslab) { slab(wbuf0, wbuf1, (s + 1) * BK); ++s; }
   BSTAMP(b2);
-  compute_step((nslab - 1) & 1, 0);  // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
-  compute_step((nslab - 1) & 1, 1);
+  // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
+  if (s & 1) { compute_step(wbuf1, 0); compute_step(wbuf1, 1); }
+  else { compute_step(wbuf0, 0); compute_step(wbuf0, 1); }
 
   BSTAMP(b3);
-  // ---- epilogue: transpose each 32x32 tile through a per-wave LDS scratch -> whole-cache-line stores ----
-  constexpr int TLD = 36;
-  static_assert(2 * BUFF >= WM * 32 * TLD && TLD == TLD_, "transpose scratch must fit the staging buffers");
-  float* tw = &lds[0][0] + wave * (32 * TLD);
+  // ---- epilogue: transpose each 32x32 tile through the wave's LDS scratch -> whole-cache-line stores ----
+  float* tw = scr;                   // same swizzled 32 x 32 image as the activation path, the other way round
   const int rr = lane >> 3, cc = 4 * (lane & 7);
-  __syncthreads();                   // every wave is done reading the last weight slab
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
@@ -295,14 +306,14 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[tn][4 * g4 + j];
-      *reinterpret_cast<f32x4*>(tw + li * TLD + 8 * g4 + 4 * lh) = v;
+      *reinterpret_cast<f32x4*>(tw + li * 32 + 4 * ((2 * g4 + lh) ^ ((li >> 1) & 7))) = v;
     }
     // everything element-wise happens after the transpose, where a lane owns 4 consecutive features of a
     // row and the wave touches whole cache lines (addend / residual are read the same way)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 8 * i;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * TLD + cc);
+      f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * 32 + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
       const int row = row0 + r;
       const int col = n0 + tn * 32 + cc;
       const int rowc = min(row, p.M - 1), colc = min(col, p.N - 4);
