@@ -1,5 +1,6 @@
 // Split-precision variant of the fused dense layer:  C = A @ W^T + bias  with fp32-equivalent accuracy on
-// the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate).
+// the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, 16x the f32 MFMA rate; on random data the chip holds a ~17 %
+// higher clock on this shape than on 32x32x16 at equal cycles per flop -- tools/exp_mfma_peak.hip).
 //
 // Every fp32 operand is written as the exact sum of three bf16 numbers (round-to-nearest residual split:
 // x = x1 + x2 + x3, 8 + 8 + 8 significant bits) and the product is expanded, keeping the six terms whose
@@ -45,7 +46,7 @@ __device__ __forceinline__ void split3(const f32x4 x0, const f32x4 x1, bf16x8& p
   }
 }
 
-template <int TN, int WM, bool PRO>
+template <int TN, int WM, bool PRO, int NB>
 __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Args p) {
   constexpr int NT = WM * 64;
   constexpr int BM = WM * 32;
@@ -64,21 +65,23 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   constexpr int NWV = (NSLOT + NT - 1) / NT;   // float4 staged per thread per slab
   constexpr int IMG = 12 * CS;
   static_assert(NWV * NT - NSLOT <= NSLOT, "surplus threads wrap once");
-  static_assert(BN % 16 == 0, "chunk stride arithmetic assumes 16-row multiples");
+  static_assert(BN % 32 == 0, "chunk stride arithmetic assumes 16-row multiples");
   constexpr int STG = IMG * 4;                 // floats per staging buffer
-  // Three LDS objects, so the compiler can tell their accesses apart (reads of one weight buffer, the stores
-  // into the other and the scratch traffic are free to interleave): two weight slabs, and per wave a 32 x 32
-  // fp32 scratch.  Activation slabs are fetched in whole 128-B lines (8 lanes per row) and turned into MFMA
-  // operand fragments through the scratch; the epilogue sends the output tiles the other way.
-  __shared__ __attribute__((aligned(16))) float wbuf0[STG];
-  __shared__ __attribute__((aligned(16))) float wbuf1[STG];
+  // Weight slabs live in a ring of NB buffers: slab s + NB/2 is staged while slab s multiplies, and the block
+  // meets at a barrier once per NB/2 slabs (NB = 4: every second slab -- with one 8-wave block per CU the pipe
+  // idles ~900 cycles around each barrier).  The scratch is a separate LDS object so the compiler can tell its
+  // traffic from the ring's.  Activation slabs are fetched in whole 128-B lines (8 lanes per row) and turned
+  // into MFMA operand fragments through the scratch; the epilogue sends the output tiles the other way.
+  static_assert(NB == 2 || NB == 4, "ring of 2 or 4 weight buffers");
+  constexpr int D = NB / 2;
+  __shared__ __attribute__((aligned(16))) float wring[NB * STG];
   __shared__ __attribute__((aligned(16))) float ascr[WM * 1024];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int li = lane & 31;
-  const int lh = lane >> 5;
+  const int lj = lane & 15;                    // MFMA 16x16x32: lane = (row-in-tile j, k-group g)
+  const int lg = lane >> 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   const int bid = blockIdx.x;
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 
   // ---- activations: lane = (row ar + 8 i, 16-B chunk ac) of the wave's 32 x 32 slab, i = 0..3 ----
   const int ar = lane >> 3, ac = lane & 7;
-  const float* arow[4];
+  unsigned arow[4];                            // element offsets from p.A (the dispatcher checks they fit 32 bits)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) arow[i] = p.A + (int64_t)min(row0 + ar + 8 * i, p.M - 1) * p.lda;
+  for (int i = 0; i < 4; ++i) arow[i] = (unsigned)min(row0 + ar + 8 * i, p.M - 1) * (unsigned)p.lda;
   // PRO: A' = A / pre_div - pre_sub before the split (ScaleTransform.backward + bias of the tail affine
   // layer, transforms.py:116-125, 960); one k-chunk per lane serves its four rows
   const float* pdiv = p.pre_div ? p.pre_div : p.pre_sub;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   auto issue_a = [&](int k0, f32x4 (&dst)[4]) {
     const int kc = min(k0 + 4 * ac, p.K - 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(arow[i] + kc);
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.A + (arow[i] + (unsigned)kc));
     if (PRO) {
       dvr = *reinterpret_cast<const f32x4*>(pdiv + kc);
       svr = *reinterpret_cast<const f32x4*>(psub + kc);
@@ -124,16 +127,18 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       const int r = ar + 8 * i;
       *reinterpret_cast<f32x4*>(scr + r * 32 + 4 * (ac ^ ((r >> 1) & 7))) = v;
     }
-    // fragment of 16-k step s: k = 16 s + 8 lh + (0..7) = chunks 4 s + 2 lh + u
+    // operand fragment of batch tile b (16 rows): lane (j, g) holds row 16 b + j, k = 8 g + (0..7) = chunks 2 g + u
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        frag[2 * s + u] = *reinterpret_cast<const f32x4*>(scr + li * 32 + 4 * ((4 * s + 2 * lh + u) ^ ((li >> 1) & 7)));
+      for (int u = 0; u < 2; ++u) {
+        const int r = 16 * b + lj;
+        frag[2 * b + u] = *reinterpret_cast<const f32x4*>(scr + r * 32 + 4 * ((2 * lg + u) ^ ((r >> 1) & 7)));
+      }
   };
 
   // ---- weights ----
-  const __bf16* wsrc[NWV];
+  unsigned wsrc[NWV];                          // element offsets from p.Wp
   int wdst[NWV];
 #pragma unroll
   for (int i = 0; i < NWV; ++i) {
@@ -141,12 +146,12 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     const int idc = (idx < NSLOT) ? idx : idx - NSLOT;
     const int pl = idc / (4 * BN), rem = idc % (4 * BN);
     const int r = rem >> 2, ch = rem & 3;
-    wsrc[i] = p.Wp + pl * p.plane_stride + (int64_t)min(n0 + r, p.N - 1) * p.ldwp + 8 * ch;
+    wsrc[i] = (unsigned)(pl * p.plane_stride + (int64_t)min(n0 + r, p.N - 1) * p.ldwp + 8 * ch);
     wdst[i] = 4 * ((pl * 4 + ch) * CS + r);
   }
   auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(wsrc[i] + k0);
+    for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + (wsrc[i] + (unsigned)k0));
   };
   auto store_w = [&](float* wb, const f32x4 (&src)[NWV]) {
 #pragma unroll
@@ -155,24 +160,23 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 
   // accumulators (C^T: batch row on the lane, 4 consecutive output features per register group) start at the bias
   const bool has_bias = p.bias != nullptr, has_pm = p.post_mul != nullptr;
-  f32x16 acc[TN];
+  constexpr int FT = BN / 16;                  // 16-feature tiles per wave; each against 2 batch tiles of 16 rows
+  f32x4 acc[FT][2];
 #pragma unroll
-  for (int tn = 0; tn < TN; ++tn)
+  for (int ft = 0; ft < FT; ++ft) {
+    const int col = n0 + ft * 16 + 4 * lg;
+    f32x4 bv = zero4;
+    if (has_bias) {
+      if (p.bias_vec) {
+        bv = *reinterpret_cast<const f32x4*>(p.bias + min(col, p.N - 4));
+      } else {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int col = n0 + tn * 32 + 8 * g4 + 4 * lh;
-      f32x4 bv = zero4;
-      if (has_bias) {
-        if (p.bias_vec) {
-          bv = *reinterpret_cast<const f32x4*>(p.bias + min(col, p.N - 4));
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[j] = p.bias[min(col + j, p.N - 1)];
-        }
+        for (int j = 0; j < 4; ++j) bv[j] = p.bias[min(col + j, p.N - 1)];
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[tn][4 * g4 + j] = bv[j];
     }
+    acc[ft][0] = bv;
+    acc[ft][1] = bv;
+  }
 
 #ifdef USF_STAMP
 #define BSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
@@ -188,30 +192,34 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   f32x4 a_nxt[4], af[4];
   f32x4 wst[NWV];
   const int nslab = (p.K + BK - 1) / BK;
-  issue_w(0, wst);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    issue_w(min(d, nslab - 1) * BK, wst);
+    store_w(wring + d * STG, wst);
+  }
   issue_a(0, a_nxt);
   transpose_a(0, a_nxt, af);
   __builtin_amdgcn_sched_barrier(0);
   issue_a(BK, a_nxt);
   split3(af[0], af[1], pc[0][0], pc[0][1], pc[0][2]);
   split3(af[2], af[3], pc[1][0], pc[1][1], pc[1][2]);
-  store_w(wbuf0, wst);
   __syncthreads();
 
-  auto compute_step = [&](const float* rb, int s) {
-    const float* wl = rb + 4 * (lh * CS + li);
+  // half h of the slab's feature tiles: per tile 3 weight-plane fragments (lane (j, g): row 16 ft + j, k-chunk g)
+  // against both batch tiles, smallest terms first; the two batch tiles alternate, so consecutive MFMAs are
+  // independent
+  auto compute_half = [&](const float* rb, int h) {
+    const float* wl = rb + 4 * (lg * CS + lj);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4 + 2 * s) * CS + tn * 32));
-      const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4 + 2 * s) * CS + tn * 32));
-      const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4 + 2 * s) * CS + tn * 32));
-      // smallest terms first
-      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, pc[s][0], acc[tn], 0, 0, 0);
-      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, pc[s][1], acc[tn], 0, 0, 0);
-      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][2], acc[tn], 0, 0, 0);
-      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, pc[s][0], acc[tn], 0, 0, 0);
-      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][1], acc[tn], 0, 0, 0);
-      acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pc[s][0], acc[tn], 0, 0, 0);
+    for (int ft = h * (FT / 2); ft < (h + 1) * (FT / 2); ++ft) {
+      const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + ft * 16));
+      const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + ft * 16));
+      const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + ft * 16));
+#define USF_MM(W, P)                                                                              \
+      acc[ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[0][P], acc[ft][0], 0, 0, 0);     \
+      acc[ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[1][P], acc[ft][1], 0, 0, 0)
+      USF_MM(w3, 0); USF_MM(w2, 1); USF_MM(w1, 2); USF_MM(w2, 0); USF_MM(w1, 1); USF_MM(w1, 0);
+#undef USF_MM
     }
   };
   // Issue order pins (masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write).
@@ -221,30 +229,31 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   //    the scratch round trip of the next activation slab and, once that has freed the registers, the
   //    activation loads of the slab after it (a full slab of latency cover);
   //  * step 1 carries the operand split of the next slab (VALU in the MFMA shadow).
-  constexpr int LPT0 = (NWV + TN - 1) / TN;
-  constexpr int T_SW = (TN >= 4) ? 1 : 0;                        // tile that carries the scratch writes
+  constexpr int HT = FT / 2;                                     // tiles per half
+  constexpr int LPT0 = (NWV + HT - 1) / HT;
+  constexpr int T_SW = (HT >= 4) ? 1 : 0;                        // tile that carries the scratch writes
   constexpr int T_SR = T_SW + 1;                                 // ... the scratch fragment reads
-  constexpr int T_LA = (T_SR + 1 < TN) ? T_SR + 1 : T_SR;        // ... the activation loads
+  constexpr int T_LA = (T_SR + 1 < HT) ? T_SR + 1 : T_SR;        // ... the activation loads
   constexpr int NLA = PRO ? 6 : 4;
-  constexpr int VPT = (120 + TN - 1) / TN;
-#define USF_PIN_STEP0()                                                                           \
+  constexpr int VPT = (120 + HT - 1) / HT;
+#define USF_PIN_HALF0()                                                                           \
   do {                                                                                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
-    _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_) {                                           \
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                          \
-      if (f_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
+    _Pragma("unroll") for (int f_ = 0; f_ < HT; ++f_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                         \
+      if (f_ + 2 < HT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
       __builtin_amdgcn_sched_group_barrier(0x020, LPT0, 0);                                       \
       if (f_ == T_SW) __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);                          \
       if (f_ == T_SR) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                          \
       if (f_ == T_LA) __builtin_amdgcn_sched_group_barrier(0x020, NLA, 0);                        \
     }                                                                                             \
   } while (0)
-#define USF_PIN_STEP1()                                                                           \
+#define USF_PIN_HALF1()                                                                           \
   do {                                                                                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
-    _Pragma("unroll") for (int f_ = 0; f_ < TN; ++f_) {                                           \
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                          \
-      if (f_ + 2 < TN) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
+    _Pragma("unroll") for (int f_ = 0; f_ < HT; ++f_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                         \
+      if (f_ + 2 < HT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
       __builtin_amdgcn_sched_group_barrier(0x002, VPT, 0);                                        \
     }                                                                                             \
   } while (0)
@@ -258,19 +267,23 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 #define LSTAMP(v)
 #define LACC(i, a, b)
 #endif
-  auto slab = [&](const float* rb, float* wb, int k1) {
+  for (int s = 0; s + 1 < nslab; ++s) {
+    const float* rb = wring + (s % NB) * STG;
+    float* wb = wring + ((s + D) % NB) * STG;
+    const int kw = min(s + D, nslab - 1) * BK;
+    const int k1 = (s + 1) * BK;
     LSTAMP(l0);
-    issue_w(k1, wst);
-    compute_step(rb, 0);
+    issue_w(kw, wst);
+    compute_half(rb, 0);
     transpose_a(k1, a_nxt, af);
     issue_a(k1 + BK, a_nxt);
-    USF_PIN_STEP0();
+    USF_PIN_HALF0();
     __builtin_amdgcn_sched_barrier(0);
     LSTAMP(l2);
     split3(af[0], af[1], pn[0][0], pn[0][1], pn[0][2]);
     split3(af[2], af[3], pn[1][0], pn[1][1], pn[1][2]);
-    compute_step(rb, 1);
-    USF_PIN_STEP1();
+    compute_half(rb, 1);
+    USF_PIN_HALF1();
     __builtin_amdgcn_sched_barrier(0);
     LSTAMP(l3);
     store_w(wb, wst);
@@ -280,20 +293,17 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       for (int pl = 0; pl < 3; ++pl) pc[q][pl] = pn[q][pl];
     __builtin_amdgcn_sched_barrier(0);
     LSTAMP(l4);
-    __syncthreads();
+    if (D == 1 || ((s + 1) % D) == 0) __syncthreads();
     LSTAMP(l5);
     LACC(1, l0, l2); LACC(2, l2, l3); LACC(3, l3, l4); LACC(4, l4, l5);
-  };
-  int s = 0;
-  for (; s + 2 < nslab; s += 2) {
-    slab(wbuf0, wbuf1, (s + 1) * BK);
-    slab(wbuf1, wbuf0, (s + 2) * BK);
   }
-  if (s + 1 < nslab) { slab(wbuf0, wbuf1, (s + 1) * BK); ++s; }
   BSTAMP(b2);
   // (K tail: the planes are zero-padded to 32, the fragments zero-selected)
-  if (s & 1) { compute_step(wbuf1, 0); compute_step(wbuf1, 1); }
-  else { compute_step(wbuf0, 0); compute_step(wbuf0, 1); }
+  {
+    const float* rb = wring + ((nslab - 1) % NB) * STG;
+    compute_half(rb, 0);
+    compute_half(rb, 1);
+  }
 
   BSTAMP(b3);
   // ---- epilogue: transpose each 32x32 tile through the wave's LDS scratch -> whole-cache-line stores ----
@@ -301,13 +311,14 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   const int rr = lane >> 3, cc = 4 * (lane & 7);
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
+    // lane (j, g) of feature tile ft, batch tile b holds features 16 ft + 4 g + (0..3) of batch row 16 b + j
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      f32x4 v;
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[tn][4 * g4 + j];
-      *reinterpret_cast<f32x4*>(tw + li * 32 + 4 * ((2 * g4 + lh) ^ ((li >> 1) & 7))) = v;
-    }
+      for (int b = 0; b < 2; ++b) {
+        const int r = 16 * b + lj;
+        *reinterpret_cast<f32x4*>(tw + r * 32 + 4 * ((4 * q + lg) ^ ((r >> 1) & 7))) = acc[2 * tn + q][b];
+      }
     // everything element-wise happens after the transpose, where a lane owns 4 consecutive features of a
     // row and the wave touches whole cache lines (addend / residual are read the same way)
 #pragma unroll
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 unsigned long long* g_bdbg = nullptr;
 #endif
 
-template <int TN, int WM>
+template <int TN, int WM, int NB>
 static int launch3(Lin3Args a, hipStream_t stream) {
   const bool pro = a.pre_div != nullptr || a.pre_sub != nullptr;
   constexpr int BM = WM * 32, BN = TN * 32;
@@ -357,8 +368,8 @@ static int launch3(Lin3Args a, hipStream_t stream) {
   a.nbn = (a.N + BN - 1) / BN;
   const int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
   if (grid > 0x7fffffffLL) { set_error("usf_linear_f32(bf16x3): grid too large"); return -3; }
-  if (pro) hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, true>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
-  else hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, false>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  if (pro) hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, true, NB>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  else hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, false, NB>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
   return check_launch("usf_linear_f32(bf16x3)");
 }
 
@@ -370,7 +381,8 @@ bool linear_bf16x3_eligible(const usf_linear_desc* d) {
          (!d->post_mul || aligned16(d->post_mul)) &&
          (!d->pre_div || aligned16(d->pre_div)) && (!d->pre_sub || aligned16(d->pre_sub)) &&
          (d->ldc & 3) == 0 && aligned16(d->C) && aligned16(d->W_split) && (d->ldw_split & 7) == 0 &&
-         d->ldw_split >= ((d->K + 31) / 32) * 32 && d->M > 64 && d->N > 64;
+         d->ldw_split >= ((d->K + 31) / 32) * 32 && d->M > 64 && d->N > 64 &&
+         d->M * d->lda < (1LL << 31) && 3 * d->split_plane_stride < (1LL << 31);   // 32-bit element offsets
 }
 
 int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
@@ -394,9 +406,9 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (wm4 < 0) { const char* e = getenv("USF_BF16X3_WM"); wm4 = (e && atoi(e) == 4) ? 1 : 0; }
   // small batches are latency-bound by one block's serial K loop: narrow column blocks (64 wide) shorten the
   // per-slab MFMA chain 2.5x and put 2.5x more blocks on the chip
-  if ((int64_t)((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) return launch3<2, 4>(a, stream);
-  if (pad160 < pad128) return (a.M >= 2048 && !wm4) ? launch3<5, 8>(a, stream) : launch3<5, 4>(a, stream);
-  return launch3<4, 4>(a, stream);
+  if ((int64_t)((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) return launch3<2, 4, 2>(a, stream);
+  if (pad160 < pad128) return (a.M >= 2048 && !wm4) ? launch3<5, 8, 4>(a, stream) : launch3<5, 4, 2>(a, stream);
+  return launch3<4, 4, 2>(a, stream);
 }
 
 }  // namespace usf
