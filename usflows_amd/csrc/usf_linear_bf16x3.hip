@@ -52,15 +52,17 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   constexpr int BM = WM * 32;
   constexpr int BN = TN * 32;
   constexpr int BK = 32;                       // two 16-k MFMA steps per slab
-  // Weight stage = 3 planes x 4 k-chunks x BN rows of 16-byte slots; LDS image slot(plane, chunk, row) =
-  // (plane * 4 + chunk) * CS + row with the chunk stride CS = BN + 4 slots (= 64 B mod 256 B).  The slots are
-  // dealt to the threads row-major (4 consecutive lanes = the 4 chunks = 64 contiguous bytes of one row; a
-  // 16-lane group = 4 rows = 4 cache lines on the global side and, thanks to the chunk stride, 16 different
-  // 16-B bank groups on the LDS side).  Fragment reads stay 32 lanes x 16 B contiguous.
+  // Weight stage = 3 planes x 4 k-chunks x BN rows of 16-byte slots; LDS image slot(plane, chunk c, row r) =
+  // (plane * 4 + c) * BN + (r ^ 2c).  The chunk stride is a multiple of 256 B, which is what the lane groups
+  // of ds_read_b128 ({0-3,12-15,20-27}, ...) want from the MFMA fragment pattern (lane (j, g) reads row
+  // 16 ft + j of chunk g: conflict free).  The slots are dealt to the threads row-major (4 consecutive lanes =
+  // the 4 chunks = 64 contiguous bytes of one row; a 16-lane group = 4 cache lines for the address unit), and
+  // the XOR keeps those stores conflict free as well: the 8 lanes of a ds_write_b128 group (2 rows x 4 chunks)
+  // land on 8 different 16-B bank groups.
   // The last round of the deal is partial: its surplus threads repeat the first slots of the deal (same
   // source, same destination, same bytes as the owner writes), so the K loop stays ONE basic block (a
   // branch around the store lets the compiler sink the operand split behind it, out of the MFMA shadow).
-  constexpr int CS = BN + 4;
+  constexpr int CS = BN;
   constexpr int NSLOT = 3 * 4 * BN;
   constexpr int NWV = (NSLOT + NT - 1) / NT;   // float4 staged per thread per slab
   constexpr int IMG = 12 * CS;
@@ -114,8 +116,11 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       svr = *reinterpret_cast<const f32x4*>(psub + kc);
     }
   };
-  // scratch image: row r = 32 floats, its 16-B chunk c stored at position c ^ ((r >> 1) & 7): the line-shaped
-  // writes (8 lanes per row) and the fragment-shaped reads (one row per lane) are both bank-conflict free
+  // scratch image: row r = 32 floats, its 16-B chunk c stored at position c ^ swz(r), swz a bit shuffle of
+  // h = (r >> 1) & 7: (h2 ^ h1, h0, h1).  With the lane groups ds_read_b128 / ds_write_b128 are served in, the
+  // line-shaped accesses (8 lanes per row) and the fragment-shaped ones (one row per lane, k-chunk by lane >> 4)
+  // are conflict free in both directions (activations in, output tiles out).
+  auto swz = [](int r) { const int h = r >> 1; return (((h >> 2) ^ (h >> 1)) & 1) | ((h & 1) << 1) | (((h >> 1) & 1) << 2); };
   float* const scr = ascr + wave * 1024;
   auto transpose_a = [&](int k0, f32x4 (&src)[4], f32x4 (&frag)[4]) {
     const bool live = k0 + 4 * ac < p.K;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       if (PRO) v = v / (has_div ? dvr : one4) - (has_sub ? svr : zero4);
       v = live ? v : zero4;
       const int r = ar + 8 * i;
-      *reinterpret_cast<f32x4*>(scr + r * 32 + 4 * (ac ^ ((r >> 1) & 7))) = v;
+      *reinterpret_cast<f32x4*>(scr + r * 32 + 4 * (ac ^ swz(r))) = v;
     }
     // operand fragment of batch tile b (16 rows): lane (j, g) holds row 16 b + j, k = 8 g + (0..7) = chunks 2 g + u
 #pragma unroll
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int r = 16 * b + lj;
-        frag[2 * b + u] = *reinterpret_cast<const f32x4*>(scr + r * 32 + 4 * ((2 * lg + u) ^ ((r >> 1) & 7)));
+        frag[2 * b + u] = *reinterpret_cast<const f32x4*>(scr + r * 32 + 4 * ((2 * lg + u) ^ swz(r)));
       }
   };
 
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     const int pl = idc / (4 * BN), rem = idc % (4 * BN);
     const int r = rem >> 2, ch = rem & 3;
     wsrc[i] = (unsigned)(pl * p.plane_stride + (int64_t)min(n0 + r, p.N - 1) * p.ldwp + 8 * ch);
-    wdst[i] = 4 * ((pl * 4 + ch) * CS + r);
+    wdst[i] = 4 * ((pl * 4 + ch) * CS + (r ^ (2 * ch)));
   }
   auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   // against both batch tiles, smallest terms first; the two batch tiles alternate, so consecutive MFMAs are
   // independent
   auto compute_half = [&](const float* rb, int h) {
-    const float* wl = rb + 4 * (lg * CS + lj);
+    const float* wl = rb + 4 * (lg * CS + (lj ^ (2 * lg)));
 #pragma unroll
     for (int ft = h * (FT / 2); ft < (h + 1) * (FT / 2); ++ft) {
       const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + ft * 16));
@@ -261,6 +266,8 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   BSTAMP(b1);
 #ifdef USF_STAMP
   unsigned long long ph[5] = {0, 0, 0, 0, 0};
+#endif
+#if defined(USF_STAMP) && USF_STAMP >= 2     // in-loop stamps drain the LDS queue five times per slab: a separate build
 #define LSTAMP(v) BSTAMP(v)
 #define LACC(i, a, b) ph[i] += (b) - (a)
 #else
@@ -317,14 +324,14 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int r = 16 * b + lj;
-        *reinterpret_cast<f32x4*>(tw + r * 32 + 4 * ((4 * q + lg) ^ ((r >> 1) & 7))) = acc[2 * tn + q][b];
+        *reinterpret_cast<f32x4*>(tw + r * 32 + 4 * ((4 * q + lg) ^ swz(r))) = acc[2 * tn + q][b];
       }
     // everything element-wise happens after the transpose, where a lane owns 4 consecutive features of a
     // row and the wave touches whole cache lines (addend / residual are read the same way)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rr + 8 * i;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * 32 + 4 * ((lane & 7) ^ ((r >> 1) & 7)));
+      f32x4 v = *reinterpret_cast<const f32x4*>(tw + r * 32 + 4 * ((lane & 7) ^ swz(r)));
       const int row = row0 + r;
       const int col = n0 + tn * 32 + cc;
       const int rowc = min(row, p.M - 1), colc = min(col, p.N - 4);
