@@ -30,6 +30,7 @@ struct Cpl3Args {
   const __bf16* Wout; int64_t ld_out, pl_out; const float* b_out;
   const float* ctx; const float* W_ctx; const float* b_ctx;
   float sign, slope; int act;
+  unsigned long long* dbg;              // tuning builds only (USF_STAMP)
 };
 
 __device__ __forceinline__ void c3_split3(const f32x4 x0, const f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -62,53 +63,74 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
   constexpr int SLOTS = 3 * 4 * HP;        // 16-B slots per stage (k-slab: 3 planes x 4 chunks x HP rows;
                                            //                       n-tile: 3 planes x (HP/8) chunks x 32 rows)
   constexpr int NST = SLOTS / C3_NT;       // float4 staged per thread per stage
-  static_assert(SLOTS % C3_NT == 0, "stage shape");
+  constexpr int NPP = NST / 3;             // ... per plane
+  static_assert(SLOTS % (3 * C3_NT) == 0, "stage shape");
+  constexpr int NC = HP / 8;               // 16-B chunks per n-tile row
+  static_assert(NC % 8 == 0, "n-tile rows are dealt in whole 128-B lines");
+  // two weight stages + per wave a 16 x 32 fp32 scratch (activation slabs in, output tiles out: global memory
+  // is touched in whole 128-B lines, 8 lanes per row, and the scratch turns lines into MFMA fragments and back)
   __shared__ __attribute__((aligned(16))) float lds[2][SLOTS * 4];
+  __shared__ __attribute__((aligned(16))) float cscr[8 * 512];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int lj = lane & 15;
+  const int lj = lane & 15;                // MFMA 16x16x32: lane = (row-in-tile j, k-group g)
   const int lg = lane >> 4;
+  const int lr = lane >> 3, lc = lane & 7; // line-shaped access: lane = (row lr (+8), 16-B chunk lc)
   const int wrow0 = blockIdx.x * C3_ROWS + wave * 16;
-  const int rowc = min(wrow0 + lj, p.M - 1);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // scratch swizzle: chunk c of row r at position c ^ swz(r) (see usf_linear_bf16x3.hip)
+  auto swz = [](int r) { const int h = r >> 1; return (((h >> 2) ^ (h >> 1)) & 1) | ((h & 1) << 1) | (((h >> 1) & 1) << 2); };
+  float* const scr = cscr + wave * 512;
 
-  // ---- weight stages: slot(plane, chunk, row) = (plane * NC + chunk) * NRW + row --------------------------
-  // k-slab: NC = 4, NRW = HP; thread -> row = (tid&7) + 8*(tid>>5) + RS*i, chunk = (tid>>3)&3, RS = 128
-  // n-tile: NC = HP/8, NRW = 32; thread idx = tid + 512 i -> row = (idx&7) + 8*(idx / (8*NC)), chunk = (idx>>3) % NC
-  constexpr int NPP = NST / 3;             // staged float4 per thread per plane
-  const int kr0 = (tid & 7) + 8 * (tid >> 5), kc = (tid >> 3) & 3;
+  // ---- weight stages -----------------------------------------------------------------------------------------
+  // k-slab image: slot(plane q, chunk c, row r) = (q * 4 + c) * HP + (r ^ 2c); dealt row-major (4 consecutive
+  // lanes = the 4 chunks = 64 contiguous bytes of a row, 16 lanes = 4 cache lines); the XOR keeps the stores
+  // (8 lanes = 2 rows x 4 chunks per ds_write_b128 group) on 8 different 16-B bank groups while the fragment
+  // reads (lane (j, g): row 16 ht + j of chunk g) stay on a chunk stride that is a multiple of 256 B.
+  unsigned ksrc[NPP];                      // element offset of (row, chunk) inside a plane
+  int kdst[NPP];                           // float offset of slot(0, c, r)
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int idx = tid + C3_NT * i;
+    const int r = idx >> 2, c = idx & 3;
+    kdst[i] = 4 * (c * HP + (r ^ (2 * c)));
+    ksrc[i] = (unsigned)r;                 // multiplied by the layer's leading dimension at issue time
+  }
   auto issue_k = [&](const __bf16* W, int64_t ld, int64_t pl, int k0, f32x4 (&st)[NST]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int i = 0; i < NPP; ++i)
-        st[q * NPP + i] = *reinterpret_cast<const f32x4*>(W + q * pl + (int64_t)(kr0 + 128 * i) * ld + k0 + 8 * kc);
+        st[q * NPP + i] = *reinterpret_cast<const f32x4*>(W + q * pl + (int64_t)ksrc[i] * ld + k0 + 8 * ((tid + C3_NT * i) & 3));
   };
   auto store_k = [&](int buf, const f32x4 (&st)[NST]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int i = 0; i < NPP; ++i)
-        *reinterpret_cast<f32x4*>(&lds[buf][4 * ((q * 4 + kc) * HP + kr0 + 128 * i)]) = st[q * NPP + i];
+      for (int i = 0; i < NPP; ++i) *reinterpret_cast<f32x4*>(&lds[buf][q * 16 * HP + kdst[i]]) = st[q * NPP + i];
   };
-  constexpr int NC = HP / 8;
-  auto n_row = [&](int i) { return ((tid + C3_NT * i) & 7) + 8 * ((tid + C3_NT * i) / (8 * NC)); };
-  auto n_chunk = [&](int i) { return ((tid + C3_NT * i) >> 3) % NC; };
+  // n-tile image: slot(plane q, chunk c, row r) = (q * NC + c) * 32 + (r ^ 2 (c & 7)); dealt row-major (8
+  // consecutive lanes = 8 chunks = one 128-B line of a row)
+  auto n_rc = [&](int i, int& r, int& c) { const int idx = tid + C3_NT * i; r = idx / NC; c = idx % NC; };
   auto issue_n = [&](const __bf16* W, int64_t ld, int64_t pl, int n0, f32x4 (&st)[NST]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int i = 0; i < NPP; ++i)
-        st[q * NPP + i] = *reinterpret_cast<const f32x4*>(W + q * pl + (int64_t)(n0 + n_row(i)) * ld + 8 * n_chunk(i));
+      for (int i = 0; i < NPP; ++i) {
+        int r, c; n_rc(i, r, c);
+        st[q * NPP + i] = *reinterpret_cast<const f32x4*>(W + q * pl + (int64_t)(n0 + r) * ld + 8 * c);
+      }
   };
   auto store_n = [&](int buf, const f32x4 (&st)[NST]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int i = 0; i < NPP; ++i)
-        *reinterpret_cast<f32x4*>(&lds[buf][4 * ((q * NC + n_chunk(i)) * 32 + n_row(i))]) = st[q * NPP + i];
+      for (int i = 0; i < NPP; ++i) {
+        int r, c; n_rc(i, r, c);
+        *reinterpret_cast<f32x4*>(&lds[buf][4 * ((q * NC + c) * 32 + (r ^ (2 * (c & 7))))]) = st[q * NPP + i];
+      }
   };
 
   const int nS1 = (p.n_pass + 31) / 32;
@@ -117,41 +139,60 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
   // accumulators start at the layer bias
   f32x4 X1[T], X2[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    X1[t] = *reinterpret_cast<const f32x4*>(p.b_in + t * 16 + 4 * lg);
-    if (NH >= 2) X2[t] = *reinterpret_cast<const f32x4*>(p.b_hid[0] + t * 16 + 4 * lg);
-  }
+  for (int t = 0; t < T; ++t) X1[t] = *reinterpret_cast<const f32x4*>(p.b_in + t * 16 + 4 * lg);
 
+  // ---- conditioning half: lines of the wave's 16 rows, 2 loads per lane per slab ----
   f32x4 st[NST];
-  f32x4 zc[2], zn[2];
-  const float* zrow = p.z + (int64_t)rowc * p.ldz + p.off_pass;
+  f32x4 zl[2];
+  unsigned zoff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) zoff[i] = (unsigned)min(wrow0 + lr + 8 * i, p.M - 1) * (unsigned)p.ldz + (unsigned)p.off_pass;
   auto issue_z = [&](int k0, f32x4 (&dst)[2]) {
+    const unsigned kc = (unsigned)min(k0 + 4 * lc, p.n_pass - 4);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) dst[u] = *reinterpret_cast<const f32x4*>(zrow + min(k0 + 8 * lg + 4 * u, p.n_pass - 4));
+    for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.z + (zoff[i] + kc));
   };
-  auto finish_z = [&](int k0, f32x4 (&dst)[2]) {
+  // lines -> scratch -> operand fragment (lane (j, g): row j, k = 8 g + (0..7)) -> three bf16 planes
+  auto z_planes = [&](int k0, const f32x4 (&src)[2], bf16x8 (&pl)[3]) {
+    const bool live = k0 + 4 * lc < p.n_pass;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) dst[u] = (k0 + 8 * lg + 4 * u < p.n_pass) ? dst[u] : zero4;
+    for (int i = 0; i < 2; ++i) {
+      const int r = lr + 8 * i;
+      *reinterpret_cast<f32x4*>(scr + r * 32 + 4 * (lc ^ swz(r))) = live ? src[i] : zero4;
+    }
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(scr + lj * 32 + 4 * ((2 * lg) ^ swz(lj)));
+    const f32x4 f1 = *reinterpret_cast<const f32x4*>(scr + lj * 32 + 4 * ((2 * lg + 1) ^ swz(lj)));
+    c3_split3(f0, f1, pl[0], pl[1], pl[2]);
   };
 
   // one 32-k step over all hidden tiles: X[ht] += W(ht) . B, B given as 3 planes; W fragments from a k-slab
-  auto mfma_slab = [&](int buf, f32x4 (&X)[T], const bf16x8 b1, const bf16x8 b2, const bf16x8 b3) {
-    const float* wl = &lds[buf][4 * (lg * HP + lj)];
+  auto mfma_slab = [&](int buf, f32x4 (&X)[T], const bf16x8 (&b)[3]) {
+    const float* wl = &lds[buf][4 * (lg * HP + (lj ^ (2 * lg)))];
 #pragma unroll
     for (int ht = 0; ht < T; ++ht) {
       const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4) * HP + ht * 16));
       const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4) * HP + ht * 16));
       const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4) * HP + ht * 16));
-      C3_MFMA6(X[ht], w1, w2, w3, b1, b2, b3);
-    }
-    // fragment reads two tiles ahead of their MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-    for (int ht = 0; ht < T; ++ht) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-      if (ht + 2 < T) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      C3_MFMA6(X[ht], w1, w2, w3, b[0], b[1], b[2]);
     }
   };
+  // Issue order pins (0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write): weight fragments
+  // two tiles ahead of their MFMAs; the next stage's global loads dealt over the first tiles (one burst behind
+  // the barrier would queue in the address unit while no wave reaches an MFMA); NSW scratch writes + NSR scratch
+  // reads early, then VPT VALU per tile (the next operand's split, in the MFMA shadow)
+#define C3_PIN_SLAB(NLD, NSW, NSR, VPT)                                                           \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
+    _Pragma("unroll") for (int ht_ = 0; ht_ < T; ++ht_) {                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                          \
+      if (ht_ + 2 < T) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
+      if (ht_ < (NLD)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
+      if (ht_ == 1 && (NSW) > 0) __builtin_amdgcn_sched_group_barrier(0x200, (NSW), 0);           \
+      if (ht_ == 2 && (NSR) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (NSR), 0);           \
+      if (ht_ >= 3 && (VPT) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (VPT), 0);           \
+    }                                                                                             \
+  } while (0)
+
   auto issue_after_input = [&](f32x4 (&s_)[NST]) {
     if (NH >= 2) issue_k(p.Whid[0], p.ld_hid, p.pl_hid, 0, s_); else issue_n(p.Wout, p.ld_out, p.pl_out, 0, s_);
   };
@@ -159,41 +200,51 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
     if (NH >= 2) store_k(buf, s_); else store_n(buf, s_);
   };
 
+#ifdef USF_STAMP
+#define C3STAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define C3STAMP(v)
+#endif
+  C3STAMP(t0);
   int g = 0;
+  bf16x8 zp[3], zn[3];
   issue_k(p.Win, p.ld_in, p.pl_in, 0, st);
-  issue_z(0, zc);
+  issue_z(0, zl);
+  z_planes(0, zl, zp);
+  __builtin_amdgcn_sched_barrier(0);
+  issue_z(32, zl);                         // (clamped when the conditioning half is a single slab)
   store_k(0, st);
-  finish_z(0, zc);
   __syncthreads();
 
   // ================= phase 1: X1[h][row] += W_in[h][k] * z[row][k] ============================
+  // slab s: multiplies with planes zp; the lines of slab s+1 (fetched a slab ago) go through the scratch and are
+  // split in the MFMA shadow; the lines of slab s+2 and the weights of slab s+1 are fetched
   for (int s = 0; s + 1 < nS1; ++s, ++g) {
     const int buf = g & 1;
     issue_k(p.Win, p.ld_in, p.pl_in, (s + 1) * 32, st);
-    issue_z((s + 1) * 32, zn);
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 z1, z2, z3;
-    c3_split3(zc[0], zc[1], z1, z2, z3);
-    mfma_slab(buf, X1, z1, z2, z3);
+    mfma_slab(buf, X1, zp);
+    z_planes((s + 1) * 32, zl, zn);
+    issue_z((s + 2) * 32, zl);
+    C3_PIN_SLAB(NST + 2, 2, 2, 6);
     __builtin_amdgcn_sched_barrier(0);
     store_k(buf ^ 1, st);
-    finish_z((s + 1) * 32, zn);
-    zc[0] = zn[0]; zc[1] = zn[1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) zp[q] = zn[q];
     __syncthreads();
   }
   {
     const int buf = g & 1;
     issue_after_input(st);
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8 z1, z2, z3;
-    c3_split3(zc[0], zc[1], z1, z2, z3);
-    mfma_slab(buf, X1, z1, z2, z3);
+    mfma_slab(buf, X1, zp);
+    C3_PIN_SLAB(NST, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     store_after_input(buf ^ 1, st);
     __syncthreads();
     ++g;
   }
 
+  C3STAMP(t1);
+  const int rowc = min(wrow0 + lj, p.M - 1);
   auto ctx_act = [&](f32x4 (&X)[T], bool with_ctx) {
     const float cv = with_ctx ? p.ctx[rowc] : 0.f;
 #pragma unroll
@@ -215,6 +266,8 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1'] * Xin[h1'][row] ====================
   auto hidden_layer = [&](f32x4 (&Xin)[T], f32x4 (&Xout)[T], int l) {
+    bf16x8 xc[3], xn[3];
+    c3_split3(Xin[0], Xin[1], xc[0], xc[1], xc[2]);            // k order {4g.., 16+4g..}: the weights' pack-time order
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int buf = g & 1;
@@ -223,51 +276,65 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
       if (!last) issue_k(p.Whid[l], p.ld_hid, p.pl_hid, (ks + 1) * 32, st);
       else if (next_is_hidden) issue_k(p.Whid[l + 1], p.ld_hid, p.pl_hid, 0, st);
       else issue_n(p.Wout, p.ld_out, p.pl_out, 0, st);
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 x1, x2, x3;
-      c3_split3(Xin[2 * ks], Xin[2 * ks + 1], x1, x2, x3);     // k order {4g.., 16+4g..}: the weights' pack-time order
-      mfma_slab(buf, Xout, x1, x2, x3);
+      mfma_slab(buf, Xout, xc);
+      if (!last) c3_split3(Xin[2 * ks + 2], Xin[2 * ks + 3], xn[0], xn[1], xn[2]);
+      C3_PIN_SLAB(NST, 0, 0, 5);
       __builtin_amdgcn_sched_barrier(0);
       if (!last || next_is_hidden) store_k(buf ^ 1, st); else store_n(buf ^ 1, st);
+      if (!last) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xc[q] = xn[q];
+      }
       __syncthreads();
       ++g;
     }
     ctx_act(Xout, false);
   };
-  if (NH >= 2) hidden_layer(X1, X2, 0);
+  if (NH >= 2) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) X2[t] = *reinterpret_cast<const f32x4*>(p.b_hid[0] + t * 16 + 4 * lg);
+    hidden_layer(X1, X2, 0);
+  }
   if (NH >= 3) {
 #pragma unroll
     for (int t = 0; t < T; ++t) X1[t] = *reinterpret_cast<const f32x4*>(p.b_hid[1] + t * 16 + 4 * lg);
     hidden_layer(X2, X1, 1);
   }
 
+  C3STAMP(t2);
   // ================= phase 3: out[row][n] = z[row][n] + sign * (b_out[n] + sum_h X[h][row] W_out[n][h']) =====
   auto output_layer = [&](f32x4 (&X)[T]) {
     // split the final hidden activations once: KS steps x 3 planes
     bf16x8 xp[KS][3];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) c3_split3(X[2 * ks], X[2 * ks + 1], xp[ks][0], xp[ks][1], xp[ks][2]);
-    const int orow = min(wrow0 + lj, p.M - 1);
+    // the transformed half is read and written in whole lines: lane (lr (+8), lc) <-> 4 features of one row
+    unsigned ooff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ooff[i] = (unsigned)min(wrow0 + lr + 8 * i, p.M - 1) * (unsigned)p.ldz + (unsigned)p.off_trans;
+    // (the tile's residual lines and its slice of the output bias are fetched one tile ahead; the bias joins
+    // behind the MFMAs, so no tile starts with a load it has to wait for)
+    f32x4 res[2], bo;
+    auto issue_res = [&](int nt, f32x4 (&dst)[2]) {
+      const unsigned cc = (unsigned)min(nt * 32 + 4 * lc, p.n_trans4 - 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.z + (ooff[i] + cc));
+      bo = *reinterpret_cast<const f32x4*>(p.b_out + nt * 32 + 4 * lc);   // b_out is padded to 32 * nS3
+    };
+    issue_res(0, res);
     for (int nt = 0; nt < nS3; ++nt, ++g) {
       const int buf = g & 1;
       issue_n(p.Wout, p.ld_out, p.pl_out, min(nt + 1, nS3 - 1) * 32, st);
-      int col[2];
-      f32x4 res[2], acc[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        col[u] = nt * 32 + u * 16 + 4 * lg;
-        res[u] = *reinterpret_cast<const f32x4*>(p.z + (int64_t)orow * p.ldz + p.off_trans + min(col[u], p.n_trans4 - 4));
-        acc[u] = *reinterpret_cast<const f32x4*>(p.b_out + col[u]);     // b_out is padded to 32 * nS3
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const float* wl = &lds[buf][4 * (lg * 32 + lj)];
+      f32x4 acc[2] = {zero4, zero4};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        const int x = 2 * ((4 * ks + lg) & 7);                 // row swizzle of chunk 4 ks + g
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * NC + 4 * ks) * 32 + u * 16));
-          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * NC + 4 * ks) * 32 + u * 16));
-          const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * NC + 4 * ks) * 32 + u * 16));
+          const float* wf = &lds[buf][4 * ((4 * ks + lg) * 32 + u * 16 + (lj ^ x))];
+          const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wf + 4 * (0 * NC * 32));
+          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wf + 4 * (1 * NC * 32));
+          const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wf + 4 * (2 * NC * 32));
           C3_MFMA6(acc[u], w1, w2, w3, xp[ks][0], xp[ks][1], xp[ks][2]);
         }
       }
@@ -276,30 +343,47 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
       for (int i = 0; i < 2 * KS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         if (i + 2 < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (i < NST + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       store_n(buf ^ 1, st);
+      // accumulator tiles -> scratch -> lines: lane (j, g) of tile u holds features 16 u + 4 g + (0..3) of row j
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f32x4 v;
+      for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(scr + lj * 32 + 4 * ((4 * u + lg) ^ swz(lj))) = acc[u];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = res[u][r] + p.sign * acc[u][r];
-        float* dst = p.out + (int64_t)(wrow0 + lj) * p.ldz + p.off_trans + col[u];
-        if (wrow0 + lj < p.M) {
-          if (col[u] + 3 < p.n_trans) {
+      for (int i = 0; i < 2; ++i) {
+        const int r = lr + 8 * i;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scr + r * 32 + 4 * (lc ^ swz(r)));
+        const f32x4 v = res[i] + p.sign * (a + bo);
+        const int row = wrow0 + r, col = nt * 32 + 4 * lc;
+        float* dst = p.out + (int64_t)row * p.ldz + p.off_trans + col;
+        if (row < p.M) {
+          if (col + 3 < p.n_trans) {
             *reinterpret_cast<f32x4*>(dst) = v;
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (col[u] + r < p.n_trans) dst[r] = v[r];
+            for (int e = 0; e < 4; ++e)
+              if (col + e < p.n_trans) dst[e] = v[e];
           }
         }
       }
+      issue_res(min(nt + 1, nS3 - 1), res);
       __syncthreads();
     }
   };
   if (NH == 2) output_layer(X2); else output_layer(X1);
+#ifdef USF_STAMP
+  C3STAMP(t3);
+  if (p.dbg && lane == 0) {
+    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 512) * 8 + wave) * 8;
+    o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; o[5] = 1;
+  }
+#endif
 }
+
+#ifdef USF_STAMP
+unsigned long long* g_c3dbg = nullptr;
+#endif
 
 bool coupling_bf16x3_eligible(const usf_coupling_desc* d) {
   if (!d->split_in || !d->split_out || d->n_hidden < 1 || d->n_hidden > 3) return false;
@@ -325,6 +409,10 @@ int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   a.Wout = reinterpret_cast<const __bf16*>(d->split_out); a.ld_out = d->split_out_ld; a.pl_out = d->split_out_plane; a.b_out = d->b_out;
   a.ctx = d->context; a.W_ctx = d->W_ctx; a.b_ctx = d->b_ctx;
   a.sign = d->sign; a.slope = d->slope; a.act = d->act;
+  a.dbg = nullptr;
+#ifdef USF_STAMP
+  a.dbg = g_c3dbg;
+#endif
   const int64_t kp = ((d->n_pass + 31) / 32) * 32;
   if (d->split_in_ld < kp || d->split_hid_ld < C3_HMAX * (d->n_hidden > 1) || d->split_out_ld < C3_HMAX || (d->split_in_ld & 7) ||
       (d->split_out_ld & 7) || !aligned16(d->split_in) || !aligned16(d->split_out)) {
