@@ -123,12 +123,13 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   auto swz = [](int r) { const int h = r >> 1; return (((h >> 2) ^ (h >> 1)) & 1) | ((h & 1) << 1) | (((h >> 1) & 1) << 2); };
   float* const scr = ascr + wave * 1024;
   auto transpose_a = [&](int k0, f32x4 (&src)[4], f32x4 (&frag)[4]) {
-    const bool live = k0 + 4 * ac < p.K;
+    // (no zero fill past K: those lanes hold a clamped, finite re-read and the weight planes are zero there --
+    // the header's padding contract)
+    (void)k0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = src[i];
       if (PRO) v = v / (has_div ? dvr : one4) - (has_sub ? svr : zero4);
-      v = live ? v : zero4;
       const int r = ar + 8 * i;
       *reinterpret_cast<f32x4*>(scr + r * 32 + 4 * (ac ^ swz(r))) = v;
     }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   constexpr int T_SR = T_SW + 1;                                 // ... the scratch fragment reads
   constexpr int T_LA = (T_SR + 1 < HT) ? T_SR + 1 : T_SR;        // ... the activation loads
   constexpr int NLA = PRO ? 6 : 4;
-  constexpr int VPT = (120 + HT - 1) / HT;
+  constexpr int VPT = (100 + HT - 1) / HT;
 #define USF_PIN_HALF0()                                                                           \
   do {                                                                                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
