@@ -91,7 +91,11 @@ def test_linear_parity(M, N, K, flags):
     assert err < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(65, 65, 8), (200, 160, 40), (257, 784, 784), (1000, 392, 256), (4096, 800, 784)])
+@pytest.mark.parametrize("M,N,K", [(65, 65, 8), (200, 160, 40), (257, 784, 784), (1000, 392, 256), (4096, 800, 784),
+                                   # the 256 x 160 tile with its ring of four weight buffers: 1, 2, 3, 4 slabs, ragged rows/cols
+                                   (8205, 800, 8), (8205, 800, 40), (8205, 800, 72), (8205, 800, 104), (8205, 784, 776),
+                                   # the 128 x 128 tile
+                                   (8192, 1024, 64), (8199, 1020, 136)])
 def test_linear_bf16x3_split_precision(M, N, K):
     """bf16x3 path: three-way residual split of both operands on the bf16 MFMA; must carry fp32-class error"""
     ext, dev = _ext(), _dev()
