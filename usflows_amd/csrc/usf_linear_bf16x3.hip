@@ -414,7 +414,7 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (wm4 < 0) { const char* e = getenv("USF_BF16X3_WM"); wm4 = (e && atoi(e) == 4) ? 1 : 0; }
   // small batches are latency-bound by one block's serial K loop: narrow column blocks (64 wide) shorten the
   // per-slab MFMA chain 2.5x and put 2.5x more blocks on the chip
-  if ((int64_t)((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) return launch3<2, 4, 2>(a, stream);
+  if ((int64_t)((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) return launch3<2, 4, 4>(a, stream);
   if (pad160 < pad128) return (a.M >= 2048 && !wm4) ? launch3<5, 8, 4>(a, stream) : launch3<5, 4, 2>(a, stream);
   return launch3<4, 4, 2>(a, stream);
 }
