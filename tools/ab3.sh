@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+run() { "$@" python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$LABEL', d['ms_per_step'], d['roofline']['all_kernels_ms_per_step'])"; }
+for i in 1 2; do
+LABEL=PRIOc run env USFLOWS_AMD_LIB=$GRAFT_REPO_ROOT/usflows_amd/csrc/libusflows_prio.so
+LABEL=PRIOall run env
+done

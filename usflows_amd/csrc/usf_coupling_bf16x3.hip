@@ -21,6 +21,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int C3_ROWS = 128;               // batch rows per block (8 waves x 16)
 constexpr int C3_NT = 512;
 constexpr int C3_HMAX = 256;
+#ifndef C3_AHEAD
+#define C3_AHEAD 3                         // weight fragments are read this many tiles ahead of their MFMAs
+#endif
 
 struct Cpl3Args {
   const float* z; float* out; int64_t ldz;
@@ -173,19 +176,25 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
       const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((0 * 4) * HP + ht * 16));
       const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((1 * 4) * HP + ht * 16));
       const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * ((2 * 4) * HP + ht * 16));
+      // issue priority alternates tile by tile: on a SIMD the older wave otherwise wins the matrix pipe whenever
+      // both are ready, reaches the barrier ~1100 cycles early and leaves the younger one to run alone; with the
+      // toggle whichever wave is a tile behind outranks the other, so the two advance in step (phases 1 and 2:
+      // -6.5 % on the layer in the flow; no gain in the output phase or in the linear kernel, not used there)
+      if (ht & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
       C3_MFMA6(X[ht], w1, w2, w3, b[0], b[1], b[2]);
     }
   };
   // Issue order pins (0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write): weight fragments
-  // two tiles ahead of their MFMAs; the next stage's global loads dealt over the first tiles (one burst behind
+  // C3_AHEAD tiles ahead of their MFMAs (on each SIMD the older wave wins the matrix pipe and reaches the barrier
+  // ~1100 cycles early; the younger one then runs alone and has to cover the LDS latency by itself); the next stage's global loads dealt over the first tiles (one burst behind
   // the barrier would queue in the address unit while no wave reaches an MFMA); NSW scratch writes + NSR scratch
   // reads early, then VPT VALU per tile (the next operand's split, in the MFMA shadow)
 #define C3_PIN_SLAB(NLD, NSW, NSR, VPT)                                                           \
   do {                                                                                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 3 * C3_AHEAD, 0);                                 \
     _Pragma("unroll") for (int ht_ = 0; ht_ < T; ++ht_) {                                         \
       __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                          \
-      if (ht_ + 2 < T) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                         \
+      if (ht_ + C3_AHEAD < T) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                  \
       if (ht_ < (NLD)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                         \
       if (ht_ == 1 && (NSW) > 0) __builtin_amdgcn_sched_group_barrier(0x200, (NSW), 0);           \
       if (ht_ == 2 && (NSR) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (NSR), 0);           \
@@ -338,11 +347,11 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
           C3_MFMA6(acc[u], w1, w2, w3, xp[ks][0], xp[ks][1], xp[ks][2]);
         }
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * C3_AHEAD, 0);
 #pragma unroll
       for (int i = 0; i < 2 * KS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        if (i + 2 < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (i + C3_AHEAD < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         if (i < NST + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
