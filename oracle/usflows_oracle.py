@@ -184,6 +184,14 @@ def conditioner_forward(sd, prefix, spec: FlowSpec, x, context=None):
             h = _act(F.linear(h, sd[f"{prefix}layers.{idx}.weight"], sd[f"{prefix}layers.{idx}.bias"]),
                      spec.negative_slope)
         return F.linear(h, sd[f"{prefix}layers.{n_hidden}.weight"], sd[f"{prefix}layers.{n_hidden}.bias"])
+    elif spec.conditioner == "ConvNet":
+        # vector path of ConvNet with gating=False, normalize_layers=False (networks.py:287-308, forward 379-389):
+        # nn.0 = Linear(D, h0); nn.{i+1} = Sequential(f, Linear(prev, c_hidden[i])); nn.{n+1} = Linear(c_hidden[-1], D)
+        # -- the activation sits IN FRONT of every block's Linear, none in front of the final Linear
+        h = F.linear(x, sd[f"{prefix}nn.0.weight"], sd[f"{prefix}nn.0.bias"])
+        for i in range(n_hidden):
+            h = F.linear(_act(h, spec.negative_slope), sd[f"{prefix}nn.{i + 1}.1.weight"], sd[f"{prefix}nn.{i + 1}.1.bias"])
+        return F.linear(h, sd[f"{prefix}nn.{n_hidden + 1}.weight"], sd[f"{prefix}nn.{n_hidden + 1}.bias"])
     raise ValueError(spec.conditioner)
 
 

@@ -60,6 +60,10 @@ def build_reference(spec, seed):
         cls = networks.ConditionalDenseNN
         args = dict(input_dim=spec.dim, context_dim=1, hidden_dims=list(spec.hidden_dims),
                     out_dim=spec.dim, nonlinearity=act)
+    elif spec.conditioner == "ConvNet":
+        cls = networks.ConvNet
+        args = dict(in_dims=[spec.dim], c_hidden=list(spec.hidden_dims), nonlinearity=act, normalize_layers=False,
+                    gating=False)
     else:
         from pyro.nn import DenseNN
         cls = DenseNN
@@ -203,6 +207,10 @@ def main():
     run_case("synth_d33_k3_lu2_hh1", S(33, 3, [40, 24], lu_transform=2, householder=1), "synth", 22)
     run_case("synth_d16_k3_densenn_relu", S(16, 3, [32, 32], householder=0, conditioner="DenseNN",
                                             negative_slope=0.0), "synth", 23)
+    # --- vector path of the generic ConvNet conditioner (gating=False, normalize_layers=False) ---
+    run_case("synth_d16_k3_convnet_vec", S(16, 3, [32, 24], householder=0, conditioner="ConvNet"), "synth", 24)
+    run_case("synth_d33_k2_convnet_vec_conj", S(33, 2, [40], householder=1, affine_conjugation=True,
+                                               conditioner="ConvNet", negative_slope=0.0), "synth", 25)
     # --- BASELINE cfg2 model (D=784, K=32, h=[256,256]); state dict regenerated from seed --
     run_case("synth_d784_k32_cfg2", S(784, 32, [256, 256], householder=0), "synth", 100, n=64, store_sd=False)
     run_case("synth_d784_k4_hh1_conj", S(784, 4, [256, 256], householder=1, affine_conjugation=True),

@@ -179,3 +179,31 @@ def test_simplify_is_equivalent():
     with torch.no_grad():
         simple = flow.simplify()
         assert torch.allclose(simple.log_prob(a["x"]), flow.log_prob(a["x"]), rtol=1e-4, atol=1e-4)
+
+
+def test_convnet_vector_path_layout_and_engine_view():
+    """vector path of the reference's generic ConvNet (networks.py:287-308): module order / state-dict keys, the
+    default gated + layer-normalised variant on the torch path, and the plain variant's folded MLP view"""
+    from usflows_amd.networks import ConvNet, GatedMLP, LayerNormVector
+    from usflows_amd.engine import conditioner_supported
+    torch.manual_seed(0)
+    plain = ConvNet([6], [8, 5], nonlinearity=torch.nn.LeakyReLU(0.01), normalize_layers=False, gating=False)
+    assert list(plain.state_dict()) == ["nn.0.weight", "nn.0.bias", "nn.1.1.weight", "nn.1.1.bias", "nn.2.1.weight",
+                                        "nn.2.1.bias", "nn.3.weight", "nn.3.bias"]
+    assert plain.nn[1][1].weight.shape == (8, 8) and plain.nn[2][1].weight.shape == (5, 8) and plain.nn[3].weight.shape == (6, 5)
+    x = torch.randn(9, 6)
+    first, hidden, (W_out, b_out), widths = plain.mlp_view()
+    h = torch.nn.functional.leaky_relu(first(x), 0.01)
+    for l in hidden:
+        h = torch.nn.functional.leaky_relu(l(h), 0.01)
+    folded = h.double() @ W_out.t() + b_out
+    assert widths == [8, 8] and torch.allclose(folded.float(), plain(x), atol=1e-6)
+    assert conditioner_supported(plain)
+    # accepted input layouts (networks.py:379-387)
+    assert torch.equal(plain(x.unsqueeze(-1)), plain(x))
+    default = ConvNet([6], [8, 5])
+    assert isinstance(default.nn[1], GatedMLP) and isinstance(default.nn[2], LayerNormVector)
+    assert default.nn[3].proj is not None and default.nn[1].proj is None      # 8 -> 5 needs the residual projection
+    assert default(x).shape == (9, 6) and not conditioner_supported(default)
+    with pytest.raises(NotImplementedError):
+        ConvNet([3, 8, 8], [4])

@@ -32,7 +32,7 @@ from torch import nn
 
 from . import _ext
 from . import transforms as T
-from .networks import ConditionalDenseNN, DenseNN
+from .networks import ConditionalDenseNN, ConvNet, DenseNN
 
 
 class EngineUnsupported(Exception):
@@ -56,6 +56,8 @@ def conditioner_supported(cond: nn.Module) -> bool:
         return cond.context_dim == 1 and _activation_of(cond.f) is not None
     if isinstance(cond, DenseNN):
         return cond.count_params == 1 and _activation_of(cond.f) is not None
+    if isinstance(cond, ConvNet):        # vector path; piece-wise linear only without gating / layer norm
+        return cond.is_plain_mlp() and _activation_of(cond.f) is not None
     return False
 
 
@@ -196,7 +198,9 @@ class FlowEngine:
         self.hmax = 4
         for s in self.steps:
             if s.kind == "coupling":
-                self.hmax = max(self.hmax, max(_round_up(int(h), 4) for h in s.module.conditioner.hidden_dims))
+                cond = s.module.conditioner
+                widths = cond.c_hidden if isinstance(cond, ConvNet) else cond.hidden_dims
+                self.hmax = max(self.hmax, max(_round_up(int(h), 4) for h in widths))
 
     def _params(self):
         seen, out = set(), []
@@ -275,13 +279,21 @@ class FlowEngine:
             pass_off, pass_n, pass_idx = 0, self.n0a, self.seg_idx[: self.n0a]
             tr_off, tr_n, tr_idx = self.n0a, self.n1, self.seg_idx[self.n0a: self.n0a + self.n1]
         act, slope = _activation_of(cond.f)
-        lin = list(cond.layers)
-        has_ctx = isinstance(cond, ConditionalDenseNN)
-        first = lin[0]
-        ctx_l = lin[1] if has_ctx else None
-        hidden = lin[2:-1] if has_ctx else lin[1:-1]
-        last = lin[-1]
         f64 = lambda t: t.detach().double().to(device)
+        has_ctx = isinstance(cond, ConditionalDenseNN)
+        ctx_l = None
+        if isinstance(cond, ConvNet):
+            # Linear, [f, Linear] x n, Linear (networks.py:287-308): the last block's Linear and the final Linear
+            # have no activation between them -> one output map, folded in fp64
+            first, hidden, (W_last, b_last), widths = cond.mlp_view()
+            W_last, b_last = W_last.to(device), b_last.to(device)
+        else:
+            lin = list(cond.layers)
+            first = lin[0]
+            ctx_l = lin[1] if has_ctx else None
+            hidden = lin[2:-1] if has_ctx else lin[1:-1]
+            W_last, b_last = f64(lin[-1].weight), f64(lin[-1].bias)
+            widths = cond.hidden_dims
 
         def pad_rows(W, b, n_pad):
             Wp = torch.zeros(n_pad, W.shape[1], dtype=W.dtype, device=W.device)
@@ -295,7 +307,7 @@ class FlowEngine:
             Wp[:, : W.shape[1]] = W
             return Wp
 
-        h = [int(x) for x in cond.hidden_dims]
+        h = [int(x) for x in widths]
         hp = [_round_up(x, 4) for x in h]
         W_in = self._perm_mat(f64(first.weight), torch.arange(h[0]), pass_idx).double()   # [h0, pass_n]
         W_in, b_in = pad_rows(W_in, f64(first.bias), hp[0])
@@ -303,8 +315,8 @@ class FlowEngine:
         for j, l in enumerate(hidden):
             W, b = pad_rows(pad_cols(f64(l.weight), hp[j]), f64(l.bias), hp[j + 1])
             layers.append((W.float().contiguous(), b.float().contiguous()))
-        W_out = pad_cols(f64(last.weight)[tr_idx.to(device)], hp[-1])                     # [tr_n, h_last_pad]
-        b_out = f64(last.bias)[tr_idx.to(device)]
+        W_out = pad_cols(W_last[tr_idx.to(device)], hp[-1])                               # [tr_n, h_last_pad]
+        b_out = b_last[tr_idx.to(device)]
         d = dict(pass_off=pass_off, pass_n=pass_n, tr_off=tr_off, tr_n=tr_n, act=act, slope=slope,
                  hidden=hp, layers=layers, W_out=W_out.float().contiguous(), b_out=b_out.float().contiguous(),
                  has_ctx=has_ctx)

@@ -4,7 +4,11 @@
 arguments, ``layers`` ModuleList ordering [input, context, hidden..., output] and therefore the
 same state-dict keys).  ``DenseNN`` stands in for ``pyro.nn.DenseNN`` (pyro-ppl 1.8.6), which the
 live vector configs name by dotted path (experiments/synthetic/gaussian_mixture.yaml:66-71);
-pyro is not a dependency of this package.  CNN conditioners are out of scope.
+pyro is not a dependency of this package.  ``ConvNet`` mirrors the *vector* path of the reference's
+generic ``ConvNet`` (networks.py:246-308, forward 379-389; ``in_dims = [D]``): with ``gating=False,
+normalize_layers=False`` it is a piece-wise linear MLP and runs on the fused device path; the gated /
+layer-normalised defaults are mirrored for the torch path only (they are not piece-wise linear).
+The spatial (CNN) path is out of scope.
 
 The modules themselves are plain torch (used under autograd / on CPU); on the device fast path
 ``usflows_amd.engine`` reads their parameters and runs the whole MLP inside the fused coupling
@@ -75,3 +79,98 @@ class DenseNN(nn.Module):
         if self.count_params == 1:
             return h
         return tuple(h[..., s] for s in self.param_slices)
+
+
+class LayerNormVector(nn.Module):
+    """LayerNorm over the feature axis of (batch, features) inputs (networks.py:206-219)."""
+
+    def __init__(self, features: int, eps: float = 1e-5):
+        super().__init__()
+        self.layernorm = nn.LayerNorm(features, eps=eps)
+
+    def forward(self, x):
+        return self.layernorm(_as_batch_features(x))
+
+
+class GatedMLP(nn.Module):
+    """Gated residual block of the vector ConvNet (networks.py:222-245):
+    ``x' + val * sigmoid(gate)`` with ``[val, gate] = Linear(f(Linear(f(x))))`` and ``x'`` = x or a projection."""
+
+    def __init__(self, in_features: int, out_features: int, nonlinearity=nn.ReLU()):
+        super().__init__()
+        self.net1 = nn.Sequential(nonlinearity, nn.Linear(in_features, out_features), nonlinearity,
+                                  nn.Linear(out_features, 2 * out_features))
+        self.proj = nn.Linear(in_features, out_features) if in_features != out_features else None
+
+    def forward(self, x):
+        val, gate = self.net1(x).chunk(2, dim=1)
+        skip = x if self.proj is None else self.proj(x)
+        return skip + val * torch.sigmoid(gate)
+
+
+def _as_batch_features(x):
+    """(batch, features, 1) and (1, batch, features) are accepted as (batch, features) (networks.py:379-387)."""
+    if x.dim() == 3 and x.shape[-1] == 1:
+        x = x.view(x.shape[0], x.shape[1])
+    if x.dim() == 3 and x.shape[0] == 1 and x.shape[2] != 1:
+        x = x.permute(1, 2, 0).contiguous().view(x.shape[1], x.shape[2])
+    return x
+
+
+class ConvNet(nn.Module):
+    """Vector path of the reference's ``ConvNet`` (``len(in_dims) == 1``): ``self.nn`` =
+    ``Linear(c_in, h0)``, one block per entry of ``c_hidden`` (block i maps ``c_hidden[i-1]`` (``h0`` for i = 0)
+    to ``c_hidden[i]``: ``Sequential(f, Linear)`` or ``GatedMLP``, optionally followed by ``LayerNormVector``),
+    ``Linear(c_hidden[-1], c_out)`` -- note: no activation in front of the final Linear.  Same constructor
+    signature and state-dict keys (``nn.<i>...``) as the reference; convolution arguments are accepted and
+    ignored as there."""
+
+    def __init__(self, in_dims, c_hidden: List[int], c_out: int = -1, nonlinearity=nn.ReLU(), kernel_size: int = 3,
+                 stride: int = 1, dilation: int = 1, padding: Optional[int] = None, normalize_layers: bool = True,
+                 gating: bool = True):
+        super().__init__()
+        try:
+            in_dims = [int(d) for d in in_dims]
+        except TypeError:
+            raise ValueError("in_dims must be an iterable like [C, H, W] or [C] for vector")
+        if len(in_dims) != 1:
+            raise NotImplementedError("usflows_amd.ConvNet: only the vector path (in_dims = [D]) is in scope")
+        if not c_hidden or any(h <= 0 for h in c_hidden):
+            raise AssertionError("c_hidden must be non-empty list of positive ints")
+        c_in = in_dims[0]
+        c_out = c_out if c_out > 0 else c_in
+        self.c_hidden = [int(h) for h in c_hidden]
+        self.gating, self.normalize_layers, self.f = bool(gating), bool(normalize_layers), nonlinearity
+        mods = [nn.Linear(c_in, self.c_hidden[0])]
+        width = self.c_hidden[0]
+        for h in self.c_hidden:
+            mods.append(GatedMLP(width, h, nonlinearity=nonlinearity) if gating else nn.Sequential(nonlinearity, nn.Linear(width, h)))
+            if normalize_layers:
+                mods.append(LayerNormVector(h))
+            width = h
+        mods.append(nn.Linear(width, c_out))
+        self.nn = nn.Sequential(*mods)
+        self.is_vector = True
+        self._vector_in_features = c_in
+
+    def forward(self, x, context=None):
+        x = _as_batch_features(x)
+        if x.dim() != 2:
+            x = x.view(x.shape[0], -1)
+        return self.nn(x)
+
+    # ---- view as a plain MLP, for the fused device path (piece-wise linear configuration only) ----
+    def is_plain_mlp(self) -> bool:
+        return not self.gating and not self.normalize_layers
+
+    def mlp_view(self):
+        """(first Linear, hidden Linears, (W_out, b_out) in fp64, hidden widths).  The last block's Linear and the
+        final Linear have no activation between them and are folded into one output map."""
+        assert self.is_plain_mlp()
+        first = self.nn[0]
+        blocks = [self.nn[i][1] for i in range(1, len(self.nn) - 1)]
+        final = self.nn[-1]
+        Wf, bf = final.weight.detach().double(), final.bias.detach().double()
+        Wk, bk = blocks[-1].weight.detach().double(), blocks[-1].bias.detach().double()
+        widths = [self.c_hidden[0]] + self.c_hidden[:-1]
+        return first, blocks[:-1], (Wf @ Wk, Wf @ bk + bf), widths

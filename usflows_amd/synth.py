@@ -27,7 +27,7 @@ class ModelSpec:
     householder: int = 1                  # flows.py:402 (ctor default)
     affine_conjugation: bool = False      # flows.py:399
     negative_slope: float = 0.01          # LeakyReLU slope; 0.0 == ReLU
-    conditioner: str = "ConditionalDenseNN"   # or "DenseNN" (pyro layout: no context layer)
+    conditioner: str = "ConditionalDenseNN"   # or "DenseNN" (pyro layout: no context layer) or "ConvNet" (vector path, plain)
     base: str = "laplace"                 # "laplace" | "normal" | "radial"
     base_loc: Optional[torch.Tensor] = None
     base_scale: Optional[torch.Tensor] = None
@@ -120,6 +120,13 @@ def synth_state_dict(spec: ModelSpec, seed: int = 0, alpha: float = 0.1) -> Dict
                     linear(c + f"layers.{idx}.", hs[i], hs[i - 1])
                     idx += 1
                 linear(c + f"layers.{idx}.", D, hs[-1])
+            elif spec.conditioner == "ConvNet":     # vector path, gating=False, normalize_layers=False
+                linear(c + "nn.0.", hs[0], D)
+                width = hs[0]
+                for i, hdim in enumerate(hs):
+                    linear(c + f"nn.{i + 1}.1.", hdim, width)
+                    width = hdim
+                linear(c + f"nn.{len(hs) + 1}.", D, width)
             else:
                 linear(c + "layers.0.", hs[0], D)
                 for i in range(1, len(hs)):
@@ -161,6 +168,10 @@ def build_usflow(spec: ModelSpec, sd: Optional[Dict[str, torch.Tensor]] = None, 
     if spec.conditioner == "ConditionalDenseNN":
         cls, args = ConditionalDenseNN, dict(input_dim=spec.dim, context_dim=1, hidden_dims=list(spec.hidden_dims),
                                              out_dim=spec.dim, nonlinearity=act)
+    elif spec.conditioner == "ConvNet":
+        from .networks import ConvNet
+        cls, args = ConvNet, dict(in_dims=[spec.dim], c_hidden=list(spec.hidden_dims), nonlinearity=act,
+                                  normalize_layers=False, gating=False)
     else:
         cls, args = DenseNN, dict(input_dim=spec.dim, hidden_dims=list(spec.hidden_dims), param_dims=[spec.dim],
                                   nonlinearity=act)
