@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 2
+#define USF_ABI_VERSION 3
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -187,8 +187,64 @@ typedef struct usf_op {
 
 int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream);
 
+/*
+ * ---- parameter prep on the device ---------------------------------------------------
+ * The reference re-derives every matrix from the raw parameters on each call with ATen CPU ops; these entry
+ * points do it in a handful of batched fp64 launches over all affine blocks of a flow (usf_prep.hip).
+ * fp64 results; the caller rounds once to fp32 through usf_pack_weight_f32.
+ *
+ * usf_lu_prepare_f64 -- LUTransform.L / .U / .matrix / .inverse_matrix / .log_abs_det_jacobian
+ *                       (transforms.py:1271-1320) for n blocks at once:
+ *   tri[2i]     = L_i = tril(L_raw_i,-1) + I          tri[2i+1]     = U_i^T = triu(U_raw_i)^T   (both lower-triangular)
+ *   tri_inv[2i] = L_i^-1                              tri_inv[2i+1] = (U_i^-1)^T
+ *   M[i] = L_i U_i,  Minv[i] = U_i^-1 L_i^-1 (either may be NULL),  ladj[i] = sum log|diag U_i| (may be NULL)
+ * L_raw / U_raw are HOST arrays of n DEVICE pointers to [D,D] fp32 row-major parameters; tri, tri_inv and the
+ * scratch `work` are [2n,D,D] fp64, M / Minv [n,D,D] fp64, all caller-owned device memory.
+ */
+typedef struct usf_lu_prep_desc {
+  int64_t n, D;
+  const float* const* L_raw;
+  const float* const* U_raw;
+  double* tri;
+  double* tri_inv;
+  double* work;
+  double* M;
+  double* Minv;
+  double* ladj;
+} usf_lu_prep_desc;
+int usf_lu_prepare_f64(const usf_lu_prep_desc* d, usf_stream_t stream);
+
+/* Batched fp64 GEMM on the f64 MFMA: C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b], row-major, op = identity or
+ * transpose (transX != 0: X is stored [K,M] resp. [N,K]); A[b] = A + b*strideA etc.  tri: 0 = full K range,
+ * 1 = op(A) lower- and op(B) upper-triangular (k <= min(i,j)), 2 = op(A) upper- and op(B) lower-triangular
+ * (k >= max(i,j)) -- a work-saving hint, the skipped products must be exact zeros.
+ * SequentialAffineTransform.matrix / .inverse_matrix (transforms.py:1457-1469) and the matrix gradients of the
+ * training path are chains of these. */
+int usf_gemm_f64(const double* A, int64_t lda, int64_t strideA, int32_t transA, const double* B, int64_t ldb,
+                 int64_t strideB, int32_t transB, double* C, int64_t ldc, int64_t strideC, int64_t M, int64_t N,
+                 int64_t K, int64_t batch, double alpha, double beta, int32_t tri, usf_stream_t stream);
+
+/* HouseholderTransform._construct_householder_permutation (transforms.py:795-809) as row-local rank-1 updates:
+ * out = w_0 prod_k (I - 2 v_k v_k^T / v_k.v_k); w_0 [D,D] fp32, vk [nvs,D] fp32, out [D,D] fp64. */
+int usf_householder_f64(const float* w_0, const float* vk, int64_t nvs, int64_t D, double* out, usf_stream_t stream);
+
+/* fp64 (or, src_is_f32 != 0, fp32) matrix -> the fp32 weight image the kernels read, rounded once:
+ *   W[o, c] = (float) src[out_idx[o], in_idx[c]]   (transpose != 0: src[in_idx[c], out_idx[o]]),   0 where an index is < 0
+ * for o < n_out, c < n_in (idx: int32 device arrays or NULL = identity), and, if planes != NULL, the bf16x3 planes of
+ * the same values ([3][n_out][ld_planes] bf16, zero for c >= n_in; usf_linear_desc.W_split).  W may be NULL.
+ * Also builds the mask-aware, zero-padded (and, for the split planes, k-permuted) conditioner weights of
+ * usf_coupling_desc from the nn.Linear parameters (networks.py:711-737) and, with n_out == 1, permuted vectors. */
+int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int32_t transpose, const int32_t* out_idx, int64_t n_out,
+                        const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ld_planes,
+                        int64_t plane_stride, usf_stream_t stream);
+
+/* out[o] = alpha * sum_k src[idx[o], k] * b[k] (0 where idx[o] < 0; idx NULL = identity), fp64 accumulation; out32 and/or
+ * out64 receive the result.  Bias folding c = -(Minv b) and SequentialAffineTransform.bias (transforms.py:1471-1476). */
+int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
+                   double alpha, float* out32, double* out64, usf_stream_t stream);
+
 int usf_abi_version(void);
-int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op) for kind 1|2|0: binding self-check */
+int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc) for kind 1|2|0|3: binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */
 

@@ -95,17 +95,18 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
         for t in pk[group].values():
             pm.add(t)
     for cp in pk["coupling"].values():
-        for W, b in cp["layers"]:
-            pm.add(W), pm.add(b)
-        pm.add(cp["W_out"]), pm.add(cp["b_out"])
+        if "unfused" in cp:
+            u = cp["unfused"]
+            for W, b in u["layers"]:
+                pm.add(W), pm.add(b)
+            for t in (u["W_out"], u["b_out"], u.get("W_ctx4"), u.get("b_ctx")):
+                pm.add(t)
         if "fused" in cp:
             f = cp["fused"]
             for t in (f["W_in"], f["b_in"], f["W_out"], f["b_out"], f.get("W_ctx"), f.get("b_ctx")):
                 pm.add(t)
             for W, b in f["hid"]:
                 pm.add(W), pm.add(b)
-        if cp["has_ctx"]:
-            pm.add(cp["W_ctx4"]), pm.add(cp["W_ctx1"]), pm.add(cp["b_ctx"])
     pm.add(x)
     pm.add(out)
     B = x.shape[0]
@@ -146,6 +147,82 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
             _gather(ws[src[0]], out, eng._gather_index(src[1], "user", x.device))
         else:
             _gather(ws[src[0]], ws[dst_name], eng._gather_index(src[1], "nat", x.device))
+
+
+# ---- parameter-prep entry points (usf_prep.hip), documented semantics of include/usflows_hip.h ----------
+def _emu_lu_prepare(L_raws, U_raws, want_M=True, want_Minv=True, keep_factors=False):
+    n, D = len(L_raws), L_raws[0].shape[0]
+    eye = torch.eye(D, dtype=torch.float64)
+    tri = torch.zeros(2 * n, D, D, dtype=torch.float64)
+    inv = torch.zeros_like(tri)
+    for i, (L, U) in enumerate(zip(L_raws, U_raws)):
+        tri[2 * i] = L.double().tril(-1) + eye
+        tri[2 * i + 1] = U.double().triu().t()
+        inv[2 * i] = torch.linalg.solve_triangular(tri[2 * i], eye, upper=False)
+        inv[2 * i + 1] = torch.linalg.solve_triangular(tri[2 * i + 1], eye, upper=False)
+    out = dict(M=(tri[0::2] @ tri[1::2].transpose(1, 2)) if want_M else None,
+               Minv=(inv[1::2].transpose(1, 2) @ inv[0::2]) if want_Minv else None,
+               ladj=torch.stack([U.double().diagonal().abs().log().sum() for U in U_raws]))
+    if keep_factors:
+        out["tri"], out["tri_inv"] = tri, inv
+    return out
+
+
+def _emu_householder(w_0, vk):
+    w = w_0.double()
+    for v in vk.double():
+        w = w - 2.0 * torch.outer(w @ v, v) / torch.dot(v, v)
+    return w.contiguous()
+
+
+def _emu_matmul_f64(A, B, transA=False, transB=False, tri=0):
+    return ((A.t() if transA else A) @ (B.t() if transB else B)).contiguous()
+
+
+def _bf16_planes(w32):
+    hi = w32.to(torch.bfloat16)
+    r = w32 - hi.float()
+    mid = r.to(torch.bfloat16)
+    return hi, mid, (r - mid.float()).to(torch.bfloat16)
+
+
+def _emu_pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
+    ld = ld_src if ld_src is not None else src.shape[-1]
+    S = torch.as_strided(src.reshape(-1), (src.numel() // ld, ld), (ld, 1))
+    if transpose:
+        S = S.t()
+    oi = torch.arange(n_out) if out_idx is None else out_idx[:n_out].long()
+    ii = torch.arange(n_in) if in_idx is None else in_idx[:n_in].long()
+    v = torch.zeros(n_out, n_in, dtype=torch.float32)
+    ro, ci = torch.nonzero(oi >= 0).flatten(), torch.nonzero(ii >= 0).flatten()
+    v[ro[:, None], ci[None, :]] = S[oi[ro][:, None], ii[ci][None, :]].float()
+    if W is not None:
+        torch.as_strided(W.reshape(-1), (n_out, n_in), (ldw, 1)).copy_(v)
+    if planes is not None:
+        planes.zero_()
+        for q, pl in enumerate(_bf16_planes(v)):
+            planes[q, :n_out, :n_in] = pl
+
+
+def _emu_matvec_f64(src, b, *, idx=None, n_out=None, alpha=1.0, out32=None, out64=None, ld_src=None):
+    n_out = src.shape[0] if n_out is None else n_out
+    oi = torch.arange(n_out) if idx is None else idx[:n_out].long()
+    r = torch.zeros(n_out, dtype=torch.float64)
+    ok = oi >= 0
+    r[ok] = alpha * (src[oi[ok]] @ b)
+    if out32 is not None:
+        out32.copy_(r.float())
+    if out64 is not None:
+        out64.copy_(r)
+
+
+def install_prep_emulation(monkeypatch):
+    """route the engine's parameter-prep calls to the torch-CPU statements above (tests without a GPU)"""
+    monkeypatch.setattr(_ext, "lu_prepare", _emu_lu_prepare)
+    monkeypatch.setattr(_ext, "householder", _emu_householder)
+    monkeypatch.setattr(_ext, "matmul_f64", _emu_matmul_f64)
+    monkeypatch.setattr(_ext, "pack_weight", _emu_pack_weight)
+    monkeypatch.setattr(_ext, "matvec_f64", _emu_matvec_f64)
 
 
 def engine_transform(eng, x, direction, context=None, fused=False):

@@ -12,6 +12,11 @@ from oracle import usflows_oracle as orc
 SMALL = case_names(small_only=True)
 
 
+@pytest.fixture(autouse=True)
+def _prep_on_cpu(monkeypatch):
+    emulator.install_prep_emulation(monkeypatch)
+
+
 def _tol(ref64):
     return 3e-5 * max(1.0, ref64.abs().max().item())
 

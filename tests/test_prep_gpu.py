@@ -1,0 +1,194 @@
+"""Parameter-prep kernels (usf_prep.hip) through the C ABI against the oracle's fp64
+restatement of LUTransform / HouseholderTransform / SequentialAffineTransform (transforms.py:1271-1320,
+795-809, 1457-1476).  fp64 on both sides: tolerance 1e-11 relative to the matrix scale; the
+fp32 packing (usf_pack_weight_f32) is bit-exact against its documented semantics (tests/emulator.py)."""
+import pytest
+import torch
+
+import emulator
+from oracle import usflows_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ext():
+    from usflows_amd import _ext
+    _ext.load()
+    return _ext
+
+
+def _lu_params(D, n, seed, alpha=0.3):
+    g = torch.Generator().manual_seed(seed)
+    Ls = [(alpha * torch.randn(D, D, generator=g)).contiguous() for _ in range(n)]
+    Us = []
+    for _ in range(n):
+        U = alpha * torch.randn(D, D, generator=g)
+        d = (0.75 + 0.5 * torch.rand(D, generator=g)) * torch.where(torch.rand(D, generator=g) < 0.5, -1.0, 1.0)
+        U = U.triu(1) + torch.diag(d) + U.tril(-1)       # garbage below the diagonal must be ignored
+        Us.append(U.contiguous())
+    return Ls, Us
+
+
+@pytest.mark.parametrize("D,n", [(1, 1), (5, 2), (31, 1), (32, 3), (33, 2), (64, 1), (100, 3), (257, 2), (784, 3)])
+def test_lu_prepare_matches_oracle(D, n):
+    ext = _ext()
+    Ls, Us = _lu_params(D, n, seed=D * 7 + n, alpha=min(0.3, 0.8 / D ** 0.5))   # keeps cond(L), cond(U) moderate
+    out = ext.lu_prepare([t.to(DEV) for t in Ls], [t.to(DEV) for t in Us], keep_factors=True)
+    torch.cuda.synchronize()
+    for i in range(n):
+        L64, U64 = Ls[i].double(), Us[i].double()
+        M_ref = orc.lu_matrix(L64, U64)
+        Minv_ref = orc.lu_inverse_matrix(L64, U64)
+        scale_m, scale_i = M_ref.abs().max().item(), Minv_ref.abs().max().item()
+        assert (out["M"][i].cpu() - M_ref).abs().max().item() <= 1e-12 * max(1.0, scale_m)
+        assert (out["Minv"][i].cpu() - Minv_ref).abs().max().item() <= 1e-10 * max(1.0, scale_i)
+        assert abs(out["ladj"][i].item() - orc.lu_ladj(U64).item()) <= 1e-11 * max(1.0, D)
+        assert torch.equal(out["tri"][2 * i].cpu(), orc.lu_L(L64))
+        assert torch.equal(out["tri"][2 * i + 1].cpu(), orc.lu_U(U64).t())
+        Linv_ref = torch.linalg.solve_triangular(orc.lu_L(L64), torch.eye(D, dtype=torch.float64), upper=False)
+        assert (out["tri_inv"][2 * i].cpu() - Linv_ref).abs().max().item() <= 1e-10 * max(1.0, Linv_ref.abs().max().item())
+        # the inverse of a lower-triangular matrix is lower-triangular: exact zeros above the diagonal
+        assert out["tri_inv"][2 * i].cpu().triu(1).abs().max().item() == 0.0
+        assert out["tri_inv"][2 * i + 1].cpu().triu(1).abs().max().item() == 0.0
+        # known-answer property of the reference's own test (tests/veriflow/transforms_test.py:35-51): M Minv = I
+        eye_err = (out["M"][i] @ out["Minv"][i] - torch.eye(D, dtype=torch.float64, device=DEV)).abs().max().item()
+        assert eye_err <= 1e-9 * max(1.0, scale_m * scale_i)
+
+
+def test_lu_prepare_identity_known_answer():
+    """LU init of the reference's transforms_test.py:35-51: L_raw = 0, U_raw = I -> M = M^-1 = I, ladj = 0"""
+    ext = _ext()
+    D = 48
+    out = ext.lu_prepare([torch.zeros(D, D, device=DEV)], [torch.eye(D, device=DEV)])
+    eye = torch.eye(D, dtype=torch.float64, device=DEV)
+    assert torch.equal(out["M"][0], eye) and torch.equal(out["Minv"][0], eye)
+    assert out["ladj"][0].item() == 0.0
+
+
+@pytest.mark.parametrize("transA", [False, True])
+@pytest.mark.parametrize("transB", [False, True])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 16), (65, 130, 33), (200, 77, 129)])
+def test_gemm_f64(transA, transB, M, N, K):
+    ext = _ext()
+    g = torch.Generator().manual_seed(M * 1000 + N * 10 + K)
+    A = torch.randn((K, M) if transA else (M, K), generator=g, dtype=torch.float64)
+    B = torch.randn((N, K) if transB else (K, N), generator=g, dtype=torch.float64)
+    C0 = torch.randn(3, M, N, generator=g, dtype=torch.float64)
+    ref = 0.5 * ((A.t() if transA else A) @ (B.t() if transB else B)) - 2.0 * C0
+    Ad, Bd, Cd = A.to(DEV), B.to(DEV), C0.to(DEV)
+    # batch of 3 sharing A and B (stride 0), distinct C
+    ext.gemm_f64(Ad, Bd, Cd, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, transA=transA, transB=transB,
+                 batch=3, strideC=M * N, alpha=0.5, beta=-2.0)
+    torch.cuda.synchronize()
+    assert (Cd.cpu() - ref).abs().max().item() <= 1e-12 * max(1.0, K)
+    got = ext.matmul_f64(Ad, Bd, transA, transB).cpu()
+    assert (got - (A.t() if transA else A) @ (B.t() if transB else B)).abs().max().item() <= 1e-12 * max(1.0, K)
+
+
+@pytest.mark.parametrize("D", [40, 130])
+def test_gemm_f64_triangular_hints(D):
+    ext = _ext()
+    g = torch.Generator().manual_seed(D)
+    Lo = torch.randn(D, D, generator=g, dtype=torch.float64).tril()
+    Up = torch.randn(D, D, generator=g, dtype=torch.float64).triu()
+    assert torch.equal(ext.matmul_f64(Lo.to(DEV), Up.to(DEV), tri=1), ext.matmul_f64(Lo.to(DEV), Up.to(DEV)))
+    assert torch.equal(ext.matmul_f64(Up.to(DEV), Lo.to(DEV), tri=2), ext.matmul_f64(Up.to(DEV), Lo.to(DEV)))
+
+
+@pytest.mark.parametrize("D,nvs", [(7, 1), (64, 2), (100, 3), (784, 2)])
+def test_householder_matches_oracle(D, nvs):
+    ext = _ext()
+    g = torch.Generator().manual_seed(D + nvs)
+    w0 = torch.zeros(D, D)
+    w0[torch.arange(D), torch.randperm(D, generator=g)] = 1.0
+    vk = 0.2 * torch.randn(nvs, D, generator=g)
+    got = ext.householder(w0.to(DEV), vk.to(DEV)).cpu()
+    ref = orc.householder_matrix(vk.double(), w0.double())
+    assert (got - ref).abs().max().item() <= 1e-13
+    assert (got @ got.t() - torch.eye(D, dtype=torch.float64)).abs().max().item() <= 1e-12     # orthogonal
+
+
+@pytest.mark.parametrize("src_dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_pack_weight_bit_exact(src_dtype, transpose):
+    ext = _ext()
+    g = torch.Generator().manual_seed(3)
+    R, Cc = 37, 53
+    src = torch.randn(R, Cc, generator=g, dtype=torch.float64).to(src_dtype)
+    n_out, n_in, ldw, ldp = 44, 40, 48, 64
+    rows_src = Cc if transpose else R
+    cols_src = R if transpose else Cc
+    oi = torch.randint(-1, rows_src, (n_out,), generator=g).to(torch.int32)
+    ii = torch.randint(-1, cols_src, (n_in,), generator=g).to(torch.int32)
+    W = torch.full((n_out, ldw), 7.0)
+    planes = torch.ones(3, n_out, ldp, dtype=torch.bfloat16)
+    W_ref, planes_ref = W.clone(), planes.clone()
+    emulator._emu_pack_weight(src, oi, n_out, ii, n_in, W=W_ref, ldw=ldw, planes=planes_ref, transpose=transpose)
+    Wd, Pd = W.to(DEV), planes.to(DEV)
+    ext.pack_weight(src.to(DEV), oi.to(DEV), n_out, ii.to(DEV), n_in, W=Wd, ldw=ldw, planes=Pd, transpose=transpose)
+    torch.cuda.synchronize()
+    assert torch.equal(Wd.cpu(), W_ref)                       # columns >= n_in of W untouched (7.0)
+    assert torch.equal(Pd.cpu().view(torch.int16), planes_ref.view(torch.int16))
+    # the three planes sum back to the fp32 value to the last bit (8+8+8 significant bits)
+    s = Pd[0].float() + Pd[1].float() + Pd[2].float()
+    assert torch.equal(s[:, :n_in].cpu(), W_ref[:, :n_in])
+
+
+def test_matvec_f64():
+    ext = _ext()
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(70, 91, generator=g, dtype=torch.float64)
+    b = torch.randn(91, generator=g, dtype=torch.float64)
+    idx = torch.tensor([3, -1, 69, 0, 0, 12, -1], dtype=torch.int32)
+    o32 = torch.empty(7, device=DEV)
+    o64 = torch.empty(7, dtype=torch.float64, device=DEV)
+    ext.matvec_f64(A.to(DEV), b.to(DEV), idx=idx.to(DEV), n_out=7, alpha=-1.0, out32=o32, out64=o64)
+    ref = torch.zeros(7, dtype=torch.float64)
+    ok = idx >= 0
+    ref[ok] = -(A[idx[ok].long()] @ b)
+    assert (o64.cpu() - ref).abs().max().item() <= 1e-13
+    assert torch.equal(o32.cpu(), o64.cpu().float())
+
+
+def _ref_affine(t):
+    """(M, Minv, b) in fp64 from a block's parameters with the oracle's statements of the reference formulas"""
+    from usflows_amd import transforms as T
+    d64 = lambda p: p.detach().cpu().double()
+    if isinstance(t, T.LUTransform):
+        return orc.lu_matrix(d64(t.L_raw), d64(t.U_raw)), orc.lu_inverse_matrix(d64(t.L_raw), d64(t.U_raw)), d64(t.bias_vector)
+    if isinstance(t, T.HouseholderTransform):
+        M = orc.householder_matrix(d64(t.vk_householder), d64(t.w_0))
+        return M, M.t().contiguous(), torch.zeros(t.dim, dtype=torch.float64)
+    parts = [_ref_affine(u) for u in t.transforms]                 # transforms.py:1457-1476
+    M = torch.eye(t.dim, dtype=torch.float64)
+    Minv = torch.eye(t.dim, dtype=torch.float64)
+    b = torch.zeros(t.dim, dtype=torch.float64)
+    for m, _, bi in parts:
+        M = M @ m
+        b = b @ m + bi
+    for _, mi, _ in parts[::-1]:
+        Minv = Minv @ mi
+    return M, Minv, b
+
+
+@pytest.mark.parametrize("case", ["synth_d64_k4_hh1_conj_laplace", "synth_d33_k3_lu2_hh1", "synth_d16_k4_hh2_conj_laplace"])
+def test_engine_prep_matches_oracle(case):
+    """the engine's prep (all affine blocks through ONE batched prepare + Sequential composition on the f64 GEMM)
+    against the oracle's matrices, for the [LU.., Householder] compositions the reference's live configs use"""
+    from golden_util import load_case
+    from model_util import build_flow
+    from usflows_amd.engine import FlowEngine, prepare_affine_blocks
+    spec, sd, a = load_case(case)
+    flow = build_flow(spec, sd, device=DEV)
+    eng = FlowEngine(flow.layers)
+    blocks = list({id(s.module): s.module for s in eng.steps if s.kind == "affine"}.values())
+    res = prepare_affine_blocks(blocks, DEV)
+    torch.cuda.synchronize()
+    for blk in blocks:
+        M_ref, Minv_ref, b_ref = _ref_affine(blk)
+        r = res[id(blk)]
+        assert (r["M"].cpu() - M_ref).abs().max().item() <= 1e-11 * max(1.0, M_ref.abs().max().item())
+        assert (r["Minv"].cpu() - Minv_ref).abs().max().item() <= 1e-9 * max(1.0, Minv_ref.abs().max().item())
+        assert (r["b"].cpu() - b_ref).abs().max().item() <= 1e-12 * max(1.0, b_ref.abs().max().item())

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 2
+USF_ABI_VERSION = 3
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -70,6 +70,14 @@ class Op(C.Structure):
     _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("u", _OpUnion)]
 
 
+class LuPrepDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("D", C.c_int64),
+        ("L_raw", C.POINTER(C.c_void_p)), ("U_raw", C.POINTER(C.c_void_p)),
+        ("tri", _fp), ("tri_inv", _fp), ("work", _fp), ("M", _fp), ("Minv", _fp), ("ladj", _fp),
+    ]
+
+
 # every symbol include/usflows_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "usf_abi_version": (C.c_int, []),
@@ -87,6 +95,14 @@ SYMBOLS = {
     "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
+    "usf_lu_prepare_f64": (C.c_int, [C.POINTER(LuPrepDesc), C.c_void_p]),
+    "usf_gemm_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int64, C.c_int64, C.c_int32,
+                               _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                               C.c_double, C.c_double, C.c_int32, C.c_void_p]),
+    "usf_householder_f64": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, _fp, C.c_void_p]),
+    "usf_pack_weight_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int64,
+                                      _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_matvec_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_double, _fp, _fp, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -113,7 +129,7 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.usf_abi_version() != USF_ABI_VERSION:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
-    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op)):
+    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -187,3 +203,78 @@ def gather_cols(src, lds, dst, ldd, M, n, idx):
 
 def run_ops(ops_array, n, device=None):
     check(load().usf_run_ops(ops_array, n, current_stream(device)), "usf_run_ops")
+
+
+# ---- parameter prep (usf_prep.hip) -------------------------------------------------
+def lu_prepare(L_raws, U_raws, want_M=True, want_Minv=True, keep_factors=False):
+    """Batched LUTransform prep (transforms.py:1271-1320) for a list of [D,D] fp32 device parameters.
+
+    Returns dict(M [n,D,D] f64 | None, Minv | None, ladj [n] f64, and with keep_factors: tri / tri_inv
+    [2n,D,D] f64 = (L_i, U_i^T) / (L_i^-1, (U_i^-1)^T))."""
+    n = len(L_raws)
+    D = int(L_raws[0].shape[0])
+    dev = L_raws[0].device
+    for t in list(L_raws) + list(U_raws):
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (D, D) or t.device != dev:
+            raise ValueError("lu_prepare: parameters must be contiguous [D,D] fp32 tensors on one device")
+    f64 = lambda *shape: torch.empty(*shape, dtype=torch.float64, device=dev)
+    tri, tri_inv, work = f64(2 * n, D, D), f64(2 * n, D, D), f64(2 * n, D, D)
+    out = dict(M=f64(n, D, D) if want_M else None, Minv=f64(n, D, D) if want_Minv else None, ladj=f64(n))
+    d = LuPrepDesc()
+    d.n, d.D = n, D
+    Lp = (C.c_void_p * n)(*[t.data_ptr() for t in L_raws])
+    Up = (C.c_void_p * n)(*[t.data_ptr() for t in U_raws])
+    d.L_raw, d.U_raw = Lp, Up
+    d.tri, d.tri_inv, d.work = tri.data_ptr(), tri_inv.data_ptr(), work.data_ptr()
+    d.M, d.Minv, d.ladj = ptr(out["M"]), ptr(out["Minv"]), out["ladj"].data_ptr()
+    check(load().usf_lu_prepare_f64(C.byref(d), current_stream(dev)), "usf_lu_prepare_f64")
+    if keep_factors:
+        out["tri"], out["tri_inv"] = tri, tri_inv
+    return out
+
+
+def gemm_f64(A, B, Cout, *, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, strideA=0, strideB=0,
+             strideC=0, alpha=1.0, beta=0.0, tri=0, a_off=0, b_off=0, c_off=0):
+    """usf_gemm_f64 on fp64 device tensors (element offsets *_off)."""
+    check(load().usf_gemm_f64(A.data_ptr() + 8 * a_off, lda, strideA, int(transA), B.data_ptr() + 8 * b_off, ldb,
+                              strideB, int(transB), Cout.data_ptr() + 8 * c_off, ldc, strideC, M, N, K, batch,
+                              float(alpha), float(beta), tri, current_stream(A.device)), "usf_gemm_f64")
+
+
+def matmul_f64(A: torch.Tensor, B: torch.Tensor, transA=False, transB=False, tri=0) -> torch.Tensor:
+    """op(A) @ op(B) for contiguous 2-D fp64 device tensors."""
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    out = torch.empty(M, N, dtype=torch.float64, device=A.device)
+    gemm_f64(A, B, out, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, transA=transA, transB=transB, tri=tri)
+    return out
+
+
+def householder(w_0, vk):
+    D = int(w_0.shape[0])
+    out = torch.empty(D, D, dtype=torch.float64, device=w_0.device)
+    check(load().usf_householder_f64(w_0.data_ptr(), vk.data_ptr(), int(vk.shape[0]), D, out.data_ptr(),
+                                     current_stream(w_0.device)), "usf_householder_f64")
+    return out
+
+
+def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
+    """usf_pack_weight_f32: src fp64/fp32 2-D (or 1-D = one row) device tensor; W [n_out, ldw] fp32 and/or planes
+    [3, n_out, ldp] bf16 (preallocated)."""
+    if src.dtype not in (torch.float32, torch.float64):
+        raise ValueError("pack_weight: source must be fp32 or fp64")
+    if ld_src is None:
+        ld_src = src.shape[-1]
+    ldp = planes.shape[2] if planes is not None else 0
+    ps = planes.shape[1] * planes.shape[2] if planes is not None else 0
+    check(load().usf_pack_weight_f32(src.data_ptr(), int(src.dtype == torch.float32), ld_src, int(transpose),
+                                     ptr(out_idx), n_out, ptr(in_idx), n_in, ptr(W), ldw, ptr(planes), ldp, ps,
+                                     current_stream(src.device)), "usf_pack_weight_f32")
+
+
+def matvec_f64(src, b, *, idx=None, n_out=None, alpha=1.0, out32=None, out64=None, ld_src=None):
+    if n_out is None:
+        n_out = src.shape[0]
+    check(load().usf_matvec_f64(src.data_ptr(), ld_src or src.shape[1], b.shape[0], ptr(idx), n_out, b.data_ptr(),
+                                float(alpha), ptr(out32), ptr(out64), current_stream(src.device)), "usf_matvec_f64")

@@ -28,6 +28,17 @@ int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t
 int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
                 hipStream_t stream);
 
+int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream);
+int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
+             double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
+             double beta, int32_t tri, hipStream_t stream);
+int householder(const float* w0, const float* vk, int64_t nvs, int64_t D, double* out, hipStream_t stream);
+int pack_weight(const void* src, int32_t src_is_f32, int64_t lds_, int32_t transpose, const int32_t* out_idx, int64_t n_out,
+                const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ldp,
+                int64_t plane_stride, hipStream_t stream);
+int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
+                double alpha, float* out32, double* out64, hipStream_t stream);
+
 }  // namespace usf
 
 extern "C" {
@@ -38,6 +49,7 @@ int usf_sizeof_desc(int32_t kind) {
     case USF_OP_LINEAR: return (int)sizeof(usf_linear_desc);
     case USF_OP_COUPLING: return (int)sizeof(usf_coupling_desc);
     case 0: return (int)sizeof(usf_op);
+    case 3: return (int)sizeof(usf_lu_prep_desc);
     default: return -1;
   }
 }
@@ -73,6 +85,31 @@ int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M,
 int usf_gather_cols_f32(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n,
                         const int32_t* idx, usf_stream_t stream) {
   return usf::gather_cols(src, lds_, dst, ldd, M, n, idx, (hipStream_t)stream);
+}
+
+int usf_lu_prepare_f64(const usf_lu_prep_desc* d, usf_stream_t stream) { return usf::lu_prepare(d, (hipStream_t)stream); }
+
+int usf_gemm_f64(const double* A, int64_t lda, int64_t strideA, int32_t transA, const double* B, int64_t ldb,
+                 int64_t strideB, int32_t transB, double* C, int64_t ldc, int64_t strideC, int64_t M, int64_t N,
+                 int64_t K, int64_t batch, double alpha, double beta, int32_t tri, usf_stream_t stream) {
+  return usf::gemm_f64(A, lda, strideA, transA, B, ldb, strideB, transB, C, ldc, strideC, M, N, K, batch, alpha, beta,
+                       tri, (hipStream_t)stream);
+}
+
+int usf_householder_f64(const float* w_0, const float* vk, int64_t nvs, int64_t D, double* out, usf_stream_t stream) {
+  return usf::householder(w_0, vk, nvs, D, out, (hipStream_t)stream);
+}
+
+int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int32_t transpose, const int32_t* out_idx, int64_t n_out,
+                        const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ld_planes,
+                        int64_t plane_stride, usf_stream_t stream) {
+  return usf::pack_weight(src, src_is_f32, ld_src, transpose, out_idx, n_out, in_idx, n_in, W, ldw, planes, ld_planes, plane_stride,
+                          (hipStream_t)stream);
+}
+
+int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
+                   double alpha, float* out32, double* out64, usf_stream_t stream) {
+  return usf::matvec_rows(src, ld_src, K, idx, n_out, b, alpha, out32, out64, (hipStream_t)stream);
 }
 
 int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {

@@ -1,0 +1,472 @@
+// Parameter prep on the device: everything the reference re-derives from the raw
+// parameters on every call with ATen CPU ops --
+//   LUTransform.L / .U / .matrix / .inverse_matrix / .log_abs_det_jacobian   transforms.py:1271-1320
+//   HouseholderTransform._construct_householder_permutation                  transforms.py:795-809
+//   SequentialAffineTransform.matrix / .inverse_matrix / .bias               transforms.py:1457-1476
+// -- as a handful of batched fp64 launches over ALL affine blocks of a flow at once:
+//
+//   lu_unpack      raw fp32 [D,D] x 2n  ->  fp64 triangles  T[2i] = tril(L_raw,-1)+I,  T[2i+1] = triu(U_raw)^T
+//                  (U is kept transposed so that all 2n matrices are lower-triangular: one code path)
+//   tri_diag_inv   exact substitution on the 32x32 diagonal blocks
+//   tri_level<1|2> recursive doubling: for [A 0; C B], X = -B^-1 (C A^-1); one pair of launches per level,
+//                  all pairs of all 2n matrices in one grid
+//   gemm_f64       M = L (U^T)^T (k <= min(i,j)),  M^-1 = ((U^T)^-1)^T L^-1 (k >= max(i,j)); also the generic
+//                  batched C = alpha op(A) op(B) + beta C behind usf_gemm_f64 (Sequential composition, the
+//                  matrix gradients of the training path)
+//   householder    one wave per row of w_0: row <- row - 2 (row.v) v^T / (v.v), all nvs reflections in one launch
+//   pack_weight    fp64 -> fp32 with the engine's row/column permutation + zero padding, and the three bf16
+//                  planes of the bf16x3 kernels, in one pass
+//   fold_bias      c = -(Minv b) in fp64 (bias folding)
+//
+// All matrix products run on v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s dense peak on MI355X); the work is tiny
+// (cfg2: ~40 GFLOP for 33 blocks), so the kernel is a plain LDS-tiled 64x64 design -- what matters is that the
+// whole prep is ~25 launches instead of ~1000 host-bound ATen calls.
+#include "usf_common.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace usf {
+
+constexpr int NB = 32;         // diagonal block of the triangular inverse
+constexpr int PTRS_PER_LAUNCH = 48;
+
+struct PtrTab {
+  const float* L[PTRS_PER_LAUNCH];
+  const float* U[PTRS_PER_LAUNCH];
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// unpack: grid (blocks, matrices of this chunk)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lu_unpack_kernel(PtrTab t, int64_t first, int64_t D, double* __restrict__ tri) {
+  const float* __restrict__ L = t.L[blockIdx.y];
+  const float* __restrict__ U = t.U[blockIdx.y];
+  double* outL = tri + 2 * (first + blockIdx.y) * D * D;
+  double* outU = outL + D * D;
+  const int64_t total = D * D;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / D, j = e - i * D;
+    outL[e] = (j < i) ? (double)L[e] : (j == i ? 1.0 : 0.0);          // transforms.py:1271-1274
+    outU[e] = (j <= i) ? (double)U[j * D + i] : 0.0;                   // (triu(U_raw))^T, :1276-1279
+  }
+}
+
+// sum log|diag U| per matrix (transforms.py:1303-1320); one wave per matrix
+__global__ __launch_bounds__(64) void lu_ladj_kernel(PtrTab t, int64_t first, int64_t D, double* __restrict__ ladj) {
+  const float* __restrict__ U = t.U[blockIdx.x];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < D; i += 64) s += log(fabs((double)U[i * D + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) ladj[first + blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// inverse of the NB x NB diagonal blocks of lower-triangular matrices; grid (blocks per matrix, matrices)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tri_diag_inv_kernel(const double* __restrict__ tri, double* __restrict__ inv,
+                                                          int64_t D) {
+  __shared__ double T[NB][NB + 1];
+  __shared__ double X[NB][NB + 1];
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * NB;
+  const int nb = (int)((D - r0) < NB ? (D - r0) : NB);
+  const double* src = tri + (int64_t)blockIdx.y * D * D;
+  double* dst = inv + (int64_t)blockIdx.y * D * D;
+  for (int e = lane; e < NB * NB; e += 64) {
+    const int i = e / NB, j = e % NB;
+    T[i][j] = (i < nb && j < nb) ? src[(r0 + i) * D + r0 + j] : (i == j ? 1.0 : 0.0);
+    X[i][j] = 0.0;
+  }
+  __syncthreads();
+  if (lane < NB) {                       // lane j: column j of the inverse by forward substitution
+    const int j = lane;
+    X[j][j] = 1.0 / T[j][j];
+    for (int i = j + 1; i < NB; ++i) {
+      double s = 0.0;
+      for (int k = j; k < i; ++k) s += T[i][k] * X[k][j];
+      X[i][j] = -s / T[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = lane; e < NB * NB; e += 64) {
+    const int i = e / NB, j = e % NB;
+    if (i < nb && j < nb) dst[(r0 + i) * D + r0 + j] = X[i][j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 64x64 output tile of C = alpha op(A) op(B) + beta C on the f64 MFMA; 256 threads, K slabs of 16
+// op(A)(i,k): A[i*lda+k] or (TA) A[k*lda+i]; op(B)(k,j): B[k*ldb+j] or (TB) B[j*ldb+k]
+// only k in [kLo, kHi) is visited (callers pass the triangular support; everything outside is exact zero)
+// ---------------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__device__ __forceinline__ void gemm_tile_f64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                                              int64_t ldb, double* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                              int r0, int c0, int kLo, int kHi, double alpha, double beta) {
+  __shared__ double As[64][17];
+  __shared__ double Bs[16][66];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  if (kLo < 0) kLo = 0;
+  kLo &= ~15;
+  if (kHi > K) kHi = K;
+
+  double ra[4], rb[4];
+  auto load = [&](int k0) {
+    if (!TA) {
+      const int row = tid >> 2, kq = (tid & 3) * 4;
+      const int gr = r0 + row;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gk = k0 + kq + e;
+        ra[e] = (gr < M && gk < K) ? A[(int64_t)gr * lda + gk] : 0.0;
+      }
+    } else {
+      const int k = tid >> 4, iq = (tid & 15) * 4;
+      const int gk = k0 + k;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gr = r0 + iq + e;
+        ra[e] = (gr < M && gk < K) ? A[(int64_t)gk * lda + gr] : 0.0;
+      }
+    }
+    if (!TB) {
+      const int k = tid >> 4, jq = (tid & 15) * 4;
+      const int gk = k0 + k;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gc = c0 + jq + e;
+        rb[e] = (gc < N && gk < K) ? B[(int64_t)gk * ldb + gc] : 0.0;
+      }
+    } else {
+      const int col = tid >> 2, kq = (tid & 3) * 4;
+      const int gc = c0 + col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gk = k0 + kq + e;
+        rb[e] = (gc < N && gk < K) ? B[(int64_t)gc * ldb + gk] : 0.0;
+      }
+    }
+  };
+  auto stage = [&]() {
+    if (!TA) {
+      const int row = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[row][kq + e] = ra[e];
+    } else {
+      const int k = tid >> 4, iq = (tid & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[iq + e][k] = ra[e];
+    }
+    if (!TB) {
+      const int k = tid >> 4, jq = (tid & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bs[k][jq + e] = rb[e];
+    } else {
+      const int col = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bs[kq + e][col] = rb[e];
+    }
+  };
+
+  if (kLo < kHi) load(kLo);
+  for (int k0 = kLo; k0 < kHi; k0 += 16) {
+    __syncthreads();                 // previous slab's fragment reads are done
+    stage();
+    __syncthreads();
+    if (k0 + 16 < kHi) load(k0 + 16);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[wm * 32 + t * 16 + (lane & 15)][kk * 4 + (lane >> 4)];
+        b[t] = Bs[kk * 4 + (lane >> 4)][wn * 32 + t * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+  }
+  // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = r0 + wm * 32 + ti * 16 + (lane >> 4) + 4 * r;
+        const int gc = c0 + wn * 32 + tj * 16 + (lane & 15);
+        if (gr < M && gc < N) {
+          double v = alpha * acc[ti][tj][r];
+          if (beta != 0.0) v += beta * C[(int64_t)gr * ldc + gc];
+          C[(int64_t)gr * ldc + gc] = v;
+        }
+      }
+}
+
+struct GemmArgs {
+  const double* A; int64_t lda, sA;
+  const double* B; int64_t ldb, sB;
+  double* C; int64_t ldc, sC;
+  int M, N, K;
+  int tri;            // 0 full K; 1: k < min(r,c)+1 (lower x upper); 2: k >= max(r,c) (upper x lower)
+  double alpha, beta;
+};
+
+// grid (tilesN, tilesM, batch)
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  int kLo = 0, kHi = g.K;
+  if (g.tri == 1) kHi = (r0 < c0 ? r0 : c0) + 64;
+  if (g.tri == 2) kLo = (r0 > c0 ? r0 : c0);
+  const int64_t b = blockIdx.z;
+  gemm_tile_f64<TA, TB>(g.A + b * g.sA, g.lda, g.B + b * g.sB, g.ldb, g.C + b * g.sC, g.ldc, g.M, g.N, g.K, r0, c0,
+                        kLo, kHi, g.alpha, g.beta);
+}
+
+// one level of the recursive doubling on lower-triangular matrices; grid (tiles, pairs, matrices)
+//   pair j covers rows/cols [p0, p0+s) (A, inverse known) and [p0+s, p0+s+sb) (B, inverse known), C = tri[B rows, A cols]
+//   PHASE 1: work[C block] = C A^-1          PHASE 2: inv[C block] = -B^-1 work[C block]
+template <int PHASE>
+__global__ __launch_bounds__(256) void tri_level_kernel(const double* __restrict__ tri, double* __restrict__ inv,
+                                                        double* __restrict__ work, int64_t D, int s) {
+  const int64_t p0 = 2 * (int64_t)blockIdx.y * s;
+  const int sa = s;
+  const int64_t rest = D - p0 - s;
+  const int sb = (int)(rest < s ? rest : s);
+  const int tilesN = (sa + 63) / 64;
+  const int r0 = (blockIdx.x / tilesN) * 64, c0 = (blockIdx.x % tilesN) * 64;
+  if (r0 >= sb) return;
+  const int64_t mo = (int64_t)blockIdx.z * D * D;
+  const int64_t offC = (p0 + s) * D + p0;
+  if (PHASE == 1) {
+    // (C A^-1)[i][j] = sum_{k >= j} C[i][k] A^-1[k][j]
+    gemm_tile_f64<false, false>(tri + mo + offC, D, inv + mo + p0 * D + p0, D, work + mo + offC, D, sb, sa, sa, r0, c0,
+                                c0, sa, 1.0, 0.0);
+  } else {
+    // (B^-1 T)[i][j] = sum_{k <= i} B^-1[i][k] T[k][j]
+    gemm_tile_f64<false, false>(inv + mo + (p0 + s) * D + (p0 + s), D, work + mo + offC, D, inv + mo + offC, D, sb, sa,
+                                sb, r0, c0, 0, r0 + 64, -1.0, 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Householder product: one wave per row of w_0 (row-local: row <- row - 2 (row.v_k) v_k^T / (v_k.v_k))
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void householder_kernel(const float* __restrict__ w0, const float* __restrict__ vk,
+                                                         int64_t nvs, int64_t D, double* __restrict__ out) {
+  extern __shared__ double row[];
+  const int lane = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  for (int64_t j = lane; j < D; j += 64) row[j] = (double)w0[i * D + j];
+  for (int64_t k = 0; k < nvs; ++k) {
+    const float* v = vk + k * D;
+    double dot = 0.0, vv = 0.0;
+    for (int64_t j = lane; j < D; j += 64) {
+      const double vj = (double)v[j];
+      dot += row[j] * vj;
+      vv += vj * vj;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      dot += __shfl_xor(dot, o, 64);
+      vv += __shfl_xor(vv, o, 64);
+    }
+    const double f = 2.0 * dot / vv;
+    for (int64_t j = lane; j < D; j += 64) row[j] -= f * (double)v[j];
+  }
+  for (int64_t j = lane; j < D; j += 64) out[i * D + j] = row[j];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp64 -> permuted / padded fp32 weight + bf16x3 planes; grid (column blocks, n_out)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+template <typename S>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const S* __restrict__ src, int64_t lds_, int transpose,
+                                                          const int32_t* __restrict__ oidx, const int32_t* __restrict__ iidx,
+                                                          int64_t n_in, float* __restrict__ W, int64_t ldw,
+                                                          uint16_t* __restrict__ planes, int64_t ldp, int64_t plane_stride) {
+  const int64_t o = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t so = oidx ? oidx[o] : (int32_t)o;
+  float w = 0.0f;
+  if (c < n_in) {
+    const int32_t si = iidx ? iidx[c] : (int32_t)c;
+    if (so >= 0 && si >= 0) w = (float)(transpose ? src[(int64_t)si * lds_ + so] : src[(int64_t)so * lds_ + si]);
+    if (W) W[o * ldw + c] = w;
+  }
+  if (planes && c < ldp) {
+    const uint16_t hi = bf16_rne(w);
+    const float r = w - bf16_to_f32(hi);
+    const uint16_t mid = bf16_rne(r);
+    const uint16_t lo = bf16_rne(r - bf16_to_f32(mid));
+    planes[o * ldp + c] = hi;
+    planes[plane_stride + o * ldp + c] = mid;
+    planes[2 * plane_stride + o * ldp + c] = lo;
+  }
+}
+
+// c[o] = alpha * sum_k src[idx[o], k] * b[k]  (0 where idx[o] < 0); one wave per output
+__global__ __launch_bounds__(64) void matvec_rows_kernel(const double* __restrict__ src, int64_t lds_, int64_t K,
+                                                         const int32_t* __restrict__ idx, const double* __restrict__ b,
+                                                         double alpha, float* __restrict__ out32,
+                                                         double* __restrict__ out64) {
+  const int64_t o = blockIdx.x;
+  const int32_t so = idx ? idx[o] : (int32_t)o;
+  double s = 0.0;
+  if (so >= 0)
+    for (int64_t k = threadIdx.x; k < K; k += 64) s += src[(int64_t)so * lds_ + k] * b[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (threadIdx.x == 0) {
+    if (out32) out32[o] = (float)(alpha * s);
+    if (out64) out64[o] = alpha * s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static int launch_gemm(const GemmArgs& g, int transA, int transB, int64_t batch, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || batch <= 0) return 0;
+  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, (unsigned)batch);
+  if (!transA && !transB) gemm_f64_kernel<false, false><<<grid, 256, 0, stream>>>(g);
+  else if (transA && !transB) gemm_f64_kernel<true, false><<<grid, 256, 0, stream>>>(g);
+  else if (!transA && transB) gemm_f64_kernel<false, true><<<grid, 256, 0, stream>>>(g);
+  else gemm_f64_kernel<true, true><<<grid, 256, 0, stream>>>(g);
+  return check_launch("usf_gemm_f64");
+}
+
+int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
+             double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
+             double beta, int32_t tri, hipStream_t stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0 || tri < 0 || tri > 2) {
+    set_error("usf_gemm_f64: bad arguments");
+    return -1;
+  }
+  if (M > (1 << 24) || N > (1 << 24) || K > (1 << 24) || batch > 65535) {
+    set_error("usf_gemm_f64: size out of range");
+    return -2;
+  }
+  GemmArgs g{A, lda, sA, B, ldb, sB, C, ldc, sC, (int)M, (int)N, (int)K, tri, alpha, beta};
+  return launch_gemm(g, transA, transB, batch, stream);
+}
+
+int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream) {
+  if (!d || d->n < 0 || d->D <= 0 || (d->n > 0 && (!d->L_raw || !d->U_raw || !d->tri || !d->tri_inv || !d->work))) {
+    set_error("usf_lu_prepare_f64: bad descriptor");
+    return -1;
+  }
+  const int64_t n = d->n, D = d->D;
+  if (n == 0) return 0;
+  if (D > (1 << 15) || 2 * n > 65535) {
+    set_error("usf_lu_prepare_f64: D (%lld) or n (%lld) out of range", (long long)D, (long long)n);
+    return -2;
+  }
+  for (int64_t i = 0; i < n; ++i)
+    if (!d->L_raw[i] || !d->U_raw[i]) {
+      set_error("usf_lu_prepare_f64: null parameter pointer at %lld", (long long)i);
+      return -3;
+    }
+  // 1. unpack (chunks of PTRS_PER_LAUNCH: the pointer table travels as a kernel argument)
+  for (int64_t first = 0; first < n; first += PTRS_PER_LAUNCH) {
+    const int cnt = (int)((n - first) < PTRS_PER_LAUNCH ? (n - first) : PTRS_PER_LAUNCH);
+    PtrTab t;
+    for (int i = 0; i < PTRS_PER_LAUNCH; ++i) {
+      t.L[i] = d->L_raw[first + (i < cnt ? i : 0)];
+      t.U[i] = d->U_raw[first + (i < cnt ? i : 0)];
+    }
+    int bx = (int)((D * D + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    lu_unpack_kernel<<<dim3(bx, cnt), 256, 0, stream>>>(t, first, D, d->tri);
+    if (d->ladj) lu_ladj_kernel<<<cnt, 64, 0, stream>>>(t, first, D, d->ladj);
+  }
+  int rc = check_launch("lu_unpack");
+  if (rc) return rc;
+  // 2. zero the inverse (its upper triangle and not-yet-written blocks must read as exact zeros), diagonal blocks
+  hipError_t e = hipMemsetAsync(d->tri_inv, 0, sizeof(double) * 2 * n * D * D, stream);
+  if (e != hipSuccess) { set_error("usf_lu_prepare_f64: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  const int nblk = (int)((D + NB - 1) / NB);
+  tri_diag_inv_kernel<<<dim3(nblk, (unsigned)(2 * n)), 64, 0, stream>>>(d->tri, d->tri_inv, D);
+  // 3. recursive doubling
+  for (int64_t s = NB; s < D; s *= 2) {
+    const int pairs = (int)((D - s + 2 * s - 1) / (2 * s));
+    const int tiles = (int)(((s + 63) / 64) * ((s + 63) / 64));
+    dim3 grid(tiles, pairs, (unsigned)(2 * n));
+    tri_level_kernel<1><<<grid, 256, 0, stream>>>(d->tri, d->tri_inv, d->work, D, (int)s);
+    tri_level_kernel<2><<<grid, 256, 0, stream>>>(d->tri, d->tri_inv, d->work, D, (int)s);
+  }
+  rc = check_launch("tri_level");
+  if (rc) return rc;
+  // 4. M = L U = L (U^T)^T ; M^-1 = U^-1 L^-1 = ((U^T)^-1)^T L^-1      (transforms.py:1281-1293)
+  const int64_t DD = D * D;
+  if (d->M) {
+    GemmArgs g{d->tri, D, 2 * DD, d->tri + DD, D, 2 * DD, d->M, D, DD, (int)D, (int)D, (int)D, 1, 1.0, 0.0};
+    rc = launch_gemm(g, 0, 1, n, stream);
+    if (rc) return rc;
+  }
+  if (d->Minv) {
+    GemmArgs g{d->tri_inv + DD, D, 2 * DD, d->tri_inv, D, 2 * DD, d->Minv, D, DD, (int)D, (int)D, (int)D, 2, 1.0, 0.0};
+    rc = launch_gemm(g, 1, 0, n, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int householder(const float* w0, const float* vk, int64_t nvs, int64_t D, double* out, hipStream_t stream) {
+  if (!w0 || !out || D <= 0 || nvs < 0 || (nvs > 0 && !vk) || D > 8000) {
+    set_error("usf_householder_f64: bad arguments");
+    return -1;
+  }
+  householder_kernel<<<(unsigned)D, 64, sizeof(double) * D, stream>>>(w0, vk, nvs, D, out);
+  return check_launch("usf_householder_f64");
+}
+
+int pack_weight(const void* src, int32_t src_is_f32, int64_t lds_, int32_t transpose, const int32_t* out_idx, int64_t n_out,
+                const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ldp,
+                int64_t plane_stride, hipStream_t stream) {
+  if (!src || n_out < 0 || n_in < 0 || (!W && !planes) || (W && ldw < n_in) || (planes && ldp < n_in) || n_out > 65535) {
+    set_error("usf_pack_weight_f32: bad arguments");
+    return -1;
+  }
+  if (n_out == 0 || n_in == 0) return 0;
+  const int64_t cols = planes ? ldp : n_in;
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)n_out);
+  if (src_is_f32)
+    pack_weight_kernel<float><<<grid, 256, 0, stream>>>((const float*)src, lds_, transpose, out_idx, in_idx, n_in, W, ldw,
+                                                        (uint16_t*)planes, ldp, plane_stride);
+  else
+    pack_weight_kernel<double><<<grid, 256, 0, stream>>>((const double*)src, lds_, transpose, out_idx, in_idx, n_in, W,
+                                                         ldw, (uint16_t*)planes, ldp, plane_stride);
+  return check_launch("usf_pack_weight_f32");
+}
+
+int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
+                double alpha, float* out32, double* out64, hipStream_t stream) {
+  if (!src || !b || (!out32 && !out64) || n_out < 0 || K < 0) {
+    set_error("usf_matvec_f64: bad arguments");
+    return -1;
+  }
+  if (n_out == 0) return 0;
+  matvec_rows_kernel<<<(unsigned)n_out, 64, 0, stream>>>(src, lds_, K, idx, b, alpha, out32, out64);
+  return check_launch("usf_matvec_f64");
+}
+
+}  // namespace usf

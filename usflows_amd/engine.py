@@ -91,42 +91,70 @@ def _analyze(layers: Sequence[nn.Module]) -> List[_Step]:
 
 
 # ---------------------------------------------------------------------------------------------
-# fp64 parameter prep (device torch ops; batch independent; cached)
+# fp64 parameter prep: batched HIP kernels (usf_prep.hip), cached per parameter version
 # ---------------------------------------------------------------------------------------------
-def _affine_mats64(blk) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(M, M^-1, bias, ladj) of an affine block in fp64, following the reference's definitions."""
-    if isinstance(blk, T.LUTransform):
-        d = blk.dim
-        dev = blk.L_raw.device
-        eye = torch.eye(d, dtype=torch.float64, device=dev)
-        L = blk.L_raw.detach().double().tril(-1) + eye          # transforms.py:1271-1274
-        U = blk.U_raw.detach().double().triu()                  # :1276-1279
-        M = L @ U                                               # :1281-1283
-        Linv = torch.linalg.solve_triangular(L, eye, upper=False, unitriangular=True)
-        Minv = torch.linalg.solve_triangular(U, Linv, upper=True)   # U^-1 L^-1, :1289-1293
-        ladj = U.diagonal().abs().log().sum()                   # :1303-1320
-        return M, Minv, blk.bias_vector.detach().double(), ladj
-    if isinstance(blk, T.HouseholderTransform):
-        w = blk.w_0.detach().double()
-        for vk in blk.vk_householder.detach().double():         # :795-809 as rank-1 updates
-            w = w - 2.0 * torch.outer(w @ vk, vk) / torch.dot(vk, vk)
-        zero = torch.zeros(blk.dim, dtype=torch.float64, device=w.device)
-        return w, w.t().contiguous(), zero, zero.sum()
-    if isinstance(blk, T.SequentialAffineTransform):
-        parts = [_affine_mats64(t) for t in blk.transforms]
-        dev = parts[0][0].device
-        M = torch.eye(blk.dim, dtype=torch.float64, device=dev)
-        Minv = torch.eye(blk.dim, dtype=torch.float64, device=dev)
-        b = torch.zeros(blk.dim, dtype=torch.float64, device=dev)
-        ladj = torch.zeros((), dtype=torch.float64, device=dev)
-        for m, _, bi, la in parts:                              # :1457-1462, :1471-1476
-            M = M @ m
-            b = b @ m + bi
-            ladj = ladj + la
-        for _, mi, _, _ in parts[::-1]:                         # :1464-1469
-            Minv = Minv @ mi
-        return M, Minv, b, ladj
-    raise EngineUnsupported(type(blk).__name__)
+def _param(t: torch.Tensor, device=None) -> torch.Tensor:
+    t = t.detach()
+    if device is not None and t.device != torch.device(device):
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors: bool = False) -> Dict[int, dict]:
+    """``id(block) -> dict(M, Minv, b, ladj)`` (fp64 device tensors) for LUTransform / HouseholderTransform /
+    SequentialAffineTransform blocks, following the reference's definitions (transforms.py:1271-1320, 795-809,
+    1457-1476).  All LU blocks of the flow go through ONE batched ``usf_lu_prepare_f64`` call (chunked only to
+    bound the fp64 scratch at large D)."""
+    lus: Dict[int, nn.Module] = {}
+    hhs: Dict[int, nn.Module] = {}
+
+    def visit(b):
+        if isinstance(b, T.LUTransform):
+            lus.setdefault(id(b), b)
+        elif isinstance(b, T.HouseholderTransform):
+            hhs.setdefault(id(b), b)
+        elif isinstance(b, T.SequentialAffineTransform):
+            for t in b.transforms:
+                visit(t)
+        else:
+            raise EngineUnsupported(type(b).__name__)
+
+    for b in blocks:
+        visit(b)
+    res: Dict[int, dict] = {}
+    lu_list = list(lus.values())
+    if lu_list:
+        D = int(lu_list[0].dim)
+        chunk = max(1, min(len(lu_list), int(8e9 // (64 * D * D))))       # 8 fp64 [D,D] arrays per block in flight
+        for c0 in range(0, len(lu_list), chunk):
+            part = lu_list[c0: c0 + chunk]
+            out = _ext.lu_prepare([_param(l.L_raw, device) for l in part], [_param(l.U_raw, device) for l in part],
+                                  keep_factors=keep_factors)
+            for j, l in enumerate(part):
+                r = dict(M=out["M"][j], Minv=out["Minv"][j], b=_param(l.bias_vector, device).double(),
+                         ladj=out["ladj"][j])
+                if keep_factors:
+                    r.update(L=out["tri"][2 * j], Ut=out["tri"][2 * j + 1], Linv=out["tri_inv"][2 * j],
+                             Uinv_t=out["tri_inv"][2 * j + 1])
+                res[id(l)] = r
+    for h in hhs.values():
+        w = _ext.householder(_param(h.w_0, device), _param(h.vk_householder, device))
+        zero = torch.zeros(h.dim, dtype=torch.float64, device=w.device)
+        res[id(h)] = dict(M=w, Minv=w.t().contiguous(), b=zero, ladj=zero.sum())
+    for b in blocks:
+        if isinstance(b, T.SequentialAffineTransform) and id(b) not in res:
+            parts = [res[id(t)] for t in b.transforms]
+            M, Minv, bias = parts[0]["M"], parts[0]["Minv"], parts[0]["b"]      # eye @ M_1 == M_1 exactly
+            ladj = parts[0]["ladj"]
+            for p_ in parts[1:]:                                                  # :1457-1462, :1471-1476
+                M = _ext.matmul_f64(M, p_["M"])
+                bias = _ext.matmul_f64(bias.reshape(1, -1).contiguous(), p_["M"]).reshape(-1) + p_["b"]
+                Minv = _ext.matmul_f64(p_["Minv"], Minv)                          # :1464-1469 (reverse order)
+                ladj = ladj + p_["ladj"]
+            res[id(b)] = dict(M=M, Minv=Minv, b=bias, ladj=ladj)
+    return res
 
 
 class FlowEngine:
@@ -248,12 +276,16 @@ class FlowEngine:
         pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}}
         ladj_total = torch.zeros((), dtype=torch.float64, device=device)
         with torch.no_grad():
+            blocks, seen = [], set()
+            for s in self.steps:
+                if s.kind == "affine" and id(s.module) not in seen:
+                    seen.add(id(s.module))
+                    blocks.append(s.module)
+            prepared = prepare_affine_blocks(blocks, device)
+            for b_ in blocks:
+                pk["affine"][id(b_)] = prepared[id(b_)]
             for i, s in enumerate(self.steps):
                 if s.kind == "affine":
-                    if id(s.module) not in pk["affine"]:
-                        M, Minv, b, ladj = _affine_mats64(s.module)
-                        pk["affine"][id(s.module)] = dict(M=M.to(device), Minv=Minv.to(device), b=b.to(device),
-                                                          ladj=ladj.to(device))
                     la = pk["affine"][id(s.module)]["ladj"]
                     ladj_total = ladj_total + (-la if s.inverted else la)
                 elif s.kind == "scale":
@@ -269,6 +301,9 @@ class FlowEngine:
         return pk
 
     def _pack_coupling(self, i: int, layer, device) -> dict:
+        """Static description of one coupling layer + handles to its raw conditioner parameters; the weight images
+        themselves (unfused: ``_unfused_pack``, fused: ``_fused_pack`` / ``_fused_split``) are built on first use
+        by ``usf_pack_weight_f32`` launches (mask-aware column / row selection, zero padding, bf16x3 planes)."""
         cond = layer.conditioner
         flip = self._flip[i]
         # mask==1 features condition, mask==0 features are transformed (transforms.py:285-290)
@@ -279,66 +314,124 @@ class FlowEngine:
             pass_off, pass_n, pass_idx = 0, self.n0a, self.seg_idx[: self.n0a]
             tr_off, tr_n, tr_idx = self.n0a, self.n1, self.seg_idx[self.n0a: self.n0a + self.n1]
         act, slope = _activation_of(cond.f)
-        f64 = lambda t: t.detach().double().to(device)
         has_ctx = isinstance(cond, ConditionalDenseNN)
         ctx_l = None
         if isinstance(cond, ConvNet):
             # Linear, [f, Linear] x n, Linear (networks.py:287-308): the last block's Linear and the final Linear
             # have no activation between them -> one output map, folded in fp64
             first, hidden, (W_last, b_last), widths = cond.mlp_view()
-            W_last, b_last = W_last.to(device), b_last.to(device)
+            W_last, b_last = W_last.to(device).contiguous(), b_last.to(device).contiguous()
         else:
             lin = list(cond.layers)
             first = lin[0]
             ctx_l = lin[1] if has_ctx else None
             hidden = lin[2:-1] if has_ctx else lin[1:-1]
-            W_last, b_last = f64(lin[-1].weight), f64(lin[-1].bias)
+            W_last, b_last = _param(lin[-1].weight, device), _param(lin[-1].bias, device)
             widths = cond.hidden_dims
-
-        def pad_rows(W, b, n_pad):
-            Wp = torch.zeros(n_pad, W.shape[1], dtype=W.dtype, device=W.device)
-            Wp[: W.shape[0]] = W
-            bp = torch.zeros(n_pad, dtype=b.dtype, device=b.device)
-            bp[: b.shape[0]] = b
-            return Wp, bp
-
-        def pad_cols(W, k_pad):
-            Wp = torch.zeros(W.shape[0], k_pad, dtype=W.dtype, device=W.device)
-            Wp[:, : W.shape[1]] = W
-            return Wp
-
         h = [int(x) for x in widths]
         hp = [_round_up(x, 4) for x in h]
-        W_in = self._perm_mat(f64(first.weight), torch.arange(h[0]), pass_idx).double()   # [h0, pass_n]
-        W_in, b_in = pad_rows(W_in, f64(first.bias), hp[0])
-        layers = [(W_in.float().contiguous(), b_in.float().contiguous())]
-        for j, l in enumerate(hidden):
-            W, b = pad_rows(pad_cols(f64(l.weight), hp[j]), f64(l.bias), hp[j + 1])
-            layers.append((W.float().contiguous(), b.float().contiguous()))
-        W_out = pad_cols(W_last[tr_idx.to(device)], hp[-1])                               # [tr_n, h_last_pad]
-        b_out = b_last[tr_idx.to(device)]
-        d = dict(pass_off=pass_off, pass_n=pass_n, tr_off=tr_off, tr_n=tr_n, act=act, slope=slope,
-                 hidden=hp, layers=layers, W_out=W_out.float().contiguous(), b_out=b_out.float().contiguous(),
-                 has_ctx=has_ctx)
-        if has_ctx:
-            Wc = torch.zeros(hp[0], 4, dtype=torch.float64, device=device)
-            Wc[: h[0], 0] = f64(ctx_l.weight)[:, 0]
-            bc = torch.zeros(hp[0], dtype=torch.float64, device=device)
-            bc[: h[0]] = f64(ctx_l.bias)
-            d["W_ctx4"] = Wc.float().contiguous()      # [h0, 4]: context rides in column 0 of a 4-wide K
-            d["W_ctx1"] = Wc[:, 0].float().contiguous()  # [h0]: form the fused coupling kernel takes
-            d["b_ctx"] = bc.float().contiguous()
-        return d
+        raw = dict(first=(_param(first.weight, device), _param(first.bias, device)),
+                   hidden=[(_param(l.weight, device), _param(l.bias, device)) for l in hidden],
+                   last=(W_last, b_last), h=h, device=device,
+                   pass_idx=pass_idx.to(torch.int32), tr_idx=tr_idx.to(torch.int32),
+                   ctx=(_param(ctx_l.weight, device), _param(ctx_l.bias, device)) if has_ctx else None)
+        return dict(pass_off=pass_off, pass_n=pass_n, tr_off=tr_off, tr_n=tr_n, act=act, slope=slope,
+                    hidden=hp, has_ctx=has_ctx, raw=raw)
+
+    def _sel(self, idx: torch.Tensor, n_total: int, device) -> torch.Tensor:
+        """int32 device selector: idx (feature numbers, -1 = padding) extended with -1 to n_total"""
+        t = torch.full((n_total,), -1, dtype=torch.int32)
+        t[: idx.numel()] = idx
+        return t.to(device)
+
+    def _packed(self, src, out_sel, n_out, in_sel, n_in, planes_sel=None, planes_ld=0, want_w=True):
+        """(W [n_out, n_in] fp32 | None, planes [3, n_out, planes_ld] bf16 | None) from a raw parameter"""
+        dev = src.device
+        W = torch.empty(n_out, n_in, dtype=torch.float32, device=dev) if want_w else None
+        if W is not None:
+            _ext.pack_weight(src, out_sel, n_out, in_sel, n_in, W=W, ldw=n_in)
+        planes = None
+        if planes_ld:
+            planes = torch.empty(3, n_out, planes_ld, dtype=torch.bfloat16, device=dev)
+            _ext.pack_weight(src, out_sel, n_out, in_sel if planes_sel is None else planes_sel,
+                             min(n_in, planes_ld) if planes_sel is None else int(planes_sel.numel()), planes=planes)
+        return W, planes
+
+    def _packed_vec(self, src, sel, n) -> torch.Tensor:
+        out = torch.empty(n, dtype=torch.float32, device=src.device)
+        _ext.pack_weight(src.reshape(1, -1), None, 1, sel, n, W=out, ldw=n, ld_src=src.numel())
+        return out
+
+    def _unfused_pack(self, pk, cp) -> dict:
+        """per-layer weight images for the chain-of-linears form of the conditioner (any width / depth)"""
+        if "unfused" in cp:
+            return cp["unfused"]
+        raw = cp["raw"]
+        dev, h, hp = raw["device"], raw["h"], cp["hidden"]
+        pass_sel = self._sel(raw["pass_idx"], cp["pass_n"], dev)
+        layers = []
+        W, b = raw["first"]
+        Wp, _ = self._packed(W, self._iarange(h[0], hp[0], dev), hp[0], pass_sel, cp["pass_n"])
+        layers.append((Wp, self._packed_vec(b, self._iarange(h[0], hp[0], dev), hp[0])))
+        for j, (W, b) in enumerate(raw["hidden"]):
+            Wp, _ = self._packed(W, self._iarange(h[j + 1], hp[j + 1], dev), hp[j + 1],
+                                 self._iarange(h[j], hp[j], dev), hp[j])
+            layers.append((Wp, self._packed_vec(b, self._iarange(h[j + 1], hp[j + 1], dev), hp[j + 1])))
+        W, b = raw["last"]
+        tr_sel = self._sel(raw["tr_idx"], cp["tr_n"], dev)
+        W_out, _ = self._packed(W, tr_sel, cp["tr_n"], self._iarange(h[-1], hp[-1], dev), hp[-1])
+        u = dict(layers=layers, W_out=W_out, b_out=self._packed_vec(b, tr_sel, cp["tr_n"]))
+        if cp["has_ctx"]:
+            Wc, bc = raw["ctx"]
+            rows = self._iarange(h[0], hp[0], dev)
+            # [h0, 4]: context rides in column 0 of a 4-wide K
+            u["W_ctx4"], _ = self._packed(Wc, rows, hp[0], self._iarange(1, 4, dev), 4)
+            u["b_ctx"] = self._packed_vec(bc, rows, hp[0])
+        cp["unfused"] = u
+        return u
+
+    def _idx_dev(self, layout: str, device) -> torch.Tensor:
+        """int32 device copy of the feature index of every column of a layout (-1 = padding column)"""
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        key = (layout, str(device))
+        if key not in cache:
+            cache[key] = self._idx(layout).to(device=device, dtype=torch.int32)
+        return cache[key]
+
+    def _iarange(self, n_valid: int, n_total: int, device) -> torch.Tensor:
+        """int32 [0 .. n_valid-1, -1, -1, ...] of length n_total (row/column selector with zero padding)"""
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        key = ("arange", n_valid, n_total, str(device))
+        if key not in cache:
+            t = torch.full((n_total,), -1, dtype=torch.int32)
+            t[:n_valid] = torch.arange(n_valid, dtype=torch.int32)
+            cache[key] = t.to(device)
+        return cache[key]
+
+    def _wants_planes(self, n_out: int, K: int) -> bool:
+        return self.gemm_mode == "bf16x3" and K % 8 == 0 and n_out > 64
 
     def _mat(self, pk, blk, which: str, out_layout: str, in_layout: str) -> torch.Tensor:
+        """permuted / padded fp32 image of an affine block's M or M^-1 (+ its bf16x3 planes), one launch"""
         key = (id(blk), which, out_layout, in_layout)
         if key not in pk["mats"]:
-            pk["mats"][key] = self._perm_mat(pk["affine"][id(blk)][which], self._idx(out_layout), self._idx(in_layout))
+            src = pk["affine"][id(blk)][which]
+            dev = src.device
+            oi, ii = self._idx_dev(out_layout, dev), self._idx_dev(in_layout, dev)
+            n_out, n_in = int(oi.numel()), int(ii.numel())
+            W = torch.empty(n_out, n_in, dtype=torch.float32, device=dev)
+            planes = None
+            if self._wants_planes(n_out, n_in):
+                planes = torch.empty(3, n_out, _round_up(n_in, 32), dtype=torch.bfloat16, device=dev)
+            _ext.pack_weight(src, oi, n_out, ii, n_in, W=W, ldw=n_in, planes=planes)
+            pk["mats"][key] = W
+            if planes is not None:
+                pk["mats"][("planes", W.data_ptr())] = planes
         return pk["mats"][key]
 
     def _split_kw(self, pk, W: torch.Tensor, K: int) -> dict:
         """descriptor fields that hand the bf16x3 planes of W to usf_linear_f32 (empty in f32 mode)"""
-        if self.gemm_mode != "bf16x3" or K % 8 != 0 or W.shape[0] <= 64:
+        if not self._wants_planes(W.shape[0], K):
             return {}
         planes = self._split_planes(pk, W)
         return dict(W_split=planes.data_ptr(), ldw_split=planes.shape[2],
@@ -350,20 +443,21 @@ class FlowEngine:
         key = ("planes", W.data_ptr())
         if key not in pk["mats"]:
             N, K = W.shape
-            Kp = _round_up(K, 32)
-            hi = W.to(torch.bfloat16)
-            r = W - hi.float()
-            mid = r.to(torch.bfloat16)
-            lo = (r - mid.float()).to(torch.bfloat16)
-            planes = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=W.device)
-            planes[0, :, :K], planes[1, :, :K], planes[2, :, :K] = hi, mid, lo
+            planes = torch.empty(3, N, _round_up(K, 32), dtype=torch.bfloat16, device=W.device)
+            _ext.pack_weight(W, None, N, None, K, planes=planes)
             pk["mats"][key] = planes
         return pk["mats"][key]
 
     def _vec(self, pk, name, v64, layout: str, pad: float) -> torch.Tensor:
         key = (name, layout, pad)
         if key not in pk["vecs"]:
-            pk["vecs"][key] = self._perm_vec(v64, self._idx(layout), pad)
+            if pad == 0.0:
+                idx = self._idx_dev(layout, v64.device)
+                out = torch.empty(idx.numel(), dtype=torch.float32, device=v64.device)
+                _ext.pack_weight(v64, None, 1, idx, int(idx.numel()), W=out, ldw=int(idx.numel()))
+                pk["vecs"][key] = out
+            else:
+                pk["vecs"][key] = self._perm_vec(v64, self._idx(layout), pad)
         return pk["vecs"][key]
 
     # ---- workspace ----------------------------------------------------------------------------
@@ -469,7 +563,8 @@ class FlowEngine:
                         # (y - b) @ Minv^T == y @ Minv^T + c with c = -(Minv b), c formed in fp64 at pack
                         # time: keeps the bias out of the K loop's registers ("bias folding")
                         if "c" not in a:
-                            a["c"] = -(a["Minv"] @ a["b"])
+                            a["c"] = torch.empty_like(a["b"])
+                            _ext.matvec_f64(a["Minv"], a["b"], alpha=-1.0, out64=a["c"])
                         kw["bias"] = self._vec(pk, ("c", id(blk)), a["c"], out_layout, 0.0).data_ptr()
                 else:
                     W = self._mat(pk, blk, "M", out_layout, in_layout)
@@ -525,15 +620,16 @@ class FlowEngine:
                 ops.append(self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None))
             else:
                 hbufs = ["H1", "H2"]
+                un = self._unfused_pack(pk, cp)
                 src_ptr, src_ld, src_K = zptr + 4 * cp["pass_off"], self.LD, cp["pass_n"]
-                for j, (W, b) in enumerate(cp["layers"]):
+                for j, (W, b) in enumerate(un["layers"]):
                     hb = ws[hbufs[j % 2]]
                     kw = {}
                     if j == 0 and use_ctx:
                         # P = ctx * Wc + bc as a K=4 GEMM (context in column 0 of a zero-padded [B,4] operand);
                         # added to (acc + b_in) before the activation, as networks.py:741-745 does
-                        ops.append(lin_op(A=ws["ctx4"].data_ptr(), lda=4, W=cp["W_ctx4"].data_ptr(), ldw=4,
-                                          bias=cp["b_ctx"].data_ptr(), C=ws["P"].data_ptr(), ldc=self.hmax,
+                        ops.append(lin_op(A=ws["ctx4"].data_ptr(), lda=4, W=un["W_ctx4"].data_ptr(), ldw=4,
+                                          bias=un["b_ctx"].data_ptr(), C=ws["P"].data_ptr(), ldc=self.hmax,
                                           M=B, N=cp["hidden"][0], K=4, res_sign=1.0, slope=0.0, act=_ext.ACT_NONE))
                         kw = dict(addend=ws["P"].data_ptr(), ldadd=self.hmax)
                     kw.update(self._split_kw(pk, W, src_K))
@@ -542,10 +638,10 @@ class FlowEngine:
                                       slope=cp["slope"], act=cp["act"], **kw))
                     src_ptr, src_ld, src_K = hb.data_ptr(), self.hmax, W.shape[0]
                 tptr = zptr + 4 * cp["tr_off"]
-                ops.append(lin_op(A=src_ptr, lda=src_ld, W=cp["W_out"].data_ptr(), ldw=cp["W_out"].shape[1],
-                                  bias=cp["b_out"].data_ptr(), residual=tptr, ldr=self.LD, C=tptr, ldc=self.LD,
+                ops.append(lin_op(A=src_ptr, lda=src_ld, W=un["W_out"].data_ptr(), ldw=un["W_out"].shape[1],
+                                  bias=un["b_out"].data_ptr(), residual=tptr, ldr=self.LD, C=tptr, ldc=self.LD,
                                   M=B, N=cp["tr_n"], K=src_K, res_sign=sign, slope=0.0, act=_ext.ACT_NONE,
-                                  **self._split_kw(pk, cp["W_out"], src_K)))
+                                  **self._split_kw(pk, un["W_out"], src_K)))
             k += 1
 
         # ---- final layout fix-up ------------------------------------------------------------------
@@ -568,30 +664,54 @@ class FlowEngine:
 
     def _fused_pack(self, cp) -> dict:
         """weights re-laid out for the fused kernel's padding contract (include/usflows_hip.h)"""
-        if "fused" in cp:
-            return cp["fused"]
         lib = _ext.load()
+        raw = cp["raw"]
+        dev, h = raw["device"], raw["h"]
         Hp = lib.usf_coupling_padded_width(max(cp["hidden"]))
         Kp = _round_up(cp["pass_n"], 32)
         Np = _round_up(cp["tr_n"], 32)
+        split = self.gemm_mode == "bf16x3" and Hp == 256
+        if "fused" in cp and (not split or "split" in cp["fused"]):
+            return cp["fused"]
+        pass_sel = self._sel(raw["pass_idx"], Kp, dev)
+        tr_sel = self._sel(raw["tr_idx"], Np, dev)
+        s3 = dict(hid=[]) if split else None
+        # hidden (K) axes of the split hidden / output planes in the accumulator order of the kernel
+        perm_sel = {}
 
-        def pad2(W, rows, cols):
-            out = torch.zeros(rows, cols, dtype=torch.float32, device=W.device)
-            out[: W.shape[0], : W.shape[1]] = W
-            return out
+        def kperm(n_valid):
+            if n_valid not in perm_sel:
+                g, j = torch.arange(4)[:, None], torch.arange(8)[None, :]
+                within = torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4)).reshape(-1)          # [32]
+                perm = (torch.arange(0, Hp, 32)[:, None] + within[None, :]).reshape(-1)
+                perm = torch.where(perm < n_valid, perm, torch.full_like(perm, -1))
+                perm_sel[n_valid] = perm.to(device=dev, dtype=torch.int32)
+            return perm_sel[n_valid]
 
-        def pad1(v, n):
-            out = torch.zeros(n, dtype=torch.float32, device=v.device)
-            out[: v.shape[0]] = v
-            return out
-
-        W0, b0 = cp["layers"][0]
-        f = dict(Hp=Hp, W_in=pad2(W0, Hp, Kp), b_in=pad1(b0, Hp),
-                 hid=[(pad2(W, Hp, Hp), pad1(b, Hp)) for W, b in cp["layers"][1:]],
-                 W_out=pad2(cp["W_out"], Np, Hp), b_out=pad1(cp["b_out"], Np))
+        W, b = raw["first"]
+        rows0 = self._iarange(h[0], Hp, dev)
+        W_in, P = self._packed(W, rows0, Hp, pass_sel, Kp, planes_ld=Kp if split else 0)
+        if split:
+            s3["in"] = P
+        f = dict(Hp=Hp, W_in=W_in, b_in=self._packed_vec(b, rows0, Hp), hid=[])
+        for j, (W, b) in enumerate(raw["hidden"]):
+            rows = self._iarange(h[j + 1], Hp, dev)
+            Wp, P = self._packed(W, rows, Hp, self._iarange(h[j], Hp, dev), Hp,
+                                 planes_sel=kperm(h[j]) if split else None, planes_ld=Hp if split else 0)
+            f["hid"].append((Wp, self._packed_vec(b, rows, Hp)))
+            if split:
+                s3["hid"].append(P)
+        W, b = raw["last"]
+        f["W_out"], P = self._packed(W, tr_sel, Np, self._iarange(h[-1], Hp, dev), Hp,
+                                     planes_sel=kperm(h[-1]) if split else None, planes_ld=Hp if split else 0)
+        f["b_out"] = self._packed_vec(b, tr_sel, Np)
+        if split:
+            s3["out"] = P
+            f["split"] = s3
         if cp["has_ctx"]:
-            f["W_ctx"] = pad1(cp["W_ctx1"], Hp)
-            f["b_ctx"] = pad1(cp["b_ctx"], Hp)
+            Wc, bc = raw["ctx"]
+            f["W_ctx"] = self._packed_vec(Wc, rows0, Hp)        # layers[1].weight is [h0, 1]: one column
+            f["b_ctx"] = self._packed_vec(bc, rows0, Hp)
         cp["fused"] = f
         return f
 
@@ -613,8 +733,8 @@ class FlowEngine:
             d.context = ws_ctx["ctx"].data_ptr()
             d.W_ctx, d.b_ctx = f["W_ctx"].data_ptr(), f["b_ctx"].data_ptr()
         d.sign, d.slope, d.act = sign, cp["slope"], cp["act"]
-        if self.gemm_mode == "bf16x3" and f["Hp"] == 256:
-            s3 = self._fused_split(f)
+        if self.gemm_mode == "bf16x3" and "split" in f:
+            s3 = f["split"]
             d.split_in, d.split_in_ld, d.split_in_plane = s3["in"].data_ptr(), s3["in"].shape[2], s3["in"].shape[1] * s3["in"].shape[2]
             for j, P in enumerate(s3["hid"]):
                 d.split_hid[j] = P.data_ptr()
@@ -622,33 +742,6 @@ class FlowEngine:
                 d.split_hid_ld, d.split_hid_plane = s3["hid"][0].shape[2], s3["hid"][0].shape[1] * s3["hid"][0].shape[2]
             d.split_out, d.split_out_ld, d.split_out_plane = s3["out"].data_ptr(), s3["out"].shape[2], s3["out"].shape[1] * s3["out"].shape[2]
         return op
-
-    @staticmethod
-    def _fused_split(f: dict) -> dict:
-        """bf16x3 planes of the fused kernel's padded weights; hidden (K) axes of the hidden / output layers in
-        the accumulator order of the kernel (include/usflows_hip.h)"""
-        if "split" in f:
-            return f["split"]
-        Hp = f["Hp"]
-        dev = f["W_in"].device
-        g, j = torch.arange(4, device=dev)[:, None], torch.arange(8, device=dev)[None, :]
-        within = torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4)).reshape(-1)          # [32]
-        perm = (torch.arange(0, Hp, 32, device=dev)[:, None] + within[None, :]).reshape(-1)
-
-        def planes(W):
-            N, K = W.shape
-            Kp = _round_up(K, 32)
-            hi = W.to(torch.bfloat16)
-            r = W - hi.float()
-            mid = r.to(torch.bfloat16)
-            lo = (r - mid.float()).to(torch.bfloat16)
-            out = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=W.device)
-            out[0, :, :K], out[1, :, :K], out[2, :, :K] = hi, mid, lo
-            return out
-
-        f["split"] = dict(**{"in": planes(f["W_in"])}, hid=[planes(W[:, perm]) for W, _ in f["hid"]],
-                          out=planes(f["W_out"][:, perm]))
-        return f["split"]
 
     # ---- execution ----------------------------------------------------------------------------
     def _plan(self, direction, B, device, has_ctx, final):
