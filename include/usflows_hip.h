@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 3
+#define USF_ABI_VERSION 4
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -242,6 +242,35 @@ int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int
  * out64 receive the result.  Bias folding c = -(Minv b) and SequentialAffineTransform.bias (transforms.py:1471-1476). */
 int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
                    double alpha, float* out32, double* out64, usf_stream_t stream);
+
+/*
+ * ---- backward pass of the training step -----------------------------------------------
+ * Flow.fit (flows.py:196-199) differentiates -log_prob(batch).mean(); these are the batch-sized pieces of that
+ * backward pass (usf_train.hip).  Data gradients of the linear layers are usf_linear_f32 launches on the transposed
+ * weight image (usf_pack_weight_f32 with transpose = 1).
+ *
+ * usf_wgrad_f32: G[n,k] = alpha * sum_m Y[m,n] * A[m,k] + beta * G[n,k]   -- the weight gradient of F.linear
+ *   (Y = gradient at the layer's output [M,N], A = the layer's input [M,K]); exact-f32 MFMA, the batch is cut into
+ *   row ranges whose partial products are summed in a fixed order (bitwise reproducible).  Y / A rows must be 16-byte
+ *   aligned (ld % 4 == 0).  workspace: at least usf_wgrad_workspace_floats(M,N,K) floats.
+ * usf_colsum_f32: out[n] = alpha * sum_m Y[m,n] + beta * out[n]           -- the bias gradient; workspace
+ *   min(512, ceil(M/512)) * N floats.
+ */
+int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
+                  int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);
+int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K);
+int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
+                   float* workspace, int64_t workspace_floats, usf_stream_t stream);
+
+/* (Leaky)ReLU backward from the saved layer OUTPUT h: d[m,j] *= (h[m,j] > 0 ? 1 : slope), slope >= 0
+ * (ATen leaky_relu_backward on the pre-activation; sign(h) == sign(pre-activation)). networks.py:745-749 */
+int usf_act_grad_f32(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
+                     usf_stream_t stream);
+
+/* Backward of usf_base_logprob_f32 for LAPLACE / NORMAL: g[m,d] = g_lp[m] * d/dz base_d(z[m,d]) for d < D, 0 for
+ * D <= d < ldg (flows.py:245 through torch Laplace.log_prob / Normal.log_prob). */
+int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base,
+                              const float* loc, const float* scale, float* g, int64_t ldg, usf_stream_t stream);
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc) for kind 1|2|0|3: binding self-check */

@@ -216,6 +216,96 @@ def _emu_matvec_f64(src, b, *, idx=None, n_out=None, alpha=1.0, out32=None, out6
         out64.copy_(r)
 
 
+# ---- batch-sized entry points as the _ext wrappers present them (tensors + element offsets) ---------------
+def _view(t, off, rows, cols, ld):
+    return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1), off)
+
+
+def _emu_linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_sub=None, residual=None, ldr=0,
+                post_mul=None, res_sign=1.0, act=_ext.ACT_NONE, slope=0.0, a_off=0, c_off=0, r_off=0, addend=None,
+                ldadd=0, W_split=None, dtype=torch.float64):
+    a = _view(A, a_off, M, K, lda).to(dtype)
+    if pre_div is not None:
+        a = a / pre_div[:K].to(dtype)
+    if pre_sub is not None:
+        a = a - pre_sub[:K].to(dtype)
+    v = a @ _view(W, 0, N, K, ldw).to(dtype).t()
+    if bias is not None:
+        v = v + bias[:N].to(dtype)
+    if addend is not None:
+        v = v + _view(addend, 0, M, N, ldadd).to(dtype)
+    if act == _ext.ACT_LEAKY_RELU:
+        v = torch.where(v > 0, v, v * slope)
+    if residual is not None:
+        v = _view(residual, r_off, M, N, ldr).to(dtype) + res_sign * v
+    if post_mul is not None:
+        v = v * post_mul[:N].to(dtype)
+    _view(C_out, c_off, M, N, ldc).copy_(v.to(torch.float32))
+
+
+def _emu_wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0):
+    y = _view(Y, y_off, M, N, ldy).double()
+    a = _view(A, a_off, M, K, lda).double()
+    g = _view(G, g_off, N, K, ldg)
+    g.copy_((alpha * (y.t() @ a) + (beta * g.double() if beta != 0.0 else 0.0)).float())
+
+
+def _emu_colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):
+    o = out.reshape(-1)[:N]
+    o.copy_((alpha * _view(Y, y_off, M, N, ldy).double().sum(0) + (beta * o.double() if beta != 0.0 else 0.0)).float())
+
+
+def _emu_act_grad(d, h, *, M, H, ldd, ldh, act, slope):
+    if act == _ext.ACT_NONE:
+        return
+    dv, hv = _view(d, 0, M, H, ldd), _view(h, 0, M, H, ldh)
+    dv.copy_(torch.where(hv > 0, dv, dv * slope))
+
+
+def _emu_base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):
+    zz = _view(z, 0, M, D, ldz).double()
+    dist = (torch.distributions.Laplace if base == _ext.BASE_LAPLACE else torch.distributions.Normal)(loc.double(), scale.double())
+    out.copy_((dist.log_prob(zz).sum(-1) + logdet_const).float())
+
+
+def _emu_base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
+    t = _view(z, 0, M, D, ldz).double() - loc.double()
+    if base == _ext.BASE_LAPLACE:
+        v = -torch.sign(t) / scale.double()
+    else:
+        v = -t / (scale.double() ** 2)
+    gv = _view(g, 0, M, ldg, ldg)
+    gv.zero_()
+    gv[:, :D] = (v * g_lp.double()[:, None]).float()
+
+
+def _emu_gemm_f64(A, B, Cout, *, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, strideA=0, strideB=0,
+                  strideC=0, alpha=1.0, beta=0.0, tri=0, a_off=0, b_off=0, c_off=0):
+    for i in range(batch):
+        a = _view(A, a_off + i * strideA, K if transA else M, M if transA else K, lda)
+        b = _view(B, b_off + i * strideB, N if transB else K, K if transB else N, ldb)
+        c = _view(Cout, c_off + i * strideC, M, N, ldc)
+        r = alpha * ((a.t() if transA else a) @ (b.t() if transB else b))
+        c.copy_(r + beta * c if beta != 0.0 else r)
+
+
+def install_training_emulation(monkeypatch):
+    """parameter prep + every batch-sized entry point of the training path on torch-CPU; FlowEngine runs its op
+    lists through run_plan.  Exercises engine.py / training.py (layouts, index maps, chain rule) without a GPU."""
+    from usflows_amd.engine import FlowEngine
+    install_prep_emulation(monkeypatch)
+    monkeypatch.setattr(_ext, "linear", _emu_linear)
+    monkeypatch.setattr(_ext, "wgrad", _emu_wgrad)
+    monkeypatch.setattr(_ext, "colsum", _emu_colsum)
+    monkeypatch.setattr(_ext, "act_grad", _emu_act_grad)
+    monkeypatch.setattr(_ext, "base_logprob", _emu_base_logprob)
+    monkeypatch.setattr(_ext, "base_logprob_grad", _emu_base_logprob_grad)
+    monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
+    monkeypatch.setattr(FlowEngine, "_check_input", lambda self, x: x.contiguous().float())
+    monkeypatch.setattr(FlowEngine, "_execute",
+                        lambda self, plan, x, out, context: run_plan(self, plan, x, out, context, dtype=torch.float64))
+
+
 def install_prep_emulation(monkeypatch):
     """route the engine's parameter-prep calls to the torch-CPU statements above (tests without a GPU)"""
     monkeypatch.setattr(_ext, "lu_prepare", _emu_lu_prepare)

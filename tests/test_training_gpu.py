@@ -1,0 +1,122 @@
+"""Device training path on MI355X: Flow.log_prob under autograd = HIP forward + HIP backward
+(usflows_amd/training.py through the C ABI), against autograd through the oracle's fp64 restatement of the
+reference's log_prob (what Flow.fit differentiates, flows.py:196-199).  Gradient tolerance: 2e-4 of the largest
+entry of each parameter's gradient (fp32 arithmetic through 2K+2 layers, forward and back)."""
+import pytest
+import torch
+
+from golden_util import load_case
+from model_util import build_flow
+from oracle import usflows_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = ["synth_d7_k3_hh0_laplace", "synth_d16_k3_densenn_relu", "synth_d7_k3_hh1_conj_normal",
+         "synth_d16_k4_hh2_conj_laplace", "synth_d33_k3_lu2_hh1", "synth_d7_k3_soft_ctx", "synth_d64_k6_hh0_laplace",
+         "synth_d64_k4_hh1_conj_laplace", "init_d2_k4_hh0_laplace"]
+
+
+def oracle_grads(spec, sd, x, g_lp, context=None):
+    sd64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    lp = orc.flow_log_prob(sd64, spec, x.double(), context.double() if context is not None else None)
+    (lp * g_lp.double()).sum().backward()
+    return lp.detach(), {k: v.grad for k, v in sd64.items() if torch.is_tensor(v) and v.is_floating_point()}
+
+
+def _compare(flow, g_ref, tol=2e-4, kink_frac=0.0):
+    """kink_frac > 0: the conditioners are piece-wise linear, so a hidden unit whose pre-activation is within fp32
+    noise of zero takes the other LeakyReLU branch than in the fp64 oracle and changes one row of a gradient by
+    O(1) of that sample's contribution -- measure-zero events that show up at 10^5..10^6 hidden units.  Then at most
+    that fraction of a tensor's entries may miss `tol` (and none by more than 5 % of the tensor's largest entry)."""
+    n = 0
+    for pname, p in flow.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = g_ref.get(pname)
+        if ref is None or ref.abs().max().item() == 0.0:
+            assert p.grad is None or p.grad.abs().max().item() < 1e-6, pname
+            continue
+        assert p.grad is not None, f"no gradient for {pname}"
+        diff = (p.grad.cpu().double() - ref.reshape(p.shape)).abs()
+        big = ref.abs().max().item()
+        if kink_frac > 0.0:
+            n_bad = int((diff > tol * big).sum().item())
+            assert n_bad <= max(2, int(kink_frac * diff.numel())), (pname, n_bad, diff.numel())
+            assert diff.max().item() <= 0.05 * big, (pname, diff.max().item(), big)
+        else:
+            assert diff.max().item() <= tol * big, (pname, diff.max().item(), big)
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("name", CASES)
+def test_log_prob_backward_matches_oracle_autograd(name, mode):
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd, device=DEV)
+    flow.engine().gemm_mode = mode
+    x = a["x"].to(DEV)
+    ctx = a.get("context")
+    g_lp = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(1))
+    before = flow.engine().launch_count
+    lp = flow.log_prob(x, ctx.to(DEV) if ctx is not None else None)
+    assert lp.requires_grad and flow.engine().launch_count > before, "device training path did not run"
+    (lp * g_lp.to(DEV)).sum().backward()
+    ctx_ref = ctx
+    if ctx_ref is None and spec.soft_training:
+        ctx_ref = torch.zeros(x.shape[0], 1)
+    lp_ref, g_ref = oracle_grads(spec, sd, a["x"], g_lp, ctx_ref)
+    assert ((lp.detach().cpu().double() - lp_ref).abs() / lp_ref.abs()).max().item() < 1e-5
+    assert _compare(flow, g_ref) >= 5
+
+
+def test_same_gradients_as_the_composite_formulation():
+    """device backward == torch autograd through the composite layer loop on the same device (USFLOWS_AMD_TRAIN=composite)"""
+    spec, sd, a = load_case("synth_d64_k4_hh1_conj_laplace")
+    x = a["x"].to(DEV)
+    grads = []
+    for device_training in (True, False):
+        flow = build_flow(spec, sd, device=DEV)
+        flow.use_device_training = device_training
+        (-flow.log_prob(x).mean()).backward()
+        grads.append({n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None})
+    assert set(grads[0]) == set(grads[1])
+    for n in grads[0]:
+        ref = grads[1][n]
+        assert (grads[0][n] - ref).abs().max().item() <= 5e-4 * max(ref.abs().max().item(), 1e-9), n
+
+
+def test_cfg2_training_step_ragged_batch():
+    """BASELINE cfg2 model, ragged batch: gradients of -mean log_prob vs the oracle on a 48-row batch; a second
+    forward before the backward (activation buffers overwritten) still gives the right gradients"""
+    spec, sd, a = load_case("synth_d784_k32_cfg2")
+    flow = build_flow(spec, sd, device=DEV)
+    x = a["x"][:48]
+    xd = x.to(DEV)
+    lp1 = flow.log_prob(xd)
+    _ = flow.log_prob(a["x"][:48].flip(0).to(DEV))       # same batch size: reuses (overwrites) the saved activations
+    (-lp1.mean()).backward()
+    lp_ref, g_ref = oracle_grads(spec, sd, x, torch.full((48,), -1.0 / 48))
+    assert ((lp1.detach().cpu().double() - lp_ref).abs() / lp_ref.abs()).max().item() < 1e-5
+    assert _compare(flow, g_ref, tol=5e-4, kink_frac=5e-3) >= 100
+
+
+def test_fit_runs_on_device_and_reduces_the_loss():
+    spec, sd, a = load_case("synth_d16_k3_densenn_relu")
+    flow = build_flow(spec, sd, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    data = torch.rand(512, 16, generator=g)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return data.shape[0]
+
+        def __getitem__(self, i):
+            return data[i], 0
+
+    before = flow.engine().launch_count
+    losses = flow.fit(DS(), optim=torch.optim.Adam, optim_params=dict(lr=1e-3), batch_size=128, shuffle=False,
+                      device=torch.device(DEV), epochs=4)
+    assert flow.engine().launch_count > before
+    assert losses[-1] < losses[0]

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 3
+USF_ABI_VERSION = 4
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -102,6 +102,15 @@ SYMBOLS = {
     "usf_householder_f64": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_pack_weight_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int64,
                                       _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_wgrad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
+                                C.c_float, C.c_float, _fp, C.c_int64, C.c_void_p]),
+    "usf_wgrad_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_colsum_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_float, _fp, C.c_int64,
+                                 C.c_void_p]),
+    "usf_act_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_float,
+                                   C.c_void_p]),
+    "usf_base_logprob_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp,
+                                            C.c_int64, C.c_void_p]),
     "usf_matvec_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_double, _fp, _fp, C.c_void_p]),
 }
 
@@ -278,3 +287,44 @@ def matvec_f64(src, b, *, idx=None, n_out=None, alpha=1.0, out32=None, out64=Non
         n_out = src.shape[0]
     check(load().usf_matvec_f64(src.data_ptr(), ld_src or src.shape[1], b.shape[0], ptr(idx), n_out, b.data_ptr(),
                                 float(alpha), ptr(out32), ptr(out64), current_stream(src.device)), "usf_matvec_f64")
+
+
+# ---- training backward (usf_train.hip) ---------------------------------------------
+_wg_ws = {}
+
+
+def _workspace(device, floats: int) -> torch.Tensor:
+    """grow-only fp32 scratch per device for the split reductions (wgrad / colsum partials)"""
+    key = str(device)
+    ws = _wg_ws.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
+        _wg_ws[key] = ws
+    return ws
+
+
+def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0):
+    """G[n,k] = alpha * sum_m Y[m,n] A[m,k] + beta * G (element offsets *_off into the fp32 tensors)"""
+    lib = load()
+    need = lib.usf_wgrad_workspace_floats(M, N, K)
+    ws = _workspace(Y.device, need)
+    check(lib.usf_wgrad_f32(Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
+                            G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ws.data_ptr(), ws.numel(),
+                            current_stream(Y.device)), "usf_wgrad_f32")
+
+
+def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):
+    ws = _workspace(Y.device, 512 * N)
+    check(load().usf_colsum_f32(Y.data_ptr() + 4 * y_off, ldy, M, N, out.data_ptr(), float(alpha), float(beta),
+                                ws.data_ptr(), ws.numel(), current_stream(Y.device)), "usf_colsum_f32")
+
+
+def act_grad(d, h, *, M, H, ldd, ldh, act, slope):
+    check(load().usf_act_grad_f32(d.data_ptr(), ldd, h.data_ptr(), ldh, M, H, act, float(slope),
+                                  current_stream(d.device)), "usf_act_grad_f32")
+
+
+def base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
+    check(load().usf_base_logprob_grad_f32(z.data_ptr(), ldz, g_lp.data_ptr(), M, D, base, loc.data_ptr(),
+                                           scale.data_ptr(), g.data_ptr(), ldg, current_stream(z.device)),
+          "usf_base_logprob_grad_f32")

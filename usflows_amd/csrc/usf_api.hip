@@ -39,6 +39,16 @@ int pack_weight(const void* src, int32_t src_is_f32, int64_t lds_, int32_t trans
 int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
                 double alpha, float* out32, double* out64, hipStream_t stream);
 
+int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
+int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
+          int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, hipStream_t stream);
+int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
+           int64_t workspace_floats, hipStream_t stream);
+int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
+             hipStream_t stream);
+int base_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
+              const float* scale, float* g, int64_t ldg, hipStream_t stream);
+
 }  // namespace usf
 
 extern "C" {
@@ -110,6 +120,27 @@ int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int
 int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
                    double alpha, float* out32, double* out64, usf_stream_t stream) {
   return usf::matvec_rows(src, ld_src, K, idx, n_out, b, alpha, out32, out64, (hipStream_t)stream);
+}
+
+int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
+                  int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+  return usf::wgrad(Y, ldy, A, lda, M, N, K, G, ldg, alpha, beta, workspace, workspace_floats, (hipStream_t)stream);
+}
+int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K) {
+  int64_t out = 0;
+  return usf::wgrad_workspace_floats(M, N, K, &out) == 0 ? out : -1;
+}
+int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
+                   float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+  return usf::colsum(Y, ldy, M, N, out, alpha, beta, workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_act_grad_f32(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
+                     usf_stream_t stream) {
+  return usf::act_grad(d, ldd, h, ldh, M, H, act, slope, (hipStream_t)stream);
+}
+int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base,
+                              const float* loc, const float* scale, float* g, int64_t ldg, usf_stream_t stream) {
+  return usf::base_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg, (hipStream_t)stream);
 }
 
 int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {

@@ -1,0 +1,277 @@
+// Backward-pass kernels of the training step: what autograd derives from Flow.log_prob
+// (flows.py:196-199: loss = -log_prob(batch).mean() - log_prior) for the layers of the hot path.
+//
+//   wgrad        G[n,k] = sum_m Y[m,n] * A[m,k]        weight gradient of every F.linear on the path
+//                (BlockAffineTransform transforms.py:913-962, conditioner Linear layers networks.py:739-751):
+//                a GEMM whose reduction runs over the BATCH, exact-f32 MFMA (v_mfma_f32_16x16x4_f32), split over
+//                row ranges into partials + a deterministic reduction (no atomics: bitwise reproducible gradients)
+//   colsum       g_bias[n] = sum_m Y[m,n]               bias gradient, same two-stage scheme
+//   act_grad     d[m,j] *= (h[m,j] > 0 ? 1 : slope)     LeakyReLU / ReLU backward from the saved OUTPUT h
+//                (slope >= 0: sign(h) == sign(pre-activation); ATen leaky_relu_backward uses x > 0 ? 1 : slope)
+//   base_grad    g[m,d] = g_lp[m] * d/dz base_d(z[m,d])  Laplace / Normal (torch Laplace.log_prob, Normal.log_prob)
+//
+// Data gradients (dgrad) are usf_linear_f32 launches with the transposed weight image (usf_pack_weight_f32,
+// transpose = 1); the parameter-sized chain rule through M^-1 = U^-1 L^-1 is usf_gemm_f64.
+#include "usf_common.h"
+
+namespace usf {
+
+constexpr int WG_T = 128;      // output tile (n and k)
+constexpr int WG_S = 16;       // batch rows per slab
+constexpr int WG_LD = 144;     // LDS row stride (floats): 4 consecutive rows start 16 banks apart
+
+struct WgradArgs {
+  const float* Y; int64_t ldy;
+  const float* A; int64_t lda;
+  float* part;                 // [splits][N][K]
+  int M, N, K;
+  int rows_per_split;
+};
+
+// 16 x 128 slab of a row-major matrix (rows m0.., columns c0..) -> two float4 per thread, zero outside [M) x [ncols)
+__device__ __forceinline__ void wg_load(const float* __restrict__ P, int64_t ld, int m0, int m_end, int c0, int ncols,
+                                        int tid, f32x4 (&r)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 5) + 8 * i;
+    const int col = c0 + (tid & 31) * 4;
+    const int m = m0 + row;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < m_end) {
+      const float* p = P + (int64_t)m * ld + col;
+      if (col + 3 < ncols) {
+        v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < ncols) v[e] = p[e];
+      }
+    }
+    r[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ys[2][WG_S][WG_LD];
+  __shared__ __attribute__((aligned(16))) float As[2][WG_S][WG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tilesK = (a.K + WG_T - 1) / WG_T;
+  const int n0 = (blockIdx.x / tilesK) * WG_T, k0 = (blockIdx.x % tilesK) * WG_T;
+  const int split = blockIdx.y;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ry[2], ra[2];
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid >> 5) + 8 * i, col = (tid & 31) * 4;
+      *reinterpret_cast<f32x4*>(&Ys[buf][row][col]) = ry[i];
+      *reinterpret_cast<f32x4*>(&As[buf][row][col]) = ra[i];
+    }
+  };
+  int buf = 0;
+  if (m_begin < m_end) {
+    wg_load(a.Y, a.ldy, m_begin, m_end, n0, a.N, tid, ry);
+    wg_load(a.A, a.lda, m_begin, m_end, k0, a.K, tid, ra);
+    stage(0);
+  }
+  __syncthreads();
+  for (int m0 = m_begin; m0 < m_end; m0 += WG_S) {
+    const bool more = m0 + WG_S < m_end;
+    if (more) {
+      wg_load(a.Y, a.ldy, m0 + WG_S, m_end, n0, a.N, tid, ry);
+      wg_load(a.A, a.lda, m0 + WG_S, m_end, k0, a.K, tid, ra);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float fy[4], fa[4];
+      const int r = kk * 4 + (lane >> 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fy[t] = Ys[buf][r][wn * 64 + t * 16 + (lane & 15)];
+        fa[t] = As[buf][r][wk * 64 + t * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // accumulator layout (f32 16x16): row = 4 * (lane >> 4) + reg, col = lane & 15
+  float* out = a.part + (int64_t)split * a.N * a.K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (n < a.N && k < a.K) out[(int64_t)n * a.K + k] = acc[i][j][r];
+      }
+}
+
+// out[r*ldo + c] = alpha * sum_s part[s][r][c] + beta * out[...]   (rows x cols elements per partial)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t rows,
+                                                              int64_t cols, float* __restrict__ out, int64_t ldo,
+                                                              float alpha, float beta) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int p = 0; p < splits; ++p) s += part[(int64_t)p * total + e];
+    const int64_t r = e / cols, c = e - r * cols;
+    float v = alpha * s;
+    if (beta != 0.f) v += beta * out[r * ldo + c];
+    out[r * ldo + c] = v;
+  }
+}
+
+// part[split][n] = sum over the split's rows of Y[m,n]; block = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, int64_t ldy, int M, int N,
+                                                     int rows_per_split, float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int m_begin = blockIdx.y * rows_per_split;
+  const int m_end = (m_begin + rows_per_split < M) ? m_begin + rows_per_split : M;
+  float s = 0.f;
+  if (c < N)
+    for (int m = m_begin + rl; m < m_end; m += 4) s += Y[(int64_t)m * ldy + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) part[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void act_grad_kernel(float* __restrict__ d, int64_t ldd, const float* __restrict__ h,
+                                                       int64_t ldh, int64_t M, int64_t H, float slope) {
+  const int64_t total = M * H;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / H, j = e - m * H;
+    const float hv = h[m * ldh + j];
+    if (!(hv > 0.f)) d[m * ldd + j] *= slope;
+  }
+}
+
+// g[m,d] = g_lp[m] * d/dz base_d(z[m,d]);  columns D..ldg-1 (layout padding) are written as zeros
+__global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ g_lp,
+                                                        int64_t M, int64_t D, int base, const float* __restrict__ loc,
+                                                        const float* __restrict__ scale, float* __restrict__ g,
+                                                        int64_t ldg) {
+  const int64_t total = M * ldg;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / ldg, d = e - m * ldg;
+    float v = 0.f;
+    if (d < D) {
+      const float t = z[m * ldz + d] - loc[d];
+      const float s = scale[d];
+      if (base == USF_BASE_LAPLACE) v = -(float)((t > 0.f) - (t < 0.f)) / s;      // d/dz -|z-loc|/b ; 0 at the kink (ATen)
+      else v = -t / (s * s);                                                      // d/dz -(z-loc)^2 / (2 s^2)
+      v *= g_lp[m];
+    }
+    g[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int pick_splits(int64_t M, int64_t tiles) {
+  // enough row ranges to give every CU ~2 blocks, each at least 256 rows
+  int64_t s = (512 + tiles - 1) / tiles;
+  const int64_t smax = (M + 255) / 256;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+
+int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out) {
+  if (M < 0 || N <= 0 || K <= 0) return -1;
+  const int64_t tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T);
+  *out = (int64_t)pick_splits(M, tiles) * N * K;
+  return 0;
+}
+
+int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
+          int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  if (((!Y || !A) && M > 0) || !G || !workspace || M < 0 || N <= 0 || K <= 0 || ldg < K || ldy < N || lda < K) {
+    set_error("usf_wgrad_f32: bad arguments");
+    return -1;
+  }
+  if (M > 0x7fffffff || N > (1 << 20) || K > (1 << 20)) { set_error("usf_wgrad_f32: size out of range"); return -2; }
+  if ((ldy & 3) || (lda & 3) || !aligned16(Y) || !aligned16(A)) {
+    set_error("usf_wgrad_f32: Y / A need 16-byte aligned rows (ld %% 4 == 0, aligned base)");
+    return -3;
+  }
+  const int64_t tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T);
+  const int splits = pick_splits(M, tiles);
+  if (workspace_floats < (int64_t)splits * N * K) {
+    set_error("usf_wgrad_f32: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
+              (long long)splits * N * K);
+    return -4;
+  }
+  int rows = (int)((M + splits - 1) / splits);
+  rows = (rows + WG_S - 1) / WG_S * WG_S;
+  WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WG_S};
+  wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
+  int64_t rb = (N * K + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta);
+  return check_launch("usf_wgrad_f32");
+}
+
+int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
+           int64_t workspace_floats, hipStream_t stream) {
+  if ((!Y && M > 0) || !out || !workspace || M < 0 || N <= 0 || ldy < N || M > 0x7fffffff) {
+    set_error("usf_colsum_f32: bad arguments");
+    return -1;
+  }
+  int64_t splits = (M + 511) / 512;
+  if (splits > 512) splits = 512;
+  if (splits < 1) splits = 1;
+  if (workspace_floats < splits * N) { set_error("usf_colsum_f32: workspace too small"); return -4; }
+  const int rows = (int)((M + splits - 1) / splits);
+  colsum_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)splits), 256, 0, stream>>>(Y, ldy, (int)M, (int)N,
+                                                                                      rows > 0 ? rows : 1, workspace);
+  reduce_partials_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(workspace, (int)splits, 1, N, out, N, alpha, beta);
+  return check_launch("usf_colsum_f32");
+}
+
+int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
+             hipStream_t stream) {
+  if (!d || !h || M < 0 || H < 0 || ldd < H || ldh < H) { set_error("usf_act_grad_f32: bad arguments"); return -1; }
+  if (act == USF_ACT_NONE || M == 0 || H == 0) return 0;
+  if (act != USF_ACT_LEAKY_RELU || slope < 0.f) { set_error("usf_act_grad_f32: unsupported activation"); return -2; }
+  int64_t blocks = (M * H + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  act_grad_kernel<<<(unsigned)blocks, 256, 0, stream>>>(d, ldd, h, ldh, M, H, slope);
+  return check_launch("usf_act_grad_f32");
+}
+
+int base_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
+              const float* scale, float* g, int64_t ldg, hipStream_t stream) {
+  if (!z || !g_lp || !loc || !scale || !g || M < 0 || D <= 0 || ldz < D || ldg < D) {
+    set_error("usf_base_logprob_grad_f32: bad arguments");
+    return -1;
+  }
+  if (base != USF_BASE_LAPLACE && base != USF_BASE_NORMAL) {
+    set_error("usf_base_logprob_grad_f32: base %d has no device gradient", base);
+    return -2;
+  }
+  if (M == 0) return 0;
+  int64_t blocks = (M * ldg + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  base_grad_kernel<<<(unsigned)blocks, 256, 0, stream>>>(z, ldz, g_lp, M, D, base, loc, scale, g, ldg);
+  return check_launch("usf_base_logprob_grad_f32");
+}
+
+}  // namespace usf

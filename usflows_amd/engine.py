@@ -175,6 +175,8 @@ class FlowEngine:
         # both operands (fp32-equivalent accuracy); "f32": exact-f32 MFMA everywhere
         # (USFLOWS_AMD_GEMM=f32 or engine.gemm_mode = "f32")
         self.gemm_mode = os.environ.get("USFLOWS_AMD_GEMM", "bf16x3")
+        # True: the pack also keeps L, U^T, L^-1, U^-T of every LU block (fp64) -- the training backward's operands
+        self.keep_factors = False
         self._layout_from_masks()
 
     # ---- static structure ---------------------------------------------------------------------
@@ -271,9 +273,9 @@ class FlowEngine:
 
     def pack(self, device) -> dict:
         key = self._version_key(device)
-        if self._pack is not None and key == self._pack_key:
+        if self._pack is not None and key == self._pack_key and (self._pack["has_factors"] or not self.keep_factors):
             return self._pack
-        pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}}
+        pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}, "has_factors": self.keep_factors}
         ladj_total = torch.zeros((), dtype=torch.float64, device=device)
         with torch.no_grad():
             blocks, seen = [], set()
@@ -281,7 +283,8 @@ class FlowEngine:
                 if s.kind == "affine" and id(s.module) not in seen:
                     seen.add(id(s.module))
                     blocks.append(s.module)
-            prepared = prepare_affine_blocks(blocks, device)
+            prepared = prepare_affine_blocks(blocks, device, keep_factors=self.keep_factors)
+            pk["affine_parts"] = prepared          # also the LU / Householder factors inside Sequential blocks
             for b_ in blocks:
                 pk["affine"][id(b_)] = prepared[id(b_)]
             for i, s in enumerate(self.steps):
@@ -492,7 +495,7 @@ class FlowEngine:
                 prims.append(("coupling_fwd" if fwd else "coupling_bwd", i))
         return prims
 
-    def _build_plan(self, direction: str, B: int, device, has_ctx: bool, final: str) -> dict:
+    def _build_plan(self, direction: str, B: int, device, has_ctx: bool, final: str, train: bool = False) -> dict:
         """final: 'user' (last op writes the caller's [B,D] tensor) or 'nat' (workspace buffer, for the tail).
 
         Returns the ctypes op array plus the few launches that are not usf_run_ops ops
@@ -507,12 +510,22 @@ class FlowEngine:
         side: List[tuple] = []         # ("gather", at, src_cur, dst_name, dst_layout) | ("scale", at, buf, ld, vec, divide, ncols)
         cur = ("user_in", "nat", self.D)     # (buffer name, layout, row stride)
         free = ["zA", "zB"]
+        meta: List[dict] = []          # per group of ops: what the training backward needs (training.py)
+        n_act = [0]
 
         def take():
+            if train:
+                # training: every affine output keeps its own buffer (the saved activations of the backward
+                # pass; (K+1) x B x LD x 4 bytes -- cfg2 at B = 65536: 6.8 GB of the 288 GB)
+                name = f"act{n_act[0]}"
+                n_act[0] += 1
+                if name not in ws:
+                    ws[name] = torch.zeros(B, self.LD, dtype=torch.float32, device=device)
+                return name
             return free.pop(0)
 
         def release(name):
-            if name in ("zA", "zB") and name not in free:
+            if not train and name in ("zA", "zB") and name not in free:
                 free.append(name)
 
         def lin_op(**kw) -> _ext.Op:
@@ -541,7 +554,9 @@ class FlowEngine:
                     cur = ("nat", "nat", self.LDn)
                 in_layout = cur[1]
                 kw = {}
+                scale_mod = None
                 if prim == "scale_div":
+                    scale_mod = s.module
                     sc64 = pk["scale"][id(s.module)]
                     kw["pre_div"] = self._vec(pk, ("scale", id(s.module)), sc64, in_layout, 1.0).data_ptr()
                     k += 1
@@ -587,6 +602,9 @@ class FlowEngine:
                     patch_in.append(len(ops))
                 if dst == "user_out":
                     patch_out.append(len(ops))
+                meta.append(dict(kind="affine", op=len(ops), prim=prim, blk=blk, in_buf=cur[0], in_layout=in_layout,
+                                 in_ld=cur[2], out_buf=dst, out_layout=out_layout, out_ld=ldc, N=Ndim, K=Kdim,
+                                 pre_scale=scale_mod, post_scale=(self.steps[nxt[1]].module if fuse_post else None)))
                 ops.append(lin_op(A=(0 if cur[0] == "user_in" else ws[cur[0]].data_ptr()), lda=cur[2],
                                   W=W.data_ptr(), ldw=W.shape[1], C=cptr, ldc=ldc, M=B, N=Ndim, K=Kdim,
                                   res_sign=1.0, slope=0.0, act=_ext.ACT_NONE, **kw))
@@ -614,6 +632,7 @@ class FlowEngine:
             sign = 1.0 if prim == "coupling_fwd" else -1.0
             zptr = ws[cur[0]].data_ptr()
             use_ctx = has_ctx and cp["has_ctx"]
+            meta.append(dict(kind="coupling", op=len(ops), step=i, buf=cur[0], sign=sign, use_ctx=use_ctx))
             # the fused kernel keeps a wave on 16 rows for the whole MLP: unbeatable when the chip is full, but
             # its latency is one wave's serial MFMA chain; small batches run the MLP as 3 short linear launches
             if self.use_fused_coupling and self._fused_ok(cp) and B >= self.fused_min_rows:
@@ -654,7 +673,7 @@ class FlowEngine:
             cur = ("nat2", "nat", self.LDn)
         arr = (_ext.Op * max(len(ops), 1))(*ops)
         return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=side,
-                    final_gather=final_gather, out_buf=cur, ws=ws, pk=pk)
+                    final_gather=final_gather, out_buf=cur, ws=ws, pk=pk, meta=meta)
 
     # fused coupling kernel availability (filled in when the kernel is present)
     def _fused_ok(self, cp) -> bool:
@@ -744,12 +763,13 @@ class FlowEngine:
         return op
 
     # ---- execution ----------------------------------------------------------------------------
-    def _plan(self, direction, B, device, has_ctx, final):
+    def _plan(self, direction, B, device, has_ctx, final, train: bool = False):
         pk = self.pack(device)   # may invalidate plans
-        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows)
+        key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
+               train)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._build_plan(direction, B, device, has_ctx, final)
+            plan = self._build_plan(direction, B, device, has_ctx, final, train)
             self._plans[key] = plan
         return plan
 

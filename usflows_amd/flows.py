@@ -12,6 +12,7 @@ used whenever the input is on a ROCm device and no autograd graph is required.  
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, Iterable, List, Literal, Optional, Type
 
 import numpy as np
@@ -61,6 +62,10 @@ class Flow(torch.nn.Module):
         self.base_distribution = base_distribution
         self._engine_obj = None
         self._engine_failed = False
+        self._train_obj = None
+        # True: log_prob under autograd runs forward AND backward on the HIP kernels (training.py); False: the
+        # differentiable composite formulation in torch ops (USFLOWS_AMD_TRAIN=composite)
+        self.use_device_training = os.environ.get("USFLOWS_AMD_TRAIN", "device") != "composite"
         self.to(device)
         self.device = device
         # batch dims of the base become event dims (flows.py:94-101)
@@ -157,10 +162,28 @@ class Flow(torch.nn.Module):
             x = layer.backward(x)
         return x
 
+    def _train_path(self, x: torch.Tensor, context=None):
+        """the device training path (training.py) when this call needs gradients of the parameters only"""
+        if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled()):
+            return None
+        if getattr(self, "_train_failed", False) or not self.use_device_training or self.engine() is None:
+            return None
+        from .training import TrainPath
+        if self._train_obj is None:
+            self._train_obj = TrainPath(self)
+        return self._train_obj if self._train_obj.supported(x, context) else None
+
     def log_prob(self, x: torch.Tensor, context: Optional[torch.Tensor] = None) -> torch.Tensor:
         """log p(x) = base.log_prob(f^-1(x)) - sum_layers log|det J|   (flows.py:225-245)"""
         if self._on_device_fast_path(x, context):
             return self._log_prob_device(x, context)
+        path = self._train_path(x, context)
+        if path is not None:
+            from .training import TrainUnsupported, log_prob_with_grad
+            try:
+                return log_prob_with_grad(path, x, context)
+            except TrainUnsupported:
+                self._train_failed = True          # this layer list has no device backward: composite from now on
         log_det = torch.zeros(x.shape[0]).to(x.device)
         for layer in reversed(self.layers):
             if context is not None:

@@ -1,0 +1,521 @@
+"""Training step on the device: ``Flow.log_prob`` under autograd as ONE autograd node whose
+forward is the engine's launch list and whose backward is hand-derived -- what ``Flow.fit`` (flows.py:196-199:
+``loss = -log_prob(batch).mean() - log_prior()``) asks autograd to differentiate.
+
+forward   the log_prob launch list (engine.py) with every affine output kept in a buffer of its own (the saved
+          activations; couplings update their transformed half in place, and their conditioning half -- all the
+          backward needs of them -- is untouched), then the base-density tail.
+backward  usf_base_logprob_grad_f32 -> per layer, last to first:
+            affine    usf_wgrad_f32 (g^T a), usf_colsum_f32, data gradient = usf_linear_f32 on the transposed image
+            coupling  hidden activations recomputed by two usf_linear_f32 launches, then per conditioner layer
+                      usf_wgrad_f32 / usf_colsum_f32 / usf_linear_f32 (transposed image) / usf_act_grad_f32;
+                      the conditioning half of the gradient is updated in place
+          then the parameter-sized chain rule, batched over all LU blocks on the f64 MFMA (usf_gemm_f64):
+            M^-1 = U^-1 L^-1:   dU = -triu(U^-T G M^-T),   dL = -tril(M^-T G L^-T, -1)
+            M    = L U      :   dL += tril(G U^T, -1),     dU += triu(L^T G)            (affine_conjugation)
+          Householder factors / longer Sequential chains go through a small torch graph over the prepared fp64
+          matrices (parameter-sized library GEMMs).
+
+Supported here: flat inputs, Laplace / Normal base without trainable parameters, inputs that do not require grad,
+ConditionalDenseNN / DenseNN conditioners; anything else keeps using the differentiable composite formulation
+(flows.py / transforms.py mirrors) -- same results, torch ops.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _ext
+from . import transforms as T
+from .engine import FlowEngine, _round_up
+from .networks import ConditionalDenseNN, DenseNN
+
+
+class TrainUnsupported(Exception):
+    pass
+
+
+def _inverse_index(idx: torch.Tensor, D: int, device) -> torch.Tensor:
+    """layout index (column -> feature, -1 = padding) -> int32 [D]: feature -> column"""
+    inv = torch.full((D,), -1, dtype=torch.int32)
+    for c, f in enumerate(idx.tolist()):
+        if f >= 0:
+            inv[f] = c
+    return inv.to(device)
+
+
+class TrainPath:
+    """forward / backward of ``Flow.log_prob`` for one flow (owned by the Flow; shares the FlowEngine)."""
+
+    def __init__(self, flow):
+        self.flow = flow
+        self.eng: FlowEngine = flow.engine()
+        self.generation = 0
+        self._inv: Dict[tuple, torch.Tensor] = {}
+
+    # ---- eligibility ----------------------------------------------------------------------------------
+    def supported(self, x: torch.Tensor, context) -> bool:
+        eng = self.eng
+        if eng is None or x.requires_grad or (context is not None and context.requires_grad):
+            return False
+        info = self.flow._base_info(x.device)
+        if info is None or info[0] not in ("laplace", "normal"):
+            return False
+        if any(p.requires_grad for p in self._base_params()):
+            return False
+        for s in eng.steps:
+            if s.kind == "coupling" and not isinstance(s.module.conditioner, (ConditionalDenseNN, DenseNN)):
+                return False
+            if s.kind == "scale" and s.inverted:
+                return False
+        return True
+
+    def _base_params(self):
+        b = self.flow.base_distribution
+        return list(b.parameters()) if isinstance(b, torch.nn.Module) else []
+
+    def params(self) -> List[torch.nn.Parameter]:
+        return self.eng._params()
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, context):
+        eng = self.eng
+        x = eng._check_input(x)
+        B = x.shape[0]
+        dev = x.device
+        eng.keep_factors = True
+        plan = eng._plan("backward", B, dev, context is not None, "nat", train=True)
+        self._check_plan(plan)
+        eng._execute(plan, x, None, context)
+        zname, _, ldn = plan["out_buf"]
+        info = self.flow._base_info(dev)
+        base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
+        lp = torch.empty(B, dtype=torch.float32, device=dev)
+        _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, info[1], info[2], -plan["pk"]["ladj_total"], lp, None)
+        self.generation += 1
+        return lp, plan, x, self.generation
+
+    def _check_plan(self, plan):
+        if plan["final_gather"] is not None:
+            raise TrainUnsupported("layer list does not end in an affine block")
+        for g in plan["side"]:
+            if g[0] != "gather" or g[1] != 0 or g[2][0] != "user_in":
+                raise TrainUnsupported("stand-alone scale layer / mid-flow layout change")
+        for m in plan["meta"]:
+            if m["kind"] == "affine" and m["post_scale"] is not None:
+                raise TrainUnsupported("forward-direction scale fusion")
+
+    # ---- helpers --------------------------------------------------------------------------------------
+    def _inv_idx(self, layout: str, device) -> torch.Tensor:
+        key = (layout, str(device))
+        if key not in self._inv:
+            self._inv[key] = _inverse_index(self.eng._idx(layout), self.eng.D, device)
+        return self._inv[key]
+
+    def _buf(self, ws, name, rows, cols, dtype=torch.float32):
+        t = ws.get(name)
+        if t is None or t.shape[0] != rows or t.shape[1] < cols:
+            t = torch.zeros(rows, cols, dtype=dtype, device=ws["zA"].device)
+            ws[name] = t
+        return t
+
+    def _mat_t(self, pk, blk, which, out_layout, in_layout):
+        """transposed image [n_in, n_out] of the affine weight (+ planes): the data-gradient operand"""
+        eng = self.eng
+        key = (id(blk), which, out_layout, in_layout, "T")
+        if key not in pk["mats"]:
+            src = pk["affine"][id(blk)][which]
+            dev = src.device
+            oi, ii = eng._idx_dev(out_layout, dev), eng._idx_dev(in_layout, dev)
+            n_out, n_in = int(oi.numel()), int(ii.numel())
+            Wt = torch.empty(n_in, n_out, dtype=torch.float32, device=dev)
+            planes = None
+            if eng._wants_planes(n_in, n_out):
+                planes = torch.empty(3, n_in, _round_up(n_out, 32), dtype=torch.bfloat16, device=dev)
+            _ext.pack_weight(src, ii, n_in, oi, n_out, W=Wt, ldw=n_out, planes=planes, transpose=True)
+            pk["mats"][key] = Wt
+            if planes is not None:
+                pk["mats"][("planes", Wt.data_ptr())] = planes
+        return pk["mats"][key]
+
+    def _linear(self, pk, A, a_off, lda, W, Cbuf, c_off, ldc, M, N, K, **kw):
+        """one usf_linear_f32 launch (bf16x3 planes attached when the engine's mode wants them)"""
+        planes = None
+        if (self.eng._wants_planes(W.shape[0], K) and W.shape[1] == K and "residual" not in kw and "addend" not in kw):
+            planes = self.eng._split_planes(pk, W)
+        _ext.linear(A, W, Cbuf, M=M, N=N, K=K, lda=lda, ldw=W.shape[1], ldc=ldc, a_off=a_off, c_off=c_off,
+                    W_split=planes, **kw)
+
+    # ---- backward -------------------------------------------------------------------------------------
+    def backward(self, plan, x, g_lp: torch.Tensor) -> Dict[int, torch.Tensor]:
+        """gradients of sum_m g_lp[m] * log_prob(x)[m] w.r.t. every trainable parameter: id(param) -> tensor"""
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        dev = x.device
+        B, D = x.shape[0], eng.D
+        wid = max(eng.LD, eng.LDn)
+        gA, gB = self._buf(ws, "gA", B, wid), self._buf(ws, "gB", B, wid)
+        g_lp = g_lp.detach().to(torch.float32).contiguous()
+        info = self.flow._base_info(dev)
+        base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
+        zname, _, ldn = plan["out_buf"]
+        _ext.base_logprob_grad(ws[zname], ldn, g_lp, B, D, base, info[1], info[2], gA, ldn)
+        g_cur, g_other, g_ld = gA, gB, ldn
+        grads: Dict[int, torch.Tensor] = {}
+        aff: Dict[int, dict] = {}            # id(block) -> accumulated natural-layout gradients of its usages
+        first_meta = plan["meta"][0] if plan["meta"] else None
+        for m in reversed(plan["meta"]):
+            if m["kind"] == "affine":
+                g_cur, g_other, g_ld = self._affine_backward(plan, m, x, g_cur, g_other, g_ld, aff,
+                                                             need_dgrad=(m is not first_meta))
+            else:
+                self._coupling_backward(plan, m, g_cur, g_ld, grads)
+        self._affine_param_grads(plan, aff, g_lp, grads)
+        return grads
+
+    # ---- affine layers --------------------------------------------------------------------------------
+    def _affine_backward(self, plan, m, x, g_cur, g_other, g_ld, aff, need_dgrad):
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        dev = x.device
+        B = x.shape[0]
+        blk = m["blk"]
+        which = "Minv" if m["prim"] == "affine_bwd" else "M"
+        oi = eng._idx_dev(m["out_layout"], dev)
+        ii = eng._idx_dev(m["in_layout"], dev)
+        n_out, n_in = int(oi.numel()), int(ii.numel())
+        if m["in_buf"] == "user_in":
+            a_in, a_ld = x, x.shape[1]
+        else:
+            a_in, a_ld = ws[m["in_buf"]], m["in_ld"]
+        # weight gradient in the image layout, then back to the natural [D, D] layout of the block's matrix
+        wid = max(eng.LD, eng.LDn)
+        Gp = self._buf(ws, "Gp", wid, wid)
+        _ext.wgrad(g_cur, a_in, Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=a_ld, ldg=Gp.shape[1])
+        gs = self._buf(ws, "gs", 1, wid)
+        _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
+        D = eng.D
+        G_nat = torch.empty(D, D, dtype=torch.float32, device=dev)
+        _ext.pack_weight(Gp, self._inv_idx(m["out_layout"], dev), D, self._inv_idx(m["in_layout"], dev), D,
+                         W=G_nat, ldw=D, ld_src=Gp.shape[1])
+        gs_nat = torch.empty(D, dtype=torch.float32, device=dev)
+        _ext.pack_weight(gs, None, 1, self._inv_idx(m["out_layout"], dev), D, W=gs_nat, ldw=D, ld_src=gs.shape[1])
+        rec = aff.setdefault(id(blk), dict(blk=blk, uses=[]))
+        rec["uses"].append(dict(which=which, G=G_nat, gsum=gs_nat, pre_scale=m["pre_scale"]))
+        if need_dgrad:
+            Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
+            self._linear(pk, g_cur, 0, g_ld, Wt, g_other, 0, n_in, B, n_in, n_out)
+            return g_other, g_cur, n_in
+        return g_cur, g_other, g_ld
+
+    # ---- coupling layers ------------------------------------------------------------------------------
+    def _coupling_backward(self, plan, m, g_cur, g_ld, grads):
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        cp = pk["coupling"][m["step"]]
+        layer = eng.steps[m["step"]].module
+        cond = layer.conditioner
+        un = eng._unfused_pack(pk, cp)
+        raw = cp["raw"]
+        dev = raw["device"]
+        zbuf = ws[m["buf"]]
+        B = zbuf.shape[0]
+        LD, hmax = eng.LD, eng.hmax
+        sign = m["sign"]
+        h, hp = raw["h"], cp["hidden"]
+        nl = len(un["layers"])
+        act, slope = cp["act"], cp["slope"]
+        # 1. hidden activations again (the conditioning half of the saved buffer is what the forward saw)
+        hbufs = [self._buf(ws, f"Hs{j}", B, hmax) for j in range(nl)]
+        src, src_off, src_ld, src_K = zbuf, cp["pass_off"], LD, cp["pass_n"]
+        for j, (W, b) in enumerate(un["layers"]):
+            kw = {}
+            if j == 0 and m["use_ctx"]:
+                self._linear(pk, ws["ctx4"], 0, 4, un["W_ctx4"], ws["P"], 0, hmax, B, hp[0], 4, bias=un["b_ctx"])
+                kw = dict(addend=ws["P"], ldadd=hmax)
+            self._linear(pk, src, src_off, src_ld, W, hbufs[j], 0, hmax, B, W.shape[0], src_K, bias=b, act=act,
+                         slope=slope, **kw)
+            src, src_off, src_ld, src_K = hbufs[j], 0, hmax, W.shape[0]
+        lin = list(cond.layers)
+        has_ctx = isinstance(cond, ConditionalDenseNN)
+        first_l, last_l = lin[0], lin[-1]
+        hidden_l = lin[2:-1] if has_ctx else lin[1:-1]
+        # 2. output layer: d_out = gradient at the transformed half (unchanged by the layer: out_T = z_T + s MLP)
+        tr_n, tr_off = cp["tr_n"], cp["tr_off"]
+        W_out = un["W_out"]                                   # [tr_n, hp_last]
+        gW = self._buf(ws, "gWc", max(hmax, LD), max(hmax, LD))
+        _ext.wgrad(g_cur, hbufs[-1], gW, M=B, N=tr_n, K=hp[-1], ldy=g_ld, lda=hmax, ldg=gW.shape[1], y_off=tr_off,
+                   alpha=sign)
+        self._scatter_weight(grads, last_l.weight, gW, rows_sel=self._sel_inv(raw["tr_idx"], dev), n_rows=eng.D,
+                             cols_sel=None, n_cols=h[-1])
+        gb = self._buf(ws, "gbc", 1, max(hmax, LD))
+        _ext.colsum(g_cur, gb, M=B, N=tr_n, ldy=g_ld, y_off=tr_off, alpha=sign)
+        self._scatter_vec(grads, last_l.bias, gb, self._sel_inv(raw["tr_idx"], dev), eng.D)
+        # d_h = d_out W_out  (sign is applied where the result leaves the MLP)
+        d_bufs = [self._buf(ws, "Dh0", B, hmax), self._buf(ws, "Dh1", B, hmax)]
+        Wt = self._transposed(pk, W_out)                      # [hp_last, tr_n4]
+        d = d_bufs[0]
+        self._linear(pk, g_cur, tr_off, g_ld, Wt, d, 0, hmax, B, hp[-1], Wt.shape[1])
+        _ext.act_grad(d, hbufs[-1], M=B, H=hp[-1], ldd=hmax, ldh=hmax, act=act, slope=slope)
+        # 3. hidden layers, last to first
+        for j in range(nl - 1, 0, -1):
+            W, _b = un["layers"][j]                           # [hp_j, hp_{j-1}]
+            l = hidden_l[j - 1]
+            _ext.wgrad(d, hbufs[j - 1], gW, M=B, N=hp[j], K=hp[j - 1], ldy=hmax, lda=hmax, ldg=gW.shape[1], alpha=sign)
+            self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
+            self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
+            d_next = d_bufs[1] if d is d_bufs[0] else d_bufs[0]
+            self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j])
+            _ext.act_grad(d_next, hbufs[j - 1], M=B, H=hp[j - 1], ldd=hmax, ldh=hmax, act=act, slope=slope)
+            d = d_next
+        # 4. input layer
+        W_in, _b = un["layers"][0]                            # [hp0, pass_n]
+        pass_n, pass_off = cp["pass_n"], cp["pass_off"]
+        _ext.wgrad(d, zbuf, gW, M=B, N=hp[0], K=pass_n, ldy=hmax, lda=LD, ldg=gW.shape[1], a_off=pass_off, alpha=sign)
+        self._scatter_weight(grads, first_l.weight, gW, None, h[0], self._sel_inv(raw["pass_idx"], dev), eng.D)
+        self._colsum_to(grads, first_l.bias, d, B, h[0], hmax, sign)
+        if has_ctx:
+            ctx_l = lin[1]
+            if m["use_ctx"]:
+                _ext.wgrad(d, ws["ctx4"], gW, M=B, N=hp[0], K=4, ldy=hmax, lda=4, ldg=gW.shape[1], alpha=sign)
+                self._scatter_weight(grads, ctx_l.weight, gW, None, h[0], None, 1)
+                self._colsum_to(grads, ctx_l.bias, d, B, h[0], hmax, sign)
+        # conditioning half of the gradient: g_P += s * d W_in   (in place)
+        self._linear(pk, d, 0, hmax, self._transposed(pk, W_in), g_cur, pass_off, g_ld, B, pass_n, hp[0],
+                     residual=g_cur, r_off=pass_off, ldr=g_ld, res_sign=sign)
+
+    def _transposed(self, pk, W: torch.Tensor) -> torch.Tensor:
+        """[K4, N] image of W^T for a conditioner weight image W [N, K] (N padded to 4 as the linear kernel's K)"""
+        key = ("T", W.data_ptr())
+        if key not in pk["mats"]:
+            N, K = W.shape
+            N4 = _round_up(N, 4)
+            Wt = torch.empty(K, N4, dtype=torch.float32, device=W.device)
+            planes = None
+            if self.eng._wants_planes(K, N4):
+                planes = torch.empty(3, K, _round_up(N4, 32), dtype=torch.bfloat16, device=W.device)
+            sel = self.eng._iarange(N, N4, W.device)
+            _ext.pack_weight(W, None, K, sel, N4, W=Wt, ldw=N4, planes=planes, transpose=True)
+            pk["mats"][key] = Wt
+            if planes is not None:
+                pk["mats"][("planes", Wt.data_ptr())] = planes
+        return pk["mats"][key]
+
+    def _sel_inv(self, idx: torch.Tensor, device) -> torch.Tensor:
+        """segment selector (position -> feature) -> int32 [D]: feature -> position in the segment (-1: not in it)"""
+        key = ("selinv", idx.data_ptr(), str(device))
+        if key not in self._inv:
+            self._inv[key] = _inverse_index(idx, self.eng.D, device)
+            self._inv[("keep", idx.data_ptr())] = idx
+        return self._inv[key]
+
+    @staticmethod
+    def _grad_slot(grads, p: torch.Tensor) -> Optional[torch.Tensor]:
+        if not p.requires_grad:
+            return None
+        g = grads.get(id(p))
+        if g is None:
+            g = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            grads[id(p)] = g
+        return g
+
+    def _scatter_weight(self, grads, p, img, rows_sel, n_rows, cols_sel, n_cols):
+        g = self._grad_slot(grads, p)
+        if g is None:
+            return
+        if g.shape != (n_rows, n_cols):
+            raise TrainUnsupported(f"unexpected parameter shape {tuple(g.shape)}")
+        _ext.pack_weight(img, rows_sel, n_rows, cols_sel, n_cols, W=g, ldw=n_cols, ld_src=img.shape[1])
+
+    def _scatter_vec(self, grads, p, vec_img, sel, n):
+        g = self._grad_slot(grads, p)
+        if g is None:
+            return
+        _ext.pack_weight(vec_img, None, 1, sel, n, W=g, ldw=n, ld_src=vec_img.shape[1])
+
+    def _colsum_to(self, grads, p, d, B, n, ld, sign):
+        g = self._grad_slot(grads, p)
+        if g is not None:
+            _ext.colsum(d, g, M=B, N=n, ldy=ld, alpha=sign)
+
+    # ---- parameter-sized chain rule -------------------------------------------------------------------
+    def _affine_param_grads(self, plan, aff, g_lp, grads):
+        eng = self.eng
+        pk = plan["pk"]
+        dev = g_lp.device
+        Gsum = g_lp.double().sum()
+        # log-det: log_prob = base(z) - ladj_total, ladj_total = sum_steps (+/-) ladj(step)  (flows.py:236-245)
+        coef: Dict[int, float] = {}
+        for s in eng.steps:
+            if s.kind == "affine":
+                coef[id(s.module)] = coef.get(id(s.module), 0.0) + (1.0 if s.inverted else -1.0)
+        lu_acc: Dict[int, dict] = {}         # id(LUTransform) -> dict(dMinv, dM, db, c) fp64
+        scale_mod = None
+        for rec in aff.values():
+            blk = rec["blk"]
+            prep = pk["affine"][id(blk)]
+            dMinv = dM = None
+            db = torch.zeros(eng.D, dtype=torch.float64, device=dev)
+            for u in rec["uses"]:
+                G = u["G"].double()
+                gs = u["gsum"].double()
+                if u["which"] == "Minv":
+                    if u["pre_scale"] is not None:
+                        # first layer: a = x / s.  G holds g^T x ("G2"); g^T a = G2 diag(1/s);
+                        # ds_d = -(1/s_d^2) sum_n Minv[n,d] G2[n,d] - Gsum / s_d   (transforms.py:116-144)
+                        scale_mod = u["pre_scale"]
+                        s64 = scale_mod.scale.detach().double()
+                        gsc = self._grad_slot(grads, scale_mod.scale)
+                        if gsc is not None:
+                            ds = -(prep["Minv"] * G).sum(0) / (s64 * s64) - Gsum / s64
+                            gsc.copy_(ds.to(gsc.dtype).reshape(gsc.shape))
+                        G = G / s64[None, :]
+                    # y = (a - b) Minv^T:  dMinv = g^T a - gsum (x) b ,  db = -Minv^T gsum
+                    G = G - torch.outer(gs, prep["b"])
+                    dMinv = G if dMinv is None else dMinv + G
+                    db = db - prep["Minv"].t() @ gs
+                else:
+                    # y = a M^T + b (InverseTransform.backward = block forward, transforms.py:370-376)
+                    dM = G if dM is None else dM + G
+                    db = db + gs
+            self._to_leaves(blk, prep, dMinv, dM, db, coef.get(id(blk), 0.0) * Gsum, lu_acc, grads, pk)
+        self._lu_param_grads(pk, lu_acc, grads)
+
+    def _to_leaves(self, blk, prep, dMinv, dM, db, ladj_coef, lu_acc, grads, pk):
+        """gradients w.r.t. a block's (M^-1, M, bias) -> its LU factors' accumulators / Householder parameters"""
+        if isinstance(blk, T.SequentialAffineTransform) and len(blk.transforms) == 1:
+            blk = blk.transforms[0]              # eye @ M_1 == M_1: the same matrices
+        if isinstance(blk, T.LUTransform):
+            a = lu_acc.setdefault(id(blk), dict(lu=blk, dMinv=None, dM=None, db=None, c=0.0))
+            for k_, v in (("dMinv", dMinv), ("dM", dM), ("db", db)):
+                if v is not None:
+                    a[k_] = v if a[k_] is None else a[k_] + v
+            a["c"] = a["c"] + ladj_coef
+            return
+        # general composition: small torch graph over the prepared fp64 matrices of the parts
+        parts = list(blk.transforms) if isinstance(blk, T.SequentialAffineTransform) else [blk]
+        with torch.enable_grad():
+            leaves = []
+            mats = []
+            for t in parts:
+                if isinstance(t, T.LUTransform):
+                    pr = pk["affine_parts"][id(t)]
+                    Mi = pr["Minv"].detach().clone().requires_grad_(True)
+                    Mm = pr["M"].detach().clone().requires_grad_(True)
+                    bb = pr["b"].detach().clone().requires_grad_(True)
+                    leaves.append(("lu", t, Mi, Mm, bb))
+                    mats.append((Mm, Mi, bb))
+                elif isinstance(t, T.HouseholderTransform):
+                    Hw = t._construct_householder_permutation().double()        # differentiable w.r.t. vk
+                    leaves.append(("hh", t, Hw))
+                    mats.append((Hw, Hw.t(), torch.zeros(t.dim, dtype=torch.float64, device=Hw.device)))
+                else:
+                    raise TrainUnsupported(type(t).__name__)
+            M, Minv, b = mats[0]
+            for m_, mi_, b_ in mats[1:]:                     # transforms.py:1457-1476
+                M = M @ m_
+                b = b @ m_ + b_
+                Minv = mi_ @ Minv
+            proxy = (b * db).sum()
+            if dMinv is not None:
+                proxy = proxy + (Minv * dMinv).sum()
+            if dM is not None:
+                proxy = proxy + (M * dM).sum()
+            wanted, owners = [], []
+            for lf in leaves:
+                if lf[0] == "lu":
+                    wanted += [lf[2], lf[3], lf[4]]
+                    owners += [(lf[1], "dMinv"), (lf[1], "dM"), (lf[1], "db")]
+                else:
+                    for p in lf[1].parameters():
+                        if p.requires_grad:
+                            wanted.append(p)
+                            owners.append((p, "param"))
+            got = torch.autograd.grad(proxy, wanted, allow_unused=True)
+        n_lu = sum(1 for lf in leaves if lf[0] == "lu")
+        for (owner, kind), g in zip(owners, got):
+            if kind == "param":
+                if g is not None:
+                    slot = self._grad_slot(grads, owner)
+                    slot.add_(g.to(slot.dtype))
+                continue
+            a = lu_acc.setdefault(id(owner), dict(lu=owner, dMinv=None, dM=None, db=None, c=0.0))
+            if g is not None:
+                a[kind] = g if a[kind] is None else a[kind] + g
+        for lf in leaves:
+            if lf[0] == "lu":                                # the block's log-det is the sum of its LU parts'
+                a = lu_acc.setdefault(id(lf[1]), dict(lu=lf[1], dMinv=None, dM=None, db=None, c=0.0))
+                a["c"] = a["c"] + ladj_coef
+        del n_lu
+
+    def _lu_param_grads(self, pk, lu_acc, grads):
+        """batched over all LU blocks: (dMinv, dM, db) -> (L_raw, U_raw, bias_vector).grad on the f64 MFMA"""
+        if not lu_acc:
+            return
+        accs = list(lu_acc.values())
+        n = len(accs)
+        D = self.eng.D
+        dev = pk["affine_parts"][id(accs[0]["lu"])]["Minv"].device
+        DD = D * D
+        f64 = lambda *shape: torch.empty(*shape, dtype=torch.float64, device=dev)
+        stack = lambda key: torch.stack([pk["affine_parts"][id(a["lu"])][key] for a in accs]).contiguous()
+        dL = torch.zeros(n, D, D, dtype=torch.float64, device=dev)
+        dU = torch.zeros(n, D, D, dtype=torch.float64, device=dev)
+        bat = dict(batch=n, strideA=DD, strideB=DD, strideC=DD, M=D, N=D, K=D, lda=D, ldb=D, ldc=D)
+        if any(a["dMinv"] is not None for a in accs):
+            G = torch.stack([a["dMinv"] if a["dMinv"] is not None else torch.zeros(D, D, dtype=torch.float64, device=dev)
+                             for a in accs]).contiguous()
+            Minv, Linv, UinvT = stack("Minv"), stack("Linv"), stack("Uinv_t")
+            T1, T2 = f64(n, D, D), f64(n, D, D)
+            _ext.gemm_f64(G, Minv, T1, transB=True, **bat)                       # G Minv^T
+            _ext.gemm_f64(UinvT, T1, dU, alpha=-1.0, **bat)                      # -U^-T (G Minv^T)
+            _ext.gemm_f64(Minv, G, T2, transA=True, **bat)                       # Minv^T G
+            _ext.gemm_f64(T2, Linv, dL, transB=True, alpha=-1.0, **bat)          # -(Minv^T G) L^-T
+        if any(a["dM"] is not None for a in accs):
+            G = torch.stack([a["dM"] if a["dM"] is not None else torch.zeros(D, D, dtype=torch.float64, device=dev)
+                             for a in accs]).contiguous()
+            L, Ut = stack("L"), stack("Ut")
+            _ext.gemm_f64(G, Ut, dL, beta=1.0, **bat)                            # + G U^T
+            _ext.gemm_f64(L, G, dU, transA=True, beta=1.0, **bat)                # + L^T G
+        for i, a in enumerate(accs):
+            lu = a["lu"]
+            gU = self._grad_slot(grads, lu.U_raw)
+            if gU is not None:
+                du = dU[i].triu()
+                if a["c"] is not None and not (isinstance(a["c"], float) and a["c"] == 0.0):
+                    # d/dU_jj of c * sum_j log|U_jj|  (transforms.py:1303-1320)
+                    du = du + torch.diag(a["c"] / lu.U_raw.detach().double().diagonal())
+                gU.add_(du.to(gU.dtype))
+            gL = self._grad_slot(grads, lu.L_raw)
+            if gL is not None:
+                gL.add_(dL[i].tril(-1).to(gL.dtype))
+            gb = self._grad_slot(grads, lu.bias_vector)
+            if gb is not None and a["db"] is not None:
+                gb.add_(a["db"].to(gb.dtype))
+
+
+class _LogProbFn(torch.autograd.Function):
+    """``Flow.log_prob`` as one autograd node (forward: launch list; backward: TrainPath.backward)."""
+
+    @staticmethod
+    def forward(ctx, path: TrainPath, x, context, *params):
+        lp, plan, xc, gen = path.forward(x, context)
+        ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
+        ctx.params = params
+        return lp
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        path: TrainPath = ctx.path
+        if path.generation != ctx.gen:
+            # another training forward ran in between and overwrote the saved activations: run this one again
+            _, ctx.plan, ctx.x, ctx.gen = path.forward(ctx.x, ctx.context)
+        grads = path.backward(ctx.plan, ctx.x, g_lp)
+        out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        return (None, None, None) + out
+
+
+def log_prob_with_grad(path: TrainPath, x, context):
+    params = path.params()
+    return _LogProbFn.apply(path, x, context, *params)
