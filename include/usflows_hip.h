@@ -161,6 +161,16 @@ int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t bas
                         const float* loc, const float* scale, uint64_t seed, uint64_t offset,
                         int64_t row_offset, usf_stream_t stream);
 
+/*
+ * RadialDistribution.sample (distributions.py:474-499): z[m,:] = loc + r[m] * u_m with u_m uniform on
+ * the unit Lp sphere as UniformUnitLpBall.sample draws it (distributions.py:283-319): base = USF_BASE_LPNORM1
+ * (Dirichlet(1..1) x random signs), LPNORM2 (normalised normals), LPNORMINF (Uniform(-1,1) coordinates, one uniformly
+ * chosen coordinate set to +1.0).  r [M]: radii drawn by the caller from the norm distribution.  Philox substreams as
+ * usf_base_sample_f32 (row m of rank-offset row_offset always consumes the same counters).
+ */
+int usf_radial_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
+                          uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream);
+
 /* ScaleTransform.forward / backward as a standalone layer (transforms.py:105-125): y = x*s or x/s */
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D,
                   const float* s, int32_t divide, usf_stream_t stream);
@@ -254,7 +264,7 @@ int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* 
  *   row ranges whose partial products are summed in a fixed order (bitwise reproducible).  Y / A rows must be 16-byte
  *   aligned (ld % 4 == 0).  workspace: at least usf_wgrad_workspace_floats(M,N,K) floats.
  * usf_colsum_f32: out[n] = alpha * sum_m Y[m,n] + beta * out[n]           -- the bias gradient; workspace
- *   min(512, ceil(M/512)) * N floats.
+ *   min(512, ceil(M/128)) * N floats.
  */
 int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
                   int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);

@@ -29,7 +29,7 @@ class PtrMap:
                 off = (ptr - base) // t.element_size()
                 flat = t.view(-1)
                 assert off + (rows - 1) * ld + cols <= flat.numel(), "descriptor reads past its tensor"
-                return torch.as_strided(flat, (rows, cols), (ld, 1), off)
+                return torch.as_strided(flat, (rows, cols), (ld, 1), t.storage_offset() + off)
         raise KeyError(f"pointer {ptr:#x} not inside any known tensor")
 
     def vec(self, ptr, n):
@@ -218,7 +218,7 @@ def _emu_matvec_f64(src, b, *, idx=None, n_out=None, alpha=1.0, out32=None, out6
 
 # ---- batch-sized entry points as the _ext wrappers present them (tensors + element offsets) ---------------
 def _view(t, off, rows, cols, ld):
-    return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1), off)
+    return torch.as_strided(t.reshape(-1), (rows, cols), (ld, 1), t.storage_offset() + off)   # as_strided offsets are absolute
 
 
 def _emu_linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_sub=None, residual=None, ldr=0,
@@ -308,6 +308,7 @@ def install_training_emulation(monkeypatch):
 
 def install_prep_emulation(monkeypatch):
     """route the engine's parameter-prep calls to the torch-CPU statements above (tests without a GPU)"""
+    monkeypatch.setattr(_ext, "TAPES_ENABLED", False)     # the emulated entry points are not taped: always rebuild
     monkeypatch.setattr(_ext, "lu_prepare", _emu_lu_prepare)
     monkeypatch.setattr(_ext, "householder", _emu_householder)
     monkeypatch.setattr(_ext, "matmul_f64", _emu_matmul_f64)

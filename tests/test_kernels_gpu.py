@@ -243,3 +243,67 @@ def test_base_sample_statistics_and_determinism(base):
         cdf = 0.5 * (1 + torch.erf(col / math.sqrt(2.0)))
     emp = (torch.arange(1, M + 1, dtype=torch.float64)) / M
     assert (cdf - emp).abs().max().item() < 1.7 / math.sqrt(M)
+
+
+# ---- RadialDistribution.sample on the device (distributions.py:283-319, 474-499) -----------------
+@pytest.mark.parametrize("p,base_id", [(1.0, 2), (2.0, 3), (float("inf"), 4)])
+@pytest.mark.parametrize("D", [7, 64, 784])
+def test_radial_sample_kernel(p, base_id, D):
+    from usflows_amd import _ext
+    _ext.load()
+    M = 4096
+    g = torch.Generator().manual_seed(D)
+    loc = torch.randn(D, generator=g).to("cuda:0")
+    r = (0.5 + torch.rand(M, generator=g)).to("cuda:0")
+    z = torch.full((M, D + 3), 7.0, device="cuda:0")
+    _ext.radial_sample(z, D + 3, M, D, base_id, loc, r, 1234, 0)
+    z2 = torch.full((M, D + 3), 7.0, device="cuda:0")
+    _ext.radial_sample(z2[: M // 2], D + 3, M // 2, D, base_id, loc, r, 1234, 0)
+    _ext.radial_sample(z2[M // 2:], D + 3, M // 2, D, base_id, loc, r[M // 2:].contiguous(), 1234, 0, row_offset=M // 2)
+    assert torch.equal(z, z2)                                   # substreams: rows do not depend on the launch split
+    assert (z[:, D:] == 7.0).all()                              # padding columns untouched
+    u = (z[:, :D] - loc).double().cpu()
+    rr = r.double().cpu()
+    # the Lp radius of every row is the radius handed in (the property RadialDistribution.log_prob relies on)
+    norm = u.abs().sum(1) if p == 1.0 else (u.pow(2).sum(1).sqrt() if p == 2.0 else u.abs().max(1).values)
+    assert ((norm - rr).abs() / rr).max().item() < 1e-5
+    un = u / rr[:, None]
+    if p == float("inf"):
+        # exactly one coordinate at +1 (the reference sets 1.0, never -1), uniformly placed; the rest U(-1,1)
+        at_one = (un - 1.0).abs() < 1e-6
+        assert (at_one.sum(1) >= 1).all()
+        idx = at_one.float().argmax(1).double()
+        assert abs(idx.mean().item() - (D - 1) / 2) < 4 * D / (12 * M) ** 0.5 + 0.5
+        rest = un[~at_one]
+        assert abs(rest.mean().item()) < 0.02 and abs(rest.var().item() - 1 / 3) < 0.02
+    else:
+        assert abs(un.mean().item()) < 4.0 / (M * D) ** 0.5 + 1e-3          # sign-symmetric
+        assert abs((un > 0).double().mean().item() - 0.5) < 0.01
+        if p == 1.0:
+            # Dirichlet(1,..,1) marginals: E|u_i| = 1/D, Var|u_i| = (D-1) / (D^2 (D+1))
+            a = un.abs()
+            assert abs(a.mean().item() * D - 1.0) < 1e-6
+            assert abs(a.var().item() / ((D - 1) / (D * D * (D + 1.0))) - 1.0) < 0.1
+        else:
+            assert abs(un.pow(2).mean().item() * D - 1.0) < 1e-5
+            assert abs(un[:, 0].var().item() * D - 1.0) < 0.15
+
+
+def test_flow_sample_with_radial_base_runs_on_device():
+    from golden_util import load_case
+    from model_util import build_flow
+    spec, sd, a = load_case("synth_d16_k3_hh1_radial2")
+    flow = build_flow(spec, sd, device="cuda:0")
+    before = flow.engine().launch_count
+    with torch.no_grad():
+        xs = flow.sample([2000], seed=11)
+        xs2 = flow.sample([2000], seed=11)
+        assert flow.engine().launch_count > before
+        assert xs.shape == (2000, 16) and torch.isfinite(xs).all()
+        # round trip: the latent radius distribution is the norm distribution's (mean of log r for a LogNormal)
+        z = flow.backward(xs)
+    r = (z - flow.base_distribution.loc).norm(p=2, dim=1)
+    nd = flow.base_distribution.norm_distribution
+    ref = nd.sample((20000,)).reshape(-1).log()
+    assert abs(r.log().mean().item() - ref.mean().item()) < 0.05 * max(1.0, ref.std().item())
+    del xs2

@@ -120,3 +120,34 @@ def test_fit_runs_on_device_and_reduces_the_loss():
                       device=torch.device(DEV), epochs=4)
     assert flow.engine().launch_count > before
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("name", ["synth_d64_k6_hh0_laplace", "synth_d64_k4_hh1_conj_laplace", "synth_d7_k3_soft_ctx"])
+def test_replayed_tapes_track_parameter_updates(name):
+    """steps 2.. of a training loop replay the recorded launch tapes (pack refresh in place + backward): gradients
+    must keep matching the composite formulation while the optimiser moves the parameters"""
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd, device=DEV)
+    ref = build_flow(spec, sd, device=DEV)
+    ref.use_device_training = False
+    opts = [torch.optim.SGD(f.parameters(), lr=1e-4) for f in (flow, ref)]
+    g = torch.Generator().manual_seed(3)
+    packs = []
+    for step in range(4):
+        x = torch.rand(96, spec.dim, generator=g).to(DEV)
+        ctx = (torch.rand(96, 1, generator=g) * 2).to(DEV) if spec.soft_training else None
+        for f, o in zip((flow, ref), opts):
+            o.zero_grad(set_to_none=True)
+            (-f.log_prob(x, ctx).mean()).backward()
+        for (n1, p1), (n2, p2) in zip(flow.named_parameters(), ref.named_parameters()):
+            if p2.grad is None:
+                assert p1.grad is None or p1.grad.abs().max().item() < 1e-6, n1
+                continue
+            big = max(p2.grad.abs().max().item(), 1e-9)
+            assert (p1.grad - p2.grad).abs().max().item() <= 5e-4 * big, (step, n1)
+        packs.append(flow.engine()._pack)
+        for o in opts:
+            o.step()
+    assert all(p is packs[0] for p in packs), "the pack was rebuilt instead of refreshed in place"
+    plan = next(p for k, p in flow.engine()._plans.items() if k[-1])
+    assert plan["bwd_tape"] is not None and len(plan["bwd_tape"].entries) > 10

@@ -92,6 +92,8 @@ SYMBOLS = {
                                        _fp, _fp, C.c_void_p]),
     "usf_base_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
                                       C.c_uint64, C.c_int64, C.c_void_p]),
+    "usf_radial_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
+                                        C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -152,6 +154,66 @@ def check(rc: int, what: str = "") -> None:
         raise RuntimeError(f"usflows_amd HIP call failed ({what}, rc={rc}): {msg}")
 
 
+# ---- launch tapes ---------------------------------------------------------------------------------
+# A training step re-issues the SAME ~2000 launches with the same device pointers every iteration (persistent
+# buffers, parameters updated in place).  A Tape records each C call once -- (function, fully converted ctypes
+# arguments) -- and `replay` re-issues them without going through the Python wrappers again (~3 us per launch
+# instead of ~40 us).  `host_op` records parameter-sized torch work that has to be redone on replay.
+TAPES_ENABLED = True
+
+
+class Tape:
+    __slots__ = ("entries", "stream")
+
+    def __init__(self):
+        self.entries = []
+        self.stream = None
+
+
+_rec: list = []          # recording stack; the innermost tape receives the launches, None = recording suspended
+
+
+class record:
+    def __init__(self, tape: Optional[Tape]):
+        self.tape = tape
+
+    def __enter__(self):
+        _rec.append(self.tape)
+        return self.tape
+
+    def __exit__(self, *exc):
+        _rec.pop()
+        return False
+
+
+def _launch(name: str, args: tuple, keep=None) -> None:
+    fn = getattr(load(), name)
+    if _rec and _rec[-1] is not None:
+        _rec[-1].entries.append((fn, args, name, keep))
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)
+
+
+def host_op(fn) -> None:
+    """run fn() now and, when recording, again on every replay (its own launches are not taped separately)"""
+    if _rec and _rec[-1] is not None:
+        _rec[-1].entries.append(fn)
+    with record(None):
+        fn()
+
+
+def replay(tape: Tape) -> None:
+    with record(None):
+        for e in tape.entries:
+            if e.__class__ is tuple:
+                rc = e[0](*e[1])
+                if rc != 0:
+                    check(rc, e[2])
+            else:
+                e()
+
+
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -186,18 +248,22 @@ def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_
     d.ldc = ldc
     d.M, d.N, d.K = M, N, K
     d.res_sign, d.slope, d.act = res_sign, slope, act
-    check(load().usf_linear_f32(C.byref(d), current_stream(A.device)), "usf_linear_f32")
+    _launch("usf_linear_f32", (C.byref(d), current_stream(A.device)), d)
 
 
 def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):
-    check(load().usf_base_logprob_f32(z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), float(logdet_const),
-                                      out.data_ptr(), ptr(sum_out), current_stream(z.device)),
-          "usf_base_logprob_f32")
+    _launch("usf_base_logprob_f32", (z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), float(logdet_const),
+                                     out.data_ptr(), ptr(sum_out), current_stream(z.device)))
 
 
 def base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset=0):
     check(load().usf_base_sample_f32(z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), seed, offset,
                                      row_offset, current_stream(z.device)), "usf_base_sample_f32")
+
+
+def radial_sample(z, ldz, M, D, base, loc, r, seed, offset, row_offset=0):
+    check(load().usf_radial_sample_f32(z.data_ptr(), ldz, M, D, base, loc.data_ptr(), r.data_ptr(), seed, offset,
+                                       row_offset, current_stream(z.device)), "usf_radial_sample_f32")
 
 
 def scale(x, ldx, y, ldy, M, D, s, divide):
@@ -236,7 +302,7 @@ def lu_prepare(L_raws, U_raws, want_M=True, want_Minv=True, keep_factors=False):
     d.L_raw, d.U_raw = Lp, Up
     d.tri, d.tri_inv, d.work = tri.data_ptr(), tri_inv.data_ptr(), work.data_ptr()
     d.M, d.Minv, d.ladj = ptr(out["M"]), ptr(out["Minv"]), out["ladj"].data_ptr()
-    check(load().usf_lu_prepare_f64(C.byref(d), current_stream(dev)), "usf_lu_prepare_f64")
+    _launch("usf_lu_prepare_f64", (C.byref(d), current_stream(dev)), (d, Lp, Up, tri, tri_inv, work, out))
     if keep_factors:
         out["tri"], out["tri_inv"] = tri, tri_inv
     return out
@@ -245,9 +311,9 @@ def lu_prepare(L_raws, U_raws, want_M=True, want_Minv=True, keep_factors=False):
 def gemm_f64(A, B, Cout, *, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, strideA=0, strideB=0,
              strideC=0, alpha=1.0, beta=0.0, tri=0, a_off=0, b_off=0, c_off=0):
     """usf_gemm_f64 on fp64 device tensors (element offsets *_off)."""
-    check(load().usf_gemm_f64(A.data_ptr() + 8 * a_off, lda, strideA, int(transA), B.data_ptr() + 8 * b_off, ldb,
-                              strideB, int(transB), Cout.data_ptr() + 8 * c_off, ldc, strideC, M, N, K, batch,
-                              float(alpha), float(beta), tri, current_stream(A.device)), "usf_gemm_f64")
+    _launch("usf_gemm_f64", (A.data_ptr() + 8 * a_off, lda, strideA, int(transA), B.data_ptr() + 8 * b_off, ldb,
+                             strideB, int(transB), Cout.data_ptr() + 8 * c_off, ldc, strideC, M, N, K, batch,
+                             float(alpha), float(beta), tri, current_stream(A.device)), (A, B, Cout))
 
 
 def matmul_f64(A: torch.Tensor, B: torch.Tensor, transA=False, transB=False, tri=0) -> torch.Tensor:
@@ -263,8 +329,8 @@ def matmul_f64(A: torch.Tensor, B: torch.Tensor, transA=False, transB=False, tri
 def householder(w_0, vk):
     D = int(w_0.shape[0])
     out = torch.empty(D, D, dtype=torch.float64, device=w_0.device)
-    check(load().usf_householder_f64(w_0.data_ptr(), vk.data_ptr(), int(vk.shape[0]), D, out.data_ptr(),
-                                     current_stream(w_0.device)), "usf_householder_f64")
+    _launch("usf_householder_f64", (w_0.data_ptr(), vk.data_ptr(), int(vk.shape[0]), D, out.data_ptr(),
+                                    current_stream(w_0.device)), (w_0, vk, out))
     return out
 
 
@@ -277,16 +343,16 @@ def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None
         ld_src = src.shape[-1]
     ldp = planes.shape[2] if planes is not None else 0
     ps = planes.shape[1] * planes.shape[2] if planes is not None else 0
-    check(load().usf_pack_weight_f32(src.data_ptr(), int(src.dtype == torch.float32), ld_src, int(transpose),
-                                     ptr(out_idx), n_out, ptr(in_idx), n_in, ptr(W), ldw, ptr(planes), ldp, ps,
-                                     current_stream(src.device)), "usf_pack_weight_f32")
+    _launch("usf_pack_weight_f32", (src.data_ptr(), int(src.dtype == torch.float32), ld_src, int(transpose),
+                                    ptr(out_idx), n_out, ptr(in_idx), n_in, ptr(W), ldw, ptr(planes), ldp, ps,
+                                    current_stream(src.device)), (src, out_idx, in_idx, W, planes))
 
 
 def matvec_f64(src, b, *, idx=None, n_out=None, alpha=1.0, out32=None, out64=None, ld_src=None):
     if n_out is None:
         n_out = src.shape[0]
-    check(load().usf_matvec_f64(src.data_ptr(), ld_src or src.shape[1], b.shape[0], ptr(idx), n_out, b.data_ptr(),
-                                float(alpha), ptr(out32), ptr(out64), current_stream(src.device)), "usf_matvec_f64")
+    _launch("usf_matvec_f64", (src.data_ptr(), ld_src or src.shape[1], b.shape[0], ptr(idx), n_out, b.data_ptr(),
+                               float(alpha), ptr(out32), ptr(out64), current_stream(src.device)), (src, b, idx, out32, out64))
 
 
 # ---- training backward (usf_train.hip) ---------------------------------------------
@@ -308,23 +374,23 @@ def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1
     lib = load()
     need = lib.usf_wgrad_workspace_floats(M, N, K)
     ws = _workspace(Y.device, need)
-    check(lib.usf_wgrad_f32(Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
-                            G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ws.data_ptr(), ws.numel(),
-                            current_stream(Y.device)), "usf_wgrad_f32")
+    _launch("usf_wgrad_f32", (Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
+                              G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ws.data_ptr(), ws.numel(),
+                              current_stream(Y.device)), (Y, A, G, ws))
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):
     ws = _workspace(Y.device, 512 * N)
-    check(load().usf_colsum_f32(Y.data_ptr() + 4 * y_off, ldy, M, N, out.data_ptr(), float(alpha), float(beta),
-                                ws.data_ptr(), ws.numel(), current_stream(Y.device)), "usf_colsum_f32")
+    _launch("usf_colsum_f32", (Y.data_ptr() + 4 * y_off, ldy, M, N, out.data_ptr(), float(alpha), float(beta),
+                               ws.data_ptr(), ws.numel(), current_stream(Y.device)), (Y, out, ws))
 
 
 def act_grad(d, h, *, M, H, ldd, ldh, act, slope):
-    check(load().usf_act_grad_f32(d.data_ptr(), ldd, h.data_ptr(), ldh, M, H, act, float(slope),
-                                  current_stream(d.device)), "usf_act_grad_f32")
+    _launch("usf_act_grad_f32", (d.data_ptr(), ldd, h.data_ptr(), ldh, M, H, act, float(slope),
+                                 current_stream(d.device)), (d, h))
 
 
 def base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
-    check(load().usf_base_logprob_grad_f32(z.data_ptr(), ldz, g_lp.data_ptr(), M, D, base, loc.data_ptr(),
-                                           scale.data_ptr(), g.data_ptr(), ldg, current_stream(z.device)),
-          "usf_base_logprob_grad_f32")
+    _launch("usf_base_logprob_grad_f32", (z.data_ptr(), ldz, g_lp.data_ptr(), M, D, base, loc.data_ptr(),
+                                          scale.data_ptr(), g.data_ptr(), ldg, current_stream(z.device)),
+            (z, g_lp, loc, scale, g))

@@ -23,6 +23,8 @@ int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base
                  const float* scale, float logdet_const, float* logp, double* sum_out, hipStream_t stream);
 int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* scale,
                 uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream);
+int radial_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
+                  uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream);
 int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s, int32_t divide,
           hipStream_t stream);
 int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
@@ -85,6 +87,11 @@ int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int3
 int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                         const float* scale, uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream) {
   return usf::base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset, (hipStream_t)stream);
+}
+
+int usf_radial_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
+                          uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream) {
+  return usf::radial_sample(z, ldz, M, D, base, loc, r, seed, offset, row_offset, (hipStream_t)stream);
 }
 
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s,

@@ -199,6 +199,87 @@ int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const
 }
 
 // ------------------------------------------------------------------------------------------
+// RadialDistribution.sample (distributions.py:474-499): x = loc + r * u,  u uniform on the unit Lp sphere
+// (UniformUnitLpBall.sample, distributions.py:283-319); r [M] comes from the caller (norm_distribution.sample).
+//   p = 1  : Dirichlet(1,..,1) (= normalised Exp(1) variates) times random signs
+//   p = 2  : normalised standard normals
+//   p = inf: Uniform(-1,1) coordinates, one coordinate (uniformly chosen) set to +1.0 (the reference sets 1.0, not +-1)
+// One wave per row: variates from Philox counter (row, d/4) of stream `offset`, wave reduction for the norm.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void radial_sample_kernel(float* __restrict__ z, int64_t ldz, int64_t M, int D, int base,
+                                                            const float* __restrict__ loc, const float* __restrict__ r,
+                                                            uint64_t seed, uint64_t offset, int64_t row_offset) {
+  const int lane = threadIdx.x & 63;
+  const int64_t groups_per_row = (D + 3) / 4;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    float* zr = z + m * ldz;
+    float acc = 0.f;
+    // pass 1: raw variates into the row, reduction of the normaliser
+    for (int64_t g = lane; g < groups_per_row; g += 64) {
+      uint32_t rnd[4], rnd2[4];
+      philox4x32_10((uint64_t)((m + row_offset) * groups_per_row + g), offset, seed, rnd);
+      float v[4];
+      if (base == USF_BASE_LPNORM1) {
+        philox4x32_10((uint64_t)((m + row_offset) * groups_per_row + g), offset ^ 0x5bd1e995u, seed, rnd2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = -logf(u01(rnd[j]));
+          acc += ((int)(g * 4 + j) < D) ? e : 0.f;
+          v[j] = (rnd2[j] & 1u) ? e : -e;
+        }
+      } else if (base == USF_BASE_LPNORM2) {
+        const float r0 = sqrtf(-2.0f * logf(u01(rnd[0]))), r1 = sqrtf(-2.0f * logf(u01(rnd[2])));
+        float s0, c0, s1, c1;
+        sincosf(6.28318530717958647692f * u01(rnd[1]), &s0, &c0);
+        sincosf(6.28318530717958647692f * u01(rnd[3]), &s1, &c1);
+        v[0] = r0 * c0; v[1] = r0 * s0; v[2] = r1 * c1; v[3] = r1 * s1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += ((int)(g * 4 + j) < D) ? v[j] * v[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = 2.0f * u01(rnd[j]) - 1.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((int)(g * 4 + j) < D) zr[g * 4 + j] = v[j];
+    }
+    acc = wave_sum(acc);
+    float mul = r[m];
+    int extremal = -1;
+    if (base == USF_BASE_LPNORM1) mul = mul / acc;
+    else if (base == USF_BASE_LPNORM2) mul = mul / sqrtf(acc);
+    else {
+      uint32_t rnd[4];
+      philox4x32_10((uint64_t)(m + row_offset), offset ^ 0x9e3779b9u, seed, rnd);
+      extremal = (int)(((uint64_t)rnd[0] * (uint64_t)D) >> 32);     // uniform index in [0, D)
+    }
+    // pass 2: each lane rescales the elements it wrote itself (no cross-lane dependency on memory)
+    for (int64_t g = lane; g < groups_per_row; g += 64)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = (int)(g * 4 + j);
+        if (d < D) zr[d] = loc[d] + mul * (d == extremal ? 1.0f : zr[d]);
+      }
+  }
+}
+
+int radial_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
+                  uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream) {
+  if (M < 0 || D <= 0 || D > 0x7fffffff || ldz < D) { set_error("usf_radial_sample_f32: bad sizes"); return -2; }
+  if (M == 0) return 0;
+  if (!z || !loc || !r) { set_error("usf_radial_sample_f32: null pointer"); return -1; }
+  if (base != USF_BASE_LPNORM1 && base != USF_BASE_LPNORM2 && base != USF_BASE_LPNORMINF) {
+    set_error("usf_radial_sample_f32: base %d is not an Lp-radial id", base);
+    return -2;
+  }
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(radial_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, ldz, M, (int)D, base, loc, r,
+                     seed, offset, row_offset);
+  return check_launch("usf_radial_sample_f32");
+}
+
+// ------------------------------------------------------------------------------------------
 // standalone scale layer and column gather
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,

@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // number of 16-wide sub-tiles of this wave's 64 x 64 patch that reach into the matrix (wave-uniform)
+  const int rem_n = a.N - (n0 + wn * 64), rem_k = a.K - (k0 + wk * 64);
+  const int ni = rem_n <= 0 ? 0 : (rem_n >= 64 ? 4 : (rem_n + 15) / 16);
+  const int nj = rem_k <= 0 ? 0 : (rem_k >= 64 ? 4 : (rem_k + 15) / 16);
+  const bool full = (ni == 4 && nj == 4);
   f32x4 ry[2], ra[2];
   auto stage = [&](int buf) {
 #pragma unroll
@@ -89,20 +94,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       wg_load(a.Y, a.ldy, m0 + WG_S, m_end, n0, a.N, tid, ry);
       wg_load(a.A, a.lda, m0 + WG_S, m_end, k0, a.K, tid, ra);
     }
+    if (full) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      float fy[4], fa[4];
-      const int r = kk * 4 + (lane >> 4);
+      for (int kk = 0; kk < 4; ++kk) {
+        float fy[4], fa[4];
+        const int r = kk * 4 + (lane >> 4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fy[t] = Ys[buf][r][wn * 64 + t * 16 + (lane & 15)];
-        fa[t] = As[buf][r][wk * 64 + t * 16 + (lane & 15)];
+        for (int t = 0; t < 4; ++t) {
+          fy[t] = Ys[buf][r][wn * 64 + t * 16 + (lane & 15)];
+          fa[t] = As[buf][r][wk * 64 + t * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
       }
+    } else {
+      // edge tile (784 = 6 x 128 + 16): only the 16 x 16 sub-tiles that hold real outputs are multiplied
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int kk = 0; kk < 4; ++kk) {
+        float fy[4], fa[4];
+        const int r = kk * 4 + (lane >> 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+          fy[t] = Ys[buf][r][wn * 64 + t * 16 + (lane & 15)];
+          fa[t] = As[buf][r][wk * 64 + t * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fa[j], acc[i][j], 0, 0, 0);
+      }
     }
     if (more) stage(buf ^ 1);
     __syncthreads();
@@ -186,7 +210,7 @@ __global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 static int pick_splits(int64_t M, int64_t tiles) {
   // enough row ranges to give every CU ~2 blocks, each at least 256 rows
-  int64_t s = (512 + tiles - 1) / tiles;
+  int64_t s = (640 + tiles - 1) / tiles;
   const int64_t smax = (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
@@ -235,7 +259,7 @@ int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float 
     set_error("usf_colsum_f32: bad arguments");
     return -1;
   }
-  int64_t splits = (M + 511) / 512;
+  int64_t splits = (M + 127) / 128;
   if (splits > 512) splits = 512;
   if (splits < 1) splits = 1;
   if (workspace_floats < splits * N) { set_error("usf_colsum_f32: workspace too small"); return -4; }

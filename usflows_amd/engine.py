@@ -93,20 +93,36 @@ def _analyze(layers: Sequence[nn.Module]) -> List[_Step]:
 # ---------------------------------------------------------------------------------------------
 # fp64 parameter prep: batched HIP kernels (usf_prep.hip), cached per parameter version
 # ---------------------------------------------------------------------------------------------
+_copied_params = [0]      # bumped whenever _param had to COPY a parameter (a pack built from copies cannot be replayed)
+
+
 def _param(t: torch.Tensor, device=None) -> torch.Tensor:
+    """fp32 contiguous device view of a parameter (its own storage when it already is one)"""
+    src = t
     t = t.detach()
     if device is not None and t.device != torch.device(device):
         t = t.to(device)
     if t.dtype != torch.float32:
         t = t.float()
-    return t if t.is_contiguous() else t.contiguous()
+    t = t if t.is_contiguous() else t.contiguous()
+    if t.data_ptr() != src.data_ptr():
+        _copied_params[0] += 1
+    return t
+
+
+def _refreshed(shape, dtype, device, fn) -> torch.Tensor:
+    """persistent tensor filled by fn(out) now and again on every replay of the pack tape"""
+    out = torch.empty(shape, dtype=dtype, device=device)
+    _ext.host_op(lambda: fn(out))
+    return out
 
 
 def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors: bool = False) -> Dict[int, dict]:
     """``id(block) -> dict(M, Minv, b, ladj)`` (fp64 device tensors) for LUTransform / HouseholderTransform /
     SequentialAffineTransform blocks, following the reference's definitions (transforms.py:1271-1320, 795-809,
     1457-1476).  All LU blocks of the flow go through ONE batched ``usf_lu_prepare_f64`` call (chunked only to
-    bound the fp64 scratch at large D)."""
+    bound the fp64 scratch at large D).  Every result lives in a tensor of its own that a replay of the recording
+    tape (``_ext.Tape``) refills in place: pointers handed to plans stay valid across optimiser steps."""
     lus: Dict[int, nn.Module] = {}
     hhs: Dict[int, nn.Module] = {}
 
@@ -125,6 +141,7 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
         visit(b)
     res: Dict[int, dict] = {}
     lu_list = list(lus.values())
+    chunks = []
     if lu_list:
         D = int(lu_list[0].dim)
         chunk = max(1, min(len(lu_list), int(8e9 // (64 * D * D))))       # 8 fp64 [D,D] arrays per block in flight
@@ -132,9 +149,13 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
             part = lu_list[c0: c0 + chunk]
             out = _ext.lu_prepare([_param(l.L_raw, device) for l in part], [_param(l.U_raw, device) for l in part],
                                   keep_factors=keep_factors)
+            dev = out["ladj"].device
+            bias = [_param(l.bias_vector, device) for l in part]
+            b64 = _refreshed((len(part), D), torch.float64, dev,
+                             lambda o, bias=bias: torch.stack([v.double() for v in bias], out=o))
+            chunks.append(dict(lus=part, out=out, b=b64))
             for j, l in enumerate(part):
-                r = dict(M=out["M"][j], Minv=out["Minv"][j], b=_param(l.bias_vector, device).double(),
-                         ladj=out["ladj"][j])
+                r = dict(M=out["M"][j], Minv=out["Minv"][j], b=b64[j], ladj=out["ladj"][j])
                 if keep_factors:
                     r.update(L=out["tri"][2 * j], Ut=out["tri"][2 * j + 1], Linv=out["tri_inv"][2 * j],
                              Uinv_t=out["tri_inv"][2 * j + 1])
@@ -142,7 +163,8 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
     for h in hhs.values():
         w = _ext.householder(_param(h.w_0, device), _param(h.vk_householder, device))
         zero = torch.zeros(h.dim, dtype=torch.float64, device=w.device)
-        res[id(h)] = dict(M=w, Minv=w.t().contiguous(), b=zero, ladj=zero.sum())
+        wt = _refreshed(tuple(w.shape), torch.float64, w.device, lambda o, w=w: o.copy_(w.t()))
+        res[id(h)] = dict(M=w, Minv=wt, b=zero, ladj=zero.sum())
     for b in blocks:
         if isinstance(b, T.SequentialAffineTransform) and id(b) not in res:
             parts = [res[id(t)] for t in b.transforms]
@@ -150,10 +172,14 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
             ladj = parts[0]["ladj"]
             for p_ in parts[1:]:                                                  # :1457-1462, :1471-1476
                 M = _ext.matmul_f64(M, p_["M"])
-                bias = _ext.matmul_f64(bias.reshape(1, -1).contiguous(), p_["M"]).reshape(-1) + p_["b"]
+                bm = _ext.matmul_f64(bias.reshape(1, -1), p_["M"])
+                bias = _refreshed(tuple(p_["b"].shape), torch.float64, bm.device,
+                                  lambda o, bm=bm, pb=p_["b"]: torch.add(bm.reshape(-1), pb, out=o))
                 Minv = _ext.matmul_f64(p_["Minv"], Minv)                          # :1464-1469 (reverse order)
-                ladj = ladj + p_["ladj"]
+                ladj = _refreshed((), torch.float64, bm.device,
+                                  lambda o, a=ladj, c=p_["ladj"]: torch.add(a, c, out=o))
             res[id(b)] = dict(M=M, Minv=Minv, b=bias, ladj=ladj)
+    res["__chunks__"] = chunks
     return res
 
 
@@ -271,13 +297,29 @@ class FlowEngine:
         out[ok] = v64[idx[ok]]
         return out.float().contiguous()
 
+    def _ptr_key(self, device):
+        return (str(device), self.keep_factors) + tuple(p.data_ptr() for p in self._params())
+
     def pack(self, device) -> dict:
         key = self._version_key(device)
-        if self._pack is not None and key == self._pack_key and (self._pack["has_factors"] or not self.keep_factors):
-            return self._pack
-        pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}, "has_factors": self.keep_factors}
-        ladj_total = torch.zeros((), dtype=torch.float64, device=device)
-        with torch.no_grad():
+        pk = self._pack
+        if pk is not None and key == self._pack_key and (pk["has_factors"] or not self.keep_factors):
+            return pk
+        if (pk is not None and _ext.TAPES_ENABLED and pk["replayable"] and torch.device(device).type == "cuda"
+                and pk["ptr_key"] == self._ptr_key(device) and pk["tape"].stream == _ext.current_stream(device)):
+            # same parameter storage, new values (an optimiser step): refill every prepared tensor in place by
+            # replaying the recorded launches -- plans and their device pointers stay valid
+            with torch.no_grad():
+                _ext.replay(pk["tape"])
+                pk["ladj_total"] = self._ladj_total(pk)
+            self._pack_key = key
+            return pk
+        pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}, "has_factors": self.keep_factors,
+              "tape": _ext.Tape(), "ptr_key": self._ptr_key(device), "ladj_terms": []}
+        pk["tape"].stream = _ext.current_stream(device) if torch.device(device).type == "cuda" else None
+        copies0 = _copied_params[0]
+        convnet = False
+        with torch.no_grad(), _ext.record(pk["tape"]):
             blocks, seen = [], set()
             for s in self.steps:
                 if s.kind == "affine" and id(s.module) not in seen:
@@ -289,19 +331,36 @@ class FlowEngine:
                 pk["affine"][id(b_)] = prepared[id(b_)]
             for i, s in enumerate(self.steps):
                 if s.kind == "affine":
-                    la = pk["affine"][id(s.module)]["ladj"]
-                    ladj_total = ladj_total + (-la if s.inverted else la)
+                    pk["ladj_terms"].append((-1.0 if s.inverted else 1.0, pk["affine"][id(s.module)]["ladj"]))
                 elif s.kind == "scale":
-                    sc = s.module.scale.detach().double().to(device)
+                    src = _param(s.module.scale, device)
+                    sc = _refreshed(tuple(src.shape), torch.float64, src.device, lambda o, src=src: o.copy_(src))
                     pk["scale"][id(s.module)] = sc
-                    la = sc.abs().log().sum()
-                    ladj_total = ladj_total + (-la if s.inverted else la)
+                    la = _refreshed((), torch.float64, src.device,
+                                    lambda o, sc=sc: torch.sum(sc.abs().log(), dim=0, out=o))
+                    pk["ladj_terms"].append((-1.0 if s.inverted else 1.0, la))
                 elif s.kind == "coupling":
                     pk["coupling"][i] = self._pack_coupling(i, s.module, device)
-        pk["ladj_total"] = float(ladj_total.item())
+                    convnet = convnet or isinstance(s.module.conditioner, ConvNet)
+            pk["ladj_total"] = self._ladj_total(pk)
+        # replay needs every source to be the parameter's own storage (no staging copies) and no torch-side folding
+        pk["replayable"] = (_copied_params[0] == copies0) and not convnet
         self._pack, self._pack_key = pk, key
         self._plans.clear()
         return pk
+
+    @staticmethod
+    def _ladj_total(pk) -> float:
+        terms = pk["ladj_terms"]
+        if not terms:
+            return 0.0
+        if "ladj_signs" not in pk:
+            pk["ladj_signs"] = torch.tensor([t[0] for t in terms], dtype=torch.float64, device=terms[0][1].device)
+        return float((torch.stack([t[1].reshape(()) for t in terms]) * pk["ladj_signs"]).sum().item())
+
+    def _pk_record(self, pk):
+        """context: launches of a lazily built pack item join the pack's tape (refreshed on replay)"""
+        return _ext.record(pk["tape"] if pk.get("replayable") else None)
 
     def _pack_coupling(self, i: int, layer, device) -> dict:
         """Static description of one coupling layer + handles to its raw conditioner parameters; the weight images
@@ -369,6 +428,10 @@ class FlowEngine:
         """per-layer weight images for the chain-of-linears form of the conditioner (any width / depth)"""
         if "unfused" in cp:
             return cp["unfused"]
+        with self._pk_record(pk):
+            return self._unfused_pack_build(cp)
+
+    def _unfused_pack_build(self, cp) -> dict:
         raw = cp["raw"]
         dev, h, hp = raw["device"], raw["h"], cp["hidden"]
         pass_sel = self._sel(raw["pass_idx"], cp["pass_n"], dev)
@@ -426,7 +489,8 @@ class FlowEngine:
             planes = None
             if self._wants_planes(n_out, n_in):
                 planes = torch.empty(3, n_out, _round_up(n_in, 32), dtype=torch.bfloat16, device=dev)
-            _ext.pack_weight(src, oi, n_out, ii, n_in, W=W, ldw=n_in, planes=planes)
+            with self._pk_record(pk):
+                _ext.pack_weight(src, oi, n_out, ii, n_in, W=W, ldw=n_in, planes=planes)
             pk["mats"][key] = W
             if planes is not None:
                 pk["mats"][("planes", W.data_ptr())] = planes
@@ -447,20 +511,24 @@ class FlowEngine:
         if key not in pk["mats"]:
             N, K = W.shape
             planes = torch.empty(3, N, _round_up(K, 32), dtype=torch.bfloat16, device=W.device)
-            _ext.pack_weight(W, None, N, None, K, planes=planes)
+            with _ext.record(pk["tape"] if pk.get("replayable") else None):
+                _ext.pack_weight(W, None, N, None, K, planes=planes)
             pk["mats"][key] = planes
         return pk["mats"][key]
 
     def _vec(self, pk, name, v64, layout: str, pad: float) -> torch.Tensor:
         key = (name, layout, pad)
         if key not in pk["vecs"]:
-            if pad == 0.0:
-                idx = self._idx_dev(layout, v64.device)
-                out = torch.empty(idx.numel(), dtype=torch.float32, device=v64.device)
-                _ext.pack_weight(v64, None, 1, idx, int(idx.numel()), W=out, ldw=int(idx.numel()))
-                pk["vecs"][key] = out
-            else:
-                pk["vecs"][key] = self._perm_vec(v64, self._idx(layout), pad)
+            with self._pk_record(pk):
+                if pad == 0.0:
+                    idx = self._idx_dev(layout, v64.device)
+                    out = torch.empty(idx.numel(), dtype=torch.float32, device=v64.device)
+                    _ext.pack_weight(v64, None, 1, idx, int(idx.numel()), W=out, ldw=int(idx.numel()))
+                    pk["vecs"][key] = out
+                else:
+                    n = int(self._idx(layout).numel())
+                    pk["vecs"][key] = _refreshed((n,), torch.float32, v64.device,
+                                                 lambda o: o.copy_(self._perm_vec(v64, self._idx(layout), pad)))
         return pk["vecs"][key]
 
     # ---- workspace ----------------------------------------------------------------------------
@@ -578,8 +646,9 @@ class FlowEngine:
                         # (y - b) @ Minv^T == y @ Minv^T + c with c = -(Minv b), c formed in fp64 at pack
                         # time: keeps the bias out of the K loop's registers ("bias folding")
                         if "c" not in a:
-                            a["c"] = torch.empty_like(a["b"])
-                            _ext.matvec_f64(a["Minv"], a["b"], alpha=-1.0, out64=a["c"])
+                            a["c"] = torch.empty(a["b"].shape, dtype=torch.float64, device=a["b"].device)
+                            with self._pk_record(pk):
+                                _ext.matvec_f64(a["Minv"], a["b"].contiguous(), alpha=-1.0, out64=a["c"])
                         kw["bias"] = self._vec(pk, ("c", id(blk)), a["c"], out_layout, 0.0).data_ptr()
                 else:
                     W = self._mat(pk, blk, "M", out_layout, in_layout)
@@ -692,6 +761,12 @@ class FlowEngine:
         split = self.gemm_mode == "bf16x3" and Hp == 256
         if "fused" in cp and (not split or "split" in cp["fused"]):
             return cp["fused"]
+        with self._pk_record(self._pack):
+            return self._fused_pack_build(cp, Hp, Kp, Np, split)
+
+    def _fused_pack_build(self, cp, Hp, Kp, Np, split) -> dict:
+        raw = cp["raw"]
+        dev, h = raw["device"], raw["h"]
         pass_sel = self._sel(raw["pass_idx"], Kp, dev)
         tr_sel = self._sel(raw["tr_idx"], Np, dev)
         s3 = dict(hid=[]) if split else None

@@ -243,6 +243,15 @@ class Flow(torch.nn.Module):
                 z = torch.empty(n, eng.D, dtype=torch.float32, device=dev)
                 base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
                 _ext.base_sample(z, eng.D, n, eng.D, base, info[1], info[2], seed, 0, row_offset)
+            elif info is not None and info[0] == "radial" and self.base_distribution.n_batch_dims == 0:
+                # RadialDistribution.sample (distributions.py:474-499): radii from the (arbitrary, 1-D) norm
+                # distribution -- O(n) torch work -- directions on the unit Lp sphere from the Philox kernel
+                if seed is None:
+                    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                r = self.base_distribution.norm_distribution.sample((n,)).reshape(n).to(device=dev, dtype=torch.float32)
+                z = torch.empty(n, eng.D, dtype=torch.float32, device=dev)
+                base = {1.0: _ext.BASE_LPNORM1, 2.0: _ext.BASE_LPNORM2}.get(info[2], _ext.BASE_LPNORMINF)
+                _ext.radial_sample(z, eng.D, n, eng.D, base, info[1], r.contiguous(), seed, 0, row_offset)
             else:
                 z = self.base_distribution.sample(shape).to(dev).reshape(n, eng.D).float()
             x = eng.transform(z, "forward")

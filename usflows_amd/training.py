@@ -133,7 +133,8 @@ class TrainPath:
             planes = None
             if eng._wants_planes(n_in, n_out):
                 planes = torch.empty(3, n_in, _round_up(n_out, 32), dtype=torch.bfloat16, device=dev)
-            _ext.pack_weight(src, ii, n_in, oi, n_out, W=Wt, ldw=n_out, planes=planes, transpose=True)
+            with eng._pk_record(pk):
+                _ext.pack_weight(src, ii, n_in, oi, n_out, W=Wt, ldw=n_out, planes=planes, transpose=True)
             pk["mats"][key] = Wt
             if planes is not None:
                 pk["mats"][("planes", Wt.data_ptr())] = planes
@@ -149,60 +150,142 @@ class TrainPath:
 
     # ---- backward -------------------------------------------------------------------------------------
     def backward(self, plan, x, g_lp: torch.Tensor) -> Dict[int, torch.Tensor]:
-        """gradients of sum_m g_lp[m] * log_prob(x)[m] w.r.t. every trainable parameter: id(param) -> tensor"""
+        """gradients of sum_m g_lp[m] * log_prob(x)[m] w.r.t. every trainable parameter: id(param) -> tensor.
+
+        The launch sequence depends only on the plan: it is recorded on the first call (``_ext.Tape``) and replayed
+        afterwards; the per-call inputs (x, g_lp) enter through ``host_op`` closures reading ``self._cur``."""
+        dev = x.device
+        self._cur = dict(x=x, g_lp=g_lp.detach().to(torch.float32).contiguous())
+        pk = plan["pk"]
+        arena = self._arena(plan)
+        tape = plan.get("bwd_tape")
+        usable = _ext.TAPES_ENABLED and pk.get("replayable", False)
+        with torch.no_grad():
+            if usable and tape is not None and tape.stream == _ext.current_stream(dev) and plan.get("bwd_pk") is pk:
+                _ext.replay(tape)
+            else:
+                tape = _ext.Tape() if usable else None
+                with _ext.record(tape):
+                    self._backward_body(plan, arena)
+                if tape is not None:
+                    tape.stream = _ext.current_stream(dev)
+                plan["bwd_tape"], plan["bwd_pk"] = tape, pk
+            flat = arena["flat"].clone()          # autograd may keep what we return: never hand out the arena itself
+        # parameters the path never reaches (a context layer without context) get no gradient, as under autograd
+        return {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items()
+                if pid in arena["touched"]}
+
+    def _arena(self, plan) -> dict:
+        """one flat fp32 buffer for all parameter gradients of this plan; the LU factors' gradients lie batched
+        ([n,D,D] L_raw | [n,D,D] U_raw | [n,D] bias, in prepare order) so the chain rule writes each with one copy"""
+        ar = plan.get("grad_arena")
+        if ar is not None and ar["pk"] is plan["pk"]:
+            return ar
+        pk = plan["pk"]
+        dev = plan["ws"]["zA"].device
+        slots, off = {}, 0
+        lu_views = []
+        for ch in pk["affine_parts"]["__chunks__"]:
+            n, D = len(ch["lus"]), self.eng.D
+            base = off
+            for name, per in (("L_raw", D * D), ("U_raw", D * D), ("bias_vector", D)):
+                for j, lu in enumerate(ch["lus"]):
+                    p = getattr(lu, name)
+                    slots[id(p)] = (off + j * per, per, tuple(p.shape))
+                off += n * per
+            lu_views.append((base, n))
+        for p in self.params():
+            if id(p) not in slots and p.requires_grad:
+                slots[id(p)] = (off, p.numel(), tuple(p.shape))
+                off += p.numel()
+        flat = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        ar = dict(flat=flat, slots=slots, lu_views=lu_views, pk=pk, touched=set(),
+                  views={pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in slots.items()})
+        plan["grad_arena"] = ar
+        return ar
+
+    def _backward_body(self, plan, arena):
         eng = self.eng
         ws, pk = plan["ws"], plan["pk"]
-        dev = x.device
-        B, D = x.shape[0], eng.D
+        dev = ws["zA"].device
+        B = ws["zA"].shape[0]
+        D = eng.D
         wid = max(eng.LD, eng.LDn)
         gA, gB = self._buf(ws, "gA", B, wid), self._buf(ws, "gB", B, wid)
-        g_lp = g_lp.detach().to(torch.float32).contiguous()
+        glp = self._buf(ws, "g_lp", 1, B)[0, :B]
+        _ext.host_op(lambda: (arena["flat"].zero_(), glp.copy_(self._cur["g_lp"])))
         info = self.flow._base_info(dev)
         base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
         zname, _, ldn = plan["out_buf"]
-        _ext.base_logprob_grad(ws[zname], ldn, g_lp, B, D, base, info[1], info[2], gA, ldn)
+        _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, info[1], info[2], gA, ldn)
         g_cur, g_other, g_ld = gA, gB, ldn
-        grads: Dict[int, torch.Tensor] = {}
-        aff: Dict[int, dict] = {}            # id(block) -> accumulated natural-layout gradients of its usages
+        grads = arena["views"]
+        self._touched = arena["touched"]
+        aff: Dict[int, dict] = {}            # id(block) -> natural-layout gradients of its usages
+        n_aff = sum(1 for m in plan["meta"] if m["kind"] == "affine")
+        stacks = dict(G=torch.zeros(max(n_aff, 1), D, D, dtype=torch.float32, device=dev),
+                      gs=torch.zeros(max(n_aff, 1), D, dtype=torch.float32, device=dev), next=0)
+        self._lu_slot = self._lu_slots(plan)
         first_meta = plan["meta"][0] if plan["meta"] else None
         for m in reversed(plan["meta"]):
             if m["kind"] == "affine":
-                g_cur, g_other, g_ld = self._affine_backward(plan, m, x, g_cur, g_other, g_ld, aff,
+                g_cur, g_other, g_ld = self._affine_backward(plan, m, g_cur, g_other, g_ld, aff, stacks,
                                                              need_dgrad=(m is not first_meta))
             else:
                 self._coupling_backward(plan, m, g_cur, g_ld, grads)
-        self._affine_param_grads(plan, aff, g_lp, grads)
-        return grads
+        _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
+
+    def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
+        """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every
+        affine block is one LU factor (bare or Sequential([LU])) used once, in its M^-1 form, one prepare chunk"""
+        pk = plan["pk"]
+        chunks = pk["affine_parts"]["__chunks__"]
+        if len(chunks) != 1:
+            return None
+        idx = {id(lu): j for j, lu in enumerate(chunks[0]["lus"])}
+        slots, seen = {}, set()
+        for m in plan["meta"]:
+            if m["kind"] != "affine":
+                continue
+            blk = m["blk"]
+            leaf = blk.transforms[0] if (isinstance(blk, T.SequentialAffineTransform) and len(blk.transforms) == 1) else blk
+            if m["prim"] != "affine_bwd" or not isinstance(leaf, T.LUTransform) or id(leaf) in seen:
+                return None
+            seen.add(id(leaf))
+            slots[id(blk)] = idx[id(leaf)]
+        return slots if len(seen) == len(idx) else None
 
     # ---- affine layers --------------------------------------------------------------------------------
-    def _affine_backward(self, plan, m, x, g_cur, g_other, g_ld, aff, need_dgrad):
+    def _affine_backward(self, plan, m, g_cur, g_other, g_ld, aff, stacks, need_dgrad):
         eng = self.eng
         ws, pk = plan["ws"], plan["pk"]
-        dev = x.device
-        B = x.shape[0]
+        dev = ws["zA"].device
+        B = ws["zA"].shape[0]
         blk = m["blk"]
         which = "Minv" if m["prim"] == "affine_bwd" else "M"
         oi = eng._idx_dev(m["out_layout"], dev)
         ii = eng._idx_dev(m["in_layout"], dev)
         n_out, n_in = int(oi.numel()), int(ii.numel())
-        if m["in_buf"] == "user_in":
-            a_in, a_ld = x, x.shape[1]
-        else:
-            a_in, a_ld = ws[m["in_buf"]], m["in_ld"]
         # weight gradient in the image layout, then back to the natural [D, D] layout of the block's matrix
         wid = max(eng.LD, eng.LDn)
         Gp = self._buf(ws, "Gp", wid, wid)
-        _ext.wgrad(g_cur, a_in, Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=a_ld, ldg=Gp.shape[1])
+        if m["in_buf"] == "user_in":
+            # the caller's tensor changes from call to call: issued through the wrapper on every replay
+            _ext.host_op(lambda g=g_cur, ld=g_ld: _ext.wgrad(g, self._cur["x"], Gp, M=B, N=n_out, K=n_in, ldy=ld,
+                                                            lda=self._cur["x"].shape[1], ldg=Gp.shape[1]))
+        else:
+            _ext.wgrad(g_cur, ws[m["in_buf"]], Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=m["in_ld"], ldg=Gp.shape[1])
         gs = self._buf(ws, "gs", 1, wid)
         _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
         D = eng.D
-        G_nat = torch.empty(D, D, dtype=torch.float32, device=dev)
+        k = self._lu_slot[id(blk)] if self._lu_slot is not None else stacks["next"]
+        stacks["next"] += 1
+        G_nat, gs_nat = stacks["G"][k], stacks["gs"][k]
         _ext.pack_weight(Gp, self._inv_idx(m["out_layout"], dev), D, self._inv_idx(m["in_layout"], dev), D,
                          W=G_nat, ldw=D, ld_src=Gp.shape[1])
-        gs_nat = torch.empty(D, dtype=torch.float32, device=dev)
         _ext.pack_weight(gs, None, 1, self._inv_idx(m["out_layout"], dev), D, W=gs_nat, ldw=D, ld_src=gs.shape[1])
         rec = aff.setdefault(id(blk), dict(blk=blk, uses=[]))
-        rec["uses"].append(dict(which=which, G=G_nat, gsum=gs_nat, pre_scale=m["pre_scale"]))
+        rec["uses"].append(dict(which=which, G=G_nat, gsum=gs_nat, pre_scale=m["pre_scale"], row=k))
         if need_dgrad:
             Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
             self._linear(pk, g_cur, 0, g_ld, Wt, g_other, 0, n_in, B, n_in, n_out)
@@ -296,7 +379,8 @@ class TrainPath:
             if self.eng._wants_planes(K, N4):
                 planes = torch.empty(3, K, _round_up(N4, 32), dtype=torch.bfloat16, device=W.device)
             sel = self.eng._iarange(N, N4, W.device)
-            _ext.pack_weight(W, None, K, sel, N4, W=Wt, ldw=N4, planes=planes, transpose=True)
+            with self.eng._pk_record(pk):
+                _ext.pack_weight(W, None, K, sel, N4, W=Wt, ldw=N4, planes=planes, transpose=True)
             pk["mats"][key] = Wt
             if planes is not None:
                 pk["mats"][("planes", Wt.data_ptr())] = planes
@@ -310,15 +394,12 @@ class TrainPath:
             self._inv[("keep", idx.data_ptr())] = idx
         return self._inv[key]
 
-    @staticmethod
-    def _grad_slot(grads, p: torch.Tensor) -> Optional[torch.Tensor]:
+    def _grad_slot(self, grads, p: torch.Tensor) -> Optional[torch.Tensor]:
+        """the parameter's view in the gradient arena (zeroed at the start of every backward)"""
         if not p.requires_grad:
             return None
-        g = grads.get(id(p))
-        if g is None:
-            g = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            grads[id(p)] = g
-        return g
+        self._touched.add(id(p))
+        return grads.get(id(p))
 
     def _scatter_weight(self, grads, p, img, rows_sel, n_rows, cols_sel, n_cols):
         g = self._grad_slot(grads, p)
@@ -340,7 +421,7 @@ class TrainPath:
             _ext.colsum(d, g, M=B, N=n, ldy=ld, alpha=sign)
 
     # ---- parameter-sized chain rule -------------------------------------------------------------------
-    def _affine_param_grads(self, plan, aff, g_lp, grads):
+    def _affine_param_grads(self, plan, aff, stacks, g_lp, grads, arena):
         eng = self.eng
         pk = plan["pk"]
         dev = g_lp.device
@@ -350,8 +431,9 @@ class TrainPath:
         for s in eng.steps:
             if s.kind == "affine":
                 coef[id(s.module)] = coef.get(id(s.module), 0.0) + (1.0 if s.inverted else -1.0)
+        if self._lu_slot is not None:
+            return self._lu_chain_rule_batched(plan, aff, stacks, Gsum, coef, grads, arena)
         lu_acc: Dict[int, dict] = {}         # id(LUTransform) -> dict(dMinv, dM, db, c) fp64
-        scale_mod = None
         for rec in aff.values():
             blk = rec["blk"]
             prep = pk["affine"][id(blk)]
@@ -362,15 +444,7 @@ class TrainPath:
                 gs = u["gsum"].double()
                 if u["which"] == "Minv":
                     if u["pre_scale"] is not None:
-                        # first layer: a = x / s.  G holds g^T x ("G2"); g^T a = G2 diag(1/s);
-                        # ds_d = -(1/s_d^2) sum_n Minv[n,d] G2[n,d] - Gsum / s_d   (transforms.py:116-144)
-                        scale_mod = u["pre_scale"]
-                        s64 = scale_mod.scale.detach().double()
-                        gsc = self._grad_slot(grads, scale_mod.scale)
-                        if gsc is not None:
-                            ds = -(prep["Minv"] * G).sum(0) / (s64 * s64) - Gsum / s64
-                            gsc.copy_(ds.to(gsc.dtype).reshape(gsc.shape))
-                        G = G / s64[None, :]
+                        G = self._scale_grad(u["pre_scale"], prep["Minv"], G, Gsum, grads)
                     # y = (a - b) Minv^T:  dMinv = g^T a - gsum (x) b ,  db = -Minv^T gsum
                     G = G - torch.outer(gs, prep["b"])
                     dMinv = G if dMinv is None else dMinv + G
@@ -381,6 +455,65 @@ class TrainPath:
                     db = db + gs
             self._to_leaves(blk, prep, dMinv, dM, db, coef.get(id(blk), 0.0) * Gsum, lu_acc, grads, pk)
         self._lu_param_grads(pk, lu_acc, grads)
+
+    def _scale_grad(self, scale_mod, Minv, G2, Gsum, grads):
+        """first layer: a = x / s.  G2 = g^T x; returns g^T a = G2 diag(1/s) and writes
+        ds_d = -(1/s_d^2) sum_n Minv[n,d] G2[n,d] - Gsum / s_d   (transforms.py:116-144)"""
+        s64 = scale_mod.scale.detach().double()
+        gsc = self._grad_slot(grads, scale_mod.scale)
+        if gsc is not None:
+            ds = -(Minv * G2).sum(0) / (s64 * s64) - Gsum / s64
+            gsc.copy_(ds.reshape(gsc.shape))
+        return G2 / s64[None, :]
+
+    def _lu_chain_rule_batched(self, plan, aff, stacks, Gsum, coef, grads, arena):
+        """all affine blocks are single LU factors used once as M^-1 = U^-1 L^-1: one pass over [n, D, D] stacks
+            dU = -triu(U^-T (G M^-T)) + c diag(1/U_jj),   dL = -tril((M^-T G) L^-T, -1),   db = -M^-T gsum
+        with G = g^T a - gsum (x) b per block; four batched launches on the f64 MFMA."""
+        pk = plan["pk"]
+        ch = pk["affine_parts"]["__chunks__"][0]
+        out = ch["out"]
+        n, D = len(ch["lus"]), self.eng.D
+        DD = D * D
+        G = stacks["G"][:n].double()
+        gs = stacks["gs"][:n].double()
+        Minv = out["Minv"]
+        for rec in aff.values():
+            for u in rec["uses"]:
+                if u["pre_scale"] is not None:
+                    G[u["row"]] = self._scale_grad(u["pre_scale"], Minv[u["row"]], G[u["row"]], Gsum, grads)
+        G -= gs[:, :, None] * ch["b"][:, None, :]
+        tmp = stacks.get("T")
+        if tmp is None:
+            tmp = stacks["T"] = torch.empty(3, n, D, D, dtype=torch.float64, device=G.device)
+        T1, dU, dL = tmp[0], tmp[1], tmp[2]
+        bat = dict(batch=n, M=D, N=D, K=D, lda=D, ldb=D, ldc=D, strideC=DD)
+        tinv = out["tri_inv"]                                   # [2n, D, D]: L^-1 at even, (U^-1)^T at odd rows
+        _ext.gemm_f64(G, Minv, T1, transB=True, strideA=DD, strideB=DD, **bat)                    # G M^-T
+        _ext.gemm_f64(tinv, T1, dU, alpha=-1.0, strideA=2 * DD, strideB=DD, a_off=DD, **bat)      # -U^-T (.)
+        _ext.gemm_f64(Minv, G, T1, transA=True, strideA=DD, strideB=DD, **bat)                    # M^-T G
+        _ext.gemm_f64(T1, tinv, dL, transB=True, alpha=-1.0, strideA=DD, strideB=2 * DD, **bat)   # -(.) L^-T
+        c = torch.tensor([coef.get(id(b_), 0.0) for b_ in self._lu_blocks(plan)], dtype=torch.float64,
+                         device=G.device) * Gsum
+        Udiag = out["tri"][1::2].diagonal(dim1=1, dim2=2)                                        # U_jj (of U^T)
+        dU = dU.triu()
+        dU.diagonal(dim1=1, dim2=2).add_(c[:, None] / Udiag)                                     # transforms.py:1303-1320
+        db = -torch.bmm(Minv.transpose(1, 2), gs.unsqueeze(2)).squeeze(2)
+        base, _n = arena["lu_views"][0]
+        flat = arena["flat"]
+        flat[base: base + n * DD].view(n, D, D).copy_(dL.tril(-1))
+        flat[base + n * DD: base + 2 * n * DD].view(n, D, D).copy_(dU)
+        flat[base + 2 * n * DD: base + 2 * n * DD + n * D].view(n, D).copy_(db)
+        for lu in ch["lus"]:
+            for name in ("L_raw", "U_raw", "bias_vector"):
+                if getattr(lu, name).requires_grad:
+                    arena["touched"].add(id(getattr(lu, name)))
+
+    def _lu_blocks(self, plan):
+        """affine blocks in the row order of the batched stacks"""
+        order = sorted(((row, bid) for bid, row in self._lu_slot.items()))
+        by_id = {id(m["blk"]): m["blk"] for m in plan["meta"] if m["kind"] == "affine"}
+        return [by_id[bid] for _row, bid in order]
 
     def _to_leaves(self, blk, prep, dMinv, dM, db, ladj_coef, lu_acc, grads, pk):
         """gradients w.r.t. a block's (M^-1, M, bias) -> its LU factors' accumulators / Householder parameters"""
