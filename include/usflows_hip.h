@@ -264,7 +264,7 @@ int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* 
  *   row ranges whose partial products are summed in a fixed order (bitwise reproducible).  Y / A rows must be 16-byte
  *   aligned (ld % 4 == 0).  workspace: at least usf_wgrad_workspace_floats(M,N,K) floats.
  * usf_colsum_f32: out[n] = alpha * sum_m Y[m,n] + beta * out[n]           -- the bias gradient; workspace
- *   min(512, ceil(M/128)) * N floats.
+ *   (ceil(M/256) + ceil(M/65536) + 2) * N floats (partials of the 256-row levels).
  */
 int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
                   int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);

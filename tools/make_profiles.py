@@ -98,4 +98,31 @@ json.dump({
              "the same run: base_logprob_kernel streams 205.5 MB with 16-B coalesced lane loads (its FETCH_SIZE should read 0.50x of "
              "that). algorithmic_bytes_per_launch: activations in + out once, weights once.",
     "kernels": kern}, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+
+# 4. training step and parameter prep (N1): bench lines + kernel stats of the training run
+lines = []
+for extra in (["--mode", "train", "--batch", "128"], ["--mode", "train", "--batch", "4096"], ["--mode", "train"]):
+    r = run(["python3", "bench.py", "--steps", "10", "--warmup", "3"] + extra)
+    lines.append(last_json_line(r.stdout))
+    for composite_env in ([("USFLOWS_AMD_TRAIN", "composite")] if extra[-1] == "4096" else []):
+        r = subprocess.run(["python3", "bench.py", "--steps", "5", "--warmup", "2"] + extra, cwd=ROOT,
+                           env=dict(env, **dict([composite_env])), capture_output=True, text=True)
+        j = json.loads(last_json_line(r.stdout))
+        j["config"]["training_path"] = "composite torch ops (USFLOWS_AMD_TRAIN=composite)"
+        lines.append(json.dumps(j))
+open(os.path.join(out, f"{tag}_train_bench.jsonl"), "w").write("\n".join(lines) + "\n")
+d = os.path.join(out, "ktrace_train")
+run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--mode",
+     "train", "--steps", "5", "--warmup", "2"])
+stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+rows = list(csv.DictReader(open(stats[0])))
+with open(os.path.join(out, f"{tag}_train_kernel_stats.md"), "w") as f:
+    f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --mode train --steps 5 --warmup 2`\n\n"
+            "One step = Flow.log_prob under autograd (device forward with saved activations) + hand-derived device backward\n"
+            "+ Adam, cfg2 model, 65536 rows; 7 steps in the trace (+ the first, recording, one).\n\n"
+            "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
+    for row in rows[:18]:
+        name = row["Name"]
+        name = name if len(name) < 110 else name[:107] + "..."
+        f.write(f"| `{name}` | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |\n")
 print("wrote", sorted(os.listdir(out)))

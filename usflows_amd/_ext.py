@@ -380,7 +380,7 @@ def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):
-    ws = _workspace(Y.device, 512 * N)
+    ws = _workspace(Y.device, (M // 256 + M // 65536 + 4) * N)
     _launch("usf_colsum_f32", (Y.data_ptr() + 4 * y_off, ldy, M, N, out.data_ptr(), float(alpha), float(beta),
                                ws.data_ptr(), ws.numel(), current_stream(Y.device)), (Y, out, ws))
 

@@ -161,20 +161,28 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
-// part[split][n] = sum over the split's rows of Y[m,n]; block = 64 columns x 4 row lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Y, int64_t ldy, int M, int N,
-                                                     int rows_per_split, float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  const int m_begin = blockIdx.y * rows_per_split;
-  const int m_end = (m_begin + rows_per_split < M) ? m_begin + rows_per_split : M;
+// column sums over a range of 256 rows: block = 64 columns x 16 row lanes (coalesced 256-byte row segments).
+// final == 0: part[split][n] = sum;  final != 0 (single split): out[n] = alpha * sum + beta * out[n]
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ Y, int64_t ldy, int M, int N,
+                                                      float* __restrict__ dst, int final, float alpha, float beta) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int m_begin = blockIdx.y * 256;
+  const int m_end = (m_begin + 256 < M) ? m_begin + 256 : M;
   float s = 0.f;
   if (c < N)
-    for (int m = m_begin + rl; m < m_end; m += 4) s += Y[(int64_t)m * ldy + c];
-  red[rl][threadIdx.x & 63] = s;
+#pragma unroll 4
+    for (int m = m_begin + rl; m < m_end; m += 16) s += Y[(int64_t)m * ldy + c];
+  red[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && c < N) part[(int64_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rl == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    if (final) dst[c] = alpha * t + (beta != 0.f ? beta * dst[c] : 0.f);
+    else dst[(int64_t)blockIdx.y * N + c] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void act_grad_kernel(float* __restrict__ d, int64_t ldd, const float* __restrict__ h,
@@ -259,14 +267,24 @@ int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float 
     set_error("usf_colsum_f32: bad arguments");
     return -1;
   }
-  int64_t splits = (M + 127) / 128;
-  if (splits > 512) splits = 512;
-  if (splits < 1) splits = 1;
-  if (workspace_floats < splits * N) { set_error("usf_colsum_f32: workspace too small"); return -4; }
-  const int rows = (int)((M + splits - 1) / splits);
-  colsum_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)splits), 256, 0, stream>>>(Y, ldy, (int)M, (int)N,
-                                                                                      rows > 0 ? rows : 1, workspace);
-  reduce_partials_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(workspace, (int)splits, 1, N, out, N, alpha, beta);
+  // levels of 256-row ranges: M -> ceil(M/256) partial rows -> ... -> 1 (fixed order: reproducible)
+  const float* src = Y;
+  int64_t rows = M, ld = ldy, used = 0;
+  const unsigned gx = (unsigned)((N + 63) / 64);
+  while (true) {
+    const int64_t splits = rows > 0 ? (rows + 255) / 256 : 1;
+    if (splits == 1) {
+      colsum_kernel<<<dim3(gx, 1), 1024, 0, stream>>>(src, ld, (int)rows, (int)N, out, 1, alpha, beta);
+      break;
+    }
+    if (used + splits * N > workspace_floats) { set_error("usf_colsum_f32: workspace too small"); return -4; }
+    float* part = workspace + used;
+    colsum_kernel<<<dim3(gx, (unsigned)splits), 1024, 0, stream>>>(src, ld, (int)rows, (int)N, part, 0, 1.f, 0.f);
+    used += splits * N;
+    src = part;
+    rows = splits;
+    ld = N;
+  }
   return check_launch("usf_colsum_f32");
 }
 

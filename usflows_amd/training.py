@@ -493,8 +493,10 @@ class TrainPath:
         _ext.gemm_f64(tinv, T1, dU, alpha=-1.0, strideA=2 * DD, strideB=DD, a_off=DD, **bat)      # -U^-T (.)
         _ext.gemm_f64(Minv, G, T1, transA=True, strideA=DD, strideB=DD, **bat)                    # M^-T G
         _ext.gemm_f64(T1, tinv, dL, transB=True, alpha=-1.0, strideA=DD, strideB=2 * DD, **bat)   # -(.) L^-T
-        c = torch.tensor([coef.get(id(b_), 0.0) for b_ in self._lu_blocks(plan)], dtype=torch.float64,
-                         device=G.device) * Gsum
+        if "coef" not in stacks:        # built once: a host-to-device copy here would drain the stream every step
+            stacks["coef"] = torch.tensor([coef.get(id(b_), 0.0) for b_ in self._lu_blocks(plan)],
+                                          dtype=torch.float64, device=G.device)
+        c = stacks["coef"] * Gsum
         Udiag = out["tri"][1::2].diagonal(dim1=1, dim2=2)                                        # U_jj (of U^T)
         dU = dU.triu()
         dU.diagonal(dim1=1, dim2=2).add_(c[:, None] / Udiag)                                     # transforms.py:1303-1320
