@@ -302,6 +302,8 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "base_logprob_grad", _emu_base_logprob_grad)
     monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
     monkeypatch.setattr(FlowEngine, "_check_input", lambda self, x: x.contiguous().float())
+    monkeypatch.setattr(FlowEngine, "_execute_plain",
+                        lambda self, plan, x, out, context: run_plan(self, plan, x, out, context, dtype=torch.float64))
     monkeypatch.setattr(FlowEngine, "_execute",
                         lambda self, plan, x, out, context: run_plan(self, plan, x, out, context, dtype=torch.float64))
 

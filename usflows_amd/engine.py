@@ -203,6 +203,11 @@ class FlowEngine:
         self.gemm_mode = os.environ.get("USFLOWS_AMD_GEMM", "bf16x3")
         # True: the pack also keeps L, U^T, L^-1, U^-T of every LU block (fp64) -- the training backward's operands
         self.keep_factors = False
+        # USFLOWS_AMD_GRAPH=1: batches up to graph_max_rows replay their launch list as one hipGraph.  Off by default:
+        # measured on MI355X / ROCm 7.2 the replay is no faster than the C-side launch loop of usf_run_ops (cfg2,
+        # B = 100: 1.22 ms either way) -- the ~7 us between two dependent dispatches is not host time
+        self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
+        self.graph_max_rows = 1024
         self._layout_from_masks()
 
     # ---- static structure ---------------------------------------------------------------------
@@ -849,6 +854,52 @@ class FlowEngine:
         return plan
 
     def _execute(self, plan, x: torch.Tensor, out: Optional[torch.Tensor], context):
+        """run the plan's launches on torch's current stream; small batches replay them as ONE hipGraph"""
+        if (self.use_graphs and x.shape[0] <= self.graph_max_rows and self.op_timing is None
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._execute_graph(plan, x, out, context)
+        return self._execute_plain(plan, x, out, context)
+
+    def _execute_graph(self, plan, x, out, context):
+        """Launch-bound regime (B <= graph_max_rows: ~130 launches of a few microseconds each): the launch list is
+        captured once into a hipGraph (torch.cuda.CUDAGraph over the C-ABI launches -- they go to the capturing
+        stream) and replayed; the caller's tensors are staged through fixed buffers so the captured pointers stay
+        valid.  An in-place pack refresh (new parameter values, same addresses) keeps the graph valid."""
+        ws = plan["ws"]
+        B = x.shape[0]
+        if "x_static" not in ws:
+            ws["x_static"] = torch.empty(B, self.D, dtype=torch.float32, device=x.device)
+        xs = ws["x_static"]
+        xs.copy_(x)
+        os_ = None
+        if out is not None:
+            if "out_static" not in ws:
+                ws["out_static"] = torch.empty(B, self.D, dtype=torch.float32, device=x.device)
+            os_ = ws["out_static"]
+        if context is not None:
+            c = context.reshape(B).to(torch.float32)
+            ws["ctx4"][:, 0].copy_(c)
+            ws["ctx"].copy_(c)
+        g = plan.get("graph")
+        if g is None:
+            if plan.get("graph_warm", 0) < 1:
+                # first call: plain launches (builds every lazily packed weight image before anything is captured)
+                plan["graph_warm"] = 1
+                self._execute_plain(plan, xs, os_, None)
+            else:
+                torch.cuda.synchronize(x.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._execute_plain(plan, xs, os_, None)
+                plan["graph"] = g
+                g.replay()
+        else:
+            g.replay()
+            self.launch_count += 1
+        if out is not None:
+            out.copy_(os_)
+
+    def _execute_plain(self, plan, x: torch.Tensor, out: Optional[torch.Tensor], context):
         ws = plan["ws"]
         B = x.shape[0]
         dev = x.device

@@ -143,7 +143,7 @@ class TrainPath:
     def _linear(self, pk, A, a_off, lda, W, Cbuf, c_off, ldc, M, N, K, **kw):
         """one usf_linear_f32 launch (bf16x3 planes attached when the engine's mode wants them)"""
         planes = None
-        if (self.eng._wants_planes(W.shape[0], K) and W.shape[1] == K and "residual" not in kw and "addend" not in kw):
+        if self.eng._wants_planes(W.shape[0], K) and W.shape[1] == K:
             planes = self.eng._split_planes(pk, W)
         _ext.linear(A, W, Cbuf, M=M, N=N, K=K, lda=lda, ldw=W.shape[1], ldc=ldc, a_off=a_off, c_off=c_off,
                     W_split=planes, **kw)
