@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--dim", type=int, default=784)
     ap.add_argument("--blocks", type=int, default=32)
     ap.add_argument("--hidden", type=int, nargs="+", default=[256, 256])
+    ap.add_argument("--householder", type=int, default=0, help="Householder vectors per affine block (USFlow ctor default 1)")
+    ap.add_argument("--conj", action="store_true", help="affine_conjugation=True (what the reference's live configs use)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run couplings as 3 linear ops instead of the fused kernel")
@@ -62,7 +64,7 @@ def main():
     from usflows_amd.synth import ModelSpec, synth_state_dict, build_usflow
     from usflows_amd.parallel import mean_log_prob
 
-    spec = ModelSpec(args.dim, args.blocks, list(args.hidden), householder=0, affine_conjugation=False,
+    spec = ModelSpec(args.dim, args.blocks, list(args.hidden), householder=args.householder, affine_conjugation=args.conj,
                         negative_slope=0.01, conditioner="ConditionalDenseNN", base="laplace")
     sd = synth_state_dict(spec, seed=100, alpha=0.1)         # same parameters on every rank
     flow = build_usflow(spec, sd, device=str(dev))
@@ -173,7 +175,7 @@ def main():
     # whole-flow algorithmic FLOP rate (mask-aware count)
     hs = list(args.hidden)
     n_pass = D - D // 2 if False else D // 2
-    flop_per_sample = (args.blocks + 1) * 2.0 * D * D + args.blocks * 2.0 * (
+    flop_per_sample = (args.blocks * (2 if args.conj else 1) + 1) * 2.0 * D * D + args.blocks * 2.0 * (
         (D // 2) * hs[0] + sum(a * b for a, b in zip(hs[:-1], hs[1:])) + hs[-1] * (D - D // 2))
     flow_tflops = flop_per_sample * value / 1e12 / world
 
@@ -225,7 +227,8 @@ def main():
            "dtype": "f32" if eng.gemm_mode == "f32" else "f32 (D x D GEMMs as bf16x3 split on the bf16 MFMA, fp32-equivalent)",
            "data": "synthetic",
            "config": {"workload": f"BASELINE cfg2: USFlow in_dims=[{D}], {args.blocks} additive coupling blocks, "
-                                  f"ConditionalDenseNN{list(args.hidden)}+LeakyReLU(0.01), lu_transform=1, householder=0, "
+                                  f"ConditionalDenseNN{list(args.hidden)}+LeakyReLU(0.01), lu_transform=1, householder={args.householder}, "
+                                  f"affine_conjugation={args.conj}, "
                                   f"Laplace(0,1) base; log_prob of {B} rows per GPU resident in HBM; conditioned "
                                   f"synthetic parameters (seed 100, alpha 0.1)",
                       "rows_per_gpu": B, "global_rows": B * world, "parallelism": f"dp{world} (batch sharded, "

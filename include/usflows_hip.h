@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 4
+#define USF_ABI_VERSION 5
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -262,12 +262,14 @@ int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* 
  * usf_wgrad_f32: G[n,k] = alpha * sum_m Y[m,n] * A[m,k] + beta * G[n,k]   -- the weight gradient of F.linear
  *   (Y = gradient at the layer's output [M,N], A = the layer's input [M,K]); exact-f32 MFMA, the batch is cut into
  *   row ranges whose partial products are summed in a fixed order (bitwise reproducible).  Y / A rows must be 16-byte
- *   aligned (ld % 4 == 0).  workspace: at least usf_wgrad_workspace_floats(M,N,K) floats.
+ *   aligned (ld % 4 == 0).  workspace: at least usf_wgrad_workspace_floats(M,N,K) floats.  mode 0: exact-f32 MFMA;
+ *   mode 1: the bf16x3 split of DESIGN.md 3.1b (fp32-equivalent accuracy on the bf16 matrix cores; used from M >= 2048).
  * usf_colsum_f32: out[n] = alpha * sum_m Y[m,n] + beta * out[n]           -- the bias gradient; workspace
  *   (ceil(M/256) + ceil(M/65536) + 2) * N floats (partials of the 256-row levels).
  */
 int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
-                  int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);
+                  int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
+                  usf_stream_t stream);
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K);
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream);

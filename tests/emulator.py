@@ -243,7 +243,7 @@ def _emu_linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None,
     _view(C_out, c_off, M, N, ldc).copy_(v.to(torch.float32))
 
 
-def _emu_wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0):
+def _emu_wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0):
     y = _view(Y, y_off, M, N, ldy).double()
     a = _view(A, a_off, M, K, lda).double()
     g = _view(G, g_off, N, K, ldg)

@@ -282,3 +282,29 @@ def test_small_batches_replay_a_hip_graph():
         lp = flow.log_prob(xs[0].to(DEV)).cpu().double()
         ref = orc.flow_log_prob(orc.to_dtype(sd2, torch.float64), spec, xs[0].double())
         assert ((lp - ref).abs() / ref.abs()).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("hh,conj", [(0, True), (1, True)])
+def test_cfg2_scale_variants_of_the_live_configs(hh, conj):
+    """the variants every live config of the reference uses (affine_conjugation=True, with and without a
+    Householder factor) at the cfg2 size (D = 784, 32 blocks): log_prob of 64 rows vs the fp64 oracle, round trip and
+    the constant-Jacobian (UDL) property on 4096 rows."""
+    from usflows_amd.synth import ModelSpec, synth_state_dict
+    spec = ModelSpec(784, 32, [256, 256], householder=hh, affine_conjugation=conj, negative_slope=0.01,
+                     conditioner="ConditionalDenseNN", base="laplace")
+    sd = synth_state_dict(spec, seed=100, alpha=0.1)
+    flow = build_flow(spec, sd, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4096, 784, generator=g)
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV))
+        z = flow.backward(x.to(DEV))
+        xr = flow._forward(z)
+    ospec = orc.FlowSpec(784, 32, [256, 256], householder=hh, affine_conjugation=conj)
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), ospec, x[:64].double())
+    assert ((lp[:64].cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5
+    assert (xr.cpu() - x).abs().max().item() < 5e-4
+    # log_prob(x) - base.log_prob(z) is one constant for all samples
+    base = torch.distributions.Laplace(torch.zeros(784), torch.ones(784)).log_prob(z.cpu()).sum(-1)
+    c = (lp.cpu() - base).double()
+    assert (c - c.mean()).abs().max().item() < 1e-5 * abs(c.mean().item()) + 2e-2

@@ -18,9 +18,11 @@ def _ext():
     return _ext
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(1, 4, 4), (17, 20, 36), (256, 128, 128), (1000, 392, 256), (4096, 784, 784),
-                                   (5000, 130, 260), (0, 8, 8)])
-def test_wgrad_matches_fp64(M, N, K):
+                                   (5000, 130, 260), (2048, 392, 256), (0, 8, 8)])
+def test_wgrad_matches_fp64(M, N, K, mode):
+    """mode 1 = bf16x3 split on the bf16 MFMA (taken from M >= 2048): same tolerance as the exact-f32 kernel"""
     ext = _ext()
     g = torch.Generator().manual_seed(M + N + K)
     ldy, lda, ldg = (N + 3) // 4 * 4 + 4, (K + 3) // 4 * 4 + 8, K + 4     # rows of Y / A 16-byte aligned (contract)
@@ -29,7 +31,7 @@ def test_wgrad_matches_fp64(M, N, K):
     G0 = torch.randn(N, ldg, generator=g)
     ref = 0.5 * (Y[:, :N].double().t() @ A[:, :K].double()) - 1.5 * G0[:, :K].double()
     Gd = G0.to(DEV)
-    ext.wgrad(Y.to(DEV), A.to(DEV), Gd, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=ldg, alpha=0.5, beta=-1.5)
+    ext.wgrad(Y.to(DEV), A.to(DEV), Gd, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=ldg, alpha=0.5, beta=-1.5, mode=mode)
     torch.cuda.synchronize()
     got = Gd.cpu()
     tol = 2e-6 * math.sqrt(max(M, 1)) * max(1.0, ref.abs().max().item())

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 4
+USF_ABI_VERSION = 5
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -105,7 +105,7 @@ SYMBOLS = {
     "usf_pack_weight_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int64,
                                       _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_wgrad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
-                                C.c_float, C.c_float, _fp, C.c_int64, C.c_void_p]),
+                                C.c_float, C.c_float, C.c_int32, _fp, C.c_int64, C.c_void_p]),
     "usf_wgrad_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_colsum_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_float, _fp, C.c_int64,
                                  C.c_void_p]),
@@ -369,14 +369,14 @@ def _workspace(device, floats: int) -> torch.Tensor:
     return ws
 
 
-def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0):
+def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0):
     """G[n,k] = alpha * sum_m Y[m,n] A[m,k] + beta * G (element offsets *_off into the fp32 tensors)"""
     lib = load()
     need = lib.usf_wgrad_workspace_floats(M, N, K)
     ws = _workspace(Y.device, need)
     _launch("usf_wgrad_f32", (Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
-                              G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ws.data_ptr(), ws.numel(),
-                              current_stream(Y.device)), (Y, A, G, ws))
+                              G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), int(mode), ws.data_ptr(),
+                              ws.numel(), current_stream(Y.device)), (Y, A, G, ws))
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):

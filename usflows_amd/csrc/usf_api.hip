@@ -43,7 +43,8 @@ int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, 
 
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
-          int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, hipStream_t stream);
+          int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
+          hipStream_t stream);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
 int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
@@ -130,8 +131,9 @@ int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* 
 }
 
 int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
-                  int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
-  return usf::wgrad(Y, ldy, A, lda, M, N, K, G, ldg, alpha, beta, workspace, workspace_floats, (hipStream_t)stream);
+                  int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
+                  usf_stream_t stream) {
+  return usf::wgrad(Y, ldy, A, lda, M, N, K, G, ldg, alpha, beta, mode, workspace, workspace_floats, (hipStream_t)stream);
 }
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K) {
   int64_t out = 0;

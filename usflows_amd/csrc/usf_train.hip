@@ -146,6 +146,136 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 variant of wgrad (mode 1): same tiling, six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product
+// (x = x1 + x2 + x3 in bf16, terms below 2^-16 of the leading one dropped, fp32 accumulation).
+// The reduction index is the batch row, so an MFMA operand fragment is a COLUMN slice of Y / A: lane (i, g)
+// needs rows 8 g .. 8 g + 7 of column i.  The 32-row slab sits row-major in LDS with a row stride of 130 floats
+// (8 rows apart = 16 banks apart: the four lane groups of a ds_read_b32 hit disjoint banks) and every fragment
+// is gathered by 8 ds_read_b32 and split in registers.
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int WB_S = 32;       // batch rows per slab (one MFMA k-extent)
+constexpr int WB_LD = 130;
+
+__device__ __forceinline__ void wb_split(const float (&x)[8], bf16x8_t& p1, bf16x8_t& p2, bf16x8_t& p3) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r = x[j] - (float)h;           // exact
+    const __bf16 m = (__bf16)r;
+    const float r2 = r - (float)m;             // exact
+    p1[j] = h; p2[j] = m; p3[j] = (__bf16)r2;
+  }
+}
+
+__device__ __forceinline__ void wb_load(const float* __restrict__ P, int64_t ld, int m0, int m_end, int c0, int ncols,
+                                        int tid, f32x4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 5) + 8 * i;
+    const int col = c0 + (tid & 31) * 4;
+    const int m = m0 + row;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < m_end) {
+      const float* p = P + (int64_t)m * ld + col;
+      if (col + 3 < ncols) {
+        v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < ncols) v[e] = p[e];
+      }
+    }
+    r[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ys[2][WB_S][WB_LD];
+  __shared__ __attribute__((aligned(16))) float As[2][WB_S][WB_LD];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tilesK = (a.K + WG_T - 1) / WG_T;
+  const int n0 = (blockIdx.x / tilesK) * WG_T, k0 = (blockIdx.x % tilesK) * WG_T;
+  const int split = blockIdx.y;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int rem_n = a.N - (n0 + wn * 64), rem_k = a.K - (k0 + wk * 64);
+  const int ni = rem_n <= 0 ? 0 : (rem_n >= 64 ? 4 : (rem_n + 15) / 16);
+  const int nj = rem_k <= 0 ? 0 : (rem_k >= 64 ? 4 : (rem_k + 15) / 16);
+
+  f32x4 ry[4], ra[4];
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 5) + 8 * i, col = (tid & 31) * 4;
+      *reinterpret_cast<f32x2*>(&Ys[buf][row][col]) = (f32x2){ry[i][0], ry[i][1]};
+      *reinterpret_cast<f32x2*>(&Ys[buf][row][col + 2]) = (f32x2){ry[i][2], ry[i][3]};
+      *reinterpret_cast<f32x2*>(&As[buf][row][col]) = (f32x2){ra[i][0], ra[i][1]};
+      *reinterpret_cast<f32x2*>(&As[buf][row][col + 2]) = (f32x2){ra[i][2], ra[i][3]};
+    }
+  };
+  int buf = 0;
+  if (m_begin < m_end) {
+    wb_load(a.Y, a.ldy, m_begin, m_end, n0, a.N, tid, ry);
+    wb_load(a.A, a.lda, m_begin, m_end, k0, a.K, tid, ra);
+    stage(0);
+  }
+  __syncthreads();
+  for (int m0 = m_begin; m0 < m_end; m0 += WB_S) {
+    const bool more = m0 + WB_S < m_end;
+    if (more) {
+      wb_load(a.Y, a.ldy, m0 + WB_S, m_end, n0, a.N, tid, ry);
+      wb_load(a.A, a.lda, m0 + WB_S, m_end, k0, a.K, tid, ra);
+    }
+    // operand planes of this slab: 4 feature sub-tiles of Y, 4 of A (lane (i, g): rows 8 g .. 8 g + 7 of column i)
+    bf16x8_t yp[4][3], ap[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float fy[8], fa[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fy[e] = Ys[buf][8 * lg + e][wn * 64 + t * 16 + li];
+        fa[e] = As[buf][8 * lg + e][wk * 64 + t * 16 + li];
+      }
+      wb_split(fy, yp[t][0], yp[t][1], yp[t][2]);
+      wb_split(fa, ap[t][0], ap[t][1], ap[t][2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i < ni && j < nj) {
+#define USF_WB(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][P], ap[j][Q], acc[i][j], 0, 0, 0)
+          USF_WB(2, 0); USF_WB(1, 1); USF_WB(0, 2); USF_WB(1, 0); USF_WB(0, 1); USF_WB(0, 0);   // smallest terms first
+#undef USF_WB
+        }
+    if (more) stage(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = a.part + (int64_t)split * a.N * a.K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (n < a.N && k < a.K) out[(int64_t)n * a.K + k] = acc[i][j][r];
+      }
+}
+
 // out[r*ldo + c] = alpha * sum_s part[s][r][c] + beta * out[...]   (rows x cols elements per partial)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t rows,
                                                               int64_t cols, float* __restrict__ out, int64_t ldo,
@@ -234,7 +364,8 @@ int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out) {
 }
 
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
-          int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, hipStream_t stream) {
+          int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
+          hipStream_t stream) {
   if (((!Y || !A) && M > 0) || !G || !workspace || M < 0 || N <= 0 || K <= 0 || ldg < K || ldy < N || lda < K) {
     set_error("usf_wgrad_f32: bad arguments");
     return -1;
@@ -252,9 +383,12 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
     return -4;
   }
   int rows = (int)((M + splits - 1) / splits);
-  rows = (rows + WG_S - 1) / WG_S * WG_S;
-  WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WG_S};
-  wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
+  rows = (rows + WB_S - 1) / WB_S * WB_S;
+  WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S};
+  if (mode != 0 && mode != 1) { set_error("usf_wgrad_f32: mode must be 0 (exact f32) or 1 (bf16x3)"); return -2; }
+  // the split-precision kernel pays off once the chip has real work (its operand split costs VALU per slab)
+  if (mode == 1 && M >= 2048) wgrad_bf16x3_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
+  else wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
   int64_t rb = (N * K + 255) / 256;
   if (rb > 4096) rb = 4096;
   reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta);

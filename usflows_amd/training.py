@@ -226,6 +226,7 @@ class TrainPath:
         stacks = dict(G=torch.zeros(max(n_aff, 1), D, D, dtype=torch.float32, device=dev),
                       gs=torch.zeros(max(n_aff, 1), D, dtype=torch.float32, device=dev), next=0)
         self._lu_slot = self._lu_slots(plan)
+        self._wmode = 1 if eng.gemm_mode == "bf16x3" else 0      # weight gradients on the same arithmetic as the GEMMs
         first_meta = plan["meta"][0] if plan["meta"] else None
         for m in reversed(plan["meta"]):
             if m["kind"] == "affine":
@@ -272,9 +273,10 @@ class TrainPath:
         if m["in_buf"] == "user_in":
             # the caller's tensor changes from call to call: issued through the wrapper on every replay
             _ext.host_op(lambda g=g_cur, ld=g_ld: _ext.wgrad(g, self._cur["x"], Gp, M=B, N=n_out, K=n_in, ldy=ld,
-                                                            lda=self._cur["x"].shape[1], ldg=Gp.shape[1]))
+                                                            lda=self._cur["x"].shape[1], ldg=Gp.shape[1], mode=self._wmode))
         else:
-            _ext.wgrad(g_cur, ws[m["in_buf"]], Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=m["in_ld"], ldg=Gp.shape[1])
+            _ext.wgrad(g_cur, ws[m["in_buf"]], Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=m["in_ld"], ldg=Gp.shape[1],
+                       mode=self._wmode)
         gs = self._buf(ws, "gs", 1, wid)
         _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
         D = eng.D
@@ -329,7 +331,7 @@ class TrainPath:
         W_out = un["W_out"]                                   # [tr_n, hp_last]
         gW = self._buf(ws, "gWc", max(hmax, LD), max(hmax, LD))
         _ext.wgrad(g_cur, hbufs[-1], gW, M=B, N=tr_n, K=hp[-1], ldy=g_ld, lda=hmax, ldg=gW.shape[1], y_off=tr_off,
-                   alpha=sign)
+                   alpha=sign, mode=self._wmode)
         self._scatter_weight(grads, last_l.weight, gW, rows_sel=self._sel_inv(raw["tr_idx"], dev), n_rows=eng.D,
                              cols_sel=None, n_cols=h[-1])
         gb = self._buf(ws, "gbc", 1, max(hmax, LD))
@@ -345,7 +347,8 @@ class TrainPath:
         for j in range(nl - 1, 0, -1):
             W, _b = un["layers"][j]                           # [hp_j, hp_{j-1}]
             l = hidden_l[j - 1]
-            _ext.wgrad(d, hbufs[j - 1], gW, M=B, N=hp[j], K=hp[j - 1], ldy=hmax, lda=hmax, ldg=gW.shape[1], alpha=sign)
+            _ext.wgrad(d, hbufs[j - 1], gW, M=B, N=hp[j], K=hp[j - 1], ldy=hmax, lda=hmax, ldg=gW.shape[1], alpha=sign,
+                       mode=self._wmode)
             self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
             self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
             d_next = d_bufs[1] if d is d_bufs[0] else d_bufs[0]
@@ -355,7 +358,8 @@ class TrainPath:
         # 4. input layer
         W_in, _b = un["layers"][0]                            # [hp0, pass_n]
         pass_n, pass_off = cp["pass_n"], cp["pass_off"]
-        _ext.wgrad(d, zbuf, gW, M=B, N=hp[0], K=pass_n, ldy=hmax, lda=LD, ldg=gW.shape[1], a_off=pass_off, alpha=sign)
+        _ext.wgrad(d, zbuf, gW, M=B, N=hp[0], K=pass_n, ldy=hmax, lda=LD, ldg=gW.shape[1], a_off=pass_off, alpha=sign,
+                   mode=self._wmode)
         self._scatter_weight(grads, first_l.weight, gW, None, h[0], self._sel_inv(raw["pass_idx"], dev), eng.D)
         self._colsum_to(grads, first_l.bias, d, B, h[0], hmax, sign)
         if has_ctx:
