@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 5
+#define USF_ABI_VERSION 6
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -225,9 +225,12 @@ typedef struct usf_lu_prep_desc {
 int usf_lu_prepare_f64(const usf_lu_prep_desc* d, usf_stream_t stream);
 
 /* Batched fp64 GEMM on the f64 MFMA: C[b] = alpha * op(A[b]) op(B[b]) + beta * C[b], row-major, op = identity or
- * transpose (transX != 0: X is stored [K,M] resp. [N,K]); A[b] = A + b*strideA etc.  tri: 0 = full K range,
- * 1 = op(A) lower- and op(B) upper-triangular (k <= min(i,j)), 2 = op(A) upper- and op(B) lower-triangular
- * (k >= max(i,j)) -- a work-saving hint, the skipped products must be exact zeros.
+ * transpose (transX != 0: X is stored [K,M] resp. [N,K]); A[b] = A + b*strideA etc.  tri, low 3 bits = k-range hint
+ * (the skipped products must be exact zeros): 0 = full K, 1 = op(A) lower- and op(B) upper-triangular (k <= min(i,j)),
+ * 2 = op(A) upper- and op(B) lower-triangular (k >= max(i,j)), 3 = op(A) lower-triangular (k <= i), 4 = op(B)
+ * upper-triangular (k <= j); + 8: only the 64x64 output tiles that touch the upper triangle (diagonal included) are
+ * computed, + 16: only those that touch the lower triangle -- the other tiles of C are left untouched (for results
+ * whose other triangle is discarded, e.g. the triu / tril of the LU gradients).
  * SequentialAffineTransform.matrix / .inverse_matrix (transforms.py:1457-1469) and the matrix gradients of the
  * training path are chains of these. */
 int usf_gemm_f64(const double* A, int64_t lda, int64_t strideA, int32_t transA, const double* B, int64_t ldb,
@@ -247,6 +250,21 @@ int usf_householder_f64(const float* w_0, const float* vk, int64_t nvs, int64_t 
 int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int32_t transpose, const int32_t* out_idx, int64_t n_out,
                         const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ld_planes,
                         int64_t plane_stride, usf_stream_t stream);
+
+/* The same for many images in ONE launch: `jobs` is a DEVICE array of n_jobs descriptors (the arguments of
+ * usf_pack_weight_f32); max_rows / max_cols bound n_out and the written columns over all jobs.  A parameter update
+ * refreshes hundreds of small images; batched, that is one dispatch instead of hundreds of dependent ones. */
+typedef struct usf_pack_job {
+  const void* src;
+  const int32_t* out_idx;
+  const int32_t* in_idx;
+  float* W;
+  void* planes;
+  int64_t ld_src, n_out, n_in, ldw, ld_planes, plane_stride;
+  int32_t src_is_f32, transpose;
+} usf_pack_job;
+int usf_pack_weights_f32(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols,
+                         usf_stream_t stream);
 
 /* out[o] = alpha * sum_k src[idx[o], k] * b[k] (0 where idx[o] < 0; idx NULL = identity), fp64 accumulation; out32 and/or
  * out64 receive the result.  Bias folding c = -(Minv b) and SequentialAffineTransform.bias (transforms.py:1471-1476). */
@@ -285,7 +303,7 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
                               const float* loc, const float* scale, float* g, int64_t ldg, usf_stream_t stream);
 
 int usf_abi_version(void);
-int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc) for kind 1|2|0|3: binding self-check */
+int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4: binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */
 

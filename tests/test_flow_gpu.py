@@ -282,6 +282,11 @@ def test_small_batches_replay_a_hip_graph():
         lp = flow.log_prob(xs[0].to(DEV)).cpu().double()
         ref = orc.flow_log_prob(orc.to_dtype(sd2, torch.float64), spec, xs[0].double())
         assert ((lp - ref).abs() / ref.abs()).max().item() < 1e-5
+        # the sampling direction reads the refreshed M / bias / scale images too
+        zin = torch.randn(100, 64, generator=g)
+        xf = flow._forward(zin.to(DEV)).cpu().double()
+        xref = orc.flow_forward(orc.to_dtype(sd2, torch.float64), spec, zin.double())
+        assert (xf - xref).abs().max().item() < 2e-5 * max(1.0, xref.abs().max().item())
 
 
 @pytest.mark.parametrize("hh,conj", [(0, True), (1, True)])

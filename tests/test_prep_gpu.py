@@ -97,6 +97,28 @@ def test_gemm_f64_triangular_hints(D):
     assert torch.equal(ext.matmul_f64(Up.to(DEV), Lo.to(DEV), tri=2), ext.matmul_f64(Up.to(DEV), Lo.to(DEV)))
 
 
+@pytest.mark.parametrize("D", [70, 200])
+def test_gemm_f64_one_sided_hints_and_output_masks(D):
+    """k <= i (3) / k <= j (4) hints, and the masks that compute only the tiles touching one triangle (+8 upper,
+    +16 lower; the other tiles of C are left untouched): what the batched LU chain rule of training.py uses"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(D)
+    X = torch.randn(D, D, generator=g, dtype=torch.float64)
+    Lo = torch.randn(D, D, generator=g, dtype=torch.float64).tril()
+    full = lambda A, B, **kw: ext.matmul_f64(A.to(DEV), B.to(DEV), **kw).cpu()
+    assert torch.equal(full(Lo, X, tri=3), full(Lo, X))                      # op(A) lower-triangular
+    assert torch.equal(full(X, Lo.t().contiguous(), tri=4), full(X, Lo.t().contiguous()))   # op(B) upper-triangular
+    for mask, keep in ((8, torch.triu), (16, torch.tril)):
+        C = torch.full((D, D), 7.0, dtype=torch.float64, device=DEV)
+        ext.gemm_f64(X.to(DEV), X.to(DEV), C, M=D, N=D, K=D, lda=D, ldb=D, ldc=D, tri=mask)
+        ref = X @ X
+        got = C.cpu()
+        assert (keep(got) - keep(ref)).abs().max().item() <= 1e-11 * D         # the wanted triangle is complete
+        r, c = torch.meshgrid(torch.arange(D), torch.arange(D), indexing="ij")
+        far = (r // 64 > c // 64) if mask == 8 else (c // 64 > r // 64)        # tiles strictly on the other side
+        assert (got[far] == 7.0).all()
+
+
 @pytest.mark.parametrize("D,nvs", [(7, 1), (64, 2), (100, 3), (784, 2)])
 def test_householder_matches_oracle(D, nvs):
     ext = _ext()

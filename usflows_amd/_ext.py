@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 5
+USF_ABI_VERSION = 6
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -78,6 +78,15 @@ class LuPrepDesc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    _fields_ = [
+        ("src", _fp), ("out_idx", _fp), ("in_idx", _fp), ("W", _fp), ("planes", _fp),
+        ("ld_src", C.c_int64), ("n_out", C.c_int64), ("n_in", C.c_int64), ("ldw", C.c_int64),
+        ("ld_planes", C.c_int64), ("plane_stride", C.c_int64),
+        ("src_is_f32", C.c_int32), ("transpose", C.c_int32),
+    ]
+
+
 # every symbol include/usflows_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "usf_abi_version": (C.c_int, []),
@@ -113,6 +122,7 @@ SYMBOLS = {
                                    C.c_void_p]),
     "usf_base_logprob_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp,
                                             C.c_int64, C.c_void_p]),
+    "usf_pack_weights_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_matvec_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_double, _fp, _fp, C.c_void_p]),
 }
 
@@ -140,7 +150,7 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.usf_abi_version() != USF_ABI_VERSION:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
-    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc)):
+    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -334,15 +344,65 @@ def householder(w_0, vk):
     return out
 
 
+_jobs: list = []         # stack of open job batches (lists), innermost receives
+
+
+class batch_jobs:
+    """Defer the usf_pack_weight_f32 calls made inside the block and issue them as ONE usf_pack_weights_f32 launch
+    per size class at exit (or at an explicit ``flush``).  Only for calls whose sources are ready when the batch is
+    flushed and whose outputs nobody reads before that."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+
+    def __enter__(self):
+        _jobs.append(self)
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        _jobs.pop()
+        if exc_type is None:
+            self.flush()
+        return False
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        # two size classes: matrices and single rows (vectors) -- keeps the grid of empty blocks small
+        for cls in (True, False):
+            part = [j for j in jobs if (j[0].n_out > 1) == cls]
+            if not part:
+                continue
+            arr = (PackJob * len(part))(*[j[0] for j in part])
+            table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            max_rows = max(j[0].n_out for j in part)
+            max_cols = max(max(j[0].n_in, j[0].ld_planes if j[0].planes else 0) for j in part)
+            _launch("usf_pack_weights_f32", (table.data_ptr(), len(part), max_rows, max_cols,
+                                             current_stream(self.device)), (table, [j[1] for j in part]))
+
+
+def flush_jobs() -> None:
+    """issue what the innermost open batch has queued so far (a later job is about to read an earlier one's output)"""
+    if _jobs:
+        _jobs[-1].flush()
+
+
 def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
     """usf_pack_weight_f32: src fp64/fp32 2-D (or 1-D = one row) device tensor; W [n_out, ldw] fp32 and/or planes
-    [3, n_out, ldp] bf16 (preallocated)."""
+    [3, n_out, ldp] bf16 (preallocated).  Inside a ``batch_jobs`` block the call is queued, not launched."""
     if src.dtype not in (torch.float32, torch.float64):
         raise ValueError("pack_weight: source must be fp32 or fp64")
     if ld_src is None:
         ld_src = src.shape[-1]
     ldp = planes.shape[2] if planes is not None else 0
     ps = planes.shape[1] * planes.shape[2] if planes is not None else 0
+    if _jobs and n_out > 0 and n_in > 0:
+        j = PackJob(src.data_ptr(), ptr(out_idx), ptr(in_idx), ptr(W), ptr(planes), ld_src, n_out, n_in, ldw, ldp, ps,
+                    int(src.dtype == torch.float32), int(transpose))
+        _jobs[-1].jobs.append((j, (src, out_idx, in_idx, W, planes)))
+        return
     _launch("usf_pack_weight_f32", (src.data_ptr(), int(src.dtype == torch.float32), ld_src, int(transpose),
                                     ptr(out_idx), n_out, ptr(in_idx), n_in, ptr(W), ldw, ptr(planes), ldp, ps,
                                     current_stream(src.device)), (src, out_idx, in_idx, W, planes))

@@ -38,6 +38,7 @@ int householder(const float* w0, const float* vk, int64_t nvs, int64_t D, double
 int pack_weight(const void* src, int32_t src_is_f32, int64_t lds_, int32_t transpose, const int32_t* out_idx, int64_t n_out,
                 const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ldp,
                 int64_t plane_stride, hipStream_t stream);
+int pack_jobs(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols, hipStream_t stream);
 int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
                 double alpha, float* out32, double* out64, hipStream_t stream);
 
@@ -63,6 +64,7 @@ int usf_sizeof_desc(int32_t kind) {
     case USF_OP_COUPLING: return (int)sizeof(usf_coupling_desc);
     case 0: return (int)sizeof(usf_op);
     case 3: return (int)sizeof(usf_lu_prep_desc);
+    case 4: return (int)sizeof(usf_pack_job);
     default: return -1;
   }
 }
@@ -123,6 +125,11 @@ int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int
                         int64_t plane_stride, usf_stream_t stream) {
   return usf::pack_weight(src, src_is_f32, ld_src, transpose, out_idx, n_out, in_idx, n_in, W, ldw, planes, ld_planes, plane_stride,
                           (hipStream_t)stream);
+}
+
+int usf_pack_weights_f32(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols,
+                         usf_stream_t stream) {
+  return usf::pack_jobs(jobs, n_jobs, max_rows, max_cols, (hipStream_t)stream);
 }
 
 int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* idx, int64_t n_out, const double* b,

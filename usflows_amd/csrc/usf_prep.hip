@@ -218,7 +218,8 @@ struct GemmArgs {
   const double* B; int64_t ldb, sB;
   double* C; int64_t ldc, sC;
   int M, N, K;
-  int tri;            // 0 full K; 1: k < min(r,c)+1 (lower x upper); 2: k >= max(r,c) (upper x lower)
+  int tri;            // low 3 bits: k-range hint (0 full; 1: k <= min(i,j); 2: k >= max(i,j); 3: k <= i; 4: k <= j);
+                      // bits 3-4: output mask (1: only tiles touching the upper triangle, 2: ... the lower triangle)
   double alpha, beta;
 };
 
@@ -226,9 +227,14 @@ struct GemmArgs {
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int kmode = g.tri & 7, omask = g.tri >> 3;
+  if (omask == 1 && r0 >= c0 + 64) return;       // tile strictly below the diagonal: not wanted, left untouched
+  if (omask == 2 && c0 >= r0 + 64) return;       // ... strictly above
   int kLo = 0, kHi = g.K;
-  if (g.tri == 1) kHi = (r0 < c0 ? r0 : c0) + 64;
-  if (g.tri == 2) kLo = (r0 > c0 ? r0 : c0);
+  if (kmode == 1) kHi = (r0 < c0 ? r0 : c0) + 64;
+  if (kmode == 2) kLo = (r0 > c0 ? r0 : c0);
+  if (kmode == 3) kHi = r0 + 64;
+  if (kmode == 4) kHi = c0 + 64;
   const int64_t b = blockIdx.z;
   gemm_tile_f64<TA, TB>(g.A + b * g.sA, g.lda, g.B + b * g.sB, g.ldb, g.C + b * g.sC, g.ldc, g.M, g.N, g.K, r0, c0,
                         kLo, kHi, g.alpha, g.beta);
@@ -323,6 +329,44 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const S* __restrict__ 
   }
 }
 
+// many pack jobs in ONE launch (grid z = job): a training step refreshes ~600 weight images, and what that costs
+// on the device is not their bytes but 600 dependent dispatches (~7.5 us each)
+template <typename S>
+__device__ __forceinline__ void pack_job_body(const usf_pack_job& j, int64_t o, int64_t c) {
+  const S* src = reinterpret_cast<const S*>(j.src);
+  const int32_t so = j.out_idx ? j.out_idx[o] : (int32_t)o;
+  float w = 0.0f;
+  if (c < j.n_in) {
+    const int32_t si = j.in_idx ? j.in_idx[c] : (int32_t)c;
+    if (so >= 0 && si >= 0) w = (float)(j.transpose ? src[(int64_t)si * j.ld_src + so] : src[(int64_t)so * j.ld_src + si]);
+    if (j.W) j.W[o * j.ldw + c] = w;
+  }
+  if (j.planes && c < j.ld_planes) {
+    uint16_t* planes = reinterpret_cast<uint16_t*>(j.planes);
+    const uint16_t hi = bf16_rne(w);
+    const float r = w - bf16_to_f32(hi);
+    const uint16_t mid = bf16_rne(r);
+    const uint16_t lo = bf16_rne(r - bf16_to_f32(mid));
+    planes[o * j.ld_planes + c] = hi;
+    planes[j.plane_stride + o * j.ld_planes + c] = mid;
+    planes[2 * j.plane_stride + o * j.ld_planes + c] = lo;
+  }
+}
+
+constexpr int PJ_ROWS = 8;     // rows per block: keeps the grid of (mostly empty) blocks of a mixed-size batch small
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const usf_pack_job* __restrict__ jobs) {
+  const usf_pack_job j = jobs[blockIdx.z];
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t cols = j.planes ? j.ld_planes : j.n_in;
+  if ((int64_t)blockIdx.y * PJ_ROWS >= j.n_out || (int64_t)blockIdx.x * 256 >= cols) return;
+  for (int r = 0; r < PJ_ROWS; ++r) {
+    const int64_t o = (int64_t)blockIdx.y * PJ_ROWS + r;
+    if (o >= j.n_out) break;
+    if (j.src_is_f32) pack_job_body<float>(j, o, c);
+    else pack_job_body<double>(j, o, c);
+  }
+}
+
 // c[o] = alpha * sum_k src[idx[o], k] * b[k]  (0 where idx[o] < 0); one wave per output
 __global__ __launch_bounds__(64) void matvec_rows_kernel(const double* __restrict__ src, int64_t lds_, int64_t K,
                                                          const int32_t* __restrict__ idx, const double* __restrict__ b,
@@ -357,7 +401,7 @@ static int launch_gemm(const GemmArgs& g, int transA, int transB, int64_t batch,
 int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
              double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
              double beta, int32_t tri, hipStream_t stream) {
-  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0 || tri < 0 || tri > 2) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0 || batch < 0 || tri < 0 || (tri & 7) > 4 || (tri >> 3) > 2) {
     set_error("usf_gemm_f64: bad arguments");
     return -1;
   }
@@ -456,6 +500,17 @@ int pack_weight(const void* src, int32_t src_is_f32, int64_t lds_, int32_t trans
     pack_weight_kernel<double><<<grid, 256, 0, stream>>>((const double*)src, lds_, transpose, out_idx, in_idx, n_in, W,
                                                          ldw, (uint16_t*)planes, ldp, plane_stride);
   return check_launch("usf_pack_weight_f32");
+}
+
+int pack_jobs(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols, hipStream_t stream) {
+  if (n_jobs < 0 || max_rows < 0 || max_cols < 0 || (n_jobs > 0 && !jobs) || n_jobs > 65535 || max_rows > 65535) {
+    set_error("usf_pack_weights_f32: bad arguments");
+    return -1;
+  }
+  if (n_jobs == 0 || max_rows == 0 || max_cols == 0) return 0;
+  pack_jobs_kernel<<<dim3((unsigned)((max_cols + 255) / 256), (unsigned)((max_rows + PJ_ROWS - 1) / PJ_ROWS),
+                          (unsigned)n_jobs), 256, 0, stream>>>(jobs);
+  return check_launch("usf_pack_weights_f32");
 }
 
 int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, int64_t n_out, const double* b,

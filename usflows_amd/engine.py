@@ -441,16 +441,26 @@ class FlowEngine:
         dev, h, hp = raw["device"], raw["h"], cp["hidden"]
         pass_sel = self._sel(raw["pass_idx"], cp["pass_n"], dev)
         layers = []
+        mats = self._pack["mats"]
+
+        def image(src, out_sel, n_out, in_sel, n_in):
+            """fp32 image + (when the linear kernel will take the bf16x3 path for it) its planes, both from `src`"""
+            pl = _round_up(n_in, 32) if self._wants_planes(n_out, n_in) else 0
+            Wp, P = self._packed(src, out_sel, n_out, in_sel, n_in, planes_ld=pl)
+            if P is not None:
+                mats[("planes", Wp.data_ptr())] = P
+            mats[("imgsrc", Wp.data_ptr())] = (src, out_sel, n_out, in_sel, n_in)      # for the transposed image
+            return Wp
+
         W, b = raw["first"]
-        Wp, _ = self._packed(W, self._iarange(h[0], hp[0], dev), hp[0], pass_sel, cp["pass_n"])
+        Wp = image(W, self._iarange(h[0], hp[0], dev), hp[0], pass_sel, cp["pass_n"])
         layers.append((Wp, self._packed_vec(b, self._iarange(h[0], hp[0], dev), hp[0])))
         for j, (W, b) in enumerate(raw["hidden"]):
-            Wp, _ = self._packed(W, self._iarange(h[j + 1], hp[j + 1], dev), hp[j + 1],
-                                 self._iarange(h[j], hp[j], dev), hp[j])
+            Wp = image(W, self._iarange(h[j + 1], hp[j + 1], dev), hp[j + 1], self._iarange(h[j], hp[j], dev), hp[j])
             layers.append((Wp, self._packed_vec(b, self._iarange(h[j + 1], hp[j + 1], dev), hp[j + 1])))
         W, b = raw["last"]
         tr_sel = self._sel(raw["tr_idx"], cp["tr_n"], dev)
-        W_out, _ = self._packed(W, tr_sel, cp["tr_n"], self._iarange(h[-1], hp[-1], dev), hp[-1])
+        W_out = image(W, tr_sel, cp["tr_n"], self._iarange(h[-1], hp[-1], dev), hp[-1])
         u = dict(layers=layers, W_out=W_out, b_out=self._packed_vec(b, tr_sel, cp["tr_n"]))
         if cp["has_ctx"]:
             Wc, bc = raw["ctx"]
@@ -517,6 +527,7 @@ class FlowEngine:
             N, K = W.shape
             planes = torch.empty(3, N, _round_up(K, 32), dtype=torch.bfloat16, device=W.device)
             with _ext.record(pk["tape"] if pk.get("replayable") else None):
+                _ext.flush_jobs()              # W itself may be the output of a queued job
                 _ext.pack_weight(W, None, N, None, K, planes=planes)
             pk["mats"][key] = planes
         return pk["mats"][key]
@@ -569,6 +580,13 @@ class FlowEngine:
         return prims
 
     def _build_plan(self, direction: str, B: int, device, has_ctx: bool, final: str, train: bool = False) -> dict:
+        # every weight image the plan needs is queued while the op list is laid out and packed by ONE batched launch
+        # per size class at the end (nothing reads them before the plan runs); the launch joins the pack's tape
+        pk = self.pack(device)
+        with self._pk_record(pk), _ext.batch_jobs(device):
+            return self._build_plan_body(direction, B, device, has_ctx, final, train)
+
+    def _build_plan_body(self, direction: str, B: int, device, has_ctx: bool, final: str, train: bool = False) -> dict:
         """final: 'user' (last op writes the caller's [B,D] tensor) or 'nat' (workspace buffer, for the tail).
 
         Returns the ctypes op array plus the few launches that are not usf_run_ops ops

@@ -228,13 +228,39 @@ class TrainPath:
         self._lu_slot = self._lu_slots(plan)
         self._wmode = 1 if eng.gemm_mode == "bf16x3" else 0      # weight gradients on the same arithmetic as the GEMMs
         first_meta = plan["meta"][0] if plan["meta"] else None
-        for m in reversed(plan["meta"]):
-            if m["kind"] == "affine":
-                g_cur, g_other, g_ld = self._affine_backward(plan, m, g_cur, g_other, g_ld, aff, stacks,
-                                                             need_dgrad=(m is not first_meta))
-            else:
-                self._coupling_backward(plan, m, g_cur, g_ld, grads)
+        self._prepare_images(plan, first_meta)
+        # gradient images -> parameter layout (scatter / un-permute): every layer has image buffers of its own, so all
+        # of these copies wait in one batch and go out as one launch per size class behind the last layer
+        with _ext.batch_jobs(dev):
+            for m in reversed(plan["meta"]):
+                if m["kind"] == "affine":
+                    g_cur, g_other, g_ld = self._affine_backward(plan, m, g_cur, g_other, g_ld, aff, stacks,
+                                                                 need_dgrad=(m is not first_meta))
+                else:
+                    self._coupling_backward(plan, m, g_cur, g_ld, grads)
         _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
+
+    def _prepare_images(self, plan, first_meta):
+        """every weight image the backward reads (unfused conditioner layers, transposed images of the data-gradient
+        GEMMs), built up front in two batched launches that join the pack's tape"""
+        eng = self.eng
+        pk = plan["pk"]
+        dev = plan["ws"]["zA"].device
+        with eng._pk_record(pk):
+            with _ext.batch_jobs(dev):
+                for m in plan["meta"]:
+                    if m["kind"] == "coupling":
+                        eng._unfused_pack(pk, pk["coupling"][m["step"]])
+            with _ext.batch_jobs(dev):
+                for m in plan["meta"]:
+                    if m["kind"] == "coupling":
+                        un = eng._unfused_pack(pk, pk["coupling"][m["step"]])
+                        for W, _b in un["layers"]:
+                            self._transposed(pk, W)
+                        self._transposed(pk, un["W_out"])
+                    elif m is not first_meta:
+                        which = "Minv" if m["prim"] == "affine_bwd" else "M"
+                        self._mat_t(pk, m["blk"], which, m["out_layout"], m["in_layout"])
 
     def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
         """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every
@@ -269,7 +295,7 @@ class TrainPath:
         n_out, n_in = int(oi.numel()), int(ii.numel())
         # weight gradient in the image layout, then back to the natural [D, D] layout of the block's matrix
         wid = max(eng.LD, eng.LDn)
-        Gp = self._buf(ws, "Gp", wid, wid)
+        Gp = self._buf(ws, f"Gp{m['op']}", wid, wid)           # own image per layer: its un-permute job runs later
         if m["in_buf"] == "user_in":
             # the caller's tensor changes from call to call: issued through the wrapper on every replay
             _ext.host_op(lambda g=g_cur, ld=g_ld: _ext.wgrad(g, self._cur["x"], Gp, M=B, N=n_out, K=n_in, ldy=ld,
@@ -277,7 +303,7 @@ class TrainPath:
         else:
             _ext.wgrad(g_cur, ws[m["in_buf"]], Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=m["in_ld"], ldg=Gp.shape[1],
                        mode=self._wmode)
-        gs = self._buf(ws, "gs", 1, wid)
+        gs = self._buf(ws, f"gs{m['op']}", 1, wid)
         _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
         D = eng.D
         k = self._lu_slot[id(blk)] if self._lu_slot is not None else stacks["next"]
@@ -329,12 +355,13 @@ class TrainPath:
         # 2. output layer: d_out = gradient at the transformed half (unchanged by the layer: out_T = z_T + s MLP)
         tr_n, tr_off = cp["tr_n"], cp["tr_off"]
         W_out = un["W_out"]                                   # [tr_n, hp_last]
-        gW = self._buf(ws, "gWc", max(hmax, LD), max(hmax, LD))
+        gimg = lambda tag: self._buf(ws, f"gW{m['step']}_{tag}", max(hmax, LD), max(hmax, LD))
+        gW = gimg("out")
         _ext.wgrad(g_cur, hbufs[-1], gW, M=B, N=tr_n, K=hp[-1], ldy=g_ld, lda=hmax, ldg=gW.shape[1], y_off=tr_off,
                    alpha=sign, mode=self._wmode)
         self._scatter_weight(grads, last_l.weight, gW, rows_sel=self._sel_inv(raw["tr_idx"], dev), n_rows=eng.D,
                              cols_sel=None, n_cols=h[-1])
-        gb = self._buf(ws, "gbc", 1, max(hmax, LD))
+        gb = self._buf(ws, f"gb{m['step']}", 1, max(hmax, LD))
         _ext.colsum(g_cur, gb, M=B, N=tr_n, ldy=g_ld, y_off=tr_off, alpha=sign)
         self._scatter_vec(grads, last_l.bias, gb, self._sel_inv(raw["tr_idx"], dev), eng.D)
         # d_h = d_out W_out  (sign is applied where the result leaves the MLP)
@@ -347,6 +374,7 @@ class TrainPath:
         for j in range(nl - 1, 0, -1):
             W, _b = un["layers"][j]                           # [hp_j, hp_{j-1}]
             l = hidden_l[j - 1]
+            gW = gimg(f"h{j}")
             _ext.wgrad(d, hbufs[j - 1], gW, M=B, N=hp[j], K=hp[j - 1], ldy=hmax, lda=hmax, ldg=gW.shape[1], alpha=sign,
                        mode=self._wmode)
             self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
@@ -358,6 +386,7 @@ class TrainPath:
         # 4. input layer
         W_in, _b = un["layers"][0]                            # [hp0, pass_n]
         pass_n, pass_off = cp["pass_n"], cp["pass_off"]
+        gW = gimg("in")
         _ext.wgrad(d, zbuf, gW, M=B, N=hp[0], K=pass_n, ldy=hmax, lda=LD, ldg=gW.shape[1], a_off=pass_off, alpha=sign,
                    mode=self._wmode)
         self._scatter_weight(grads, first_l.weight, gW, None, h[0], self._sel_inv(raw["pass_idx"], dev), eng.D)
@@ -365,6 +394,7 @@ class TrainPath:
         if has_ctx:
             ctx_l = lin[1]
             if m["use_ctx"]:
+                gW = gimg("ctx")
                 _ext.wgrad(d, ws["ctx4"], gW, M=B, N=hp[0], K=4, ldy=hmax, lda=4, ldg=gW.shape[1], alpha=sign)
                 self._scatter_weight(grads, ctx_l.weight, gW, None, h[0], None, 1)
                 self._colsum_to(grads, ctx_l.bias, d, B, h[0], hmax, sign)
@@ -373,7 +403,8 @@ class TrainPath:
                      residual=g_cur, r_off=pass_off, ldr=g_ld, res_sign=sign)
 
     def _transposed(self, pk, W: torch.Tensor) -> torch.Tensor:
-        """[K4, N] image of W^T for a conditioner weight image W [N, K] (N padded to 4 as the linear kernel's K)"""
+        """[K, N4] image of W^T for a conditioner weight image W [N, K] (N padded to 4: it is the linear kernel's K),
+        built from the raw parameter the image came from (no dependency on the image: both can sit in one batch)"""
         key = ("T", W.data_ptr())
         if key not in pk["mats"]:
             N, K = W.shape
@@ -382,9 +413,16 @@ class TrainPath:
             planes = None
             if self.eng._wants_planes(K, N4):
                 planes = torch.empty(3, K, _round_up(N4, 32), dtype=torch.bfloat16, device=W.device)
-            sel = self.eng._iarange(N, N4, W.device)
             with self.eng._pk_record(pk):
-                _ext.pack_weight(W, None, K, sel, N4, W=Wt, ldw=N4, planes=planes, transpose=True)
+                origin = pk["mats"].get(("imgsrc", W.data_ptr()))
+                if origin is not None:
+                    src, out_sel, n_out, in_sel, n_in = origin           # W[o, c] = src[out_sel[o], in_sel[c]]
+                    rows = self.eng._sel(out_sel[:n_out].cpu(), N4, W.device) if N4 != n_out else out_sel
+                    _ext.pack_weight(src, in_sel, n_in, rows, N4, W=Wt, ldw=N4, planes=planes, transpose=True)
+                else:
+                    _ext.flush_jobs()
+                    sel = self.eng._iarange(N, N4, W.device)
+                    _ext.pack_weight(W, None, K, sel, N4, W=Wt, ldw=N4, planes=planes, transpose=True)
             pk["mats"][key] = Wt
             if planes is not None:
                 pk["mats"][("planes", Wt.data_ptr())] = planes
@@ -488,15 +526,17 @@ class TrainPath:
                     G[u["row"]] = self._scale_grad(u["pre_scale"], Minv[u["row"]], G[u["row"]], Gsum, grads)
         G -= gs[:, :, None] * ch["b"][:, None, :]
         tmp = stacks.get("T")
-        if tmp is None:
-            tmp = stacks["T"] = torch.empty(3, n, D, D, dtype=torch.float64, device=G.device)
+        if tmp is None:      # zero-filled once: tiles the masked products never write must stay finite for triu / tril
+            tmp = stacks["T"] = torch.zeros(3, n, D, D, dtype=torch.float64, device=G.device)
         T1, dU, dL = tmp[0], tmp[1], tmp[2]
         bat = dict(batch=n, M=D, N=D, K=D, lda=D, ldb=D, ldc=D, strideC=DD)
         tinv = out["tri_inv"]                                   # [2n, D, D]: L^-1 at even, (U^-1)^T at odd rows
-        _ext.gemm_f64(G, Minv, T1, transB=True, strideA=DD, strideB=DD, **bat)                    # G M^-T
-        _ext.gemm_f64(tinv, T1, dU, alpha=-1.0, strideA=2 * DD, strideB=DD, a_off=DD, **bat)      # -U^-T (.)
-        _ext.gemm_f64(Minv, G, T1, transA=True, strideA=DD, strideB=DD, **bat)                    # M^-T G
-        _ext.gemm_f64(T1, tinv, dL, transB=True, alpha=-1.0, strideA=DD, strideB=2 * DD, **bat)   # -(.) L^-T
+        # only one triangle of each result survives (triu / tril below) and the inverses are triangular: the tile masks
+        # and k-range hints of usf_gemm_f64 cut the four products to ~3/8 of their dense cost
+        _ext.gemm_f64(G, Minv, T1, transB=True, strideA=DD, strideB=DD, tri=8, **bat)             # triu(G M^-T)
+        _ext.gemm_f64(tinv, T1, dU, alpha=-1.0, strideA=2 * DD, strideB=DD, a_off=DD, tri=8 + 3, **bat)   # -U^-T (.)
+        _ext.gemm_f64(Minv, G, T1, transA=True, strideA=DD, strideB=DD, tri=16, **bat)            # tril(M^-T G)
+        _ext.gemm_f64(T1, tinv, dL, transB=True, alpha=-1.0, strideA=DD, strideB=2 * DD, tri=16 + 4, **bat)  # -(.) L^-T
         if "coef" not in stacks:        # built once: a host-to-device copy here would drain the stream every step
             stacks["coef"] = torch.tensor([coef.get(id(b_), 0.0) for b_ in self._lu_blocks(plan)],
                                           dtype=torch.float64, device=G.device)
