@@ -344,7 +344,7 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_linear_f32: bad act"); return -2; }
   if (d->residual && d->addend) { set_error("usf_linear_f32: residual and addend are mutually exclusive"); return -2; }
-  if (linear_skinny_eligible(d)) return linear_skinny_dispatch(d, stream);     // M <= 512: latency, not FLOPs
+  if (linear_skinny_eligible(d)) return linear_skinny_dispatch(d, stream);     // small batches: latency, not FLOPs
   if (linear_bf16x3_eligible(d)) return linear_bf16x3_dispatch(d, stream);
   LinArgs a;
   a.A = d->A; a.W = d->W; a.bias = d->bias; a.pre_div = d->pre_div; a.pre_sub = d->pre_sub;

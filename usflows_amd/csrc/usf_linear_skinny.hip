@@ -1,4 +1,4 @@
-// usf_linear_f32 for SMALL batches (M <= 512): the reference's evaluation loops feed the flow in chunks of 100
+// usf_linear_f32 for SMALL batches (M <= 768: measured cross-over against the narrow tiled kernel): the reference's evaluation loops feed the flow in chunks of 100
 // (explib/hyperopt.py:273-278) and Flow.fit defaults to batch_size = 32 (flows.py:113).  At those sizes a layer is
 // a weight-streaming problem -- 2 M flops per row against 2.4 MB of weights -- and what matters is the latency of
 // one launch, not its FLOP rate: the tiled kernels put 5-13 blocks on the chip, each walking K in 25 serial,
@@ -16,6 +16,8 @@
 //   * the KS partial accumulators meet in LDS once, after the loop; the k-range-0 waves apply the epilogue
 //     (bias / addend / LeakyReLU / residual / post_mul, same order as the tiled kernels) and store 4 consecutive
 //     features per lane.
+#include <stdlib.h>
+
 #include "usf_common.h"
 
 namespace usf {
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(512) void linear_skinny_kernel(const SkArgs p) {
   }
 }
 
-bool linear_skinny_eligible(const usf_linear_desc* d) { return d->M <= 512; }
+bool linear_skinny_eligible(const usf_linear_desc* d) {
+  static int64_t max_rows = -1;                 // USF_SKINNY_MAX: tuning aid (cross-over against the tiled kernels)
+  if (max_rows < 0) { const char* e = getenv("USF_SKINNY_MAX"); max_rows = e ? atoll(e) : 768; }
+  return d->M <= max_rows;
+}
 
 int linear_skinny_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   SkArgs a;

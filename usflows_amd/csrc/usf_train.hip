@@ -26,6 +26,9 @@ struct WgradArgs {
   float* part;                 // [splits][N][K]
   int M, N, K;
   int rows_per_split;
+  float* G; int64_t ldg;       // single row range: the kernel writes alpha * acc + beta * G itself (no reduce launch)
+  float alpha, beta;
+  int direct;
 };
 
 // 16 x 128 slab of a row-major matrix (rows m0.., columns c0..) -> two float4 per thread, zero outside [M) x [ncols)
@@ -142,7 +145,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
         const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-        if (n < a.N && k < a.K) out[(int64_t)n * a.K + k] = acc[i][j][r];
+        if (n < a.N && k < a.K) {
+          if (a.direct) {
+            float* dst = a.G + (int64_t)n * a.ldg + k;
+            float v = a.alpha * acc[i][j][r];
+            if (a.beta != 0.f) v += a.beta * *dst;
+            *dst = v;
+          } else {
+            out[(int64_t)n * a.K + k] = acc[i][j][r];
+          }
+        }
       }
 }
 
@@ -272,7 +284,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
         const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-        if (n < a.N && k < a.K) out[(int64_t)n * a.K + k] = acc[i][j][r];
+        if (n < a.N && k < a.K) {
+          if (a.direct) {
+            float* dst = a.G + (int64_t)n * a.ldg + k;
+            float v = a.alpha * acc[i][j][r];
+            if (a.beta != 0.f) v += a.beta * *dst;
+            *dst = v;
+          } else {
+            out[(int64_t)n * a.K + k] = acc[i][j][r];
+          }
+        }
       }
 }
 
@@ -384,14 +405,17 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
   }
   int rows = (int)((M + splits - 1) / splits);
   rows = (rows + WB_S - 1) / WB_S * WB_S;
-  WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S};
+  WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S, G, ldg, alpha, beta,
+              splits == 1 ? 1 : 0};
   if (mode != 0 && mode != 1) { set_error("usf_wgrad_f32: mode must be 0 (exact f32) or 1 (bf16x3)"); return -2; }
   // the split-precision kernel pays off once the chip has real work (its operand split costs VALU per slab)
   if (mode == 1 && M >= 2048) wgrad_bf16x3_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
   else wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
-  int64_t rb = (N * K + 255) / 256;
-  if (rb > 4096) rb = 4096;
-  reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta);
+  if (splits > 1) {
+    int64_t rb = (N * K + 255) / 256;
+    if (rb > 4096) rb = 4096;
+    reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta);
+  }
   return check_launch("usf_wgrad_f32");
 }
 
