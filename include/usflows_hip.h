@@ -297,8 +297,10 @@ int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out
 int usf_act_grad_f32(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
                      usf_stream_t stream);
 
-/* Backward of usf_base_logprob_f32 for LAPLACE / NORMAL: g[m,d] = g_lp[m] * d/dz base_d(z[m,d]) for d < D, 0 for
- * D <= d < ldg (flows.py:245 through torch Laplace.log_prob / Normal.log_prob). */
+/* Backward of usf_base_logprob_f32: g[m,d] = g_lp[m] * d/dz base_d(z[m,d]) for d < D, 0 for D <= d < ldg
+ * (flows.py:245 through torch Laplace.log_prob / Normal.log_prob).  For the LPNORM* ids g_lp is the gradient at the
+ * radius r[m] = ||z[m,:] - loc||_p (RadialDistribution.log_prob, distributions.py:501-505) and `scale` carries that
+ * radius vector [M] (the forward kernel's output). */
 int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base,
                               const float* loc, const float* scale, float* g, int64_t ldg, usf_stream_t stream);
 

@@ -264,6 +264,10 @@ def _emu_act_grad(d, h, *, M, H, ldd, ldh, act, slope):
 
 def _emu_base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):
     zz = _view(z, 0, M, D, ldz).double()
+    if base in (_ext.BASE_LPNORM1, _ext.BASE_LPNORM2, _ext.BASE_LPNORMINF):
+        p = {_ext.BASE_LPNORM1: 1.0, _ext.BASE_LPNORM2: 2.0}.get(base, float("inf"))
+        out.copy_((zz - loc.double()).norm(p=p, dim=1).float())
+        return
     dist = (torch.distributions.Laplace if base == _ext.BASE_LAPLACE else torch.distributions.Normal)(loc.double(), scale.double())
     out.copy_((dist.log_prob(zz).sum(-1) + logdet_const).float())
 
@@ -272,8 +276,14 @@ def _emu_base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
     t = _view(z, 0, M, D, ldz).double() - loc.double()
     if base == _ext.BASE_LAPLACE:
         v = -torch.sign(t) / scale.double()
-    else:
+    elif base == _ext.BASE_NORMAL:
         v = -t / (scale.double() ** 2)
+    elif base == _ext.BASE_LPNORM1:
+        v = torch.sign(t)
+    elif base == _ext.BASE_LPNORM2:
+        v = t / t.norm(dim=1, keepdim=True)
+    else:
+        v = torch.sign(t) * (t.abs() == t.abs().max(dim=1, keepdim=True).values)
     gv = _view(g, 0, M, ldg, ldg)
     gv.zero_()
     gv[:, :D] = (v * g_lp.double()[:, None]).float()

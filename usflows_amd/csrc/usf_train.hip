@@ -346,7 +346,9 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* __restrict__ d, in
   }
 }
 
-// g[m,d] = g_lp[m] * d/dz base_d(z[m,d]);  columns D..ldg-1 (layout padding) are written as zeros
+// g[m,d] = g_lp[m] * d/dz base_d(z[m,d]);  columns D..ldg-1 (layout padding) are written as zeros.
+// LPNORM* (RadialDistribution, distributions.py:501-505): g_lp is the gradient at the radius r[m] = ||z - loc||_p and
+// `scale` carries r [M]:  p = 1: sign(t),  p = 2: t / r,  p = inf: sign(t) where |t| == r (ATen's norm backward).
 __global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ g_lp,
                                                         int64_t M, int64_t D, int base, const float* __restrict__ loc,
                                                         const float* __restrict__ scale, float* __restrict__ g,
@@ -357,9 +359,12 @@ __global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict_
     float v = 0.f;
     if (d < D) {
       const float t = z[m * ldz + d] - loc[d];
-      const float s = scale[d];
-      if (base == USF_BASE_LAPLACE) v = -(float)((t > 0.f) - (t < 0.f)) / s;      // d/dz -|z-loc|/b ; 0 at the kink (ATen)
-      else v = -t / (s * s);                                                      // d/dz -(z-loc)^2 / (2 s^2)
+      const float sg = (float)((t > 0.f) - (t < 0.f));
+      if (base == USF_BASE_LAPLACE) v = -sg / scale[d];                           // d/dz -|z-loc|/b ; 0 at the kink (ATen)
+      else if (base == USF_BASE_NORMAL) v = -t / (scale[d] * scale[d]);           // d/dz -(z-loc)^2 / (2 s^2)
+      else if (base == USF_BASE_LPNORM1) v = sg;
+      else if (base == USF_BASE_LPNORM2) v = scale[m] > 0.f ? t / scale[m] : 0.f;
+      else v = (fabsf(t) == scale[m]) ? sg : 0.f;
       v *= g_lp[m];
     }
     g[e] = v;
@@ -463,8 +468,8 @@ int base_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t
     set_error("usf_base_logprob_grad_f32: bad arguments");
     return -1;
   }
-  if (base != USF_BASE_LAPLACE && base != USF_BASE_NORMAL) {
-    set_error("usf_base_logprob_grad_f32: base %d has no device gradient", base);
+  if (base < USF_BASE_LAPLACE || base > USF_BASE_LPNORMINF) {
+    set_error("usf_base_logprob_grad_f32: unknown base %d", base);
     return -2;
   }
   if (M == 0) return 0;

@@ -10,13 +10,16 @@ backward  usf_base_logprob_grad_f32 -> per layer, last to first:
             coupling  hidden activations recomputed by two usf_linear_f32 launches, then per conditioner layer
                       usf_wgrad_f32 / usf_colsum_f32 / usf_linear_f32 (transposed image) / usf_act_grad_f32;
                       the conditioning half of the gradient is updated in place
+          (every layer keeps gradient images of its own; the scatter / un-permute copies into the parameter layout are
+          queued and leave as one usf_pack_weights_f32 launch per size class behind the last layer)
           then the parameter-sized chain rule, batched over all LU blocks on the f64 MFMA (usf_gemm_f64):
             M^-1 = U^-1 L^-1:   dU = -triu(U^-T G M^-T),   dL = -tril(M^-T G L^-T, -1)
             M    = L U      :   dL += tril(G U^T, -1),     dU += triu(L^T G)            (affine_conjugation)
           Householder factors / longer Sequential chains go through a small torch graph over the prepared fp64
           matrices (parameter-sized library GEMMs).
 
-Supported here: flat inputs, Laplace / Normal base without trainable parameters, inputs that do not require grad,
+Supported here: flat inputs, Laplace / Normal base without trainable parameters or a RadialDistribution base (the
+node then returns the Lp radius + log-det and the finishing formula stays in torch), inputs that do not require grad,
 ConditionalDenseNN / DenseNN conditioners; anything else keeps using the differentiable composite formulation
 (flows.py / transforms.py mirrors) -- same results, torch ops.
 """
@@ -60,9 +63,14 @@ class TrainPath:
         if eng is None or x.requires_grad or (context is not None and context.requires_grad):
             return False
         info = self.flow._base_info(x.device)
-        if info is None or info[0] not in ("laplace", "normal"):
+        if info is None:
             return False
-        if any(p.requires_grad for p in self._base_params()):
+        if info[0] == "radial":
+            # RadialDistribution (distributions.py:327-549): trainable loc / norm distribution are fine -- the node
+            # returns the Lp radius and the finishing formula stays in torch (O(B), differentiable)
+            if getattr(self.flow.base_distribution, "n_batch_dims", 1) != 0:
+                return False
+        elif any(p.requires_grad for p in self._base_params()):
             return False
         for s in eng.steps:
             if s.kind == "coupling" and not isinstance(s.module.conditioner, (ConditionalDenseNN, DenseNN)):
@@ -90,11 +98,22 @@ class TrainPath:
         eng._execute(plan, x, None, context)
         zname, _, ldn = plan["out_buf"]
         info = self.flow._base_info(dev)
-        base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
-        lp = torch.empty(B, dtype=torch.float32, device=dev)
-        _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, info[1], info[2], -plan["pk"]["ladj_total"], lp, None)
+        base, loc, scale = self._base_ids(info)
         self.generation += 1
+        if info[0] == "radial":
+            # the radius stays in a plan-owned buffer (the backward's d r / d z needs it); the caller gets a copy
+            rbuf = self._buf(plan["ws"], "radius", 1, B)[0, :B]
+            _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, None, 0.0, rbuf, None)
+            return rbuf.clone(), plan, x, self.generation
+        lp = torch.empty(B, dtype=torch.float32, device=dev)
+        _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, scale, -plan["pk"]["ladj_total"], lp, None)
         return lp, plan, x, self.generation
+
+    @staticmethod
+    def _base_ids(info):
+        if info[0] == "radial":
+            return {1.0: _ext.BASE_LPNORM1, 2.0: _ext.BASE_LPNORM2}.get(info[2], _ext.BASE_LPNORMINF), info[1], None
+        return (_ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL), info[1], info[2]
 
     def _check_plan(self, plan):
         if plan["final_gather"] is not None:
@@ -149,13 +168,16 @@ class TrainPath:
                     W_split=planes, **kw)
 
     # ---- backward -------------------------------------------------------------------------------------
-    def backward(self, plan, x, g_lp: torch.Tensor) -> Dict[int, torch.Tensor]:
+    def backward(self, plan, x, g_lp: torch.Tensor, gsum: Optional[torch.Tensor] = None) -> Dict[int, torch.Tensor]:
         """gradients of sum_m g_lp[m] * log_prob(x)[m] w.r.t. every trainable parameter: id(param) -> tensor.
 
         The launch sequence depends only on the plan: it is recorded on the first call (``_ext.Tape``) and replayed
         afterwards; the per-call inputs (x, g_lp) enter through ``host_op`` closures reading ``self._cur``."""
         dev = x.device
-        self._cur = dict(x=x, g_lp=g_lp.detach().to(torch.float32).contiguous())
+        # gsum: gradient at the log-det output (radial bases: log_prob = f(radius) + logdet, the node returns both);
+        # None: log_prob = base(z) + logdet came out of the node itself, so it is sum(g_lp)
+        self._cur = dict(x=x, g_lp=g_lp.detach().to(torch.float32).contiguous(),
+                         gsum=None if gsum is None else gsum.detach())
         pk = plan["pk"]
         arena = self._arena(plan)
         tape = plan.get("bwd_tape")
@@ -194,7 +216,11 @@ class TrainPath:
                     slots[id(p)] = (off + j * per, per, tuple(p.shape))
                 off += n * per
             lu_views.append((base, n))
-        for p in self.params():
+        extra = []
+        info = self.flow._base_info(dev)
+        if info is not None and info[0] == "radial":
+            extra.append(self.flow.base_distribution.loc)
+        for p in list(self.params()) + extra:
             if id(p) not in slots and p.requires_grad:
                 slots[id(p)] = (off, p.numel(), tuple(p.shape))
                 off += p.numel()
@@ -215,12 +241,18 @@ class TrainPath:
         glp = self._buf(ws, "g_lp", 1, B)[0, :B]
         _ext.host_op(lambda: (arena["flat"].zero_(), glp.copy_(self._cur["g_lp"])))
         info = self.flow._base_info(dev)
-        base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
+        base, loc, scale = self._base_ids(info)
         zname, _, ldn = plan["out_buf"]
-        _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, info[1], info[2], gA, ldn)
-        g_cur, g_other, g_ld = gA, gB, ldn
         grads = arena["views"]
         self._touched = arena["touched"]
+        if info[0] == "radial":
+            scale = self._buf(ws, "radius", 1, B)[0, :B]              # the forward left r = ||z - loc||_p here
+        _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, loc, scale, gA, ldn)
+        if info[0] == "radial":
+            g_loc = self._grad_slot(grads, self.flow.base_distribution.loc)
+            if g_loc is not None:                                     # r depends on z - loc: d/dloc = -sum_m d/dz
+                _ext.colsum(gA, g_loc, M=B, N=D, ldy=ldn, alpha=-1.0)
+        g_cur, g_other, g_ld = gA, gB, ldn
         aff: Dict[int, dict] = {}            # id(block) -> natural-layout gradients of its usages
         n_aff = sum(1 for m in plan["meta"] if m["kind"] == "affine")
         stacks = dict(G=torch.zeros(max(n_aff, 1), D, D, dtype=torch.float32, device=dev),
@@ -467,7 +499,7 @@ class TrainPath:
         eng = self.eng
         pk = plan["pk"]
         dev = g_lp.device
-        Gsum = g_lp.double().sum()
+        Gsum = g_lp.double().sum() if self._cur["gsum"] is None else self._cur["gsum"].double().reshape(())
         # log-det: log_prob = base(z) - ladj_total, ladj_total = sum_steps (+/-) ladj(step)  (flows.py:236-245)
         coef: Dict[int, float] = {}
         for s in eng.steps:
@@ -612,7 +644,6 @@ class TrainPath:
                             wanted.append(p)
                             owners.append((p, "param"))
             got = torch.autograd.grad(proxy, wanted, allow_unused=True)
-        n_lu = sum(1 for lf in leaves if lf[0] == "lu")
         for (owner, kind), g in zip(owners, got):
             if kind == "param":
                 if g is not None:
@@ -626,7 +657,6 @@ class TrainPath:
             if lf[0] == "lu":                                # the block's log-det is the sum of its LU parts'
                 a = lu_acc.setdefault(id(lf[1]), dict(lu=lf[1], dMinv=None, dM=None, db=None, c=0.0))
                 a["c"] = a["c"] + ladj_coef
-        del n_lu
 
     def _lu_param_grads(self, pk, lu_acc, grads):
         """batched over all LU blocks: (dMinv, dM, db) -> (L_raw, U_raw, bias_vector).grad on the f64 MFMA"""
@@ -695,6 +725,38 @@ class _LogProbFn(torch.autograd.Function):
         return (None, None, None) + out
 
 
+class _RadiusFn(torch.autograd.Function):
+    """Radial bases: the node returns (r = ||f^-1(x) - loc||_p, log-det); ``RadialDistribution.log_prob``'s finishing
+    formula norm_dist.log_prob(r) - log dV_p(r) (distributions.py:506-511) is applied outside, in torch, so a trainable
+    norm distribution gets its gradients from autograd and this node's backward starts from d/dr."""
+
+    @staticmethod
+    def forward(ctx, path: TrainPath, x, context, *params):
+        r, plan, xc, gen = path.forward(x, context)
+        ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
+        ctx.params = params
+        logdet = torch.full((), -plan["pk"]["ladj_total"], dtype=torch.float32, device=r.device)
+        return r, logdet
+
+    @staticmethod
+    def backward(ctx, g_r, g_logdet):
+        path: TrainPath = ctx.path
+        if path.generation != ctx.gen:
+            _, ctx.plan, ctx.x, ctx.gen = path.forward(ctx.x, ctx.context)
+        if g_r is None:
+            g_r = torch.zeros(ctx.x.shape[0], dtype=torch.float32, device=ctx.x.device)
+        if g_logdet is None:
+            g_logdet = torch.zeros((), dtype=torch.float32, device=ctx.x.device)
+        grads = path.backward(ctx.plan, ctx.x, g_r, gsum=g_logdet)
+        out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+        return (None, None, None) + out
+
+
 def log_prob_with_grad(path: TrainPath, x, context):
-    params = path.params()
+    params = list(path.params())
+    info = path.flow._base_info(x.device)
+    if info[0] == "radial":
+        base = path.flow.base_distribution
+        r, logdet = _RadiusFn.apply(path, x, context, base.loc, *params)
+        return base.log_prob_from_radius(r) + logdet
     return _LogProbFn.apply(path, x, context, *params)
