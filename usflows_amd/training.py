@@ -258,6 +258,10 @@ class TrainPath:
         stacks = dict(G=torch.zeros(max(n_aff, 1), D, D, dtype=torch.float32, device=dev),
                       gs=torch.zeros(max(n_aff, 1), D, dtype=torch.float32, device=dev), next=0)
         self._lu_slot = self._lu_slots(plan)
+        if self._lu_slot is not None and any(m["kind"] == "affine" and m["prim"] == "affine_fwd" for m in plan["meta"]):
+            # affine_conjugation: a block is also used in its M form (InverseTransform.backward): stacks of their own
+            stacks["GM"] = torch.zeros_like(stacks["G"])
+            stacks["gsM"] = torch.zeros_like(stacks["gs"])
         self._wmode = 1 if eng.gemm_mode == "bf16x3" else 0      # weight gradients on the same arithmetic as the GEMMs
         first_meta = plan["meta"][0] if plan["meta"] else None
         self._prepare_images(plan, first_meta)
@@ -295,8 +299,9 @@ class TrainPath:
                         self._mat_t(pk, m["blk"], which, m["out_layout"], m["in_layout"])
 
     def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
-        """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every
-        affine block is one LU factor (bare or Sequential([LU])) used once, in its M^-1 form, one prepare chunk"""
+        """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every affine
+        block is one LU factor (bare or Sequential([LU])), used once in its M^-1 form and at most once in its M form
+        (affine_conjugation), all prepared in one chunk"""
         pk = plan["pk"]
         chunks = pk["affine_parts"]["__chunks__"]
         if len(chunks) != 1:
@@ -308,11 +313,14 @@ class TrainPath:
                 continue
             blk = m["blk"]
             leaf = blk.transforms[0] if (isinstance(blk, T.SequentialAffineTransform) and len(blk.transforms) == 1) else blk
-            if m["prim"] != "affine_bwd" or not isinstance(leaf, T.LUTransform) or id(leaf) in seen:
+            use = (id(leaf), m["prim"])
+            if not isinstance(leaf, T.LUTransform) or use in seen or (m["prim"] == "affine_fwd" and m["pre_scale"] is not None):
                 return None
-            seen.add(id(leaf))
+            seen.add(use)
             slots[id(blk)] = idx[id(leaf)]
-        return slots if len(seen) == len(idx) else None
+        if {u[0] for u in seen if u[1] == "affine_bwd"} != set(idx):
+            return None
+        return slots
 
     # ---- affine layers --------------------------------------------------------------------------------
     def _affine_backward(self, plan, m, g_cur, g_other, g_ld, aff, stacks, need_dgrad):
@@ -340,7 +348,10 @@ class TrainPath:
         D = eng.D
         k = self._lu_slot[id(blk)] if self._lu_slot is not None else stacks["next"]
         stacks["next"] += 1
-        G_nat, gs_nat = stacks["G"][k], stacks["gs"][k]
+        if self._lu_slot is not None and which == "M":
+            G_nat, gs_nat = stacks["GM"][k], stacks["gsM"][k]
+        else:
+            G_nat, gs_nat = stacks["G"][k], stacks["gs"][k]
         _ext.pack_weight(Gp, self._inv_idx(m["out_layout"], dev), D, self._inv_idx(m["in_layout"], dev), D,
                          W=G_nat, ldw=D, ld_src=Gp.shape[1])
         _ext.pack_weight(gs, None, 1, self._inv_idx(m["out_layout"], dev), D, W=gs_nat, ldw=D, ld_src=gs.shape[1])
@@ -577,9 +588,20 @@ class TrainPath:
         dU = dU.triu()
         dU.diagonal(dim1=1, dim2=2).add_(c[:, None] / Udiag)                                     # transforms.py:1303-1320
         db = -torch.bmm(Minv.transpose(1, 2), gs.unsqueeze(2)).squeeze(2)
+        dL = dL.tril(-1)
+        if "GM" in stacks:
+            # the M = L U usages (y = a M^T + b):  dL += tril(G U^T, -1),  dU += triu(L^T G),  db += gsum
+            GM = stacks["GM"][:n].double()
+            tri = out["tri"]                                    # [2n, D, D]: L at even, U^T at odd rows
+            TL, TU = tmp[0], stacks.setdefault("T2", torch.zeros(n, D, D, dtype=torch.float64, device=G.device))
+            _ext.gemm_f64(GM, tri, TL, strideA=DD, strideB=2 * DD, b_off=DD, tri=16, **bat)       # tril(G U^T)
+            _ext.gemm_f64(tri, GM, TU, transA=True, strideA=2 * DD, strideB=DD, tri=8, **bat)     # triu(L^T G)
+            dL = dL + TL.tril(-1)
+            dU = dU + TU.triu()
+            db = db + stacks["gsM"][:n].double()
         base, _n = arena["lu_views"][0]
         flat = arena["flat"]
-        flat[base: base + n * DD].view(n, D, D).copy_(dL.tril(-1))
+        flat[base: base + n * DD].view(n, D, D).copy_(dL)
         flat[base + n * DD: base + 2 * n * DD].view(n, D, D).copy_(dU)
         flat[base + 2 * n * DD: base + 2 * n * DD + n * D].view(n, D).copy_(db)
         for lu in ch["lus"]:
