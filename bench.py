@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run couplings as 3 linear ops instead of the fused kernel")
+    ap.add_argument("--fused-min-rows", type=int, default=None, help="batch size from which couplings take the fused kernel")
     ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=None,
                     help="affine GEMM arithmetic: bf16x3 = 3-way split on the bf16 MFMA (default), f32 = exact-f32 MFMA")
     ap.add_argument("--mode", choices=["log_prob", "sample", "train"], default="log_prob",
@@ -70,6 +71,8 @@ def main():
     flow = build_usflow(spec, sd, device=str(dev))
     eng = flow.engine()
     eng.use_fused_coupling = not args.unfused
+    if args.fused_min_rows is not None:
+        eng.fused_min_rows = args.fused_min_rows
     if args.gemm:
         eng.gemm_mode = args.gemm
     B, D = args.batch, args.dim

@@ -196,7 +196,8 @@ class FlowEngine:
         self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
         self.op_timing = None          # set to a list to record (tag, start_event, end_event) per op (bench.py)
         self.use_fused_coupling = True
-        self.fused_min_rows = 24576    # measured cross-over on MI355X at D=784, hidden 256 (bench.py --batch sweep)
+        self.fused_min_rows = 14336    # measured cross-over on MI355X at D=784, hidden 256 (bench.py --fused-min-rows sweep:
+        #                                fused / unfused ms per step: 8192 4.79 / 3.98, 12288 5.06 / 5.05, 16384 6.45 / 6.66, 20480 7.54 / 8.43)
         # "bf16x3" (default): the D x D affine GEMMs run on the bf16 matrix cores with a 3-way residual split of
         # both operands (fp32-equivalent accuracy); "f32": exact-f32 MFMA everywhere
         # (USFLOWS_AMD_GEMM=f32 or engine.gemm_mode = "f32")
