@@ -300,10 +300,12 @@ class TrainPath:
 
     def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
         """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every affine
-        block is one LU factor (bare or Sequential([LU])), used once in its M^-1 form and at most once in its M form
-        (affine_conjugation), all prepared in one chunk"""
+        block is one LU factor -- bare, Sequential([LU]) or Sequential([LU, Householder with one vector]) (the USFlow
+        constructor's default) --, used once in its M^-1 form and at most once in its M form (affine_conjugation),
+        all LU factors prepared in one chunk.  Also fills self._hh: row -> Householder module (or absent)."""
         pk = plan["pk"]
         chunks = pk["affine_parts"]["__chunks__"]
+        self._hh = {}
         if len(chunks) != 1:
             return None
         idx = {id(lu): j for j, lu in enumerate(chunks[0]["lus"])}
@@ -312,12 +314,20 @@ class TrainPath:
             if m["kind"] != "affine":
                 continue
             blk = m["blk"]
-            leaf = blk.transforms[0] if (isinstance(blk, T.SequentialAffineTransform) and len(blk.transforms) == 1) else blk
+            leaf, hh = blk, None
+            if isinstance(blk, T.SequentialAffineTransform):
+                parts = list(blk.transforms)
+                if len(parts) == 1:
+                    leaf = parts[0]
+                elif (len(parts) == 2 and isinstance(parts[1], T.HouseholderTransform) and parts[1].nvs == 1):
+                    leaf, hh = parts
             use = (id(leaf), m["prim"])
             if not isinstance(leaf, T.LUTransform) or use in seen or (m["prim"] == "affine_fwd" and m["pre_scale"] is not None):
                 return None
             seen.add(use)
             slots[id(blk)] = idx[id(leaf)]
+            if hh is not None:
+                self._hh[idx[id(leaf)]] = hh
         if {u[0] for u in seen if u[1] == "affine_bwd"} != set(idx):
             return None
         return slots
@@ -552,62 +562,118 @@ class TrainPath:
         return G2 / s64[None, :]
 
     def _lu_chain_rule_batched(self, plan, aff, stacks, Gsum, coef, grads, arena):
-        """all affine blocks are single LU factors used once as M^-1 = U^-1 L^-1: one pass over [n, D, D] stacks
-            dU = -triu(U^-T (G M^-T)) + c diag(1/U_jj),   dL = -tril((M^-T G) L^-T, -1),   db = -M^-T gsum
-        with G = g^T a - gsum (x) b per block; four batched launches on the f64 MFMA."""
+        """One pass over [n, D, D] stacks for all affine blocks (block matrix M_t = M_lu H, H = the block's Householder
+        factor or I; transforms.py:1457-1476):
+            usage M_t^-1 (y = (a - b_t) M_t^-T):  dMinv_t = g^T a - gsum (x) b_t,   db_t = -M_t^-T gsum
+            usage M_t    (y = a M_t^T + b_t)    :  dM_t = g^T a,                     db_t += gsum
+            M_t^-1 = H^T M_lu^-1, M_t = M_lu H, b_t = b_lu H:
+               dMinv_lu = H dMinv_t,  dM_lu = dM_t H^T,  db_lu = H db_t,
+               dH = M_lu^-1 dMinv_t^T + M_lu^T dM_t + b_lu (x) db_t
+            M_lu^-1 = U^-1 L^-1, M_lu = L U:
+               dU = -triu(U^-T (dMinv_lu M_lu^-T)) + triu(L^T dM_lu) + c diag(1/U_jj)
+               dL = -tril((M_lu^-T dMinv_lu) L^-T, -1) + tril(dM_lu U^T, -1)
+            H = w_0 (I - 2 v v^T / v.v),  A = w_0^T dH:   dv = -2 (A + A^T) v / s + 4 (v^T A v) v / s^2,  s = v.v
+        everything batched on the f64 MFMA (usf_gemm_f64) / batched torch ops."""
         pk = plan["pk"]
         ch = pk["affine_parts"]["__chunks__"][0]
         out = ch["out"]
         n, D = len(ch["lus"]), self.eng.D
         DD = D * D
+        dev = out["Minv"].device
+        bat = dict(batch=n, M=D, N=D, K=D, lda=D, ldb=D, ldc=D, strideC=DD)
+        f64 = lambda: torch.zeros(n, D, D, dtype=torch.float64, device=dev)
+        Minv_lu, b_lu = out["Minv"], ch["b"]
+        has_hh = bool(self._hh)
+        blocks = self._lu_blocks(plan)
+        if has_hh:
+            # block-level matrices M_t^-1 / b_t and H per row (H = I where the block has no Householder factor)
+            eye = stacks.setdefault("eye", torch.eye(D, dtype=torch.float64, device=dev))
+            H = torch.stack([pk["affine_parts"][id(self._hh[j])]["M"] if j in self._hh else eye for j in range(n)])
+            Minv_t = torch.stack([pk["affine"][id(b_)]["Minv"] for b_ in blocks])
+            b_t = torch.stack([pk["affine"][id(b_)]["b"] for b_ in blocks])
+        else:
+            H, Minv_t, b_t = None, Minv_lu, b_lu
         G = stacks["G"][:n].double()
         gs = stacks["gs"][:n].double()
-        Minv = out["Minv"]
         for rec in aff.values():
             for u in rec["uses"]:
                 if u["pre_scale"] is not None:
-                    G[u["row"]] = self._scale_grad(u["pre_scale"], Minv[u["row"]], G[u["row"]], Gsum, grads)
-        G -= gs[:, :, None] * ch["b"][:, None, :]
+                    G[u["row"]] = self._scale_grad(u["pre_scale"], Minv_t[u["row"]], G[u["row"]], Gsum, grads)
+        dMinv_t = G - gs[:, :, None] * b_t[:, None, :]
+        db_t = -torch.bmm(Minv_t.transpose(1, 2), gs.unsqueeze(2)).squeeze(2)
+        dM_t = None
+        if "GM" in stacks:
+            dM_t = stacks["GM"][:n].double()
+            db_t = db_t + stacks["gsM"][:n].double()
+        if has_hh:
+            dMinv_lu, dH = stacks.setdefault("dMinv_lu", f64()), stacks.setdefault("dH", f64())
+            _ext.gemm_f64(H, dMinv_t, dMinv_lu, strideA=DD, strideB=DD, **bat)                    # H dMinv_t
+            _ext.gemm_f64(Minv_lu, dMinv_t, dH, transB=True, strideA=DD, strideB=DD, **bat)       # M_lu^-1 dMinv_t^T
+            db_lu = torch.bmm(H, db_t.unsqueeze(2)).squeeze(2)
+            dH += b_lu[:, :, None] * db_t[:, None, :]
+            dM_lu = None
+            if dM_t is not None:
+                dM_lu = stacks.setdefault("dM_lu", f64())
+                _ext.gemm_f64(dM_t, H, dM_lu, transB=True, strideA=DD, strideB=DD, **bat)         # dM_t H^T
+                _ext.gemm_f64(out["M"], dM_t, dH, transA=True, strideA=DD, strideB=DD, beta=1.0, **bat)   # + M_lu^T dM_t
+            self._householder_grads(dH, stacks, grads, n, D, dev)
+        else:
+            dMinv_lu, dM_lu, db_lu = dMinv_t, dM_t, db_t
+        # ---- LU factors
         tmp = stacks.get("T")
         if tmp is None:      # zero-filled once: tiles the masked products never write must stay finite for triu / tril
-            tmp = stacks["T"] = torch.zeros(3, n, D, D, dtype=torch.float64, device=G.device)
+            tmp = stacks["T"] = torch.zeros(3, n, D, D, dtype=torch.float64, device=dev)
         T1, dU, dL = tmp[0], tmp[1], tmp[2]
-        bat = dict(batch=n, M=D, N=D, K=D, lda=D, ldb=D, ldc=D, strideC=DD)
         tinv = out["tri_inv"]                                   # [2n, D, D]: L^-1 at even, (U^-1)^T at odd rows
         # only one triangle of each result survives (triu / tril below) and the inverses are triangular: the tile masks
         # and k-range hints of usf_gemm_f64 cut the four products to ~3/8 of their dense cost
-        _ext.gemm_f64(G, Minv, T1, transB=True, strideA=DD, strideB=DD, tri=8, **bat)             # triu(G M^-T)
+        _ext.gemm_f64(dMinv_lu, Minv_lu, T1, transB=True, strideA=DD, strideB=DD, tri=8, **bat)   # triu(G M^-T)
         _ext.gemm_f64(tinv, T1, dU, alpha=-1.0, strideA=2 * DD, strideB=DD, a_off=DD, tri=8 + 3, **bat)   # -U^-T (.)
-        _ext.gemm_f64(Minv, G, T1, transA=True, strideA=DD, strideB=DD, tri=16, **bat)            # tril(M^-T G)
+        _ext.gemm_f64(Minv_lu, dMinv_lu, T1, transA=True, strideA=DD, strideB=DD, tri=16, **bat)  # tril(M^-T G)
         _ext.gemm_f64(T1, tinv, dL, transB=True, alpha=-1.0, strideA=DD, strideB=2 * DD, tri=16 + 4, **bat)  # -(.) L^-T
         if "coef" not in stacks:        # built once: a host-to-device copy here would drain the stream every step
-            stacks["coef"] = torch.tensor([coef.get(id(b_), 0.0) for b_ in self._lu_blocks(plan)],
-                                          dtype=torch.float64, device=G.device)
+            stacks["coef"] = torch.tensor([coef.get(id(b_), 0.0) for b_ in blocks], dtype=torch.float64, device=dev)
         c = stacks["coef"] * Gsum
         Udiag = out["tri"][1::2].diagonal(dim1=1, dim2=2)                                        # U_jj (of U^T)
         dU = dU.triu()
         dU.diagonal(dim1=1, dim2=2).add_(c[:, None] / Udiag)                                     # transforms.py:1303-1320
-        db = -torch.bmm(Minv.transpose(1, 2), gs.unsqueeze(2)).squeeze(2)
         dL = dL.tril(-1)
-        if "GM" in stacks:
-            # the M = L U usages (y = a M^T + b):  dL += tril(G U^T, -1),  dU += triu(L^T G),  db += gsum
-            GM = stacks["GM"][:n].double()
+        if dM_lu is not None:
+            # the M = L U usages:  dL += tril(G U^T, -1),  dU += triu(L^T G)
             tri = out["tri"]                                    # [2n, D, D]: L at even, U^T at odd rows
-            TL, TU = tmp[0], stacks.setdefault("T2", torch.zeros(n, D, D, dtype=torch.float64, device=G.device))
-            _ext.gemm_f64(GM, tri, TL, strideA=DD, strideB=2 * DD, b_off=DD, tri=16, **bat)       # tril(G U^T)
-            _ext.gemm_f64(tri, GM, TU, transA=True, strideA=2 * DD, strideB=DD, tri=8, **bat)     # triu(L^T G)
+            TL, TU = tmp[0], stacks.setdefault("T2", f64())
+            _ext.gemm_f64(dM_lu, tri, TL, strideA=DD, strideB=2 * DD, b_off=DD, tri=16, **bat)    # tril(G U^T)
+            _ext.gemm_f64(tri, dM_lu, TU, transA=True, strideA=2 * DD, strideB=DD, tri=8, **bat)  # triu(L^T G)
             dL = dL + TL.tril(-1)
             dU = dU + TU.triu()
-            db = db + stacks["gsM"][:n].double()
         base, _n = arena["lu_views"][0]
         flat = arena["flat"]
         flat[base: base + n * DD].view(n, D, D).copy_(dL)
         flat[base + n * DD: base + 2 * n * DD].view(n, D, D).copy_(dU)
-        flat[base + 2 * n * DD: base + 2 * n * DD + n * D].view(n, D).copy_(db)
+        flat[base + 2 * n * DD: base + 2 * n * DD + n * D].view(n, D).copy_(db_lu)
         for lu in ch["lus"]:
             for name in ("L_raw", "U_raw", "bias_vector"):
                 if getattr(lu, name).requires_grad:
                     arena["touched"].add(id(getattr(lu, name)))
+
+    def _householder_grads(self, dH, stacks, grads, n, D, dev):
+        """dLoss/dv of H = w_0 (I - 2 v v^T / v.v) for the rows that have a Householder factor (one vector each)"""
+        rows = sorted(self._hh)
+        hhs = [self._hh[j] for j in rows]
+        if "w0T" not in stacks:     # w_0 is a fixed permutation (requires_grad = False, transforms.py:789)
+            stacks["w0T"] = torch.stack([h.w_0.detach().double().t() for h in hhs]).contiguous()
+            stacks["hh_rows"] = torch.tensor(rows, dtype=torch.long, device=dev)
+        A = torch.bmm(stacks["w0T"], dH[stacks["hh_rows"]])                          # w_0^T dH
+        v = torch.stack([h.vk_householder.detach()[0].double() for h in hhs])        # [m, D]
+        s_ = (v * v).sum(1, keepdim=True)
+        Av = torch.bmm(A, v.unsqueeze(2)).squeeze(2)
+        ATv = torch.bmm(A.transpose(1, 2), v.unsqueeze(2)).squeeze(2)
+        vAv = (v * Av).sum(1, keepdim=True)
+        dv = -2.0 * (Av + ATv) / s_ + 4.0 * vAv * v / (s_ * s_)
+        for i, h in enumerate(hhs):
+            g = self._grad_slot(grads, h.vk_householder)
+            if g is not None:
+                g.copy_(dv[i].reshape(g.shape))
 
     def _lu_blocks(self, plan):
         """affine blocks in the row order of the batched stacks"""
