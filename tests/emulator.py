@@ -168,10 +168,13 @@ def _emu_lu_prepare(L_raws, U_raws, want_M=True, want_Minv=True, keep_factors=Fa
     return out
 
 
-def _emu_householder(w_0, vk):
+def _emu_householder(w_0, vk, out=None):
     w = w_0.double()
     for v in vk.double():
         w = w - 2.0 * torch.outer(w @ v, v) / torch.dot(v, v)
+    if out is not None:
+        out.copy_(w)
+        return out
     return w.contiguous()
 
 
@@ -326,6 +329,7 @@ def install_prep_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "matmul_f64", _emu_matmul_f64)
     monkeypatch.setattr(_ext, "pack_weight", _emu_pack_weight)
     monkeypatch.setattr(_ext, "matvec_f64", _emu_matvec_f64)
+    monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
 
 
 def engine_transform(eng, x, direction, context=None, fused=False):

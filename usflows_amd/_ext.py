@@ -336,9 +336,10 @@ def matmul_f64(A: torch.Tensor, B: torch.Tensor, transA=False, transB=False, tri
     return out
 
 
-def householder(w_0, vk):
+def householder(w_0, vk, out=None):
     D = int(w_0.shape[0])
-    out = torch.empty(D, D, dtype=torch.float64, device=w_0.device)
+    if out is None:
+        out = torch.empty(D, D, dtype=torch.float64, device=w_0.device)
     _launch("usf_householder_f64", (w_0.data_ptr(), vk.data_ptr(), int(vk.shape[0]), D, out.data_ptr(),
                                     current_stream(w_0.device)), (w_0, vk, out))
     return out

@@ -160,13 +160,44 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
                     r.update(L=out["tri"][2 * j], Ut=out["tri"][2 * j + 1], Linv=out["tri_inv"][2 * j],
                              Uinv_t=out["tri_inv"][2 * j + 1])
                 res[id(l)] = r
-    for h in hhs.values():
-        w = _ext.householder(_param(h.w_0, device), _param(h.vk_householder, device))
-        zero = torch.zeros(h.dim, dtype=torch.float64, device=w.device)
-        wt = _refreshed(tuple(w.shape), torch.float64, w.device, lambda o, w=w: o.copy_(w.t()))
-        res[id(h)] = dict(M=w, Minv=wt, b=zero, ladj=zero.sum())
-    for b in blocks:
-        if isinstance(b, T.SequentialAffineTransform) and id(b) not in res:
+    hh_list = list(hhs.values())
+    if hh_list:
+        D = int(hh_list[0].dim)
+        dev = torch.device(device) if device is not None else hh_list[0].w_0.device
+        Hs = torch.empty(len(hh_list), D, D, dtype=torch.float64, device=dev)     # one stack: batched composition below
+        HsT = torch.empty(len(hh_list), D, D, dtype=torch.float64, device=dev)
+        zero = torch.zeros(D, dtype=torch.float64, device=dev)
+        for i, h in enumerate(hh_list):
+            _ext.householder(_param(h.w_0, device), _param(h.vk_householder, device), out=Hs[i])
+        _ext.host_op(lambda: HsT.copy_(Hs.transpose(1, 2)))                       # (after the launches above)
+        for i, h in enumerate(hh_list):
+            res[id(h)] = dict(M=Hs[i], Minv=HsT[i], b=zero, ladj=zero.sum(), row=i)
+    seq = [b for b in blocks if isinstance(b, T.SequentialAffineTransform) and id(b) not in res]
+    # the USFlow constructor's block: Sequential([LU, Householder]) for every coupling block.  When the LU factors are
+    # rows first .. first+m-1 of one prepare chunk and the Householder factors rows 0 .. m-1 of their stack, the
+    # composition (transforms.py:1457-1476) is three batched launches instead of three per block
+    batched = False
+    if (len(seq) > 1 and len(chunks) == 1 and all(len(b.transforms) == 2 and isinstance(b.transforms[0], T.LUTransform)
+                                                  and isinstance(b.transforms[1], T.HouseholderTransform) for b in seq)):
+        lu_row = {id(l): j for j, l in enumerate(chunks[0]["lus"])}
+        rows = [lu_row[id(b.transforms[0])] for b in seq]
+        hrows = [res[id(b.transforms[1])]["row"] for b in seq]
+        m = len(seq)
+        if rows == list(range(rows[0], rows[0] + m)) and hrows == list(range(m)):
+            out, D = chunks[0]["out"], int(seq[0].dim)
+            DD, r0 = D * D, rows[0]
+            f64 = lambda *shape: torch.empty(*shape, dtype=torch.float64, device=Hs.device)
+            Mt, Mit, bt = f64(m, D, D), f64(m, D, D), f64(m, D)
+            bat = dict(batch=m, M=D, N=D, K=D, lda=D, ldb=D, ldc=D, strideA=DD, strideB=DD, strideC=DD)
+            _ext.gemm_f64(out["M"], Hs, Mt, a_off=r0 * DD, **bat)                          # M_lu H
+            _ext.gemm_f64(Hs, out["Minv"], Mit, transA=True, b_off=r0 * DD, **bat)         # H^T M_lu^-1
+            _ext.gemm_f64(chunks[0]["b"], Hs, bt, batch=m, M=1, N=D, K=D, lda=D, ldb=D, ldc=D, strideA=D, strideB=DD,
+                          strideC=D, a_off=r0 * D)                                         # b_lu H
+            for i, b in enumerate(seq):
+                res[id(b)] = dict(M=Mt[i], Minv=Mit[i], b=bt[i], ladj=out["ladj"][r0 + i])  # (Householder: ladj 0)
+            batched = True
+    for b in (seq if not batched else []):
+        if True:                                                                  # general composition, block by block
             parts = [res[id(t)] for t in b.transforms]
             M, Minv, bias = parts[0]["M"], parts[0]["Minv"], parts[0]["b"]      # eye @ M_1 == M_1 exactly
             ladj = parts[0]["ladj"]
