@@ -72,3 +72,64 @@ def test_shard_rows_partition():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        import emulator
+        from golden_util import load_case
+        from model_util import build_flow
+        from usflows_amd import training
+        from usflows_amd.parallel import data_parallel_training, shard_rows
+        emulator.install_training_emulation(pytest.MonkeyPatch())       # HIP entry points -> documented semantics on CPU
+        spec, sd, a = load_case("synth_d16_k3_densenn_relu")
+        flow = build_flow(spec, sd)
+        data_parallel_training(flow)
+        lo, hi = shard_rows(a["x"].shape[0], rank, world)               # 48 rows: 24 + 24
+        loss = -training.log_prob_with_grad(flow._train_obj, a["x"][lo:hi], None).mean()
+        loss.backward()
+        # (numpy: pickled by value -- torch tensors would travel as shared-memory handles that die with the worker)
+        q.put((rank, {n: p.grad.numpy().copy() for n, p in flow.named_parameters() if p.grad is not None}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_training_gradients_world2():
+    """two ranks, half the batch each, ONE all-reduce of the flat gradient arena: every rank ends with the
+    gradient of the full-batch mean loss"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulator
+    from golden_util import load_case
+    from model_util import build_flow
+    from usflows_amd import training
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mpatch = pytest.MonkeyPatch()
+    try:
+        emulator.install_training_emulation(mpatch)
+        spec, sd, a = load_case("synth_d16_k3_densenn_relu")
+        flow = build_flow(spec, sd)
+        path = training.TrainPath(flow)
+        (-training.log_prob_with_grad(path, a["x"], None).mean()).backward()
+        ref = {n: p.grad for n, p in flow.named_parameters() if p.grad is not None}
+    finally:
+        mpatch.undo()
+    assert set(res[0]) == set(ref) and len(ref) >= 10
+    for n, g in ref.items():
+        big = max(g.abs().max().item(), 1e-12)
+        for r in (0, 1):
+            assert (torch.from_numpy(res[r][n]) - g).abs().max().item() <= 1e-5 * big, (r, n)

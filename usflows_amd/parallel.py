@@ -43,6 +43,20 @@ def mean_log_prob(flow, x_shard: torch.Tensor, context: Optional[torch.Tensor] =
     return acc[0] / acc[1], lp
 
 
+def data_parallel_training(flow, group=None, average: bool = True) -> None:
+    """Replicated parameters, batch sharded over the ranks: after this call every backward pass of the device training
+    path (training.py) all-reduces the flow's gradients across ``group`` -- ONE collective per step over the flat
+    gradient arena (cfg2: 195 MB), averaged by default, so an optimiser step on every rank keeps the replicas
+    identical.  (Gradients produced outside the node -- a trainable radial norm distribution -- are not included.)
+    The reference has no distributed training; this is the data-parallel row of the scope table for ``Flow.fit``."""
+    from .training import TrainPath
+    if flow.engine() is None:
+        raise RuntimeError("data_parallel_training: this flow has no device form")
+    if flow._train_obj is None:
+        flow._train_obj = TrainPath(flow)
+    flow._train_obj.grad_allreduce = (group, average)
+
+
 def sample_sharded(flow, n_total: int, seed: int, rank: int, world_size: int) -> torch.Tensor:
     """this rank's rows of a global draw of ``n_total`` samples (same result for any world size)"""
     lo, hi = shard_rows(n_total, rank, world_size)

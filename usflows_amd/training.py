@@ -56,6 +56,9 @@ class TrainPath:
         self.eng: FlowEngine = flow.engine()
         self.generation = 0
         self._inv: Dict[tuple, torch.Tensor] = {}
+        # data-parallel training (parallel.data_parallel_training): (process group | None, average?) -- the whole flat
+        # gradient arena goes through ONE all-reduce per step (RCCL over xGMI with the "nccl" backend)
+        self.grad_allreduce = None
 
     # ---- eligibility ----------------------------------------------------------------------------------
     def supported(self, x: torch.Tensor, context) -> bool:
@@ -193,6 +196,13 @@ class TrainPath:
                     tape.stream = _ext.current_stream(dev)
                 plan["bwd_tape"], plan["bwd_pk"] = tape, pk
             flat = arena["flat"].clone()          # autograd may keep what we return: never hand out the arena itself
+            if self.grad_allreduce is not None:
+                import torch.distributed as dist
+                group, average = self.grad_allreduce
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+                    if average:
+                        flat /= dist.get_world_size(group)
         # parameters the path never reaches (a context layer without context) get no gradient, as under autograd
         return {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items()
                 if pid in arena["touched"]}
