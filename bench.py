@@ -81,6 +81,9 @@ def main():
     acc = torch.zeros(2, dtype=torch.float64, device=dev)
 
     opt = torch.optim.Adam(flow.parameters(), lr=1e-6) if args.mode == "train" else None
+    if args.mode == "train" and distributed:
+        from usflows_amd.parallel import data_parallel_training
+        data_parallel_training(flow)                       # one all-reduce of the flat gradient arena per step
 
     def step():
         if args.mode == "train":
