@@ -29,7 +29,21 @@ struct WgradArgs {
   float* G; int64_t ldg;       // single row range: the kernel writes alpha * acc + beta * G itself (no reduce launch)
   float alpha, beta;
   int direct;
+  int tiles, splits;           // 1-D grid, XCD-aware: see wg_decode
 };
+
+// Block -> (tile, row range).  Every tile column re-reads the Y slab and every tile row the A slab (7 x each at
+// 784 x 784), so per launch the blocks ask for 14 x the operand bytes; whether that comes from HBM or from L2 decides
+// the kernel (32 flop/byte per block: HBM-bound at ~90 TFLOP/s).  Consecutive block ids are dealt round-robin to the
+// 8 XCDs, each with an L2 of its own: all tiles of one row range are therefore given to ONE XCD (ids b, b + 8,
+// b + 16, ...), so that XCD's L2 serves the re-reads and HBM sees each operand row once.
+__device__ __forceinline__ bool wg_decode(const WgradArgs& a, int& tile, int& split) {
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  tile = q % a.tiles;
+  split = (q / a.tiles) * 8 + xcd;
+  return split < a.splits;
+}
 
 // 16 x 128 slab of a row-major matrix (rows m0.., columns c0..) -> two float4 per thread, zero outside [M) x [ncols)
 __device__ __forceinline__ void wg_load(const float* __restrict__ P, int64_t ld, int m0, int m_end, int c0, int ncols,
@@ -60,8 +74,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tilesK = (a.K + WG_T - 1) / WG_T;
-  const int n0 = (blockIdx.x / tilesK) * WG_T, k0 = (blockIdx.x % tilesK) * WG_T;
-  const int split = blockIdx.y;
+  int tile, split;
+  if (!wg_decode(a, tile, split)) return;
+  const int n0 = (tile / tilesK) * WG_T, k0 = (tile % tilesK) * WG_T;
   const int m_begin = split * a.rows_per_split;
   const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
   f32x4 acc[4][4];
@@ -163,13 +178,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // bf16x3 variant of wgrad (mode 1): same tiling, six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product
 // (x = x1 + x2 + x3 in bf16, terms below 2^-16 of the leading one dropped, fp32 accumulation).
 // The reduction index is the batch row, so an MFMA operand fragment is a COLUMN slice of Y / A: lane (i, g)
-// needs rows 8 g .. 8 g + 7 of column i.  The 32-row slab sits row-major in LDS with a row stride of 130 floats
-// (8 rows apart = 16 banks apart: the four lane groups of a ds_read_b32 hit disjoint banks) and every fragment
-// is gathered by 8 ds_read_b32 and split in registers.
+// needs rows 8 g .. 8 g + 7 of column i.
 // ---------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int WB_S = 32;       // batch rows per slab (one MFMA k-extent)
-constexpr int WB_LD = 130;
 
 __device__ __forceinline__ void wb_split(const float (&x)[8], bf16x8_t& p1, bf16x8_t& p2, bf16x8_t& p3) {
 #pragma unroll
@@ -204,16 +216,20 @@ __device__ __forceinline__ void wb_load(const float* __restrict__ P, int64_t ld,
   }
 }
 
+// Cooperative split: the block turns each 32 x 128 slab of Y and of A into bf16 planes ONCE (thread = 8 rows x 4
+// columns: 8 coalesced 16-byte row loads, 4 column slices of 8 rows -> 4 x 3 bf16x8 units) and leaves them in LDS in
+// fragment order [plane][k-group g][column] -- a fragment read is then a single conflict-free ds_read_b128 per plane
+// instead of 8 ds_read_b32 + a private split per wave (the two waves sharing a fragment used to split it twice).
 __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ys[2][WB_S][WB_LD];
-  __shared__ __attribute__((aligned(16))) float As[2][WB_S][WB_LD];
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) bf16x8_t Yp[3][4][WG_T];
+  __shared__ __attribute__((aligned(16))) bf16x8_t Ap[3][4][WG_T];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
   const int tilesK = (a.K + WG_T - 1) / WG_T;
-  const int n0 = (blockIdx.x / tilesK) * WG_T, k0 = (blockIdx.x % tilesK) * WG_T;
-  const int split = blockIdx.y;
+  int tile, split;
+  if (!wg_decode(a, tile, split)) return;
+  const int n0 = (tile / tilesK) * WG_T, k0 = (tile % tilesK) * WG_T;
   const int m_begin = split * a.rows_per_split;
   const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
   f32x4 acc[4][4];
@@ -225,55 +241,71 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
   const int ni = rem_n <= 0 ? 0 : (rem_n >= 64 ? 4 : (rem_n + 15) / 16);
   const int nj = rem_k <= 0 ? 0 : (rem_k >= 64 ? 4 : (rem_k + 15) / 16);
 
-  f32x4 ry[4], ra[4];
-  auto stage = [&](int buf) {
+  // loader role: threads 0..127 carry Y, 128..255 carry A; (row group rg = k-group, column group cg)
+  const bool isA = tid >= 128;
+  const int lt = tid & 127, rg = lt >> 5, cg = lt & 31;
+  const float* __restrict__ src = isA ? a.A : a.Y;
+  const int64_t ld = isA ? a.lda : a.ldy;
+  const int c_base = (isA ? k0 : n0) + 4 * cg;
+  const int ncols = isA ? a.K : a.N;
+  bf16x8_t (*dstp)[4][WG_T] = isA ? Ap : Yp;
+  f32x4 v[8];
+  auto fetch = [&](int m0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 5) + 8 * i, col = (tid & 31) * 4;
-      *reinterpret_cast<f32x2*>(&Ys[buf][row][col]) = (f32x2){ry[i][0], ry[i][1]};
-      *reinterpret_cast<f32x2*>(&Ys[buf][row][col + 2]) = (f32x2){ry[i][2], ry[i][3]};
-      *reinterpret_cast<f32x2*>(&As[buf][row][col]) = (f32x2){ra[i][0], ra[i][1]};
-      *reinterpret_cast<f32x2*>(&As[buf][row][col + 2]) = (f32x2){ra[i][2], ra[i][3]};
+    for (int e = 0; e < 8; ++e) {
+      const int m = m0 + 8 * rg + e;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        const float* p = src + (int64_t)m * ld + c_base;
+        if (c_base + 3 < ncols) {
+          x = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c_base + q < ncols) x[q] = p[q];
+        }
+      }
+      v[e] = x;
     }
   };
-  int buf = 0;
-  if (m_begin < m_end) {
-    wb_load(a.Y, a.ldy, m_begin, m_end, n0, a.N, tid, ry);
-    wb_load(a.A, a.lda, m_begin, m_end, k0, a.K, tid, ra);
-    stage(0);
-  }
-  __syncthreads();
+  auto split_store = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float col[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) col[e] = v[e][q];
+      bf16x8_t p1, p2, p3;
+      wb_split(col, p1, p2, p3);
+      dstp[0][rg][4 * cg + q] = p1;
+      dstp[1][rg][4 * cg + q] = p2;
+      dstp[2][rg][4 * cg + q] = p3;
+    }
+  };
+  if (m_begin < m_end) fetch(m_begin);
   for (int m0 = m_begin; m0 < m_end; m0 += WB_S) {
-    const bool more = m0 + WB_S < m_end;
-    if (more) {
-      wb_load(a.Y, a.ldy, m0 + WB_S, m_end, n0, a.N, tid, ry);
-      wb_load(a.A, a.lda, m0 + WB_S, m_end, k0, a.K, tid, ra);
-    }
-    // operand planes of this slab: 4 feature sub-tiles of Y, 4 of A (lane (i, g): rows 8 g .. 8 g + 7 of column i)
-    bf16x8_t yp[4][3], ap[4][3];
+    __syncthreads();                       // the previous slab's fragment reads are done
+    split_store();
+    __syncthreads();
+    if (m0 + WB_S < m_end) fetch(m0 + WB_S);
+    bf16x8_t yp[4][3];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float fy[8], fa[8];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        fy[e] = Ys[buf][8 * lg + e][wn * 64 + t * 16 + li];
-        fa[e] = As[buf][8 * lg + e][wk * 64 + t * 16 + li];
-      }
-      wb_split(fy, yp[t][0], yp[t][1], yp[t][2]);
-      wb_split(fa, ap[t][0], ap[t][1], ap[t][2]);
-    }
+      for (int pl = 0; pl < 3; ++pl) yp[t][pl] = Yp[pl][lg][wn * 64 + t * 16 + li];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      if (j >= nj) break;
+      bf16x8_t ap[3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (i < ni && j < nj) {
-#define USF_WB(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][P], ap[j][Q], acc[i][j], 0, 0, 0)
+      for (int pl = 0; pl < 3; ++pl) ap[pl] = Ap[pl][lg][wk * 64 + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < ni) {
+#define USF_WB(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][P], ap[Q], acc[i][j], 0, 0, 0)
           USF_WB(2, 0); USF_WB(1, 1); USF_WB(0, 2); USF_WB(1, 0); USF_WB(0, 1); USF_WB(0, 0);   // smallest terms first
 #undef USF_WB
         }
-    if (more) stage(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    }
   }
   float* out = a.part + (int64_t)split * a.N * a.K;
 #pragma unroll
@@ -287,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
         if (n < a.N && k < a.K) {
           if (a.direct) {
             float* dst = a.G + (int64_t)n * a.ldg + k;
-            float v = a.alpha * acc[i][j][r];
-            if (a.beta != 0.f) v += a.beta * *dst;
-            *dst = v;
+            float vv = a.alpha * acc[i][j][r];
+            if (a.beta != 0.f) vv += a.beta * *dst;
+            *dst = vv;
           } else {
             out[(int64_t)n * a.K + k] = acc[i][j][r];
           }
@@ -411,11 +443,12 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
   int rows = (int)((M + splits - 1) / splits);
   rows = (rows + WB_S - 1) / WB_S * WB_S;
   WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S, G, ldg, alpha, beta,
-              splits == 1 ? 1 : 0};
+              splits == 1 ? 1 : 0, (int)tiles, splits};
+  const unsigned grid = (unsigned)(tiles * ((splits + 7) / 8) * 8);
   if (mode != 0 && mode != 1) { set_error("usf_wgrad_f32: mode must be 0 (exact f32) or 1 (bf16x3)"); return -2; }
   // the split-precision kernel pays off once the chip has real work (its operand split costs VALU per slab)
-  if (mode == 1 && M >= 2048) wgrad_bf16x3_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
-  else wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, 0, stream>>>(a);
+  if (mode == 1 && M >= 2048) wgrad_bf16x3_kernel<<<grid, 256, 0, stream>>>(a);
+  else wgrad_kernel<<<grid, 256, 0, stream>>>(a);
   if (splits > 1) {
     int64_t rb = (N * K + 255) / 256;
     if (rb > 4096) rb = 4096;
