@@ -170,3 +170,15 @@ def test_replayed_tapes_track_parameter_updates(name):
     assert all(p is packs[0] for p in packs), "the pack was rebuilt instead of refreshed in place"
     plan = next(p for k, p in flow.engine()._plans.items() if k[-1])
     assert plan["bwd_tape"] is not None and len(plan["bwd_tape"].entries) > 10
+
+
+def test_single_row_batch_under_autograd():
+    """(an empty batch under autograd takes the composite loop, which fails inside torch's Independent.log_prob exactly
+    as the reference does; without grad it returns an empty tensor, tests/test_flow_gpu.py)"""
+    spec, sd, a = load_case("synth_d16_k3_densenn_relu")
+    flow = build_flow(spec, sd, device=DEV)
+    lp1 = flow.log_prob(a["x"][:1].to(DEV))
+    lp1.sum().backward()
+    lp_ref, g_ref = oracle_grads(spec, sd, a["x"][:1], torch.ones(1))
+    assert abs(lp1.item() - lp_ref.item()) < 1e-5 * abs(lp_ref.item())
+    assert _compare(flow, g_ref) >= 5

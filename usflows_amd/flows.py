@@ -164,7 +164,7 @@ class Flow(torch.nn.Module):
 
     def _train_path(self, x: torch.Tensor, context=None):
         """the device training path (training.py) when this call needs gradients of the parameters only"""
-        if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled()):
+        if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and torch.is_grad_enabled()):
             return None
         if getattr(self, "_train_failed", False) or not self.use_device_training or self.engine() is None:
             return None
