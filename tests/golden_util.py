@@ -13,7 +13,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def case_names(small_only=False):
-    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                   if not os.path.basename(p).startswith("grads_"))
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -42,3 +43,14 @@ def load_case(name):
     if "base_scale" in arrays:
         spec.base_scale = arrays["base_scale"]
     return spec, sd, arrays
+
+
+def grad_case_names():
+    """cases with golden GRADIENTS of the training loss from the real reference (tests/golden/make_golden_grads.py)"""
+    return sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "grads_*.npz")))
+
+
+def load_grads(name):
+    """(loss, {parameter name: d(-log_prob(x, context).mean()) / d parameter}) of the reference's fp64 run"""
+    z = np.load(os.path.join(GOLDEN_DIR, "grads_" + name + ".npz"), allow_pickle=False)
+    return float(z["loss"]), {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}

@@ -123,3 +123,34 @@ def test_oracle_vs_live_reference():
     with torch.no_grad():
         ref = flow.log_prob(x)
     assert _rel(orc.flow_log_prob(sd, spec, x), ref) < 2e-6
+
+
+# ---- the oracle's GRADIENTS against the real reference's (tests/golden/grads_*.npz) ---------------------------
+from golden_util import grad_case_names, load_grads  # noqa: E402
+
+
+@pytest.mark.parametrize("name", grad_case_names())
+def test_oracle_autograd_matches_reference_gradients(name):
+    """what Flow.fit differentiates (flows.py:196-199): -log_prob(x, context).mean(); fp64 on both sides"""
+    import copy
+    spec, sd, a = load_case(name)
+    loss_ref, g_ref = load_grads(name)
+    sd64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    if spec.base == "radial":
+        spec = copy.copy(spec)
+        spec.base_loc = sd64["base_distribution.loc"]
+    ctx = a["context"].double() if "context" in a else None
+    if ctx is None and spec.soft_training:
+        ctx = torch.zeros(a["x"].shape[0], 1, dtype=torch.float64)
+    loss = -orc.flow_log_prob(sd64, spec, a["x"].double(), ctx).mean()
+    loss.backward()
+    assert abs(loss.item() - loss_ref) <= 1e-10 * abs(loss_ref)
+    checked = 0
+    for k, ref in g_ref.items():
+        if "norm_distribution" in k:
+            continue                       # constants in the oracle's FlowSpec
+        got = sd64[k].grad
+        assert got is not None, k
+        assert (got - ref.reshape(got.shape)).abs().max().item() <= 1e-9 * max(1.0, ref.abs().max().item()), k
+        checked += 1
+    assert checked >= 20

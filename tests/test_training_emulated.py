@@ -84,3 +84,34 @@ def test_autograd_node_and_optimizer_step(monkeypatch):
             n += 1
     assert n >= 5
     assert abs(loss.item() + lp_ref.mean().item()) < 2e-5 * abs(lp_ref.mean().item())
+
+
+from golden_util import grad_case_names, load_grads  # noqa: E402
+
+
+@pytest.mark.parametrize("name", grad_case_names())
+def test_training_path_matches_reference_gradients(name):
+    """the device training path's host logic (entry points emulated) against gradients computed by the REAL
+    reference (tests/golden/grads_*.npz, fp64): loss = -log_prob(x, context).mean() as in Flow.fit"""
+    from usflows_amd import training
+    spec, sd, a = load_case(name)
+    loss_ref, g_ref = load_grads(name)
+    flow = build_flow(spec, sd)
+    x = a["x"]
+    ctx = a.get("context")
+    if ctx is None and spec.soft_training:
+        ctx = torch.zeros(x.shape[0], 1)
+    loss = -training.log_prob_with_grad(TrainPath(flow), x, ctx).mean()
+    loss.backward()
+    assert abs(loss.item() - loss_ref) <= 2e-5 * abs(loss_ref)
+    checked = 0
+    for pname, p in flow.named_parameters():
+        if pname not in g_ref:
+            assert p.grad is None or not p.requires_grad or p.grad.abs().max().item() < 1e-6, pname
+            continue
+        ref = g_ref[pname].reshape(p.shape)
+        assert p.grad is not None, pname
+        tol = 2e-4 * max(ref.abs().max().item(), 1e-9)
+        assert (p.grad.double() - ref).abs().max().item() <= tol, pname
+        checked += 1
+    assert checked >= 20

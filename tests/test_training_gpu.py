@@ -182,3 +182,31 @@ def test_single_row_batch_under_autograd():
     lp_ref, g_ref = oracle_grads(spec, sd, a["x"][:1], torch.ones(1))
     assert abs(lp1.item() - lp_ref.item()) < 1e-5 * abs(lp_ref.item())
     assert _compare(flow, g_ref) >= 5
+
+
+from golden_util import grad_case_names, load_grads  # noqa: E402
+
+
+@pytest.mark.parametrize("name", grad_case_names())
+def test_device_gradients_match_the_real_reference(name):
+    """Flow.fit's loss differentiated on the MI355X (HIP forward + HIP backward) against the gradients the REAL
+    reference computed in fp64 (tests/golden/grads_*.npz, made by tests/golden/make_golden_grads.py)"""
+    spec, sd, a = load_case(name)
+    loss_ref, g_ref = load_grads(name)
+    flow = build_flow(spec, sd, device=DEV)
+    ctx = a.get("context")
+    before = flow.engine().launch_count
+    loss = -flow.log_prob(a["x"].to(DEV), ctx.to(DEV) if ctx is not None else None).mean()
+    loss.backward()
+    assert flow.engine().launch_count > before
+    assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref)
+    checked = 0
+    for pname, p in flow.named_parameters():
+        if pname not in g_ref:
+            assert p.grad is None or p.grad.abs().max().item() < 1e-6, pname
+            continue
+        ref = g_ref[pname].reshape(p.shape)
+        assert p.grad is not None, pname
+        assert (p.grad.cpu().double() - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-9), pname
+        checked += 1
+    assert checked >= 20
