@@ -67,6 +67,19 @@ def test_lu_prepare_identity_known_answer():
     assert out["ladj"][0].item() == 0.0
 
 
+def test_lu_prepare_reference_known_answer():
+    """the reference's own LU test (tests/veriflow/transforms_test.py:35-51): L = tril(ones), U = I, b = 0 =>
+    y = M x = arange(dim) + 1 for x = ones, exact inverse, log|det J| = 0 -- through the device prep kernels"""
+    ext = _ext()
+    D = 10
+    out = ext.lu_prepare([torch.ones(D, D, device=DEV)], [torch.eye(D, device=DEV)])
+    ones = torch.ones(D, dtype=torch.float64, device=DEV)
+    y = out["M"][0] @ ones
+    assert torch.equal(y.cpu(), torch.arange(D, dtype=torch.float64) + 1)
+    assert torch.equal((out["Minv"][0] @ y).cpu(), torch.ones(D, dtype=torch.float64))
+    assert out["ladj"][0].item() == 0.0
+
+
 @pytest.mark.parametrize("transA", [False, True])
 @pytest.mark.parametrize("transB", [False, True])
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 16), (65, 130, 33), (200, 77, 129)])
