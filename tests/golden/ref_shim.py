@@ -40,6 +40,15 @@ from torch.distributions import Independent, Laplace, Normal, Uniform, Dirichlet
 from . import transforms as transforms       # pyro.distributions.transforms (Permute name only)
 
 
+class TransformedDistribution(TransformedDistribution):
+    # pyro's subclass adds clear_cache() (Flow.fit calls it after every optimiser step, flows.py:207): drops the
+    # cached (x, y) pairs of the transforms -- plumbing, no arithmetic
+    def clear_cache(self):
+        for t in self.transforms:
+            if getattr(t, "_cache_size", 0) == 1:
+                t._cached_x_y = None, None
+
+
 class TransformModule(torch.distributions.Transform, torch.nn.Module):
     # class plumbing only: pyro's TransformModule is exactly this multiple inheritance
     def __init__(self, *args, **kwargs):

@@ -14,7 +14,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names(small_only=False):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith("grads_"))
+                   if not os.path.basename(p).startswith(("grads_", "fit_")))
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -54,3 +54,16 @@ def load_grads(name):
     """(loss, {parameter name: d(-log_prob(x, context).mean()) / d parameter}) of the reference's fp64 run"""
     z = np.load(os.path.join(GOLDEN_DIR, "grads_" + name + ".npz"), allow_pickle=False)
     return float(z["loss"]), {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}
+
+
+def fit_case_names():
+    """cases with a golden Flow.fit run of the real reference (tests/golden/make_golden_fit.py)"""
+    return sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "fit_*.npz")))
+
+
+def load_fit(name):
+    """(training rows, per-epoch losses, state dict after the run) of the reference's Flow.fit:
+    2 epochs of SGD(lr=1e-3), batch 32, shuffle=True under numpy seed 5"""
+    z = np.load(os.path.join(GOLDEN_DIR, "fit_" + name + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd

@@ -207,3 +207,38 @@ def test_convnet_vector_path_layout_and_engine_view():
     assert default(x).shape == (9, 6) and not conditioner_supported(default)
     with pytest.raises(NotImplementedError):
         ConvNet([3, 8, 8], [4])
+
+
+# ---- Flow.fit against a golden run of the real reference (tests/golden/fit_*.npz) ---------------------------------
+def _run_fit(flow, data, device):
+    import numpy as np
+    ds = torch.utils.data.TensorDataset(data, torch.zeros(data.shape[0]))
+    np.random.seed(5)
+    return flow.fit(ds, optim=torch.optim.SGD, optim_params=dict(lr=1e-3), batch_size=32, shuffle=True,
+                    device=torch.device(device), epochs=2)
+
+
+def _check_fit(flow, losses, losses_ref, sd_ref, tol):
+    for a, b in zip(losses, losses_ref):
+        assert abs(a - b) <= 1e-4 * abs(b), (losses, losses_ref)
+    sd = flow.state_dict()
+    n = 0
+    for k, ref in sd_ref.items():
+        if not ref.is_floating_point() or k not in sd:
+            continue
+        got = sd[k].detach().cpu()
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), k
+        n += 1
+    assert n >= 20
+
+
+def test_fit_matches_reference_run_cpu():
+    """the mirror's training loop (shuffling, batching, loss, SGD steps) on CPU = the composite formulation"""
+    from golden_util import fit_case_names, load_case, load_fit
+    from model_util import build_flow
+    for name in fit_case_names():
+        spec, sd, _ = load_case(name)
+        data, losses_ref, sd_ref = load_fit(name)
+        flow = build_flow(spec, sd)
+        losses = _run_fit(flow, data, "cpu")
+        _check_fit(flow, losses, losses_ref, sd_ref, 2e-5)

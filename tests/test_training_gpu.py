@@ -210,3 +210,19 @@ def test_device_gradients_match_the_real_reference(name):
         assert (p.grad.cpu().double() - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-9), pname
         checked += 1
     assert checked >= 20
+
+
+def test_fit_on_device_matches_reference_run():
+    """Flow.fit on the MI355X (HIP forward + backward, launch tapes replayed from step 2, pack refreshed in place
+    after every SGD step) against the golden run of the REAL reference's Flow.fit: per-epoch losses and every
+    parameter after the 6 steps"""
+    from golden_util import fit_case_names, load_fit
+    from test_modules_cpu import _check_fit, _run_fit
+    for name in fit_case_names():
+        spec, sd, _ = load_case(name)
+        data, losses_ref, sd_ref = load_fit(name)
+        flow = build_flow(spec, sd, device=DEV)
+        before = flow.engine().launch_count
+        losses = _run_fit(flow, data, DEV)
+        assert flow.engine().launch_count > before and not getattr(flow, "_train_failed", False)
+        _check_fit(flow, losses, losses_ref, sd_ref, 5e-5)
