@@ -14,7 +14,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names(small_only=False):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("grads_", "fit_")))
+                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_")))
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -67,3 +67,15 @@ def load_fit(name):
     z = np.load(os.path.join(GOLDEN_DIR, "fit_" + name + ".npz"), allow_pickle=False)
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
     return torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd
+
+
+def udl_case_names():
+    """radial cases with golden UDL profiles of the real reference (tests/golden/make_golden_udl.py)"""
+    return sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "udl_*.npz")))
+
+
+def load_udl(name):
+    z = np.load(os.path.join(GOLDEN_DIR, "udl_" + name + ".npz"), allow_pickle=False)
+    return dict(q=float(z["q"]), r_max=float(z["r_max"]), n_samples=int(z["n_samples"]),
+                cut=torch.from_numpy(z["cut"]), full=torch.from_numpy(z["full"]),
+                latent_radius=torch.from_numpy(z["latent_radius"]))

@@ -314,3 +314,16 @@ def test_cfg2_scale_variants_of_the_live_configs(hh, conj):
     base = torch.distributions.Laplace(torch.zeros(784), torch.ones(784)).log_prob(z.cpu()).sum(-1)
     c = (lp.cpu() - base).double()
     assert (c - c.mean()).abs().max().item() < 1e-5 * abs(c.mean().item()) + 2e-2
+
+
+def test_udl_profile_on_device_matches_reference():
+    """calibrated_latent_radial_udl_profile (flows.py:294-378) with the latents from the device backward pass against
+    the profiles the REAL reference computed (tests/golden/udl_*.npz)"""
+    from golden_util import load_udl, udl_case_names
+    from test_modules_cpu import _check_udl
+    for name in udl_case_names():
+        spec, sd, a = load_case(name)
+        flow = build_flow(spec, sd, device=DEV)
+        before = flow.engine().launch_count
+        _check_udl(flow, a["x"].to(DEV), load_udl(name))
+        assert flow.engine().launch_count > before

@@ -242,3 +242,22 @@ def test_fit_matches_reference_run_cpu():
         flow = build_flow(spec, sd)
         losses = _run_fit(flow, data, "cpu")
         _check_fit(flow, losses, losses_ref, sd_ref, 2e-5)
+
+
+# ---- the UDL machinery (flows.py:294-378, distributions.py:390-456) against the real reference -------------------
+def _check_udl(flow, x, g):
+    step = g["r_max"] / g["n_samples"]
+    for cut in (True, False):
+        prof = flow.calibrated_latent_radial_udl_profile(g["q"], x, r_max=g["r_max"], n_samples=g["n_samples"],
+                                                         cut_to_data_tail=cut).cpu().double()
+        ref = g["cut" if cut else "full"]
+        assert prof.shape == ref.shape, (prof, ref)
+        assert (prof - ref).abs().max().item() <= 1.5 * step, (prof, ref)      # interval ends sit on the r grid
+
+
+def test_udl_profile_matches_reference_cpu():
+    from golden_util import load_case, load_udl, udl_case_names
+    from model_util import build_flow
+    for name in udl_case_names():
+        spec, sd, a = load_case(name)
+        _check_udl(build_flow(spec, sd), a["x"], load_udl(name))
