@@ -20,15 +20,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import make_golden as mg  # noqa: E402
 from golden_util import load_case  # noqa: E402
 
-CASES = ["synth_d7_k3_hh0_laplace", "synth_d16_k3_hh1_radial2"]
+# (case, prior_scale): with a prior scale the loss carries -log_prior() (LUTransform.log_prior, transforms.py:1371-1379)
+CASES = [("synth_d7_k3_hh0_laplace", None), ("synth_d16_k3_hh1_radial2", None), ("synth_d7_k3_hh1_conj_normal", 0.5)]
 LR, NP_SEED, N_ROWS, BATCH, EPOCHS = 1e-3, 5, 96, 32, 2
 
 
 def main():
-    for name in CASES:
+    for name, prior_scale in CASES:
         spec, sd, a = load_case(name)
         seed = int(np.load(os.path.join(HERE, name + ".npz"))["seed"])
         flow = mg.build_reference(spec, seed)
+        if prior_scale is not None:
+            # same constructor call as make_golden.build_reference, plus the prior scale (flows.py:397)
+            act = torch.nn.LeakyReLU(spec.negative_slope)
+            flow = mg.flows.USFlow(mg.make_base(spec), [spec.dim], spec.coupling_blocks, mg.networks.ConditionalDenseNN,
+                                   dict(input_dim=spec.dim, context_dim=1, hidden_dims=list(spec.hidden_dims),
+                                        out_dim=spec.dim, nonlinearity=act),
+                                   affine_conjugation=spec.affine_conjugation, lu_transform=spec.lu_transform,
+                                   householder=spec.householder, prior_scale=prior_scale)
         res = flow.load_state_dict(sd, strict=False)
         assert not res.unexpected_keys
         data = torch.rand(N_ROWS, spec.dim, generator=torch.Generator().manual_seed(77))
@@ -36,7 +45,8 @@ def main():
         np.random.seed(NP_SEED)
         losses = flow.fit(ds, optim=torch.optim.SGD, optim_params=dict(lr=LR), batch_size=BATCH, shuffle=True,
                           device=torch.device("cpu"), epochs=EPOCHS)
-        arrays = {"losses": np.array(losses, dtype=np.float64), "data": data.numpy()}
+        arrays = {"losses": np.array(losses, dtype=np.float64), "data": data.numpy(),
+                  "prior_scale": np.array(-1.0 if prior_scale is None else prior_scale)}
         for k, v in flow.state_dict().items():
             arrays["sd/" + k] = v.detach().numpy()
         path = os.path.join(HERE, "fit_" + name + ".npz")

@@ -66,7 +66,8 @@ def load_fit(name):
     2 epochs of SGD(lr=1e-3), batch 32, shuffle=True under numpy seed 5"""
     z = np.load(os.path.join(GOLDEN_DIR, "fit_" + name + ".npz"), allow_pickle=False)
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
-    return torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd
+    ps = float(z["prior_scale"]) if "prior_scale" in z.files else -1.0
+    return torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd, (None if ps < 0 else ps)
 
 
 def udl_case_names():

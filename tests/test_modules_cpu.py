@@ -238,7 +238,9 @@ def test_fit_matches_reference_run_cpu():
     from model_util import build_flow
     for name in fit_case_names():
         spec, sd, _ = load_case(name)
-        data, losses_ref, sd_ref = load_fit(name)
+        data, losses_ref, sd_ref, prior_scale = load_fit(name)
+        if prior_scale is not None:
+            spec.extra["prior_scale"] = prior_scale      # the loss then carries -log_prior() (transforms.py:1371-1379)
         flow = build_flow(spec, sd)
         losses = _run_fit(flow, data, "cpu")
         _check_fit(flow, losses, losses_ref, sd_ref, 2e-5)

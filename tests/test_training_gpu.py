@@ -220,7 +220,9 @@ def test_fit_on_device_matches_reference_run():
     from test_modules_cpu import _check_fit, _run_fit
     for name in fit_case_names():
         spec, sd, _ = load_case(name)
-        data, losses_ref, sd_ref = load_fit(name)
+        data, losses_ref, sd_ref, prior_scale = load_fit(name)
+        if prior_scale is not None:
+            spec.extra["prior_scale"] = prior_scale      # the loss then carries -log_prior() (transforms.py:1371-1379)
         flow = build_flow(spec, sd, device=DEV)
         before = flow.engine().launch_count
         losses = _run_fit(flow, data, DEV)

@@ -178,7 +178,8 @@ def build_usflow(spec: ModelSpec, sd: Optional[Dict[str, torch.Tensor]] = None, 
     prior = torch.distributions.Uniform(1e-20, 0.01) if spec.soft_training else None
     flow = USFlow(make_base(spec, device), [spec.dim], spec.coupling_blocks, cls, args, soft_training=spec.soft_training,
                   training_noise_prior=prior, affine_conjugation=spec.affine_conjugation,
-                  lu_transform=spec.lu_transform, householder=spec.householder)
+                  lu_transform=spec.lu_transform, householder=spec.householder,
+                  prior_scale=spec.extra.get("prior_scale"))
     if sd is not None:
         res = flow.load_state_dict(sd, strict=False)
         assert not res.unexpected_keys, res.unexpected_keys

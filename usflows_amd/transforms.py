@@ -470,8 +470,8 @@ class SequentialAffineTransform(AffineTransform):
         for t in self.transforms:
             t.add_jitter(jitter)
 
-    def log_prior(self):
-        return sum(t.log_prior() for t in self.transforms)
+    # (no log_prior override: the reference's SequentialAffineTransform, transforms.py:1381-1486, inherits
+    # BaseTransform.log_prior == 0.0 -- see BlockAffineTransform below)
 
     def to(self, device):
         for t in self.transforms:
@@ -523,8 +523,10 @@ class BlockAffineTransform(BaseTransform):
     def add_jitter(self, jitter: float = 1e-6):
         self.block_transform.add_jitter(jitter)
 
-    def log_prior(self):
-        return self.block_transform.log_prior()
+    # No log_prior override, exactly as in the reference (transforms.py:874-1029): BlockAffineTransform inherits
+    # BaseTransform.log_prior == 0.0 (transforms.py:62-64), so LUTransform.log_prior (transforms.py:1371-1379) is never
+    # reached through USFlow.log_prior (flows.py:538-549) and prior_scale does not change the training loss.  Pinned by
+    # the golden Flow.fit run with prior_scale = 0.5 (tests/golden/fit_synth_d7_k3_hh1_conj_normal.npz).
 
     def simplify(self):
         return BlockAffineTransform(self.in_dims, self.block_transform._to_plane_linear())
