@@ -99,8 +99,16 @@ def test_feasibility_and_jitter():
     spec, sd, _ = load_case("synth_d7_k3_hh0_laplace")
     flow = build_flow(spec, sd)
     assert flow.is_feasible()
+    lu = flow.layers[0].block_transform.transforms[0]
     with torch.no_grad():
-        flow.layers[0].block_transform.transforms[0].U_raw[2, 2] = 0.0
+        lu.U_raw[2, 2] = 0.0
+    # as in the reference, the wrappers (BlockAffineTransform / SequentialAffineTransform) do not forward
+    # is_feasible / add_jitter (transforms.py:32-34): only the LU factor itself reports the zero pivot
+    assert flow.is_feasible() and not lu.is_feasible()
+    lu.add_jitter(1e-3)
+    assert lu.is_feasible()
+    with torch.no_grad():
+        flow.layers[-1].scale[1] = 0.0          # ScaleTransform is a direct layer: this one Flow.is_feasible sees
     assert not flow.is_feasible()
     flow.add_jitter(1e-3)
     assert flow.is_feasible()
