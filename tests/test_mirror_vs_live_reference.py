@@ -114,3 +114,78 @@ def test_soft_training_context_side_by_side():
     with torch.no_grad():
         assert torch.allclose(ref.log_prob(x), mine.log_prob(x), rtol=1e-5)              # implicit zero context
         assert torch.allclose(ref.log_prob(x, context=ctx), mine.log_prob(x, context=ctx), rtol=1e-5)
+
+
+# ---- distributions (distributions.py): the radial base and its parametrised norm distributions ----------------------
+@pytest.mark.parametrize("p", [1.0, 2.0, float("inf")])
+def test_radial_distribution_side_by_side(p):
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import ref_shim
+    _, _, _, rdist = ref_shim.install()
+    from usflows_amd import distributions as mdist
+    D = 9
+    loc = torch.linspace(-0.3, 0.4, D)
+    ref = rdist.RadialDistribution(loc.clone(), rdist.LogNormal(torch.tensor([0.8]), torch.tensor([0.4])), p)
+    mine = mdist.RadialDistribution(loc.clone(), mdist.LogNormal(torch.tensor([0.8]), torch.tensor([0.4])), p)
+    assert sorted(ref.state_dict()) == sorted(mine.state_dict())
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(11, D, generator=torch.Generator().manual_seed(2)) * 2
+    r = torch.linspace(0.05, 9.0, 17)
+    with torch.no_grad():
+        assert torch.allclose(ref.log_prob(x), mine.log_prob(x), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(ref.r_profile(r), mine.r_profile(r), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(ref.log_delta_volume(p, r), mine.log_delta_volume(p, r), rtol=1e-6)
+        for thr in (-25.0, -18.0):
+            a = ref.radial_udl_profile(threshold=torch.tensor(thr), r_max=40.0, n_samples=4000)
+            b = mine.radial_udl_profile(threshold=torch.tensor(thr), r_max=40.0, n_samples=4000)
+            assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5), thr
+            a = ref.radial_ldl_profile(threshold=torch.tensor(thr), r_max=40.0, n_samples=4000)
+            b = mine.radial_ldl_profile(threshold=torch.tensor(thr), r_max=40.0, n_samples=4000)
+            assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5), thr
+        for shape in (None, [5], [2, 3]):
+            assert tuple(ref.sample(shape).shape) == tuple(mine.sample(shape).shape), shape
+        assert float(ref.unit_ball_distribution.log_prob(x[0])) == pytest.approx(
+            float(mine.unit_ball_distribution.log_prob(x[0])), rel=1e-6)
+
+
+@pytest.mark.parametrize("cls", ["LogNormal", "Laplace", "Normal", "Gamma"])
+def test_distribution_modules_side_by_side(cls):
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import ref_shim
+    _, _, _, rdist = ref_shim.install()
+    from usflows_amd import distributions as mdist
+    a, b = torch.tensor([0.3, 1.1]), torch.tensor([0.6, 1.4])
+    ref, mine = getattr(rdist, cls)(a.clone(), b.clone()), getattr(mdist, cls)(a.clone(), b.clone())
+    assert sorted(ref.state_dict()) == sorted(mine.state_dict())
+    mine.load_state_dict(ref.state_dict())
+    v = torch.tensor([[0.2, 0.9], [1.7, 2.5]])
+    with torch.no_grad():
+        assert torch.allclose(ref.log_prob(v), mine.log_prob(v), rtol=1e-5, atol=1e-6)
+        assert tuple(ref.sample([4]).shape) == tuple(mine.sample([4]).shape)
+
+
+# ---- conditioners (networks.py): same state-dict keys, same outputs with and without context ------------------------
+def test_conditioners_side_by_side():
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import ref_shim
+    _, _, rnet, _ = ref_shim.install()
+    from usflows_amd import networks as mnet
+    torch.manual_seed(11)
+    act = torch.nn.LeakyReLU(0.01)
+    pairs = [
+        (rnet.ConditionalDenseNN(input_dim=9, context_dim=1, hidden_dims=[14, 10], out_dim=9, nonlinearity=act),
+         mnet.ConditionalDenseNN(input_dim=9, context_dim=1, hidden_dims=[14, 10], out_dim=9, nonlinearity=act)),
+        (rnet.ConvNet(in_dims=[9], c_hidden=[12, 8], nonlinearity=act, normalize_layers=False, gating=False),
+         mnet.ConvNet(in_dims=[9], c_hidden=[12, 8], nonlinearity=act, normalize_layers=False, gating=False)),
+        (rnet.ConvNet(in_dims=[9], c_hidden=[12, 8], nonlinearity=act),          # defaults: gated + layer-normalised
+         mnet.ConvNet(in_dims=[9], c_hidden=[12, 8], nonlinearity=act)),
+    ]
+    x = torch.rand(6, 9)
+    ctx = torch.rand(6, 1)
+    for ref, mine in pairs:
+        assert sorted(ref.state_dict()) == sorted(mine.state_dict()), type(ref).__name__
+        mine.load_state_dict(ref.state_dict())
+        with torch.no_grad():
+            assert torch.allclose(ref(x), mine(x), rtol=1e-5, atol=1e-6), type(ref).__name__
+            if isinstance(ref, rnet.ConditionalDenseNN):
+                assert torch.allclose(ref(x, ctx), mine(x, ctx), rtol=1e-5, atol=1e-6)
