@@ -6,6 +6,9 @@
 2. `rocprofv3 --kernel-trace --stats -- python3 bench.py`          -> <tag>_bench_kernel_stats.{csv,md}, <tag>_bench_under_rocprof.json
 3. `rocprofv3 --pmc FETCH_SIZE` and, separately, `--pmc WRITE_SIZE` on a short bench run
                                                                    -> <tag>_hbm_traffic.json
+3b. `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE` (own pass)        -> <tag>_mfma_util.json
+4. `bench.py --mode train` at 128 / 4096 / 65536 rows (+ the composite path at 4096), kernel stats of the training run
+                                                                   -> <tag>_train_bench.jsonl, <tag>_train_kernel_stats.md
 This script never touches the GPU itself (every step is a child process), so the profiler wraps the
 program directly.
 """
@@ -98,6 +101,47 @@ json.dump({
              "the same run: base_logprob_kernel streams 205.5 MB with 16-B coalesced lane loads (its FETCH_SIZE should read 0.50x of "
              "that). algorithmic_bytes_per_launch: activations in + out once, weights once.",
     "kernels": kern}, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+
+# 3b. matrix-pipe utilisation (own PMC pass: SQ + GRBM counters, no tracing options)
+def mfma_util(csv_path, out_path):
+    agg2 = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(csv_path)):
+        k = row["Kernel_Name"]
+        if "usf::" not in k:
+            continue
+        k = k[k.index("usf::") + 5:]
+        k = k[: k.index("(")] if "(" in k else k
+        agg2[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    res = {}
+    for k, dct in sorted(agg2.items()):
+        m = {c: sum(v) / len(v) for c, v in dct.items()}
+        if not m.get("GRBM_GUI_ACTIVE"):
+            continue
+        cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs
+        res[k] = {"dispatches": len(dct["GRBM_GUI_ACTIVE"]), "gpu_cycles": round(cyc),
+                  "mfma_busy_cycles": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0),
+                  "mfma_util": round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024.0), 4),
+                  "wave_quad_cycles": {c: m.get(c) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
+                                                             "SQ_WAIT_ANY")}}
+    json.dump({
+        "source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+                  "SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE on `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                  "--no-kernel-timing` (own pass, no tracing options), MI355X; tools/make_profiles.py",
+        "units": "means per dispatch.  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (gpu_cycles x 1024 SIMDs): fraction of all matrix-pipe "
+                 "cycles spent in an MFMA at the clock the kernel actually ran at (gpu_cycles = GRBM_GUI_ACTIVE / 8 XCDs; "
+                 "SQ_VALU_MFMA_BUSY_CYCLES = 16 per v_mfma_f32_16x16x32_bf16, exactly the kernel's MFMA count x 16).  "
+                 "Times achieved clock / 2.4 GHz it is the fraction of the 2.5 PFLOP/s bf16 peak, i.e. bench.py's roofline.frac.  "
+                 "wave_quad_cycles: SQ_WAIT_INST_ANY = issue stalls (matrix-pipe dependency / pipe busy), SQ_WAIT_ANY = parked at "
+                 "s_waitcnt / barriers, SQ_ACTIVE_INST_ANY = issuing; they sum to ~SQ_WAVE_CYCLES (MI355X_MICROARCH.md).",
+        "kernels": res}, open(out_path, "w"), indent=1)
+
+
+d = os.path.join(out, "pmc_mfma")
+run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+     "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "2",
+     "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
+for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    mfma_util(fn, os.path.join(out, f"{tag}_mfma_util.json"))
 
 # 4. training step and parameter prep (N1): bench lines + kernel stats of the training run
 lines = []
