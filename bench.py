@@ -172,8 +172,18 @@ def main():
                 traffic = max(cand, key=lambda c: c[0])[1]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        # matrix-pipe utilisation of that kernel from the SQ counters (own PMC pass, profiles/r01_mfma_util.json)
+        mfma_util = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_mfma_util.json")))
+            cand = [(v.get("dispatches", 0), v) for k, v in prof["kernels"].items() if k.split("<")[0] == base]
+            if cand and B == 65536 and D == 784 and list(args.hidden) == [256, 256]:
+                mfma_util = max(cand, key=lambda c: c[0])[1]["mfma_util"]
+        except Exception:
+            mfma_util = None
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "kernel": name, "peak_is": peak_note,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "mfma_pipe_util": mfma_util, "kernel": name,
+                    "peak_is": peak_note,
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(classes[dom]),
                     "share_of_gpu_time": round(share, 3),
                     "algorithmic_flops_per_launch": flops,
