@@ -216,17 +216,32 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   // independent
   auto compute_half = [&](const float* rb, int h) {
     const float* wl = rb + 4 * (lg * CS + (lj ^ (2 * lg)));
+    constexpr int H0 = FT / 2;
+    // feature tiles in PAIRS where the half has an even start: the six products of two tiles interleaved give four
+    // independent accumulators in a row (acc[ft][0], acc[ft][1], acc[ft+1][0], acc[ft+1][1]) instead of two
+#define USF_MM(FT_, W, P)                                                                           \
+      acc[FT_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[0][P], acc[FT_][0], 0, 0, 0);     \
+      acc[FT_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[1][P], acc[FT_][1], 0, 0, 0)
+    int ft = h * H0;
 #pragma unroll
-    for (int ft = h * (FT / 2); ft < (h + 1) * (FT / 2); ++ft) {
+    for (int pr = 0; pr < H0 / 2; ++pr, ft += 2) {
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + ft * 16));
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + ft * 16));
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + ft * 16));
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + (ft + 1) * 16));
+      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + (ft + 1) * 16));
+      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + (ft + 1) * 16));
+      USF_MM(ft, a3, 0); USF_MM(ft + 1, b3, 0); USF_MM(ft, a2, 1); USF_MM(ft + 1, b2, 1);
+      USF_MM(ft, a1, 2); USF_MM(ft + 1, b1, 2); USF_MM(ft, a2, 0); USF_MM(ft + 1, b2, 0);
+      USF_MM(ft, a1, 1); USF_MM(ft + 1, b1, 1); USF_MM(ft, a1, 0); USF_MM(ft + 1, b1, 0);
+    }
+    if (H0 & 1) {
       const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + ft * 16));
       const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + ft * 16));
       const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + ft * 16));
-#define USF_MM(W, P)                                                                              \
-      acc[ft][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[0][P], acc[ft][0], 0, 0, 0);     \
-      acc[ft][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, pc[1][P], acc[ft][1], 0, 0, 0)
-      USF_MM(w3, 0); USF_MM(w2, 1); USF_MM(w1, 2); USF_MM(w2, 0); USF_MM(w1, 1); USF_MM(w1, 0);
-#undef USF_MM
+      USF_MM(ft, w3, 0); USF_MM(ft, w2, 1); USF_MM(ft, w1, 2); USF_MM(ft, w2, 0); USF_MM(ft, w1, 1); USF_MM(ft, w1, 0);
     }
+#undef USF_MM
   };
   // Issue order pins (masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write).
   // Weight fragments are read one tile ahead of the MFMAs that use them.
