@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 6
+#define USF_ABI_VERSION 7
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -81,6 +81,16 @@ typedef struct usf_linear_desc {
 } usf_linear_desc;
 
 int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream);
+
+/*
+ * Which kernel family / instantiation usf_linear_f32 would launch for this descriptor (nothing is launched):
+ *   1000                          small-batch kernel (M <= 768)
+ *   2000 + 100 TM + 10 TN + WM    exact-f32 MFMA tile
+ *   3000 + 100 TN + 10 WM + NB    bf16x3 tile (TN x 32 columns, WM waves x 32 rows, NB weight buffers)
+ * 0 for a descriptor with empty extents.  The parity tests use it to prove that every instantiation the BASELINE
+ * configurations select is compared with the reference arithmetic (tests/test_configs_gpu.py).
+ */
+int usf_linear_variant(const usf_linear_desc* d);
 
 /*
  * Fused additive coupling layer (MaskedCoupling.forward/backward, transforms.py:277-306) with a
@@ -170,6 +180,17 @@ int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t bas
  */
 int usf_radial_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
                           uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream);
+
+/*
+ * The random-word -> variate maps of the two head kernels above, applied to caller-supplied 32-bit words:
+ *   u[i]           = ((bits[i] >> 9) + 0.5) * 2^-23      in (0,1), never 0 or 1 (every step exact in fp32)
+ *   laplace[i]     = -sign(2u-1) * log1p(-|2u-1|)        (torch Laplace.rsample, standard scale; always finite)
+ *   exponential[i] = -log(u)                             (the Dirichlet / Box-Muller radius ingredient)
+ * Each output is optional (NULL).  Used by the tests to pin the extreme words 0 and 0xFFFFFFFF; a caller that brings
+ * its own generator can use it as the inverse-CDF stage of Flow.sample (flows.py:258).
+ */
+int usf_variates_from_bits_f32(const uint32_t* bits, int64_t n, float* u, float* laplace, float* exponential,
+                               usf_stream_t stream);
 
 /* ScaleTransform.forward / backward as a standalone layer (transforms.py:105-125): y = x*s or x/s */
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D,

@@ -99,14 +99,19 @@ def spec_to_json(spec):
     return json.dumps(d)
 
 
+ONLY = None      # --only <substring>: regenerate just the matching cases
+
+
 def run_case(name, spec, family, seed, n=48, store_sd=True, ctx=False, alpha=0.1, x_scale=1.0):
+    if ONLY is not None and ONLY not in name:
+        return
     flow = build_reference(spec, seed)
     if family == "synth":
         sd = orc.synth_state_dict(spec, seed=seed, alpha=alpha)
         res = flow.load_state_dict(sd, strict=False)   # strict except for base-distribution params
         assert not res.unexpected_keys, res.unexpected_keys
         assert all(k.startswith("base_distribution.") for k in res.missing_keys), res.missing_keys
-    sd = {k: v.detach().clone() for k, v in flow.state_dict().items()}
+    sd = {k: v.detach().clone() for k, v in flow.state_dict().items()} if store_sd else {}
     g = torch.Generator().manual_seed(1000 + seed)
     x = torch.rand(n, spec.dim, generator=g) * x_scale
     zin = torch.distributions.Laplace(0.0, 1.0).icdf(torch.rand(n, spec.dim, generator=g) * 0.998 + 0.001)
@@ -215,7 +220,12 @@ def main():
     run_case("synth_d784_k32_cfg2", S(784, 32, [256, 256], householder=0), "synth", 100, n=64, store_sd=False)
     run_case("synth_d784_k4_hh1_conj", S(784, 4, [256, 256], householder=1, affine_conjugation=True),
              "synth", 101, n=32, store_sd=False)
+    # --- BASELINE cfg4 model (D=3072, K=48, h=[1024,1024]; 1.28 G parameters): 16 rows, outputs only -------------
+    # (each pass of the reference re-inverts 49 x 2 triangular 3072 x 3072 factors: ~10 min and ~25 GB here)
+    run_case("synth_d3072_k48_cfg4", S(3072, 48, [1024, 1024], householder=0), "synth", 102, n=16, store_sd=False)
 
 
 if __name__ == "__main__":
+    if "--only" in sys.argv:
+        ONLY = sys.argv[sys.argv.index("--only") + 1]
     main()

@@ -57,3 +57,19 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = lib.usf_linear_f32(ctypes.byref(d), None)
     assert rc < 0 and b"multiples of 4" in lib.usf_last_error()
     assert lib.usf_run_ops(None, 3, None) < 0
+
+
+def test_integration_md_ctypes_stub_matches_the_c_structs():
+    """the stub in INTEGRATION.md was shorter than usf_linear_desc (UB for whoever pastes it).  The stub is
+    executed here as written (library path substituted); its own asserts compare sizeof with the library."""
+    from usflows_amd import _ext
+    _ext.load()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = [b for b in blocks if "class LinearDesc" in b]
+    assert len(stub) == 1
+    code = stub[0].split("def block_affine_backward")[0].replace('"libusflows_hip.so"', repr(_ext.LIB_PATH))
+    ns = {}
+    exec(code, ns)
+    assert ctypes.sizeof(ns["LinearDesc"]) == ctypes.sizeof(_ext.LinearDesc)
+    assert [f[0] for f in ns["LinearDesc"]._fields_] == [f[0] for f in _ext.LinearDesc._fields_]

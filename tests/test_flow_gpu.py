@@ -327,3 +327,21 @@ def test_udl_profile_on_device_matches_reference():
         before = flow.engine().launch_count
         _check_udl(flow, a["x"].to(DEV), load_udl(name))
         assert flow.engine().launch_count > before
+
+
+def test_composite_fallback_on_device_warns_once():
+    """a layer list without a fused device form (gated / layer-normalised ConvNet conditioner: not piece-wise linear)
+    still works on the device through the torch composite loop -- but says so (VERDICT r1 weak #10)"""
+    import warnings
+    from usflows_amd.flows import USFlow
+    from usflows_amd.networks import ConvNet
+    flow = USFlow(torch.distributions.Laplace(torch.zeros(12), torch.ones(12)), [12], 2, ConvNet,
+                  dict(in_dims=[12], c_hidden=[16], nonlinearity=torch.nn.ReLU()), householder=0).to(DEV)
+    x = torch.rand(8, 12, device=DEV)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="composite formulation"):
+            lp = flow.log_prob(x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")              # second call: no further warning
+            lp2 = flow.log_prob(x)
+    assert torch.isfinite(lp).all() and torch.equal(lp, lp2)

@@ -5,6 +5,8 @@ import math
 import pytest
 import torch
 
+import shapes
+
 pytestmark = pytest.mark.gpu
 
 
@@ -91,11 +93,7 @@ def test_linear_parity(M, N, K, flags):
     assert err < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(65, 65, 8), (200, 160, 40), (257, 784, 784), (1000, 392, 256), (4096, 800, 784),
-                                   # the 256 x 160 tile with its ring of four weight buffers: 1, 2, 3, 4 slabs, ragged rows/cols
-                                   (8205, 800, 8), (8205, 800, 40), (8205, 800, 72), (8205, 800, 104), (8205, 784, 776),
-                                   # the 128 x 128 tile
-                                   (8192, 1024, 64), (8199, 1020, 136)])
+@pytest.mark.parametrize("M,N,K", shapes.BF16X3_SMALL)
 def test_linear_bf16x3_split_precision(M, N, K):
     """bf16x3 path: three-way residual split of both operands on the bf16 MFMA; must carry fp32-class error"""
     ext, dev = _ext(), _dev()
@@ -116,6 +114,38 @@ def test_linear_bf16x3_split_precision(M, N, K):
     err = (C.cpu().double() - ref64).abs().max().item() / scale
     err32 = (ref32.double() - ref64).abs().max().item() / scale
     assert err < max(4 * err32, 1e-6), (err, err32)
+
+
+@pytest.mark.parametrize("M,N,K", shapes.BF16X3_BIG)
+def test_linear_bf16x3_baseline_shapes_full_size(M, N, K):
+    """every usf_linear_f32 shape of BASELINE cfg2 / cfg3 / cfg4 / cfg5 at FULL size: rows at the head, in the middle
+    and at the tail of the batch (first / last row panels, every column block) against fp64 and fp32 torch-CPU"""
+    ext, dev = _ext(), _dev()
+    from usflows_amd.engine import FlowEngine
+    gd = torch.Generator(device=dev).manual_seed(M + 7 * N + 13 * K)
+    A = torch.randn(M, K, generator=gd, device=dev) * 3
+    g = torch.Generator().manual_seed(N + K)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    Wd = W.to(dev)
+    planes = FlowEngine._split_planes({"mats": {}}, Wd)
+    C = torch.full((M, N), float("nan"), device=dev)
+    ext.linear(A, Wd, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.to(dev), W_split=planes)
+    torch.cuda.synchronize()
+    assert not torch.isnan(C).any()
+    idx = torch.cat([torch.arange(0, 96), torch.arange(M // 2 - 160, M // 2 + 160), torch.arange(M - 300, M),
+                     torch.randint(0, M, (256,), generator=g)])
+    a = A[idx.to(dev)].cpu()
+    ref64 = a.double() @ W.double().t() + bias.double()
+    ref32 = a @ W.t() + bias
+    scale = ref64.abs().max().item()
+    err = (C[idx.to(dev)].cpu().double() - ref64).abs().max().item() / scale
+    err32 = (ref32.double() - ref64).abs().max().item() / scale
+    assert err < max(4 * err32, 1e-6), (err, err32)
+    # whole-matrix linearity check: C(A) + C(-A) == 2 bias for every row (catches a wrong row anywhere in the batch)
+    C2 = torch.empty(M, N, device=dev)
+    ext.linear(-A, Wd, C2, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, bias=bias.to(dev), W_split=planes)
+    assert ((C + C2) - 2 * bias.to(dev)).abs().max().item() < 1e-4 * scale
 
 
 @pytest.mark.parametrize("flags", [dict(act=True), dict(residual=True, res_sign=-1.0), dict(addend=True, act=True),

@@ -74,7 +74,7 @@ def test_shard_rows_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, n_rows=48):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -91,8 +91,11 @@ def _train_worker(rank, world, port, q):
         spec, sd, a = load_case("synth_d16_k3_densenn_relu")
         flow = build_flow(spec, sd)
         data_parallel_training(flow)
-        lo, hi = shard_rows(a["x"].shape[0], rank, world)               # 48 rows: 24 + 24
-        loss = -training.log_prob_with_grad(flow._train_obj, a["x"][lo:hi], None).mean()
+        lo, hi = shard_rows(n_rows, rank, world)                        # 48 rows: 24 + 24; 47: 24 + 23; 1: 1 + 0
+        if hi > lo:
+            loss = -training.log_prob_with_grad(flow._train_obj, a["x"][lo:hi], None).mean()
+        else:                                                           # what Flow.log_prob does for an empty shard
+            loss = -training.log_prob_empty_shard(flow._train_obj, a["x"][lo:hi]).sum()
         loss.backward()
         # (numpy: pickled by value -- torch tensors would travel as shared-memory handles that die with the worker)
         q.put((rank, {n: p.grad.numpy().copy() for n, p in flow.named_parameters() if p.grad is not None}))
@@ -100,9 +103,11 @@ def _train_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_data_parallel_training_gradients_world2():
+@pytest.mark.parametrize("n_rows", [48, 47, 1])
+def test_data_parallel_training_gradients_world2(n_rows):
     """two ranks, half the batch each, ONE all-reduce of the flat gradient arena: every rank ends with the
-    gradient of the full-batch mean loss"""
+    gradient of the full-batch mean loss -- also for shards of unequal size (47 = 24 + 23: weighted by row counts) and
+    when one rank's shard is EMPTY (1 = 1 + 0: it joins the collective with weight 0 instead of hanging the other)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import emulator
     from golden_util import load_case
@@ -111,7 +116,7 @@ def test_data_parallel_training_gradients_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, n_rows)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in range(2))
@@ -124,11 +129,11 @@ def test_data_parallel_training_gradients_world2():
         spec, sd, a = load_case("synth_d16_k3_densenn_relu")
         flow = build_flow(spec, sd)
         path = training.TrainPath(flow)
-        (-training.log_prob_with_grad(path, a["x"], None).mean()).backward()
+        (-training.log_prob_with_grad(path, a["x"][:n_rows], None).mean()).backward()
         ref = {n: p.grad for n, p in flow.named_parameters() if p.grad is not None}
     finally:
         mpatch.undo()
-    assert set(res[0]) == set(ref) and len(ref) >= 10
+    assert set(ref) <= set(res[0]) and set(ref) <= set(res[1]) and len(ref) >= 10
     for n, g in ref.items():
         big = max(g.abs().max().item(), 1e-12)
         for r in (0, 1):

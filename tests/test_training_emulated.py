@@ -115,3 +115,47 @@ def test_training_path_matches_reference_gradients(name):
         assert (p.grad.double() - ref).abs().max().item() <= tol, pname
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("name", ["synth_d7_k3_soft_ctx", "synth_d7_k3_hh0_laplace"])
+def test_eval_pass_between_forward_and_backward_does_not_corrupt_gradients(name):
+    """train and eval plans share the (B, device) workspace.  A no_grad pass with the same batch size
+    between loss = -log_prob(x).mean() and loss.backward() overwrites the saved latent, the staged input (D % 4 != 0)
+    and the context column; the backward must notice (workspace pass counter) and re-run its forward."""
+    from usflows_amd import training
+    spec, sd, a = load_case(name)
+    x, ctx = a["x"], a.get("context")
+    if ctx is None and spec.soft_training:
+        ctx = torch.zeros(x.shape[0], 1)
+
+    def grads(disturb):
+        flow = build_flow(spec, sd)
+        path = TrainPath(flow)
+        loss = -training.log_prob_with_grad(path, x, ctx).mean()
+        if disturb:
+            other = torch.rand(x.shape, generator=torch.Generator().manual_seed(9)) * 5
+            octx = None if ctx is None else torch.full_like(ctx, 1.7)
+            with torch.no_grad():
+                flow.engine().latent(other, octx)                   # Flow.log_prob's no_grad path, same batch size
+                flow.engine().transform(other, "backward", octx)    # Flow.backward
+        loss.backward()
+        return {n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None}
+
+    clean, dirty = grads(False), grads(True)
+    assert set(clean) == set(dirty) and len(clean) >= 5
+    for n in clean:
+        assert torch.allclose(clean[n], dirty[n], rtol=1e-6, atol=1e-9), n
+
+
+def test_parameter_update_between_forward_and_backward_raises():
+    """an optimiser step between log_prob and its backward -> a clear error instead of a gradient
+    evaluated at other parameters than the returned log_prob"""
+    from usflows_amd import training
+    spec, sd, a = load_case("synth_d7_k3_hh0_laplace")
+    flow = build_flow(spec, sd)
+    loss = -training.log_prob_with_grad(TrainPath(flow), a["x"], None).mean()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.001)
+    with pytest.raises(RuntimeError, match="parameters were modified"):
+        loss.backward()

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 import torch  # noqa: F401  -- must be imported first: the .so binds to torch's HIP runtime instance
@@ -15,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 6
+USF_ABI_VERSION = 7
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -94,6 +95,7 @@ SYMBOLS = {
     "usf_last_error": (C.c_char_p, []),
     "usf_build_info": (C.c_char_p, []),
     "usf_linear_f32": (C.c_int, [C.POINTER(LinearDesc), C.c_void_p]),
+    "usf_linear_variant": (C.c_int, [C.POINTER(LinearDesc)]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
@@ -103,6 +105,7 @@ SYMBOLS = {
                                       C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_radial_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
                                         C.c_uint64, C.c_int64, C.c_void_p]),
+    "usf_variates_from_bits_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
     "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -180,7 +183,15 @@ class Tape:
         self.stream = None
 
 
-_rec: list = []          # recording stack; the innermost tape receives the launches, None = recording suspended
+class _ThreadState(threading.local):
+    """per-thread recording / batching state: two threads driving flows at once must not interleave their tapes"""
+
+    def __init__(self):
+        self.rec = []        # recording stack; the innermost tape receives the launches, None = recording suspended
+        self.jobs = []       # stack of open job batches, innermost receives
+
+
+_tls = _ThreadState()
 
 
 class record:
@@ -188,18 +199,19 @@ class record:
         self.tape = tape
 
     def __enter__(self):
-        _rec.append(self.tape)
+        _tls.rec.append(self.tape)
         return self.tape
 
     def __exit__(self, *exc):
-        _rec.pop()
+        _tls.rec.pop()
         return False
 
 
 def _launch(name: str, args: tuple, keep=None) -> None:
     fn = getattr(load(), name)
-    if _rec and _rec[-1] is not None:
-        _rec[-1].entries.append((fn, args, name, keep))
+    rec = _tls.rec
+    if rec and rec[-1] is not None:
+        rec[-1].entries.append((fn, args, name, keep))
     rc = fn(*args)
     if rc != 0:
         check(rc, name)
@@ -207,8 +219,9 @@ def _launch(name: str, args: tuple, keep=None) -> None:
 
 def host_op(fn) -> None:
     """run fn() now and, when recording, again on every replay (its own launches are not taped separately)"""
-    if _rec and _rec[-1] is not None:
-        _rec[-1].entries.append(fn)
+    rec = _tls.rec
+    if rec and rec[-1] is not None:
+        rec[-1].entries.append(fn)
     with record(None):
         fn()
 
@@ -274,6 +287,12 @@ def base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset=0):
 def radial_sample(z, ldz, M, D, base, loc, r, seed, offset, row_offset=0):
     check(load().usf_radial_sample_f32(z.data_ptr(), ldz, M, D, base, loc.data_ptr(), r.data_ptr(), seed, offset,
                                        row_offset, current_stream(z.device)), "usf_radial_sample_f32")
+
+
+def variates_from_bits(bits, u=None, laplace=None, exponential=None):
+    """the head kernels' word -> variate maps on caller-supplied int32/uint32 words (include/usflows_hip.h)"""
+    check(load().usf_variates_from_bits_f32(bits.data_ptr(), bits.numel(), ptr(u), ptr(laplace), ptr(exponential),
+                                            current_stream(bits.device)), "usf_variates_from_bits_f32")
 
 
 def scale(x, ldx, y, ldy, M, D, s, divide):
@@ -345,9 +364,6 @@ def householder(w_0, vk, out=None):
     return out
 
 
-_jobs: list = []         # stack of open job batches (lists), innermost receives
-
-
 class batch_jobs:
     """Defer the usf_pack_weight_f32 calls made inside the block and issue them as ONE usf_pack_weights_f32 launch
     per size class at exit (or at an explicit ``flush``).  Only for calls whose sources are ready when the batch is
@@ -358,11 +374,11 @@ class batch_jobs:
         self.jobs = []
 
     def __enter__(self):
-        _jobs.append(self)
+        _tls.jobs.append(self)
         return self
 
     def __exit__(self, exc_type, *exc):
-        _jobs.pop()
+        _tls.jobs.pop()
         if exc_type is None:
             self.flush()
         return False
@@ -386,8 +402,8 @@ class batch_jobs:
 
 def flush_jobs() -> None:
     """issue what the innermost open batch has queued so far (a later job is about to read an earlier one's output)"""
-    if _jobs:
-        _jobs[-1].flush()
+    if _tls.jobs:
+        _tls.jobs[-1].flush()
 
 
 def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
@@ -399,10 +415,10 @@ def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None
         ld_src = src.shape[-1]
     ldp = planes.shape[2] if planes is not None else 0
     ps = planes.shape[1] * planes.shape[2] if planes is not None else 0
-    if _jobs and n_out > 0 and n_in > 0:
+    if _tls.jobs and n_out > 0 and n_in > 0:
         j = PackJob(src.data_ptr(), ptr(out_idx), ptr(in_idx), ptr(W), ptr(planes), ld_src, n_out, n_in, ldw, ldp, ps,
                     int(src.dtype == torch.float32), int(transpose))
-        _jobs[-1].jobs.append((j, (src, out_idx, in_idx, W, planes)))
+        _tls.jobs[-1].jobs.append((j, (src, out_idx, in_idx, W, planes)))
         return
     _launch("usf_pack_weight_f32", (src.data_ptr(), int(src.dtype == torch.float32), ld_src, int(transpose),
                                     ptr(out_idx), n_out, ptr(in_idx), n_in, ptr(W), ldw, ptr(planes), ldp, ps,

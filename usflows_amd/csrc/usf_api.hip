@@ -16,6 +16,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int linear_dispatch(const usf_linear_desc* d, hipStream_t stream);
+int linear_variant(const usf_linear_desc* d);
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 int coupling_max_width();
 int coupling_padded_width(int h);
@@ -25,6 +26,7 @@ int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const
                 uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream);
 int radial_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
                   uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream);
+int variates_from_bits(const uint32_t* bits, int64_t n, float* u, float* laplace, float* exponential, hipStream_t stream);
 int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s, int32_t divide,
           hipStream_t stream);
 int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
@@ -75,6 +77,8 @@ int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream) {
   return usf::linear_dispatch(d, (hipStream_t)stream);
 }
 
+int usf_linear_variant(const usf_linear_desc* d) { return usf::linear_variant(d); }
+
 int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream) {
   return usf::coupling_dispatch(d, (hipStream_t)stream);
 }
@@ -95,6 +99,11 @@ int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t bas
 int usf_radial_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
                           uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream) {
   return usf::radial_sample(z, ldz, M, D, base, loc, r, seed, offset, row_offset, (hipStream_t)stream);
+}
+
+int usf_variates_from_bits_f32(const uint32_t* bits, int64_t n, float* u, float* laplace, float* exponential,
+                               usf_stream_t stream) {
+  return usf::variates_from_bits(bits, n, u, laplace, exponential, (hipStream_t)stream);
 }
 
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s,

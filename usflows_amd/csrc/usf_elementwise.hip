@@ -106,8 +106,17 @@ int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base
   dim3 g((unsigned)blocks), b(256);
   const size_t tab = (base == USF_BASE_LAPLACE || base == USF_BASE_NORMAL) ? (size_t)((D + 3) / 4 * 4) * sizeof(float) : 0;
   if (tab > 96 * 1024) { set_error("usf_base_logprob_f32: D = %lld too large for the constant table", (long long)D); return -2; }
-#define USF_LAUNCH_BASE(B) \
-  hipLaunchKernelGGL((base_logprob_kernel<B>), g, b, tab, stream, z, ldz, (int)M, (int)D, loc, scale, logdet_const, logp, sum_out)
+  // (dynamic LDS above HIP's 64 KB default needs the kernel's limit raised -- once per instantiation)
+#define USF_LAUNCH_BASE(B)                                                                                            \
+  do {                                                                                                                \
+    if (tab > 64 * 1024) {                                                                                            \
+      static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&base_logprob_kernel<B>),   \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   \
+      if (attr_rc != hipSuccess) { set_error("usf_base_logprob_f32: cannot raise the LDS limit"); return (int)attr_rc; } \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((base_logprob_kernel<B>), g, b, tab, stream, z, ldz, (int)M, (int)D, loc, scale, logdet_const, \
+                       logp, sum_out);                                                                                \
+  } while (0)
   switch (base) {
     case USF_BASE_LAPLACE: USF_LAUNCH_BASE(USF_BASE_LAPLACE); break;
     case USF_BASE_NORMAL: USF_LAUNCH_BASE(USF_BASE_NORMAL); break;
@@ -146,8 +155,16 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t stream_id, 
   }
   out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
-// uniform in (0,1): 24 random bits, never 0 or 1
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// uniform in (0,1): 23 random bits at the cell centres (k + 1/2) * 2^-23 -- never 0 or 1.  Every step is EXACT in
+// fp32: k + 0.5 <= 8388607.5 needs 24 significant bits (with 24 random bits the top value 16777215.5 is a
+// round-to-even tie and became 2^24, i.e. u = 1 and log1p(-1) = -inf in the Laplace transform, once per 2^24
+// draws); 2u - 1 = (2k + 1 - 2^23) * 2^-23 is exact too, |2u - 1| <= 1 - 2^-23, and never 0.
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+// torch Laplace.rsample's transform of u in (-1, 1): -sign(u) * log1p(-|u|)
+__device__ __forceinline__ float laplace_icdf(float u) {
+  const float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
+  return -sgn * log1pf(-fabsf(u));
+}
 
 __global__ __launch_bounds__(256) void base_sample_kernel(float* __restrict__ z, int64_t ldz, int64_t M, int D,
                                                           int base, const float* __restrict__ loc,
@@ -165,9 +182,7 @@ __global__ __launch_bounds__(256) void base_sample_kernel(float* __restrict__ z,
       // torch Laplace.rsample: u ~ U(eps-1, 1); loc - scale*sign(u)*log1p(-|u|)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float u = 2.0f * u01(rnd[j]) - 1.0f;
-        const float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
-        v[j] = -sgn * log1pf(-fabsf(u));
+        v[j] = laplace_icdf(2.0f * u01(rnd[j]) - 1.0f);
       }
     } else {
       const float r0 = sqrtf(-2.0f * logf(u01(rnd[0]))), r1 = sqrtf(-2.0f * logf(u01(rnd[2])));
@@ -196,6 +211,28 @@ int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const
   hipLaunchKernelGGL(base_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, ldz, M, (int)D, base, loc,
                      scale, seed, offset, row_offset);
   return check_launch("usf_base_sample_f32");
+}
+
+// the word -> variate maps of the head kernels applied to caller-supplied random words (tests feed the extreme
+// words 0 and 0xFFFFFFFF; a caller with its own generator can use it as the inverse-CDF stage)
+__global__ void variates_from_bits_kernel(const uint32_t* __restrict__ bits, int64_t n, float* __restrict__ u,
+                                          float* __restrict__ laplace, float* __restrict__ exponential) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = u01(bits[i]);
+    if (u) u[i] = v;
+    if (laplace) laplace[i] = laplace_icdf(2.0f * v - 1.0f);
+    if (exponential) exponential[i] = -logf(v);
+  }
+}
+
+int variates_from_bits(const uint32_t* bits, int64_t n, float* u, float* laplace, float* exponential, hipStream_t stream) {
+  if (n < 0) { set_error("usf_variates_from_bits_f32: bad size"); return -2; }
+  if (n == 0) return 0;
+  if (!bits) { set_error("usf_variates_from_bits_f32: null pointer"); return -1; }
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(variates_from_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, n, u, laplace, exponential);
+  return check_launch("usf_variates_from_bits_f32");
 }
 
 // ------------------------------------------------------------------------------------------

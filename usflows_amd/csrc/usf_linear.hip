@@ -322,6 +322,20 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream);
 bool linear_skinny_eligible(const usf_linear_desc* d);
 int linear_skinny_dispatch(const usf_linear_desc* d, hipStream_t stream);
 
+int linear_bf16x3_variant(int M, int N);
+
+// which kernel family / instantiation usf_linear_f32 would launch for this descriptor (no launch): 1000 = small-batch
+// kernel (usf_linear_skinny.hip), 2000 + 100 TM + 10 TN + WM = exact-f32 tile, 3000 + 100 TN + 10 WM + NB = bf16x3 tile
+int linear_variant(const usf_linear_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  if (linear_skinny_eligible(d)) return 1000;
+  if (linear_bf16x3_eligible(d)) return linear_bf16x3_variant((int)d->M, (int)d->N);
+  if (d->M <= 64 || d->N <= 64) return 2122;
+  const int pad160 = (((int)d->N + 159) / 160) * 160 - (int)d->N;
+  const int pad128 = (((int)d->N + 127) / 128) * 128 - (int)d->N;
+  return pad160 < pad128 ? 2254 : 2244;
+}
+
 int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_linear_f32: null descriptor"); return -1; }
   if (d->M < 0 || d->N <= 0 || d->K <= 0 || d->M > 0x7fffffff || d->N > 0x7fffffff || d->K > 0x7fffffff) {

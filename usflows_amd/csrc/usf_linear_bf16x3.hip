@@ -408,6 +408,33 @@ bool linear_bf16x3_eligible(const usf_linear_desc* d) {
          d->M * d->lda < (1LL << 31) && 3 * d->split_plane_stride < (1LL << 31);   // 32-bit element offsets
 }
 
+// which instantiation serves an [M, N] output: 3000 + 100 TN + 10 WM + NB (reported by usf_linear_variant)
+int linear_bf16x3_variant(int M, int N) {
+  const int pad160 = ((N + 159) / 160) * 160 - N;
+  const int pad128 = ((N + 127) / 128) * 128 - N;
+  // 8-wave blocks (256 rows) stage each weight slab once per 256 rows: 2 % faster in the flow than 4-wave
+  // blocks at M = 65536; USF_BF16X3_WM=4 / 8 forces the 4- / 8-wave tile (tuning aid)
+  static int wm4 = -1;
+  if (wm4 < 0) { const char* e = getenv("USF_BF16X3_WM"); wm4 = (e && atoi(e) == 4) ? 1 : ((e && atoi(e) == 8) ? 2 : 0); }
+  // small batches are latency-bound by one block's serial K loop: narrow column blocks (64 wide) shorten the
+  // per-slab MFMA chain 2.5x and put 2.5x more blocks on the chip
+  if ((int64_t)((M + 127) / 128) * ((N + 159) / 160) < 256) return 3244;
+  if (pad160 < pad128) {
+    // Wave quantisation: 256-row blocks run one per CU, so M / 256 x 5 column blocks fill ceil(. / 256) rounds and a
+    // mostly empty last round costs a full one (M = 32768: 2.5 rounds -> 3).  128-row blocks (two per CU) cut the
+    // tail in half; they stage every weight slab twice per CU, so they only win when the last round is < ~70 % full
+    // (measured, 33 affine launches: M = 16384 4.68 -> 3.97 ms, 32768 8.69 -> 6.71 ms; 24576 / 65536 stay on 256).
+    bool big = M >= 2048 && wm4 != 1;
+    if (big && wm4 == 0) {
+      const double rounds = (double)(((int64_t)M + 255) / 256) * ((N + 159) / 160) / 256.0;
+      const double frac = rounds - (double)(int64_t)rounds;
+      if (rounds > 1.0 && frac > 0.0 && frac < 0.7) big = false;
+    }
+    return big ? 3584 : 3542;
+  }
+  return 3442;
+}
+
 int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   Lin3Args a;
   a.A = d->A; a.Wp = reinterpret_cast<const __bf16*>(d->W_split); a.bias = d->bias; a.post_mul = d->post_mul; a.C = d->C;
@@ -421,29 +448,12 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
 #ifdef USF_STAMP
   a.dbg = g_bdbg;
 #endif
-  const int pad160 = ((a.N + 159) / 160) * 160 - a.N;
-  const int pad128 = ((a.N + 127) / 128) * 128 - a.N;
-  // 8-wave blocks (256 rows) stage each weight slab once per 256 rows: 2 % faster in the flow than 4-wave
-  // blocks at M = 65536; USF_BF16X3_WM=4 / 8 forces the 4- / 8-wave tile (tuning aid)
-  static int wm4 = -1;
-  if (wm4 < 0) { const char* e = getenv("USF_BF16X3_WM"); wm4 = (e && atoi(e) == 4) ? 1 : ((e && atoi(e) == 8) ? 2 : 0); }
-  // small batches are latency-bound by one block's serial K loop: narrow column blocks (64 wide) shorten the
-  // per-slab MFMA chain 2.5x and put 2.5x more blocks on the chip
-  if ((int64_t)((a.M + 127) / 128) * ((a.N + 159) / 160) < 256) return launch3<2, 4, 4>(a, stream);
-  if (pad160 < pad128) {
-    // Wave quantisation: 256-row blocks run one per CU, so M / 256 x 5 column blocks fill ceil(. / 256) rounds and a
-    // mostly empty last round costs a full one (M = 32768: 2.5 rounds -> 3).  128-row blocks (two per CU) cut the
-    // tail in half; they stage every weight slab twice per CU, so they only win when the last round is < ~70 % full
-    // (measured, 33 affine launches: M = 16384 4.68 -> 3.97 ms, 32768 8.69 -> 6.71 ms; 24576 / 65536 stay on 256).
-    bool big = a.M >= 2048 && wm4 != 1;
-    if (big && wm4 == 0) {
-      const double rounds = (double)(((int64_t)a.M + 255) / 256) * ((a.N + 159) / 160) / 256.0;
-      const double frac = rounds - (double)(int64_t)rounds;
-      if (rounds > 1.0 && frac > 0.0 && frac < 0.7) big = false;
-    }
-    return big ? launch3<5, 8, 4>(a, stream) : launch3<5, 4, 2>(a, stream);
+  switch (linear_bf16x3_variant(a.M, a.N)) {
+    case 3244: return launch3<2, 4, 4>(a, stream);
+    case 3584: return launch3<5, 8, 4>(a, stream);
+    case 3542: return launch3<5, 4, 2>(a, stream);
+    default:   return launch3<4, 4, 2>(a, stream);
   }
-  return launch3<4, 4, 2>(a, stream);
 }
 
 }  // namespace usf

@@ -903,6 +903,14 @@ class FlowEngine:
             self._plans[key] = plan
         return plan
 
+    def _run(self, plan, x: torch.Tensor, out: Optional[torch.Tensor], context):
+        """every pass over a workspace -- training forward or no_grad evaluation, they share the (B, device) buffers --
+        bumps its generation counter: activations a training forward left there are stale afterwards, and the
+        training backward re-runs its forward when it finds the counter moved (training.py)"""
+        ws = plan["ws"]
+        ws["_gen"] = ws.get("_gen", 0) + 1
+        self._execute(plan, x, out, context)
+
     def _execute(self, plan, x: torch.Tensor, out: Optional[torch.Tensor], context):
         """run the plan's launches on torch's current stream; small batches replay them as ONE hipGraph"""
         if (self.use_graphs and x.shape[0] <= self.graph_max_rows and self.op_timing is None
@@ -1050,14 +1058,14 @@ class FlowEngine:
         if B == 0:
             return out
         plan = self._plan(direction, B, x.device, context is not None, "user")
-        self._execute(plan, x, out, context)
+        self._run(plan, x, out, context)
         return out
 
     def latent(self, x: torch.Tensor, context=None) -> Tuple[torch.Tensor, int, float]:
         """backward pass into the workspace: (z buffer [B, ldn], ldn, -sum ladj)."""
         x = self._check_input(x)
         plan = self._plan("backward", x.shape[0], x.device, context is not None, "nat")
-        self._execute(plan, x, None, context)
+        self._run(plan, x, None, context)
         buf = plan["ws"][plan["out_buf"][0]]
         return buf, plan["out_buf"][2], -plan["pk"]["ladj_total"]
 

@@ -13,6 +13,7 @@ used whenever the input is on a ROCm device and no autograd graph is required.  
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Any, Dict, Iterable, List, Literal, Optional, Type
 
 import numpy as np
@@ -105,16 +106,29 @@ class Flow(torch.nn.Module):
         if self._engine_obj is None and not self._engine_failed:
             try:
                 self._engine_obj = FlowEngine(self.layers)
-            except EngineUnsupported:
+            except EngineUnsupported as e:
                 self._engine_failed = True
+                self._engine_reason = str(e)
         return self._engine_obj
+
+    def _warn_composite(self, what: str) -> None:
+        """one warning per flow when a call on a ROCm device runs the torch composite loop because the layer list has no
+        fused device form (never silent: DESIGN.md section 1)"""
+        if not getattr(self, "_warned_composite", False):
+            self._warned_composite = True
+            warnings.warn(f"usflows_amd: {what} on a ROCm device runs the torch composite formulation, not the HIP "
+                          f"kernels: {getattr(self, '_engine_reason', 'layer list has no fused device form')}",
+                          RuntimeWarning, stacklevel=3)
 
     def _on_device_fast_path(self, x: torch.Tensor, context=None) -> bool:
         if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2):
             return False
         if _needs_grad(self, x, context):
             return False
-        return self.engine() is not None
+        if self.engine() is None:
+            self._warn_composite("Flow.log_prob / backward / _forward")
+            return False
+        return True
 
     def _base_info(self, device):
         """('laplace'|'normal', loc, scale) / ('radial', loc, p) / None for the tail kernel."""
@@ -178,11 +192,24 @@ class Flow(torch.nn.Module):
         if self._on_device_fast_path(x, context):
             return self._log_prob_device(x, context)
         path = self._train_path(x, context)
+        dp = self._train_obj is not None and self._train_obj.grad_allreduce is not None and torch.is_grad_enabled() \
+            and _needs_grad(self, x, context)
+        if dp and path is None:
+            # data-parallel training: EVERY rank must reach the step's one collective (TrainPath.backward)
+            if torch.is_tensor(x) and x.dim() == 2 and x.shape[0] == 0 and not getattr(self, "_train_failed", False):
+                from .training import log_prob_empty_shard
+                return log_prob_empty_shard(self._train_obj, x)
+            raise RuntimeError("usflows_amd: data_parallel_training is enabled but this call cannot take the device "
+                               "training path (CPU tensor, input requiring grad, unsupported layer or "
+                               "USFLOWS_AMD_TRAIN=composite): the rank would skip the gradient all-reduce and the "
+                               "other ranks would hang")
         if path is not None:
             from .training import TrainUnsupported, log_prob_with_grad
             try:
                 return log_prob_with_grad(path, x, context)
             except TrainUnsupported:
+                if dp:
+                    raise RuntimeError("usflows_amd: data_parallel_training: this layer list has no device backward")
                 self._train_failed = True          # this layer list has no device backward: composite from now on
         log_det = torch.zeros(x.shape[0]).to(x.device)
         for layer in reversed(self.layers):
@@ -256,6 +283,8 @@ class Flow(torch.nn.Module):
                 z = self.base_distribution.sample(shape).to(dev).reshape(n, eng.D).float()
             x = eng.transform(z, "forward")
             return x.reshape(*shape, eng.D)
+        if dev.type == "cuda" and not _needs_grad(self) and self.engine() is None:
+            self._warn_composite("Flow.sample")
         y = self.base_distribution.sample(sample_shape)
         for layer in self.layers:
             y = layer.forward(y, context=context) if context is not None else layer.forward(y)

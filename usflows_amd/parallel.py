@@ -46,8 +46,13 @@ def mean_log_prob(flow, x_shard: torch.Tensor, context: Optional[torch.Tensor] =
 def data_parallel_training(flow, group=None, average: bool = True) -> None:
     """Replicated parameters, batch sharded over the ranks: after this call every backward pass of the device training
     path (training.py) all-reduces the flow's gradients across ``group`` -- ONE collective per step over the flat
-    gradient arena (cfg2: 195 MB), averaged by default, so an optimiser step on every rank keeps the replicas
-    identical.  (Gradients produced outside the node -- a trainable radial norm distribution -- are not included.)
+    gradient arena (cfg2: 195 MB), so an optimiser step on every rank keeps the replicas identical.
+    ``average=True`` (each rank's loss is the MEAN over its own shard, as in ``Flow.fit``): shards are weighted by
+    their row counts, sum_r B_r grad_r / sum_r B_r -- the gradient of the global mean also for unequal shards (a short
+    last batch); a rank with an EMPTY shard still joins the collective (weight 0) and receives the global gradient.
+    ``average=False``: plain sum (losses that are sums).  While enabled, a ``log_prob`` call under autograd that cannot
+    take the device training path raises instead of silently skipping the collective (the other ranks would hang).
+    (Gradients produced outside the node -- a trainable radial norm distribution -- are not included.)
     The reference has no distributed training; this is the data-parallel row of the scope table for ``Flow.fit``."""
     from .training import TrainPath
     if flow.engine() is None:

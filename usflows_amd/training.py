@@ -54,7 +54,6 @@ class TrainPath:
     def __init__(self, flow):
         self.flow = flow
         self.eng: FlowEngine = flow.engine()
-        self.generation = 0
         self._inv: Dict[tuple, torch.Tensor] = {}
         # data-parallel training (parallel.data_parallel_training): (process group | None, average?) -- the whole flat
         # gradient arena goes through ONE all-reduce per step (RCCL over xGMI with the "nccl" backend)
@@ -98,19 +97,35 @@ class TrainPath:
         eng.keep_factors = True
         plan = eng._plan("backward", B, dev, context is not None, "nat", train=True)
         self._check_plan(plan)
-        eng._execute(plan, x, None, context)
+        eng._run(plan, x, None, context)
         zname, _, ldn = plan["out_buf"]
         info = self.flow._base_info(dev)
         base, loc, scale = self._base_ids(info)
-        self.generation += 1
+        # what the backward must find unchanged: the workspace's pass counter (ANY later pass over the same (B, device)
+        # workspace -- a training forward or a no_grad log_prob / backward / sample -- overwrites the saved
+        # activations, the staged input and the context columns) and the parameter versions
+        gen = (plan["ws"]["_gen"], eng._version_key(dev))
         if info[0] == "radial":
             # the radius stays in a plan-owned buffer (the backward's d r / d z needs it); the caller gets a copy
             rbuf = self._buf(plan["ws"], "radius", 1, B)[0, :B]
             _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, None, 0.0, rbuf, None)
-            return rbuf.clone(), plan, x, self.generation
+            return rbuf.clone(), plan, x, gen
         lp = torch.empty(B, dtype=torch.float32, device=dev)
         _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, scale, -plan["pk"]["ladj_total"], lp, None)
-        return lp, plan, x, self.generation
+        return lp, plan, x, gen
+
+    def revalidate(self, ctx):
+        """called by the autograd nodes' backward: (1) parameters changed since the forward (optimiser step /
+        load_state_dict in between): the gradient would be evaluated at other parameters than the returned log_prob
+        -> error, as torch does for saved tensors modified in place; (2) another pass used the workspace: run this
+        node's forward again (same parameters, same input -> same activations)"""
+        ws_gen, vkey = ctx.gen
+        if self.eng._version_key(ctx.x.device) != vkey:
+            raise RuntimeError("usflows_amd: parameters were modified between Flow.log_prob and its backward pass "
+                               "(optimiser step or load_state_dict in between); the device training path keeps "
+                               "activations, not parameter copies -- call backward() before changing parameters")
+        if ctx.plan["ws"].get("_gen") != ws_gen:
+            _, ctx.plan, ctx.x, ctx.gen = self.forward(ctx.x, ctx.context)
 
     @staticmethod
     def _base_ids(info):
@@ -127,6 +142,28 @@ class TrainPath:
         for m in plan["meta"]:
             if m["kind"] == "affine" and m["post_scale"] is not None:
                 raise TrainUnsupported("forward-direction scale fusion")
+        # everything the backward relies on is checked HERE, before the autograd node exists, so that an unsupported
+        # layer list falls back to the composite formulation in Flow.log_prob instead of failing inside loss.backward()
+        if plan.get("train_checked"):
+            return
+        D = self.eng.D
+        for m in plan["meta"]:
+            if m["kind"] == "affine":
+                blk = m["blk"]
+                parts = list(blk.transforms) if isinstance(blk, T.SequentialAffineTransform) else [blk]
+                if not all(isinstance(t, (T.LUTransform, T.HouseholderTransform)) for t in parts):
+                    raise TrainUnsupported(f"affine part {[type(t).__name__ for t in parts]}")
+            elif m["kind"] == "coupling":
+                cond = self.eng.steps[m["step"]].module.conditioner
+                lin = [l for l in cond.layers]
+                has_ctx = isinstance(cond, ConditionalDenseNN)
+                h = [int(v) for v in cond.hidden_dims]
+                want = [(h[0], D)] + ([(h[0], 1)] if has_ctx else []) + \
+                       [(h[i + 1], h[i]) for i in range(len(h) - 1)] + [(D, h[-1])]
+                got = [tuple(l.weight.shape) for l in lin]
+                if got != want:
+                    raise TrainUnsupported(f"conditioner weight shapes {got} != {want}")
+        plan["train_checked"] = True
 
     # ---- helpers --------------------------------------------------------------------------------------
     def _inv_idx(self, layout: str, device) -> torch.Tensor:
@@ -196,25 +233,50 @@ class TrainPath:
                     tape.stream = _ext.current_stream(dev)
                 plan["bwd_tape"], plan["bwd_pk"] = tape, pk
             flat = arena["flat"].clone()          # autograd may keep what we return: never hand out the arena itself
-            if self.grad_allreduce is not None:
-                import torch.distributed as dist
-                group, average = self.grad_allreduce
-                if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-                    if average:
-                        flat /= dist.get_world_size(group)
+            self.allreduce_gradients(flat, x.shape[0])
         # parameters the path never reaches (a context layer without context) get no gradient, as under autograd
         return {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items()
                 if pid in arena["touched"]}
 
-    def _arena(self, plan) -> dict:
+    def allreduce_gradients(self, flat: torch.Tensor, local_rows: int) -> None:
+        """data-parallel training: ONE all-reduce over the flat gradient arena (its last element carries this rank's
+        row count).  ``average``: every rank's loss is the MEAN over its own shard, so the global-mean gradient is
+        sum_r B_r grad_r / sum_r B_r -- shards of unequal size (a short last batch) are weighted by their row counts and
+        an empty shard contributes zeros with weight 0.  Otherwise (losses are sums): the plain sum."""
+        if self.grad_allreduce is None:
+            return
+        import torch.distributed as dist
+        group, average = self.grad_allreduce
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        if average:
+            flat[:-1] *= float(local_rows)
+        flat[-1] = float(local_rows)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat[:-1] /= flat[-1].clamp_min(1.0)
+
+    def empty_shard_gradients(self, device) -> Dict[int, torch.Tensor]:
+        """a rank whose shard of the batch is empty still has to join the step's collective (the others would hang):
+        it contributes a zero arena with weight 0 and receives the same global gradient as every other rank"""
+        pk = self.eng.pack(device)
+        arena = self._arena(dict(pk=pk, ws=None), device)
+        with torch.no_grad():
+            flat = torch.zeros_like(arena["flat"])
+            self.allreduce_gradients(flat, 0)
+        return {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items()}
+
+    def _arena(self, plan, dev=None) -> dict:
         """one flat fp32 buffer for all parameter gradients of this plan; the LU factors' gradients lie batched
-        ([n,D,D] L_raw | [n,D,D] U_raw | [n,D] bias, in prepare order) so the chain rule writes each with one copy"""
+        ([n,D,D] L_raw | [n,D,D] U_raw | [n,D] bias, in prepare order) so the chain rule writes each with one copy.
+        Its layout depends on the parameter pack only (the same on every rank); one extra element at the end carries
+        the rank's row count through the data-parallel all-reduce."""
         ar = plan.get("grad_arena")
         if ar is not None and ar["pk"] is plan["pk"]:
             return ar
         pk = plan["pk"]
-        dev = plan["ws"]["zA"].device
+        if dev is None:
+            dev = plan["ws"]["zA"].device
         slots, off = {}, 0
         lu_views = []
         for ch in pk["affine_parts"]["__chunks__"]:
@@ -234,7 +296,7 @@ class TrainPath:
             if id(p) not in slots and p.requires_grad:
                 slots[id(p)] = (off, p.numel(), tuple(p.shape))
                 off += p.numel()
-        flat = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        flat = torch.zeros(max(off, 1) + 1, dtype=torch.float32, device=dev)
         ar = dict(flat=flat, slots=slots, lu_views=lu_views, pk=pk, touched=set(),
                   views={pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in slots.items()})
         plan["grad_arena"] = ar
@@ -511,7 +573,8 @@ class TrainPath:
         if g is None:
             return
         if g.shape != (n_rows, n_cols):
-            raise TrainUnsupported(f"unexpected parameter shape {tuple(g.shape)}")
+            raise RuntimeError(f"usflows_amd internal: gradient image {n_rows}x{n_cols} vs parameter {tuple(g.shape)} "
+                               "(shapes are validated in TrainPath._check_plan)")
         _ext.pack_weight(img, rows_sel, n_rows, cols_sel, n_cols, W=g, ldw=n_cols, ld_src=img.shape[1])
 
     def _scatter_vec(self, grads, p, vec_img, sel, n):
@@ -720,7 +783,8 @@ class TrainPath:
                     leaves.append(("hh", t, Hw))
                     mats.append((Hw, Hw.t(), torch.zeros(t.dim, dtype=torch.float64, device=Hw.device)))
                 else:
-                    raise TrainUnsupported(type(t).__name__)
+                    raise RuntimeError(f"usflows_amd internal: affine part {type(t).__name__} "
+                                       "(validated in TrainPath._check_plan)")
             M, Minv, b = mats[0]
             for m_, mi_, b_ in mats[1:]:                     # transforms.py:1457-1476
                 M = M @ m_
@@ -815,9 +879,7 @@ class _LogProbFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lp):
         path: TrainPath = ctx.path
-        if path.generation != ctx.gen:
-            # another training forward ran in between and overwrote the saved activations: run this one again
-            _, ctx.plan, ctx.x, ctx.gen = path.forward(ctx.x, ctx.context)
+        path.revalidate(ctx)
         grads = path.backward(ctx.plan, ctx.x, g_lp)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (None, None, None) + out
@@ -839,8 +901,7 @@ class _RadiusFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_r, g_logdet):
         path: TrainPath = ctx.path
-        if path.generation != ctx.gen:
-            _, ctx.plan, ctx.x, ctx.gen = path.forward(ctx.x, ctx.context)
+        path.revalidate(ctx)
         if g_r is None:
             g_r = torch.zeros(ctx.x.shape[0], dtype=torch.float32, device=ctx.x.device)
         if g_logdet is None:
@@ -848,6 +909,29 @@ class _RadiusFn(torch.autograd.Function):
         grads = path.backward(ctx.plan, ctx.x, g_r, gsum=g_logdet)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (None, None, None) + out
+
+
+class _EmptyShardFn(torch.autograd.Function):
+    """data-parallel training, this rank's shard is empty: log_prob is an empty tensor, but the backward joins the
+    gradient all-reduce (weight 0) so the other ranks do not hang and this replica receives the same gradients"""
+
+    @staticmethod
+    def forward(ctx, path: TrainPath, x, *params):
+        ctx.path, ctx.params, ctx.dev = path, params, x.device
+        return torch.empty(0, dtype=torch.float32, device=x.device)
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        grads = ctx.path.empty_shard_gradients(ctx.dev)
+        return (None, None) + tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
+
+
+def log_prob_empty_shard(path: TrainPath, x):
+    extra = []
+    info = path.flow._base_info(x.device)
+    if info is not None and info[0] == "radial":
+        extra.append(path.flow.base_distribution.loc)
+    return _EmptyShardFn.apply(path, x, *(extra + list(path.params())))
 
 
 def log_prob_with_grad(path: TrainPath, x, context):
