@@ -154,3 +154,17 @@ def test_oracle_autograd_matches_reference_gradients(name):
         assert (got - ref.reshape(got.shape)).abs().max().item() <= 1e-9 * max(1.0, ref.abs().max().item()), k
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("USFLOWS_SLOW") != "1", reason="minutes of CPU (98 triangular 3072x3072 inversions per "
+                    "call, 10 GB of fp64 parameters): run with USFLOWS_SLOW=1")
+def test_oracle_matches_reference_at_cfg4():
+    """BASELINE cfg4 (D=3072, K=48, h=[1024,1024]): the oracle's fp32 log_prob of the fixture's 16 rows against the
+    real reference's fp32 and fp64 runs"""
+    spec, sd, a = load_case("synth_d3072_k48_cfg4")
+    with torch.no_grad():
+        lp = orc.flow_log_prob(sd, spec, a["x"])
+    rel64 = ((lp.double() - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
+    rel32 = ((lp.double() - a["log_prob32"].double()).abs() / a["log_prob64"].abs()).max().item()
+    assert rel64 < 1e-5 and rel32 < 1e-5, (rel64, rel32)
