@@ -335,7 +335,7 @@ def test_composite_fallback_on_device_warns_once():
     import warnings
     from usflows_amd.flows import USFlow
     from usflows_amd.networks import ConvNet
-    flow = USFlow(torch.distributions.Laplace(torch.zeros(12), torch.ones(12)), [12], 2, ConvNet,
+    flow = USFlow(torch.distributions.Laplace(torch.zeros(12, device=DEV), torch.ones(12, device=DEV)), [12], 2, ConvNet,
                   dict(in_dims=[12], c_hidden=[16], nonlinearity=torch.nn.ReLU()), householder=0).to(DEV)
     x = torch.rand(8, 12, device=DEV)
     with torch.no_grad():
