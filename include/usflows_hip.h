@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 7
+#define USF_ABI_VERSION 8
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -202,17 +202,79 @@ int usf_gather_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, 
                         const int32_t* idx, usf_stream_t stream);
 
 /*
+ * ---- "Planes pipeline" (large batches) ---------------------------------------------------
+ * Between the dense layers of a flow the activations travel as three bf16 planes (x == p1 + p2 + p3 exactly,
+ * round-to-nearest residual split -- the operand form of the bf16x3 arithmetic above) in the order the consumer's
+ * MFMA operand wants them, so that a GEMM's K loop is loads + MFMAs only (no split, no LDS transposition):
+ *
+ *   planes buffer of M rows and nkb 32-feature blocks: ceil(M/16) row panels x nkb blocks x 3 planes of 1 KiB
+ *   chunks, chunk(p, kb, q) at ((p * nkb + kb) * 3 + q) * 1024 bytes; inside a chunk 64 lines of 16 bytes
+ *   (8 bf16): line L = 16 g + j holds row 16 p + j, slots 8 g .. 8 g + 7 of block kb; slot s = 8 g + u holds the
+ *   block's feature 16 (u >> 2) + 4 g + (u & 3).  Rows >= M of the last panel are padding (any value).
+ *
+ * The "logical layout" of a buffer (which feature sits at logical position 32 kb + f) is the caller's business
+ * (the engine uses its segment layout [mask==0 features | mask==1 features]).
+ */
+
+/* fp32 row-major -> planes:  logical position l of row m  <-  (src[m, idx[l]] / pre_div[l]) - pre_sub[l]
+ * (idx[l] < 0: zero; pre_div / pre_sub optional).  Head of Flow.log_prob (ScaleTransform.backward + the tail affine
+ * layer's bias subtraction, transforms.py:116-125, 960) and of Flow.sample (base noise). */
+typedef struct usf_pack_planes_desc {
+  const float* src; int64_t ld;         /* [M, ld] */
+  int64_t M;
+  int64_t nkb;                          /* blocks per panel of the planes buffer */
+  const int32_t* idx;                   /* [32 * nkb] device */
+  const float* pre_div;                 /* [32 * nkb] or NULL */
+  const float* pre_sub;                 /* [32 * nkb] or NULL */
+  void* planes;
+} usf_pack_planes_desc;
+int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream);
+
+/*
+ * Dense layer on planes:  C = epilogue(A[:, K range] @ W^T + bias)   (F.linear of BlockAffineTransform,
+ * transforms.py:913-962, and of the conditioner MLP, networks.py:739-751; MaskedCoupling's residual add / subtract,
+ * transforms.py:277-306, in the epilogue).  Arithmetic: bf16x3 (six v_mfma_f32_16x16x32_bf16 per product, fp32
+ * accumulation) -- the same as usf_linear_f32 with W_split.
+ *   A        planes buffer with a_nkb blocks per panel; the K range is blocks a_kb0 .. a_kb0 + nk - 1
+ *   W_planes three bf16 planes [w_rows, ldw] (plane q at + q * w_plane_stride elements), ldw >= 32 nk; column
+ *            32 kb + s of a row multiplies SLOT s of block a_kb0 + kb (i.e. the K axis carries the slot permutation
+ *            above); rows beyond the wanted outputs must be zero (w_rows: a multiple of 4, >= 32 c_kbn resp. >= N)
+ *   bias, post_mul  [w_rows] fp32 or NULL (post_mul: fp32 output only)
+ *   planes output (C_planes != NULL): output feature n lands at logical position 32 c_kb0 + n of a buffer with c_nkb
+ *            blocks per panel, for n < 32 c_kbn;  v = act(acc + bias);  with residual (a planes buffer of C's
+ *            geometry, may alias C_planes): v = residual + res_sign * v
+ *   fp32 output (C_f32 != NULL): C_f32[m, n] = act(acc + bias) * post_mul, n < N, row-major with stride ldc
+ */
+typedef struct usf_gemm_planes_desc {
+  const void* A; int64_t a_nkb, a_kb0, nk;
+  const void* W_planes; int64_t ldw, w_plane_stride, w_rows;
+  const float* bias;
+  const float* post_mul;
+  const void* residual;
+  void* C_planes; int64_t c_nkb, c_kb0, c_kbn;
+  float* C_f32; int64_t ldc, N;
+  int64_t M;
+  float res_sign, slope;
+  int32_t act, reserved;
+} usf_gemm_planes_desc;
+int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream);
+
+/*
  * Run a prebuilt list of ops with ONE call (the whole flow: ~2K+2 launches). op.kind selects the
  * member of the union; pointers inside may be patched by the caller between calls.
  */
 #define USF_OP_LINEAR 1
 #define USF_OP_COUPLING 2
+#define USF_OP_PACK_PLANES 5
+#define USF_OP_GEMM_PLANES 6
 typedef struct usf_op {
   int32_t kind;
   int32_t reserved;
   union {
     usf_linear_desc linear;
     usf_coupling_desc coupling;
+    usf_pack_planes_desc pack_planes;
+    usf_gemm_planes_desc gemm_planes;
   } u;
 } usf_op;
 
@@ -326,7 +388,8 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
                               const float* loc, const float* scale, float* g, int64_t ldg, usf_stream_t stream);
 
 int usf_abi_version(void);
-int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4: binding self-check */
+int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;
+                                           usf_pack_planes_desc|usf_gemm_planes_desc for 5|6: binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */
 

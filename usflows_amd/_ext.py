@@ -16,12 +16,12 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 7
+USF_ABI_VERSION = 8
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
 BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
-OP_LINEAR, OP_COUPLING = 1, 2
+OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES = 1, 2, 5, 6
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -63,8 +63,23 @@ class CouplingDesc(C.Structure):
     ]
 
 
+class PackPlanesDesc(C.Structure):
+    _fields_ = [("src", _fp), ("ld", C.c_int64), ("M", C.c_int64), ("nkb", C.c_int64), ("idx", _fp),
+                ("pre_div", _fp), ("pre_sub", _fp), ("planes", _fp)]
+
+
+class GemmPlanesDesc(C.Structure):
+    _fields_ = [("A", _fp), ("a_nkb", C.c_int64), ("a_kb0", C.c_int64), ("nk", C.c_int64),
+                ("W_planes", _fp), ("ldw", C.c_int64), ("w_plane_stride", C.c_int64), ("w_rows", C.c_int64),
+                ("bias", _fp), ("post_mul", _fp), ("residual", _fp),
+                ("C_planes", _fp), ("c_nkb", C.c_int64), ("c_kb0", C.c_int64), ("c_kbn", C.c_int64),
+                ("C_f32", _fp), ("ldc", C.c_int64), ("N", C.c_int64), ("M", C.c_int64),
+                ("res_sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("reserved", C.c_int32)]
+
+
 class _OpUnion(C.Union):
-    _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc)]
+    _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc), ("pack_planes", PackPlanesDesc),
+                ("gemm_planes", GemmPlanesDesc)]
 
 
 class Op(C.Structure):
@@ -96,6 +111,8 @@ SYMBOLS = {
     "usf_build_info": (C.c_char_p, []),
     "usf_linear_f32": (C.c_int, [C.POINTER(LinearDesc), C.c_void_p]),
     "usf_linear_variant": (C.c_int, [C.POINTER(LinearDesc)]),
+    "usf_pack_planes_f32": (C.c_int, [C.POINTER(PackPlanesDesc), C.c_void_p]),
+    "usf_gemm_planes_bf16x3": (C.c_int, [C.POINTER(GemmPlanesDesc), C.c_void_p]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
@@ -153,7 +170,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.usf_abi_version() != USF_ABI_VERSION:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
-    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob)):
+    for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
+                     (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")

@@ -1,0 +1,398 @@
+// "Planes pipeline": the dense layers of a flow with activations travelling BETWEEN layers as pre-split bf16 planes in
+// an MFMA-fragment-tiled layout (large batches; usf_pack_planes_f32 / usf_gemm_planes_bf16x3 in the header).
+//
+// Why: in usf_linear_bf16x3.hip every block re-splits its fp32 activation slab into three bf16 planes inside the K
+// loop (~100 VALU per 32-k slab and wave, repeated by each of the 5 column blocks of a row panel) and turns
+// line-shaped loads into operand fragments through an LDS scratch.  On gfx950 a 16x16x32 MFMA holds the SIMD's vector
+// issue for 8 of its 16 cycles, so two waves per SIMD have ~2 filler slots per MFMA: the split + scratch traffic
+// saturates vector issue and the matrix pipe idles 30 % of the loop (profiles/r01_mfma_util.json).  Here the PRODUCER
+// of an activation splits it once, in its epilogue, and stores the planes in the exact order the consumer's MFMA B
+// operand wants them:
+//
+//   chunk(panel p, k-block kb, plane q) = 1 KiB at ((p * nkb + kb) * 3 + q) * 1024; lane L = 16 g + j holds 16 bytes
+//   (8 bf16) at L * 16: batch row 16 p + j, slots 8 g .. 8 g + 7 of the 32-feature block kb.
+//   Slot s = 8 g + u of a block holds feature f(s) = 16 (u >> 2) + 4 g + (u & 3) of that block -- the order in which
+//   two neighbouring 16 x 16 accumulator tiles of the producing GEMM present a lane's 8 outputs (C^T layout: lane
+//   (j, g), register r of tile t = feature 16 t + 4 g + r of row j).  The consumer's weight planes carry the same
+//   permutation on their K axis (applied once at pack time), so a producer lane's registers ARE a consumer operand.
+//
+// A consumer wave loads its B operand with ONE coalesced 16-byte load per lane, plane and batch tile (1 KiB
+// contiguous per instruction), straight into registers: no LDS scratch, no split, no conversion in the K loop.
+// Weights go through the LDS ring exactly as in usf_linear_bf16x3.hip.  Arithmetic is unchanged: six
+// v_mfma_f32_16x16x32_bf16 per fp32-equivalent product, a1 w1 + (a1 w2 + a2 w1) + (a1 w3 + a2 w2 + a3 w1), fp32
+// accumulation, smallest terms first.
+#include <stdlib.h>
+
+#include "usf_common.h"
+
+namespace usf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// feature offset (0..31) held by slot s of a 32-feature block
+__host__ __device__ __forceinline__ int plane_feature_of_slot(int s) { return 16 * ((s & 7) >> 2) + 4 * (s >> 3) + (s & 3); }
+
+__device__ __forceinline__ void split3_8(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    const float r = x[j] - (float)h;           // exact
+    const __bf16 m = (__bf16)r;
+    const float r2 = r - (float)m;             // exact
+    p1[j] = h; p2[j] = m; p3[j] = (__bf16)r2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pack: fp32 row-major [M, ld] -> planes (optionally x / pre_div - pre_sub first, columns gathered through idx)
+// ------------------------------------------------------------------------------------------------------------
+// one wave per (panel, k-block): lane (j, g) produces its 8 slots of row 16 p + j
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ src, int64_t ld, int M, int npanels,
+                                                          int nkb, const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ pre_div,
+                                                          const float* __restrict__ pre_sub, char* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int lj = lane & 15, lg = lane >> 4;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= (int64_t)npanels * nkb) return;
+  const int p = (int)(chunk / nkb), kb = (int)(chunk % nkb);
+  const int row = 16 * p + lj;
+  float x[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int l = 32 * kb + 16 * (u >> 2) + 4 * lg + (u & 3);          // position in the buffer's logical layout
+    const int c = idx[l];                                             // source column (-1: padding)
+    float v = 0.f;
+    if (c >= 0 && row < M) {
+      v = src[(int64_t)row * ld + c];
+      if (pre_div) v = v / pre_div[l];
+      if (pre_sub) v = v - pre_sub[l];
+    }
+    x[u] = v;
+  }
+  bf16x8 p1, p2, p3;
+  split3_8(x, p1, p2, p3);
+  char* o = dst + (chunk * 3) * 1024 + lane * 16;
+  *reinterpret_cast<bf16x8*>(o) = p1;
+  *reinterpret_cast<bf16x8*>(o + 1024) = p2;
+  *reinterpret_cast<bf16x8*>(o + 2048) = p3;
+}
+
+int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
+  if (!d) { set_error("usf_pack_planes_f32: null descriptor"); return -1; }
+  if (d->M < 0 || d->nkb <= 0 || d->M > 0x7fffffff || d->nkb > 0x7fffff || d->ld < 1) { set_error("usf_pack_planes_f32: bad sizes"); return -2; }
+  if (d->M == 0) return 0;
+  if (!d->src || !d->idx || !d->planes) { set_error("usf_pack_planes_f32: null pointer"); return -1; }
+  if (!aligned16(d->planes)) { set_error("usf_pack_planes_f32: planes must be 16-byte aligned"); return -2; }
+  const int64_t npanels = (d->M + 15) / 16;
+  const int64_t chunks = npanels * d->nkb;
+  const int64_t blocks = (chunks + 3) / 4;
+  if (blocks > 0x7fffffffLL) { set_error("usf_pack_planes_f32: grid too large"); return -3; }
+  hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d->src, d->ld, (int)d->M, (int)npanels,
+                     (int)d->nkb, d->idx, d->pre_div, d->pre_sub, reinterpret_cast<char*>(d->planes));
+  return check_launch("usf_pack_planes_f32");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GEMM on planes
+// ------------------------------------------------------------------------------------------------------------
+struct PlArgs {
+  const char* A; const __bf16* Wp; const float* bias; const float* post_mul;
+  const char* R; char* Cp; float* Cf;
+  int64_t ldc, plane_stride;
+  int ldwp, wrows;
+  int M, npanels;
+  int a_nkb, a_kb0, nk;
+  int c_nkb, c_kb0, c_kbn;
+  int N, nbm, nbn;
+  float res_sign, slope; int act;
+  unsigned long long* dbg;
+};
+
+template <int TN, bool F32OUT>
+__global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
+  constexpr int NT = 512;
+  constexpr int BN = TN * 32;
+  constexpr int FT = 2 * TN;                    // 16-feature tiles per wave, each against 2 batch tiles of 16 rows
+  // weight stage: 3 planes x 4 k-chunks x BN rows of 16-byte slots, image slot(plane, chunk c, row r) =
+  // (plane * 4 + c) * BN + (r ^ 2c)  (conflict-free for the fragment reads and for the row-major deal; see
+  // usf_linear_bf16x3.hip); ring of four buffers, the block meets at a barrier every second slab
+  constexpr int CS = BN;
+  constexpr int NSLOT = 3 * 4 * BN;
+  constexpr int NWV = (NSLOT + NT - 1) / NT;
+  constexpr int STG = 12 * CS * 4;              // floats per staging buffer
+  constexpr int NB = 4, D = 2;
+  static_assert(NWV * NT - NSLOT <= NSLOT, "surplus threads wrap once");
+  __shared__ __attribute__((aligned(16))) float wring[NB * STG];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lj = lane & 15, lg = lane >> 4;
+
+  // XCD-aware block map: the column blocks of one 256-row panel group run back to back on one XCD
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
+  const int pg = (seq / p.nbn) * 8 + xcd;       // group of 16 panels (256 rows)
+  const int bn = seq % p.nbn;
+  if (pg >= p.nbm) return;
+  const int n0 = bn * BN;
+  int pw[2];                                    // this wave's two panels (unclamped: >= npanels means "no rows")
+  pw[0] = pg * 16 + wave * 2;
+  pw[1] = pw[0] + 1;
+
+  // ---- activations: one 16-byte load per lane, plane and batch tile, straight into the MFMA B operand ----
+  unsigned aoff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+    aoff[b] = ((unsigned)min(pw[b], p.npanels - 1) * (unsigned)p.a_nkb + (unsigned)p.a_kb0) * 3072u + (unsigned)lane * 16u;
+  auto issue_a = [&](int kb, bf16x8 (&dst)[2][3]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        dst[b][q] = *reinterpret_cast<const bf16x8*>(p.A + (aoff[b] + (unsigned)kb * 3072u + (unsigned)q * 1024u));
+  };
+
+  // ---- weights: register-staged into the LDS ring ----
+  unsigned wsrc[NWV];
+  int wdst[NWV];
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) {
+    const int idx = tid + NT * i;
+    const int idc = (idx < NSLOT) ? idx : idx - NSLOT;
+    const int pl = idc / (4 * BN), rem = idc % (4 * BN);
+    const int r = rem >> 2, ch = rem & 3;
+    wsrc[i] = (unsigned)(pl * p.plane_stride + (int64_t)min(n0 + r, p.wrows - 1) * p.ldwp + 8 * ch);
+    wdst[i] = 4 * ((pl * 4 + ch) * CS + (r ^ (2 * ch)));
+  }
+  auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + (wsrc[i] + (unsigned)k0));
+  };
+  auto store_w = [&](float* wb, const f32x4 (&src)[NWV]) {
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) *reinterpret_cast<f32x4*>(wb + wdst[i]) = src[i];
+  };
+
+  // accumulators (C^T: batch row on the lane, 4 consecutive output features per register group) start at the bias
+  f32x4 acc[FT][2];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    f32x4 bv = zero4;
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + min(n0 + ft * 16 + 4 * lg, p.wrows - 4));
+    acc[ft][0] = bv;
+    acc[ft][1] = bv;
+  }
+
+#ifdef USF_STAMP
+#define PSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define PSTAMP(v)
+#endif
+  PSTAMP(t0);
+  bf16x8 pa[2][3], pb[2][3];
+  f32x4 wst[NWV];
+  const int nslab = p.nk;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    issue_w(min(d, nslab - 1) * 32, wst);
+    store_w(wring + d * STG, wst);
+  }
+  issue_a(0, pa);
+  __syncthreads();
+
+  // one slab: 12 MFMAs per feature tile (6 products x 2 batch tiles), weight fragments read from LDS two tiles ahead;
+  // the next slab's operands (global -> registers) and the weights of the slab after next (global -> staging
+  // registers) are issued under the first tiles' MFMAs
+#define USF_MM(FT_, W, P)                                                                                \
+  acc[FT_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, cur[0][P], acc[FT_][0], 0, 0, 0);             \
+  acc[FT_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, cur[1][P], acc[FT_][1], 0, 0, 0)
+  constexpr int NLD = NWV + 6;                  // vector-memory loads per slab and thread
+  constexpr int LPT = (NLD + FT - 1) / FT;      // ... dealt over the feature tiles
+  auto slab = [&](int s, const bf16x8 (&cur)[2][3], bf16x8 (&nxt)[2][3], bool sync_after) {
+    const float* rb = wring + (s % NB) * STG;
+    float* wb = wring + ((s + D) % NB) * STG;
+    const float* wl = rb + 4 * (lg * CS + (lj ^ (2 * lg)));
+    issue_w(min(s + D, nslab - 1) * 32, wst);
+    issue_a(min(s + 1, nslab - 1), nxt);
+#pragma unroll
+    for (int ft = 0; ft < FT; ft += 2) {
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + ft * 16));
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + ft * 16));
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + ft * 16));
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + (ft + 1) * 16));
+      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + (ft + 1) * 16));
+      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + (ft + 1) * 16));
+      USF_MM(ft, a3, 0); USF_MM(ft + 1, b3, 0); USF_MM(ft, a2, 1); USF_MM(ft + 1, b2, 1);
+      USF_MM(ft, a1, 2); USF_MM(ft + 1, b1, 2); USF_MM(ft, a2, 0); USF_MM(ft + 1, b2, 0);
+      USF_MM(ft, a1, 1); USF_MM(ft + 1, b1, 1); USF_MM(ft, a1, 0); USF_MM(ft + 1, b1, 0);
+    }
+    // issue order pins (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      if (f + 2 < FT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      if (f * LPT < NLD) __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_w(wb, wst);
+    __builtin_amdgcn_sched_barrier(0);
+    if (sync_after) __syncthreads();
+  };
+  PSTAMP(t1);
+  int s = 0;
+  for (; s + 2 <= nslab; s += 2) {
+    slab(s, pa, pb, false);
+    slab(s + 1, pb, pa, true);
+  }
+  if (s < nslab) slab(s, pa, pb, false);
+#undef USF_MM
+  PSTAMP(t2);
+
+  // ---- epilogue ----
+  if (F32OUT) {
+    // fp32 row-major: lane (j, g) of tile (ft, b) holds features n0 + 16 ft + 4 g + (0..3) of row 16 pw[b] + j
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.Cf) & 15u) == 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int row = 16 * pw[b] + lj;
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        const int col = n0 + 16 * ft + 4 * lg;
+        f32x4 v = acc[ft][b];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act, p.slope);
+        if (p.post_mul) v = v * *reinterpret_cast<const f32x4*>(p.post_mul + min(col, p.wrows - 4));
+        if (row < p.M && col < p.N) {
+          float* dst = p.Cf + (int64_t)row * p.ldc + col;
+          if (vec_ok && col + 3 < p.N) {
+            *reinterpret_cast<f32x4*>(dst) = v;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (col + j < p.N) dst[j] = v[j];
+          }
+        }
+      }
+    }
+  } else {
+    // planes: two neighbouring tiles give a lane the 8 slots of its chunk line; activation, residual (read back
+    // from planes: p1 + p2 + p3 is the exact fp32 value), 3-way split, three 16-byte stores -- all lane-local
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int kbo = bn * TN + t;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (kbo < p.c_kbn && pw[b] < p.npanels) {
+          const size_t off = (((size_t)pw[b] * p.c_nkb + (p.c_kb0 + kbo)) * 3) * 1024 + (size_t)lane * 16;
+          float x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = act_apply(acc[2 * t + (u >> 2)][b][u & 3], p.act, p.slope);
+          if (p.R) {
+            const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(p.R + off);
+            const bf16x8 r2 = *reinterpret_cast<const bf16x8*>(p.R + off + 1024);
+            const bf16x8 r3 = *reinterpret_cast<const bf16x8*>(p.R + off + 2048);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (((float)r1[u] + (float)r2[u]) + (float)r3[u]) + p.res_sign * x[u];
+          }
+          bf16x8 o1, o2, o3;
+          split3_8(x, o1, o2, o3);
+          *reinterpret_cast<bf16x8*>(p.Cp + off) = o1;
+          *reinterpret_cast<bf16x8*>(p.Cp + off + 1024) = o2;
+          *reinterpret_cast<bf16x8*>(p.Cp + off + 2048) = o3;
+        }
+      }
+    }
+  }
+#ifdef USF_STAMP
+  PSTAMP(t3);
+  if (p.dbg && lane == 0) {
+    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 1024) * 8 + wave) * 8;
+    o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; o[4] = 1;
+  }
+#endif
+}
+
+#ifdef USF_STAMP
+unsigned long long* g_pdbg = nullptr;
+#endif
+
+template <int TN>
+static int launch_planes(PlArgs a, bool f32out, hipStream_t stream) {
+  constexpr int BN = TN * 32;
+  a.nbm = (a.npanels + 15) / 16;
+  a.nbn = f32out ? (a.N + BN - 1) / BN : (a.c_kbn + TN - 1) / TN;
+  const int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
+  if (grid > 0x7fffffffLL) { set_error("usf_gemm_planes_bf16x3: grid too large"); return -3; }
+  if (f32out) hipLaunchKernelGGL((gemm_planes_kernel<TN, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_planes_kernel<TN, false>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+  return check_launch("usf_gemm_planes_bf16x3");
+}
+
+// column-block width (in 32-feature blocks) for an output of nblk blocks: the one that pads less, 5 on a tie
+int gemm_planes_tn(int64_t nblk) {
+  const int64_t pad5 = (nblk + 4) / 5 * 5 - nblk, pad4 = (nblk + 3) / 4 * 4 - nblk;
+  return pad4 < pad5 ? 4 : 5;
+}
+
+int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
+  if (!d) { set_error("usf_gemm_planes_bf16x3: null descriptor"); return -1; }
+  if (d->M < 0 || d->M > 0x7fffffff || d->nk <= 0 || d->a_nkb <= 0 || d->a_kb0 < 0 || d->a_kb0 + d->nk > d->a_nkb ||
+      d->w_rows < 4 || d->w_rows > 0x7fffffff) {
+    set_error("usf_gemm_planes_bf16x3: bad sizes (M=%lld nk=%lld a_nkb=%lld a_kb0=%lld w_rows=%lld)", (long long)d->M,
+              (long long)d->nk, (long long)d->a_nkb, (long long)d->a_kb0, (long long)d->w_rows);
+    return -2;
+  }
+  if (d->M == 0) return 0;
+  const bool f32out = d->C_f32 != nullptr;
+  if (!d->A || !d->W_planes || (!f32out && !d->C_planes)) { set_error("usf_gemm_planes_bf16x3: null A / W / C"); return -1; }
+  if (f32out && d->C_planes) { set_error("usf_gemm_planes_bf16x3: give C_planes or C_f32, not both"); return -2; }
+  if (!aligned16(d->A) || !aligned16(d->W_planes) || (d->C_planes && !aligned16(d->C_planes)) ||
+      (d->residual && !aligned16(d->residual)) || (d->bias && !aligned16(d->bias)) || (d->post_mul && !aligned16(d->post_mul))) {
+    set_error("usf_gemm_planes_bf16x3: pointers must be 16-byte aligned");
+    return -2;
+  }
+  if ((d->ldw & 7) || d->ldw < 32 * d->nk || (d->w_rows & 3)) { set_error("usf_gemm_planes_bf16x3: ldw must be a multiple of 8 and >= 32 nk; w_rows a multiple of 4"); return -2; }
+  if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_gemm_planes_bf16x3: bad act"); return -2; }
+  const int64_t npanels = (d->M + 15) / 16;
+  if (npanels * d->a_nkb * 3072 >= (1LL << 32) || 3 * d->w_plane_stride >= (1LL << 31)) {
+    set_error("usf_gemm_planes_bf16x3: operand larger than the kernel's 32-bit offsets");
+    return -3;
+  }
+  PlArgs a;
+  a.A = reinterpret_cast<const char*>(d->A); a.Wp = reinterpret_cast<const __bf16*>(d->W_planes);
+  a.bias = d->bias; a.post_mul = d->post_mul; a.R = reinterpret_cast<const char*>(d->residual);
+  a.Cp = reinterpret_cast<char*>(d->C_planes); a.Cf = d->C_f32; a.ldc = d->ldc; a.plane_stride = d->w_plane_stride;
+  a.ldwp = (int)d->ldw; a.wrows = (int)d->w_rows; a.M = (int)d->M; a.npanels = (int)npanels;
+  a.a_nkb = (int)d->a_nkb; a.a_kb0 = (int)d->a_kb0; a.nk = (int)d->nk;
+  a.c_nkb = (int)d->c_nkb; a.c_kb0 = (int)d->c_kb0; a.c_kbn = (int)d->c_kbn; a.N = (int)d->N;
+  a.res_sign = d->res_sign; a.slope = d->slope; a.act = d->act; a.nbm = a.nbn = 0;
+  a.dbg = nullptr;
+#ifdef USF_STAMP
+  a.dbg = g_pdbg;
+#endif
+  int64_t nblk;
+  if (f32out) {
+    if (d->N <= 0 || d->N > d->w_rows || d->ldc < d->N) { set_error("usf_gemm_planes_bf16x3: bad N / ldc for fp32 output"); return -2; }
+    if (d->residual) { set_error("usf_gemm_planes_bf16x3: residual needs planes output"); return -2; }
+    nblk = (d->N + 31) / 32;
+  } else {
+    if (d->c_kbn <= 0 || d->c_kb0 < 0 || d->c_kb0 + d->c_kbn > d->c_nkb || d->c_kbn * 32 > d->w_rows) {
+      set_error("usf_gemm_planes_bf16x3: bad output block range (c_kb0=%lld c_kbn=%lld c_nkb=%lld w_rows=%lld)",
+                (long long)d->c_kb0, (long long)d->c_kbn, (long long)d->c_nkb, (long long)d->w_rows);
+      return -2;
+    }
+    if (npanels * d->c_nkb * 3072 >= (1LL << 40)) { set_error("usf_gemm_planes_bf16x3: output too large"); return -3; }
+    nblk = d->c_kbn;
+  }
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("USF_PLANES_TN"); force = e ? atoi(e) : 0; }
+  const int tn = (force == 4 || force == 5) ? force : gemm_planes_tn(nblk);
+  return tn == 4 ? launch_planes<4>(a, f32out, stream) : launch_planes<5>(a, f32out, stream);
+}
+
+}  // namespace usf
