@@ -258,6 +258,9 @@ typedef struct usf_gemm_planes_desc {
   int32_t act, reserved;
 } usf_gemm_planes_desc;
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream);
+/* which instantiation serves the descriptor (nothing is launched): 5000 + 10 TN + (1: fp32 output, 0: planes output),
+ * TN = column-block width in 32-feature blocks (4 or 5, whichever pads the output less); 0 for empty extents */
+int usf_gemm_planes_variant(const usf_gemm_planes_desc* d);
 
 /*
  * Run a prebuilt list of ops with ONE call (the whole flow: ~2K+2 launches). op.kind selects the

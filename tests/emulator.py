@@ -78,6 +78,92 @@ def emulate_coupling(d, pm: PtrMap, dtype=torch.float32):
         pm.view(d.out + 4 * d.off_pass, M, d.n_pass, d.ldo).copy_(pm.view(d.z + 4 * d.off_pass, M, d.n_pass, d.ldz))
 
 
+# ---- planes pipeline (include/usflows_hip.h: usf_pack_planes_f32 / usf_gemm_planes_bf16x3) -------------------------
+def _slot_feature(s):
+    return 16 * ((s & 7) >> 2) + 4 * (s >> 3) + (s & 3)
+
+
+_SLOT_OF_FEATURE = [0] * 32
+for _s in range(32):
+    _SLOT_OF_FEATURE[_slot_feature(_s)] = _s
+
+
+def planes_view(pm: PtrMap, ptr, npanels, nkb):
+    """[npanels, nkb, 3, 64 lines, 8] bf16 view of a planes buffer at raw address ptr"""
+    raw = pm.view(ptr, 1, npanels * nkb * 3072, npanels * nkb * 3072, dtype=torch.uint8)[0]
+    return raw.view(torch.bfloat16).view(npanels, nkb, 3, 64, 8)
+
+
+def planes_decode(v, M):
+    """logical fp32 matrix [M, 32 nkb] of a planes view (p1 + p2 + p3 in fp32, exactly as the kernel reads it back)"""
+    npan, nkb = v.shape[0], v.shape[1]
+    x = (v[:, :, 0].float() + v[:, :, 1].float()) + v[:, :, 2].float()          # [npan, nkb, 64, 8]
+    x = x.view(npan, nkb, 4, 16, 8)                                               # line = 16 g + j -> [g, j, u]
+    out = torch.zeros(npan, 16, nkb, 32)
+    for g in range(4):
+        for u in range(8):
+            out[:, :, :, _slot_feature(8 * g + u)] = x[:, :, g, :, u].permute(0, 2, 1)
+    return out.reshape(npan * 16, nkb * 32)[:M]
+
+
+def planes_encode(v, X, kb0):
+    """write logical fp32 matrix X [M, 32 nb] into blocks kb0 .. of a planes view (3-way round-to-nearest split)"""
+    npan = v.shape[0]
+    M, nb = X.shape[0], X.shape[1] // 32
+    Xp = torch.zeros(npan * 16, nb * 32)
+    Xp[:M] = X
+    Xp = Xp.view(npan, 16, nb, 32)
+    p1 = Xp.to(torch.bfloat16)
+    r = Xp - p1.float()
+    p2 = r.to(torch.bfloat16)
+    p3 = (r - p2.float()).to(torch.bfloat16)
+    for pl, P in enumerate((p1, p2, p3)):
+        for g in range(4):
+            for u in range(8):
+                v[:, kb0: kb0 + nb, pl, 16 * g: 16 * g + 16, u] = P[:, :, :, _slot_feature(8 * g + u)].permute(0, 2, 1)
+
+
+def emulate_pack_planes(d, pm: PtrMap, dtype=torch.float32):
+    M, nkb = d.M, d.nkb
+    npan = -(-M // 16)
+    idx = pm.view(d.idx, 1, 32 * nkb, 32 * nkb, dtype=torch.int32)[0].long()
+    src = pm.view(d.src, M, int(idx.max()) + 1, d.ld)
+    X = torch.zeros(M, 32 * nkb)
+    ok = idx >= 0
+    X[:, ok] = src[:, idx[ok]]
+    if d.pre_div:
+        X[:, ok] = X[:, ok] / pm.vec(d.pre_div, 32 * nkb)[ok]
+    if d.pre_sub:
+        X[:, ok] = X[:, ok] - pm.vec(d.pre_sub, 32 * nkb)[ok]
+    planes_encode(planes_view(pm, d.planes, npan, nkb), X, 0)
+
+
+def emulate_gemm_planes(d, pm: PtrMap, dtype=torch.float32):
+    M = d.M
+    npan = -(-M // 16)
+    A = planes_decode(planes_view(pm, d.A, npan, d.a_nkb), M)[:, 32 * d.a_kb0: 32 * (d.a_kb0 + d.nk)]
+    Wp = pm.view(d.W_planes, 3, d.w_rows * d.ldw, d.w_plane_stride, dtype=torch.bfloat16).view(3, d.w_rows, d.ldw)
+    W = ((Wp[0].float() + Wp[1].float()) + Wp[2].float())[:, : 32 * d.nk]             # K axis in physical slot order
+    slot = torch.tensor([32 * (c // 32) + _SLOT_OF_FEATURE[c % 32] for c in range(32 * d.nk)])
+    W = W[:, slot]                                                                    # -> logical order
+    v = A.to(dtype) @ W.to(dtype).t()
+    if d.bias:
+        v = v + pm.vec(d.bias, d.w_rows).to(dtype)
+    if d.act == _ext.ACT_LEAKY_RELU:
+        v = torch.where(v > 0, v, v * d.slope)
+    if d.C_f32:
+        if d.post_mul:
+            v = v * pm.vec(d.post_mul, d.w_rows).to(dtype)
+        pm.view(d.C_f32, M, d.N, d.ldc).copy_(v[:, : d.N].to(torch.float32))
+        return
+    v = v[:, : 32 * d.c_kbn]
+    Cv = planes_view(pm, d.C_planes, npan, d.c_nkb)
+    if d.residual:
+        R = planes_decode(planes_view(pm, d.residual, npan, d.c_nkb), M)[:, 32 * d.c_kb0: 32 * (d.c_kb0 + d.c_kbn)]
+        v = R.to(dtype) + d.res_sign * v
+    planes_encode(Cv, v.to(torch.float32), d.c_kb0)
+
+
 def _gather(src, dst, idx):
     out = torch.zeros(src.shape[0], idx.numel())
     ok = idx >= 0
@@ -90,6 +176,8 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
     ws, pk = plan["ws"], plan["pk"]
     pm = PtrMap()
     for t in ws.values():
+        pm.add(t)
+    for t in eng.__dict__.get("_idx_cache", {}).values():
         pm.add(t)
     for group in ("mats", "vecs"):
         for t in pk[group].values():
@@ -114,10 +202,10 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
         ws["ctx4"][:, 0].copy_(context.reshape(B))
         ws["ctx"].copy_(context.reshape(B))
     arr = plan["arr"]
-    for idx in plan["patch_in"]:
-        arr[idx].u.linear.A = x.data_ptr()
-    for idx in plan["patch_out"]:
-        arr[idx].u.linear.C = out.data_ptr()
+    for idx, member, field in plan["patch_in"]:
+        setattr(getattr(arr[idx].u, member), field, x.data_ptr())
+    for idx, member, field in plan["patch_out"]:
+        setattr(getattr(arr[idx].u, member), field, out.data_ptr())
     pos = 0
 
     def run_until(end):
@@ -126,6 +214,10 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
             op = arr[pos]
             if op.kind == _ext.OP_LINEAR:
                 emulate_linear(op.u.linear, pm, dtype)
+            elif op.kind == _ext.OP_PACK_PLANES:
+                emulate_pack_planes(op.u.pack_planes, pm, dtype)
+            elif op.kind == _ext.OP_GEMM_PLANES:
+                emulate_gemm_planes(op.u.gemm_planes, pm, dtype)
             else:
                 emulate_coupling(op.u.coupling, pm, dtype)
             pos += 1
@@ -332,9 +424,10 @@ def install_prep_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
 
 
-def engine_transform(eng, x, direction, context=None, fused=False):
+def engine_transform(eng, x, direction, context=None, fused=False, planes=False):
     eng.use_fused_coupling = fused
     eng.fused_min_rows = 0
+    eng.use_planes, eng.planes_min_rows = planes, 0
     if fused:
         eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     B = x.shape[0]
@@ -344,9 +437,10 @@ def engine_transform(eng, x, direction, context=None, fused=False):
     return out
 
 
-def engine_latent(eng, x, context=None, fused=False):
+def engine_latent(eng, x, context=None, fused=False, planes=False):
     eng.use_fused_coupling = fused
     eng.fused_min_rows = 0
+    eng.use_planes, eng.planes_min_rows = planes, 0
     if fused:
         eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     plan = eng._plan("backward", x.shape[0], x.device, context is not None, "nat")

@@ -25,3 +25,13 @@ BASELINE_LINEAR_SHAPES = {
     "cfg4 (B=32768)": [(32768, 3072, 3072), (32768, 1024, 1536), (32768, 1024, 1024), (32768, 1536, 1024)],
     "cfg5 per rank (N=125000)": [(125000, 784, 784), (125000, 256, 392), (125000, 256, 256), (125000, 392, 256)],
 }
+
+# planes pipeline: (M, K blocks, output blocks or fp32 N as a negative number) of the usf_gemm_planes_bf16x3 launches that
+# tests/test_planes_gpu.py compares with reference arithmetic ...
+PLANES_TESTED = [(100, 3, 2), (1000, 25, 25), (3000, 13, 8), (3000, 8, 13), (8205, 25, -784), (513, 2, -77),
+                 (65536, 25, 25), (32768, 96, 96)]
+# ... and the launches of the BASELINE configurations' plans
+BASELINE_PLANES_SHAPES = {
+    "cfg2 / cfg3 / cfg5": [(65536, 25, 25), (65536, 13, 8), (65536, 8, 8), (65536, 8, 13), (65536, 25, -784)],
+    "cfg4": [(32768, 96, 96), (32768, 48, 32), (32768, 32, 32), (32768, 32, 48), (32768, 96, -3072)],
+}

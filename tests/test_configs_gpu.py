@@ -39,6 +39,8 @@ def plan_variants(eng):
         for j in range(plan["n"]):
             if arr[j].kind == _ext.OP_LINEAR:
                 out.add(lib.usf_linear_variant(C.byref(arr[j].u.linear)))
+            elif arr[j].kind == _ext.OP_GEMM_PLANES:
+                out.add(lib.usf_gemm_planes_variant(C.byref(arr[j].u.gemm_planes)))
     return out
 
 
@@ -77,11 +79,16 @@ def _properties(flow, x, lp, ladj, base=None, rt_tol=2e-4):
     return z
 
 
+@pytest.mark.parametrize("planes", [True, False])
 @pytest.mark.parametrize("B", [16384, 32768, 65536])
-def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B):
-    """B = 32768 is cfg3's per-rank batch (262144 / 8); with 16384 it selects the 128-row bf16x3 tile with the 2-buffer
-    ring, 65536 the 256-row tile with the 4-buffer ring."""
+def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B, planes):
+    """B = 32768 is cfg3's per-rank batch (262144 / 8).  planes=True: the default plan at these sizes (activations as
+    bf16 planes between layers, usf_gemm_planes_bf16x3); planes=False: the fp32-activation plan (what training, context
+    and small batches use) -- there 16384 / 32768 select the 128-row bf16x3 tile with the 2-buffer ring, 65536 the
+    256-row tile with the 4-buffer ring."""
     spec, sd, a, flow, ladj = cfg2
+    flow.engine().use_planes = planes
+    flow.engine()._plans.clear()
     x = torch.rand(B, 784, generator=torch.Generator().manual_seed(1234 + B))
     idx = place_probes(x, a["x"])
     xd = x.to(DEV)
@@ -98,8 +105,11 @@ def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B):
     s = max(1.0, a["backward64"].abs().max().item())
     assert (z[idx.to(DEV)].cpu().double() - a["backward64"]).abs().max().item() < 2e-5 * s
     v = plan_variants(eng)
-    want = {16384: 3542, 32768: 3542, 65536: 3584}[B]
-    assert want in v, (B, v)
+    if planes:
+        assert {5050, 5040, 5051} <= v, (B, v)      # affine / conditioner layers on planes, fp32 output of the last layer
+    else:
+        assert {16384: 3542, 32768: 3542, 65536: 3584}[B] in v, (B, v)
+    flow.engine().use_planes = True
 
 
 def test_cfg5_per_rank_sample(cfg2):
@@ -138,7 +148,7 @@ def test_cfg5_per_rank_sample(cfg2):
     # through the 65 layers, not bitwise)
     dev_ = (part - xs[5000:6000]).abs().max().item()
     assert dev_ < 2e-5 * max(1.0, xs.abs().max().item()), dev_
-    assert 3542 in plan_variants(eng) or 3584 in plan_variants(eng)
+    assert 5050 in plan_variants(eng) and 5051 in plan_variants(eng)
 
 
 @pytest.fixture(scope="module")
@@ -174,7 +184,7 @@ def test_cfg4_full_size(cfg4):
         xf = flow._forward(a["zin"].to(DEV))
     s = max(1.0, a["forward64"].abs().max().item())
     assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2e-5 * s
-    assert 3442 in plan_variants(eng), plan_variants(eng)      # (the 16-row _forward above takes the small-batch kernel)
+    assert {5040, 5041} <= plan_variants(eng), plan_variants(eng)  # (the 16-row _forward above takes the small-batch kernel)
 
 
 def test_laplace_head_extreme_words_are_finite():

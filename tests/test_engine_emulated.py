@@ -43,6 +43,29 @@ def test_engine_ops_reproduce_golden(name, fused):
     assert rel < 2e-5, rel
 
 
+@pytest.mark.parametrize("name", SMALL)
+def test_planes_pipeline_ops_reproduce_golden(name):
+    """the planes pipeline's launch list (usf_pack_planes_f32 + usf_gemm_planes_bf16x3 ops: block / slot permutation of
+    the activation planes, weight images in slot order, K-range of the conditioning blocks, in-place residual on the
+    transformed blocks) interpreted on CPU against the reference's outputs"""
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd)
+    eng = FlowEngine(flow.layers)
+    if a.get("context") is not None or spec.soft_training:
+        eng.use_planes, eng.planes_min_rows = True, 0
+        assert not eng._planes_ok("backward", 48, True, False)           # context: the fp32 path serves it
+        return
+    z = emulator.engine_transform(eng, a["x"], "backward", None, False, planes=True)
+    assert any(p.get("planes") for p in eng._plans.values()), "planes plan was not built"
+    assert (z.double() - a["backward64"]).abs().max().item() < _tol(a["backward64"])
+    xf = emulator.engine_transform(eng, a["zin"], "forward", None, False, planes=True)
+    assert (xf.double() - a["forward64"]).abs().max().item() < _tol(a["forward64"])
+    zl, logdet = emulator.engine_latent(eng, a["x"], None, False, planes=True)
+    lp = orc.base_log_prob(spec, zl.double()) + logdet
+    rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
+    assert rel < 2e-5, rel
+
+
 def test_single_layer_engines():
     """every layer type as a one-layer engine (what layer.forward/backward dispatch to)"""
     spec, sd, a = load_case("synth_d7_k3_hh1_conj_normal")

@@ -1,0 +1,194 @@
+"""Planes pipeline on a real MI355X, through the C ABI: usf_pack_planes_f32 / usf_gemm_planes_bf16x3 against torch
+reference arithmetic (kernel level), and whole flows through the planes launch plan against the reference's outputs."""
+import math
+
+import pytest
+import torch
+
+import emulator
+import shapes
+from golden_util import case_names, load_case
+from model_util import build_flow
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ext():
+    from usflows_amd import _ext
+    _ext.load()
+    return _ext
+
+
+def _view(buf, M, nkb):
+    return buf.cpu().view(torch.bfloat16).view(-(-M // 16), nkb, 3, 64, 8)
+
+
+def _weight_planes(W, n_rows_pad):
+    """[3, rows, K] bf16 planes of logical W [n, K] with the slot permutation on K (K a multiple of 32)"""
+    n, K = W.shape
+    Wp = torch.zeros(n_rows_pad, K)
+    Wp[:n] = W
+    phys = torch.tensor([32 * (c // 32) + emulator._slot_feature(c % 32) for c in range(K)])
+    Wp = Wp[:, phys]
+    p1 = Wp.to(torch.bfloat16)
+    r = Wp - p1.float()
+    p2 = r.to(torch.bfloat16)
+    p3 = (r - p2.float()).to(torch.bfloat16)
+    return torch.stack([p1, p2, p3]).contiguous()
+
+
+@pytest.mark.parametrize("M,D,nkb", [(1, 5, 1), (37, 50, 2), (1000, 784, 25), (4099, 96, 3)])
+def test_pack_planes_is_the_exact_three_way_split(M, D, nkb):
+    ext = _ext()
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D + 3, generator=g) * 5
+    perm = torch.randperm(D, generator=g)
+    idx = torch.full((32 * nkb,), -1, dtype=torch.int32)
+    pos = torch.randperm(32 * nkb, generator=g)[:D]
+    idx[pos] = perm.to(torch.int32)
+    pdiv = torch.rand(32 * nkb, generator=g) + 0.5
+    psub = torch.randn(32 * nkb, generator=g)
+    buf = torch.zeros(ext.planes_bytes(M, nkb), dtype=torch.uint8, device=DEV)
+    ext.pack_planes(x.to(DEV), buf, M=M, nkb=nkb, idx=idx.to(DEV), pre_div=pdiv.to(DEV), pre_sub=psub.to(DEV))
+    torch.cuda.synchronize()
+    Mp = -(-M // 16) * 16
+    got = emulator.planes_decode(_view(buf, M, nkb), Mp)
+    ref = torch.zeros(M, 32 * nkb)
+    ok = idx >= 0
+    ref[:, ok] = x[:, idx[ok].long()] / pdiv[ok] - psub[ok]
+    assert torch.equal(got[:M], ref)        # p1 + p2 + p3 == x exactly (24 significant bits in three bf16)
+    assert (got[M:] == 0).all()             # padding rows of the last panel: zeros
+
+
+CASES = [
+    # M, a_nkb, a_kb0, nk, out blocks (c_nkb, c_kb0, c_kbn) or fp32 N, flags
+    (100, 3, 0, 3, (4, 1, 2), dict(bias=True)),
+    (1000, 25, 0, 25, (25, 0, 25), dict(bias=True)),                              # affine, TN = 5
+    (3000, 25, 12, 13, (8, 0, 8), dict(bias=True, act=True)),                     # conditioner first layer (K range), TN = 4
+    (3000, 8, 0, 8, (25, 0, 13), dict(bias=True, residual=True, sign=-1.0)),      # conditioner last layer, in place
+    (3000, 8, 0, 8, (25, 12, 13), dict(bias=True, residual=True, sign=1.0)),
+    (8205, 25, 0, 25, 784, dict(bias=True, post_mul=True)),                       # fp32 output, ragged rows / columns
+    (513, 4, 1, 2, 77, dict()),                                                   # fp32 output, TN = 4
+    (65536, 25, 0, 25, (25, 0, 25), dict(bias=True)),                             # BASELINE cfg2 affine at full size
+    (32768, 96, 0, 96, (96, 0, 96), dict(bias=True)),                             # BASELINE cfg4 affine at full size
+]
+
+
+@pytest.mark.parametrize("M,a_nkb,a_kb0,nk,out,flags", CASES)
+def test_gemm_planes_parity(M, a_nkb, a_kb0, nk, out, flags):
+    ext = _ext()
+    g = torch.Generator().manual_seed(M + 31 * nk)
+    K = 32 * nk
+    f32out = isinstance(out, int)
+    n_out = out if f32out else 32 * out[2]
+    w_rows = -(-n_out // 32) * 32
+    X = torch.randn(M, 32 * a_nkb, generator=g) * 3
+    W = torch.randn(n_out, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(w_rows, generator=g) if flags.get("bias") else None
+    if bias is not None:
+        bias[n_out:] = 0
+    Abuf = torch.zeros(ext.planes_bytes(M, a_nkb), dtype=torch.uint8)
+    emulator.planes_encode(Abuf.view(torch.bfloat16).view(-(-M // 16), a_nkb, 3, 64, 8), X, 0)
+    Wp = _weight_planes(W, w_rows).to(DEV)
+    d = lambda t: None if t is None else t.to(DEV)
+    # reference on sampled rows (head / middle / tail) in fp64 and fp32
+    idx = torch.unique(torch.cat([torch.arange(0, min(M, 40)), torch.arange(max(M // 2 - 20, 0), min(M // 2 + 20, M)),
+                                  torch.arange(max(M - 40, 0), M)]))
+    Xk = X[idx][:, 32 * a_kb0: 32 * (a_kb0 + nk)]
+
+    def ref(dt):
+        v = Xk.to(dt) @ W.to(dt).t()
+        if bias is not None:
+            v = v + bias[:n_out].to(dt)
+        if flags.get("act"):
+            v = torch.nn.functional.leaky_relu(v, 0.01)
+        return v
+
+    if f32out:
+        pm = torch.randn(w_rows, generator=g) if flags.get("post_mul") else None
+        C = torch.full((M, n_out + 3), float("nan"), device=DEV)
+        ext.gemm_planes(Abuf.to(DEV), Wp, M=M, a_nkb=a_nkb, a_kb0=a_kb0, nk=nk, bias=d(bias), post_mul=d(pm), C_f32=C,
+                        ldc=n_out + 3, N=n_out)
+        torch.cuda.synchronize()
+        assert torch.isnan(C[:, n_out:]).all() and not torch.isnan(C[:, :n_out]).any()
+        got = C[:, :n_out].cpu()[idx].double()
+        r64, r32 = ref(torch.float64), ref(torch.float32)
+        if pm is not None:
+            r64, r32 = r64 * pm[:n_out].double(), r32 * pm[:n_out]
+    else:
+        c_nkb, c_kb0, c_kbn = out
+        R = torch.randn(M, 32 * c_nkb, generator=g) * 2
+        Cbuf = torch.zeros(ext.planes_bytes(M, c_nkb), dtype=torch.uint8)
+        emulator.planes_encode(Cbuf.view(torch.bfloat16).view(-(-M // 16), c_nkb, 3, 64, 8), R, 0)
+        Cd = Cbuf.to(DEV)
+        ext.gemm_planes(Abuf.to(DEV), Wp, M=M, a_nkb=a_nkb, a_kb0=a_kb0, nk=nk, bias=d(bias), C_planes=Cd, c_nkb=c_nkb,
+                        c_kb0=c_kb0, c_kbn=c_kbn, residual=Cd if flags.get("residual") else None,
+                        res_sign=flags.get("sign", 1.0), act=1 if flags.get("act") else 0, slope=0.01)
+        torch.cuda.synchronize()
+        full = emulator.planes_decode(_view(Cd, M, c_nkb), M)
+        lo, hi = 32 * c_kb0, 32 * (c_kb0 + c_kbn)
+        # blocks outside the output range are untouched
+        assert torch.equal(full[:, :lo], R[:, :lo]) and torch.equal(full[:, hi:], R[:, hi:])
+        got = full[idx][:, lo:hi].double()
+        r64, r32 = ref(torch.float64), ref(torch.float32)
+        if flags.get("residual"):
+            s = flags.get("sign", 1.0)
+            r64, r32 = R[idx][:, lo:hi].double() + s * r64, R[idx][:, lo:hi] + s * r32
+    scale = r64.abs().max().item()
+    err = (got - r64).abs().max().item() / scale
+    err32 = (r32.double() - r64).abs().max().item() / scale
+    assert err < max(4 * err32, 6e-8 * math.sqrt(K)), (err, err32)
+    assert err < 1e-5
+
+
+def test_gemm_planes_rejects_bad_args():
+    ext = _ext()
+    A = torch.zeros(ext.planes_bytes(64, 2), dtype=torch.uint8, device=DEV)
+    W = torch.zeros(3, 32, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.gemm_planes(A, W, M=64, a_nkb=2, a_kb0=1, nk=2, C_planes=A, c_nkb=2, c_kbn=1)      # K range past the buffer
+    with pytest.raises(RuntimeError):
+        ext.gemm_planes(A, W, M=64, a_nkb=2, nk=2)                                             # no output
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_parity_through_the_planes_plan(name):
+    """every golden case of the reference through the planes launch plan (forced: planes_min_rows = 0)"""
+    spec, sd, a = load_case(name)
+    if a.get("context") is not None or spec.soft_training:
+        pytest.skip("context: served by the fp32-activation path")
+    flow = build_flow(spec, sd, device=DEV)
+    eng = flow.engine()
+    eng.use_planes, eng.planes_min_rows = True, 0
+    with torch.no_grad():
+        lp = flow.log_prob(a["x"].to(DEV))
+        z = flow.backward(a["x"].to(DEV))
+        xf = flow._forward(a["zin"].to(DEV))
+    assert any(p.get("planes") for p in eng._plans.values()), "planes plan was not built"
+    rel = lambda u, v: ((u.double().cpu() - v.double()).abs() / v.double().abs().clamp_min(1e-30)).max().item()
+    assert rel(lp, a["log_prob64"]) < 1e-5 and rel(lp, a["log_prob32"]) < 1e-5, name
+    s = max(1.0, a["backward64"].abs().max().item())
+    assert (z.cpu().double() - a["backward64"]).abs().max().item() < 2e-5 * s
+    s = max(1.0, a["forward64"].abs().max().item())
+    assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2e-5 * s
+
+
+@pytest.mark.parametrize("B", [1, 17, 8191, 8200])
+def test_planes_plan_ragged_rows_vs_fp32_plan(B):
+    """row counts that are not multiples of the 16-row panels / 256-row blocks: planes plan == fp32-activation plan"""
+    from oracle import usflows_oracle as orc
+    spec = orc.FlowSpec(72, 3, [40, 24], householder=1, affine_conjugation=True)
+    sd = orc.synth_state_dict(spec, seed=31)
+    flow = build_flow(spec, sd, device=DEV)
+    eng = flow.engine()
+    x = torch.rand(B, 72, generator=torch.Generator().manual_seed(B)).to(DEV)
+    with torch.no_grad():
+        eng.use_planes, eng.planes_min_rows = True, 0
+        lp1, z1 = flow.log_prob(x), flow.backward(x)
+        eng.use_planes = False
+        lp2, z2 = flow.log_prob(x), flow.backward(x)
+    assert ((lp1 - lp2).abs() / lp2.abs()).max().item() < 5e-6
+    assert (z1 - z2).abs().max().item() < 1e-4 * max(1.0, z2.abs().max().item())
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x[:64].cpu().double())
+    assert ((lp1[:64].cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5

@@ -41,3 +41,22 @@ def test_every_baseline_instantiation_is_parity_tested():
         for s in lst:
             if s[1] >= 784 or cfg.startswith("cfg4"):
                 assert s in shapes.BF16X3_BIG, (cfg, s)
+
+
+def _planes_variant(M, nk, out):
+    from usflows_amd import _ext
+    d = _ext.GemmPlanesDesc()
+    d.M, d.nk, d.a_nkb = M, nk, nk
+    if out < 0:
+        d.C_f32, d.N = 1 << 20, -out
+    else:
+        d.C_planes, d.c_kbn, d.c_nkb = 1 << 20, out, out
+    return _ext.load().usf_gemm_planes_variant(C.byref(d))
+
+
+def test_every_baseline_planes_instantiation_is_parity_tested():
+    tested = {_planes_variant(*s) for s in shapes.PLANES_TESTED}
+    assert tested == {5040, 5041, 5050, 5051}                  # all four instantiations of gemm_planes_kernel
+    for cfg, lst in shapes.BASELINE_PLANES_SHAPES.items():
+        for s in lst:
+            assert _planes_variant(*s) in tested, (cfg, s)

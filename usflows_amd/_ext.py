@@ -113,6 +113,7 @@ SYMBOLS = {
     "usf_linear_variant": (C.c_int, [C.POINTER(LinearDesc)]),
     "usf_pack_planes_f32": (C.c_int, [C.POINTER(PackPlanesDesc), C.c_void_p]),
     "usf_gemm_planes_bf16x3": (C.c_int, [C.POINTER(GemmPlanesDesc), C.c_void_p]),
+    "usf_gemm_planes_variant": (C.c_int, [C.POINTER(GemmPlanesDesc)]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
@@ -290,6 +291,33 @@ def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_
     d.M, d.N, d.K = M, N, K
     d.res_sign, d.slope, d.act = res_sign, slope, act
     _launch("usf_linear_f32", (C.byref(d), current_stream(A.device)), d)
+
+
+def planes_bytes(M: int, nkb: int) -> int:
+    """size of a planes buffer of M rows and nkb 32-feature blocks (include/usflows_hip.h)"""
+    return (-(-M // 16)) * nkb * 3072
+
+
+def pack_planes(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None):
+    d = PackPlanesDesc()
+    d.src, d.ld, d.M, d.nkb = src.data_ptr(), (src.stride(0) if ld is None else ld), M, nkb
+    d.idx, d.pre_div, d.pre_sub, d.planes = idx.data_ptr(), ptr(pre_div), ptr(pre_sub), planes.data_ptr()
+    _launch("usf_pack_planes_f32", (C.byref(d), current_stream(src.device)), (d, src, planes, idx, pre_div, pre_sub))
+
+
+def gemm_planes(A, W_planes, *, M, a_nkb, nk, a_kb0=0, bias=None, post_mul=None, residual=None, C_planes=None, c_nkb=0,
+                c_kb0=0, c_kbn=0, C_f32=None, ldc=0, N=0, res_sign=1.0, act=ACT_NONE, slope=0.0):
+    """usf_gemm_planes_bf16x3; W_planes: [3, w_rows, ldw] bf16 (K axis in slot order)"""
+    d = GemmPlanesDesc()
+    d.A, d.a_nkb, d.a_kb0, d.nk = A.data_ptr(), a_nkb, a_kb0, nk
+    d.W_planes, d.ldw, d.w_plane_stride, d.w_rows = (W_planes.data_ptr(), W_planes.shape[2],
+                                                      W_planes.shape[1] * W_planes.shape[2], W_planes.shape[1])
+    d.bias, d.post_mul, d.residual = ptr(bias), ptr(post_mul), ptr(residual)
+    d.C_planes, d.c_nkb, d.c_kb0, d.c_kbn = ptr(C_planes), c_nkb, c_kb0, c_kbn
+    d.C_f32, d.ldc, d.N, d.M = ptr(C_f32), ldc, N, M
+    d.res_sign, d.slope, d.act = res_sign, slope, act
+    _launch("usf_gemm_planes_bf16x3", (C.byref(d), current_stream(A.device)),
+            (d, A, W_planes, bias, post_mul, residual, C_planes, C_f32))
 
 
 def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):

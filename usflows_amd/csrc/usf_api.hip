@@ -34,6 +34,7 @@ int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t
 
 int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream);
 int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream);
+int gemm_planes_variant(const usf_gemm_planes_desc* d);
 int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream);
 int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
              double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
@@ -90,6 +91,7 @@ int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream) {
 int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream) { return usf::pack_planes(d, (hipStream_t)stream); }
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream) { return usf::gemm_planes(d, (hipStream_t)stream); }
 
+int usf_gemm_planes_variant(const usf_gemm_planes_desc* d) { return usf::gemm_planes_variant(d); }
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }
 

@@ -339,6 +339,15 @@ int gemm_planes_tn(int64_t nblk) {
   return pad4 < pad5 ? 4 : 5;
 }
 
+// which instantiation usf_gemm_planes_bf16x3 launches for this descriptor: 5000 + 10 TN + (1: fp32 output, 0: planes)
+int gemm_planes_variant(const usf_gemm_planes_desc* d) {
+  if (!d || d->M <= 0) return 0;
+  const bool f32out = d->C_f32 != nullptr;
+  const int64_t nblk = f32out ? (d->N + 31) / 32 : d->c_kbn;
+  if (nblk <= 0) return 0;
+  return 5000 + 10 * gemm_planes_tn(nblk) + (f32out ? 1 : 0);
+}
+
 int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_gemm_planes_bf16x3: null descriptor"); return -1; }
   if (d->M < 0 || d->M > 0x7fffffff || d->nk <= 0 || d->a_nkb <= 0 || d->a_kb0 < 0 || d->a_kb0 + d->nk > d->a_nkb ||

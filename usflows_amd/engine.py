@@ -238,6 +238,10 @@ class FlowEngine:
         # USFLOWS_AMD_GRAPH=1: batches up to graph_max_rows replay their launch list as one hipGraph.  Off by default:
         # measured on MI355X / ROCm 7.2 the replay is no faster than the C-side launch loop of usf_run_ops (cfg2,
         # B = 100: 1.22 ms either way) -- the ~7 us between two dependent dispatches is not host time
+        # planes pipeline: from planes_min_rows rows, inference plans in bf16x3 mode keep the activations
+        # between layers as pre-split bf16 planes in MFMA-operand order (usf_planes.hip); USFLOWS_AMD_PLANES=0 disables
+        self.use_planes = os.environ.get("USFLOWS_AMD_PLANES", "1") != "0"
+        self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
         self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
         self.graph_max_rows = 1024
         self._layout_from_masks()
@@ -288,6 +292,12 @@ class FlowEngine:
         nat = torch.full((self.LDn,), -1, dtype=torch.long)
         nat[:D] = torch.arange(D)
         self.nat_idx = nat
+        # the same two layouts padded to whole 32-feature blocks (planes pipeline, usf_planes.hip)
+        self.LDp, self.LDnp = _round_up(self.LD, 32), _round_up(D, 32)
+        self.segp_idx = torch.full((self.LDp,), -1, dtype=torch.long)
+        self.segp_idx[: self.LD] = seg
+        self.natp_idx = torch.full((self.LDnp,), -1, dtype=torch.long)
+        self.natp_idx[:D] = torch.arange(D)
         self.hmax = 4
         for s in self.steps:
             if s.kind == "coupling":
@@ -315,7 +325,7 @@ class FlowEngine:
         self._plans.clear()
 
     def _idx(self, layout: str) -> torch.Tensor:
-        return self.seg_idx if layout == "seg" else self.nat_idx
+        return {"seg": self.seg_idx, "nat": self.nat_idx, "segp": self.segp_idx, "natp": self.natp_idx}[layout]
 
     @staticmethod
     def _perm_mat(mat64: torch.Tensor, out_idx: torch.Tensor, in_idx: torch.Tensor) -> torch.Tensor:
@@ -616,6 +626,8 @@ class FlowEngine:
         # per size class at the end (nothing reads them before the plan runs); the launch joins the pack's tape
         pk = self.pack(device)
         with self._pk_record(pk), _ext.batch_jobs(device):
+            if self._planes_ok(direction, B, has_ctx, train):
+                return self._build_plan_planes(direction, B, device, final)
             return self._build_plan_body(direction, B, device, has_ctx, final, train)
 
     def _build_plan_body(self, direction: str, B: int, device, has_ctx: bool, final: str, train: bool = False) -> dict:
@@ -796,8 +808,217 @@ class FlowEngine:
             final_gather = (cur, "nat2")
             cur = ("nat2", "nat", self.LDn)
         arr = (_ext.Op * max(len(ops), 1))(*ops)
-        return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=side,
+        return dict(arr=arr, n=len(ops), patch_in=[(i_, "linear", "A") for i_ in patch_in],
+                    patch_out=[(i_, "linear", "C") for i_ in patch_out], side=side,
                     final_gather=final_gather, out_buf=cur, ws=ws, pk=pk, meta=meta)
+
+    # ---- planes pipeline (usf_planes.hip) ---------------------------------------------------------
+    @staticmethod
+    def _slot_feature(s_: int) -> int:
+        """feature offset (0..31) held by slot s of a 32-feature block of a planes buffer (include/usflows_hip.h)"""
+        return 16 * ((s_ & 7) >> 2) + 4 * (s_ >> 3) + (s_ & 3)
+
+    def _phys(self, logical: torch.Tensor) -> torch.Tensor:
+        """reorder a per-logical-position selector (length a multiple of 32) into physical slot order"""
+        n = int(logical.numel())
+        perm = torch.tensor([32 * (c // 32) + self._slot_feature(c % 32) for c in range(n)], dtype=torch.long)
+        return logical[perm]
+
+    def _planes_ok(self, direction: str, B: int, has_ctx: bool, train: bool) -> bool:
+        if (train or has_ctx or not self.use_planes or self.gemm_mode != "bf16x3" or B < self.planes_min_rows
+                or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
+            return False
+        prims = self._primitive_ops(direction)
+        kinds = [p_[0] for p_ in prims]
+        for k_, kind in enumerate(kinds):
+            if kind == "scale_div" and not (k_ == 0 and len(kinds) > 1 and kinds[1] == "affine_bwd"):
+                return False
+            if kind == "scale_mul" and not (k_ == len(kinds) - 1 and k_ > 0 and kinds[k_ - 1] == "affine_fwd"):
+                return False
+        body = [k_ for k_ in kinds if not k_.startswith("scale")]
+        # the last layer must be an affine (it writes the fp32 result) and the chain needs at least two GEMM-sized ops
+        return len(body) >= 2 and body[-1].startswith("affine")
+
+    def _planes_image(self, pk, key, src, out_sel: torch.Tensor, in_sel: torch.Tensor):
+        """cached bf16x3 planes [3, len(out_sel), len(in_sel)] of src[out_sel][:, in_sel] (-1: zero), one queued launch"""
+        mats = pk["mats"]
+        if key not in mats:
+            dev = src.device
+            n_out, n_in = int(out_sel.numel()), int(in_sel.numel())
+            P = torch.empty(3, n_out, n_in, dtype=torch.bfloat16, device=dev)
+            _ext.pack_weight(src, out_sel.to(device=dev, dtype=torch.int32), n_out,
+                             in_sel.to(device=dev, dtype=torch.int32), n_in, planes=P)
+            mats[key] = P
+        return mats[key]
+
+    def _planes_vec(self, pk, key, src, sel: torch.Tensor, pad: float = 0.0) -> torch.Tensor:
+        """cached fp32 vector src[sel] (-1: pad) of length len(sel)"""
+        vecs = pk["vecs"]
+        if key not in vecs:
+            dev = src.device
+            n = int(sel.numel())
+            if pad == 0.0:
+                out = torch.empty(n, dtype=torch.float32, device=dev)
+                _ext.pack_weight(src.reshape(1, -1), None, 1, sel.to(device=dev, dtype=torch.int32), n, W=out, ldw=n,
+                                 ld_src=src.numel())
+                vecs[key] = out
+            else:
+                vecs[key] = _refreshed((n,), torch.float32, dev,
+                                       lambda o, src=src, sel=sel: o.copy_(self._perm_vec(src.double(), sel, pad)))
+        return vecs[key]
+
+    def _build_plan_planes(self, direction: str, B: int, device, final: str) -> dict:
+        """Launch list of the planes pipeline: pack -> (GEMM on planes)* -> GEMM with fp32 output.
+
+        Every layer is the same kernel: an affine block one GEMM, an additive coupling the chain of its conditioner's
+        dense layers (the hidden activations make a round trip through HBM / the Infinity Cache as planes; the last
+        one adds / subtracts into the transformed half of z IN PLACE, reading the residual from the planes).  The
+        buffer z keeps the engine's segment layout [mask==0 | mask==1] padded to whole 32-feature blocks; a coupling
+        reads the blocks that hold its conditioning features (zero weights on the others) and rewrites the blocks
+        that hold its transformed features (zero rows elsewhere: those values are rewritten unchanged)."""
+        pk = self.pack(device)
+        ws = self._workspace(B, device)
+        prims = self._primitive_ops(direction)
+        npan = -(-B // 16)
+        nkb = self.LDp // 32
+        segp, natp = self.segp_idx, self.natp_idx
+        seg_phys = self._phys(segp)
+        Hp = _round_up(self.hmax, 32)
+
+        def planes_buf(name, blocks):
+            if name not in ws:
+                ws[name] = torch.empty(npan * blocks * 3072, dtype=torch.uint8, device=device)
+            return ws[name]
+
+        zbufs = [planes_buf("pzA", nkb), planes_buf("pzB", nkb)]
+        cur = 0
+        ops: List[_ext.Op] = []
+        patch_in, patch_out = [], []
+
+        def gemm_op(**kw) -> _ext.Op:
+            op = _ext.Op()
+            op.kind = _ext.OP_GEMM_PLANES
+            g = op.u.gemm_planes
+            g.M, g.res_sign, g.slope, g.act = B, 1.0, 0.0, _ext.ACT_NONE
+            for k_, v_ in kw.items():
+                setattr(g, k_, v_)
+            return op
+
+        # ---- head: the caller's fp32 rows -> planes in segment layout (+ x / s - b of the first layer) -------------
+        n = len(prims)
+        k = 0
+        pack = _ext.Op()
+        pack.kind = _ext.OP_PACK_PLANES
+        d = pack.u.pack_planes
+        d.src, d.ld, d.M, d.nkb = 0, self.D, B, nkb
+        d.idx = self._idx_dev("segp", device).data_ptr()
+        d.planes = zbufs[cur].data_ptr()
+        first_bias_in_prologue = False
+        if prims[0][0] == "scale_div":
+            s0 = self.steps[prims[0][1]]
+            blk = self.steps[prims[1][1]].module
+            d.pre_div = self._planes_vec(pk, ("pl_scale", id(s0.module), "segp"), pk["scale"][id(s0.module)], segp, 1.0).data_ptr()
+            d.pre_sub = self._planes_vec(pk, ("pl_b", id(blk), "segp"), pk["affine"][id(blk)]["b"], segp).data_ptr()
+            first_bias_in_prologue = True
+            k = 1
+        patch_in.append((len(ops), "pack_planes", "src"))
+        ops.append(pack)
+
+        while k < n:
+            prim, i = prims[k]
+            s = self.steps[i]
+            nxt = prims[k + 1] if k + 1 < n else None
+            if prim in ("affine_fwd", "affine_bwd"):
+                blk = s.module
+                a = pk["affine"][id(blk)]
+                fuse_post = prim == "affine_fwd" and nxt is not None and nxt[0] == "scale_mul"
+                is_last = (k == n - 1) or (fuse_post and k == n - 2)
+                out_sel = natp if is_last else segp
+                which = "Minv" if prim == "affine_bwd" else "M"
+                W = self._planes_image(pk, ("pl_aff", id(blk), which, is_last), a[which], out_sel, seg_phys)
+                kw = dict(A=zbufs[cur].data_ptr(), a_nkb=nkb, a_kb0=0, nk=nkb, W_planes=W.data_ptr(), ldw=W.shape[2],
+                          w_plane_stride=W.shape[1] * W.shape[2], w_rows=W.shape[1])
+                lay = "natp" if is_last else "segp"
+                if prim == "affine_bwd":
+                    if first_bias_in_prologue:
+                        first_bias_in_prologue = False        # (x / s - b) @ Minv^T: bias already subtracted by the head
+                    else:
+                        # (y - b) @ Minv^T == y @ Minv^T + c, c = -(Minv b) formed in fp64 at pack time ("bias folding")
+                        if "c" not in a:
+                            a["c"] = torch.empty(a["b"].shape, dtype=torch.float64, device=a["b"].device)
+                            _ext.flush_jobs()
+                            _ext.matvec_f64(a["Minv"], a["b"].contiguous(), alpha=-1.0, out64=a["c"])
+                        kw["bias"] = self._planes_vec(pk, ("pl_c", id(blk), lay), a["c"], out_sel).data_ptr()
+                else:
+                    kw["bias"] = self._planes_vec(pk, ("pl_b", id(blk), lay), a["b"], out_sel).data_ptr()
+                if is_last:
+                    if fuse_post:
+                        s2 = self.steps[nxt[1]]
+                        kw["post_mul"] = self._planes_vec(pk, ("pl_scale", id(s2.module), "natp"),
+                                                          pk["scale"][id(s2.module)], natp, 1.0).data_ptr()
+                        k += 1
+                    if final == "user":
+                        kw.update(C_f32=0, ldc=self.D, N=self.D)
+                        patch_out.append((len(ops), "gemm_planes", "C_f32"))
+                        out_buf = ("user_out", "nat", self.D)
+                    else:
+                        if "nat2" not in ws:
+                            ws["nat2"] = torch.zeros(B, self.LDn, dtype=torch.float32, device=device)
+                        kw.update(C_f32=ws["nat2"].data_ptr(), ldc=self.LDn, N=self.D)
+                        out_buf = ("nat2", "nat", self.LDn)
+                else:
+                    kw.update(C_planes=zbufs[1 - cur].data_ptr(), c_nkb=nkb, c_kb0=0, c_kbn=nkb)
+                    cur = 1 - cur
+                ops.append(gemm_op(**kw))
+                k += 1
+                continue
+            # ---- additive coupling: its conditioner MLP as a chain of GEMMs, in place on the transformed blocks ----
+            cp = pk["coupling"][i]
+            raw = cp["raw"]
+            sign = 1.0 if prim == "coupling_fwd" else -1.0
+            z = zbufs[cur]
+            lo_p, hi_p = cp["pass_off"], cp["pass_off"] + int((raw["pass_idx"] >= 0).sum())
+            lo_t, hi_t = cp["tr_off"], cp["tr_off"] + cp["tr_n"]
+            kb_p0, kb_p1 = lo_p // 32, -(-hi_p // 32)
+            kb_t0, kb_t1 = lo_t // 32, -(-hi_t // 32)
+            pos = torch.arange(self.LDp)
+            feat_p = torch.where((pos >= lo_p) & (pos < hi_p), segp, torch.full_like(segp, -1))
+            feat_t = torch.where((pos >= lo_t) & (pos < hi_t), segp, torch.full_like(segp, -1))
+            layers = [raw["first"]] + list(raw["hidden"]) + [raw["last"]]
+            h = list(raw["h"])
+            hbufs = [planes_buf("pH1", Hp // 32), planes_buf("pH2", Hp // 32)]
+            src_buf, src_nkb, src_kb0, src_nk = z, nkb, kb_p0, kb_p1 - kb_p0
+            in_sel = self._phys(feat_p[32 * kb_p0: 32 * kb_p1])
+            for j, (W_, b_) in enumerate(layers):
+                last = j == len(layers) - 1
+                if last:
+                    out_sel = feat_t[32 * kb_t0: 32 * kb_t1]
+                else:
+                    hj = _round_up(h[j], 32)
+                    out_sel = torch.full((hj,), -1, dtype=torch.long)
+                    out_sel[: h[j]] = torch.arange(h[j])
+                Wimg = self._planes_image(pk, ("pl_mlp", i, j), W_, out_sel, in_sel)
+                bvec = self._planes_vec(pk, ("pl_mlpb", i, j), b_, out_sel)
+                kw = dict(A=src_buf.data_ptr(), a_nkb=src_nkb, a_kb0=src_kb0, nk=src_nk, W_planes=Wimg.data_ptr(),
+                          ldw=Wimg.shape[2], w_plane_stride=Wimg.shape[1] * Wimg.shape[2], w_rows=Wimg.shape[1],
+                          bias=bvec.data_ptr())
+                if last:
+                    kw.update(C_planes=z.data_ptr(), c_nkb=nkb, c_kb0=kb_t0, c_kbn=kb_t1 - kb_t0, residual=z.data_ptr(),
+                              res_sign=sign)
+                else:
+                    dst = hbufs[j % 2]
+                    kw.update(C_planes=dst.data_ptr(), c_nkb=Hp // 32, c_kb0=0, c_kbn=hj // 32, act=cp["act"],
+                              slope=cp["slope"])
+                    src_buf, src_nkb, src_kb0, src_nk = dst, Hp // 32, 0, hj // 32
+                    hsel = torch.full((hj,), -1, dtype=torch.long)
+                    hsel[: h[j]] = torch.arange(h[j])
+                    in_sel = self._phys(hsel)
+                ops.append(gemm_op(**kw))
+            k += 1
+
+        arr = (_ext.Op * len(ops))(*ops)
+        return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=[], final_gather=None,
+                    out_buf=out_buf, ws=ws, pk=pk, meta=[], planes=True)
 
     # fused coupling kernel availability (filled in when the kernel is present)
     def _fused_ok(self, cp) -> bool:
@@ -896,7 +1117,7 @@ class FlowEngine:
     def _plan(self, direction, B, device, has_ctx, final, train: bool = False):
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
-               train)
+               train, self.use_planes, self.planes_min_rows)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final, train)
@@ -966,10 +1187,10 @@ class FlowEngine:
             ws["ctx4"][:, 0].copy_(c)
             ws["ctx"].copy_(c)
         arr = plan["arr"]
-        for idx in plan["patch_in"]:
-            arr[idx].u.linear.A = x.data_ptr()
-        for idx in plan["patch_out"]:
-            arr[idx].u.linear.C = out.data_ptr()
+        for idx, member, field in plan["patch_in"]:
+            setattr(getattr(arr[idx].u, member), field, x.data_ptr())
+        for idx, member, field in plan["patch_out"]:
+            setattr(getattr(arr[idx].u, member), field, out.data_ptr())
         lib = _ext.load()
         stream = _ext.current_stream(dev)
         pos = 0
@@ -983,6 +1204,11 @@ class FlowEngine:
                     if op.kind == _ext.OP_LINEAR:
                         kind = "linear_bf16x3" if op.u.linear.W_split else "linear"
                         tag = (kind, op.u.linear.M, op.u.linear.N, op.u.linear.K)
+                    elif op.kind == _ext.OP_GEMM_PLANES:
+                        g_ = op.u.gemm_planes
+                        tag = ("gemm_planes", g_.M, g_.N if g_.C_f32 else 32 * g_.c_kbn, 32 * g_.nk)
+                    elif op.kind == _ext.OP_PACK_PLANES:
+                        tag = ("pack_planes", op.u.pack_planes.M, 32 * op.u.pack_planes.nkb, 0)
                     else:
                         tag = ("coupling", op.u.coupling.M, op.u.coupling.n_trans, op.u.coupling.n_pass)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
