@@ -58,8 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run couplings as 3 linear ops instead of the fused kernel")
     ap.add_argument("--fused-min-rows", type=int, default=None, help="batch size from which couplings take the fused kernel")
-    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=None,
-                    help="affine GEMM arithmetic: bf16x3 = 3-way split on the bf16 MFMA (default), f32 = exact-f32 MFMA")
+    ap.add_argument("--gemm", choices=["bf16x3", "f16x2", "f32"], default=None,
+                    help="GEMM arithmetic: bf16x3 = 3-way bf16 split (24 bits/operand, 6 MFMAs per product), f16x2 = 2-way "
+                         "fp16 split in the planes pipeline (22 bits/operand, 3 MFMAs per product), f32 = exact-f32 MFMA")
     ap.add_argument("--mode", choices=["log_prob", "sample", "train"], default=None,
                     help="sample: time Flow.sample (Philox head + forward pass); train: one optimiser step of Flow.fit's "
                          "loss (-log_prob.mean(): device forward + backward + Adam)")
@@ -232,6 +233,17 @@ def main():
                 # fp32-equivalent GEMM on the bf16 matrix cores: 6 bf16 MFMA products per fp32 product, so the
                 # roof for ALGORITHMIC (fp32) flops is the dense bf16 peak / 6
                 peak, peak_note = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
+        elif dom[0] == "gemm_planes":
+            _, M, N, K = dom
+            flops = 2.0 * M * min(N, D) * min(K, D) if (N >= D and K >= D) else 2.0 * M * N * K
+            what = "BlockAffineTransform D x D" if (N >= D and K >= D) else f"conditioner layer N={N} K={K}"
+            f16 = eng.gemm_mode == "f16x2"
+            name = f"gemm_planes_kernel<{2 if f16 else 3},5,planes> ({what})"
+            base = "gemm_planes_kernel"
+            if f16:
+                peak, peak_note = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1), "dense f16 MFMA peak (2500) / 3 products per fp32 product (fp16x2 split)"
+            else:
+                peak, peak_note = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1), "dense bf16 MFMA peak (2500) / 6 products per fp32 product"
         else:
             _, M, ntr, npass = dom
             flops = 2.0 * M * (npass * hs[0] + sum(a * b for a, b in zip(hs[:-1], hs[1:])) + hs[-1] * ntr)
@@ -351,6 +363,8 @@ def main():
            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": scaling, "vs_baseline": None,
            "dtype": ("f32" if (not on_gpu or eng.gemm_mode == "f32") else
+                     "f32 (GEMMs as fp16x2 split on the f16 MFMA: 22 significant bits per operand, 3 products, fp32 accumulate)"
+                     if eng.gemm_mode == "f16x2" else
                      "f32 (GEMMs as bf16x3 split on the bf16 MFMA: 24 significant bits, fp32 accumulate)"),
            "data": "synthetic",
            "world_size": world, "backend": backend, "device": str(dev),

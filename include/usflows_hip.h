@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 8
+#define USF_ABI_VERSION 9
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -219,6 +219,10 @@ int usf_gather_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, 
 /* fp32 row-major -> planes:  logical position l of row m  <-  (src[m, idx[l]] / pre_div[l]) - pre_sub[l]
  * (idx[l] < 0: zero; pre_div / pre_sub optional).  Head of Flow.log_prob (ScaleTransform.backward + the tail affine
  * layer's bias subtraction, transforms.py:116-125, 960) and of Flow.sample (base noise). */
+#define USF_PLANES_BF16X3 0 /* three bf16 planes: 24 significant bits, fp32's exponent range; six MFMAs per product */
+#define USF_PLANES_F16X2 1  /* two fp16 planes: 22 significant bits; three MFMAs per product (a1 w1 + a1 w2 + a2 w1);
+                             * values must stay inside fp16's range: see range_flag.  Weight planes of this format:
+                             * usf_pack_weight_f32 with bit 1 of `transpose` set (two planes instead of three) */
 typedef struct usf_pack_planes_desc {
   const float* src; int64_t ld;         /* [M, ld] */
   int64_t M;
@@ -227,6 +231,9 @@ typedef struct usf_pack_planes_desc {
   const float* pre_div;                 /* [32 * nkb] or NULL */
   const float* pre_sub;                 /* [32 * nkb] or NULL */
   void* planes;
+  int32_t format, reserved;             /* USF_PLANES_* */
+  int32_t* range_flag;                  /* F16X2 only, may be NULL: set to 1 when a value is NaN or |x| >= 65000 (cannot
+                                           travel as fp16): the caller must then redo the pass in BF16X3 */
 } usf_pack_planes_desc;
 int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream);
 
@@ -255,7 +262,11 @@ typedef struct usf_gemm_planes_desc {
   float* C_f32; int64_t ldc, N;
   int64_t M;
   float res_sign, slope;
-  int32_t act, reserved;
+  int32_t act;
+  int32_t format;                       /* USF_PLANES_*: of A, W_planes, residual and C_planes alike */
+  int32_t* range_flag;                  /* F16X2 only, may be NULL: set to 1 when an output that has to travel as fp16
+                                           planes is NaN or |x| >= 65000, or an fp32 output is not finite (an overflowed
+                                           plane upstream) -- the results of the pass are void, redo it in BF16X3 */
 } usf_gemm_planes_desc;
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream);
 /* which instantiation serves the descriptor (nothing is launched): 5000 + 10 TN + (1: fp32 output, 0: planes output),
@@ -328,9 +339,10 @@ int usf_gemm_f64(const double* A, int64_t lda, int64_t strideA, int32_t transA, 
 int usf_householder_f64(const float* w_0, const float* vk, int64_t nvs, int64_t D, double* out, usf_stream_t stream);
 
 /* fp64 (or, src_is_f32 != 0, fp32) matrix -> the fp32 weight image the kernels read, rounded once:
- *   W[o, c] = (float) src[out_idx[o], in_idx[c]]   (transpose != 0: src[in_idx[c], out_idx[o]]),   0 where an index is < 0
+ *   W[o, c] = (float) src[out_idx[o], in_idx[c]]   (transpose & 1: src[in_idx[c], out_idx[o]]),   0 where an index is < 0
  * for o < n_out, c < n_in (idx: int32 device arrays or NULL = identity), and, if planes != NULL, the bf16x3 planes of
- * the same values ([3][n_out][ld_planes] bf16, zero for c >= n_in; usf_linear_desc.W_split).  W may be NULL.
+ * the same values ([3][n_out][ld_planes] bf16, zero for c >= n_in; usf_linear_desc.W_split) or, with transpose & 2,
+ * the fp16x2 planes ([2][n_out][ld_planes] fp16: hi = fp16(w), lo = fp16(w - hi); USF_PLANES_F16X2).  W may be NULL.
  * Also builds the mask-aware, zero-padded (and, for the split planes, k-permuted) conditioner weights of
  * usf_coupling_desc from the nn.Linear parameters (networks.py:711-737) and, with n_out == 1, permuted vectors. */
 int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int32_t transpose, const int32_t* out_idx, int64_t n_out,

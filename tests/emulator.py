@@ -88,16 +88,19 @@ for _s in range(32):
     _SLOT_OF_FEATURE[_slot_feature(_s)] = _s
 
 
-def planes_view(pm: PtrMap, ptr, npanels, nkb):
-    """[npanels, nkb, 3, 64 lines, 8] bf16 view of a planes buffer at raw address ptr"""
-    raw = pm.view(ptr, 1, npanels * nkb * 3072, npanels * nkb * 3072, dtype=torch.uint8)[0]
-    return raw.view(torch.bfloat16).view(npanels, nkb, 3, 64, 8)
+def planes_view(pm: PtrMap, ptr, npanels, nkb, fmt=0):
+    """[npanels, nkb, NPL, 64 lines, 8] view of a planes buffer at raw address ptr (bf16 x 3 or fp16 x 2)"""
+    npl, dt = (2, torch.float16) if fmt == 1 else (3, torch.bfloat16)
+    raw = pm.view(ptr, 1, npanels * nkb * npl * 1024, npanels * nkb * npl * 1024, dtype=torch.uint8)[0]
+    return raw.view(dt).view(npanels, nkb, npl, 64, 8)
 
 
 def planes_decode(v, M):
-    """logical fp32 matrix [M, 32 nkb] of a planes view (p1 + p2 + p3 in fp32, exactly as the kernel reads it back)"""
+    """logical fp32 matrix [M, 32 nkb] of a planes view (sum of the planes in fp32, exactly as the kernel reads it back)"""
     npan, nkb = v.shape[0], v.shape[1]
-    x = (v[:, :, 0].float() + v[:, :, 1].float()) + v[:, :, 2].float()          # [npan, nkb, 64, 8]
+    x = v[:, :, 0].float() + v[:, :, 1].float()                                   # [npan, nkb, 64, 8]
+    if v.shape[2] == 3:
+        x = x + v[:, :, 2].float()
     x = x.view(npan, nkb, 4, 16, 8)                                               # line = 16 g + j -> [g, j, u]
     out = torch.zeros(npan, 16, nkb, 32)
     for g in range(4):
@@ -113,11 +116,12 @@ def planes_encode(v, X, kb0):
     Xp = torch.zeros(npan * 16, nb * 32)
     Xp[:M] = X
     Xp = Xp.view(npan, 16, nb, 32)
-    p1 = Xp.to(torch.bfloat16)
+    dt = v.dtype
+    p1 = Xp.to(dt)
     r = Xp - p1.float()
-    p2 = r.to(torch.bfloat16)
-    p3 = (r - p2.float()).to(torch.bfloat16)
-    for pl, P in enumerate((p1, p2, p3)):
+    p2 = r.to(dt)
+    planes = (p1, p2, (r - p2.float()).to(dt)) if v.shape[2] == 3 else (p1, p2)
+    for pl, P in enumerate(planes):
         for g in range(4):
             for u in range(8):
                 v[:, kb0: kb0 + nb, pl, 16 * g: 16 * g + 16, u] = P[:, :, :, _slot_feature(8 * g + u)].permute(0, 2, 1)
@@ -135,15 +139,22 @@ def emulate_pack_planes(d, pm: PtrMap, dtype=torch.float32):
         X[:, ok] = X[:, ok] / pm.vec(d.pre_div, 32 * nkb)[ok]
     if d.pre_sub:
         X[:, ok] = X[:, ok] - pm.vec(d.pre_sub, 32 * nkb)[ok]
-    planes_encode(planes_view(pm, d.planes, npan, nkb), X, 0)
+    if d.format == 1 and d.range_flag and not bool((X.abs() < 65000.0).all()):
+        pm.view(d.range_flag, 1, 1, 1, dtype=torch.int32)[0, 0] = 1
+    planes_encode(planes_view(pm, d.planes, npan, nkb, d.format), X, 0)
 
 
 def emulate_gemm_planes(d, pm: PtrMap, dtype=torch.float32):
     M = d.M
     npan = -(-M // 16)
-    A = planes_decode(planes_view(pm, d.A, npan, d.a_nkb), M)[:, 32 * d.a_kb0: 32 * (d.a_kb0 + d.nk)]
-    Wp = pm.view(d.W_planes, 3, d.w_rows * d.ldw, d.w_plane_stride, dtype=torch.bfloat16).view(3, d.w_rows, d.ldw)
-    W = ((Wp[0].float() + Wp[1].float()) + Wp[2].float())[:, : 32 * d.nk]             # K axis in physical slot order
+    fmt = d.format
+    npl = 2 if fmt == 1 else 3
+    A = planes_decode(planes_view(pm, d.A, npan, d.a_nkb, fmt), M)[:, 32 * d.a_kb0: 32 * (d.a_kb0 + d.nk)]
+    Wp = pm.view(d.W_planes, npl, d.w_rows * d.ldw, d.w_plane_stride).view(npl, d.w_rows, d.ldw)
+    W = Wp[0].float() + Wp[1].float()
+    if npl == 3:
+        W = W + Wp[2].float()
+    W = W[:, : 32 * d.nk]                                                             # K axis in physical slot order
     slot = torch.tensor([32 * (c // 32) + _SLOT_OF_FEATURE[c % 32] for c in range(32 * d.nk)])
     W = W[:, slot]                                                                    # -> logical order
     v = A.to(dtype) @ W.to(dtype).t()
@@ -154,13 +165,17 @@ def emulate_gemm_planes(d, pm: PtrMap, dtype=torch.float32):
     if d.C_f32:
         if d.post_mul:
             v = v * pm.vec(d.post_mul, d.w_rows).to(dtype)
+        if fmt == 1 and d.range_flag and not bool(torch.isfinite(v[:, : d.N]).all()):
+            pm.view(d.range_flag, 1, 1, 1, dtype=torch.int32)[0, 0] = 1
         pm.view(d.C_f32, M, d.N, d.ldc).copy_(v[:, : d.N].to(torch.float32))
         return
     v = v[:, : 32 * d.c_kbn]
-    Cv = planes_view(pm, d.C_planes, npan, d.c_nkb)
+    Cv = planes_view(pm, d.C_planes, npan, d.c_nkb, fmt)
     if d.residual:
-        R = planes_decode(planes_view(pm, d.residual, npan, d.c_nkb), M)[:, 32 * d.c_kb0: 32 * (d.c_kb0 + d.c_kbn)]
+        R = planes_decode(planes_view(pm, d.residual, npan, d.c_nkb, fmt), M)[:, 32 * d.c_kb0: 32 * (d.c_kb0 + d.c_kbn)]
         v = R.to(dtype) + d.res_sign * v
+    if fmt == 1 and d.range_flag and not bool((v.abs() < 65000.0).all()):
+        pm.view(d.range_flag, 1, 1, 1, dtype=torch.int32)[0, 0] = 1
     planes_encode(Cv, v.to(torch.float32), d.c_kb0)
 
 
@@ -293,7 +308,12 @@ def _emu_pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes
     v[ro[:, None], ci[None, :]] = S[oi[ro][:, None], ii[ci][None, :]].float()
     if W is not None:
         torch.as_strided(W.reshape(-1), (n_out, n_in), (ldw, 1)).copy_(v)
-    if planes is not None:
+    if planes is not None and planes.dtype == torch.float16:           # fp16x2 planes (transpose bit 1 of the C entry)
+        planes.zero_()
+        hi = v.to(torch.float16)
+        planes[0, :n_out, :n_in] = hi
+        planes[1, :n_out, :n_in] = (v - hi.float()).to(torch.float16)
+    elif planes is not None:
         planes.zero_()
         for q, pl in enumerate(_bf16_planes(v)):
             planes[q, :n_out, :n_in] = pl
@@ -427,7 +447,9 @@ def install_prep_emulation(monkeypatch):
 def engine_transform(eng, x, direction, context=None, fused=False, planes=False):
     eng.use_fused_coupling = fused
     eng.fused_min_rows = 0
-    eng.use_planes, eng.planes_min_rows = planes, 0
+    eng.use_planes, eng.planes_min_rows = bool(planes), 0
+    if planes:
+        eng.gemm_mode = planes if isinstance(planes, str) else "bf16x3"
     if fused:
         eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     B = x.shape[0]
@@ -440,7 +462,9 @@ def engine_transform(eng, x, direction, context=None, fused=False, planes=False)
 def engine_latent(eng, x, context=None, fused=False, planes=False):
     eng.use_fused_coupling = fused
     eng.fused_min_rows = 0
-    eng.use_planes, eng.planes_min_rows = planes, 0
+    eng.use_planes, eng.planes_min_rows = bool(planes), 0
+    if planes:
+        eng.gemm_mode = planes if isinstance(planes, str) else "bf16x3"
     if fused:
         eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
     plan = eng._plan("backward", x.shape[0], x.device, context is not None, "nat")

@@ -20,27 +20,36 @@ def _ext():
     return _ext
 
 
-def _view(buf, M, nkb):
-    return buf.cpu().view(torch.bfloat16).view(-(-M // 16), nkb, 3, 64, 8)
+FMT = {"bf16x3": 0, "f16x2": 1}
 
 
-def _weight_planes(W, n_rows_pad):
-    """[3, rows, K] bf16 planes of logical W [n, K] with the slot permutation on K (K a multiple of 32)"""
+def _view(buf, M, nkb, fmt=0):
+    npl, dt = (2, torch.float16) if fmt == 1 else (3, torch.bfloat16)
+    return buf.cpu().view(dt).view(-(-M // 16), nkb, npl, 64, 8)
+
+
+def _weight_planes(W, n_rows_pad, fmt=0):
+    """[3, rows, K] bf16 / [2, rows, K] fp16 planes of logical W [n, K] with the slot permutation on K (K % 32 == 0)"""
     n, K = W.shape
     Wp = torch.zeros(n_rows_pad, K)
     Wp[:n] = W
     phys = torch.tensor([32 * (c // 32) + emulator._slot_feature(c % 32) for c in range(K)])
     Wp = Wp[:, phys]
-    p1 = Wp.to(torch.bfloat16)
+    dt = torch.float16 if fmt == 1 else torch.bfloat16
+    p1 = Wp.to(dt)
     r = Wp - p1.float()
-    p2 = r.to(torch.bfloat16)
-    p3 = (r - p2.float()).to(torch.bfloat16)
+    p2 = r.to(dt)
+    if fmt == 1:
+        return torch.stack([p1, p2]).contiguous()
+    p3 = (r - p2.float()).to(dt)
     return torch.stack([p1, p2, p3]).contiguous()
 
 
+@pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("M,D,nkb", [(1, 5, 1), (37, 50, 2), (1000, 784, 25), (4099, 96, 3)])
-def test_pack_planes_is_the_exact_three_way_split(M, D, nkb):
+def test_pack_planes_is_the_exact_three_way_split(M, D, nkb, fmt):
     ext = _ext()
+    fmt = FMT[fmt]
     g = torch.Generator().manual_seed(M + D)
     x = torch.randn(M, D + 3, generator=g) * 5
     perm = torch.randperm(D, generator=g)
@@ -49,15 +58,24 @@ def test_pack_planes_is_the_exact_three_way_split(M, D, nkb):
     idx[pos] = perm.to(torch.int32)
     pdiv = torch.rand(32 * nkb, generator=g) + 0.5
     psub = torch.randn(32 * nkb, generator=g)
-    buf = torch.zeros(ext.planes_bytes(M, nkb), dtype=torch.uint8, device=DEV)
-    ext.pack_planes(x.to(DEV), buf, M=M, nkb=nkb, idx=idx.to(DEV), pre_div=pdiv.to(DEV), pre_sub=psub.to(DEV))
+    buf = torch.zeros(ext.planes_bytes(M, nkb, fmt), dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ext.pack_planes(x.to(DEV), buf, M=M, nkb=nkb, idx=idx.to(DEV), pre_div=pdiv.to(DEV), pre_sub=psub.to(DEV), fmt=fmt,
+                    range_flag=flag)
     torch.cuda.synchronize()
     Mp = -(-M // 16) * 16
-    got = emulator.planes_decode(_view(buf, M, nkb), Mp)
+    got = emulator.planes_decode(_view(buf, M, nkb, fmt), Mp)
     ref = torch.zeros(M, 32 * nkb)
     ok = idx >= 0
     ref[:, ok] = x[:, idx[ok].long()] / pdiv[ok] - psub[ok]
-    assert torch.equal(got[:M], ref)        # p1 + p2 + p3 == x exactly (24 significant bits in three bf16)
+    if fmt == 0:
+        assert torch.equal(got[:M], ref)    # p1 + p2 + p3 == x exactly (24 significant bits in three bf16)
+    else:                                   # two fp16 planes: 22 significant bits (11 + 11), absolute floor 2^-25
+        assert ((got[:M] - ref).abs() <= ref.abs() * 2.0 ** -22 + 2.0 ** -25).all()
+        # bitwise what the documented split gives
+        hi = ref.to(torch.float16)
+        assert torch.equal(got[:M], hi.float() + (ref - hi.float()).to(torch.float16).float())
+        assert int(flag.item()) == 0
     assert (got[M:] == 0).all()             # padding rows of the last panel: zeros
 
 
@@ -75,9 +93,37 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("M,a_nkb,a_kb0,nk,out,flags", CASES)
-def test_gemm_planes_parity(M, a_nkb, a_kb0, nk, out, flags):
+def test_fp16_range_guard_flags_values_fp16_cannot_carry():
     ext = _ext()
+    x = torch.ones(40, 32)
+    idx = torch.arange(32, dtype=torch.int32).to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    buf = torch.zeros(ext.planes_bytes(40, 1, 1), dtype=torch.uint8, device=DEV)
+    for bad, expect in ((None, 0), (64999.0, 0), (65000.0, 1), (-1e9, 1), (float("nan"), 1), (float("inf"), 1)):
+        xx = x.clone()
+        if bad is not None:
+            xx[37, 5] = bad
+        flag.zero_()
+        ext.pack_planes(xx.to(DEV), buf, M=40, nkb=1, idx=idx, fmt=1, range_flag=flag)
+        assert int(flag.item()) == expect, bad
+    # GEMM output that leaves fp16's range: flagged by the planes epilogue; fp32 output: only non-finite values are
+    W = _weight_planes(torch.full((32, 32), 100.0), 32, 1).to(DEV)
+    A = torch.zeros(ext.planes_bytes(40, 1, 1), dtype=torch.uint8)
+    emulator.planes_encode(_view(A, 40, 1, 1), torch.full((40, 32), 30.0), 0)        # 32 * 30 * 100 = 96000 > 65000
+    flag.zero_()
+    ext.gemm_planes(A.to(DEV), W, M=40, a_nkb=1, nk=1, C_planes=buf, c_nkb=1, c_kbn=1, fmt=1, range_flag=flag)
+    assert int(flag.item()) == 1
+    flag.zero_()
+    C = torch.empty(40, 32, device=DEV)
+    ext.gemm_planes(A.to(DEV), W, M=40, a_nkb=1, nk=1, C_f32=C, ldc=32, N=32, fmt=1, range_flag=flag)
+    assert int(flag.item()) == 0 and torch.allclose(C.cpu(), torch.full((40, 32), 96000.0))
+
+
+@pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("M,a_nkb,a_kb0,nk,out,flags", CASES)
+def test_gemm_planes_parity(M, a_nkb, a_kb0, nk, out, flags, fmt):
+    ext = _ext()
+    fmt = FMT[fmt]
     g = torch.Generator().manual_seed(M + 31 * nk)
     K = 32 * nk
     f32out = isinstance(out, int)
@@ -88,14 +134,16 @@ def test_gemm_planes_parity(M, a_nkb, a_kb0, nk, out, flags):
     bias = torch.randn(w_rows, generator=g) if flags.get("bias") else None
     if bias is not None:
         bias[n_out:] = 0
-    Abuf = torch.zeros(ext.planes_bytes(M, a_nkb), dtype=torch.uint8)
-    emulator.planes_encode(Abuf.view(torch.bfloat16).view(-(-M // 16), a_nkb, 3, 64, 8), X, 0)
-    Wp = _weight_planes(W, w_rows).to(DEV)
+    Abuf = torch.zeros(ext.planes_bytes(M, a_nkb, fmt), dtype=torch.uint8)
+    emulator.planes_encode(_view(Abuf, M, a_nkb, fmt), X, 0)
+    Wp = _weight_planes(W, w_rows, fmt).to(DEV)
     d = lambda t: None if t is None else t.to(DEV)
     # reference on sampled rows (head / middle / tail) in fp64 and fp32
     idx = torch.unique(torch.cat([torch.arange(0, min(M, 40)), torch.arange(max(M // 2 - 20, 0), min(M // 2 + 20, M)),
                                   torch.arange(max(M - 40, 0), M)]))
     Xk = X[idx][:, 32 * a_kb0: 32 * (a_kb0 + nk)]
+    # (the reference multiplies the fp32 values; the kernel's operands are those values as planes: exact in bf16x3, rounded
+    # to 22 significant bits in fp16x2 -- the error that format is allowed, inside the same gate)
 
     def ref(dt):
         v = Xk.to(dt) @ W.to(dt).t()
@@ -109,7 +157,7 @@ def test_gemm_planes_parity(M, a_nkb, a_kb0, nk, out, flags):
         pm = torch.randn(w_rows, generator=g) if flags.get("post_mul") else None
         C = torch.full((M, n_out + 3), float("nan"), device=DEV)
         ext.gemm_planes(Abuf.to(DEV), Wp, M=M, a_nkb=a_nkb, a_kb0=a_kb0, nk=nk, bias=d(bias), post_mul=d(pm), C_f32=C,
-                        ldc=n_out + 3, N=n_out)
+                        ldc=n_out + 3, N=n_out, fmt=fmt)
         torch.cuda.synchronize()
         assert torch.isnan(C[:, n_out:]).all() and not torch.isnan(C[:, :n_out]).any()
         got = C[:, :n_out].cpu()[idx].double()
@@ -119,14 +167,15 @@ def test_gemm_planes_parity(M, a_nkb, a_kb0, nk, out, flags):
     else:
         c_nkb, c_kb0, c_kbn = out
         R = torch.randn(M, 32 * c_nkb, generator=g) * 2
-        Cbuf = torch.zeros(ext.planes_bytes(M, c_nkb), dtype=torch.uint8)
-        emulator.planes_encode(Cbuf.view(torch.bfloat16).view(-(-M // 16), c_nkb, 3, 64, 8), R, 0)
+        Cbuf = torch.zeros(ext.planes_bytes(M, c_nkb, fmt), dtype=torch.uint8)
+        emulator.planes_encode(_view(Cbuf, M, c_nkb, fmt), R, 0)
+        R = emulator.planes_decode(_view(Cbuf, M, c_nkb, fmt), M)          # what the buffer holds (fp16x2: R rounded to 22 bits)
         Cd = Cbuf.to(DEV)
         ext.gemm_planes(Abuf.to(DEV), Wp, M=M, a_nkb=a_nkb, a_kb0=a_kb0, nk=nk, bias=d(bias), C_planes=Cd, c_nkb=c_nkb,
                         c_kb0=c_kb0, c_kbn=c_kbn, residual=Cd if flags.get("residual") else None,
-                        res_sign=flags.get("sign", 1.0), act=1 if flags.get("act") else 0, slope=0.01)
+                        res_sign=flags.get("sign", 1.0), act=1 if flags.get("act") else 0, slope=0.01, fmt=fmt)
         torch.cuda.synchronize()
-        full = emulator.planes_decode(_view(Cd, M, c_nkb), M)
+        full = emulator.planes_decode(_view(Cd, M, c_nkb, fmt), M)
         lo, hi = 32 * c_kb0, 32 * (c_kb0 + c_kbn)
         # blocks outside the output range are untouched
         assert torch.equal(full[:, :lo], R[:, :lo]) and torch.equal(full[:, hi:], R[:, hi:])
@@ -152,20 +201,23 @@ def test_gemm_planes_rejects_bad_args():
         ext.gemm_planes(A, W, M=64, a_nkb=2, nk=2)                                             # no output
 
 
+@pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", case_names())
-def test_golden_parity_through_the_planes_plan(name):
-    """every golden case of the reference through the planes launch plan (forced: planes_min_rows = 0)"""
+def test_golden_parity_through_the_planes_plan(name, fmt):
+    """every golden case of the reference through the planes launch plan (forced: planes_min_rows = 0), activations as
+    bf16x3 or as fp16x2 planes"""
     spec, sd, a = load_case(name)
     if a.get("context") is not None or spec.soft_training:
         pytest.skip("context: served by the fp32-activation path")
     flow = build_flow(spec, sd, device=DEV)
     eng = flow.engine()
-    eng.use_planes, eng.planes_min_rows = True, 0
+    eng.use_planes, eng.planes_min_rows, eng.gemm_mode = True, 0, fmt
     with torch.no_grad():
         lp = flow.log_prob(a["x"].to(DEV))
         z = flow.backward(a["x"].to(DEV))
         xf = flow._forward(a["zin"].to(DEV))
-    assert any(p.get("planes") for p in eng._plans.values()), "planes plan was not built"
+    assert any(p.get("planes") and p["planes_fmt"] == FMT[fmt] for p in eng._plans.values()), "planes plan was not built"
+    assert eng.f16_fallbacks == 0
     rel = lambda u, v: ((u.double().cpu() - v.double()).abs() / v.double().abs().clamp_min(1e-30)).max().item()
     assert rel(lp, a["log_prob64"]) < 1e-5 and rel(lp, a["log_prob32"]) < 1e-5, name
     s = max(1.0, a["backward64"].abs().max().item())
@@ -192,3 +244,26 @@ def test_planes_plan_ragged_rows_vs_fp32_plan(B):
     assert (z1 - z2).abs().max().item() < 1e-4 * max(1.0, z2.abs().max().item())
     ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x[:64].cpu().double())
     assert ((lp1[:64].cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5
+
+
+def test_fp16_overflow_falls_back_to_bf16x3_planes():
+    """a flow whose activations leave fp16's range (inputs ~1e6): the fp16x2 pass raises its range flag, the engine
+    redoes it with bf16x3 planes -- same result as the bf16x3 mode, never an inf / NaN from the plane format"""
+    from oracle import usflows_oracle as orc
+    spec = orc.FlowSpec(64, 3, [48, 48], householder=0)
+    sd = orc.synth_state_dict(spec, seed=77)
+    flow = build_flow(spec, sd, device=DEV)
+    eng = flow.engine()
+    eng.use_planes, eng.planes_min_rows = True, 0
+    x = (torch.rand(300, 64, generator=torch.Generator().manual_seed(1)) * 2e6).to(DEV)
+    with torch.no_grad():
+        eng.gemm_mode = "f16x2"
+        lp1 = flow.log_prob(x)
+        assert eng.f16_fallbacks == 1
+        small = flow.log_prob(x * 1e-6)          # in range again: fp16x2 planes, no fallback
+        assert eng.f16_fallbacks == 1
+        eng.gemm_mode = "bf16x3"
+        lp2 = flow.log_prob(x)
+    assert torch.isfinite(lp1).all() and torch.equal(lp1, lp2) and torch.isfinite(small).all()
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x.cpu().double())
+    assert ((lp1.cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5

@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 8
+USF_ABI_VERSION = 9
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -65,7 +65,7 @@ class CouplingDesc(C.Structure):
 
 class PackPlanesDesc(C.Structure):
     _fields_ = [("src", _fp), ("ld", C.c_int64), ("M", C.c_int64), ("nkb", C.c_int64), ("idx", _fp),
-                ("pre_div", _fp), ("pre_sub", _fp), ("planes", _fp)]
+                ("pre_div", _fp), ("pre_sub", _fp), ("planes", _fp), ("format", C.c_int32), ("reserved", C.c_int32), ("range_flag", _fp)]
 
 
 class GemmPlanesDesc(C.Structure):
@@ -74,7 +74,7 @@ class GemmPlanesDesc(C.Structure):
                 ("bias", _fp), ("post_mul", _fp), ("residual", _fp),
                 ("C_planes", _fp), ("c_nkb", C.c_int64), ("c_kb0", C.c_int64), ("c_kbn", C.c_int64),
                 ("C_f32", _fp), ("ldc", C.c_int64), ("N", C.c_int64), ("M", C.c_int64),
-                ("res_sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("reserved", C.c_int32)]
+                ("res_sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("format", C.c_int32), ("range_flag", _fp)]
 
 
 class _OpUnion(C.Union):
@@ -293,22 +293,28 @@ def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_
     _launch("usf_linear_f32", (C.byref(d), current_stream(A.device)), d)
 
 
-def planes_bytes(M: int, nkb: int) -> int:
+def planes_bytes(M: int, nkb: int, fmt: int = 0) -> int:
     """size of a planes buffer of M rows and nkb 32-feature blocks (include/usflows_hip.h)"""
-    return (-(-M // 16)) * nkb * 3072
+    return (-(-M // 16)) * nkb * (2048 if fmt == 1 else 3072)
 
 
-def pack_planes(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None):
+PLANES_BF16X3, PLANES_F16X2 = 0, 1
+
+
+def pack_planes(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None, fmt=PLANES_BF16X3, range_flag=None):
     d = PackPlanesDesc()
+    d.format, d.range_flag = fmt, ptr(range_flag)
     d.src, d.ld, d.M, d.nkb = src.data_ptr(), (src.stride(0) if ld is None else ld), M, nkb
     d.idx, d.pre_div, d.pre_sub, d.planes = idx.data_ptr(), ptr(pre_div), ptr(pre_sub), planes.data_ptr()
     _launch("usf_pack_planes_f32", (C.byref(d), current_stream(src.device)), (d, src, planes, idx, pre_div, pre_sub))
 
 
 def gemm_planes(A, W_planes, *, M, a_nkb, nk, a_kb0=0, bias=None, post_mul=None, residual=None, C_planes=None, c_nkb=0,
-                c_kb0=0, c_kbn=0, C_f32=None, ldc=0, N=0, res_sign=1.0, act=ACT_NONE, slope=0.0):
-    """usf_gemm_planes_bf16x3; W_planes: [3, w_rows, ldw] bf16 (K axis in slot order)"""
+                c_kb0=0, c_kbn=0, C_f32=None, ldc=0, N=0, res_sign=1.0, act=ACT_NONE, slope=0.0, fmt=PLANES_BF16X3,
+                range_flag=None):
+    """usf_gemm_planes_bf16x3; W_planes: [3, w_rows, ldw] bf16 or [2, w_rows, ldw] fp16 (K axis in slot order)"""
     d = GemmPlanesDesc()
+    d.format, d.range_flag = fmt, ptr(range_flag)
     d.A, d.a_nkb, d.a_kb0, d.nk = A.data_ptr(), a_nkb, a_kb0, nk
     d.W_planes, d.ldw, d.w_plane_stride, d.w_rows = (W_planes.data_ptr(), W_planes.shape[2],
                                                       W_planes.shape[1] * W_planes.shape[2], W_planes.shape[1])
@@ -453,6 +459,7 @@ def flush_jobs() -> None:
 
 
 def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
+    transpose = int(transpose) | (2 if (planes is not None and planes.dtype == torch.float16) else 0)   # bit 1: fp16x2 planes
     """usf_pack_weight_f32: src fp64/fp32 2-D (or 1-D = one row) device tensor; W [n_out, ldw] fp32 and/or planes
     [3, n_out, ldp] bf16 (preallocated).  Inside a ``batch_jobs`` block the call is queued, not launched."""
     if src.dtype not in (torch.float32, torch.float64):

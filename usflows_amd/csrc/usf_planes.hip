@@ -28,29 +28,54 @@
 namespace usf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define USF_F16_GUARD 65000.0f      // |x| at or above this (or NaN) cannot travel as fp16 planes (fp16 max = 65504)
+
+// NPL = 3: bf16 planes, six products per fp32 product (24 significant bits per operand, fp32's exponent range);
+// NPL = 2: fp16 planes, three products a1 w1 + (a1 w2 + a2 w1) (22 significant bits per operand; half the matrix
+//          instructions -- the chip is power-bound on this instruction mix, tools/exp_mfma_peak.hip)
+template <int NPL> struct Planes;
+template <> struct Planes<3> {
+  typedef bf16x8 vec;
+  static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(const float (&x)[8], vec (&o)[3]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 h = (__bf16)x[j];
+      const float r = x[j] - (float)h;           // exact
+      const __bf16 m = (__bf16)r;
+      const float r2 = r - (float)m;             // exact
+      o[0][j] = h; o[1][j] = m; o[2][j] = (__bf16)r2;
+    }
+  }
+};
+template <> struct Planes<2> {
+  typedef f16x8 vec;
+  static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(const float (&x)[8], vec (&o)[2]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 h = (_Float16)x[j];
+      const float r = x[j] - (float)h;           // exact while h is finite
+      o[0][j] = h; o[1][j] = (_Float16)r;
+    }
+  }
+};
 
 // feature offset (0..31) held by slot s of a 32-feature block
 __host__ __device__ __forceinline__ int plane_feature_of_slot(int s) { return 16 * ((s & 7) >> 2) + 4 * (s >> 3) + (s & 3); }
-
-__device__ __forceinline__ void split3_8(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)x[j];
-    const float r = x[j] - (float)h;           // exact
-    const __bf16 m = (__bf16)r;
-    const float r2 = r - (float)m;             // exact
-    p1[j] = h; p2[j] = m; p3[j] = (__bf16)r2;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // pack: fp32 row-major [M, ld] -> planes (optionally x / pre_div - pre_sub first, columns gathered through idx)
 // ------------------------------------------------------------------------------------------------------------
 // one wave per (panel, k-block): lane (j, g) produces its 8 slots of row 16 p + j
+template <int NPL>
 __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ src, int64_t ld, int M, int npanels,
                                                           int nkb, const int32_t* __restrict__ idx,
                                                           const float* __restrict__ pre_div,
-                                                          const float* __restrict__ pre_sub, char* __restrict__ dst) {
+                                                          const float* __restrict__ pre_sub, char* __restrict__ dst,
+                                                          int32_t* __restrict__ range_flag) {
+  typedef Planes<NPL> PT;
   const int lane = threadIdx.x & 63;
   const int lj = lane & 15, lg = lane >> 4;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -70,12 +95,17 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
     }
     x[u] = v;
   }
-  bf16x8 p1, p2, p3;
-  split3_8(x, p1, p2, p3);
-  char* o = dst + (chunk * 3) * 1024 + lane * 16;
-  *reinterpret_cast<bf16x8*>(o) = p1;
-  *reinterpret_cast<bf16x8*>(o + 1024) = p2;
-  *reinterpret_cast<bf16x8*>(o + 2048) = p3;
+  if (NPL == 2 && range_flag) {                 // fp16 planes: a value outside fp16's range (or a NaN) voids the run
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bad = bad || !(fabsf(x[u]) < USF_F16_GUARD);
+    if (bad) atomicOr(range_flag, 1);
+  }
+  typename PT::vec o[NPL];
+  PT::split(x, o);
+  char* out = dst + (chunk * NPL) * 1024 + lane * 16;
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) *reinterpret_cast<typename PT::vec*>(out + q * 1024) = o[q];
 }
 
 int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
@@ -84,12 +114,17 @@ int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
   if (d->M == 0) return 0;
   if (!d->src || !d->idx || !d->planes) { set_error("usf_pack_planes_f32: null pointer"); return -1; }
   if (!aligned16(d->planes)) { set_error("usf_pack_planes_f32: planes must be 16-byte aligned"); return -2; }
+  if (d->format != USF_PLANES_BF16X3 && d->format != USF_PLANES_F16X2) { set_error("usf_pack_planes_f32: unknown format %d", d->format); return -2; }
   const int64_t npanels = (d->M + 15) / 16;
   const int64_t chunks = npanels * d->nkb;
   const int64_t blocks = (chunks + 3) / 4;
   if (blocks > 0x7fffffffLL) { set_error("usf_pack_planes_f32: grid too large"); return -3; }
-  hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d->src, d->ld, (int)d->M, (int)npanels,
-                     (int)d->nkb, d->idx, d->pre_div, d->pre_sub, reinterpret_cast<char*>(d->planes));
+  if (d->format == USF_PLANES_F16X2)
+    hipLaunchKernelGGL(pack_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, d->src, d->ld, (int)d->M, (int)npanels,
+                       (int)d->nkb, d->idx, d->pre_div, d->pre_sub, reinterpret_cast<char*>(d->planes), d->range_flag);
+  else
+    hipLaunchKernelGGL(pack_planes_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, d->src, d->ld, (int)d->M, (int)npanels,
+                       (int)d->nkb, d->idx, d->pre_div, d->pre_sub, reinterpret_cast<char*>(d->planes), d->range_flag);
   return check_launch("usf_pack_planes_f32");
 }
 
@@ -97,30 +132,35 @@ int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
 // GEMM on planes
 // ------------------------------------------------------------------------------------------------------------
 struct PlArgs {
-  const char* A; const __bf16* Wp; const float* bias; const float* post_mul;
+  const char* A; const char* Wp; const float* bias; const float* post_mul;
   const char* R; char* Cp; float* Cf;
   int64_t ldc, plane_stride;
   int ldwp, wrows;
   int M, npanels;
   int a_nkb, a_kb0, nk;
   int c_nkb, c_kb0, c_kbn;
-  int N, nbm, nbn;
+  int N, nbm, nbn, nvb;
   float res_sign, slope; int act;
+  int32_t* range_flag;
   unsigned long long* dbg;
+  unsigned long long* span;             // tuning builds only: [first wave start, last wave end] in s_memrealtime ticks
 };
 
-template <int TN, bool F32OUT>
+template <int NPL, int TN, bool F32OUT>
 __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
+  typedef Planes<NPL> PT;
+  typedef typename PT::vec vec8;
   constexpr int NT = 512;
   constexpr int BN = TN * 32;
   constexpr int FT = 2 * TN;                    // 16-feature tiles per wave, each against 2 batch tiles of 16 rows
-  // weight stage: 3 planes x 4 k-chunks x BN rows of 16-byte slots, image slot(plane, chunk c, row r) =
+  constexpr unsigned CHB = NPL * 1024u;         // bytes of one (panel, k-block) chunk group
+  // weight stage: NPL planes x 4 k-chunks x BN rows of 16-byte slots, image slot(plane, chunk c, row r) =
   // (plane * 4 + c) * BN + (r ^ 2c)  (conflict-free for the fragment reads and for the row-major deal; see
   // usf_linear_bf16x3.hip); ring of four buffers, the block meets at a barrier every second slab
   constexpr int CS = BN;
-  constexpr int NSLOT = 3 * 4 * BN;
+  constexpr int NSLOT = NPL * 4 * BN;
   constexpr int NWV = (NSLOT + NT - 1) / NT;
-  constexpr int STG = 12 * CS * 4;              // floats per staging buffer
+  constexpr int STG = NPL * 4 * CS * 4;         // floats per staging buffer
   constexpr int NB = 4, D = 2;
   static_assert(NWV * NT - NSLOT <= NSLOT, "surplus threads wrap once");
   __shared__ __attribute__((aligned(16))) float wring[NB * STG];
@@ -129,14 +169,20 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int lj = lane & 15, lg = lane >> 4;
+#ifdef USF_STAMP
+  if (p.span && tid == 0) atomicMin(p.span, __builtin_amdgcn_s_memrealtime());
+#endif
 
-  // XCD-aware block map: the column blocks of one 256-row panel group run back to back on one XCD
-  const int bid = blockIdx.x;
+  // Persistent blocks: the grid is one block per CU (a multiple of 8); block b works through the virtual blocks
+  // b, b + grid, b + 2 grid, ... -- the order in which the hardware would have dispatched a grid of that size.
+  // XCD-aware map of a virtual block: the column blocks of one 256-row panel group run back to back on one XCD.
+  for (int bid = blockIdx.x; bid < p.nvb; bid += gridDim.x) {
   const int xcd = bid & 7;
   const int seq = bid >> 3;
   const int pg = (seq / p.nbn) * 8 + xcd;       // group of 16 panels (256 rows)
   const int bn = seq % p.nbn;
-  if (pg >= p.nbm) return;
+  if (pg >= p.nbm) continue;
+  if (bid != (int)blockIdx.x) __syncthreads();  // the previous tile's last reads of the weight ring are done
   const int n0 = bn * BN;
   int pw[2];                                    // this wave's two panels (unclamped: >= npanels means "no rows")
   pw[0] = pg * 16 + wave * 2;
@@ -146,16 +192,16 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   unsigned aoff[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
-    aoff[b] = ((unsigned)min(pw[b], p.npanels - 1) * (unsigned)p.a_nkb + (unsigned)p.a_kb0) * 3072u + (unsigned)lane * 16u;
-  auto issue_a = [&](int kb, bf16x8 (&dst)[2][3]) {
+    aoff[b] = ((unsigned)min(pw[b], p.npanels - 1) * (unsigned)p.a_nkb + (unsigned)p.a_kb0) * CHB + (unsigned)lane * 16u;
+  auto issue_a = [&](int kb, vec8 (&dst)[2][NPL]) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-        dst[b][q] = *reinterpret_cast<const bf16x8*>(p.A + (aoff[b] + (unsigned)kb * 3072u + (unsigned)q * 1024u));
+      for (int q = 0; q < NPL; ++q)
+        dst[b][q] = *reinterpret_cast<const vec8*>(p.A + (aoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u));
   };
 
-  // ---- weights: register-staged into the LDS ring ----
+  // ---- weights: register-staged into the LDS ring (2-byte elements; offsets in bytes) ----
   unsigned wsrc[NWV];
   int wdst[NWV];
 #pragma unroll
@@ -164,12 +210,12 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     const int idc = (idx < NSLOT) ? idx : idx - NSLOT;
     const int pl = idc / (4 * BN), rem = idc % (4 * BN);
     const int r = rem >> 2, ch = rem & 3;
-    wsrc[i] = (unsigned)(pl * p.plane_stride + (int64_t)min(n0 + r, p.wrows - 1) * p.ldwp + 8 * ch);
+    wsrc[i] = (unsigned)(2 * (pl * p.plane_stride + (int64_t)min(n0 + r, p.wrows - 1) * p.ldwp + 8 * ch));
     wdst[i] = 4 * ((pl * 4 + ch) * CS + (r ^ (2 * ch)));
   }
   auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + (wsrc[i] + (unsigned)k0));
+    for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + (wsrc[i] + 2u * (unsigned)k0));
   };
   auto store_w = [&](float* wb, const f32x4 (&src)[NWV]) {
 #pragma unroll
@@ -193,7 +239,10 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #define PSTAMP(v)
 #endif
   PSTAMP(t0);
-  bf16x8 pa[2][3], pb[2][3];
+#ifdef USF_STAMP
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  vec8 pa[2][NPL], pb[2][NPL];
   f32x4 wst[NWV];
   const int nslab = p.nk;
 #pragma unroll
@@ -204,15 +253,16 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   issue_a(0, pa);
   __syncthreads();
 
-  // one slab: 12 MFMAs per feature tile (6 products x 2 batch tiles), weight fragments read from LDS two tiles ahead;
-  // the next slab's operands (global -> registers) and the weights of the slab after next (global -> staging
-  // registers) are issued under the first tiles' MFMAs
-#define USF_MM(FT_, W, P)                                                                                \
-  acc[FT_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, cur[0][P], acc[FT_][0], 0, 0, 0);             \
-  acc[FT_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, cur[1][P], acc[FT_][1], 0, 0, 0)
-  constexpr int NLD = NWV + 6;                  // vector-memory loads per slab and thread
+  // one slab: NPR products per feature tile and batch tile (NPL = 3: six, smallest terms first; NPL = 2: three),
+  // weight fragments read from LDS two tiles ahead; the next slab's operands (global -> registers) and the weights of
+  // the slab after next (global -> staging registers) are issued under the first tiles' MFMAs
+  constexpr int NPR = (NPL == 3) ? 6 : 3;
+  constexpr int NLD = NWV + 2 * NPL;            // vector-memory loads per slab and thread
   constexpr int LPT = (NLD + FT - 1) / FT;      // ... dealt over the feature tiles
-  auto slab = [&](int s, const bf16x8 (&cur)[2][3], bf16x8 (&nxt)[2][3], bool sync_after) {
+#define USF_MM(FT_, W, P)                                        \
+  acc[FT_][0] = PT::mfma(W, cur[0][P], acc[FT_][0]);             \
+  acc[FT_][1] = PT::mfma(W, cur[1][P], acc[FT_][1])
+  auto slab = [&](int s, const vec8 (&cur)[2][NPL], vec8 (&nxt)[2][NPL], bool sync_after) {
     const float* rb = wring + (s % NB) * STG;
     float* wb = wring + ((s + D) % NB) * STG;
     const float* wl = rb + 4 * (lg * CS + (lj ^ (2 * lg)));
@@ -220,22 +270,27 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     issue_a(min(s + 1, nslab - 1), nxt);
 #pragma unroll
     for (int ft = 0; ft < FT; ft += 2) {
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + ft * 16));
-      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + ft * 16));
-      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + ft * 16));
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + 4 * (0 * 4 * CS + (ft + 1) * 16));
-      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wl + 4 * (1 * 4 * CS + (ft + 1) * 16));
-      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wl + 4 * (2 * 4 * CS + (ft + 1) * 16));
-      USF_MM(ft, a3, 0); USF_MM(ft + 1, b3, 0); USF_MM(ft, a2, 1); USF_MM(ft + 1, b2, 1);
-      USF_MM(ft, a1, 2); USF_MM(ft + 1, b1, 2); USF_MM(ft, a2, 0); USF_MM(ft + 1, b2, 0);
-      USF_MM(ft, a1, 1); USF_MM(ft + 1, b1, 1); USF_MM(ft, a1, 0); USF_MM(ft + 1, b1, 0);
+      vec8 wa[NPL], wb2[NPL];
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        wa[q] = *reinterpret_cast<const vec8*>(wl + 4 * (q * 4 * CS + ft * 16));
+        wb2[q] = *reinterpret_cast<const vec8*>(wl + 4 * (q * 4 * CS + (ft + 1) * 16));
+      }
+      if (NPL == 3) {
+        USF_MM(ft, wa[2], 0); USF_MM(ft + 1, wb2[2], 0); USF_MM(ft, wa[1], 1); USF_MM(ft + 1, wb2[1], 1);
+        USF_MM(ft, wa[0], NPL - 1); USF_MM(ft + 1, wb2[0], NPL - 1); USF_MM(ft, wa[1], 0); USF_MM(ft + 1, wb2[1], 0);
+        USF_MM(ft, wa[0], 1); USF_MM(ft + 1, wb2[0], 1); USF_MM(ft, wa[0], 0); USF_MM(ft + 1, wb2[0], 0);
+      } else {
+        USF_MM(ft, wa[1], 0); USF_MM(ft + 1, wb2[1], 0); USF_MM(ft, wa[0], 1); USF_MM(ft + 1, wb2[0], 1);
+        USF_MM(ft, wa[0], 0); USF_MM(ft + 1, wb2[0], 0);
+      }
     }
     // issue order pins (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
-    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-      if (f + 2 < FT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0);
+      if (f + 2 < FT) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
       if (f * LPT < NLD) __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -254,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   PSTAMP(t2);
 
   // ---- epilogue ----
+  bool bad = false;                            // fp16 planes only: range guard (see usf_gemm_planes_desc.range_flag)
   if (F32OUT) {
     // fp32 row-major: lane (j, g) of tile (ft, b) holds features n0 + 16 ft + 4 g + (0..3) of row 16 pw[b] + j
     const bool vec_ok = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.Cf) & 15u) == 0);
@@ -267,6 +323,11 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act, p.slope);
         if (p.post_mul) v = v * *reinterpret_cast<const f32x4*>(p.post_mul + min(col, p.wrows - 4));
+        if (NPL == 2 && row < p.M && col < p.N) {
+          // (an overflowed weight or activation plane upstream shows up here as inf / NaN)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bad = bad || (col + j < p.N && !(fabsf(v[j]) < 3.0e38f));
+        }
         if (row < p.M && col < p.N) {
           float* dst = p.Cf + (int64_t)row * p.ldc + col;
           if (vec_ok && col + 3 < p.N) {
@@ -281,56 +342,84 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     }
   } else {
     // planes: two neighbouring tiles give a lane the 8 slots of its chunk line; activation, residual (read back
-    // from planes: p1 + p2 + p3 is the exact fp32 value), 3-way split, three 16-byte stores -- all lane-local
+    // from planes: the sum of the planes is the stored fp32 value), split, NPL 16-byte stores -- all lane-local
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
       const int kbo = bn * TN + t;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         if (kbo < p.c_kbn && pw[b] < p.npanels) {
-          const size_t off = (((size_t)pw[b] * p.c_nkb + (p.c_kb0 + kbo)) * 3) * 1024 + (size_t)lane * 16;
+          const size_t off = (((size_t)pw[b] * p.c_nkb + (p.c_kb0 + kbo)) * NPL) * 1024 + (size_t)lane * 16;
           float x[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) x[u] = act_apply(acc[2 * t + (u >> 2)][b][u & 3], p.act, p.slope);
           if (p.R) {
-            const bf16x8 r1 = *reinterpret_cast<const bf16x8*>(p.R + off);
-            const bf16x8 r2 = *reinterpret_cast<const bf16x8*>(p.R + off + 1024);
-            const bf16x8 r3 = *reinterpret_cast<const bf16x8*>(p.R + off + 2048);
+            vec8 r[NPL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = (((float)r1[u] + (float)r2[u]) + (float)r3[u]) + p.res_sign * x[u];
+            for (int q = 0; q < NPL; ++q) r[q] = *reinterpret_cast<const vec8*>(p.R + off + q * 1024);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              float rv = (float)r[0][u] + (float)r[1][u];
+              if (NPL == 3) rv = rv + (float)r[NPL - 1][u];
+              x[u] = rv + p.res_sign * x[u];
+            }
           }
-          bf16x8 o1, o2, o3;
-          split3_8(x, o1, o2, o3);
-          *reinterpret_cast<bf16x8*>(p.Cp + off) = o1;
-          *reinterpret_cast<bf16x8*>(p.Cp + off + 1024) = o2;
-          *reinterpret_cast<bf16x8*>(p.Cp + off + 2048) = o3;
+          if (NPL == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bad = bad || (16 * pw[b] + lj < p.M && !(fabsf(x[u]) < USF_F16_GUARD));
+          }
+          vec8 o[NPL];
+          PT::split(x, o);
+#ifdef USF_NOSTORE                          // tuning aid: how much of the kernel is the output stream?
+          if (o[0][0] == (decltype(o[0][0] + o[0][0]))1234.5f && o[1][1] == (decltype(o[0][0] + o[0][0]))77.f)
+#endif
+          {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<vec8*>(p.Cp + off + q * 1024) = o[q];
+          }
         }
       }
     }
   }
+  if (NPL == 2 && p.range_flag && bad) atomicOr(p.range_flag, 1);
 #ifdef USF_STAMP
   PSTAMP(t3);
   if (p.dbg && lane == 0) {
-    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 1024) * 8 + wave) * 8;
-    o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; o[4] = 1;
+    unsigned long long* o = p.dbg + (size_t)((bid % 2048) * 8 + wave) * 8;
+    o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; o[4] = 1; o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+    o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
   }
+#endif
+  }  // virtual blocks
+#ifdef USF_STAMP
+  if (p.span && tid == 0) atomicMax(p.span + 1, __builtin_amdgcn_s_memrealtime());
 #endif
 }
 
 #ifdef USF_STAMP
 unsigned long long* g_pdbg = nullptr;
+unsigned long long* g_pspan = nullptr;
 #endif
 
-template <int TN>
+template <int NPL, int TN>
 static int launch_planes(PlArgs a, bool f32out, hipStream_t stream) {
   constexpr int BN = TN * 32;
   a.nbm = (a.npanels + 15) / 16;
   a.nbn = f32out ? (a.N + BN - 1) / BN : (a.c_kbn + TN - 1) / TN;
-  const int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
-  if (grid > 0x7fffffffLL) { set_error("usf_gemm_planes_bf16x3: grid too large"); return -3; }
-  if (f32out) hipLaunchKernelGGL((gemm_planes_kernel<TN, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_planes_kernel<TN, false>), dim3((unsigned)grid), dim3(512), 0, stream, a);
-  return check_launch("usf_gemm_planes_bf16x3");
+  int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
+  if (grid > 0x7fffffffLL) { set_error("usf_gemm_planes: grid too large"); return -3; }
+  a.nvb = (int)grid;
+  static int cus = -1, persist = -1;
+  if (cus < 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    cus = (cus / 8) * 8 > 0 ? (cus / 8) * 8 : 8;
+    const char* e = getenv("USF_PLANES_PERSIST"); persist = e ? atoi(e) : 1;       // tuning aid: 0 = one block per tile
+  }
+  if (persist && grid > cus) grid = cus;
+  if (f32out) hipLaunchKernelGGL((gemm_planes_kernel<NPL, TN, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_planes_kernel<NPL, TN, false>), dim3((unsigned)grid), dim3(512), 0, stream, a);
+  return check_launch("usf_gemm_planes");
 }
 
 // column-block width (in 32-feature blocks) for an output of nblk blocks: the one that pads less, 5 on a tie
@@ -368,21 +457,25 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
   if ((d->ldw & 7) || d->ldw < 32 * d->nk || (d->w_rows & 3)) { set_error("usf_gemm_planes_bf16x3: ldw must be a multiple of 8 and >= 32 nk; w_rows a multiple of 4"); return -2; }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_gemm_planes_bf16x3: bad act"); return -2; }
   const int64_t npanels = (d->M + 15) / 16;
-  if (npanels * d->a_nkb * 3072 >= (1LL << 32) || 3 * d->w_plane_stride >= (1LL << 31)) {
+  if (d->format != USF_PLANES_BF16X3 && d->format != USF_PLANES_F16X2) { set_error("usf_gemm_planes_bf16x3: unknown format %d", d->format); return -2; }
+  const int64_t npl = d->format == USF_PLANES_F16X2 ? 2 : 3;
+  if (npanels * d->a_nkb * npl * 1024 >= (1LL << 32) || 2 * npl * d->w_plane_stride >= (1LL << 32)) {
     set_error("usf_gemm_planes_bf16x3: operand larger than the kernel's 32-bit offsets");
     return -3;
   }
   PlArgs a;
-  a.A = reinterpret_cast<const char*>(d->A); a.Wp = reinterpret_cast<const __bf16*>(d->W_planes);
+  a.A = reinterpret_cast<const char*>(d->A); a.Wp = reinterpret_cast<const char*>(d->W_planes);
   a.bias = d->bias; a.post_mul = d->post_mul; a.R = reinterpret_cast<const char*>(d->residual);
   a.Cp = reinterpret_cast<char*>(d->C_planes); a.Cf = d->C_f32; a.ldc = d->ldc; a.plane_stride = d->w_plane_stride;
   a.ldwp = (int)d->ldw; a.wrows = (int)d->w_rows; a.M = (int)d->M; a.npanels = (int)npanels;
   a.a_nkb = (int)d->a_nkb; a.a_kb0 = (int)d->a_kb0; a.nk = (int)d->nk;
   a.c_nkb = (int)d->c_nkb; a.c_kb0 = (int)d->c_kb0; a.c_kbn = (int)d->c_kbn; a.N = (int)d->N;
-  a.res_sign = d->res_sign; a.slope = d->slope; a.act = d->act; a.nbm = a.nbn = 0;
-  a.dbg = nullptr;
+  a.res_sign = d->res_sign; a.slope = d->slope; a.act = d->act; a.nbm = a.nbn = a.nvb = 0;
+  a.range_flag = d->range_flag;
+  a.dbg = nullptr; a.span = nullptr;
 #ifdef USF_STAMP
-  a.dbg = g_pdbg;
+  a.dbg = g_pdbg; a.span = g_pspan;
+  if (g_pspan) g_pspan += 2;            // one [start, end] pair per launch
 #endif
   int64_t nblk;
   if (f32out) {
@@ -395,13 +488,14 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
                 (long long)d->c_kb0, (long long)d->c_kbn, (long long)d->c_nkb, (long long)d->w_rows);
       return -2;
     }
-    if (npanels * d->c_nkb * 3072 >= (1LL << 40)) { set_error("usf_gemm_planes_bf16x3: output too large"); return -3; }
+    if (npanels * d->c_nkb * npl * 1024 >= (1LL << 40)) { set_error("usf_gemm_planes_bf16x3: output too large"); return -3; }
     nblk = d->c_kbn;
   }
   static int force = -1;
   if (force < 0) { const char* e = getenv("USF_PLANES_TN"); force = e ? atoi(e) : 0; }
   const int tn = (force == 4 || force == 5) ? force : gemm_planes_tn(nblk);
-  return tn == 4 ? launch_planes<4>(a, f32out, stream) : launch_planes<5>(a, f32out, stream);
+  if (npl == 2) return tn == 4 ? launch_planes<2, 4>(a, f32out, stream) : launch_planes<2, 5>(a, f32out, stream);
+  return tn == 4 ? launch_planes<3, 4>(a, f32out, stream) : launch_planes<3, 5>(a, f32out, stream);
 }
 
 }  // namespace usf

@@ -315,10 +315,15 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const S* __restrict__ 
   float w = 0.0f;
   if (c < n_in) {
     const int32_t si = iidx ? iidx[c] : (int32_t)c;
-    if (so >= 0 && si >= 0) w = (float)(transpose ? src[(int64_t)si * lds_ + so] : src[(int64_t)so * lds_ + si]);
+    if (so >= 0 && si >= 0) w = (float)((transpose & 1) ? src[(int64_t)si * lds_ + so] : src[(int64_t)so * lds_ + si]);
     if (W) W[o * ldw + c] = w;
   }
-  if (planes && c < ldp) {
+  if (planes && c < ldp && (transpose & 2)) {          // two fp16 planes (USF_PLANES_F16X2)
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
+    planes[o * ldp + c] = __builtin_bit_cast(uint16_t, hi);
+    planes[plane_stride + o * ldp + c] = __builtin_bit_cast(uint16_t, lo);
+  } else if (planes && c < ldp) {
     const uint16_t hi = bf16_rne(w);
     const float r = w - bf16_to_f32(hi);
     const uint16_t mid = bf16_rne(r);
@@ -338,10 +343,16 @@ __device__ __forceinline__ void pack_job_body(const usf_pack_job& j, int64_t o, 
   float w = 0.0f;
   if (c < j.n_in) {
     const int32_t si = j.in_idx ? j.in_idx[c] : (int32_t)c;
-    if (so >= 0 && si >= 0) w = (float)(j.transpose ? src[(int64_t)si * j.ld_src + so] : src[(int64_t)so * j.ld_src + si]);
+    if (so >= 0 && si >= 0) w = (float)((j.transpose & 1) ? src[(int64_t)si * j.ld_src + so] : src[(int64_t)so * j.ld_src + si]);
     if (j.W) j.W[o * j.ldw + c] = w;
   }
-  if (j.planes && c < j.ld_planes) {
+  if (j.planes && c < j.ld_planes && (j.transpose & 2)) {   // two fp16 planes (USF_PLANES_F16X2)
+    uint16_t* planes = reinterpret_cast<uint16_t*>(j.planes);
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
+    planes[o * j.ld_planes + c] = __builtin_bit_cast(uint16_t, hi);
+    planes[j.plane_stride + o * j.ld_planes + c] = __builtin_bit_cast(uint16_t, lo);
+  } else if (j.planes && c < j.ld_planes) {
     uint16_t* planes = reinterpret_cast<uint16_t*>(j.planes);
     const uint16_t hi = bf16_rne(w);
     const float r = w - bf16_to_f32(hi);

@@ -229,9 +229,10 @@ class FlowEngine:
         self.use_fused_coupling = True
         self.fused_min_rows = 14336    # measured cross-over on MI355X at D=784, hidden 256 (bench.py --fused-min-rows sweep:
         #                                fused / unfused ms per step: 8192 4.79 / 3.98, 12288 5.06 / 5.05, 16384 6.45 / 6.66, 20480 7.54 / 8.43)
-        # "bf16x3" (default): the D x D affine GEMMs run on the bf16 matrix cores with a 3-way residual split of
-        # both operands (fp32-equivalent accuracy); "f32": exact-f32 MFMA everywhere
-        # (USFLOWS_AMD_GEMM=f32 or engine.gemm_mode = "f32")
+        # "bf16x3": the GEMMs run on the bf16 matrix cores with a 3-way residual split of both operands (24 significant
+        # bits, six MFMAs per product); "f16x2": the planes pipeline uses two fp16 planes per operand
+        # (22 significant bits, three MFMAs per product, range-guarded with a bf16x3 redo; everything outside the planes
+        # pipeline as "bf16x3"); "f32": exact-f32 MFMA everywhere (USFLOWS_AMD_GEMM=... or engine.gemm_mode = ...)
         self.gemm_mode = os.environ.get("USFLOWS_AMD_GEMM", "bf16x3")
         # True: the pack also keeps L, U^T, L^-1, U^-T of every LU block (fp64) -- the training backward's operands
         self.keep_factors = False
@@ -240,6 +241,8 @@ class FlowEngine:
         # B = 100: 1.22 ms either way) -- the ~7 us between two dependent dispatches is not host time
         # planes pipeline: from planes_min_rows rows, inference plans in bf16x3 mode keep the activations
         # between layers as pre-split bf16 planes in MFMA-operand order (usf_planes.hip); USFLOWS_AMD_PLANES=0 disables
+        self._f16_overflow = False      # set while a pass is being redone in bf16x3 because fp16 planes overflowed
+        self.f16_fallbacks = 0          # number of such passes (tests / diagnostics)
         self.use_planes = os.environ.get("USFLOWS_AMD_PLANES", "1") != "0"
         self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
         self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
@@ -532,7 +535,7 @@ class FlowEngine:
         return cache[key]
 
     def _wants_planes(self, n_out: int, K: int) -> bool:
-        return self.gemm_mode == "bf16x3" and K % 8 == 0 and n_out > 64
+        return self.gemm_mode in ("bf16x3", "f16x2") and K % 8 == 0 and n_out > 64
 
     def _mat(self, pk, blk, which: str, out_layout: str, in_layout: str) -> torch.Tensor:
         """permuted / padded fp32 image of an affine block's M or M^-1 (+ its bf16x3 planes), one launch"""
@@ -824,9 +827,14 @@ class FlowEngine:
         perm = torch.tensor([32 * (c // 32) + self._slot_feature(c % 32) for c in range(n)], dtype=torch.long)
         return logical[perm]
 
+    def _planes_fmt(self) -> int:
+        """activation / weight plane format of the planes pipeline: fp16x2 in "f16x2" mode (three MFMAs per product,
+        22 significant bits per operand) unless a pass just overflowed fp16's range, bf16x3 otherwise"""
+        return _ext.PLANES_F16X2 if (self.gemm_mode == "f16x2" and not self._f16_overflow) else _ext.PLANES_BF16X3
+
     def _planes_ok(self, direction: str, B: int, has_ctx: bool, train: bool) -> bool:
-        if (train or has_ctx or not self.use_planes or self.gemm_mode != "bf16x3" or B < self.planes_min_rows
-                or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
+        if (train or has_ctx or not self.use_planes or self.gemm_mode not in ("bf16x3", "f16x2")
+                or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
         prims = self._primitive_ops(direction)
         kinds = [p_[0] for p_ in prims]
@@ -839,13 +847,18 @@ class FlowEngine:
         # the last layer must be an affine (it writes the fp32 result) and the chain needs at least two GEMM-sized ops
         return len(body) >= 2 and body[-1].startswith("affine")
 
-    def _planes_image(self, pk, key, src, out_sel: torch.Tensor, in_sel: torch.Tensor):
-        """cached bf16x3 planes [3, len(out_sel), len(in_sel)] of src[out_sel][:, in_sel] (-1: zero), one queued launch"""
+    def _planes_image(self, pk, key, src, out_sel: torch.Tensor, in_sel: torch.Tensor, fmt: int = 0):
+        """cached weight planes of src[out_sel][:, in_sel] (-1: zero), one queued launch: [3, rows, cols] bf16
+        (bf16x3) or [2, rows, cols] fp16 (fp16x2)"""
         mats = pk["mats"]
+        key = key + (fmt,)
         if key not in mats:
             dev = src.device
             n_out, n_in = int(out_sel.numel()), int(in_sel.numel())
-            P = torch.empty(3, n_out, n_in, dtype=torch.bfloat16, device=dev)
+            if fmt == _ext.PLANES_F16X2:
+                P = torch.empty(2, n_out, n_in, dtype=torch.float16, device=dev)
+            else:
+                P = torch.empty(3, n_out, n_in, dtype=torch.bfloat16, device=dev)
             _ext.pack_weight(src, out_sel.to(device=dev, dtype=torch.int32), n_out,
                              in_sel.to(device=dev, dtype=torch.int32), n_in, planes=P)
             mats[key] = P
@@ -884,10 +897,15 @@ class FlowEngine:
         segp, natp = self.segp_idx, self.natp_idx
         seg_phys = self._phys(segp)
         Hp = _round_up(self.hmax, 32)
+        fmt = self._planes_fmt()
+        chunk = 2048 if fmt == _ext.PLANES_F16X2 else 3072        # bytes per (panel, block): NPL planes of 1 KiB
+        if "pflag" not in ws:
+            ws["pflag"] = torch.zeros(1, dtype=torch.int32, device=device)
+        flag = ws["pflag"].data_ptr() if fmt == _ext.PLANES_F16X2 else 0
 
         def planes_buf(name, blocks):
-            if name not in ws:
-                ws[name] = torch.empty(npan * blocks * 3072, dtype=torch.uint8, device=device)
+            if name not in ws or ws[name].numel() < npan * blocks * 3072:
+                ws[name] = torch.empty(npan * blocks * 3072, dtype=torch.uint8, device=device)     # (sized for either format)
             return ws[name]
 
         zbufs = [planes_buf("pzA", nkb), planes_buf("pzB", nkb)]
@@ -900,6 +918,7 @@ class FlowEngine:
             op.kind = _ext.OP_GEMM_PLANES
             g = op.u.gemm_planes
             g.M, g.res_sign, g.slope, g.act = B, 1.0, 0.0, _ext.ACT_NONE
+            g.format, g.range_flag = fmt, flag
             for k_, v_ in kw.items():
                 setattr(g, k_, v_)
             return op
@@ -911,6 +930,7 @@ class FlowEngine:
         pack.kind = _ext.OP_PACK_PLANES
         d = pack.u.pack_planes
         d.src, d.ld, d.M, d.nkb = 0, self.D, B, nkb
+        d.format, d.range_flag = fmt, flag
         d.idx = self._idx_dev("segp", device).data_ptr()
         d.planes = zbufs[cur].data_ptr()
         first_bias_in_prologue = False
@@ -935,7 +955,7 @@ class FlowEngine:
                 is_last = (k == n - 1) or (fuse_post and k == n - 2)
                 out_sel = natp if is_last else segp
                 which = "Minv" if prim == "affine_bwd" else "M"
-                W = self._planes_image(pk, ("pl_aff", id(blk), which, is_last), a[which], out_sel, seg_phys)
+                W = self._planes_image(pk, ("pl_aff", id(blk), which, is_last), a[which], out_sel, seg_phys, fmt)
                 kw = dict(A=zbufs[cur].data_ptr(), a_nkb=nkb, a_kb0=0, nk=nkb, W_planes=W.data_ptr(), ldw=W.shape[2],
                           w_plane_stride=W.shape[1] * W.shape[2], w_rows=W.shape[1])
                 lay = "natp" if is_last else "segp"
@@ -997,7 +1017,7 @@ class FlowEngine:
                     hj = _round_up(h[j], 32)
                     out_sel = torch.full((hj,), -1, dtype=torch.long)
                     out_sel[: h[j]] = torch.arange(h[j])
-                Wimg = self._planes_image(pk, ("pl_mlp", i, j), W_, out_sel, in_sel)
+                Wimg = self._planes_image(pk, ("pl_mlp", i, j), W_, out_sel, in_sel, fmt)
                 bvec = self._planes_vec(pk, ("pl_mlpb", i, j), b_, out_sel)
                 kw = dict(A=src_buf.data_ptr(), a_nkb=src_nkb, a_kb0=src_kb0, nk=src_nk, W_planes=Wimg.data_ptr(),
                           ldw=Wimg.shape[2], w_plane_stride=Wimg.shape[1] * Wimg.shape[2], w_rows=Wimg.shape[1],
@@ -1018,7 +1038,7 @@ class FlowEngine:
 
         arr = (_ext.Op * len(ops))(*ops)
         return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=[], final_gather=None,
-                    out_buf=out_buf, ws=ws, pk=pk, meta=[], planes=True)
+                    out_buf=out_buf, ws=ws, pk=pk, meta=[], planes=True, planes_fmt=fmt)
 
     # fused coupling kernel availability (filled in when the kernel is present)
     def _fused_ok(self, cp) -> bool:
@@ -1034,7 +1054,7 @@ class FlowEngine:
         Hp = lib.usf_coupling_padded_width(max(cp["hidden"]))
         Kp = _round_up(cp["pass_n"], 32)
         Np = _round_up(cp["tr_n"], 32)
-        split = self.gemm_mode == "bf16x3" and Hp == 256
+        split = self.gemm_mode in ("bf16x3", "f16x2") and Hp == 256
         if "fused" in cp and (not split or "split" in cp["fused"]):
             return cp["fused"]
         with self._pk_record(self._pack):
@@ -1103,7 +1123,7 @@ class FlowEngine:
             d.context = ws_ctx["ctx"].data_ptr()
             d.W_ctx, d.b_ctx = f["W_ctx"].data_ptr(), f["b_ctx"].data_ptr()
         d.sign, d.slope, d.act = sign, cp["slope"], cp["act"]
-        if self.gemm_mode == "bf16x3" and "split" in f:
+        if self.gemm_mode in ("bf16x3", "f16x2") and "split" in f:
             s3 = f["split"]
             d.split_in, d.split_in_ld, d.split_in_plane = s3["in"].data_ptr(), s3["in"].shape[2], s3["in"].shape[1] * s3["in"].shape[2]
             for j, P in enumerate(s3["hid"]):
@@ -1117,11 +1137,29 @@ class FlowEngine:
     def _plan(self, direction, B, device, has_ctx, final, train: bool = False):
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
-               train, self.use_planes, self.planes_min_rows)
+               train, self.use_planes, self.planes_min_rows, self._planes_fmt())
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final, train)
             self._plans[key] = plan
+        return plan
+
+    def _run_guarded(self, direction, x, out, context, final):
+        """plan + run; a planes pass in fp16x2 format whose range guard fired (a NaN or |value| >= 65000 somewhere in
+        the flow: fp16 planes cannot carry it) is void and is redone with bf16x3 planes.  The check reads one int32
+        back from the device, i.e. it waits for the pass: only plans of >= planes_min_rows rows (milliseconds) do it."""
+        B = x.shape[0]
+        plan = self._plan(direction, B, x.device, context is not None, final)
+        self._run(plan, x, out, context)
+        if plan.get("planes_fmt") == _ext.PLANES_F16X2 and int(plan["ws"]["pflag"].item()) != 0:
+            plan["ws"]["pflag"].zero_()
+            self.f16_fallbacks += 1
+            self._f16_overflow = True
+            try:
+                plan = self._plan(direction, B, x.device, context is not None, final)
+                self._run(plan, x, out, context)
+            finally:
+                self._f16_overflow = False
         return plan
 
     def _run(self, plan, x: torch.Tensor, out: Optional[torch.Tensor], context):
@@ -1283,15 +1321,13 @@ class FlowEngine:
         out = torch.empty(B, self.D, dtype=torch.float32, device=x.device)
         if B == 0:
             return out
-        plan = self._plan(direction, B, x.device, context is not None, "user")
-        self._run(plan, x, out, context)
+        self._run_guarded(direction, x, out, context, "user")
         return out
 
     def latent(self, x: torch.Tensor, context=None) -> Tuple[torch.Tensor, int, float]:
         """backward pass into the workspace: (z buffer [B, ldn], ldn, -sum ladj)."""
         x = self._check_input(x)
-        plan = self._plan("backward", x.shape[0], x.device, context is not None, "nat")
-        self._run(plan, x, None, context)
+        plan = self._run_guarded("backward", x, None, context, "nat")
         buf = plan["ws"][plan["out_buf"][0]]
         return buf, plan["out_buf"][2], -plan["pk"]["ladj_total"]
 
