@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
   usf_gemm_planes_desc g2 = {}; g2.A = pB; g2.a_nkb = nout; g2.nk = nout; g2.W_planes = W2; g2.ldw = N; g2.w_plane_stride = N * N; g2.w_rows = N;
   g2.C_f32 = C; g2.ldc = N; g2.N = N; g2.M = M; g2.res_sign = 1.f; g2.format = fmt;
 #ifdef USF_STAMP
-  unsigned long long* dbg; hipMalloc(&dbg, 16384 * 8 * 8); hipMemset(dbg, 0, 16384 * 8 * 8); usf::g_pdbg = dbg;
+  unsigned long long* dbg; hipMalloc(&dbg, 2 * 16384 * 8 * 8); hipMemset(dbg, 0, 2 * 16384 * 8 * 8); usf::g_pdbg = dbg;
 #endif
   if (usf::pack_planes(&pd, 0) || usf::gemm_planes(&g1, 0) || usf::gemm_planes(&g2, 0)) return 1;
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 2; }
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
   { std::vector<unsigned long long> sp(128); hipMemcpy(sp.data(), span, 64 * 16, hipMemcpyDeviceToHost);
     double din = 0, gap = 0; for (int i = 30; i < 39; ++i) { din += (sp[2 * i + 1] - sp[2 * i]) * 0.01; gap += (sp[2 * i + 2] - sp[2 * i + 1]) * 0.01; }
     printf("  launches 30..38: first wave start -> last wave end %.1f us; last end -> next launch's first start %.1f us\n", din / 9, gap / 9); }
-  std::vector<unsigned long long> hd(16384 * 8); hipMemcpy(hd.data(), dbg, 16384 * 8 * 8, hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> hd(2 * 16384 * 8); hipMemcpy(hd.data(), dbg, 2 * 16384 * 8 * 8, hipMemcpyDeviceToHost);
   double sm[6] = {0, 0, 0, 0, 0, 0}; int nw = 0;
   for (int w = 0; w < 16384; ++w) if (hd[w * 8 + 4]) { for (int j = 0; j < 6; ++j) sm[j] += hd[w * 8 + j]; ++nw; }
   { unsigned long long mn = ~0ull, mx = 0; double busy = 0;
@@ -116,6 +116,12 @@ int main(int argc, char** argv) {
         st += (hd[e + 6] - k0) * 0.01; en += (hd[e + 7] - k0) * 0.01; mxe = std::max(mxe, (hd[e + 7] - k0) * 0.01); ++nb; }
       if (nb) printf("    round %d: mean start %.1f us, mean end %.1f us (span %.1f), last end %.1f us  [%d blocks]\n", r, st / nb, en / nb, (en - st) / nb, mxe, nb);
     } }
+#if USF_STAMP >= 2
+  { double ph[4] = {0, 0, 0, 0}; int n2 = 0;
+    for (int w = 0; w < 16384; ++w) if (hd[w * 8 + 4]) { for (int j = 0; j < 4; ++j) ph[j] += hd[(16384 + w) * 8 + j]; ++n2; }
+    printf("  per slab and wave (cycles): pairs before barrier %.0f, stage stores %.0f, barrier %.0f, pairs after %.0f\n",
+           ph[0] / n2 / nkb, ph[1] / n2 / nkb, ph[2] / n2 / nkb, ph[3] / n2 / nkb); }
+#endif
   printf("  waves %d: cycles per wave: prologue %.0f loop %.0f (%.0f per slab) epilogue %.0f total %.0f; in-kernel clock %.0f MHz\n", nw, sm[0] / nw, sm[1] / nw, sm[1] / nw / nkb, sm[2] / nw, sm[3] / nw, sm[3] / sm[5] * 100.0);
 #endif
   return 0;

@@ -156,12 +156,12 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   constexpr unsigned CHB = NPL * 1024u;         // bytes of one (panel, k-block) chunk group
   // weight stage: NPL planes x 4 k-chunks x BN rows of 16-byte slots, image slot(plane, chunk c, row r) =
   // (plane * 4 + c) * BN + (r ^ 2c)  (conflict-free for the fragment reads and for the row-major deal; see
-  // usf_linear_bf16x3.hip); ring of four buffers, the block meets at a barrier every second slab
+  // usf_linear_bf16x3.hip)
   constexpr int CS = BN;
   constexpr int NSLOT = NPL * 4 * BN;
   constexpr int NWV = (NSLOT + NT - 1) / NT;
   constexpr int STG = NPL * 4 * CS * 4;         // floats per staging buffer
-  constexpr int NB = 4, D = 2;
+  constexpr int NB = 3;                         // ring of three weight buffers (see the K loop)
   static_assert(NWV * NT - NSLOT <= NSLOT, "surplus threads wrap once");
   __shared__ __attribute__((aligned(16))) float wring[NB * STG];
 
@@ -243,68 +243,126 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   vec8 pa[2][NPL], pb[2][NPL];
+  vec8 fr[2][NPL], f2[2][NPL];                   // weight fragments: current tile pair / the pair being read
   f32x4 wst[NWV];
   const int nslab = p.nk;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    issue_w(min(d, nslab - 1) * 32, wst);
-    store_w(wring + d * STG, wst);
-  }
+  issue_w(0, wst);
+  store_w(wring, wst);
   issue_a(0, pa);
+  issue_w(min(1, nslab - 1) * 32, wst);         // staged at the middle of slab 0
   __syncthreads();
+  const float* const wl0 = wring + 4 * (lg * CS + (lj ^ (2 * lg)));
+  auto read_pair = [&](const float* wl, int pr, vec8 (&f)[2][NPL]) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      f[0][q] = *reinterpret_cast<const vec8*>(wl + 4 * (q * 4 * CS + (2 * pr) * 16));
+      f[1][q] = *reinterpret_cast<const vec8*>(wl + 4 * (q * 4 * CS + (2 * pr + 1) * 16));
+    }
+  };
+  read_pair(wl0, 0, fr);
 
-  // one slab: NPR products per feature tile and batch tile (NPL = 3: six, smallest terms first; NPL = 2: three),
-  // weight fragments read from LDS two tiles ahead; the next slab's operands (global -> registers) and the weights of
-  // the slab after next (global -> staging registers) are issued under the first tiles' MFMAs
+  // One slab = TN tile pairs, NPR products per feature tile and batch tile (NPL = 3: six, smallest terms first;
+  // NPL = 2: three).  Software pipeline: the weight fragments of pair i + 1 are read from LDS under the MFMAs of pair
+  // i -- ACROSS the slab boundary too (the last pair of slab s reads the first pair of slab s + 1), so the matrix pipe
+  // never waits for an LDS round trip at a slab start.  The block's ONE barrier per slab sits in the MIDDLE of the
+  // slab, right behind the stores that stage slab s + 1 into the ring: the waves cross it with their next fragments
+  // already in registers and resume with MFMAs.  Ring of three buffers: slab s + 1 is written (mid-slab s) into the
+  // buffer slab s - 2 was read from, and every wave has passed barrier s - 1, i.e. has finished slab s - 2.
   constexpr int NPR = (NPL == 3) ? 6 : 3;
-  constexpr int NLD = NWV + 2 * NPL;            // vector-memory loads per slab and thread
-  constexpr int LPT = (NLD + FT - 1) / FT;      // ... dealt over the feature tiles
+  constexpr int NP = TN;                        // tile pairs per slab
+  constexpr int MID = (NP - 1) / 2;             // the barrier follows pair MID
+  constexpr int NLD = 2 * NPL;                  // operand loads per slab and thread
+  constexpr int LPP = (NLD + MID) / (MID + 1);  // ... dealt over the pairs in front of the barrier
 #define USF_MM(FT_, W, P)                                        \
   acc[FT_][0] = PT::mfma(W, cur[0][P], acc[FT_][0]);             \
   acc[FT_][1] = PT::mfma(W, cur[1][P], acc[FT_][1])
-  auto slab = [&](int s, const vec8 (&cur)[2][NPL], vec8 (&nxt)[2][NPL], bool sync_after) {
-    const float* rb = wring + (s % NB) * STG;
-    float* wb = wring + ((s + D) % NB) * STG;
-    const float* wl = rb + 4 * (lg * CS + (lj ^ (2 * lg)));
-    issue_w(min(s + D, nslab - 1) * 32, wst);
+  auto mm_pair = [&](int pr, const vec8 (&f)[2][NPL], const vec8 (&cur)[2][NPL]) {
+    const int ft = 2 * pr;
+    if (NPL == 3) {
+      USF_MM(ft, f[0][2], 0); USF_MM(ft + 1, f[1][2], 0); USF_MM(ft, f[0][1], 1); USF_MM(ft + 1, f[1][1], 1);
+      USF_MM(ft, f[0][0], NPL - 1); USF_MM(ft + 1, f[1][0], NPL - 1); USF_MM(ft, f[0][1], 0); USF_MM(ft + 1, f[1][1], 0);
+      USF_MM(ft, f[0][0], 1); USF_MM(ft + 1, f[1][0], 1); USF_MM(ft, f[0][0], 0); USF_MM(ft + 1, f[1][0], 0);
+    } else {
+      USF_MM(ft, f[0][1], 0); USF_MM(ft + 1, f[1][1], 0); USF_MM(ft, f[0][0], 1); USF_MM(ft + 1, f[1][0], 1);
+      USF_MM(ft, f[0][0], 0); USF_MM(ft + 1, f[1][0], 0);
+    }
+  };
+#if defined(USF_STAMP) && USF_STAMP >= 2     // in-loop phase stamps (they drain the LDS queue: a diagnostic build of its own)
+  unsigned long long ph[4] = {0, 0, 0, 0};
+#define LSTAMP(v) PSTAMP(v)
+#define LACC(i, a, b) ph[i] += (b) - (a)
+#else
+#define LSTAMP(v)
+#define LACC(i, a, b)
+#endif
+  // fA holds the slab's first pair on entry; the two fragment sets alternate as "current" / "being read"; the first
+  // pair of the NEXT slab lands in fA when NP is even, in fB when NP is odd (the caller swaps them then)
+  auto slab = [&](int s, int ring_s, const vec8 (&cur)[2][NPL], vec8 (&nxt)[2][NPL], vec8 (&fA)[2][NPL], vec8 (&fB)[2][NPL]) {
+    LSTAMP(l0);
+    const int ring_n = (ring_s == 2) ? 0 : ring_s + 1;
+    const float* wl = wl0 + ring_s * STG;
+    const float* wln = wl0 + ring_n * STG;
+    float* wb = wring + ring_n * STG;
     issue_a(min(s + 1, nslab - 1), nxt);
+    // ---- pairs in front of the barrier; the last of them carries the stores that stage slab s + 1 ----
 #pragma unroll
-    for (int ft = 0; ft < FT; ft += 2) {
-      vec8 wa[NPL], wb2[NPL];
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) {
-        wa[q] = *reinterpret_cast<const vec8*>(wl + 4 * (q * 4 * CS + ft * 16));
-        wb2[q] = *reinterpret_cast<const vec8*>(wl + 4 * (q * 4 * CS + (ft + 1) * 16));
-      }
-      if (NPL == 3) {
-        USF_MM(ft, wa[2], 0); USF_MM(ft + 1, wb2[2], 0); USF_MM(ft, wa[1], 1); USF_MM(ft + 1, wb2[1], 1);
-        USF_MM(ft, wa[0], NPL - 1); USF_MM(ft + 1, wb2[0], NPL - 1); USF_MM(ft, wa[1], 0); USF_MM(ft + 1, wb2[1], 0);
-        USF_MM(ft, wa[0], 1); USF_MM(ft + 1, wb2[0], 1); USF_MM(ft, wa[0], 0); USF_MM(ft + 1, wb2[0], 0);
+    for (int pr = 0; pr <= MID; ++pr) {
+      if (pr & 1) { if (pr + 1 < NP) read_pair(wl, pr + 1, fA); mm_pair(pr, fB, cur); }
+      else        { if (pr + 1 < NP) read_pair(wl, pr + 1, fB); mm_pair(pr, fA, cur); }
+      if (pr == MID) store_w(wb, wst);
+      // pins (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write): the fragment reads first, then the
+      // pair's MFMAs with this pair's share of the global loads / the staging stores dealt in
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
+      if (pr < MID) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0);
+        if (pr * LPP < NLD) __builtin_amdgcn_sched_group_barrier(0x020, LPP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0);
       } else {
-        USF_MM(ft, wa[1], 0); USF_MM(ft + 1, wb2[1], 0); USF_MM(ft, wa[0], 1); USF_MM(ft + 1, wb2[0], 1);
-        USF_MM(ft, wa[0], 0); USF_MM(ft + 1, wb2[0], 0);
+        constexpr int MPS = (4 * NPR) / (NWV + 1);        // MFMAs between two staging stores
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MPS, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NPR - NWV * MPS, 0);
       }
     }
-    // issue order pins (masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    LSTAMP(l1);
+    LSTAMP(l2);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    LSTAMP(l3);
+    // ---- pairs behind the barrier; the first carries the global loads of the weights of slab s + 2 (the staging
+    // registers are free again: a full slab of latency cover until the middle of slab s + 1 stores them); the last
+    // one reads the first pair of the NEXT slab (staged just now) ----
+    issue_w(min(s + 2, nslab - 1) * 32, wst);
 #pragma unroll
-    for (int f = 0; f < FT; ++f) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0);
-      if (f + 2 < FT) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
-      if (f * LPT < NLD) __builtin_amdgcn_sched_group_barrier(0x020, LPT, 0);
+    for (int pr = MID + 1; pr < NP; ++pr) {
+      if (pr & 1) { if (pr + 1 < NP) read_pair(wl, pr + 1, fA); else read_pair(wln, 0, fA); mm_pair(pr, fB, cur); }
+      else        { if (pr + 1 < NP) read_pair(wl, pr + 1, fB); else read_pair(wln, 0, fB); mm_pair(pr, fA, cur); }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
+      if (pr == MID + 1) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, NWV, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NPR, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NPR, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    store_w(wb, wst);
-    __builtin_amdgcn_sched_barrier(0);
-    if (sync_after) __syncthreads();
+    LSTAMP(l4);
+    LACC(0, l0, l1); LACC(1, l1, l2); LACC(2, l2, l3); LACC(3, l3, l4);
   };
   PSTAMP(t1);
-  int s = 0;
+  int s = 0, ring = 0;
   for (; s + 2 <= nslab; s += 2) {
-    slab(s, pa, pb, false);
-    slab(s + 1, pb, pa, true);
+    slab(s, ring, pa, pb, fr, f2);
+    ring = (ring == 2) ? 0 : ring + 1;
+    if (NP & 1) slab(s + 1, ring, pb, pa, f2, fr); else slab(s + 1, ring, pb, pa, fr, f2);
+    ring = (ring == 2) ? 0 : ring + 1;
   }
-  if (s < nslab) slab(s, pa, pb, false);
+  if (s < nslab) slab(s, ring, pa, pb, fr, f2);
 #undef USF_MM
   PSTAMP(t2);
 
@@ -388,6 +446,10 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     unsigned long long* o = p.dbg + (size_t)((bid % 2048) * 8 + wave) * 8;
     o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t3 - t0; o[4] = 1; o[5] = __builtin_amdgcn_s_memrealtime() - rt0;
     o[6] = rt0; o[7] = __builtin_amdgcn_s_memrealtime();
+#if USF_STAMP >= 2
+    unsigned long long* o2 = p.dbg + 16384 * 8 + (size_t)((bid % 2048) * 8 + wave) * 8;
+    for (int i = 0; i < 4; ++i) o2[i] = ph[i];
+#endif
   }
 #endif
   }  // virtual blocks
