@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--conj", action="store_true", help="affine_conjugation=True (what the reference's live configs use)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra measurement of the opt-in fp16x2 mode")
     ap.add_argument("--unfused", action="store_true", help="run couplings as 3 linear ops instead of the fused kernel")
     ap.add_argument("--fused-min-rows", type=int, default=None, help="batch size from which couplings take the fused kernel")
     ap.add_argument("--gemm", choices=["bf16x3", "f16x2", "f32"], default=None,
@@ -201,6 +202,38 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = global_rows * args.steps / elapsed
 
+    # ---- opt-in fast mode, measured beside the headline (same process, same inputs, every rank): the planes pipeline
+    # with fp16x2 planes -- 22 significant bits per operand instead of 24, three MFMAs per product instead of six.
+    # NOT the headline: `value` above is the default (bf16x3) mode.
+    fast = None
+    if on_gpu and mode == "log_prob" and args.gemm is None and not args.no_fast_mode:
+        lp_default = lp.clone()
+        eng.gemm_mode = "f16x2"
+        for _ in range(3):
+            mean_f, lp_f = step()
+        if under_launcher:
+            dist.barrier()
+        sync()
+        tf0 = time.perf_counter()
+        for _ in range(args.steps):
+            mean_f, lp_f = step()
+        sync()
+        if under_launcher:
+            dist.barrier()
+        tfe = torch.tensor([time.perf_counter() - tf0], dtype=torch.float64, device=dev)
+        if under_launcher:
+            dist.all_reduce(tfe, op=dist.ReduceOp.MAX)
+        el_f = float(tfe.item())
+        lp_fast = lp_f.clone()
+        fast = {"gemm_mode": "f16x2", "value": round(global_rows * args.steps / el_f, 1), "unit": "samples/s",
+                "ms_per_step": round(el_f / args.steps * 1e3, 3),
+                "max_rel_vs_default_mode": float(((lp_fast.double() - lp_default.double()).abs() / lp_default.double().abs()).max().item()),
+                "range_guard_fallbacks": eng.f16_fallbacks,
+                "what": "planes pipeline: activations travel between layers as two fp16 planes in MFMA-operand order, "
+                        "a1 w1 + a1 w2 + a2 w1 on v_mfma_f32_16x16x32_f16, fp32 accumulation; engine.gemm_mode = 'f16x2' "
+                        "or USFLOWS_AMD_GEMM=f16x2; same batch, parameters and step definition as the headline"}
+        eng.gemm_mode = "bf16x3"
+
     if rank != 0:
         if under_launcher:
             dist.destroy_process_group()
@@ -321,6 +354,8 @@ def main():
         else:
             rel = ((lp[:rows].cpu().double() - ref_s.double()).abs() / ref_s.double().abs())
             sample, v_full = f"{n_it} x log_prob of the first {rows} rows", rows * n_it / cpu_s
+        if fast is not None and ref is not None:
+            fast["parity_max_rel_vs_cpu_fp32"] = float(((lp_fast.cpu().double() - ref.double()).abs() / ref.double().abs()).max().item())
         third = max(B // 3, 1)
         cpu = {"value": round(v_full, 1), "unit": "samples/s", "cores": torch.get_num_threads(),
                "kind": "port", "sample": sample, "host_cpus": os.cpu_count(),
@@ -381,7 +416,7 @@ def main():
            "param_prep_warm_ms": None if prep_warm_ms is None else round(prep_warm_ms, 2),
            "mean_log_prob": float(mean.item()) if mode != "sample" else None,
            "udl_check": udl,
-           "roofline": roofline, "cpu_baseline": cpu}
+           "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast}
     print(json.dumps(out), flush=True)
     if under_launcher:
         dist.destroy_process_group()

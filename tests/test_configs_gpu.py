@@ -87,7 +87,7 @@ def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B, planes):
     and small batches use) -- there 16384 / 32768 select the 128-row bf16x3 tile with the 2-buffer ring, 65536 the
     256-row tile with the 4-buffer ring."""
     spec, sd, a, flow, ladj = cfg2
-    flow.engine().use_planes = planes
+    flow.engine().use_planes = planes            # (None = automatic: planes only in "f16x2" mode)
     flow.engine()._plans.clear()
     x = torch.rand(B, 784, generator=torch.Generator().manual_seed(1234 + B))
     idx = place_probes(x, a["x"])
@@ -109,10 +109,11 @@ def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B, planes):
         assert {5050, 5040, 5051} <= v, (B, v)      # affine / conditioner layers on planes, fp32 output of the last layer
     else:
         assert {16384: 3542, 32768: 3542, 65536: 3584}[B] in v, (B, v)
-    flow.engine().use_planes = True
+    flow.engine().use_planes = None
 
 
-def test_cfg5_per_rank_sample(cfg2):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_cfg5_per_rank_sample(cfg2, mode):
     """cfg5 per rank: rank 3's 125000 of the 10^6 draws.  (1) sample() == _forward of the head kernel's own noise;
     (2) head / middle / tail rows of x vs the fp64 oracle's Flow._forward of that same noise; (3) the UDL check of
     BASELINE cfg5: log_prob(x) - base.log_prob(backward(x)) is one constant; (4) the draw is the matching slice of
@@ -121,6 +122,8 @@ def test_cfg5_per_rank_sample(cfg2):
     spec, sd, a, flow, ladj = cfg2
     n, rank, seed = 125000, 3, 2026
     eng = flow.engine()
+    eng.gemm_mode, eng.use_planes = mode, None      # "f16x2": the planes pipeline with fp16x2 planes (opt-in fast mode)
+    eng._plans.clear()
     with torch.no_grad():
         xs = flow.sample([n], seed=seed, row_offset=rank * n)
         z = torch.empty(n, 784, device=DEV)
@@ -148,7 +151,10 @@ def test_cfg5_per_rank_sample(cfg2):
     # through the 65 layers, not bitwise)
     dev_ = (part - xs[5000:6000]).abs().max().item()
     assert dev_ < 2e-5 * max(1.0, xs.abs().max().item()), dev_
-    assert 5050 in plan_variants(eng) and 5051 in plan_variants(eng)
+    v = plan_variants(eng)
+    assert ({5050, 5051} <= v) if mode == "f16x2" else (3542 in v or 3584 in v), v
+    assert eng.f16_fallbacks == 0
+    eng.gemm_mode = "bf16x3"
 
 
 @pytest.fixture(scope="module")
@@ -160,7 +166,8 @@ def cfg4():
     return spec, a, flow, ladj
 
 
-def test_cfg4_full_size(cfg4):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_cfg4_full_size(cfg4, mode):
     """BASELINE cfg4: D = 3072, 48 blocks, hidden [1024, 1024] (1.28 G parameters), B = 32768.  The 3072 x 3072 affine
     layers and the 1536 <-> 1024 conditioner layers run on the bf16x3 tiles (hidden width > 256: chain of linears)."""
     spec, a, flow, ladj = cfg4
@@ -169,6 +176,8 @@ def test_cfg4_full_size(cfg4):
     idx = place_probes(x, a["x"])
     xd = x.to(DEV)
     eng = flow.engine()
+    eng.gemm_mode, eng.use_planes = mode, None
+    eng._plans.clear()
     n0 = eng.launch_count
     with torch.no_grad():
         lp = flow.log_prob(xd)
@@ -184,7 +193,10 @@ def test_cfg4_full_size(cfg4):
         xf = flow._forward(a["zin"].to(DEV))
     s = max(1.0, a["forward64"].abs().max().item())
     assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2e-5 * s
-    assert {5040, 5041} <= plan_variants(eng), plan_variants(eng)  # (the 16-row _forward above takes the small-batch kernel)
+    v = plan_variants(eng)                                      # (the 16-row _forward above takes the small-batch kernel)
+    assert ({5040, 5041} <= v) if mode == "f16x2" else (3442 in v), v
+    assert eng.f16_fallbacks == 0
+    eng.gemm_mode = "bf16x3"
 
 
 def test_laplace_head_extreme_words_are_finite():

@@ -243,7 +243,11 @@ class FlowEngine:
         # between layers as pre-split bf16 planes in MFMA-operand order (usf_planes.hip); USFLOWS_AMD_PLANES=0 disables
         self._f16_overflow = False      # set while a pass is being redone in bf16x3 because fp16 planes overflowed
         self.f16_fallbacks = 0          # number of such passes (tests / diagnostics)
-        self.use_planes = os.environ.get("USFLOWS_AMD_PLANES", "1") != "0"
+        # use_planes: None = automatic (in "f16x2" mode only: with bf16x3 planes the affine GEMM gains ~5 % but the
+        # conditioner as three GEMMs loses to the fused coupling kernel -- 21.6 vs 19.1 ms per cfg2 step), True / False =
+        # forced (USFLOWS_AMD_PLANES=1 / 0)
+        env_planes = os.environ.get("USFLOWS_AMD_PLANES", "auto")
+        self.use_planes = None if env_planes == "auto" else env_planes != "0"
         self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
         self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
         self.graph_max_rows = 1024
@@ -833,7 +837,8 @@ class FlowEngine:
         return _ext.PLANES_F16X2 if (self.gemm_mode == "f16x2" and not self._f16_overflow) else _ext.PLANES_BF16X3
 
     def _planes_ok(self, direction: str, B: int, has_ctx: bool, train: bool) -> bool:
-        if (train or has_ctx or not self.use_planes or self.gemm_mode not in ("bf16x3", "f16x2")
+        use = (self.gemm_mode == "f16x2") if self.use_planes is None else bool(self.use_planes)
+        if (train or has_ctx or not use or self.gemm_mode not in ("bf16x3", "f16x2")
                 or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
         prims = self._primitive_ops(direction)
