@@ -218,7 +218,19 @@ def _mask_for(spec, flip, dtype):
 # --------------------------------------------------------------------------------------
 # base distributions (distributions.py:709-728 wrapper; torch Laplace/Normal; Radial 501-549)
 # --------------------------------------------------------------------------------------
-def base_log_prob(spec: FlowSpec, z: torch.Tensor) -> torch.Tensor:
+def gammamm_log_prob(sd, r: torch.Tensor, prefix="base_distribution.norm_distribution.") -> torch.Tensor:
+    """GammaMM.log_prob (distributions.py:674-707) = torch MixtureSameFamily over Gamma components:
+    logsumexp_k( log_softmax(logits)_k + Gamma(softplus(c_k), softplus(b_k)).log_prob(r) )"""
+    dt = r.dtype
+    c = F.softplus(sd[prefix + "concentration_unconstrained"].to(dt))
+    b = F.softplus(sd[prefix + "rate_unconstrained"].to(dt))
+    logw = torch.log_softmax(sd[prefix + "mixture_logits"].to(dt), dim=-1)
+    rr = r.unsqueeze(-1)
+    comp = c * torch.log(b) + (c - 1) * torch.log(rr) - b * rr - torch.lgamma(c)      # torch Gamma.log_prob
+    return torch.logsumexp(comp + logw, dim=-1)
+
+
+def base_log_prob(spec: FlowSpec, z: torch.Tensor, sd=None) -> torch.Tensor:
     dt = z.dtype
     D = spec.dim
     if spec.base in ("laplace", "normal"):
@@ -234,12 +246,17 @@ def base_log_prob(spec: FlowSpec, z: torch.Tensor) -> torch.Tensor:
         loc = (spec.base_loc if spec.base_loc is not None else torch.zeros(D)).to(dt)
         x = z - loc
         r = x.norm(p=spec.radial_p, dim=(-1,))
-        if spec.radial_norm != "lognormal":
+        if spec.radial_norm == "gammamm":
+            if sd is None:
+                raise ValueError("a GammaMM norm distribution needs the state dict (its parameters live there)")
+            log_prob_norm = gammamm_log_prob(sd, r)
+        elif spec.radial_norm == "lognormal":
+            nd = torch.distributions.LogNormal(torch.tensor([spec.radial_norm_loc], dtype=dt),
+                                               torch.tensor([spec.radial_norm_scale], dtype=dt))
+            nd = torch.distributions.Independent(nd, 1)     # DistributionModule.distribution :131-139
+            log_prob_norm = nd.log_prob(r.unsqueeze(-1)).squeeze(-1)
+        else:
             raise ValueError(spec.radial_norm)
-        nd = torch.distributions.LogNormal(torch.tensor([spec.radial_norm_loc], dtype=dt),
-                                           torch.tensor([spec.radial_norm_scale], dtype=dt))
-        nd = torch.distributions.Independent(nd, 1)     # DistributionModule.distribution :131-139
-        log_prob_norm = nd.log_prob(r.unsqueeze(-1)).squeeze(-1)
         p = spec.radial_p
         if p == 1:
             log_den = sum(math.log(i) for i in range(1, D))
@@ -288,7 +305,7 @@ def flow_log_prob(sd, spec: FlowSpec, x, context=None):
     if spec.soft_training and context is None:
         context = torch.zeros(x.shape[0], dtype=x.dtype).unsqueeze(-1)
     z, log_det = flow_backward(sd, spec, x, context, return_logdet=True)
-    return base_log_prob(spec, z) + log_det
+    return base_log_prob(spec, z, sd) + log_det
 
 
 def flow_forward(sd, spec: FlowSpec, z, context=None):

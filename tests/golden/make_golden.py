@@ -45,8 +45,12 @@ def make_base(spec, dtype=torch.float32):
         sc = spec.base_scale if spec.base_scale is not None else torch.ones(D)
         return torch.distributions.Normal(loc.to(dtype), sc.to(dtype))
     if spec.base == "radial":
-        nd = distributions.LogNormal(torch.tensor([spec.radial_norm_loc]),
-                                     torch.tensor([spec.radial_norm_scale]))
+        if spec.radial_norm == "gammamm":
+            k = int(spec.extra.get("gammamm_k", 4))
+            nd = distributions.GammaMM(torch.linspace(2.0, 6.0, k), torch.ones(k), torch.ones(k) / k)
+        else:
+            nd = distributions.LogNormal(torch.tensor([spec.radial_norm_loc]),
+                                         torch.tensor([spec.radial_norm_scale]))
         loc = spec.base_loc if spec.base_loc is not None else torch.zeros(D)
         rd = distributions.RadialDistribution(loc.clone(), nd, float(spec.radial_p))
         return rd.to(dtype)
@@ -83,6 +87,10 @@ def to_double(flow, spec):
         if isinstance(l, transforms.MaskedCoupling):
             l.mask = l.mask.double()
     b = make_base(spec, torch.float64)
+    if spec.base == "radial" and spec.radial_norm == "gammamm":
+        # (this runs under default dtype float64: the GammaMM constructor would draw its parameters afresh in fp64;
+        # the fp64 run must see the SAME parameters as the fp32 run and the stored state dict)
+        b.load_state_dict({k: v.double() for k, v in flow.base_distribution.state_dict().items()})
     if len(getattr(b, "batch_shape", ())) > 0:
         b = distributions.Independent(b, 1)
     flow.base_distribution = b
@@ -95,7 +103,7 @@ def spec_to_json(spec):
              affine_conjugation=spec.affine_conjugation, negative_slope=spec.negative_slope,
              conditioner=spec.conditioner, base=spec.base, radial_p=("inf" if spec.radial_p == math.inf else spec.radial_p),
              radial_norm=spec.radial_norm, radial_norm_loc=spec.radial_norm_loc,
-             radial_norm_scale=spec.radial_norm_scale, soft_training=spec.soft_training)
+             radial_norm_scale=spec.radial_norm_scale, soft_training=spec.soft_training, extra=dict(spec.extra))
     return json.dumps(d)
 
 
@@ -205,6 +213,10 @@ def main():
                                            radial_norm_loc=1.0, radial_norm_scale=0.5), "synth", 16)
     run_case("synth_d16_k3_hh0_radialinf", S(16, 3, [32], householder=0, base="radial", radial_p=math.inf,
                                              radial_norm_loc=0.5, radial_norm_scale=0.5), "synth", 17)
+    # radial base with the live configs' norm distribution: a Gamma mixture (gaussian_mixture.yaml:84-93), p = 1
+    run_case("synth_d16_k3_hh0_conj_radial1_gammamm", S(16, 3, [32, 32], householder=0, affine_conjugation=True,
+                                                        base="radial", radial_p=1.0, radial_norm="gammamm",
+                                                        extra={"gammamm_k": 5}), "synth", 26)
     run_case("synth_d64_k6_hh0_laplace", S(64, 6, [96, 64], householder=0), "synth", 18)
     run_case("synth_d64_k4_hh1_conj_laplace", S(64, 4, [64, 64], householder=1, affine_conjugation=True), "synth", 19)
     run_case("synth_d7_k3_soft_ctx", S(7, 3, [16, 16], householder=0, soft_training=True), "synth", 20, ctx=True)

@@ -38,7 +38,7 @@ def test_engine_ops_reproduce_golden(name, fused):
         ctx_lp = torch.zeros(a["x"].shape[0], 1)
     zl, logdet = emulator.engine_latent(eng, a["x"], ctx_lp, fused)
     assert abs(logdet + float(a["total_ladj64"])) < 1e-9 * max(1.0, abs(float(a["total_ladj64"])))
-    lp = orc.base_log_prob(spec, zl.double()) + logdet
+    lp = orc.base_log_prob(spec, zl.double(), orc.to_dtype(sd, torch.float64)) + logdet
     rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
     assert rel < 2e-5, rel
 
@@ -62,7 +62,7 @@ def test_planes_pipeline_ops_reproduce_golden(name, fmt):
     xf = emulator.engine_transform(eng, a["zin"], "forward", None, False, planes=fmt)
     assert (xf.double() - a["forward64"]).abs().max().item() < _tol(a["forward64"])
     zl, logdet = emulator.engine_latent(eng, a["x"], None, False, planes=fmt)
-    lp = orc.base_log_prob(spec, zl.double()) + logdet
+    lp = orc.base_log_prob(spec, zl.double(), orc.to_dtype(sd, torch.float64)) + logdet
     rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
     assert rel < 2e-5, rel
 

@@ -345,3 +345,24 @@ def test_composite_fallback_on_device_warns_once():
             warnings.simplefilter("error")              # second call: no further warning
             lp2 = flow.log_prob(x)
     assert torch.isfinite(lp).all() and torch.equal(lp, lp2)
+
+
+def test_radial_base_with_gammamm_norm_on_device():
+    """the base distribution of the reference's live configs (gaussian_mixture.yaml:74-93: RadialDistribution, p = 1, over
+    a GammaMM norm distribution): log_prob against the golden of the real reference comes through test_golden_parity;
+    here Flow.sample on the device -- the latent radii of the drawn samples follow the Gamma mixture"""
+    spec, sd, a = load_case("synth_d16_k3_hh0_conj_radial1_gammamm")
+    flow = build_flow(spec, sd, device=DEV)
+    before = flow.engine().launch_count
+    with torch.no_grad():
+        xs = flow.sample([4000], seed=5)
+        assert flow.engine().launch_count > before and xs.shape == (4000, 16) and torch.isfinite(xs).all()
+        z = flow.backward(xs)
+        lp = flow.log_prob(xs)
+    r = (z - flow.base_distribution.loc).abs().sum(-1)
+    ref = flow.base_distribution.norm_distribution.sample((40000,)).reshape(-1)
+    assert abs(r.mean().item() - ref.mean().item()) < 0.05 * ref.mean().item()
+    assert abs(r.std().item() - ref.std().item()) < 0.08 * ref.std().item()
+    # UDL: log_prob(x) - base.log_prob(z) is one constant
+    c = lp.double() - flow.base_distribution.log_prob(z).double()
+    assert (c - c.mean()).abs().max().item() < 1e-4 * max(1.0, abs(c.mean().item()))

@@ -1,8 +1,9 @@
 """Base distributions of the hot path -- mirror of the in-scope part of the reference's
 ``src/usflows/distributions.py``: the ``Independent`` wrapper
 ``Flow.__init__`` applies, the ``DistributionModule`` family (LogNormal / Laplace / Normal / Gamma)
-and the Lp-``RadialDistribution`` with its unit-ball sampler and UDL profile helpers.  Mixture
-bases and data generators (RotatedLaplace, Chi, *MM, GMM ...) are out of scope.
+and the Lp-``RadialDistribution`` with its unit-ball sampler and UDL profile helpers, and the mixture families
+used as radial norm distributions / data generators by the live configs (``GammaMM``, ``MixtureModel`` with
+``GMM`` / ``LogNormalMM`` / ``WeibullMM``).  ``RotatedLaplace`` / ``Chi`` are out of scope.
 
 On the device fast path the per-sample reduction over the feature axis (the only per-sample
 reduction on the whole path) runs in ``usf_base_logprob_f32``; the code here is the host-side
@@ -115,6 +116,86 @@ class Normal(_LocScale):
         if self.scale_unconstrained.dim() == 0:
             sc = sc.expand_as(self.loc)
         return {"loc": self.loc, "scale": sc}
+
+
+class GammaMM(DistributionModule):
+    """Mixture of Gamma distributions (distributions.py:674-707): the radial norm distribution of the reference's
+    live configs (experiments/synthetic/gaussian_mixture.yaml:84, tests/explib/mnist.yaml:84).  Parameters: softplus-
+    constrained concentration / rate with the COMPONENT axis first, mixture logits."""
+
+    def __init__(self, concentration: torch.Tensor, rate: torch.Tensor, mixture_weights: torch.Tensor, device: str = "cpu"):
+        super().__init__(torch.distributions.MixtureSameFamily)
+        self.concentration_unconstrained = Parameter(inv_softplus(concentration))
+        self.rate_unconstrained = Parameter(inv_softplus(rate))
+        self.mixture_logits = Parameter(mixture_weights)
+        self.to(device)
+
+    def _get_distribution_params(self):
+        concentration = softplus(self.concentration_unconstrained)
+        rate = softplus(self.rate_unconstrained)
+        order = list(range(1, concentration.dim())) + [0]          # component axis last (:690-694)
+        comp = torch.distributions.Gamma(concentration.permute(*order), rate.permute(*order))
+        mix = torch.distributions.Categorical(logits=self.mixture_logits)
+        return {"mixture_distribution": mix, "component_distribution": comp}
+
+
+class MixtureModel(DistributionModule):
+    """Mixture of ``distribution_class`` components (distributions.py:730-795): parameters named ``param_names`` with
+    ``constraints.positive`` ones stored through inv_softplus, mixture logits."""
+
+    def __init__(self, distribution_class, param_names, param_constraints, *params, mixture_weights, device="cpu"):
+        super().__init__(distribution_class=torch.distributions.MixtureSameFamily)
+        self.component_distribution_class = distribution_class
+        self.param_names = param_names
+        self.param_constraints = param_constraints
+        self.unconstrained_params = nn.ParameterList()
+        for name, param in zip(param_names, params):
+            if param_constraints.get(name) == constraints.positive:
+                self.unconstrained_params.append(nn.Parameter(inv_softplus(param)))
+            else:
+                self.unconstrained_params.append(nn.Parameter(param))
+        self.mixture_logits = nn.Parameter(mixture_weights)
+        self.to(device)
+
+    def _get_constrained_params(self):
+        out = []
+        for i, name in enumerate(self.param_names):
+            c = self.param_constraints.get(name)
+            p = self.unconstrained_params[i]
+            positive = isinstance(c, type(constraints.positive)) and c.lower_bound == 0.0       # (:762)
+            out.append(softplus(p) if positive else p)
+        return out
+
+    def _get_distribution_params(self):
+        comp = self.component_distribution_class(**dict(zip(self.param_names, self._get_constrained_params())))
+        return {"mixture_distribution": torch.distributions.Categorical(logits=self.mixture_logits),
+                "component_distribution": comp}
+
+
+class GMM(MixtureModel):
+    """Gaussian mixture with full covariances (distributions.py:798-820); the covariance is stored unconstrained."""
+
+    def __init__(self, loc, covariance_matrix, mixture_weights, device: str = "cpu"):
+        super().__init__(torch.distributions.MultivariateNormal, ["loc", "covariance_matrix"],
+                         {"loc": constraints.real, "covariance_matrix": constraints.positive_definite},
+                         loc, covariance_matrix, mixture_weights=mixture_weights, device=device)
+
+
+class LogNormalMM(MixtureModel):
+    """Mixture of log-normals (distributions.py:822-834)."""
+
+    def __init__(self, loc, scale, mixture_weights, device="cpu"):
+        super().__init__(torch.distributions.LogNormal, ["loc", "scale"], {"loc": None, "scale": constraints.positive},
+                         loc, scale, mixture_weights=mixture_weights, device=device)
+
+
+class WeibullMM(MixtureModel):
+    """Mixture of Weibulls (distributions.py:836-850)."""
+
+    def __init__(self, scale, concentration, mixture_weights, device="cpu"):
+        super().__init__(torch.distributions.Weibull, ["scale", "concentration"],
+                         {"scale": constraints.positive, "concentration": constraints.positive},
+                         scale, concentration, mixture_weights=mixture_weights, device=device)
 
 
 class UniformUnitLpBall(torch.distributions.Distribution):

@@ -32,7 +32,8 @@ class ModelSpec:
     base_loc: Optional[torch.Tensor] = None
     base_scale: Optional[torch.Tensor] = None
     radial_p: float = 1.0                 # RadialDistribution p (1, 2, inf)
-    radial_norm: str = "lognormal"        # norm_distribution family
+    radial_norm: str = "lognormal"        # norm_distribution family: "lognormal" | "gammamm" (GammaMM: parameters in the
+    #                                       state dict under base_distribution.norm_distribution.*; extra["gammamm_k"] components)
     radial_norm_loc: float = 0.0
     radial_norm_scale: float = 1.0        # (already soft-plussed) sigma
     soft_training: bool = False
@@ -155,7 +156,12 @@ def make_base(spec: ModelSpec, device="cpu"):
         sc = (spec.base_scale if spec.base_scale is not None else torch.ones(n)).to(device)
         cls = torch.distributions.Laplace if spec.base == "laplace" else torch.distributions.Normal
         return cls(loc, sc)
-    nd = D.LogNormal(torch.tensor([spec.radial_norm_loc]), torch.tensor([spec.radial_norm_scale]), device=device)
+    if spec.radial_norm == "gammamm":
+        # the norm distribution of the live configs (gaussian_mixture.yaml:84-93): its parameters travel in the state dict
+        k = int(spec.extra.get("gammamm_k", 4))
+        nd = D.GammaMM(torch.linspace(2.0, 6.0, k), torch.ones(k), torch.ones(k) / k, device=device)
+    else:
+        nd = D.LogNormal(torch.tensor([spec.radial_norm_loc]), torch.tensor([spec.radial_norm_scale]), device=device)
     loc = spec.base_loc if spec.base_loc is not None else torch.zeros(n)
     return D.RadialDistribution(loc.clone(), nd, float(spec.radial_p), device=device)
 
