@@ -196,6 +196,16 @@ int usf_variates_from_bits_f32(const uint32_t* bits, int64_t n, float* u, float*
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D,
                   const float* s, int32_t divide, usf_stream_t stream);
 
+/*
+ * BlockAffineTransform on image-shaped inputs (in_dims = [C, H, W]): the 1 x 1 convolution of
+ * transforms.py:904-962 (F.conv2d with the C x C block matrix viewed [C, C, 1, 1]) on NCHW-contiguous data,
+ *   y[b, c, p] = sum_c' W[c, c'] * (x[b, c', p] - pre_sub[c']) + bias[c],   p < P = H * W,  1 <= C <= 64
+ * forward: W = M, bias = b; backward: W = M^-1, pre_sub = b (each optional).  x != y.  HBM-bound (8 bytes per
+ * element for 2 C flops): every element is read once, coalesced along p.
+ */
+int usf_channel_affine_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W,
+                           const float* pre_sub, const float* bias, usf_stream_t stream);
+
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */
 int usf_gather_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int64_t n,

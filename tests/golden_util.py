@@ -16,7 +16,7 @@ def case_names(small_only=False):
     # (the BASELINE cfg4 fixture -- 1.28 G parameters regenerated from the seed -- is loaded by name in
     # tests/test_configs_gpu.py only: far too big for the per-case loops)
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_")) and "cfg4" not in p)
+                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_")) and "cfg4" not in p)
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -82,3 +82,27 @@ def load_udl(name):
     return dict(q=float(z["q"]), r_max=float(z["r_max"]), n_samples=int(z["n_samples"]),
                 cut=torch.from_numpy(z["cut"]), full=torch.from_numpy(z["full"]),
                 latent_radius=torch.from_numpy(z["latent_radius"]))
+
+
+def image_case_names():
+    """image-shaped flows of the real reference (tests/golden/make_golden_image.py)"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "image_*.npz")))
+
+
+def load_image_case(name, device="cpu"):
+    """(usflows_amd USFlow loaded with the reference's state dict, arrays) of an image-shaped golden case"""
+    from usflows_amd.flows import USFlow
+    from usflows_amd.networks import ConvNet2D
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    d = json.loads(str(z["spec"]))
+    dims = d["in_dims"]
+    base = torch.distributions.Laplace(torch.zeros(dims).to(device), torch.ones(dims).to(device))
+    flow = USFlow(base, dims, d["coupling_blocks"], ConvNet2D, dict(d["cond_args"]), householder=d["householder"],
+                  affine_conjugation=d["affine_conjugation"], masktype=d["masktype"])
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    res = flow.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    if device != "cpu":
+        flow = flow.to(device)
+    arrays = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("sd/") and k != "spec"}
+    return flow, arrays

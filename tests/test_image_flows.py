@@ -1,0 +1,78 @@
+"""Image-shaped flows (first slice): USFlow(in_dims=[C, H, W]) with the reference's 1x1-conv
+BlockAffineTransform, image checkerboard / channel masks and the ConvNet2D conditioner, against outputs of the REAL
+reference (tests/golden/image_*.npz).  CPU: the mirror's torch formulation; GPU: the same flows on the device, where every
+BlockAffineTransform call runs usf_channel_affine_f32."""
+import pytest
+import torch
+
+from golden_util import image_case_names, load_image_case
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double()).abs() / b.double().abs().clamp_min(1e-30)).max().item()
+
+
+def _check(flow, a, dev):
+    with torch.no_grad():
+        lp = flow.log_prob(a["x"].to(dev))
+        z = flow.backward(a["x"].to(dev))
+        xf = flow._forward(a["zin"].to(dev))
+    assert _rel(lp, a["log_prob64"]) < 1e-5 and _rel(lp, a["log_prob32"]) < 1e-5
+    s = max(1.0, a["backward64"].abs().max().item())
+    assert (z.cpu().double() - a["backward64"]).abs().max().item() < 2e-5 * s
+    s = max(1.0, a["forward64"].abs().max().item())
+    assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2e-5 * s
+    # uniformly scaling: log_prob(x) - base.log_prob(f^-1(x)) is the parameter-only constant -sum ladj; the 1x1-conv block's
+    # log-det counts once per spatial position (transforms.py:980)
+    base_lp = torch.distributions.Laplace(0.0, 1.0).log_prob(z.double().cpu()).flatten(1).sum(-1)
+    const = lp.double().cpu() - base_lp
+    assert (const + float(a["total_ladj64"])).abs().max().item() < 1e-5 * base_lp.abs().max().item()
+
+
+@pytest.mark.parametrize("name", image_case_names())
+def test_image_flow_mirror_matches_reference_cpu(name):
+    flow, a = load_image_case(name)
+    _check(flow, a, "cpu")
+    # masks as the reference builds them (flows.py:494-536)
+    m0 = flow.layers[1].mask
+    assert m0.shape == (1, *flow.in_dims) and set(m0.unique().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", image_case_names())
+def test_image_flow_on_device_matches_reference(name, monkeypatch):
+    from usflows_amd import _ext
+    calls = []
+    real = _ext.channel_affine
+    monkeypatch.setattr(_ext, "channel_affine", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+    flow, a = load_image_case(name, device="cuda:0")
+    _check(flow, a, "cuda:0")
+    n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
+    assert len(calls) == 3 * n_aff, "the 1x1-conv affine layers did not run on usf_channel_affine_f32"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,P", [(1, 1, 1), (3, 3, 64), (5, 8, 49), (7, 16, 49), (2, 17, 100), (4, 33, 1000), (2, 64, 77),
+                                   (65536, 16, 49)])
+def test_channel_affine_kernel_vs_conv2d(B, C, P):
+    """usf_channel_affine_f32 against F.conv2d with the [C, C, 1, 1] weight (transforms.py:904-962), both directions;
+    the last shape is the reference's MNIST configuration (in_dims [16, 7, 7]) at the benchmark batch"""
+    from usflows_amd import _ext
+    _ext.load()
+    g = torch.Generator().manual_seed(B + C + P)
+    x = torch.randn(B, C, P, 1, generator=g)
+    W = torch.randn(C, C, generator=g) / C ** 0.5
+    b = torch.randn(C, generator=g)
+    xd = x.to("cuda:0")
+    y = torch.full_like(xd, float("nan"))
+    _ext.channel_affine(xd, y, W.to("cuda:0"), bias=b.to("cuda:0"))
+    idx = torch.unique(torch.cat([torch.arange(min(B, 8)), torch.arange(max(B - 8, 0), B)]))
+    ref = torch.nn.functional.conv2d(x[idx].double(), W.double().view(C, C, 1, 1), b.double())
+    scale = ref.abs().max().item()
+    assert not torch.isnan(y).any()
+    assert (y[idx.to("cuda:0")].cpu().double() - ref).abs().max().item() < 2e-6 * scale
+    _ext.channel_affine(xd, y, W.to("cuda:0"), pre_sub=b.to("cuda:0"))
+    ref = torch.nn.functional.conv2d(x[idx].double() - b.double().view(1, C, 1, 1), W.double().view(C, C, 1, 1))
+    assert (y[idx.to("cuda:0")].cpu().double() - ref).abs().max().item() < 2e-6 * max(scale, ref.abs().max().item())
+    with pytest.raises(RuntimeError):
+        _ext.channel_affine(xd, xd, W.to("cuda:0"))           # in place is rejected

@@ -258,3 +258,39 @@ def test_radial_distribution_with_gammamm_norm_side_by_side():
         ref.sample([12])
     with pytest.raises(RuntimeError):
         mine.sample([12])
+
+
+@pytest.mark.parametrize("masktype,gating,norm", [("checkerboard", True, True), ("channel", False, False)])
+def test_image_shaped_usflow_side_by_side(masktype, gating, norm):
+    """USFlow(in_dims=[C, H, W]): same layer list, masks (flows.py:494-536), state-dict keys and outputs as
+    the live reference -- 1x1-conv BlockAffineTransform (transforms.py:904-962) and ConvNet2D (networks.py:405-510)"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import ref_shim
+    flows, transforms, networks, _ = ref_shim.install()
+    from usflows_amd.flows import USFlow
+    from usflows_amd.networks import ConvNet2D
+    dims = [4, 5, 6]
+    args = dict(c_in=4, c_hidden=6, num_layers=2, padding="same", normalize_layers=norm, gating=gating)
+    mk = lambda F, N: F(torch.distributions.Laplace(torch.zeros(dims), torch.ones(dims)), dims, 2, N, dict(args),
+                        householder=1, affine_conjugation=True, masktype=masktype)
+    torch.manual_seed(5)
+    ref = mk(flows.USFlow, networks.ConvNet2D)
+    mine = mk(USFlow, ConvNet2D)
+    assert list(ref.state_dict()) == list(mine.state_dict())
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    assert [type(l).__name__ for l in ref.layers] == [type(l).__name__ for l in mine.layers]
+    for lr, lm in zip(ref.layers, mine.layers):
+        if hasattr(lr, "mask"):
+            assert torch.equal(lr.mask, lm.mask)
+    x = torch.rand(7, *dims)
+    with torch.no_grad():
+        assert torch.allclose(ref.log_prob(x), mine.log_prob(x), rtol=1e-6)
+        assert torch.allclose(ref.backward(x), mine.backward(x), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(ref._forward(x), mine._forward(x), rtol=1e-5, atol=1e-6)
+        for lr, lm in zip(ref.layers, mine.layers):
+            assert abs(_val(lr.log_abs_det_jacobian(x, x)) - _val(lm.log_abs_det_jacobian(x, x))) < 1e-5
+        torch.manual_seed(1)
+        sr = ref.sample([3])
+        torch.manual_seed(1)
+        sm = mine.sample([3])
+        assert sr.shape == sm.shape == (3, *dims) and torch.allclose(sr, sm, rtol=1e-5, atol=1e-6)

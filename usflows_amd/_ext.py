@@ -125,6 +125,7 @@ SYMBOLS = {
                                         C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_variates_from_bits_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
     "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
+    "usf_channel_affine_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
     "usf_lu_prepare_f64": (C.c_int, [C.POINTER(LuPrepDesc), C.c_void_p]),
@@ -350,6 +351,14 @@ def variates_from_bits(bits, u=None, laplace=None, exponential=None):
 def scale(x, ldx, y, ldy, M, D, s, divide):
     check(load().usf_scale_f32(x.data_ptr(), ldx, y.data_ptr(), ldy, M, D, s.data_ptr(), int(divide),
                                current_stream(x.device)), "usf_scale_f32")
+
+
+def channel_affine(x, y, W, *, pre_sub=None, bias=None):
+    """usf_channel_affine_f32 on a contiguous [B, C, *spatial] fp32 tensor (1 x 1 convolution over the channel axis)"""
+    B, Cc = x.shape[0], x.shape[1]
+    P = x.numel() // max(B * Cc, 1)
+    check(load().usf_channel_affine_f32(x.data_ptr(), y.data_ptr(), B, Cc, P, W.data_ptr(), ptr(pre_sub), ptr(bias),
+                                        current_stream(x.device)), "usf_channel_affine_f32")
 
 
 def gather_cols(src, lds, dst, ldd, M, n, idx):

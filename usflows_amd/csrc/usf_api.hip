@@ -29,6 +29,8 @@ int radial_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, con
 int variates_from_bits(const uint32_t* bits, int64_t n, float* u, float* laplace, float* exponential, hipStream_t stream);
 int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s, int32_t divide,
           hipStream_t stream);
+int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* pre_sub,
+                   const float* bias, hipStream_t stream);
 int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
                 hipStream_t stream);
 
@@ -118,6 +120,11 @@ int usf_variates_from_bits_f32(const uint32_t* bits, int64_t n, float* u, float*
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s,
                   int32_t divide, usf_stream_t stream) {
   return usf::scale(x, ldx, y, ldy, M, D, s, divide, (hipStream_t)stream);
+}
+
+int usf_channel_affine_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W,
+                           const float* pre_sub, const float* bias, usf_stream_t stream) {
+  return usf::channel_affine(x, y, B, C, P, W, pre_sub, bias, (hipStream_t)stream);
 }
 
 int usf_gather_cols_f32(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n,

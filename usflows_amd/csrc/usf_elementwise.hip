@@ -364,4 +364,60 @@ int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t
   return check_launch("usf_gather_cols_f32");
 }
 
+// ------------------------------------------------------------------------------------------
+// BlockAffineTransform for image-shaped inputs: the 1 x 1 convolution
+//   y[b, c, p] = sum_c' W[c, c'] * (x[b, c', p] - pre_sub[c']) + bias[c]        (x: [B, C, P] contiguous, P = H * W)
+// (transforms.py:904-962: F.conv2d with the C x C block matrix viewed [C, C, 1, 1]).  C is the channel count (16 in
+// the reference's MNIST configs): 2 C flops per 8 bytes -- HBM-bound.  One thread per pixel: every x element is read
+// once, coalesced along p; the weights are wave-uniform (scalar loads); CMAX accumulators per thread.
+// ------------------------------------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                             int64_t P, const float* __restrict__ W,
+                                                             const float* __restrict__ pre_sub,
+                                                             const float* __restrict__ bias) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (p >= P) return;
+  const float* xb = x + b * C * P + p;
+  float acc[CMAX];
+#pragma unroll
+  for (int co = 0; co < CMAX; ++co) acc[co] = 0.f;
+  for (int ci = 0; ci < C; ++ci) {
+    float v = xb[(int64_t)ci * P];
+    if (pre_sub) v -= pre_sub[ci];
+#pragma unroll
+    for (int co = 0; co < CMAX; ++co) {
+      const float w = (co < C) ? W[co * C + ci] : 0.f;       // wave-uniform address
+      acc[co] = fmaf(w, v, acc[co]);
+    }
+  }
+  float* yb = y + b * C * P + p;
+#pragma unroll
+  for (int co = 0; co < CMAX; ++co)
+    if (co < C) yb[(int64_t)co * P] = acc[co] + (bias ? bias[co] : 0.f);
+}
+
+int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* pre_sub,
+                   const float* bias, hipStream_t stream) {
+  if (B < 0 || C <= 0 || P <= 0 || C > 64 || B > 65535 * 64LL) { set_error("usf_channel_affine_f32: bad sizes (C must be 1..64)"); return -2; }
+  if (B == 0) return 0;
+  if (!x || !y || !W) { set_error("usf_channel_affine_f32: null pointer"); return -1; }
+  if (x == y) { set_error("usf_channel_affine_f32: in-place operation is not supported"); return -2; }
+  const dim3 b(256);
+  for (int64_t b0 = 0; b0 < B; b0 += 65535) {                // grid.y limit
+    const int64_t nb = (B - b0 < 65535) ? B - b0 : 65535;
+    const dim3 g((unsigned)((P + 255) / 256), (unsigned)nb);
+    const float* xs = x + b0 * C * P;
+    float* ys = y + b0 * C * P;
+    if (C <= 8) hipLaunchKernelGGL(channel_affine_kernel<8>, g, b, 0, stream, xs, ys, (int)C, P, W, pre_sub, bias);
+    else if (C <= 16) hipLaunchKernelGGL(channel_affine_kernel<16>, g, b, 0, stream, xs, ys, (int)C, P, W, pre_sub, bias);
+    else if (C <= 32) hipLaunchKernelGGL(channel_affine_kernel<32>, g, b, 0, stream, xs, ys, (int)C, P, W, pre_sub, bias);
+    else hipLaunchKernelGGL(channel_affine_kernel<64>, g, b, 0, stream, xs, ys, (int)C, P, W, pre_sub, bias);
+    const int rc = check_launch("usf_channel_affine_f32");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 }  // namespace usf

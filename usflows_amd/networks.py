@@ -174,3 +174,69 @@ class ConvNet(nn.Module):
         Wk, bk = blocks[-1].weight.detach().double(), blocks[-1].bias.detach().double()
         widths = [self.c_hidden[0]] + self.c_hidden[:-1]
         return first, blocks[:-1], (Wf @ Wk, Wf @ bk + bf), widths
+
+
+# ---- CNN conditioners for image-shaped in_dims (networks.py:40-122, 405-510) --------------------------
+class LayerNormChannels(nn.Module):
+    """layer norm across the channel axis of [B, C, H, W] (networks.py:40-58)"""
+
+    def __init__(self, c_in, eps=1e-5):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(1, c_in, 1, 1))
+        self.beta = nn.Parameter(torch.zeros(1, c_in, 1, 1))
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(dim=1, keepdim=True)
+        var = x.var(dim=1, unbiased=False, keepdim=True)
+        return (x - mean) / torch.sqrt(var + self.eps) * self.gamma + self.beta
+
+
+class GatedConv(nn.Module):
+    """two-layer convolutional block with a sigmoid input gate: x + val * sigmoid(gate) (networks.py:61-122)"""
+
+    def __init__(self, c_in, c_hidden, kernel_size=3, padding=1, stride=1, nonlinearity=nn.ReLU(), dilation=1):
+        super().__init__()
+        assert stride == 1, "Stride > 1 cannot be used to skip connection."
+        self.net = nn.Sequential(
+            nonlinearity,
+            nn.Conv2d(c_in, c_hidden, kernel_size=kernel_size, padding=padding, stride=stride, dilation=dilation),
+            nonlinearity,
+            nn.Conv2d(c_hidden, 2 * c_in, kernel_size=1, padding=padding, stride=stride, dilation=dilation),
+        )
+
+    def forward(self, x):
+        val, gate = self.net(x).chunk(2, dim=1)
+        ret = x + val * torch.sigmoid(gate)
+        assert ret.shape == x.shape, f"Shape mismatch: {ret.shape} != {x.shape}"
+        return ret
+
+
+class ConvNet2D(nn.Module):
+    """the CNN conditioner of the reference's image configs (networks.py:405-510): Conv2d(c_in, c_hidden), then
+    ``num_layers`` x [GatedConv | Conv2d, nonlinearity, (LayerNormChannels)], then Conv2d(c_hidden, c_out).  Same
+    module tree (``nn.{i}``) and state-dict keys; runs as torch ops (MIOpen convolutions on a ROCm device)."""
+
+    def __init__(self, c_in: int, c_hidden: int = 3, c_out: int = -1, num_layers: int = 3, nonlinearity=nn.ReLU(),
+                 kernel_size: int = 3, stride: int = 1, dilation: int = 1, padding=0, normalize_layers: bool = True,
+                 gating: bool = True):
+        super().__init__()
+        if padding is None:
+            padding = kernel_size // 2
+        self.nonlinearity = nonlinearity
+        c_out = c_out if c_out > 0 else c_in
+        conv = lambda a, b: nn.Conv2d(a, b, kernel_size=kernel_size, padding=padding, stride=stride, dilation=dilation)
+        layers = [conv(c_in, c_hidden)]
+        for _ in range(num_layers):
+            if gating:
+                layers += [GatedConv(c_hidden, c_hidden, kernel_size=kernel_size, padding=padding, stride=stride,
+                                     dilation=dilation), nonlinearity]
+            else:
+                layers += [conv(c_hidden, c_hidden), nonlinearity]
+            if normalize_layers:
+                layers += [LayerNormChannels(c_hidden)]
+        layers += [conv(c_hidden, c_out)]
+        self.nn = nn.Sequential(*layers)
+
+    def forward(self, x, context=None):
+        return self.nn(x)

@@ -10,8 +10,10 @@ Dispatch rule (every layer, every call):
     formulation below, written with torch ops exactly as the math in the reference reads.
     (HIP backward kernels are SURVEY row N2, "next".)
 
-Only flat inputs (``in_dims=[D]``) are in scope: the 1x1-conv form of
-``BlockAffineTransform`` for image-shaped inputs is not built.
+Flat inputs (``in_dims=[D]``) are the accelerated hot path.  Image-shaped inputs (row N4, first
+slice): ``BlockAffineTransform`` for ``in_dims=[C, *spatial]`` -- the reference's 1x1 convolution over the channel axis
+-- runs on ``usf_channel_affine_f32`` for rank-3 ``in_dims`` on a ROCm device; masks, scale layer and CNN conditioners
+of such flows run as torch ops.
 """
 from __future__ import annotations
 
@@ -473,34 +475,73 @@ class SequentialAffineTransform(AffineTransform):
 
 
 class BlockAffineTransform(BaseTransform):
-    """y = A x + b applied to flat inputs with ``F.linear`` (transforms.py:874-1029);
-    ``n_blocks`` = prod(in_dims[1:]) = 1 for the in-scope flat case."""
+    """y = A x + b with the SAME block matrix applied at every position of the trailing axes (transforms.py:874-1029):
+    ``F.linear`` for flat ``in_dims=[D]`` (``n_blocks`` = 1), a 1x1 convolution over the channel axis for
+    ``in_dims=[C, *spatial]`` (``n_blocks`` = prod(spatial): the log-det counts once per position)."""
 
     def __init__(self, in_dims: Iterable[int], block_transform: AffineTransform, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.in_dims = in_dims
         if block_transform.dim != in_dims[0]:
             raise ValueError("block_transform dim must match input dim")
-        if len(in_dims) != 1:
-            raise NotImplementedError(
-                "usflows_amd: image-shaped in_dims (1x1-conv BlockAffineTransform) are out of scope "
-                "(SURVEY.md section 8a/N4); use flat in_dims=[D]")
         self.block_size = in_dims[0]
         self.input_rank = len(in_dims) - 1
         self.n_blocks = math.prod(in_dims[1:])
+        self.global_transform = {1: F.linear, 2: F.conv1d, 3: F.conv2d, 4: F.conv3d}[len(in_dims)]   # (:904-910)
         self.block_transform = block_transform
+        self._chan_cache = None
+
+    def _channel_prep(self, device):
+        """(M, M^-1, bias) fp32 on the device for the image-shaped path, cached per parameter version; derived by the
+        same batched fp64 prep kernels as the flat path (engine.prepare_affine_blocks)"""
+        from .engine import prepare_affine_blocks
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.block_transform.parameters())
+        if self._chan_cache is None or self._chan_cache[0] != key:
+            with torch.no_grad():
+                r = prepare_affine_blocks([self.block_transform], device)[id(self.block_transform)]
+                self._chan_cache = (key, r["M"].float().contiguous(), r["Minv"].float().contiguous(),
+                                    r["b"].float().contiguous())
+        return self._chan_cache[1:]
+
+    def _channel_hip(self, x, forward: bool):
+        """usf_channel_affine_f32: the 1x1 convolution on NCHW data (row N4); HBM-bound"""
+        from . import _ext
+        M, Minv, b = self._channel_prep(x.device)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        if forward:
+            _ext.channel_affine(x, y, M, bias=b)
+        else:
+            _ext.channel_affine(x, y, Minv, pre_sub=b)
+        return y
+
+    def _use_channel_hip(self, x) -> bool:
+        return (self.input_rank >= 1 and x.dim() == self.input_rank + 2 and x.shape[1] == self.block_size
+                and self.block_size <= 64 and use_hip(self, x))
 
     def forward(self, x, context=None):
-        if x.dim() == 2 and use_hip(self, x):
-            return self._hip("forward", x)
-        return F.linear(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device))
+        if self.input_rank == 0:
+            if x.dim() == 2 and use_hip(self, x):
+                return self._hip("forward", x)
+            return F.linear(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device))
+        if self._use_channel_hip(x):
+            return self._channel_hip(x, True)
+        w = self.block_transform.matrix().view(self.block_size, self.block_size, *([1] * self.input_rank)).to(x.device)
+        return self.global_transform(x, w, self.block_transform.bias().to(x.device))
 
     def backward(self, y, context=None):
-        if y.dim() == 2 and use_hip(self, y):
-            return self._hip("backward", y)
-        w = self.block_transform.inverse_matrix().to(y.device)
-        b = self.block_transform.bias().to(y.device)
-        return F.linear(y - b, w)
+        if self.input_rank == 0:
+            if y.dim() == 2 and use_hip(self, y):
+                return self._hip("backward", y)
+            w = self.block_transform.inverse_matrix().to(y.device)
+            b = self.block_transform.bias().to(y.device)
+            return F.linear(y - b, w)
+        if self._use_channel_hip(y):
+            return self._channel_hip(y, False)
+        w = self.block_transform.inverse_matrix().view(self.block_size, self.block_size,
+                                                       *([1] * self.input_rank)).to(y.device)
+        b = self.block_transform.bias().view(self.block_size, *([1] * self.input_rank)).to(y.device)
+        return self.global_transform(y - b, w)
 
     def log_abs_det_jacobian(self, x, y, context=None):
         return self.block_transform.log_abs_det_jacobian(x, y, context) * self.n_blocks
