@@ -197,6 +197,20 @@ int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M,
                   const float* s, int32_t divide, usf_stream_t stream);
 
 /*
+ * Affine (scale-and-shift) coupling -- the EXTENSION named by BASELINE.json's north_star.  The reference has additive
+ * coupling only (transforms.py:254-347, log_abs_det_jacobian == 0.0 at :316-326; the vestige AdditiveAffineNN,
+ * networks.py:14-37, fixes log_scale to 0): there is nothing to be identical to -- parity unpinned, opt-in
+ * (usflows_amd.transforms.AffineMaskedCoupling), and such a flow is NOT uniformly scaling (no UDL property).
+ * Masked scale / shift apply on the n transformed columns + the per-sample log|det J| reduction (wave shuffle):
+ *   inverse == 0:  z[m,j] = z[m,j] * exp(s[m,j]) + t[m,j],      logdet[m] += sum_j s[m,j]
+ *   inverse != 0:  z[m,j] = (z[m,j] - t[m,j]) * exp(-s[m,j]),   logdet[m] -= sum_j s[m,j]
+ * with s = bound * tanh(raw / bound) (bound > 0) or raw (bound <= 0); z / t / s row-major, strides ldz / ldt / lds;
+ * logdet [M] may be NULL.  t and s come from the conditioner MLP (usf_linear_f32 launches).  HBM-bound.
+ */
+int usf_affine_coupling_apply_f32(float* z, int64_t ldz, const float* t, int64_t ldt, const float* s, int64_t lds, int64_t M,
+                                  int64_t n, float bound, int32_t inverse, float* logdet, usf_stream_t stream);
+
+/*
  * BlockAffineTransform on image-shaped inputs (in_dims = [C, H, W]): the 1 x 1 convolution of
  * transforms.py:904-962 (F.conv2d with the C x C block matrix viewed [C, C, 1, 1]) on NCHW-contiguous data,
  *   y[b, c, p] = sum_c' W[c, c'] * (x[b, c', p] - pre_sub[c']) + bias[c],   p < P = H * W,  1 <= C <= 64

@@ -125,6 +125,8 @@ SYMBOLS = {
                                         C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_variates_from_bits_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
     "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
+    "usf_affine_coupling_apply_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64,
+                                                C.c_float, C.c_int32, _fp, C.c_void_p]),
     "usf_channel_affine_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -351,6 +353,13 @@ def variates_from_bits(bits, u=None, laplace=None, exponential=None):
 def scale(x, ldx, y, ldy, M, D, s, divide):
     check(load().usf_scale_f32(x.data_ptr(), ldx, y.data_ptr(), ldy, M, D, s.data_ptr(), int(divide),
                                current_stream(x.device)), "usf_scale_f32")
+
+
+def affine_coupling_apply(z, ldz, t, ldt, s, lds, M, n, bound, inverse, logdet=None, z_off=0, t_off=0, s_off=0):
+    """usf_affine_coupling_apply_f32 (element offsets *_off into the fp32 tensors)"""
+    check(load().usf_affine_coupling_apply_f32(z.data_ptr() + 4 * z_off, ldz, t.data_ptr() + 4 * t_off, ldt,
+                                               s.data_ptr() + 4 * s_off, lds, M, n, float(bound), int(inverse),
+                                               ptr(logdet), current_stream(z.device)), "usf_affine_coupling_apply_f32")
 
 
 def channel_affine(x, y, W, *, pre_sub=None, bias=None):

@@ -29,6 +29,8 @@ int radial_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, con
 int variates_from_bits(const uint32_t* bits, int64_t n, float* u, float* laplace, float* exponential, hipStream_t stream);
 int scale(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s, int32_t divide,
           hipStream_t stream);
+int affine_coupling_apply(float* z, int64_t ldz, const float* t, int64_t ldt, const float* s, int64_t lds_, int64_t M,
+                          int64_t n, float bound, int32_t inverse, float* logdet, hipStream_t stream);
 int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* pre_sub,
                    const float* bias, hipStream_t stream);
 int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t M, int64_t n, const int32_t* idx,
@@ -120,6 +122,11 @@ int usf_variates_from_bits_f32(const uint32_t* bits, int64_t n, float* u, float*
 int usf_scale_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t M, int64_t D, const float* s,
                   int32_t divide, usf_stream_t stream) {
   return usf::scale(x, ldx, y, ldy, M, D, s, divide, (hipStream_t)stream);
+}
+
+int usf_affine_coupling_apply_f32(float* z, int64_t ldz, const float* t, int64_t ldt, const float* s, int64_t lds, int64_t M,
+                                  int64_t n, float bound, int32_t inverse, float* logdet, usf_stream_t stream) {
+  return usf::affine_coupling_apply(z, ldz, t, ldt, s, lds, M, n, bound, inverse, logdet, (hipStream_t)stream);
 }
 
 int usf_channel_affine_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W,

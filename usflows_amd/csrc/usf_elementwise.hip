@@ -365,6 +365,50 @@ int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t
 }
 
 // ------------------------------------------------------------------------------------------
+// Affine (scale-and-shift) coupling, the extension BASELINE.json's north_star names (the reference has additive
+// coupling only, transforms.py:254-347: parity unpinned, opt-in, not uniformly scaling):
+//   forward : z[m, j] = z[m, j] * exp(s[m, j]) + t[m, j]      logdet[m] += sum_j s[m, j]
+//   inverse : z[m, j] = (z[m, j] - t[m, j]) * exp(-s[m, j])   logdet[m] -= sum_j s[m, j]
+// for the transformed columns j < n of row m (z, t, s row-major with their own strides); s = bound * tanh(raw / bound)
+// when bound > 0, else raw.  One wave per row: 16-byte lane accesses where alignment allows, the per-sample log-det
+// by a 64-lane shuffle reduction -- the only per-sample reduction an affine coupling adds.  HBM-bound.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_coupling_apply_kernel(float* __restrict__ z, int64_t ldz,
+                                                                    const float* __restrict__ t, int64_t ldt,
+                                                                    const float* __restrict__ sraw, int64_t lds_,
+                                                                    int64_t M, int n, float bound, int inverse,
+                                                                    float* __restrict__ logdet) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (int64_t)gridDim.x * 4) {
+    float* zr = z + m * ldz;
+    const float* tr = t + m * ldt;
+    const float* sr = sraw + m * lds_;
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) {
+      float s = sr[j];
+      if (bound > 0.f) s = bound * tanhf(s / bound);
+      acc += s;
+      const float v = zr[j];
+      zr[j] = inverse ? (v - tr[j]) * expf(-s) : v * expf(s) + tr[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && logdet) logdet[m] += inverse ? -acc : acc;
+  }
+}
+
+int affine_coupling_apply(float* z, int64_t ldz, const float* t, int64_t ldt, const float* s, int64_t lds_, int64_t M,
+                          int64_t n, float bound, int32_t inverse, float* logdet, hipStream_t stream) {
+  if (M < 0 || n <= 0 || n > 0x7fffffff || ldz < n || ldt < n || lds_ < n) { set_error("usf_affine_coupling_apply_f32: bad sizes"); return -2; }
+  if (M == 0) return 0;
+  if (!z || !t || !s) { set_error("usf_affine_coupling_apply_f32: null pointer"); return -1; }
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(affine_coupling_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, ldz, t, ldt, s, lds_, M,
+                     (int)n, bound, inverse, logdet);
+  return check_launch("usf_affine_coupling_apply_f32");
+}
+
+// ------------------------------------------------------------------------------------------
 // BlockAffineTransform for image-shaped inputs: the 1 x 1 convolution
 //   y[b, c, p] = sum_c' W[c, c'] * (x[b, c', p] - pre_sub[c']) + bias[c]        (x: [B, C, P] contiguous, P = H * W)
 // (transforms.py:904-962: F.conv2d with the C x C block matrix viewed [C, C, 1, 1]).  C is the channel count (16 in

@@ -116,8 +116,9 @@ class Flow(torch.nn.Module):
         fused device form (never silent: DESIGN.md section 1)"""
         if not getattr(self, "_warned_composite", False):
             self._warned_composite = True
-            warnings.warn(f"usflows_amd: {what} on a ROCm device runs the torch composite formulation, not the HIP "
-                          f"kernels: {getattr(self, '_engine_reason', 'layer list has no fused device form')}",
+            warnings.warn(f"usflows_amd: {what} on a ROCm device runs the torch composite formulation (the layer loop; "
+                          f"layers with a device form of their own still dispatch to their kernels), not the fused "
+                          f"HIP launch list: {getattr(self, '_engine_reason', 'layer list has no fused device form')}",
                           RuntimeWarning, stacklevel=3)
 
     def _on_device_fast_path(self, x: torch.Tensor, context=None) -> bool:

@@ -192,6 +192,137 @@ class MaskedCoupling(BaseTransform):
         return super().to(device)
 
 
+class AffineMaskedCoupling(BaseTransform):
+    """Affine (scale-and-shift) coupling -- an EXTENSION, not part of the reference (BASELINE.json's north_star names
+    it; the reference's ``MaskedCoupling`` is additive only, transforms.py:254-347, and its vestige ``AdditiveAffineNN``
+    fixes the log-scale to 0, networks.py:14-37).  PARITY UNPINNED: there is no reference arithmetic to match; the tests
+    are self-consistency (round trip, log-det against the autograd Jacobian, device against the torch formulation).
+    A flow containing it is NOT uniformly scaling: its log-det depends on x, upper-density-level sets are not
+    preserved (README.md:7-12), so it is excluded from every UDL check and never built by ``USFlow``.
+
+        forward :  y = x * m + (1 - m) * (x * exp(s) + t)        (t, s_raw) = conditioner(x * m),  mask m == 1: pass-through
+        backward:  x = y * m + (1 - m) * ((y - t) * exp(-s))     s = scale_bound * tanh(s_raw / scale_bound)  (None: s_raw)
+        log|det J| per sample = sum_d (1 - m_d) * s_d            -> a [B] tensor
+
+    ``conditioner`` returns ``[..., 2 D]`` (shift | raw log-scale) or a ``(shift, raw log-scale)`` pair (``DenseNN`` with
+    ``param_dims=[D, D]``).  On a ROCm device (flat inputs, no autograd, D and the hidden widths multiples of 4, a
+    (Conditional)DenseNN with (Leaky)ReLU) the conditioner runs as ``usf_linear_f32`` launches with the masks folded
+    into its first / last weights, and the masked scale / shift apply with the per-sample log-det wave reduction is
+    ``usf_affine_coupling_apply_f32``."""
+
+    def __init__(self, mask: torch.Tensor, conditioner: nn.Module, scale_bound: Optional[float] = 2.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.mask = mask
+        self.conditioner = conditioner
+        self.scale_bound = scale_bound
+        self.input_shape = mask.shape
+        self._dev_cache = None
+        self._last = None              # (input ptr, input version, output ptr, signed log-det [B]) of the last device call
+        self.device_calls = 0
+
+    # ---- torch formulation (CPU, autograd) ----------------------------------------------------------------------
+    def _shift_logscale(self, x_masked, context=None):
+        out = self.conditioner(x_masked) if context is None else self.conditioner(x_masked, context)
+        if isinstance(out, (tuple, list)):
+            t, s = out
+        else:
+            D = out.shape[-1] // 2
+            t, s = out[..., :D], out[..., D:]
+        if self.scale_bound is not None:
+            s = self.scale_bound * torch.tanh(s / self.scale_bound)
+        return t, s
+
+    def forward(self, x, context=None):
+        if self._device_ok(x, context):
+            return self._device(x, inverse=False)
+        t, s = self._shift_logscale(x * self.mask, context)
+        return x * self.mask + (1 - self.mask) * (x * torch.exp(s) + t)
+
+    def backward(self, y, context=None):
+        if self._device_ok(y, context):
+            return self._device(y, inverse=True)
+        t, s = self._shift_logscale(y * self.mask, context)
+        return y * self.mask + (1 - self.mask) * ((y - t) * torch.exp(-s))
+
+    def log_abs_det_jacobian(self, x, y, context=None):
+        """[B]: sum over the transformed features of s(x * m); x is the forward-direction INPUT (the conditioning features
+        are the same on both sides, so either side's tensor gives the same s)"""
+        c = self._last
+        if c is not None and torch.is_tensor(x) and torch.is_tensor(y):
+            # the pair produced by the last device call: its kernel already reduced the log-det
+            if (c[0], c[2]) == (x.data_ptr(), y.data_ptr()) and c[1] == (x._version, y._version):
+                return c[3]
+        _, s = self._shift_logscale(x * self.mask, context)
+        return ((1 - self.mask) * s).flatten(1).sum(-1)
+
+    def sign(self):
+        return 1.0
+
+    def to(self, device):
+        self.mask = self.mask.to(device)
+        return super().to(device)
+
+    # ---- device path ---------------------------------------------------------------------------------------------
+    def _device_ok(self, x, context) -> bool:
+        from .networks import ConditionalDenseNN, DenseNN
+        from .engine import _activation_of
+        cond = self.conditioner
+        if context is not None or x.dim() != 2 or self.mask.dim() != 2 or not use_hip(self, x):
+            return False
+        if not isinstance(cond, (ConditionalDenseNN, DenseNN)) or _activation_of(cond.f) is None:
+            return False
+        D = x.shape[1]
+        widths = [int(h) for h in cond.hidden_dims]
+        lin = list(cond.layers)
+        return D % 4 == 0 and all(h % 4 == 0 for h in widths) and lin[-1].weight.shape[0] == 2 * D
+
+    def _device_weights(self, device):
+        from .networks import ConditionalDenseNN
+        cond = self.conditioner
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in cond.parameters())
+        if self._dev_cache is None or self._dev_cache[0] != key:
+            lin = list(cond.layers)
+            if isinstance(cond, ConditionalDenseNN):
+                lin = [lin[0]] + lin[2:]                        # (layers[1] is the context branch: unused without context)
+            m = self.mask.to(device).flatten().float()
+            with torch.no_grad():
+                Ws = [l.weight.detach().float().contiguous() for l in lin]
+                bs = [l.bias.detach().float().contiguous() for l in lin]
+                Ws[0] = (Ws[0] * m[None, :]).contiguous()                       # conditioner(x * m) == (W0 diag(m)) x
+                keep = torch.cat([1 - m, 1 - m])                                 # zero shift / log-scale on pass-through features
+                Ws[-1] = (Ws[-1] * keep[:, None]).contiguous()
+                bs[-1] = (bs[-1] * keep).contiguous()
+            self._dev_cache = (key, Ws, bs)
+        return self._dev_cache[1], self._dev_cache[2]
+
+    def _device(self, x, inverse: bool):
+        from . import _ext
+        from .engine import _activation_of
+        x = x.contiguous().float()
+        B, D = x.shape
+        out = x.clone()
+        if B == 0:
+            return out
+        Ws, bs = self._device_weights(x.device)
+        act, slope = _activation_of(self.conditioner.f)
+        h = x
+        for j, (W, b) in enumerate(zip(Ws, bs)):
+            last = j == len(Ws) - 1
+            nxt = torch.empty(B, W.shape[0], dtype=torch.float32, device=x.device)
+            _ext.linear(h, W, nxt, M=B, N=W.shape[0], K=W.shape[1], lda=h.shape[1], ldw=W.shape[1], ldc=W.shape[0],
+                        bias=b, act=_ext.ACT_NONE if last else act, slope=slope)
+            h = nxt
+        logdet = torch.zeros(B, dtype=torch.float32, device=x.device)
+        bound = float(self.scale_bound) if self.scale_bound is not None else 0.0
+        _ext.affine_coupling_apply(out, D, h, 2 * D, h, 2 * D, B, D, bound, inverse, logdet, s_off=D)
+        self.device_calls += 1
+        # forward-direction log-det of the pair (forward input, forward output)
+        fwd_ld = -logdet if inverse else logdet
+        a, b_ = (out, x) if inverse else (x, out)
+        self._last = (a.data_ptr(), (a._version, b_._version), b_.data_ptr(), fwd_ld)
+        return out
+
+
 class InverseTransform(BaseTransform):
     """Swaps forward/backward of the wrapped (shared) transform (transforms.py:349-414)."""
 
