@@ -39,9 +39,9 @@ def test_round_trip_and_logdet_vs_autograd_jacobian(cond, bound):
     assert ld.std().item() > 1e-3                                         # data-dependent: NOT uniformly scaling
 
 
-def _flow(D, seed):
+def _flow(D, seed, device="cpu"):
     torch.manual_seed(seed)
-    base = torch.distributions.Laplace(torch.zeros(D), torch.ones(D))
+    base = torch.distributions.Laplace(torch.zeros(D, device=device), torch.ones(D, device=device))
     mask = USFlow.create_checkerboard_mask([D])
     layers = []
     for k in range(3):
@@ -99,9 +99,7 @@ def test_device_path_matches_torch_formulation(cond, bound, B):
 def test_flow_with_affine_couplings_on_device():
     import warnings
     D = 16
-    flow_cpu, flow_dev = _flow(D, 11), _flow(D, 11)
-    flow_dev.base_distribution = torch.distributions.Independent(
-        torch.distributions.Laplace(torch.zeros(D, device="cuda:0"), torch.ones(D, device="cuda:0")), 1)
+    flow_cpu, flow_dev = _flow(D, 11), _flow(D, 11, "cuda:0")
     flow_dev = flow_dev.to("cuda:0")
     x = torch.rand(300, D, generator=torch.Generator().manual_seed(3))
     with torch.no_grad():

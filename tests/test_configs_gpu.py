@@ -141,7 +141,8 @@ def test_cfg5_per_rank_sample(cfg2, mode):
     base_lp = torch.distributions.Laplace(0.0, 1.0).log_prob(zb.double()).sum(-1)
     const = lp.double() - base_lp
     assert (const + ladj).abs().max().item() < 1e-5 * base_lp.abs().max().item()
-    assert (zb - z).abs().max().item() < 5e-4                   # f^-1(f(z)) == z
+    # f^-1(f(z)) == z through 2 x 65 layers (fp16x2 planes carry 22 instead of 24 significant bits per operand: 4x the slack)
+    assert (zb - z).abs().max().item() < (2e-3 if mode == "f16x2" else 5e-4)
     # noise statistics of the rank's substream: Laplace(0,1) -> E|z| = 1, no +-inf (u01 reached 1.0)
     assert abs(z.abs().mean().item() - 1.0) < 5e-3 and z.abs().max().item() < 40.0
     # the rank's rows are rows [rank*n, (rank+1)*n) of a single-process draw
@@ -186,7 +187,7 @@ def test_cfg4_full_size(cfg4, mode):
     got = lp[idx.to(DEV)]
     assert _rel(got, a["log_prob64"]) < RTOL
     assert _rel(got, a["log_prob32"]) < 2 * RTOL        # (the reference's own fp32-vs-fp64 gap at this depth: see fixture log)
-    z = _properties(flow, xd, lp, ladj, rt_tol=1e-3)
+    z = _properties(flow, xd, lp, ladj, rt_tol=4e-3 if mode == "f16x2" else 1e-3)
     s = max(1.0, a["backward64"].abs().max().item())
     assert (z[idx.to(DEV)].cpu().double() - a["backward64"]).abs().max().item() < 2e-5 * s
     with torch.no_grad():

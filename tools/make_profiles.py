@@ -71,7 +71,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out, "pmc_" + ctr)
     run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "2",
-         "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
+         "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-fast-mode"])
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(fn)):
             k = row["Kernel_Name"]
@@ -139,9 +139,77 @@ def mfma_util(csv_path, out_path):
 d = os.path.join(out, "pmc_mfma")
 run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
      "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "2",
-     "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
+     "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-fast-mode"])
 for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     mfma_util(fn, os.path.join(out, f"{tag}_mfma_util.json"))
+
+# 3c. the opt-in fp16x2 mode (planes pipeline): bench line, kernel stats, matrix-pipe utilisation, HBM traffic
+r = run(["python3", "bench.py", "--gemm", "f16x2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+open(os.path.join(out, f"{tag}_bench_f16x2.json"), "w").write(last_json_line(r.stdout) + "\n")
+d = os.path.join(out, "ktrace_f16x2")
+run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--gemm", "f16x2",
+     "--no-cpu-baseline"])
+stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+rows = list(csv.DictReader(open(stats[0])))
+with open(os.path.join(out, f"{tag}_bench_f16x2_kernel_stats.md"), "w") as f:
+    f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --gemm f16x2 --no-cpu-baseline`\n\n"
+            "(opt-in fast mode: planes pipeline with fp16x2 planes; per pass 1 pack + 32 affine GEMMs on planes + 32 x 3\n"
+            "conditioner GEMMs on planes + the last affine with fp32 output + 1 tail)\n\n"
+            "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
+    for row in rows[:10]:
+        name = row["Name"]
+        name = name if len(name) < 110 else name[:107] + "..."
+        f.write(f"| `{name}` | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |\n")
+d = os.path.join(out, "pmc_mfma_f16x2")
+run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+     "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--gemm", "f16x2",
+     "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
+for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    mfma_util(fn, os.path.join(out, f"{tag}_mfma_util_f16x2.json"))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = os.path.join(out, "pmc_f16x2_" + ctr)
+    run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--gemm", "f16x2", "--steps",
+         "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
+    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(fn)):
+            k = row["Kernel_Name"]
+            if "usf::" not in k:
+                continue
+            k = k[k.index("usf::") + 5:]
+            k = k[: k.index("(")] if "(" in k else k
+            agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+kern = {}
+for k, dct in sorted(agg.items()):
+    f_ = sum(dct["FETCH_SIZE"]) / max(1, len(dct["FETCH_SIZE"]))
+    w_ = sum(dct["WRITE_SIZE"]) / max(1, len(dct["WRITE_SIZE"]))
+    kern[k] = {"FETCH_SIZE_KB": round(f_, 1), "WRITE_SIZE_KB": round(w_, 1), "dispatches": len(dct["FETCH_SIZE"]),
+               "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
+json.dump({
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --gemm f16x2 --steps 2 --warmup 1 "
+              "--no-cpu-baseline --no-kernel-timing`, MI355X; tools/make_profiles.py",
+    "units": "as in the bf16x3 file; gemm_planes_kernel<2, 5, false> entries average over the affine launches (800 -> 800: "
+             "algorithmic 2 x 65536 x 800 x 4 B = 419 MB) AND the conditioner's last layer (256 -> 416 with the in-place residual)",
+    "kernels": kern}, open(os.path.join(out, f"{tag}_hbm_traffic_f16x2.json"), "w"), indent=1)
+
+# 3d. what the chip sustains on the split-precision instruction mix (register / LDS operand loops; tools/exp_mfma_peak.hip)
+exe = os.path.join(ROOT, "tools", "exp_mfma_peak")
+if os.path.exists(exe):
+    r = run([exe, "400"])
+    json.dump({"source": "tools/exp_mfma_peak 400 (hipcc -O3 --offload-arch=gfx950 tools/exp_mfma_peak.hip), MI355X: register-only "
+                         "loops of the bf16x3 instruction mix at the occupancy of the GEMM kernels; TF = bf16 MFMA flops, "
+                         "fp32-equiv = / 6; the clock column is s_memtime / s_memrealtime x 100 MHz and reads ~14 % high on "
+                         "this part (the real-time counter ticks slower than 100 MHz: 2054 TF at 100 % pipe occupancy is "
+                         "1.97 GHz)",
+               "lines": r.stdout.strip().splitlines()}, open(os.path.join(out, f"{tag}_mfma_peak.json"), "w"), indent=1)
+
+# 3e. the other BASELINE configurations on one GPU
+lines = []
+for cfg, extra in (("cfg3", ["--steps", "5", "--warmup", "2"]), ("cfg4", ["--steps", "3", "--warmup", "1"]),
+                   ("cfg5", ["--steps", "3", "--warmup", "1"])):
+    r = run(["python3", "bench.py", "--config", cfg, "--no-cpu-baseline"] + extra)
+    lines.append(last_json_line(r.stdout))
+open(os.path.join(out, f"{tag}_bench_other_configs.jsonl"), "w").write("\n".join(lines) + "\n")
 
 # 4. training step and parameter prep (N1): bench lines + kernel stats of the training run
 lines = []
