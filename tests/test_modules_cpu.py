@@ -70,8 +70,11 @@ def test_constructor_errors():
         T.BlockAffineTransform([5], T.LUTransform(4))
     with pytest.raises(ValueError):
         T.SequentialAffineTransform([T.LUTransform(4), T.LUTransform(5)])
-    with pytest.raises(NotImplementedError):
-        T.BlockAffineTransform([4, 2, 2], T.LUTransform(4))
+    # image-shaped in_dims: the 1x1-conv form, n_blocks = prod(spatial) (transforms.py:904-911)
+    blk = T.BlockAffineTransform([4, 2, 3], T.LUTransform(4))
+    assert blk.n_blocks == 6 and blk.input_rank == 2 and blk.global_transform is torch.nn.functional.conv2d
+    with pytest.raises(KeyError):
+        T.BlockAffineTransform([4, 2, 2, 2, 2], T.LUTransform(4))        # rank 5: no conv form, as in the reference
 
 
 def test_reference_known_answer_tests_on_product_layers():
