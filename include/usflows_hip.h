@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 9
+#define USF_ABI_VERSION 10
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -298,6 +298,32 @@ int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream);
 int usf_gemm_planes_variant(const usf_gemm_planes_desc* d);
 
 /*
+ * Fused additive coupling layer on a planes buffer: MaskedCoupling.forward / backward (transforms.py:277-306) with its
+ * whole conditioner MLP (networks.py:739-751) in ONE launch, in place on z:
+ *   z[:, transformed blocks] += sign * (W_out act(W_h act(W_in z[:, conditioning blocks] + b_in) + b_h) + b_out)
+ * z: planes buffer with z_nkb blocks per panel; the conditioning features are blocks kb_p0 .. kb_p0 + nk_p - 1, the
+ * transformed ones kb_t0 .. kb_t0 + nk_t - 1 (the ranges may share a straddling block: weights / rows of the other
+ * set's features are zero, those values are rewritten unchanged).  Weight planes (format as z; usf_pack_weight_f32):
+ *   W_in  [256, ldw_in >= 32 nk_p]   K axis = slots of the conditioning blocks;  b_in [256]
+ *   W_hid[i] [256, ldw_hid >= 256]   K axis = slots of the previous hidden layer (n_hidden - 1 of them);  b_hid[i] [256]
+ *   W_out [32 nk_t, ldw_out >= 256]  rows = logical positions of the transformed blocks;  b_out [32 nk_t]
+ * hidden widths are padded to hidden_padded = 256 with zero rows / columns (1 <= n_hidden <= 3).  Same arithmetic as
+ * usf_gemm_planes_bf16x3 applied layer by layer; hidden activations never leave the registers.  range_flag: as there.
+ */
+typedef struct usf_coupling_planes_desc {
+  void* z; int64_t z_nkb; int64_t M;
+  int64_t kb_p0, nk_p, kb_t0, nk_t;
+  int32_t n_hidden, hidden_padded;
+  const void* W_in; int64_t ldw_in, w_in_plane; const float* b_in;
+  const void* W_hid[2]; const float* b_hid[2]; int64_t ldw_hid, w_hid_plane;
+  const void* W_out; int64_t ldw_out, w_out_plane; const float* b_out;
+  float sign, slope;
+  int32_t act, format;
+  int32_t* range_flag;
+} usf_coupling_planes_desc;
+int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream);
+
+/*
  * Run a prebuilt list of ops with ONE call (the whole flow: ~2K+2 launches). op.kind selects the
  * member of the union; pointers inside may be patched by the caller between calls.
  */
@@ -305,6 +331,7 @@ int usf_gemm_planes_variant(const usf_gemm_planes_desc* d);
 #define USF_OP_COUPLING 2
 #define USF_OP_PACK_PLANES 5
 #define USF_OP_GEMM_PLANES 6
+#define USF_OP_COUPLING_PLANES 7
 typedef struct usf_op {
   int32_t kind;
   int32_t reserved;
@@ -313,6 +340,7 @@ typedef struct usf_op {
     usf_coupling_desc coupling;
     usf_pack_planes_desc pack_planes;
     usf_gemm_planes_desc gemm_planes;
+    usf_coupling_planes_desc coupling_planes;
   } u;
 } usf_op;
 
@@ -428,7 +456,7 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;
-                                           usf_pack_planes_desc|usf_gemm_planes_desc for 5|6: binding self-check */
+                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc for 5|6|7: binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */
 

@@ -179,6 +179,33 @@ def emulate_gemm_planes(d, pm: PtrMap, dtype=torch.float32):
     planes_encode(Cv, v.to(torch.float32), d.c_kb0)
 
 
+def emulate_coupling_planes(d, pm: PtrMap, dtype=torch.float32):
+    M, fmt = d.M, d.format
+    npl = 2 if fmt == 1 else 3
+    npan = -(-M // 16)
+    zv = planes_view(pm, d.z, npan, d.z_nkb, fmt)
+    Z = planes_decode(zv, M)
+
+    def weights(ptr, rows, ld, plane, K):
+        Wp = pm.view(ptr, npl, rows * ld, plane).view(npl, rows, ld)
+        W = Wp[0].float() + Wp[1].float()
+        if npl == 3:
+            W = W + Wp[2].float()
+        slot = torch.tensor([32 * (c // 32) + _SLOT_OF_FEATURE[c % 32] for c in range(K)])
+        return W[:, :K][:, slot]
+
+    act = (lambda v: torch.where(v > 0, v, v * d.slope)) if d.act == _ext.ACT_LEAKY_RELU else (lambda v: v)
+    A = Z[:, 32 * d.kb_p0: 32 * (d.kb_p0 + d.nk_p)].to(dtype)
+    h = act(A @ weights(d.W_in, 256, d.ldw_in, d.w_in_plane, 32 * d.nk_p).to(dtype).t() + pm.vec(d.b_in, 256).to(dtype))
+    for j in range(d.n_hidden - 1):
+        h = act(h @ weights(d.W_hid[j], 256, d.ldw_hid, d.w_hid_plane, 256).to(dtype).t() + pm.vec(d.b_hid[j], 256).to(dtype))
+    out = h @ weights(d.W_out, 32 * d.nk_t, d.ldw_out, d.w_out_plane, 256).to(dtype).t() + pm.vec(d.b_out, 32 * d.nk_t).to(dtype)
+    v = Z[:, 32 * d.kb_t0: 32 * (d.kb_t0 + d.nk_t)].to(dtype) + d.sign * out
+    if fmt == 1 and d.range_flag and not bool((v.abs() < 65000.0).all() and (h.abs() < 65000.0).all()):
+        pm.view(d.range_flag, 1, 1, 1, dtype=torch.int32)[0, 0] = 1
+    planes_encode(zv, v.to(torch.float32), d.kb_t0)
+
+
 def _gather(src, dst, idx):
     out = torch.zeros(src.shape[0], idx.numel())
     ok = idx >= 0
@@ -233,6 +260,8 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
                 emulate_pack_planes(op.u.pack_planes, pm, dtype)
             elif op.kind == _ext.OP_GEMM_PLANES:
                 emulate_gemm_planes(op.u.gemm_planes, pm, dtype)
+            elif op.kind == _ext.OP_COUPLING_PLANES:
+                emulate_coupling_planes(op.u.coupling_planes, pm, dtype)
             else:
                 emulate_coupling(op.u.coupling, pm, dtype)
             pos += 1

@@ -43,9 +43,10 @@ def test_engine_ops_reproduce_golden(name, fused):
     assert rel < 2e-5, rel
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", SMALL)
-def test_planes_pipeline_ops_reproduce_golden(name, fmt):
+def test_planes_pipeline_ops_reproduce_golden(name, fmt, fused):
     """the planes pipeline's launch list (usf_pack_planes_f32 + usf_gemm_planes_bf16x3 ops: block / slot permutation of
     the activation planes, weight images in slot order, K-range of the conditioning blocks, in-place residual on the
     transformed blocks) interpreted on CPU against the reference's outputs"""
@@ -56,12 +57,16 @@ def test_planes_pipeline_ops_reproduce_golden(name, fmt):
         eng.use_planes, eng.planes_min_rows = True, 0
         assert not eng._planes_ok("backward", 48, True, False)           # context: the fp32 path serves it
         return
-    z = emulator.engine_transform(eng, a["x"], "backward", None, False, planes=fmt)
+    z = emulator.engine_transform(eng, a["x"], "backward", None, fused, planes=fmt)
     assert any(p.get("planes") and p["planes_fmt"] == (1 if fmt == "f16x2" else 0) for p in eng._plans.values())
+    if fused and not (fmt == "bf16x3" and len(spec.hidden_dims) == 3):
+        from usflows_amd import _ext
+        assert any(p["arr"][j].kind == _ext.OP_COUPLING_PLANES for p in eng._plans.values() if p.get("planes")
+                   for j in range(p["n"])), "fused coupling on planes was not selected"
     assert (z.double() - a["backward64"]).abs().max().item() < _tol(a["backward64"])
-    xf = emulator.engine_transform(eng, a["zin"], "forward", None, False, planes=fmt)
+    xf = emulator.engine_transform(eng, a["zin"], "forward", None, fused, planes=fmt)
     assert (xf.double() - a["forward64"]).abs().max().item() < _tol(a["forward64"])
-    zl, logdet = emulator.engine_latent(eng, a["x"], None, False, planes=fmt)
+    zl, logdet = emulator.engine_latent(eng, a["x"], None, fused, planes=fmt)
     lp = orc.base_log_prob(spec, zl.double(), orc.to_dtype(sd, torch.float64)) + logdet
     rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
     assert rel < 2e-5, rel

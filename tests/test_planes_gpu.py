@@ -201,22 +201,28 @@ def test_gemm_planes_rejects_bad_args():
         ext.gemm_planes(A, W, M=64, a_nkb=2, nk=2)                                             # no output
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", case_names())
-def test_golden_parity_through_the_planes_plan(name, fmt):
+def test_golden_parity_through_the_planes_plan(name, fmt, fused):
     """every golden case of the reference through the planes launch plan (forced: planes_min_rows = 0), activations as
-    bf16x3 or as fp16x2 planes"""
+    bf16x3 or as fp16x2 planes, couplings as ONE fused launch (usf_coupling_planes) or as a chain of GEMMs on planes"""
     spec, sd, a = load_case(name)
     if a.get("context") is not None or spec.soft_training:
         pytest.skip("context: served by the fp32-activation path")
     flow = build_flow(spec, sd, device=DEV)
     eng = flow.engine()
     eng.use_planes, eng.planes_min_rows, eng.gemm_mode = True, 0, fmt
+    eng.use_fused_coupling, eng.fused_min_rows = fused, 0
     with torch.no_grad():
         lp = flow.log_prob(a["x"].to(DEV))
         z = flow.backward(a["x"].to(DEV))
         xf = flow._forward(a["zin"].to(DEV))
     assert any(p.get("planes") and p["planes_fmt"] == FMT[fmt] for p in eng._plans.values()), "planes plan was not built"
+    from usflows_amd import _ext as E
+    has_fused = any(p["arr"][j].kind == E.OP_COUPLING_PLANES for p in eng._plans.values() if p.get("planes")
+                    for j in range(p["n"]))
+    assert has_fused == (fused and not (fmt == "bf16x3" and len(spec.hidden_dims) == 3))
     assert eng.f16_fallbacks == 0
     rel = lambda u, v: ((u.double().cpu() - v.double()).abs() / v.double().abs().clamp_min(1e-30)).max().item()
     tol = 1e-5
@@ -272,3 +278,84 @@ def test_fp16_overflow_falls_back_to_bf16x3_planes():
     assert torch.isfinite(lp1).all() and torch.equal(lp1, lp2) and torch.isfinite(small).all()
     ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x.cpu().double())
     assert ((lp1.cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("M,nh", [(40, 1), (3000, 2), (65536, 2), (2051, 3)])
+def test_coupling_planes_kernel_vs_reference_arithmetic(M, nh, fmt):
+    """usf_coupling_planes at the cfg2 layer shape (25 blocks; conditioning blocks 12..24, transformed blocks 0..12 sharing
+    the straddling block 12; hidden widths 256 / 200 / 136 padded to 256) against torch fp64 / fp32 of the same layer"""
+    ext = _ext()
+    if fmt == "bf16x3" and nh == 3:
+        pytest.skip("three hidden layers in bf16x3 take the GEMM chain (register budget)")
+    f = FMT[fmt]
+    g = torch.Generator().manual_seed(M + nh)
+    nkb, kb_p0, nk_p, kb_t0, nk_t = 25, 12, 13, 0, 13
+    widths = [256, 200, 136][:nh]
+    X = torch.randn(M, 32 * nkb, generator=g) * 2
+    is_p = torch.zeros(800, dtype=torch.bool); is_p[392:784] = True       # conditioning features
+    is_t = torch.zeros(800, dtype=torch.bool); is_t[:392] = True          # transformed features
+    Ws, bs = [], []
+    k_in = 32 * nk_p
+    W0 = torch.randn(widths[0], k_in, generator=g) / math.sqrt(392)
+    W0[:, ~is_p[32 * kb_p0: 32 * (kb_p0 + nk_p)]] = 0                      # zero weights on the other set's features
+    Ws.append(W0); bs.append(torch.randn(widths[0], generator=g) * 0.1)
+    for j in range(1, nh):
+        Ws.append(torch.randn(widths[j], widths[j - 1], generator=g) / math.sqrt(widths[j - 1]))
+        bs.append(torch.randn(widths[j], generator=g) * 0.1)
+    Wo = torch.randn(32 * nk_t, widths[-1], generator=g) / math.sqrt(widths[-1])
+    bo = torch.randn(32 * nk_t, generator=g) * 0.1
+    dead = ~is_t[32 * kb_t0: 32 * (kb_t0 + nk_t)]
+    Wo[dead] = 0; bo[dead] = 0
+
+    def pad(W, rows, cols):
+        o = torch.zeros(rows, cols); o[: W.shape[0], : W.shape[1]] = W; return o
+
+    def padv(b, n):
+        o = torch.zeros(n); o[: b.numel()] = b; return o
+
+    zbuf = torch.zeros(ext.planes_bytes(M, nkb, f), dtype=torch.uint8)
+    emulator.planes_encode(_view(zbuf, M, nkb, f), X, 0)
+    X = emulator.planes_decode(_view(zbuf, M, nkb, f), M)                  # what the buffer holds
+    zd = zbuf.to(DEV)
+    d = ext.CouplingPlanesDesc()
+    keep = []
+    d.z, d.z_nkb, d.M = zd.data_ptr(), nkb, M
+    d.kb_p0, d.nk_p, d.kb_t0, d.nk_t = kb_p0, nk_p, kb_t0, nk_t
+    d.n_hidden, d.hidden_padded = nh, 256
+    Wi = _weight_planes(pad(Ws[0], 256, k_in), 256, f).to(DEV); keep.append(Wi)
+    d.W_in, d.ldw_in, d.w_in_plane = Wi.data_ptr(), Wi.shape[2], Wi.shape[1] * Wi.shape[2]
+    b0 = padv(bs[0], 256).to(DEV); keep.append(b0); d.b_in = b0.data_ptr()
+    for j in range(1, nh):
+        Wh = _weight_planes(pad(Ws[j], 256, 256), 256, f).to(DEV); keep.append(Wh)
+        bh = padv(bs[j], 256).to(DEV); keep.append(bh)
+        d.W_hid[j - 1], d.b_hid[j - 1] = Wh.data_ptr(), bh.data_ptr()
+        d.ldw_hid, d.w_hid_plane = Wh.shape[2], Wh.shape[1] * Wh.shape[2]
+    Wod = _weight_planes(pad(Wo, 32 * nk_t, 256), 32 * nk_t, f).to(DEV); keep.append(Wod)
+    d.W_out, d.ldw_out, d.w_out_plane = Wod.data_ptr(), Wod.shape[2], Wod.shape[1] * Wod.shape[2]
+    bod = bo.to(DEV); keep.append(bod); d.b_out = bod.data_ptr()
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d.sign, d.slope, d.act, d.format, d.range_flag = -1.0, 0.01, 1, f, flag.data_ptr()
+    import ctypes
+    ext.check(ext.load().usf_coupling_planes(ctypes.byref(d), ext.current_stream(zd.device)), "usf_coupling_planes")
+    torch.cuda.synchronize()
+    got = emulator.planes_decode(_view(zd, M, nkb, f), M)
+    idx = torch.unique(torch.cat([torch.arange(0, min(M, 40)), torch.arange(max(M // 2 - 20, 0), min(M // 2 + 20, M)),
+                                  torch.arange(max(M - 40, 0), M)]))
+
+    def ref(dt):
+        h = X[idx][:, 32 * kb_p0: 32 * (kb_p0 + nk_p)].to(dt)
+        for W, b in zip(Ws, bs):
+            h = torch.nn.functional.leaky_relu(h @ W.to(dt).t() + b.to(dt), 0.01)
+        return X[idx][:, 32 * kb_t0: 32 * (kb_t0 + nk_t)].to(dt) - (h @ Wo.to(dt).t() + bo.to(dt))
+
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    out = got[idx][:, 32 * kb_t0: 32 * (kb_t0 + nk_t)].double()
+    scale = r64.abs().max().item()
+    err = (out - r64).abs().max().item() / scale
+    err32 = (r32.double() - r64).abs().max().item() / scale
+    assert err < max(4 * err32, 2e-6), (err, err32)
+    # conditioning-only blocks untouched, the other set's features of the shared block rewritten unchanged
+    assert torch.equal(got[:, 32 * (kb_t0 + nk_t):], X[:, 32 * (kb_t0 + nk_t):])
+    assert torch.equal(got[:, 392:416], X[:, 392:416])
+    assert int(flag.item()) == 0

@@ -16,12 +16,12 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 9
+USF_ABI_VERSION = 10
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
 BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
-OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES = 1, 2, 5, 6
+OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES = 1, 2, 5, 6, 7
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -77,9 +77,20 @@ class GemmPlanesDesc(C.Structure):
                 ("res_sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("format", C.c_int32), ("range_flag", _fp)]
 
 
+class CouplingPlanesDesc(C.Structure):
+    _fields_ = [("z", _fp), ("z_nkb", C.c_int64), ("M", C.c_int64),
+                ("kb_p0", C.c_int64), ("nk_p", C.c_int64), ("kb_t0", C.c_int64), ("nk_t", C.c_int64),
+                ("n_hidden", C.c_int32), ("hidden_padded", C.c_int32),
+                ("W_in", _fp), ("ldw_in", C.c_int64), ("w_in_plane", C.c_int64), ("b_in", _fp),
+                ("W_hid", _fp * 2), ("b_hid", _fp * 2), ("ldw_hid", C.c_int64), ("w_hid_plane", C.c_int64),
+                ("W_out", _fp), ("ldw_out", C.c_int64), ("w_out_plane", C.c_int64), ("b_out", _fp),
+                ("sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("format", C.c_int32),
+                ("range_flag", _fp)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc), ("pack_planes", PackPlanesDesc),
-                ("gemm_planes", GemmPlanesDesc)]
+                ("gemm_planes", GemmPlanesDesc), ("coupling_planes", CouplingPlanesDesc)]
 
 
 class Op(C.Structure):
@@ -114,6 +125,7 @@ SYMBOLS = {
     "usf_pack_planes_f32": (C.c_int, [C.POINTER(PackPlanesDesc), C.c_void_p]),
     "usf_gemm_planes_bf16x3": (C.c_int, [C.POINTER(GemmPlanesDesc), C.c_void_p]),
     "usf_gemm_planes_variant": (C.c_int, [C.POINTER(GemmPlanesDesc)]),
+    "usf_coupling_planes": (C.c_int, [C.POINTER(CouplingPlanesDesc), C.c_void_p]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
@@ -175,7 +187,8 @@ def load() -> C.CDLL:
     if lib.usf_abi_version() != USF_ABI_VERSION:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
     for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
-                     (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc)):
+                     (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc),
+                     (OP_COUPLING_PLANES, CouplingPlanesDesc)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")

@@ -39,6 +39,7 @@ int gather_cols(const float* src, int64_t lds_, float* dst, int64_t ldd, int64_t
 int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream);
 int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream);
 int gemm_planes_variant(const usf_gemm_planes_desc* d);
+int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream);
 int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream);
 int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
              double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
@@ -76,6 +77,7 @@ int usf_sizeof_desc(int32_t kind) {
     case 4: return (int)sizeof(usf_pack_job);
     case USF_OP_PACK_PLANES: return (int)sizeof(usf_pack_planes_desc);
     case USF_OP_GEMM_PLANES: return (int)sizeof(usf_gemm_planes_desc);
+    case USF_OP_COUPLING_PLANES: return (int)sizeof(usf_coupling_planes_desc);
     default: return -1;
   }
 }
@@ -95,6 +97,7 @@ int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream) {
 int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream) { return usf::pack_planes(d, (hipStream_t)stream); }
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream) { return usf::gemm_planes(d, (hipStream_t)stream); }
 
+int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream) { return usf::coupling_planes(d, (hipStream_t)stream); }
 int usf_gemm_planes_variant(const usf_gemm_planes_desc* d) { return usf::gemm_planes_variant(d); }
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }
@@ -200,6 +203,7 @@ int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {
       case USF_OP_COUPLING: rc = usf::coupling_dispatch(&ops[i].u.coupling, (hipStream_t)stream); break;
       case USF_OP_PACK_PLANES: rc = usf::pack_planes(&ops[i].u.pack_planes, (hipStream_t)stream); break;
       case USF_OP_GEMM_PLANES: rc = usf::gemm_planes(&ops[i].u.gemm_planes, (hipStream_t)stream); break;
+      case USF_OP_COUPLING_PLANES: rc = usf::coupling_planes(&ops[i].u.coupling_planes, (hipStream_t)stream); break;
       default: usf::set_error("usf_run_ops: op %d has unknown kind %d", i, ops[i].kind); return -2;
     }
     if (rc != 0) return rc;

@@ -1011,6 +1011,35 @@ class FlowEngine:
             feat_t = torch.where((pos >= lo_t) & (pos < hi_t), segp, torch.full_like(segp, -1))
             layers = [raw["first"]] + list(raw["hidden"]) + [raw["last"]]
             h = list(raw["h"])
+            if (self.use_fused_coupling and B >= self.fused_min_rows and len(h) <= 3 and max(h) <= 256
+                    and not (fmt == _ext.PLANES_BF16X3 and len(h) == 3)):
+                # ONE launch per layer: usf_coupling_planes (hidden activations stay in registers; widths padded to 256)
+                def pad256(n_valid):
+                    t = torch.full((256,), -1, dtype=torch.long)
+                    t[:n_valid] = torch.arange(n_valid)
+                    return t
+                op = _ext.Op()
+                op.kind = _ext.OP_COUPLING_PLANES
+                c = op.u.coupling_planes
+                c.z, c.z_nkb, c.M = z.data_ptr(), nkb, B
+                c.kb_p0, c.nk_p, c.kb_t0, c.nk_t = kb_p0, kb_p1 - kb_p0, kb_t0, kb_t1 - kb_t0
+                c.n_hidden, c.hidden_padded = len(h), 256
+                Wi = self._planes_image(pk, ("pl_cin", i), layers[0][0], pad256(h[0]), self._phys(feat_p[32 * kb_p0: 32 * kb_p1]), fmt)
+                c.W_in, c.ldw_in, c.w_in_plane = Wi.data_ptr(), Wi.shape[2], Wi.shape[1] * Wi.shape[2]
+                c.b_in = self._planes_vec(pk, ("pl_cinb", i), layers[0][1], pad256(h[0])).data_ptr()
+                for j in range(1, len(h)):
+                    Wh = self._planes_image(pk, ("pl_chid", i, j), layers[j][0], pad256(h[j]), self._phys(pad256(h[j - 1])), fmt)
+                    c.W_hid[j - 1] = Wh.data_ptr()
+                    c.b_hid[j - 1] = self._planes_vec(pk, ("pl_chidb", i, j), layers[j][1], pad256(h[j])).data_ptr()
+                    c.ldw_hid, c.w_hid_plane = Wh.shape[2], Wh.shape[1] * Wh.shape[2]
+                out_sel = feat_t[32 * kb_t0: 32 * kb_t1]
+                Wo = self._planes_image(pk, ("pl_cout", i), layers[-1][0], out_sel, self._phys(pad256(h[-1])), fmt)
+                c.W_out, c.ldw_out, c.w_out_plane = Wo.data_ptr(), Wo.shape[2], Wo.shape[1] * Wo.shape[2]
+                c.b_out = self._planes_vec(pk, ("pl_coutb", i), layers[-1][1], out_sel).data_ptr()
+                c.sign, c.slope, c.act, c.format, c.range_flag = sign, cp["slope"], cp["act"], fmt, flag
+                ops.append(op)
+                k += 1
+                continue
             hbufs = [planes_buf("pH1", Hp // 32), planes_buf("pH2", Hp // 32)]
             src_buf, src_nkb, src_kb0, src_nk = z, nkb, kb_p0, kb_p1 - kb_p0
             in_sel = self._phys(feat_p[32 * kb_p0: 32 * kb_p1])
@@ -1252,6 +1281,9 @@ class FlowEngine:
                         tag = ("gemm_planes", g_.M, g_.N if g_.C_f32 else 32 * g_.c_kbn, 32 * g_.nk)
                     elif op.kind == _ext.OP_PACK_PLANES:
                         tag = ("pack_planes", op.u.pack_planes.M, 32 * op.u.pack_planes.nkb, 0)
+                    elif op.kind == _ext.OP_COUPLING_PLANES:
+                        c_ = op.u.coupling_planes
+                        tag = ("coupling_planes", c_.M, 32 * c_.nk_t, 32 * c_.nk_p)
                     else:
                         tag = ("coupling", op.u.coupling.M, op.u.coupling.n_trans, op.u.coupling.n_pass)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
