@@ -243,12 +243,15 @@ class FlowEngine:
         # between layers as pre-split bf16 planes in MFMA-operand order (usf_planes.hip); USFLOWS_AMD_PLANES=0 disables
         self._f16_overflow = False      # set while a pass is being redone in bf16x3 because fp16 planes overflowed
         self.f16_fallbacks = 0          # number of such passes (tests / diagnostics)
-        # use_planes: None = automatic (in "f16x2" mode only: with bf16x3 planes the affine GEMM gains ~5 % but the
-        # conditioner as three GEMMs loses to the fused coupling kernel -- 21.6 vs 19.1 ms per cfg2 step), True / False =
-        # forced (USFLOWS_AMD_PLANES=1 / 0)
+        # use_planes: None = automatic, True / False = forced (USFLOWS_AMD_PLANES=1 / 0).  Automatic: "f16x2" mode from
+        # planes_min_rows rows; "bf16x3" mode from planes_min_rows_bf16x3 rows (measured on MI355X, cfg2, ms per step
+        # planes / fp32-activation kernels: 8192 4.38 / 4.04, 16384 6.79 / 6.42, 32768 9.80 / 9.71, 65536 18.74 / 19.24),
+        # or from planes_min_rows when a conditioner is too wide / deep for the fused coupling kernels (cfg4, hidden 1024:
+        # 176.6 vs 215.8 ms at 32768 rows)
         env_planes = os.environ.get("USFLOWS_AMD_PLANES", "auto")
         self.use_planes = None if env_planes == "auto" else env_planes != "0"
         self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
+        self.planes_min_rows_bf16x3 = 49152
         self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
         self.graph_max_rows = 1024
         self._layout_from_masks()
@@ -837,7 +840,10 @@ class FlowEngine:
         return _ext.PLANES_F16X2 if (self.gemm_mode == "f16x2" and not self._f16_overflow) else _ext.PLANES_BF16X3
 
     def _planes_ok(self, direction: str, B: int, has_ctx: bool, train: bool) -> bool:
-        use = (self.gemm_mode == "f16x2") if self.use_planes is None else bool(self.use_planes)
+        if self.use_planes is None:
+            use = self.gemm_mode == "f16x2" or B >= self.planes_min_rows_bf16x3 or self._has_wide_conditioner()
+        else:
+            use = bool(self.use_planes)
         if (train or has_ctx or not use or self.gemm_mode not in ("bf16x3", "f16x2")
                 or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
@@ -851,6 +857,16 @@ class FlowEngine:
         body = [k_ for k_ in kinds if not k_.startswith("scale")]
         # the last layer must be an affine (it writes the fp32 result) and the chain needs at least two GEMM-sized ops
         return len(body) >= 2 and body[-1].startswith("affine")
+
+    def _has_wide_conditioner(self) -> bool:
+        """a conditioner wider than 256 or deeper than 3 hidden layers: no fused coupling kernel serves it"""
+        for s_ in self.steps:
+            if s_.kind == "coupling":
+                cond = s_.module.conditioner
+                widths = cond.c_hidden if isinstance(cond, ConvNet) else cond.hidden_dims
+                if len(widths) > 3 or max(int(w) for w in widths) > 256:
+                    return True
+        return False
 
     def _planes_image(self, pk, key, src, out_sel: torch.Tensor, in_sel: torch.Tensor, fmt: int = 0):
         """cached weight planes of src[out_sel][:, in_sel] (-1: zero), one queued launch: [3, rows, cols] bf16
@@ -1171,7 +1187,7 @@ class FlowEngine:
     def _plan(self, direction, B, device, has_ctx, final, train: bool = False):
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
-               train, self.use_planes, self.planes_min_rows, self._planes_fmt())
+               train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final, train)
