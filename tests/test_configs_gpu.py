@@ -41,6 +41,8 @@ def plan_variants(eng):
                 out.add(lib.usf_linear_variant(C.byref(arr[j].u.linear)))
             elif arr[j].kind == _ext.OP_GEMM_PLANES:
                 out.add(lib.usf_gemm_planes_variant(C.byref(arr[j].u.gemm_planes)))
+            elif arr[j].kind == _ext.OP_COUPLING_PLANES:       # fused coupling on planes: 6000 + planes per operand
+                out.add(6002 if arr[j].u.coupling_planes.format == _ext.PLANES_F16X2 else 6003)
     return out
 
 
@@ -106,7 +108,7 @@ def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B, planes):
     assert (z[idx.to(DEV)].cpu().double() - a["backward64"]).abs().max().item() < 2e-5 * s
     v = plan_variants(eng)
     if planes:
-        assert {5050, 5040, 5051} <= v, (B, v)      # affine / conditioner layers on planes, fp32 output of the last layer
+        assert {5050, 6003, 5051} <= v, (B, v)      # affine GEMMs on planes, fused couplings on planes, fp32 output of the last layer
     else:
         assert {16384: 3542, 32768: 3542, 65536: 3584}[B] in v, (B, v)
     flow.engine().use_planes = None
@@ -153,7 +155,8 @@ def test_cfg5_per_rank_sample(cfg2, mode):
     dev_ = (part - xs[5000:6000]).abs().max().item()
     assert dev_ < 2e-5 * max(1.0, xs.abs().max().item()), dev_
     v = plan_variants(eng)
-    assert {5050, 5051} <= v, v            # 125000 rows: the planes pipeline in both modes (automatic from 49152 rows in bf16x3)
+    # 125000 rows: the planes pipeline in both modes (automatic from 49152 rows in bf16x3), fused couplings on planes
+    assert {5050, 5051, 6002 if mode == "f16x2" else 6003} <= v, v
     assert eng.f16_fallbacks == 0
     eng.gemm_mode = "bf16x3"
 
