@@ -82,7 +82,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
 B, D, H = 65536, 784, 256
-alg = {"linear_bf16x3_kernel": 2 * B * D * 4 + 3 * D * 800 * 2,
+alg = {"gemm_planes_kernel": 2 * B * 800 * 6 + 3 * 800 * 800 * 2,          # planes in + planes out + weight planes (bf16x3)
+       "coupling_planes_kernel": 3 * 13 * 32 * B * 6 + 3 * 2 * (H * 416 + H * H + 416 * H),
+       "linear_bf16x3_kernel": 2 * B * D * 4 + 3 * D * 800 * 2,
        "coupling_bf16x3_kernel": (B * D + B * (D // 2)) * 4 + 3 * 2 * (H * 416 + H * H + 416 * H),
        "base_logprob_kernel": B * D * 4 + B * 4}
 kern = {}
