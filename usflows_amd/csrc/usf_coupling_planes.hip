@@ -64,7 +64,14 @@ struct CplPArgs {
   const char* Wout; int64_t ld_out, pl_out; const float* b_out;
   float sign, slope; int act;
   int32_t* range_flag;
+  unsigned long long* dbg;               // tuning builds (-DUSF_STAMP) only
 };
+
+#ifdef USF_STAMP
+#define CSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define CSTAMP(v)
+#endif
 
 template <int NPL, int NH>
 __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs p) {
@@ -180,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     }
   };
 
+  CSTAMP(c0);
   int g = 0;
   f32x4 st[NST];
   vec8 zp[NPL], zn[NPL];
@@ -220,6 +228,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     }
   };
   activate(X1);
+  CSTAMP(c1);
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1'] * Xin[h1'][row] ====================
   auto hidden_layer = [&](f32x4 (&Xin)[T], f32x4 (&Xout)[T], int l) {
@@ -258,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     hidden_layer(X2, X1, 1);
   }
 
+  CSTAMP(c2);
   // ================= phase 3: z_T[row][n] += sign * (b_out[n] + sum_h X[h][row] W_out[n][h']) on the transformed blocks =====
   auto output_layer = [&](f32x4 (&X)[T]) {
     vec8 xp[KS][NPL];
@@ -323,9 +333,20 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     }
   };
   if (NH == 2) output_layer(X2); else output_layer(X1);
+#ifdef USF_STAMP
+  CSTAMP(c3);
+  if (p.dbg && lane == 0) {
+    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 2048) * 8 + wave) * 4;
+    o[0] = c1 - c0; o[1] = c2 - c1; o[2] = c3 - c2; o[3] = 1;
+  }
+#endif
   if (NPL == 2 && p.range_flag && bad && live && (16 * panel + lj) < p.M) atomicOr(p.range_flag, 1);
 #undef CP_PIN_SLAB
 }
+
+#ifdef USF_STAMP
+unsigned long long* g_cdbg = nullptr;
+#endif
 
 int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_planes: null descriptor"); return -1; }
@@ -360,6 +381,10 @@ int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
   a.ld_hid = d->ldw_hid; a.pl_hid = d->w_hid_plane;
   a.Wout = reinterpret_cast<const char*>(d->W_out); a.ld_out = d->ldw_out; a.pl_out = d->w_out_plane; a.b_out = d->b_out;
   a.sign = d->sign; a.slope = d->slope; a.act = d->act; a.range_flag = d->range_flag;
+  a.dbg = nullptr;
+#ifdef USF_STAMP
+  a.dbg = g_cdbg;
+#endif
   const dim3 grid((unsigned)((npanels + 7) / 8)), block(512);
 #define USF_CPL(NPL_, NH_) hipLaunchKernelGGL((coupling_planes_kernel<NPL_, NH_>), grid, block, 0, stream, a)
   if (npl == 2) {
