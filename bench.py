@@ -182,6 +182,9 @@ def main():
         step()
     if on_gpu and not args.no_kernel_timing and mode != "train":
         eng.op_timing = []
+    if on_gpu and not args.no_kernel_timing and mode == "train":
+        from usflows_amd import _ext as _ext_t
+        _ext_t.launch_timing = {"usf_wgrad_f32": []}        # HIP events around every weight-gradient launch
     if under_launcher:
         dist.barrier()
     sync()
@@ -193,8 +196,12 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timing = None
+    wg_timing = None
     if on_gpu:
         timing, eng.op_timing = eng.op_timing, None
+        if mode == "train" and not args.no_kernel_timing:
+            from usflows_amd import _ext as _ext_t
+            wg_timing, _ext_t.launch_timing = _ext_t.launch_timing["usf_wgrad_f32"], None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if under_launcher:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -300,6 +307,32 @@ def main():
                     "share_of_gpu_time": round(share, 3),
                     "algorithmic_flops_per_launch": flops,
                     "all_kernels_ms_per_step": {f"{k[0]}:{k[2]}x{k[3]}": round(v / args.steps, 3) for k, v in tot.items()}}
+    if wg_timing:
+        # training step: the weight gradients are the largest kernel class (usf_wgrad_f32 = the wgrad kernel + the
+        # reduction of its row-range partials); the D x D launches of the affine layers are the dominant shape
+        from usflows_amd import _ext as _ext_t
+        shapes = {}
+        for e0, e1, a in wg_timing:
+            shapes.setdefault((int(a[4]), int(a[5]), int(a[6])), []).append(e0.elapsed_time(e1))
+        tot = {k: sum(v) for k, v in shapes.items()}
+        dom = max(tot, key=tot.get)
+        M_, N_, K_ = dom
+        avg_ms = tot[dom] / len(shapes[dom])
+        flops = 2.0 * M_ * N_ * K_
+        variant = _ext_t.load().usf_wgrad_variant(M_, N_, K_, (N_ + 3) // 4 * 4, (K_ + 3) // 4 * 4, 1 if eng.gemm_mode != "f32" else 0)
+        bf = variant != 0
+        peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if bf else F32_MFMA_PEAK_TFLOPS
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "traffic_source": None,
+                    "kernel": {0: "wgrad_kernel (exact f32)", 1: "wgrad_bf16x3_kernel", 2: "wgrad_lw_kernel (bf16x3, loader waves)"}[variant]
+                              + f" + reduce_partials_kernel: usf_wgrad_f32 N={N_} K={K_} over {M_} rows",
+                    "peak_is": "dense bf16 MFMA peak (2500) / 6 products per fp32 product" if bf else "dense f32 MFMA",
+                    "measured_by": "HIP events around every usf_wgrad_f32 launch of this run's timed region",
+                    "avg_launch_ms": round(avg_ms, 4), "launches": len(shapes[dom]),
+                    "algorithmic_flops_per_launch": flops,
+                    "wgrad_ms_per_step": {f"{k[1]}x{k[2]}": round(v / args.steps, 3) for k, v in tot.items()},
+                    "wgrad_share_of_step": round(sum(tot.values()) / args.steps / ms_per_step, 3)}
     # whole-flow algorithmic FLOP rate (mask-aware count)
     hs = list(hidden)
     flop_per_sample = (blocks * (2 if args.conj else 1) + 1) * 2.0 * D * D + blocks * 2.0 * (

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 10
+#define USF_ABI_VERSION 11
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -431,7 +431,12 @@ int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* 
  *   (Y = gradient at the layer's output [M,N], A = the layer's input [M,K]); exact-f32 MFMA, the batch is cut into
  *   row ranges whose partial products are summed in a fixed order (bitwise reproducible).  Y / A rows must be 16-byte
  *   aligned (ld % 4 == 0).  workspace: at least usf_wgrad_workspace_floats(M,N,K) floats.  mode 0: exact-f32 MFMA;
- *   mode 1: the bf16x3 split of DESIGN.md 3.1b (fp32-equivalent accuracy on the bf16 matrix cores; used from M >= 2048).
+ *   mode 1: the bf16x3 split of DESIGN.md 3.1b (fp32-equivalent accuracy on the bf16 matrix cores; used from M >= 2048;
+ *   from 8192 rows with enough output tiles to fill the chip, and while (M + 448) * max(ldy, lda) * 4 < 2^32, the
+ *   loader-wave kernel: it reads Y / A with 16-byte loads up to the end of the row extent ((M-1) * ld + N resp. K
+ *   floats from the base pointer) -- the same memory the contract above names).
+ * usf_wgrad_variant: which kernel such a call launches -- 0 exact-f32, 1 bf16x3 (256 threads), 2 bf16x3 with loader
+ *   waves (introspection for the parity tests).
  * usf_colsum_f32: out[n] = alpha * sum_m Y[m,n] + beta * out[n]           -- the bias gradient; workspace
  *   (ceil(M/256) + ceil(M/65536) + 2) * N floats (partials of the 256-row levels).
  */
@@ -439,6 +444,7 @@ int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int6
                   int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
                   usf_stream_t stream);
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K);
+int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream);
 

@@ -20,10 +20,16 @@ def _ext():
 
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("M,N,K", [(1, 4, 4), (17, 20, 36), (256, 128, 128), (1000, 392, 256), (4096, 784, 784),
-                                   (5000, 130, 260), (2048, 392, 256), (0, 8, 8)])
+                                   (5000, 130, 260), (2048, 392, 256), (0, 8, 8), (8200, 784, 784), (33001, 130, 260),
+                                   (21000, 392, 256)])
 def test_wgrad_matches_fp64(M, N, K, mode):
-    """mode 1 = bf16x3 split on the bf16 MFMA (taken from M >= 2048): same tolerance as the exact-f32 kernel"""
+    """mode 1 = bf16x3 split on the bf16 MFMA (taken from M >= 2048; the loader-wave kernel from 8192 rows with
+    enough tiles: the last three shapes -- ragged row counts, edge tiles in both directions): same tolerance as the
+    exact-f32 kernel"""
     ext = _ext()
+    if M > 8000:
+        lib = ext.load()
+        assert lib.usf_wgrad_variant(M, N, K, (N + 3) // 4 * 4 + 4, (K + 3) // 4 * 4 + 8, mode) == (2 if mode == 1 else 0)
     g = torch.Generator().manual_seed(M + N + K)
     ldy, lda, ldg = (N + 3) // 4 * 4 + 4, (K + 3) // 4 * 4 + 8, K + 4     # rows of Y / A 16-byte aligned (contract)
     Y = torch.randn(M, ldy, generator=g)

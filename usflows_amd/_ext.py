@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 10
+USF_ABI_VERSION = 11
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -152,6 +152,7 @@ SYMBOLS = {
     "usf_wgrad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
                                 C.c_float, C.c_float, C.c_int32, _fp, C.c_int64, C.c_void_p]),
     "usf_wgrad_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_wgrad_variant": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "usf_colsum_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_float, _fp, C.c_int64,
                                  C.c_void_p]),
     "usf_act_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_float,
@@ -242,12 +243,29 @@ class record:
         return False
 
 
+# bench.py --mode train: {entry-point name: [(start_event, end_event, args), ...]} -- every launch (and replay) of the
+# named entry points is bracketed by HIP events on torch's current stream.  None (the default): no events, no cost.
+launch_timing = None
+
+
+def _timed_call(fn, args, name):
+    lt = launch_timing
+    if lt is not None and name in lt:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        lt[name].append((e0, e1, args))
+        return rc
+    return fn(*args)
+
+
 def _launch(name: str, args: tuple, keep=None) -> None:
     fn = getattr(load(), name)
     rec = _tls.rec
     if rec and rec[-1] is not None:
         rec[-1].entries.append((fn, args, name, keep))
-    rc = fn(*args)
+    rc = _timed_call(fn, args, name)
     if rc != 0:
         check(rc, name)
 
@@ -265,7 +283,7 @@ def replay(tape: Tape) -> None:
     with record(None):
         for e in tape.entries:
             if e.__class__ is tuple:
-                rc = e[0](*e[1])
+                rc = e[0](*e[1]) if launch_timing is None else _timed_call(e[0], e[1], e[2])
                 if rc != 0:
                     check(rc, e[2])
             else:

@@ -53,6 +53,7 @@ int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, 
                 double alpha, float* out32, double* out64, hipStream_t stream);
 
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
+int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
           hipStream_t stream);
@@ -176,6 +177,9 @@ int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int6
                   int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
                   usf_stream_t stream) {
   return usf::wgrad(Y, ldy, A, lda, M, N, K, G, ldg, alpha, beta, mode, workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
+  return usf::wgrad_variant(M, N, K, ldy, lda, mode);
 }
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K) {
   int64_t out = 0;

@@ -13,6 +13,7 @@
 // Data gradients (dgrad) are usf_linear_f32 launches with the transposed weight image (usf_pack_weight_f32,
 // transpose = 1); the parameter-sized chain rule through M^-1 = U^-1 L^-1 is usf_gemm_f64.
 #include "usf_common.h"
+#include <type_traits>
 
 namespace usf {
 
@@ -30,7 +31,12 @@ struct WgradArgs {
   float alpha, beta;
   int direct;
   int tiles, splits;           // 1-D grid, XCD-aware: see wg_decode
+  unsigned long long* dbg;     // tuning builds (-DUSF_STAMP) only
 };
+#ifdef USF_STAMP
+#define WSTAMP() __builtin_amdgcn_s_memtime()
+unsigned long long* g_wdbg = nullptr;
+#endif
 
 // Block -> (tile, row range).  Every tile column re-reads the Y slab and every tile row the A slab (7 x each at
 // 784 x 784), so per launch the blocks ask for 14 x the operand bytes; whether that comes from HBM or from L2 decides
@@ -329,6 +335,280 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
       }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 wgrad with LOADER WAVES (mode 1 from 2048 rows; round 2).  The kernel above runs fetch -> barrier ->
+// split -> barrier -> MFMA in every wave: the matrix pipe idles while the block splits, and the next slab's loads
+// have one MFMA phase to come back from HBM.  Here a 512-thread block (one per CU, 128 x 128 tile) has two roles:
+//   waves 0..3 (one per SIMD): nothing but ds_read_b128 + MFMA on a 64 x 64 patch (96 MFMAs per 32-row slab); the
+//                first fragments of slab s + 1 are read under the last MFMAs of slab s;
+//   waves 4..7 (one per SIMD): fetch fp32 rows ahead of their use (USF_WL_DEPTH slabs in flight per thread; two measured
+//                better than four), split them into bf16 planes and store them in fragment order two slabs ahead
+//                into a ring of three images.
+// Measured (tools/exp_wgrad.hip stamps, 784 x 784 x 65 536): an MFMA wave needs ~1600 cycles per slab; with the split
+// switched off the kernel runs at 164 TFLOP/s, with it at 115-125 -- the loaders' VALU and the MFMAs of the same SIMD
+// largely take turns instead of overlapping (an MFMA holds the SIMD's vector issue for half of its cycles), so the
+// split (5.25 instructions per value, every value split by the 7 blocks that share its row slab) is what is left.
+// One barrier per slab.  The image is swizzled (unit u of a line sits at u ^ ((u >> 4) & 3)) so that both the
+// loaders' stores (lane stride 4 units) and the fragment reads (16 consecutive units) are bank-conflict free.
+// Loads are unconditional 16-byte buffer loads: rows beyond M are out of the resource's range and read as zeros
+// (row ranges are whole slabs, so inside a range "beyond m_end" means "beyond M"); columns beyond N / K read
+// whatever lies there (row padding or the next row) -- they only ever reach output columns that are not stored.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wl_swz(int c) { return c ^ ((c >> 4) & 3); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WlShared {
+  bf16x8_t Yp[3][3][4][WG_T];                 // [ring][plane][8-row group][column]
+  bf16x8_t Ap[3][3][4][WG_T];
+};
+
+// fp32 -> three bf16 planes for 8 values, two at a time (v_cvt_pk_bf16_f32 / v_pk_add_f32): 5.25 instructions per value
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wl_split(const float (&x)[8], bf16x8_t& p1, bf16x8_t& p2, bf16x8_t& p3) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x2 v = {x[2 * t], x[2 * t + 1]};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);            // exact
+    const bf16x2_t m = __builtin_convertvector(r, bf16x2_t);
+    const f32x2 r2 = r - __builtin_convertvector(m, f32x2);           // exact
+    const bf16x2_t l = __builtin_convertvector(r2, bf16x2_t);
+    p1[2 * t] = h[0]; p1[2 * t + 1] = h[1];
+    p2[2 * t] = m[0]; p2[2 * t + 1] = m[1];
+    p3[2 * t] = l[0]; p3[2 * t + 1] = l[1];
+  }
+}
+
+#ifdef USF_STAMP
+#define WL_Q(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = WSTAMP()
+#else
+#define WL_Q(v)
+#endif
+
+// the MFMA waves' main loop for a patch of NI x NJ live 16 x 16 sub-tiles (rounded up to a power of two; columns
+// beyond N / K produce values that are not stored)
+template <int NI, int NJ>
+__device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], int nslab, int nslab4, int wn, int wk, int li, int lg,
+                                             unsigned long long* dbg_slot) {
+  int ycol[NI], acol[NJ];
+#pragma unroll
+  for (int t = 0; t < NI; ++t) ycol[t] = wl_swz(wn * 64 + t * 16 + li);
+#pragma unroll
+  for (int t = 0; t < NJ; ++t) acol[t] = wl_swz(wk * 64 + t * 16 + li);
+  bf16x8_t ypa[NI][3], ypb[NI][3], ap[2][3];
+  auto read_y = [&](int ring, bf16x8_t (&yp)[NI][3]) {
+#pragma unroll
+    for (int t = 0; t < NI; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) yp[t][pl] = sh.Yp[ring][pl][lg][ycol[t]];
+  };
+  auto read_a = [&](int ring, int j, bf16x8_t (&f)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) f[pl] = sh.Ap[ring][pl][lg][acol[j]];
+  };
+  // B0: which of the two A-fragment registers holds column 0 of this slab (alternates from slab to slab when NJ is odd)
+  auto slab = [&](int ring, int ring_next, const bf16x8_t (&yp)[NI][3], bf16x8_t (&ypn)[NI][3], auto b0) {
+    constexpr int B0 = decltype(b0)::value;
+#define USF_WL(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][P], ap[(j + B0) & 1][Q], acc[i][j], 0, 0, 0)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j + 1 < NJ) {
+        read_a(ring, j + 1, ap[(j + 1 + B0) & 1]);
+      } else {                                  // the next slab's first fragments (its image is complete since the last barrier)
+        read_a(ring_next, 0, ap[(j + 1 + B0) & 1]);
+        read_y(ring_next, ypn);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        USF_WL(2, 0); USF_WL(1, 1); USF_WL(0, 2); USF_WL(1, 0); USF_WL(0, 1); USF_WL(0, 0);   // smallest terms first
+      }
+    }
+#undef USF_WL
+    // per A fragment: the next fragment's reads, then its MFMAs (the last column also carries the next slab's Y reads)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      if (j + 1 == NJ) {
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI, 0);
+      }
+    }
+  };
+  typedef std::integral_constant<int, 0> C0;
+  typedef std::integral_constant<int, NJ & 1> C1;      // after an odd number of columns the roles of ap[0] / ap[1] swap
+  read_y(0, ypa);
+  read_a(0, 0, ap[0]);
+#ifdef USF_STAMP
+  unsigned long long tw = 0, tb = 0;
+#endif
+  int s = 0, ring = 0;
+  auto nxt = [](int r) { return r == 2 ? 0 : r + 1; };
+  for (; s < nslab4; s += 2) {
+    WL_Q(q0);
+    if (s < nslab) slab(ring, nxt(ring), ypa, ypb, C0());
+    WL_Q(q1);
+    __syncthreads();
+    WL_Q(q2);
+    ring = nxt(ring);
+    if (s + 1 < nslab) slab(ring, nxt(ring), ypb, ypa, C1());
+    WL_Q(q3);
+    __syncthreads();
+    ring = nxt(ring);
+#ifdef USF_STAMP
+    tw += (q1 - q0) + (q3 - q2); tb += (q2 - q1) + (WSTAMP() - q3);
+#endif
+  }
+#ifdef USF_STAMP
+  if (dbg_slot) { dbg_slot[0] = tw; dbg_slot[1] = tb; dbg_slot[2] = nslab; dbg_slot[3] = 1; }
+#endif
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad_lw_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) WlShared sh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tilesK = (a.K + WG_T - 1) / WG_T;
+  int tile, split;
+  if (!wg_decode(a, tile, split)) return;
+  const int n0 = (tile / tilesK) * WG_T, k0 = (tile % tilesK) * WG_T;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
+  const int nslab = (m_end - m_begin + WB_S - 1) / WB_S;
+  const int nslab4 = (nslab + 3) & ~3;        // iterations every wave runs (barrier count): see the loader loop
+  unsigned long long* dbg_slot = nullptr;
+#ifdef USF_STAMP
+  if (a.dbg && lane == 0) dbg_slot = a.dbg + (size_t)((blockIdx.x % 1024) * 8 + wave) * 4;
+#endif
+
+  if (wave >= 4) {
+    // ------------------------------- loader waves -------------------------------
+    // thread = one (8 rows x 4 columns) unit of the slab: waves 4, 5 carry Y, waves 6, 7 carry A
+    const int lt = tid - 256;
+    const bool isA = wave >= 6;                 // wave-uniform (the buffer resource must sit in scalar registers)
+    const int u = lt & 127, rg = u >> 5, cg = u & 31;
+    const unsigned ld = (unsigned)(isA ? a.lda : a.ldy);
+    const unsigned c0 = (unsigned)((isA ? k0 : n0) + 4 * cg);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(isA ? a.A : a.Y), 0, (int)((((unsigned)a.M - 1u) * ld + (unsigned)(isA ? a.K : a.N)) * 4u), 0x00020000);
+    // (the row within the 8-row unit goes into the instruction's scalar offset: one vector add per slab, not per load)
+    const unsigned vo = (((unsigned)m_begin + 8u * rg) * ld + c0) * 4u;
+    auto fetch = [&](int sl, f32x4 (&v)[8]) {
+      const unsigned o = vo + (unsigned)sl * (WB_S * 4u) * ld;
+#ifdef USF_WL_X_NOLOAD
+      if (sl > 8) return;
+#endif
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, (int)((unsigned)e * ld * 4u), 0));
+    };
+    auto split_store = [&](int ring, const f32x4 (&v)[8]) {
+      bf16x8_t* d = isA ? &sh.Ap[ring][0][rg][0] : &sh.Yp[ring][0][rg][0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float col[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) col[e] = v[e][q];
+        bf16x8_t p1, p2, p3;
+#ifdef USF_WL_X_NOSPLIT
+        p1 = __builtin_bit_cast(bf16x8_t, v[q]); p2 = __builtin_bit_cast(bf16x8_t, v[q + 4]); p3 = p1;
+#else
+        wl_split(col, p1, p2, p3);
+#endif
+        const int us = wl_swz(4 * cg + q);
+        d[us] = p1; d[4 * WG_T + us] = p2; d[8 * WG_T + us] = p3;
+      }
+    };
+#ifndef USF_WL_DEPTH
+#define USF_WL_DEPTH 2
+#endif
+    constexpr int DEPTH = USF_WL_DEPTH;         // slabs in flight per thread: slab t lives in set t % DEPTH from fetch to split
+    f32x4 vs[DEPTH][8];
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) fetch(t, vs[t]);
+    split_store(0, vs[0]); fetch(DEPTH, vs[0]);
+    split_store(1, vs[1]); fetch(DEPTH + 1, vs[1]);
+    __syncthreads();
+    // iteration s: slab s is multiplied out of ring s % 3 while slab s + 2 is split into ring (s + 2) % 3 and slab
+    // s + 2 + DEPTH is fetched
+#ifdef USF_STAMP
+    unsigned long long tw = 0, tb = 0;
+#endif
+    // (straight-line groups of DEPTH iterations, no switch on s: the compiler's vmcnt bookkeeping stays exact, so a
+    // wait for slab s + 2 does not also drain the younger loads of the slabs behind it; every wave of the block runs
+    // the slab count rounded up to a multiple of four -- the surplus iterations only keep the barriers)
+    int ring2 = 2;                              // (s + 2) % 3
+    for (int s0 = 0; s0 < nslab4; s0 += DEPTH) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        WL_Q(q0);
+        split_store(ring2, vs[(k + 2) % DEPTH]);
+        fetch(s0 + k + 2 + DEPTH, vs[(k + 2) % DEPTH]);
+        WL_Q(q1);
+        __syncthreads();
+        ring2 = ring2 == 2 ? 0 : ring2 + 1;
+#ifdef USF_STAMP
+        tw += q1 - q0; tb += WSTAMP() - q1;
+#endif
+      }
+    }
+#ifdef USF_STAMP
+    if (dbg_slot) { dbg_slot[0] = tw; dbg_slot[1] = tb; dbg_slot[2] = nslab; dbg_slot[3] = 1; }
+#endif
+    return;
+  }
+
+  // ------------------------------- MFMA waves -------------------------------
+  const int li = lane & 15, lg = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int rem_n = a.N - (n0 + wn * 64), rem_k = a.K - (k0 + wk * 64);
+  const int ni = rem_n <= 0 ? 0 : (rem_n >= 64 ? 4 : (rem_n + 15) / 16);
+  const int nj = rem_k <= 0 ? 0 : (rem_k >= 64 ? 4 : (rem_k + 15) / 16);
+  __syncthreads();
+  // wave-uniform choice of the patch size: live sub-tiles rounded up to {1, 2, 4} x {1, 2, 4}; a wave whose patch lies
+  // outside the matrix only keeps the barriers
+  if (ni == 0 || nj == 0) {
+    for (int s = 0; s < nslab4; ++s) __syncthreads();
+  } else {
+#define WL_GO(NI_, NJ_) wl_mfma_loop<NI_, NJ_>(sh, acc, nslab, nslab4, wn, wk, li, lg, dbg_slot)
+#define WL_ROW(NI_) do { if (nj > 2) WL_GO(NI_, 4); else if (nj > 1) WL_GO(NI_, 2); else WL_GO(NI_, 1); } while (0)
+    if (ni > 2) WL_ROW(4); else if (ni > 1) WL_ROW(2); else WL_ROW(1);
+#undef WL_ROW
+#undef WL_GO
+  }
+  float* out = a.part + (int64_t)split * a.N * a.K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (n < a.N && k < a.K) {
+          if (a.direct) {
+            float* dst = a.G + (int64_t)n * a.ldg + k;
+            float vv = a.alpha * acc[i][j][r];
+            if (a.beta != 0.f) vv += a.beta * *dst;
+            *dst = vv;
+          } else {
+            out[(int64_t)n * a.K + k] = acc[i][j][r];
+          }
+        }
+      }
+}
+#undef WL_Q
+
 // out[r*ldo + c] = alpha * sum_s part[s][r][c] + beta * out[...]   (rows x cols elements per partial)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t rows,
                                                               int64_t cols, float* __restrict__ out, int64_t ldo,
@@ -404,21 +684,45 @@ __global__ __launch_bounds__(256) void base_grad_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-static int pick_splits(int64_t M, int64_t tiles) {
-  // enough row ranges to give every CU ~2 blocks, each at least 256 rows
-  int64_t s = (640 + tiles - 1) / tiles;
-  const int64_t smax = (M + 255) / 256;
+static int pick_splits(int64_t M, int64_t tiles, bool lw) {
+  // row ranges of at least 256 rows.  256-thread kernels (two blocks per CU): enough to give every CU ~2 blocks.
+  // Loader-wave kernel (one 512-thread block per CU): ~3 rounds of blocks, so that the short edge tiles (784 = 6 x 128
+  // + 16) and the full ones even out over the CUs, at >= 64 slabs per block.
+  static int lw_blocks = -1;
+  if (lw_blocks < 0) { const char* e = getenv("USF_WGRAD_BLOCKS"); lw_blocks = e ? atoi(e) : 768; if (lw_blocks < 1) lw_blocks = 768; }
+  const int64_t target = lw ? lw_blocks : 640;
+  int64_t s = (target + tiles - 1) / tiles;
+  const int64_t smax = lw ? (M + 1023) / 1024 : (M + 255) / 256;
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   if (s > 256) s = 256;
   return (int)s;
 }
+// The loader-wave kernel: from the measured cross-over against the 256-thread kernel (at least 8192 rows and enough
+// work to fill its one block per CU; 4096 x 784 x 784 and 8192 x 256 x 392 are still faster on the old one), and
+// while its 32-bit byte offsets hold (prefetch distance included).  USF_WGRAD_LW_MIN: tuning aid.
+static bool use_lw(int64_t M, int32_t mode, int64_t tiles, int64_t ldy, int64_t lda) {
+  static int64_t lw_min = -1;
+  if (lw_min < 0) { const char* e = getenv("USF_WGRAD_LW_MIN"); lw_min = e ? atoll(e) : 8192; }
+  return mode == 1 && M >= lw_min && M * tiles >= 160000 && (M + 448) * (ldy > lda ? ldy : lda) * 4 < (1LL << 32);
+}
+
+static int64_t wg_tiles(int64_t N, int64_t K) { return ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T); }
 
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out) {
   if (M < 0 || N <= 0 || K <= 0) return -1;
-  const int64_t tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T);
-  *out = (int64_t)pick_splits(M, tiles) * N * K;
+  const int sa = pick_splits(M, wg_tiles(N, K), false), sb = pick_splits(M, wg_tiles(N, K), true);      // either kernel may be chosen
+  *out = (int64_t)(sa > sb ? sa : sb) * N * K;
   return 0;
+}
+
+// which kernel usf_wgrad_f32 launches: 0 exact-f32 MFMA, 1 bf16x3 (256 threads), 2 bf16x3 with loader waves
+int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  static int old_kernel = -1;                 // tuning aid: USF_WGRAD_OLD=1 keeps the round-1 bf16x3 kernel
+  if (old_kernel < 0) { const char* e = getenv("USF_WGRAD_OLD"); old_kernel = e ? atoi(e) : 0; }
+  if (use_lw(M, mode, wg_tiles(N, K), ldy, lda) && !old_kernel) return 2;
+  return (mode == 1 && M >= 2048) ? 1 : 0;
 }
 
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
@@ -433,8 +737,12 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
     set_error("usf_wgrad_f32: Y / A need 16-byte aligned rows (ld %% 4 == 0, aligned base)");
     return -3;
   }
-  const int64_t tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T);
-  const int splits = pick_splits(M, tiles);
+  if (mode != 0 && mode != 1) { set_error("usf_wgrad_f32: mode must be 0 (exact f32) or 1 (bf16x3)"); return -2; }
+  // the split-precision kernels pay off once the chip has real work (the operand split costs VALU per slab)
+  const int64_t tiles = wg_tiles(N, K);
+  const int variant = wgrad_variant(M, N, K, ldy, lda, mode);
+  const bool lw = variant == 2;
+  const int splits = pick_splits(M, tiles, lw);
   if (workspace_floats < (int64_t)splits * N * K) {
     set_error("usf_wgrad_f32: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
               (long long)splits * N * K);
@@ -443,11 +751,13 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
   int rows = (int)((M + splits - 1) / splits);
   rows = (rows + WB_S - 1) / WB_S * WB_S;
   WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S, G, ldg, alpha, beta,
-              splits == 1 ? 1 : 0, (int)tiles, splits};
+              splits == 1 ? 1 : 0, (int)tiles, splits, nullptr};
+#ifdef USF_STAMP
+  a.dbg = g_wdbg;
+#endif
   const unsigned grid = (unsigned)(tiles * ((splits + 7) / 8) * 8);
-  if (mode != 0 && mode != 1) { set_error("usf_wgrad_f32: mode must be 0 (exact f32) or 1 (bf16x3)"); return -2; }
-  // the split-precision kernel pays off once the chip has real work (its operand split costs VALU per slab)
-  if (mode == 1 && M >= 2048) wgrad_bf16x3_kernel<<<grid, 256, 0, stream>>>(a);
+  if (lw) wgrad_lw_kernel<<<grid, 512, 0, stream>>>(a);
+  else if (variant == 1) wgrad_bf16x3_kernel<<<grid, 256, 0, stream>>>(a);
   else wgrad_kernel<<<grid, 256, 0, stream>>>(a);
   if (splits > 1) {
     int64_t rb = (N * K + 255) / 256;
