@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--gemm", choices=["bf16x3", "f16x2", "f32"], default=None,
                     help="GEMM arithmetic: bf16x3 = 3-way bf16 split (24 bits/operand, 6 MFMAs per product), f16x2 = 2-way "
                          "fp16 split in the planes pipeline (22 bits/operand, 3 MFMAs per product), f32 = exact-f32 MFMA")
+    ap.add_argument("--optim", choices=["sophia", "adam"], default="sophia",
+                    help="--mode train: SophiaG (the reference's Flow.fit default) or torch's Adam")
     ap.add_argument("--mode", choices=["log_prob", "sample", "train"], default=None,
                     help="sample: time Flow.sample (Philox head + forward pass); train: one optimiser step of Flow.fit's "
                          "loss (-log_prob.mean(): device forward + backward + Adam)")
@@ -155,7 +157,11 @@ def main():
         x = torch.rand(B, D, generator=g).to(dev)           # this rank's shard, resident in HBM
     acc = torch.zeros(2, dtype=torch.float64, device=dev)
 
-    opt = torch.optim.Adam(flow.parameters(), lr=1e-6) if mode == "train" else None
+    opt = None
+    if mode == "train":
+        # the optimiser Flow.fit defaults to (flows.py:116): SophiaG -- one multi-tensor HIP launch per step on the GPU
+        from usflows_amd.sophia import SophiaG
+        opt = SophiaG(flow.parameters(), lr=1e-6) if args.optim == "sophia" else torch.optim.Adam(flow.parameters(), lr=1e-6)
     if mode == "train" and under_launcher and world > 1:
         from usflows_amd.parallel import data_parallel_training
         data_parallel_training(flow)                       # one all-reduce of the flat gradient arena per step
@@ -415,7 +421,7 @@ def main():
     metric = {"log_prob": "log_prob samples/sec (whole node), 32-layer 784-dim flow, batch 65536" if headline else
               f"log_prob samples/sec (whole node), {blocks}-layer {D}-dim flow, {args.config}",
               "sample": f"sample() samples/sec (whole node), {blocks}-layer {D}-dim flow",
-              "train": f"training-step samples/sec (forward + backward + Adam), {blocks}-layer {D}-dim flow"}[mode]
+              "train": f"training-step samples/sec (forward + backward + {'SophiaG' if args.optim == 'sophia' else 'Adam'} step), {blocks}-layer {D}-dim flow"}[mode]
     if not on_gpu:
         metric = "[CPU PLUMBING TEST -- not a measurement] " + metric
     if world == 1:

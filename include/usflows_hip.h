@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 11
+#define USF_ABI_VERSION 12
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -448,6 +448,25 @@ int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda,
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream);
 
+/*
+ * SophiaG over all parameter tensors of a model in one launch (sophia.py:39-58 update_hessian, 151-199
+ * _single_tensor_sophiag -- the optimiser Flow.fit defaults to, flows.py:116).  `chunks` is a DEVICE array; a chunk is
+ * one block's share (any length; the host side cuts tensors into pieces of 16 384 elements) of one fp32 parameter
+ * tensor p with its gradient g, momentum m (exp_avg) and Hessian estimate h.
+ *   usf_sophiag_step_f32:    p *= decay (= 1 - lr * weight_decay);  m = m * beta1 + g * one_minus_beta1 (g negated with
+ *                            maximize);  ratio = min(|m| / (rho_bs * h + 1e-15), 1) (rho_bs = rho * bs);
+ *                            p += neg_lr * sign(m) * ratio
+ *   usf_sophiag_hessian_f32: h = h * beta2 + one_minus_beta2 * g * g
+ */
+typedef struct usf_mt_chunk {
+  float* p; const float* g; float* m; float* h;
+  int32_t n; int32_t reserved;
+} usf_mt_chunk;
+int usf_sophiag_step_f32(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1,
+                         float rho_bs, float neg_lr, int32_t maximize, usf_stream_t stream);
+int usf_sophiag_hessian_f32(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2,
+                            usf_stream_t stream);
+
 /* (Leaky)ReLU backward from the saved layer OUTPUT h: d[m,j] *= (h[m,j] > 0 ? 1 : slope), slope >= 0
  * (ATen leaky_relu_backward on the pre-activation; sign(h) == sign(pre-activation)). networks.py:745-749 */
 int usf_act_grad_f32(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
@@ -462,7 +481,7 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;
-                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc for 5|6|7: binding self-check */
+                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc|usf_mt_chunk for 5|6|7|8: binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */
 

@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 11
+USF_ABI_VERSION = 12
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -88,6 +88,11 @@ class CouplingPlanesDesc(C.Structure):
                 ("range_flag", _fp)]
 
 
+class MtChunk(C.Structure):
+    """usf_mt_chunk: one block's share of one parameter tensor (SophiaG multi-tensor kernels)"""
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("h", _fp), ("n", C.c_int32), ("reserved", C.c_int32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc), ("pack_planes", PackPlanesDesc),
                 ("gemm_planes", GemmPlanesDesc), ("coupling_planes", CouplingPlanesDesc)]
@@ -153,6 +158,9 @@ SYMBOLS = {
                                 C.c_float, C.c_float, C.c_int32, _fp, C.c_int64, C.c_void_p]),
     "usf_wgrad_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_variant": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
+    "usf_sophiag_step_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                       C.c_void_p]),
+    "usf_sophiag_hessian_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p]),
     "usf_colsum_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_float, _fp, C.c_int64,
                                  C.c_void_p]),
     "usf_act_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_float,
@@ -189,7 +197,7 @@ def load() -> C.CDLL:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
     for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
                      (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc),
-                     (OP_COUPLING_PLANES, CouplingPlanesDesc)):
+                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -573,3 +581,14 @@ def base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
     _launch("usf_base_logprob_grad_f32", (z.data_ptr(), ldz, g_lp.data_ptr(), M, D, base, loc.data_ptr(),
                                           scale.data_ptr(), g.data_ptr(), ldg, current_stream(z.device)),
             (z, g_lp, loc, scale, g))
+
+
+def sophiag_step(chunks_dev: torch.Tensor, n_chunks: int, *, decay, beta1, rho_bs, lr, maximize=False) -> None:
+    """usf_sophiag_step_f32 on a device table of usf_mt_chunk (see usflows_amd/sophia.py)"""
+    _launch("usf_sophiag_step_f32", (chunks_dev.data_ptr(), n_chunks, decay, beta1, 1.0 - beta1, rho_bs, -lr,
+                                     1 if maximize else 0, current_stream(chunks_dev.device)), keep=chunks_dev)
+
+
+def sophiag_hessian(chunks_dev: torch.Tensor, n_chunks: int, *, beta2) -> None:
+    _launch("usf_sophiag_hessian_f32", (chunks_dev.data_ptr(), n_chunks, beta2, 1.0 - beta2,
+                                        current_stream(chunks_dev.device)), keep=chunks_dev)

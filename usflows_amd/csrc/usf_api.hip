@@ -54,6 +54,9 @@ int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, 
 
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
 int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
+int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
+                 float neg_lr, int32_t maximize, hipStream_t stream);
+int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2, hipStream_t stream);
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
           hipStream_t stream);
@@ -79,6 +82,7 @@ int usf_sizeof_desc(int32_t kind) {
     case USF_OP_PACK_PLANES: return (int)sizeof(usf_pack_planes_desc);
     case USF_OP_GEMM_PLANES: return (int)sizeof(usf_gemm_planes_desc);
     case USF_OP_COUPLING_PLANES: return (int)sizeof(usf_coupling_planes_desc);
+    case 8: return (int)sizeof(usf_mt_chunk);
     default: return -1;
   }
 }
@@ -177,6 +181,14 @@ int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int6
                   int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
                   usf_stream_t stream) {
   return usf::wgrad(Y, ldy, A, lda, M, N, K, G, ldg, alpha, beta, mode, workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_sophiag_step_f32(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1,
+                         float rho_bs, float neg_lr, int32_t maximize, usf_stream_t stream) {
+  return usf::sophiag_step(chunks, n_chunks, decay, beta1, one_minus_beta1, rho_bs, neg_lr, maximize, (hipStream_t)stream);
+}
+int usf_sophiag_hessian_f32(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2,
+                            usf_stream_t stream) {
+  return usf::sophiag_hessian(chunks, n_chunks, beta2, one_minus_beta2, (hipStream_t)stream);
 }
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   return usf::wgrad_variant(M, N, K, ldy, lda, mode);

@@ -794,6 +794,52 @@ int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float 
   return check_launch("usf_colsum_f32");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// SophiaG (sophia.py:151-199: _single_tensor_sophiag, and update_hessian sophia.py:39-58) over ALL parameter tensors
+// of a model in one launch: a table of chunks (one block each) replaces the reference's per-tensor loop of seven
+// elementwise ATen ops.  HBM-bound: 24 bytes per parameter and step (read p, g, m, h; write p, m).
+//   step:     p *= decay;  m = m * beta1 + g' * (1 - beta1);  ratio = min(|m| / (rho_bs * h + 1e-15), 1);
+//             p += neg_lr * sign(m) * ratio            (g' = -g with maximize; the operation order of the reference)
+//   hessian:  h = h * beta2 + (1 - beta2) * g * g
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sophiag_step_kernel(const usf_mt_chunk* __restrict__ chunks, float decay, float beta1,
+                                                           float omb1, float rho_bs, float neg_lr, int maximize) {
+  const usf_mt_chunk c = chunks[blockIdx.x];
+  for (int i = threadIdx.x; i < c.n; i += 256) {
+    float g = c.g[i];
+    if (maximize) g = -g;
+    const float p = c.p[i] * decay;
+    const float m = fmaf(g, omb1, c.m[i] * beta1);        // exp_avg.mul_(beta1).add_(grad, alpha): ATen's add-with-alpha is a fused multiply-add
+    const float ratio = fminf(fabsf(m) / (rho_bs * c.h[i] + 1e-15f), 1.f);
+    const float sg = (float)((m > 0.f) - (m < 0.f));
+    c.m[i] = m;
+    c.p[i] = p + neg_lr * (sg * ratio);
+  }
+}
+
+__global__ __launch_bounds__(256) void sophiag_hessian_kernel(const usf_mt_chunk* __restrict__ chunks, float beta2, float omb2) {
+  const usf_mt_chunk c = chunks[blockIdx.x];
+  for (int i = threadIdx.x; i < c.n; i += 256) {
+    const float g = c.g[i];
+    c.h[i] = c.h[i] * beta2 + omb2 * (g * g);
+  }
+}
+
+int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
+                 float neg_lr, int32_t maximize, hipStream_t stream) {
+  if (n_chunks < 0 || n_chunks > 0x7fffffff || (!chunks && n_chunks > 0)) { set_error("usf_sophiag_step_f32: bad arguments"); return -1; }
+  if (n_chunks == 0) return 0;
+  sophiag_step_kernel<<<(unsigned)n_chunks, 256, 0, stream>>>(chunks, decay, beta1, one_minus_beta1, rho_bs, neg_lr, maximize);
+  return check_launch("usf_sophiag_step_f32");
+}
+
+int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2, hipStream_t stream) {
+  if (n_chunks < 0 || n_chunks > 0x7fffffff || (!chunks && n_chunks > 0)) { set_error("usf_sophiag_hessian_f32: bad arguments"); return -1; }
+  if (n_chunks == 0) return 0;
+  sophiag_hessian_kernel<<<(unsigned)n_chunks, 256, 0, stream>>>(chunks, beta2, one_minus_beta2);
+  return check_launch("usf_sophiag_hessian_f32");
+}
+
 int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
              hipStream_t stream) {
   if (!d || !h || M < 0 || H < 0 || ldd < H || ldh < H) { set_error("usf_act_grad_f32: bad arguments"); return -1; }

@@ -304,9 +304,10 @@ class Flow(torch.nn.Module):
             shuffle: bool = True, gradient_clip: float = None, device: torch.device = None, epochs: int = 1):
         """Maximum-posterior fitting loop with the reference's semantics (flows.py:113-210):
         loss = -log_prob(batch).mean() - log_prior(); feasibility check after every step.
-        ``optim`` defaults to Adam here (the reference's SophiaG optimizer is out of scope)."""
+        ``optim`` defaults to SophiaG as in the reference (flows.py:116; usflows_amd/sophia.py)."""
         if optim is None:
-            optim = torch.optim.Adam
+            from .sophia import SophiaG
+            optim = SophiaG
         if device is None:
             device = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
         model = self.to(device)
