@@ -212,7 +212,7 @@ class Flow(torch.nn.Module):
                 if dp:
                     raise RuntimeError("usflows_amd: data_parallel_training: this layer list has no device backward")
                 self._train_failed = True          # this layer list has no device backward: composite from now on
-        log_det = torch.zeros(x.shape[0]).to(x.device)
+        log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
         for layer in reversed(self.layers):
             if context is not None:
                 y = layer.backward(x, context=context)
@@ -221,7 +221,38 @@ class Flow(torch.nn.Module):
                 y = layer.backward(x)
                 log_det = log_det - layer.log_abs_det_jacobian(y, x)
             x = y
-        return self.base_distribution.log_prob(y) + log_det
+        lp = self._base_log_prob_layer_loop(y)
+        return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
+
+    def _base_log_prob_layer_loop(self, y: torch.Tensor):
+        """Laplace / Normal base density of the layer loop's result through ``usf_base_logprob_f32`` (rows flattened) when
+        nothing needs a gradient: one launch instead of the distribution object's op chain, whose argument validation
+        (``_validate_sample``) synchronises the host with the device on every call.  None: not applicable."""
+        if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() >= 2 and y.shape[0] > 0) \
+                or (torch.is_grad_enabled() and (y.requires_grad or _needs_grad(self, y, None))):
+            return None
+        d, n_ind = self.base_distribution, 0
+        if isinstance(d, DistributionModule):
+            return None
+        while isinstance(d, tdist.Independent):
+            n_ind += d.reinterpreted_batch_ndims
+            d = d.base_dist
+        ev = tuple(y.shape[1:])
+        if not isinstance(d, (tdist.Laplace, tdist.Normal)) or n_ind != len(ev) or tuple(d.batch_shape) != ev:
+            return None
+        key = (id(d), d.loc.data_ptr(), d.loc._version, d.scale.data_ptr(), d.scale._version, str(y.device), ev)
+        cache = getattr(self, "_base_loop_cache", None)
+        if cache is None or cache[0] != key:
+            loc = d.loc.detach().to(device=y.device, dtype=torch.float32).expand(ev).reshape(-1).contiguous()
+            scale = d.scale.detach().to(device=y.device, dtype=torch.float32).expand(ev).reshape(-1).contiguous()
+            cache = self._base_loop_cache = (key, loc, scale)
+        _ext.load()
+        B, D = y.shape[0], cache[1].numel()
+        yf = y.reshape(B, D).contiguous()
+        out = torch.empty(B, dtype=torch.float32, device=y.device)
+        _ext.base_logprob(yf, D, B, D, _ext.BASE_LAPLACE if isinstance(d, tdist.Laplace) else _ext.BASE_NORMAL, cache[1], cache[2],
+                          0.0, out)
+        return out
 
     def _log_prob_device(self, x, context=None, sum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         eng = self.engine()
@@ -462,7 +493,7 @@ class USFlow(Flow):
     def log_prob(self, x: torch.Tensor, context: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.soft_training and context is None:
             # implicit conditioning with noise scale 0 (flows.py:559-565)
-            context = torch.zeros(x.shape[0]).unsqueeze(-1).to(x.device)
+            context = torch.zeros(x.shape[0], 1, device=x.device)
         return super().log_prob(x, context)
 
     def sample(self, sample_shape: Iterable[int] = None, context: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
