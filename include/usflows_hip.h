@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 12
+#define USF_ABI_VERSION 13
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -150,14 +150,16 @@ int usf_coupling_padded_width(int h);   /* Hp of the padding contract for hidden
 
 /*
  * Tail of Flow.log_prob (flows.py:245): per-sample reduction over the feature axis.
- *   LAPLACE/NORMAL: logp[m] = sum_d base_d(z[m,d]) + logdet_const
+ *   LAPLACE/NORMAL: logp[m] = sum_d base_d(z[m,d]) + logdet_const (+ (float)*logdet_dev when logdet_dev != NULL: the
+ *                   flow's parameter-only log-det as a DEVICE fp64 scalar, so that a caller whose parameters just changed
+ *                   -- every optimiser step -- does not read it back to the host first)
  *   LPNORM*:        logp[m] = ||z[m,:] - loc||_p   (the caller finishes RadialDistribution.log_prob
  *                             on the [M] vector: distributions.py:506-511)
  * loc/scale: [D] (scale unused for LPNORM*). If sum_out != NULL, sum_out[0] += sum_m logp[m] and
  * sum_out[1] += M (fp64 accumulators, for the data-parallel mean: one RCCL all-reduce of 2 scalars).
  */
 int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base,
-                         const float* loc, const float* scale, float logdet_const,
+                         const float* loc, const float* scale, float logdet_const, const double* logdet_dev,
                          float* logp, double* sum_out, usf_stream_t stream);
 
 /*

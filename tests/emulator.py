@@ -406,7 +406,9 @@ def _emu_act_grad(d, h, *, M, H, ldd, ldh, act, slope):
     dv.copy_(torch.where(hv > 0, dv, dv * slope))
 
 
-def _emu_base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):
+def _emu_base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None, logdet_dev=None):
+    if logdet_dev is not None:
+        logdet_const = float(logdet_const) + float(logdet_dev.float())
     zz = _view(z, 0, M, D, ldz).double()
     if base in (_ext.BASE_LPNORM1, _ext.BASE_LPNORM2, _ext.BASE_LPNORMINF):
         p = {_ext.BASE_LPNORM1: 1.0, _ext.BASE_LPNORM2: 2.0}.get(base, float("inf"))
@@ -499,4 +501,4 @@ def engine_latent(eng, x, context=None, fused=False, planes=False):
     plan = eng._plan("backward", x.shape[0], x.device, context is not None, "nat")
     run_plan(eng, plan, x.contiguous(), None, context)
     buf = plan["ws"][plan["out_buf"][0]]
-    return buf[:, : eng.D].clone(), -plan["pk"]["ladj_total"]
+    return buf[:, : eng.D].clone(), -float(plan["pk"]["ladj_total"])

@@ -96,4 +96,4 @@ def test_pack_cache_invalidation():
         flow.layers[-1].scale.mul_(2.0)          # in-place update bumps the version counter
     p2 = eng.pack(torch.device("cpu"))
     assert p2 is not p1
-    assert abs((p2["ladj_total"] - p1["ladj_total"]) - 7 * torch.log(torch.tensor(2.0)).item()) < 1e-6
+    assert abs((float(p2["ladj_total"]) - float(p1["ladj_total"])) - 7 * torch.log(torch.tensor(2.0)).item()) < 1e-6

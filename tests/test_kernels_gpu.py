@@ -208,6 +208,12 @@ def test_base_logprob(base, M, D):
                linf=ext.BASE_LPNORMINF)
     ext.base_logprob(z.to(dev), ld, M, D, ids[base], loc.to(dev), sc.to(dev), const, out, acc)
     torch.cuda.synchronize()
+    if base in ("laplace", "normal"):
+        # the same constant as a device fp64 scalar (what the engine passes: no host read-back): identical bits
+        out2 = torch.empty(M, device=dev)
+        ext.base_logprob(z.to(dev), ld, M, D, ids[base], loc.to(dev), sc.to(dev), 0.0, out2, None,
+                         logdet_dev=torch.tensor(const, dtype=torch.float64, device=dev))
+        assert torch.equal(out, out2)
     zz = z[:, :D].double()
     l64, s64 = loc.double(), sc.double()
     if base == "laplace":

@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 12
+USF_ABI_VERSION = 13
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -135,7 +135,7 @@ SYMBOLS = {
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
     "usf_base_logprob_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_float,
-                                       _fp, _fp, C.c_void_p]),
+                                       _fp, _fp, _fp, C.c_void_p]),
     "usf_base_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
                                       C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_radial_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
@@ -368,9 +368,11 @@ def gemm_planes(A, W_planes, *, M, a_nkb, nk, a_kb0=0, bias=None, post_mul=None,
             (d, A, W_planes, bias, post_mul, residual, C_planes, C_f32))
 
 
-def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None):
+def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None, logdet_dev=None):
+    """logdet_dev: optional fp64 device scalar added to logdet_const by the kernel (no host read-back of the constant)"""
     _launch("usf_base_logprob_f32", (z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), float(logdet_const),
-                                     out.data_ptr(), ptr(sum_out), current_stream(z.device)))
+                                     ptr(logdet_dev), out.data_ptr(), ptr(sum_out), current_stream(z.device)),
+            keep=logdet_dev)
 
 
 def base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset=0):

@@ -21,7 +21,8 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 int coupling_max_width();
 int coupling_padded_width(int h);
 int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
-                 const float* scale, float logdet_const, float* logp, double* sum_out, hipStream_t stream);
+                 const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
+                 hipStream_t stream);
 int base_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* scale,
                 uint64_t seed, uint64_t offset, int64_t row_offset, hipStream_t stream);
 int radial_sample(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
@@ -108,8 +109,9 @@ int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }
 
 int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
-                         const float* scale, float logdet_const, float* logp, double* sum_out, usf_stream_t stream) {
-  return usf::base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, logp, sum_out, (hipStream_t)stream);
+                         const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
+                         usf_stream_t stream) {
+  return usf::base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, logdet_dev, logp, sum_out, (hipStream_t)stream);
 }
 
 int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,

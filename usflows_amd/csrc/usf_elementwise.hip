@@ -32,7 +32,9 @@ template <int BASE>
 __global__ __launch_bounds__(256) void base_logprob_kernel(const float* __restrict__ z, int64_t ldz, int M, int D,
                                                            const float* __restrict__ loc,
                                                            const float* __restrict__ scale, float logdet_const,
+                                                           const double* __restrict__ logdet_dev,
                                                            float* __restrict__ logp, double* __restrict__ sum_out) {
+  if (logdet_dev) logdet_const += (float)*logdet_dev;      // the constant as a device scalar: no host round trip
   extern __shared__ __attribute__((aligned(16))) float cst_tab[];      // [D4 rounded] per-feature constants (or empty)
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(256) void base_logprob_kernel(const float* __restri
 __global__ void add_count_kernel(double* sum_out, double n) { sum_out[1] += n; }
 
 int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
-                 const float* scale, float logdet_const, float* logp, double* sum_out, hipStream_t stream) {
+                 const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
+                 hipStream_t stream) {
   if (M < 0 || D <= 0 || M > 0x7fffffff || D > 0x7fffffff || ldz < D) { set_error("usf_base_logprob_f32: bad sizes"); return -2; }
   if (M == 0) return 0;
   if (!z || !loc || !logp) { set_error("usf_base_logprob_f32: null pointer"); return -1; }
@@ -115,7 +118,7 @@ int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base
       if (attr_rc != hipSuccess) { set_error("usf_base_logprob_f32: cannot raise the LDS limit"); return (int)attr_rc; } \
     }                                                                                                                 \
     hipLaunchKernelGGL((base_logprob_kernel<B>), g, b, tab, stream, z, ldz, (int)M, (int)D, loc, scale, logdet_const, \
-                       logp, sum_out);                                                                                \
+                       logdet_dev, logp, sum_out);                                                                                \
   } while (0)
   switch (base) {
     case USF_BASE_LAPLACE: USF_LAUNCH_BASE(USF_BASE_LAPLACE); break;

@@ -110,6 +110,32 @@ def _param(t: torch.Tensor, device=None) -> torch.Tensor:
     return t
 
 
+class LogDet:
+    """Sum of the layers' log|det J| (parameter-only for these flows: flows.py:236-245).  ``neg_dev`` is a persistent
+    fp64 device scalar holding MINUS the total (what log_prob adds); kernels take its pointer
+    (``usf_base_logprob_f32(logdet_dev=...)``), torch expressions the tensor.  ``float(obj)`` is the total as a Python
+    float -- the one host read-back, done on demand and cached until the next refresh."""
+    __slots__ = ("neg_dev", "_val")
+
+    def __init__(self, neg_dev):
+        self.neg_dev, self._val = neg_dev, (0.0 if neg_dev is None else None)
+
+    def refresh(self, total: torch.Tensor) -> None:
+        torch.neg(total, out=self.neg_dev)
+        self._val = None
+
+    def __float__(self) -> float:
+        if self._val is None:
+            self._val = -float(self.neg_dev.item())
+        return self._val
+
+    def neg32(self, device) -> torch.Tensor:
+        """-total as a 0-dim fp32 tensor on ``device`` (for torch-side sums)"""
+        if self.neg_dev is None:
+            return torch.zeros((), dtype=torch.float32, device=device)
+        return self.neg_dev.to(torch.float32)
+
+
 def _refreshed(shape, dtype, device, fn) -> torch.Tensor:
     """persistent tensor filled by fn(out) now and again on every replay of the pack tape"""
     out = torch.empty(shape, dtype=dtype, device=device)
@@ -348,10 +374,10 @@ class FlowEngine:
 
     @staticmethod
     def _perm_vec(v64: torch.Tensor, idx: torch.Tensor, pad: float) -> torch.Tensor:
+        # (no boolean-mask indexing, no host index tensor: both would synchronise the host on every pack refresh,
+        # i.e. on every optimiser step)
         idx = idx.to(v64.device)
-        out = torch.full((idx.numel(),), pad, dtype=torch.float64, device=v64.device)
-        ok = idx >= 0
-        out[ok] = v64[idx[ok]]
+        out = torch.where(idx >= 0, v64[idx.clamp(min=0).long()], torch.full((), pad, dtype=torch.float64, device=v64.device))
         return out.float().contiguous()
 
     def _ptr_key(self, device):
@@ -407,13 +433,20 @@ class FlowEngine:
         return pk
 
     @staticmethod
-    def _ladj_total(pk) -> float:
+    def _ladj_total(pk) -> "LogDet":
+        """the flow's parameter-only log|det J| as a LogDet: refreshed in place on the device after every parameter
+        change, read back to the host only when somebody asks for the Python float"""
+        ld = pk.get("ladj_total")
         terms = pk["ladj_terms"]
         if not terms:
-            return 0.0
+            return ld if ld is not None else LogDet(None)
         if "ladj_signs" not in pk:
-            pk["ladj_signs"] = torch.tensor([t[0] for t in terms], dtype=torch.float64, device=terms[0][1].device)
-        return float((torch.stack([t[1].reshape(()) for t in terms]) * pk["ladj_signs"]).sum().item())
+            pk["ladj_signs"] = torch.tensor([t[0] for t in terms], dtype=torch.float64).to(terms[0][1].device)
+        total = (torch.stack([t[1].reshape(()) for t in terms]) * pk["ladj_signs"]).sum()
+        if ld is None:
+            ld = LogDet(torch.empty((), dtype=torch.float64, device=total.device))
+        ld.refresh(total)
+        return ld
 
     def _pk_record(self, pk):
         """context: launches of a lazily built pack item join the pack's tape (refreshed on replay)"""
@@ -596,7 +629,7 @@ class FlowEngine:
                 else:
                     n = int(self._idx(layout).numel())
                     pk["vecs"][key] = _refreshed((n,), torch.float32, v64.device,
-                                                 lambda o: o.copy_(self._perm_vec(v64, self._idx(layout), pad)))
+                                                 lambda o: o.copy_(self._perm_vec(v64, self._idx_dev(layout, v64.device), pad)))
         return pk["vecs"][key]
 
     # ---- workspace ----------------------------------------------------------------------------
@@ -897,8 +930,9 @@ class FlowEngine:
                                  ld_src=src.numel())
                 vecs[key] = out
             else:
+                sel_dev = sel.to(dev)                    # (once: a host index in the refresh would synchronise every step)
                 vecs[key] = _refreshed((n,), torch.float32, dev,
-                                       lambda o, src=src, sel=sel: o.copy_(self._perm_vec(src.double(), sel, pad)))
+                                       lambda o, src=src, sel=sel_dev: o.copy_(self._perm_vec(src.double(), sel, pad)))
         return vecs[key]
 
     def _build_plan_planes(self, direction: str, B: int, device, final: str) -> dict:
@@ -1377,12 +1411,12 @@ class FlowEngine:
         self._run_guarded(direction, x, out, context, "user")
         return out
 
-    def latent(self, x: torch.Tensor, context=None) -> Tuple[torch.Tensor, int, float]:
-        """backward pass into the workspace: (z buffer [B, ldn], ldn, -sum ladj)."""
+    def latent(self, x: torch.Tensor, context=None) -> Tuple[torch.Tensor, int, "LogDet"]:
+        """backward pass into the workspace: (z buffer [B, ldn], ldn, the flow's LogDet)."""
         x = self._check_input(x)
         plan = self._run_guarded("backward", x, None, context, "nat")
         buf = plan["ws"][plan["out_buf"][0]]
-        return buf, plan["out_buf"][2], -plan["pk"]["ladj_total"]
+        return buf, plan["out_buf"][2], plan["pk"]["ladj_total"]
 
     def ladj_total(self, device) -> float:
-        return self.pack(device)["ladj_total"]
+        return float(self.pack(device)["ladj_total"])

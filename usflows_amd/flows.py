@@ -265,19 +265,19 @@ class Flow(torch.nn.Module):
         if info is None:
             # arbitrary torch base distribution: density evaluated by the distribution object itself
             z = zbuf[:, : eng.D]
-            res = self.base_distribution.log_prob(z) + logdet
+            res = self.base_distribution.log_prob(z) + logdet.neg32(z.device)
             if sum_out is not None:
                 sum_out[0] += res.double().sum()
                 sum_out[1] += B
             return res
         if info[0] in ("laplace", "normal"):
             base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
-            _ext.base_logprob(zbuf, ldz, B, eng.D, base, info[1], info[2], logdet, out, sum_out)
+            _ext.base_logprob(zbuf, ldz, B, eng.D, base, info[1], info[2], 0.0, out, sum_out, logdet_dev=logdet.neg_dev)
             return out
         p = info[2]
         base = {1.0: _ext.BASE_LPNORM1, 2.0: _ext.BASE_LPNORM2}.get(p, _ext.BASE_LPNORMINF)
         _ext.base_logprob(zbuf, ldz, B, eng.D, base, info[1], None, 0.0, out, None)
-        res = self.base_distribution.log_prob_from_radius(out) + logdet     # O(B) finishing math
+        res = self.base_distribution.log_prob_from_radius(out) + logdet.neg32(out.device)     # O(B) finishing math
         if sum_out is not None:
             sum_out[0] += res.double().sum()
             sum_out[1] += B

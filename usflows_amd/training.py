@@ -111,7 +111,8 @@ class TrainPath:
             _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, None, 0.0, rbuf, None)
             return rbuf.clone(), plan, x, gen
         lp = torch.empty(B, dtype=torch.float32, device=dev)
-        _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, scale, -plan["pk"]["ladj_total"], lp, None)
+        _ext.base_logprob(plan["ws"][zname], ldn, B, eng.D, base, loc, scale, 0.0, lp, None,
+                          logdet_dev=plan["pk"]["ladj_total"].neg_dev)
         return lp, plan, x, gen
 
     def revalidate(self, ctx):
@@ -895,7 +896,7 @@ class _RadiusFn(torch.autograd.Function):
         r, plan, xc, gen = path.forward(x, context)
         ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
         ctx.params = params
-        logdet = torch.full((), -plan["pk"]["ladj_total"], dtype=torch.float32, device=r.device)
+        logdet = plan["pk"]["ladj_total"].neg32(r.device)
         return r, logdet
 
     @staticmethod
