@@ -54,9 +54,10 @@ with open(os.path.join(out, f"{tag}_bench_kernel_stats.csv"), "w") as f:
 with open(os.path.join(out, f"{tag}_bench_kernel_stats.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py`\n\n"
             "Command (GPU box): `rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py`\n"
-            "(defaults: --gpus 1 --steps 10 --warmup 3, gemm_mode bf16x3; per pass 33 affine launches (1 with the\n"
-            "scale/bias prologue) + 32 fused coupling launches + 1 tail; the CPU-baseline leg and the first\n"
-            "(parameter-prep) call add the torch/rocBLAS kernels at the bottom)\n\n"
+            "(defaults: --gpus 1 --steps 10 --warmup 3, gemm_mode bf16x3, planes pipeline; per pass 1 pack + 33 affine GEMMs on\n"
+            "planes (the last with fp32 output) + 32 fused couplings on planes + 1 tail; the same process then measures the\n"
+            "opt-in fp16x2 mode (the <2, ...> instantiations); the CPU-baseline leg and the first (parameter-prep) call add\n"
+            "the torch/rocBLAS kernels at the bottom)\n\n"
             "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
     for row in rows[:14]:
         name = row["Name"]
@@ -233,7 +234,8 @@ rows = list(csv.DictReader(open(stats[0])))
 with open(os.path.join(out, f"{tag}_train_kernel_stats.md"), "w") as f:
     f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --mode train --steps 5 --warmup 2`\n\n"
             "One step = Flow.log_prob under autograd (device forward with saved activations) + hand-derived device backward\n"
-            "+ Adam, cfg2 model, 65536 rows; 7 steps in the trace (+ the first, recording, one).\n\n"
+            "+ SophiaG step (the reference's Flow.fit default), cfg2 model, 65536 rows; 7 steps in the trace (+ the first,\n"
+            "recording, one).\n\n"
             "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
     for row in rows[:18]:
         name = row["Name"]
