@@ -86,7 +86,10 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
   constexpr int NPP = NST / NPL;            // ... per plane
   constexpr int NC = HP / 8;                // 16-B chunks per n-tile row
   constexpr int NPR = (NPL == 3) ? 6 : 3;   // MFMAs per (tile, operand) product
-  constexpr int AHEAD = 3;                  // weight fragments are read this many tiles ahead of their MFMAs
+#ifndef USF_CP_AHEAD
+#define USF_CP_AHEAD 3
+#endif
+  constexpr int AHEAD = USF_CP_AHEAD;       // weight fragments are read this many tiles ahead of their MFMAs
   __shared__ __attribute__((aligned(16))) float lds[2][SLOTS * 4];
 
   const int tid = threadIdx.x;
@@ -164,7 +167,9 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
 #pragma unroll
       for (int q = 0; q < NPL; ++q) w[q] = *reinterpret_cast<const vec8*>(wl + 4 * ((q * 4) * HP + ht * 16));
       // issue priority alternates tile by tile so that the two waves of a SIMD advance in step (usf_coupling_bf16x3.hip)
+#ifndef USF_CP_NOPRIO
       if (ht & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+#endif
       PT::mm(X[ht], w, b);
     }
   };
