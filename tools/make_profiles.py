@@ -187,12 +187,14 @@ for k, dct in sorted(agg.items()):
     f_ = sum(dct["FETCH_SIZE"]) / max(1, len(dct["FETCH_SIZE"]))
     w_ = sum(dct["WRITE_SIZE"]) / max(1, len(dct["WRITE_SIZE"]))
     kern[k] = {"FETCH_SIZE_KB": round(f_, 1), "WRITE_SIZE_KB": round(w_, 1), "dispatches": len(dct["FETCH_SIZE"]),
-               "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
+               "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024),
+               "algorithmic_bytes_per_launch": {"gemm_planes_kernel": 2 * B * 800 * 4 + 2 * 800 * 800 * 2,
+                                                "coupling_planes_kernel": 3 * 13 * 32 * B * 4 + 2 * 2 * (H * 416 + H * H + 416 * H)
+                                                }.get(k.split("<")[0])}
 json.dump({
     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --gemm f16x2 --steps 2 --warmup 1 "
               "--no-cpu-baseline --no-kernel-timing`, MI355X; tools/make_profiles.py",
-    "units": "as in the bf16x3 file; gemm_planes_kernel<2, 5, false> entries average over the affine launches (800 -> 800: "
-             "algorithmic 2 x 65536 x 800 x 4 B = 419 MB) AND the conditioner's last layer (256 -> 416 with the in-place residual)",
+    "units": "as in the bf16x3 file (fp16x2 planes: 4 bytes per element)",
     "kernels": kern}, open(os.path.join(out, f"{tag}_hbm_traffic_f16x2.json"), "w"), indent=1)
 
 # 3d. what the chip sustains on the split-precision instruction mix (register / LDS operand loops; tools/exp_mfma_peak.hip)
