@@ -200,28 +200,6 @@ __device__ __forceinline__ void wb_split(const float (&x)[8], bf16x8_t& p1, bf16
   }
 }
 
-__device__ __forceinline__ void wb_load(const float* __restrict__ P, int64_t ld, int m0, int m_end, int c0, int ncols,
-                                        int tid, f32x4 (&r)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (tid >> 5) + 8 * i;
-    const int col = c0 + (tid & 31) * 4;
-    const int m = m0 + row;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m < m_end) {
-      const float* p = P + (int64_t)m * ld + col;
-      if (col + 3 < ncols) {
-        v = *reinterpret_cast<const f32x4*>(p);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (col + e < ncols) v[e] = p[e];
-      }
-    }
-    r[i] = v;
-  }
-}
-
 // Cooperative split: the block turns each 32 x 128 slab of Y and of A into bf16 planes ONCE (thread = 8 rows x 4
 // columns: 8 coalesced 16-byte row loads, 4 column slices of 8 rows -> 4 x 3 bf16x8 units) and leaves them in LDS in
 // fragment order [plane][k-group g][column] -- a fragment read is then a single conflict-free ds_read_b128 per plane

@@ -69,7 +69,8 @@ class SophiaG(Optimizer):
     def _table(self, gi: int, ps: List[torch.Tensor]):
         """device table of usf_mt_chunk for the tensors ``ps`` of group ``gi`` (rebuilt when a pointer moved)"""
         from . import _ext
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["hessian"].data_ptr())
+                    for p in ps)
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
