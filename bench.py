@@ -62,6 +62,8 @@ def parse_args(argv=None):
     ap.add_argument("--gemm", choices=["bf16x3", "f16x2", "f32"], default=None,
                     help="GEMM arithmetic: bf16x3 = 3-way bf16 split (24 bits/operand, 6 MFMAs per product), f16x2 = 2-way "
                          "fp16 split in the planes pipeline (22 bits/operand, 3 MFMAs per product), f32 = exact-f32 MFMA")
+    ap.add_argument("--merge-affine", action="store_true",
+                    help="inference: consecutive affine maps (--conj) as one composed D x D map (FlowEngine.merge_affine)")
     ap.add_argument("--optim", choices=["sophia", "adam"], default="sophia",
                     help="--mode train: SophiaG (the reference's Flow.fit default) or torch's Adam")
     ap.add_argument("--mode", choices=["log_prob", "sample", "train"], default=None,
@@ -137,6 +139,8 @@ def main():
         if eng is None:
             raise RuntimeError("bench.py: the flow has no device engine -- refusing to time a fallback")
         eng.use_fused_coupling = not args.unfused
+        if args.merge_affine:
+            eng.merge_affine = True      # opt-in: consecutive affine maps (affine_conjugation) composed at pack time
         if args.fused_min_rows is not None:
             eng.fused_min_rows = args.fused_min_rows
         if args.gemm:
@@ -448,7 +452,8 @@ def main():
                                   f"({global_rows} over {world} GPU(s)) resident in HBM; conditioned synthetic parameters "
                                   f"(seed 100, alpha 0.1)",
                       "rows_per_gpu": B, "global_rows": global_rows, "parallelism": par,
-                      "fused_coupling": not args.unfused, "gemm_mode": eng.gemm_mode if on_gpu else "torch-cpu"},
+                      "fused_coupling": not args.unfused, "gemm_mode": eng.gemm_mode if on_gpu else "torch-cpu",
+                      "merge_affine": bool(args.merge_affine)},
            "flow_algorithmic_tflops_per_gpu": round(flow_tflops, 2),
            "flow_frac_of_f32_mfma_peak": round(flow_tflops / F32_MFMA_PEAK_TFLOPS, 4),
            "param_prep_first_call_s": round(prep_s, 3),

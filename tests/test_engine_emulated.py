@@ -43,6 +43,37 @@ def test_engine_ops_reproduce_golden(name, fused):
     assert rel < 2e-5, rel
 
 
+@pytest.mark.parametrize("planes", [None, "bf16x3"])
+@pytest.mark.parametrize("name", [n for n in SMALL if "conj" in n])
+def test_merged_affine_runs_reproduce_golden(name, planes):
+    """opt-in engine.merge_affine: block_i^-1 and block_(i+1) between two couplings (affine_conjugation) as ONE composed
+    map -- fewer GEMM ops in the list, the same outputs (well-conditioned cases to the usual tolerance; the
+    default-initialised ones, where the composite rounds differently from the reference's one-by-one fp32 products, to 3e-5:
+    why the switch is off by default)"""
+    from usflows_amd import _ext
+    spec, sd, a = load_case(name)
+    if a.get("context") is not None or spec.soft_training:
+        pytest.skip("context flows stay on the fp32-activation path, covered by the fp32 variant of another case")
+    counts = {}
+    for merge in (False, True):
+        flow = build_flow(spec, sd)
+        eng = FlowEngine(flow.layers)
+        eng.merge_affine = merge
+        z = emulator.engine_transform(eng, a["x"], "backward", None, True, planes=planes)
+        xf = emulator.engine_transform(eng, a["zin"], "forward", None, True, planes=planes)
+        zl, logdet = emulator.engine_latent(eng, a["x"], None, True, planes=planes)
+        lp = orc.base_log_prob(spec, zl.double(), orc.to_dtype(sd, torch.float64)) + logdet
+        rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
+        loose = name.startswith("init_")
+        assert rel < (3e-5 if loose else 2e-6), (merge, rel)
+        assert (z.double() - a["backward64"]).abs().max().item() < (3 if loose else 1) * _tol(a["backward64"])
+        assert (xf.double() - a["forward64"]).abs().max().item() < (3 if loose else 1) * _tol(a["forward64"])
+        kinds = (_ext.OP_LINEAR, _ext.OP_GEMM_PLANES)
+        counts[merge] = min(sum(1 for j in range(p["n"]) if p["arr"][j].kind in kinds and p["arr"][j].u.linear.M != 0 or
+                                p["arr"][j].kind == _ext.OP_GEMM_PLANES) for p in eng._plans.values())
+    assert counts[True] < counts[False], counts
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", SMALL)

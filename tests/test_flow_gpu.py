@@ -366,3 +366,35 @@ def test_radial_base_with_gammamm_norm_on_device():
     # UDL: log_prob(x) - base.log_prob(z) is one constant
     c = lp.double() - flow.base_distribution.log_prob(z).double()
     assert (c - c.mean()).abs().max().item() < 1e-4 * max(1.0, abs(c.mean().item()))
+
+
+@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("name", [n for n in case_names() if "conj" in n and "cfg4" not in n])
+def test_merged_affine_runs_on_device(name, planes):
+    """opt-in FlowEngine.merge_affine (consecutive affine maps of a conjugated flow composed at pack time): golden parity
+    on the device in both activation formats -- 1e-5 on the conditioned cases, 3e-5 on the default-initialised ones (the
+    reason the switch is opt-in) -- and fewer launches than the one-by-one plan"""
+    spec, sd, a = load_case(name)
+    if a.get("context") is not None or spec.soft_training:
+        pytest.skip("context flows: training / soft-training plans are never merged")
+    counts = {}
+    for merge in (False, True):
+        flow = build_flow(spec, sd, device=DEV)
+        eng = flow.engine()
+        eng.merge_affine = merge
+        eng.fused_min_rows = 0
+        if planes:
+            eng.use_planes, eng.planes_min_rows = True, 0
+        x, zin = a["x"].to(DEV), a["zin"].to(DEV)
+        with torch.no_grad():
+            lp = flow.log_prob(x)
+            z = flow.backward(x)
+            xf = flow._forward(zin)
+        tol = 3e-5 if name.startswith("init_") else RTOL
+        assert _rel(lp, a["log_prob64"]) < tol, (name, merge)
+        s = max(1.0, a["backward64"].abs().max().item())
+        assert (z.cpu().double() - a["backward64"]).abs().max().item() < 2 * tol * s
+        s = max(1.0, a["forward64"].abs().max().item())
+        assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2 * tol * s
+        counts[merge] = min(p["n"] for p in eng._plans.values())
+    assert counts[True] < counts[False], counts

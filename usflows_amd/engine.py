@@ -68,6 +68,17 @@ class _Step:
     inverted: bool       # wrapped in InverseTransform
 
 
+class _MergedAffine:
+    """Stand-in block for a run of consecutive affine steps of one direction (inference plans only): with
+    ``affine_conjugation`` every coupling is followed by block_i^-1 and block_(i+1), two dense D x D maps with nothing
+    in between -- applied as ONE map y = (W2 W1) x + (W2 c1 + c2) composed in fp64 at pack time (half the affine GEMMs
+    of such a flow; the reference applies them one by one).  ``pk["affine"][id(self)]`` holds the composite as the M / b
+    of an ``affine_fwd`` step."""
+
+    def __init__(self, parts):
+        self.parts = parts          # [(prim, block)] in application order
+
+
 def _analyze(layers: Sequence[nn.Module]) -> List[_Step]:
     steps = []
     for l in layers:
@@ -250,6 +261,14 @@ class FlowEngine:
         self._pack_key = None
         self._plans: Dict[tuple, dict] = {}
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
+        # opt-in (USFLOWS_AMD_MERGE_AFFINE=1 / engine.merge_affine = True, set before the first call): consecutive affine
+        # steps of an inference plan run as ONE composed map (_MergedAffine) -- with affine_conjugation that halves the
+        # D x D GEMMs.  Off by default: the reference applies the maps one by one in fp32, and on badly conditioned
+        # (default-initialised) blocks the composite rounds differently -- golden init_d7_k2_hh1_conj_laplace: relative
+        # log_prob error 4e-6 one by one, 1.0e-5 composed (well-conditioned flows: unchanged, 5e-8 .. 1.5e-7)
+        self.merge_affine = os.environ.get("USFLOWS_AMD_MERGE_AFFINE", "0") == "1"
+        self._virtual: List[_Step] = []          # merged steps, addressed as step index len(self.steps) + n
+        self._virtual_ix: Dict[tuple, int] = {}
         self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
         self.op_timing = None          # set to a list to record (tag, start_event, end_event) per op (bench.py)
         self.use_fused_coupling = True
@@ -648,8 +667,12 @@ class FlowEngine:
         return ws
 
     # ---- plan construction --------------------------------------------------------------------
-    def _primitive_ops(self, direction: str):
-        """[(prim, step_index)] with prim in scale_mul/scale_div/affine_fwd/affine_bwd/coupling_fwd/coupling_bwd"""
+    def _step(self, i: int) -> _Step:
+        return self.steps[i] if i < len(self.steps) else self._virtual[i - len(self.steps)]
+
+    def _primitive_ops(self, direction: str, merge: bool = False):
+        """[(prim, step_index)] with prim in scale_mul/scale_div/affine_fwd/affine_bwd/coupling_fwd/coupling_bwd;
+        merge: runs of consecutive affine steps become one ``affine_fwd`` on a ``_MergedAffine`` (``_step(index)``)"""
         seq = list(enumerate(self.steps))
         if direction == "backward":
             seq = seq[::-1]
@@ -662,7 +685,53 @@ class FlowEngine:
                 prims.append(("affine_fwd" if fwd else "affine_bwd", i))
             else:
                 prims.append(("coupling_fwd" if fwd else "coupling_bwd", i))
-        return prims
+        if not (merge and self.merge_affine):
+            return prims
+        out, k = [], 0
+        while k < len(prims):
+            j = k
+            while j < len(prims) and prims[j][0] in ("affine_fwd", "affine_bwd"):
+                j += 1
+            if j - k >= 2:
+                parts = [(p_, self.steps[i_].module) for p_, i_ in prims[k:j]]
+                key = tuple((p_, id(b_)) for p_, b_ in parts)
+                if key not in self._virtual_ix:
+                    self._virtual.append(_Step("affine", _MergedAffine(parts), False))
+                    self._virtual_ix[key] = len(self.steps) + len(self._virtual) - 1
+                out.append(("affine_fwd", self._virtual_ix[key]))
+                k = j
+            else:
+                out.append(prims[k])
+                k += 1
+        return out
+
+    def _affine_entry(self, pk, blk) -> dict:
+        """pk["affine"] entry of a block; a merged run is composed here on first use (fp64, launches on the pack's tape:
+        refreshed in place with the parameters)"""
+        if id(blk) in pk["affine"] or not isinstance(blk, _MergedAffine):
+            return pk["affine"][id(blk)]
+        with self._pk_record(pk):
+            _ext.flush_jobs()
+            W = c = None
+            for prim, b_ in blk.parts:
+                a = pk["affine"][id(b_)]
+                if prim == "affine_fwd":
+                    Wk, ck = a["M"], a["b"]
+                else:
+                    if "c" not in a:        # (y - b) Minv^T == y Minv^T + c, c = -(Minv b)
+                        a["c"] = torch.empty(a["b"].shape, dtype=torch.float64, device=a["b"].device)
+                        _ext.matvec_f64(a["Minv"], a["b"].contiguous(), alpha=-1.0, out64=a["c"])
+                    Wk, ck = a["Minv"], a["c"]
+                if W is None:
+                    W, c = Wk, ck
+                else:
+                    W = _ext.matmul_f64(Wk.contiguous(), W.contiguous())
+                    t = torch.empty(ck.shape, dtype=torch.float64, device=ck.device)
+                    _ext.matvec_f64(Wk.contiguous(), c.contiguous(), alpha=1.0, out64=t)
+                    c = _refreshed(tuple(ck.shape), torch.float64, ck.device,
+                                   lambda o, t=t, ck=ck: torch.add(t, ck, out=o))
+            pk["affine"][id(blk)] = dict(M=W, b=c)
+        return pk["affine"][id(blk)]
 
     def _build_plan(self, direction: str, B: int, device, has_ctx: bool, final: str, train: bool = False) -> dict:
         # every weight image the plan needs is queued while the op list is laid out and packed by ONE batched launch
@@ -681,7 +750,7 @@ class FlowEngine:
         before which it runs."""
         pk = self.pack(device)
         ws = self._workspace(B, device)
-        prims = self._primitive_ops(direction)
+        prims = self._primitive_ops(direction, merge=not train)     # (the training backward needs every block's own launch)
         ops: List[_ext.Op] = []
         patch_in: List[int] = []       # ops whose A is the caller's input tensor
         patch_out: List[int] = []      # ops whose C is the caller's output tensor
@@ -722,10 +791,10 @@ class FlowEngine:
         k = 0
         while k < n:
             prim, i = prims[k]
-            s = self.steps[i]
+            s = self._step(i)
             nxt = prims[k + 1] if k + 1 < n else None
             # ---- affine (optionally with the scale layer fused on its outer side) ---------------
-            if prim in ("affine_fwd", "affine_bwd") or (prim == "scale_div" and nxt and nxt[0] == "affine_bwd"):
+            if prim in ("affine_fwd", "affine_bwd") or (prim == "scale_div" and nxt and nxt[0] in ("affine_bwd", "affine_fwd")):
                 if cur[0] == "user_in" and self.D % 4 != 0:
                     # rows of the caller's tensor are not 16-B aligned: stage through a padded copy
                     side.append(("gather", len(ops), cur, "nat", "nat"))
@@ -739,10 +808,10 @@ class FlowEngine:
                     kw["pre_div"] = self._vec(pk, ("scale", id(s.module)), sc64, in_layout, 1.0).data_ptr()
                     k += 1
                     prim, i = prims[k]
-                    s = self.steps[i]
+                    s = self._step(i)
                     nxt = prims[k + 1] if k + 1 < n else None
                 blk = s.module
-                a = pk["affine"][id(blk)]
+                a = self._affine_entry(pk, blk)
                 fuse_post = prim == "affine_fwd" and nxt is not None and nxt[0] == "scale_mul"
                 is_last = (k == n - 1) or (fuse_post and k == n - 2)
                 out_layout = "nat" if is_last else "seg"
@@ -764,7 +833,7 @@ class FlowEngine:
                     W = self._mat(pk, blk, "M", out_layout, in_layout)
                     kw["bias"] = self._vec(pk, ("b", id(blk)), a["b"], out_layout, 0.0).data_ptr()
                     if fuse_post:
-                        s2 = self.steps[nxt[1]]
+                        s2 = self._step(nxt[1])
                         kw["post_mul"] = self._vec(pk, ("scale", id(s2.module)), pk["scale"][id(s2.module)],
                                                    out_layout, 1.0).data_ptr()
                         k += 1
@@ -783,7 +852,7 @@ class FlowEngine:
                     patch_out.append(len(ops))
                 meta.append(dict(kind="affine", op=len(ops), prim=prim, blk=blk, in_buf=cur[0], in_layout=in_layout,
                                  in_ld=cur[2], out_buf=dst, out_layout=out_layout, out_ld=ldc, N=Ndim, K=Kdim,
-                                 pre_scale=scale_mod, post_scale=(self.steps[nxt[1]].module if fuse_post else None)))
+                                 pre_scale=scale_mod, post_scale=(self._step(nxt[1]).module if fuse_post else None)))
                 ops.append(lin_op(A=(0 if cur[0] == "user_in" else ws[cur[0]].data_ptr()), lda=cur[2],
                                   W=W.data_ptr(), ldw=W.shape[1], C=cptr, ldc=ldc, M=B, N=Ndim, K=Kdim,
                                   res_sign=1.0, slope=0.0, act=_ext.ACT_NONE, **kw))
@@ -880,10 +949,10 @@ class FlowEngine:
         if (train or has_ctx or not use or self.gemm_mode not in ("bf16x3", "f16x2")
                 or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
-        prims = self._primitive_ops(direction)
+        prims = self._primitive_ops(direction, merge=True)
         kinds = [p_[0] for p_ in prims]
         for k_, kind in enumerate(kinds):
-            if kind == "scale_div" and not (k_ == 0 and len(kinds) > 1 and kinds[1] == "affine_bwd"):
+            if kind == "scale_div" and not (k_ == 0 and len(kinds) > 1 and kinds[1] in ("affine_bwd", "affine_fwd")):
                 return False
             if kind == "scale_mul" and not (k_ == len(kinds) - 1 and k_ > 0 and kinds[k_ - 1] == "affine_fwd"):
                 return False
@@ -946,7 +1015,7 @@ class FlowEngine:
         that hold its transformed features (zero rows elsewhere: those values are rewritten unchanged)."""
         pk = self.pack(device)
         ws = self._workspace(B, device)
-        prims = self._primitive_ops(direction)
+        prims = self._primitive_ops(direction, merge=True)
         npan = -(-B // 16)
         nkb = self.LDp // 32
         segp, natp = self.segp_idx, self.natp_idx
@@ -990,22 +1059,23 @@ class FlowEngine:
         d.planes = zbufs[cur].data_ptr()
         first_bias_in_prologue = False
         if prims[0][0] == "scale_div":
-            s0 = self.steps[prims[0][1]]
-            blk = self.steps[prims[1][1]].module
+            s0 = self._step(prims[0][1])
             d.pre_div = self._planes_vec(pk, ("pl_scale", id(s0.module), "segp"), pk["scale"][id(s0.module)], segp, 1.0).data_ptr()
-            d.pre_sub = self._planes_vec(pk, ("pl_b", id(blk), "segp"), pk["affine"][id(blk)]["b"], segp).data_ptr()
-            first_bias_in_prologue = True
+            if prims[1][0] == "affine_bwd":      # (x / s - b) Minv^T: the bias goes into the head as well
+                blk = self._step(prims[1][1]).module
+                d.pre_sub = self._planes_vec(pk, ("pl_b", id(blk), "segp"), pk["affine"][id(blk)]["b"], segp).data_ptr()
+                first_bias_in_prologue = True
             k = 1
         patch_in.append((len(ops), "pack_planes", "src"))
         ops.append(pack)
 
         while k < n:
             prim, i = prims[k]
-            s = self.steps[i]
+            s = self._step(i)
             nxt = prims[k + 1] if k + 1 < n else None
             if prim in ("affine_fwd", "affine_bwd"):
                 blk = s.module
-                a = pk["affine"][id(blk)]
+                a = self._affine_entry(pk, blk)
                 fuse_post = prim == "affine_fwd" and nxt is not None and nxt[0] == "scale_mul"
                 is_last = (k == n - 1) or (fuse_post and k == n - 2)
                 out_sel = natp if is_last else segp
@@ -1028,7 +1098,7 @@ class FlowEngine:
                     kw["bias"] = self._planes_vec(pk, ("pl_b", id(blk), lay), a["b"], out_sel).data_ptr()
                 if is_last:
                     if fuse_post:
-                        s2 = self.steps[nxt[1]]
+                        s2 = self._step(nxt[1])
                         kw["post_mul"] = self._planes_vec(pk, ("pl_scale", id(s2.module), "natp"),
                                                           pk["scale"][id(s2.module)], natp, 1.0).data_ptr()
                         k += 1
