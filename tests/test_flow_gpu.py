@@ -397,4 +397,13 @@ def test_merged_affine_runs_on_device(name, planes):
         s = max(1.0, a["forward64"].abs().max().item())
         assert (xf.cpu().double() - a["forward64"]).abs().max().item() < 2 * tol * s
         counts[merge] = min(p["n"] for p in eng._plans.values())
+        # an in-place parameter update (optimiser step): the pack refresh recomposes the merged maps in place
+        with torch.no_grad():
+            for p in flow.parameters():
+                if p.dim() >= 1 and p.numel() > 1:
+                    p.mul_(1.0 + 1e-3)
+            counts[("lp2", merge)] = flow.log_prob(x).cpu()
     assert counts[True] < counts[False], counts
+    a2, b2 = counts[("lp2", False)], counts[("lp2", True)]
+    assert not torch.equal(a2, lp.cpu())                                    # the update changed the result ...
+    assert ((a2 - b2).abs() / a2.abs()).max().item() < (3e-5 if name.startswith("init_") else 2e-6)   # ... in both plans alike
