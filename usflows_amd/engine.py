@@ -261,7 +261,7 @@ class FlowEngine:
         self._pack_key = None
         self._plans: Dict[tuple, dict] = {}
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
-        # opt-in (USFLOWS_AMD_MERGE_AFFINE=1 / engine.merge_affine = True, set before the first call): consecutive affine
+        # opt-in (USFLOWS_AMD_MERGE_AFFINE=1 / engine.merge_affine = True): consecutive affine
         # steps of an inference plan run as ONE composed map (_MergedAffine) -- with affine_conjugation that halves the
         # D x D GEMMs.  Off by default: the reference applies the maps one by one in fp32, and on badly conditioned
         # (default-initialised) blocks the composite rounds differently -- golden init_d7_k2_hh1_conj_laplace: relative
@@ -1291,7 +1291,8 @@ class FlowEngine:
     def _plan(self, direction, B, device, has_ctx, final, train: bool = False):
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
-               train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3)
+               train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3,
+               self.merge_affine)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final, train)
