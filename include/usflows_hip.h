@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 13
+#define USF_ABI_VERSION 14
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -221,6 +221,22 @@ int usf_affine_coupling_apply_f32(float* z, int64_t ldz, const float* t, int64_t
  */
 int usf_channel_affine_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W,
                            const float* pre_sub, const float* bias, usf_stream_t stream);
+
+/*
+ * Elementwise pieces of the image-shaped coupling layer, one pass each over contiguous [B, C, P] fp32 tensors (P = H * W):
+ *   usf_layernorm_channels_f32: y = (a - mean_c a) / sqrt(var_c a + eps) * gamma + beta with a = act(x) (act = USF_ACT_NONE or
+ *     USF_ACT_LEAKY_RELU with slope; slope 0 = ReLU): LayerNormChannels.forward (networks.py:40-58; biased variance over
+ *     the channel axis) with the nonlinearity ConvNet2D puts in front of it (networks.py:480-493).  C <= 64.
+ *   usf_gated_residual_f32:     y = x + vg[:, :C] * sigmoid(vg[:, C:]), vg [B, 2C, P]: GatedConv.forward (networks.py:108-122);
+ *     CP = C * P.
+ *   usf_masked_residual_f32:    y = x + sign * one_minus_mask * t, one_minus_mask [C * P] broadcast over the batch:
+ *     MaskedCoupling.forward (+1) / backward (-1) on image-shaped inputs (transforms.py:277-306).
+ */
+int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma,
+                               const float* beta, float eps, int32_t act, float slope, usf_stream_t stream);
+int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B, int64_t CP, usf_stream_t stream);
+int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
+                            int64_t CP, usf_stream_t stream);
 
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */

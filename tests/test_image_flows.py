@@ -101,3 +101,34 @@ def test_channel_affine_kernel_vs_conv2d(B, C, P):
     assert (y[idx.to("cuda:0")].cpu().double() - ref).abs().max().item() < 2e-6 * max(scale, ref.abs().max().item())
     with pytest.raises(RuntimeError):
         _ext.channel_affine(xd, xd, W.to("cuda:0"))           # in place is rejected
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,P", [(1, 1, 1), (3, 5, 49), (7, 32, 49), (2, 64, 100), (4097, 16, 49)])
+def test_image_elementwise_kernels_vs_torch(B, C, P):
+    """usf_layernorm_channels_f32 (with and without the folded (Leaky)ReLU), usf_gated_residual_f32 and
+    usf_masked_residual_f32 against the torch formulas of the reference's modules (networks.py:40-58, 108-122;
+    transforms.py:277-306) in fp64"""
+    from usflows_amd import _ext
+    _ext.load()
+    g = torch.Generator().manual_seed(B * 7 + C + P)
+    x = torch.randn(B, C, P, 1, generator=g) * 3
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xd = x.to("cuda:0")
+    for act, slope, f in ((_ext.ACT_NONE, 0.0, lambda v: v), (_ext.ACT_LEAKY_RELU, 0.0, torch.relu),
+                          (_ext.ACT_LEAKY_RELU, 0.01, lambda v: torch.nn.functional.leaky_relu(v, 0.01))):
+        a = f(x.double())
+        mean, var = a.mean(dim=1, keepdim=True), a.var(dim=1, unbiased=False, keepdim=True)
+        ref = (a - mean) / torch.sqrt(var + 1e-5) * gamma.double().view(1, C, 1, 1) + beta.double().view(1, C, 1, 1)
+        got = _ext.layernorm_channels(xd, gamma.to("cuda:0"), beta.to("cuda:0"), 1e-5, act, slope)
+        assert (got.cpu().double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    vg = torch.randn(B, 2 * C, P, 1, generator=g) * 2
+    ref = x.double() + vg[:, :C].double() * torch.sigmoid(vg[:, C:].double())
+    got = _ext.gated_residual(xd, vg.to("cuda:0"))
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    t = torch.randn(B, C, P, 1, generator=g)
+    om = (torch.rand(C * P, generator=g) > 0.5).float()
+    for sign in (1.0, -1.0):
+        ref = x.double() + sign * om.double().view(1, C, P, 1) * t.double()
+        got = _ext.masked_residual(xd, t.to("cuda:0"), om.to("cuda:0"), sign)
+        assert torch.equal(got.cpu().double(), ref.float().double())

@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 13
+USF_ABI_VERSION = 14
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU = 0, 1
@@ -145,6 +145,10 @@ SYMBOLS = {
     "usf_affine_coupling_apply_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64,
                                                 C.c_float, C.c_int32, _fp, C.c_void_p]),
     "usf_channel_affine_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
+    "usf_layernorm_channels_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, C.c_float, C.c_int32,
+                                             C.c_float, C.c_void_p]),
+    "usf_gated_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_masked_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
     "usf_lu_prepare_f64": (C.c_int, [C.POINTER(LuPrepDesc), C.c_void_p]),
@@ -409,6 +413,36 @@ def channel_affine(x, y, W, *, pre_sub=None, bias=None):
     P = x.numel() // max(B * Cc, 1)
     check(load().usf_channel_affine_f32(x.data_ptr(), y.data_ptr(), B, Cc, P, W.data_ptr(), ptr(pre_sub), ptr(bias),
                                         current_stream(x.device)), "usf_channel_affine_f32")
+
+
+def layernorm_channels(x, gamma, beta, eps, act=ACT_NONE, slope=0.0):
+    """usf_layernorm_channels_f32 on a contiguous [B, C, *spatial] fp32 tensor -> new tensor"""
+    B, Cc = x.shape[0], x.shape[1]
+    P = x.numel() // max(B * Cc, 1)
+    y = torch.empty_like(x)
+    check(load().usf_layernorm_channels_f32(x.data_ptr(), y.data_ptr(), B, Cc, P, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                            int(act), float(slope), current_stream(x.device)), "usf_layernorm_channels_f32")
+    return y
+
+
+def gated_residual(x, vg):
+    """x + vg[:, :C] * sigmoid(vg[:, C:]) for contiguous x [B, C, *spatial], vg [B, 2C, *spatial] -> new tensor"""
+    B = x.shape[0]
+    CP = x.numel() // max(B, 1)
+    y = torch.empty_like(x)
+    check(load().usf_gated_residual_f32(x.data_ptr(), vg.data_ptr(), y.data_ptr(), B, CP, current_stream(x.device)),
+          "usf_gated_residual_f32")
+    return y
+
+
+def masked_residual(x, t, one_minus_mask, sign):
+    """x + sign * one_minus_mask * t (mask [C * P] fp32, broadcast over the batch) -> new tensor"""
+    B = x.shape[0]
+    CP = x.numel() // max(B, 1)
+    y = torch.empty_like(x)
+    check(load().usf_masked_residual_f32(x.data_ptr(), t.data_ptr(), one_minus_mask.data_ptr(), float(sign), y.data_ptr(), B,
+                                         CP, current_stream(x.device)), "usf_masked_residual_f32")
+    return y
 
 
 def gather_cols(src, lds, dst, ldd, M, n, idx):

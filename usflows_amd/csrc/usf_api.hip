@@ -55,6 +55,11 @@ int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, 
 
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
 int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
+int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
+                       float eps, int32_t act, float slope, hipStream_t stream);
+int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
+int masked_residual(const float* x, const float* t, const float* om, float sign, float* y, int64_t B, int64_t CP,
+                    hipStream_t stream);
 int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
                  float neg_lr, int32_t maximize, hipStream_t stream);
 int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2, hipStream_t stream);
@@ -191,6 +196,17 @@ int usf_sophiag_step_f32(const usf_mt_chunk* chunks, int64_t n_chunks, float dec
 int usf_sophiag_hessian_f32(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2,
                             usf_stream_t stream) {
   return usf::sophiag_hessian(chunks, n_chunks, beta2, one_minus_beta2, (hipStream_t)stream);
+}
+int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma,
+                               const float* beta, float eps, int32_t act, float slope, usf_stream_t stream) {
+  return usf::layernorm_channels(x, y, B, C, P, gamma, beta, eps, act, slope, (hipStream_t)stream);
+}
+int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B, int64_t CP, usf_stream_t stream) {
+  return usf::gated_residual(x, vg, y, B, CP, (hipStream_t)stream);
+}
+int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
+                            int64_t CP, usf_stream_t stream) {
+  return usf::masked_residual(x, t, one_minus_mask, sign, y, B, CP, (hipStream_t)stream);
 }
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   return usf::wgrad_variant(M, N, K, ldy, lda, mode);

@@ -467,4 +467,99 @@ int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, co
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Elementwise pieces of the image-shaped coupling layer, each ONE pass over [B, C, P] (P = H * W):
+//   layernorm_channels  y = (a - mean_c a) / sqrt(var_c a + eps) * gamma + beta,  a = act(x)        LayerNormChannels.forward
+//                       (networks.py:40-58: mean / biased variance over the channel axis) with the (Leaky)ReLU that
+//                       precedes it in ConvNet2D (networks.py:480-493) folded in; the reference chain is 8 passes
+//   gated_residual      y = x + val * sigmoid(gate),  (val, gate) = chunk(vg, 2, dim=1)              GatedConv.forward
+//                       (networks.py:108-122), 4 passes there
+//   masked_residual     y = x + sign * om * t,  om = 1 - mask broadcast over the batch                MaskedCoupling
+//                       (transforms.py:277-306), 2 passes there
+// One thread per pixel (b, p): channel values strided by P (a wave reads 64 consecutive pixels of one channel plane:
+// coalesced within a sample); HBM-bound, 8 / 12 / 12 bytes per element.
+// ------------------------------------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void layernorm_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t BP,
+                                                                 int C, int64_t P, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, int act,
+                                                                 float slope) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BP) return;
+  const int64_t b = i / P, p = i - b * P;
+  const float* xb = x + b * C * P + p;
+  float v[CMAX];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    v[c] = (c < C) ? act_apply(xb[(int64_t)c * P], act, slope) : 0.f;
+    sum += v[c];
+  }
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const float d = (c < C) ? v[c] - mean : 0.f;
+    sq += d * d;
+  }
+  const float den = sqrtf(sq / (float)C + eps);
+  float* yb = y + b * C * P + p;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) yb[(int64_t)c * P] = (v[c] - mean) / den * gamma[c] + beta[c];
+}
+
+__global__ __launch_bounds__(256) void gated_residual_kernel(const float* __restrict__ x, const float* __restrict__ vg,
+                                                             float* __restrict__ y, int64_t total, int64_t CP) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / CP, r = e - b * CP;
+    const float val = vg[b * 2 * CP + r], gate = vg[b * 2 * CP + CP + r];
+    y[e] = x[e] + val * (1.f / (1.f + expf(-gate)));
+  }
+}
+
+__global__ __launch_bounds__(256) void masked_residual_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                              const float* __restrict__ om, float sign,
+                                                              float* __restrict__ y, int64_t total, int64_t CP) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    y[e] = x[e] + sign * (om[e % CP] * t[e]);
+}
+
+int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
+                       float eps, int32_t act, float slope, hipStream_t stream) {
+  if (B < 0 || C <= 0 || P <= 0 || C > 64) { set_error("usf_layernorm_channels_f32: bad sizes (C must be 1..64)"); return -2; }
+  if (B == 0) return 0;
+  if (!x || !y || !gamma || !beta) { set_error("usf_layernorm_channels_f32: null pointer"); return -1; }
+  if (act != USF_ACT_NONE && act != USF_ACT_LEAKY_RELU) { set_error("usf_layernorm_channels_f32: bad act"); return -2; }
+  const int64_t BP = B * P, blocks = (BP + 255) / 256;
+  if (blocks > 0x7fffffffLL) { set_error("usf_layernorm_channels_f32: grid too large"); return -3; }
+  const dim3 g((unsigned)blocks), b(256);
+  if (C <= 8) hipLaunchKernelGGL(layernorm_channels_kernel<8>, g, b, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+  else if (C <= 16) hipLaunchKernelGGL(layernorm_channels_kernel<16>, g, b, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+  else if (C <= 32) hipLaunchKernelGGL(layernorm_channels_kernel<32>, g, b, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+  else hipLaunchKernelGGL(layernorm_channels_kernel<64>, g, b, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+  return check_launch("usf_layernorm_channels_f32");
+}
+
+int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream) {
+  if (B < 0 || CP <= 0) { set_error("usf_gated_residual_f32: bad sizes"); return -2; }
+  if (B == 0) return 0;
+  if (!x || !vg || !y) { set_error("usf_gated_residual_f32: null pointer"); return -1; }
+  int64_t blocks = (B * CP + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(gated_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, vg, y, B * CP, CP);
+  return check_launch("usf_gated_residual_f32");
+}
+
+int masked_residual(const float* x, const float* t, const float* om, float sign, float* y, int64_t B, int64_t CP,
+                    hipStream_t stream) {
+  if (B < 0 || CP <= 0) { set_error("usf_masked_residual_f32: bad sizes"); return -2; }
+  if (B == 0) return 0;
+  if (!x || !t || !om || !y) { set_error("usf_masked_residual_f32: null pointer"); return -1; }
+  int64_t blocks = (B * CP + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(masked_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, t, om, sign, y, B * CP, CP);
+  return check_launch("usf_masked_residual_f32");
+}
+
 }  // namespace usf

@@ -177,6 +177,16 @@ class ConvNet(nn.Module):
 
 
 # ---- CNN conditioners for image-shaped in_dims (networks.py:40-122, 405-510) --------------------------
+def _relu_kind(m):
+    """(USF_ACT_LEAKY_RELU, slope) for nn.ReLU / nn.LeakyReLU modules (slope 0 = ReLU), else None"""
+    from . import _ext
+    if isinstance(m, nn.ReLU):
+        return (_ext.ACT_LEAKY_RELU, 0.0)
+    if isinstance(m, nn.LeakyReLU):
+        return (_ext.ACT_LEAKY_RELU, float(m.negative_slope))
+    return None
+
+
 class LayerNormChannels(nn.Module):
     """layer norm across the channel axis of [B, C, H, W] (networks.py:40-58)"""
 
@@ -186,7 +196,19 @@ class LayerNormChannels(nn.Module):
         self.beta = nn.Parameter(torch.zeros(1, c_in, 1, 1))
         self.eps = eps
 
-    def forward(self, x):
+    def _hip_ok(self, x) -> bool:
+        return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.shape[1] <= 64
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.gamma.requires_grad or self.beta.requires_grad)))
+
+    def forward(self, x, pre_act=None):
+        """pre_act: None or (USF_ACT id, slope) of a nonlinearity to apply to x first (ConvNet2D folds the (Leaky)ReLU in
+        front of this layer into the same device pass)"""
+        if self._hip_ok(x):
+            from . import _ext
+            act, slope = pre_act if pre_act is not None else (_ext.ACT_NONE, 0.0)
+            return _ext.layernorm_channels(x.contiguous(), self.gamma.detach().reshape(-1).contiguous(),
+                                           self.beta.detach().reshape(-1).contiguous(), self.eps, act, slope)
+        assert pre_act is None
         mean = x.mean(dim=1, keepdim=True)
         var = x.var(dim=1, unbiased=False, keepdim=True)
         return (x - mean) / torch.sqrt(var + self.eps) * self.gamma + self.beta
@@ -206,7 +228,12 @@ class GatedConv(nn.Module):
         )
 
     def forward(self, x):
-        val, gate = self.net(x).chunk(2, dim=1)
+        vg = self.net(x)
+        if (x.is_cuda and x.dtype == torch.float32 and vg.dtype == torch.float32 and vg.shape[1] == 2 * x.shape[1]
+                and vg.shape[2:] == x.shape[2:] and not (torch.is_grad_enabled() and (x.requires_grad or vg.requires_grad))):
+            from . import _ext
+            return _ext.gated_residual(x.contiguous(), vg.contiguous())        # one pass instead of chunk / sigmoid / mul / add
+        val, gate = vg.chunk(2, dim=1)
         ret = x + val * torch.sigmoid(gate)
         assert ret.shape == x.shape, f"Shape mismatch: {ret.shape} != {x.shape}"
         return ret
@@ -239,4 +266,19 @@ class ConvNet2D(nn.Module):
         self.nn = nn.Sequential(*layers)
 
     def forward(self, x, context=None):
-        return self.nn(x)
+        mods = list(self.nn)
+        if not (x.is_cuda and x.dtype == torch.float32 and any(isinstance(m, LayerNormChannels) for m in mods)):
+            return self.nn(x)
+        # the same module sequence; a (Leaky)ReLU directly in front of a LayerNormChannels joins that layer's device pass
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            act = _relu_kind(m)
+            if act is not None and isinstance(nxt, LayerNormChannels) and nxt._hip_ok(x):
+                x = nxt(x, pre_act=act)
+                k += 2
+            else:
+                x = m(x)
+                k += 1
+        return x
