@@ -25,11 +25,14 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 14
+#define USF_ABI_VERSION 15
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
 #define USF_ACT_LEAKY_RELU 1 /* slope 0 == ReLU */
+#define USF_ACT_GATE 2       /* usf_linear_f32 only: `addend` is NOT added but read as a gate h [M,N]:
+                                C = (A W^T + bias) * (h > 0 ? 1 : slope) -- the (Leaky)ReLU backward from the saved layer
+                                output (usf_act_grad_f32) folded into the data-gradient GEMM's epilogue */
 
 /* base distribution ids */
 #define USF_BASE_LAPLACE 0 /* torch Laplace.log_prob summed over D (Independent, distributions.py:709-728) */

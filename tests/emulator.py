@@ -376,7 +376,9 @@ def _emu_linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None,
     v = a @ _view(W, 0, N, K, ldw).to(dtype).t()
     if bias is not None:
         v = v + bias[:N].to(dtype)
-    if addend is not None:
+    if act == _ext.ACT_GATE:
+        v = torch.where(_view(addend, 0, M, N, ldadd) > 0, v, v * slope)
+    elif addend is not None:
         v = v + _view(addend, 0, M, N, ldadd).to(dtype)
     if act == _ext.ACT_LEAKY_RELU:
         v = torch.where(v > 0, v, v * slope)

@@ -347,3 +347,28 @@ def test_flow_sample_with_radial_base_runs_on_device():
     ref = nd.sample((20000,)).reshape(-1).log()
     assert abs(r.log().mean().item() - ref.mean().item()) < 0.05 * max(1.0, ref.std().item())
     del xs2
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("M,N,K", [(5, 12, 20), (300, 256, 392), (4096, 256, 256), (20000, 392, 256)])
+def test_linear_gate_epilogue_is_act_grad_of_the_plain_product(M, N, K, mode):
+    """USF_ACT_GATE (`addend` read as the saved layer output h): C = (A W^T) * (h > 0 ? 1 : slope) -- the same values as
+    usf_linear_f32 followed by usf_act_grad_f32, for the small-batch, exact-f32 and bf16x3 kernels (the shapes of the
+    conditioner's data gradients)"""
+    ext, dev = _ext(), _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    ldh = N + 4
+    h = torch.randn(M, ldh, generator=g).to(dev)
+    planes = None
+    if mode == "bf16x3":
+        planes = torch.empty(3, N, (K + 31) // 32 * 32, dtype=torch.bfloat16, device=dev)
+        ext.pack_weight(W, None, N, None, K, planes=planes)
+    ref = torch.empty(M, N, device=dev)
+    ext.linear(A, W, ref, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, W_split=planes)
+    ext.act_grad(ref, h, M=M, H=N, ldd=N, ldh=ldh, act=ext.ACT_LEAKY_RELU, slope=0.01)
+    got = torch.empty(M, N, device=dev)
+    ext.linear(A, W, got, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, W_split=planes, act=ext.ACT_GATE, slope=0.01, addend=h, ldadd=ldh)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)

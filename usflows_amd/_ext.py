@@ -16,10 +16,10 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 14
+USF_ABI_VERSION = 15
 USF_MAX_HIDDEN = 4
 
-ACT_NONE, ACT_LEAKY_RELU = 0, 1
+ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
 BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
 OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES = 1, 2, 5, 6, 7
 

@@ -30,6 +30,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   return (act == USF_ACT_LEAKY_RELU) ? (v > 0.0f ? v : v * slope) : v;
 }
+// USF_ACT_GATE: leaky_relu_backward from the saved OUTPUT h (as usf_act_grad_f32: h > 0 ? v : v * slope)
+__device__ __forceinline__ float gate_apply(float v, float h, float slope) { return (h > 0.0f) ? v : v * slope; }
 
 // 64-lane sum via DPP-friendly shuffles (wavefront = 64 on gfx950)
 __device__ __forceinline__ float wave_sum(float v) {

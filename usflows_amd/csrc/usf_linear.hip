@@ -275,8 +275,11 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_kernel(const LinArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float x = acc[tm][tn][4 * g4 + j];
-          if (EPI == 2) x = x + ex[j];
-          x = act_apply(x, p.act, p.slope);
+          if (EPI == 2 && p.act == USF_ACT_GATE) x = gate_apply(x, ex[j], p.slope);
+          else {
+            if (EPI == 2) x = x + ex[j];
+            x = act_apply(x, p.act, p.slope);
+          }
           if (EPI == 1) x = ex[j] + p.res_sign * x;
           v[j] = x * pm[j];
         }
@@ -356,7 +359,8 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
     set_error("usf_linear_f32: A/W/pre_div/pre_sub must be 16-byte aligned");
     return -2;
   }
-  if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_linear_f32: bad act"); return -2; }
+  if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU && d->act != USF_ACT_GATE) { set_error("usf_linear_f32: bad act"); return -2; }
+  if (d->act == USF_ACT_GATE && (!d->addend || d->residual)) { set_error("usf_linear_f32: USF_ACT_GATE reads the gate from `addend` (required) and takes no residual"); return -2; }
   if (d->residual && d->addend) { set_error("usf_linear_f32: residual and addend are mutually exclusive"); return -2; }
   if (linear_skinny_eligible(d)) return linear_skinny_dispatch(d, stream);     // small batches: latency, not FLOPs
   if (linear_bf16x3_eligible(d)) return linear_bf16x3_dispatch(d, stream);

@@ -351,9 +351,15 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
       const int row = row0 + r;
       const int col = n0 + tn * 32 + cc;
       const int rowc = min(row, p.M - 1), colc = min(col, p.N - 4);
-      if (p.addend) v = v + *reinterpret_cast<const f32x4*>(p.addend + (int64_t)rowc * p.ldadd + colc);
+      if (p.act == USF_ACT_GATE) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(p.addend + (int64_t)rowc * p.ldadd + colc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act, p.slope);
+        for (int j = 0; j < 4; ++j) v[j] = gate_apply(v[j], h[j], p.slope);
+      } else {
+        if (p.addend) v = v + *reinterpret_cast<const f32x4*>(p.addend + (int64_t)rowc * p.ldadd + colc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act, p.slope);
+      }
       if (p.residual) v = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)rowc * p.ldr + colc) + p.res_sign * v;
       if (has_pm) v = v * *reinterpret_cast<const f32x4*>(p.post_mul + colc);
       float* dst = p.C + (int64_t)row * p.ldc + col;

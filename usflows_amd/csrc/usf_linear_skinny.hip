@@ -127,8 +127,11 @@ __global__ __launch_bounds__(512) void linear_skinny_kernel(const SkArgs p) {
       const int c = min(col + j, p.N - 1);
       float x = v[j];
       if (p.bias) x += p.bias[c];
-      if (p.addend) x += p.addend[(int64_t)row * p.ldadd + c];
-      x = act_apply(x, p.act, p.slope);
+      if (p.act == USF_ACT_GATE) x = gate_apply(x, p.addend[(int64_t)row * p.ldadd + c], p.slope);
+      else {
+        if (p.addend) x += p.addend[(int64_t)row * p.ldadd + c];
+        x = act_apply(x, p.act, p.slope);
+      }
       if (p.residual) x = p.residual[(int64_t)row * p.ldr + c] + p.res_sign * x;
       if (p.post_mul) x *= p.post_mul[c];
       v[j] = x;

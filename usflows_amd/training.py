@@ -494,8 +494,9 @@ class TrainPath:
         d_bufs = [self._buf(ws, "Dh0", B, hmax), self._buf(ws, "Dh1", B, hmax)]
         Wt = self._transposed(pk, W_out)                      # [hp_last, tr_n4]
         d = d_bufs[0]
-        self._linear(pk, g_cur, tr_off, g_ld, Wt, d, 0, hmax, B, hp[-1], Wt.shape[1])
-        _ext.act_grad(d, hbufs[-1], M=B, H=hp[-1], ldd=hmax, ldh=hmax, act=act, slope=slope)
+        # (the (Leaky)ReLU backward from the saved layer output rides in the GEMM's epilogue: USF_ACT_GATE)
+        gate = lambda hbuf: dict(act=_ext.ACT_GATE, slope=slope, addend=hbuf, ldadd=hmax) if act != _ext.ACT_NONE else {}
+        self._linear(pk, g_cur, tr_off, g_ld, Wt, d, 0, hmax, B, hp[-1], Wt.shape[1], **gate(hbufs[-1]))
         # 3. hidden layers, last to first
         for j in range(nl - 1, 0, -1):
             W, _b = un["layers"][j]                           # [hp_j, hp_{j-1}]
@@ -506,8 +507,7 @@ class TrainPath:
             self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
             self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
             d_next = d_bufs[1] if d is d_bufs[0] else d_bufs[0]
-            self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j])
-            _ext.act_grad(d_next, hbufs[j - 1], M=B, H=hp[j - 1], ldd=hmax, ldh=hmax, act=act, slope=slope)
+            self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j], **gate(hbufs[j - 1]))
             d = d_next
         # 4. input layer
         W_in, _b = un["layers"][0]                            # [hp0, pass_n]
