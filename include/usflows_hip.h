@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 15
+#define USF_ABI_VERSION 16
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -240,6 +240,24 @@ int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, i
 int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B, int64_t CP, usf_stream_t stream);
 int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
                             int64_t CP, usf_stream_t stream);
+
+/*
+ * Conv2d of the CNN conditioner (networks.py:405-510 ConvNet2D, :61-122 GatedConv): stride 1, dilation 1, "same" zero
+ * padding, kernel ks = 1 or 3, on contiguous NCHW fp32 tensors, fp32-equivalent bf16x3 arithmetic on the matrix cores:
+ *   y[b, co, p] = out_act( bias[co] + sum_{tap, ci} W[co, ci, tap] * (in_act(x[b, ci, p + tap]) * in_mul[ci, p + tap]) )
+ * in_act / out_act: USF_ACT_NONE or USF_ACT_LEAKY_RELU (slope 0 = ReLU); in_mul [cin * H * W] or NULL (the coupling mask
+ * in front of a conditioner's first convolution); bias [cout] or NULL.  Channels <= 64, H * W <= 256.
+ * w_planes: three bf16 planes [3][coutp][kp] of the weight with W1 + W2 + W3 == W (round-to-nearest residual split),
+ * coutp = ceil16(cout), K order tap-major / channel-minor with the channels padded to cp = ceil8(cin):
+ * element [co][tap * cp + ci] = W[co, ci, tap / ks, tap % ks]; kp = ceil32(ks * ks * cp); zeros in all padding
+ * (usf_conv2d_weight_elems(cin, cout, ks) = 3 * coutp * kp elements).
+ */
+int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
+/* > 0 (samples per LDS group) when usf_conv2d_same_f32 serves these sizes: weight planes + one padded sample must fit 144 KB of LDS */
+int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
+int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                        const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                        int32_t out_act, float out_slope, usf_stream_t stream);
 
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */

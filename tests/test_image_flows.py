@@ -132,3 +132,45 @@ def test_image_elementwise_kernels_vs_torch(B, C, P):
         ref = x.double() + sign * om.double().view(1, C, P, 1) * t.double()
         got = _ext.masked_residual(xd, t.to("cuda:0"), om.to("cuda:0"), sign)
         assert torch.equal(got.cpu().double(), ref.float().double())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W,ks", [(1, 1, 1, 1, 1, 1), (3, 16, 32, 7, 7, 3), (5, 32, 32, 7, 7, 3), (4, 32, 64, 7, 7, 1),
+                                               (9, 32, 16, 7, 7, 3), (2, 48, 32, 8, 8, 3), (3, 4, 32, 14, 14, 3), (2, 5, 7, 3, 9, 3),
+                                               (2, 32, 32, 16, 16, 3), (2, 64, 64, 5, 5, 1), (7, 33, 17, 5, 6, 1), (4099, 16, 32, 7, 7, 3)])
+def test_conv2d_same_kernel_vs_torch(B, cin, cout, H, W, ks):
+    """usf_conv2d_same_f32 (implicit GEMM on the bf16 matrix cores, bf16x3 arithmetic) against F.conv2d in fp64: the
+    conditioner shapes of the reference's MNIST / CIFAR configurations (networks.py:405-510), ragged sizes, the folded
+    input (Leaky)ReLU, the folded coupling mask and the output activation"""
+    import torch.nn.functional as F
+    from usflows_amd import _ext
+    _ext.load()
+    lib = _ext.load()
+    assert lib.usf_conv2d_same_fits(cin, cout, H, W, ks) > 0 and lib.usf_conv2d_same_fits(64, 64, 16, 16, 3) == 0
+    g = torch.Generator().manual_seed(B + cin * 3 + cout * 5 + H + ks)
+    x = torch.randn(B, cin, H, W, generator=g) * 2
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    b = torch.randn(cout, generator=g)
+    mask = (torch.rand(cin, H, W, generator=g) > 0.5).float()
+    planes = _ext.conv2d_weight_planes(w.to("cuda:0"))
+    xd = x.to("cuda:0")
+    rows = torch.unique(torch.cat([torch.arange(min(B, 6)), torch.arange(max(B - 6, 0), B)]))
+    for in_act, in_slope, use_mask, out_act in ((_ext.ACT_NONE, 0.0, False, _ext.ACT_NONE), (_ext.ACT_LEAKY_RELU, 0.0, False, _ext.ACT_NONE),
+                                                (_ext.ACT_NONE, 0.0, True, _ext.ACT_LEAKY_RELU), (_ext.ACT_LEAKY_RELU, 0.01, True, _ext.ACT_NONE)):
+        a = x[rows].double()
+        if in_act == _ext.ACT_LEAKY_RELU:
+            a = F.leaky_relu(a, in_slope)
+        if use_mask:
+            a = a * mask.double()
+        ref = F.conv2d(a, w.double(), b.double(), padding=ks // 2)
+        if out_act == _ext.ACT_LEAKY_RELU:
+            ref = F.leaky_relu(ref, 0.0)
+        got = _ext.conv2d_same(xd, planes, cout, ks, bias=b.to("cuda:0"), in_mul=mask.reshape(-1).to("cuda:0") if use_mask else None,
+                               in_act=in_act, in_slope=in_slope, out_act=out_act, out_slope=0.0)
+        assert got.shape == (B, cout, H, W) and not torch.isnan(got).any()
+        err = (got[rows.to("cuda:0")].cpu().double() - ref).abs().max().item()
+        assert err < 3e-6 * max(1.0, ref.abs().max().item()), (in_act, use_mask, out_act, err)
+    # no bias
+    got = _ext.conv2d_same(xd, planes, cout, ks)
+    ref = F.conv2d(x[rows].double(), w.double(), None, padding=ks // 2)
+    assert (got[rows.to("cuda:0")].cpu().double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())

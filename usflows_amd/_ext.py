@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 15
+USF_ABI_VERSION = 16
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -148,6 +148,10 @@ SYMBOLS = {
     "usf_layernorm_channels_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, C.c_float, C.c_int32,
                                              C.c_float, C.c_void_p]),
     "usf_gated_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_conv2d_weight_elems": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_conv2d_same_fits": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "usf_conv2d_same_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
+                                      C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
     "usf_masked_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -422,6 +426,35 @@ def layernorm_channels(x, gamma, beta, eps, act=ACT_NONE, slope=0.0):
     y = torch.empty_like(x)
     check(load().usf_layernorm_channels_f32(x.data_ptr(), y.data_ptr(), B, Cc, P, gamma.data_ptr(), beta.data_ptr(), float(eps),
                                             int(act), float(slope), current_stream(x.device)), "usf_layernorm_channels_f32")
+    return y
+
+
+def conv2d_weight_planes(weight: torch.Tensor) -> torch.Tensor:
+    """bf16x3 planes [3, coutp, kp] of a Conv2d weight [cout, cin, k, k] in the K order usf_conv2d_same_f32 reads
+    (tap-major, channel-minor, channels padded to a multiple of 8; include/usflows_hip.h)"""
+    cout, cin, k, _ = weight.shape
+    cp, coutp = (cin + 7) // 8 * 8, (cout + 15) // 16 * 16
+    kp = (k * k * cp + 31) // 32 * 32
+    w = torch.zeros(coutp, k * k, cp, dtype=torch.float32, device=weight.device)
+    w[:cout, :, :cin] = weight.detach().to(torch.float32).reshape(cout, cin, k * k).permute(0, 2, 1)
+    flat = torch.zeros(coutp, kp, dtype=torch.float32, device=weight.device)
+    flat[:, : k * k * cp] = w.reshape(coutp, k * k * cp)
+    h = flat.to(torch.bfloat16)
+    r = flat - h.float()
+    m = r.to(torch.bfloat16)
+    lo = (r - m.float()).to(torch.bfloat16)
+    planes = torch.stack([h, m, lo]).contiguous()
+    assert planes.numel() == load().usf_conv2d_weight_elems(cin, cout, k)
+    return planes
+
+
+def conv2d_same(x, planes, cout, ks, bias=None, in_mul=None, in_act=ACT_NONE, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0):
+    """usf_conv2d_same_f32 on a contiguous [B, cin, H, W] fp32 tensor -> new [B, cout, H, W] tensor"""
+    B, cin, H, W = x.shape
+    y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    check(load().usf_conv2d_same_f32(x.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, planes.data_ptr(), ptr(bias),
+                                     ptr(in_mul), int(in_act), float(in_slope), int(out_act), float(out_slope),
+                                     current_stream(x.device)), "usf_conv2d_same_f32")
     return y
 
 

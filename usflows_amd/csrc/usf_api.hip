@@ -55,6 +55,11 @@ int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, 
 
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
 int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
+int64_t conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
+int conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
+int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                int32_t out_act, float out_slope, hipStream_t stream);
 int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
                        float eps, int32_t act, float slope, hipStream_t stream);
 int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
@@ -207,6 +212,14 @@ int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B,
 int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
                             int64_t CP, usf_stream_t stream) {
   return usf::masked_residual(x, t, one_minus_mask, sign, y, B, CP, (hipStream_t)stream);
+}
+int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks) { return usf::conv2d_weight_elems(cin, cout, ks); }
+int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) { return usf::conv2d_same_fits(cin, cout, H, W, ks); }
+int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                        const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                        int32_t out_act, float out_slope, usf_stream_t stream) {
+  return usf::conv2d_same(x, y, B, cin, cout, H, W, ks, w_planes, bias, in_mul, in_act, in_slope, out_act, out_slope,
+                          (hipStream_t)stream);
 }
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   return usf::wgrad_variant(M, N, K, ldy, lda, mode);

@@ -187,6 +187,39 @@ def _relu_kind(m):
     return None
 
 
+def _conv_hip_ok(conv, x) -> bool:
+    """this nn.Conv2d call is served by usf_conv2d_same_f32: stride 1, "same" zero padding, kernel 1 or 3, fp32 on a ROCm
+    device, nothing to differentiate, and at least two samples per LDS group (below that torch's convolution is faster)"""
+    if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return False
+    k = conv.kernel_size
+    if k[0] != k[1] or k[0] not in (1, 3) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 \
+            or conv.padding_mode != "zeros" or x.shape[1] != conv.in_channels:
+        return False
+    pad = conv.padding
+    if not (pad == "same" or (not isinstance(pad, str) and tuple(pad) == (k[0] // 2, k[0] // 2))):
+        return False
+    from . import _ext
+    return _ext.load().usf_conv2d_same_fits(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3], k[0]) >= 2
+
+
+def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None):
+    """usf_conv2d_same_f32 for an nn.Conv2d (weight planes cached per parameter version); in_act / out_act: (id, slope)"""
+    from . import _ext
+    key = (conv.weight.data_ptr(), conv.weight._version, str(x.device))
+    cache = getattr(conv, "_usf_planes", None)
+    if cache is None or cache[0] != key:
+        cache = (key, _ext.conv2d_weight_planes(conv.weight.detach().to(x.device)))
+        conv._usf_planes = cache
+    ia, isl = in_act if in_act is not None else (_ext.ACT_NONE, 0.0)
+    oa, osl = out_act if out_act is not None else (_ext.ACT_NONE, 0.0)
+    bias = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
+    return _ext.conv2d_same(x.contiguous(), cache[1], conv.out_channels, conv.kernel_size[0], bias=bias, in_mul=in_mul,
+                            in_act=ia, in_slope=isl, out_act=oa, out_slope=osl)
+
+
 class LayerNormChannels(nn.Module):
     """layer norm across the channel axis of [B, C, H, W] (networks.py:40-58)"""
 
@@ -228,6 +261,16 @@ class GatedConv(nn.Module):
         )
 
     def forward(self, x):
+        n = self.net
+        a0, a2 = _relu_kind(n[0]), _relu_kind(n[2])
+        if a0 is not None and a2 is not None and _conv_hip_ok(n[1], x):
+            # device form: the two nonlinearities ride in the convolutions' staging passes, the gate in one more pass
+            from . import _ext
+            h = _conv_hip(n[1], x, in_act=a0)
+            if _conv_hip_ok(n[3], h):
+                vg = _conv_hip(n[3], h, in_act=a2)
+                if vg.shape[1] == 2 * x.shape[1] and vg.shape[2:] == x.shape[2:]:
+                    return _ext.gated_residual(x.contiguous(), vg)
         vg = self.net(x)
         if (x.is_cuda and x.dtype == torch.float32 and vg.dtype == torch.float32 and vg.shape[1] == 2 * x.shape[1]
                 and vg.shape[2:] == x.shape[2:] and not (torch.is_grad_enabled() and (x.requires_grad or vg.requires_grad))):
@@ -265,20 +308,36 @@ class ConvNet2D(nn.Module):
         layers += [conv(c_hidden, c_out)]
         self.nn = nn.Sequential(*layers)
 
-    def forward(self, x, context=None):
+    def forward(self, x, context=None, in_mul=None):
+        """in_mul (device path only, see ``first_conv_on_device``): a [C * H * W] mask the FIRST convolution multiplies
+        into its input -- MaskedCoupling hands over the unmasked x and its mask instead of a masked copy"""
         mods = list(self.nn)
-        if not (x.is_cuda and x.dtype == torch.float32 and any(isinstance(m, LayerNormChannels) for m in mods)):
+        if not (x.is_cuda and x.dtype == torch.float32):
+            assert in_mul is None
             return self.nn(x)
-        # the same module sequence; a (Leaky)ReLU directly in front of a LayerNormChannels joins that layer's device pass
+        # the same module sequence on the device: convolutions on usf_conv2d_same_f32 (a nonlinearity behind a plain
+        # convolution rides in its epilogue), a (Leaky)ReLU in front of a LayerNormChannels joins that layer's pass
         k = 0
         while k < len(mods):
             m = mods[k]
             nxt = mods[k + 1] if k + 1 < len(mods) else None
             act = _relu_kind(m)
-            if act is not None and isinstance(nxt, LayerNormChannels) and nxt._hip_ok(x):
+            if isinstance(m, nn.Conv2d) and _conv_hip_ok(m, x):
+                fold = _relu_kind(nxt) if nxt is not None else None
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                if fold is not None and isinstance(after, LayerNormChannels):
+                    fold = None                                   # that ReLU belongs to the layer norm's pass
+                x = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, out_act=fold)
+                k += 2 if fold is not None else 1
+            elif act is not None and isinstance(nxt, LayerNormChannels) and nxt._hip_ok(x):
                 x = nxt(x, pre_act=act)
                 k += 2
             else:
+                assert not (k == 0 and in_mul is not None)
                 x = m(x)
                 k += 1
         return x
+
+    def first_conv_on_device(self, x) -> bool:
+        """True when forward(x, in_mul=mask) may be used: the first module is a convolution the HIP kernel serves"""
+        return len(self.nn) > 0 and _conv_hip_ok(self.nn[0], x)

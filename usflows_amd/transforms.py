@@ -178,19 +178,31 @@ class MaskedCoupling(BaseTransform):
             cache = self._om_cache = (key, om)
         return _ext.masked_residual(x.contiguous(), t.contiguous(), cache[1], sign)
 
+    def _conditioner_masked(self, x, context):
+        """conditioner(x * mask); a ConvNet2D on the device takes x and the mask and multiplies inside its first
+        convolution's staging pass"""
+        cond = self.conditioner
+        if context is None and hasattr(cond, "first_conv_on_device") and x.dim() == 4 \
+                and self.mask.numel() == x[0].numel() and use_hip(self, x) and cond.first_conv_on_device(x):
+            key = (self.mask.data_ptr(), self.mask._version, str(x.device))
+            cache = getattr(self, "_m_cache", None)
+            if cache is None or cache[0] != key:
+                cache = self._m_cache = (key, self.mask.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous())
+            return cond(x, in_mul=cache[1])
+        x_masked = x * self.mask
+        return cond(x_masked) if context is None else cond(x_masked, context)
+
     def forward(self, x, context=None):
         if self._hip_ok(x, context):
             return self._hip("forward", x, context)
-        x_masked = x * self.mask
-        t = self.conditioner(x_masked) if context is None else self.conditioner(x_masked, context)
+        t = self._conditioner_masked(x, context)
         y = self._image_residual(x, t, 1.0)
         return y if y is not None else x + (1 - self.mask) * t
 
     def backward(self, y, context=None):
         if self._hip_ok(y, context):
             return self._hip("backward", y, context)
-        y_masked = y * self.mask
-        t = self.conditioner(y_masked) if context is None else self.conditioner(y_masked, context)
+        t = self._conditioner_masked(y, context)
         x = self._image_residual(y, t, -1.0)
         return x if x is not None else y - (1 - self.mask) * t
 
