@@ -253,7 +253,7 @@ int usf_masked_residual_f32(const float* x, const float* t, const float* one_min
  * (usf_conv2d_weight_elems(cin, cout, ks) = 3 * coutp * kp elements).
  */
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
-/* > 0 (samples per LDS group) when usf_conv2d_same_f32 serves these sizes: weight planes + one padded sample must fit 144 KB of LDS */
+/* > 0 (samples per LDS group) when usf_conv2d_same_f32 serves these sizes: weight planes + one padded sample must fit 158 KB of LDS */
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                         const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,

@@ -20,6 +20,7 @@
 // Row strides of both LDS images are an odd number of 16-byte units: the 16 lanes of a fragment read hit 16 different
 // bank groups.
 #include "usf_common.h"
+#include <type_traits>
 
 namespace usf {
 
@@ -74,7 +75,6 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
 
   const int ngroups = (a.B + a.S - 1) / a.S;
   const int nblk = a.kp / 32;
-  const int ct_n = (a.coutp + 31) / 32;
   const int cpairs = (a.cin + 1) >> 1;
   const int ppass = (HW + 63) >> 6;                                  // 64-pixel passes over a channel plane
   // Staging: a wave takes (sample, channel pair) planes, a lane one pixel of both channels -- two coalesced loads, two
@@ -147,86 +147,98 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
     __syncthreads();
     if (gidx + (int)gridDim.x < ngroups) fetch(gidx + gridDim.x);
     // ---- implicit GEMM: 32 (co) x 32 (rows) patches dealt over the waves ----
-    const int rt_n = (R + 31) / 32;
-    for (int t = wave; t < ct_n * rt_n; t += 8) {
-      const int ct = t / rt_n, rt = t - ct * rt_n;
-      // this lane's two row positions (B operand columns): row r -> (sample, pixel) -> top-left of its window
-      int xbase[2];
+    // Patch shape by the amount of work in the group: 32 (co) x 32 (rows) when that gives every wave a patch, otherwise
+    // 16 x 32 or 16 x 16 (more patches, fewer MFMAs per fragment read)
+    auto patches = [&](auto pc_, auto pr_) {
+      constexpr int PC = decltype(pc_)::value, PR = decltype(pr_)::value;      // 16-row tiles per patch in co / rows
+      const int ctn = (a.coutp / 16 + PC - 1) / PC, rtn = (R + 16 * PR - 1) / (16 * PR);
+      for (int t = wave; t < ctn * rtn; t += 8) {
+        const int ct = t / rtn, rt = t - ct * rtn;
+        // this lane's row positions (B operand columns): row r -> (sample, pixel) -> top-left of its window
+        int xbase[PR];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = min(rt * 32 + b * 16 + li, R - 1);
-        const int s = r / HW, p = r - s * HW;
-        const int py = p / a.W, px = p - py * a.W;
-        xbase[b] = (s * PP + py * PW + px) * xrow;
-      }
-      const int co0 = ct * 32;
-      const bool two_co = co0 + 16 < a.coutp;                         // wave-uniform
-      int wbase[2];
-      wbase[0] = (co0 + li) * wrow;
-      wbase[1] = (min(co0 + 16, a.coutp - 16) + li) * wrow;
-      f32x4 acc[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[i][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      cv_bf16x8 wf[2][2][3], xf[2][2][3];                              // [buffer][tile][plane]: block k + 1 is read under block k
-      auto read_blk = [&](int blk, cv_bf16x8 (&w)[2][3], cv_bf16x8 (&xv)[2][3]) {
-        const int kflat = blk * 32 + 8 * lg;
-        int tap = kflat / a.cp;
-        const int c = kflat - tap * a.cp;
-        tap = min(tap, taps - 1);                                      // K padding: weights are zero there
-        const int dy = tap / a.ks, dx = tap - dy * a.ks;
-        const int xoff = (dy * PW + dx) * xrow + 2 * c;
-        const int woff = 2 * kflat;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          w[0][pl] = *reinterpret_cast<const cv_bf16x8*>(Wl + pl * wplane + wbase[0] + woff);
-          w[1][pl] = *reinterpret_cast<const cv_bf16x8*>(Wl + pl * wplane + wbase[1] + woff);
-          xv[0][pl] = *reinterpret_cast<const cv_bf16x8*>(Xl + pl * xplane + xbase[0] + xoff);
-          xv[1][pl] = *reinterpret_cast<const cv_bf16x8*>(Xl + pl * xplane + xbase[1] + xoff);
+        for (int b = 0; b < PR; ++b) {
+          const int r = min(rt * 16 * PR + b * 16 + li, R - 1);
+          const int sl = r / HW, p = r - sl * HW;
+          const int py = p / a.W, px = p - py * a.W;
+          xbase[b] = (sl * PP + py * PW + px) * xrow;
         }
-      };
-      auto mm_blk = [&](const cv_bf16x8 (&w)[2][3], const cv_bf16x8 (&xv)[2][3]) {
+        const int co0 = ct * 16 * PC;
+        const bool two_co = PC == 2 && co0 + 16 < a.coutp;              // wave-uniform
+        int wbase[PC];
+        wbase[0] = (co0 + li) * wrow;
+        if (PC == 2) wbase[PC - 1] = (min(co0 + 16, a.coutp - 16) + li) * wrow;
+        f32x4 acc[PC][PR];
+#pragma unroll
+        for (int i = 0; i < PC; ++i)
+#pragma unroll
+          for (int b = 0; b < PR; ++b) acc[i][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        cv_bf16x8 wf[2][PC][3], xf[2][PR][3];                            // [buffer][tile][plane]: block k + 1 is read under block k
+        auto read_blk = [&](int blk, cv_bf16x8 (&w)[PC][3], cv_bf16x8 (&xv)[PR][3]) {
+          const int kflat = blk * 32 + 8 * lg;
+          int tap = kflat / a.cp;
+          const int c = kflat - tap * a.cp;
+          tap = min(tap, taps - 1);                                      // K padding: weights are zero there
+          const int dy = tap / a.ks, dx = tap - dy * a.ks;
+          const int xoff = (dy * PW + dx) * xrow + 2 * c;
+          const int woff = 2 * kflat;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < PC; ++i) w[i][pl] = *reinterpret_cast<const cv_bf16x8*>(Wl + pl * wplane + wbase[i] + woff);
+#pragma unroll
+            for (int b = 0; b < PR; ++b) xv[b][pl] = *reinterpret_cast<const cv_bf16x8*>(Xl + pl * xplane + xbase[b] + xoff);
+          }
+        };
+        auto mm_blk = [&](const cv_bf16x8 (&w)[PC][3], const cv_bf16x8 (&xv)[PR][3]) {
 #define USF_CV(I, B_, P, Q) acc[I][B_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[I][P], xv[B_][Q], acc[I][B_], 0, 0, 0)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          USF_CV(0, b, 2, 0); USF_CV(0, b, 1, 1); USF_CV(0, b, 0, 2); USF_CV(0, b, 1, 0); USF_CV(0, b, 0, 1); USF_CV(0, b, 0, 0);
-          if (two_co) {
-            USF_CV(1, b, 2, 0); USF_CV(1, b, 1, 1); USF_CV(1, b, 0, 2); USF_CV(1, b, 1, 0); USF_CV(1, b, 0, 1); USF_CV(1, b, 0, 0);
+          for (int b = 0; b < PR; ++b) {
+            USF_CV(0, b, 2, 0); USF_CV(0, b, 1, 1); USF_CV(0, b, 0, 2); USF_CV(0, b, 1, 0); USF_CV(0, b, 0, 1); USF_CV(0, b, 0, 0);
+            if (PC == 2 && two_co) {
+              USF_CV(PC - 1, b, 2, 0); USF_CV(PC - 1, b, 1, 1); USF_CV(PC - 1, b, 0, 2); USF_CV(PC - 1, b, 1, 0); USF_CV(PC - 1, b, 0, 1);
+              USF_CV(PC - 1, b, 0, 0);
+            }
           }
-        }
 #undef USF_CV
-      };
-      read_blk(0, wf[0], xf[0]);
-      int blk = 0;
-      for (; blk + 2 <= nblk; blk += 2) {
-        read_blk(blk + 1, wf[1], xf[1]);
-        mm_blk(wf[0], xf[0]);
-        read_blk(min(blk + 2, nblk - 1), wf[0], xf[0]);
-        mm_blk(wf[1], xf[1]);
-      }
-      if (blk < nblk) mm_blk(wf[0], xf[0]);
-      // ---- epilogue: lane (col = li, g = lg) of tile (i, b) holds output channels co0 + 16 i + 4 g + (0..3) of row b*16 + li
+        };
+        read_blk(0, wf[0], xf[0]);
+        int blk = 0;
+        for (; blk + 2 <= nblk; blk += 2) {
+          read_blk(blk + 1, wf[1], xf[1]);
+          mm_blk(wf[0], xf[0]);
+          read_blk(min(blk + 2, nblk - 1), wf[0], xf[0]);
+          mm_blk(wf[1], xf[1]);
+        }
+        if (blk < nblk) mm_blk(wf[0], xf[0]);
+        // ---- epilogue: lane (col = li, g = lg) of tile (i, b) holds output channels co0 + 16 i + 4 g + (0..3) of row b*16 + li
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = rt * 32 + b * 16 + li;
-        if (r >= R) continue;
-        const int s = r / HW, p = r - s * HW;
-        float* yb = a.y + ((size_t)(s0 + s) * a.cout) * HW + p;
+        for (int b = 0; b < PR; ++b) {
+          const int r = rt * 16 * PR + b * 16 + li;
+          if (r >= R) continue;
+          const int sl = r / HW, p = r - sl * HW;
+          float* yb = a.y + ((size_t)(s0 + sl) * a.cout) * HW + p;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          if (i == 1 && !two_co) break;
+          for (int i = 0; i < PC; ++i) {
+            if (i == 1 && !two_co) break;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int co = co0 + 16 * i + 4 * lg + j;
-            if (co < a.cout) {
-              float v = acc[i][b][j] + (a.bias ? a.bias[co] : 0.f);
-              yb[(size_t)co * HW] = act_apply(v, a.out_act, a.out_slope);
+            for (int j = 0; j < 4; ++j) {
+              const int co = co0 + 16 * i + 4 * lg + j;
+              if (co < a.cout) {
+                float v = acc[i][b][j] + (a.bias ? a.bias[co] : 0.f);
+                yb[(size_t)co * HW] = act_apply(v, a.out_act, a.out_slope);
+              }
             }
           }
         }
       }
-    }
+    };
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    const int c16 = a.coutp / 16, r32 = (R + 31) / 32;
+    if (((c16 + 1) / 2) * r32 >= 7) patches(I2(), I2());
+    else if (c16 * r32 >= 7) patches(I1(), I2());
+    else patches(I1(), I1());
     __syncthreads();                                                 // the image is rewritten by the next group
   }
 }
@@ -255,7 +267,7 @@ int conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks
   if (cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || cin > 64 || cout > 64 || H * W > 256 || (ks != 1 && ks != 3)) return 0;
   int xs, ws, cp, kp, coutp;
   for (int S = 8; S >= 1; --S)
-    if (conv_lds_bytes((int)cin, (int)cout, (int)H, (int)W, (int)ks, S, &xs, &ws, &cp, &kp, &coutp) <= 144 * 1024 &&
+    if (conv_lds_bytes((int)cin, (int)cout, (int)H, (int)W, (int)ks, S, &xs, &ws, &cp, &kp, &coutp) <= 158 * 1024 &&
         conv_stage_iters((int)cin, (int)(H * W), S) <= 16) return S;
   return 0;
 }
@@ -278,12 +290,12 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W; a.ks = (int)ks;
   a.in_act = in_act; a.out_act = out_act; a.in_slope = in_slope; a.out_slope = out_slope;
-  // samples per group: as many as fit ~144 KB of LDS (at most 8; at least one has to fit)
+  // samples per group: as many as fit 158 KB of LDS (at most 8; at least one has to fit)
   int S = 8;
   int64_t lds = 0;
   for (; S >= 1; --S) {
     lds = conv_lds_bytes(a.cin, a.cout, a.H, a.W, a.ks, S, &a.xs16, &a.ws16, &a.cp, &a.kp, &a.coutp);
-    if (lds <= 144 * 1024 && conv_stage_iters(a.cin, a.H * a.W, S) <= 16) break;
+    if (lds <= 158 * 1024 && conv_stage_iters(a.cin, a.H * a.W, S) <= 16) break;
   }
   if (S < 1) { set_error("usf_conv2d_same_f32: one sample does not fit the LDS / staging registers (%lld bytes)", (long long)lds); return -3; }
   if (S > B) {
