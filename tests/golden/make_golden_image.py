@@ -39,6 +39,8 @@ def condition_(flow, seed, alpha=0.3):
 
 
 def run_case(name, in_dims, K, cond_args, seed, hh=1, conj=True, masktype="checkerboard", n=12):
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:
+        return
     torch.manual_seed(seed)
     base = torch.distributions.Laplace(torch.zeros(in_dims), torch.ones(in_dims))
     flow = flows.USFlow(base, list(in_dims), K, networks.ConvNet2D, dict(cond_args), householder=hh,
@@ -78,6 +80,7 @@ def run_case(name, in_dims, K, cond_args, seed, hh=1, conj=True, masktype="check
 
 
 def main():
+    only = sys.argv[1:]
     # (ConvNet2D's activation is its default nn.ReLU(); padding="same" as in tests/explib/mnist.yaml:62)
     run_case("image_c4_6x6_k3_gated_ln_hh1_conj", (4, 6, 6), 3,
              dict(c_in=4, c_hidden=8, num_layers=2, padding="same", normalize_layers=True, gating=True), 31)
@@ -86,6 +89,13 @@ def main():
              hh=0, conj=False, masktype="channel")
     run_case("image_c3_8x8_k2_gated_hh2_conj", (3, 8, 8), 2,
              dict(c_in=3, c_hidden=6, num_layers=1, padding="same", normalize_layers=False, gating=True), 33, hh=2)
+    # the live configurations themselves (tests/explib/mnist.yaml:44-77; experiments/cifar/cifar.yaml:56-77 with 2 of its
+    # 10 coupling blocks): the shapes the convolution kernel serves
+    run_case("image_mnistcfg_c16_7x7_k2_gated_ln_hh1_conj", (16, 7, 7), 2,
+             dict(c_in=16, c_hidden=32, num_layers=1, padding="same", kernel_size=3, normalize_layers=True, gating=True), 34)
+    run_case("image_cifarcfg_c48_8x8_k2_gated_ln_hh1_conj", (48, 8, 8), 2,
+             dict(c_in=48, c_hidden=32, num_layers=3, padding="same", kernel_size=3, normalize_layers=True, gating=True), 35,
+             n=6)
 
 
 if __name__ == "__main__":
