@@ -42,13 +42,20 @@ def test_image_flow_mirror_matches_reference_cpu(name):
 @pytest.mark.parametrize("name", image_case_names())
 def test_image_flow_on_device_matches_reference(name, monkeypatch):
     from usflows_amd import _ext
-    calls = []
-    real = _ext.channel_affine
+    calls, convs = [], []
+    real, real_conv = _ext.channel_affine, _ext.conv2d_same
     monkeypatch.setattr(_ext, "channel_affine", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+    monkeypatch.setattr(_ext, "conv2d_same", lambda x_, pl_, co_, ks_, **k_: (convs.append((x_.shape[1], co_, ks_)),
+                                                                             real_conv(x_, pl_, co_, ks_, **k_))[1])
     flow, a = load_image_case(name, device="cuda:0")
     _check(flow, a, "cuda:0")
     n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
-    assert len(calls) == 3 * n_aff, "the 1x1-conv affine layers did not run on usf_channel_affine_f32"
+    C = flow.in_dims[0]
+    # the 1 x 1-convolution affine layers: usf_channel_affine_f32 up to 16 channels, the matrix-core convolution above
+    n_aff_conv = sum(1 for c_ in convs if c_ == (C, C, 1))
+    assert len(calls) + n_aff_conv == 3 * n_aff and (n_aff_conv == 0) == (C <= 16), (len(calls), n_aff_conv, n_aff)
+    # the CNN conditioner's convolutions run on usf_conv2d_same_f32
+    assert any(c_[2] == 3 for c_ in convs), "the conditioner's 3 x 3 convolutions did not run on the HIP kernel"
 
 
 @pytest.mark.gpu

@@ -9,13 +9,14 @@ from usflows_amd.flows import USFlow
 from usflows_amd.networks import ConvNet2D
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+CFG = sys.argv[2] if len(sys.argv) > 2 else "mnist"      # "cifar": in_dims [48, 8, 8], 3 conditioner layers, 10 blocks
 dev = "cuda:0"
-dims = [16, 7, 7]
+dims = [16, 7, 7] if CFG == "mnist" else [48, 8, 8]
 torch.manual_seed(0)
 base = torch.distributions.Laplace(torch.zeros(dims).to(dev), torch.ones(dims).to(dev))
-flow = USFlow(base, dims, 2, ConvNet2D, dict(c_in=16, c_hidden=32, num_layers=1, padding="same", kernel_size=3,
+flow = USFlow(base, dims, 2 if CFG == "mnist" else 10, ConvNet2D, dict(c_in=dims[0], c_hidden=32, num_layers=1 if CFG == "mnist" else 3, padding="same", kernel_size=3,
                                             normalize_layers=True, gating=True, nonlinearity=torch.nn.ReLU()),
-              householder=1, affine_conjugation=True).to(dev)
+              householder=1 if CFG == "mnist" else 0, affine_conjugation=True).to(dev)
 x = torch.rand(B, *dims, device=dev)
 import warnings
 warnings.simplefilter("ignore")

@@ -655,15 +655,29 @@ class BlockAffineTransform(BaseTransform):
         if self._chan_cache is None or self._chan_cache[0] != key:
             with torch.no_grad():
                 r = prepare_affine_blocks([self.block_transform], device)[id(self.block_transform)]
-                self._chan_cache = (key, r["M"].float().contiguous(), r["Minv"].float().contiguous(),
-                                    r["b"].float().contiguous())
+                M, Minv, b = r["M"], r["Minv"], r["b"]
+                C = M.shape[0]
+                conv = None
+                if C > 16:
+                    # wide channel counts: the 1 x 1 convolution goes to the matrix cores (usf_conv2d_same_f32, kernel 1):
+                    # forward y = M x + b, backward x = Minv y + c with c = -(Minv b) folded in fp64
+                    from . import _ext
+                    c = -(Minv @ b)
+                    conv = (_ext.conv2d_weight_planes(M.float().reshape(C, C, 1, 1)), b.float().contiguous(),
+                            _ext.conv2d_weight_planes(Minv.float().reshape(C, C, 1, 1)), c.float().contiguous())
+                self._chan_cache = (key, M.float().contiguous(), Minv.float().contiguous(), b.float().contiguous(), conv)
         return self._chan_cache[1:]
 
     def _channel_hip(self, x, forward: bool):
-        """usf_channel_affine_f32: the 1x1 convolution on NCHW data (row N4); HBM-bound"""
+        """the 1x1 convolution on NCHW data (row N4): usf_channel_affine_f32 (one thread per pixel, HBM-bound) up to 16
+        channels; above that (CIFAR configuration: 48 channels, where that kernel's C^2 scalar FMAs per pixel take 10 x
+        the HBM time) usf_conv2d_same_f32 with kernel 1 on the matrix cores when the shape fits it"""
         from . import _ext
-        M, Minv, b = self._channel_prep(x.device)
+        M, Minv, b, conv = self._channel_prep(x.device)
         x = x.contiguous()
+        if conv is not None and x.dim() == 4 and \
+                _ext.load().usf_conv2d_same_fits(x.shape[1], x.shape[1], x.shape[2], x.shape[3], 1) >= 2:
+            return _ext.conv2d_same(x, conv[0] if forward else conv[2], x.shape[1], 1, bias=conv[1] if forward else conv[3])
         y = torch.empty_like(x)
         if forward:
             _ext.channel_affine(x, y, M, bias=b)
