@@ -181,3 +181,32 @@ def test_conv2d_same_kernel_vs_torch(B, cin, cout, H, W, ks):
     got = _ext.conv2d_same(xd, planes, cout, ks)
     ref = F.conv2d(x[rows].double(), w.double(), None, padding=ks // 2)
     assert (got[rows.to("cuda:0")].cpu().double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_conv2d_same_kernel_random_shapes():
+    """40 random shapes the kernel accepts (channels 1..64, H * W <= 256, kernel 1 or 3, batches that leave the last
+    sample group ragged) against F.conv2d in fp64"""
+    import random
+    import torch.nn.functional as F
+    from usflows_amd import _ext
+    lib = _ext.load()
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(99)
+    done = 0
+    while done < 40:
+        cin, cout, ks = rnd.randint(1, 64), rnd.randint(1, 64), rnd.choice([1, 3])
+        H = rnd.randint(1, 16)
+        W = rnd.randint(1, min(16, 256 // H))
+        B = rnd.randint(1, 40)
+        if lib.usf_conv2d_same_fits(cin, cout, H, W, ks) < 1:
+            continue
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+        b = torch.randn(cout, generator=g)
+        got = _ext.conv2d_same(x.to("cuda:0"), _ext.conv2d_weight_planes(w.to("cuda:0")), cout, ks, bias=b.to("cuda:0"),
+                               in_act=_ext.ACT_LEAKY_RELU, in_slope=0.1)
+        ref = F.conv2d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=ks // 2)
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err < 3e-6 * max(1.0, ref.abs().max().item()), (B, cin, cout, H, W, ks, err)
+        done += 1
