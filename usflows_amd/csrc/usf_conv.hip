@@ -36,6 +36,7 @@ struct ConvArgs {
   int S;                       // samples per group
   int xs16, ws16;              // LDS row strides in 16-byte units (odd)
   int in_act, out_act; float in_slope, out_slope;
+  int dbg;                     // tuning aid (USF_CONV_DBG): 1 no staging, 2 no k loop, 4 no output stores, 8 no input loads
 };
 
 __device__ __forceinline__ void cv_split(float x, __bf16& h, __bf16& m, __bf16& l) {
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
     const int s0 = gidx * a.S;
     const int ns = min(a.S, a.B - s0);
     const int R = ns * HW;                                           // live rows of this group
-    stage(gidx);
+    if (!(a.dbg & 1)) stage(gidx);
     __syncthreads();
-    if (gidx + (int)gridDim.x < ngroups) fetch(gidx + gridDim.x);
+    if (gidx + (int)gridDim.x < ngroups && !(a.dbg & 8)) fetch(gidx + gridDim.x);
     // ---- implicit GEMM: 32 (co) x 32 (rows) patches dealt over the waves ----
     // Patch shape by the amount of work in the group: 32 (co) x 32 (rows) when that gives every wave a patch, otherwise
     // 16 x 32 or 16 x 16 (more patches, fewer MFMAs per fragment read)
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
 #undef USF_CV
         };
         read_blk(0, wf[0], xf[0]);
-        int blk = 0;
+        int blk = (a.dbg & 2) ? nblk : 0;
         for (; blk + 2 <= nblk; blk += 2) {
           read_blk(blk + 1, wf[1], xf[1]);
           mm_blk(wf[0], xf[0]);
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int co = co0 + 16 * i + 4 * lg + j;
-              if (co < a.cout) {
+              if (co < a.cout && !(a.dbg & 4)) {
                 float v = acc[i][b][j] + (a.bias ? a.bias[co] : 0.f);
                 yb[(size_t)co * HW] = act_apply(v, a.out_act, a.out_slope);
               }
@@ -290,6 +291,9 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W; a.ks = (int)ks;
   a.in_act = in_act; a.out_act = out_act; a.in_slope = in_slope; a.out_slope = out_slope;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("USF_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
   // samples per group: as many as fit 158 KB of LDS (at most 8; at least one has to fit)
   int S = 8;
   int64_t lds = 0;
