@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 16
+#define USF_ABI_VERSION 17
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -251,13 +251,18 @@ int usf_masked_residual_f32(const float* x, const float* t, const float* one_min
  * coutp = ceil16(cout), K order tap-major / channel-minor with the channels padded to cp = ceil8(cin):
  * element [co][tap * cp + ci] = W[co, ci, tap / ks, tap % ks]; kp = ceil32(ks * ks * cp); zeros in all padding
  * (usf_conv2d_weight_elems(cin, cout, ks) = 3 * coutp * kp elements).
+ * Gated mode (gate_x != NULL, gate_channels = C): the convolution is GatedConv's second one (networks.py:108-122,
+ * 2C output channels: C values, then C gates) fused with the gate: y [B, C, H, W] = gate_x + value * sigmoid(gate), and
+ * the [B, 2C, H, W] tensor never exists.  The caller packs rows (and bias) interleaved in tiles of 16: packed row
+ * 32 t + r = value channel 16 t + r for r < 16, gate channel 16 t + r - 16 (original row C + 16 t + r - 16) for r >= 16,
+ * zero rows where 16 t + r >= C; cout = 32 * ceil(C / 16) is passed; out_act must be USF_ACT_NONE.
  */
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
 /* > 0 (samples per LDS group) when usf_conv2d_same_f32 serves these sizes: weight planes + one padded sample must fit 158 KB of LDS */
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                         const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
-                        int32_t out_act, float out_slope, usf_stream_t stream);
+                        int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, usf_stream_t stream);
 
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */

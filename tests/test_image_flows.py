@@ -210,3 +210,21 @@ def test_conv2d_same_kernel_random_shapes():
         err = (got.cpu().double() - ref).abs().max().item()
         assert err < 3e-6 * max(1.0, ref.abs().max().item()), (B, cin, cout, H, W, ks, err)
         done += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,ch,H,W", [(5, 32, 32, 7, 7), (3, 8, 8, 6, 6), (4, 6, 6, 8, 8), (1000, 32, 32, 7, 7), (2, 20, 12, 5, 5)])
+def test_gated_conv_module_on_device_vs_torch(B, C, ch, H, W):
+    """GatedConv (networks.py:61-122) on the device -- first convolution with the ReLU folded in, second convolution fused
+    with the gate (value / gate rows packed pairwise; channel counts that fill, half-fill and straddle the 16-row tiles)
+    -- against the same module's torch formulation in fp64"""
+    import copy
+    from usflows_amd.networks import GatedConv
+    torch.manual_seed(B + C + H)
+    m = GatedConv(C, ch, kernel_size=3, padding="same")
+    x = torch.randn(B, C, H, W) * 2
+    ref = copy.deepcopy(m).double()(x.double())
+    md = m.to("cuda:0")
+    with torch.no_grad():
+        got = md(x.to("cuda:0"))
+    assert (got.cpu().double() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())

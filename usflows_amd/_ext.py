@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 16
+USF_ABI_VERSION = 17
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -151,7 +151,7 @@ SYMBOLS = {
     "usf_conv2d_weight_elems": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_fits": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
-                                      C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+                                      C.c_int32, C.c_float, C.c_int32, C.c_float, _fp, C.c_int64, C.c_void_p]),
     "usf_masked_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -429,14 +429,20 @@ def layernorm_channels(x, gamma, beta, eps, act=ACT_NONE, slope=0.0):
     return y
 
 
-def conv2d_weight_planes(weight: torch.Tensor) -> torch.Tensor:
+def conv2d_weight_planes(weight: torch.Tensor, gate_channels: int = 0) -> torch.Tensor:
     """bf16x3 planes [3, coutp, kp] of a Conv2d weight [cout, cin, k, k] in the K order usf_conv2d_same_f32 reads
-    (tap-major, channel-minor, channels padded to a multiple of 8; include/usflows_hip.h)"""
+    (tap-major, channel-minor, channels padded to a multiple of 8; include/usflows_hip.h).  gate_channels = C > 0: the
+    weight has 2C rows (C values, C gates) and is packed for the gated mode (rows interleaved in tiles of 16)"""
     cout, cin, k, _ = weight.shape
+    w32 = weight.detach().to(torch.float32)
+    if gate_channels:
+        w32 = w32[conv2d_gate_row_order(gate_channels, weight.device)] * \
+            (conv2d_gate_row_order(gate_channels, weight.device, valid=True)).view(-1, 1, 1, 1)
+        cout = w32.shape[0]
     cp, coutp = (cin + 7) // 8 * 8, (cout + 15) // 16 * 16
     kp = (k * k * cp + 31) // 32 * 32
     w = torch.zeros(coutp, k * k, cp, dtype=torch.float32, device=weight.device)
-    w[:cout, :, :cin] = weight.detach().to(torch.float32).reshape(cout, cin, k * k).permute(0, 2, 1)
+    w[:cout, :, :cin] = w32.reshape(cout, cin, k * k).permute(0, 2, 1)
     flat = torch.zeros(coutp, kp, dtype=torch.float32, device=weight.device)
     flat[:, : k * k * cp] = w.reshape(coutp, k * k * cp)
     h = flat.to(torch.bfloat16)
@@ -448,13 +454,31 @@ def conv2d_weight_planes(weight: torch.Tensor) -> torch.Tensor:
     return planes
 
 
-def conv2d_same(x, planes, cout, ks, bias=None, in_mul=None, in_act=ACT_NONE, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0):
-    """usf_conv2d_same_f32 on a contiguous [B, cin, H, W] fp32 tensor -> new [B, cout, H, W] tensor"""
+def conv2d_gate_row_order(C: int, device, valid: bool = False) -> torch.Tensor:
+    """gated mode of usf_conv2d_same_f32: packed row 32 t + r <- original row (16 t + r | C + 16 t + r - 16), clamped;
+    valid=True: 1.0 where the packed row is a real channel, 0.0 where it is padding"""
+    nt = (C + 15) // 16
+    t = torch.arange(nt, device=device).view(-1, 1)
+    r = torch.arange(16, device=device).view(1, -1)
+    ch = 16 * t + r                                         # [nt, 16]
+    ok = (ch < C)
+    val = ch.clamp(max=C - 1)
+    rows = torch.stack([val, val + C], dim=1).reshape(-1)   # per tile: 16 value rows, then 16 gate rows
+    if valid:
+        return torch.stack([ok, ok], dim=1).reshape(-1).to(torch.float32)
+    return rows
+
+
+def conv2d_same(x, planes, cout, ks, bias=None, in_mul=None, in_act=ACT_NONE, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0,
+                gate_x=None):
+    """usf_conv2d_same_f32 on a contiguous [B, cin, H, W] fp32 tensor -> new [B, cout, H, W] tensor; gate_x [B, C, H, W]:
+    gated mode (planes / bias packed with gate_channels = C, cout = 32 * ceil(C / 16)) -> new [B, C, H, W] tensor"""
     B, cin, H, W = x.shape
-    y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    gc = 0 if gate_x is None else gate_x.shape[1]
+    y = torch.empty(B, gc if gc else cout, H, W, dtype=torch.float32, device=x.device)
     check(load().usf_conv2d_same_f32(x.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, planes.data_ptr(), ptr(bias),
                                      ptr(in_mul), int(in_act), float(in_slope), int(out_act), float(out_slope),
-                                     current_stream(x.device)), "usf_conv2d_same_f32")
+                                     ptr(gate_x), gc, current_stream(x.device)), "usf_conv2d_same_f32")
     return y
 
 

@@ -59,7 +59,7 @@ int64_t conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
 int conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                 const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
-                int32_t out_act, float out_slope, hipStream_t stream);
+                int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, hipStream_t stream);
 int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
                        float eps, int32_t act, float slope, hipStream_t stream);
 int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
@@ -217,9 +217,9 @@ int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks) { return 
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) { return usf::conv2d_same_fits(cin, cout, H, W, ks); }
 int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                         const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
-                        int32_t out_act, float out_slope, usf_stream_t stream) {
+                        int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, usf_stream_t stream) {
   return usf::conv2d_same(x, y, B, cin, cout, H, W, ks, w_planes, bias, in_mul, in_act, in_slope, out_act, out_slope,
-                          (hipStream_t)stream);
+                          gate_x, gate_channels, (hipStream_t)stream);
 }
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   return usf::wgrad_variant(M, N, K, ldy, lda, mode);

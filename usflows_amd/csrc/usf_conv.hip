@@ -36,6 +36,7 @@ struct ConvArgs {
   int S;                       // samples per group
   int xs16, ws16;              // LDS row strides in 16-byte units (odd)
   int in_act, out_act; float in_slope, out_slope;
+  const float* gate_x; int gateC;   // gated mode (GatedConv's second convolution + its gate): see usf_conv2d_same_f32
   int dbg;                     // tuning aid (USF_CONV_DBG): 1 no staging, 2 no k loop, 4 no output stores, 8 no input loads
 };
 
@@ -219,6 +220,21 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
           if (r >= R) continue;
           const int sl = r / HW, p = r - sl * HW;
           float* yb = a.y + ((size_t)(s0 + sl) * a.cout) * HW + p;
+          if (PC == 2 && a.gateC > 0) {
+            // gated mode: the patch's two tiles are (value, gate) of the same 16 channels (rows interleaved at pack time):
+            // y[c] = x[c] + value * sigmoid(gate) -- GatedConv.forward's tail (networks.py:108-122) without the [B, 2C] tensor
+            const size_t gb = ((size_t)(s0 + sl) * a.gateC) * HW + p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = (co0 >> 1) + 4 * lg + j;
+              if (c < a.gateC && !(a.dbg & 4)) {
+                const float val = acc[0][b][j] + (a.bias ? a.bias[co0 + 4 * lg + j] : 0.f);
+                const float gt = acc[PC - 1][b][j] + (a.bias ? a.bias[co0 + 16 + 4 * lg + j] : 0.f);
+                a.y[gb + (size_t)c * HW] = a.gate_x[gb + (size_t)c * HW] + val * (1.f / (1.f + expf(-gt)));
+              }
+            }
+            continue;
+          }
 #pragma unroll
           for (int i = 0; i < PC; ++i) {
             if (i == 1 && !two_co) break;
@@ -237,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
     typedef std::integral_constant<int, 1> I1;
     typedef std::integral_constant<int, 2> I2;
     const int c16 = a.coutp / 16, r32 = (R + 31) / 32;
-    if (((c16 + 1) / 2) * r32 >= 7) patches(I2(), I2());
+    if (((c16 + 1) / 2) * r32 >= 7 || (a.gateC > 0 && (c16 / 2) * r32 >= 4)) patches(I2(), I2());
+    else if (a.gateC > 0) patches(I2(), I1());                       // (value, gate) tile pairs stay together
     else if (c16 * r32 >= 7) patches(I1(), I2());
     else patches(I1(), I1());
     __syncthreads();                                                 // the image is rewritten by the next group
@@ -275,7 +292,7 @@ int conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks
 
 int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                 const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
-                int32_t out_act, float out_slope, hipStream_t stream) {
+                int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, hipStream_t stream) {
   if (B < 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || cin > 64 || cout > 64 || H * W > 256 || (ks != 1 && ks != 3) ||
       B > 0x7fffffff) {
     set_error("usf_conv2d_same_f32: unsupported sizes (channels 1..64, H * W <= 256, kernel 1 or 3)");
@@ -284,6 +301,10 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   if (B == 0) return 0;
   if (!x || !y || !wplanes) { set_error("usf_conv2d_same_f32: null pointer"); return -1; }
   if (x == y) { set_error("usf_conv2d_same_f32: in-place operation is not supported"); return -2; }
+  if ((gate_x != nullptr) != (gate_channels > 0) || (gate_x && (cout != 32 * ((gate_channels + 15) / 16) || out_act != USF_ACT_NONE))) {
+    set_error("usf_conv2d_same_f32: gated mode wants gate_x, gate_channels C > 0, cout = 32 * ceil(C / 16) interleaved rows, no output activation");
+    return -2;
+  }
   if (!aligned16(wplanes)) { set_error("usf_conv2d_same_f32: weight planes must be 16-byte aligned"); return -2; }
   for (int32_t act : {in_act, out_act})
     if (act != USF_ACT_NONE && act != USF_ACT_LEAKY_RELU) { set_error("usf_conv2d_same_f32: bad act"); return -2; }
@@ -294,6 +315,7 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("USF_CONV_DBG"); dbg = e ? atoi(e) : 0; }
   a.dbg = dbg;
+  a.gate_x = gate_x; a.gateC = (int)gate_channels;
   // samples per group: as many as fit 158 KB of LDS (at most 8; at least one has to fit)
   int S = 8;
   int64_t lds = 0;

@@ -267,9 +267,26 @@ class GatedConv(nn.Module):
             # device form: the two nonlinearities ride in the convolutions' staging passes, the gate in one more pass
             from . import _ext
             h = _conv_hip(n[1], x, in_act=a0)
-            if _conv_hip_ok(n[3], h):
+            C = x.shape[1]
+            if _conv_hip_ok(n[3], h) and n[3].out_channels == 2 * C:
+                cout_g = 32 * ((C + 15) // 16)
+                if cout_g <= 64 and _ext.load().usf_conv2d_same_fits(h.shape[1], cout_g, h.shape[2], h.shape[3],
+                                                                        n[3].kernel_size[0]) >= 2:
+                    # the second convolution and the gate in ONE launch: its (value, gate) rows are packed pairwise and
+                    # the epilogue writes x + value * sigmoid(gate) -- the [B, 2C, H, W] tensor never exists
+                    conv = n[3]
+                    key = (conv.weight.data_ptr(), conv.weight._version, str(x.device), "gate")
+                    cache = getattr(conv, "_usf_gate_planes", None)
+                    if cache is None or cache[0] != key:
+                        w = conv.weight.detach().to(x.device)
+                        rows = _ext.conv2d_gate_row_order(C, x.device)
+                        ok = _ext.conv2d_gate_row_order(C, x.device, valid=True)
+                        bias = None if conv.bias is None else (conv.bias.detach().to(torch.float32)[rows] * ok).contiguous()
+                        cache = conv._usf_gate_planes = (key, _ext.conv2d_weight_planes(w, gate_channels=C), bias)
+                    return _ext.conv2d_same(h, cache[1], cout_g, conv.kernel_size[0], bias=cache[2], in_act=a2[0],
+                                            in_slope=a2[1], gate_x=x.contiguous())
                 vg = _conv_hip(n[3], h, in_act=a2)
-                if vg.shape[1] == 2 * x.shape[1] and vg.shape[2:] == x.shape[2:]:
+                if vg.shape[1] == 2 * C and vg.shape[2:] == x.shape[2:]:
                     return _ext.gated_residual(x.contiguous(), vg)
         vg = self.net(x)
         if (x.is_cuda and x.dtype == torch.float32 and vg.dtype == torch.float32 and vg.shape[1] == 2 * x.shape[1]
