@@ -48,6 +48,7 @@ def test_image_flow_on_device_matches_reference(name, monkeypatch):
     monkeypatch.setattr(_ext, "conv2d_same", lambda x_, pl_, co_, ks_, **k_: (convs.append((x_.shape[1], co_, ks_)),
                                                                              real_conv(x_, pl_, co_, ks_, **k_))[1])
     flow, a = load_image_case(name, device="cuda:0")
+    flow.graph_max_rows = 0                      # count the eager loop's launches (the hipGraph path: its own test below)
     _check(flow, a, "cuda:0")
     n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
     C = flow.in_dims[0]
@@ -228,3 +229,32 @@ def test_gated_conv_module_on_device_vs_torch(B, C, ch, H, W):
     with torch.no_grad():
         got = md(x.to("cuda:0"))
     assert (got.cpu().double() - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", image_case_names())
+def test_small_batch_layer_loop_replays_a_hip_graph(name):
+    """log_prob of <= 256 rows of an image-shaped flow: captured once per (shape, parameter versions), replayed afterwards --
+    bit-equal to the eager loop, recaptured after an in-place parameter update, a second shape gets a graph of its own"""
+    flow, a = load_image_case(name, device="cuda:0")
+    x = a["x"].to("cuda:0")
+    with torch.no_grad():
+        flow.graph_max_rows = 0
+        eager = flow.log_prob(x)
+        eager_half = flow.log_prob(x[: x.shape[0] // 2])
+        flow.graph_max_rows = 256
+        g1 = flow.log_prob(x)
+        g2 = flow.log_prob(x)
+        assert len(flow._loop_graphs) == 1 and not getattr(flow, "_loop_graph_off", False)
+        assert torch.equal(g1, eager) and torch.equal(g2, eager)
+        assert torch.equal(flow.log_prob(x[: x.shape[0] // 2]), eager_half) and len(flow._loop_graphs) == 2
+        for p in flow.parameters():
+            if p.numel() > 1:
+                p.mul_(1.0 + 1e-3)
+        flow.graph_max_rows = 0
+        eager2 = flow.log_prob(x)
+        flow.graph_max_rows = 256
+        assert torch.equal(flow.log_prob(x), eager2) and not torch.equal(eager2, eager)
+    # under autograd the eager (composite) loop serves the call
+    lp = flow.log_prob(x)
+    assert lp.requires_grad

@@ -212,6 +212,14 @@ class Flow(torch.nn.Module):
                 if dp:
                     raise RuntimeError("usflows_amd: data_parallel_training: this layer list has no device backward")
                 self._train_failed = True          # this layer list has no device backward: composite from now on
+        if self._layer_loop_graph_ok(x, context):
+            out = self._layer_loop_graphed(x)
+            if out is not None:
+                return out
+        return self._layer_loop_log_prob(x, context)
+
+    def _layer_loop_log_prob(self, x, context=None):
+        """the reference's loop (flows.py:236-245), layer by layer"""
         log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
         for layer in reversed(self.layers):
             if context is not None:
@@ -223,6 +231,57 @@ class Flow(torch.nn.Module):
             x = y
         lp = self._base_log_prob_layer_loop(y)
         return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
+
+    # ---- small batches of the layer loop (image-shaped flows): one hipGraph replay instead of ~50 launches ------------
+    graph_max_rows = 256          # the reference evaluates in chunks of 100 (hyperopt.py:273-278); USFLOWS_AMD_LOOP_GRAPH=0: off
+
+    def _layer_loop_graph_ok(self, x, context) -> bool:
+        return (context is None and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
+                and 0 < x.shape[0] <= self.graph_max_rows and not getattr(self, "_loop_graph_off", False)
+                and os.environ.get("USFLOWS_AMD_LOOP_GRAPH", "1") != "0" and not _needs_grad(self, x)
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _layer_loop_graphed(self, x):
+        """The sync-free layer loop captured once per (input shape, parameter versions) and replayed: at 32 .. 256 rows the
+        loop is ~50 dependent launches whose host side (module calls, ctypes, allocations) costs twice their GPU time --
+        MNIST image configuration, 100 rows: 0.90 -> 0.43 ms.  Any failure to capture switches this off for the flow (the
+        eager loop serves the call).  Returns None when it did not run."""
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+        d = self.base_distribution                               # (a torch distribution's tensors are not module state)
+        while isinstance(d, tdist.Independent):
+            d = d.base_dist
+        ver += tuple((t.data_ptr(), t._version) for t in (getattr(d, "loc", None), getattr(d, "scale", None)) if torch.is_tensor(t))
+        ver += tuple((l.mask.data_ptr(), l.mask._version) for l in self.layers if torch.is_tensor(getattr(l, "mask", None)))
+        cache = self.__dict__.setdefault("_loop_graphs", {})
+        key = (tuple(x.shape), str(x.device))
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            try:
+                with torch.no_grad():
+                    static_x = x.detach().clone()
+                    side = torch.cuda.Stream(device=x.device)
+                    side.wait_stream(torch.cuda.current_stream(x.device))
+                    with torch.cuda.stream(side):
+                        for _ in range(2):                       # caches (prep, weight planes, masks) fill outside the capture
+                            self._layer_loop_log_prob(static_x)
+                    torch.cuda.current_stream(x.device).wait_stream(side)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        static_out = self._layer_loop_log_prob(static_x)
+                hit = cache[key] = (ver, g, static_x, static_out)
+                if len(cache) > 8:
+                    cache.pop(next(iter(cache)))
+            except Exception as e:                               # noqa: BLE001 -- capture is an optimisation, never a requirement
+                import warnings
+                warnings.warn(f"usflows_amd: hipGraph capture of the layer loop failed ({type(e).__name__}: {e}); "
+                              "small batches keep the eager loop", RuntimeWarning)
+                self._loop_graph_off = True
+                return None
+        _, g, static_x, static_out = hit
+        static_x.copy_(x)
+        g.replay()
+        return static_out.clone()
 
     def _base_log_prob_layer_loop(self, y: torch.Tensor):
         """Laplace / Normal base density of the layer loop's result through ``usf_base_logprob_f32`` (rows flattened) when
