@@ -31,6 +31,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
 print(f"image flow log_prob B={B}: {ms:.2f} ms per call, {B / ms * 1e3:.0f} samples/s")
+if os.environ.get("IMAGE_PROFILE_PLAIN") == "1":      # under rocprofv3: no second profiler in the process
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for _ in range(3):
