@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 17
+#define USF_ABI_VERSION 18
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -368,6 +368,27 @@ typedef struct usf_coupling_planes_desc {
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream);
 
 /*
+ * Row pass of the vector ConvNet conditioner's blocks (networks.py:222-245 GatedMLP, :206-219 LayerNormVector, vector
+ * branch of ConvNet.__init__ :287-308), rows of [M, C] fp32:
+ *     r = skip + vg[:, :C] * sigmoid(vg[:, gate_off : gate_off + C])      (vg == NULL: r = skip)
+ *     y = (r - mean r) / sqrt(var r + eps) * gamma + beta                  (gamma == beta == NULL: y = r; biased variance)
+ *     out = y, out_act = act(y)                                            (either may be NULL, not both)
+ * Columns [C, c_pad) of out / out_act are written as zeros (operand padding of usf_linear_f32).  out may alias skip.
+ * 1 <= C <= c_pad <= 4096.
+ */
+typedef struct usf_gated_norm_desc {
+  const float* skip;    int64_t ld_skip;
+  const float* vg;      int64_t ld_vg;    int64_t gate_off;
+  const float* gamma;   const float* beta;
+  float*       out;     int64_t ld_out;
+  float*       out_act; int64_t ld_act;
+  int64_t M, C, c_pad;
+  float eps, slope;
+  int32_t act, reserved;
+} usf_gated_norm_desc;
+int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream);
+
+/*
  * Run a prebuilt list of ops with ONE call (the whole flow: ~2K+2 launches). op.kind selects the
  * member of the union; pointers inside may be patched by the caller between calls.
  */
@@ -376,6 +397,7 @@ int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream);
 #define USF_OP_PACK_PLANES 5
 #define USF_OP_GEMM_PLANES 6
 #define USF_OP_COUPLING_PLANES 7
+#define USF_OP_GATED_NORM 9
 typedef struct usf_op {
   int32_t kind;
   int32_t reserved;
@@ -385,6 +407,7 @@ typedef struct usf_op {
     usf_pack_planes_desc pack_planes;
     usf_gemm_planes_desc gemm_planes;
     usf_coupling_planes_desc coupling_planes;
+    usf_gated_norm_desc gated_norm;
   } u;
 } usf_op;
 
@@ -525,7 +548,8 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;
-                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc|usf_mt_chunk for 5|6|7|8: binding self-check */
+                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc|usf_mt_chunk|usf_gated_norm_desc for 5|6|7|8|9:
+                                           binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */
 

@@ -185,13 +185,29 @@ def conditioner_forward(sd, prefix, spec: FlowSpec, x, context=None):
                      spec.negative_slope)
         return F.linear(h, sd[f"{prefix}layers.{n_hidden}.weight"], sd[f"{prefix}layers.{n_hidden}.bias"])
     elif spec.conditioner == "ConvNet":
-        # vector path of ConvNet with gating=False, normalize_layers=False (networks.py:287-308, forward 379-389):
+        # vector path of ConvNet (networks.py:287-308, forward 379-389); plain form (gating=False, normalize_layers=False):
         # nn.0 = Linear(D, h0); nn.{i+1} = Sequential(f, Linear(prev, c_hidden[i])); nn.{n+1} = Linear(c_hidden[-1], D)
         # -- the activation sits IN FRONT of every block's Linear, none in front of the final Linear
-        h = F.linear(x, sd[f"{prefix}nn.0.weight"], sd[f"{prefix}nn.0.bias"])
+        # with gating (spec.extra["gating"]): block = GatedMLP (networks.py:222-245): [val, gate] = Linear(f(Linear(f(h)))),
+        # h <- (h or proj(h)) + val * sigmoid(gate); with spec.extra["normalize_layers"]: LayerNormVector (networks.py:206-219)
+        # after every block
+        gating, norm = bool(spec.extra.get("gating", False)), bool(spec.extra.get("normalize_layers", False))
+        lin = lambda h_, q: F.linear(h_, sd[f"{prefix}{q}.weight"], sd[f"{prefix}{q}.bias"])      # noqa: E731
+        h = lin(x, "nn.0")
+        m = 1
         for i in range(n_hidden):
-            h = F.linear(_act(h, spec.negative_slope), sd[f"{prefix}nn.{i + 1}.1.weight"], sd[f"{prefix}nn.{i + 1}.1.bias"])
-        return F.linear(h, sd[f"{prefix}nn.{n_hidden + 1}.weight"], sd[f"{prefix}nn.{n_hidden + 1}.bias"])
+            if gating:
+                vg = lin(_act(lin(_act(h, spec.negative_slope), f"nn.{m}.net1.1"), spec.negative_slope), f"nn.{m}.net1.3")
+                val, gate = vg.chunk(2, dim=1)
+                skip = lin(h, f"nn.{m}.proj") if f"{prefix}nn.{m}.proj.weight" in sd else h
+                h = skip + val * torch.sigmoid(gate)
+            else:
+                h = lin(_act(h, spec.negative_slope), f"nn.{m}.1")
+            m += 1
+            if norm:
+                h = F.layer_norm(h, (h.shape[1],), sd[f"{prefix}nn.{m}.layernorm.weight"], sd[f"{prefix}nn.{m}.layernorm.bias"], 1e-5)
+                m += 1
+        return lin(h, f"nn.{m}")
     raise ValueError(spec.conditioner)
 
 

@@ -58,6 +58,25 @@ def emulate_linear(d, pm: PtrMap, dtype=torch.float32):
     pm.view(d.C, M, N, d.ldc).copy_(v.to(torch.float32))
 
 
+def emulate_gated_norm(d, pm: PtrMap, dtype=torch.float32):
+    """usf_gated_norm_rows_f32 as include/usflows_hip.h documents it"""
+    M, Cn, Cp = d.M, d.C, d.c_pad
+    r = pm.view(d.skip, M, Cn, d.ld_skip).to(dtype)
+    if d.vg:
+        r = r + pm.view(d.vg, M, Cn, d.ld_vg).to(dtype) * torch.sigmoid(pm.view(d.vg + 4 * d.gate_off, M, Cn, d.ld_vg).to(dtype))
+    if d.gamma:
+        mean = r.mean(dim=1, keepdim=True)
+        var = ((r - mean) ** 2).mean(dim=1, keepdim=True)
+        r = (r - mean) / torch.sqrt(var + d.eps) * pm.vec(d.gamma, Cn).to(dtype) + pm.vec(d.beta, Cn).to(dtype)
+    full = torch.zeros(M, Cp, dtype=dtype)
+    full[:, :Cn] = r
+    if d.out:
+        pm.view(d.out, M, Cp, d.ld_out).copy_(full.to(torch.float32))
+    if d.out_act:
+        a = torch.where(full > 0, full, full * d.slope) if d.act == _ext.ACT_LEAKY_RELU else full
+        pm.view(d.out_act, M, Cp, d.ld_act).copy_(a.to(torch.float32))
+
+
 def emulate_coupling(d, pm: PtrMap, dtype=torch.float32):
     M = d.M
     zp = pm.view(d.z + 4 * d.off_pass, M, d.n_pass, d.ldz).to(dtype)
@@ -227,9 +246,9 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
     for cp in pk["coupling"].values():
         if "unfused" in cp:
             u = cp["unfused"]
-            for W, b in u["layers"]:
+            for W, b in u.get("layers", []):
                 pm.add(W), pm.add(b)
-            for t in (u["W_out"], u["b_out"], u.get("W_ctx4"), u.get("b_ctx")):
+            for t in [u["W_out"], u["b_out"], u.get("W_ctx4"), u.get("b_ctx")] + u.get("tensors", []):
                 pm.add(t)
         if "fused" in cp:
             f = cp["fused"]
@@ -262,6 +281,8 @@ def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
                 emulate_gemm_planes(op.u.gemm_planes, pm, dtype)
             elif op.kind == _ext.OP_COUPLING_PLANES:
                 emulate_coupling_planes(op.u.coupling_planes, pm, dtype)
+            elif op.kind == _ext.OP_GATED_NORM:
+                emulate_gated_norm(op.u.gated_norm, pm, dtype)
             else:
                 emulate_coupling(op.u.coupling, pm, dtype)
             pos += 1

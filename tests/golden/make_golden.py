@@ -66,8 +66,8 @@ def build_reference(spec, seed):
                     out_dim=spec.dim, nonlinearity=act)
     elif spec.conditioner == "ConvNet":
         cls = networks.ConvNet
-        args = dict(in_dims=[spec.dim], c_hidden=list(spec.hidden_dims), nonlinearity=act, normalize_layers=False,
-                    gating=False)
+        args = dict(in_dims=[spec.dim], c_hidden=list(spec.hidden_dims), nonlinearity=act,
+                    normalize_layers=bool(spec.extra.get("normalize_layers", False)), gating=bool(spec.extra.get("gating", False)))
     else:
         from pyro.nn import DenseNN
         cls = DenseNN
@@ -228,6 +228,15 @@ def main():
     run_case("synth_d16_k3_convnet_vec", S(16, 3, [32, 24], householder=0, conditioner="ConvNet"), "synth", 24)
     run_case("synth_d33_k2_convnet_vec_conj", S(33, 2, [40], householder=1, affine_conjugation=True,
                                                conditioner="ConvNet", negative_slope=0.0), "synth", 25)
+    # --- the same class as the reference constructs it by default: GatedMLP blocks + LayerNormVector (networks.py:206-245) ---
+    run_case("synth_d16_k3_convnet_gated_ln", S(16, 3, [32, 24], householder=0, conditioner="ConvNet",
+                                                extra={"gating": True, "normalize_layers": True}), "synth", 27)
+    run_case("synth_d33_k2_convnet_gated_conj", S(33, 2, [40, 40], householder=1, affine_conjugation=True, conditioner="ConvNet",
+                                                  negative_slope=0.0, extra={"gating": True}), "synth", 28)
+    run_case("synth_d64_k3_convnet_ln", S(64, 3, [96, 50], householder=0, conditioner="ConvNet",
+                                          extra={"normalize_layers": True}), "synth", 29)
+    run_case("init_d4_k2_convnet_default", S(4, 2, [32, 32], householder=1, conditioner="ConvNet", negative_slope=0.0,
+                                              extra={"gating": True, "normalize_layers": True}), "init", 5)
     # --- BASELINE cfg2 model (D=784, K=32, h=[256,256]); state dict regenerated from seed --
     run_case("synth_d784_k32_cfg2", S(784, 32, [256, 256], householder=0), "synth", 100, n=64, store_sd=False)
     run_case("synth_d784_k4_hh1_conj", S(784, 4, [256, 256], householder=1, affine_conjugation=True),

@@ -88,6 +88,10 @@ def test_planes_pipeline_ops_reproduce_golden(name, fmt, fused):
         eng.use_planes, eng.planes_min_rows = True, 0
         assert not eng._planes_ok("backward", 48, True, False)           # context: the fp32 path serves it
         return
+    if spec.conditioner == "ConvNet" and (spec.extra.get("gating") or spec.extra.get("normalize_layers")):
+        eng.use_planes, eng.planes_min_rows = True, 0
+        assert not eng._planes_ok("backward", 48, False, False)          # gate / layer-norm blocks: chain of fp32 ops
+        return
     z = emulator.engine_transform(eng, a["x"], "backward", None, fused, planes=fmt)
     assert any(p.get("planes") and p["planes_fmt"] == (1 if fmt == "f16x2" else 0) for p in eng._plans.values())
     if fused and not (fmt == "bf16x3" and len(spec.hidden_dims) == 3):

@@ -372,3 +372,56 @@ def test_linear_gate_epilogue_is_act_grad_of_the_plain_product(M, N, K, mode):
     ext.linear(A, W, got, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, W_split=planes, act=ext.ACT_GATE, slope=0.01, addend=h, ldadd=ldh)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("gated,norm,act", [(True, True, True), (True, False, True), (False, True, False), (False, False, True),
+                                            (True, True, False)])
+@pytest.mark.parametrize("M,C", [(1, 1), (7, 24), (130, 50), (1000, 256), (4099, 300), (257, 1024), (33, 1500)])
+def test_gated_norm_rows(M, C, gated, norm, act):
+    """usf_gated_norm_rows_f32 -- the row pass of the vector ConvNet conditioner's blocks (networks.py:206-245): gate,
+    torch.nn.LayerNorm and the activation in front of the next Linear -- against the torch fp64 formulation; padded
+    strides, zero-filled operand padding, in place on the skip buffer"""
+    ext, dev = _ext(), _dev()
+    g = torch.Generator().manual_seed(1000 * M + C)
+    cp = (C + 3) // 4 * 4
+    ld = cp + 4
+    skip = torch.randn(M, ld, generator=g).to(dev)
+    vg = torch.randn(M, 2 * cp + 8, generator=g).to(dev)
+    gamma, beta = (0.5 + torch.rand(C, generator=g)).to(dev), torch.randn(C, generator=g).to(dev)
+    out = torch.full((M, ld), 7.0, device=dev)
+    out_act = torch.full((M, ld), 7.0, device=dev)
+    r = skip[:, :C].double()
+    if gated:
+        r = r + vg[:, :C].double() * torch.sigmoid(vg[:, cp: cp + C].double())
+    if norm:
+        r = torch.nn.functional.layer_norm(r, (C,), gamma.double(), beta.double(), 1e-5)
+    ext.gated_norm_rows(skip, M=M, C_cols=C, c_pad=cp, ld_skip=ld, vg=vg if gated else None, ld_vg=vg.shape[1], gate_off=cp,
+                        gamma=gamma if norm else None, beta=beta if norm else None, eps=1e-5, out=out, ld_out=ld,
+                        out_act=out_act if act else None, ld_act=ld, act=ext.ACT_LEAKY_RELU if act else ext.ACT_NONE, slope=0.01)
+    torch.cuda.synchronize()
+    tol = 2e-6 * max(1.0, r.abs().max().item()) * (4 if norm else 1)
+    assert (out[:, :C].double() - r).abs().max().item() < tol
+    assert torch.equal(out[:, C:cp], torch.zeros(M, cp - C, device=dev)) and torch.equal(out[:, cp:], torch.full((M, ld - cp), 7.0, device=dev))
+    if act:
+        assert torch.equal(out_act[:, :cp], torch.nn.functional.leaky_relu(out[:, :cp], 0.01))
+    else:
+        assert torch.equal(out_act, torch.full((M, ld), 7.0, device=dev))
+    # in place on the skip buffer (what the engine does when the block needs no projection)
+    skip2 = skip.clone()
+    ext.gated_norm_rows(skip2, M=M, C_cols=C, c_pad=cp, ld_skip=ld, vg=vg if gated else None, ld_vg=vg.shape[1], gate_off=cp,
+                        gamma=gamma if norm else None, beta=beta if norm else None, eps=1e-5, out=skip2, ld_out=ld)
+    torch.cuda.synchronize()
+    assert torch.equal(skip2[:, :cp], out[:, :cp])
+
+
+def test_gated_norm_rows_rejects_bad_args():
+    ext, dev = _ext(), _dev()
+    x = torch.zeros(4, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        ext.gated_norm_rows(x, M=4, C_cols=8, ld_skip=8)                                    # no output
+    with pytest.raises(RuntimeError):
+        ext.gated_norm_rows(x, M=4, C_cols=8, ld_skip=4, out=x, ld_out=8)                   # stride shorter than the row
+    with pytest.raises(RuntimeError):
+        ext.gated_norm_rows(x, M=4, C_cols=8, ld_skip=8, out=x, ld_out=8, gamma=x)          # gamma without beta
+    with pytest.raises(RuntimeError):
+        ext.gated_norm_rows(x, M=4, C_cols=5000, c_pad=5000, ld_skip=5000, out=x, ld_out=5000)

@@ -194,7 +194,7 @@ def test_simplify_is_equivalent():
 
 def test_convnet_vector_path_layout_and_engine_view():
     """vector path of the reference's generic ConvNet (networks.py:287-308): module order / state-dict keys, the
-    default gated + layer-normalised variant on the torch path, and the plain variant's folded MLP view"""
+    default gated + layer-normalised variant and its block view, and the plain variant's folded MLP view"""
     from usflows_amd.networks import ConvNet, GatedMLP, LayerNormVector
     from usflows_amd.engine import conditioner_supported
     torch.manual_seed(0)
@@ -215,7 +215,12 @@ def test_convnet_vector_path_layout_and_engine_view():
     default = ConvNet([6], [8, 5])
     assert isinstance(default.nn[1], GatedMLP) and isinstance(default.nn[2], LayerNormVector)
     assert default.nn[3].proj is not None and default.nn[1].proj is None      # 8 -> 5 needs the residual projection
-    assert default(x).shape == (9, 6) and not conditioner_supported(default)
+    assert default(x).shape == (9, 6) and conditioner_supported(default)      # device form: chain of ops (engine.py)
+    first, blocks, final = default.block_view()
+    assert first is default.nn[0] and final is default.nn[-1] and [b["w_in"] for b in blocks] == [8, 8]
+    assert blocks[0]["l1"] is default.nn[1].net1[1] and blocks[1]["proj"] is default.nn[3].proj
+    assert blocks[1]["ln"] is default.nn[4].layernorm and "lin" not in blocks[0]
+    assert not conditioner_supported(ConvNet([6], [8, 5], nonlinearity=torch.nn.Tanh()))
     with pytest.raises(NotImplementedError):
         ConvNet([3, 8, 8], [4])
 

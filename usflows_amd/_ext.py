@@ -16,12 +16,12 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 17
+USF_ABI_VERSION = 18
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
 BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
-OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES = 1, 2, 5, 6, 7
+OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES, OP_GATED_NORM = 1, 2, 5, 6, 7, 9
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -93,9 +93,17 @@ class MtChunk(C.Structure):
     _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("h", _fp), ("n", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GatedNormDesc(C.Structure):
+    """usf_gated_norm_desc: row pass of the vector ConvNet conditioner (gate, layer norm, activation)"""
+    _fields_ = [("skip", _fp), ("ld_skip", C.c_int64), ("vg", _fp), ("ld_vg", C.c_int64), ("gate_off", C.c_int64),
+                ("gamma", _fp), ("beta", _fp), ("out", _fp), ("ld_out", C.c_int64), ("out_act", _fp), ("ld_act", C.c_int64),
+                ("M", C.c_int64), ("C", C.c_int64), ("c_pad", C.c_int64), ("eps", C.c_float), ("slope", C.c_float),
+                ("act", C.c_int32), ("reserved", C.c_int32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc), ("pack_planes", PackPlanesDesc),
-                ("gemm_planes", GemmPlanesDesc), ("coupling_planes", CouplingPlanesDesc)]
+                ("gemm_planes", GemmPlanesDesc), ("coupling_planes", CouplingPlanesDesc), ("gated_norm", GatedNormDesc)]
 
 
 class Op(C.Structure):
@@ -148,6 +156,7 @@ SYMBOLS = {
     "usf_layernorm_channels_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, C.c_float, C.c_int32,
                                              C.c_float, C.c_void_p]),
     "usf_gated_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_gated_norm_rows_f32": (C.c_int, [C.POINTER(GatedNormDesc), C.c_void_p]),
     "usf_conv2d_weight_elems": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_fits": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
@@ -205,7 +214,7 @@ def load() -> C.CDLL:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
     for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
                      (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc),
-                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk)):
+                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk), (OP_GATED_NORM, GatedNormDesc)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -490,6 +499,15 @@ def gated_residual(x, vg):
     check(load().usf_gated_residual_f32(x.data_ptr(), vg.data_ptr(), y.data_ptr(), B, CP, current_stream(x.device)),
           "usf_gated_residual_f32")
     return y
+
+
+def gated_norm_rows(skip, *, M, C_cols, c_pad=None, ld_skip=None, vg=None, ld_vg=0, gate_off=0, gamma=None, beta=None, eps=1e-5,
+                    out=None, ld_out=0, out_act=None, ld_act=0, act=ACT_NONE, slope=0.0):
+    """usf_gated_norm_rows_f32 on raw [M, ld] fp32 buffers (see include/usflows_hip.h)"""
+    d = GatedNormDesc(skip=skip.data_ptr(), ld_skip=ld_skip if ld_skip is not None else C_cols, vg=ptr(vg), ld_vg=ld_vg,
+                      gate_off=gate_off, gamma=ptr(gamma), beta=ptr(beta), out=ptr(out), ld_out=ld_out, out_act=ptr(out_act),
+                      ld_act=ld_act, M=M, C=C_cols, c_pad=c_pad if c_pad is not None else C_cols, eps=eps, slope=slope, act=act)
+    _launch("usf_gated_norm_rows_f32", (C.byref(d), current_stream(skip.device)), (d, skip, vg, gamma, beta, out, out_act))
 
 
 def masked_residual(x, t, one_minus_mask, sign):

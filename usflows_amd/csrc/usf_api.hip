@@ -63,6 +63,7 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
 int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
                        float eps, int32_t act, float slope, hipStream_t stream);
 int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
+int gated_norm_rows(const usf_gated_norm_desc* d, hipStream_t stream);
 int masked_residual(const float* x, const float* t, const float* om, float sign, float* y, int64_t B, int64_t CP,
                     hipStream_t stream);
 int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
@@ -94,6 +95,7 @@ int usf_sizeof_desc(int32_t kind) {
     case USF_OP_GEMM_PLANES: return (int)sizeof(usf_gemm_planes_desc);
     case USF_OP_COUPLING_PLANES: return (int)sizeof(usf_coupling_planes_desc);
     case 8: return (int)sizeof(usf_mt_chunk);
+    case USF_OP_GATED_NORM: return (int)sizeof(usf_gated_norm_desc);
     default: return -1;
   }
 }
@@ -209,6 +211,9 @@ int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, i
 int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B, int64_t CP, usf_stream_t stream) {
   return usf::gated_residual(x, vg, y, B, CP, (hipStream_t)stream);
 }
+int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream) {
+  return usf::gated_norm_rows(d, (hipStream_t)stream);
+}
 int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
                             int64_t CP, usf_stream_t stream) {
   return usf::masked_residual(x, t, one_minus_mask, sign, y, B, CP, (hipStream_t)stream);
@@ -251,6 +256,7 @@ int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {
       case USF_OP_PACK_PLANES: rc = usf::pack_planes(&ops[i].u.pack_planes, (hipStream_t)stream); break;
       case USF_OP_GEMM_PLANES: rc = usf::gemm_planes(&ops[i].u.gemm_planes, (hipStream_t)stream); break;
       case USF_OP_COUPLING_PLANES: rc = usf::coupling_planes(&ops[i].u.coupling_planes, (hipStream_t)stream); break;
+      case USF_OP_GATED_NORM: rc = usf::gated_norm_rows(&ops[i].u.gated_norm, (hipStream_t)stream); break;
       default: usf::set_error("usf_run_ops: op %d has unknown kind %d", i, ops[i].kind); return -2;
     }
     if (rc != 0) return rc;

@@ -562,4 +562,90 @@ int masked_residual(const float* x, const float* t, const float* om, float sign,
   return check_launch("usf_masked_residual_f32");
 }
 
+// ------------------------------------------------------------------------------------------
+// Row pass of the vector ConvNet conditioner's blocks (networks.py:206-245: GatedMLP, LayerNormVector; ConvNet.__init__
+// vector branch :287-308): for each row of [M, C]
+//     r = skip + vg[:, :C] * sigmoid(vg[:, gate_off : gate_off + C])      (vg == NULL: r = skip)
+//     y = (r - mean r) / sqrt(var r + eps) * gamma + beta                 (gamma == NULL: y = r)
+//     out = y,  out_act = f(y)          (either may be NULL; f = the (Leaky)ReLU in front of the next block's Linear)
+// columns [C, c_pad) of out / out_act are written as zeros (the operand padding of the linear kernels).
+// One wave per row, the row in registers (C <= 64 * NIT); mean and biased variance by two wave reductions, as
+// torch.nn.LayerNorm computes them.  HBM-bound: 4 * (3..5) * C bytes per row.
+// ------------------------------------------------------------------------------------------
+template <int NIT>
+__global__ __launch_bounds__(256) void gated_norm_rows_kernel(usf_gated_norm_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.M) return;
+  const int C = (int)d.C, CP = (int)d.c_pad;
+  const float* sk = d.skip + row * d.ld_skip;
+  const float* vg = d.vg ? d.vg + row * d.ld_vg : nullptr;
+  float r[NIT];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    float v = 0.f;
+    if (c < C) {
+      v = sk[c];
+      if (vg) v += vg[c] * (1.f / (1.f + expf(-vg[d.gate_off + c])));
+    }
+    r[it] = v;
+    sum += v;
+  }
+  if (d.gamma) {
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const float dv = (it * 64 + lane < C) ? r[it] - mean : 0.f;
+      sq += dv * dv;
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)C + d.eps);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 64 + lane;
+      if (c < C) r[it] = (r[it] - mean) * rstd * d.gamma[c] + d.beta[c];
+    }
+  }
+  float* o = d.out ? d.out + row * d.ld_out : nullptr;
+  float* oa = d.out_act ? d.out_act + row * d.ld_act : nullptr;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    if (c < CP) {
+      const float v = (c < C) ? r[it] : 0.f;
+      if (o) o[c] = v;
+      if (oa) oa[c] = act_apply(v, d.act, d.slope);
+    }
+  }
+}
+
+int gated_norm_rows(const usf_gated_norm_desc* d, hipStream_t stream) {
+  if (!d) { set_error("usf_gated_norm_rows_f32: null descriptor"); return -1; }
+  if (d->M < 0 || d->C <= 0 || d->c_pad < d->C || d->c_pad > 4096) {
+    set_error("usf_gated_norm_rows_f32: bad sizes (1 <= C <= c_pad <= 4096)");
+    return -2;
+  }
+  if (d->M == 0) return 0;
+  if (!d->skip || (!d->out && !d->out_act) || ((d->gamma == nullptr) != (d->beta == nullptr))) {
+    set_error("usf_gated_norm_rows_f32: null pointer (skip, one of out / out_act, gamma and beta together)");
+    return -1;
+  }
+  if (d->ld_skip < d->C || (d->out && d->ld_out < d->c_pad) || (d->out_act && d->ld_act < d->c_pad) ||
+      (d->vg && (d->gate_off < 0 || d->ld_vg < d->gate_off + d->C))) {
+    set_error("usf_gated_norm_rows_f32: row stride shorter than the row");
+    return -2;
+  }
+  if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU) { set_error("usf_gated_norm_rows_f32: bad act"); return -2; }
+  const int64_t blocks = (d->M + 3) / 4;
+  if (blocks > 0x7fffffffLL) { set_error("usf_gated_norm_rows_f32: grid too large"); return -3; }
+  const dim3 g((unsigned)blocks), b(256);
+  if (d->c_pad <= 256) hipLaunchKernelGGL(gated_norm_rows_kernel<4>, g, b, 0, stream, *d);
+  else if (d->c_pad <= 1024) hipLaunchKernelGGL(gated_norm_rows_kernel<16>, g, b, 0, stream, *d);
+  else hipLaunchKernelGGL(gated_norm_rows_kernel<64>, g, b, 0, stream, *d);
+  return check_launch("usf_gated_norm_rows_f32");
+}
+
+
 }  // namespace usf

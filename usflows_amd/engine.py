@@ -56,8 +56,8 @@ def conditioner_supported(cond: nn.Module) -> bool:
         return cond.context_dim == 1 and _activation_of(cond.f) is not None
     if isinstance(cond, DenseNN):
         return cond.count_params == 1 and _activation_of(cond.f) is not None
-    if isinstance(cond, ConvNet):        # vector path; piece-wise linear only without gating / layer norm
-        return cond.is_plain_mlp() and _activation_of(cond.f) is not None
+    if isinstance(cond, ConvNet):        # vector path: plain chain of Linears, or GatedMLP / LayerNormVector blocks
+        return _activation_of(cond.f) is not None
     return False
 
 
@@ -354,11 +354,13 @@ class FlowEngine:
         self.natp_idx = torch.full((self.LDnp,), -1, dtype=torch.long)
         self.natp_idx[:D] = torch.arange(D)
         self.hmax = 4
+        self._general_cond = False       # a conditioner with gate / layer-norm blocks: chain of ops, no fused kernel
         for s in self.steps:
             if s.kind == "coupling":
                 cond = s.module.conditioner
                 widths = cond.c_hidden if isinstance(cond, ConvNet) else cond.hidden_dims
                 self.hmax = max(self.hmax, max(_round_up(int(h), 4) for h in widths))
+                self._general_cond = self._general_cond or (isinstance(cond, ConvNet) and not cond.is_plain_mlp())
 
     def _params(self):
         seen, out = set(), []
@@ -487,6 +489,17 @@ class FlowEngine:
         act, slope = _activation_of(cond.f)
         has_ctx = isinstance(cond, ConditionalDenseNN)
         ctx_l = None
+        if isinstance(cond, ConvNet) and not cond.is_plain_mlp():
+            # Linear, [GatedMLP | (f, Linear)] [+ LayerNormVector] x n, Linear (networks.py:287-308)
+            first, blocks, final = cond.block_view()
+            P = lambda l: (_param(l.weight, device), _param(l.bias, device))     # noqa: E731
+            raw = dict(first=P(first), last=P(final), device=device, ctx=None, h=[int(first.out_features)],
+                       pass_idx=pass_idx.to(torch.int32), tr_idx=tr_idx.to(torch.int32),
+                       blocks=[dict(w_in=int(b["w_in"]), w_out=int(b["w_out"]), eps=(float(b["ln"].eps) if b["ln"] is not None else 0.0),
+                                    **{k_: P(b[k_]) for k_ in ("lin", "l1", "l2", "proj", "ln") if b.get(k_) is not None})
+                               for b in blocks])
+            return dict(pass_off=pass_off, pass_n=pass_n, tr_off=tr_off, tr_n=tr_n, act=act, slope=slope, general=True,
+                        hidden=[_round_up(int(w), 4) for w in [first.out_features] + list(cond.c_hidden)], has_ctx=False, raw=raw)
         if isinstance(cond, ConvNet):
             # Linear, [f, Linear] x n, Linear (networks.py:287-308): the last block's Linear and the final Linear
             # have no activation between them -> one output map, folded in fp64
@@ -556,6 +569,8 @@ class FlowEngine:
             mats[("imgsrc", Wp.data_ptr())] = (src, out_sel, n_out, in_sel, n_in)      # for the transposed image
             return Wp
 
+        if cp.get("general"):
+            return self._general_pack_build(cp, image, pass_sel)
         W, b = raw["first"]
         Wp = image(W, self._iarange(h[0], hp[0], dev), hp[0], pass_sel, cp["pass_n"])
         layers.append((Wp, self._packed_vec(b, self._iarange(h[0], hp[0], dev), hp[0])))
@@ -572,6 +587,50 @@ class FlowEngine:
             # [h0, 4]: context rides in column 0 of a 4-wide K
             u["W_ctx4"], _ = self._packed(Wc, rows, hp[0], self._iarange(1, 4, dev), 4)
             u["b_ctx"] = self._packed_vec(bc, rows, hp[0])
+        cp["unfused"] = u
+        return u
+
+    def _general_pack_build(self, cp, image, pass_sel) -> dict:
+        """weight images of a vector ConvNet conditioner with GatedMLP / LayerNormVector blocks: every Linear padded to
+        multiples of 4 with zeros; a GatedMLP's second Linear keeps its value rows in [0, wp) and its gate rows in
+        [wp, 2 wp) (wp = padded block width), so ``chunk(2, dim=1)`` is two column offsets"""
+        raw = cp["raw"]
+        dev = raw["device"]
+        r4 = lambda n: _round_up(n, 4)      # noqa: E731
+        ar = lambda n: self._iarange(n, r4(n), dev)      # noqa: E731
+        tensors = []
+
+        def lin(Wb, out_sel, n_out, in_sel, n_in):
+            W, b = Wb
+            Wp = image(W, out_sel, n_out, in_sel, n_in)
+            bp = self._packed_vec(b, out_sel, n_out)
+            tensors.extend([Wp, bp])
+            return Wp, bp
+
+        h0 = raw["h"][0]
+        u = dict(general=True, first=lin(raw["first"], ar(h0), r4(h0), pass_sel, cp["pass_n"]), blocks=[])
+        for b in raw["blocks"]:
+            wi, wo = b["w_in"], b["w_out"]
+            e = dict(w_in=wi, w_out=wo, eps=b["eps"])
+            if "lin" in b:
+                e["lin"] = lin(b["lin"], ar(wo), r4(wo), ar(wi), r4(wi))
+            else:
+                e["l1"] = lin(b["l1"], ar(wo), r4(wo), ar(wi), r4(wi))
+                two = torch.full((2 * r4(wo),), -1, dtype=torch.int32)
+                two[:wo] = torch.arange(wo, dtype=torch.int32)
+                two[r4(wo): r4(wo) + wo] = torch.arange(wo, 2 * wo, dtype=torch.int32)
+                e["l2"] = lin(b["l2"], two.to(dev), 2 * r4(wo), ar(wo), r4(wo))
+                if "proj" in b:
+                    e["proj"] = lin(b["proj"], ar(wo), r4(wo), ar(wi), r4(wi))
+            if "ln" in b:
+                g_, b_ = b["ln"]
+                e["ln"] = (self._packed_vec(g_, ar(wo), r4(wo)), self._packed_vec(b_, ar(wo), r4(wo)))
+                tensors.extend(e["ln"])
+            u["blocks"].append(e)
+        w_last = raw["blocks"][-1]["w_out"]
+        tr_sel = self._sel(raw["tr_idx"], cp["tr_n"], dev)
+        u["W_out"], u["b_out"] = lin(raw["last"], tr_sel, cp["tr_n"], ar(w_last), r4(w_last))
+        u["tensors"] = tensors
         cp["unfused"] = u
         return u
 
@@ -883,7 +942,9 @@ class FlowEngine:
             meta.append(dict(kind="coupling", op=len(ops), step=i, buf=cur[0], sign=sign, use_ctx=use_ctx))
             # the fused kernel keeps a wave on 16 rows for the whole MLP: unbeatable when the chip is full, but
             # its latency is one wave's serial MFMA chain; small batches run the MLP as 3 short linear launches
-            if self.use_fused_coupling and self._fused_ok(cp) and B >= self.fused_min_rows:
+            if cp.get("general"):
+                self._general_coupling_ops(ops, lin_op, pk, cp, ws, zptr, B, sign, device)
+            elif self.use_fused_coupling and self._fused_ok(cp) and B >= self.fused_min_rows:
                 ops.append(self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None))
             else:
                 hbufs = ["H1", "H2"]
@@ -924,6 +985,63 @@ class FlowEngine:
                     patch_out=[(i_, "linear", "C") for i_ in patch_out], side=side,
                     final_gather=final_gather, out_buf=cur, ws=ws, pk=pk, meta=meta)
 
+    def _general_coupling_ops(self, ops, lin_op, pk, cp, ws, zptr, B, sign, device):
+        """the vector ConvNet conditioner with GatedMLP / LayerNormVector blocks (networks.py:206-245, 287-308) as a chain
+        of linear launches and one row pass per block (usf_gated_norm_rows_f32: gate, layer norm and the activation in
+        front of the next Linear in one kernel), then the masked residual in the last Linear's epilogue"""
+        un = self._unfused_pack(pk, cp)
+        hm = self.hmax
+
+        def buf(name, width=hm):
+            key = f"G_{name}"
+            if key not in ws:
+                ws[key] = torch.zeros(B, width, dtype=torch.float32, device=device)
+            return ws[key]
+
+        def linear(Wb, src, src_ld, dst, dst_ld, act=False, **extra):
+            W, b = Wb
+            K = W.shape[1]
+            ops.append(lin_op(A=src, lda=src_ld, W=W.data_ptr(), ldw=K, bias=b.data_ptr(), C=dst, ldc=dst_ld, M=B,
+                              N=W.shape[0], K=K, res_sign=extra.pop("res_sign", 1.0), slope=cp["slope"] if act else 0.0,
+                              act=cp["act"] if act else _ext.ACT_NONE, **extra, **self._split_kw(pk, W, K)))
+
+        def rows(skip, C_, out, out_act, vg=None, gate_off=0, ln=None, eps=0.0):
+            op = _ext.Op()
+            op.kind = _ext.OP_GATED_NORM
+            g = op.u.gated_norm
+            g.skip, g.ld_skip, g.M, g.C, g.c_pad = skip.data_ptr(), skip.shape[1], B, C_, _round_up(C_, 4)
+            if vg is not None:
+                g.vg, g.ld_vg, g.gate_off = vg.data_ptr(), vg.shape[1], gate_off
+            if ln is not None:
+                g.gamma, g.beta, g.eps = ln[0].data_ptr(), ln[1].data_ptr(), eps
+            if out is not None:
+                g.out, g.ld_out = out.data_ptr(), out.shape[1]
+            if out_act is not None:
+                g.out_act, g.ld_act, g.act, g.slope = out_act.data_ptr(), out_act.shape[1], cp["act"], cp["slope"]
+            ops.append(op)
+
+        hcur, hnext, A, T, S, VG = buf("H1"), buf("H2"), buf("A"), buf("T"), buf("S"), buf("VG", 2 * hm)
+        linear(un["first"], zptr + 4 * cp["pass_off"], self.LD, hcur.data_ptr(), hm)
+        rows(hcur, cp["raw"]["h"][0], None, A)          # a = f(h): the activation in front of block 0's Linear
+        nb = len(un["blocks"])
+        for j, e in enumerate(un["blocks"]):
+            wo = e["w_out"]
+            nxt_act = A if j + 1 < nb else None          # the final Linear has no activation in front of it
+            if "lin" in e:
+                linear(e["lin"], A.data_ptr(), hm, T.data_ptr(), hm)
+                rows(T, wo, hnext, nxt_act, ln=e.get("ln"), eps=e["eps"])
+            else:
+                linear(e["l1"], A.data_ptr(), hm, T.data_ptr(), hm, act=True)
+                linear(e["l2"], T.data_ptr(), hm, VG.data_ptr(), 2 * hm)
+                skip = hcur
+                if "proj" in e:
+                    linear(e["proj"], hcur.data_ptr(), hm, S.data_ptr(), hm)
+                    skip = S
+                rows(skip, wo, hnext, nxt_act, vg=VG, gate_off=_round_up(wo, 4), ln=e.get("ln"), eps=e["eps"])
+            hcur, hnext = hnext, hcur
+        tptr = zptr + 4 * cp["tr_off"]
+        linear((un["W_out"], un["b_out"]), hcur.data_ptr(), hm, tptr, self.LD, residual=tptr, ldr=self.LD, res_sign=sign)
+
     # ---- planes pipeline (usf_planes.hip; DESIGN.md 3.8) ---------------------------------------------------------
     @staticmethod
     def _slot_feature(s_: int) -> int:
@@ -946,7 +1064,7 @@ class FlowEngine:
             use = self.gemm_mode == "f16x2" or B >= self.planes_min_rows_bf16x3 or self._has_wide_conditioner()
         else:
             use = bool(self.use_planes)
-        if (train or has_ctx or not use or self.gemm_mode not in ("bf16x3", "f16x2")
+        if (train or has_ctx or not use or self._general_cond or self.gemm_mode not in ("bf16x3", "f16x2")
                 or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
         prims = self._primitive_ops(direction, merge=True)
@@ -1198,7 +1316,7 @@ class FlowEngine:
     def _fused_ok(self, cp) -> bool:
         lib = _ext.load()
         wmax = lib.usf_coupling_max_width()
-        return wmax > 0 and len(cp["hidden"]) <= 3 and max(cp["hidden"]) <= wmax
+        return not cp.get("general") and wmax > 0 and len(cp["hidden"]) <= 3 and max(cp["hidden"]) <= wmax
 
     def _fused_pack(self, cp) -> dict:
         """weights re-laid out for the fused kernel's padding contract (include/usflows_hip.h)"""

@@ -175,6 +175,29 @@ class ConvNet(nn.Module):
         widths = [self.c_hidden[0]] + self.c_hidden[:-1]
         return first, blocks[:-1], (Wf @ Wk, Wf @ bk + bf), widths
 
+    def block_view(self):
+        """(first Linear, blocks, final Linear) of the general vector configuration; blocks = one dict per entry of
+        ``c_hidden``: ``lin`` (ungated: the Linear behind the activation) or ``l1`` / ``l2`` / ``proj`` (GatedMLP), ``ln``
+        (the block's nn.LayerNorm or None), ``w_in`` / ``w_out`` widths"""
+        mods = list(self.nn)
+        first, final = mods[0], mods[-1]
+        blocks, i, width = [], 1, self.c_hidden[0]
+        for h in self.c_hidden:
+            m = mods[i]
+            i += 1
+            blk = dict(w_in=width, w_out=h, ln=None)
+            if isinstance(m, GatedMLP):
+                blk.update(l1=m.net1[1], l2=m.net1[3], proj=m.proj)
+            else:
+                blk.update(lin=m[1])
+            if self.normalize_layers:
+                blk["ln"] = mods[i].layernorm
+                i += 1
+            blocks.append(blk)
+            width = h
+        assert i == len(mods) - 1
+        return first, blocks, final
+
 
 # ---- CNN conditioners for image-shaped in_dims (SURVEY row N4; networks.py:40-122, 405-510) --------------------------
 def _relu_kind(m):

@@ -121,13 +121,25 @@ def synth_state_dict(spec: ModelSpec, seed: int = 0, alpha: float = 0.1) -> Dict
                     linear(c + f"layers.{idx}.", hs[i], hs[i - 1])
                     idx += 1
                 linear(c + f"layers.{idx}.", D, hs[-1])
-            elif spec.conditioner == "ConvNet":     # vector path, gating=False, normalize_layers=False
+            elif spec.conditioner == "ConvNet":     # vector path; extra["gating"] / extra["normalize_layers"] (default off)
+                gating, norm = bool(spec.extra.get("gating", False)), bool(spec.extra.get("normalize_layers", False))
                 linear(c + "nn.0.", hs[0], D)
-                width = hs[0]
-                for i, hdim in enumerate(hs):
-                    linear(c + f"nn.{i + 1}.1.", hdim, width)
+                width, m = hs[0], 1
+                for hdim in hs:
+                    if gating:          # GatedMLP (networks.py:222-245): net1 = [f, Linear, f, Linear], proj if widths differ
+                        linear(c + f"nn.{m}.net1.1.", hdim, width)
+                        linear(c + f"nn.{m}.net1.3.", 2 * hdim, hdim)
+                        if width != hdim:
+                            linear(c + f"nn.{m}.proj.", hdim, width)
+                    else:
+                        linear(c + f"nn.{m}.1.", hdim, width)
+                    m += 1
+                    if norm:            # LayerNormVector (networks.py:206-219): gain around 1, small offset
+                        sd[c + f"nn.{m}.layernorm.weight"] = 0.75 + 0.5 * torch.rand(hdim, generator=g)
+                        sd[c + f"nn.{m}.layernorm.bias"] = 0.2 * (torch.rand(hdim, generator=g) * 2 - 1)
+                        m += 1
                     width = hdim
-                linear(c + f"nn.{len(hs) + 1}.", D, width)
+                linear(c + f"nn.{m}.", D, width)
             else:
                 linear(c + "layers.0.", hs[0], D)
                 for i in range(1, len(hs)):
@@ -177,7 +189,8 @@ def build_usflow(spec: ModelSpec, sd: Optional[Dict[str, torch.Tensor]] = None, 
     elif spec.conditioner == "ConvNet":
         from .networks import ConvNet
         cls, args = ConvNet, dict(in_dims=[spec.dim], c_hidden=list(spec.hidden_dims), nonlinearity=act,
-                                  normalize_layers=False, gating=False)
+                                  normalize_layers=bool(spec.extra.get("normalize_layers", False)),
+                                  gating=bool(spec.extra.get("gating", False)))
     else:
         cls, args = DenseNN, dict(input_dim=spec.dim, hidden_dims=list(spec.hidden_dims), param_dims=[spec.dim],
                                   nonlinearity=act)
