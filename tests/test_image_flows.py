@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from golden_util import image_case_names, load_image_case
+from usflows_amd import transforms as T
 
 
 def _rel(a, b):
@@ -258,3 +259,91 @@ def test_small_batch_layer_loop_replays_a_hip_graph(name):
     # under autograd the eager (composite) loop serves the call
     lp = flow.log_prob(x)
     assert lp.requires_grad
+
+
+def _fit_twice(make_flow, data, optim, optim_params, batch_size, epochs):
+    """Flow.fit from the same start with the graphed training step and with eager steps"""
+    import copy
+    import numpy as np
+    f_graph = make_flow().to("cuda:0")
+    f_eager = copy.deepcopy(f_graph)
+    f_eager.use_train_graph = False
+    ds = torch.utils.data.TensorDataset(data, torch.zeros(data.shape[0]))
+    out = []
+    for f in (f_graph, f_eager):
+        np.random.seed(5)
+        out.append(f.fit(ds, optim=optim, optim_params=optim_params, batch_size=batch_size, shuffle=True,
+                         device=torch.device("cuda:0"), epochs=epochs))
+    return f_graph, f_eager, out[0], out[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optim", ["sgd", "sophia"])
+def test_fit_replays_the_training_step_of_an_image_flow_as_a_hip_graph(optim):
+    """Flow.fit on an image-shaped flow (composite torch formulation under autograd): after three eager steps the whole
+    step -- gradient zeroing, log_prob, backward, optimiser update -- is one hipGraph replay; the ragged last batch of each
+    epoch runs eagerly; same losses and parameters as eager steps from the same start (SGD: to rounding; SophiaG: its
+    update is lr * sign(m) while the Hessian estimate is zero, so single elements may differ by 2 lr)"""
+    from usflows_amd.flows import USFlow
+    from usflows_amd.networks import ConvNet2D
+    from usflows_amd.sophia import SophiaG
+    dims = [4, 6, 6]
+
+    def make_flow():
+        torch.manual_seed(3)
+        base = torch.distributions.Laplace(torch.zeros(dims, device="cuda:0"), torch.ones(dims, device="cuda:0"))
+        return USFlow(base, dims, 2, ConvNet2D, dict(c_in=4, c_hidden=8, num_layers=1, padding="same", kernel_size=3,
+                                                    normalize_layers=True, gating=True, nonlinearity=torch.nn.ReLU()),
+                      householder=1, affine_conjugation=True)
+
+    def tamed():
+        # (the reference's default initialisation is ill-conditioned -- SURVEY 7-H2: losses of 1e5 that amplify the last-bit
+        # run-to-run differences of the convolution's atomically accumulated weight gradients; compare on a tame start)
+        f = make_flow()
+        g = torch.Generator().manual_seed(4)
+        with torch.no_grad():
+            for m in f.modules():
+                if isinstance(m, T.LUTransform):
+                    d = m.dim
+                    m.L_raw.copy_(torch.eye(d) + 0.1 * torch.randn(d, d, generator=g).tril(-1))
+                    m.U_raw.copy_(torch.diag(0.75 + 0.5 * torch.rand(d, generator=g)) + 0.1 * torch.randn(d, d, generator=g).triu(1))
+                elif isinstance(m, T.ScaleTransform):
+                    m.scale.fill_(1.0)
+        return f
+
+    data = torch.rand(8 * 16 + 5, *dims, generator=torch.Generator().manual_seed(1))
+    cls, params = (torch.optim.SGD, dict(lr=1e-4)) if optim == "sgd" else (SophiaG, dict(lr=1e-5))
+    fg, fe, lg, le = _fit_twice(tamed, data, cls, params, 16, 2)
+    st = fg._train_graph_state
+    assert st["graph"] is not None and st["replays"] == (8 - 3) + 8, st["replays"]
+    assert "_train_graph_state" not in fe.__dict__
+    assert lg[1] < lg[0]
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 2e-5 * abs(b), (lg, le)
+    tol = 2e-5 if optim == "sgd" else 2.5e-5
+    for (k, a), (_, b) in zip(fg.state_dict().items(), fe.state_dict().items()):
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), k
+    # the version-keyed caches of the inference path see the replayed updates: device log_prob == the torch composite
+    x = data[:7].to("cuda:0")
+    with torch.no_grad():
+        lp = fg.log_prob(x)
+        fg.graph_max_rows = 0
+        ref = fg._layer_loop_log_prob(x)
+    assert ((lp - ref).abs() / ref.abs()).max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_fit_graph_serves_flat_flows_without_a_device_backward():
+    """a flat flow whose conditioner has no HIP backward (the gated / layer-normalised vector ConvNet): Flow.fit's steps are
+    the torch composite under autograd -- replayed as a graph like the image-shaped flows', same result as eager steps"""
+    from oracle import usflows_oracle as orc
+    from model_util import build_flow
+    spec = orc.FlowSpec(12, 2, [16, 16], householder=1, conditioner="ConvNet", extra={"gating": True, "normalize_layers": True})
+    sd = orc.synth_state_dict(spec, seed=9)
+    data = torch.rand(6 * 8, 12, generator=torch.Generator().manual_seed(2))
+    fg, fe, lg, le = _fit_twice(lambda: build_flow(spec, sd, device="cuda:0"), data, torch.optim.SGD, dict(lr=1e-3), 8, 1)
+    assert fg._train_graph_state["replays"] == 3
+    for a, b in zip(lg, le):
+        assert abs(a - b) <= 1e-5 * abs(b), (lg, le)
+    for (k, a), (_, b) in zip(fg.state_dict().items(), fe.state_dict().items()):
+        assert (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), k

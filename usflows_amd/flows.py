@@ -423,18 +423,98 @@ class Flow(torch.nn.Module):
                     sample = sample + torch.normal(torch.zeros_like(sigma), sigma)
                     # conditioning scale recommended by SoftFlow (flows.py:188-191)
                     noise = noise.unsqueeze(-1).detach() * 2 / self.training_noise_prior.high
-                optim.zero_grad()
-                loss = -model.log_prob(sample, context=noise).mean() - model.log_prior()
-                loss.backward()
-                losses.append(float(loss.detach()))
-                if gradient_clip is not None:
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
-                optim.step()
+                graphed = model._train_graph_step(optim, sample, noise) if gradient_clip is None else None
+                if graphed is not None:
+                    losses.append(graphed)
+                else:
+                    optim.zero_grad()
+                    loss = -model.log_prob(sample, context=noise).mean() - model.log_prior()
+                    loss.backward()
+                    losses.append(float(loss.detach()))
+                    if gradient_clip is not None:
+                        torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
+                    optim.step()
+                    # (drop the step's autograd graph now: it keeps the parameters' AccumulateGrad nodes alive, and those are
+                    # bound to the stream they were created on -- a later capture of the step must create its own)
+                    del loss
                 if not self.is_feasible():
                     raise RuntimeError("Model is not invertible")
                 model.transform.clear_cache()
             epoch_losses.append(np.mean(losses))
         return epoch_losses
+
+    # ---- Flow.fit: steps of the composite formulation replayed as ONE hipGraph -------------------------------------
+    # A step of a flow without a device training path (image-shaped inputs, conditioners with no HIP backward) is some
+    # hundreds of small torch ops forward and as many backward: ~10 ms of host time per step whatever the batch (MNIST image
+    # configuration, batch 32 .. 4096).  After three eager steps the whole step -- zeroing the gradients, log_prob, backward,
+    # the optimiser's update -- is captured once per (batch shape, optimiser) and replayed; a ragged last batch runs eagerly.
+    use_train_graph = True        # USFLOWS_AMD_TRAIN_GRAPH=0: off
+    _TRAIN_GRAPH_EAGER_STEPS = 3
+
+    def _train_graph_step(self, optim, sample: torch.Tensor, noise) -> Optional[float]:
+        """one optimiser step as a graph replay; the loss as a float, or None when the step has to run eagerly.  The caller
+        must not hold the loss tensor (or anything else with a grad_fn over the parameters) of an earlier eager step: the
+        parameters' gradient-accumulation nodes stay bound to the eager stream through it, and a capture that reaches over
+        to that stream does not survive hipStreamEndCapture."""
+        if not (self.use_train_graph and os.environ.get("USFLOWS_AMD_TRAIN_GRAPH", "1") != "0"
+                and torch.is_tensor(sample) and sample.is_cuda and sample.dtype == torch.float32 and sample.shape[0] > 0
+                and not getattr(self, "_train_graph_failed", False) and not torch.cuda.is_current_stream_capturing()):
+            return None
+        from .sophia import SophiaG
+        if not (isinstance(optim, SophiaG) or type(optim) is torch.optim.SGD):
+            return None               # (optimisers whose step is known to be free of host synchronisation)
+        if any(g_.get("capturable") for g_ in optim.param_groups if isinstance(optim, SophiaG)):
+            return None
+        with torch.enable_grad():
+            if self._train_path(sample, noise) is not None:
+                return None           # flat flows with a device backward: training.py's launch tapes serve them
+        st = self.__dict__.get("_train_graph_state")
+        key = (tuple(sample.shape), None if noise is None else tuple(noise.shape))
+        if st is None or st["optim"] is not optim:
+            st = self.__dict__["_train_graph_state"] = dict(optim=optim, key=key, seen=0, graph=None, replays=0)
+        if st["key"] != key:
+            if st["graph"] is not None:
+                return None           # ragged last batch of an epoch: eagerly; the captured graph serves the next epoch
+            st.update(key=key, seen=0)
+        if st["graph"] is None:
+            st["seen"] += 1
+            if st["seen"] <= self._TRAIN_GRAPH_EAGER_STEPS:
+                return None           # allocations, MIOpen searches, the optimiser's state and pointer tables
+            params = [p for g_ in optim.param_groups for p in g_["params"]]
+            if any(p.grad is not None and not p.grad.is_contiguous() for p in params):
+                return None
+            sx = sample.detach().clone()
+            sc = noise.detach().clone() if noise is not None else None
+
+            def body():
+                for p in params:
+                    if p.grad is not None:
+                        p.grad.zero_()          # (in place: the optimiser's pointer table and the graph keep their addresses)
+                with _unvalidated(self.base_distribution):
+                    loss = -self.log_prob(sx, context=sc).mean() - self.log_prior()
+                loss.backward()
+                optim.step()
+                return loss.detach()
+
+            try:
+                torch.cuda.synchronize(sample.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    sl = body()
+            except Exception as e:      # noqa: BLE001  (an op that cannot be captured: eager steps from now on)
+                self._train_graph_failed = True
+                warnings.warn(f"usflows_amd: hipGraph capture of the training step failed ({type(e).__name__}: "
+                              f"{str(e).splitlines()[0] if str(e) else ''}); Flow.fit runs eager steps", RuntimeWarning)
+                return None
+            st.update(graph=graph, x=sx, ctx=sc, loss=sl, params=params)
+        st["x"].copy_(sample)
+        if st["ctx"] is not None:
+            st["ctx"].copy_(noise)
+        st["graph"].replay()
+        st["replays"] += 1
+        for p in st["params"]:
+            torch.autograd.graph.increment_version(p)      # a replay runs no Python: tell the version-keyed caches
+        return float(st["loss"])
 
     def is_feasible(self) -> bool:
         return all(bool(l.is_feasible()) for l in self.layers if isinstance(l, BaseTransform))
@@ -460,6 +540,40 @@ class Flow(torch.nn.Module):
             return profile
         tail = self.base_distribution.radial_ldl_profile(threshold=lp[0], r_max=r_max, n_samples=n_samples)
         return _intersect_intervals(profile, tail)
+
+
+class _unvalidated:
+    """context: argument validation of a (nested) torch distribution switched off -- ``_validate_sample`` reads a flag back
+    to the host, which a stream capture does not allow (NaN inputs then propagate instead of raising)"""
+
+    def __init__(self, dist):
+        self.saved = []
+        seen, stack = set(), [dist]
+        while stack:
+            d = stack.pop()
+            if d is None or id(d) in seen:
+                continue
+            seen.add(id(d))
+            if isinstance(d, tdist.Distribution):
+                self.saved.append((d, d.__dict__.get("_validate_args", None)))
+            for name in ("base_dist", "distribution", "norm_distribution"):
+                try:
+                    stack.append(getattr(d, name, None))
+                except Exception:      # noqa: BLE001  (a property that needs arguments)
+                    pass
+
+    def __enter__(self):
+        for d, _ in self.saved:
+            d._validate_args = False
+        return self
+
+    def __exit__(self, *exc):
+        for d, v in self.saved:
+            if v is None:
+                d.__dict__.pop("_validate_args", None)
+            else:
+                d._validate_args = v
+        return False
 
 
 def _intersect_intervals(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

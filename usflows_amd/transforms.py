@@ -529,16 +529,25 @@ class LUTransform(AffineTransform):
     def bias(self):
         return self.bias_vector
 
+    @staticmethod
+    def _tri_inverse(t: torch.Tensor, upper: bool) -> torch.Tensor:
+        """``torch.inverse`` of a triangular factor (transforms.py:1289-1293).  On a ROCm device: a triangular solve against
+        the identity -- the same matrix without a pivoted LU behind it, differentiable, no host synchronisation, so a
+        training step of the composite formulation can be captured in a hipGraph (``Flow.fit``)"""
+        if t.is_cuda:
+            return torch.linalg.solve_triangular(t, torch.eye(t.shape[-1], dtype=t.dtype, device=t.device), upper=upper)
+        return torch.inverse(t)
+
     def inverse_matrix(self):
-        return torch.matmul(torch.inverse(self.U), torch.inverse(self.L))
+        return torch.matmul(self._tri_inverse(self.U, True), self._tri_inverse(self.L, False))
 
     def forward(self, x, context=None):
         return F.linear(x, self.matrix(), self.bias())
 
     def backward(self, y, context=None):
         x = y - self.bias_vector
-        x = F.linear(x, torch.inverse(self.L))
-        return F.linear(x, torch.inverse(self.U))
+        x = F.linear(x, self._tri_inverse(self.L, False))
+        return F.linear(x, self._tri_inverse(self.U, True))
 
     def log_abs_det_jacobian(self, x, y, context=None):
         # sum log|diag U| in the reference's diag()-free (ONNX-friendly) form, transforms.py:1313-1320
