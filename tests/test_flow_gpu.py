@@ -146,9 +146,10 @@ def test_wide_conditioner_unfused_path_cfg4_like():
     assert (xr.cpu() - x).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("extra,hidden", [({"gating": True, "normalize_layers": True}, [256, 192]),
-                                          ({"gating": True}, [128, 128, 128]), ({"normalize_layers": True}, [300, 256])])
-@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+@pytest.mark.parametrize("extra,hidden,mode", [({"gating": True, "normalize_layers": True}, [256, 192], "bf16x3"),
+                                               ({"gating": True, "normalize_layers": True}, [256, 192], "f32"),
+                                               ({"gating": True}, [128, 128, 128], "bf16x3"),
+                                               ({"normalize_layers": True}, [300, 256], "bf16x3")])
 def test_vector_convnet_gated_layernorm_conditioner_on_the_engine(extra, hidden, mode):
     """the reference's default vector ConvNet (GatedMLP blocks + LayerNormVector, networks.py:206-245, 287-308) at the
     headline width: the engine runs it as usf_linear_f32 launches plus one usf_gated_norm_rows_f32 pass per block (no torch
@@ -365,13 +366,13 @@ def test_udl_profile_on_device_matches_reference():
 
 
 def test_composite_fallback_on_device_warns_once():
-    """a layer list without a fused device form (gated / layer-normalised ConvNet conditioner: not piece-wise linear)
+    """a layer list without a fused device form (a conditioner whose nonlinearity the kernels do not have: Tanh)
     still works on the device through the torch composite loop -- but says so (VERDICT r1 weak #10)"""
     import warnings
     from usflows_amd.flows import USFlow
     from usflows_amd.networks import ConvNet
     flow = USFlow(torch.distributions.Laplace(torch.zeros(12, device=DEV), torch.ones(12, device=DEV)), [12], 2, ConvNet,
-                  dict(in_dims=[12], c_hidden=[16], nonlinearity=torch.nn.ReLU()), householder=0).to(DEV)
+                  dict(in_dims=[12], c_hidden=[16], nonlinearity=torch.nn.Tanh()), householder=0).to(DEV)
     x = torch.rand(8, 12, device=DEV)
     with torch.no_grad():
         with pytest.warns(RuntimeWarning, match="composite formulation"):
