@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
   hipMalloc(&Y, M * N * 4); hipMalloc(&A, M * K * 4); hipMalloc(&G, N * K * 4); hipMalloc(&ws, wsf * 4);
   hipMemcpy(Y, hy.data(), M * N * 4, hipMemcpyHostToDevice); hipMemcpy(A, ha.data(), M * K * 4, hipMemcpyHostToDevice);
 #ifdef USF_STAMP
-  unsigned long long* dbg; hipMalloc(&dbg, 1024 * 8 * 4 * 8); hipMemset(dbg, 0, 1024 * 8 * 4 * 8); usf::g_wdbg = dbg;
+  unsigned long long* dbg; hipMalloc(&dbg, 1024 * 12 * 4 * 8); hipMemset(dbg, 0, 1024 * 12 * 4 * 8); usf::g_wdbg = dbg;
 #endif
   for (int i = 0; i < 3; ++i) if (usf::wgrad(Y, N, A, K, M, N, K, G, K, 1.f, 0.f, 1, ws, wsf, 0)) return 1;
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 2; }
@@ -29,9 +29,9 @@ int main(int argc, char** argv) {
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
   printf("wgrad M=%lld N=%lld K=%lld: %.3f ms  %.1f TF/s fp32-equivalent\n", (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
 #ifdef USF_STAMP
-  std::vector<unsigned long long> h(1024 * 8 * 4); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> h(1024 * 12 * 4); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
   double w[2] = {0, 0}, b[2] = {0, 0}, sl[2] = {0, 0}; int n[2] = {0, 0};
-  for (int i = 0; i < 1024 * 8; ++i) if (h[4 * i + 3]) { const int r = (i % 8) >= 4; w[r] += h[4 * i]; b[r] += h[4 * i + 1]; sl[r] += h[4 * i + 2]; ++n[r]; }
+  for (int i = 0; i < 1024 * 12; ++i) if (h[4 * i + 3]) { const int r = (i % 12) >= 4; w[r] += h[4 * i]; b[r] += h[4 * i + 1]; sl[r] += h[4 * i + 2]; ++n[r]; }
   for (int r = 0; r < 2; ++r) if (n[r]) printf("  %s waves (%d): per slab: work %.0f cycles, barrier wait %.0f cycles\n", r ? "loader" : "MFMA  ", n[r], w[r] / sl[r], b[r] / sl[r]);
 #endif
   return 0;

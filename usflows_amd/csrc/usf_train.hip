@@ -316,19 +316,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // bf16x3 wgrad with LOADER WAVES (mode 1 from 2048 rows; round 2).  The kernel above runs fetch -> barrier ->
 // split -> barrier -> MFMA in every wave: the matrix pipe idles while the block splits, and the next slab's loads
-// have one MFMA phase to come back from HBM.  Here a 512-thread block (one per CU, 128 x 128 tile) has two roles:
+// have one MFMA phase to come back from HBM.  Here a 768-thread block (one per CU, 128 x 128 tile) has two roles:
 //   waves 0..3 (one per SIMD): nothing but ds_read_b128 + MFMA on a 64 x 64 patch (96 MFMAs per 32-row slab); the
-//                first fragments of slab s + 1 are read under the last MFMAs of slab s;
-//   waves 4..7 (one per SIMD): fetch fp32 rows ahead of their use (USF_WL_DEPTH slabs in flight per thread; two measured
-//                better than four), split them into bf16 planes and store them in fragment order two slabs ahead
-//                into a ring of three images.
+//                first fragments of slab s + 1 are read under the last MFMAs of slab s (one set of Y fragment
+//                registers, refilled row by row in the slab's last column);
+//   waves 4..11 (two per SIMD; 4..7 carry Y, 8..11 carry A): fetch fp32 rows ahead of their use (USF_WL_DEPTH slabs in
+//                flight per thread; two measured better than four), split them into bf16 planes and store them in
+//                fragment order two slabs ahead into a ring of three images.  (Round 2 first shipped four loader waves
+//                with 8 x 4-column units: eight with 8 x 2 measured 1.4 % faster -- the split is bound by vector issue,
+//                not by its dependency chains.)
 // Measured (tools/exp_wgrad.hip stamps, 784 x 784 x 65 536): an MFMA wave needs ~1600 cycles per slab; with the split
 // switched off the kernel runs at 164 TFLOP/s, with it at 115-125 -- the loaders' VALU and the MFMAs of the same SIMD
 // largely take turns instead of overlapping (an MFMA holds the SIMD's vector issue for half of its cycles), so the
 // split (5.25 instructions per value, every value split by the 7 blocks that share its row slab) is what is left.
 // One barrier per slab.  The image is swizzled (unit u of a line sits at u ^ ((u >> 4) & 3)) so that both the
-// loaders' stores (lane stride 4 units) and the fragment reads (16 consecutive units) are bank-conflict free.
-// Loads are unconditional 16-byte buffer loads: rows beyond M are out of the resource's range and read as zeros
+// loaders' stores (lane stride 2 units) and the fragment reads (16 consecutive units) are bank-conflict free.
+// Loads are unconditional 8-byte buffer loads: rows beyond M are out of the resource's range and read as zeros
 // (row ranges are whole slabs, so inside a range "beyond m_end" means "beyond M"); columns beyond N / K read
 // whatever lies there (row padding or the next row) -- they only ever reach output columns that are not stored.
 // ---------------------------------------------------------------------------------------------------------
@@ -373,19 +376,19 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
   for (int t = 0; t < NI; ++t) ycol[t] = wl_swz(wn * 64 + t * 16 + li);
 #pragma unroll
   for (int t = 0; t < NJ; ++t) acol[t] = wl_swz(wk * 64 + t * 16 + li);
-  bf16x8_t ypa[NI][3], ypb[NI][3], ap[2][3];
-  auto read_y = [&](int ring, bf16x8_t (&yp)[NI][3]) {
+  bf16x8_t yp[NI][3], ap[2][3];
+  auto read_y1 = [&](int ring, int t) {
 #pragma unroll
-    for (int t = 0; t < NI; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) yp[t][pl] = sh.Yp[ring][pl][lg][ycol[t]];
+    for (int pl = 0; pl < 3; ++pl) yp[t][pl] = sh.Yp[ring][pl][lg][ycol[t]];
   };
   auto read_a = [&](int ring, int j, bf16x8_t (&f)[3]) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) f[pl] = sh.Ap[ring][pl][lg][acol[j]];
   };
   // B0: which of the two A-fragment registers holds column 0 of this slab (alternates from slab to slab when NJ is odd)
-  auto slab = [&](int ring, int ring_next, const bf16x8_t (&yp)[NI][3], bf16x8_t (&ypn)[NI][3], auto b0) {
+  // (one set of Y fragments: in the slab's last column each row's registers are refilled with the next slab's fragments
+  // as soon as the row's products are issued -- 48 registers less than a second set, which is what lets twelve waves share a CU)
+  auto slab = [&](int ring, int ring_next, auto b0) {
     constexpr int B0 = decltype(b0)::value;
 #define USF_WL(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][P], ap[(j + B0) & 1][Q], acc[i][j], 0, 0, 0)
 #pragma unroll
@@ -394,11 +397,11 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
         read_a(ring, j + 1, ap[(j + 1 + B0) & 1]);
       } else {                                  // the next slab's first fragments (its image is complete since the last barrier)
         read_a(ring_next, 0, ap[(j + 1 + B0) & 1]);
-        read_y(ring_next, ypn);
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         USF_WL(2, 0); USF_WL(1, 1); USF_WL(0, 2); USF_WL(1, 0); USF_WL(0, 1); USF_WL(0, 0);   // smallest terms first
+        if (j + 1 == NJ) read_y1(ring_next, i);
       }
     }
 #undef USF_WL
@@ -420,7 +423,8 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
   };
   typedef std::integral_constant<int, 0> C0;
   typedef std::integral_constant<int, NJ & 1> C1;      // after an odd number of columns the roles of ap[0] / ap[1] swap
-  read_y(0, ypa);
+#pragma unroll
+  for (int t = 0; t < NI; ++t) read_y1(0, t);
   read_a(0, 0, ap[0]);
 #ifdef USF_STAMP
   unsigned long long tw = 0, tb = 0;
@@ -429,12 +433,12 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
   auto nxt = [](int r) { return r == 2 ? 0 : r + 1; };
   for (; s < nslab4; s += 2) {
     WL_Q(q0);
-    if (s < nslab) slab(ring, nxt(ring), ypa, ypb, C0());
+    if (s < nslab) slab(ring, nxt(ring), C0());
     WL_Q(q1);
     __syncthreads();
     WL_Q(q2);
     ring = nxt(ring);
-    if (s + 1 < nslab) slab(ring, nxt(ring), ypb, ypa, C1());
+    if (s + 1 < nslab) slab(ring, nxt(ring), C1());
     WL_Q(q3);
     __syncthreads();
     ring = nxt(ring);
@@ -447,7 +451,7 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
 #endif
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_lw_kernel(WgradArgs a) {
+__global__ __launch_bounds__(768) void wgrad_lw_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) WlShared sh;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -461,44 +465,45 @@ __global__ __launch_bounds__(512, 2) void wgrad_lw_kernel(WgradArgs a) {
   const int nslab4 = (nslab + 3) & ~3;        // iterations every wave runs (barrier count): see the loader loop
   unsigned long long* dbg_slot = nullptr;
 #ifdef USF_STAMP
-  if (a.dbg && lane == 0) dbg_slot = a.dbg + (size_t)((blockIdx.x % 1024) * 8 + wave) * 4;
+  if (a.dbg && lane == 0) dbg_slot = a.dbg + (size_t)((blockIdx.x % 1024) * 12 + wave) * 4;
 #endif
 
   if (wave >= 4) {
     // ------------------------------- loader waves -------------------------------
-    // thread = one (8 rows x 4 columns) unit of the slab: waves 4, 5 carry Y, waves 6, 7 carry A
+    // thread = one (8 rows x 2 columns) unit of the slab: waves 4 .. 7 carry Y, waves 8 .. 11 carry A -- two loader waves per
+    // SIMD beside its MFMA wave: the split is a chain of dependent conversions, one wave alone runs it at its latency
     const int lt = tid - 256;
-    const bool isA = wave >= 6;                 // wave-uniform (the buffer resource must sit in scalar registers)
-    const int u = lt & 127, rg = u >> 5, cg = u & 31;
+    const bool isA = wave >= 8;                 // wave-uniform (the buffer resource must sit in scalar registers)
+    const int u = lt & 255, rg = u >> 6, cg = u & 63;
     const unsigned ld = (unsigned)(isA ? a.lda : a.ldy);
-    const unsigned c0 = (unsigned)((isA ? k0 : n0) + 4 * cg);
+    const unsigned c0 = (unsigned)((isA ? k0 : n0) + 2 * cg);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(isA ? a.A : a.Y), 0, (int)((((unsigned)a.M - 1u) * ld + (unsigned)(isA ? a.K : a.N)) * 4u), 0x00020000);
     // (the row within the 8-row unit goes into the instruction's scalar offset: one vector add per slab, not per load)
     const unsigned vo = (((unsigned)m_begin + 8u * rg) * ld + c0) * 4u;
-    auto fetch = [&](int sl, f32x4 (&v)[8]) {
+    auto fetch = [&](int sl, f32x2 (&v)[8]) {
       const unsigned o = vo + (unsigned)sl * (WB_S * 4u) * ld;
 #ifdef USF_WL_X_NOLOAD
       if (sl > 8) return;
 #endif
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        v[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, (int)((unsigned)e * ld * 4u), 0));
+        v[e] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)o, (int)((unsigned)e * ld * 4u), 0));
     };
-    auto split_store = [&](int ring, const f32x4 (&v)[8]) {
+    auto split_store = [&](int ring, const f32x2 (&v)[8]) {
       bf16x8_t* d = isA ? &sh.Ap[ring][0][rg][0] : &sh.Yp[ring][0][rg][0];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 2; ++q) {
         float col[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) col[e] = v[e][q];
         bf16x8_t p1, p2, p3;
 #ifdef USF_WL_X_NOSPLIT
-        p1 = __builtin_bit_cast(bf16x8_t, v[q]); p2 = __builtin_bit_cast(bf16x8_t, v[q + 4]); p3 = p1;
+        p1 = __builtin_bit_cast(bf16x8_t, (f32x4){v[q][0], v[q][1], v[q + 2][0], v[q + 2][1]}); p2 = p1; p3 = p1;
 #else
         wl_split(col, p1, p2, p3);
 #endif
-        const int us = wl_swz(4 * cg + q);
+        const int us = wl_swz(2 * cg + q);
         d[us] = p1; d[4 * WG_T + us] = p2; d[8 * WG_T + us] = p3;
       }
     };
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_lw_kernel(WgradArgs a) {
 #define USF_WL_DEPTH 2
 #endif
     constexpr int DEPTH = USF_WL_DEPTH;         // slabs in flight per thread: slab t lives in set t % DEPTH from fetch to split
-    f32x4 vs[DEPTH][8];
+    f32x2 vs[DEPTH][8];
 #pragma unroll
     for (int t = 0; t < DEPTH; ++t) fetch(t, vs[t]);
     split_store(0, vs[0]); fetch(DEPTH, vs[0]);
@@ -734,7 +739,7 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
   a.dbg = g_wdbg;
 #endif
   const unsigned grid = (unsigned)(tiles * ((splits + 7) / 8) * 8);
-  if (lw) wgrad_lw_kernel<<<grid, 512, 0, stream>>>(a);
+  if (lw) wgrad_lw_kernel<<<grid, 768, 0, stream>>>(a);
   else if (variant == 1) wgrad_bf16x3_kernel<<<grid, 256, 0, stream>>>(a);
   else wgrad_kernel<<<grid, 256, 0, stream>>>(a);
   if (splits > 1) {
