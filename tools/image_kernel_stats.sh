@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp IMAGE_PROFILE_PLAIN=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/img_ktrace -- python3 tools/image_profile.py 65536 > gpurun_out/img_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/img_ktrace -- python3 tools/image_profile.py ${IMG_ROWS:-65536} ${IMG_CFG:-mnist} > gpurun_out/img_rocprof.log 2>&1
 f=$(find gpurun_out/img_ktrace -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
