@@ -7,6 +7,7 @@ for gfx950.  There is NO fallback: if the library is missing or a call fails, a
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import threading
 from typing import Optional
@@ -423,7 +424,7 @@ def affine_coupling_apply(z, ldz, t, ldt, s, lds, M, n, bound, inverse, logdet=N
 def channel_affine(x, y, W, *, pre_sub=None, bias=None):
     """usf_channel_affine_f32 on a contiguous [B, C, *spatial] fp32 tensor (1 x 1 convolution over the channel axis)"""
     B, Cc = x.shape[0], x.shape[1]
-    P = x.numel() // max(B * Cc, 1)
+    P = math.prod(x.shape[2:])            # (from the shape, not from numel: an empty batch still has pixels)
     check(load().usf_channel_affine_f32(x.data_ptr(), y.data_ptr(), B, Cc, P, W.data_ptr(), ptr(pre_sub), ptr(bias),
                                         current_stream(x.device)), "usf_channel_affine_f32")
 
@@ -431,7 +432,7 @@ def channel_affine(x, y, W, *, pre_sub=None, bias=None):
 def layernorm_channels(x, gamma, beta, eps, act=ACT_NONE, slope=0.0):
     """usf_layernorm_channels_f32 on a contiguous [B, C, *spatial] fp32 tensor -> new tensor"""
     B, Cc = x.shape[0], x.shape[1]
-    P = x.numel() // max(B * Cc, 1)
+    P = math.prod(x.shape[2:])            # (from the shape, not from numel: an empty batch still has pixels)
     y = torch.empty_like(x)
     check(load().usf_layernorm_channels_f32(x.data_ptr(), y.data_ptr(), B, Cc, P, gamma.data_ptr(), beta.data_ptr(), float(eps),
                                             int(act), float(slope), current_stream(x.device)), "usf_layernorm_channels_f32")
@@ -494,7 +495,7 @@ def conv2d_same(x, planes, cout, ks, bias=None, in_mul=None, in_act=ACT_NONE, in
 def gated_residual(x, vg):
     """x + vg[:, :C] * sigmoid(vg[:, C:]) for contiguous x [B, C, *spatial], vg [B, 2C, *spatial] -> new tensor"""
     B = x.shape[0]
-    CP = x.numel() // max(B, 1)
+    CP = math.prod(x.shape[1:])
     y = torch.empty_like(x)
     check(load().usf_gated_residual_f32(x.data_ptr(), vg.data_ptr(), y.data_ptr(), B, CP, current_stream(x.device)),
           "usf_gated_residual_f32")
@@ -513,7 +514,7 @@ def gated_norm_rows(skip, *, M, C_cols, c_pad=None, ld_skip=None, vg=None, ld_vg
 def masked_residual(x, t, one_minus_mask, sign):
     """x + sign * one_minus_mask * t (mask [C * P] fp32, broadcast over the batch) -> new tensor"""
     B = x.shape[0]
-    CP = x.numel() // max(B, 1)
+    CP = math.prod(x.shape[1:])
     y = torch.empty_like(x)
     check(load().usf_masked_residual_f32(x.data_ptr(), t.data_ptr(), one_minus_mask.data_ptr(), float(sign), y.data_ptr(), B,
                                          CP, current_stream(x.device)), "usf_masked_residual_f32")

@@ -168,7 +168,7 @@ class MaskedCoupling(BaseTransform):
     def _image_residual(self, x, t, sign):
         """x + sign * (1 - mask) * t for image-shaped inputs on the device: one ``usf_masked_residual_f32`` pass"""
         if not (x.dim() >= 3 and torch.is_tensor(t) and t.shape == x.shape and t.dtype == torch.float32
-                and self.mask.numel() == x[0].numel() and use_hip(self, x, t)):
+                and self.mask.numel() == math.prod(x.shape[1:]) and use_hip(self, x, t)):
             return None
         from . import _ext
         key = (self.mask.data_ptr(), self.mask._version, str(x.device))
@@ -183,7 +183,7 @@ class MaskedCoupling(BaseTransform):
         convolution's staging pass"""
         cond = self.conditioner
         if context is None and hasattr(cond, "first_conv_on_device") and x.dim() == 4 \
-                and self.mask.numel() == x[0].numel() and use_hip(self, x) and cond.first_conv_on_device(x):
+                and self.mask.numel() == math.prod(x.shape[1:]) and use_hip(self, x) and cond.first_conv_on_device(x):
             key = (self.mask.data_ptr(), self.mask._version, str(x.device))
             cache = getattr(self, "_m_cache", None)
             if cache is None or cache[0] != key:
