@@ -182,6 +182,24 @@ def test_vector_convnet_gated_layernorm_conditioner_on_the_engine(extra, hidden,
     assert _rel(lp_t.detach(), ref) < RTOL
 
 
+@pytest.mark.parametrize("B", [0, 1, 3, 257])
+def test_vector_convnet_gated_conditioner_ragged_batches_and_sampling(B):
+    """the op chain of the gated / layer-normalised vector ConvNet at empty, single-row and ragged batches (partial row
+    blocks of usf_gated_norm_rows_f32, the skinny linear kernel), a non-contiguous input view, and Flow.sample through it"""
+    spec = orc.FlowSpec(20, 3, [24, 16], householder=1, conditioner="ConvNet", extra={"gating": True, "normalize_layers": True})
+    sd = orc.synth_state_dict(spec, seed=5)
+    flow = build_flow(spec, sd, device=DEV)
+    big = torch.rand(B, 45, generator=torch.Generator().manual_seed(B))
+    x = big[:, 5:25]
+    with torch.no_grad():
+        lp = flow.log_prob(big.to(DEV)[:, 5:25])
+        xs = flow.sample([7], seed=1)
+    assert lp.shape == (B,) and xs.shape == (7, 20) and torch.isfinite(xs).all()
+    if B:
+        ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x.double())
+        assert _rel(lp, ref) < RTOL
+
+
 def test_three_hidden_layers_and_narrow_widths_fused():
     spec = orc.FlowSpec(40, 3, [48, 20, 136], householder=1, affine_conjugation=True, negative_slope=0.0)
     sd = orc.synth_state_dict(spec, seed=8)
