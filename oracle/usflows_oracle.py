@@ -39,7 +39,40 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------------------
 # spec
 # --------------------------------------------------------------------------------------
-from usflows_amd.synth import ModelSpec as FlowSpec, layer_plan  # noqa: E402  (plain dataclass + layer order, no arithmetic)
+from usflows_amd.synth import ModelSpec as FlowSpec  # noqa: E402  (the plain dataclass of a case's hyper-parameters: data, no logic)
+
+
+def layer_plan(spec: FlowSpec):
+    """The oracle's OWN restatement of the layer list USFlow.__init__ builds (flows.py:434-482) -- independent of the
+    product's `usflows_amd.synth.layer_plan` (tests/test_oracle.py holds the two against each other).  One entry per
+    element of ``Flow.layers``: (kind, state-dict prefix of its parameters, mask flip, wrapped in SequentialAffineTransform?).
+
+    per coupling block i (flows.py:435-472):
+      * lu_transform x LUTransform + (householder > 0: one HouseholderTransform) collected in ``affine_layers``; if there
+        are any: BlockAffineTransform(SequentialAffineTransform(affine_layers))                     -> 'affine' (sequential)
+      * MaskedCoupling(mask, conditioner)                                                           -> 'coupling'
+      * affine_conjugation and a block exists: InverseTransform(block) -- shares the block's parameters, registered a
+        second time under its own trainable_layers index                                            -> 'inv_affine'
+      * mask = 1 - mask                                                                             (flip for the next block)
+    after the blocks (flows.py:475-482): BlockAffineTransform(LUTransform) -- a bare LU, no Sequential wrapper -- and
+    ScaleTransform."""
+    entries = []
+    n = 0                                     # running index into trainable_layers (every layer is registered there)
+    block_has_affine = (spec.lu_transform + (1 if spec.householder > 0 else 0)) > 0
+    for i in range(spec.coupling_blocks):
+        block_idx = None
+        if block_has_affine:
+            block_idx = n
+            entries.append(("affine", "trainable_layers.%d.block_transform." % n, None, True))
+            n += 1
+        entries.append(("coupling", "trainable_layers.%d." % n, i % 2, None))
+        n += 1
+        if spec.affine_conjugation and block_idx is not None:
+            entries.append(("inv_affine", "trainable_layers.%d.block_transform." % block_idx, None, True))
+            n += 1
+    entries.append(("affine", "trainable_layers.%d.block_transform." % n, None, False))
+    entries.append(("scale", "trainable_layers.%d." % (n + 1), None, None))
+    return entries
 
 
 def checkerboard_mask(dim: int, dtype=torch.float32) -> torch.Tensor:
@@ -224,7 +257,7 @@ def coupling_backward(sd, prefix, spec, mask, y, context=None):
 
 
 # --------------------------------------------------------------------------------------
-# layer list (USFlow.__init__, flows.py:434-482): usflows_amd.synth.layer_plan
+# layer list (USFlow.__init__, flows.py:434-482): layer_plan above
 # --------------------------------------------------------------------------------------
 def _mask_for(spec, flip, dtype):
     m = checkerboard_mask(spec.dim, dtype)

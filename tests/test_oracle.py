@@ -168,3 +168,29 @@ def test_oracle_matches_reference_at_cfg4():
     rel64 = ((lp.double() - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
     rel32 = ((lp.double() - a["log_prob32"].double()).abs() / a["log_prob64"].abs()).max().item()
     assert rel64 < 1e-5 and rel32 < 1e-5, (rel64, rel32)
+
+
+def test_oracle_layer_plan_is_its_own_restatement_and_agrees_with_the_product():
+    """the oracle restates the layer list of USFlow.__init__ (flows.py:434-482) itself; the product's copy
+    (usflows_amd.synth.layer_plan, which the parameter generator and the engine tests walk) must agree with it, and both
+    with the state-dict keys of a model the REAL reference built (the fixtures)"""
+    from usflows_amd import synth
+    assert orc.layer_plan is not synth.layer_plan and orc.layer_plan.__module__ == "oracle.usflows_oracle"
+    S = orc.FlowSpec
+    specs = [S(6, 1, [8], householder=0), S(6, 2, [8], householder=1), S(6, 3, [8], householder=2, affine_conjugation=True),
+             S(6, 2, [8], lu_transform=2, householder=0, affine_conjugation=True), S(6, 2, [8], lu_transform=0, householder=0),
+             S(6, 3, [8], lu_transform=0, householder=0, affine_conjugation=True), S(6, 4, [8], lu_transform=0, householder=1)]
+    for spec in specs:
+        assert orc.layer_plan(spec) == synth.layer_plan(spec), spec
+    for name in case_names(small_only=True):
+        spec, sd, _ = load_case(name)
+        prefixes = {p for _, p, _, _ in orc.layer_plan(spec)}
+        keys = [k for k in sd if k.startswith("trainable_layers.")]
+        # every parameter of the reference's model lives under one of the plan's prefixes (InverseTransform re-registers its
+        # block under `<idx>.transform.`: those aliases are the same tensors)
+        for k in keys:
+            if ".transform.block_transform." in k:
+                continue
+            assert any(k.startswith(p) for p in prefixes), (name, k)
+        for p in prefixes:
+            assert any(k.startswith(p) for k in keys), (name, p)
