@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 18
+#define USF_ABI_VERSION 19
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -240,6 +240,20 @@ int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, i
 int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B, int64_t CP, usf_stream_t stream);
 int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
                             int64_t CP, usf_stream_t stream);
+
+/*
+ * Pointwise (1 x 1) convolution with few input channels on the vector ALUs, contiguous [B, cin, P] fp32 -> [B, cout, P]
+ * (plain) or [B, cout / 2, P] (gated), P = H * W; W [cout, cin] row-major (nn.Conv2d weight [cout, cin, 1, 1]), bias [cout] or NULL:
+ *   plain (gate_x == NULL): y[b, co, p] = out_act(bias[co] + sum_ci W[co, ci] * in_act(x[b, ci, p]))
+ *   gated (gate_x [B, C, P], cout = 2 C): y[b, c, p] = gate_x[b, c, p] + (bias[c] + W[c] . a) * sigmoid(bias[C + c] + W[C + c] . a)
+ *     -- GatedConv.forward's second convolution with `x + val * sigmoid(gate)` (networks.py:108-122) in one pass.
+ * Exact fp32 FMAs (sums over ci in ascending order).  cin in {8, 16, 24, 32, 48, 64}, cout <= 256
+ * (usf_pointwise_conv_supported: 1 if the shape is served); HBM-bound: 4 (cin + cout) bytes per pixel.
+ */
+int usf_pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated);
+int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W,
+                           const float* bias, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
+                           const float* gate_x, usf_stream_t stream);
 
 /*
  * Conv2d of the CNN conditioner (networks.py:405-510 ConvNet2D, :61-122 GatedConv): stride 1, dilation 1, "same" zero

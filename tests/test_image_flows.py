@@ -53,9 +53,11 @@ def test_image_flow_on_device_matches_reference(name, monkeypatch):
     _check(flow, a, "cuda:0")
     n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
     C = flow.in_dims[0]
-    # the 1 x 1-convolution affine layers: usf_channel_affine_f32 up to 16 channels, the matrix-core convolution above
+    # the 1 x 1-convolution affine layers: usf_channel_affine_f32 up to 16 channels and at the widths with an instance of
+    # their own (24 / 32 / 48 / 64: the CIFAR configuration's 48), the matrix-core convolution at other widths
     n_aff_conv = sum(1 for c_ in convs if c_ == (C, C, 1))
-    assert len(calls) + n_aff_conv == 3 * n_aff and (n_aff_conv == 0) == (C <= 16), (len(calls), n_aff_conv, n_aff)
+    assert len(calls) + n_aff_conv == 3 * n_aff and (n_aff_conv == 0) == (C <= 16 or C in (24, 32, 48, 64)), \
+        (len(calls), n_aff_conv, n_aff)
     # the CNN conditioner's convolutions run on usf_conv2d_same_f32
     assert any(c_[2] == 3 for c_ in convs), "the conditioner's 3 x 3 convolutions did not run on the HIP kernel"
 
@@ -376,3 +378,46 @@ def test_image_flow_empty_and_ragged_batches_on_device(B):
     assert lp.shape == (B,)
     assert _rel(lp.cpu(), ref) < 1e-5
     assert (xr.cpu() - x).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gated", [True, False])
+@pytest.mark.parametrize("B,cin,cout,H,W", [(1, 8, 2, 1, 1), (5, 32, 64, 7, 7), (3, 16, 32, 7, 7), (1000, 32, 64, 7, 7), (7, 48, 96, 8, 8),
+                                            (2, 24, 10, 5, 3), (4, 64, 256, 4, 4), (130, 32, 32, 14, 14)])
+def test_pointwise_conv_kernel_vs_torch(B, cin, cout, H, W, gated):
+    """usf_pointwise_conv_f32 (1 x 1 convolution on the vector ALUs, exact fp32) against F.conv2d in fp64: plain with
+    bias / activations, and GatedConv's `x + val * sigmoid(gate)` form (networks.py:108-122)"""
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout)
+    dev = "cuda:0"
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    a = torch.nn.functional.leaky_relu(x.double(), 0.01)
+    full = torch.nn.functional.conv2d(a, w.double().view(cout, cin, 1, 1), b.double())
+    if gated:
+        C = cout // 2
+        gx = torch.randn(B, C, H, W, generator=g).to(dev)
+        ref = gx.double() + full[:, :C] * torch.sigmoid(full[:, C:])
+        y = _ext.pointwise_conv(x, w, b, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.01, gate_x=gx)
+    else:
+        ref = torch.relu(full)
+        y = _ext.pointwise_conv(x, w, b, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.01, out_act=_ext.ACT_LEAKY_RELU, out_slope=0.0)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert (y.double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    # without bias / activations
+    y2 = _ext.pointwise_conv(x, w) if not gated else None
+    if y2 is not None:
+        ref2 = torch.nn.functional.conv2d(x.double(), w.double().view(cout, cin, 1, 1))
+        assert (y2.double() - ref2).abs().max().item() < 3e-6 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_pointwise_conv_rejects_what_it_does_not_serve():
+    from usflows_amd import _ext
+    x = torch.zeros(2, 20, 3, 3, device="cuda:0")
+    assert not _ext.pointwise_conv_supported(20, 8) and _ext.pointwise_conv_supported(32, 64, True)
+    assert not _ext.pointwise_conv_supported(32, 63, True) and not _ext.pointwise_conv_supported(32, 300)
+    with pytest.raises(RuntimeError):
+        _ext.pointwise_conv(x, torch.zeros(8, 20, device="cuda:0"))

@@ -17,7 +17,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 18
+USF_ABI_VERSION = 19
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -158,6 +158,9 @@ SYMBOLS = {
                                              C.c_float, C.c_void_p]),
     "usf_gated_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gated_norm_rows_f32": (C.c_int, [C.POINTER(GatedNormDesc), C.c_void_p]),
+    "usf_pointwise_conv_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32]),
+    "usf_pointwise_conv_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, C.c_int32, C.c_float,
+                                         C.c_int32, C.c_float, _fp, C.c_void_p]),
     "usf_conv2d_weight_elems": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_fits": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
@@ -489,6 +492,23 @@ def conv2d_same(x, planes, cout, ks, bias=None, in_mul=None, in_act=ACT_NONE, in
     check(load().usf_conv2d_same_f32(x.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, planes.data_ptr(), ptr(bias),
                                      ptr(in_mul), int(in_act), float(in_slope), int(out_act), float(out_slope),
                                      ptr(gate_x), gc, current_stream(x.device)), "usf_conv2d_same_f32")
+    return y
+
+
+def pointwise_conv_supported(cin: int, cout: int, gated: bool = False) -> bool:
+    return bool(load().usf_pointwise_conv_supported(int(cin), int(cout), int(bool(gated))))
+
+
+def pointwise_conv(x, W, bias=None, in_act=ACT_NONE, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, gate_x=None):
+    """usf_pointwise_conv_f32: 1 x 1 convolution of a contiguous [B, cin, *spatial] fp32 tensor with W [cout, cin] on the vector
+    ALUs -> new [B, cout, *spatial] tensor; gate_x [B, cout / 2, *spatial]: gated mode -> new tensor shaped like gate_x"""
+    B, cin = x.shape[0], x.shape[1]
+    cout = W.shape[0]
+    P = math.prod(x.shape[2:])
+    y = torch.empty_like(gate_x) if gate_x is not None else torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    check(load().usf_pointwise_conv_f32(x.data_ptr(), y.data_ptr(), B, cin, cout, P, W.data_ptr(), ptr(bias), int(in_act),
+                                        float(in_slope), int(out_act), float(out_slope), ptr(gate_x), current_stream(x.device)),
+          "usf_pointwise_conv_f32")
     return y
 
 

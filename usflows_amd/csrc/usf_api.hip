@@ -64,6 +64,9 @@ int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P
                        float eps, int32_t act, float slope, hipStream_t stream);
 int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
 int gated_norm_rows(const usf_gated_norm_desc* d, hipStream_t stream);
+int pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated);
+int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W, const float* bias,
+                   int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x, hipStream_t stream);
 int masked_residual(const float* x, const float* t, const float* om, float sign, float* y, int64_t B, int64_t CP,
                     hipStream_t stream);
 int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
@@ -210,6 +213,12 @@ int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, i
 }
 int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B, int64_t CP, usf_stream_t stream) {
   return usf::gated_residual(x, vg, y, B, CP, (hipStream_t)stream);
+}
+int usf_pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated) { return usf::pointwise_conv_supported(cin, cout, gated); }
+int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W,
+                           const float* bias, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
+                           const float* gate_x, usf_stream_t stream) {
+  return usf::pointwise_conv(x, y, B, cin, cout, P, W, bias, in_act, in_slope, out_act, out_slope, gate_x, (hipStream_t)stream);
 }
 int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream) {
   return usf::gated_norm_rows(d, (hipStream_t)stream);

@@ -467,9 +467,103 @@ int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, co
     if (C == CM) hipLaunchKernelGGL((channel_affine_kernel<CM, true>), g, b, 0, stream, x, y, (int)C, P, W, pre_sub, bias, BP);  \
     else hipLaunchKernelGGL((channel_affine_kernel<CM, false>), g, b, 0, stream, x, y, (int)C, P, W, pre_sub, bias, BP);         \
   } while (0)
-  if (C <= 8) USF_CA(8); else if (C <= 16) USF_CA(16); else if (C <= 32) USF_CA(32); else USF_CA(64);
+  if (C <= 8) USF_CA(8); else if (C <= 16) USF_CA(16); else if (C <= 24) USF_CA(24); else if (C <= 32) USF_CA(32);
+  else if (C <= 48) USF_CA(48); else USF_CA(64);
 #undef USF_CA
   return check_launch("usf_channel_affine_f32");
+}
+
+// ------------------------------------------------------------------------------------------
+// Pointwise (1 x 1) convolution with few channels on the vector ALUs -- GatedConv's second convolution with its gate
+// (networks.py:108-122: `x + val * sigmoid(gate)`, [val, gate] = conv1x1(f(t))) and plain 1 x 1 convolutions:
+//     a = in_act(x);  plain:  y[b, co, p] = out_act(bias[co] + sum_ci W[co, ci] a[b, ci, p])
+//                     gated:  y[b, c, p]  = gate_x[b, c, p] + (bias[c] + W[c] . a) * sigmoid(bias[C + c] + W[C + c] . a),  cout = 2 C
+// 2 cin flops per 4-byte output element next to 4 (cin + cout) bytes per pixel: HBM-bound work that the matrix-core kernel
+// (usf_conv.hip: LDS image, bf16x3 split, per-group barriers) serves at a quarter of the HBM rate; here one thread owns a
+// pixel, loads its cin channel values once (coalesced along p), and walks the output channels with wave-uniform weight
+// rows (wide scalar loads) -- exact fp32 FMAs, sums over ci in ascending order.
+// ------------------------------------------------------------------------------------------
+template <int CIN, bool GATED>
+__global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __restrict__ x, float* __restrict__ y, int cout,
+                                                             int64_t P, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, int in_act, float in_slope,
+                                                             int out_act, float out_slope,
+                                                             const float* __restrict__ gate_x, int64_t BP) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BP) return;
+  const int64_t b = i / P, p = i - b * P;
+  const float* xb = x + b * CIN * P + p;
+  float v[CIN];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) v[ci] = act_apply(xb[(int64_t)ci * P], in_act, in_slope);
+  if (GATED) {
+    const int C = cout >> 1;
+    const float* gb = gate_x + b * C * P + p;
+    float* yb = y + b * C * P + p;
+    for (int c = 0; c < C; ++c) {
+      const float* wv = W + c * CIN;
+      const float* wg = W + (C + c) * CIN;
+      float av = 0.f, ag = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        av = fmaf(wv[ci], v[ci], av);
+        ag = fmaf(wg[ci], v[ci], ag);
+      }
+      if (bias) { av += bias[c]; ag += bias[C + c]; }
+      yb[(int64_t)c * P] = gb[(int64_t)c * P] + av * (1.f / (1.f + expf(-ag)));
+    }
+  } else {
+    float* yb = y + b * cout * P + p;
+    for (int co = 0; co < cout; ++co) {
+      const float* wr = W + co * CIN;
+      float acc = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) acc = fmaf(wr[ci], v[ci], acc);
+      if (bias) acc += bias[co];
+      yb[(int64_t)co * P] = act_apply(acc, out_act, out_slope);
+    }
+  }
+}
+
+int pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated) {
+  const bool cin_ok = cin == 8 || cin == 16 || cin == 24 || cin == 32 || cin == 48 || cin == 64;
+  return cin_ok && cout >= 1 && cout <= 256 && (!gated || (cout & 1) == 0);
+}
+
+int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W, const float* bias,
+                   int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x, hipStream_t stream) {
+  const int gated = gate_x != nullptr;
+  if (B < 0 || P <= 0 || !pointwise_conv_supported(cin, cout, gated)) {
+    set_error("usf_pointwise_conv_f32: unsupported sizes (cin in {8, 16, 24, 32, 48, 64}, 1 <= cout <= 256, even cout when gated)");
+    return -2;
+  }
+  if (B == 0) return 0;
+  if (!x || !y || !W) { set_error("usf_pointwise_conv_f32: null pointer"); return -1; }
+  if (x == y || gate_x == y) { set_error("usf_pointwise_conv_f32: in-place operation is not supported"); return -2; }
+  if ((in_act != USF_ACT_NONE && in_act != USF_ACT_LEAKY_RELU) || (out_act != USF_ACT_NONE && out_act != USF_ACT_LEAKY_RELU)) {
+    set_error("usf_pointwise_conv_f32: bad act");
+    return -2;
+  }
+  const int64_t BP = B * P, blocks = (BP + 255) / 256;
+  if (blocks > 0x7fffffffLL) { set_error("usf_pointwise_conv_f32: grid too large"); return -3; }
+  const dim3 g((unsigned)blocks), bl(256);
+#define USF_PW(CI)                                                                                                      \
+  do {                                                                                                                  \
+    if (gated) hipLaunchKernelGGL((pointwise_conv_kernel<CI, true>), g, bl, 0, stream, x, y, (int)cout, P, W, bias, in_act,       \
+                                  in_slope, out_act, out_slope, gate_x, BP);                                            \
+    else hipLaunchKernelGGL((pointwise_conv_kernel<CI, false>), g, bl, 0, stream, x, y, (int)cout, P, W, bias, in_act, in_slope,  \
+                            out_act, out_slope, gate_x, BP);                                                            \
+  } while (0)
+  switch ((int)cin) {
+    case 8: USF_PW(8); break;
+    case 16: USF_PW(16); break;
+    case 24: USF_PW(24); break;
+    case 32: USF_PW(32); break;
+    case 48: USF_PW(48); break;
+    default: USF_PW(64); break;
+  }
+#undef USF_PW
+  return check_launch("usf_pointwise_conv_f32");
 }
 
 // ------------------------------------------------------------------------------------------

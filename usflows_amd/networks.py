@@ -16,6 +16,7 @@ kernel -- ``forward`` below is not called there.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -210,9 +211,9 @@ def _relu_kind(m):
     return None
 
 
-def _conv_hip_ok(conv, x) -> bool:
-    """this nn.Conv2d call is served by usf_conv2d_same_f32: stride 1, "same" zero padding, kernel 1 or 3, fp32 on a ROCm
-    device, nothing to differentiate, and at least two samples per LDS group (below that torch's convolution is faster)"""
+def _conv_same_shaped(conv, x) -> bool:
+    """an nn.Conv2d call the device kernels can express: stride 1, "same" zero padding, kernel 1 or 3, fp32 on a ROCm
+    device, nothing to differentiate"""
     if not (isinstance(conv, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         return False
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
@@ -222,10 +223,34 @@ def _conv_hip_ok(conv, x) -> bool:
             or conv.padding_mode != "zeros" or x.shape[1] != conv.in_channels:
         return False
     pad = conv.padding
-    if not (pad == "same" or (not isinstance(pad, str) and tuple(pad) == (k[0] // 2, k[0] // 2))):
+    return pad == "same" or (not isinstance(pad, str) and tuple(pad) == (k[0] // 2, k[0] // 2))
+
+
+def _conv_hip_ok(conv, x) -> bool:
+    """this nn.Conv2d call is served by usf_conv2d_same_f32: `_conv_same_shaped`, and at least two samples per LDS group
+    (below that torch's convolution is faster)"""
+    if not _conv_same_shaped(conv, x):
         return False
     from . import _ext
-    return _ext.load().usf_conv2d_same_fits(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3], k[0]) >= 2
+    return _ext.load().usf_conv2d_same_fits(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3], conv.kernel_size[0]) >= 2
+
+
+def _pointwise_hip(conv, x, in_act=None, gate_x=None):
+    """a 1 x 1 nn.Conv2d with few input channels on usf_pointwise_conv_f32 (vector ALUs, exact fp32; HBM-bound work that the
+    matrix-core kernel serves at a quarter of the HBM rate), optionally with GatedConv's gate; None if the shape is not served"""
+    from . import _ext
+    if conv.kernel_size != (1, 1) or not _conv_same_shaped(conv, x) or \
+            not _ext.pointwise_conv_supported(conv.in_channels, conv.out_channels, gate_x is not None):
+        return None
+    key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else conv.bias._version, str(x.device))
+    cache = getattr(conv, "_usf_pointwise", None)
+    if cache is None or cache[0] != key:
+        w = conv.weight.detach().to(device=x.device, dtype=torch.float32).reshape(conv.out_channels, conv.in_channels).contiguous()
+        b = None if conv.bias is None else conv.bias.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        cache = conv._usf_pointwise = (key, w, b)
+    ia, isl = in_act if in_act is not None else (_ext.ACT_NONE, 0.0)
+    return _ext.pointwise_conv(x.contiguous(), cache[1], cache[2], in_act=ia, in_slope=isl,
+                               gate_x=None if gate_x is None else gate_x.contiguous())
 
 
 def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None):
@@ -291,6 +316,10 @@ class GatedConv(nn.Module):
             from . import _ext
             h = _conv_hip(n[1], x, in_act=a0)
             C = x.shape[1]
+            if n[3].out_channels == 2 * C and os.environ.get("USF_POINTWISE", "1") != "0":
+                out = _pointwise_hip(n[3], h, in_act=a2, gate_x=x)      # second convolution + gate: one pass on the vector ALUs
+                if out is not None:
+                    return out
             if _conv_hip_ok(n[3], h) and n[3].out_channels == 2 * C:
                 cout_g = 32 * ((C + 15) // 16)
                 if cout_g <= 64 and _ext.load().usf_conv2d_same_fits(h.shape[1], cout_g, h.shape[2], h.shape[3],

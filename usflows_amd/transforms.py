@@ -18,6 +18,7 @@ of such flows run as torch ops.
 from __future__ import annotations
 
 import math
+import os
 from typing import Any, Iterable, List, Optional
 
 import torch
@@ -667,7 +668,7 @@ class BlockAffineTransform(BaseTransform):
                 M, Minv, b = r["M"], r["Minv"], r["b"]
                 C = M.shape[0]
                 conv = None
-                if C > 16:
+                if C > 16 and C not in (24, 32, 48, 64):      # (those widths have a full-width instance of usf_channel_affine_f32)
                     # wide channel counts: the 1 x 1 convolution goes to the matrix cores (usf_conv2d_same_f32, kernel 1):
                     # forward y = M x + b, backward x = Minv y + c with c = -(Minv b) folded in fp64
                     from . import _ext
@@ -678,9 +679,9 @@ class BlockAffineTransform(BaseTransform):
         return self._chan_cache[1:]
 
     def _channel_hip(self, x, forward: bool):
-        """the 1x1 convolution on NCHW data (row N4): usf_channel_affine_f32 (one thread per pixel, HBM-bound) up to 16
-        channels; above that (CIFAR configuration: 48 channels, where that kernel's C^2 scalar FMAs per pixel take 10 x
-        the HBM time) usf_conv2d_same_f32 with kernel 1 on the matrix cores when the shape fits it"""
+        """the 1x1 convolution on NCHW data (row N4): usf_channel_affine_f32 (one thread per pixel, C^2 scalar FMAs, HBM-bound)
+        up to 16 channels and at 24 / 32 / 48 / 64 (widths with an instance of their own: the CIFAR configuration's 48);
+        other widths above 16 go to usf_conv2d_same_f32 with kernel 1 on the matrix cores when the shape fits it"""
         from . import _ext
         M, Minv, b, conv = self._channel_prep(x.device)
         x = x.contiguous()
