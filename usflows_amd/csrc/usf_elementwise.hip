@@ -496,31 +496,49 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __rest
   float v[CIN];
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci) v[ci] = act_apply(xb[(int64_t)ci * P], in_act, in_slope);
+  // output channels in groups of 8 (unrolled): the group's weight rows, gate values and stores are independent of each
+  // other, so scalar loads, global loads and FMAs of neighbouring channels overlap
   if (GATED) {
     const int C = cout >> 1;
     const float* gb = gate_x + b * C * P + p;
     float* yb = y + b * C * P + p;
-    for (int c = 0; c < C; ++c) {
-      const float* wv = W + c * CIN;
-      const float* wg = W + (C + c) * CIN;
-      float av = 0.f, ag = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float gx[8];
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) {
-        av = fmaf(wv[ci], v[ci], av);
-        ag = fmaf(wg[ci], v[ci], ag);
+      for (int j = 0; j < 8; ++j) gx[j] = (c0 + j < C) ? gb[(int64_t)(c0 + j) * P] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        if (c < C) {
+          const float* wv = W + c * CIN;
+          const float* wg = W + (C + c) * CIN;
+          float av = 0.f, ag = 0.f;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            av = fmaf(wv[ci], v[ci], av);
+            ag = fmaf(wg[ci], v[ci], ag);
+          }
+          if (bias) { av += bias[c]; ag += bias[C + c]; }
+          // (v_exp_f32 / v_rcp_f32: 1 ulp each)
+          yb[(int64_t)c * P] = gx[j] + av * __builtin_amdgcn_rcpf(1.f + __expf(-ag));
+        }
       }
-      if (bias) { av += bias[c]; ag += bias[C + c]; }
-      yb[(int64_t)c * P] = gb[(int64_t)c * P] + av * (1.f / (1.f + expf(-ag)));
     }
   } else {
     float* yb = y + b * cout * P + p;
-    for (int co = 0; co < cout; ++co) {
-      const float* wr = W + co * CIN;
-      float acc = 0.f;
+    for (int c0 = 0; c0 < cout; c0 += 8) {
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) acc = fmaf(wr[ci], v[ci], acc);
-      if (bias) acc += bias[co];
-      yb[(int64_t)co * P] = act_apply(acc, out_act, out_slope);
+      for (int j = 0; j < 8; ++j) {
+        const int co = c0 + j;
+        if (co < cout) {
+          const float* wr = W + co * CIN;
+          float acc = 0.f;
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) acc = fmaf(wr[ci], v[ci], acc);
+          if (bias) acc += bias[co];
+          yb[(int64_t)co * P] = act_apply(acc, out_act, out_slope);
+        }
+      }
     }
   }
 }
