@@ -247,13 +247,16 @@ int usf_masked_residual_f32(const float* x, const float* t, const float* one_min
  *   plain (gate_x == NULL): y[b, co, p] = out_act(bias[co] + sum_ci W[co, ci] * in_act(x[b, ci, p]))
  *   gated (gate_x [B, C, P], cout = 2 C): y[b, c, p] = gate_x[b, c, p] + (bias[c] + W[c] . a) * sigmoid(bias[C + c] + W[C + c] . a)
  *     -- GatedConv.forward's second convolution with `x + val * sigmoid(gate)` (networks.py:108-122) in one pass.
+ *   gated + layer norm (ln_gamma / ln_beta [C] non-NULL; needs cout == 2 cin, cin <= 32): the gated result r, then
+ *     y = (a' - mean_c a') / sqrt(var_c a' + ln_eps) * ln_gamma + ln_beta with a' = out_act(r) -- the nonlinearity and the
+ *     LayerNormChannels that follow a GatedConv in ConvNet2D (networks.py:480-493, :40-58) joined to the same pass.
  * Exact fp32 FMAs (sums over ci in ascending order).  cin in {8, 16, 24, 32, 48, 64}, cout <= 256
  * (usf_pointwise_conv_supported: 1 if the shape is served); HBM-bound: 4 (cin + cout) bytes per pixel.
  */
 int usf_pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated);
 int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W,
                            const float* bias, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
-                           const float* gate_x, usf_stream_t stream);
+                           const float* gate_x, const float* ln_gamma, const float* ln_beta, float ln_eps, usf_stream_t stream);
 
 /*
  * Conv2d of the CNN conditioner (networks.py:405-510 ConvNet2D, :61-122 GatedConv): stride 1, dilation 1, "same" zero

@@ -421,3 +421,61 @@ def test_pointwise_conv_rejects_what_it_does_not_serve():
     assert not _ext.pointwise_conv_supported(32, 63, True) and not _ext.pointwise_conv_supported(32, 300)
     with pytest.raises(RuntimeError):
         _ext.pointwise_conv(x, torch.zeros(8, 20, device="cuda:0"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(1, 8, 1, 1), (5, 32, 7, 7), (3, 16, 7, 7), (1000, 32, 7, 7), (7, 24, 8, 8), (130, 32, 14, 14)])
+def test_pointwise_conv_gated_layernorm_form_vs_torch(B, C, H, W):
+    """usf_pointwise_conv_f32 with the layer norm joined to the gated pass: GatedConv's `x + val * sigmoid(gate)`, the ReLU
+    and the LayerNormChannels behind it (networks.py:108-122, 480-493, 40-58) against the torch fp64 formulation, and
+    bit-equal to the two-pass device form (gated pointwise pass, then usf_layernorm_channels_f32 with the ReLU folded in)"""
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(B * 100 + C)
+    dev = "cuda:0"
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    gx = torch.randn(B, C, H, W, generator=g).to(dev)
+    w = (torch.randn(2 * C, C, generator=g) / C ** 0.5).to(dev)
+    b = torch.randn(2 * C, generator=g).to(dev)
+    gamma, beta = (0.5 + torch.rand(C, generator=g)).to(dev), torch.randn(C, generator=g).to(dev)
+    a = torch.relu(x.double())
+    full = torch.nn.functional.conv2d(a, w.double().view(2 * C, C, 1, 1), b.double())
+    r = torch.relu(gx.double() + full[:, :C] * torch.sigmoid(full[:, C:]))
+    mean = r.mean(dim=1, keepdim=True)
+    var = r.var(dim=1, unbiased=False, keepdim=True)
+    ref = (r - mean) / torch.sqrt(var + 1e-5) * gamma.double().view(1, C, 1, 1) + beta.double().view(1, C, 1, 1)
+    relu = (_ext.ACT_LEAKY_RELU, 0.0)
+    y = _ext.pointwise_conv(x, w, b, in_act=relu[0], in_slope=relu[1], out_act=relu[0], out_slope=relu[1], gate_x=gx,
+                            ln=(gamma, beta, 1e-5))
+    two = _ext.layernorm_channels(_ext.pointwise_conv(x, w, b, in_act=relu[0], in_slope=relu[1], gate_x=gx), gamma, beta, 1e-5,
+                                  relu[0], relu[1])
+    torch.cuda.synchronize()
+    assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, two)
+    with pytest.raises(RuntimeError):
+        _ext.pointwise_conv(x, w, b, ln=(gamma, beta, 1e-5))             # the layer-norm form needs the gated mode
+
+
+@pytest.mark.gpu
+def test_convnet2d_joins_gated_conv_relu_and_layernorm_into_one_pass(monkeypatch):
+    """ConvNet2D on the device: [GatedConv, ReLU, LayerNormChannels] runs as conv 3x3 + ONE pointwise pass (no separate layer
+    norm launch); same values as with USF_POINTWISE=0 (matrix-core 1 x 1 convolution + layer-norm pass) to rounding and as the
+    torch modules on the CPU"""
+    from usflows_amd import _ext
+    from usflows_amd.networks import ConvNet2D
+    torch.manual_seed(2)
+    net = ConvNet2D(16, c_hidden=32, num_layers=2, padding="same", kernel_size=3, normalize_layers=True, gating=True,
+                    nonlinearity=torch.nn.ReLU())
+    x = torch.randn(37, 16, 7, 7)
+    with torch.no_grad():
+        ref = net(x)
+        dnet = net.to("cuda:0")
+        ln_calls = []
+        real = _ext.layernorm_channels
+        monkeypatch.setattr(_ext, "layernorm_channels", lambda *a_, **k_: (ln_calls.append(1), real(*a_, **k_))[1])
+        y = dnet(x.to("cuda:0"))
+        assert not ln_calls, "the layer norm ran as a pass of its own"
+        monkeypatch.setenv("USF_POINTWISE", "0")
+        y0 = dnet(x.to("cuda:0"))
+        assert len(ln_calls) == 2
+    assert (y.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (y - y0).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

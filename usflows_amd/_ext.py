@@ -160,7 +160,7 @@ SYMBOLS = {
     "usf_gated_norm_rows_f32": (C.c_int, [C.POINTER(GatedNormDesc), C.c_void_p]),
     "usf_pointwise_conv_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32]),
     "usf_pointwise_conv_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, C.c_int32, C.c_float,
-                                         C.c_int32, C.c_float, _fp, C.c_void_p]),
+                                         C.c_int32, C.c_float, _fp, _fp, _fp, C.c_float, C.c_void_p]),
     "usf_conv2d_weight_elems": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_fits": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
@@ -499,15 +499,18 @@ def pointwise_conv_supported(cin: int, cout: int, gated: bool = False) -> bool:
     return bool(load().usf_pointwise_conv_supported(int(cin), int(cout), int(bool(gated))))
 
 
-def pointwise_conv(x, W, bias=None, in_act=ACT_NONE, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, gate_x=None):
+def pointwise_conv(x, W, bias=None, in_act=ACT_NONE, in_slope=0.0, out_act=ACT_NONE, out_slope=0.0, gate_x=None, ln=None):
     """usf_pointwise_conv_f32: 1 x 1 convolution of a contiguous [B, cin, *spatial] fp32 tensor with W [cout, cin] on the vector
-    ALUs -> new [B, cout, *spatial] tensor; gate_x [B, cout / 2, *spatial]: gated mode -> new tensor shaped like gate_x"""
+    ALUs -> new [B, cout, *spatial] tensor; gate_x [B, cout / 2, *spatial]: gated mode -> new tensor shaped like gate_x;
+    ln = (gamma [C], beta [C], eps): out_act and a layer norm over the channels joined to the gated pass"""
     B, cin = x.shape[0], x.shape[1]
     cout = W.shape[0]
     P = math.prod(x.shape[2:])
     y = torch.empty_like(gate_x) if gate_x is not None else torch.empty((B, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     check(load().usf_pointwise_conv_f32(x.data_ptr(), y.data_ptr(), B, cin, cout, P, W.data_ptr(), ptr(bias), int(in_act),
-                                        float(in_slope), int(out_act), float(out_slope), ptr(gate_x), current_stream(x.device)),
+                                        float(in_slope), int(out_act), float(out_slope), ptr(gate_x),
+                                        None if ln is None else ln[0].data_ptr(), None if ln is None else ln[1].data_ptr(),
+                                        0.0 if ln is None else float(ln[2]), current_stream(x.device)),
           "usf_pointwise_conv_f32")
     return y
 

@@ -66,7 +66,8 @@ int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t
 int gated_norm_rows(const usf_gated_norm_desc* d, hipStream_t stream);
 int pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated);
 int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W, const float* bias,
-                   int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x, hipStream_t stream);
+                   int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x,
+                   const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream);
 int masked_residual(const float* x, const float* t, const float* om, float sign, float* y, int64_t B, int64_t CP,
                     hipStream_t stream);
 int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
@@ -217,8 +218,9 @@ int usf_gated_residual_f32(const float* x, const float* vg, float* y, int64_t B,
 int usf_pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated) { return usf::pointwise_conv_supported(cin, cout, gated); }
 int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W,
                            const float* bias, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
-                           const float* gate_x, usf_stream_t stream) {
-  return usf::pointwise_conv(x, y, B, cin, cout, P, W, bias, in_act, in_slope, out_act, out_slope, gate_x, (hipStream_t)stream);
+                           const float* gate_x, const float* ln_gamma, const float* ln_beta, float ln_eps, usf_stream_t stream) {
+  return usf::pointwise_conv(x, y, B, cin, cout, P, W, bias, in_act, in_slope, out_act, out_slope, gate_x, ln_gamma, ln_beta,
+                             ln_eps, (hipStream_t)stream);
 }
 int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream) {
   return usf::gated_norm_rows(d, (hipStream_t)stream);

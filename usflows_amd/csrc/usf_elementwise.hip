@@ -483,12 +483,14 @@ int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, co
 // pixel, loads its cin channel values once (coalesced along p), and walks the output channels with wave-uniform weight
 // rows (wide scalar loads) -- exact fp32 FMAs, sums over ci in ascending order.
 // ------------------------------------------------------------------------------------------
-template <int CIN, bool GATED>
+struct PwLn { const float* gamma; const float* beta; float eps; };
+
+template <int CIN, bool GATED, bool LN>
 __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __restrict__ x, float* __restrict__ y, int cout,
                                                              int64_t P, const float* __restrict__ W,
                                                              const float* __restrict__ bias, int in_act, float in_slope,
                                                              int out_act, float out_slope,
-                                                             const float* __restrict__ gate_x, int64_t BP) {
+                                                             const float* __restrict__ gate_x, int64_t BP, PwLn ln) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= BP) return;
   const int64_t b = i / P, p = i - b * P;
@@ -496,6 +498,41 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __rest
   float v[CIN];
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci) v[ci] = act_apply(xb[(int64_t)ci * P], in_act, in_slope);
+  if (LN) {
+    // gated convolution + out_act + LayerNormChannels over the C == CIN output channels of this pixel (GatedConv, the
+    // nonlinearity and the layer norm that follow it in ConvNet2D, networks.py:480-493): the pixel's outputs stay in
+    // registers, mean / biased variance / normalisation with the arithmetic of layernorm_channels_kernel
+    constexpr int C = CIN;
+    const float* gb = gate_x + b * C * P + p;
+    float r[C];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* wv = W + c * CIN;
+      const float* wg = W + (C + c) * CIN;
+      float av = 0.f, ag = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        av = fmaf(wv[ci], v[ci], av);
+        ag = fmaf(wg[ci], v[ci], ag);
+      }
+      if (bias) { av += bias[c]; ag += bias[C + c]; }
+      r[c] = act_apply(gb[(int64_t)c * P] + av * __builtin_amdgcn_rcpf(1.f + __expf(-ag)), out_act, out_slope);
+      sum += r[c];
+    }
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float d = r[c] - mean;
+      sq += d * d;
+    }
+    const float den = sqrtf(sq / (float)C + ln.eps);
+    float* yb = y + b * C * P + p;
+#pragma unroll
+    for (int c = 0; c < C; ++c) yb[(int64_t)c * P] = (r[c] - mean) / den * ln.gamma[c] + ln.beta[c];
+    return;
+  }
   // output channels in groups of 8 (unrolled): the group's weight rows, gate values and stores are independent of each
   // other, so scalar loads, global loads and FMAs of neighbouring channels overlap
   if (GATED) {
@@ -549,8 +586,15 @@ int pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated) {
 }
 
 int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W, const float* bias,
-                   int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x, hipStream_t stream) {
+                   int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x,
+                   const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream) {
+  if (B == 0 && P > 0 && cin > 0 && cout > 0) return 0;      // (an empty batch: its tensors have no storage to point to)
   const int gated = gate_x != nullptr;
+  const bool lnorm = ln_gamma != nullptr;
+  if (lnorm && (!ln_beta || !gated || cout != 2 * cin || cin > 32)) {
+    set_error("usf_pointwise_conv_f32: the layer-norm form needs gamma and beta, the gated mode, cout == 2 cin and cin <= 32");
+    return -2;
+  }
   if (B < 0 || P <= 0 || !pointwise_conv_supported(cin, cout, gated)) {
     set_error("usf_pointwise_conv_f32: unsupported sizes (cin in {8, 16, 24, 32, 48, 64}, 1 <= cout <= 256, even cout when gated)");
     return -2;
@@ -565,13 +609,25 @@ int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cou
   const int64_t BP = B * P, blocks = (BP + 255) / 256;
   if (blocks > 0x7fffffffLL) { set_error("usf_pointwise_conv_f32: grid too large"); return -3; }
   const dim3 g((unsigned)blocks), bl(256);
+  const PwLn ln{ln_gamma, ln_beta, ln_eps};
 #define USF_PW(CI)                                                                                                      \
   do {                                                                                                                  \
-    if (gated) hipLaunchKernelGGL((pointwise_conv_kernel<CI, true>), g, bl, 0, stream, x, y, (int)cout, P, W, bias, in_act,       \
-                                  in_slope, out_act, out_slope, gate_x, BP);                                            \
-    else hipLaunchKernelGGL((pointwise_conv_kernel<CI, false>), g, bl, 0, stream, x, y, (int)cout, P, W, bias, in_act, in_slope,  \
-                            out_act, out_slope, gate_x, BP);                                                            \
+    if (gated) hipLaunchKernelGGL((pointwise_conv_kernel<CI, true, false>), g, bl, 0, stream, x, y, (int)cout, P, W, bias,       \
+                                  in_act, in_slope, out_act, out_slope, gate_x, BP, ln);                                \
+    else hipLaunchKernelGGL((pointwise_conv_kernel<CI, false, false>), g, bl, 0, stream, x, y, (int)cout, P, W, bias, in_act,    \
+                            in_slope, out_act, out_slope, gate_x, BP, ln);                                              \
   } while (0)
+#define USF_PWLN(CI) hipLaunchKernelGGL((pointwise_conv_kernel<CI, true, true>), g, bl, 0, stream, x, y, (int)cout, P, W, bias, \
+                                        in_act, in_slope, out_act, out_slope, gate_x, BP, ln)
+  if (lnorm) {
+    switch ((int)cin) {
+      case 8: USF_PWLN(8); break;
+      case 16: USF_PWLN(16); break;
+      case 24: USF_PWLN(24); break;
+      default: USF_PWLN(32); break;
+    }
+    return check_launch("usf_pointwise_conv_f32");
+  }
   switch ((int)cin) {
     case 8: USF_PW(8); break;
     case 16: USF_PW(16); break;
@@ -581,6 +637,7 @@ int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cou
     default: USF_PW(64); break;
   }
 #undef USF_PW
+#undef USF_PWLN
   return check_launch("usf_pointwise_conv_f32");
 }
 

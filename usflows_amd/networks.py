@@ -235,9 +235,11 @@ def _conv_hip_ok(conv, x) -> bool:
     return _ext.load().usf_conv2d_same_fits(conv.in_channels, conv.out_channels, x.shape[2], x.shape[3], conv.kernel_size[0]) >= 2
 
 
-def _pointwise_hip(conv, x, in_act=None, gate_x=None):
+def _pointwise_hip(conv, x, in_act=None, gate_x=None, post=None):
     """a 1 x 1 nn.Conv2d with few input channels on usf_pointwise_conv_f32 (vector ALUs, exact fp32; HBM-bound work that the
-    matrix-core kernel serves at a quarter of the HBM rate), optionally with GatedConv's gate; None if the shape is not served"""
+    matrix-core kernel serves at a quarter of the HBM rate), optionally with GatedConv's gate; None if the shape is not served.
+    post = ((act id, slope), LayerNormChannels): the nonlinearity and layer norm behind a GatedConv joined to the same pass
+    (the caller has checked that the shape allows it)"""
     from . import _ext
     if conv.kernel_size != (1, 1) or not _conv_same_shaped(conv, x) or \
             not _ext.pointwise_conv_supported(conv.in_channels, conv.out_channels, gate_x is not None):
@@ -249,8 +251,12 @@ def _pointwise_hip(conv, x, in_act=None, gate_x=None):
         b = None if conv.bias is None else conv.bias.detach().to(device=x.device, dtype=torch.float32).contiguous()
         cache = conv._usf_pointwise = (key, w, b)
     ia, isl = in_act if in_act is not None else (_ext.ACT_NONE, 0.0)
-    return _ext.pointwise_conv(x.contiguous(), cache[1], cache[2], in_act=ia, in_slope=isl,
-                               gate_x=None if gate_x is None else gate_x.contiguous())
+    oa, osl, ln = _ext.ACT_NONE, 0.0, None
+    if post is not None:
+        (oa, osl), lnm = post
+        ln = (lnm.gamma.detach().reshape(-1).contiguous(), lnm.beta.detach().reshape(-1).contiguous(), lnm.eps)
+    return _ext.pointwise_conv(x.contiguous(), cache[1], cache[2], in_act=ia, in_slope=isl, out_act=oa, out_slope=osl,
+                               gate_x=None if gate_x is None else gate_x.contiguous(), ln=ln)
 
 
 def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None):
@@ -308,9 +314,29 @@ class GatedConv(nn.Module):
             nn.Conv2d(c_hidden, 2 * c_in, kernel_size=1, padding=padding, stride=stride, dilation=dilation),
         )
 
-    def forward(self, x):
+    def can_join_layernorm(self, x, ln) -> bool:
+        """True when forward(x, post=(act, ln)) computes nonlinearity + LayerNormChannels in the gated convolution's pass:
+        the second convolution is 1 x 1 on usf_pointwise_conv_f32 with c_hidden == c_in <= 32 channels"""
+        n = self.net
+        C = x.shape[1]
+        if not (x.is_cuda and x.dim() == 4 and isinstance(ln, LayerNormChannels) and ln._hip_ok(x) and ln.gamma.numel() == C
+                and os.environ.get("USF_POINTWISE", "1") != "0" and _relu_kind(n[0]) is not None and _relu_kind(n[2]) is not None):
+            return False
+        from . import _ext
+        c2 = n[3]
+        return (isinstance(c2, nn.Conv2d) and c2.kernel_size == (1, 1) and c2.in_channels == C and c2.out_channels == 2 * C
+                and C <= 32 and _ext.pointwise_conv_supported(C, 2 * C, True) and _conv_hip_ok(n[1], x)
+                and n[1].out_channels == C)
+
+    def forward(self, x, post=None):
+        """post = ((act id, slope), LayerNormChannels) only after ``can_join_layernorm`` said yes"""
         n = self.net
         a0, a2 = _relu_kind(n[0]), _relu_kind(n[2])
+        if post is not None:
+            h = _conv_hip(n[1], x, in_act=a0)
+            out = _pointwise_hip(n[3], h, in_act=a2, gate_x=x, post=post)
+            assert out is not None
+            return out
         if a0 is not None and a2 is not None and _conv_hip_ok(n[1], x):
             # device form: the two nonlinearities ride in the convolutions' staging passes, the gate in one more pass
             from . import _ext
@@ -398,6 +424,10 @@ class ConvNet2D(nn.Module):
                     fold = None                                   # that ReLU belongs to the layer norm's pass
                 x = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, out_act=fold)
                 k += 2 if fold is not None else 1
+            elif isinstance(m, GatedConv) and _relu_kind(nxt) is not None and k + 2 < len(mods) \
+                    and m.can_join_layernorm(x, mods[k + 2]):
+                x = m(x, post=(_relu_kind(nxt), mods[k + 2]))     # GatedConv + nonlinearity + layer norm: its last pass does all
+                k += 3
             elif act is not None and isinstance(nxt, LayerNormChannels) and nxt._hip_ok(x):
                 x = nxt(x, pre_act=act)
                 k += 2
