@@ -427,7 +427,7 @@ class Flow(torch.nn.Module):
                 if graphed is not None:
                     losses.append(graphed)
                 else:
-                    optim.zero_grad()
+                    model._zero_grad_for_step(optim)
                     loss = -model.log_prob(sample, context=noise).mean() - model.log_prior()
                     loss.backward()
                     losses.append(float(loss.detach()))
@@ -506,7 +506,11 @@ class Flow(torch.nn.Module):
                 warnings.warn(f"usflows_amd: hipGraph capture of the training step failed ({type(e).__name__}: "
                               f"{str(e).splitlines()[0] if str(e) else ''}); Flow.fit runs eager steps", RuntimeWarning)
                 return None
-            st.update(graph=graph, x=sx, ctx=sc, loss=sl, params=params)
+            # the graph holds raw addresses: keep what it writes to and reads from alive whatever happens to `p.grad` or to
+            # the optimiser's pointer tables afterwards (an eager step in between -- the ragged last batch of an epoch --
+            # must not free them: a replay into freed gradient buffers is a GPU memory fault waiting for the allocator)
+            keep = ([p.grad for p in params], dict(getattr(optim, "_tables", {}) or {}))
+            st.update(graph=graph, x=sx, ctx=sc, loss=sl, params=params, keep=keep)
         st["x"].copy_(sample)
         if st["ctx"] is not None:
             st["ctx"].copy_(noise)
@@ -515,6 +519,20 @@ class Flow(torch.nn.Module):
         for p in st["params"]:
             torch.autograd.graph.increment_version(p)      # a replay runs no Python: tell the version-keyed caches
         return float(st["loss"])
+
+    def _zero_grad_for_step(self, optim) -> None:
+        """``optim.zero_grad()`` of an eager step -- but once a training step of this optimiser has been captured, the
+        gradients are zeroed IN PLACE: the captured graph (and the optimiser's pointer table inside it) address exactly these
+        buffers, and autograd accumulates into an existing ``.grad`` in place, so eager steps and replays keep sharing them"""
+        st = self.__dict__.get("_train_graph_state")
+        if st is not None and st.get("graph") is not None and st["optim"] is optim:
+            for p, g in zip(st["params"], st["keep"][0]):
+                if g is not None:
+                    if p.grad is not g:
+                        p.grad = g              # (someone set it to None or replaced it: back to the graph's buffer)
+                    g.zero_()
+            return
+        optim.zero_grad()
 
     def is_feasible(self) -> bool:
         return all(bool(l.is_feasible()) for l in self.layers if isinstance(l, BaseTransform))
