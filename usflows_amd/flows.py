@@ -218,8 +218,43 @@ class Flow(torch.nn.Module):
                 return out
         return self._layer_loop_log_prob(x, context)
 
+    def _parameter_only_ladj_total(self, x):
+        """Sum of the layers' log|det J| when every one of them depends on the parameters only (what makes the flow uniformly
+        scaling: transforms.py:316-326, 1303-1320, ScaleTransform; not the affine-coupling extension) and nothing is to be
+        differentiated -- computed once per parameter version on the device (a 0-dim tensor, no host copy) instead of ~10
+        small torch launches per affine layer on every call, as the reference's loop does.  None when it does not apply."""
+        if not (torch.is_tensor(x) and x.is_cuda) or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return None
+        if not all(_ladj_is_parameter_only(l) for l in self.layers):
+            return None
+        key = (str(x.device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        c = self.__dict__.get("_ladj_total_cache")
+        if c is None or c[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None           # (never fill a cache inside a capture: its values would only exist after a replay)
+            total = None
+            with torch.no_grad():
+                for layer in reversed(self.layers):
+                    v = layer.log_abs_det_jacobian(None, None)
+                    if not torch.is_tensor(v):
+                        if float(v) == 0.0:
+                            continue                                   # (MaskedCoupling: ladj == 0.0, transforms.py:316-326)
+                        v = torch.full((), float(v), dtype=torch.float32, device=x.device)
+                    total = v.to(x.device) if total is None else total + v.to(x.device)
+                if total is None:
+                    total = torch.zeros((), dtype=torch.float32, device=x.device)
+            c = self.__dict__["_ladj_total_cache"] = (key, total)
+        return c[1]
+
     def _layer_loop_log_prob(self, x, context=None):
         """the reference's loop (flows.py:236-245), layer by layer"""
+        ladj_total = self._parameter_only_ladj_total(x)
+        if ladj_total is not None:
+            for layer in reversed(self.layers):
+                x = layer.backward(x, context=context) if context is not None else layer.backward(x)
+            y = x
+            lp = self._base_log_prob_layer_loop(y)
+            return (self.base_distribution.log_prob(y) if lp is None else lp) - ladj_total
         log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
         for layer in reversed(self.layers):
             if context is not None:
@@ -558,6 +593,15 @@ class Flow(torch.nn.Module):
             return profile
         tail = self.base_distribution.radial_ldl_profile(threshold=lp[0], r_max=r_max, n_samples=n_samples)
         return _intersect_intervals(profile, tail)
+
+
+def _ladj_is_parameter_only(layer) -> bool:
+    """True for the layers whose log|det J| does not depend on the sample (the reference's own layer set)"""
+    if isinstance(layer, InverseTransform):
+        return _ladj_is_parameter_only(layer.transform)
+    if isinstance(layer, BlockAffineTransform):
+        return isinstance(layer.block_transform, (LUTransform, HouseholderTransform, SequentialAffineTransform))
+    return type(layer) in (ScaleTransform, MaskedCoupling)
 
 
 class _unvalidated:
