@@ -484,3 +484,46 @@ def test_convnet2d_joins_gated_conv_relu_and_layernorm_into_one_pass(monkeypatch
         assert len(ln_calls) == 2
     assert (y.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
     assert (y - y0).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_layer_loop_log_det_total_is_cached_per_parameter_version(monkeypatch):
+    """the layer loop's sum of parameter-only log-determinants (Flow._parameter_only_ladj_total): same log_prob as the loop
+    that asks every layer on every call, recomputed after an in-place parameter update, not used under autograd nor for a
+    flow with the affine-coupling extension (whose log-det depends on the sample)"""
+    from usflows_amd.flows import Flow
+    name = [n for n in image_case_names() if "mnistcfg" in n][0]
+    flow, a = load_image_case(name, device="cuda:0")
+    flow.graph_max_rows = 0
+    x = a["x"].to("cuda:0")
+
+    def both():
+        with torch.no_grad():
+            cached = flow.log_prob(x)
+            assert flow.__dict__.get("_ladj_total_cache") is not None
+            with monkeypatch.context() as m:
+                m.setattr(Flow, "_parameter_only_ladj_total", lambda self, x_: None)
+                plain = flow.log_prob(x)
+        return cached, plain
+
+    c1, p1 = both()
+    assert _rel(c1, p1.cpu()) < 1e-6 and _rel(c1, a["log_prob64"]) < 1e-5
+    key1 = flow._ladj_total_cache[0]
+    with torch.no_grad():
+        flow.layers[-1].scale.mul_(1.25)
+    c2, p2 = both()
+    assert flow._ladj_total_cache[0] != key1 and _rel(c2, p2.cpu()) < 1e-6 and (c2 - c1).abs().min().item() > 1.0
+    with torch.no_grad():
+        assert flow._parameter_only_ladj_total(x) is not None
+    with torch.enable_grad():
+        assert flow._parameter_only_ladj_total(x) is None              # parameters require grad: nothing is cached
+
+
+@pytest.mark.gpu
+def test_log_det_cache_is_not_used_with_the_affine_coupling_extension():
+    from usflows_amd.flows import _ladj_is_parameter_only
+    from usflows_amd import transforms as T_
+    assert _ladj_is_parameter_only(T_.ScaleTransform([4])) and _ladj_is_parameter_only(T_.BlockAffineTransform([4], T_.LUTransform(4)))
+    assert _ladj_is_parameter_only(T_.InverseTransform(T_.BlockAffineTransform([4], T_.LUTransform(4))))
+    amc = T_.AffineMaskedCoupling(torch.tensor([[1.0, 0.0, 1.0, 0.0]]), torch.nn.Linear(4, 8))
+    assert not _ladj_is_parameter_only(amc) and not _ladj_is_parameter_only(T_.InverseTransform(amc))
