@@ -279,3 +279,24 @@ def test_udl_profile_matches_reference_cpu():
     for name in udl_case_names():
         spec, sd, a = load_case(name)
         _check_udl(build_flow(spec, sd), a["x"], load_udl(name))
+
+
+def test_round2_host_switches_are_inert_on_the_cpu():
+    """the device-only shortcuts added to the host code leave CPU calls on the reference's formulation: no graphed training
+    step, `optim.zero_grad()` semantics, no cached log-determinant total, LUTransform's inverse through torch.inverse"""
+    spec, sd, a = load_case("synth_d7_k3_hh0_laplace")
+    flow = build_flow(spec, sd)
+    x = a["x"]
+    opt = torch.optim.SGD(flow.parameters(), lr=1e-3)
+    assert flow._train_graph_step(opt, x, None) is None and "_train_graph_state" not in flow.__dict__
+    loss = -flow.log_prob(x).mean()
+    loss.backward()
+    assert any(p.grad is not None for p in flow.parameters())
+    flow._zero_grad_for_step(opt)                                   # no captured graph: plain zero_grad()
+    assert all(p.grad is None or float(p.grad.abs().sum()) == 0.0 for p in flow.parameters())
+    with torch.no_grad():
+        assert flow._parameter_only_ladj_total(x) is None
+    lu = flow.layers[0].block_transform.transforms[0]
+    assert torch.equal(lu._tri_inverse(lu.L, False), torch.inverse(lu.L))
+    from usflows_amd.flows import _ladj_is_parameter_only
+    assert all(_ladj_is_parameter_only(l) for l in flow.layers)
