@@ -484,6 +484,24 @@ int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, co
 // rows (wide scalar loads) -- exact fp32 FMAs, sums over ci in ascending order.
 // ------------------------------------------------------------------------------------------
 struct PwLn { const float* gamma; const float* beta; float eps; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two dot products of wave-uniform weight rows with the pixel's channel values, on PACKED FMAs (v_pk_fma_f32: two fp32 FMAs per
+// lane and instruction): input channels in pairs -- the pair of weights is one 64-bit scalar operand, the pair of values two
+// neighbouring registers -- so each row keeps an even and an odd partial sum (ascending ci within each), added at the end
+template <int CIN>
+__device__ __forceinline__ void pw_dot2(const float* __restrict__ wa, const float* __restrict__ wb, const float (&v)[CIN],
+                                        float& ra, float& rb) {
+  f32x2 a2 = {0.f, 0.f}, b2 = {0.f, 0.f};
+#pragma unroll
+  for (int ci = 0; ci < CIN; ci += 2) {
+    const f32x2 vv = {v[ci], v[ci + 1]};
+    a2 = __builtin_elementwise_fma(*reinterpret_cast<const f32x2*>(wa + ci), vv, a2);
+    b2 = __builtin_elementwise_fma(*reinterpret_cast<const f32x2*>(wb + ci), vv, b2);
+  }
+  ra = a2[0] + a2[1];
+  rb = b2[0] + b2[1];
+}
 
 template <int CIN, bool GATED, bool LN>
 __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __restrict__ x, float* __restrict__ y, int cout,
@@ -510,12 +528,8 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __rest
     for (int c = 0; c < C; ++c) {
       const float* wv = W + c * CIN;
       const float* wg = W + (C + c) * CIN;
-      float av = 0.f, ag = 0.f;
-#pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) {
-        av = fmaf(wv[ci], v[ci], av);
-        ag = fmaf(wg[ci], v[ci], ag);
-      }
+      float av, ag;
+      pw_dot2<CIN>(wv, wg, v, av, ag);
       if (bias) { av += bias[c]; ag += bias[C + c]; }
       r[c] = act_apply(gb[(int64_t)c * P] + av * __builtin_amdgcn_rcpf(1.f + __expf(-ag)), out_act, out_slope);
       sum += r[c];
@@ -549,12 +563,8 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __rest
         if (c < C) {
           const float* wv = W + c * CIN;
           const float* wg = W + (C + c) * CIN;
-          float av = 0.f, ag = 0.f;
-#pragma unroll
-          for (int ci = 0; ci < CIN; ++ci) {
-            av = fmaf(wv[ci], v[ci], av);
-            ag = fmaf(wg[ci], v[ci], ag);
-          }
+          float av, ag;
+          pw_dot2<CIN>(wv, wg, v, av, ag);
           if (bias) { av += bias[c]; ag += bias[C + c]; }
           // (v_exp_f32 / v_rcp_f32: 1 ulp each)
           yb[(int64_t)c * P] = gx[j] + av * __builtin_amdgcn_rcpf(1.f + __expf(-ag));
