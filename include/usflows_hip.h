@@ -250,7 +250,8 @@ int usf_masked_residual_f32(const float* x, const float* t, const float* one_min
  *   gated + layer norm (ln_gamma / ln_beta [C] non-NULL; needs cout == 2 cin, cin <= 32): the gated result r, then
  *     y = (a' - mean_c a') / sqrt(var_c a' + ln_eps) * ln_gamma + ln_beta with a' = out_act(r) -- the nonlinearity and the
  *     LayerNormChannels that follow a GatedConv in ConvNet2D (networks.py:480-493, :40-58) joined to the same pass.
- * Exact fp32 FMAs (sums over ci in ascending order).  cin in {8, 16, 24, 32, 48, 64}, cout <= 256
+ * Exact fp32 FMAs (plain: sums over ci in ascending order; gated: an even-ci and an odd-ci partial sum per row, packed FMAs,
+ * added at the end).  cin in {8, 16, 24, 32, 48, 64}, cout <= 256
  * (usf_pointwise_conv_supported: 1 if the shape is served); HBM-bound: 4 (cin + cout) bytes per pixel.
  */
 int usf_pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated);

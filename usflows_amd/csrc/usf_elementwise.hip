@@ -481,7 +481,7 @@ int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, co
 // 2 cin flops per 4-byte output element next to 4 (cin + cout) bytes per pixel: HBM-bound work that the matrix-core kernel
 // (usf_conv.hip: LDS image, bf16x3 split, per-group barriers) serves at a quarter of the HBM rate; here one thread owns a
 // pixel, loads its cin channel values once (coalesced along p), and walks the output channels with wave-uniform weight
-// rows (wide scalar loads) -- exact fp32 FMAs, sums over ci in ascending order.
+// rows (wide scalar loads) -- exact fp32 FMAs (plain form: sums over ci in ascending order; gated forms: pw_dot2 below).
 // ------------------------------------------------------------------------------------------
 struct PwLn { const float* gamma; const float* beta; float eps; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
