@@ -16,6 +16,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))          # tests/: image_synth
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import ref_shim  # noqa: E402
@@ -38,15 +39,22 @@ def condition_(flow, seed, alpha=0.3):
                 m.scale.copy_(sign * (0.5 + torch.rand(m.scale.shape, generator=g)))
 
 
-def run_case(name, in_dims, K, cond_args, seed, hh=1, conj=True, masktype="checkerboard", n=12):
+def run_case(name, in_dims, K, cond_args, seed, hh=1, conj=True, masktype="checkerboard", n=12, synth=False):
+    """synth: the parameters come from tests/image_synth.py (a pure function of the seed and the module structure, which
+    the mirror shares key for key): no state dict is stored, the test regenerates it"""
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         return
     torch.manual_seed(seed)
     base = torch.distributions.Laplace(torch.zeros(in_dims), torch.ones(in_dims))
     flow = flows.USFlow(base, list(in_dims), K, networks.ConvNet2D, dict(cond_args), householder=hh,
                         affine_conjugation=conj, masktype=masktype)
-    condition_(flow, seed)
-    sd = {k: v.detach().clone() for k, v in flow.state_dict().items()}
+    if synth:
+        from image_synth import synth_image_params_
+        synth_image_params_(flow, seed)
+        sd = {}
+    else:
+        condition_(flow, seed)
+        sd = {k: v.detach().clone() for k, v in flow.state_dict().items()}
     g = torch.Generator().manual_seed(1000 + seed)
     x = torch.rand(n, *in_dims, generator=g)
     zin = torch.distributions.Laplace(0.0, 1.0).icdf(torch.rand(n, *in_dims, generator=g) * 0.998 + 0.001)
@@ -70,8 +78,11 @@ def run_case(name, in_dims, K, cond_args, seed, hh=1, conj=True, masktype="check
     arrays.update({k: v.detach().numpy() for k, v in out.items()})
     arrays.update({"sd/" + k: v.numpy() for k, v in sd.items()})
     ca = dict(cond_args)
-    arrays["spec"] = np.array(json.dumps(dict(in_dims=list(in_dims), coupling_blocks=K, cond_args=ca, householder=hh,
-                                              affine_conjugation=conj, masktype=masktype)))
+    spec = dict(in_dims=list(in_dims), coupling_blocks=K, cond_args=ca, householder=hh, affine_conjugation=conj,
+                masktype=masktype)
+    if synth:
+        spec["synth_seed"] = seed
+    arrays["spec"] = np.array(json.dumps(spec))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
     rel = (out["log_prob32"].double() - out["log_prob64"]).abs() / out["log_prob64"].abs()
@@ -96,6 +107,16 @@ def main():
     run_case("image_cifarcfg_c48_8x8_k2_gated_ln_hh1_conj", (48, 8, 8), 2,
              dict(c_in=48, c_hidden=32, num_layers=3, padding="same", kernel_size=3, normalize_layers=True, gating=True), 35,
              n=6)
+    # the CIFAR configuration in full: all 10 coupling blocks, householder 0 (experiments/cifar/cifar.yaml:56-77);
+    # parameters from tests/image_synth.py, so the fixture holds inputs and outputs only
+    run_case("image_cifarcfg_full_c48_8x8_k10_gated_ln_hh0_conj_synth", (48, 8, 8), 10,
+             dict(c_in=48, c_hidden=32, num_layers=3, padding="same", kernel_size=3, normalize_layers=True, gating=True), 36,
+             hh=0, n=6, synth=True)
+    # the MNIST configuration with synthesized parameters at 24 rows: the rows the full-batch tests place at the head,
+    # middle and tail of 65 536
+    run_case("image_mnistcfg_c16_7x7_k2_gated_ln_hh1_conj_synth", (16, 7, 7), 2,
+             dict(c_in=16, c_hidden=32, num_layers=1, padding="same", kernel_size=3, normalize_layers=True, gating=True), 37,
+             n=24, synth=True)
 
 
 if __name__ == "__main__":

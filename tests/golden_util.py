@@ -99,9 +99,15 @@ def load_image_case(name, device="cpu"):
     base = torch.distributions.Laplace(torch.zeros(dims).to(device), torch.ones(dims).to(device))
     flow = USFlow(base, dims, d["coupling_blocks"], ConvNet2D, dict(d["cond_args"]), householder=d["householder"],
                   affine_conjugation=d["affine_conjugation"], masktype=d["masktype"])
-    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
-    res = flow.load_state_dict(sd, strict=True)
-    assert not res.missing_keys and not res.unexpected_keys
+    if "synth_seed" in d:
+        # parameters regenerated from the seed (tests/image_synth.py: the same call conditioned the reference's flow
+        # when the fixture was made; the mirror shares its module structure key for key)
+        from image_synth import synth_image_params_
+        synth_image_params_(flow, int(d["synth_seed"]))
+    else:
+        sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+        res = flow.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
     if device != "cpu":
         flow = flow.to(device)
     arrays = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("sd/") and k != "spec"}

@@ -74,6 +74,34 @@ def test_flow_log_prob_is_the_change_of_variables_density():
     assert torch.allclose(flow._forward(flow.backward(x)), x, rtol=1e-4, atol=1e-5)
 
 
+def test_cached_device_logdet_is_keyed_on_identity_and_never_served_under_autograd():
+    """The log-det a device call leaves behind belongs to ONE (input, output) pair: it is matched by object identity and
+    version (a freed tensor's address can come back), dropped by the next forward / backward, and never returned where
+    a gradient could be asked of it (it is detached)."""
+    D = 6
+    c = _coupling(D, 7)
+    x = torch.randn(5, D, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        y = c.forward(x)
+        true_ld = c.log_abs_det_jacobian(x, y)
+    fake = torch.full((5,), 123.0)
+    c._last = (x, y, (x._version, y._version), fake)                 # what a device call would have left
+    with torch.no_grad():
+        assert c.log_abs_det_jacobian(x, y) is fake                   # same pair, unmodified, no autograd: served
+        assert torch.allclose(c.log_abs_det_jacobian(x.clone(), y), true_ld)      # equal values, other object: recomputed
+    ld = c.log_abs_det_jacobian(x, y)                                 # grad mode on, trainable conditioner: recomputed
+    assert ld.requires_grad and torch.allclose(ld, true_ld)
+    x.add_(0.0)                                                       # in-place edit bumps the version
+    with torch.no_grad():
+        assert c.log_abs_det_jacobian(x, y) is not fake
+        c._last = (x, y, (x._version, y._version), fake)
+        c.forward(x)                                                  # any later call drops the cache (torch path too)
+        assert c._last is None
+        c._last = (x, y, (x._version, y._version), fake)
+        c.backward(y)
+        assert c._last is None
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cond,bound,B", [("dense", 2.0, 1), ("dense", 2.0, 777), ("conditional", None, 4100)])
 def test_device_path_matches_torch_formulation(cond, bound, B):

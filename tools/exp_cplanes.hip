@@ -57,6 +57,24 @@ int main(int argc, char** argv) {
 #ifdef USF_STAMP
   unsigned long long* dbg; hipMalloc(&dbg, 2048 * 8 * 4 * 8); hipMemset(dbg, 0, 2048 * 8 * 4 * 8); usf::g_cdbg = dbg;
 #endif
+  // ---- the two kernels on the same input must agree bit for bit (same summation order per accumulator) ----
+  {
+    const size_t zb = (size_t)np * nkb * NPL * 1024;
+    char* z2; hipMalloc(&z2, zb); hipMemcpy(z2, z, zb, hipMemcpyDeviceToDevice);
+    char* z0; hipMalloc(&z0, zb); hipMemcpy(z0, z, zb, hipMemcpyDeviceToDevice);
+    usf::g_cp_w32 = 0; d.z = z; if (usf::coupling_planes(&d, 0)) return 1;
+    usf::g_cp_w32 = 1; d.z = z2; if (usf::coupling_planes(&d, 0)) return 1;
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 2; }
+    std::vector<unsigned short> a(zb / 2), b(zb / 2), c(zb / 2);
+    hipMemcpy(a.data(), z, zb, hipMemcpyDeviceToHost); hipMemcpy(b.data(), z2, zb, hipMemcpyDeviceToHost); hipMemcpy(c.data(), z0, zb, hipMemcpyDeviceToHost);
+    size_t diff = 0, changed = 0, first = (size_t)-1;
+    for (size_t i = 0; i < a.size(); ++i) { if (a[i] != b[i]) { ++diff; if (first == (size_t)-1) first = i; } if (a[i] != c[i]) ++changed; }
+    printf("16-row kernel vs 32-row kernel: %zu of %zu plane elements differ (first at %zd: panel %zd block %zd); the layer changed %zu elements -> %s\n",
+           diff, a.size(), (ssize_t)first, first == (size_t)-1 ? -1 : (ssize_t)(first / (nkb * NPL * 512)), first == (size_t)-1 ? -1 : (ssize_t)((first / (NPL * 512)) % nkb), changed, diff == 0 && changed > 0 ? "OK" : "FAIL");
+    hipMemcpy(z, z0, zb, hipMemcpyDeviceToDevice); d.z = z; hipFree(z2); hipFree(z0);
+  }
+  for (int variant = 0; variant < 2; ++variant) {
+  usf::g_cp_w32 = variant;
   for (int i = 0; i < 5; ++i) if (usf::coupling_planes(&d, 0)) return 1;
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 2; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -67,7 +85,7 @@ int main(int argc, char** argv) {
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
   const double flops = 2.0 * M * (392.0 * 256 + (NH - 1) * 256.0 * 256 + 256.0 * 392);
   int32_t hf; hipMemcpy(&hf, flag, 4, hipMemcpyDeviceToHost);
-  printf("[%s NH=%d] coupling on planes M=%lld: %.4f ms  %.1f TF/s fp32-equivalent (algorithmic)  range flag %d\n", NPL == 2 ? "f16x2" : "bf16x3", NH, (long long)M, ms, flops / ms / 1e9, hf);
+  printf("[%s NH=%d %s] coupling on planes M=%lld: %.4f ms  %.1f TF/s fp32-equivalent (algorithmic)  range flag %d\n", NPL == 2 ? "f16x2" : "bf16x3", NH, variant ? "32-row waves" : "16-row waves", (long long)M, ms, flops / ms / 1e9, hf);
 #ifdef USF_STAMP
   std::vector<unsigned long long> h(2048 * 8 * 4); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
   double sm[3] = {0, 0, 0}; int nw = 0;
@@ -77,6 +95,8 @@ int main(int argc, char** argv) {
   printf("  waves %d: cycles per wave: phase 1 %.0f (MFMA issue of a SIMD's two waves %d), phase 2 %.0f (%d), phase 3 %.0f (%d), total %.0f -> %.1f %% matrix-pipe issue\n",
          nw, sm[0] / nw, 2 * 13 * 16 * npr * 16, sm[1] / nw, 2 * (NH - 1) * 8 * 16 * npr * 16, sm[2] / nw, 2 * 13 * 16 * npr * 16,
          tot, 100.0 * (2.0 * (13 * 16 * 2 + (NH - 1) * 8 * 16) * npr * 16) / tot);
+  hipMemset(dbg, 0, 2048 * 8 * 4 * 8);
 #endif
+  }
   return 0;
 }

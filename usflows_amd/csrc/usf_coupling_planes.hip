@@ -12,6 +12,8 @@
 //     [32 n x 256 k] n-tile (output layer) of NPL planes, double-buffered; hidden widths are padded to 256.
 //   * weights: the planes images of the planes pipeline (K axis in slot order; rows beyond the real width zero).
 //   * NPL = 3: bf16, six MFMAs per product; NPL = 2: fp16, three (range guard as in usf_planes.hip).
+#include <stdlib.h>
+
 #include "usf_common.h"
 
 namespace usf {
@@ -34,6 +36,13 @@ template <> struct CPlanes<3> {
       o[0][j] = h; o[1][j] = m; o[2][j] = (__bf16)(r - (float)m);
     }
   }
+  // one value into slot j of a chunk line's planes
+  static __device__ __forceinline__ void split1(const float x, const int j, vec (&o)[3]) {
+    const __bf16 h = (__bf16)x;
+    const float r = x - (float)h;
+    const __bf16 m = (__bf16)r;
+    o[0][j] = h; o[1][j] = m; o[2][j] = (__bf16)(r - (float)m);
+  }
   // six-term product, smallest terms first
   static __device__ __forceinline__ void mm(f32x4& acc, const vec (&w)[3], const vec (&a)[3]) {
     acc = mfma(w[2], a[0], acc); acc = mfma(w[1], a[1], acc); acc = mfma(w[0], a[2], acc);
@@ -50,6 +59,10 @@ template <> struct CPlanes<2> {
       const _Float16 h = (_Float16)x;
       o[0][j] = h; o[1][j] = (_Float16)(x - (float)h);
     }
+  }
+  static __device__ __forceinline__ void split1(const float x, const int j, vec (&o)[2]) {
+    const _Float16 h = (_Float16)x;
+    o[0][j] = h; o[1][j] = (_Float16)(x - (float)h);
   }
   static __device__ __forceinline__ void mm(f32x4& acc, const vec (&w)[2], const vec (&a)[2]) {
     acc = mfma(w[1], a[0], acc); acc = mfma(w[0], a[1], acc); acc = mfma(w[0], a[0], acc);
@@ -349,9 +362,421 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
 #undef CP_PIN_SLAB
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// coupling_planes_w32_kernel: the same layer with 32 batch rows (two row panels) per wave and ONE wave per SIMD
+// (256-thread blocks of 128 rows on the 512-register budget).  Why (profiles/r02_tuning_experiments.md section 3 and the
+// round-2 review): with 16-row waves every weight fragment read from LDS feeds 6 MFMAs (the planes GEMM: 12) -- twice
+// the LDS read bytes per product on a chip whose clock is set by the energy per product.  Here a fragment feeds the
+// wave's two batch tiles (12 MFMAs); both hidden layers' accumulators of 32 rows (2 x 128 registers) fit because the
+// wave owns the whole register file of its SIMD.  Weight stages travel through a ring of three LDS buffers with ONE
+// barrier in the MIDDLE of a stage (the planes GEMM's loop structure): a stage's staging stores sit in the first half
+// of the stage in front of it, its global loads half a stage earlier still, and its first three fragments are read
+// under the last MFMAs of the stage before -- across phase boundaries too.  The stage list of a layer is linear: nk_p
+// k-slabs of W_in, 8 k-slabs per hidden layer, nk_t n-tiles of W_out.  Per accumulator the products are summed in the
+// order of coupling_planes_kernel: the two kernels give bit-identical results.
+// ------------------------------------------------------------------------------------------------------------
+template <bool B> struct CpBool { static constexpr bool value = B; };
+template <int I> struct CpInt { static constexpr int value = I; };
+
+template <int NPL, int NH>
+__global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs p) {
+  typedef CPlanes<NPL> PT;
+  typedef typename PT::vec vec8;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int T = 16;                     // tiles per stage (hidden width 256 / n-tile of 32 outputs x 8 k-steps)
+  constexpr int HP = 16 * T;
+  constexpr int KS = T / 2;
+  constexpr int NT = 256;
+  constexpr int SLOTS = NPL * 4 * HP;       // 16-B slots per stage
+  constexpr int STGF = SLOTS * 4;           // floats per stage
+  constexpr int NPP = (4 * HP) / NT;        // staged 16-B pieces per thread and plane
+  constexpr int NST = NPL * NPP;
+  constexpr int NB = 3;
+  constexpr int PLF = 16 * HP;              // floats between the planes of a stage image (both image kinds)
+  constexpr int AH = 3;                     // fragments are read this many tiles ahead (four register sets)
+  constexpr unsigned CHB = NPL * 1024u;
+  constexpr int NPR2 = (NPL == 3) ? 12 : 6; // MFMAs per tile (both batch tiles)
+  __shared__ __attribute__((aligned(16))) float lds[NB * STGF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lj = lane & 15, lg = lane >> 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const float slope_eff = (p.act == USF_ACT_LEAKY_RELU) ? p.slope : 1.0f;     // x > 0 ? x : x * 1 == x
+
+  // ---- z through a buffer resource that covers exactly this block's valid panels: rows beyond M load zeros and
+  // their stores are dropped by the hardware (no branch anywhere in the stage bodies) ----
+  const int panel0 = blockIdx.x * 8;
+  const int nvalid = min(8, p.npanels - panel0);
+  const unsigned panel_bytes = (unsigned)p.z_nkb * CHB;
+  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(
+      p.z + (size_t)panel0 * panel_bytes, 0, (int)((unsigned)nvalid * panel_bytes), 0x00020000);
+  unsigned zoff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) zoff[b] = (unsigned)(2 * wave + b) * panel_bytes + (unsigned)lane * 16u;
+  auto load_zblk = [&](int kb, vec8 (&dst)[2][NPL]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        dst[b][q] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(zoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u), 0, 0));
+  };
+  auto store_zblk = [&](int kb, int b, const vec8 (&src)[NPL]) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, src[q]), zrs, (int)(zoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u), 0, 0);
+  };
+
+  // ---- weight stages: the layer's stage list is linear (nk_p k-slabs of W_in, 8 k-slabs per hidden layer, nk_t
+  // n-tiles of W_out).  Which matrix / image kind a stage has is a compile-time fact everywhere except in the loop of
+  // phase 1, whose last two stages stage the first two stages of the next phase: selects there, no branch ----
+  // (pointers made opaque: a select of two kernel-argument loads is turned into a load from a selected address, i.e. a
+  //  scalar-load latency in front of the MFMAs of every stage)
+  auto opaque = [](const char* q) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)q);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)q >> 32));
+    return reinterpret_cast<const char*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+  };
+  const char* const wp_in = opaque(p.Win);
+  const char* const wp_a1 = opaque(NH >= 2 ? p.Whid[0] : p.Wout);        // the matrix behind phase 1
+  const unsigned ld_in = (unsigned)__builtin_amdgcn_readfirstlane((int)p.ld_in), pl2_in = 2u * (unsigned)__builtin_amdgcn_readfirstlane((int)p.pl_in);
+  const unsigned ld_a1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(NH >= 2 ? p.ld_hid : p.ld_out));
+  const unsigned pl2_a1 = 2u * (unsigned)__builtin_amdgcn_readfirstlane((int)(NH >= 2 ? p.pl_hid : p.pl_out));
+  // staging geometry of this thread: k-slab image piece i = (row (tid >> 2) + 64 i, chunk tid & 3);
+  // n-tile image piece i = (row (tid >> 5) + 8 i, chunk tid & 31)
+  int kdst[NPP], ndst[NPP];
+#pragma unroll
+  for (int i = 0; i < NPP; ++i) {
+    const int rk = (tid >> 2) + 64 * i, ck = tid & 3;
+    kdst[i] = 4 * (ck * HP + (rk ^ (2 * ck)));
+    const int rn = (tid >> 5) + 8 * i, cn = tid & 31;
+    ndst[i] = 4 * (cn * 32 + (rn ^ (2 * (cn & 7))));
+  }
+  f32x4 st[NST];
+  // global loads of one stage: k-slab at column x0 (is_n false) or n-tile at row x0 (is_n true) of W
+  auto issue_w = [&](const char* W, unsigned ld, unsigned pl2, unsigned x0, bool is_n) {
+    const unsigned cpart = is_n ? 8u * (unsigned)(tid & 31) : x0 + 8u * (unsigned)(tid & 3);
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+      const unsigned r = is_n ? x0 + (unsigned)((tid >> 5) + 8 * i) : (unsigned)((tid >> 2) + 64 * i);
+      const unsigned off = 2u * (r * ld + cpart);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) st[q * NPP + i] = *reinterpret_cast<const f32x4*>(W + (size_t)((unsigned)q * pl2 + off));
+    }
+  };
+  // staging store of piece j (= q * NPP + i) into ring slot `ring`
+  auto store_piece = [&](int ring, int j, bool is_n) {
+    const int i = j % NPP, q = j / NPP;
+    *reinterpret_cast<f32x4*>(lds + ring * STGF + q * PLF + (is_n ? ndst[i] : kdst[i])) = st[j];
+  };
+  // fragment addresses: k-slab image tile ht: kfr + 64 ht; n-tile image tile 2 ks + u: nfr[ks & 1] + 512 ks + 64 u
+  const int kfr = 4 * (lg * HP + (lj ^ (2 * lg)));
+  int nfr[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) nfr[e] = 4 * (32 * lg + (lj ^ (2 * ((4 * e + lg) & 7))));
+  auto frag = [&](const float* a, vec8 (&w)[NPL]) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) w[q] = *reinterpret_cast<const vec8*>(a + q * PLF);
+  };
+  auto tile_ptr = [&](int ring, int i, bool is_n) -> const float* {
+    return lds + ring * STGF + (is_n ? nfr[(i >> 1) & 1] + 512 * (i >> 1) + 64 * (i & 1) : kfr + 64 * i);
+  };
+  auto next_ring = [](int r) { return r == NB - 1 ? 0 : r + 1; };
+
+  // two batch tiles against one weight fragment set: twelve (six) MFMAs, the two accumulators alternating; in two
+  // halves (a tile = two half-tile chunks of the instruction stream, below)
+  auto mm2a = [&](f32x4& a0, f32x4& a1, const vec8 (&w)[NPL], const vec8 (&b0)[NPL], const vec8 (&b1)[NPL]) {
+    if (NPL == 3) {
+      a0 = PT::mfma(w[NPL - 1], b0[0], a0); a1 = PT::mfma(w[NPL - 1], b1[0], a1);
+      a0 = PT::mfma(w[1], b0[1], a0); a1 = PT::mfma(w[1], b1[1], a1);
+      a0 = PT::mfma(w[0], b0[NPL - 1], a0); a1 = PT::mfma(w[0], b1[NPL - 1], a1);
+    } else {
+      a0 = PT::mfma(w[1], b0[0], a0); a1 = PT::mfma(w[1], b1[0], a1);
+      a0 = PT::mfma(w[0], b0[1], a0); a1 = PT::mfma(w[0], b1[1], a1);
+    }
+  };
+  auto mm2b = [&](f32x4& a0, f32x4& a1, const vec8 (&w)[NPL], const vec8 (&b0)[NPL], const vec8 (&b1)[NPL]) {
+    if (NPL == 3) {
+      a0 = PT::mfma(w[1], b0[0], a0); a1 = PT::mfma(w[1], b1[0], a1);
+      a0 = PT::mfma(w[0], b0[1], a0); a1 = PT::mfma(w[0], b1[1], a1);
+    }
+    a0 = PT::mfma(w[0], b0[0], a0); a1 = PT::mfma(w[0], b1[0], a1);
+  };
+  constexpr int NMA = (NPL == 3) ? 6 : 4;   // MFMAs of the two half tiles
+  constexpr int NMB = (NPL == 3) ? 6 : 2;
+
+  bool bad = false;
+  auto guard1 = [&](float v) { if (NPL == 2) bad = bad || !(fabsf(v) < USF_CP_F16_GUARD); };
+  auto act1 = [&](float v) { v = v > 0.0f ? v : v * slope_eff; guard1(v); return v; };
+  // lane-local split of values (j, j + 1) of a chunk line (j even: the pair shares a dword of every plane)
+  auto split_pair = [&](float x0, float x1, int j, vec8 (&o)[NPL]) {
+    PT::split1(x0, j, o);
+    PT::split1(x1, j + 1, o);
+  };
+
+  // The instruction stream of a stage is written as 32 half-tile CHUNKS separated by scheduling fences: chunk A of tile i
+  // = the first half of its MFMAs + the fragment reads of tile i + AH + a piece of side work, chunk B = the other MFMAs
+  // + another piece (staging stores in front of the barrier, the weight loads of stage g + 2 behind it, operand loads,
+  // the next operand's activation + split, the previous n-tile's epilogue).  Inside a chunk the pins alternate one
+  // MFMA with two vector instructions (a 16x16x32 MFMA leaves the SIMD's issue port free for 8 of its 16 cycles) and
+  // put memory instructions behind them.  One wave per SIMD: whatever is not under an MFMA is idle matrix pipe.
+  auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+  auto pins = [&](int nm) {
+    // (literal counts; the chain folds)
+    if (nm >= 1) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    if (nm >= 2) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    if (nm >= 3) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    if (nm >= 4) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    if (nm >= 5) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    if (nm >= 6) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);      // fragment reads
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);        // loads
+    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);        // staging stores
+    __builtin_amdgcn_sched_group_barrier(0x040, NPL, 0);      // plane stores
+  };
+  auto mid_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // accumulators: X1 starts at the first layer's bias
+  f32x4 X1[T][2], X2[T][2];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { X1[t][0] = *reinterpret_cast<const f32x4*>(p.b_in + t * 16 + 4 * lg); X1[t][1] = X1[t][0]; }
+
+  CSTAMP(c0);
+  constexpr bool A1N = (NH < 2);             // the stage behind phase 1 is an n-tile (no hidden layer)
+  // ---- pipeline fill: stage 0 staged, stage 1 in the staging registers, first fragments and operands in flight ----
+  vec8 zp[2][NPL], zn[2][NPL];
+  issue_w(wp_in, ld_in, pl2_in, 0, false);
+  load_zblk(p.kb_p0, zp);
+#pragma unroll
+  for (int j = 0; j < NST; ++j) store_piece(0, j, false);
+  issue_w(wp_in, ld_in, pl2_in, 32, false);  // (nk_p >= 2: the host routes narrower layers to the 16-row kernel)
+  __syncthreads();
+  vec8 f0[NPL], f1[NPL], f2[NPL], f3[NPL];    // weight fragments: tile i lives in set i % 4; sets 0..2 hold tiles 0..2 on stage entry
+  frag(tile_ptr(0, 0, false), f0);
+  frag(tile_ptr(0, 1, false), f1);
+  frag(tile_ptr(0, 2, false), f2);
+  int ring = 0;
+
+  // (MFMAs first in program order: at the head of a loop body the compiler waits for EVERY outstanding LDS operation
+  //  before the first MFMA -- its counters are merged conservatively across the back edge -- and a read issued in front
+  //  of that wait would expose its latency in every stage.)
+#define W32_HALF_A(I_, NXPTR_, A0_, A1_, B0_, B1_)                                                \
+  do {                                                                                            \
+    if ((I_) % 4 == 0)      { mm2a(A0_, A1_, f0, B0_, B1_); frag(NXPTR_, f3); }                   \
+    else if ((I_) % 4 == 1) { mm2a(A0_, A1_, f1, B0_, B1_); frag(NXPTR_, f0); }                   \
+    else if ((I_) % 4 == 2) { mm2a(A0_, A1_, f2, B0_, B1_); frag(NXPTR_, f1); }                   \
+    else                    { mm2a(A0_, A1_, f3, B0_, B1_); frag(NXPTR_, f2); }                   \
+  } while (0)
+#define W32_HALF_B(I_, A0_, A1_, B0_, B1_)                                                        \
+  do {                                                                                            \
+    if ((I_) % 4 == 0)      mm2b(A0_, A1_, f0, B0_, B1_);                                         \
+    else if ((I_) % 4 == 1) mm2b(A0_, A1_, f1, B0_, B1_);                                         \
+    else if ((I_) % 4 == 2) mm2b(A0_, A1_, f2, B0_, B1_);                                         \
+    else                    mm2b(A0_, A1_, f3, B0_, B1_);                                         \
+  } while (0)
+  // side work every stage carries in its B chunks: the staging stores of the next stage in front of the barrier (IN
+  // PROGRAM ORDER between the fragment reads: the ring slots are runtime values, LDS accesses keep their order) ...
+  auto stage_stores = [&](int i, int rn, bool next_n) {
+    if (i < NST - T / 2) { store_piece(rn, 2 * i, next_n); store_piece(rn, 2 * i + 1, next_n); }
+    else if (i < T / 2) store_piece(rn, i + NST - T / 2, next_n);
+  };
+  // ... and the global loads of the stage after that behind it (pieces 2 (i - 8), 2 (i - 8) + 1 in tile i = 8 .. 13)
+  auto issue_piece = [&](const char* W, unsigned ld, unsigned pl2, unsigned x0, bool is_n, int j) {
+    const int i = j % NPP, q = j / NPP;
+    const unsigned cpart = is_n ? 8u * (unsigned)(tid & 31) : x0 + 8u * (unsigned)(tid & 3);
+    const unsigned r = is_n ? x0 + (unsigned)((tid >> 5) + 8 * i) : (unsigned)((tid >> 2) + 64 * i);
+    st[j] = *reinterpret_cast<const f32x4*>(W + (size_t)((unsigned)q * pl2 + 2u * (r * ld + cpart)));
+  };
+  auto stage_loads = [&](int i, const char* W, unsigned ld, unsigned pl2, unsigned x0, bool is_n) {
+    if (i >= T / 2 && i < T / 2 + NST / 2) { issue_piece(W, ld, pl2, x0, is_n, 2 * (i - T / 2)); issue_piece(W, ld, pl2, x0, is_n, 2 * (i - T / 2) + 1); }
+  };
+  auto zload_piece = [&](int kb, int j, vec8 (&dst)[2][NPL]) {          // j = b * NPL + q
+    const int b = j / NPL, q = j % NPL;
+    dst[b][q] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(zoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u), 0, 0));
+  };
+
+  // one k-slab stage out of ring slot `ring`: X[ht] += W[ht] . (b0 | b1).  sideA(i): the stage's own piece of side work
+  // for chunk A of tile i; next_n: image kind of the following stage; (W2, ld2, pl22, x02, n2): the stage after that
+  auto kslab_stage = [&](f32x4 (&X)[T][2], const vec8 (&b0)[NPL], const vec8 (&b1)[NPL], auto sideA, bool next_n,
+                         const char* W2, unsigned ld2, unsigned pl22, unsigned x02, bool n2) {
+    const int rn = next_ring(ring);
+#pragma unroll
+    for (int ht = 0; ht < T; ++ht) {
+      const float* nx = (ht + AH < T) ? tile_ptr(ring, ht + AH, false) : tile_ptr(rn, ht + AH - T, next_n);
+      W32_HALF_A(ht, nx, X[ht][0], X[ht][1], b0, b1);
+      sideA(ht);
+      pins(NMA);
+      fence();
+      W32_HALF_B(ht, X[ht][0], X[ht][1], b0, b1);
+      stage_stores(ht, rn, next_n);
+      stage_loads(ht, W2, ld2, pl22, x02, n2);
+      pins(NMB);
+      fence();
+      if (ht == T / 2 - 1) mid_barrier();
+    }
+    ring = rn;
+  };
+
+  // ================= phase 1: X1[h][row] += W_in[h][k] * z[row][k] over the conditioning blocks ============
+  // stage s: next stage's kind and the weights of stage s + 2 are runtime facts near the end of the phase; the operand
+  // planes of slab s + 1 are loaded under tiles 1 .. 2 NPL (behind the first staging stores: those wait for the staged
+  // weights with a conservative vmcnt(0) at the head of a loop body, which must not cover a load issued a moment ago)
+  auto p1_stage = [&](int s, const vec8 (&zc)[2][NPL], vec8 (&zo)[2][NPL]) {
+    const bool next_n = A1N && (s + 1 >= p.nk_p);
+    const bool beyond = s + 2 >= p.nk_p;                         // stage s + 2 belongs to the next phase
+    const unsigned j = (unsigned)(s + 2 - p.nk_p);               // ... as its stage j (0 or 1)
+    const char* W = beyond ? wp_a1 : wp_in;
+    const unsigned ld = beyond ? ld_a1 : ld_in, pl2 = beyond ? pl2_a1 : pl2_in;
+    const unsigned x0 = beyond ? 32u * (A1N ? min(j, (unsigned)p.nk_t - 1u) : j) : 32u * (unsigned)(s + 2);
+    const int kbn = p.kb_p0 + min(s + 1, p.nk_p - 1);
+    kslab_stage(X1, zc[0], zc[1], [&](int i) { if (i >= 1 && i <= 2 * NPL) zload_piece(kbn, i - 1, zo); }, next_n,
+                W, ld, pl2, x0, A1N && beyond);
+  };
+  for (int s = 0; s < p.nk_p; s += 2) {
+    p1_stage(s, zp, zn);
+    if (s + 1 < p.nk_p) p1_stage(s + 1, zn, zp);
+  }
+  CSTAMP(c1);
+
+  // ================= phase 2: Xout[h2][row] += W_h[h2][h1'] * act(Xin)[h1'][row] ====================
+  // the activation and the split of the next k-step's operand ride under the current step's MFMAs, two values (one
+  // dword of every plane) per chunk: piece k = 4 b + jj covers slots 2 jj, 2 jj + 1 of batch tile b
+  auto act_split_piece = [&](f32x4 (&X)[T][2], int ks, int k, vec8 (&o)[2][NPL]) {
+    const int b = k >> 2, j = 2 * (k & 3);
+    split_pair(act1(X[2 * ks + (j >> 2)][b][j & 3]), act1(X[2 * ks + (j >> 2)][b][(j & 3) + 1]), j, o[b]);
+  };
+  auto hidden_layer = [&](f32x4 (&Xin)[T][2], f32x4 (&Xout)[T][2], auto layer_tag) {
+    constexpr int L = decltype(layer_tag)::value;          // hidden layer index: weights W_hid[L]
+    constexpr bool MORE = (L + 2 < NH);                    // another hidden layer follows
+    vec8 xa[2][NPL], xb[2][NPL];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) act_split_piece(Xin, 0, k, xa);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bool next_n = !(ks + 1 < KS || MORE);
+      const bool own = ks + 2 < KS;
+      const char* W2 = own ? p.Whid[L] : (MORE ? p.Whid[L + 1 < 2 ? L + 1 : 1] : p.Wout);
+      const unsigned ld2 = (unsigned)((own || MORE) ? p.ld_hid : p.ld_out), pl22 = 2u * (unsigned)((own || MORE) ? p.pl_hid : p.pl_out);
+      const bool n2 = !(own || MORE);
+      const unsigned x02 = own ? 32u * (ks + 2) : (n2 ? 32u * (unsigned)min(ks + 2 - KS, p.nk_t - 1) : 32u * (ks + 2 - KS));
+      if (ks & 1) kslab_stage(Xout, xb[0], xb[1], [&](int i) { if (ks + 1 < KS && i >= 2 && i < 10) act_split_piece(Xin, ks + 1, i - 2, xa); }, next_n, W2, ld2, pl22, x02, n2);
+      else        kslab_stage(Xout, xa[0], xa[1], [&](int i) { if (ks + 1 < KS && i >= 2 && i < 10) act_split_piece(Xin, ks + 1, i - 2, xb); }, next_n, W2, ld2, pl22, x02, n2);
+    }
+  };
+  if (NH >= 2) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) { X2[t][0] = *reinterpret_cast<const f32x4*>(p.b_hid[0] + t * 16 + 4 * lg); X2[t][1] = X2[t][0]; }
+    hidden_layer(X1, X2, CpInt<0>());
+  }
+  if (NH >= 3) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) { X1[t][0] = *reinterpret_cast<const f32x4*>(p.b_hid[1] + t * 16 + 4 * lg); X1[t][1] = X1[t][0]; }
+    hidden_layer(X2, X1, CpInt<1>());
+  }
+  CSTAMP(c2);
+
+  // ================= phase 3: z_T[row][n] += sign * (b_out[n] + sum_h X[h][row] W_out[n][h']) on the transformed blocks =====
+  auto output_layer = [&](f32x4 (&X)[T][2]) {
+    vec8 xp[KS][2][NPL];
+    // two sets that alternate between "n-tile being computed" and "finished n-tile whose epilogue is due"
+    vec8 rA[2][NPL], rB[2][NPL];            // residual planes
+    f32x4 bA[2], bB[2];                     // output bias slices
+    f32x4 aA[2][2], aB[2][2];               // accumulators [u][batch tile]
+    // epilogue of a finished n-tile (residual from the planes, update, split, store in place -- all lane-local) in pieces
+    // that ride in the chunks of the following stage: value v = 8 b + 4 u + e in chunk A of tile v; the split of the
+    // pair (v - 1, v) in chunk B of odd tiles; a batch tile's three plane stores behind its last pair (tiles 7, 15)
+    float ev[8];                            // (one batch tile at a time: tile b's stores are issued before tile b + 1 starts)
+    vec8 eo[NPL];
+    auto epi_value = [&](int v, const f32x4 (&a)[2][2], const vec8 (&r)[2][NPL], const f32x4 (&bb)[2]) {
+      const int b = v >> 3, u = (v >> 2) & 1, e = v & 3;
+      float rr = (float)r[b][0][4 * u + e] + (float)r[b][1][4 * u + e];
+      if (NPL == 3) rr = rr + (float)r[b][NPL - 1][4 * u + e];
+      ev[4 * u + e] = rr + p.sign * (a[u][b][e] + bb[u][e]);
+      guard1(ev[4 * u + e]);
+    };
+    auto epi_pair = [&](int nt, int v) {              // v odd: values v - 1, v
+      const int b = v >> 3, j = (v & 7) - 1;
+      split_pair(ev[j], ev[j + 1], j, eo);
+      if ((v & 7) == 7) store_zblk(p.kb_t0 + nt, b, eo);
+    };
+    auto epilogue = [&](int nt, const f32x4 (&a)[2][2], const vec8 (&r)[2][NPL], const f32x4 (&bb)[2]) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { epi_value(v, a, r, bb); if (v & 1) epi_pair(nt, v); }
+    };
+    // the operand planes of k-step ks (FIRST n-tile only): piece k = 4 b + jj as in phase 2
+    auto xp_piece = [&](int ks, int k) {
+      const int b = k >> 2, j = 2 * (k & 3);
+      split_pair(act1(X[2 * ks + (j >> 2)][b][j & 3]), act1(X[2 * ks + (j >> 2)][b][(j & 3) + 1]), j, xp[ks][b]);
+    };
+    // one n-tile stage
+    auto ntile_stage = [&](int nt, auto first_tag, f32x4 (&acc)[2][2], vec8 (&rnew)[2][NPL], f32x4 (&bnew)[2],
+                           const f32x4 (&accp)[2][2], const vec8 (&rcur)[2][NPL], const f32x4 (&bcur)[2]) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+      const int rn = next_ring(ring);
+      const unsigned x02 = 32u * (unsigned)min(nt + 2, p.nk_t - 1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { acc[u][0] = zero4; acc[u][1] = zero4; }
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const int ks = i >> 1, u = i & 1;
+        const float* nx = (i + AH < T) ? tile_ptr(ring, i + AH, true) : tile_ptr(rn, i + AH - T, true);
+        W32_HALF_A(i, nx, acc[u][0], acc[u][1], xp[ks][0], xp[ks][1]);
+        if (i >= 1 && i <= 2 * NPL) zload_piece(p.kb_t0 + nt, i - 1, rnew);           // this n-tile's residual planes
+        if (i == 2 * NPL + 1) {
+#pragma unroll
+          for (int uu = 0; uu < 2; ++uu) bnew[uu] = *reinterpret_cast<const f32x4*>(p.b_out + nt * 32 + 16 * uu + 4 * lg);
+        }
+        if (FIRST) { if (ks + 1 < KS) { xp_piece(ks + 1, 4 * u); xp_piece(ks + 1, 4 * u + 1); } }
+        else epi_value(i, accp, rcur, bcur);
+        pins(NMA);
+        fence();
+        W32_HALF_B(i, acc[u][0], acc[u][1], xp[ks][0], xp[ks][1]);
+        stage_stores(i, rn, true);
+        stage_loads(i, p.Wout, (unsigned)p.ld_out, 2u * (unsigned)p.pl_out, x02, true);
+        if (FIRST) { if (ks + 1 < KS) { xp_piece(ks + 1, 4 * u + 2); xp_piece(ks + 1, 4 * u + 3); } }
+        else if (i & 1) epi_pair(nt - 1, i);
+        pins(NMB);
+        fence();
+        if (i == T / 2 - 1) mid_barrier();
+      }
+      ring = rn;
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xp_piece(0, k);
+    ntile_stage(0, CpBool<true>(), aA, rA, bA, aB, rB, bB);
+    int nt = 1;
+    for (; nt < p.nk_t; nt += 2) {
+      ntile_stage(nt, CpBool<false>(), aB, rB, bB, aA, rA, bA);
+      if (nt + 1 < p.nk_t) ntile_stage(nt + 1, CpBool<false>(), aA, rA, bA, aB, rB, bB);
+    }
+    // the last n-tile sits in set A when nk_t is odd, in set B when it is even
+    if (p.nk_t & 1) epilogue(p.nk_t - 1, aA, rA, bA); else epilogue(p.nk_t - 1, aB, rB, bB);
+  };
+  if (NH == 2) output_layer(X2); else output_layer(X1);
+#undef W32_HALF_A
+#undef W32_HALF_B
+#ifdef USF_STAMP
+  CSTAMP(c3);
+  if (p.dbg && lane == 0) {
+    unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 2048) * 8 + wave) * 4;
+    o[0] = c1 - c0; o[1] = c2 - c1; o[2] = c3 - c2; o[3] = 1;
+  }
+#endif
+  // (rows beyond M load zeros, so a flag raised by such a row is a bias-only value beyond fp16's range: the pass is
+  //  voided and redone in bf16x3, which is safe)
+  if (NPL == 2 && p.range_flag && bad) atomicOr(p.range_flag, 1);
+}
+
 #ifdef USF_STAMP
 unsigned long long* g_cdbg = nullptr;
 #endif
+int g_cp_w32 = -1;                        // harness override of USF_CP_W32 (-1: environment)
 
 int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_planes: null descriptor"); return -1; }
@@ -390,7 +815,20 @@ int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
 #ifdef USF_STAMP
   a.dbg = g_cdbg;
 #endif
-  const dim3 grid((unsigned)((npanels + 7) / 8)), block(512);
+  const dim3 grid((unsigned)((npanels + 7) / 8));
+  static int w32_env = -1;
+  if (w32_env < 0) { const char* e = getenv("USF_CP_W32"); w32_env = e ? atoi(e) : 1; }   // tuning aid: 0 = the 16-row-wave kernel
+  const int w32 = g_cp_w32 >= 0 ? g_cp_w32 : w32_env;
+  if (w32 && d->n_hidden <= 2 && d->nk_p >= 2 && 2 * npl * d->w_in_plane < (1LL << 31) && 2 * npl * d->w_hid_plane < (1LL << 31) &&
+      2 * npl * d->w_out_plane < (1LL << 31) && npanels * 0 + d->z_nkb * npl * 1024 * 8 < (1LL << 31)) {
+    const dim3 block(256);
+#define USF_CPW(NPL_, NH_) hipLaunchKernelGGL((coupling_planes_w32_kernel<NPL_, NH_>), grid, block, 0, stream, a)
+    if (npl == 2) { if (d->n_hidden == 1) USF_CPW(2, 1); else USF_CPW(2, 2); }
+    else { if (d->n_hidden == 1) USF_CPW(3, 1); else USF_CPW(3, 2); }
+#undef USF_CPW
+    return check_launch("usf_coupling_planes");
+  }
+  const dim3 block(512);
 #define USF_CPL(NPL_, NH_) hipLaunchKernelGGL((coupling_planes_kernel<NPL_, NH_>), grid, block, 0, stream, a)
   if (npl == 2) {
     switch (d->n_hidden) { case 1: USF_CPL(2, 1); break; case 2: USF_CPL(2, 2); break; default: USF_CPL(2, 3); break; }

@@ -29,7 +29,22 @@ namespace usf {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#define USF_F16_GUARD 65000.0f      // |x| at or above this (or NaN) cannot travel as fp16 planes (fp16 max = 65504)
+#define USF_F16_GUARD 65000.0f
+// cache policy of the activation stream (tuning: -DUSF_PL_NT=1 marks the operand loads / 2 the plane stores / 3 both
+// non-temporal, so that the streamed panels do not push the layer's weight planes out of the XCD's 4 MiB L2)
+#ifndef USF_PL_NT
+#define USF_PL_NT 0
+#endif
+#if USF_PL_NT & 1
+#define USF_PL_LOAD_A(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define USF_PL_LOAD_A(ptr) (*(ptr))
+#endif
+#if USF_PL_NT & 2
+#define USF_PL_STORE_C(v, ptr) __builtin_nontemporal_store(v, ptr)
+#else
+#define USF_PL_STORE_C(v, ptr) (*(ptr) = (v))
+#endif      // |x| at or above this (or NaN) cannot travel as fp16 planes (fp16 max = 65504)
 
 // NPL = 3: bf16 planes, six products per fp32 product (24 significant bits per operand, fp32's exponent range);
 // NPL = 2: fp16 planes, three products a1 w1 + (a1 w2 + a2 w1) (22 significant bits per operand; half the matrix
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
-        dst[b][q] = *reinterpret_cast<const vec8*>(p.A + (aoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u));
+        dst[b][q] = USF_PL_LOAD_A(reinterpret_cast<const vec8*>(p.A + (aoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u)));
   };
 
   // ---- weights: register-staged into the LDS ring (2-byte elements; offsets in bytes) ----
@@ -368,6 +383,14 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 
   // ---- epilogue ----
   bool bad = false;                            // fp16 planes only: range guard (see usf_gemm_planes_desc.range_flag)
+  if (p.act == USF_ACT_LEAKY_RELU) {           // wave-uniform branch: the affine layers (no activation) skip the selects
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[ft][b][j] = act_apply(acc[ft][b][j], USF_ACT_LEAKY_RELU, p.slope);
+  }
   if (F32OUT) {
     // fp32 row-major: lane (j, g) of tile (ft, b) holds features n0 + 16 ft + 4 g + (0..3) of row 16 pw[b] + j
     const bool vec_ok = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.Cf) & 15u) == 0);
@@ -378,8 +401,6 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
       for (int ft = 0; ft < FT; ++ft) {
         const int col = n0 + 16 * ft + 4 * lg;
         f32x4 v = acc[ft][b];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act, p.slope);
         if (p.post_mul) v = v * *reinterpret_cast<const f32x4*>(p.post_mul + min(col, p.wrows - 4));
         if (NPL == 2 && row < p.M && col < p.N) {
           // (an overflowed weight or activation plane upstream shows up here as inf / NaN)
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
           const size_t off = (((size_t)pw[b] * p.c_nkb + (p.c_kb0 + kbo)) * NPL) * 1024 + (size_t)lane * 16;
           float x[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = act_apply(acc[2 * t + (u >> 2)][b][u & 3], p.act, p.slope);
+          for (int u = 0; u < 8; ++u) x[u] = acc[2 * t + (u >> 2)][b][u & 3];
           if (p.R) {
             vec8 r[NPL];
 #pragma unroll
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #endif
           {
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) *reinterpret_cast<vec8*>(p.Cp + off + q * 1024) = o[q];
+            for (int q = 0; q < NPL; ++q) USF_PL_STORE_C(o[q], reinterpret_cast<vec8*>(p.Cp + off + q * 1024));
           }
         }
       }

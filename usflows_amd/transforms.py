@@ -243,7 +243,8 @@ class AffineMaskedCoupling(BaseTransform):
         self.scale_bound = scale_bound
         self.input_shape = mask.shape
         self._dev_cache = None
-        self._last = None              # (input ptr, input version, output ptr, signed log-det [B]) of the last device call
+        self._last = None              # (forward input, forward output, versions, log-det [B]) of the last device call; holds
+                                       # the tensors themselves: an address can be reused by a later allocation
         self.device_calls = 0
 
     # ---- torch formulation (CPU, autograd) ----------------------------------------------------------------------
@@ -259,12 +260,14 @@ class AffineMaskedCoupling(BaseTransform):
         return t, s
 
     def forward(self, x, context=None):
+        self._last = None
         if self._device_ok(x, context):
             return self._device(x, inverse=False)
         t, s = self._shift_logscale(x * self.mask, context)
         return x * self.mask + (1 - self.mask) * (x * torch.exp(s) + t)
 
     def backward(self, y, context=None):
+        self._last = None
         if self._device_ok(y, context):
             return self._device(y, inverse=True)
         t, s = self._shift_logscale(y * self.mask, context)
@@ -274,9 +277,12 @@ class AffineMaskedCoupling(BaseTransform):
         """[B]: sum over the transformed features of s(x * m); x is the forward-direction INPUT (the conditioning features
         are the same on both sides, so either side's tensor gives the same s)"""
         c = self._last
-        if c is not None and torch.is_tensor(x) and torch.is_tensor(y):
-            # the pair produced by the last device call: its kernel already reduced the log-det
-            if (c[0], c[2]) == (x.data_ptr(), y.data_ptr()) and c[1] == (x._version, y._version):
+        if c is not None and c[0] is x and c[1] is y and c[2] == (x._version, y._version):
+            # the very pair (by identity, unmodified since) the last device call produced: its kernel already reduced the
+            # log-det.  The value is detached, so it is never served where a gradient could be asked of it.
+            needs_grad = torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or
+                                                      any(q.requires_grad for q in self.conditioner.parameters()))
+            if not needs_grad:
                 return c[3]
         _, s = self._shift_logscale(x * self.mask, context)
         return ((1 - self.mask) * s).flatten(1).sum(-1)
@@ -345,7 +351,7 @@ class AffineMaskedCoupling(BaseTransform):
         # forward-direction log-det of the pair (forward input, forward output)
         fwd_ld = -logdet if inverse else logdet
         a, b_ = (out, x) if inverse else (x, out)
-        self._last = (a.data_ptr(), (a._version, b_._version), b_.data_ptr(), fwd_ld)
+        self._last = (a, b_, (a._version, b_._version), fwd_ld)
         return out
 
 
