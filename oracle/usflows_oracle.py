@@ -8,9 +8,9 @@ What it is: an op-for-op restatement, in plain torch-CPU tensor ops, of what the
 computes on the path named by BASELINE.json (reference = /root/reference, aai-institute/USFlows
 @2025-09-12).  It is *functional*: it consumes a reference-layout ``state_dict`` plus a small
 ``FlowSpec`` and never instantiates reference or product modules, so it cannot accidentally
-share arithmetic with either.  (The only thing it shares with the product is plain data: the
-``ModelSpec`` dataclass, the layer-order list and the synthetic-parameter generator of
-``usflows_amd/synth.py`` -- so that fixtures, oracle and device path see the same parameters.)
+share arithmetic with either.  Nothing under ``oracle/`` imports the product package: the case
+description (``FlowSpec``) and the synthetic-parameter generator are the oracle's own
+(``oracle/synth.py``; tests/test_oracle.py holds them against the product-side copies bench.py uses).
 Each function cites the reference lines it follows.
 
 Pinning: checked (a) against the reference's own known-answer tests
@@ -39,7 +39,7 @@ import torch.nn.functional as F
 # --------------------------------------------------------------------------------------
 # spec
 # --------------------------------------------------------------------------------------
-from usflows_amd.synth import ModelSpec as FlowSpec  # noqa: E402  (the plain dataclass of a case's hyper-parameters: data, no logic)
+from .synth import ModelSpec as FlowSpec  # noqa: E402  (the plain dataclass of a case's hyper-parameters: data, no logic)
 
 
 def layer_plan(spec: FlowSpec):
@@ -396,7 +396,7 @@ def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
 
 
 # --------------------------------------------------------------------------------------
-# deterministic synthetic parameters: pure data generation shared with bench.py / smoke (no flow
-# arithmetic); lives in usflows_amd/synth.py, re-exported here for the tests
+# deterministic synthetic parameters: pure data generation (no flow arithmetic), the oracle's own
+# copy (oracle/synth.py), re-exported here for the tests
 # --------------------------------------------------------------------------------------
-from usflows_amd.synth import synth_state_dict  # noqa: E402,F401
+from .synth import synth_state_dict  # noqa: E402,F401

@@ -194,3 +194,29 @@ def test_oracle_layer_plan_is_its_own_restatement_and_agrees_with_the_product():
             assert any(k.startswith(p) for p in prefixes), (name, k)
         for p in prefixes:
             assert any(k.startswith(p) for k in keys), (name, p)
+
+
+def test_oracle_owns_its_case_description_and_parameter_generator():
+    """Nothing under oracle/ imports the product package (its FlowSpec and synth_state_dict live in oracle/synth.py); the
+    product-side copies that bench.py / smoke() build their flows from (usflows_amd/synth.py) produce the same
+    parameters bit for bit, so oracle, fixtures and device path still see one model."""
+    import ast
+    import glob
+    import os
+    from usflows_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "oracle", "*.py")):
+        for node in ast.walk(ast.parse(open(path).read())):
+            mods = [a.name for a in node.names] if isinstance(node, ast.Import) else \
+                [node.module or ""] if isinstance(node, ast.ImportFrom) and node.level == 0 else []
+            assert not any(m.split(".")[0] == "usflows_amd" for m in mods), (path, mods)
+    assert orc.FlowSpec is not synth.ModelSpec and orc.synth_state_dict is not synth.synth_state_dict
+    kw = [dict(dim=6, coupling_blocks=2, hidden_dims=[8, 8]),
+          dict(dim=7, coupling_blocks=3, hidden_dims=[16, 8], householder=2, affine_conjugation=True, conditioner="DenseNN"),
+          dict(dim=9, coupling_blocks=2, hidden_dims=[12], lu_transform=2, householder=0, affine_conjugation=True,
+               conditioner="ConvNet", extra={"gating": True, "normalize_layers": True})]
+    for k in kw:
+        a = orc.synth_state_dict(orc.FlowSpec(**k), seed=17, alpha=0.2)
+        b = synth.synth_state_dict(synth.ModelSpec(**k), seed=17, alpha=0.2)
+        assert list(a) == list(b)
+        assert all(torch.equal(a[n], b[n]) for n in a), k

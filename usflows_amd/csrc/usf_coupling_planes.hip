@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     for (int nt = 0; nt < p.nk_t; ++nt, ++g) {
       const int buf = g & 1;
       issue_n(p.Wout, p.ld_out, p.pl_out, min(nt + 1, p.nk_t - 1) * 32, st);
-      f32x4 acc[2] = {zero4, zero4};
+      f32x4 acc[2] = {bo[0], bo[1]};                         // the output bias is the accumulators' starting value
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int x = 2 * ((4 * ks + lg) & 7);                 // row swizzle of chunk 4 ks + g
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
         for (int e = 0; e < 4; ++e) {
           float r = (float)res[0][4 * u + e] + (float)res[1][4 * u + e];
           if (NPL == 3) r = r + (float)res[NPL - 1][4 * u + e];
-          v[u][e] = r + p.sign * (acc[u][e] + bo[u][e]);
+          v[u][e] = r + p.sign * acc[u][e];
         }
         guard(v[u]);
       }
@@ -394,7 +394,14 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   constexpr int NST = NPL * NPP;
   constexpr int NB = 3;
   constexpr int PLF = 16 * HP;              // floats between the planes of a stage image (both image kinds)
-  constexpr int AH = 3;                     // fragments are read this many tiles ahead (four register sets)
+#ifndef USF_CPW_AH
+#define USF_CPW_AH 3
+#endif
+#ifndef USF_CPW_ABL
+#define USF_CPW_ABL 0      // tuning builds (wrong results): 1 no operand / residual loads, 2 no staging stores, 4 no weight loads,
+#endif                     // 8 no mid-stage barriers, 16 no plane stores, 32 no fragment reads, 64 no side VALU (act / split / epilogue)
+  constexpr int AH = USF_CPW_AH;            // fragments are read this many tiles ahead (tile i lives in register set i % 4)
+  static_assert(AH >= 1 && AH <= 3, "four fragment sets");
   constexpr unsigned CHB = NPL * 1024u;
   constexpr int NPR2 = (NPL == 3) ? 12 : 6; // MFMAs per tile (both batch tiles)
   __shared__ __attribute__((aligned(16))) float lds[NB * STGF];
@@ -426,6 +433,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   auto store_zblk = [&](int kb, int b, const vec8 (&src)[NPL]) {
 #pragma unroll
     for (int q = 0; q < NPL; ++q)
+      if (USF_CPW_ABL & 16) asm volatile("" :: "v"(src[q])); else
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, src[q]), zrs, (int)(zoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u), 0, 0);
   };
 
@@ -467,8 +475,10 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
     }
   };
   // staging store of piece j (= q * NPP + i) into ring slot `ring`
-  auto store_piece = [&](int ring, int j, bool is_n) {
+  auto store_piece = [&](int ring, int j, bool is_n) {     // (ring < 0: slot -ring - 1, exempt from the ablation switch)
     const int i = j % NPP, q = j / NPP;
+    if ((USF_CPW_ABL & 2) && ring >= 0) { asm volatile("" :: "v"(st[j])); return; }
+    if (ring < 0) ring = -ring - 1;
     *reinterpret_cast<f32x4*>(lds + ring * STGF + q * PLF + (is_n ? ndst[i] : kdst[i])) = st[j];
   };
   // fragment addresses: k-slab image tile ht: kfr + 64 ht; n-tile image tile 2 ks + u: nfr[ks & 1] + 512 ks + 64 u
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   };
   auto mid_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    if (!(USF_CPW_ABL & 8)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -554,13 +564,15 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   issue_w(wp_in, ld_in, pl2_in, 0, false);
   load_zblk(p.kb_p0, zp);
 #pragma unroll
-  for (int j = 0; j < NST; ++j) store_piece(0, j, false);
+  for (int j = 0; j < NST; ++j) {
+    store_piece(-1, j, false);
+    if (USF_CPW_ABL & 6) { store_piece(-2, j, false); store_piece(-3, j, false); }       // ablation builds: sane bytes in every slot
+  }
   issue_w(wp_in, ld_in, pl2_in, 32, false);  // (nk_p >= 2: the host routes narrower layers to the 16-row kernel)
   __syncthreads();
-  vec8 f0[NPL], f1[NPL], f2[NPL], f3[NPL];    // weight fragments: tile i lives in set i % 4; sets 0..2 hold tiles 0..2 on stage entry
-  frag(tile_ptr(0, 0, false), f0);
-  frag(tile_ptr(0, 1, false), f1);
-  frag(tile_ptr(0, 2, false), f2);
+  vec8 fr[4][NPL];                            // weight fragments: tile i lives in set i % 4; tiles 0 .. AH - 1 are in flight on stage entry
+#pragma unroll
+  for (int i = 0; i < AH; ++i) frag(tile_ptr(0, i, false), fr[i]);
   int ring = 0;
 
   // (MFMAs first in program order: at the head of a loop body the compiler waits for EVERY outstanding LDS operation
@@ -568,18 +580,10 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   //  of that wait would expose its latency in every stage.)
 #define W32_HALF_A(I_, NXPTR_, A0_, A1_, B0_, B1_)                                                \
   do {                                                                                            \
-    if ((I_) % 4 == 0)      { mm2a(A0_, A1_, f0, B0_, B1_); frag(NXPTR_, f3); }                   \
-    else if ((I_) % 4 == 1) { mm2a(A0_, A1_, f1, B0_, B1_); frag(NXPTR_, f0); }                   \
-    else if ((I_) % 4 == 2) { mm2a(A0_, A1_, f2, B0_, B1_); frag(NXPTR_, f1); }                   \
-    else                    { mm2a(A0_, A1_, f3, B0_, B1_); frag(NXPTR_, f2); }                   \
+    mm2a(A0_, A1_, fr[(I_) % 4], B0_, B1_);                                                       \
+    if (!(USF_CPW_ABL & 32)) frag(NXPTR_, fr[((I_) + AH) % 4]);                                   \
   } while (0)
-#define W32_HALF_B(I_, A0_, A1_, B0_, B1_)                                                        \
-  do {                                                                                            \
-    if ((I_) % 4 == 0)      mm2b(A0_, A1_, f0, B0_, B1_);                                         \
-    else if ((I_) % 4 == 1) mm2b(A0_, A1_, f1, B0_, B1_);                                         \
-    else if ((I_) % 4 == 2) mm2b(A0_, A1_, f2, B0_, B1_);                                         \
-    else                    mm2b(A0_, A1_, f3, B0_, B1_);                                         \
-  } while (0)
+#define W32_HALF_B(I_, A0_, A1_, B0_, B1_) mm2b(A0_, A1_, fr[(I_) % 4], B0_, B1_)
   // side work every stage carries in its B chunks: the staging stores of the next stage in front of the barrier (IN
   // PROGRAM ORDER between the fragment reads: the ring slots are runtime values, LDS accesses keep their order) ...
   auto stage_stores = [&](int i, int rn, bool next_n) {
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   // ... and the global loads of the stage after that behind it (pieces 2 (i - 8), 2 (i - 8) + 1 in tile i = 8 .. 13)
   auto issue_piece = [&](const char* W, unsigned ld, unsigned pl2, unsigned x0, bool is_n, int j) {
     const int i = j % NPP, q = j / NPP;
+    if (USF_CPW_ABL & 4) return;
     const unsigned cpart = is_n ? 8u * (unsigned)(tid & 31) : x0 + 8u * (unsigned)(tid & 3);
     const unsigned r = is_n ? x0 + (unsigned)((tid >> 5) + 8 * i) : (unsigned)((tid >> 2) + 64 * i);
     st[j] = *reinterpret_cast<const f32x4*>(W + (size_t)((unsigned)q * pl2 + 2u * (r * ld + cpart)));
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   };
   auto zload_piece = [&](int kb, int j, vec8 (&dst)[2][NPL]) {          // j = b * NPL + q
     const int b = j / NPL, q = j % NPL;
+    if (USF_CPW_ABL & 1) { dst[b][q] = zp[b][q]; return; }
     dst[b][q] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(zoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u), 0, 0));
   };
 
@@ -649,6 +655,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   // dword of every plane) per chunk: piece k = 4 b + jj covers slots 2 jj, 2 jj + 1 of batch tile b
   auto act_split_piece = [&](f32x4 (&X)[T][2], int ks, int k, vec8 (&o)[2][NPL]) {
     const int b = k >> 2, j = 2 * (k & 3);
+    if ((USF_CPW_ABL & 64) && ks > 0) { if (k == 0) { for (int bb = 0; bb < 2; ++bb) for (int q = 0; q < NPL; ++q) o[bb][q] = zp[bb][q]; } return; }
     split_pair(act1(X[2 * ks + (j >> 2)][b][j & 3]), act1(X[2 * ks + (j >> 2)][b][(j & 3) + 1]), j, o[b]);
   };
   auto hidden_layer = [&](f32x4 (&Xin)[T][2], f32x4 (&Xout)[T][2], auto layer_tag) {
@@ -684,30 +691,40 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   // ================= phase 3: z_T[row][n] += sign * (b_out[n] + sum_h X[h][row] W_out[n][h']) on the transformed blocks =====
   auto output_layer = [&](f32x4 (&X)[T][2]) {
     vec8 xp[KS][2][NPL];
-    // two sets that alternate between "n-tile being computed" and "finished n-tile whose epilogue is due"
-    vec8 rA[2][NPL], rB[2][NPL];            // residual planes
-    f32x4 bA[2], bB[2];                     // output bias slices
-    f32x4 aA[2][2], aB[2][2];               // accumulators [u][batch tile]
+    // Register plan (the stage bodies of this phase are the tightest: 192 registers of operand planes): ONE set of
+    // residual planes with staggered lifetimes -- batch tile 0's planes of n-tile nt are loaded under tiles 8..10 of stage nt
+    // (its epilogue reads them under tiles 0..7 of stage nt + 1), batch tile 1's planes of n-tile nt - 1 under tiles 0..2 of
+    // stage nt (read under tiles 8..15 of the same stage) -- and the output bias as the accumulators' starting value.
+    vec8 r0[NPL], r1[NPL];                  // residual planes: batch tile 0 / 1
+    f32x4 bn[2];                            // bias slices of the NEXT n-tile
+    f32x4 aA[2][2], aB[2][2];               // accumulators [u][batch tile]: the two sets alternate between "being computed" and "finished"
+    auto load_bias = [&](int nt) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) bn[u] = *reinterpret_cast<const f32x4*>(p.b_out + min(nt, p.nk_t - 1) * 32 + 16 * u + 4 * lg);
+    };
+    auto rload = [&](int nt, int b, int q, vec8 (&dst)[NPL]) {
+      if (USF_CPW_ABL & 1) { dst[q] = zp[b][q]; return; }
+      dst[q] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(zoff[b] + (unsigned)(p.kb_t0 + nt) * CHB + (unsigned)q * 1024u), 0, 0));
+    };
     // epilogue of a finished n-tile (residual from the planes, update, split, store in place -- all lane-local) in pieces
     // that ride in the chunks of the following stage: value v = 8 b + 4 u + e in chunk A of tile v; the split of the
     // pair (v - 1, v) in chunk B of odd tiles; a batch tile's three plane stores behind its last pair (tiles 7, 15)
     float ev[8];                            // (one batch tile at a time: tile b's stores are issued before tile b + 1 starts)
     vec8 eo[NPL];
-    auto epi_value = [&](int v, const f32x4 (&a)[2][2], const vec8 (&r)[2][NPL], const f32x4 (&bb)[2]) {
+    auto epi_value = [&](int v, const f32x4 (&a)[2][2]) {
       const int b = v >> 3, u = (v >> 2) & 1, e = v & 3;
-      float rr = (float)r[b][0][4 * u + e] + (float)r[b][1][4 * u + e];
-      if (NPL == 3) rr = rr + (float)r[b][NPL - 1][4 * u + e];
-      ev[4 * u + e] = rr + p.sign * (a[u][b][e] + bb[u][e]);
+      if (USF_CPW_ABL & 64) { ev[4 * u + e] = a[u][b][e]; return; }
+      const vec8 (&r)[NPL] = b ? r1 : r0;
+      float rr = (float)r[0][4 * u + e] + (float)r[1][4 * u + e];
+      if (NPL == 3) rr = rr + (float)r[NPL - 1][4 * u + e];
+      ev[4 * u + e] = rr + p.sign * a[u][b][e];
       guard1(ev[4 * u + e]);
     };
     auto epi_pair = [&](int nt, int v) {              // v odd: values v - 1, v
       const int b = v >> 3, j = (v & 7) - 1;
+      if (USF_CPW_ABL & 64) { if ((v & 7) == 7) { for (int q = 0; q < NPL; ++q) eo[q] = zp[b][q]; eo[0][0] = (decltype(eo[0][0] + eo[0][0]))ev[0]; store_zblk(p.kb_t0 + nt, b, eo); } return; }
       split_pair(ev[j], ev[j + 1], j, eo);
       if ((v & 7) == 7) store_zblk(p.kb_t0 + nt, b, eo);
-    };
-    auto epilogue = [&](int nt, const f32x4 (&a)[2][2], const vec8 (&r)[2][NPL], const f32x4 (&bb)[2]) {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) { epi_value(v, a, r, bb); if (v & 1) epi_pair(nt, v); }
     };
     // the operand planes of k-step ks (FIRST n-tile only): piece k = 4 b + jj as in phase 2
     auto xp_piece = [&](int ks, int k) {
@@ -715,25 +732,22 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
       split_pair(act1(X[2 * ks + (j >> 2)][b][j & 3]), act1(X[2 * ks + (j >> 2)][b][(j & 3) + 1]), j, xp[ks][b]);
     };
     // one n-tile stage
-    auto ntile_stage = [&](int nt, auto first_tag, f32x4 (&acc)[2][2], vec8 (&rnew)[2][NPL], f32x4 (&bnew)[2],
-                           const f32x4 (&accp)[2][2], const vec8 (&rcur)[2][NPL], const f32x4 (&bcur)[2]) {
+    auto ntile_stage = [&](int nt, auto first_tag, f32x4 (&acc)[2][2], const f32x4 (&accp)[2][2]) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const int rn = next_ring(ring);
       const unsigned x02 = 32u * (unsigned)min(nt + 2, p.nk_t - 1);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) { acc[u][0] = zero4; acc[u][1] = zero4; }
+      for (int u = 0; u < 2; ++u) { acc[u][0] = bn[u]; acc[u][1] = bn[u]; }
 #pragma unroll
       for (int i = 0; i < T; ++i) {
         const int ks = i >> 1, u = i & 1;
         const float* nx = (i + AH < T) ? tile_ptr(ring, i + AH, true) : tile_ptr(rn, i + AH - T, true);
         W32_HALF_A(i, nx, acc[u][0], acc[u][1], xp[ks][0], xp[ks][1]);
-        if (i >= 1 && i <= 2 * NPL) zload_piece(p.kb_t0 + nt, i - 1, rnew);           // this n-tile's residual planes
-        if (i == 2 * NPL + 1) {
-#pragma unroll
-          for (int uu = 0; uu < 2; ++uu) bnew[uu] = *reinterpret_cast<const f32x4*>(p.b_out + nt * 32 + 16 * uu + 4 * lg);
-        }
+        if (!FIRST && i < NPL) rload(nt - 1, 1, i, r1);                 // batch tile 1 of the finished n-tile
         if (FIRST) { if (ks + 1 < KS) { xp_piece(ks + 1, 4 * u); xp_piece(ks + 1, 4 * u + 1); } }
-        else epi_value(i, accp, rcur, bcur);
+        else epi_value(i, accp);
+        if (i >= T / 2 && i < T / 2 + NPL) rload(nt, 0, i - T / 2, r0); // batch tile 0 of this n-tile (r0 is free: read under tiles 0..7)
+        if (i == T - 3) load_bias(nt + 1);
         pins(NMA);
         fence();
         W32_HALF_B(i, acc[u][0], acc[u][1], xp[ks][0], xp[ks][1]);
@@ -747,16 +761,23 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
       }
       ring = rn;
     };
+    load_bias(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) xp_piece(0, k);
-    ntile_stage(0, CpBool<true>(), aA, rA, bA, aB, rB, bB);
+    ntile_stage(0, CpBool<true>(), aA, aB);
     int nt = 1;
     for (; nt < p.nk_t; nt += 2) {
-      ntile_stage(nt, CpBool<false>(), aB, rB, bB, aA, rA, bA);
-      if (nt + 1 < p.nk_t) ntile_stage(nt + 1, CpBool<false>(), aA, rA, bA, aB, rB, bB);
+      ntile_stage(nt, CpBool<false>(), aB, aA);
+      if (nt + 1 < p.nk_t) ntile_stage(nt + 1, CpBool<false>(), aA, aB);
     }
-    // the last n-tile sits in set A when nk_t is odd, in set B when it is even
-    if (p.nk_t & 1) epilogue(p.nk_t - 1, aA, rA, bA); else epilogue(p.nk_t - 1, aB, rB, bB);
+    // the last n-tile: batch tile 1's residual planes are still to be fetched; it sits in set A when nk_t is odd
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) rload(p.nk_t - 1, 1, q, r1);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      if (p.nk_t & 1) epi_value(v, aA); else epi_value(v, aB);
+      if (v & 1) epi_pair(p.nk_t - 1, v);
+    }
   };
   if (NH == 2) output_layer(X2); else output_layer(X1);
 #undef W32_HALF_A
