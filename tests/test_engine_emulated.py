@@ -74,6 +74,38 @@ def test_merged_affine_runs_reproduce_golden(name, planes):
     assert counts[True] < counts[False], counts
 
 
+@pytest.mark.parametrize("name", [n for n in SMALL if "conj" in n])
+def test_guarded_merge_is_the_default_and_never_costs_accuracy(name):
+    """merge_affine = "auto" (the default): runs of consecutive affine maps are composed only in flows where an end-to-end
+    probe (64 rows through the composed and through the layer-by-layer plan, FlowEngine.resolve_merge) finds the two
+    plans in agreement to 2e-6.  On every conjugated golden case the default plan is as close to the reference's fp64
+    run as the layer-by-layer plan (within 1.5 x, or the 2e-6 floor); on the well-conditioned cases the probe accepts
+    (fewer GEMM ops)."""
+    from usflows_amd import _ext
+    spec, sd, a = load_case(name)
+    if a.get("context") is not None or spec.soft_training:
+        pytest.skip("context flows: covered by the unconditional variant")
+    rels, counts, logs = {}, {}, {}
+    for merge in (False, "auto"):
+        flow = build_flow(spec, sd)
+        eng = FlowEngine(flow.layers)
+        assert eng.merge_affine == "auto"                      # the constructor's default
+        eng.merge_affine = merge
+        emulator.engine_transform(eng, a["x"][:1], "backward", None, True)         # (sets the emulation's engine switches)
+        if merge == "auto":       # what FlowEngine._run_guarded does in front of the first pass, with the CPU interpreter as runner
+            eng.resolve_merge("backward", a["x"], runner=lambda plan, xs, out: emulator.run_plan(eng, plan, xs, out, None))
+        zl, logdet = emulator.engine_latent(eng, a["x"], None, True)
+        lp = orc.base_log_prob(spec, zl.double(), orc.to_dtype(sd, torch.float64)) + logdet
+        rels[merge] = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
+        counts[merge] = min(sum(1 for j in range(p["n"]) if p["arr"][j].kind == _ext.OP_LINEAR and p["arr"][j].u.linear.M != 0)
+                            for p in eng._plans.values())
+        logs[merge] = list(eng.merge_guard_log)
+    assert rels["auto"] <= max(1.5 * rels[False], 2e-6), (rels, logs["auto"])
+    assert logs["auto"], "the probe never ran"
+    if not name.startswith("init_"):
+        assert all(ok for ok, _ in logs["auto"]) and counts["auto"] < counts[False], (counts, logs["auto"])
+
+
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", SMALL)

@@ -68,7 +68,16 @@ int main(int argc, char** argv) {
     std::vector<unsigned short> a(zb / 2), b(zb / 2), c(zb / 2);
     hipMemcpy(a.data(), z, zb, hipMemcpyDeviceToHost); hipMemcpy(b.data(), z2, zb, hipMemcpyDeviceToHost); hipMemcpy(c.data(), z0, zb, hipMemcpyDeviceToHost);
     size_t diff = 0, changed = 0, first = (size_t)-1;
-    for (size_t i = 0; i < a.size(); ++i) { if (a[i] != b[i]) { ++diff; if (first == (size_t)-1) first = i; } if (a[i] != c[i]) ++changed; }
+    size_t lastchunk = (size_t)-1; int shown = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+      if (a[i] != b[i]) {
+        ++diff; if (first == (size_t)-1) first = i;
+        const size_t ch = i / (NPL * 512);
+        if (ch != lastchunk && shown < 12) { printf("   differs: panel %zu block %zu plane %zu lane %zu slot %zu: 16-row %04x, 32-row %04x, before %04x\n", ch / nkb, ch % nkb, (i % (NPL * 512)) / 512, (i % 512) / 8, i % 8, a[i], b[i], c[i]); ++shown; }
+        lastchunk = ch;
+      }
+      if (a[i] != c[i]) ++changed;
+    }
     printf("16-row kernel vs 32-row kernel: %zu of %zu plane elements differ (first at %zd: panel %zd block %zd); the layer changed %zu elements -> %s\n",
            diff, a.size(), (ssize_t)first, first == (size_t)-1 ? -1 : (ssize_t)(first / (nkb * NPL * 512)), first == (size_t)-1 ? -1 : (ssize_t)((first / (NPL * 512)) % nkb), changed, diff == 0 && changed > 0 ? "OK" : "FAIL");
     hipMemcpy(z, z0, zb, hipMemcpyDeviceToDevice); d.z = z; hipFree(z2); hipFree(z0);

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
         for (int e = 0; e < 4; ++e) {
           float r = (float)res[0][4 * u + e] + (float)res[1][4 * u + e];
           if (NPL == 3) r = r + (float)res[NPL - 1][4 * u + e];
-          v[u][e] = r + p.sign * acc[u][e];
+          v[u][e] = __builtin_fmaf(p.sign, acc[u][e], r);      // (sign = +-1: the product is exact, one rounding either way)
         }
         guard(v[u]);
       }
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
       const vec8 (&r)[NPL] = b ? r1 : r0;
       float rr = (float)r[0][4 * u + e] + (float)r[1][4 * u + e];
       if (NPL == 3) rr = rr + (float)r[NPL - 1][4 * u + e];
-      ev[4 * u + e] = rr + p.sign * a[u][b][e];
+      ev[4 * u + e] = __builtin_fmaf(p.sign, a[u][b][e], rr);
       guard1(ev[4 * u + e]);
     };
     auto epi_pair = [&](int nt, int v) {              // v odd: values v - 1, v

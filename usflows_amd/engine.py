@@ -261,12 +261,16 @@ class FlowEngine:
         self._pack_key = None
         self._plans: Dict[tuple, dict] = {}
         self._ws: Dict[tuple, Dict[str, torch.Tensor]] = {}
-        # opt-in (USFLOWS_AMD_MERGE_AFFINE=1 / engine.merge_affine = True): consecutive affine
-        # steps of an inference plan run as ONE composed map (_MergedAffine) -- with affine_conjugation that halves the
-        # D x D GEMMs.  Off by default: the reference applies the maps one by one in fp32, and on badly conditioned
-        # (default-initialised) blocks the composite rounds differently -- golden init_d7_k2_hh1_conj_laplace: relative
-        # log_prob error 4e-6 one by one, 1.0e-5 composed (well-conditioned flows: unchanged, 5e-8 .. 1.5e-7)
-        self.merge_affine = os.environ.get("USFLOWS_AMD_MERGE_AFFINE", "0") == "1"
+        # Consecutive affine steps of an inference plan run as ONE composed map (_MergedAffine) -- with affine_conjugation
+        # (every live configuration of the reference) that halves the D x D GEMMs.  The reference applies the maps one
+        # by one in fp32, and on badly conditioned (default-initialised) blocks the composite rounds differently -- golden
+        # init_d7_k2_hh1_conj_laplace: relative log_prob error 4e-6 one by one, 1.0e-5 composed (well-conditioned
+        # flows: unchanged, 5e-8 .. 1.5e-7).  merge_affine = "auto" (default): every run of layers is composed only if a
+        # pack-time probe says the composite is as accurate as the run applied layer by layer (_merge_guard); True
+        # (USFLOWS_AMD_MERGE_AFFINE=1): always; False (=0): never.
+        _m = os.environ.get("USFLOWS_AMD_MERGE_AFFINE", "auto")
+        self.merge_affine = True if _m == "1" else (False if _m == "0" else "auto")
+        self.merge_guard_log: List[tuple] = []   # (accepted, max deviation composed vs layer-by-layer) per probe
         self._virtual: List[_Step] = []          # merged steps, addressed as step index len(self.steps) + n
         self._virtual_ix: Dict[tuple, int] = {}
         self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
@@ -417,6 +421,9 @@ class FlowEngine:
                 _ext.replay(pk["tape"])
                 pk["ladj_total"] = self._ladj_total(pk)
             self._pack_key = key
+            pk["replays"] = pk.get("replays", 0) + 1
+            if pk["replays"] % 256 == 0:
+                pk.pop("auto_merge", None)          # training moves the parameters: probe the composed plans again
             return pk
         pk = {"affine": {}, "coupling": {}, "scale": {}, "mats": {}, "vecs": {}, "has_factors": self.keep_factors,
               "tape": _ext.Tape(), "ptr_key": self._ptr_key(device), "ladj_terms": []}
@@ -729,9 +736,55 @@ class FlowEngine:
     def _step(self, i: int) -> _Step:
         return self.steps[i] if i < len(self.steps) else self._virtual[i - len(self.steps)]
 
+    def _merge_on(self, direction: str, device=None) -> bool:
+        """are runs of consecutive affine maps composed in this direction's inference plans right now?"""
+        if self.merge_affine != "auto":
+            return bool(self.merge_affine)
+        pk = self._pack
+        return bool(pk is not None and pk.get("auto_merge", {}).get(direction, False))
+
+    def resolve_merge(self, direction: str, x: torch.Tensor, runner=None) -> bool:
+        """merge_affine == "auto": decide, once per pack and direction, whether this flow's runs of consecutive affine
+        maps may be composed.  The probe is end to end -- up to 64 rows of the caller's own batch through the plan with
+        composed runs and through the layer-by-layer plan: the composite itself is as accurate as its parts (both are
+        rounded once from fp64 factors), what differs between flows is how far ANY change of rounding pattern is
+        amplified downstream.  Where the two results agree to 2e-6 of the largest output the flow is well conditioned
+        and the composed plan (half the D x D GEMMs of a conjugated flow) is indistinguishable from the reference's
+        arithmetic at the 1e-5 parity bar; where they do not (default-initialised, exploding flows: the reference's
+        own fp32 run is 2 - 7e-6 from its fp64 run there) the layers keep their own launches.  Costs two 64-row passes
+        and one scalar read-back at the first inference call after a (re)pack; re-probed every 256 in-place refreshes.
+        runner(plan, x, out): how a plan is executed (tests interpret the op list on the CPU)."""
+        if self.merge_affine != "auto":
+            return bool(self.merge_affine)
+        pk = self.pack(x.device)
+        state = pk.setdefault("auto_merge", {})
+        if direction in state:
+            return state[direction]
+        has_run = any(a.startswith("affine") and b_.startswith("affine")
+                      for (a, _), (b_, _) in zip(self._primitive_ops(direction)[:-1], self._primitive_ops(direction)[1:]))
+        if not has_run or x.shape[0] == 0:
+            state[direction] = False
+            return False
+        run = runner if runner is not None else (lambda plan, xs, out: self._run(plan, xs, out, None))
+        n = min(64, x.shape[0])
+        xs = x[:n].contiguous()
+        outs = []
+        with torch.no_grad():
+            for mode in (False, True):
+                state[direction] = mode
+                out = torch.empty(n, self.D, dtype=torch.float32, device=x.device)
+                run(self._plan(direction, n, x.device, False, "user"), xs, out)
+                outs.append(out.double())
+            d = ((outs[1] - outs[0]).abs().max() / outs[0].abs().max().clamp_min(1e-30)).item()
+        ok = bool(d <= 2e-6)                              # (NaN / inf compare False)
+        self.merge_guard_log.append((ok, d))
+        state[direction] = ok
+        return ok
+
     def _primitive_ops(self, direction: str, merge: bool = False):
         """[(prim, step_index)] with prim in scale_mul/scale_div/affine_fwd/affine_bwd/coupling_fwd/coupling_bwd;
-        merge: runs of consecutive affine steps become one ``affine_fwd`` on a ``_MergedAffine`` (``_step(index)``)"""
+        merge: runs of consecutive affine steps become one ``affine_fwd`` on a ``_MergedAffine`` (``_step(index)``) when
+        merging is on for this direction (``_merge_on``: merge_affine True, or "auto" and the probe accepted)"""
         seq = list(enumerate(self.steps))
         if direction == "backward":
             seq = seq[::-1]
@@ -744,7 +797,7 @@ class FlowEngine:
                 prims.append(("affine_fwd" if fwd else "affine_bwd", i))
             else:
                 prims.append(("coupling_fwd" if fwd else "coupling_bwd", i))
-        if not (merge and self.merge_affine):
+        if not (merge and self._merge_on(direction)):
             return prims
         out, k = [], 0
         while k < len(prims):
@@ -1067,7 +1120,8 @@ class FlowEngine:
         if (train or has_ctx or not use or self._general_cond or self.gemm_mode not in ("bf16x3", "f16x2")
                 or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
-        prims = self._primitive_ops(direction, merge=True)
+        # (the structure check does not depend on which runs are merged: a merged run is an affine step like its parts)
+        prims = self._primitive_ops(direction, merge=False)
         kinds = [p_[0] for p_ in prims]
         for k_, kind in enumerate(kinds):
             if kind == "scale_div" and not (k_ == 0 and len(kinds) > 1 and kinds[1] in ("affine_bwd", "affine_fwd")):
@@ -1410,7 +1464,7 @@ class FlowEngine:
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
                train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3,
-               self.merge_affine)
+               (not train) and self._merge_on(direction))
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final, train)
@@ -1422,6 +1476,8 @@ class FlowEngine:
         the flow: fp16 planes cannot carry it) is void and is redone with bf16x3 planes.  The check reads one int32
         back from the device, i.e. it waits for the pass: only plans of >= planes_min_rows rows (milliseconds) do it."""
         B = x.shape[0]
+        if self.merge_affine == "auto" and context is None:
+            self.resolve_merge(direction, x)
         plan = self._plan(direction, B, x.device, context is not None, final)
         self._run(plan, x, out, context)
         if plan.get("planes_fmt") == _ext.PLANES_F16X2 and int(plan["ws"]["pflag"].item()) != 0:
