@@ -473,7 +473,8 @@ def main():
                       "rows_per_gpu": B, "global_rows": global_rows, "parallelism": par,
                       "fused_coupling": not args.unfused, "gemm_mode": eng.gemm_mode if on_gpu else "torch-cpu",
                       "merge_affine": (eng.merge_affine if eng.merge_affine != "auto" else
-                                       f"auto -> {eng._merge_on('backward' if mode != 'sample' else 'forward')}") if on_gpu else None},
+                                       f"auto -> {eng._merge_on('backward' if mode != 'sample' else 'forward')}; probe (accepted, element-wise, L1) "
+                                       f"{eng.merge_guard_log[-1:]}") if on_gpu else None},
            "flow_algorithmic_tflops_per_gpu": round(flow_tflops, 2),
            "flow_frac_of_f32_mfma_peak": round(flow_tflops / F32_MFMA_PEAK_TFLOPS, 4),
            "param_prep_first_call_s": round(prep_s, 3),

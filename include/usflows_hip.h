@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 19
+#define USF_ABI_VERSION 20
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -384,6 +384,12 @@ typedef struct usf_coupling_planes_desc {
   int32_t* range_flag;
 } usf_coupling_planes_desc;
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream);
+/* Which kernel serves usf_coupling_planes: 0 = 16 batch rows per wave, two waves per SIMD (the default); 1 = 32 rows per
+ * wave on the 512-register budget, one wave per SIMD (n_hidden <= 2, nk_p >= 2; other layers keep the 16-row kernel);
+ * -1 = back to the environment's choice (USF_CP_W32, default 0).  The two kernels sum every accumulator in the same order:
+ * bit-identical results in the bf16x3 format.  Returns the previous setting.  (A tuning knob: process-wide, not
+ * thread-safe against concurrent launches.) */
+int usf_coupling_planes_select(int w32);
 
 /*
  * Row pass of the vector ConvNet conditioner's blocks (networks.py:222-245 GatedMLP, :206-219 LayerNormVector, vector

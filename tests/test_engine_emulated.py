@@ -78,7 +78,7 @@ def test_merged_affine_runs_reproduce_golden(name, planes):
 def test_guarded_merge_is_the_default_and_never_costs_accuracy(name):
     """merge_affine = "auto" (the default): runs of consecutive affine maps are composed only in flows where an end-to-end
     probe (64 rows through the composed and through the layer-by-layer plan, FlowEngine.resolve_merge) finds the two
-    plans in agreement to 2e-6.  On every conjugated golden case the default plan is as close to the reference's fp64
+    plans in agreement (1e-5 element-wise, 1e-6 in the rows' L1 norms).  On every conjugated golden case the default plan is as close to the reference's fp64
     run as the layer-by-layer plan (within 1.5 x, or the 2e-6 floor); on the well-conditioned cases the probe accepts
     (fewer GEMM ops)."""
     from usflows_amd import _ext
@@ -103,7 +103,7 @@ def test_guarded_merge_is_the_default_and_never_costs_accuracy(name):
     assert rels["auto"] <= max(1.5 * rels[False], 2e-6), (rels, logs["auto"])
     assert logs["auto"], "the probe never ran"
     if not name.startswith("init_"):
-        assert all(ok for ok, _ in logs["auto"]) and counts["auto"] < counts[False], (counts, logs["auto"])
+        assert all(ok for ok, _, _ in logs["auto"]) and counts["auto"] < counts[False], (counts, logs["auto"])
 
 
 @pytest.mark.parametrize("fused", [False, True])

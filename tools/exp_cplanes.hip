@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
   d.sign = 1.f; d.slope = 0.01f; d.act = USF_ACT_LEAKY_RELU; d.format = NPL == 2 ? USF_PLANES_F16X2 : USF_PLANES_BF16X3;
   int32_t* flag; hipMalloc(&flag, 4); hipMemset(flag, 0, 4); d.range_flag = flag;
 #ifdef USF_STAMP
-  unsigned long long* dbg; hipMalloc(&dbg, 2048 * 8 * 4 * 8); hipMemset(dbg, 0, 2048 * 8 * 4 * 8); usf::g_cdbg = dbg;
+  unsigned long long* dbg; hipMalloc(&dbg, 2048 * 8 * 12 * 8); hipMemset(dbg, 0, 2048 * 8 * 12 * 8); usf::g_cdbg = dbg;
 #endif
   // ---- the two kernels on the same input must agree bit for bit (same summation order per accumulator) ----
   {
@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
   int32_t hf; hipMemcpy(&hf, flag, 4, hipMemcpyDeviceToHost);
   printf("[%s NH=%d %s] coupling on planes M=%lld: %.4f ms  %.1f TF/s fp32-equivalent (algorithmic)  range flag %d\n", NPL == 2 ? "f16x2" : "bf16x3", NH, variant ? "32-row waves" : "16-row waves", (long long)M, ms, flops / ms / 1e9, hf);
 #ifdef USF_STAMP
-  std::vector<unsigned long long> h(2048 * 8 * 4); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> h(2048 * 8 * 12); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
   double sm[3] = {0, 0, 0}; int nw = 0;
   for (size_t i = 0; i < 2048 * 8; ++i) if (h[4 * i + 3]) { for (int j = 0; j < 3; ++j) sm[j] += (double)h[4 * i + j]; ++nw; }
   const double tot = (sm[0] + sm[1] + sm[2]) / nw;
@@ -104,7 +104,12 @@ int main(int argc, char** argv) {
   printf("  waves %d: cycles per wave: phase 1 %.0f (MFMA issue of a SIMD's two waves %d), phase 2 %.0f (%d), phase 3 %.0f (%d), total %.0f -> %.1f %% matrix-pipe issue\n",
          nw, sm[0] / nw, 2 * 13 * 16 * npr * 16, sm[1] / nw, 2 * (NH - 1) * 8 * 16 * npr * 16, sm[2] / nw, 2 * 13 * 16 * npr * 16,
          tot, 100.0 * (2.0 * (13 * 16 * 2 + (NH - 1) * 8 * 16) * npr * 16) / tot);
-  hipMemset(dbg, 0, 2048 * 8 * 4 * 8);
+#if USF_STAMP >= 2
+  if (variant == 1) { double bw[3] = {0, 0, 0}, mn = 0, mx = 0; int n2 = 0;
+    for (size_t i = 0; i < 2048 * 8; ++i) if (h[4 * i + 3]) { const unsigned long long* o2 = &h[2048 * 8 * 4 + 8 * i]; for (int j = 0; j < 3; ++j) bw[j] += (double)o2[j]; mn += (double)o2[3]; mx += (double)o2[4]; ++n2; }
+    printf("  32-row waves: barrier wait per wave and phase %.0f / %.0f / %.0f cycles; barrier-to-barrier interval min %.0f max %.0f (ideal 3072)\n", bw[0] / n2, bw[1] / n2, bw[2] / n2, mn / n2, mx / n2); }
+#endif
+  hipMemset(dbg, 0, 2048 * 8 * 12 * 8);
 #endif
   }
   return 0;

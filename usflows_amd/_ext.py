@@ -17,7 +17,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 19
+USF_ABI_VERSION = 20
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -140,6 +140,7 @@ SYMBOLS = {
     "usf_gemm_planes_bf16x3": (C.c_int, [C.POINTER(GemmPlanesDesc), C.c_void_p]),
     "usf_gemm_planes_variant": (C.c_int, [C.POINTER(GemmPlanesDesc)]),
     "usf_coupling_planes": (C.c_int, [C.POINTER(CouplingPlanesDesc), C.c_void_p]),
+    "usf_coupling_planes_select": (C.c_int, [C.c_int]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),

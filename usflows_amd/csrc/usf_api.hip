@@ -41,6 +41,7 @@ int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream);
 int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream);
 int gemm_planes_variant(const usf_gemm_planes_desc* d);
 int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream);
+extern int g_cp_w32;
 int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream);
 int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
              double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
@@ -120,6 +121,7 @@ int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream) { re
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream) { return usf::gemm_planes(d, (hipStream_t)stream); }
 
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream) { return usf::coupling_planes(d, (hipStream_t)stream); }
+int usf_coupling_planes_select(int w32) { const int old = usf::g_cp_w32; usf::g_cp_w32 = w32 < 0 ? -1 : (w32 ? 1 : 0); return old; }
 int usf_gemm_planes_variant(const usf_gemm_planes_desc* d) { return usf::gemm_planes_variant(d); }
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }

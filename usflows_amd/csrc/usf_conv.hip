@@ -261,6 +261,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
   }
 }
 
+// second kernel (usf_conv_wreg.hip): 1 = launched, 0 = shape not served there, < 0 = error
+int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
+                     const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
+                     hipStream_t stream);
+
 static int odd16(int units) { return units | 1; }
 // register-staged iterations per thread for a group of S samples (the kernel holds at most 16 pixel pairs per thread)
 static int conv_stage_iters(int cin, int HW, int S) { return ((S * ((cin + 1) / 2) + 7) / 8) * ((HW + 63) / 64); }
@@ -308,6 +313,11 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   if (!aligned16(wplanes)) { set_error("usf_conv2d_same_f32: weight planes must be 16-byte aligned"); return -2; }
   for (int32_t act : {in_act, out_act})
     if (act != USF_ACT_NONE && act != USF_ACT_LEAKY_RELU) { set_error("usf_conv2d_same_f32: bad act"); return -2; }
+  if (ks == 3 && !gate_x) {
+    // the register-weight kernel where it serves the shape (the conditioner layers of the reference's image configurations)
+    const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, bias, in_mul, in_act, in_slope, out_act, out_slope, stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   ConvArgs a;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W; a.ks = (int)ks;

@@ -1,0 +1,302 @@
+// 3 x 3 "same" convolution of the CNN conditioner (networks.py:405-510 ConvNet2D, :61-122 GatedConv), second kernel of
+// usf_conv2d_same_f32: WEIGHTS IN REGISTERS, the three phases of a sample group overlapped.
+//
+// conv2d_same_bf16x3_kernel (usf_conv.hip) runs a group of samples as stage -> barrier -> matrix phase -> stores ->
+// barrier: its phases add up (profiles/r02_tuning_experiments.md section 5: the matrix phase is 0.23 of 0.67 ms at the
+// MNIST configuration's 32 -> 32 layer) and 57 of its 158 KB of LDS hold the weight planes.  Here
+//   * a wave owns ONE 16-channel output tile for the whole launch and keeps that tile's weight fragments (all k-blocks,
+//     three bf16 planes: 60 / 108 registers at 16 / 32 input channels) in registers: no weight image in LDS,
+//     no weight fragment reads in the k loop -- the LDS read traffic of the matrix phase halves;
+//   * the freed LDS double-buffers the input image (bf16x3 planes, channel-minor, NO zero border: a tap that leaves the
+//     picture reads a shared all-zero row instead) and holds an fp32 output staging area in the tensor's own flat
+//     [sample][channel][pixel] order, so both HBM streams are plain 16-byte-per-lane runs over contiguous memory
+//     (the old kernel: 4-byte loads, 4-byte stores in 64-byte segments);
+//   * per group every wave: issues the next group's loads, multiplies its row tiles (16 rows of (sample, pixel) x its 16
+//     channels: 6 MFMAs per k-block against a B operand read from the image), streams the previous group's staged
+//     outputs to HBM, splits and stores the next group's image -- two barriers per group; the two waves of a SIMD run
+//     the same program, the hardware interleaves one wave's vector / memory work with the other's MFMAs.
+// Arithmetic: unchanged (six v_mfma_f32_16x16x32_bf16 per fp32-equivalent product, fp32 accumulation, K order
+// tap-major / channel-minor, smallest terms first).  Served: 3 x 3 kernels, 16 / 32 input channels (k-block counts
+// 5 / 9; 48 channels = 14 k-blocks = 168 weight registers do not fit beside the rest), 16 / 32 / 64 output channels
+// (1 / 2 / 4 tiles: 8 / 4 / 2 waves each), H W <= 64 with (channels x H W) a multiple of 4, no gate; everything else
+// stays on the first kernel.
+#include <stdlib.h>
+
+#include "usf_common.h"
+
+namespace usf {
+
+typedef __bf16 cw_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvWArgs {
+  const float* x; float* y;
+  const __bf16* wp;            // [3][coutp][kp]
+  const float* bias;           // [cout] or null
+  const float* in_mul;         // [cin * hw] or null
+  int B, cin, cout, H, W;
+  int kp, coutp;
+  int S;                       // samples per group
+  int xrow;                    // bytes per image position (odd multiple of 16)
+  int img_bytes;               // bytes of one plane of one image buffer (S * HW positions + the zero row)
+  int in_act, out_act; float in_slope, out_slope;
+  unsigned mHW, mW, mSE;       // floor(2^32 / d) + 1 for d = H W, W, cin H W: n / d == umulhi(n, m) for n < 2^16
+};
+
+__device__ __forceinline__ int cw_div(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
+
+__device__ __forceinline__ void cw_split(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r = x - (float)h;
+  m = (__bf16)r;
+  l = (__bf16)(r - (float)m);
+}
+
+// NB: k-blocks of 32 (= kp / 32), CP: input channels padded to a multiple of 8, NCT: 16-channel output tiles
+template <int NB, int CP, int NCT>
+__global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WPC = 8 / NCT;                        // waves per output tile
+  constexpr int MAXRT = 4;                            // row tiles per wave and group (host: ceil(S HW / 16) <= MAXRT * WPC)
+  constexpr int MAXIT = 5;                            // 16-byte staging pieces per thread and group (host checks)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int ct = wave / WPC, wi = wave % WPC;
+  const int HW = a.H * a.W;
+  const int xrow = a.xrow;
+  const int plane = a.img_bytes;                       // one plane of one buffer
+  unsigned char* const img = smem;                     // [2 buffers][3 planes][S HW + 1 positions][xrow]
+  float* const ostage = reinterpret_cast<float*>(smem + 6 * plane);     // [S][cout][HW] fp32
+  const int zrow = a.S * HW * xrow;                    // byte offset of the all-zero position inside a plane
+
+  // ---- once per block: this wave's weight fragments, zeroed images (padding channels and the zero rows stay zero) ----
+  cw_bf16x8 wreg[NB][3];
+  {
+    const int co = min(ct * 16 + li, a.coutp - 1);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        wreg[blk][q] = *reinterpret_cast<const cw_bf16x8*>(a.wp + ((size_t)(q * a.coutp + co) * a.kp + 32 * blk + 8 * lg));
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 6 * plane / 16; i += 512) *reinterpret_cast<f32x4*>(img + i * 16) = z;
+  }
+  // per k-block: which tap and which channel offset this lane's 8 k belong to (the same for every row tile)
+  // packed: bits 0..7 dy + 1 (K padding: 200, always "outside" -> the zero row; the weights are zero there too), 8..15 dx + 1,
+  // 16.. byte offset of the lane's first channel
+  int tapinfo[NB];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int kflat = 32 * blk + 8 * lg;
+    const int tap = kflat / CP;
+    tapinfo[blk] = (tap < 9 ? tap / 3 : 200) | ((tap - (tap / 3) * 3) << 8) | ((2 * (kflat - tap * CP)) << 16);
+  }
+  __syncthreads();
+
+  const int ngroups = (a.B + a.S - 1) / a.S;
+  const int sample_elems = a.cin * HW;                 // a multiple of 4 (host)
+  // staging piece `it` of this thread: elements 4 f .. 4 f + 3 of the group's contiguous input chunk, f = tid + 512 it
+  f32x4 pre[MAXIT];
+  auto issue_loads = [&](int gidx) {
+    const int s0 = gidx * a.S;
+    const int n4 = min(a.S, a.B - s0) * sample_elems / 4;
+    const f32x4* xg = reinterpret_cast<const f32x4*>(a.x + (size_t)s0 * sample_elems);
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int f = tid + 512 * it;
+      if (f < n4) pre[it] = xg[f];
+    }
+  };
+  auto stage = [&](int gidx, int which) {
+    const int s0 = gidx * a.S;
+    const int n4 = min(a.S, a.B - s0) * sample_elems / 4;
+    unsigned char* const buf = img + which * 3 * plane;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int f = tid + 512 * it;
+      if (f < n4) {
+        const int e0 = 4 * f;
+        const int sl = cw_div(e0, a.mSE), rem0 = e0 - sl * sample_elems;    // (4 | sample_elems: the four elements share the sample)
+        f32x4 mv = {1.f, 1.f, 1.f, 1.f};
+        if (a.in_mul) mv = *reinterpret_cast<const f32x4*>(a.in_mul + rem0);
+        int c = cw_div(rem0, a.mHW), p = rem0 - c * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j > 0 && ++p == HW) { p = 0; ++c; }
+          float v = act_apply(pre[it][j], a.in_act, a.in_slope);
+          if (a.in_mul) v *= mv[j];
+          __bf16 h, m, l;
+          cw_split(v, h, m, l);
+          unsigned char* dst = buf + (sl * HW + p) * xrow + 2 * c;
+          *reinterpret_cast<__bf16*>(dst) = h;
+          *reinterpret_cast<__bf16*>(dst + plane) = m;
+          *reinterpret_cast<__bf16*>(dst + 2 * plane) = l;
+        }
+      }
+    }
+  };
+  // the previous group's staged outputs -> HBM: one contiguous chunk, 16 bytes per lane
+  auto flush = [&](int gidx) {
+    const int s0 = gidx * a.S;
+    const int n4 = min(a.S, a.B - s0) * a.cout * HW / 4;
+    f32x4* yg = reinterpret_cast<f32x4*>(a.y + (size_t)s0 * a.cout * HW);
+    for (int f = tid; f < n4; f += 512) yg[f] = *reinterpret_cast<const f32x4*>(ostage + 4 * f);
+  };
+
+  int first = blockIdx.x;
+  if (first < ngroups) { issue_loads(first); stage(first, 0); }
+  __syncthreads();
+  int prev = -1, cur = 0;
+  for (int gidx = first; gidx < ngroups; gidx += gridDim.x) {
+    const int s0 = gidx * a.S;
+    const int R = min(a.S, a.B - s0) * HW;               // live rows of this group
+    const int nrt = (R + 15) >> 4;
+    const int nxt = gidx + gridDim.x;
+    if (nxt < ngroups) issue_loads(nxt);
+    const unsigned char* const buf = img + cur * 3 * plane;
+    f32x4 res[MAXRT];
+#pragma unroll
+    for (int t = 0; t < MAXRT; ++t) {
+      const int rt = wi + WPC * t;
+      res[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (rt < nrt) {                                    // wave-uniform
+        const int r = min(rt * 16 + li, R - 1);
+        const int sl = cw_div(r, a.mHW), p = r - sl * HW;
+        const int py = cw_div(p, a.mW), px = p - py * a.W;
+        const int base = r * xrow;                       // (sl * HW + p == r: the image is the group's rows in order)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        cw_bf16x8 xf[2][3];
+        auto read_blk = [&](int blk, cw_bf16x8 (&xv)[3]) {
+          const int dy = (tapinfo[blk] & 0xff) - 1, dx = ((tapinfo[blk] >> 8) & 0xff) - 1;
+          const int yy = py + dy, xx = px + dx;
+          const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+          const int off = (ok ? base + (dy * a.W + dx) * xrow : zrow) + (tapinfo[blk] >> 16);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) xv[q] = *reinterpret_cast<const cw_bf16x8*>(buf + q * plane + off);
+        };
+        read_blk(0, xf[0]);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          if (blk + 1 < NB) read_blk(blk + 1, xf[(blk + 1) & 1]);
+          const cw_bf16x8 (&xv)[3] = xf[blk & 1];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][2], xv[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][1], xv[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][0], xv[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][1], xv[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][0], xv[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][0], xv[0], acc, 0, 0, 0);
+        }
+        res[t] = acc;
+      }
+      if (t == 1 && prev >= 0) flush(prev);              // the previous group's outputs leave under the matrix work
+    }
+    if (nxt < ngroups) stage(nxt, cur ^ 1);
+    __syncthreads();                                     // every wave is done with the staged outputs of the previous group
+    // ---- this group's results -> staging area: lane (li, lg) of a row tile holds channels ct * 16 + 4 lg + (0..3) of row li ----
+#pragma unroll
+    for (int t = 0; t < MAXRT; ++t) {
+      const int rt = wi + WPC * t;
+      const int r = rt * 16 + li;
+      if (rt < nrt && r < R) {
+        const int sl = cw_div(r, a.mHW), p = r - sl * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = ct * 16 + 4 * lg + j;
+          if (co < a.cout) {
+            const float v = res[t][j] + (a.bias ? a.bias[co] : 0.f);
+            ostage[(sl * a.cout + co) * HW + p] = act_apply(v, a.out_act, a.out_slope);
+          }
+        }
+      }
+    }
+    __syncthreads();                                     // staged outputs and the next group's image are complete
+    prev = gidx;
+    cur ^= 1;
+  }
+  if (prev >= 0) flush(prev);
+}
+
+static int cw_odd16(int units) { return units | 1; }
+
+// samples per group for the register-weight kernel (0: the shape is not served by it)
+static int conv_wreg_plan(int cin, int cout, int H, int W, int* xrow, int* img_bytes, int64_t* lds) {
+  const int HW = H * W;
+  if (!((cin == 16 || cin == 32) && (cout == 16 || cout == 32 || cout == 64)) || HW > 64 || HW < 1 ||
+      ((cin * HW) & 3) || ((cout * HW) & 3)) return 0;
+  const int cp = cin, wpc = 8 / ((cout + 15) / 16);
+  *xrow = cw_odd16(cp / 8) * 16;
+  int best = 0; double best_eff = 0.0;
+  for (int S = 1; S <= 16; ++S) {
+    const int nrt = (S * HW + 15) / 16;
+    if (nrt > 4 * wpc) break;
+    const int64_t plane = ((int64_t)(S * HW + 1) * (*xrow) + 15) / 16 * 16;
+    const int64_t bytes = 6 * plane + (int64_t)S * cout * HW * 4;
+    if (bytes > 158 * 1024) break;
+    if (((int64_t)S * cin * HW / 4 + 511) / 512 > 5) break;
+    // fill of the wave slots of the matrix phase (rows in 16-row tiles, tiles dealt over wpc waves), the more samples the
+    // fewer barriers per row: ties go to the larger group
+    const double eff = (double)(S * HW) / (16.0 * wpc * ((nrt + wpc - 1) / wpc));
+    if (eff >= best_eff - 1e-9) { best_eff = eff; best = S; }
+  }
+  if (best == 0 || best_eff < 0.7) return 0;
+  const int64_t plane = ((int64_t)(best * HW + 1) * (*xrow) + 15) / 16 * 16;
+  *img_bytes = (int)plane;
+  *lds = 6 * plane + (int64_t)best * cout * HW * 4;
+  return best;
+}
+
+int conv2d_same_wreg_fits(int64_t cin, int64_t cout, int64_t H, int64_t W) {
+  int xrow, ib; int64_t lds;
+  if (cin > 64 || cout > 64 || H * W > 256 || cin < 1 || cout < 1) return 0;
+  return conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &xrow, &ib, &lds);
+}
+
+// returns 1 when the launch was made, 0 when the shape is not served (the caller uses the first kernel), < 0 on error
+int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
+                     const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
+                     hipStream_t stream) {
+  static int enabled = -1;
+  if (enabled < 0) { const char* e = getenv("USF_CONV_WREG"); enabled = e ? atoi(e) : 1; }     // tuning aid: 0 = first kernel only
+  if (!enabled) return 0;
+  ConvWArgs a;
+  int64_t lds = 0;
+  const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.xrow, &a.img_bytes, &lds) : 0;
+  if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul))) return 0;
+  a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
+  a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W;
+  a.coutp = (int)((cout + 15) / 16 * 16); a.kp = (int)((9 * cin + 31) / 32 * 32);
+  a.S = S; a.in_act = in_act; a.out_act = out_act; a.in_slope = in_slope; a.out_slope = out_slope;
+  a.mHW = (unsigned)(0x100000000ULL / (uint64_t)(H * W)) + 1u; a.mW = (unsigned)(0x100000000ULL / (uint64_t)W) + 1u;
+  a.mSE = (unsigned)(0x100000000ULL / (uint64_t)(cin * H * W)) + 1u;
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int64_t ngroups = (B + S - 1) / S;
+  const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
+  const int nct = a.coutp / 16;
+#define USF_CW(NB_, CP_, NCT_)                                                                                     \
+  do {                                                                                                              \
+    static bool attr_done = false;                                                                                  \
+    if (!attr_done) {                                                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_same_wreg_kernel<NB_, CP_, NCT_>),              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {              \
+        set_error("usf_conv2d_same_f32: cannot raise the LDS limit");                                               \
+        return -4;                                                                                                  \
+      }                                                                                                             \
+      attr_done = true;                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((conv2d_same_wreg_kernel<NB_, CP_, NCT_>), dim3(grid), dim3(512), (size_t)lds, stream, a);   \
+  } while (0)
+#define USF_CW_NCT(NB_, CP_)                                                                                       \
+  do { if (nct == 1) USF_CW(NB_, CP_, 1); else if (nct == 2) USF_CW(NB_, CP_, 2); else USF_CW(NB_, CP_, 4); } while (0)
+  if (cin == 16) USF_CW_NCT(5, 16);
+  else USF_CW_NCT(9, 32);
+#undef USF_CW_NCT
+#undef USF_CW
+  int rc = check_launch("usf_conv2d_same_f32");
+  return rc ? rc : 1;
+}
+
+}  // namespace usf

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   constexpr int NB = 3;
   constexpr int PLF = 16 * HP;              // floats between the planes of a stage image (both image kinds)
 #ifndef USF_CPW_AH
-#define USF_CPW_AH 3
+#define USF_CPW_AH 1
 #endif
 #ifndef USF_CPW_ABL
 #define USF_CPW_ABL 0      // tuning builds (wrong results): 1 no operand / residual loads, 2 no staging stores, 4 no weight loads,
@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
       const unsigned r = is_n ? x0 + (unsigned)((tid >> 5) + 8 * i) : (unsigned)((tid >> 2) + 64 * i);
       const unsigned off = 2u * (r * ld + cpart);
 #pragma unroll
-      for (int q = 0; q < NPL; ++q) st[q * NPP + i] = *reinterpret_cast<const f32x4*>(W + (size_t)((unsigned)q * pl2 + off));
+      for (int q = 0; q < NPL; ++q) {
+        typedef const f32x4 __attribute__((address_space(1)))* gptr;
+        st[q * NPP + i] = *(gptr)(uintptr_t)(W + (size_t)((unsigned)q * pl2 + off));
+      }
     }
   };
   // staging store of piece j (= q * NPP + i) into ring slot `ring`
@@ -533,22 +536,36 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   // MFMA with two vector instructions (a 16x16x32 MFMA leaves the SIMD's issue port free for 8 of its 16 cycles) and
   // put memory instructions behind them.  One wave per SIMD: whatever is not under an MFMA is idle matrix pipe.
   auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
-  auto pins = [&](int nm) {
+  auto pins = [&](int nm, bool reads_first = false) {
     // (literal counts; the chain folds)
+    if (reads_first) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
     if (nm >= 1) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
     if (nm >= 2) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
     if (nm >= 3) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
     if (nm >= 4) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
     if (nm >= 5) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
     if (nm >= 6) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);      // fragment reads
+    if (!reads_first) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);      // fragment reads
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);        // loads
     __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);        // staging stores
     __builtin_amdgcn_sched_group_barrier(0x040, NPL, 0);      // plane stores
   };
+#if defined(USF_STAMP) && USF_STAMP >= 2
+  unsigned long long bwait = 0, bw_mark[3] = {0, 0, 0}, tstage = 0, smax = 0, smin = ~0ull;
+#endif
   auto mid_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
+#if defined(USF_STAMP) && USF_STAMP >= 2
+    const unsigned long long ta = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tstage) { const unsigned long long dt = ta - tstage; smax = dt > smax ? dt : smax; smin = dt < smin ? dt : smin; }
+    tstage = ta;
+#endif
     if (!(USF_CPW_ABL & 8)) __syncthreads();
+#if defined(USF_STAMP) && USF_STAMP >= 2
+    __builtin_amdgcn_sched_barrier(0);
+    bwait += __builtin_amdgcn_s_memtime() - ta;
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -580,26 +597,37 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   //  of that wait would expose its latency in every stage.)
 #define W32_HALF_A(I_, NXPTR_, A0_, A1_, B0_, B1_)                                                \
   do {                                                                                            \
-    mm2a(A0_, A1_, fr[(I_) % 4], B0_, B1_);                                                       \
-    if (!(USF_CPW_ABL & 32)) frag(NXPTR_, fr[((I_) + AH) % 4]);                                   \
+    if ((I_) == 0) {                      /* stage head: MFMAs first (see above) */               \
+      mm2a(A0_, A1_, fr[(I_) % 4], B0_, B1_);                                                     \
+      if (!(USF_CPW_ABL & 32)) frag(NXPTR_, fr[((I_) + AH) % 4]);                                 \
+    } else {                              /* elsewhere the reads lead: AH tiles + half a tile of latency cover */ \
+      if (!(USF_CPW_ABL & 32)) frag(NXPTR_, fr[((I_) + AH) % 4]);                                 \
+      mm2a(A0_, A1_, fr[(I_) % 4], B0_, B1_);                                                     \
+    }                                                                                             \
   } while (0)
 #define W32_HALF_B(I_, A0_, A1_, B0_, B1_) mm2b(A0_, A1_, fr[(I_) % 4], B0_, B1_)
-  // side work every stage carries in its B chunks: the staging stores of the next stage in front of the barrier (IN
-  // PROGRAM ORDER between the fragment reads: the ring slots are runtime values, LDS accesses keep their order) ...
-  auto stage_stores = [&](int i, int rn, bool next_n) {
-    if (i < NST - T / 2) { store_piece(rn, 2 * i, next_n); store_piece(rn, 2 * i + 1, next_n); }
-    else if (i < T / 2) store_piece(rn, i + NST - T / 2, next_n);
-  };
-  // ... and the global loads of the stage after that behind it (pieces 2 (i - 8), 2 (i - 8) + 1 in tile i = 8 .. 13)
+  // side work every stage carries in the B chunks in front of its barrier: staging piece j is stored (weights of stage
+  // g + 1, loaded a stage ago) and its registers are re-loaded at once (weights of stage g + 2: a full stage of latency
+  // cover).  IN PROGRAM ORDER between the fragment reads: the ring slots are runtime values, LDS accesses keep their
+  // order.  Why in the first half: vmcnt counts loads and stores together, in issue order -- a staging store waits for
+  // everything older than its load, and with the loads in front of the stage's plane stores that is never a store a
+  // few hundred cycles old.
   auto issue_piece = [&](const char* W, unsigned ld, unsigned pl2, unsigned x0, bool is_n, int j) {
     const int i = j % NPP, q = j / NPP;
     if (USF_CPW_ABL & 4) return;
     const unsigned cpart = is_n ? 8u * (unsigned)(tid & 31) : x0 + 8u * (unsigned)(tid & 3);
     const unsigned r = is_n ? x0 + (unsigned)((tid >> 5) + 8 * i) : (unsigned)((tid >> 2) + 64 * i);
-    st[j] = *reinterpret_cast<const f32x4*>(W + (size_t)((unsigned)q * pl2 + 2u * (r * ld + cpart)));
+    typedef const f32x4 __attribute__((address_space(1)))* gptr;       // a pointer rebuilt from integers is FLAT to the compiler: flat
+    st[j] = *(gptr)(uintptr_t)(W + (size_t)((unsigned)q * pl2 + 2u * (r * ld + cpart)));   // loads count in lgkmcnt too, out of order
   };
-  auto stage_loads = [&](int i, const char* W, unsigned ld, unsigned pl2, unsigned x0, bool is_n) {
-    if (i >= T / 2 && i < T / 2 + NST / 2) { issue_piece(W, ld, pl2, x0, is_n, 2 * (i - T / 2)); issue_piece(W, ld, pl2, x0, is_n, 2 * (i - T / 2) + 1); }
+  auto stage_side = [&](int i, int rn, bool next_n, const char* W2, unsigned ld2, unsigned pl22, unsigned x02, bool n2) {
+    if (i < NST - T / 2) {
+      store_piece(rn, 2 * i, next_n); store_piece(rn, 2 * i + 1, next_n);
+      issue_piece(W2, ld2, pl22, x02, n2, 2 * i); issue_piece(W2, ld2, pl22, x02, n2, 2 * i + 1);
+    } else if (i < T / 2) {
+      store_piece(rn, i + NST - T / 2, next_n);
+      issue_piece(W2, ld2, pl22, x02, n2, i + NST - T / 2);
+    }
   };
   auto zload_piece = [&](int kb, int j, vec8 (&dst)[2][NPL]) {          // j = b * NPL + q
     const int b = j / NPL, q = j % NPL;
@@ -617,11 +645,10 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
       const float* nx = (ht + AH < T) ? tile_ptr(ring, ht + AH, false) : tile_ptr(rn, ht + AH - T, next_n);
       W32_HALF_A(ht, nx, X[ht][0], X[ht][1], b0, b1);
       sideA(ht);
-      pins(NMA);
+      pins(NMA, ht > 0);
       fence();
       W32_HALF_B(ht, X[ht][0], X[ht][1], b0, b1);
-      stage_stores(ht, rn, next_n);
-      stage_loads(ht, W2, ld2, pl22, x02, n2);
+      stage_side(ht, rn, next_n, W2, ld2, pl22, x02, n2);
       pins(NMB);
       fence();
       if (ht == T / 2 - 1) mid_barrier();
@@ -649,6 +676,9 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
     if (s + 1 < p.nk_p) p1_stage(s + 1, zn, zp);
   }
   CSTAMP(c1);
+#if defined(USF_STAMP) && USF_STAMP >= 2
+  bw_mark[0] = bwait;
+#endif
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1'] * act(Xin)[h1'][row] ====================
   // the activation and the split of the next k-step's operand ride under the current step's MFMAs, two values (one
@@ -687,34 +717,34 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
     hidden_layer(X2, X1, CpInt<1>());
   }
   CSTAMP(c2);
+#if defined(USF_STAMP) && USF_STAMP >= 2
+  bw_mark[1] = bwait;
+#endif
 
   // ================= phase 3: z_T[row][n] += sign * (b_out[n] + sum_h X[h][row] W_out[n][h']) on the transformed blocks =====
   auto output_layer = [&](f32x4 (&X)[T][2]) {
     vec8 xp[KS][2][NPL];
-    // Register plan (the stage bodies of this phase are the tightest: 192 registers of operand planes): ONE set of
-    // residual planes with staggered lifetimes -- batch tile 0's planes of n-tile nt are loaded under tiles 8..10 of stage nt
-    // (its epilogue reads them under tiles 0..7 of stage nt + 1), batch tile 1's planes of n-tile nt - 1 under tiles 0..2 of
-    // stage nt (read under tiles 8..15 of the same stage) -- and the output bias as the accumulators' starting value.
-    vec8 r0[NPL], r1[NPL];                  // residual planes: batch tile 0 / 1
+    // Register plan (the stage bodies of this phase are the tightest: 192 registers of operand planes): the output bias
+    // is the accumulators' starting value; the residual planes of n-tile nt are loaded under tiles 1 .. 2 NPL of stage
+    // nt and read by its epilogue under stage nt + 1 (two sets that alternate with the accumulators: a full stage of
+    // latency cover -- a set re-loaded in the stage that reads it would wait for HBM with a single wave on the SIMD).
+    vec8 rA[2][NPL], rB[2][NPL];            // residual planes [batch tile][plane]
     f32x4 bn[2];                            // bias slices of the NEXT n-tile
     f32x4 aA[2][2], aB[2][2];               // accumulators [u][batch tile]: the two sets alternate between "being computed" and "finished"
     auto load_bias = [&](int nt) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) bn[u] = *reinterpret_cast<const f32x4*>(p.b_out + min(nt, p.nk_t - 1) * 32 + 16 * u + 4 * lg);
     };
-    auto rload = [&](int nt, int b, int q, vec8 (&dst)[NPL]) {
-      if (USF_CPW_ABL & 1) { dst[q] = zp[b][q]; return; }
-      dst[q] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(zrs, (int)(zoff[b] + (unsigned)(p.kb_t0 + nt) * CHB + (unsigned)q * 1024u), 0, 0));
-    };
+
     // epilogue of a finished n-tile (residual from the planes, update, split, store in place -- all lane-local) in pieces
     // that ride in the chunks of the following stage: value v = 8 b + 4 u + e in chunk A of tile v; the split of the
     // pair (v - 1, v) in chunk B of odd tiles; a batch tile's three plane stores behind its last pair (tiles 7, 15)
     float ev[8];                            // (one batch tile at a time: tile b's stores are issued before tile b + 1 starts)
     vec8 eo[NPL];
-    auto epi_value = [&](int v, const f32x4 (&a)[2][2]) {
+    auto epi_value = [&](int v, const f32x4 (&a)[2][2], const vec8 (&rr_)[2][NPL]) {
       const int b = v >> 3, u = (v >> 2) & 1, e = v & 3;
       if (USF_CPW_ABL & 64) { ev[4 * u + e] = a[u][b][e]; return; }
-      const vec8 (&r)[NPL] = b ? r1 : r0;
+      const vec8 (&r)[NPL] = rr_[b];
       float rr = (float)r[0][4 * u + e] + (float)r[1][4 * u + e];
       if (NPL == 3) rr = rr + (float)r[NPL - 1][4 * u + e];
       ev[4 * u + e] = __builtin_fmaf(p.sign, a[u][b][e], rr);
@@ -732,7 +762,8 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
       split_pair(act1(X[2 * ks + (j >> 2)][b][j & 3]), act1(X[2 * ks + (j >> 2)][b][(j & 3) + 1]), j, xp[ks][b]);
     };
     // one n-tile stage
-    auto ntile_stage = [&](int nt, auto first_tag, f32x4 (&acc)[2][2], const f32x4 (&accp)[2][2]) {
+    auto ntile_stage = [&](int nt, auto first_tag, f32x4 (&acc)[2][2], vec8 (&rnew)[2][NPL], const f32x4 (&accp)[2][2],
+                           const vec8 (&rcur)[2][NPL]) {
       constexpr bool FIRST = decltype(first_tag)::value;
       const int rn = next_ring(ring);
       const unsigned x02 = 32u * (unsigned)min(nt + 2, p.nk_t - 1);
@@ -743,16 +774,14 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
         const int ks = i >> 1, u = i & 1;
         const float* nx = (i + AH < T) ? tile_ptr(ring, i + AH, true) : tile_ptr(rn, i + AH - T, true);
         W32_HALF_A(i, nx, acc[u][0], acc[u][1], xp[ks][0], xp[ks][1]);
-        if (!FIRST && i < NPL) rload(nt - 1, 1, i, r1);                 // batch tile 1 of the finished n-tile
+        if (i >= 1 && i <= 2 * NPL) zload_piece(p.kb_t0 + nt, i - 1, rnew);           // this n-tile's residual planes
         if (FIRST) { if (ks + 1 < KS) { xp_piece(ks + 1, 4 * u); xp_piece(ks + 1, 4 * u + 1); } }
-        else epi_value(i, accp);
-        if (i >= T / 2 && i < T / 2 + NPL) rload(nt, 0, i - T / 2, r0); // batch tile 0 of this n-tile (r0 is free: read under tiles 0..7)
-        if (i == T - 3) load_bias(nt + 1);
-        pins(NMA);
+        else epi_value(i, accp, rcur);
+        if (i == 2 * NPL + 1) load_bias(nt + 1);
+        pins(NMA, i > 0);
         fence();
         W32_HALF_B(i, acc[u][0], acc[u][1], xp[ks][0], xp[ks][1]);
-        stage_stores(i, rn, true);
-        stage_loads(i, p.Wout, (unsigned)p.ld_out, 2u * (unsigned)p.pl_out, x02, true);
+        stage_side(i, rn, true, p.Wout, (unsigned)p.ld_out, 2u * (unsigned)p.pl_out, x02, true);
         if (FIRST) { if (ks + 1 < KS) { xp_piece(ks + 1, 4 * u + 2); xp_piece(ks + 1, 4 * u + 3); } }
         else if (i & 1) epi_pair(nt - 1, i);
         pins(NMB);
@@ -764,18 +793,16 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
     load_bias(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) xp_piece(0, k);
-    ntile_stage(0, CpBool<true>(), aA, aB);
+    ntile_stage(0, CpBool<true>(), aA, rA, aB, rB);
     int nt = 1;
     for (; nt < p.nk_t; nt += 2) {
-      ntile_stage(nt, CpBool<false>(), aB, aA);
-      if (nt + 1 < p.nk_t) ntile_stage(nt + 1, CpBool<false>(), aA, aB);
+      ntile_stage(nt, CpBool<false>(), aB, rB, aA, rA);
+      if (nt + 1 < p.nk_t) ntile_stage(nt + 1, CpBool<false>(), aA, rA, aB, rB);
     }
-    // the last n-tile: batch tile 1's residual planes are still to be fetched; it sits in set A when nk_t is odd
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) rload(p.nk_t - 1, 1, q, r1);
+    // the last n-tile sits in set A when nk_t is odd, in set B when it is even
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-      if (p.nk_t & 1) epi_value(v, aA); else epi_value(v, aB);
+      if (p.nk_t & 1) epi_value(v, aA, rA); else epi_value(v, aB, rB);
       if (v & 1) epi_pair(p.nk_t - 1, v);
     }
   };
@@ -787,6 +814,10 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
   if (p.dbg && lane == 0) {
     unsigned long long* o = p.dbg + (size_t)((blockIdx.x % 2048) * 8 + wave) * 4;
     o[0] = c1 - c0; o[1] = c2 - c1; o[2] = c3 - c2; o[3] = 1;
+#if USF_STAMP >= 2
+    unsigned long long* o2 = p.dbg + (size_t)2048 * 8 * 4 + (size_t)((blockIdx.x % 2048) * 8 + wave) * 8;
+    o2[0] = bw_mark[0]; o2[1] = bw_mark[1] - bw_mark[0]; o2[2] = bwait - bw_mark[1]; o2[3] = smin; o2[4] = smax;
+#endif
   }
 #endif
   // (rows beyond M load zeros, so a flag raised by such a row is a bias-only value beyond fp16's range: the pass is
@@ -797,7 +828,7 @@ __global__ __launch_bounds__(256) void coupling_planes_w32_kernel(const CplPArgs
 #ifdef USF_STAMP
 unsigned long long* g_cdbg = nullptr;
 #endif
-int g_cp_w32 = -1;                        // harness override of USF_CP_W32 (-1: environment)
+int g_cp_w32 = -1;                        // usf_coupling_planes_select (-1: the environment's USF_CP_W32, default 0)
 
 int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_planes: null descriptor"); return -1; }
@@ -838,7 +869,7 @@ int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
 #endif
   const dim3 grid((unsigned)((npanels + 7) / 8));
   static int w32_env = -1;
-  if (w32_env < 0) { const char* e = getenv("USF_CP_W32"); w32_env = e ? atoi(e) : 1; }   // tuning aid: 0 = the 16-row-wave kernel
+  if (w32_env < 0) { const char* e = getenv("USF_CP_W32"); w32_env = e ? atoi(e) : 0; }   // 1: the 32-row-wave kernel (usf_coupling_planes_select)
   const int w32 = g_cp_w32 >= 0 ? g_cp_w32 : w32_env;
   if (w32 && d->n_hidden <= 2 && d->nk_p >= 2 && 2 * npl * d->w_in_plane < (1LL << 31) && 2 * npl * d->w_hid_plane < (1LL << 31) &&
       2 * npl * d->w_out_plane < (1LL << 31) && npanels * 0 + d->z_nkb * npl * 1024 * 8 < (1LL << 31)) {

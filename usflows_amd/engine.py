@@ -270,7 +270,7 @@ class FlowEngine:
         # (USFLOWS_AMD_MERGE_AFFINE=1): always; False (=0): never.
         _m = os.environ.get("USFLOWS_AMD_MERGE_AFFINE", "auto")
         self.merge_affine = True if _m == "1" else (False if _m == "0" else "auto")
-        self.merge_guard_log: List[tuple] = []   # (accepted, max deviation composed vs layer-by-layer) per probe
+        self.merge_guard_log: List[tuple] = []   # (accepted, element-wise deviation, L1-norm deviation) of composed vs layer-by-layer, per probe
         self._virtual: List[_Step] = []          # merged steps, addressed as step index len(self.steps) + n
         self._virtual_ix: Dict[tuple, int] = {}
         self.launch_count = 0          # number of usf_run_ops calls (tests assert the HIP path ran)
@@ -748,7 +748,10 @@ class FlowEngine:
         maps may be composed.  The probe is end to end -- up to 64 rows of the caller's own batch through the plan with
         composed runs and through the layer-by-layer plan: the composite itself is as accurate as its parts (both are
         rounded once from fp64 factors), what differs between flows is how far ANY change of rounding pattern is
-        amplified downstream.  Where the two results agree to 2e-6 of the largest output the flow is well conditioned
+        amplified downstream.  Where the two results agree (1e-5 of the largest output element-wise, 1e-6 in the rows'
+        L1 norms -- half resp. a tenth of what the parity bars allow; measured: the reference's default-initialised
+        golden flows 4e-6 .. 1.4e-5 in the L1 measure, conditioned flows up to the 65-layer cfg2 model 1e-7 .. 4e-7)
+        the flow is well conditioned
         and the composed plan (half the D x D GEMMs of a conjugated flow) is indistinguishable from the reference's
         arithmetic at the 1e-5 parity bar; where they do not (default-initialised, exploding flows: the reference's
         own fp32 run is 2 - 7e-6 from its fp64 run there) the layers keep their own launches.  Costs two 64-row passes
@@ -775,9 +778,14 @@ class FlowEngine:
                 out = torch.empty(n, self.D, dtype=torch.float32, device=x.device)
                 run(self._plan(direction, n, x.device, False, "user"), xs, out)
                 outs.append(out.double())
+            # two measures: the largest element-wise deviation against the largest output (the parity tests allow 2e-5 of
+            # it), and the deviation of the rows' L1 norms -- what a Laplace / radial base density sums, i.e. the log_prob's
+            # sensitivity (bar: 1e-5 relative)
             d = ((outs[1] - outs[0]).abs().max() / outs[0].abs().max().clamp_min(1e-30)).item()
-        ok = bool(d <= 2e-6)                              # (NaN / inf compare False)
-        self.merge_guard_log.append((ok, d))
+            l1 = outs[0].abs().sum(-1)
+            d1 = ((outs[1].abs().sum(-1) - l1).abs() / l1.clamp_min(1e-30)).max().item()
+        ok = bool(d <= 1e-5 and d1 <= 1e-6)               # (NaN / inf compare False)
+        self.merge_guard_log.append((ok, d, d1))
         state[direction] = ok
         return ok
 
