@@ -570,7 +570,10 @@ def test_image_flow_full_batch_head_middle_tail_vs_reference(name, rows):
     base_lp = torch.distributions.Laplace(0.0, 1.0).log_prob(z.double()).flatten(1).sum(-1)
     const = lp.double() - base_lp
     assert (const + float(a["total_ladj64"])).abs().max().item() < 1e-5 * base_lp.abs().max().item()
-    assert (xr - xd).abs().max().item() < 2e-5 * max(1.0, xd.abs().max().item())
+    # (the round trip passes every layer twice in fp32: the bound grows with the depth -- 2 blocks: 2e-5, the CIFAR
+    #  configuration's 10 blocks: 1e-4)
+    depth = sum(1 for l in flow.layers if type(l).__name__ == "MaskedCoupling")
+    assert (xr - xd).abs().max().item() < 1e-5 * max(2, depth) * max(1.0, xd.abs().max().item())
     # a second call on the same rows is bit-identical (no dependence on the groups' walk order)
     with torch.no_grad():
         assert torch.equal(flow.log_prob(xd), lp)

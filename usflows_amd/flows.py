@@ -12,6 +12,7 @@ used whenever the input is on a ROCm device and no autograd graph is required.  
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import warnings
 from typing import Any, Dict, Iterable, List, Literal, Optional, Type
@@ -439,6 +440,22 @@ class Flow(torch.nn.Module):
         optim = optim(model.parameters(), **optim_params) if optim_params is not None else optim(model.parameters())
         N = len(data_train)
         epoch_losses = []
+        # On a GPU the whole loop runs on a stream of the flow's own (created once): the launch tapes of the device training
+        # path record the stream they were made on, and a training step can only be captured into a hipGraph on that very
+        # stream (a capture does not reach over to another one) -- never torch's legacy default stream.
+        side = None
+        if torch.device(device).type == "cuda" and self.use_train_graph and os.environ.get("USFLOWS_AMD_TRAIN_GRAPH", "1") != "0":
+            side = self.__dict__.get("_fit_stream")
+            if side is None or side.device != torch.device(device):
+                side = self.__dict__["_fit_stream"] = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            self._fit_epochs(model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses)
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
+        return epoch_losses
+
+    def _fit_epochs(self, model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses):
         for _ in range(epochs):
             losses = []
             if shuffle:
@@ -476,7 +493,6 @@ class Flow(torch.nn.Module):
                     raise RuntimeError("Model is not invertible")
                 model.transform.clear_cache()
             epoch_losses.append(np.mean(losses))
-        return epoch_losses
 
     # ---- Flow.fit: steps of the composite formulation replayed as ONE hipGraph -------------------------------------
     # A step of a flow without a device training path (image-shaped inputs, conditioners with no HIP backward) is some
@@ -484,6 +500,7 @@ class Flow(torch.nn.Module):
     # configuration, batch 32 .. 4096).  After three eager steps the whole step -- zeroing the gradients, log_prob, backward,
     # the optimiser's update -- is captured once per (batch shape, optimiser) and replayed; a ragged last batch runs eagerly.
     use_train_graph = True        # USFLOWS_AMD_TRAIN_GRAPH=0: off
+    train_graph_max_rows = 4096   # flat flows with a device backward: above this the step is not launch-bound any more
     _TRAIN_GRAPH_EAGER_STEPS = 3
 
     def _train_graph_step(self, optim, sample: torch.Tensor, noise) -> Optional[float]:
@@ -502,7 +519,12 @@ class Flow(torch.nn.Module):
             return None
         with torch.enable_grad():
             if self._train_path(sample, noise) is not None:
-                return None           # flat flows with a device backward: training.py's launch tapes serve them
+                # flat flows with a device backward (training.py): the step is ~850 dependent launches of a few microseconds
+                # at the reference's batch of 32 -- launch-bound.  Capturable when the loop runs on the flow's own stream
+                # (Flow.fit): the tapes replay on the stream they were recorded on.
+                if torch.cuda.current_stream(sample.device) != self.__dict__.get("_fit_stream") or \
+                        sample.shape[0] > self.train_graph_max_rows:
+                    return None
         st = self.__dict__.get("_train_graph_state")
         key = (tuple(sample.shape), None if noise is None else tuple(noise.shape))
         if st is None or st["optim"] is not optim:
@@ -534,7 +556,9 @@ class Flow(torch.nn.Module):
             try:
                 torch.cuda.synchronize(sample.device)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                cur = torch.cuda.current_stream(sample.device)
+                on_own = cur == self.__dict__.get("_fit_stream")
+                with (torch.cuda.graph(graph, stream=cur) if on_own else torch.cuda.graph(graph)):
                     sl = body()
             except Exception as e:      # noqa: BLE001  (an op that cannot be captured: eager steps from now on)
                 self._train_graph_failed = True
