@@ -228,3 +228,50 @@ def test_fit_on_device_matches_reference_run():
         losses = _run_fit(flow, data, DEV)
         assert flow.engine().launch_count > before and not getattr(flow, "_train_failed", False)
         _check_fit(flow, losses, losses_ref, sd_ref, 5e-5)
+
+
+def test_failed_capture_of_a_training_step_is_recoverable(monkeypatch):
+    """A training step whose hipGraph capture breaks off (an op that synchronises the host) must leave the flow usable:
+    the capture ran no GPU work but its Python side moved version counters and the engine's pack key -- Flow.fit drops
+    every cache keyed on them and continues with eager steps whose losses equal those of a run that never tried to
+    capture (the recovery path was untested)."""
+    import numpy as np
+    from usflows_amd.flows import Flow
+    from oracle import usflows_oracle as orc
+    spec = orc.FlowSpec(12, 3, [16, 16], householder=1, affine_conjugation=True)
+    sd = orc.synth_state_dict(spec, seed=21)
+    x = torch.rand(32 * 8, 12, generator=torch.Generator().manual_seed(3))
+
+    class DS:
+        def __len__(self):
+            return x.shape[0]
+
+        def __getitem__(self, i):
+            return (x[i],)
+
+    def run(break_capture):
+        flow = build_flow(spec, sd, device=DEV)
+        if break_capture:
+            real = Flow.log_prior
+
+            def syncing_prior(self):
+                if torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()            # not permitted while capturing: the capture fails here
+                return real(self)
+            monkeypatch.setattr(Flow, "log_prior", syncing_prior)
+        else:
+            monkeypatch.setenv("USFLOWS_AMD_TRAIN_GRAPH", "0")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            losses = flow.fit(DS(), torch.optim.SGD, dict(lr=1e-3), batch_size=32, shuffle=False, device=torch.device(DEV), epochs=2)
+        monkeypatch.undo()
+        with torch.no_grad():
+            lp = flow.log_prob(x[:64].to(DEV)).cpu()
+        return losses, lp, getattr(flow, "_train_graph_failed", False)
+
+    import warnings
+    l_ref, lp_ref, _ = run(False)
+    l_brk, lp_brk, failed = run(True)
+    assert failed, "the capture was expected to fail"
+    assert np.allclose(l_brk, l_ref, rtol=1e-6, atol=0), (l_brk, l_ref)
+    assert torch.allclose(lp_brk, lp_ref, rtol=1e-6, atol=1e-5)

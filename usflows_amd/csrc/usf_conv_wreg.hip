@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WPC = 8 / NCT;                        // waves per output tile
   constexpr int MAXRT = 4;                            // row tiles per wave and group (host: ceil(S HW / 16) <= MAXRT * WPC)
-  constexpr int MAXIT = 5;                            // 16-byte staging pieces per thread and group (host checks)
+  constexpr int MAXIT = 4;                            // 16-byte staging pieces per thread and group (host checks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -81,22 +81,41 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < 6 * plane / 16; i += 512) *reinterpret_cast<f32x4*>(img + i * 16) = z;
   }
-  // per k-block: which tap and which channel offset this lane's 8 k belong to (the same for every row tile)
-  // packed: bits 0..7 dy + 1 (K padding: 200, always "outside" -> the zero row; the weights are zero there too), 8..15 dx + 1,
-  // 16.. byte offset of the lane's first channel
+  // per k-block (the same for every row tile): which tap this lane's 8 k belong to and the byte offset that tap and the
+  // lane's first channel add to a row's image position; packed: bits 0..3 tap (9: K padding -> always the zero row; the
+  // weights are zero there too), bits 4.. signed offset (dy W + dx) xrow + 2 c
   int tapinfo[NB];
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int kflat = 32 * blk + 8 * lg;
-    const int tap = kflat / CP;
-    tapinfo[blk] = (tap < 9 ? tap / 3 : 200) | ((tap - (tap / 3) * 3) << 8) | ((2 * (kflat - tap * CP)) << 16);
+    const int tap = min(kflat / CP, 9);
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    tapinfo[blk] = tap | (((dy * a.W + dx) * xrow + 2 * (kflat - (kflat / CP) * CP)) << 4);
   }
   __syncthreads();
 
   const int ngroups = (a.B + a.S - 1) / a.S;
   const int sample_elems = a.cin * HW;                 // a multiple of 4 (host)
+  const bool leaky_in = a.in_act == USF_ACT_LEAKY_RELU;
   // staging piece `it` of this thread: elements 4 f .. 4 f + 3 of the group's contiguous input chunk, f = tid + 512 it
   f32x4 pre[MAXIT];
+  // LDS byte offsets (inside a plane) of the four elements of every piece, in units of 2 bytes, two per register: the
+  // same for every group (a plane is < 128 KB)
+  unsigned soff[MAXIT][2];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int e0 = 4 * (tid + 512 * it);
+    const int sl = cw_div(e0, a.mSE), rem0 = e0 - sl * sample_elems;    // (4 | sample_elems: the four elements share the sample)
+    int c = cw_div(rem0, a.mHW), p = rem0 - c * HW;
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j > 0 && ++p == HW) { p = 0; ++c; }
+      o[j] = (unsigned)(((sl * HW + p) * xrow + 2 * c) >> 1) & 0xffffu;
+    }
+    soff[it][0] = o[0] | (o[1] << 16);
+    soff[it][1] = o[2] | (o[3] << 16);
+  }
   auto issue_loads = [&](int gidx) {
     const int s0 = gidx * a.S;
     const int n4 = min(a.S, a.B - s0) * sample_elems / 4;
@@ -115,19 +134,19 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
     for (int it = 0; it < MAXIT; ++it) {
       const int f = tid + 512 * it;
       if (f < n4) {
-        const int e0 = 4 * f;
-        const int sl = cw_div(e0, a.mSE), rem0 = e0 - sl * sample_elems;    // (4 | sample_elems: the four elements share the sample)
         f32x4 mv = {1.f, 1.f, 1.f, 1.f};
-        if (a.in_mul) mv = *reinterpret_cast<const f32x4*>(a.in_mul + rem0);
-        int c = cw_div(rem0, a.mHW), p = rem0 - c * HW;
+        if (a.in_mul) {
+          const int e0 = 4 * f;
+          mv = *reinterpret_cast<const f32x4*>(a.in_mul + (e0 - cw_div(e0, a.mSE) * sample_elems));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (j > 0 && ++p == HW) { p = 0; ++c; }
-          float v = act_apply(pre[it][j], a.in_act, a.in_slope);
+          float v = pre[it][j];
+          if (leaky_in) v = v > 0.0f ? v : v * a.in_slope;
           if (a.in_mul) v *= mv[j];
           __bf16 h, m, l;
           cw_split(v, h, m, l);
-          unsigned char* dst = buf + (sl * HW + p) * xrow + 2 * c;
+          unsigned char* dst = buf + 2u * ((soff[it][j >> 1] >> (16 * (j & 1))) & 0xffffu);
           *reinterpret_cast<__bf16*>(dst) = h;
           *reinterpret_cast<__bf16*>(dst + plane) = m;
           *reinterpret_cast<__bf16*>(dst + 2 * plane) = l;
@@ -164,13 +183,15 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
         const int sl = cw_div(r, a.mHW), p = r - sl * HW;
         const int py = cw_div(p, a.mW), px = p - py * a.W;
         const int base = r * xrow;                       // (sl * HW + p == r: the image is the group's rows in order)
+        // which of the nine taps stay inside the picture for this row's pixel (bit 9, the K padding, stays clear)
+        const unsigned rowok = (py > 0 ? 0x007u : 0u) | 0x038u | (py + 1 < a.H ? 0x1c0u : 0u);
+        const unsigned colok = (px > 0 ? 0x049u : 0u) | 0x092u | (px + 1 < a.W ? 0x124u : 0u);
+        const unsigned vmask = rowok & colok;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         cw_bf16x8 xf[2][3];
         auto read_blk = [&](int blk, cw_bf16x8 (&xv)[3]) {
-          const int dy = (tapinfo[blk] & 0xff) - 1, dx = ((tapinfo[blk] >> 8) & 0xff) - 1;
-          const int yy = py + dy, xx = px + dx;
-          const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-          const int off = (ok ? base + (dy * a.W + dx) * xrow : zrow) + (tapinfo[blk] >> 16);
+          const bool ok = (vmask >> (tapinfo[blk] & 15)) & 1u;
+          const int off = ok ? base + (tapinfo[blk] >> 4) : zrow;     // (the zero row is zero in every channel: no channel offset needed)
 #pragma unroll
           for (int q = 0; q < 3; ++q) xv[q] = *reinterpret_cast<const cw_bf16x8*>(buf + q * plane + off);
         };
@@ -189,8 +210,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
         res[t] = acc;
       }
       if (t == 1 && prev >= 0) flush(prev);              // the previous group's outputs leave under the matrix work
+      // the two waves of a SIMD (w and w + 4) split and store the next group's image at different points of the group:
+      // one of them is multiplying while the other one's vector instructions run
+      if (t == 1 && wave >= 4 && nxt < ngroups) stage(nxt, cur ^ 1);
     }
-    if (nxt < ngroups) stage(nxt, cur ^ 1);
+    if (wave < 4 && nxt < ngroups) stage(nxt, cur ^ 1);
     __syncthreads();                                     // every wave is done with the staged outputs of the previous group
     // ---- this group's results -> staging area: lane (li, lg) of a row tile holds channels ct * 16 + 4 lg + (0..3) of row li ----
 #pragma unroll
@@ -232,7 +256,7 @@ static int conv_wreg_plan(int cin, int cout, int H, int W, int* xrow, int* img_b
     const int64_t plane = ((int64_t)(S * HW + 1) * (*xrow) + 15) / 16 * 16;
     const int64_t bytes = 6 * plane + (int64_t)S * cout * HW * 4;
     if (bytes > 158 * 1024) break;
-    if (((int64_t)S * cin * HW / 4 + 511) / 512 > 5) break;
+    if (((int64_t)S * cin * HW / 4 + 511) / 512 > 4) break;
     // fill of the wave slots of the matrix phase (rows in 16-row tiles, tiles dealt over wpc waves), the more samples the
     // fewer barriers per row: ties go to the larger group
     const double eff = (double)(S * HW) / (16.0 * wpc * ((nrt + wpc - 1) / wpc));

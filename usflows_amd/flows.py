@@ -517,6 +517,11 @@ class Flow(torch.nn.Module):
             return None               # (optimisers whose step is known to be free of host synchronisation)
         if any(g_.get("capturable") for g_ in optim.param_groups if isinstance(optim, SophiaG)):
             return None
+        # bases that build a fresh, argument-validating torch distribution on every log_prob (DistributionModule:
+        # RadialDistribution with its norm distribution) read a flag back to the host inside the step, and a parameter
+        # prior (prior_scale) is evaluated by host-side torch code: neither survives a stream capture -- eager steps
+        if isinstance(self.base_distribution, DistributionModule) or getattr(self, "prior_scale", None) is not None:
+            return None
         with torch.enable_grad():
             if self._train_path(sample, noise) is not None:
                 # flat flows with a device backward (training.py): the step is ~850 dependent launches of a few microseconds
@@ -562,6 +567,7 @@ class Flow(torch.nn.Module):
                     sl = body()
             except Exception as e:      # noqa: BLE001  (an op that cannot be captured: eager steps from now on)
                 self._train_graph_failed = True
+                self._recover_from_failed_capture(optim, params)
                 warnings.warn(f"usflows_amd: hipGraph capture of the training step failed ({type(e).__name__}: "
                               f"{str(e).splitlines()[0] if str(e) else ''}); Flow.fit runs eager steps", RuntimeWarning)
                 return None
@@ -578,6 +584,26 @@ class Flow(torch.nn.Module):
         for p in st["params"]:
             torch.autograd.graph.increment_version(p)      # a replay runs no Python: tell the version-keyed caches
         return float(st["loss"])
+
+    def _recover_from_failed_capture(self, optim, params) -> None:
+        """A capture that broke off ran no GPU work, but its Python side ran: version counters moved, the engine took its
+        parameter pack for refreshed (the refreshing launches were only recorded, then discarded) and the training path
+        its tapes for current.  Drop every cache keyed on them -- the next (eager) step rebuilds from the parameters'
+        actual values -- and make sure the device is out of capture mode."""
+        try:
+            torch.cuda.synchronize()
+        except Exception:               # noqa: BLE001
+            pass
+        eng = getattr(self, "_engine_obj", None)
+        if eng is not None:
+            eng._pack, eng._pack_key = None, None
+            eng._plans.clear()
+            eng._ws.clear()
+        self._train_obj = None
+        self.__dict__.pop("_train_graph_state", None)
+        for p in params:
+            if p.grad is not None:
+                p.grad = None
 
     def _zero_grad_for_step(self, optim) -> None:
         """``optim.zero_grad()`` of an eager step -- but once a training step of this optimiser has been captured, the
