@@ -7,8 +7,8 @@
 //   * a wave owns ONE 16-channel output tile for the whole launch and keeps that tile's weight fragments (all k-blocks,
 //     three bf16 planes: 60 / 108 registers at 16 / 32 input channels) in registers: no weight image in LDS,
 //     no weight fragment reads in the k loop -- the LDS read traffic of the matrix phase halves;
-//   * the freed LDS double-buffers the input image (bf16x3 planes, channel-minor, NO zero border: a tap that leaves the
-//     picture reads a shared all-zero row instead) and holds an fp32 output staging area in the tensor's own flat
+//   * the freed LDS double-buffers the input image (bf16x3 planes, groups of 8 channels x positions, NO zero border: a
+//     tap that leaves the picture reads a shared all-zero position instead) and holds an fp32 output staging area in the tensor's own flat
 //     [sample][channel][pixel] order, so both HBM streams are plain 16-byte-per-lane runs over contiguous memory
 //     (the old kernel: 4-byte loads, 4-byte stores in 64-byte segments);
 //   * per group every wave: issues the next group's loads, multiplies its row tiles (16 rows of (sample, pixel) x its 16
@@ -36,8 +36,8 @@ struct ConvWArgs {
   int B, cin, cout, H, W;
   int kp, coutp;
   int S;                       // samples per group
-  int xrow;                    // bytes per image position (odd multiple of 16)
-  int img_bytes;               // bytes of one plane of one image buffer (S * HW positions + the zero row)
+  int cgs;                     // bytes of one channel group (8 channels) of an image plane: (S * HW positions + the zero one) * 16, rounded up to 256
+  int img_bytes;               // bytes of one plane of one image buffer: (cin / 8) * cgs
   int in_act, out_act; float in_slope, out_slope;
   unsigned mHW, mW, mSE;       // floor(2^32 / d) + 1 for d = H W, W, cin H W: n / d == umulhi(n, m) for n < 2^16
 };
@@ -63,11 +63,16 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
   const int li = lane & 15, lg = lane >> 4;
   const int ct = wave / WPC, wi = wave % WPC;
   const int HW = a.H * a.W;
-  const int xrow = a.xrow;
+  const int cgs = a.cgs;
   const int plane = a.img_bytes;                       // one plane of one buffer
-  unsigned char* const img = smem;                     // [2 buffers][3 planes][S HW + 1 positions][xrow]
+  // image: [2 buffers][3 planes][channel group of 8][S HW + 1 positions] x 16 bytes.  Channel-group-major with a group
+  // stride that is a multiple of 256 bytes: a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
+  // 28-31}, ... (MI355X_MICROARCH.md, LDS) -- rows li of one channel group next to rows li of the next one -- and 16
+  // consecutive positions of any channel groups are 16 different 16-byte bank groups (position-major rows of 80 bytes
+  // collide 2-way under that grouping)
+  unsigned char* const img = smem;
   float* const ostage = reinterpret_cast<float*>(smem + 6 * plane);     // [S][cout][HW] fp32
-  const int zrow = a.S * HW * xrow;                    // byte offset of the all-zero position inside a plane
+  const int zpos = a.S * HW * 16;                      // byte offset of the all-zero position inside a channel group
 
   // ---- once per block: this wave's weight fragments, zeroed images (padding channels and the zero rows stay zero) ----
   cw_bf16x8 wreg[NB][3];
@@ -82,15 +87,15 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
     for (int i = tid; i < 6 * plane / 16; i += 512) *reinterpret_cast<f32x4*>(img + i * 16) = z;
   }
   // per k-block (the same for every row tile): which tap this lane's 8 k belong to and the byte offset that tap and the
-  // lane's first channel add to a row's image position; packed: bits 0..3 tap (9: K padding -> always the zero row; the
-  // weights are zero there too), bits 4.. signed offset (dy W + dx) xrow + 2 c
+  // lane's channel group add to a row's image position; packed: bits 0..3 tap (9: K padding -> always the zero position;
+  // the weights are zero there too), bits 4.. signed offset (dy W + dx) 16 + channel group * cgs
   int tapinfo[NB];
 #pragma unroll
   for (int blk = 0; blk < NB; ++blk) {
     const int kflat = 32 * blk + 8 * lg;
     const int tap = min(kflat / CP, 9);
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-    tapinfo[blk] = tap | (((dy * a.W + dx) * xrow + 2 * (kflat - (kflat / CP) * CP)) << 4);
+    tapinfo[blk] = tap | (((dy * a.W + dx) * 16 + ((kflat - (kflat / CP) * CP) >> 3) * cgs) << 4);
   }
   __syncthreads();
 
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j > 0 && ++p == HW) { p = 0; ++c; }
-      o[j] = (unsigned)(((sl * HW + p) * xrow + 2 * c) >> 1) & 0xffffu;
+      o[j] = (unsigned)(((c >> 3) * cgs + (sl * HW + p) * 16 + 2 * (c & 7)) >> 1) & 0xffffu;
     }
     soff[it][0] = o[0] | (o[1] << 16);
     soff[it][1] = o[2] | (o[3] << 16);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
         const int r = min(rt * 16 + li, R - 1);
         const int sl = cw_div(r, a.mHW), p = r - sl * HW;
         const int py = cw_div(p, a.mW), px = p - py * a.W;
-        const int base = r * xrow;                       // (sl * HW + p == r: the image is the group's rows in order)
+        const int base = r * 16;                         // (sl * HW + p == r: the image is the group's rows in order)
         // which of the nine taps stay inside the picture for this row's pixel (bit 9, the K padding, stays clear)
         const unsigned rowok = (py > 0 ? 0x007u : 0u) | 0x038u | (py + 1 < a.H ? 0x1c0u : 0u);
         const unsigned colok = (px > 0 ? 0x049u : 0u) | 0x092u | (px + 1 < a.W ? 0x124u : 0u);
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
         cw_bf16x8 xf[2][3];
         auto read_blk = [&](int blk, cw_bf16x8 (&xv)[3]) {
           const bool ok = (vmask >> (tapinfo[blk] & 15)) & 1u;
-          const int off = ok ? base + (tapinfo[blk] >> 4) : zrow;     // (the zero row is zero in every channel: no channel offset needed)
+          const int off = ok ? base + (tapinfo[blk] >> 4) : zpos;     // (any channel group's zero position will do)
 #pragma unroll
           for (int q = 0; q < 3; ++q) xv[q] = *reinterpret_cast<const cw_bf16x8*>(buf + q * plane + off);
         };
@@ -240,20 +245,19 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
   if (prev >= 0) flush(prev);
 }
 
-static int cw_odd16(int units) { return units | 1; }
-
 // samples per group for the register-weight kernel (0: the shape is not served by it)
-static int conv_wreg_plan(int cin, int cout, int H, int W, int* xrow, int* img_bytes, int64_t* lds) {
+static int conv_wreg_plan(int cin, int cout, int H, int W, int* cgs, int* img_bytes, int64_t* lds) {
   const int HW = H * W;
   if (!((cin == 16 || cin == 32) && (cout == 16 || cout == 32 || cout == 64)) || HW > 64 || HW < 1 ||
       ((cin * HW) & 3) || ((cout * HW) & 3)) return 0;
-  const int cp = cin, wpc = 8 / ((cout + 15) / 16);
-  *xrow = cw_odd16(cp / 8) * 16;
+  const int wpc = 8 / ((cout + 15) / 16);
+  auto group_bytes = [&](int S) { return (int64_t)(((S * HW + 1) * 16 + 255) / 256 * 256); };
   int best = 0; double best_eff = 0.0;
   for (int S = 1; S <= 16; ++S) {
     const int nrt = (S * HW + 15) / 16;
     if (nrt > 4 * wpc) break;
-    const int64_t plane = ((int64_t)(S * HW + 1) * (*xrow) + 15) / 16 * 16;
+    const int64_t plane = (cin / 8) * group_bytes(S);
+    if (plane >= 128 * 1024) break;                                  // (staging offsets are 16-bit counts of 2 bytes)
     const int64_t bytes = 6 * plane + (int64_t)S * cout * HW * 4;
     if (bytes > 158 * 1024) break;
     if (((int64_t)S * cin * HW / 4 + 511) / 512 > 4) break;
@@ -263,16 +267,16 @@ static int conv_wreg_plan(int cin, int cout, int H, int W, int* xrow, int* img_b
     if (eff >= best_eff - 1e-9) { best_eff = eff; best = S; }
   }
   if (best == 0 || best_eff < 0.7) return 0;
-  const int64_t plane = ((int64_t)(best * HW + 1) * (*xrow) + 15) / 16 * 16;
-  *img_bytes = (int)plane;
-  *lds = 6 * plane + (int64_t)best * cout * HW * 4;
+  *cgs = (int)group_bytes(best);
+  *img_bytes = (cin / 8) * (*cgs);
+  *lds = 6LL * (*img_bytes) + (int64_t)best * cout * HW * 4;
   return best;
 }
 
 int conv2d_same_wreg_fits(int64_t cin, int64_t cout, int64_t H, int64_t W) {
-  int xrow, ib; int64_t lds;
+  int cgs, ib; int64_t lds;
   if (cin > 64 || cout > 64 || H * W > 256 || cin < 1 || cout < 1) return 0;
-  return conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &xrow, &ib, &lds);
+  return conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &cgs, &ib, &lds);
 }
 
 // returns 1 when the launch was made, 0 when the shape is not served (the caller uses the first kernel), < 0 on error
@@ -284,7 +288,7 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   if (!enabled) return 0;
   ConvWArgs a;
   int64_t lds = 0;
-  const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.xrow, &a.img_bytes, &lds) : 0;
+  const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
   if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul))) return 0;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W;
