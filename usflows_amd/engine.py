@@ -294,13 +294,14 @@ class FlowEngine:
         self.f16_fallbacks = 0          # number of such passes (tests / diagnostics)
         # use_planes: None = automatic, True / False = forced (USFLOWS_AMD_PLANES=1 / 0).  Automatic: "f16x2" mode from
         # planes_min_rows rows; "bf16x3" mode from planes_min_rows_bf16x3 rows (measured on MI355X, cfg2, ms per step
-        # planes / fp32-activation kernels: 8192 4.38 / 4.04, 16384 6.79 / 6.42, 32768 9.80 / 9.71, 65536 18.74 / 19.24),
+        # planes / fp32-activation kernels, round 3, same box: 16384 6.77 / 6.55-6.78, 24576 7.48 / 7.75, 32768 9.71 / 9.91
+        # -- the per-rank shard of the 8-GPU configuration cfg3 --, 40960 14.05 / 14.30, 65536 18.8 / 19.2),
         # or from planes_min_rows when a conditioner is too wide / deep for the fused coupling kernels (cfg4, hidden 1024:
         # 176.6 vs 215.8 ms at 32768 rows)
         env_planes = os.environ.get("USFLOWS_AMD_PLANES", "auto")
         self.use_planes = None if env_planes == "auto" else env_planes != "0"
         self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
-        self.planes_min_rows_bf16x3 = 49152
+        self.planes_min_rows_bf16x3 = 24576
         self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
         self.graph_max_rows = 1024
         self._layout_from_masks()
