@@ -237,7 +237,7 @@ def test_gated_conv_module_on_device_vs_torch(B, C, ch, H, W):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", image_case_names())
 def test_small_batch_layer_loop_replays_a_hip_graph(name):
-    """log_prob of <= 256 rows of an image-shaped flow: captured once per (shape, parameter versions), replayed afterwards --
+    """log_prob of <= 256 rows of an image-shaped flow: captured once per (shape, parameter versions) -- at its second sighting --, replayed afterwards --
     bit-equal to the eager loop, recaptured after an in-place parameter update, a second shape gets a graph of its own"""
     flow, a = load_image_case(name, device="cuda:0")
     x = a["x"].to("cuda:0")
@@ -250,6 +250,8 @@ def test_small_batch_layer_loop_replays_a_hip_graph(name):
         g2 = flow.log_prob(x)
         assert len(flow._loop_graphs) == 1 and not getattr(flow, "_loop_graph_off", False)
         assert torch.equal(g1, eager) and torch.equal(g2, eager)
+        # (a (shape, parameter version) pair is captured the second time it is seen: the first call runs the eager loop)
+        assert torch.equal(flow.log_prob(x[: x.shape[0] // 2]), eager_half) and len(flow._loop_graphs) == 1
         assert torch.equal(flow.log_prob(x[: x.shape[0] // 2]), eager_half) and len(flow._loop_graphs) == 2
         for p in flow.parameters():
             if p.numel() > 1:
@@ -258,6 +260,7 @@ def test_small_batch_layer_loop_replays_a_hip_graph(name):
         eager2 = flow.log_prob(x)
         flow.graph_max_rows = 256
         assert torch.equal(flow.log_prob(x), eager2) and not torch.equal(eager2, eager)
+        assert torch.equal(flow.log_prob(x), eager2)            # second sighting of the new versions: recaptured, replayed
     # under autograd the eager (composite) loop serves the call
     lp = flow.log_prob(x)
     assert lp.requires_grad

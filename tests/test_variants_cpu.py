@@ -60,3 +60,40 @@ def test_every_baseline_planes_instantiation_is_parity_tested():
     for cfg, lst in shapes.BASELINE_PLANES_SHAPES.items():
         for s in lst:
             assert _planes_variant(*s) in tested, (cfg, s)
+
+
+def test_cfg1_moons_plumbing_on_cpu():
+    """BASELINE configs[0] (plumbing, no GPU): the 2-D moons data set (datasets.py:181-183: sklearn make_moons, noise 0.05),
+    USFlow(in_dims=[2], 4 additive coupling blocks, ConditionalDenseNN [32, 32] + ReLU, Laplace base), batch 4096 through
+    the CPU formulation of the mirror: log_prob / backward / _forward against the oracle, the UDL constant, and a short
+    Flow.fit that lowers the loss"""
+    import numpy as np
+    import torch
+    from sklearn.datasets import make_moons
+    from oracle import usflows_oracle as orc
+    from usflows_amd.synth import build_usflow
+    xs, _ = make_moons(n_samples=4096, noise=0.05, random_state=0)
+    x = torch.from_numpy(xs.astype(np.float32))
+    spec = orc.FlowSpec(2, 4, [32, 32], householder=1, negative_slope=0.0, conditioner="ConditionalDenseNN", base="laplace")
+    sd = orc.synth_state_dict(spec, seed=1, alpha=0.3)
+    flow = build_usflow(spec, sd, device="cpu")
+    with torch.no_grad():
+        lp, z = flow.log_prob(x), flow.backward(x)
+        xr = flow._forward(z)
+    sd64 = orc.to_dtype(sd, torch.float64)
+    ref = orc.flow_log_prob(sd64, spec, x.double())
+    assert ((lp.double() - ref).abs() / ref.abs()).max().item() < 1e-5
+    assert (z.double() - orc.flow_backward(sd64, spec, x.double())).abs().max().item() < 1e-4
+    assert (xr - x).abs().max().item() < 1e-4
+    const = lp.double() - torch.distributions.Laplace(0.0, 1.0).log_prob(z.double()).sum(-1)
+    assert (const + float(orc.total_ladj(sd64, spec))).abs().max().item() < 1e-5      # uniformly scaling: one constant
+
+    class DS:
+        def __len__(self):
+            return x.shape[0]
+
+        def __getitem__(self, i):
+            return (x[i],)
+
+    losses = flow.fit(DS(), torch.optim.Adam, dict(lr=2e-3), batch_size=256, shuffle=False, device=torch.device("cpu"), epochs=3)
+    assert losses[-1] < losses[0]

@@ -655,9 +655,9 @@ def flush_jobs() -> None:
 
 
 def pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
-    transpose = int(transpose) | (2 if (planes is not None and planes.dtype == torch.float16) else 0)   # bit 1: fp16x2 planes
     """usf_pack_weight_f32: src fp64/fp32 2-D (or 1-D = one row) device tensor; W [n_out, ldw] fp32 and/or planes
     [3, n_out, ldp] bf16 (preallocated).  Inside a ``batch_jobs`` block the call is queued, not launched."""
+    transpose = int(transpose) | (2 if (planes is not None and planes.dtype == torch.float16) else 0)   # bit 1: fp16x2 planes
     if src.dtype not in (torch.float32, torch.float64):
         raise ValueError("pack_weight: source must be fp32 or fp64")
     if ld_src is None:

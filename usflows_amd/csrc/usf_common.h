@@ -26,6 +26,24 @@ static inline int check_launch(const char* what) {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Per-device launch state (a process may drive several GPUs: function attributes and the CU count belong to a device)
+#define USF_MAX_DEVICES 64
+static inline int current_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= USF_MAX_DEVICES) dev = 0;
+  return dev;
+}
+// compute units of the current device (cached per device; 256 when the query fails)
+static inline int device_cu_count() {
+  static int cus[USF_MAX_DEVICES] = {0};
+  const int dev = current_device_slot();
+  if (cus[dev] <= 0) {
+    hipDeviceProp_t prop;
+    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
 // leaky_relu exactly as ATen: x > 0 ? x : x * slope
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   return (act == USF_ACT_LEAKY_RELU) ? (v > 0.0f ? v : v * slope) : v;

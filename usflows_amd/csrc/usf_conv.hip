@@ -339,7 +339,8 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
     lds = conv_lds_bytes(a.cin, a.cout, a.H, a.W, a.ks, S, &a.xs16, &a.ws16, &a.cp, &a.kp, &a.coutp);
   }
   a.S = S;
-  static bool attr_done = false;
+  static bool attr_done_dev[USF_MAX_DEVICES] = {false};      // (the attribute belongs to the device)
+  bool& attr_done = attr_done_dev[current_device_slot()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_same_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
@@ -348,11 +349,7 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
     }
     attr_done = true;
   }
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cu_count();
   const int64_t ngroups = (B + S - 1) / S;
   const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
   hipLaunchKernelGGL(conv2d_same_bf16x3_kernel, dim3(grid), dim3(512), (size_t)lds, stream, a);

@@ -297,17 +297,14 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   a.S = S; a.in_act = in_act; a.out_act = out_act; a.in_slope = in_slope; a.out_slope = out_slope;
   a.mHW = (unsigned)(0x100000000ULL / (uint64_t)(H * W)) + 1u; a.mW = (unsigned)(0x100000000ULL / (uint64_t)W) + 1u;
   a.mSE = (unsigned)(0x100000000ULL / (uint64_t)(cin * H * W)) + 1u;
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
+  const int cus = device_cu_count();
   const int64_t ngroups = (B + S - 1) / S;
   const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
   const int nct = a.coutp / 16;
 #define USF_CW(NB_, CP_, NCT_)                                                                                     \
   do {                                                                                                              \
-    static bool attr_done = false;                                                                                  \
+    static bool attr_done_dev[USF_MAX_DEVICES] = {false};                                                           \
+    bool& attr_done = attr_done_dev[current_device_slot()];                                                         \
     if (!attr_done) {                                                                                               \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_same_wreg_kernel<NB_, CP_, NCT_>),              \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {              \

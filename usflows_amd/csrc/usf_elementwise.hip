@@ -113,9 +113,14 @@ int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base
 #define USF_LAUNCH_BASE(B)                                                                                            \
   do {                                                                                                                \
     if (tab > 64 * 1024) {                                                                                            \
-      static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&base_logprob_kernel<B>),   \
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   \
-      if (attr_rc != hipSuccess) { set_error("usf_base_logprob_f32: cannot raise the LDS limit"); return (int)attr_rc; } \
+      static bool attr_done_dev[USF_MAX_DEVICES] = {false};      /* (the attribute belongs to the device) */             \
+      bool& attr_done = attr_done_dev[current_device_slot()];                                                         \
+      if (!attr_done) {                                                                                               \
+        const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&base_logprob_kernel<B>),        \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);        \
+        if (attr_rc != hipSuccess) { set_error("usf_base_logprob_f32: cannot raise the LDS limit"); return (int)attr_rc; } \
+        attr_done = true;                                                                                             \
+      }                                                                                                               \
     }                                                                                                                 \
     hipLaunchKernelGGL((base_logprob_kernel<B>), g, b, tab, stream, z, ldz, (int)M, (int)D, loc, scale, logdet_const, \
                        logdet_dev, logp, sum_out);                                                                                \

@@ -492,13 +492,10 @@ static int launch_planes(PlArgs a, bool f32out, hipStream_t stream) {
   int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
   if (grid > 0x7fffffffLL) { set_error("usf_gemm_planes: grid too large"); return -3; }
   a.nvb = (int)grid;
-  static int cus = -1, persist = -1;
-  if (cus < 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    cus = (cus / 8) * 8 > 0 ? (cus / 8) * 8 : 8;
-    const char* e = getenv("USF_PLANES_PERSIST"); persist = e ? atoi(e) : 1;       // tuning aid: 0 = one block per tile
-  }
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("USF_PLANES_PERSIST"); persist = e ? atoi(e) : 1; }      // tuning aid: 0 = one block per tile
+  int cus = device_cu_count();
+  cus = (cus / 8) * 8 > 0 ? (cus / 8) * 8 : 8;
   if (persist && grid > cus) grid = cus;
   if (f32out) hipLaunchKernelGGL((gemm_planes_kernel<NPL, TN, true>), dim3((unsigned)grid), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL((gemm_planes_kernel<NPL, TN, false>), dim3((unsigned)grid), dim3(512), 0, stream, a);

@@ -293,6 +293,15 @@ class Flow(torch.nn.Module):
         key = (tuple(x.shape), str(x.device))
         hit = cache.get(key)
         if hit is None or hit[0] != ver:
+            # hysteresis: a capture costs two warm-up passes and a capture pass -- several eager calls' worth.  A (shape,
+            # parameter version) pair is captured the SECOND time it is seen; a caller that alternates one optimiser step with
+            # one small evaluation (new versions every call) keeps the eager loop and pays nothing.
+            seen = self.__dict__.setdefault("_loop_graph_seen", {})
+            if seen.get(key) != ver:
+                seen[key] = ver
+                if len(seen) > 16:
+                    seen.pop(next(iter(seen)))
+                return None
             try:
                 with torch.no_grad():
                     static_x = x.detach().clone()
@@ -452,7 +461,7 @@ class Flow(torch.nn.Module):
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             self._fit_epochs(model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses)
         if side is not None:
-            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.current_stream(device).wait_stream(self.__dict__.get("_fit_stream", side))
         return epoch_losses
 
     def _fit_epochs(self, model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses):
@@ -581,6 +590,8 @@ class Flow(torch.nn.Module):
             st["ctx"].copy_(noise)
         st["graph"].replay()
         st["replays"] += 1
+        if hasattr(optim, "note_graph_replays"):
+            optim.note_graph_replays(1)             # (SophiaG's per-parameter step counters live on the host)
         for p in st["params"]:
             torch.autograd.graph.increment_version(p)      # a replay runs no Python: tell the version-keyed caches
         return float(st["loss"])
@@ -590,10 +601,18 @@ class Flow(torch.nn.Module):
         parameter pack for refreshed (the refreshing launches were only recorded, then discarded) and the training path
         its tapes for current.  Drop every cache keyed on them -- the next (eager) step rebuilds from the parameters'
         actual values -- and make sure the device is out of capture mode."""
-        try:
-            torch.cuda.synchronize()
-        except Exception:               # noqa: BLE001
-            pass
+        dev = params[0].device if params else None
+        for _ in range(2):              # (the first call may report -- and thereby clear -- the capture's sticky error)
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:           # noqa: BLE001
+                pass
+        if dev is not None and dev.type == "cuda" and torch.cuda.current_stream(dev) == self.__dict__.get("_fit_stream"):
+            # the capture ran on the loop's own stream and leaves it invalidated: the rest of the loop moves to a fresh one
+            # (Flow.fit's stream context restores the caller's stream on exit whatever the current one is by then)
+            fresh = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(fresh)
+            self.__dict__["_fit_stream"] = fresh
         eng = getattr(self, "_engine_obj", None)
         if eng is not None:
             eng._pack, eng._pack_key = None, None

@@ -109,6 +109,16 @@ class SophiaG(Optimizer):
                 dev, n = self._table(gi, hip)
                 _ext.sophiag_hessian(dev, n, beta2=beta2)
 
+    def note_graph_replays(self, n: int = 1) -> None:
+        """A hipGraph replay of a captured training step (Flow.fit) runs the update kernels but no Python: the per-parameter
+        ``state['step']`` counters (CPU tensors, bumped by ``step()``) do not move.  Flow.fit reports every replay here so
+        that ``state_dict()`` stays interchangeable with the reference's (sophia.py:151-163)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st is not None and "step" in st and p.grad is not None:
+                    st["step"] += n
+
     @torch.no_grad()
     def step(self, closure=None, bs=5120):
         loss = None
