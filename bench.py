@@ -490,7 +490,7 @@ def main():
 # ----------------------------------------------------------------------------------------------------------------------
 # image-shaped flows
 # ----------------------------------------------------------------------------------------------------------------------
-_IMAGE_KERNELS = ("usf_conv2d_same_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
+_IMAGE_KERNELS = ("usf_conv2d_same_f32", "usf_conv2d_same_res_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
                   "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32")
 
 
@@ -502,6 +502,9 @@ def _image_launch_cost(name, a):
         flops = 2.0 * B * H * W * cin * cout * ks * ks
         byts = 4.0 * B * H * W * (cin + (gc if gc else cout) + (gc if gc else 0))        # gated: + the gate's skip input, C outputs
         return ("conv2d_same", cin, cout, ks, H, W, bool(gc)), flops, byts
+    if name == "usf_conv2d_same_res_f32":    # (x, y, B, cin, cout, H, W, ks, planes, bias, in_mul, in_act, in_slope, res_x, res_mul, res_sign, stream)
+        B, cin, cout, H, W, ks = int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7])
+        return ("conv2d_same+residual", cin, cout, ks, H, W), 2.0 * B * H * W * cin * cout * ks * ks, 4.0 * B * H * W * (cin + 2 * cout)
     if name == "usf_channel_affine_f32":     # (x, y, B, C, P, W, pre_sub, bias, stream)
         B, C, P = int(a[2]), int(a[3]), int(a[4])
         return ("channel_affine", C, P), 2.0 * B * P * C * C, 8.0 * B * P * C
@@ -609,7 +612,7 @@ def main_image(args, under_launcher):
         c = classes[dom]
         avg_ms = c["ms"] / c["n"]
         mfma_peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
-        t_mfma = c["flops"] / (mfma_peak * 1e12) if dom[0] == "conv2d_same" else 0.0       # only the convolution runs on the matrix cores
+        t_mfma = c["flops"] / (mfma_peak * 1e12) if dom[0].startswith("conv2d_same") else 0.0   # only the convolutions run on the matrix cores
         t_hbm = c["bytes"] / (HBM_PEAK_GBS * 1e9)
         total_ms = sum(v["ms"] for v in classes.values())
         per_kernel = {"/".join(str(p_) for p_ in k): {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["n"] // args.steps,

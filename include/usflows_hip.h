@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 20
+#define USF_ABI_VERSION 21
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -281,6 +281,15 @@ int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_
 int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                         const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
                         int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, usf_stream_t stream);
+/* The LAST convolution of a coupling layer's conditioner with MaskedCoupling's masked residual (transforms.py:277-306) in
+ * its output stream:  y = res_x + res_sign * (res_mul * conv(in_act(x) * in_mul)),  res_x [B, cout, H, W] (the coupling's
+ * input), res_mul [cout * H * W] = 1 - mask -- the arithmetic of usf_conv2d_same_f32 followed by usf_masked_residual_f32,
+ * without the conditioner's output tensor ever reaching HBM.  Returns 0 when done, 1 when this shape is not served by the
+ * fused form (3 x 3 kernel, 16 / 32 input channels, 16 / 32 / 64 output channels, H W <= 64, 16-byte aligned tensors):
+ * the caller then runs the two entry points one after the other; < 0: error. */
+int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                            const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                            const float* res_x, const float* res_mul, float res_sign, usf_stream_t stream);
 
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */

@@ -607,3 +607,31 @@ def test_conv2d_same_kernel_full_batch(cin, cout, ks):
     ref = F.conv2d(F.relu(x[rows].double()), w.double(), b.double(), padding=ks // 2)
     err = (got[rows.to("cuda:0")].cpu().double() - ref).abs().max().item()
     assert err < 3e-6 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,H,W", [(3, 32, 16, 7, 7), (4099, 32, 16, 7, 7), (65536, 32, 16, 7, 7), (130, 16, 32, 8, 8)])
+def test_conv2d_with_masked_residual_equals_the_two_passes(B, cin, cout, H, W):
+    """usf_conv2d_same_res_f32 (the conditioner's last convolution with MaskedCoupling's residual x +- (1 - mask) t in its
+    output stream) against usf_conv2d_same_f32 followed by usf_masked_residual_f32: the same arithmetic, bit for bit; and
+    shapes the fused form does not serve are refused with the documented code (the caller then runs the two passes)"""
+    from usflows_amd import _ext
+    _ext.load()
+    g = torch.Generator().manual_seed(B + cin + cout)
+    x = (torch.randn(B, cin, H, W, generator=g) * 2).to("cuda:0")
+    rx = torch.randn(B, cout, H, W, generator=g).to("cuda:0")
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g).to("cuda:0")
+    om = (torch.rand(cout * H * W, generator=g) > 0.5).float().to("cuda:0")
+    planes = _ext.conv2d_weight_planes(w.to("cuda:0"))
+    for sign in (1.0, -1.0):
+        fused = _ext.conv2d_same_res(x, planes, cout, 3, rx, om, sign, bias=b, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.0)
+        assert fused is not None
+        t = _ext.conv2d_same(x, planes, cout, 3, bias=b, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.0)
+        two = _ext.masked_residual(rx, t, om, sign)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, two)
+    # 48 output channels / a 1 x 1 kernel: not served by the fused form
+    w48 = torch.randn(48, cin, 3, 3, generator=g).to("cuda:0")
+    assert _ext.conv2d_same_res(x, _ext.conv2d_weight_planes(w48), 48, 3, torch.zeros(B, 48, H, W, device="cuda:0"),
+                                torch.zeros(48 * H * W, device="cuda:0"), 1.0) is None

@@ -17,7 +17,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 20
+USF_ABI_VERSION = 21
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -166,6 +166,8 @@ SYMBOLS = {
     "usf_conv2d_same_fits": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "usf_conv2d_same_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
                                       C.c_int32, C.c_float, C.c_int32, C.c_float, _fp, C.c_int64, C.c_void_p]),
+    "usf_conv2d_same_res_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
+                                          C.c_int32, C.c_float, _fp, _fp, C.c_float, C.c_void_p]),
     "usf_masked_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -498,6 +500,21 @@ def conv2d_same(x, planes, cout, ks, bias=None, in_mul=None, in_act=ACT_NONE, in
     _direct("usf_conv2d_same_f32", x.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, planes.data_ptr(), ptr(bias),
                                      ptr(in_mul), int(in_act), float(in_slope), int(out_act), float(out_slope),
                                      ptr(gate_x), gc, current_stream(x.device))
+    return y
+
+
+def conv2d_same_res(x, planes, cout, ks, res_x, res_mul, res_sign, bias=None, in_mul=None, in_act=ACT_NONE, in_slope=0.0):
+    """usf_conv2d_same_res_f32: the conditioner's last convolution with MaskedCoupling's residual in its output stream ->
+    res_x + res_sign * (res_mul * conv(x)) as a new tensor, or None when the fused form does not serve the shape"""
+    B, cin, H, W = x.shape
+    y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    fn = load().usf_conv2d_same_res_f32
+    args = (x.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, planes.data_ptr(), ptr(bias), ptr(in_mul), int(in_act),
+            float(in_slope), res_x.data_ptr(), res_mul.data_ptr(), float(res_sign), current_stream(x.device))
+    rc = _timed_call(fn, args, "usf_conv2d_same_res_f32")
+    if rc == 1:
+        return None
+    check(rc, "usf_conv2d_same_res_f32")
     return y
 
 

@@ -58,6 +58,9 @@ int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out);
 int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 int64_t conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
 int conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
+int conv2d_same_res(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                    const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                    const float* res_x, const float* res_mul, float res_sign, hipStream_t stream);
 int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                 const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
                 int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, hipStream_t stream);
@@ -238,6 +241,12 @@ int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_
                         int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, usf_stream_t stream) {
   return usf::conv2d_same(x, y, B, cin, cout, H, W, ks, w_planes, bias, in_mul, in_act, in_slope, out_act, out_slope,
                           gate_x, gate_channels, (hipStream_t)stream);
+}
+int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                            const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                            const float* res_x, const float* res_mul, float res_sign, usf_stream_t stream) {
+  return usf::conv2d_same_res(x, y, B, cin, cout, H, W, ks, w_planes, bias, in_mul, in_act, in_slope, res_x, res_mul, res_sign,
+                              (hipStream_t)stream);
 }
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   return usf::wgrad_variant(M, N, K, ldy, lda, mode);

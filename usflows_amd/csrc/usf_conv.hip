@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
 // second kernel (usf_conv_wreg.hip): 1 = launched, 0 = shape not served there, < 0 = error
 int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
                      const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
-                     hipStream_t stream);
+                     const float* res_x, const float* res_mul, float res_sign, hipStream_t stream);
 
 static int odd16(int units) { return units | 1; }
 // register-staged iterations per thread for a group of S samples (the kernel holds at most 16 pixel pairs per thread)
@@ -315,7 +315,8 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
     if (act != USF_ACT_NONE && act != USF_ACT_LEAKY_RELU) { set_error("usf_conv2d_same_f32: bad act"); return -2; }
   if (ks == 3 && !gate_x) {
     // the register-weight kernel where it serves the shape (the conditioner layers of the reference's image configurations)
-    const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, bias, in_mul, in_act, in_slope, out_act, out_slope, stream);
+    const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, bias, in_mul, in_act, in_slope, out_act, out_slope, nullptr,
+                                    nullptr, 0.f, stream);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   ConvArgs a;
@@ -354,6 +355,23 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
   hipLaunchKernelGGL(conv2d_same_bf16x3_kernel, dim3(grid), dim3(512), (size_t)lds, stream, a);
   return check_launch("usf_conv2d_same_f32");
+}
+
+// y = res_x + res_sign * (res_mul * conv(...)): the last convolution of a coupling's conditioner with MaskedCoupling's
+// residual in its output stream.  Only where the register-weight kernel serves the shape: 0 = done, 1 = not served here (the
+// caller runs the convolution and usf_masked_residual_f32 as two passes), < 0 = error.
+int conv2d_same_res(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                    const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
+                    const float* res_x, const float* res_mul, float res_sign, hipStream_t stream) {
+  if (B < 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || B > 0x7fffffff) { set_error("usf_conv2d_same_res_f32: bad sizes"); return -2; }
+  if (B == 0) return 0;
+  if (!x || !y || !wplanes || !res_x || !res_mul) { set_error("usf_conv2d_same_res_f32: null pointer"); return -1; }
+  if (x == y || res_x == y) { set_error("usf_conv2d_same_res_f32: in-place operation is not supported"); return -2; }
+  if (in_act != USF_ACT_NONE && in_act != USF_ACT_LEAKY_RELU) { set_error("usf_conv2d_same_res_f32: bad act"); return -2; }
+  if (ks != 3) return 1;
+  const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, bias, in_mul, in_act, in_slope, USF_ACT_NONE, 0.f, res_x, res_mul,
+                                  res_sign, stream);
+  return rc < 0 ? rc : (rc == 1 ? 0 : 1);
 }
 
 }  // namespace usf

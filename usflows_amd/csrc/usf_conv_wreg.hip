@@ -39,6 +39,8 @@ struct ConvWArgs {
   int cgs;                     // bytes of one channel group (8 channels) of an image plane: (S * HW positions + the zero one) * 16, rounded up to 256
   int img_bytes;               // bytes of one plane of one image buffer: (cin / 8) * cgs
   int in_act, out_act; float in_slope, out_slope;
+  const float* res_x; const float* res_mul; float res_sign;   // y = res_x + res_sign * (res_mul * conv): MaskedCoupling's residual, or null
+  unsigned mSO;                // magic of cout * H W
   int dbg;                     // tuning aid (USF_CONVW_DBG; wrong results): 1 no staging, 2 no k loop, 4 no output flush, 8 no input loads,
                                // 16 no staging-area writes, 32 no barriers
   unsigned mHW, mW, mSE;       // floor(2^32 / d) + 1 for d = H W, W, cin H W: n / d == umulhi(n, m) for n < 2^16
@@ -163,6 +165,23 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
     const int s0 = gidx * a.S;
     const int n4 = min(a.S, a.B - s0) * a.cout * HW / 4;
     f32x4* yg = reinterpret_cast<f32x4*>(a.y + (size_t)s0 * a.cout * HW);
+    if (a.res_x) {
+      // MaskedCoupling's residual (transforms.py:277-306) joined to the output stream: x +- (1 - mask) * t in the arithmetic of
+      // usf_masked_residual_f32 (x + sign * (om * t)) -- the [B, C, H, W] tensor t never reaches HBM
+      const int so = a.cout * HW;
+      const f32x4* xg = reinterpret_cast<const f32x4*>(a.res_x + (size_t)s0 * so);
+      for (int f = tid; f < n4; f += 512) {
+        const int e0 = 4 * f;
+        const f32x4 om = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ostage + e0);
+        const f32x4 xv = xg[f];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = xv[j] + a.res_sign * (om[j] * t[j]);
+        yg[f] = o;
+      }
+      return;
+    }
     for (int f = tid; f < n4; f += 512) yg[f] = *reinterpret_cast<const f32x4*>(ostage + 4 * f);
   };
 
@@ -280,14 +299,17 @@ int conv2d_same_wreg_fits(int64_t cin, int64_t cout, int64_t H, int64_t W) {
 // returns 1 when the launch was made, 0 when the shape is not served (the caller uses the first kernel), < 0 on error
 int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
                      const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
-                     hipStream_t stream) {
+                     const float* res_x, const float* res_mul, float res_sign, hipStream_t stream) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("USF_CONV_WREG"); enabled = e ? atoi(e) : 1; }     // tuning aid: 0 = first kernel only
   if (!enabled) return 0;
   ConvWArgs a;
   int64_t lds = 0;
   const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
-  if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul))) return 0;
+  if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul)) ||
+      (res_x && (!res_mul || !aligned16(res_x) || !aligned16(res_mul) || res_x == y))) return 0;
+  a.res_x = res_x; a.res_mul = res_mul; a.res_sign = res_sign;
+  a.mSO = (unsigned)(0x100000000ULL / (uint64_t)(cout * H * W)) + 1u;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W;
   a.coutp = (int)((cout + 15) / 16 * 16); a.kp = (int)((9 * cin + 31) / 32 * 32);

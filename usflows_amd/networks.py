@@ -259,8 +259,11 @@ def _pointwise_hip(conv, x, in_act=None, gate_x=None, post=None):
                                gate_x=None if gate_x is None else gate_x.contiguous(), ln=ln)
 
 
-def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None):
-    """usf_conv2d_same_f32 for an nn.Conv2d (weight planes cached per parameter version); in_act / out_act: (id, slope)"""
+def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None, residual=None):
+    """usf_conv2d_same_f32 for an nn.Conv2d (weight planes cached per parameter version); in_act / out_act: (id, slope);
+    residual = (res_x, one_minus_mask, sign): MaskedCoupling's residual joined to the convolution's output stream
+    (usf_conv2d_same_res_f32) where the shape allows -- the result is then the coupling's output, flagged by the caller's
+    second return value"""
     from . import _ext
     key = (conv.weight.data_ptr(), conv.weight._version, str(x.device))
     cache = getattr(conv, "_usf_planes", None)
@@ -270,8 +273,15 @@ def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None):
     ia, isl = in_act if in_act is not None else (_ext.ACT_NONE, 0.0)
     oa, osl = out_act if out_act is not None else (_ext.ACT_NONE, 0.0)
     bias = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
-    return _ext.conv2d_same(x.contiguous(), cache[1], conv.out_channels, conv.kernel_size[0], bias=bias, in_mul=in_mul,
-                            in_act=ia, in_slope=isl, out_act=oa, out_slope=osl)
+    if residual is not None and out_act is None and os.environ.get("USF_CONV_RES", "1") != "0":
+        rx, om, sign = residual
+        y = _ext.conv2d_same_res(x.contiguous(), cache[1], conv.out_channels, conv.kernel_size[0], rx.contiguous(), om, sign,
+                                 bias=bias, in_mul=in_mul, in_act=ia, in_slope=isl)
+        if y is not None:
+            return y, True
+    out = _ext.conv2d_same(x.contiguous(), cache[1], conv.out_channels, conv.kernel_size[0], bias=bias, in_mul=in_mul,
+                           in_act=ia, in_slope=isl, out_act=oa, out_slope=osl)
+    return (out, False) if residual is not None else out
 
 
 class LayerNormChannels(nn.Module):
@@ -403,13 +413,17 @@ class ConvNet2D(nn.Module):
         layers += [conv(c_hidden, c_out)]
         self.nn = nn.Sequential(*layers)
 
-    def forward(self, x, context=None, in_mul=None):
+    def forward(self, x, context=None, in_mul=None, residual=None):
         """in_mul (device path only, see ``first_conv_on_device``): a [C * H * W] mask the FIRST convolution multiplies
-        into its input -- MaskedCoupling hands over the unmasked x and its mask instead of a masked copy"""
+        into its input -- MaskedCoupling hands over the unmasked x and its mask instead of a masked copy.
+        residual = (res_x, one_minus_mask, sign) (device path only): the caller is a MaskedCoupling that wants
+        res_x + sign * one_minus_mask * net(x); the return value is then (tensor, done) -- done: the LAST convolution
+        wrote the coupling's output itself (usf_conv2d_same_res_f32), otherwise tensor is net(x) as usual"""
         mods = list(self.nn)
         if not (x.is_cuda and x.dtype == torch.float32):
-            assert in_mul is None
+            assert in_mul is None and residual is None
             return self.nn(x)
+        done = False
         # the same module sequence on the device: convolutions on usf_conv2d_same_f32 (a nonlinearity behind a plain
         # convolution rides in its epilogue), a (Leaky)ReLU in front of a LayerNormChannels joins that layer's pass
         k = 0
@@ -422,7 +436,10 @@ class ConvNet2D(nn.Module):
                 after = mods[k + 2] if k + 2 < len(mods) else None
                 if fold is not None and isinstance(after, LayerNormChannels):
                     fold = None                                   # that ReLU belongs to the layer norm's pass
-                x = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, out_act=fold)
+                if residual is not None and k == len(mods) - 1 and fold is None:
+                    x, done = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, residual=residual)
+                else:
+                    x = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, out_act=fold)
                 k += 2 if fold is not None else 1
             elif isinstance(m, GatedConv) and _relu_kind(nxt) is not None and k + 2 < len(mods) \
                     and m.can_join_layernorm(x, mods[k + 2]):
@@ -435,7 +452,7 @@ class ConvNet2D(nn.Module):
                 assert not (k == 0 and in_mul is not None)
                 x = m(x)
                 k += 1
-        return x
+        return (x, done) if residual is not None else x
 
     def first_conv_on_device(self, x) -> bool:
         """True when forward(x, in_mul=mask) may be used: the first module is a convolution the HIP kernel serves"""

@@ -172,16 +172,20 @@ class MaskedCoupling(BaseTransform):
                 and self.mask.numel() == math.prod(x.shape[1:]) and use_hip(self, x, t)):
             return None
         from . import _ext
+        return _ext.masked_residual(x.contiguous(), t.contiguous(), self._one_minus_mask(x), sign)
+
+    def _one_minus_mask(self, x):
         key = (self.mask.data_ptr(), self.mask._version, str(x.device))
         cache = getattr(self, "_om_cache", None)
         if cache is None or cache[0] != key:
             om = (1 - self.mask).to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
             cache = self._om_cache = (key, om)
-        return _ext.masked_residual(x.contiguous(), t.contiguous(), cache[1], sign)
+        return cache[1]
 
-    def _conditioner_masked(self, x, context):
+    def _conditioner_masked(self, x, context, sign=None):
         """conditioner(x * mask); a ConvNet2D on the device takes x and the mask and multiplies inside its first
-        convolution's staging pass"""
+        convolution's staging pass.  sign (+-1.0, device image path): the conditioner may also write the coupling's output
+        x + sign * (1 - mask) * t from its last convolution -- returns (tensor, done)"""
         cond = self.conditioner
         if context is None and hasattr(cond, "first_conv_on_device") and x.dim() == 4 \
                 and self.mask.numel() == math.prod(x.shape[1:]) and use_hip(self, x) and cond.first_conv_on_device(x):
@@ -189,21 +193,28 @@ class MaskedCoupling(BaseTransform):
             cache = getattr(self, "_m_cache", None)
             if cache is None or cache[0] != key:
                 cache = self._m_cache = (key, self.mask.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous())
+            if sign is not None:
+                return cond(x, in_mul=cache[1], residual=(x, self._one_minus_mask(x), sign))
             return cond(x, in_mul=cache[1])
         x_masked = x * self.mask
-        return cond(x_masked) if context is None else cond(x_masked, context)
+        t = cond(x_masked) if context is None else cond(x_masked, context)
+        return (t, False) if sign is not None else t
 
     def forward(self, x, context=None):
         if self._hip_ok(x, context):
             return self._hip("forward", x, context)
-        t = self._conditioner_masked(x, context)
+        t, done = self._conditioner_masked(x, context, 1.0)
+        if done:
+            return t
         y = self._image_residual(x, t, 1.0)
         return y if y is not None else x + (1 - self.mask) * t
 
     def backward(self, y, context=None):
         if self._hip_ok(y, context):
             return self._hip("backward", y, context)
-        t = self._conditioner_masked(y, context)
+        t, done = self._conditioner_masked(y, context, -1.0)
+        if done:
+            return t
         x = self._image_residual(y, t, -1.0)
         return x if x is not None else y - (1 - self.mask) * t
 
