@@ -170,15 +170,26 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
       // usf_masked_residual_f32 (x + sign * (om * t)) -- the [B, C, H, W] tensor t never reaches HBM
       const int so = a.cout * HW;
       const f32x4* xg = reinterpret_cast<const f32x4*>(a.res_x + (size_t)s0 * so);
-      for (int f = tid; f < n4; f += 512) {
-        const int e0 = 4 * f;
-        const f32x4 om = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
-        const f32x4 t = *reinterpret_cast<const f32x4*>(ostage + e0);
-        const f32x4 xv = xg[f];
-        f32x4 o;
+      // (all of the thread's residual loads are in flight before the first one is used: a loop that waits for each in
+      //  turn pays the HBM latency four times per group)
+      constexpr int NF = 4;                              // host: S * cout * HW / 4 <= NF * 512
+      f32x4 xv[NF], om[NF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = xv[j] + a.res_sign * (om[j] * t[j]);
-        yg[f] = o;
+      for (int i = 0; i < NF; ++i) {
+        const int f = min(tid + 512 * i, n4 - 1), e0 = 4 * f;
+        xv[i] = xg[f];
+        om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int f = tid + 512 * i;
+        if (f < n4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(ostage + 4 * f);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = xv[i][j] + a.res_sign * (om[i][j] * t[j]);
+          yg[f] = o;
+        }
       }
       return;
     }
@@ -308,6 +319,7 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
   if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul)) ||
       (res_x && (!res_mul || !aligned16(res_x) || !aligned16(res_mul) || res_x == y))) return 0;
+  if (res_x && (int64_t)S * cout * H * W / 4 > 4 * 512) return 0;
   a.res_x = res_x; a.res_mul = res_mul; a.res_sign = res_sign;
   a.mSO = (unsigned)(0x100000000ULL / (uint64_t)(cout * H * W)) + 1u;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
