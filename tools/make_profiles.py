@@ -46,6 +46,9 @@ def run(cmd, **kw):
 SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "image"]
 
 
+B, D, H = 65536, 784, 256          # cfg2 shape (algorithmic byte counts of the traffic summaries)
+
+
 def want(name):
     return name in SECTIONS
 
@@ -129,7 +132,6 @@ if want("pmc"):
                 k = k[: k.index("(")] if "(" in k else k
                 agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 
-    B, D, H = 65536, 784, 256
     alg = {"gemm_planes_kernel": 2 * B * 800 * 6 + 3 * 800 * 800 * 2,          # planes in + planes out + weight planes (bf16x3)
            "coupling_planes_kernel": 3 * 13 * 32 * B * 6 + 3 * 2 * (H * 416 + H * H + 416 * H),
            "linear_bf16x3_kernel": 2 * B * D * 4 + 3 * D * 800 * 2,
