@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 21
+#define USF_ABI_VERSION 22
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -233,7 +233,8 @@ int usf_channel_affine_f32(const float* x, float* y, int64_t B, int64_t C, int64
  *   usf_gated_residual_f32:     y = x + vg[:, :C] * sigmoid(vg[:, C:]), vg [B, 2C, P]: GatedConv.forward (networks.py:108-122);
  *     CP = C * P.
  *   usf_masked_residual_f32:    y = x + sign * one_minus_mask * t, one_minus_mask [C * P] broadcast over the batch:
- *     MaskedCoupling.forward (+1) / backward (-1) on image-shaped inputs (transforms.py:277-306).
+ *     MaskedCoupling.forward (+1) / backward (-1) on image-shaped inputs (transforms.py:277-306).  x may be NULL (taken
+ *     as zeros: y = sign * one_minus_mask * t, the gradient of the layer with respect to t, or any broadcast mask product).
  */
 int usf_layernorm_channels_f32(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma,
                                const float* beta, float eps, int32_t act, float slope, usf_stream_t stream);
@@ -290,6 +291,35 @@ int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_
 int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                             const void* w_planes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
                             const float* res_x, const float* res_mul, float res_sign, usf_stream_t stream);
+
+/*
+ * Gradients of the image-shaped coupling layer's pieces: what torch autograd computes for networks.py:40-122, 405-510 and the
+ * 1 x 1 convolution of transforms.py:904-962 when Flow.fit (flows.py:113-210) trains an image flow.  All tensors contiguous
+ * fp32; sums over the batch are deterministic (per-wave partial sums in the caller's workspace, added in a fixed order).
+ *
+ * usf_conv_wgrad_f32: weight and bias gradient of a stride-1 "same" convolution with kernel ks = 1 or 3,
+ *     dW[co, ci, ky, kx] = sum_{b, p} dy[b, co, p] * xin[b, ci, p + (ky - ks/2, kx - ks/2)]     (nn.Conv2d weight layout [cout, cin, ks, ks])
+ *     db[co]             = sum_{b, p} dy[b, co, p]                                             (db may be NULL)
+ *   with xin = in_act(x - pre_sub[ci]) * in_mul -- the input transforms of usf_conv2d_same_f32 (in_act, in_mul) and of
+ *   usf_channel_affine_f32 (pre_sub), each optional -- and zeros outside the image.  Exact fp32 products and sums on
+ *   v_mfma_f32_16x16x4_f32.  Served: cin, cout multiples of 16 up to 64 (kernel 3: cin * cout <= 1536), H * W <= 64, 16-byte
+ *   aligned tensors; returns 1 (nothing written) for other shapes, 0 when done, < 0 on error.  workspace: at least
+ *   usf_conv_wgrad_workspace(...) floats (0 = shape not served).  The DATA gradient of these layers is the forward entry point
+ *   on the flipped, transposed weight (usf_conv2d_same_f32 / usf_pointwise_conv_f32 / usf_channel_affine_f32).
+ * usf_layernorm_channels_bwd_f32: backward of usf_layernorm_channels_f32 (same x, gamma, eps, act, slope):
+ *     dx [B, C, P]; dgamma_dbeta [2 C] = (sum dy * xhat, sum dy); workspace >= usf_layernorm_channels_bwd_workspace(B, C, P) floats.
+ * usf_gated_residual_bwd_f32: backward of usf_gated_residual_f32 with respect to vg: dvg [B, 2C, P] =
+ *     (dy * sigmoid(gate), dy * val * sigmoid(gate) * (1 - sigmoid(gate))); the gradient with respect to x is dy itself.
+ */
+int64_t usf_conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
+int usf_conv_wgrad_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                       const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
+                       float* workspace, int64_t workspace_floats, usf_stream_t stream);
+int64_t usf_layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P);
+int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma,
+                                   float eps, int32_t act, float slope, float* dgamma_dbeta, float* workspace,
+                                   int64_t workspace_floats, usf_stream_t stream);
+int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream);
 
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */

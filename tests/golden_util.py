@@ -112,3 +112,22 @@ def load_image_case(name, device="cpu"):
         flow = flow.to(device)
     arrays = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("sd/") and k != "spec"}
     return flow, arrays
+
+
+def image_grad_case_names():
+    """image cases with golden gradients of the real reference (tests/golden/make_golden_image_grads.py)"""
+    return sorted("image_" + os.path.basename(p)[len("imagegrads_"):-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "imagegrads_*.npz")))
+
+
+def load_image_grads(name):
+    """(loss, {parameter name: d(-log_prob(x).mean()) / d parameter}) of the reference's fp64 run on the case's x"""
+    z = np.load(os.path.join(GOLDEN_DIR, "imagegrads_" + name[len("image_"):] + ".npz"), allow_pickle=False)
+    return float(z["loss"]), {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}
+
+
+def load_image_fit(name):
+    """(training rows, per-epoch losses, state dict after the run) of the reference's Flow.fit on an image case:
+    2 epochs of SGD(lr=1e-3), batch 32, shuffle=True under numpy seed 5 (fp32 on the CPU)"""
+    z = np.load(os.path.join(GOLDEN_DIR, "imagefit_" + name[len("image_"):] + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd

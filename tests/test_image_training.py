@@ -1,0 +1,291 @@
+"""Training of image-shaped flows on the device (SURVEY rows N2 x N4; usflows_amd/image_training.py): the gradient kernels
+against fp64 torch autograd of the same expressions, whole-flow gradients and a Flow.fit run against the REAL reference
+(tests/golden/imagegrads_*.npz, imagefit_*.npz; made by tests/golden/make_golden_image_grads.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import image_grad_case_names, load_image_case, load_image_fit, load_image_grads
+
+DEV = "cuda:0"
+
+
+def _close(got, want, tol=1e-5, what=""):
+    want = want.double().cpu()
+    got = got.double().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    s = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item()
+    assert err <= tol * s, f"{what}: max abs err {err:.3e} vs scale {s:.3e} (rel {err / s:.2e})"
+
+
+@pytest.mark.parametrize("name", image_grad_case_names())
+def test_mirror_autograd_matches_reference_gradients_cpu(name):
+    """the mirror's torch formulation under autograd (fp64, CPU) reproduces the reference's gradients: pins what the device
+    path below is compared with"""
+    flow, a = load_image_case(name)
+    loss_ref, g_ref = load_image_grads(name)
+    torch.set_default_dtype(torch.float64)
+    try:
+        # the same flow built in fp64 (constructor under the fp64 default, parameters copied from the fp32 mirror)
+        from usflows_amd.flows import USFlow
+        from usflows_amd.networks import ConvNet2D
+        import json, os
+        from golden_util import GOLDEN_DIR
+        d = json.loads(str(np.load(os.path.join(GOLDEN_DIR, name + ".npz"))["spec"]))
+        dims = d["in_dims"]
+        f64 = USFlow(torch.distributions.Laplace(torch.zeros(dims), torch.ones(dims)), dims, d["coupling_blocks"], ConvNet2D,
+                     dict(d["cond_args"]), householder=d["householder"], affine_conjugation=d["affine_conjugation"],
+                     masktype=d["masktype"])
+        f64.load_state_dict({k: v.double() for k, v in flow.state_dict().items()}, strict=True)
+        f64 = f64.double()                                  # (the Householder permutation is created as fp32 on purpose)
+        lp = f64.log_prob(a["x"].double())
+        loss = -lp.mean()
+        loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert abs(float(loss.detach()) - loss_ref) < 1e-9 * abs(loss_ref)
+    named = dict(f64.named_parameters())
+    assert set(g_ref) <= set(named)
+    for k, g in g_ref.items():
+        _close(named[k].grad, g, 1e-8, k)
+
+
+# ---- kernels ---------------------------------------------------------------------------------------------------------
+WG_SHAPES = [  # (cin, cout, H, W, ks)
+    (16, 32, 7, 7, 3), (32, 32, 7, 7, 3), (32, 16, 7, 7, 3), (32, 64, 7, 7, 1), (16, 16, 7, 7, 1),
+    (48, 32, 8, 8, 3), (32, 32, 8, 8, 3), (32, 48, 8, 8, 3), (32, 64, 8, 8, 1), (48, 48, 8, 8, 1), (64, 32, 8, 8, 1),
+    (16, 16, 3, 5, 3), (32, 16, 1, 1, 3), (16, 48, 8, 8, 3),
+]
+
+
+def _wgrad_ref(x, dy, ks, in_mul=None, pre_sub=None, act=None):
+    x = x.double()
+    if pre_sub is not None:
+        x = x - pre_sub.double().view(1, -1, 1, 1)
+    if act is not None:
+        x = F.leaky_relu(x, act)
+    if in_mul is not None:
+        x = x * in_mul.double().view(1, *x.shape[1:])
+    B, cin, H, W = x.shape
+    cols = F.unfold(x, ks, padding=ks // 2)                                   # [B, cin * ks * ks, HW]
+    dW = torch.einsum("bop,bkp->ok", dy.double().flatten(2), cols).reshape(dy.shape[1], cin, ks, ks)
+    return dW, dy.double().sum(dim=(0, 2, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", WG_SHAPES)
+@pytest.mark.parametrize("B", [1, 5, 300])
+def test_conv_wgrad_vs_fp64(shape, B):
+    from usflows_amd import _ext
+    cin, cout, H, W, ks = shape
+    g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + ks + B)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    dy = torch.randn(B, cout, H, W, generator=g).to(DEV)
+    r = _ext.conv_wgrad(x, dy, ks)
+    assert r is not None, "shape not served"
+    dW, db = r
+    rW, rb = _wgrad_ref(x, dy, ks)
+    _close(dW, rW, 2e-6, "dW")
+    _close(db, rb, 2e-6, "db")
+    # the input transforms of the forward kernels
+    in_mul = (torch.rand(cin * H * W, generator=g) < 0.5).float().to(DEV)
+    pre = torch.randn(cin, generator=g).to(DEV)
+    r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.0, want_bias=False)
+    assert r[1] is None
+    _close(r[0], _wgrad_ref(x, dy, ks, in_mul=in_mul, act=0.0)[0], 2e-6, "dW relu mask")
+    r = _ext.conv_wgrad(x, dy, ks, pre_sub=pre, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.1)
+    _close(r[0], _wgrad_ref(x, dy, ks, pre_sub=pre, act=0.1)[0], 2e-6, "dW pre_sub leaky")
+    # deterministic: the same launch twice gives the same bits
+    r2 = _ext.conv_wgrad(x, dy, ks, pre_sub=pre, in_act=_ext.ACT_LEAKY_RELU, in_slope=0.1)
+    assert torch.equal(r[0], r2[0]) and torch.equal(r[1], r2[1])
+
+
+@pytest.mark.gpu
+def test_conv_wgrad_full_batch_and_unserved_shapes():
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(9)
+    B = 65536
+    x = torch.randn(B, 32, 7, 7, generator=g).to(DEV)
+    dy = torch.randn(B, 32, 7, 7, generator=g).to(DEV)
+    dW, db = _ext.conv_wgrad(x, dy, 3)
+    ref = torch.zeros(32, 32, 3, 3, dtype=torch.float64, device=DEV)
+    rb = torch.zeros(32, dtype=torch.float64, device=DEV)
+    for i in range(0, B, 8192):
+        w_, b_ = _wgrad_ref(x[i:i + 8192], dy[i:i + 8192], 3)
+        ref += w_
+        rb += b_
+    # sums of 3.2 M products of unit normals: |dW| ~ 1.8e3; fp32 partial sums of ~3 600 terms, then 1 024 partials
+    assert (dW.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    assert (db.double() - rb).abs().max().item() < 2e-5 * max(rb.abs().max().item(), 1.0) * 10
+    # shapes outside the kernel's range are reported, not computed wrongly
+    assert _ext.conv_wgrad(torch.zeros(2, 24, 7, 7, device=DEV), torch.zeros(2, 32, 7, 7, device=DEV), 3) is None
+    assert _ext.conv_wgrad(torch.zeros(2, 16, 9, 9, device=DEV), torch.zeros(2, 16, 9, 9, device=DEV), 3) is None
+    assert _ext.conv_wgrad(torch.zeros(2, 64, 8, 8, device=DEV), torch.zeros(2, 64, 8, 8, device=DEV), 3) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,P,B,act", [(32, 49, 300, (1, 0.0)), (32, 64, 7, None), (16, 49, 65536, (1, 0.1)), (48, 64, 33, (1, 0.0)),
+                                       (5, 6, 9, None)])
+def test_layernorm_channels_bwd_vs_fp64(C, P, B, act):
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(C + P + B)
+    x = torch.randn(B, C, P, generator=g).to(DEV)
+    dy = torch.randn(B, C, P, generator=g).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV)
+    eps = 1e-5
+    a = act if act is not None else (_ext.ACT_NONE, 0.0)
+    dx, dg, dbt = _ext.layernorm_channels_bwd(x, dy, gamma, eps, a[0], a[1])
+    x64 = x.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = torch.zeros(C, dtype=torch.float64, device=DEV, requires_grad=True)
+    v = F.leaky_relu(x64, act[1]) if act is not None else x64
+    mean = v.mean(dim=1, keepdim=True)
+    var = v.var(dim=1, unbiased=False, keepdim=True)
+    y = (v - mean) / torch.sqrt(var + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
+    y.backward(dy.double())
+    _close(dx, x64.grad, 1e-5, "dx")
+    _close(dg, g64.grad, 1e-5, "dgamma")
+    _close(dbt, b64.grad, 1e-5, "dbeta")
+
+
+@pytest.mark.gpu
+def test_gated_residual_bwd_and_masked_product():
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(4)
+    B, C, P = 37, 32, 49
+    x = torch.randn(B, C, P, generator=g).to(DEV)
+    vg = torch.randn(B, 2 * C, P, generator=g).to(DEV)
+    dy = torch.randn(B, C, P, generator=g).to(DEV)
+    dvg = _ext.gated_residual_bwd(dy, vg)
+    v64 = vg.double().requires_grad_(True)
+    val, gate = v64.chunk(2, dim=1)
+    (x.double() + val * torch.sigmoid(gate)).backward(dy.double())
+    _close(dvg, v64.grad, 1e-6, "dvg")
+    om = (torch.rand(C * P, generator=g) < 0.5).float().to(DEV)
+    out = _ext.masked_residual(None, dy, om, -1.0)
+    assert torch.equal(out, -(om.view(1, C, P) * dy))
+
+
+# ---- the autograd functions against fp64 torch autograd of the same module ------------------------------------------------
+def _grads_of(module_fn, params, x, dy):
+    for p in params:
+        p.grad = None
+    xx = x.clone().requires_grad_(True)
+    y = module_fn(xx)
+    y.backward(dy)
+    return y.detach(), xx.grad, [p.grad.clone() for p in params]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(c_in=16, c_hidden=32, num_layers=1, gating=True, normalize_layers=True, HW=(7, 7)),
+                                 dict(c_in=48, c_hidden=32, num_layers=3, gating=True, normalize_layers=True, HW=(8, 8)),
+                                 dict(c_in=16, c_hidden=32, num_layers=2, gating=False, normalize_layers=True, HW=(7, 7)),
+                                 dict(c_in=16, c_hidden=32, num_layers=1, gating=False, normalize_layers=False, HW=(7, 7)),
+                                 dict(c_in=16, c_hidden=32, num_layers=1, gating=True, normalize_layers=False, HW=(5, 4), leaky=0.1)])
+def test_convnet2d_trains_on_device_like_fp64_autograd(cfg, monkeypatch):
+    import copy
+    from usflows_amd import _ext
+    from usflows_amd.networks import ConvNet2D
+    torch.manual_seed(7)
+    H, W = cfg["HW"]
+    act = torch.nn.LeakyReLU(cfg["leaky"]) if "leaky" in cfg else torch.nn.ReLU()
+    net = ConvNet2D(c_in=cfg["c_in"], c_hidden=cfg["c_hidden"], num_layers=cfg["num_layers"], nonlinearity=act, padding="same",
+                    kernel_size=3, normalize_layers=cfg["normalize_layers"], gating=cfg["gating"])
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    ref = copy.deepcopy(net).double()
+    net = net.to(DEV)
+    B = 19
+    x = torch.randn(B, cfg["c_in"], H, W)
+    dy = torch.randn(B, cfg["c_in"], H, W)
+    mask = (torch.rand(cfg["c_in"] * H * W) < 0.5).float()
+    wg = []
+    real = _ext.conv_wgrad
+    monkeypatch.setattr(_ext, "conv_wgrad", lambda *a_, **k_: (wg.append(1), real(*a_, **k_))[1])
+    assert net.train_on_device(x.to(DEV).requires_grad_(True))
+    y, dx, gp = _grads_of(lambda t: net(t, in_mul=mask.to(DEV)), list(net.parameters()), x.to(DEV), dy.to(DEV))
+    n_convs = sum(1 for m in net.modules() if isinstance(m, torch.nn.Conv2d))
+    assert len(wg) == n_convs, "a convolution's weight gradient did not come from usf_conv_wgrad_f32"
+    y64, dx64, gp64 = _grads_of(lambda t: ref(t * mask.double().view(1, cfg["c_in"], H, W)), list(ref.parameters()), x.double(), dy.double())
+    _close(y, y64, 2e-5, "y")
+    _close(dx, dx64, 2e-5, "dx")
+    for (k, _), a_, b_ in zip(net.named_parameters(), gp, gp64):
+        _close(a_, b_, 2e-5, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,HW", [(16, (7, 7)), (48, (8, 8))])
+def test_channel_affine_function_vs_fp64(C, HW):
+    from usflows_amd.image_training import ChannelAffine
+    g = torch.Generator().manual_seed(C)
+    B = 21
+    x = torch.randn(B, C, *HW, generator=g)
+    dy = torch.randn(B, C, *HW, generator=g)
+    Wm = torch.randn(C, C, generator=g) / C ** 0.5
+    b = torch.randn(C, generator=g)
+    for pre_sub in (False, True):
+        xd, Wd, bd = x.to(DEV).requires_grad_(True), Wm.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = ChannelAffine.apply(xd, Wd, bd, pre_sub)
+        y.backward(dy.to(DEV))
+        x6, W6, b6 = x.double().requires_grad_(True), Wm.double().requires_grad_(True), b.double().requires_grad_(True)
+        y6 = F.conv2d(x6 - b6.view(1, C, 1, 1), W6.view(C, C, 1, 1)) if pre_sub else F.conv2d(x6, W6.view(C, C, 1, 1), b6)
+        y6.backward(dy.double())
+        _close(y, y6, 1e-5, "y")
+        _close(xd.grad, x6.grad, 1e-5, "dx")
+        _close(Wd.grad, W6.grad, 1e-5, "dW")
+        _close(bd.grad, b6.grad, 1e-5, "db")
+
+
+# ---- whole flows against the real reference -----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", image_grad_case_names())
+def test_image_flow_device_gradients_match_the_real_reference(name, monkeypatch):
+    from usflows_amd import _ext
+    flow, a = load_image_case(name, device=DEV)
+    loss_ref, g_ref = load_image_grads(name)
+    wg = []
+    real = _ext.conv_wgrad
+    monkeypatch.setattr(_ext, "conv_wgrad", lambda *a_, **k_: (wg.append(1), real(*a_, **k_))[1])
+    lp = flow.log_prob(a["x"].to(DEV))
+    _close(lp.detach(), a["log_prob64"], 1e-5, "log_prob under autograd")
+    loss = -lp.mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-5 * abs(loss_ref)
+    n_convs = sum(1 for m in flow.modules() if isinstance(m, torch.nn.Conv2d))
+    n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
+    assert len(wg) >= n_convs + n_aff, f"{len(wg)} weight-gradient launches for {n_convs} convolutions + {n_aff} affine layers"
+    named = dict(flow.named_parameters())
+    for k, g in g_ref.items():
+        assert named[k].grad is not None, k
+        _close(named[k].grad, g, 5e-5, k)
+
+
+@pytest.mark.gpu
+def test_image_flow_fit_on_device_matches_reference_run(monkeypatch):
+    """Flow.fit of the MNIST experiment model on the device reproduces the reference's own run (2 epochs of SGD on 96
+    rows): same shuffling, same losses, same parameters after 6 steps -- with the convolutions' gradients on the HIP
+    kernels, eager and as a replayed hipGraph"""
+    from usflows_amd import _ext
+    name = "image_mnistcfg_c16_7x7_k2_gated_ln_hh1_conj"
+    data, losses_ref, sd_ref = load_image_fit(name)
+    for graph in ("0", "1"):
+        monkeypatch.setenv("USFLOWS_AMD_TRAIN_GRAPH", graph)
+        flow, _ = load_image_case(name, device=DEV)
+        wg = []
+        real = _ext.conv_wgrad
+        monkeypatch.setattr(_ext, "conv_wgrad", lambda *a_, **k_: (wg.append(1), real(*a_, **k_))[1])
+        ds = torch.utils.data.TensorDataset(data, torch.zeros(data.shape[0]))
+        np.random.seed(5)
+        losses = flow.fit(ds, optim=torch.optim.SGD, optim_params=dict(lr=1e-3), batch_size=32, shuffle=True,
+                          device=torch.device(DEV), epochs=2)
+        monkeypatch.setattr(_ext, "conv_wgrad", real)
+        assert len(wg) > 0, "Flow.fit did not take the device training path"
+        for l, r in zip(losses, losses_ref):
+            assert abs(float(l) - r) < 2e-4 * abs(r), (graph, losses, losses_ref)
+        sd = flow.state_dict()
+        for k, v in sd_ref.items():
+            s = max(v.abs().max().item(), 1e-3)
+            assert (sd[k].cpu().double() - v.double()).abs().max().item() < 2e-3 * s, (graph, k)

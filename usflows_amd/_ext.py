@@ -17,7 +17,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 21
+USF_ABI_VERSION = 22
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -169,6 +169,13 @@ SYMBOLS = {
     "usf_conv2d_same_res_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
                                           C.c_int32, C.c_float, _fp, _fp, C.c_float, C.c_void_p]),
     "usf_masked_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_conv_wgrad_workspace": (C.c_int64, [C.c_int64] * 6),
+    "usf_conv_wgrad_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
+                                     C.c_void_p]),
+    "usf_layernorm_channels_bwd_workspace": (C.c_int64, [C.c_int64] * 3),
+    "usf_layernorm_channels_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_int32, C.c_float,
+                                                 _fp, _fp, C.c_int64, C.c_void_p]),
+    "usf_gated_residual_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
     "usf_lu_prepare_f64": (C.c_int, [C.POINTER(LuPrepDesc), C.c_void_p]),
@@ -556,13 +563,58 @@ def gated_norm_rows(skip, *, M, C_cols, c_pad=None, ld_skip=None, vg=None, ld_vg
 
 
 def masked_residual(x, t, one_minus_mask, sign):
-    """x + sign * one_minus_mask * t (mask [C * P] fp32, broadcast over the batch) -> new tensor"""
-    B = x.shape[0]
-    CP = math.prod(x.shape[1:])
-    y = torch.empty_like(x)
-    _direct("usf_masked_residual_f32", x.data_ptr(), t.data_ptr(), one_minus_mask.data_ptr(), float(sign), y.data_ptr(), B,
-                                         CP, current_stream(x.device))
+    """x + sign * one_minus_mask * t (mask [C * P] fp32, broadcast over the batch) -> new tensor; x None: taken as zeros"""
+    B = t.shape[0]
+    CP = math.prod(t.shape[1:])
+    y = torch.empty_like(t)
+    _direct("usf_masked_residual_f32", ptr(x), t.data_ptr(), one_minus_mask.data_ptr(), float(sign), y.data_ptr(), B,
+                                         CP, current_stream(t.device))
     return y
+
+
+def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True):
+    """usf_conv_wgrad_f32: (dW [cout, cin, ks, ks], db [cout] | None) of a stride-1 "same" convolution from its input x
+    [B, cin, H, W] (with the forward's input transforms) and the output gradient dy [B, cout, H, W]; None when the shape is
+    not served"""
+    B, cin, H, W = x.shape
+    cout = dy.shape[1]
+    lib = load()
+    ws_n = lib.usf_conv_wgrad_workspace(B, cin, cout, H, W, ks)
+    if ws_n <= 0:
+        return None
+    ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
+    dW = torch.empty(cout, cin, ks, ks, dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    args = (x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act), float(in_slope),
+            dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, current_stream(x.device))
+    rc = _timed_call(lib.usf_conv_wgrad_f32, args, "usf_conv_wgrad_f32")
+    if rc == 1:
+        return None
+    check(rc, "usf_conv_wgrad_f32")
+    return dW, db
+
+
+def layernorm_channels_bwd(x, dy, gamma, eps, act=ACT_NONE, slope=0.0):
+    """usf_layernorm_channels_bwd_f32 -> (dx, dgamma [C], dbeta [C])"""
+    B, Cc = x.shape[0], x.shape[1]
+    P = math.prod(x.shape[2:])
+    lib = load()
+    ws_n = lib.usf_layernorm_channels_bwd_workspace(B, Cc, P)
+    ws = torch.empty(max(1, ws_n), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+    _direct("usf_layernorm_channels_bwd_f32", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, Cc, P, gamma.data_ptr(), float(eps),
+            int(act), float(slope), dgb.data_ptr(), ws.data_ptr(), ws_n, current_stream(x.device))
+    return dx, dgb[:Cc], dgb[Cc:]
+
+
+def gated_residual_bwd(dy, vg):
+    """usf_gated_residual_bwd_f32 -> d(vg) [B, 2C, *spatial] (the gradient with respect to x is dy)"""
+    B = dy.shape[0]
+    CP = math.prod(dy.shape[1:])
+    dvg = torch.empty_like(vg)
+    _direct("usf_gated_residual_bwd_f32", dy.data_ptr(), vg.data_ptr(), dvg.data_ptr(), B, CP, current_stream(dy.device))
+    return dvg
 
 
 def gather_cols(src, lds, dst, ldd, M, n, idx):

@@ -74,6 +74,15 @@ int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cou
                    const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream);
 int masked_residual(const float* x, const float* t, const float* om, float sign, float* y, int64_t B, int64_t CP,
                     hipStream_t stream);
+int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
+int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+               const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
+               int64_t workspace_floats, hipStream_t stream);
+int64_t layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P);
+int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma, float eps,
+                           int32_t act, float slope, float* dgamma, float* dbeta, float* workspace, int64_t workspace_floats,
+                           hipStream_t stream);
+int gated_residual_bwd(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, hipStream_t stream);
 int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
                  float neg_lr, int32_t maximize, hipStream_t stream);
 int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2, hipStream_t stream);
@@ -233,6 +242,25 @@ int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream) {
 int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
                             int64_t CP, usf_stream_t stream) {
   return usf::masked_residual(x, t, one_minus_mask, sign, y, B, CP, (hipStream_t)stream);
+}
+int64_t usf_conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) {
+  return usf::conv_wgrad_workspace(B, cin, cout, H, W, ks);
+}
+int usf_conv_wgrad_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                       const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
+                       float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+  return usf::conv_wgrad(x, dy, B, cin, cout, H, W, ks, in_mul, pre_sub, in_act, in_slope, dW, db, workspace, workspace_floats,
+                         (hipStream_t)stream);
+}
+int64_t usf_layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P) { return usf::layernorm_channels_bwd_workspace(B, C, P); }
+int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma,
+                                   float eps, int32_t act, float slope, float* dgamma_dbeta, float* workspace,
+                                   int64_t workspace_floats, usf_stream_t stream) {
+  return usf::layernorm_channels_bwd(x, dy, dx, B, C, P, gamma, eps, act, slope, dgamma_dbeta, dgamma_dbeta ? dgamma_dbeta + C : nullptr,
+                                     workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream) {
+  return usf::gated_residual_bwd(dy, vg, dvg, B, CP, (hipStream_t)stream);
 }
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks) { return usf::conv2d_weight_elems(cin, cout, ks); }
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) { return usf::conv2d_same_fits(cin, cout, H, W, ks); }

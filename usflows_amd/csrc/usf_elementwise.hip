@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256) void masked_residual_kernel(const float* __res
                                                               const float* __restrict__ om, float sign,
                                                               float* __restrict__ y, int64_t total, int64_t CP) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
-    y[e] = x[e] + sign * (om[e % CP] * t[e]);
+    y[e] = (x ? x[e] : 0.f) + sign * (om[e % CP] * t[e]);
 }
 
 int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
@@ -744,7 +744,7 @@ int masked_residual(const float* x, const float* t, const float* om, float sign,
                     hipStream_t stream) {
   if (B < 0 || CP <= 0) { set_error("usf_masked_residual_f32: bad sizes"); return -2; }
   if (B == 0) return 0;
-  if (!x || !t || !om || !y) { set_error("usf_masked_residual_f32: null pointer"); return -1; }
+  if (!t || !om || !y) { set_error("usf_masked_residual_f32: null pointer"); return -1; }
   int64_t blocks = (B * CP + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(masked_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, t, om, sign, y, B * CP, CP);

@@ -332,9 +332,11 @@ class Flow(torch.nn.Module):
         """Laplace / Normal base density of the layer loop's result through ``usf_base_logprob_f32`` (rows flattened) when
         nothing needs a gradient: one launch instead of the distribution object's op chain, whose argument validation
         (``_validate_sample``) synchronises the host with the device on every call.  None: not applicable."""
-        if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() >= 2 and y.shape[0] > 0) \
-                or (torch.is_grad_enabled() and (y.requires_grad or _needs_grad(self, y, None))):
+        if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() >= 2 and y.shape[0] > 0):
             return None
+        train = torch.is_grad_enabled() and (y.requires_grad or _needs_grad(self, y, None))
+        if train and (y.dim() < 3 or os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") == "0"):
+            return None                                  # (flat flows train through training.py; image flows: below)
         d, n_ind = self.base_distribution, 0
         if isinstance(d, DistributionModule):
             return None
@@ -351,6 +353,13 @@ class Flow(torch.nn.Module):
             scale = d.scale.detach().to(device=y.device, dtype=torch.float32).expand(ev).reshape(-1).contiguous()
             cache = self._base_loop_cache = (key, loc, scale)
         _ext.load()
+        if train:
+            # an image-shaped flow in training: the density and its gradient on the device (image_training.BaseLogProb);
+            # a base with trainable parameters keeps the distribution object's op chain
+            if d.loc.requires_grad or d.scale.requires_grad:
+                return None
+            from .image_training import BaseLogProb
+            return BaseLogProb.apply(y, cache[1], cache[2], _ext.BASE_LAPLACE if isinstance(d, tdist.Laplace) else _ext.BASE_NORMAL)
         B, D = y.shape[0], cache[1].numel()
         yf = y.reshape(B, D).contiguous()
         out = torch.empty(B, dtype=torch.float32, device=y.device)

@@ -1,0 +1,260 @@
+"""Device backward of image-shaped flows (SURVEY rows N2 x N4): what torch autograd computes when ``Flow.fit``
+(flows.py:113-210) trains a flow whose layers are the 1 x 1-convolution ``BlockAffineTransform`` (transforms.py:904-962)
+and ``MaskedCoupling`` over a ``ConvNet2D`` conditioner (networks.py:40-122, 405-510).
+
+Each ``torch.autograd.Function`` here is one device pass of the inference path with its gradient on the HIP kernels:
+
+* data gradients reuse the forward kernels on the transposed (and, for 3 x 3, flipped) weight:
+  ``usf_conv2d_same_f32``, ``usf_pointwise_conv_f32``, ``usf_channel_affine_f32``;
+* weight / bias gradients come from ``usf_conv_wgrad_f32`` (exact fp32 on the f32 matrix instruction, deterministic);
+* ``usf_layernorm_channels_bwd_f32``, ``usf_gated_residual_bwd_f32``, ``usf_act_grad_f32``, ``usf_masked_residual_f32`` and
+  ``usf_base_logprob_grad_f32`` cover the elementwise pieces.
+
+autograd only orders the calls; the tiny parameter maps (LU / Householder factors -> the C x C block matrix and its
+inverse) stay torch ops on C x C tensors, as in the reference.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _ext
+
+
+def _act(a):
+    return a if a is not None else (_ext.ACT_NONE, 0.0)
+
+
+def _gate_inplace(d: torch.Tensor, h: torch.Tensor, act) -> None:
+    """d *= act'(h) for a (Leaky)ReLU (sign of the pre-activation == sign of the output)"""
+    if act is None or act[0] == _ext.ACT_NONE:
+        return
+    B = d.shape[0]
+    n = d.numel() // B
+    _ext.act_grad(d, h, M=B, H=n, ldd=n, ldh=n, act=act[0], slope=act[1])
+
+
+def conv_shape_ok(conv, B: int, H: int, W: int) -> bool:
+    """forward, data gradient (the transposed shape) and weight gradient of this nn.Conv2d at [B, cin, H, W] are all served"""
+    if not isinstance(conv, torch.nn.Conv2d):
+        return False
+    k = conv.kernel_size
+    if k[0] != k[1] or k[0] not in (1, 3) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 \
+            or conv.padding_mode != "zeros":
+        return False
+    pad = conv.padding
+    if not (pad == "same" or (not isinstance(pad, str) and tuple(pad) == (k[0] // 2, k[0] // 2))):
+        return False
+    lib = _ext.load()
+    cin, cout = conv.in_channels, conv.out_channels
+    return (lib.usf_conv2d_same_fits(cin, cout, H, W, k[0]) >= 2 and lib.usf_conv2d_same_fits(cout, cin, H, W, k[0]) >= 2
+            and lib.usf_conv_wgrad_workspace(max(B, 1), cin, cout, H, W, k[0]) > 0)
+
+
+class ConvSame(torch.autograd.Function):
+    """out_act(bias + conv(in_act(x) * in_mul)) on usf_conv2d_same_f32 (kernel 1 or 3, stride 1, "same")"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_mul, in_act, out_act):
+        x = x.contiguous()
+        w = weight.detach()
+        ks = w.shape[2]
+        ia, oa = _act(in_act), _act(out_act)
+        y = _ext.conv2d_same(x, _ext.conv2d_weight_planes(w), w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
+                             in_mul=in_mul, in_act=ia[0], in_slope=ia[1], out_act=oa[0], out_slope=oa[1])
+        ctx.save_for_backward(x, w, in_mul, y if out_act is not None else None)
+        ctx.cfg = (ks, in_act, out_act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, in_mul, y = ctx.saved_tensors
+        ks, in_act, out_act, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        if out_act is not None:
+            dy = dy.clone()
+            _gate_inplace(dy, y, out_act)
+        ia = _act(in_act)
+        dW = db = dx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+            if r is None:
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_train_ok was not consulted)")
+            dW, db = r
+        if ctx.needs_input_grad[0]:
+            wt = w.flip(2, 3).transpose(0, 1).contiguous() if ks > 1 else w.transpose(0, 1).contiguous()
+            dx = _ext.conv2d_same(dy, _ext.conv2d_weight_planes(wt), w.shape[1], ks)
+            _gate_inplace(dx, x, in_act)
+            if in_mul is not None:
+                dx = _ext.masked_residual(None, dx, in_mul, 1.0)
+        return dx, dW, db, None, None, None
+
+
+class Pointwise(torch.autograd.Function):
+    """bias + W in_act(x) per pixel on usf_pointwise_conv_f32 (W [cout, cin]: an nn.Conv2d weight with kernel 1)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_act):
+        x = x.contiguous()
+        w2 = weight.detach().reshape(weight.shape[0], weight.shape[1]).contiguous()
+        ia = _act(in_act)
+        y = _ext.pointwise_conv(x, w2, None if bias is None else bias.detach().contiguous(), in_act=ia[0], in_slope=ia[1])
+        ctx.save_for_backward(x, w2)
+        ctx.cfg = (in_act, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        in_act, has_bias, wshape = ctx.cfg
+        dy = dy.contiguous()
+        ia = _act(in_act)
+        dW = db = dx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+            if r is None:
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
+            dW, db = r[0].reshape(wshape), r[1]
+        if ctx.needs_input_grad[0]:
+            dx = _ext.pointwise_conv(dy, w2.t().contiguous())
+            _gate_inplace(dx, x, in_act)
+        return dx, dW, db, None
+
+
+def pointwise_shape_ok(conv, B: int, H: int, W: int) -> bool:
+    """a kernel-1 nn.Conv2d whose forward and data gradient run on usf_pointwise_conv_f32"""
+    if not (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1):
+        return False
+    pad = conv.padding
+    if not (pad == "same" or (not isinstance(pad, str) and tuple(pad) == (0, 0))):
+        return False
+    cin, cout = conv.in_channels, conv.out_channels
+    return (_ext.pointwise_conv_supported(cin, cout, False) and _ext.pointwise_conv_supported(cout, cin, False)
+            and _ext.load().usf_conv_wgrad_workspace(max(B, 1), cin, cout, H, W, 1) > 0)
+
+
+class GatedResidual(torch.autograd.Function):
+    """x + vg[:, :C] * sigmoid(vg[:, C:])  (GatedConv.forward's last line, networks.py:108-122)"""
+
+    @staticmethod
+    def forward(ctx, x, vg):
+        x, vg = x.contiguous(), vg.contiguous()
+        ctx.save_for_backward(vg)
+        return _ext.gated_residual(x, vg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (vg,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        return dy, _ext.gated_residual_bwd(dy, vg)
+
+
+class LayerNormCh(torch.autograd.Function):
+    """LayerNormChannels (networks.py:40-58) with the (Leaky)ReLU ConvNet2D puts in front of it"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, pre_act):
+        x = x.contiguous()
+        g = gamma.detach().reshape(-1).contiguous()
+        a = _act(pre_act)
+        y = _ext.layernorm_channels(x, g, beta.detach().reshape(-1).contiguous(), eps, a[0], a[1])
+        ctx.save_for_backward(x, g)
+        ctx.cfg = (eps, pre_act, tuple(gamma.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        eps, pre_act, pshape = ctx.cfg
+        a = _act(pre_act)
+        dx, dg, dbt = _ext.layernorm_channels_bwd(x, dy.contiguous(), g, eps, a[0], a[1])
+        return dx, dg.reshape(pshape), dbt.reshape(pshape), None, None
+
+
+class MaskedResidual(torch.autograd.Function):
+    """x + sign * (1 - mask) * t  (MaskedCoupling on image-shaped inputs, transforms.py:277-306)"""
+
+    @staticmethod
+    def forward(ctx, x, t, one_minus_mask, sign):
+        ctx.save_for_backward(one_minus_mask)
+        ctx.sign = sign
+        return _ext.masked_residual(x.contiguous(), t.contiguous(), one_minus_mask, sign)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (om,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dt = _ext.masked_residual(None, dy, om, ctx.sign) if ctx.needs_input_grad[1] else None
+        return dy, dt, None, None
+
+
+class ChannelAffine(torch.autograd.Function):
+    """the 1 x 1 convolution of BlockAffineTransform on NCHW data: pre_sub False: y = W x + b (forward direction);
+    pre_sub True: y = W (x - b) (backward direction, W = M^-1); W [C, C], b [C] are tiny differentiable torch tensors"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pre_sub):
+        x = x.contiguous()
+        Wd, bd = W.detach().contiguous(), b.detach().contiguous()
+        y = torch.empty_like(x)
+        if pre_sub:
+            _ext.channel_affine(x, y, Wd, pre_sub=bd)
+        else:
+            _ext.channel_affine(x, y, Wd, bias=bd)
+        ctx.save_for_backward(x, Wd, bd)
+        ctx.pre_sub = pre_sub
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Wd, bd = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dW = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            r = _ext.conv_wgrad(x, dy, 1, pre_sub=bd if ctx.pre_sub else None, want_bias=True)
+            if r is None:
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this channel count")
+            dW = r[0].reshape(Wd.shape)
+            db = -(Wd.t() @ r[1]) if ctx.pre_sub else r[1]
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            _ext.channel_affine(dy, dx, Wd.t().contiguous())
+        return dx, dW, db, None
+
+
+def channel_affine_train_ok(x, C) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == C and C in (16, 32, 48, 64)
+            and _ext.load().usf_conv_wgrad_workspace(max(x.shape[0], 1), C, C, x.shape[2], x.shape[3], 1) > 0)
+
+
+class BaseLogProb(torch.autograd.Function):
+    """sum_d log p(z_d) of a Laplace / Normal base with fixed parameters (usf_base_logprob_f32 and its gradient kernel)"""
+
+    @staticmethod
+    def forward(ctx, z, loc, scale, base_id):
+        B = z.shape[0]
+        D = loc.numel()
+        zf = z.reshape(B, D).contiguous()
+        out = torch.empty(B, dtype=torch.float32, device=z.device)
+        _ext.base_logprob(zf, D, B, D, base_id, loc, scale, 0.0, out)
+        ctx.save_for_backward(zf, loc, scale)
+        ctx.cfg = (base_id, tuple(z.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_lp):
+        zf, loc, scale = ctx.saved_tensors
+        base_id, shape = ctx.cfg
+        B, D = zf.shape
+        g = torch.empty_like(zf)
+        _ext.base_logprob_grad(zf, D, g_lp.contiguous(), B, D, base_id, loc, scale, g, D)
+        return g.reshape(shape), None, None, None
+
+
+def needs_grad(module, *tensors) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    if any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())

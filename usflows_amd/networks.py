@@ -338,6 +338,27 @@ class GatedConv(nn.Module):
                 and C <= 32 and _ext.pointwise_conv_supported(C, 2 * C, True) and _conv_hip_ok(n[1], x)
                 and n[1].out_channels == C)
 
+    def train_shape_ok(self, B: int, C: int, H: int, W: int) -> bool:
+        """every piece of this block has a device backward at [B, C, H, W] (image_training.py)"""
+        from . import image_training as it
+        n = self.net
+        return (_relu_kind(n[0]) is not None and _relu_kind(n[2]) is not None and isinstance(n[1], nn.Conv2d)
+                and isinstance(n[3], nn.Conv2d) and n[1].in_channels == C and n[3].out_channels == 2 * C
+                and n[3].in_channels == n[1].out_channels and it.conv_shape_ok(n[1], B, H, W)
+                and (it.pointwise_shape_ok(n[3], B, H, W) or it.conv_shape_ok(n[3], B, H, W)))
+
+    def forward_train_device(self, x):
+        """the block as three differentiable device passes: 3 x 3 convolution, 1 x 1 convolution, gate"""
+        from . import image_training as it
+        n = self.net
+        a0, a2 = _relu_kind(n[0]), _relu_kind(n[2])
+        h = it.ConvSame.apply(x, n[1].weight, n[1].bias, None, a0, None)
+        if it.pointwise_shape_ok(n[3], x.shape[0], x.shape[2], x.shape[3]):
+            vg = it.Pointwise.apply(h, n[3].weight, n[3].bias, a2)
+        else:
+            vg = it.ConvSame.apply(h, n[3].weight, n[3].bias, None, a2, None)
+        return it.GatedResidual.apply(x, vg)
+
     def forward(self, x, post=None):
         """post = ((act id, slope), LayerNormChannels) only after ``can_join_layernorm`` said yes"""
         n = self.net
@@ -423,6 +444,8 @@ class ConvNet2D(nn.Module):
         if not (x.is_cuda and x.dtype == torch.float32):
             assert in_mul is None and residual is None
             return self.nn(x)
+        if residual is None and self.train_on_device(x):
+            return self._forward_train_device(x, in_mul)
         done = False
         # the same module sequence on the device: convolutions on usf_conv2d_same_f32 (a nonlinearity behind a plain
         # convolution rides in its epilogue), a (Leaky)ReLU in front of a LayerNormChannels joins that layer's pass
@@ -453,6 +476,75 @@ class ConvNet2D(nn.Module):
                 x = m(x)
                 k += 1
         return (x, done) if residual is not None else x
+
+    # ---- training on the device (rows N2 x N4): the same module sequence as differentiable device passes ----------------
+    def train_on_device(self, x) -> bool:
+        """True when this call needs gradients and every module of the sequence has a device backward at this shape
+        (image_training.py); USFLOWS_AMD_IMAGE_TRAIN=0 keeps torch autograd"""
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
+                and torch.is_grad_enabled() and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0"):
+            return False
+        if not (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        from . import image_training as it
+        B, C, H, W = x.shape
+        mods = list(self.nn)
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            if isinstance(m, nn.Conv2d):
+                if m.in_channels != C or not it.conv_shape_ok(m, B, H, W):
+                    return False
+                C = m.out_channels
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                k += 2 if (_relu_kind(nxt) is not None and not isinstance(after, LayerNormChannels)) else 1
+            elif isinstance(m, GatedConv):
+                if not m.train_shape_ok(B, C, H, W):
+                    return False
+                k += 1
+            elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
+                if nxt.gamma.numel() != C or C > 64:
+                    return False
+                k += 2
+            elif isinstance(m, LayerNormChannels):
+                if m.gamma.numel() != C or C > 64:
+                    return False
+                k += 1
+            elif _relu_kind(m) is not None:
+                k += 1                                            # (a stand-alone nonlinearity: a torch elementwise op)
+            else:
+                return False
+        return True
+
+    def _forward_train_device(self, x, in_mul=None):
+        from . import image_training as it
+        mods = list(self.nn)
+        assert in_mul is None or isinstance(mods[0], nn.Conv2d)
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            if isinstance(m, nn.Conv2d):
+                fold = _relu_kind(nxt) if nxt is not None else None
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                if fold is not None and isinstance(after, LayerNormChannels):
+                    fold = None                                   # that ReLU belongs to the layer norm's pass
+                x = it.ConvSame.apply(x, m.weight, m.bias, in_mul if k == 0 else None, None, fold)
+                k += 2 if fold is not None else 1
+            elif isinstance(m, GatedConv):
+                x = m.forward_train_device(x)
+                k += 1
+            elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
+                x = it.LayerNormCh.apply(x, nxt.gamma, nxt.beta, nxt.eps, _relu_kind(m))
+                k += 2
+            elif isinstance(m, LayerNormChannels):
+                x = it.LayerNormCh.apply(x, m.gamma, m.beta, m.eps, None)
+                k += 1
+            else:
+                x = m(x)
+                k += 1
+        return x
 
     def first_conv_on_device(self, x) -> bool:
         """True when forward(x, in_mul=mask) may be used: the first module is a convolution the HIP kernel serves"""

@@ -182,6 +182,27 @@ class MaskedCoupling(BaseTransform):
             cache = self._om_cache = (key, om)
         return cache[1]
 
+    def _mask_flat(self, x):
+        key = (self.mask.data_ptr(), self.mask._version, str(x.device))
+        cache = getattr(self, "_m_cache", None)
+        if cache is None or cache[0] != key:
+            cache = self._m_cache = (key, self.mask.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous())
+        return cache[1]
+
+    def _image_train(self, x, context, sign):
+        """the layer as differentiable device passes when this call trains an image-shaped flow (image_training.py: the
+        conditioner's convolutions, their weight gradients and this residual on the HIP kernels); None: not applicable"""
+        cond = self.conditioner
+        if context is not None or not (torch.is_tensor(x) and x.dim() == 4 and x.is_cuda and x.dtype == torch.float32
+                                       and torch.is_grad_enabled() and hasattr(cond, "train_on_device")
+                                       and self.mask.numel() == math.prod(x.shape[1:])):
+            return None
+        if not cond.train_on_device(x):
+            return None
+        from .image_training import MaskedResidual
+        t = cond(x, in_mul=self._mask_flat(x))
+        return MaskedResidual.apply(x, t, self._one_minus_mask(x), sign)
+
     def _conditioner_masked(self, x, context, sign=None):
         """conditioner(x * mask); a ConvNet2D on the device takes x and the mask and multiplies inside its first
         convolution's staging pass.  sign (+-1.0, device image path): the conditioner may also write the coupling's output
@@ -189,13 +210,9 @@ class MaskedCoupling(BaseTransform):
         cond = self.conditioner
         if context is None and hasattr(cond, "first_conv_on_device") and x.dim() == 4 \
                 and self.mask.numel() == math.prod(x.shape[1:]) and use_hip(self, x) and cond.first_conv_on_device(x):
-            key = (self.mask.data_ptr(), self.mask._version, str(x.device))
-            cache = getattr(self, "_m_cache", None)
-            if cache is None or cache[0] != key:
-                cache = self._m_cache = (key, self.mask.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous())
             if sign is not None:
-                return cond(x, in_mul=cache[1], residual=(x, self._one_minus_mask(x), sign))
-            return cond(x, in_mul=cache[1])
+                return cond(x, in_mul=self._mask_flat(x), residual=(x, self._one_minus_mask(x), sign))
+            return cond(x, in_mul=self._mask_flat(x))
         x_masked = x * self.mask
         t = cond(x_masked) if context is None else cond(x_masked, context)
         return (t, False) if sign is not None else t
@@ -203,6 +220,9 @@ class MaskedCoupling(BaseTransform):
     def forward(self, x, context=None):
         if self._hip_ok(x, context):
             return self._hip("forward", x, context)
+        y = self._image_train(x, context, 1.0)
+        if y is not None:
+            return y
         t, done = self._conditioner_masked(x, context, 1.0)
         if done:
             return t
@@ -212,6 +232,9 @@ class MaskedCoupling(BaseTransform):
     def backward(self, y, context=None):
         if self._hip_ok(y, context):
             return self._hip("backward", y, context)
+        x = self._image_train(y, context, -1.0)
+        if x is not None:
+            return x
         t, done = self._conditioner_masked(y, context, -1.0)
         if done:
             return t
@@ -712,6 +735,15 @@ class BlockAffineTransform(BaseTransform):
             _ext.channel_affine(x, y, Minv, pre_sub=b)
         return y
 
+    def _channel_train(self, x) -> bool:
+        """a call that needs gradients on NCHW data: the 1 x 1 convolution, its data gradient and the C x C weight gradient
+        on the HIP kernels (image_training.ChannelAffine); the parameter maps stay torch ops on C x C tensors"""
+        if not (self.input_rank == 2 and torch.is_tensor(x) and x.dim() == 4 and x.shape[0] > 0 and torch.is_grad_enabled()
+                and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0"):
+            return False
+        from .image_training import channel_affine_train_ok
+        return channel_affine_train_ok(x, self.block_size) and _needs_grad(self, x)
+
     def _use_channel_hip(self, x) -> bool:
         return (self.input_rank >= 1 and x.dim() == self.input_rank + 2 and x.shape[1] == self.block_size
                 and self.block_size <= 64 and use_hip(self, x))
@@ -723,6 +755,9 @@ class BlockAffineTransform(BaseTransform):
             return F.linear(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device))
         if self._use_channel_hip(x):
             return self._channel_hip(x, True)
+        if self._channel_train(x):
+            from .image_training import ChannelAffine
+            return ChannelAffine.apply(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device), False)
         w = self.block_transform.matrix().view(self.block_size, self.block_size, *([1] * self.input_rank)).to(x.device)
         return self.global_transform(x, w, self.block_transform.bias().to(x.device))
 
@@ -735,6 +770,10 @@ class BlockAffineTransform(BaseTransform):
             return F.linear(y - b, w)
         if self._use_channel_hip(y):
             return self._channel_hip(y, False)
+        if self._channel_train(y):
+            from .image_training import ChannelAffine
+            return ChannelAffine.apply(y, self.block_transform.inverse_matrix().to(y.device),
+                                       self.block_transform.bias().to(y.device), True)
         w = self.block_transform.inverse_matrix().view(self.block_size, self.block_size,
                                                        *([1] * self.input_rank)).to(y.device)
         b = self.block_transform.bias().view(self.block_size, *([1] * self.input_rank)).to(y.device)
