@@ -491,7 +491,8 @@ def main():
 # image-shaped flows
 # ----------------------------------------------------------------------------------------------------------------------
 _IMAGE_KERNELS = ("usf_conv2d_same_f32", "usf_conv2d_same_res_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
-                  "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32")
+                  "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32", "usf_conv_wgrad_f32",
+                  "usf_layernorm_channels_bwd_f32", "usf_gated_residual_bwd_f32")
 
 
 def _image_launch_cost(name, a):
@@ -524,6 +525,15 @@ def _image_launch_cost(name, a):
     if name == "usf_base_logprob_f32":       # (z, ldz, M, D, ...)
         M, D = int(a[2]), int(a[3])
         return ("base_logprob", D), 4.0 * M * D, 4.0 * M * D
+    if name == "usf_conv_wgrad_f32":         # (x, dy, B, cin, cout, H, W, ks, ...): exact fp32 on the f32 MFMA
+        B, cin, cout, H, W, ks = int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7])
+        return ("conv_wgrad", cin, cout, ks, H, W), 2.0 * B * H * W * cin * cout * ks * ks, 4.0 * B * H * W * (cin + cout)
+    if name == "usf_layernorm_channels_bwd_f32":   # (x, dy, dx, B, C, P, ...)
+        B, C, P = int(a[3]), int(a[4]), int(a[5])
+        return ("layernorm_channels_bwd", C, P), 16.0 * B * C * P, 12.0 * B * C * P
+    if name == "usf_gated_residual_bwd_f32":       # (dy, vg, dvg, B, CP, stream)
+        B, CP = int(a[3]), int(a[4])
+        return ("gated_residual_bwd", CP), 8.0 * B * CP, 20.0 * B * CP
     return (name,), 0.0, 0.0
 
 
@@ -570,7 +580,25 @@ def main_image(args, under_launcher):
     x = torch.rand(B, *dims, generator=g).to(dev)                    # this rank's shard, resident in HBM
     acc = torch.zeros(2, dtype=torch.float64, device=dev)
 
+    mode = args.mode or "log_prob"
+    if mode not in ("log_prob", "train"):
+        raise SystemExit("bench.py: the image configurations measure --mode log_prob (default) or train")
+    opt = None
+    if mode == "train":
+        if world > 1:
+            raise SystemExit("bench.py: image training is a single-GPU measurement (no gradient all-reduce for image flows yet)")
+        # one step of Flow.fit (flows.py:196-210) on the resident batch with the optimiser fit defaults to (SophiaG, flows.py:116)
+        from usflows_amd.sophia import SophiaG
+        opt = SophiaG(flow.parameters(), lr=1e-6) if args.optim == "sophia" else torch.optim.Adam(flow.parameters(), lr=1e-6)
+
     def step():
+        if mode == "train":
+            opt.zero_grad(set_to_none=True)
+            lp_ = flow.log_prob(x)
+            loss = -lp_.mean()
+            loss.backward()
+            opt.step()
+            return -loss.detach().double(), lp_.detach()
         return mean_log_prob(flow, x, acc=acc)
 
     for _ in range(max(args.warmup, 1)):
@@ -600,7 +628,7 @@ def main_image(args, under_launcher):
     value = global_rows * args.steps / elapsed
 
     roofline = None
-    if timing:
+    if timing and any(timing.values()):
         classes = {}
         for name, recs in timing.items():
             for e0, e1, a in recs:
@@ -612,7 +640,9 @@ def main_image(args, under_launcher):
         c = classes[dom]
         avg_ms = c["ms"] / c["n"]
         mfma_peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
-        t_mfma = c["flops"] / (mfma_peak * 1e12) if dom[0].startswith("conv2d_same") else 0.0   # only the convolutions run on the matrix cores
+        if dom[0] == "conv_wgrad":
+            mfma_peak = F32_MFMA_PEAK_TFLOPS                    # exact fp32 on v_mfma_f32_16x16x4_f32
+        t_mfma = c["flops"] / (mfma_peak * 1e12) if dom[0].startswith("conv") else 0.0   # only the convolutions run on the matrix cores
         t_hbm = c["bytes"] / (HBM_PEAK_GBS * 1e9)
         total_ms = sum(v["ms"] for v in classes.values())
         per_kernel = {"/".join(str(p_) for p_ in k): {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["n"] // args.steps,
@@ -621,7 +651,8 @@ def main_image(args, under_launcher):
         if t_mfma >= t_hbm:
             ach = c["flops"] / (avg_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(ach / mfma_peak, 4),
-                        "peak_is": "dense bf16 MFMA peak (2500) / 6 products per fp32 product (bf16x3 split)"}
+                        "peak_is": "f32-input MFMA peak (v_mfma_f32_16x16x4_f32, exact fp32)" if dom[0] == "conv_wgrad" else
+                                   "dense bf16 MFMA peak (2500) / 6 products per fp32 product (bf16x3 split)"}
         else:
             ach = c["bytes"] / (avg_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -636,7 +667,7 @@ def main_image(args, under_launcher):
     # ---- CPU baseline + parity: the image oracle (torch-CPU restatement of the reference's image path) on a bounded
     # sample of the same rows; rank 0 at N = 1 only ----
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and mode == "log_prob":
         from oracle import usflows_image_oracle as iorc           # the CPU oracle: this leg only
         spec = iorc.ImageSpec(in_dims=dims, coupling_blocks=cfg["blocks"], cond_args=dict(cfg["cond"]), householder=cfg["householder"],
                               affine_conjugation=True)
@@ -661,7 +692,8 @@ def main_image(args, under_launcher):
 
     hw = dims[1] * dims[2]
     cnd = cfg["cond"]
-    out = {"metric": f"log_prob samples/sec (whole node), image flow {args.config}", "value": round(value, 1), "unit": "samples/s",
+    what = "log_prob" if mode == "log_prob" else "training-step (log_prob + backward + optimiser step)"
+    out = {"metric": f"{what} samples/sec (whole node), image flow {args.config}", "value": round(value, 1), "unit": "samples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (3 x 3 convolutions as bf16x3 split on the bf16 MFMA: 24 significant bits, fp32 accumulate; everything else fp32 VALU)",
@@ -669,7 +701,7 @@ def main_image(args, under_launcher):
            "config": {"workload": f"{args.config}: USFlow in_dims={dims} ({cfg['ref']}), {cfg['blocks']} additive coupling blocks, "
                                   f"ConvNet2D(c_hidden {cnd['c_hidden']}, {cnd['num_layers']} gated layer(s), layer norm, ReLU), lu_transform=1, "
                                   f"householder={cfg['householder']}, affine_conjugation=True, Laplace(0,1) base (the goldens' base; the "
-                                  f"reference's config draws a radial base); log_prob of {B} rows per GPU ({global_rows} over {world} GPU(s)) "
+                                  f"reference's config draws a radial base); {what} of {B} rows per GPU ({global_rows} over {world} GPU(s)) "
                                   f"resident in HBM; conditioned synthetic parameters (seed 100)",
                       "rows_per_gpu": B, "global_rows": global_rows, "pixels": hw,
                       "parallelism": "dp1 (single GPU: no collective)" if world == 1 else

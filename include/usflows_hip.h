@@ -277,6 +277,12 @@ int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int
  * zero rows where 16 t + r >= C; cout = 32 * ceil(C / 16) is passed; out_act must be USF_ACT_NONE.
  */
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
+/* The planes above from an fp32 nn.Conv2d weight w [cout, cin, ks, ks] on the device, one launch.  transposed == 0: planes of
+ * this convolution (usf_conv2d_weight_elems(cin, cout, ks) bf16 elements).  transposed != 0: planes of the convolution that
+ * computes its DATA gradient -- cout -> cin channels with W'[ci, co, ky, kx] = w[co, ci, ks-1-ky, ks-1-kx]
+ * (usf_conv2d_weight_elems(cout, cin, ks) elements).  Not for the gated row packing (the caller packs that on the host side). */
+int usf_conv2d_weight_planes_f32(const float* w, void* planes, int64_t cin, int64_t cout, int64_t ks, int32_t transposed,
+                                 usf_stream_t stream);
 /* > 0 (samples per LDS group) when usf_conv2d_same_f32 serves these sizes: weight planes + one padded sample must fit 158 KB of LDS */
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int usf_conv2d_same_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,

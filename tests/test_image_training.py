@@ -168,6 +168,20 @@ def test_gated_residual_bwd_and_masked_product():
     assert torch.equal(out, -(om.view(1, C, P) * dy))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout,cin,ks", [(32, 16, 3), (16, 32, 3), (48, 32, 3), (64, 32, 1), (5, 3, 3), (7, 9, 1)])
+def test_weight_planes_kernel_gives_the_bits_of_the_torch_split(cout, cin, ks):
+    from usflows_amd import _ext
+    w = torch.randn(cout, cin, ks, ks, generator=torch.Generator().manual_seed(cout + cin)) * 3
+    w[0, 0, 0, 0] = 0.0
+    for transposed in (False, True):
+        ref = _ext.conv2d_weight_planes(w, transposed=transposed)                       # CPU tensor: the torch formulation
+        got = _ext.conv2d_weight_planes(w.to(DEV), transposed=transposed)                # device tensor: one launch
+        assert got.shape == ref.shape and got.dtype == torch.bfloat16
+        assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+        assert torch.equal(ref.float().sum(0)[: (cin if transposed else cout)].double().abs().sum() > 0, torch.tensor(True))
+
+
 # ---- the autograd functions against fp64 torch autograd of the same module ------------------------------------------------
 def _grads_of(module_fn, params, x, dy):
     for p in params:

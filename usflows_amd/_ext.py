@@ -176,6 +176,7 @@ SYMBOLS = {
     "usf_layernorm_channels_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_int32, C.c_float,
                                                  _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_gated_residual_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_conv2d_weight_planes_f32": (C.c_int, [_fp, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
     "usf_lu_prepare_f64": (C.c_int, [C.POINTER(LuPrepDesc), C.c_void_p]),
@@ -457,11 +458,27 @@ def layernorm_channels(x, gamma, beta, eps, act=ACT_NONE, slope=0.0):
     return y
 
 
-def conv2d_weight_planes(weight: torch.Tensor, gate_channels: int = 0) -> torch.Tensor:
+def conv2d_weight_planes(weight: torch.Tensor, gate_channels: int = 0, transposed: bool = False) -> torch.Tensor:
     """bf16x3 planes [3, coutp, kp] of a Conv2d weight [cout, cin, k, k] in the K order usf_conv2d_same_f32 reads
     (tap-major, channel-minor, channels padded to a multiple of 8; include/usflows_hip.h).  gate_channels = C > 0: the
-    weight has 2C rows (C values, C gates) and is packed for the gated mode (rows interleaved in tiles of 16)"""
+    weight has 2C rows (C values, C gates) and is packed for the gated mode (rows interleaved in tiles of 16).
+    transposed: planes of the convolution that computes the data gradient (flipped taps, channels swapped).  A device
+    weight without gate packing is split by usf_conv2d_weight_planes_f32 (one launch); the torch formulation below gives the
+    same bits (round-to-nearest-even residual split)"""
     cout, cin, k, _ = weight.shape
+    if weight.is_cuda and not gate_channels and weight.dtype == torch.float32:
+        lib = load()
+        w = weight.detach().contiguous()
+        rows, cols = (cin, cout) if transposed else (cout, cin)
+        cp, coutp = (cols + 7) // 8 * 8, (rows + 15) // 16 * 16
+        planes = torch.empty(3, coutp, (k * k * cp + 31) // 32 * 32, dtype=torch.bfloat16, device=weight.device)
+        assert planes.numel() == lib.usf_conv2d_weight_elems(cols, rows, k)
+        check(lib.usf_conv2d_weight_planes_f32(w.data_ptr(), planes.data_ptr(), cin, cout, k, int(transposed),
+                                               current_stream(weight.device)), "usf_conv2d_weight_planes_f32")
+        return planes
+    if transposed:
+        weight = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+        cout, cin = cin, cout
     w32 = weight.detach().to(torch.float32)
     if gate_channels:
         w32 = w32[conv2d_gate_row_order(gate_channels, weight.device)] * \

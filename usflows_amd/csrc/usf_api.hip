@@ -83,6 +83,7 @@ int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B
                            int32_t act, float slope, float* dgamma, float* dbeta, float* workspace, int64_t workspace_floats,
                            hipStream_t stream);
 int gated_residual_bwd(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, hipStream_t stream);
+int conv2d_weight_planes(const float* w, void* planes, int64_t cin, int64_t cout, int64_t ks, int32_t transposed, hipStream_t stream);
 int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, float beta1, float one_minus_beta1, float rho_bs,
                  float neg_lr, int32_t maximize, hipStream_t stream);
 int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2, hipStream_t stream);
@@ -258,6 +259,10 @@ int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, i
                                    int64_t workspace_floats, usf_stream_t stream) {
   return usf::layernorm_channels_bwd(x, dy, dx, B, C, P, gamma, eps, act, slope, dgamma_dbeta, dgamma_dbeta ? dgamma_dbeta + C : nullptr,
                                      workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_conv2d_weight_planes_f32(const float* w, void* planes, int64_t cin, int64_t cout, int64_t ks, int32_t transposed,
+                                 usf_stream_t stream) {
+  return usf::conv2d_weight_planes(w, planes, cin, cout, ks, transposed, (hipStream_t)stream);
 }
 int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream) {
   return usf::gated_residual_bwd(dy, vg, dvg, B, CP, (hipStream_t)stream);

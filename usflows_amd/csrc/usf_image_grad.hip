@@ -403,6 +403,51 @@ int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B
   return check_launch("usf_layernorm_channels_bwd_f32 (reduce)");
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight planes of usf_conv2d_same_f32 from an fp32 nn.Conv2d weight [cout, cin, ks, ks] in one launch (the training step
+// needs them twice per convolution and step: as they are, and flipped / transposed for the data gradient):
+//   planes[q][co][tap * cp + ci] = q-th bf16 term of W[co, ci, tap]           (transposed == 0)
+//                                = q-th bf16 term of W[ci, co, ks*ks-1 - tap] (transposed != 0: rows = the forward's INPUT channels)
+// round-to-nearest-even residual split h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); zeros in all padding.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, int rows,
+                                                                 int cols, int ks2, int cp, int kp, int coutp, int transposed) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= coutp * kp) return;
+  const int r = i / kp, k = i - r * kp;
+  const int tap = k / cp, c = k - tap * cp;
+  float v = 0.f;
+  if (r < rows && tap < ks2 && c < cols)
+    v = transposed ? w[((int64_t)c * rows + r) * ks2 + (ks2 - 1 - tap)] : w[((int64_t)r * cols + c) * ks2 + tap];
+  const unsigned short h = bf16_rne(v);
+  const float r1 = v - bf16_to_f32(h);
+  const unsigned short m = bf16_rne(r1);
+  const unsigned short l = bf16_rne(r1 - bf16_to_f32(m));
+  planes[i] = h;
+  planes[(int64_t)coutp * kp + i] = m;
+  planes[2 * (int64_t)coutp * kp + i] = l;
+}
+
+int conv2d_weight_planes(const float* w, void* planes, int64_t cin, int64_t cout, int64_t ks, int32_t transposed, hipStream_t stream) {
+  if (cin <= 0 || cout <= 0 || cin > 4096 || cout > 4096 || (ks != 1 && ks != 3)) { set_error("usf_conv2d_weight_planes_f32: bad sizes"); return -2; }
+  if (!w || !planes) { set_error("usf_conv2d_weight_planes_f32: null pointer"); return -1; }
+  // rows / cols of the packed matrix: the convolution the planes are FOR maps `cols` channels to `rows` channels
+  const int rows = (int)(transposed ? cin : cout), cols = (int)(transposed ? cout : cin);
+  const int cp = (cols + 7) / 8 * 8, kp = (int)((ks * ks * cp + 31) / 32 * 32), coutp = (rows + 15) / 16 * 16;
+  const int n = coutp * kp;
+  hipLaunchKernelGGL(conv_weight_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w,
+                     reinterpret_cast<unsigned short*>(planes), rows, cols, (int)(ks * ks), cp, kp, coutp, (int)transposed);
+  return check_launch("usf_conv2d_weight_planes_f32");
+}
+
 // d(vg) of y = x + val * sigmoid(gate): d val = dy * s, d gate = dy * val * s * (1 - s); dx = dy (no kernel)
 __global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ vg,
                                                                  float* __restrict__ dvg, int64_t total, int64_t CP) {

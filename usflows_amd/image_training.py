@@ -83,8 +83,7 @@ class ConvSame(torch.autograd.Function):
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_train_ok was not consulted)")
             dW, db = r
         if ctx.needs_input_grad[0]:
-            wt = w.flip(2, 3).transpose(0, 1).contiguous() if ks > 1 else w.transpose(0, 1).contiguous()
-            dx = _ext.conv2d_same(dy, _ext.conv2d_weight_planes(wt), w.shape[1], ks)
+            dx = _ext.conv2d_same(dy, _ext.conv2d_weight_planes(w, transposed=True), w.shape[1], ks)
             _gate_inplace(dx, x, in_act)
             if in_mul is not None:
                 dx = _ext.masked_residual(None, dx, in_mul, 1.0)
