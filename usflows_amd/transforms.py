@@ -756,7 +756,10 @@ class BlockAffineTransform(BaseTransform):
         if self._use_channel_hip(x):
             return self._channel_hip(x, True)
         if self._channel_train(x):
-            from .image_training import ChannelAffine
+            from .image_training import ChannelAffine, current_prep
+            prep = current_prep(self.block_transform)
+            if prep is not None:
+                return ChannelAffine.apply(x, prep[0], prep[2], False)
             return ChannelAffine.apply(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device), False)
         w = self.block_transform.matrix().view(self.block_size, self.block_size, *([1] * self.input_rank)).to(x.device)
         return self.global_transform(x, w, self.block_transform.bias().to(x.device))
@@ -771,7 +774,10 @@ class BlockAffineTransform(BaseTransform):
         if self._use_channel_hip(y):
             return self._channel_hip(y, False)
         if self._channel_train(y):
-            from .image_training import ChannelAffine
+            from .image_training import ChannelAffine, current_prep
+            prep = current_prep(self.block_transform)
+            if prep is not None:
+                return ChannelAffine.apply(y, prep[1], prep[2], True)
             return ChannelAffine.apply(y, self.block_transform.inverse_matrix().to(y.device),
                                        self.block_transform.bias().to(y.device), True)
         w = self.block_transform.inverse_matrix().view(self.block_size, self.block_size,
@@ -780,6 +786,11 @@ class BlockAffineTransform(BaseTransform):
         return self.global_transform(y - b, w)
 
     def log_abs_det_jacobian(self, x, y, context=None):
+        if self.input_rank >= 1 and torch.is_grad_enabled():
+            from .image_training import current_prep
+            prep = current_prep(self.block_transform)           # (inside Flow.log_prob of an image flow in training)
+            if prep is not None:
+                return prep[3] * self.n_blocks
         return self.block_transform.log_abs_det_jacobian(x, y, context) * self.n_blocks
 
     def sign(self):
