@@ -308,7 +308,7 @@ int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, in
  *     db[co]             = sum_{b, p} dy[b, co, p]                                             (db may be NULL)
  *   with xin = in_act(x - pre_sub[ci]) * in_mul -- the input transforms of usf_conv2d_same_f32 (in_act, in_mul) and of
  *   usf_channel_affine_f32 (pre_sub), each optional -- and zeros outside the image.  Exact fp32 products and sums on
- *   v_mfma_f32_16x16x4_f32.  Served: cin, cout multiples of 16 up to 64 (kernel 3: cin * cout <= 1536), H * W <= 64, 16-byte
+ *   v_mfma_f32_16x16x4_f32.  Served: cin, cout multiples of 16 up to 64 (kernel 3: cin * cout <= 1536), H * W <= 64, W >= 2, 16-byte
  *   aligned tensors; returns 1 (nothing written) for other shapes, 0 when done, < 0 on error.  workspace: at least
  *   usf_conv_wgrad_workspace(...) floats (0 = shape not served).  The DATA gradient of these layers is the forward entry point
  *   on the flipped, transposed weight (usf_conv2d_same_f32 / usf_pointwise_conv_f32 / usf_channel_affine_f32).

@@ -56,7 +56,7 @@ def test_mirror_autograd_matches_reference_gradients_cpu(name):
 WG_SHAPES = [  # (cin, cout, H, W, ks)
     (16, 32, 7, 7, 3), (32, 32, 7, 7, 3), (32, 16, 7, 7, 3), (32, 64, 7, 7, 1), (16, 16, 7, 7, 1),
     (48, 32, 8, 8, 3), (32, 32, 8, 8, 3), (32, 48, 8, 8, 3), (32, 64, 8, 8, 1), (48, 48, 8, 8, 1), (64, 32, 8, 8, 1),
-    (16, 16, 3, 5, 3), (32, 16, 1, 1, 3), (16, 48, 8, 8, 3),
+    (16, 16, 3, 5, 3), (32, 16, 1, 2, 3), (16, 48, 8, 8, 3), (32, 32, 6, 8, 1), (16, 32, 2, 2, 1),
 ]
 
 
@@ -123,6 +123,7 @@ def test_conv_wgrad_full_batch_and_unserved_shapes():
     assert _ext.conv_wgrad(torch.zeros(2, 24, 7, 7, device=DEV), torch.zeros(2, 32, 7, 7, device=DEV), 3) is None
     assert _ext.conv_wgrad(torch.zeros(2, 16, 9, 9, device=DEV), torch.zeros(2, 16, 9, 9, device=DEV), 3) is None
     assert _ext.conv_wgrad(torch.zeros(2, 64, 8, 8, device=DEV), torch.zeros(2, 64, 8, 8, device=DEV), 3) is None
+    assert _ext.conv_wgrad(torch.zeros(2, 16, 5, 1, device=DEV), torch.zeros(2, 16, 5, 1, device=DEV), 3) is None      # (W == 1)
 
 
 @pytest.mark.gpu

@@ -1,6 +1,4 @@
-#!/usr/bin/env python3
-"""usf_wgrad_f32 at the training shapes of the cfg2 model (tuning aid): ms per launch and fp32-equivalent TFLOP/s.
-USF_WGRAD_OLD=1 selects the round-1 bf16x3 kernel, USF_WGRAD_BLOCKS=n the block target of the loader-wave kernel."""
+"""usf_conv_wgrad_f32 / usf_layernorm_channels_bwd_f32 alone at the image models' shapes (python3 tools/bench_wgrad.py)"""
 import os
 import sys
 
@@ -9,25 +7,36 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from usflows_amd import _ext  # noqa: E402
 
-_ext.load()
 dev = "cuda:0"
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for N, K in [(784, 784), (256, 392), (256, 256), (392, 256)]:
-    ld_y, ld_a = (N + 3) // 4 * 4, (K + 3) // 4 * 4
-    Y = torch.randn(M, ld_y, device=dev)
-    A = torch.randn(M, ld_a, device=dev)
-    G = torch.zeros(N, K, device=dev)
-    ref = (Y[:4096, :N].double().t() @ A[:4096, :K].double())
-    _ext.wgrad(Y[:4096], A[:4096], G, M=4096, N=N, K=K, ldy=ld_y, lda=ld_a, ldg=K, mode=1)
-    err = (G.double() - ref).abs().max().item() / ref.abs().max().item()
-    for _ in range(3):
-        _ext.wgrad(Y, A, G, M=M, N=N, K=K, ldy=ld_y, lda=ld_a, ldg=K, mode=1)
+SHAPES = [(65536, 32, 32, 7, 7, 3), (65536, 16, 32, 7, 7, 3), (65536, 32, 16, 7, 7, 3), (65536, 32, 64, 7, 7, 1), (65536, 16, 16, 7, 7, 1),
+          (16384, 32, 32, 8, 8, 3), (16384, 48, 32, 8, 8, 3), (16384, 32, 48, 8, 8, 3), (16384, 48, 48, 8, 8, 1)]
+
+
+def timeit(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    it = 20
     e0.record()
-    for _ in range(it):
-        _ext.wgrad(Y, A, G, M=M, N=N, K=K, ldy=ld_y, lda=ld_a, ldg=K, mode=1)
+    for _ in range(n):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / it
-    print(f"wgrad M={M} N={N} K={K}: {ms:.3f} ms  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s fp32-equivalent  (4096-row check: rel err {err:.1e})", flush=True)
+    return e0.elapsed_time(e1) / n
+
+
+out = []
+for B, cin, cout, H, W, ks in SHAPES:
+    x = torch.randn(B, cin, H, W, device=dev)
+    dy = torch.randn(B, cout, H, W, device=dev)
+    pre = torch.randn(cin, device=dev) if ks == 1 and cin == cout else None
+    ms = timeit(lambda: _ext.conv_wgrad(x, dy, ks, pre_sub=pre))
+    fl = 2.0 * B * H * W * cin * cout * ks * ks
+    by = 4.0 * B * H * W * (cin + cout)
+    out.append(f"{cin}->{cout} k{ks} {H}x{W}: {ms:.3f} ms ({fl / ms / 1e9:.1f} TF/s, {by / ms / 1e6:.0f} GB/s)")
+for B, C, P in [(65536, 32, 49), (16384, 32, 64)]:
+    x = torch.randn(B, C, P, device=dev)
+    dy = torch.randn(B, C, P, device=dev)
+    g = torch.ones(C, device=dev)
+    ms = timeit(lambda: _ext.layernorm_channels_bwd(x, dy, g, 1e-5, _ext.ACT_LEAKY_RELU, 0.0))
+    out.append(f"ln_bwd C{C} P{P}: {ms:.3f} ms ({12.0 * B * C * P / ms / 1e6:.0f} GB/s)")
+print(f"DBG={os.environ.get('USF_WGRAD_DBG', '0')} " + " | ".join(out))

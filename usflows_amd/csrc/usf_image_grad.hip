@@ -12,16 +12,20 @@
 // Reductions over the batch are deterministic: every wave writes its partial sums to a workspace slot of its own and one
 // more launch adds the slots in a fixed order.
 #include "usf_common.h"
+#include <stdlib.h>
 
 namespace usf {
 
 // ------------------------------------------------------------------------------------------
-// Weight gradient.  One wave owns one sample at a time and ALL (cout tile, cin tile, tap) accumulator tiles, so a block
-// needs no barrier: the wave stages its sample's x and dy into a private LDS image [channel][padded position] (fp32; row
+// Weight gradient.  One wave owns one sample at a time and ALL (cout tile, cin tile, tap) accumulator tiles, so the sample
+// loop needs no barrier: the wave stages its sample's x and dy into a private LDS image [channel][padded position] (fp32; row
 // stride S = W + 1 and one zero row above / below for kernel 3, so a tap is a constant offset and the zero padding is
 // real zeros), then walks the positions four at a time: A = dy[16 co][4 q], B = x[16 ci][4 (q + tap)] -> D[co][ci].
 // The channel stride CS is 2 * odd: the 32 lanes of a ds_read_b32 group (16 channels x 2 positions) hit 32 banks.
-// The next sample's 16-byte global loads are in flight during the matrix work (registers), 1 wave per SIMD on the
+// Staging is branch-free: element -> LDS index and the input mask come from small tables the block builds once in LDS
+// (consecutive lanes take consecutive elements: coalesced loads, conflict-free stores); the nonlinearity is a select
+// (identity = leaky slope 1).  The next sample's global loads are in flight during the matrix work (registers), the
+// fragments of chunk ch + 1 are read between the MFMAs of chunk ch (sched_group_barrier), 1 wave per SIMD on the
 // 512-register budget.  MFMA-issue bound: 2 * B * HW * cin * cout * taps flops at the exact-fp32 matrix rate
 // (157 TFLOP/s), padded positions included: (H - 1) * S + W of H * W (MNIST 7 x 7: 56 / 49).
 // ------------------------------------------------------------------------------------------
@@ -31,11 +35,11 @@ struct WgArgs {
   float* part;             // [waves][nacc]
   const float* in_mul;     // [cin * HW] or NULL
   const float* pre_sub;    // [cin] or NULL
-  int B, cin, cout, HW, W, S, base, CS, nch, q0, nvx, nvy, nacc;
-  unsigned m_hw, m_w;      // ceil(2^32 / HW), ceil(2^32 / W)
-  int in_act;
-  float in_slope;
+  int B, cin, cout, HW, W, S, base, CS, nch, q0, nex, ney, nacc;
+  unsigned m_hw, m_w;      // ceil(2^32 / HW), ceil(2^32 / W)  (HW, W >= 2)
+  float slope_eff;         // leaky slope of the input nonlinearity; 1 = none
   int toff[9];
+  int tab_floats;          // LDS floats in front of the waves' images: index tables (u16), mask, pre_sub
 };
 
 template <int CIT, int COT, int T>
@@ -43,10 +47,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wg_lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-  const int wsz = (a.cin + a.cout) * a.CS;
-  float* xl = wg_lds + wave * wsz;
+  const int nex = a.nex, ney = a.ney;                          // elements per sample
+  // ---- tables (once per block), one entry per (lane, register) slot of the staging below: the LDS index of the slot's
+  // element (slots past the sample's end point at a scratch word behind the wave's image), the input mask, pre_sub
+  constexpr int NSX = CIT * 1024, NSY = COT * 1024;           // slots: 64 lanes x 16 registers per channel tile
+  unsigned short* lut_x = reinterpret_cast<unsigned short*>(wg_lds);
+  unsigned short* lut_y = lut_x + NSX;
+  float* mul = reinterpret_cast<float*>(lut_y + NSY);
+  float* psl = mul + NSX;
+  const int wsz = (a.cin + a.cout) * a.CS + 4;                 // (+ the scratch word, 16-byte granularity)
+  auto lidx = [&](int e) {
+    const int c = (int)__umulhi((unsigned)e, a.m_hw);
+    const int p = e - c * a.HW;
+    const int r = (int)__umulhi((unsigned)p, a.m_w);
+    return c * a.CS + a.base + p + r * (a.S - a.W);
+  };
+  for (int e = threadIdx.x; e < NSX; e += 256) {
+    lut_x[e] = (unsigned short)(e < nex ? lidx(e) : wsz - 4);
+    mul[e] = (a.in_mul && e < nex) ? a.in_mul[e] : 1.f;
+  }
+  for (int e = threadIdx.x; e < NSY; e += 256) lut_y[e] = (unsigned short)(e < ney ? lidx(e) : wsz - 4 - a.cin * a.CS);
+  for (int c = threadIdx.x; c < a.cin; c += 256) psl[c] = a.pre_sub ? a.pre_sub[c] : 0.f;
+  float* xl = wg_lds + a.tab_floats + wave * wsz;
   float* dl = xl + a.cin * a.CS;
   for (int i = lane; i < wsz; i += 64) xl[i] = 0.f;           // padding positions stay zero for the whole launch
+  __syncthreads();
 
   f32x4 acc[COT][CIT][T];
 #pragma unroll
@@ -59,93 +84,94 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 #pragma unroll
   for (int i = 0; i < COT; ++i) bs[i] = 0.f;
 
-  constexpr int VX = CIT * 4, VY = COT * 4;                   // 16-byte vectors per lane (HW <= 64)
-  constexpr int UNR = (COT * CIT * T > 36) ? 1 : 2;           // position chunks in flight (register budget)
-  f32x4 px[VX], py[VY];
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
-  const f32x4* y4 = reinterpret_cast<const f32x4*>(a.dy);
-  const f32x4* m4 = reinterpret_cast<const f32x4*>(a.in_mul);
-
+  constexpr int VX = CIT * 16, VY = COT * 16;                 // dwords per lane (HW <= 64): lane l holds elements l + 64 j
+  float px[VX], py[VY];
+  // no predicates anywhere: a slot past the end re-reads the sample's last element and stores it to the scratch word
   auto gload = [&](int s) {
-    const f32x4* xs = x4 + (int64_t)s * a.nvx;
-    const f32x4* ys = y4 + (int64_t)s * a.nvy;
+    const float* xs = a.x + (int64_t)s * nex;
+    const float* ys = a.dy + (int64_t)s * ney;
+    int z;                                                     // (opaque zero: the clamped offsets are not kept in registers)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 #pragma unroll
     for (int j = 0; j < VX; ++j) {
-      const int v = lane + 64 * j;
-      if (v < a.nvx) px[j] = xs[v];
+      const int e = lane + 64 * j + z;
+      px[j] = xs[e < nex ? e : nex - 1];
     }
 #pragma unroll
     for (int j = 0; j < VY; ++j) {
-      const int v = lane + 64 * j;
-      if (v < a.nvy) py[j] = ys[v];
+      const int e = lane + 64 * j + z;
+      py[j] = ys[e < ney ? e : ney - 1];
     }
   };
-  // element e of a sample -> (channel, LDS index)
-  auto lidx = [&](int e, int& c) {
-    c = a.m_hw ? (int)__umulhi((unsigned)e, a.m_hw) : e;       // (magic 0: divisor 1)
-    const int p = e - c * a.HW;
-    const int r = a.m_w ? (int)__umulhi((unsigned)p, a.m_w) : p;
-    return c * a.CS + a.base + p + r * (a.S - a.W);
-  };
+  const bool has_ps = a.pre_sub != nullptr;
   auto stage = [&]() {
+    // the table entries are re-read per sample (two LDS reads per element under the matrix work) instead of living in ~150
+    // registers for the whole launch: `z` is an opaque zero the compiler cannot hoist the reads across
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 #pragma unroll
     for (int j = 0; j < VX; ++j) {
-      const int v = lane + 64 * j;
-      if (v < a.nvx) {
-        f32x4 m = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (m4) m = m4[v];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int c;
-          const int idx = lidx(4 * v + i, c);
-          float val = px[j][i];
-          if (a.pre_sub) val -= a.pre_sub[c];
-          val = act_apply(val, a.in_act, a.in_slope);
-          xl[idx] = val * m[i];
-        }
-      }
+      const int e = lane + 64 * j + z;
+      float val = px[j];
+      if (has_ps) val -= psl[__umulhi((unsigned)(e < nex ? e : 0), a.m_hw)];   // (wave-uniform; the 1 x 1 fallback path only)
+      val = val > 0.f ? val : val * a.slope_eff;
+      xl[lut_x[e]] = val * mul[e];
+      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // eight elements' table reads in flight, not all of them
     }
 #pragma unroll
     for (int j = 0; j < VY; ++j) {
-      const int v = lane + 64 * j;
-      if (v < a.nvy) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int c;
-          const int idx = lidx(4 * v + i, c);
-          dl[idx] = py[j][i];
-        }
-      }
+      dl[lut_y[lane + 64 * j + z]] = py[j];
+      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   int s = gw;
   if (s < a.B) gload(s);
   const int loff = (lane & 15) * a.CS + a.q0 + (lane >> 4);
+  constexpr int NR = COT + CIT * T, NM = COT * CIT * T;        // fragment reads / MFMAs per chunk
   for (; s < a.B; s += nw) {
     stage();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (s + nw < a.B) gload(s + nw);
-#pragma unroll UNR
-    for (int ch = 0; ch < a.nch; ++ch) {
+    float av[2][COT], bv[2][CIT][T];
+    auto frags = [&](int ch, int slot) {                       // (a chunk past the last one reads slack, never used)
       const int o = loff + 4 * ch;
-      float av[COT], bv[CIT][T];
 #pragma unroll
-      for (int i = 0; i < COT; ++i) av[i] = dl[i * 16 * a.CS + o];
+      for (int i = 0; i < COT; ++i) av[slot][i] = dl[i * 16 * a.CS + o];
 #pragma unroll
       for (int j = 0; j < CIT; ++j)
 #pragma unroll
-        for (int t = 0; t < T; ++t) bv[j][t] = xl[j * 16 * a.CS + o + a.toff[t]];
+        for (int t = 0; t < T; ++t) bv[slot][j][t] = xl[j * 16 * a.CS + o + a.toff[t]];
+    };
+    auto mults = [&](int slot) {
 #pragma unroll
       for (int i = 0; i < COT; ++i) {
-        bs[i] += av[i];
+        bs[i] += av[slot][i];
 #pragma unroll
         for (int j = 0; j < CIT; ++j)
 #pragma unroll
-          for (int t = 0; t < T; ++t) acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j][t], acc[i][j][t], 0, 0, 0);
+          for (int t = 0; t < T; ++t)
+            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[slot][i], bv[slot][j][t], acc[i][j][t], 0, 0, 0);
       }
+    };
+    auto interleave = [&]() {                                  // one fragment read of the next chunk per MFMA of this one
+#pragma unroll
+      for (int r = 0; r < (NR < NM ? NR : NM); ++r) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    };
+    frags(0, 0);
+    for (int ch = 0; ch + 1 < a.nch; ch += 2) {
+      frags(ch + 1, 1);
+      mults(0);
+      interleave();
+      frags(ch + 2, 0);
+      mults(1);
+      interleave();
     }
+    if (a.nch & 1) mults(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -171,23 +197,108 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
   }
 }
 
+// Kernel 1 (the pointwise convolution of GatedConv, the 1 x 1 convolution of BlockAffineTransform) without an input mask,
+// 48 < HW <= 64: no tap shifts, so the order of the positions inside the sum is free as long as both operands use the same
+// one.  Lane (channel c = l & 15, quad kq = l >> 4) reads the 16 bytes of positions 16 m + 4 kq + {0..3} of its channel row
+// from HBM (64 contiguous bytes per row and instruction) and MFMA (m, r) takes component r of every lane: no LDS, no
+// staging, no shuffles, no branches; a handful of waves per SIMD hide the latency.  A row that is not a multiple of 16 long
+// reads its LAST 16 positions as the fourth block (whole loads, all inside the row) and the positions the third block
+// already covered are zeroed in the dy operand, so every position enters the sums once.
+// HBM-bound: 4 (cin + cout) bytes per pixel.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // (channel rows of 49 floats are only 4-byte aligned)
+
+template <int CIT, int COT>
+__global__ __launch_bounds__(256) void conv_wgrad_k1_kernel(const WgArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  const int ch_l = lane & 15, kq = lane >> 4;
+  f32x4 acc[COT][CIT];
+  float bs[COT], ps[CIT];
+#pragma unroll
+  for (int i = 0; i < COT; ++i) {
+    bs[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CIT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < CIT; ++j) ps[j] = a.pre_sub ? a.pre_sub[j * 16 + ch_l] : 0.f;
+  const int HW = a.HW;
+  int p0[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) p0[m] = 16 * m + 4 * kq;
+  p0[3] = HW - 16 + 4 * kq;                                    // (== 48 + 4 kq when HW == 64)
+  f32x4 keep;                                                  // 1 where the fourth block's position is new, 0 where block 2 had it
+#pragma unroll
+  for (int r = 0; r < 4; ++r) keep[r] = (p0[3] + r >= 48) ? 1.f : 0.f;
+  for (int s = gw; s < a.B; s += nw) {
+    const float* xs = a.x + ((int64_t)s * a.cin + ch_l) * HW;
+    const float* ys = a.dy + ((int64_t)s * a.cout + ch_l) * HW;
+    f32x4 fa[COT][4], fb[CIT][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int i = 0; i < COT; ++i) fa[i][m] = *reinterpret_cast<const f32x4u*>(ys + i * 16 * HW + p0[m]);
+#pragma unroll
+      for (int j = 0; j < CIT; ++j) fb[j][m] = *reinterpret_cast<const f32x4u*>(xs + j * 16 * HW + p0[m]);
+    }
+#pragma unroll
+    for (int i = 0; i < COT; ++i) fa[i][3] = fa[i][3] * keep;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float bvv[CIT];
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) {
+          const float v = fb[j][m][r] - ps[j];
+          bvv[j] = v > 0.f ? v : v * a.slope_eff;
+        }
+#pragma unroll
+        for (int i = 0; i < COT; ++i) {
+          bs[i] += fa[i][m][r];
+#pragma unroll
+          for (int j = 0; j < CIT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][m][r], bvv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+  }
+  float* pw = a.part + (int64_t)gw * a.nacc;
+#pragma unroll
+  for (int i = 0; i < COT; ++i)
+#pragma unroll
+    for (int j = 0; j < CIT; ++j) {
+      const int tile = i * CIT + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[tile * 256 + r * 64 + lane] = acc[i][j][r];
+    }
+#pragma unroll
+  for (int i = 0; i < COT; ++i) {
+    float v = bs[i];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 16) pw[COT * CIT * 256 + i * 16 + lane] = v;
+  }
+}
+
 // out[j] = sum over the partial slots in a fixed order (four interleaved chains, then ((0 + 1) + 2) + 3).
 // mode 0: out[j] for j < n.  mode 1 (weight gradient): slot layout of conv_wgrad_kernel -> dW [cout][cin][T], db [cout].
-__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out,
-                                                          float* __restrict__ out2, int mode, int cin, int cout, int CIT, int T,
-                                                          int ntile) {
+// blockIdx.y selects a slice of `per` slots and (mode 0) its own output row: reduce_partials below adds many slots in two
+// rounds so that the sum over thousands of slots is not left to a handful of blocks.
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, int nparts, int per, int n,
+                                                          float* __restrict__ out, float* __restrict__ out2, int mode, int cin,
+                                                          int cout, int CIT, int T, int ntile) {
   __shared__ float red[4][64];
   const int jj = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jj;
+  const int p0 = blockIdx.y * per, p1 = (p0 + per < nparts) ? p0 + per : nparts;
   float s = 0.f;
   if (j < n)
-    for (int p = g; p < nparts; p += 4) s += part[(int64_t)p * n + j];
+    for (int p = p0 + g; p < p1; p += 4) s += part[(int64_t)p * n + j];
   red[g][jj] = s;
   __syncthreads();
   if (g != 0 || j >= n) return;
   const float total = ((red[0][jj] + red[1][jj]) + red[2][jj]) + red[3][jj];
   if (mode == 0) {
-    out[j] = total;
+    out[(int64_t)blockIdx.y * n + j] = total;
     return;
   }
   if (j >= ntile * 256) {
@@ -201,19 +312,78 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
   if (co < cout && ci < cin) out[((int64_t)co * cin + ci) * T + t] = total;
 }
 
-// ceil(2^32 / d): floor(n / d) == umulhi(n, magic) for n * d < 2^32; 0 stands for d == 1
-static unsigned magic_div(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+constexpr int kReduceRows = 64;        // scratch rows of the two-round sum (workspace: kReduceRows * n floats behind the slots)
+
+// sum of `nparts` slots of n floats: one round up to 64 slots, else a first round into <= 64 rows of scratch
+static int reduce_partials(const float* part, int nparts, int n, float* scratch, float* out, float* out2, int mode, int cin, int cout,
+                           int CIT, int T, int ntile, hipStream_t stream, const char* what) {
+  const unsigned gx = (unsigned)((n + 63) / 64);
+  if (nparts > 64) {
+    const int rows = nparts / 16 < kReduceRows ? (nparts + 15) / 16 : kReduceRows;
+    const int per = (nparts + rows - 1) / rows;
+    const int used = (nparts + per - 1) / per;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(gx, (unsigned)used), dim3(256), 0, stream, part, nparts, per, n, scratch,
+                       (float*)nullptr, 0, 0, 0, 0, 0, 0);
+    part = scratch;
+    nparts = used;
+  }
+  hipLaunchKernelGGL(partial_sum_kernel, dim3(gx, 1u), dim3(256), 0, stream, part, nparts, nparts, n, out, out2, mode, cin, cout, CIT, T, ntile);
+  return check_launch(what);
+}
+
+// ceil(2^32 / d), d >= 2: floor(n / d) == umulhi(n, magic) for n * d < 2^32
+static unsigned magic_div(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
 // workspace floats needed by conv_wgrad for this shape / batch (0: shape not served)
 int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 
+#define USF_WG_INSTANCES(X)                                                                                                \
+  X(1, 1, 9) X(1, 2, 9) X(2, 1, 9) X(2, 2, 9) X(3, 2, 9) X(2, 3, 9) X(1, 3, 9) X(3, 1, 9)                                  \
+  X(1, 1, 1) X(1, 2, 1) X(2, 1, 1) X(2, 2, 1) X(2, 4, 1) X(4, 2, 1) X(3, 3, 1) X(4, 4, 1)                                  \
+  X(1, 4, 1) X(4, 1, 1) X(3, 2, 1) X(2, 3, 1) X(1, 3, 1) X(3, 1, 1) X(3, 4, 1) X(4, 3, 1)
+
+#define USF_WG_K1_INSTANCES(X)                                                                                             \
+  X(1, 1) X(1, 2) X(1, 3) X(1, 4) X(2, 1) X(2, 2) X(2, 3) X(2, 4) X(3, 1) X(3, 2) X(3, 3) X(3, 4) X(4, 1) X(4, 2) X(4, 3) X(4, 4)
+
 namespace {
+int wgrad_k1_blocks_per_cu(int CIT, int COT) {
+  int nb = 0;
+#define USF_WG_OCC1(CIT_, COT_)                                                                                            \
+  if (CIT == CIT_ && COT == COT_ &&                                                                                        \
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv_wgrad_k1_kernel<CIT_, COT_>),  \
+                                                   256, 0) != hipSuccess) nb = 1;
+  USF_WG_K1_INSTANCES(USF_WG_OCC1)
+#undef USF_WG_OCC1
+  return nb < 1 ? 1 : nb;
+}
+
+// resident blocks per CU of an instance at this LDS size (registers and LDS decide); 0: no such instance
+int wgrad_blocks_per_cu(int CIT, int COT, int T, int lds_bytes) {
+  static bool attr_done[USF_MAX_DEVICES][5][5][2];
+  const int dev = current_device_slot();
+  int nb = 0;
+#define USF_WG_OCC(CIT_, COT_, T_)                                                                                         \
+  if (CIT == CIT_ && COT == COT_ && T == T_) {                                                                             \
+    const void* fn = reinterpret_cast<const void*>(&conv_wgrad_kernel<CIT_, COT_, T_>);                                    \
+    if (!attr_done[dev][CIT_][COT_][T_ == 9]) {                                                                            \
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 0;         \
+      attr_done[dev][CIT_][COT_][T_ == 9] = true;                                                                          \
+    }                                                                                                                      \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)lds_bytes) != hipSuccess) nb = 1;               \
+    if (nb < 1) nb = 1;                                                                                                    \
+  }
+  USF_WG_INSTANCES(USF_WG_OCC)
+#undef USF_WG_OCC
+  return nb;
+}
+
 struct WgPlan {
-  int CIT, COT, T, S, base, CS, nch, q0, nacc, lds_bytes, blocks;
+  int CIT, COT, T, S, base, CS, nch, q0, nacc, lds_bytes, blocks, tab_floats;
+  bool direct;               // kernel 1 without an input mask: conv_wgrad_k1_kernel
 };
-bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks, WgPlan& pl) {
-  if (B <= 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || H <= 0 || W <= 0 || H * W > 64 || (ks != 1 && ks != 3))
-    return false;
+bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks, bool masked, WgPlan& pl) {
+  if (B <= 0 || cin <= 0 || cout <= 0 || (cin & 15) || (cout & 15) || H <= 0 || W < 2 || H * W > 64 || (ks != 1 && ks != 3))
+    return false;                                                // (W >= 2: the index tables divide by W and H * W with 32-bit magic numbers)
   pl.CIT = (int)(cin / 16);
   pl.COT = (int)(cout / 16);
   pl.T = (int)(ks * ks);
@@ -226,13 +396,13 @@ bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int6
     pl.q0 = pl.S + 1;
     const int nk = (int)((H - 1) * pl.S + W);                    // padded positions from the first to the last pixel
     pl.nch = (nk + 3) / 4;
-    need = pl.q0 + 4 * pl.nch + pl.S + 1;                         // last position read + 1
+    need = pl.q0 + 4 * (pl.nch + 1) + pl.S + 1;                   // last position read (one chunk of slack) + 1
   } else {
     pl.S = (int)W;
     pl.base = 0;
     pl.q0 = 0;
     pl.nch = (int)((H * W + 3) / 4);
-    need = 4 * pl.nch;
+    need = 4 * (pl.nch + 1);
   }
   const int full = (ks == 3) ? (int)((H + 2) * pl.S + 1) : (int)(H * W);
   if (need < full) need = full;
@@ -240,9 +410,23 @@ bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int6
   if (!(cs & 1)) ++cs;
   pl.CS = 2 * cs;
   pl.nacc = pl.COT * pl.CIT * pl.T * 256 + pl.COT * 16;
-  pl.lds_bytes = 4 * (int)(cin + cout) * pl.CS * 4;
+  pl.direct = (ks == 1 && !masked && H * W > 48);
+  if (pl.direct) {
+    pl.lds_bytes = 0;
+    int per_cu = wgrad_k1_blocks_per_cu(pl.CIT, pl.COT);
+    if (per_cu > 8) per_cu = 8;
+    int64_t blocks = (B + 3) / 4;
+    const int64_t cap = (int64_t)device_cu_count() * per_cu;
+    pl.blocks = (int)(blocks > cap ? cap : blocks);
+    return true;
+  }
+  pl.tab_floats = (pl.CIT * 1024 + pl.COT * 1024) / 2 + pl.CIT * 1024 + (int)cin;      // index tables (u16), mask, pre_sub
+  pl.tab_floats = (pl.tab_floats + 3) & ~3;
+  pl.lds_bytes = (pl.tab_floats + 4 * ((int)(cin + cout) * pl.CS + 4)) * 4;
   if (pl.lds_bytes > 160 * 1024) return false;
-  const int per_cu = (2 * pl.lds_bytes <= 160 * 1024 && pl.CIT * pl.COT * pl.T * 4 <= 96) ? 2 : 1;
+  int per_cu = wgrad_blocks_per_cu(pl.CIT, pl.COT, pl.T, pl.lds_bytes);
+  if (per_cu <= 0) return false;
+  if (per_cu > 4) per_cu = 4;                                    // (more partial slots than that buy nothing)
   int64_t blocks = (B + 3) / 4;
   const int64_t cap = (int64_t)device_cu_count() * per_cu;
   if (blocks > cap) blocks = cap;
@@ -252,9 +436,10 @@ bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int6
 }  // namespace
 
 int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) {
-  WgPlan pl;
-  if (!wgrad_plan(B, cin, cout, H, W, ks, pl)) return 0;
-  return (int64_t)pl.blocks * 4 * pl.nacc;
+  // (the masked form of kernel 1 needs at least the slots of the direct form: both sized here)
+  WgPlan pl, pm;
+  if (!wgrad_plan(B, cin, cout, H, W, ks, false, pl) || !wgrad_plan(B, cin, cout, H, W, ks, true, pm)) return 0;
+  return ((int64_t)(pl.blocks > pm.blocks ? pl.blocks : pm.blocks) * 4 + kReduceRows) * pl.nacc;
 }
 
 int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
@@ -262,46 +447,46 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
                int64_t workspace_floats, hipStream_t stream) {
   WgPlan pl;
   if (B < 0) { set_error("usf_conv_wgrad_f32: bad sizes"); return -2; }
-  if (B == 0 || !wgrad_plan(B, cin, cout, H, W, ks, pl)) {
+  if (B == 0 || !wgrad_plan(B, cin, cout, H, W, ks, in_mul != nullptr, pl)) {
     if (B == 0) { set_error("usf_conv_wgrad_f32: empty batch"); return -2; }
     return 1;                                                     // shape not served
   }
   if (!x || !dy || !dW || !workspace) { set_error("usf_conv_wgrad_f32: null pointer"); return -1; }
   if (!aligned16(x) || !aligned16(dy) || (in_mul && !aligned16(in_mul))) { set_error("usf_conv_wgrad_f32: tensors must be 16-byte aligned"); return -2; }
   if (in_act != USF_ACT_NONE && in_act != USF_ACT_LEAKY_RELU) { set_error("usf_conv_wgrad_f32: bad act"); return -2; }
-  if (workspace_floats < (int64_t)pl.blocks * 4 * pl.nacc) { set_error("usf_conv_wgrad_f32: workspace too small"); return -2; }
+  if (workspace_floats < ((int64_t)pl.blocks * 4 + kReduceRows) * pl.nacc) { set_error("usf_conv_wgrad_f32: workspace too small"); return -2; }
   WgArgs a;
   a.x = x; a.dy = dy; a.part = workspace; a.in_mul = in_mul; a.pre_sub = pre_sub;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.HW = (int)(H * W); a.W = (int)W; a.S = pl.S; a.base = pl.base;
-  a.CS = pl.CS; a.nch = pl.nch; a.q0 = pl.q0; a.nvx = (int)(cin * H * W / 4); a.nvy = (int)(cout * H * W / 4); a.nacc = pl.nacc;
-  a.m_hw = magic_div(a.HW); a.m_w = magic_div(a.W); a.in_act = in_act; a.in_slope = in_slope;
+  a.CS = pl.CS; a.nch = pl.nch; a.q0 = pl.q0; a.nex = (int)(cin * H * W); a.ney = (int)(cout * H * W); a.nacc = pl.nacc;
+  a.m_hw = magic_div(a.HW); a.m_w = magic_div(a.W); a.slope_eff = (in_act == USF_ACT_LEAKY_RELU) ? in_slope : 1.f;
+  a.tab_floats = pl.tab_floats;
   for (int t = 0; t < 9; ++t) a.toff[t] = (ks == 3) ? ((t / 3) - 1) * pl.S + ((t % 3) - 1) : 0;
   const dim3 g((unsigned)pl.blocks), b(256);
-  static bool attr_done[USF_MAX_DEVICES][5][5][2];
-  const int dev = current_device_slot();
 #define USF_WG(CIT_, COT_, T_)                                                                                             \
   if (pl.CIT == CIT_ && pl.COT == COT_ && pl.T == T_) {                                                                     \
-    if (!attr_done[dev][CIT_][COT_][T_ == 9]) {                                                                            \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<CIT_, COT_, T_>),                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {                     \
-        set_error("usf_conv_wgrad_f32: cannot raise the dynamic LDS limit"); return -4; }                                  \
-      attr_done[dev][CIT_][COT_][T_ == 9] = true;                                                                          \
-    }                                                                                                                      \
     hipLaunchKernelGGL((conv_wgrad_kernel<CIT_, COT_, T_>), g, b, (size_t)pl.lds_bytes, stream, a);                        \
     launched = true;                                                                                                       \
   }
   bool launched = false;
-  USF_WG(1, 1, 9) USF_WG(1, 2, 9) USF_WG(2, 1, 9) USF_WG(2, 2, 9) USF_WG(3, 2, 9) USF_WG(2, 3, 9) USF_WG(1, 3, 9) USF_WG(3, 1, 9)
-  USF_WG(1, 1, 1) USF_WG(1, 2, 1) USF_WG(2, 1, 1) USF_WG(2, 2, 1) USF_WG(2, 4, 1) USF_WG(4, 2, 1) USF_WG(3, 3, 1) USF_WG(4, 4, 1)
-  USF_WG(1, 4, 1) USF_WG(4, 1, 1) USF_WG(3, 2, 1) USF_WG(2, 3, 1) USF_WG(1, 3, 1) USF_WG(3, 1, 1) USF_WG(3, 4, 1) USF_WG(4, 3, 1)
+  if (pl.direct) {
+#define USF_WG1(CIT_, COT_)                                                                                                \
+  if (pl.CIT == CIT_ && pl.COT == COT_) {                                                                                  \
+    hipLaunchKernelGGL((conv_wgrad_k1_kernel<CIT_, COT_>), g, b, 0, stream, a);                                            \
+    launched = true;                                                                                                       \
+  }
+    USF_WG_K1_INSTANCES(USF_WG1)
+#undef USF_WG1
+  } else {
+    USF_WG_INSTANCES(USF_WG)
+  }
 #undef USF_WG
   if (!launched) return 1;
   int rc = check_launch("usf_conv_wgrad_f32");
   if (rc) return rc;
   const int ntile = pl.COT * pl.CIT * pl.T;
-  hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((pl.nacc + 63) / 64)), dim3(256), 0, stream, workspace, pl.blocks * 4,
-                     pl.nacc, dW, db, 1, (int)cin, (int)cout, pl.CIT, pl.T, ntile);
-  return check_launch("usf_conv_wgrad_f32 (reduce)");
+  return reduce_partials(workspace, pl.blocks * 4, pl.nacc, workspace + (int64_t)pl.blocks * 4 * pl.nacc, dW, db, 1, (int)cin, (int)cout,
+                         pl.CIT, pl.T, ntile, stream, "usf_conv_wgrad_f32 (reduce)");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,54 +497,64 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
 // One thread per pixel, grid-stride; the parameter sums stay in registers and leave once per wave.
 // HBM-bound: 12 bytes per element.
 // ------------------------------------------------------------------------------------------
-template <int CMAX>
+template <int CMAX, bool FULL>
 __global__ __launch_bounds__(256) void layernorm_channels_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                     float* __restrict__ dx, int64_t BP, int C, int64_t P,
+                                                                     float* __restrict__ dx, int64_t BP, int C_, int64_t P,
                                                                      const float* __restrict__ gamma, float eps, int act,
                                                                      float slope, float* __restrict__ part) {
-  float dg[CMAX], dbt[CMAX];
+  const int C = FULL ? CMAX : C_;                              // FULL: every channel slot is real -- no predicates, straight-line loads
+  float dg[CMAX], dbt[CMAX], gam[CMAX];
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) dg[c] = dbt[c] = 0.f;
+  for (int c = 0; c < CMAX; ++c) {
+    dg[c] = dbt[c] = 0.f;
+    gam[c] = (FULL || c < C) ? gamma[c] : 0.f;
+  }
+  const float inv_c = 1.f / (float)C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < BP; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / P, p = i - b * P;
     const float* xb = x + b * C * P + p;
     const float* gb = dy + b * C * P + p;
-    float v[CMAX], xr[CMAX];
+    float v[CMAX], d[CMAX];
+    unsigned long long pos = 0;                                // bit c: x[c] > 0 (the nonlinearity's gate)
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {                           // both tensors' loads are in flight together
+      v[c] = (FULL || c < C) ? xb[(int64_t)c * P] : 0.f;
+      d[c] = (FULL || c < C) ? gb[(int64_t)c * P] : 0.f;
+    }
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-      xr[c] = (c < C) ? xb[(int64_t)c * P] : 0.f;
-      v[c] = (c < C) ? act_apply(xr[c], act, slope) : 0.f;
+      if (v[c] > 0.f) pos |= 1ull << c;
+      if (FULL || c < C) v[c] = act_apply(v[c], act, slope);
       sum += v[c];
     }
-    const float mean = sum / (float)C;
+    const float mean = sum * inv_c;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-      const float d = (c < C) ? v[c] - mean : 0.f;
-      sq += d * d;
+      const float t = (FULL || c < C) ? v[c] - mean : 0.f;
+      sq += t * t;
     }
-    const float den = sqrtf(sq / (float)C + eps);
+    const float rden = 1.f / sqrtf(sq * inv_c + eps);
     float m1 = 0.f, m2 = 0.f;
-    float g[CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-      const float d = (c < C) ? gb[(int64_t)c * P] : 0.f;
-      v[c] = (c < C) ? (v[c] - mean) / den : 0.f;            // xh
-      g[c] = (c < C) ? d * gamma[c] : 0.f;
-      m1 += g[c];
-      m2 += g[c] * v[c];
-      dg[c] += d * v[c];
-      dbt[c] += d;
+      v[c] = (FULL || c < C) ? (v[c] - mean) * rden : 0.f;    // xh
+      const float g = d[c] * gam[c];
+      m1 += g;
+      m2 += g * v[c];
+      dg[c] += d[c] * v[c];
+      dbt[c] += d[c];
+      d[c] = g;
     }
-    m1 /= (float)C;
-    m2 /= (float)C;
+    m1 *= inv_c;
+    m2 *= inv_c;
     float* ob = dx + b * C * P + p;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-      if (c < C) {
-        float da = (g[c] - m1 - v[c] * m2) / den;
-        if (act == USF_ACT_LEAKY_RELU) da = gate_apply(da, xr[c], slope);
+      if (FULL || c < C) {
+        float da = (d[c] - m1 - v[c] * m2) * rden;
+        if (act == USF_ACT_LEAKY_RELU && !((pos >> c) & 1ull)) da *= slope;
         ob[(int64_t)c * P] = da;
       }
   }
@@ -367,17 +562,104 @@ __global__ __launch_bounds__(256) void layernorm_channels_bwd_kernel(const float
   float* pw = part + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (2 * C);
 #pragma unroll
   for (int c = 0; c < CMAX; ++c)
-    if (c < C) {
+    if (FULL || c < C) {
       const float a = wave_sum(dg[c]), bsum = wave_sum(dbt[c]);
       if (lane == 0) { pw[c] = a; pw[C + c] = bsum; }
     }
 }
 
+// C == 2 * CPT channels, two lanes per pixel (lane l and l ^ 32 share pixel l & 31; the lower half owns channels [0, CPT), the
+// upper half [CPT, 2 CPT)): half the registers of the one-thread-per-pixel form, so 3-4 waves per SIMD keep the loads in
+// flight; every wave instruction reads two 128-byte runs.  The four per-pixel sums cross the halves by one exchange each.
+template <int CPT>
+__global__ __launch_bounds__(256) void layernorm_channels_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      float* __restrict__ dx, int64_t BP, int64_t P,
+                                                                      const float* __restrict__ gamma, float eps, int act,
+                                                                      float slope, float* __restrict__ part) {
+  constexpr int C = 2 * CPT;
+  const int lane = threadIdx.x & 63, half = lane >> 5, pl = lane & 31;
+  const int c0 = half * CPT;
+  float dg[CPT], dbt[CPT], gam[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    dg[c] = dbt[c] = 0.f;
+    gam[c] = gamma[c0 + c];
+  }
+  const float inv_c = 1.f / (float)C;
+  const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwv = (int64_t)gridDim.x * 4;
+  for (int64_t base = wv * 32; base < BP; base += nwv * 32) {       // wave-uniform trip count (the exchanges need every lane)
+    const bool valid = base + pl < BP;
+    const int64_t i = valid ? base + pl : BP - 1;
+    const int64_t b = i / P, p = i - b * P;
+    const float* xb = x + (b * C + c0) * P + p;
+    const float* gb = dy + (b * C + c0) * P + p;
+    float v[CPT], d[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      v[c] = xb[(int64_t)c * P];
+      d[c] = valid ? gb[(int64_t)c * P] : 0.f;
+    }
+    unsigned pos = 0;
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      if (v[c] > 0.f) pos |= 1u << c;
+      v[c] = act_apply(v[c], act, slope);
+      sum += v[c];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const float t = v[c] - mean;
+      sq += t * t;
+    }
+    sq += __shfl_xor(sq, 32, 64);
+    const float rden = 1.f / sqrtf(sq * inv_c + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      v[c] = (v[c] - mean) * rden;                               // xh
+      const float g = d[c] * gam[c];
+      m1 += g;
+      m2 += g * v[c];
+      dg[c] += d[c] * v[c];
+      dbt[c] += d[c];
+      d[c] = g;
+    }
+    m1 += __shfl_xor(m1, 32, 64);
+    m2 += __shfl_xor(m2, 32, 64);
+    m1 *= inv_c;
+    m2 *= inv_c;
+    if (valid) {
+      float* ob = dx + (b * C + c0) * P + p;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        float da = (d[c] - m1 - v[c] * m2) * rden;
+        if (act == USF_ACT_LEAKY_RELU && !((pos >> c) & 1u)) da *= slope;
+        ob[(int64_t)c * P] = da;
+      }
+    }
+  }
+  float* pw = part + wv * (2 * C);
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    float a = dg[c], bsum = dbt[c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {                           // within each half
+      a += __shfl_xor(a, o, 64);
+      bsum += __shfl_xor(bsum, o, 64);
+    }
+    if (pl == 0) { pw[c0 + c] = a; pw[C + c0 + c] = bsum; }
+  }
+}
+
 int64_t layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P) {
   if (B <= 0 || C <= 0 || C > 64 || P <= 0) return 0;
   int64_t blocks = (B * P + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  return blocks * 4 * 2 * C;
+  if (blocks > 2048) blocks = 2048;
+  return (blocks * 4 + kReduceRows) * 2 * C;
 }
 
 int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma, float eps,
@@ -390,17 +672,24 @@ int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B
   const int64_t need = layernorm_channels_bwd_workspace(B, C, P);
   if (workspace_floats < need) { set_error("usf_layernorm_channels_bwd_f32: workspace too small"); return -2; }
   const int64_t BP = B * P;
-  const int blocks = (int)(need / (4 * 2 * C));
+  const int blocks = (int)(need / (2 * C) - kReduceRows) / 4;
   const dim3 g((unsigned)blocks), b(256);
-  if (C <= 16) hipLaunchKernelGGL(layernorm_channels_bwd_kernel<16>, g, b, 0, stream, x, dy, dx, BP, (int)C, P, gamma, eps, act, slope, workspace);
-  else if (C <= 32) hipLaunchKernelGGL(layernorm_channels_bwd_kernel<32>, g, b, 0, stream, x, dy, dx, BP, (int)C, P, gamma, eps, act, slope, workspace);
-  else hipLaunchKernelGGL(layernorm_channels_bwd_kernel<64>, g, b, 0, stream, x, dy, dx, BP, (int)C, P, gamma, eps, act, slope, workspace);
+#define USF_LNB(CM_, FULL_) hipLaunchKernelGGL((layernorm_channels_bwd_kernel<CM_, FULL_>), g, b, 0, stream, x, dy, dx, BP, (int)C, P, gamma, eps, act, slope, workspace)
+#define USF_LNB2(CPT_) hipLaunchKernelGGL((layernorm_channels_bwd2_kernel<CPT_>), g, b, 0, stream, x, dy, dx, BP, P, gamma, eps, act, slope, workspace)
+  if (C == 16) USF_LNB2(8);
+  else if (C == 32) USF_LNB2(16);
+  else if (C == 48) USF_LNB2(24);
+  else if (C == 64) USF_LNB2(32);
+  else if (C < 16) USF_LNB(16, false);
+  else if (C < 32) USF_LNB(32, false);
+  else USF_LNB(64, false);
+#undef USF_LNB
+#undef USF_LNB2
   int rc = check_launch("usf_layernorm_channels_bwd_f32");
   if (rc) return rc;
   const int n = (int)(2 * C);
-  hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, workspace, blocks * 4, n, dgamma,
-                     (float*)nullptr, 0, 0, 0, 0, 0, 0);
-  return check_launch("usf_layernorm_channels_bwd_f32 (reduce)");
+  return reduce_partials(workspace, blocks * 4, n, workspace + (int64_t)blocks * 4 * n, dgamma, nullptr, 0, 0, 0, 0, 0, 0, stream,
+                         "usf_layernorm_channels_bwd_f32 (reduce)");
 }
 
 // ------------------------------------------------------------------------------------------
