@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--eager-train", action="store_true", help="image --mode train: eager optimiser steps instead of Flow.fit's replayed hipGraph")
     ap.add_argument("--config", choices=sorted(CONFIGS) + sorted(IMAGE_CONFIGS), default="cfg2", help="BASELINE.json configuration")
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (overrides the configuration's)")
     ap.add_argument("--dim", type=int, default=None)
@@ -591,9 +592,17 @@ def main_image(args, under_launcher):
         from usflows_amd.sophia import SophiaG
         opt = SophiaG(flow.parameters(), lr=1e-6) if args.optim == "sophia" else torch.optim.Adam(flow.parameters(), lr=1e-6)
 
+    graph_steps = [0]
+
     def step():
         if mode == "train":
-            opt.zero_grad(set_to_none=True)
+            # the optimiser step as Flow.fit issues it (flows.py:196-210): after three eager steps the step is captured as a
+            # hipGraph and replayed (Flow._train_graph_step); the eager form serves until then
+            loss = flow._train_graph_step(opt, x, None) if not args.eager_train else None
+            if loss is not None:
+                graph_steps[0] += 1
+                return torch.tensor(-loss, dtype=torch.float64), None
+            flow._zero_grad_for_step(opt)
             lp_ = flow.log_prob(x)
             loss = -lp_.mean()
             loss.backward()
@@ -601,9 +610,26 @@ def main_image(args, under_launcher):
             return -loss.detach().double(), lp_.detach()
         return mean_log_prob(flow, x, acc=acc)
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 5 if mode == "train" else 1)):
         mean, lp = step()
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and mode == "train" and not args.eager_train:
+        # per-kernel times of the step: three eager steps with HIP events around every launch (a replayed graph runs no
+        # host code to put events around), before the timed region
+        _ext.launch_timing = {n: [] for n in _IMAGE_KERNELS}
+        os.environ["USFLOWS_AMD_TRAIN_GRAPH"] = "0"
+        keep = args.eager_train
+        args.eager_train = True
+        for _ in range(3):
+            step()
+        args.eager_train = keep
+        os.environ.pop("USFLOWS_AMD_TRAIN_GRAPH", None)
+        torch.cuda.synchronize()
+        eager_timing, _ext.launch_timing = _ext.launch_timing, None
+        eager_steps = 3
+    else:
+        eager_timing, eager_steps = None, 0
+    graph_steps[0] = 0
+    if not args.no_kernel_timing and eager_timing is None:
         _ext.launch_timing = {n: [] for n in _IMAGE_KERNELS}
     if under_launcher:
         dist.barrier()
@@ -616,6 +642,9 @@ def main_image(args, under_launcher):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timing, _ext.launch_timing = _ext.launch_timing, None
+    n_timed = args.steps
+    if eager_timing is not None:
+        timing, n_timed = eager_timing, eager_steps
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if under_launcher:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -645,7 +674,7 @@ def main_image(args, under_launcher):
         t_mfma = c["flops"] / (mfma_peak * 1e12) if dom[0].startswith("conv") else 0.0   # only the convolutions run on the matrix cores
         t_hbm = c["bytes"] / (HBM_PEAK_GBS * 1e9)
         total_ms = sum(v["ms"] for v in classes.values())
-        per_kernel = {"/".join(str(p_) for p_ in k): {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["n"] // args.steps,
+        per_kernel = {"/".join(str(p_) for p_ in k): {"ms_per_step": round(v["ms"] / n_timed, 3), "launches_per_step": v["n"] // n_timed,
                                                       "hbm_frac": round(v["bytes"] / (v["ms"] / v["n"] * 1e-3) / (HBM_PEAK_GBS * 1e9), 3)}
                       for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["ms"])}
         if t_mfma >= t_hbm:
@@ -662,7 +691,10 @@ def main_image(args, under_launcher):
                          "measured_by": "HIP events around every launch of this run's timed region",
                          "avg_launch_ms": round(avg_ms, 4), "launches": c["n"], "share_of_gpu_time": round(c["ms"] / total_ms, 3),
                          "algorithmic_flops_per_launch": c["flops"], "algorithmic_bytes_per_launch": c["bytes"],
-                         "all_kernels": per_kernel, "kernel_ms_per_step": round(total_ms / args.steps, 3)})
+                         "all_kernels": per_kernel, "kernel_ms_per_step": round(total_ms / n_timed, 3)})
+        if eager_timing is not None:
+            roofline["measured_by"] = ("HIP events around every launch of three eager steps of this run, before the timed region "
+                                       "(the timed steps are hipGraph replays, as in Flow.fit)")
 
     # ---- CPU baseline + parity: the image oracle (torch-CPU restatement of the reference's image path) on a bounded
     # sample of the same rows; rank 0 at N = 1 only ----
@@ -707,6 +739,9 @@ def main_image(args, under_launcher):
                       "parallelism": "dp1 (single GPU: no collective)" if world == 1 else
                                      f"dp{world} (batch sharded, one all-reduce of 2 fp64 scalars [sum log_prob, count] per step)"},
            "mean_log_prob": float(mean.item()), "roofline": roofline, "cpu_baseline": cpu}
+    if mode == "train":
+        out["train_step"] = {"graph_replays": graph_steps[0], "of_steps": args.steps,
+                             "what": "Flow.fit's optimiser step (zero grads, log_prob, backward, SophiaG update) on the resident batch"}
     print(json.dumps(out), flush=True)
     if under_launcher:
         dist.destroy_process_group()
