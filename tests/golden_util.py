@@ -16,7 +16,7 @@ def case_names(small_only=False):
     # (the BASELINE cfg4 fixture -- 1.28 G parameters regenerated from the seed -- is loaded by name in
     # tests/test_configs_gpu.py only: far too big for the per-case loops)
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "fitsophia_", "sophia_")) and "cfg4" not in p)
+                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "fitsophia_", "sophia_")) and "cfg4" not in p)
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
