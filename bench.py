@@ -586,8 +586,6 @@ def main_image(args, under_launcher):
         raise SystemExit("bench.py: the image configurations measure --mode log_prob (default) or train")
     opt = None
     if mode == "train":
-        if world > 1:
-            raise SystemExit("bench.py: image training is a single-GPU measurement (no gradient all-reduce for image flows yet)")
         # one step of Flow.fit (flows.py:196-210) on the resident batch with the optimiser fit defaults to (SophiaG, flows.py:116)
         from usflows_amd.sophia import SophiaG
         opt = SophiaG(flow.parameters(), lr=1e-6) if args.optim == "sophia" else torch.optim.Adam(flow.parameters(), lr=1e-6)
@@ -598,7 +596,8 @@ def main_image(args, under_launcher):
         if mode == "train":
             # the optimiser step as Flow.fit issues it (flows.py:196-210): after three eager steps the step is captured as a
             # hipGraph and replayed (Flow._train_graph_step); the eager form serves until then
-            loss = flow._train_graph_step(opt, x, None) if not args.eager_train else None
+            # (data-parallel: eager steps -- the gradient all-reduce sits between backward and the optimiser's update)
+            loss = flow._train_graph_step(opt, x, None) if not (args.eager_train or world > 1) else None
             if loss is not None:
                 graph_steps[0] += 1
                 return torch.tensor(-loss, dtype=torch.float64), None
@@ -606,13 +605,16 @@ def main_image(args, under_launcher):
             lp_ = flow.log_prob(x)
             loss = -lp_.mean()
             loss.backward()
+            if world > 1:
+                from usflows_amd.parallel import allreduce_gradients
+                allreduce_gradients(flow, B)                   # ONE all-reduce of the flattened gradients, weighted by row counts
             opt.step()
             return -loss.detach().double(), lp_.detach()
         return mean_log_prob(flow, x, acc=acc)
 
     for _ in range(max(args.warmup, 5 if mode == "train" else 1)):
         mean, lp = step()
-    if not args.no_kernel_timing and mode == "train" and not args.eager_train:
+    if not args.no_kernel_timing and mode == "train" and not args.eager_train and world == 1:
         # per-kernel times of the step: three eager steps with HIP events around every launch (a replayed graph runs no
         # host code to put events around), before the timed region
         _ext.launch_timing = {n: [] for n in _IMAGE_KERNELS}

@@ -138,3 +138,54 @@ def test_data_parallel_training_gradients_world2(n_rows):
         big = max(g.abs().max().item(), 1e-12)
         for r in (0, 1):
             assert (torch.from_numpy(res[r][n]) - g).abs().max().item() <= 1e-5 * big, (r, n)
+
+
+# ---- image-shaped flows: gradients live in p.grad, one all-reduce of the flattened gradients per step -------------------
+def _image_train_worker(rank, world, port, q, n_rows):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from golden_util import load_image_case
+        from usflows_amd.parallel import data_parallel_training, shard_rows
+        flow, a = load_image_case("image_c4_6x6_k3_gated_ln_hh1_conj")
+        x = a["x"][:n_rows]
+        data_parallel_training(flow)
+        assert flow.__dict__.get("_grad_allreduce") is not None
+        lo, hi = shard_rows(n_rows, rank, world)                        # 12 rows: 6 + 6; 11: 6 + 5
+        ds = torch.utils.data.TensorDataset(x[lo:hi], torch.zeros(hi - lo))
+        np.random.seed(3)
+        flow.fit(ds, optim=torch.optim.SGD, optim_params=dict(lr=1e-3), batch_size=hi - lo, shuffle=False, device=torch.device("cpu"),
+                 epochs=1)
+        # (numpy: pickled by value -- torch tensors would travel as shared-memory handles that die with the worker)
+        q.put((rank, {k: v.detach().numpy().copy() for k, v in flow.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [12, 11])
+def test_image_flow_data_parallel_fit_world2(n_rows):
+    """two ranks, each fitting its shard with the gradient all-reduce between backward and the optimiser step, end with the
+    parameters of ONE process fitting the whole batch (equal and unequal shards)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import load_image_case
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_image_train_worker, args=(r, 2, port, q, n_rows)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    flow, a = load_image_case("image_c4_6x6_k3_gated_ln_hh1_conj")
+    ds = torch.utils.data.TensorDataset(a["x"][:n_rows], torch.zeros(n_rows))
+    flow.fit(ds, optim=torch.optim.SGD, optim_params=dict(lr=1e-3), batch_size=n_rows, shuffle=False, device=torch.device("cpu"), epochs=1)
+    ref = flow.state_dict()
+    for rank in (0, 1):
+        for k, v in ref.items():
+            s = max(v.abs().max().item(), 1e-6)
+            assert (torch.from_numpy(got[rank][k]) - v).abs().max().item() <= 2e-6 * s + 1e-9, (rank, k)

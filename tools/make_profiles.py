@@ -1,7 +1,7 @@
 """Regenerate the committed profile summaries (run on the GPU box from the repo root):
 
     python3 tools/make_profiles.py r03 [sections]   # writes gpurun_out/profiles_r03/*, copy them into profiles/
-    sections (default all): bench pmc f16 peak other train image -- several calls fit gpurun's 20-minute limit
+    sections (default all): bench pmc f16 peak other train image imagetrain -- several calls fit gpurun's 20-minute limit
 
 1. `python3 bench.py` (defaults)                                   -> <tag>_bench.json
 2. `rocprofv3 --kernel-trace --stats -- python3 bench.py`          -> <tag>_bench_kernel_stats.{csv,md}, <tag>_bench_under_rocprof.json
@@ -12,6 +12,8 @@
                                                                    -> <tag>_train_bench.jsonl, <tag>_train_kernel_stats.md
 5. image-shaped flows: `bench.py --config mnist_image / cifar_image`, kernel trace and PMC passes of the MNIST model
                                                                    -> <tag>_bench_{mnist,cifar}_image.json, <tag>_image_*.{md,json}
+6. image-shaped flows, training: `bench.py --config mnist_image / cifar_image --mode train` at several batch sizes (+ the torch
+   autograd path), kernel trace and PMC passes of eager steps     -> <tag>_image_train_bench.jsonl, <tag>_image_train_*.{md,json}
 This script never touches the GPU itself (every step is a child process), so the profiler wraps the
 program directly.
 """
@@ -43,7 +45,7 @@ def run(cmd, **kw):
 
 
 
-SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "image"]
+SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "image", "imagetrain"]
 
 
 B, D, H = 65536, 784, 256          # cfg2 shape (algorithmic byte counts of the traffic summaries)
@@ -317,5 +319,72 @@ if want("image"):
          "mnist_image", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         mfma_util(fn, os.path.join(out, f"{tag}_image_mfma_util.json"))
+
+# 6. image-shaped flows, training step (SURVEY rows N2 x N4): bench lines, kernel trace of eager steps, PMC passes
+if want("imagetrain"):
+    with open(os.path.join(out, f"{tag}_image_train_bench.jsonl"), "w") as f:
+        for cfg, batch in (("mnist_image", "65536"), ("mnist_image", "4096"), ("mnist_image", "32"), ("cifar_image", "16384"),
+                           ("cifar_image", "32")):
+            r = run(["python3", "bench.py", "--config", cfg, "--mode", "train", "--batch", batch, "--steps", "10"])
+            f.write(last_json_line(r.stdout) + "\n")
+        # the same flow through torch autograd + MIOpen (what round 2 replayed): USFLOWS_AMD_IMAGE_TRAIN=0
+        env_t = dict(env, USFLOWS_AMD_IMAGE_TRAIN="0")
+        for cfg, batch in (("mnist_image", "65536"), ("mnist_image", "32")):
+            print("+ USFLOWS_AMD_IMAGE_TRAIN=0 python3 bench.py --config", cfg, "--mode train --batch", batch, flush=True)
+            r = subprocess.run(["python3", "bench.py", "--config", cfg, "--mode", "train", "--batch", batch, "--steps", "10"], cwd=ROOT,
+                               env=env_t, capture_output=True, text=True)
+            line = json.loads(last_json_line(r.stdout))
+            line["config"]["workload"] += " [USFLOWS_AMD_IMAGE_TRAIN=0: torch autograd + MIOpen backward]"
+            f.write(json.dumps(line) + "\n")
+    d = os.path.join(out, "ktrace_image_train")
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--config",
+         "mnist_image", "--mode", "train", "--eager-train", "--steps", "10", "--no-kernel-timing"])
+    stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, f"{tag}_image_train_kernel_stats.md"), "w") as f:
+        f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --config mnist_image --mode train --eager-train --steps 10 --no-kernel-timing`\n\n"
+                "(optimiser steps of the reference's MNIST experiment model, tests/explib/mnist.yaml:44-77, on 65 536 resident rows: 15 eager\n"
+                "steps in the trace -- 5 warm-up + 10 timed; per step 6 convolutions forward, 6 data-gradient convolutions and 6 weight\n"
+                "gradients (usf_conv_wgrad_f32: conv_wgrad_kernel / conv_wgrad_k1_kernel + partial_sum_kernel), 2 pointwise convolutions each\n"
+                "way, 5 channel-affine launches each way with their weight gradients, layer norm / gate forward and backward, SophiaG)\n\n"
+                "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
+        for row in rows[:24]:
+            name = row["Name"]
+            name = name if len(name) < 110 else name[:107] + "..."
+            f.write(f"| `{name}` | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |\n")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, "pmc_image_train_" + ctr)
+        run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--config", "mnist_image",
+             "--mode", "train", "--eager-train", "--steps", "2", "--warmup", "1", "--no-kernel-timing"])
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                k = row["Kernel_Name"]
+                if "usf::" not in k:
+                    continue
+                k = k[k.index("usf::") + 5:]
+                k = k[: k.index("(")] if "(" in k else k
+                agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    kern = {}
+    for k, dct in sorted(agg.items()):
+        f_ = sum(dct["FETCH_SIZE"]) / max(1, len(dct["FETCH_SIZE"]))
+        w_ = sum(dct["WRITE_SIZE"]) / max(1, len(dct["WRITE_SIZE"]))
+        kern[k] = {"FETCH_SIZE_KB": round(f_, 1), "WRITE_SIZE_KB": round(w_, 1), "dispatches": len(dct["FETCH_SIZE"]),
+                   "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
+    json.dump({
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --config mnist_image --mode train "
+                  "--eager-train --steps 2 --warmup 1 --no-kernel-timing`, MI355X; tools/make_profiles.py",
+        "units": "means per dispatch over ALL shapes a kernel instance served; hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KB "
+                 "(FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Algorithmic bytes of a weight gradient at 65 536 rows "
+                 "of 7 x 7 pixels = 4 (cin + cout) B per pixel: 32 -> 32: 822 MB, 16 -> 32 / 32 -> 16: 616 MB, 32 -> 64: 1233 MB, 16 -> 16: "
+                 "411 MB (+ the per-wave partial sums: 1024 slots of 4 (256 tiles + 16) cout/16 cin/16 taps bytes); layer-norm backward: 12 B "
+                 "per element = 1233 MB.",
+        "kernels": kern}, open(os.path.join(out, f"{tag}_image_train_hbm_traffic.json"), "w"), indent=1)
+    d = os.path.join(out, "pmc_image_train_mfma")
+    run(["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+         "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--config",
+         "mnist_image", "--mode", "train", "--eager-train", "--steps", "2", "--warmup", "1", "--no-kernel-timing"])
+    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        mfma_util(fn, os.path.join(out, f"{tag}_image_train_mfma_util.json"))
 
 print("wrote", sorted(os.listdir(out)))

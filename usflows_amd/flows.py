@@ -501,7 +501,8 @@ class Flow(torch.nn.Module):
                     sample = sample + torch.normal(torch.zeros_like(sigma), sigma)
                     # conditioning scale recommended by SoftFlow (flows.py:188-191)
                     noise = noise.unsqueeze(-1).detach() * 2 / self.training_noise_prior.high
-                graphed = model._train_graph_step(optim, sample, noise) if gradient_clip is None else None
+                dp = self.__dict__.get("_grad_allreduce")      # parallel.data_parallel_training on a flow without the flat arena
+                graphed = model._train_graph_step(optim, sample, noise) if (gradient_clip is None and dp is None) else None
                 if graphed is not None:
                     losses.append(graphed)
                 else:
@@ -509,6 +510,9 @@ class Flow(torch.nn.Module):
                     loss = -model.log_prob(sample, context=noise).mean() - model.log_prior()
                     loss.backward()
                     losses.append(float(loss.detach()))
+                    if dp is not None:
+                        from .parallel import allreduce_gradients
+                        allreduce_gradients(model, sample.shape[0], group=dp[0], average=dp[1])
                     if gradient_clip is not None:
                         torch.nn.utils.clip_grad_norm_(model.parameters(), gradient_clip)
                     optim.step()

@@ -55,11 +55,46 @@ def data_parallel_training(flow, group=None, average: bool = True) -> None:
     (Gradients produced outside the node -- a trainable radial norm distribution -- are not included.)
     The reference has no distributed training; this is the data-parallel row of the scope table for ``Flow.fit``."""
     from .training import TrainPath
-    if flow.engine() is None:
-        raise RuntimeError("data_parallel_training: this flow has no device form")
+    if _is_image_flow(flow) or flow.engine() is None:
+        # flows that train through per-layer autograd functions (image-shaped inputs: image_training.py) or torch autograd:
+        # their gradients land in ``p.grad``; ``Flow.fit`` calls ``allreduce_gradients`` between backward and the optimiser
+        # step (eager steps: a collective is not captured into the step's hipGraph), a caller's own loop does the same
+        flow.__dict__["_grad_allreduce"] = (group, average)
+        return
     if flow._train_obj is None:
         flow._train_obj = TrainPath(flow)
     flow._train_obj.grad_allreduce = (group, average)
+
+
+def _is_image_flow(flow) -> bool:
+    dims = getattr(flow, "in_dims", None)
+    return dims is not None and len(dims) > 1
+
+
+def allreduce_gradients(flow, local_rows: int, group=None, average: bool = True) -> None:
+    """ONE all-reduce of every parameter gradient of ``flow`` (flattened into one buffer, the rank's row count as its last
+    element): ``average=True`` leaves sum_r B_r grad_r / sum_r B_r in every ``p.grad`` -- the gradient of the global mean when
+    each rank's loss is the mean over its own ``local_rows`` rows (``Flow.fit``); a rank with no rows passes 0 and receives
+    the global gradient.  ``average=False``: plain sum.  Call between ``loss.backward()`` and ``optimizer.step()``; every
+    rank must call it once per step."""
+    import torch.distributed as dist
+    params = [p for p in flow.parameters() if p.requires_grad]
+    if not params:
+        return
+    dev, dt = params[0].device, torch.float32
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    w = float(local_rows) if average else 1.0
+    flat = torch.cat([p.grad.reshape(-1).to(dt) * w for p in params] + [torch.tensor([float(local_rows)], dtype=dt, device=dev)])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat = flat / flat[-1].clamp_min(1.0)
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[o: o + n].reshape(p.shape).to(p.grad.dtype))
+        o += n
 
 
 def sample_sharded(flow, n_total: int, seed: int, rank: int, world_size: int) -> torch.Tensor:
