@@ -492,7 +492,7 @@ def main():
 # image-shaped flows
 # ----------------------------------------------------------------------------------------------------------------------
 _IMAGE_KERNELS = ("usf_conv2d_same_f32", "usf_conv2d_same_res_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
-                  "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32", "usf_conv_wgrad_f32",
+                  "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32", "usf_conv_wgrad_f32", "usf_conv2d_same_gate_f32",
                   "usf_layernorm_channels_bwd_f32", "usf_gated_residual_bwd_f32")
 
 
@@ -507,6 +507,9 @@ def _image_launch_cost(name, a):
     if name == "usf_conv2d_same_res_f32":    # (x, y, B, cin, cout, H, W, ks, planes, bias, in_mul, in_act, in_slope, res_x, res_mul, res_sign, stream)
         B, cin, cout, H, W, ks = int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7])
         return ("conv2d_same+residual", cin, cout, ks, H, W), 2.0 * B * H * W * cin * cout * ks * ks, 4.0 * B * H * W * (cin + 2 * cout)
+    if name == "usf_conv2d_same_gate_f32":   # (x, y, B, cin, cout, H, W, ks, planes, gate_h, gate_slope, gate_mul, stream)
+        B, cin, cout, H, W, ks = int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7])
+        return ("conv2d_same+gate", cin, cout, ks, H, W), 2.0 * B * H * W * cin * cout * ks * ks, 4.0 * B * H * W * (cin + 2 * cout)
     if name == "usf_channel_affine_f32":     # (x, y, B, C, P, W, pre_sub, bias, stream)
         B, C, P = int(a[2]), int(a[3]), int(a[4])
         return ("channel_affine", C, P), 2.0 * B * P * C * C, 8.0 * B * P * C

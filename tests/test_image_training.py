@@ -183,6 +183,31 @@ def test_weight_planes_kernel_gives_the_bits_of_the_torch_split(cout, cin, ks):
         assert torch.equal(ref.float().sum(0)[: (cin if transposed else cout)].double().abs().sum() > 0, torch.tensor(True))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,HW,B", [(32, 32, (7, 7), 300), (32, 16, (7, 7), 65), (16, 32, (8, 8), 33), (32, 32, (8, 8), 4099)])
+def test_gated_data_gradient_convolution_is_conv_then_gate_then_mask(cin, cout, HW, B):
+    """usf_conv2d_same_gate_f32 == usf_conv2d_same_f32, then usf_act_grad_f32 on the input tensor, then the mask product:
+    same bits (the factors join the output stream of the same accumulators)"""
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(cin + cout + B)
+    H, W = HW
+    dy = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(DEV)
+    h = torch.randn(B, cout, H, W, generator=g).to(DEV)
+    h[0, 0, 0, 0] = 0.0
+    mask = (torch.rand(cout * H * W, generator=g) < 0.5).float().to(DEV)
+    planes = _ext.conv2d_weight_planes(w)
+    for slope, mul in ((0.0, None), (0.1, mask), (1.0, mask)):
+        got = _ext.conv2d_same_gate(dy, planes, cout, 3, h, slope, mul)
+        assert got is not None, "shape not served by the fused form"
+        ref = _ext.conv2d_same(dy, planes, cout, 3)
+        n = ref.numel() // B
+        _ext.act_grad(ref, h, M=B, H=n, ldd=n, ldh=n, act=_ext.ACT_LEAKY_RELU, slope=slope)
+        if mul is not None:
+            ref = _ext.masked_residual(None, ref, mul, 1.0)
+        assert torch.equal(got, ref), (slope, mul is not None, (got - ref).abs().max().item())
+
+
 # ---- the autograd functions against fp64 torch autograd of the same module ------------------------------------------------
 def _grads_of(module_fn, params, x, dy):
     for p in params:

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_bf16x3_kernel(const ConvAr
 // second kernel (usf_conv_wreg.hip): 1 = launched, 0 = shape not served there, < 0 = error
 int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
                      const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
-                     const float* res_x, const float* res_mul, float res_sign, hipStream_t stream);
+                     const float* res_x, const float* res_mul, float res_sign, int res_mode, hipStream_t stream);
 
 static int odd16(int units) { return units | 1; }
 // register-staged iterations per thread for a group of S samples (the kernel holds at most 16 pixel pairs per thread)
@@ -316,7 +316,7 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   if (ks == 3 && !gate_x) {
     // the register-weight kernel where it serves the shape (the conditioner layers of the reference's image configurations)
     const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, bias, in_mul, in_act, in_slope, out_act, out_slope, nullptr,
-                                    nullptr, 0.f, stream);
+                                    nullptr, 0.f, 0, stream);
     if (rc != 0) return rc < 0 ? rc : 0;
   }
   ConvArgs a;
@@ -370,7 +370,22 @@ int conv2d_same_res(const float* x, float* y, int64_t B, int64_t cin, int64_t co
   if (in_act != USF_ACT_NONE && in_act != USF_ACT_LEAKY_RELU) { set_error("usf_conv2d_same_res_f32: bad act"); return -2; }
   if (ks != 3) return 1;
   const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, bias, in_mul, in_act, in_slope, USF_ACT_NONE, 0.f, res_x, res_mul,
-                                  res_sign, stream);
+                                  res_sign, 0, stream);
+  return rc < 0 ? rc : (rc == 1 ? 0 : 1);
+}
+
+// y = conv(x) * (gate_h > 0 ? 1 : gate_slope) * gate_mul: a data-gradient convolution with the (Leaky)ReLU and mask factors
+// of the layer's INPUT in its output stream (what usf_act_grad_f32 and a mask product would do in two more passes).
+// 0 = done, 1 = not served here, < 0 = error.
+int conv2d_same_gate(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                     const void* wplanes, const float* gate_h, float gate_slope, const float* gate_mul, hipStream_t stream) {
+  if (B < 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || B > 0x7fffffff) { set_error("usf_conv2d_same_gate_f32: bad sizes"); return -2; }
+  if (B == 0) return 0;
+  if (!x || !y || !wplanes || !gate_h) { set_error("usf_conv2d_same_gate_f32: null pointer"); return -1; }
+  if (x == y || gate_h == y) { set_error("usf_conv2d_same_gate_f32: in-place operation is not supported"); return -2; }
+  if (ks != 3) return 1;
+  const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, nullptr, nullptr, USF_ACT_NONE, 0.f, USF_ACT_NONE, 0.f, gate_h,
+                                  gate_mul, gate_slope, 1, stream);
   return rc < 0 ? rc : (rc == 1 ? 0 : 1);
 }
 

@@ -40,6 +40,8 @@ struct ConvWArgs {
   int img_bytes;               // bytes of one plane of one image buffer: (cin / 8) * cgs
   int in_act, out_act; float in_slope, out_slope;
   const float* res_x; const float* res_mul; float res_sign;   // y = res_x + res_sign * (res_mul * conv): MaskedCoupling's residual, or null
+  int res_mode;                // 1: gate instead -- y = conv * (res_x > 0 ? 1 : res_sign) * res_mul (res_mul may be null): the data gradient's
+                               // (Leaky)ReLU / mask factors, see usf_conv2d_same_gate_f32
   unsigned mSO;                // magic of cout * H W
   int dbg;                     // tuning aid (USF_CONVW_DBG; wrong results): 1 no staging, 2 no k loop, 4 no output flush, 8 no input loads,
                                // 16 no staging-area writes, 32 no barriers
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
       for (int i = 0; i < NF; ++i) {
         const int f = min(tid + 512 * i, n4 - 1), e0 = 4 * f;
         xv[i] = xg[f];
-        om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
+        om[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (a.res_mul) om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
       }
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
           const f32x4 t = *reinterpret_cast<const f32x4*>(ostage + 4 * f);
           f32x4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = xv[i][j] + a.res_sign * (om[i][j] * t[j]);
+          for (int j = 0; j < 4; ++j)
+            o[j] = a.res_mode ? (xv[i][j] > 0.f ? t[j] : t[j] * a.res_sign) * om[i][j] : xv[i][j] + a.res_sign * (om[i][j] * t[j]);
           yg[f] = o;
         }
       }
@@ -310,7 +314,7 @@ int conv2d_same_wreg_fits(int64_t cin, int64_t cout, int64_t H, int64_t W) {
 // returns 1 when the launch was made, 0 when the shape is not served (the caller uses the first kernel), < 0 on error
 int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
                      const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
-                     const float* res_x, const float* res_mul, float res_sign, hipStream_t stream) {
+                     const float* res_x, const float* res_mul, float res_sign, int res_mode, hipStream_t stream) {
   static int enabled = -1;
   if (enabled < 0) { const char* e = getenv("USF_CONV_WREG"); enabled = e ? atoi(e) : 1; }     // tuning aid: 0 = first kernel only
   if (!enabled) return 0;
@@ -318,9 +322,9 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   int64_t lds = 0;
   const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
   if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul)) ||
-      (res_x && (!res_mul || !aligned16(res_x) || !aligned16(res_mul) || res_x == y))) return 0;
+      (res_x && ((!res_mul && !res_mode) || !aligned16(res_x) || (res_mul && !aligned16(res_mul)) || res_x == y))) return 0;
   if (res_x && (int64_t)S * cout * H * W / 4 > 4 * 512) return 0;
-  a.res_x = res_x; a.res_mul = res_mul; a.res_sign = res_sign;
+  a.res_x = res_x; a.res_mul = res_mul; a.res_sign = res_sign; a.res_mode = res_mode;
   a.mSO = (unsigned)(0x100000000ULL / (uint64_t)(cout * H * W)) + 1u;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W;

@@ -83,10 +83,16 @@ class ConvSame(torch.autograd.Function):
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_train_ok was not consulted)")
             dW, db = r
         if ctx.needs_input_grad[0]:
-            dx = _ext.conv2d_same(dy, _ext.conv2d_weight_planes(w, transposed=True), w.shape[1], ks)
-            _gate_inplace(dx, x, in_act)
-            if in_mul is not None:
-                dx = _ext.masked_residual(None, dx, in_mul, 1.0)
+            planes_t = _ext.conv2d_weight_planes(w, transposed=True)
+            dx = None
+            if in_act is not None or in_mul is not None:
+                # the input's (Leaky)ReLU and mask factors in the data-gradient convolution's output stream
+                dx = _ext.conv2d_same_gate(dy, planes_t, w.shape[1], ks, x, ia[1] if in_act is not None else 1.0, in_mul)
+            if dx is None:
+                dx = _ext.conv2d_same(dy, planes_t, w.shape[1], ks)
+                _gate_inplace(dx, x, in_act)
+                if in_mul is not None:
+                    dx = _ext.masked_residual(None, dx, in_mul, 1.0)
         return dx, dW, db, None, None, None
 
 
