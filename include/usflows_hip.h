@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 23
+#define USF_ABI_VERSION 24
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -476,6 +476,28 @@ int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream);
 #define USF_OP_GEMM_PLANES 6
 #define USF_OP_COUPLING_PLANES 7
 #define USF_OP_GATED_NORM 9
+#define USF_OP_CALL 10
+/* One call of an elementwise / image-path entry point inside an op list: the function and its arguments in the order of the
+ * C prototype without the stream, every argument one 64-bit word (pointers and integers as they are, a float as its bit
+ * pattern in the low 32 bits).  This is how a layer loop that is not a chain of the dense ops above (image-shaped flows:
+ * Flow.log_prob / backward over usf_scale_f32, usf_channel_affine_f32, usf_conv2d_same_f32 / _res_f32, usf_pointwise_conv_f32,
+ * the elementwise passes, usf_base_logprob_f32) runs as ONE usf_run_ops call: the host records the loop's calls once per
+ * (input shape, parameter version) and replays the list. */
+#define USF_FN_SCALE 1
+#define USF_FN_CHANNEL_AFFINE 2
+#define USF_FN_LAYERNORM_CHANNELS 3
+#define USF_FN_GATED_RESIDUAL 4
+#define USF_FN_MASKED_RESIDUAL 5
+#define USF_FN_POINTWISE_CONV 6
+#define USF_FN_CONV2D_SAME 7
+#define USF_FN_CONV2D_SAME_RES 8
+#define USF_FN_BASE_LOGPROB 9
+#define USF_CALL_MAX_ARGS 20
+typedef struct usf_call_desc {
+  int32_t fn;
+  int32_t n_args;
+  uint64_t a[USF_CALL_MAX_ARGS];
+} usf_call_desc;
 typedef struct usf_op {
   int32_t kind;
   int32_t reserved;
@@ -486,6 +508,7 @@ typedef struct usf_op {
     usf_gemm_planes_desc gemm_planes;
     usf_coupling_planes_desc coupling_planes;
     usf_gated_norm_desc gated_norm;
+    usf_call_desc call;
   } u;
 } usf_op;
 

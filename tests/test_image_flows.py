@@ -240,6 +240,7 @@ def test_small_batch_layer_loop_replays_a_hip_graph(name):
     """log_prob of <= 256 rows of an image-shaped flow: captured once per (shape, parameter versions) -- at its second sighting --, replayed afterwards --
     bit-equal to the eager loop, recaptured after an in-place parameter update, a second shape gets a graph of its own"""
     flow, a = load_image_case(name, device="cuda:0")
+    flow.list_max_rows = 0                       # (the op-list form would serve these calls first: its own test below)
     x = a["x"].to("cuda:0")
     with torch.no_grad():
         flow.graph_max_rows = 0
@@ -264,6 +265,47 @@ def test_small_batch_layer_loop_replays_a_hip_graph(name):
     # under autograd the eager (composite) loop serves the call
     lp = flow.log_prob(x)
     assert lp.requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", image_case_names())
+def test_layer_loop_runs_as_one_op_list(name, monkeypatch):
+    """log_prob of an image-shaped batch as ONE usf_run_ops call (USF_OP_CALL entries recorded from the eager loop at the second
+    sighting of a (shape, parameter version) pair): bit-equal to the eager loop, on fresh inputs too, re-recorded after an
+    in-place parameter update; flows with a layer the kernels do not serve (a torch op inside the pass) are recognised and
+    keep the eager loop / the hipGraph"""
+    from usflows_amd import _ext
+    flow, a = load_image_case(name, device="cuda:0")
+    x = a["x"].to("cuda:0")
+    x2 = (x * 0.5 + 0.25).contiguous()
+    runs = []
+    real = _ext.run_ops
+    monkeypatch.setattr(_ext, "run_ops", lambda ops, n, dev=None: (runs.append(n), real(ops, n, dev))[1])
+    with torch.no_grad():
+        flow.graph_max_rows = 0
+        eager, eager2 = flow.log_prob(x), flow.log_prob(x2)
+        flow.graph_max_rows = 256
+        r1 = flow.log_prob(x)                    # second sighting: recorded while it runs
+        plan = flow._loop_lists[(tuple(x.shape), "cuda:0")][1]
+        C = flow.in_dims[0]
+        served = C % 16 == 0                     # (the goldens with 3 / 4 channels: convolutions on torch)
+        assert (plan is not None) == served, (name, plan is not None)
+        r2, r3 = flow.log_prob(x), flow.log_prob(x2)
+        assert torch.equal(r1, eager) and torch.equal(r2, eager) and torch.equal(r3, eager2)
+        if served:
+            assert runs == [plan["n"], plan["n"]] and plan["n"] >= 10, runs
+            # an in-place parameter update: new versions -> eager call, then a new recording
+            for p in flow.parameters():
+                if p.numel() > 1:
+                    p.mul_(1.0 + 1e-3)
+            flow.graph_max_rows = 0
+            e3 = flow.log_prob(x)
+            flow.graph_max_rows = 256
+            assert torch.equal(flow.log_prob(x), e3) and torch.equal(flow.log_prob(x), e3) and torch.equal(flow.log_prob(x), e3)
+            assert len(runs) == 3 and not torch.equal(e3, eager)
+        else:
+            assert runs == []
+    _check(flow, a, "cuda:0") if not served else None
 
 
 def _fit_twice(make_flow, data, optim, optim_params, batch_size, epochs):

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import struct
 import threading
 from typing import Optional
 
@@ -17,12 +18,12 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 23
+USF_ABI_VERSION = 24
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
 BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
-OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES, OP_GATED_NORM = 1, 2, 5, 6, 7, 9
+OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES, OP_GATED_NORM, OP_CALL = 1, 2, 5, 6, 7, 9, 10
 
 _fp = C.c_void_p  # device pointers travel as integers
 
@@ -102,9 +103,15 @@ class GatedNormDesc(C.Structure):
                 ("act", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CallDesc(C.Structure):
+    """usf_call_desc: one entry-point call inside an op list, arguments as 64-bit words"""
+    _fields_ = [("fn", C.c_int32), ("n_args", C.c_int32), ("a", C.c_uint64 * 20)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("linear", LinearDesc), ("coupling", CouplingDesc), ("pack_planes", PackPlanesDesc),
-                ("gemm_planes", GemmPlanesDesc), ("coupling_planes", CouplingPlanesDesc), ("gated_norm", GatedNormDesc)]
+                ("gemm_planes", GemmPlanesDesc), ("coupling_planes", CouplingPlanesDesc), ("gated_norm", GatedNormDesc),
+                ("call", CallDesc)]
 
 
 class Op(C.Structure):
@@ -230,7 +237,7 @@ def load() -> C.CDLL:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
     for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
                      (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc),
-                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk), (OP_GATED_NORM, GatedNormDesc)):
+                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk), (OP_GATED_NORM, GatedNormDesc), (OP_CALL, CallDesc)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -301,11 +308,72 @@ def _timed_call(fn, args, name):
     return fn(*args)
 
 
+# ---- a layer loop's calls as ONE op list (USF_OP_CALL; flows.py: image-shaped flows) ------------------------------------
+CALL_FNS = {"usf_scale_f32": 1, "usf_channel_affine_f32": 2, "usf_layernorm_channels_f32": 3, "usf_gated_residual_f32": 4,
+            "usf_masked_residual_f32": 5, "usf_pointwise_conv_f32": 6, "usf_conv2d_same_f32": 7, "usf_conv2d_same_res_f32": 8,
+            "usf_base_logprob_f32": 9}
+
+
+class CallList:
+    """the entry-point calls of one pass, recorded while they run (``with recording_calls(cl)``): (function id, argument
+    words, which of them are pointers).  ``bad`` names the first call that has no USF_OP_CALL form."""
+
+    def __init__(self):
+        self.calls = []
+        self.bad = None
+
+    def add(self, name, args):
+        fid = CALL_FNS.get(name)
+        if fid is None:
+            self.bad = self.bad or name
+            return
+        types = SYMBOLS[name][1][:-1]                       # (the stream is not part of the record)
+        words, is_ptr = [], []
+        for v, t in zip(args[:-1], types):
+            if t is C.c_float:
+                words.append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
+                is_ptr.append(False)
+            elif t in (C.c_void_p, _fp):
+                words.append(int(v) if v else 0)
+                is_ptr.append(True)
+            else:
+                words.append(int(v) & 0xFFFFFFFFFFFFFFFF)
+                is_ptr.append(False)
+        self.calls.append((fid, words, is_ptr))
+
+    def ops(self):
+        """the list as a ctypes array of usf_op (kind USF_OP_CALL)"""
+        arr = (Op * max(1, len(self.calls)))()
+        for i, (fid, words, _) in enumerate(self.calls):
+            arr[i].kind = OP_CALL
+            arr[i].u.call.fn = fid
+            arr[i].u.call.n_args = len(words)
+            for j, w in enumerate(words):
+                arr[i].u.call.a[j] = w
+        return arr
+
+
+class recording_calls:
+    def __init__(self, cl):
+        self.cl, self.prev = cl, None
+
+    def __enter__(self):
+        self.prev, _tls.calls = getattr(_tls, "calls", None), self.cl
+        return self.cl
+
+    def __exit__(self, *exc):
+        _tls.calls = self.prev
+        return False
+
+
 def _launch(name: str, args: tuple, keep=None) -> None:
     fn = getattr(load(), name)
     rec = _tls.rec
     if rec and rec[-1] is not None:
         rec[-1].entries.append((fn, args, name, keep))
+    cl = getattr(_tls, "calls", None)
+    if cl is not None:
+        cl.add(name, args)
     rc = _timed_call(fn, args, name)
     if rc != 0:
         check(rc, name)
@@ -313,6 +381,9 @@ def _launch(name: str, args: tuple, keep=None) -> None:
 
 def _direct(name: str, *args) -> None:
     """call entry point `name` now (never taped); bracketed by HIP events when launch_timing asks for this name"""
+    cl = getattr(_tls, "calls", None)
+    if cl is not None:
+        cl.add(name, args)
     check(_timed_call(getattr(load(), name), args, name), name)
 
 
@@ -430,8 +501,7 @@ def variates_from_bits(bits, u=None, laplace=None, exponential=None):
 
 
 def scale(x, ldx, y, ldy, M, D, s, divide):
-    check(load().usf_scale_f32(x.data_ptr(), ldx, y.data_ptr(), ldy, M, D, s.data_ptr(), int(divide),
-                               current_stream(x.device)), "usf_scale_f32")
+    _direct("usf_scale_f32", x.data_ptr(), ldx, y.data_ptr(), ldy, M, D, s.data_ptr(), int(divide), current_stream(x.device))
 
 
 def affine_coupling_apply(z, ldz, t, ldt, s, lds, M, n, bound, inverse, logdet=None, z_off=0, t_off=0, s_off=0):
@@ -539,6 +609,9 @@ def conv2d_same_res(x, planes, cout, ks, res_x, res_mul, res_sign, bias=None, in
     rc = _timed_call(fn, args, "usf_conv2d_same_res_f32")
     if rc == 1:
         return None
+    cl = getattr(_tls, "calls", None)
+    if cl is not None and rc == 0:
+        cl.add("usf_conv2d_same_res_f32", args)
     check(rc, "usf_conv2d_same_res_f32")
     return y
 

@@ -116,6 +116,7 @@ int usf_sizeof_desc(int32_t kind) {
     case USF_OP_COUPLING_PLANES: return (int)sizeof(usf_coupling_planes_desc);
     case 8: return (int)sizeof(usf_mt_chunk);
     case USF_OP_GATED_NORM: return (int)sizeof(usf_gated_norm_desc);
+    case USF_OP_CALL: return (int)sizeof(usf_call_desc);
     default: return -1;
   }
 }
@@ -307,6 +308,47 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
   return usf::base_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg, (hipStream_t)stream);
 }
 
+// USF_OP_CALL: the recorded arguments back into the entry point's prototype
+static int run_call(const usf_call_desc* c, usf_stream_t stream) {
+  const uint64_t* a = c->a;
+#define P(i) (reinterpret_cast<const float*>((uintptr_t)a[i]))
+#define Q(i) (reinterpret_cast<float*>((uintptr_t)a[i]))
+#define I(i) ((int64_t)a[i])
+#define J(i) ((int32_t)a[i])
+  auto F = [&](int i) { float f; uint32_t u = (uint32_t)a[i]; memcpy(&f, &u, 4); return f; };
+  static const int nargs[] = {0, 8, 8, 10, 5, 7, 16, 17, 16, 11};
+  if (c->fn < 1 || c->fn > USF_FN_BASE_LOGPROB || c->n_args != nargs[c->fn]) {
+    usf::set_error("usf_run_ops: call op with unknown function %d or %d arguments", c->fn, c->n_args);
+    return -2;
+  }
+  switch (c->fn) {
+    case USF_FN_SCALE: return usf_scale_f32(P(0), I(1), Q(2), I(3), I(4), I(5), P(6), J(7), stream);
+    case USF_FN_CHANNEL_AFFINE: return usf_channel_affine_f32(P(0), Q(1), I(2), I(3), I(4), P(5), P(6), P(7), stream);
+    case USF_FN_LAYERNORM_CHANNELS: return usf_layernorm_channels_f32(P(0), Q(1), I(2), I(3), I(4), P(5), P(6), F(7), J(8), F(9), stream);
+    case USF_FN_GATED_RESIDUAL: return usf_gated_residual_f32(P(0), P(1), Q(2), I(3), I(4), stream);
+    case USF_FN_MASKED_RESIDUAL: return usf_masked_residual_f32(P(0), P(1), P(2), F(3), Q(4), I(5), I(6), stream);
+    case USF_FN_POINTWISE_CONV:
+      return usf_pointwise_conv_f32(P(0), Q(1), I(2), I(3), I(4), I(5), P(6), P(7), J(8), F(9), J(10), F(11), P(12), P(13), P(14), F(15), stream);
+    case USF_FN_CONV2D_SAME:
+      return usf_conv2d_same_f32(P(0), Q(1), I(2), I(3), I(4), I(5), I(6), I(7), (const void*)(uintptr_t)a[8], P(9), P(10), J(11), F(12),
+                                 J(13), F(14), P(15), I(16), stream);
+    case USF_FN_CONV2D_SAME_RES: {
+      const int rc = usf_conv2d_same_res_f32(P(0), Q(1), I(2), I(3), I(4), I(5), I(6), I(7), (const void*)(uintptr_t)a[8], P(9), P(10), J(11),
+                                             F(12), P(13), P(14), F(15), stream);
+      if (rc == 1) usf::set_error("usf_run_ops: recorded usf_conv2d_same_res_f32 call is not served by the fused form any more");
+      return rc;
+    }
+    case USF_FN_BASE_LOGPROB:
+      return usf_base_logprob_f32(P(0), I(1), I(2), I(3), J(4), P(5), P(6), F(7), reinterpret_cast<const double*>((uintptr_t)a[8]), Q(9),
+                                  reinterpret_cast<double*>((uintptr_t)a[10]), stream);
+  }
+#undef P
+#undef Q
+#undef I
+#undef J
+  return -2;
+}
+
 int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {
   if (n_ops < 0 || (n_ops > 0 && !ops)) { usf::set_error("usf_run_ops: bad op list"); return -1; }
   for (int32_t i = 0; i < n_ops; ++i) {
@@ -318,6 +360,7 @@ int usf_run_ops(const usf_op* ops, int32_t n_ops, usf_stream_t stream) {
       case USF_OP_GEMM_PLANES: rc = usf::gemm_planes(&ops[i].u.gemm_planes, (hipStream_t)stream); break;
       case USF_OP_COUPLING_PLANES: rc = usf::coupling_planes(&ops[i].u.coupling_planes, (hipStream_t)stream); break;
       case USF_OP_GATED_NORM: rc = usf::gated_norm_rows(&ops[i].u.gated_norm, (hipStream_t)stream); break;
+      case USF_OP_CALL: rc = run_call(&ops[i].u.call, stream); break;
       default: usf::set_error("usf_run_ops: op %d has unknown kind %d", i, ops[i].kind); return -2;
     }
     if (rc != 0) return rc;

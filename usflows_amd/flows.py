@@ -213,6 +213,10 @@ class Flow(torch.nn.Module):
                 if dp:
                     raise RuntimeError("usflows_amd: data_parallel_training: this layer list has no device backward")
                 self._train_failed = True          # this layer list has no device backward: composite from now on
+        if self._layer_loop_list_ok(x, context):
+            out = self._layer_loop_listed(x)
+            if out is not None:
+                return out
         if self._layer_loop_graph_ok(x, context):
             out = self._layer_loop_graphed(x)
             if out is not None:
@@ -244,7 +248,7 @@ class Flow(torch.nn.Module):
                     total = v.to(x.device) if total is None else total + v.to(x.device)
                 if total is None:
                     total = torch.zeros((), dtype=torch.float32, device=x.device)
-            c = self.__dict__["_ladj_total_cache"] = (key, total)
+            c = self.__dict__["_ladj_total_cache"] = (key, total, (-total.detach().double()).reshape(1).contiguous())
         return c[1]
 
     def _layer_loop_log_prob(self, x, context=None):
@@ -254,6 +258,10 @@ class Flow(torch.nn.Module):
             for layer in reversed(self.layers):
                 x = layer.backward(x, context=context) if context is not None else layer.backward(x)
             y = x
+            # the log-det constant joins the base density's pass (an fp64 device scalar, no torch op)
+            lp = self._base_log_prob_layer_loop(y, logdet_dev=self.__dict__["_ladj_total_cache"][2])
+            if lp is not None:
+                return lp
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) - ladj_total
         import contextlib
@@ -276,6 +284,78 @@ class Flow(torch.nn.Module):
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
 
+    # ---- the layer loop of an image-shaped flow as ONE op list (usf_run_ops / USF_OP_CALL) ------------------------------
+    # On the device the loop of an image-shaped flow is HIP calls only (scale, channel affine, convolutions, pointwise /
+    # elementwise passes, base density with the log-det constant).  The second time a (shape, parameter version) pair is
+    # seen the loop runs once more while its calls are RECORDED (argument words as they are; a torch dispatch mode keeps
+    # every tensor the pass allocates alive and checks that nothing but allocations and views ran beside the HIP calls);
+    # from then on the call is one C-side list with the input / output pointers patched in: no per-layer Python, no
+    # per-layer ctypes call, no stream capture and none of its restrictions.  The list keeps the pass's intermediates
+    # alive, so it serves batches whose intermediates stay under ``list_max_bytes``; a pass that is not pure (a shape one of
+    # the kernels does not serve -> torch fallback inside a layer) is remembered as such and keeps the eager loop / graph.
+    list_max_rows = 4096          # USFLOWS_AMD_LOOP_LIST=0: off (and graph_max_rows = 0 switches every replay form off)
+    list_max_bytes = 1 << 30
+
+    def _layer_loop_list_ok(self, x, context) -> bool:
+        return (context is None and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
+                and 0 < x.shape[0] <= self.list_max_rows and self.graph_max_rows > 0 and x.is_contiguous()
+                and os.environ.get("USFLOWS_AMD_LOOP_LIST", "1") != "0" and not _needs_grad(self, x)
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _loop_versions(self):
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+        d = self.base_distribution                               # (a torch distribution's tensors are not module state)
+        while isinstance(d, tdist.Independent):
+            d = d.base_dist
+        ver += tuple((t.data_ptr(), t._version) for t in (getattr(d, "loc", None), getattr(d, "scale", None)) if torch.is_tensor(t))
+        ver += tuple((l.mask.data_ptr(), l.mask._version) for l in self.layers if torch.is_tensor(getattr(l, "mask", None)))
+        return ver
+
+    def _layer_loop_listed(self, x):
+        """log_prob of an image-shaped batch through the recorded op list; None when it did not run (first sighting, impure
+        pass, too large)"""
+        ver = self._loop_versions()
+        cache = self.__dict__.setdefault("_loop_lists", {})
+        key = (tuple(x.shape), str(x.device))
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            plan = hit[1]
+            if plan is None:
+                return None
+            out = torch.empty(plan["out_shape"], dtype=torch.float32, device=x.device)
+            ops = plan["ops"]
+            for i, j in plan["in_pos"]:
+                ops[i].u.call.a[j] = x.data_ptr()
+            for i, j in plan["out_pos"]:
+                ops[i].u.call.a[j] = out.data_ptr()
+            _ext.run_ops(ops, plan["n"], x.device)
+            return out
+        seen = self.__dict__.setdefault("_loop_list_seen", {})
+        if seen.get(key) != ver:                                 # hysteresis: record on the second sighting (caches are warm)
+            seen[key] = ver
+            if len(seen) > 16:
+                seen.pop(next(iter(seen)))
+            return None
+        cl = _ext.CallList()
+        mode = _pure_pass_mode()
+        with torch.no_grad(), _ext.recording_calls(cl), mode:
+            out = self._layer_loop_log_prob(x)
+        plan = None
+        kept = {t.untyped_storage().data_ptr(): t.untyped_storage().nbytes() for t in mode.kept}
+        if cl.bad is None and not mode.impure and cl.calls and sum(kept.values()) <= self.list_max_bytes \
+                and torch.is_tensor(out) and out.dtype == torch.float32 and out.is_contiguous():
+            xin, xout = x.data_ptr(), out.data_ptr()
+            in_pos = [(i, j) for i, (_, words, isp) in enumerate(cl.calls) for j, w in enumerate(words) if isp[j] and w == xin]
+            out_pos = [(i, j) for i, (_, words, isp) in enumerate(cl.calls) for j, w in enumerate(words) if isp[j] and w == xout]
+            if in_pos and out_pos:
+                plan = dict(ops=cl.ops(), n=len(cl.calls), in_pos=in_pos, out_pos=out_pos, out_shape=tuple(out.shape),
+                            keep=mode.kept, bytes=sum(kept.values()))
+        cache[key] = (ver, plan)
+        if len(cache) > 8:
+            cache.pop(next(iter(cache)))
+        return out
+
     # ---- small batches of the layer loop (image-shaped flows): one hipGraph replay instead of ~50 launches ------------
     graph_max_rows = 256          # the reference evaluates in chunks of 100 (hyperopt.py:273-278); USFLOWS_AMD_LOOP_GRAPH=0: off
 
@@ -290,13 +370,7 @@ class Flow(torch.nn.Module):
         loop is ~50 dependent launches whose host side (module calls, ctypes, allocations) costs twice their GPU time --
         MNIST image configuration, 100 rows: 0.90 -> 0.43 ms.  Any failure to capture switches this off for the flow (the
         eager loop serves the call).  Returns None when it did not run."""
-        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
-            tuple((b.data_ptr(), b._version) for b in self.buffers())
-        d = self.base_distribution                               # (a torch distribution's tensors are not module state)
-        while isinstance(d, tdist.Independent):
-            d = d.base_dist
-        ver += tuple((t.data_ptr(), t._version) for t in (getattr(d, "loc", None), getattr(d, "scale", None)) if torch.is_tensor(t))
-        ver += tuple((l.mask.data_ptr(), l.mask._version) for l in self.layers if torch.is_tensor(getattr(l, "mask", None)))
+        ver = self._loop_versions()
         cache = self.__dict__.setdefault("_loop_graphs", {})
         key = (tuple(x.shape), str(x.device))
         hit = cache.get(key)
@@ -336,7 +410,7 @@ class Flow(torch.nn.Module):
         g.replay()
         return static_out.clone()
 
-    def _base_log_prob_layer_loop(self, y: torch.Tensor):
+    def _base_log_prob_layer_loop(self, y: torch.Tensor, logdet_dev: Optional[torch.Tensor] = None):
         """Laplace / Normal base density of the layer loop's result through ``usf_base_logprob_f32`` (rows flattened) when
         nothing needs a gradient: one launch instead of the distribution object's op chain, whose argument validation
         (``_validate_sample``) synchronises the host with the device on every call.  None: not applicable."""
@@ -372,7 +446,7 @@ class Flow(torch.nn.Module):
         yf = y.reshape(B, D).contiguous()
         out = torch.empty(B, dtype=torch.float32, device=y.device)
         _ext.base_logprob(yf, D, B, D, _ext.BASE_LAPLACE if isinstance(d, tdist.Laplace) else _ext.BASE_NORMAL, cache[1], cache[2],
-                          0.0, out)
+                          0.0, out, logdet_dev=logdet_dev)
         return out
 
     def _log_prob_device(self, x, context=None, sum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -683,6 +757,41 @@ class Flow(torch.nn.Module):
             return profile
         tail = self.base_distribution.radial_ldl_profile(threshold=lp[0], r_max=r_max, n_samples=n_samples)
         return _intersect_intervals(profile, tail)
+
+
+def _pure_pass_mode():
+    """a torch dispatch mode for recording a layer loop: keeps every device tensor the pass creates alive (``kept``) and
+    notes every torch op on device tensors that is not an allocation or a view (``impure``): such a pass cannot be
+    replayed from its recorded HIP calls alone"""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils._pytree import tree_flatten
+    aten = torch.ops.aten
+    allowed = set()
+    for name in ("empty.memory_format", "empty_like.default", "empty_strided.default", "view.default", "_unsafe_view.default",
+                 "detach.default", "alias.default", "expand.default", "as_strided.default", "reshape.default", "t.default",
+                 "transpose.int", "select.int", "slice.Tensor", "unsqueeze.default", "squeeze.dim", "_reshape_alias.default",
+                 "permute.default", "lift_fresh.default", "squeeze.default", "flatten.using_ints", "unflatten.int"):
+        pkt, _, ov = name.partition(".")
+        op = getattr(getattr(aten, pkt, None), ov, None)
+        if op is not None:
+            allowed.add(op)
+
+    class _Mode(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.kept, self.impure = [], []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            res = func(*args, **(kwargs or {}))
+            outs = [t for t in tree_flatten(res)[0] if torch.is_tensor(t) and t.is_cuda]
+            if func not in allowed:
+                ins = [t for t in tree_flatten((args, kwargs or {}))[0] if torch.is_tensor(t) and t.is_cuda]
+                if ins or outs:
+                    self.impure.append(str(func))
+            self.kept.extend(outs)
+            return res
+
+    return _Mode()
 
 
 def _ladj_is_parameter_only(layer) -> bool:

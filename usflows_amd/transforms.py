@@ -123,15 +123,33 @@ class ScaleTransform(BaseTransform):
         bound = 1 / math.sqrt(self.dim) if self.dim > 0 else 0
         init.uniform_(self.scale, -bound, bound)
 
+    def _image_hip(self, x, divide: bool):
+        """image-shaped inputs on the device: usf_scale_f32 over the flattened rows (one HBM-bound pass; the layer loop of an
+        image flow is then HIP calls only and can run as one op list, flows.py); None: not applicable"""
+        if not (x.dim() == self.scale.dim() + 1 and x.dim() >= 3 and tuple(x.shape[1:]) == tuple(self.scale.shape)
+                and x.shape[0] > 0 and use_hip(self, x) and x.is_contiguous()):
+            return None
+        from . import _ext
+        key = (self.scale.data_ptr(), self.scale._version, str(x.device))
+        cache = getattr(self, "_scale_flat", None)
+        if cache is None or cache[0] != key:
+            cache = self._scale_flat = (key, self.scale.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous())
+        B, D = x.shape[0], cache[1].numel()
+        y = torch.empty_like(x)
+        _ext.scale(x, D, y, D, B, D, cache[1], divide)
+        return y
+
     def forward(self, x, context=None):
         if x.dim() == 2 and self.scale.dim() == 1 and use_hip(self, x):
             return self._hip("forward", x)
-        return x * self.scale
+        y = self._image_hip(x, False)
+        return y if y is not None else x * self.scale
 
     def backward(self, x, context=None):
         if x.dim() == 2 and self.scale.dim() == 1 and use_hip(self, x):
             return self._hip("backward", x)
-        return x / self.scale
+        y = self._image_hip(x, True)
+        return y if y is not None else x / self.scale
 
     def log_abs_det_jacobian(self, x, y, context=None):
         return self.scale.abs().log().sum()
