@@ -285,11 +285,11 @@ def test_layer_loop_runs_as_one_op_list(name, monkeypatch):
         flow.graph_max_rows = 0
         eager, eager2 = flow.log_prob(x), flow.log_prob(x2)
         flow.graph_max_rows = 256
+        assert torch.equal(flow.log_prob(x), eager)   # first sighting of (shape, versions) with the replay forms on: eager loop
         r1 = flow.log_prob(x)                    # second sighting: recorded while it runs
         plan = flow._loop_lists[(tuple(x.shape), "cuda:0")][1]
-        C = flow.in_dims[0]
-        served = C % 16 == 0                     # (the goldens with 3 / 4 channels: convolutions on torch)
-        assert (plan is not None) == served, (name, plan is not None)
+        served = plan is not None                # (a pass with a torch op inside -- a shape a kernel does not serve -- keeps the loop)
+        assert served or not any(k in name for k in ("mnistcfg", "cifarcfg", "c16_7x7")), name
         r2, r3 = flow.log_prob(x), flow.log_prob(x2)
         assert torch.equal(r1, eager) and torch.equal(r2, eager) and torch.equal(r3, eager2)
         if served:
@@ -301,8 +301,9 @@ def test_layer_loop_runs_as_one_op_list(name, monkeypatch):
             flow.graph_max_rows = 0
             e3 = flow.log_prob(x)
             flow.graph_max_rows = 256
-            assert torch.equal(flow.log_prob(x), e3) and torch.equal(flow.log_prob(x), e3) and torch.equal(flow.log_prob(x), e3)
-            assert len(runs) == 3 and not torch.equal(e3, eager)
+            for _ in range(4):                    # eager (first sighting), recorded, replayed, replayed
+                assert torch.equal(flow.log_prob(x), e3)
+            assert len(runs) == 4 and not torch.equal(e3, eager)
         else:
             assert runs == []
     _check(flow, a, "cuda:0") if not served else None
