@@ -278,6 +278,257 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
   if (prev >= 0) flush(prev);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same convolution with the block's waves SPECIALISED (round 3, second step): in the kernel above every wave multiplies,
+// stages, flushes in turn and the two waves of a SIMD run the same program in step, so the phases still add up (18.3 k
+// cycles per group of which 6.9 k are MFMA issue, MNIST 32 -> 32).  Here
+//   * waves 0-3 (one per SIMD) do nothing but read image fragments and multiply: each owns one 16-channel output tile (its
+//     weight fragments in registers, as above) and 4 / NCT of the waves share a tile's row tiles; a row tile's results go
+//     straight into the fp32 output staging area;
+//   * waves 4-7 (the other wave of each SIMD) do everything else: the next group's input loads (two groups ahead), the
+//     activation / mask / three-way split and the image stores of the next group, and the previous group's staged outputs
+//     -> HBM with the residual / gate factors.  Their vector and memory instructions issue in the gaps of the other wave's
+//     MFMAs (an MFMA holds the SIMD's issue port for 8 of its 16 cycles);
+//   * image AND output staging area are double-buffered, ONE barrier per group.
+// Arithmetic and summation order are those of the kernel above: bit-identical results.
+// ------------------------------------------------------------------------------------------
+template <int NB, int CP, int NCT>
+__global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WPC = 4 / NCT;                        // multiplying waves per output tile
+  constexpr int MAXRT = 16 / WPC;                     // row tiles per multiplying wave and group (host: ceil(S HW / 16) <= 16)
+  constexpr int MAXIT = 4;                            // staging units per service thread and group (host checks)
+  constexpr int NCG = CP / 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int HW = a.H * a.W;
+  const int cgs = a.cgs;
+  const int bufbytes = a.img_bytes;                   // one image buffer: every channel group's positions with the three planes side by side
+  // image: [2 buffers][channel group][S HW + 1 positions][3 planes] x 16 bytes.  The planes of a position are neighbours, so a
+  // fragment's three reads (and a staging unit's three stores) differ by an IMMEDIATE offset: one address register per k-block --
+  // the multiplying wave has the SIMD's MFMA stream to itself and every vector instruction in its loop costs issue time.
+  // Positions are 48 bytes apart: 16 consecutive positions start at banks 12 i mod 64, 4 banks each -- all disjoint; the channel-
+  // group stride is a multiple of 256 bytes (the ds_read_b128 lane groups mix rows of neighbouring channel groups).
+  unsigned char* const img = smem;
+  const int ost_floats = a.S * a.cout * HW;
+  float* const ostage = reinterpret_cast<float*>(smem + 2 * bufbytes);   // [2][S][cout][HW] fp32
+  const int zpos = a.S * HW * 48;
+  {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * bufbytes / 16; i += 512) *reinterpret_cast<f32x4*>(img + i * 16) = z;
+  }
+  __syncthreads();
+  const int ngroups = (a.B + a.S - 1) / a.S;
+  const int first = blockIdx.x, stride = gridDim.x;
+
+  if (wave < 4) {
+    // ================= multiplying waves =================
+    const int ct = wave / WPC, wi = wave % WPC;
+    cw_bf16x8 wreg[NB][3];
+    {
+      const int co = min(ct * 16 + li, a.coutp - 1);
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          wreg[blk][q] = *reinterpret_cast<const cw_bf16x8*>(a.wp + ((size_t)(q * a.coutp + co) * a.kp + 32 * blk + 8 * lg));
+    }
+    int tapinfo[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const int kflat = 32 * blk + 8 * lg;
+      const int tap = min(kflat / CP, 9);
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      // packed: bits 0..9 the tap as a one-hot bit (bit 9: K padding -- never set in a row's tap mask), bits 10.. the signed offset
+      tapinfo[blk] = (1 << tap) | (((dy * a.W + dx) * 48 + ((kflat - (kflat / CP) * CP) >> 3) * cgs) << 10);
+    }
+    float bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = ct * 16 + 4 * lg + j;
+      bias4[j] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
+    // this wave's row tiles are the same rows in every group: image offset, tap mask and output offset of the lane's row,
+    // once per kernel (a row past a short last group's end is masked by the row count at the store; its reads are harmless)
+    struct RowTile { int base, ooff; unsigned vmask; bool live; };
+    int tbase[MAXRT], toff[MAXRT];
+    unsigned tmask[MAXRT];
+#pragma unroll
+    for (int t = 0; t < MAXRT; ++t) {
+      const int r = min((wi + WPC * t) * 16 + li, a.S * HW - 1);
+      const int sl = cw_div(r, a.mHW), p = r - sl * HW;
+      const int py = cw_div(p, a.mW), px = p - py * a.W;
+      const unsigned rowok = (py > 0 ? 0x007u : 0u) | 0x038u | (py + 1 < a.H ? 0x1c0u : 0u);
+      const unsigned colok = (px > 0 ? 0x049u : 0u) | 0x092u | (px + 1 < a.W ? 0x124u : 0u);
+      tbase[t] = r * 48;
+      tmask[t] = rowok & colok;
+      toff[t] = (sl * a.cout + ct * 16 + 4 * lg) * HW + p;
+    }
+    __syncthreads();                                    // (A) the first group's image is staged
+    int cur = 0;
+    for (int gidx = first; gidx < ngroups; gidx += stride) {
+      const int s0 = gidx * a.S;
+      const int R_ = min(a.S, a.B - s0) * HW;             // live rows of this group
+      const int nrt = (R_ + 15) >> 4;
+      const unsigned char* const buf = img + cur * bufbytes;
+      float* const ost = ostage + cur * ost_floats;
+      // The fragments of a k-block are read D blocks ahead of its MFMAs, ACROSS row-tile boundaries (a ring of R fragment
+      // sets with NB a multiple of R, so the slots are static): one wave per SIMD has nobody to hide its LDS latency behind.
+      constexpr int R = (NB % 3 == 0) ? 3 : NB, D = R - 1;
+      auto tile_of = [&](int t) {                          // (tables built once per kernel, below; t is a compile-time index)
+        RowTile q;
+        q.live = (wi + WPC * t) < nrt;
+        q.base = tbase[t < MAXRT ? t : MAXRT - 1];
+        q.ooff = toff[t < MAXRT ? t : MAXRT - 1];
+        q.vmask = (q.live && t < MAXRT) ? tmask[t < MAXRT ? t : MAXRT - 1] : 0u;   // (a tile past the end reads the zero position only)
+        return q;
+      };
+      cw_bf16x8 xf[R][3];
+      auto read_blk = [&](const RowTile& q, int blk, cw_bf16x8 (&xv)[3]) {
+        const bool ok = (q.vmask & (unsigned)tapinfo[blk]) != 0u;          // (the mask has bits 0..8 only)
+        const int off = ok ? q.base + (tapinfo[blk] >> 10) : zpos;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) xv[qq] = *reinterpret_cast<const cw_bf16x8*>(buf + off + 16 * qq);
+      };
+      RowTile tc = tile_of(0);
+#pragma unroll
+      for (int b = 0; b < D; ++b) read_blk(tc, b, xf[b % R]);
+#pragma unroll
+      for (int t = 0; t < MAXRT; ++t) {
+        if (!tc.live || (a.dbg & 2)) break;               // wave-uniform (dbg 2: no matrix work)
+        const RowTile tn = tile_of(t + 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          if (blk + D < NB) read_blk(tc, blk + D, xf[(blk + D) % R]);
+          else read_blk(tn, blk + D - NB, xf[(blk + D) % R]);
+          const cw_bf16x8 (&xv)[3] = xf[blk % R];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][2], xv[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][1], xv[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][0], xv[2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][1], xv[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][0], xv[1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[blk][0], xv[0], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // this block's three fragment reads (for block blk + D) ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... then its six MFMAs: the reads stay D blocks ahead
+        }
+        // lane (li, lg) holds channels ct * 16 + 4 lg + (0..3) of row li
+        if ((wi + WPC * t) * 16 + li < R_ && ct * 16 + 4 * lg < a.cout) {        // (cout is a multiple of 4 here: 16 / 32 / 64)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ost[tc.ooff + j * HW] = act_apply(acc[j] + bias4[j], a.out_act, a.out_slope);
+        }
+        tc = tn;
+      }
+      __syncthreads();                                  // (B) this group's outputs are staged, the next image is ready
+      cur ^= 1;
+    }
+    __syncthreads();                                    // (C) the service waves' last flush has this group's outputs
+    return;
+  }
+
+  // ================= service waves =================
+  const int st = tid - 256;                             // 0 .. 255
+  const int sample_elems = a.cin * HW;
+  const bool leaky_in = a.in_act == USF_ACT_LEAKY_RELU;
+  float pre[MAXIT][8];
+  int usrc[MAXIT], udst[MAXIT];
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const int u = st + 256 * it;
+    const int sc = cw_div(u, a.mHW), p = u - sc * HW;   // sc = sample * NCG + channel group
+    const int sl = sc / NCG, cg = sc - sl * NCG;
+    usrc[it] = (sl * a.cin + 8 * cg) * HW + p;
+    udst[it] = cg * cgs + (sl * HW + p) * 48;
+  }
+  auto issue_loads = [&](int gidx) {
+    const int s0 = gidx * a.S;
+    const int nu = min(a.S, a.B - s0) * NCG * HW;
+    const float* xg = a.x + (size_t)s0 * sample_elems;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      if (st + 256 * it < nu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[it][j] = xg[usrc[it] + j * HW];
+      }
+    }
+  };
+  auto stage = [&](int gidx, int which) {
+    const int s0 = gidx * a.S;
+    const int nu = min(a.S, a.B - s0) * NCG * HW;
+    unsigned char* const buf = img + which * bufbytes;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      if (st + 256 * it < nu) {
+        cw_bf16x8 h, m, l;
+        const int mrem = usrc[it] - cw_div(usrc[it], a.mSE) * sample_elems;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = pre[it][j];
+          if (leaky_in) v = v > 0.0f ? v : v * a.in_slope;
+          if (a.in_mul) v *= a.in_mul[mrem + j * HW];
+          __bf16 hh, mm, ll;
+          cw_split(v, hh, mm, ll);
+          h[j] = hh; m[j] = mm; l[j] = ll;
+        }
+        unsigned char* dst = buf + udst[it];
+        *reinterpret_cast<cw_bf16x8*>(dst) = h;
+        *reinterpret_cast<cw_bf16x8*>(dst + 16) = m;
+        *reinterpret_cast<cw_bf16x8*>(dst + 32) = l;
+      }
+    }
+  };
+  auto flush = [&](int gidx, int which) {
+    const int s0 = gidx * a.S;
+    const int n4 = min(a.S, a.B - s0) * a.cout * HW / 4;
+    const float* const ost = ostage + which * ost_floats;
+    f32x4* yg = reinterpret_cast<f32x4*>(a.y + (size_t)s0 * a.cout * HW);
+    if (a.res_x) {
+      const int so = a.cout * HW;
+      const f32x4* xg = reinterpret_cast<const f32x4*>(a.res_x + (size_t)s0 * so);
+      constexpr int NF = 8;                              // host: S * cout * HW / 4 <= NF * 256
+      f32x4 xv[NF], om[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int f = min(st + 256 * i, n4 - 1), e0 = 4 * f;
+        xv[i] = xg[f];
+        om[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (a.res_mul) om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
+      }
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        const int f = st + 256 * i;
+        if (f < n4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(ost + 4 * f);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = a.res_mode ? (xv[i][j] > 0.f ? t[j] : t[j] * a.res_sign) * om[i][j] : xv[i][j] + a.res_sign * (om[i][j] * t[j]);
+          yg[f] = o;
+        }
+      }
+      return;
+    }
+    for (int f = st; f < n4; f += 256) yg[f] = *reinterpret_cast<const f32x4*>(ost + 4 * f);
+  };
+
+  if (first < ngroups) { issue_loads(first); stage(first, 0); }
+  if (first + stride < ngroups) issue_loads(first + stride);
+  __syncthreads();                                      // (A)
+  int cur = 0, prev = -1;
+  for (int gidx = first; gidx < ngroups; gidx += stride) {
+    const int nxt = gidx + stride;
+    if (nxt < ngroups && !(a.dbg & 1)) stage(nxt, cur ^ 1);               // (its loads were issued a group ago)
+    if (nxt + stride < ngroups && !(a.dbg & 8)) issue_loads(nxt + stride);
+    if (prev >= 0 && !(a.dbg & 4)) flush(prev, cur ^ 1);                  // the previous group's outputs leave while this one multiplies
+    __syncthreads();                                      // (B)
+    prev = gidx;
+    cur ^= 1;
+  }
+  if (prev >= 0) flush(prev, cur ^ 1);
+  __syncthreads();                                        // (C)
+}
+
 // samples per group for the register-weight kernel (0: the shape is not served by it)
 static int conv_wreg_plan(int cin, int cout, int H, int W, int* cgs, int* img_bytes, int64_t* lds) {
   const int HW = H * W;
@@ -305,6 +556,33 @@ static int conv_wreg_plan(int cin, int cout, int H, int W, int* cgs, int* img_by
   return best;
 }
 
+// samples per group for the wave-specialised kernel (0: not served): 16 row tiles per group at most (dealt over the 4 / NCT
+// multiplying waves of an output tile), 4 staging units per service thread, image and output staging area double-buffered
+static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cgs, int* img_bytes, int64_t* lds) {
+  const int HW = H * W;
+  if (!((cin == 16 || cin == 32) && (cout == 16 || cout == 32 || cout == 64)) || HW > 64 || HW < 1 ||
+      ((cin * HW) & 3) || ((cout * HW) & 3)) return 0;
+  const int wpc = 4 / ((cout + 15) / 16);
+  auto group_bytes = [&](int S) { return (int64_t)(((S * HW + 1) * 48 + 255) / 256 * 256); };   // three planes per position
+  int best = 0; double best_eff = 0.0;
+  for (int S = 1; S <= 16; ++S) {
+    const int nrt = (S * HW + 15) / 16;
+    if (nrt > 16) break;
+    const int64_t bufb = (cin / 8) * group_bytes(S);
+    const int64_t bytes = 2 * bufb + 2LL * S * cout * HW * 4;
+    if (bytes > 158 * 1024) break;
+    if ((int64_t)S * (cin / 8) * HW > 4 * 256) break;
+    if (with_res && (int64_t)S * cout * HW / 4 > 8 * 256) break;
+    const double eff = (double)(S * HW) / (16.0 * wpc * ((nrt + wpc - 1) / wpc));
+    if (eff >= best_eff - 1e-9) { best_eff = eff; best = S; }
+  }
+  if (best == 0 || best_eff < 0.7) return 0;
+  *cgs = (int)group_bytes(best);
+  *img_bytes = (cin / 8) * (*cgs);                      // one image BUFFER (all three planes)
+  *lds = 2LL * (*img_bytes) + 2LL * best * cout * HW * 4;
+  return best;
+}
+
 int conv2d_same_wreg_fits(int64_t cin, int64_t cout, int64_t H, int64_t W) {
   int cgs, ib; int64_t lds;
   if (cin > 64 || cout > 64 || H * W > 256 || cin < 1 || cout < 1) return 0;
@@ -320,10 +598,19 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   if (!enabled) return 0;
   ConvWArgs a;
   int64_t lds = 0;
-  const int S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
+  static int wsp = -1;
+  if (wsp < 0) { const char* e = getenv("USF_CONV_WSP"); wsp = e ? atoi(e) : 1; }            // tuning aid: 0 = the unspecialised kernel
+  int S = 0;
+  bool specialised = false;
+  if (wsp && conv2d_same_wreg_fits(cin, cout, H, W)) {
+    S = conv_wsp_plan((int)cin, (int)cout, (int)H, (int)W, res_x != nullptr, &a.cgs, &a.img_bytes, &lds);
+    specialised = S > 0;
+  }
+  if (!specialised)
+    S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
   if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul)) ||
       (res_x && ((!res_mul && !res_mode) || !aligned16(res_x) || (res_mul && !aligned16(res_mul)) || res_x == y))) return 0;
-  if (res_x && (int64_t)S * cout * H * W / 4 > 4 * 512) return 0;
+  if (!specialised && res_x && (int64_t)S * cout * H * W / 4 > 4 * 512) return 0;
   a.res_x = res_x; a.res_mul = res_mul; a.res_sign = res_sign; a.res_mode = res_mode;
   a.mSO = (unsigned)(0x100000000ULL / (uint64_t)(cout * H * W)) + 1u;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
@@ -351,7 +638,21 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
       }                                                                                                             \
       attr_done = true;                                                                                             \
     }                                                                                                               \
-    hipLaunchKernelGGL((conv2d_same_wreg_kernel<NB_, CP_, NCT_>), dim3(grid), dim3(512), (size_t)lds, stream, a);   \
+    if (specialised) {                                                                                              \
+      static bool attr2_dev[USF_MAX_DEVICES] = {false};                                                             \
+      bool& attr2 = attr2_dev[current_device_slot()];                                                               \
+      if (!attr2) {                                                                                                 \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_same_wsp_kernel<NB_, CP_, NCT_>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {            \
+          set_error("usf_conv2d_same_f32: cannot raise the LDS limit");                                             \
+          return -4;                                                                                                \
+        }                                                                                                           \
+        attr2 = true;                                                                                               \
+      }                                                                                                             \
+      hipLaunchKernelGGL((conv2d_same_wsp_kernel<NB_, CP_, NCT_>), dim3(grid), dim3(512), (size_t)lds, stream, a);  \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL((conv2d_same_wreg_kernel<NB_, CP_, NCT_>), dim3(grid), dim3(512), (size_t)lds, stream, a); \
+    }                                                                                                               \
   } while (0)
 #define USF_CW_NCT(NB_, CP_)                                                                                       \
   do { if (nct == 1) USF_CW(NB_, CP_, 1); else if (nct == 2) USF_CW(NB_, CP_, 2); else USF_CW(NB_, CP_, 4); } while (0)
