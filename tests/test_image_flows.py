@@ -674,7 +674,14 @@ def test_conv2d_with_masked_residual_equals_the_two_passes(B, cin, cout, H, W):
         two = _ext.masked_residual(rx, t, om, sign)
         torch.cuda.synchronize()
         assert torch.equal(fused, two)
-    # 48 output channels / a 1 x 1 kernel: not served by the fused form
-    w48 = torch.randn(48, cin, 3, 3, generator=g).to("cuda:0")
-    assert _ext.conv2d_same_res(x, _ext.conv2d_weight_planes(w48), 48, 3, torch.zeros(B, 48, H, W, device="cuda:0"),
-                                torch.zeros(48 * H * W, device="cuda:0"), 1.0) is None
+    # 48 output channels (the CIFAR configuration's last convolution; round 3: the wave-specialised kernel serves them)
+    w48 = (torch.randn(48, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to("cuda:0")
+    p48 = _ext.conv2d_weight_planes(w48)
+    rx48 = torch.randn(B, 48, H, W, generator=g).to("cuda:0")
+    om48 = (torch.rand(48 * H * W, generator=g) > 0.5).float().to("cuda:0")
+    fused = _ext.conv2d_same_res(x, p48, 48, 3, rx48, om48, -1.0)
+    if fused is not None:
+        assert torch.equal(fused, _ext.masked_residual(rx48, _ext.conv2d_same(x, p48, 48, 3), om48, -1.0))
+    # a 1 x 1 kernel: not served by the fused form
+    w1 = torch.randn(cout, cin, 1, 1, generator=g).to("cuda:0")
+    assert _ext.conv2d_same_res(x, _ext.conv2d_weight_planes(w1), cout, 1, rx, om, 1.0) is None

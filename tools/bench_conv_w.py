@@ -10,7 +10,7 @@ dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 tag = f"WREG={os.environ.get('USF_CONV_WREG', '1')} DBG={os.environ.get('USF_CONVW_DBG', '0')}"
 out = []
-for cin, cout, H, W in [(32, 32, 7, 7), (16, 32, 7, 7), (32, 16, 7, 7), (32, 32, 8, 8)]:
+for cin, cout, H, W in [(32, 32, 7, 7), (16, 32, 7, 7), (32, 16, 7, 7), (32, 32, 8, 8), (48, 32, 8, 8), (32, 48, 8, 8)]:
     b_ = B if H * W < 60 else B // 4
     x = torch.randn(b_, cin, H, W, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
       float* const ost = ostage + cur * ost_floats;
       // The fragments of a k-block are read D blocks ahead of its MFMAs, ACROSS row-tile boundaries (a ring of R fragment
       // sets with NB a multiple of R, so the slots are static): one wave per SIMD has nobody to hide its LDS latency behind.
-      constexpr int R = (NB % 3 == 0) ? 3 : NB, D = R - 1;
+      constexpr int R = (NB % 3 == 0) ? 3 : ((NB % 2 == 0) ? 2 : NB), D = R - 1;   // 9 -> 3, 14 -> 2 (168 weight registers), 5 -> 5
       auto tile_of = [&](int t) {                          // (tables built once per kernel, below; t is a compile-time index)
         RowTile q;
         q.live = (wi + WPC * t) < nrt;
@@ -560,9 +560,10 @@ static int conv_wreg_plan(int cin, int cout, int H, int W, int* cgs, int* img_by
 // multiplying waves of an output tile), 4 staging units per service thread, image and output staging area double-buffered
 static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cgs, int* img_bytes, int64_t* lds) {
   const int HW = H * W;
-  if (!((cin == 16 || cin == 32) && (cout == 16 || cout == 32 || cout == 64)) || HW > 64 || HW < 1 ||
+  if (!((cin == 16 || cin == 32 || cin == 48) && (cout == 16 || cout == 32 || cout == 48 || cout == 64)) || HW > 64 || HW < 1 ||
       ((cin * HW) & 3) || ((cout * HW) & 3)) return 0;
-  const int wpc = 4 / ((cout + 15) / 16);
+  const int nct_k = (cout + 15) / 16 == 3 ? 4 : (cout + 15) / 16;       // (48 channels: the four-tile instance, one multiplying wave idle)
+  const int wpc = 4 / nct_k;
   auto group_bytes = [&](int S) { return (int64_t)(((S * HW + 1) * 48 + 255) / 256 * 256); };   // three planes per position
   int best = 0; double best_eff = 0.0;
   for (int S = 1; S <= 16; ++S) {
@@ -602,10 +603,11 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   if (wsp < 0) { const char* e = getenv("USF_CONV_WSP"); wsp = e ? atoi(e) : 1; }            // tuning aid: 0 = the unspecialised kernel
   int S = 0;
   bool specialised = false;
-  if (wsp && conv2d_same_wreg_fits(cin, cout, H, W)) {
+  if (wsp && cin <= 64 && cout <= 64 && H * W <= 64) {
     S = conv_wsp_plan((int)cin, (int)cout, (int)H, (int)W, res_x != nullptr, &a.cgs, &a.img_bytes, &lds);
     specialised = S > 0;
   }
+  if (!specialised && cin == 48) return 0;
   if (!specialised)
     S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
   if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul)) ||
@@ -654,11 +656,29 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
       hipLaunchKernelGGL((conv2d_same_wreg_kernel<NB_, CP_, NCT_>), dim3(grid), dim3(512), (size_t)lds, stream, a); \
     }                                                                                                               \
   } while (0)
+#define USF_CW_SP(NB_, CP_, NCT_)                                                                                  \
+  do {                                                                                                              \
+    static bool attr3_dev[USF_MAX_DEVICES] = {false};                                                               \
+    bool& attr3 = attr3_dev[current_device_slot()];                                                                 \
+    if (!attr3) {                                                                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_same_wsp_kernel<NB_, CP_, NCT_>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {              \
+        set_error("usf_conv2d_same_f32: cannot raise the LDS limit");                                               \
+        return -4;                                                                                                  \
+      }                                                                                                             \
+      attr3 = true;                                                                                                 \
+    }                                                                                                               \
+    hipLaunchKernelGGL((conv2d_same_wsp_kernel<NB_, CP_, NCT_>), dim3(grid), dim3(512), (size_t)lds, stream, a);    \
+  } while (0)
 #define USF_CW_NCT(NB_, CP_)                                                                                       \
   do { if (nct == 1) USF_CW(NB_, CP_, 1); else if (nct == 2) USF_CW(NB_, CP_, 2); else USF_CW(NB_, CP_, 4); } while (0)
   if (cin == 16) USF_CW_NCT(5, 16);
-  else USF_CW_NCT(9, 32);
+  else if (cin == 32) USF_CW_NCT(9, 32);
+  else {                                                  // 48 input channels: the specialised kernel only
+    if (nct == 1) USF_CW_SP(14, 48, 1); else if (nct == 2) USF_CW_SP(14, 48, 2); else USF_CW_SP(14, 48, 4);
+  }
 #undef USF_CW_NCT
+#undef USF_CW_SP
 #undef USF_CW
   int rc = check_launch("usf_conv2d_same_f32");
   return rc ? rc : 1;
