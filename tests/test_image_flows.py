@@ -50,6 +50,7 @@ def test_image_flow_on_device_matches_reference(name, monkeypatch):
                                                                              real_conv(x_, pl_, co_, ks_, **k_))[1])
     flow, a = load_image_case(name, device="cuda:0")
     flow.graph_max_rows = 0                      # count the eager loop's launches (the hipGraph path: its own test below)
+    flow.merge_image_affine = False              # ... one per affine layer (composed runs: test_image_affine_runs_are_composed)
     _check(flow, a, "cuda:0")
     n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
     C = flow.in_dims[0]
@@ -60,6 +61,42 @@ def test_image_flow_on_device_matches_reference(name, monkeypatch):
         (len(calls), n_aff_conv, n_aff)
     # the CNN conditioner's convolutions run on usf_conv2d_same_f32
     assert any(c_[2] == 3 for c_ in convs), "the conditioner's 3 x 3 convolutions did not run on the HIP kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", image_case_names())
+def test_image_affine_runs_are_composed(name, monkeypatch):
+    """log_prob of an image-shaped flow composes runs of consecutive 1 x 1-convolution affine layers (block_i^-1 followed by
+    block_(i+1) under affine conjugation; the tail block in front of them) into one usf_channel_affine_f32 launch each, behind
+    the end-to-end probe: same parity against the reference as the layer-by-layer loop, fewer launches"""
+    from usflows_amd import _ext
+    flow, a = load_image_case(name, device="cuda:0")
+    flow.graph_max_rows = 0
+    calls = []
+    real = _ext.channel_affine
+    monkeypatch.setattr(_ext, "channel_affine", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+    x = a["x"].to("cuda:0")
+    with torch.no_grad():
+        flow.merge_image_affine = False
+        lp0 = flow.log_prob(x)
+        n0 = len(calls)
+        flow.merge_image_affine = "auto"
+        del calls[:]
+        lp1 = flow.log_prob(x)                   # (the probe's two short passes run here)
+        del calls[:]
+        lp2 = flow.log_prob(x)
+        n1 = len(calls)
+    log = flow.__dict__.get("merge_guard_log", [])
+    n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
+    conj = any(type(l).__name__ == "InverseTransform" for l in flow.layers)
+    if conj and n0 == n_aff:                     # (all affine layers on the channel kernel: C <= 16 or 24 / 32 / 48 / 64)
+        assert log and log[-1][0], log           # conditioned parameters: the probe accepts
+        assert n1 < n0, (n0, n1)
+        # K blocks with conjugation: [tail, A_K fwd], [A_K^-1, A_(K-1) fwd], ... , [A_1^-1]: K + 1 launches instead of 2 K + 1
+        assert n1 == (n_aff - 1) // 2 + 1, (n_aff, n1)
+    assert torch.equal(lp1, lp2)
+    assert _rel(lp1, a["log_prob64"]) < 1e-5 and _rel(lp1, a["log_prob32"]) < 1e-5
+    assert (lp1 - lp0).abs().max().item() <= 2e-6 * lp0.abs().max().item()
 
 
 @pytest.mark.gpu

@@ -255,8 +255,13 @@ class Flow(torch.nn.Module):
         """the reference's loop (flows.py:236-245), layer by layer"""
         ladj_total = self._parameter_only_ladj_total(x)
         if ladj_total is not None:
-            for layer in reversed(self.layers):
-                x = layer.backward(x, context=context) if context is not None else layer.backward(x)
+            steps = self._image_loop_steps(x) if context is None else None
+            if steps is not None:
+                for fn in steps:
+                    x = fn(x)
+            else:
+                for layer in reversed(self.layers):
+                    x = layer.backward(x, context=context) if context is not None else layer.backward(x)
             y = x
             # the log-det constant joins the base density's pass (an fp64 device scalar, no torch op)
             lp = self._base_log_prob_layer_loop(y, logdet_dev=self.__dict__["_ladj_total_cache"][2])
@@ -283,6 +288,101 @@ class Flow(torch.nn.Module):
                 x = y
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
+
+    # ---- runs of consecutive 1 x 1-convolution affine layers composed (image-shaped flows, inference) -------------------
+    # With ``affine_conjugation=True`` a coupling is followed by ``block_i^-1`` and ``block_(i+1)`` (flows.py:452-470): two
+    # C x C maps per pixel with nothing in between -- two HBM-bound passes where one does.  As FlowEngine.merge_affine does
+    # for flat flows: every run is composed in fp64 once per parameter version (y = A2 (A1 x + c1) + c2) and applied by ONE
+    # usf_channel_affine_f32 launch -- when an end-to-end probe (up to 64 rows of the caller's batch through the loop with
+    # composed and with separate layers) agrees to 1e-5 of the largest log-density and 1e-6 in relative L1: a flow that
+    # amplifies a change of rounding pattern beyond that (default-initialised, exploding) keeps the reference's layer list.
+    merge_image_affine = "auto"   # True / False force it; USFLOWS_AMD_MERGE_AFFINE=0/1 likewise
+
+    def _image_loop_steps(self, x):
+        """the reversed layer loop of an image-shaped flow as a list of callables, runs of channel-affine layers composed;
+        None: use the plain loop"""
+        from .transforms import BlockAffineTransform, InverseTransform
+        env = os.environ.get("USFLOWS_AMD_MERGE_AFFINE")
+        mode = self.merge_image_affine if env is None else (env != "0")
+        if mode is False or not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0) \
+                or (torch.is_grad_enabled() and _needs_grad(self, x)):
+            return None
+        ver = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(x.device), tuple(x.shape[1:]))
+        c = self.__dict__.get("_image_steps_cache")
+        if c is not None and c[0] == ver:
+            return c[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None
+
+        def affine_of(layer):
+            """(block, forward?) when the layer's backward is a channel-affine launch on this input"""
+            inv = isinstance(layer, InverseTransform)
+            blk = layer.transform if inv else layer
+            if isinstance(blk, BlockAffineTransform) and blk._use_channel_hip(x) and blk._channel_prep(x.device)[3] is None:
+                return blk, inv                          # InverseTransform(block).backward == block.forward
+            return None
+
+        seq, runs = list(reversed(self.layers)), []
+        i = 0
+        while i < len(seq):
+            j = i
+            while j < len(seq) and affine_of(seq[j]) is not None:
+                j += 1
+            if j - i >= 2:
+                runs.append((i, j))
+            i = max(j, i + 1)
+        steps = None
+        if runs:
+            from .engine import prepare_affine_blocks
+            merged = {}
+            with torch.no_grad():
+                for (i0, i1) in runs:
+                    A = cvec = None
+                    for layer in seq[i0:i1]:
+                        blk, fwd = affine_of(layer)
+                        r = prepare_affine_blocks([blk.block_transform], x.device)[id(blk.block_transform)]
+                        Ak = r["M"] if fwd else r["Minv"]                       # fp64
+                        ck = r["b"] if fwd else -(r["Minv"] @ r["b"])
+                        A, cvec = (Ak, ck) if A is None else (Ak @ A, Ak @ cvec + ck)
+                    merged[i0] = (i1, A.float().contiguous(), cvec.float().contiguous())
+
+            def make(Wm, cm):
+                def run(t):
+                    t = t.contiguous()
+                    y = torch.empty_like(t)
+                    _ext.channel_affine(t, y, Wm, bias=cm)
+                    return y
+                return run
+
+            steps, k = [], 0
+            while k < len(seq):
+                if k in merged:
+                    i1, Wm, cm = merged[k]
+                    steps.append(make(Wm, cm))
+                    k = i1
+                else:
+                    steps.append(seq[k].backward)
+                    k += 1
+            if mode == "auto":                           # the end-to-end probe
+                n = min(64, x.shape[0])
+                xs = x[:n].contiguous()
+                with torch.no_grad():
+                    a_ = xs
+                    for layer in seq:
+                        a_ = layer.backward(a_)
+                    b_ = xs
+                    for fn in steps:
+                        b_ = fn(b_)
+                    a_, b_ = a_.double().flatten(1), b_.double().flatten(1)
+                    d = ((b_ - a_).abs().max() / a_.abs().max().clamp_min(1e-30)).item()
+                    l1 = a_.abs().sum(-1)
+                    d1 = ((b_.abs().sum(-1) - l1).abs() / l1.clamp_min(1e-30)).max().item()
+                ok = bool(d <= 1e-5 and d1 <= 1e-6)
+                self.__dict__.setdefault("merge_guard_log", []).append((ok, d, d1))
+                if not ok:
+                    steps = None
+        self.__dict__["_image_steps_cache"] = (ver, steps)
+        return steps
 
     # ---- the layer loop of an image-shaped flow as ONE op list (usf_run_ops / USF_OP_CALL) ------------------------------
     # On the device the loop of an image-shaped flow is HIP calls only (scale, channel affine, convolutions, pointwise /
