@@ -430,8 +430,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
   // ================= service waves =================
   const int st = tid - 256;                             // 0 .. 255
   const int sample_elems = a.cin * HW;
-  const bool leaky_in = a.in_act == USF_ACT_LEAKY_RELU;
-  float pre[MAXIT][8];
+  // the input nonlinearity as a select (slope 1 = none) and the coupling mask as a factor per element that is the same in
+  // every group (a unit is a fixed (sample slot, channel group, position)): straight-line staging, no loads, no branches
+  const float slope_eff = (a.in_act == USF_ACT_LEAKY_RELU) ? a.in_slope : 1.f;
+  float pre[MAXIT][8], mulv[MAXIT][8];
   int usrc[MAXIT], udst[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
@@ -440,6 +442,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
     const int sl = sc / NCG, cg = sc - sl * NCG;
     usrc[it] = (sl * a.cin + 8 * cg) * HW + p;
     udst[it] = cg * cgs + (sl * HW + p) * 48;
+    const bool live = u < a.S * NCG * HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mulv[it][j] = (a.in_mul && live) ? a.in_mul[(8 * cg + j) * HW + p] : 1.f;
   }
   auto issue_loads = [&](int gidx) {
     const int s0 = gidx * a.S;
@@ -461,12 +466,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
     for (int it = 0; it < MAXIT; ++it) {
       if (st + 256 * it < nu) {
         cw_bf16x8 h, m, l;
-        const int mrem = usrc[it] - cw_div(usrc[it], a.mSE) * sample_elems;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float v = pre[it][j];
-          if (leaky_in) v = v > 0.0f ? v : v * a.in_slope;
-          if (a.in_mul) v *= a.in_mul[mrem + j * HW];
+          v = (v > 0.0f ? v : v * slope_eff) * mulv[it][j];
           __bf16 hh, mm, ll;
           cw_split(v, hh, mm, ll);
           h[j] = hh; m[j] = mm; l[j] = ll;
