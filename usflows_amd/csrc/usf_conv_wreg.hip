@@ -295,9 +295,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wreg_kernel(const ConvWArg
 template <int NB, int CP, int NCT>
 __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int WPC = 4 / NCT;                        // multiplying waves per output tile
+  constexpr int NMW = (NCT == 1) ? 2 : 4;             // multiplying waves (16 output channels: half the matrix work, the service side is the bottleneck -> 2 + 6)
+  constexpr int NSV = 512 - 64 * NMW;                 // service threads
+  constexpr int WPC = NMW / NCT;                      // multiplying waves per output tile
   constexpr int MAXRT = 16 / WPC;                     // row tiles per multiplying wave and group (host: ceil(S HW / 16) <= 16)
-  constexpr int MAXIT = 4;                            // staging units per service thread and group (host checks)
+  constexpr int MAXIT = (1024 + NSV - 1) / NSV;       // staging units per service thread and group (host: at most 1024 units)
   constexpr int NCG = CP / 8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
   const int ngroups = (a.B + a.S - 1) / a.S;
   const int first = blockIdx.x, stride = gridDim.x;
 
-  if (wave < 4) {
+  if (wave < NMW) {
     // ================= multiplying waves =================
     const int ct = wave / WPC, wi = wave % WPC;
     cw_bf16x8 wreg[NB][3];
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
   }
 
   // ================= service waves =================
-  const int st = tid - 256;                             // 0 .. 255
+  const int st = tid - 64 * NMW;                        // 0 .. NSV - 1
   const int sample_elems = a.cin * HW;
   // the input nonlinearity as a select (slope 1 = none) and the coupling mask as a factor per element that is the same in
   // every group (a unit is a fixed (sample slot, channel group, position)): straight-line staging, no loads, no branches
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
   int usrc[MAXIT], udst[MAXIT];
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
-    const int u = st + 256 * it;
+    const int u = st + NSV * it;
     const int sc = cw_div(u, a.mHW), p = u - sc * HW;   // sc = sample * NCG + channel group
     const int sl = sc / NCG, cg = sc - sl * NCG;
     usrc[it] = (sl * a.cin + 8 * cg) * HW + p;
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
     const float* xg = a.x + (size_t)s0 * sample_elems;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      if (st + 256 * it < nu) {
+      if (st + NSV * it < nu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) pre[it][j] = xg[usrc[it] + j * HW];
       }
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
     unsigned char* const buf = img + which * bufbytes;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-      if (st + 256 * it < nu) {
+      if (st + NSV * it < nu) {
         cw_bf16x8 h, m, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -489,18 +491,18 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
     if (a.res_x) {
       const int so = a.cout * HW;
       const f32x4* xg = reinterpret_cast<const f32x4*>(a.res_x + (size_t)s0 * so);
-      constexpr int NF = 8;                              // host: S * cout * HW / 4 <= NF * 256
+      constexpr int NF = (2048 + NSV - 1) / NSV;         // host: S * cout * HW / 4 <= 2048
       f32x4 xv[NF], om[NF];
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        const int f = min(st + 256 * i, n4 - 1), e0 = 4 * f;
+        const int f = min(st + NSV * i, n4 - 1), e0 = 4 * f;
         xv[i] = xg[f];
         om[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
         if (a.res_mul) om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
       }
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
-        const int f = st + 256 * i;
+        const int f = st + NSV * i;
         if (f < n4) {
           const f32x4 t = *reinterpret_cast<const f32x4*>(ost + 4 * f);
           f32x4 o;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
       }
       return;
     }
-    for (int f = st; f < n4; f += 256) yg[f] = *reinterpret_cast<const f32x4*>(ost + 4 * f);
+    for (int f = st; f < n4; f += NSV) yg[f] = *reinterpret_cast<const f32x4*>(ost + 4 * f);
   };
 
   if (first < ngroups) { issue_loads(first); stage(first, 0); }
@@ -566,7 +568,7 @@ static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cg
   if (!((cin == 16 || cin == 32 || cin == 48) && (cout == 16 || cout == 32 || cout == 48 || cout == 64)) || HW > 64 || HW < 1 ||
       ((cin * HW) & 3) || ((cout * HW) & 3)) return 0;
   const int nct_k = (cout + 15) / 16 == 3 ? 4 : (cout + 15) / 16;       // (48 channels: the four-tile instance, one multiplying wave idle)
-  const int wpc = 4 / nct_k;
+  const int wpc = (nct_k == 1 ? 2 : 4) / nct_k;                         // (16 channels: two multiplying waves, six service waves)
   auto group_bytes = [&](int S) { return (int64_t)(((S * HW + 1) * 48 + 255) / 256 * 256); };   // three planes per position
   int best = 0; double best_eff = 0.0;
   for (int S = 1; S <= 16; ++S) {
