@@ -296,7 +296,10 @@ def test_image_flow_device_gradients_match_the_real_reference(name, monkeypatch)
     assert abs(float(loss.detach()) - loss_ref) < 1e-5 * abs(loss_ref)
     n_convs = sum(1 for m in flow.modules() if isinstance(m, torch.nn.Conv2d))
     n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
-    assert len(wg) >= n_convs + n_aff, f"{len(wg)} weight-gradient launches for {n_convs} convolutions + {n_aff} affine layers"
+    # (runs of consecutive affine layers are composed: K + 1 channel-affine passes for the 2 K + 1 affine layers of a conjugated flow)
+    conj = any(type(l).__name__ == "InverseTransform" for l in flow.layers)
+    n_aff_runs = (n_aff - 1) // 2 + 1 if conj else n_aff
+    assert len(wg) == n_convs + n_aff_runs, f"{len(wg)} weight-gradient launches for {n_convs} convolutions + {n_aff} affine layers"
     named = dict(flow.named_parameters())
     for k, g in g_ref.items():
         assert named[k].grad is not None, k

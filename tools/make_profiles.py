@@ -279,8 +279,9 @@ if want("image"):
     with open(os.path.join(out, f"{tag}_image_kernel_stats.md"), "w") as f:
         f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --config mnist_image --steps 10 --no-cpu-baseline`\n\n"
                 "(log_prob of 65 536 rows of the reference's MNIST experiment model, tests/explib/mnist.yaml:44-77: 13 calls in the\n"
-                "trace -- 3 warm-up + 10 timed; per call 6 convolutions on the matrix cores, 2 gated pointwise passes, 5 channel\n"
-                "affine launches, 2 masked residuals, 1 base density)\n\n"
+                "trace -- 3 warm-up + 10 timed; per call 6 convolutions on the matrix cores (the last one of each coupling with the\n"
+                "residual in its output stream), 2 gated pointwise passes, 3 channel affine launches (composed runs), 1 scale pass,\n"
+                "1 base density)\n\n"
                 "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
         for row in rows[:12]:
             name = row["Name"]

@@ -269,7 +269,6 @@ class Flow(torch.nn.Module):
                 return lp
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) - ladj_total
-        import contextlib
         prep = contextlib.nullcontext()
         if torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and torch.is_grad_enabled() \
                 and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0":
@@ -278,7 +277,21 @@ class Flow(torch.nn.Module):
             prep = batched_affine_prep(self.layers, x.device)
         with prep:
             log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
-            for layer in reversed(self.layers):
+            seq = list(reversed(self.layers))
+            k = 0
+            while k < len(seq):
+                layer = seq[k]
+                run = self._train_affine_run(seq, k, x) if not isinstance(prep, contextlib.nullcontext) else None
+                if run is not None:
+                    # a run of consecutive 1 x 1-convolution affine layers in training: ONE differentiable channel-affine
+                    # pass on the composed map (the C x C compositions are torch ops on the batched prep's tensors)
+                    k1, A, cvec = run
+                    from .image_training import ChannelAffine
+                    y = ChannelAffine.apply(x, A, cvec, False)
+                    for l2 in seq[k:k1]:
+                        log_det = log_det - l2.log_abs_det_jacobian(None, None)
+                    x, k = y, k1
+                    continue
                 if context is not None:
                     y = layer.backward(x, context=context)
                     log_det = log_det - layer.log_abs_det_jacobian(y, x, context=context)
@@ -286,8 +299,33 @@ class Flow(torch.nn.Module):
                     y = layer.backward(x)
                     log_det = log_det - layer.log_abs_det_jacobian(y, x)
                 x = y
+                k += 1
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
+
+    def _train_affine_run(self, seq, k, x):
+        """(end index, A, c) when seq[k:] starts with >= 2 affine layers whose backward is a device channel-affine pass in
+        training and whose parameter maps come from the batched prep: y = A x + c for the whole run; else None"""
+        from .transforms import BlockAffineTransform, InverseTransform
+        from .image_training import current_prep
+        if os.environ.get("USFLOWS_AMD_MERGE_AFFINE") == "0" or self.merge_image_affine is False:
+            return None
+        A = cvec = None
+        j = k
+        while j < len(seq):
+            layer = seq[j]
+            inv = isinstance(layer, InverseTransform)
+            blk = layer.transform if inv else layer
+            if not (isinstance(blk, BlockAffineTransform) and blk._channel_train(x)):
+                break
+            pr = current_prep(blk.block_transform)
+            if pr is None:
+                break
+            M, Minv, b, _ = pr
+            Ak, ck = (M, b) if inv else (Minv, -(Minv @ b))        # InverseTransform(block).backward == block.forward
+            A, cvec = (Ak, ck) if A is None else (Ak @ A, Ak @ cvec + ck)
+            j += 1
+        return (j, A, cvec) if j - k >= 2 else None
 
     # ---- runs of consecutive 1 x 1-convolution affine layers composed (image-shaped flows, inference) -------------------
     # With ``affine_conjugation=True`` a coupling is followed by ``block_i^-1`` and ``block_(i+1)`` (flows.py:452-470): two
