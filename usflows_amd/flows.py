@@ -416,7 +416,9 @@ class Flow(torch.nn.Module):
                     l1 = a_.abs().sum(-1)
                     d1 = ((b_.abs().sum(-1) - l1).abs() / l1.clamp_min(1e-30)).max().item()
                 ok = bool(d <= 1e-5 and d1 <= 1e-6)
-                self.__dict__.setdefault("merge_guard_log", []).append((ok, d, d1))
+                log = self.__dict__.setdefault("merge_guard_log", [])
+                log.append((ok, d, d1))
+                del log[:-64]
                 if not ok:
                     steps = None
         self.__dict__["_image_steps_cache"] = (ver, steps)
@@ -490,7 +492,8 @@ class Flow(torch.nn.Module):
                 plan = dict(ops=cl.ops(), n=len(cl.calls), in_pos=in_pos, out_pos=out_pos, out_shape=tuple(out.shape),
                             keep=mode.kept, bytes=sum(kept.values()))
         cache[key] = (ver, plan)
-        if len(cache) > 8:
+        # at most 8 lists and 2 GB of kept intermediates over all of them (oldest first out)
+        while len(cache) > 8 or (len(cache) > 1 and sum(v[1]["bytes"] for v in cache.values() if v[1] is not None) > (2 << 30)):
             cache.pop(next(iter(cache)))
         return out
 
