@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 24
+#define USF_ABI_VERSION 25
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -328,13 +328,16 @@ int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, i
 int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream);
 
 /* A data-gradient convolution with the factors of the layer's INPUT transforms in its output stream:
- *   y = conv(x) * (gate_h > 0 ? 1 : gate_slope) * gate_mul
+ *   y = conv(x) * (gate_h > 0 ? 1 : gate_slope) * gate_mul          (gate_add == NULL)
+ *   y = gate_add + conv(x) * (gate_h > 0 ? 1 : gate_slope)          (gate_add != NULL; then gate_mul must be NULL)
  * gate_h [B, cout, H, W] = the forward layer's input (its (Leaky)ReLU's derivative; gate_slope 0 = ReLU, 1 = no nonlinearity),
- * gate_mul [cout * H * W] or NULL = the forward layer's input mask.  The arithmetic of usf_conv2d_same_f32 followed by
- * usf_act_grad_f32 and the mask product, in one pass.  Returns 0 when done, 1 when the shape is not served by this form
- * (as usf_conv2d_same_res_f32), < 0 on error. */
+ * gate_mul [cout * H * W] or NULL = the forward layer's input mask, gate_add [B, cout, H, W] or NULL = the gradient that
+ * reaches the same tensor along another branch (the forward input forks: GatedConv's skip connection, networks.py:108-122).
+ * The arithmetic of usf_conv2d_same_f32 followed by usf_act_grad_f32 and the mask product / the sum, in one pass.  Returns 0
+ * when done, 1 when the shape is not served by this form (as usf_conv2d_same_res_f32), < 0 on error. */
 int usf_conv2d_same_gate_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
-                             const void* w_planes, const float* gate_h, float gate_slope, const float* gate_mul, usf_stream_t stream);
+                             const void* w_planes, const float* gate_h, float gate_slope, const float* gate_mul,
+                             const float* gate_add, usf_stream_t stream);
 
 /* column gather/scatter between the user's natural layout and the engine's segment layout:
  * dst[m, j] = src[m, idx[j]] for j < n (idx: int32 device array); idx[j] < 0 writes 0. */

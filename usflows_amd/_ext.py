@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 24
+USF_ABI_VERSION = 25
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -176,7 +176,7 @@ SYMBOLS = {
     "usf_conv2d_same_res_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, _fp,
                                           C.c_int32, C.c_float, _fp, _fp, C.c_float, C.c_void_p]),
     "usf_masked_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_float, _fp, C.c_int64, C.c_int64, C.c_void_p]),
-    "usf_conv2d_same_gate_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [C.c_void_p, _fp, C.c_float, _fp, C.c_void_p]),
+    "usf_conv2d_same_gate_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [C.c_void_p, _fp, C.c_float, _fp, _fp, C.c_void_p]),
     "usf_conv_wgrad_workspace": (C.c_int64, [C.c_int64] * 6),
     "usf_conv_wgrad_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
                                      C.c_void_p]),
@@ -616,13 +616,14 @@ def conv2d_same_res(x, planes, cout, ks, res_x, res_mul, res_sign, bias=None, in
     return y
 
 
-def conv2d_same_gate(x, planes, cout, ks, gate_h, gate_slope, gate_mul=None):
-    """usf_conv2d_same_gate_f32: conv(x) * (gate_h > 0 ? 1 : gate_slope) * gate_mul as a new tensor (a data-gradient convolution
-    with the input nonlinearity's and the input mask's factors in its output stream), or None when not served"""
+def conv2d_same_gate(x, planes, cout, ks, gate_h, gate_slope, gate_mul=None, gate_add=None):
+    """usf_conv2d_same_gate_f32: conv(x) * (gate_h > 0 ? 1 : gate_slope) * gate_mul, or gate_add + conv(x) * (...), as a new
+    tensor (a data-gradient convolution with the input nonlinearity's / mask's factors, or the other branch's gradient, in its
+    output stream), or None when not served"""
     B, cin, H, W = x.shape
     y = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
     args = (x.data_ptr(), y.data_ptr(), B, cin, cout, H, W, ks, planes.data_ptr(), gate_h.data_ptr(), float(gate_slope), ptr(gate_mul),
-            current_stream(x.device))
+            ptr(gate_add), current_stream(x.device))
     rc = _timed_call(load().usf_conv2d_same_gate_f32, args, "usf_conv2d_same_gate_f32")
     if rc == 1:
         return None

@@ -65,7 +65,8 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
                 const void* wplanes, const float* bias, const float* in_mul, int32_t in_act, float in_slope,
                 int32_t out_act, float out_slope, const float* gate_x, int64_t gate_channels, hipStream_t stream);
 int conv2d_same_gate(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
-                     const void* wplanes, const float* gate_h, float gate_slope, const float* gate_mul, hipStream_t stream);
+                     const void* wplanes, const float* gate_h, float gate_slope, const float* gate_mul, const float* gate_add,
+                     hipStream_t stream);
 int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* gamma, const float* beta,
                        float eps, int32_t act, float slope, hipStream_t stream);
 int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
@@ -248,8 +249,9 @@ int usf_masked_residual_f32(const float* x, const float* t, const float* one_min
   return usf::masked_residual(x, t, one_minus_mask, sign, y, B, CP, (hipStream_t)stream);
 }
 int usf_conv2d_same_gate_f32(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
-                             const void* w_planes, const float* gate_h, float gate_slope, const float* gate_mul, usf_stream_t stream) {
-  return usf::conv2d_same_gate(x, y, B, cin, cout, H, W, ks, w_planes, gate_h, gate_slope, gate_mul, (hipStream_t)stream);
+                             const void* w_planes, const float* gate_h, float gate_slope, const float* gate_mul, const float* gate_add,
+                             usf_stream_t stream) {
+  return usf::conv2d_same_gate(x, y, B, cin, cout, H, W, ks, w_planes, gate_h, gate_slope, gate_mul, gate_add, (hipStream_t)stream);
 }
 int64_t usf_conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) {
   return usf::conv_wgrad_workspace(B, cin, cout, H, W, ks);

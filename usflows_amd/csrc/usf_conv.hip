@@ -378,14 +378,17 @@ int conv2d_same_res(const float* x, float* y, int64_t B, int64_t cin, int64_t co
 // of the layer's INPUT in its output stream (what usf_act_grad_f32 and a mask product would do in two more passes).
 // 0 = done, 1 = not served here, < 0 = error.
 int conv2d_same_gate(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
-                     const void* wplanes, const float* gate_h, float gate_slope, const float* gate_mul, hipStream_t stream) {
+                     const void* wplanes, const float* gate_h, float gate_slope, const float* gate_mul, const float* gate_add,
+                     hipStream_t stream) {
   if (B < 0 || cin <= 0 || cout <= 0 || H <= 0 || W <= 0 || B > 0x7fffffff) { set_error("usf_conv2d_same_gate_f32: bad sizes"); return -2; }
   if (B == 0) return 0;
   if (!x || !y || !wplanes || !gate_h) { set_error("usf_conv2d_same_gate_f32: null pointer"); return -1; }
   if (x == y || gate_h == y) { set_error("usf_conv2d_same_gate_f32: in-place operation is not supported"); return -2; }
   if (ks != 3) return 1;
+  if (gate_add && gate_mul) { set_error("usf_conv2d_same_gate_f32: gate_mul and gate_add exclude each other"); return -2; }
+  if (gate_add == y) { set_error("usf_conv2d_same_gate_f32: in-place operation is not supported"); return -2; }
   const int rc = conv2d_same_wreg(x, y, B, cin, cout, H, W, wplanes, nullptr, nullptr, USF_ACT_NONE, 0.f, USF_ACT_NONE, 0.f, gate_h,
-                                  gate_mul, gate_slope, 1, stream);
+                                  gate_add ? gate_add : gate_mul, gate_slope, gate_add ? 2 : 1, stream);
   return rc < 0 ? rc : (rc == 1 ? 0 : 1);
 }
 

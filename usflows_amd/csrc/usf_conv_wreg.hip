@@ -41,7 +41,8 @@ struct ConvWArgs {
   int in_act, out_act; float in_slope, out_slope;
   const float* res_x; const float* res_mul; float res_sign;   // y = res_x + res_sign * (res_mul * conv): MaskedCoupling's residual, or null
   int res_mode;                // 1: gate instead -- y = conv * (res_x > 0 ? 1 : res_sign) * res_mul (res_mul may be null): the data gradient's
-                               // (Leaky)ReLU / mask factors, see usf_conv2d_same_gate_f32
+                               // (Leaky)ReLU / mask factors, see usf_conv2d_same_gate_f32; 2: y = res_mul + conv * (res_x > 0 ? 1 : res_sign) with
+                               // res_mul a FULL [B, cout, H, W] tensor (the other branch's gradient where the forward input forks)
   unsigned mSO;                // magic of cout * H W
   int dbg;                     // tuning aid (USF_CONVW_DBG; wrong results): 1 no staging, 2 no k loop, 4 no output flush, 8 no input loads,
                                // 16 no staging-area writes, 32 no barriers
@@ -498,7 +499,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
         const int f = min(st + NSV * i, n4 - 1), e0 = 4 * f;
         xv[i] = xg[f];
         om[i] = (f32x4){1.f, 1.f, 1.f, 1.f};
-        if (a.res_mul) om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
+        if (a.res_mode == 2) om[i] = reinterpret_cast<const f32x4*>(a.res_mul + (size_t)s0 * so)[f];       // the addend: a full tensor
+        else if (a.res_mul) om[i] = *reinterpret_cast<const f32x4*>(a.res_mul + (e0 - cw_div(e0, a.mSO) * so));
       }
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
@@ -508,7 +510,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_same_wsp_kernel(const ConvWArgs
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = a.res_mode ? (xv[i][j] > 0.f ? t[j] : t[j] * a.res_sign) * om[i][j] : xv[i][j] + a.res_sign * (om[i][j] * t[j]);
+            o[j] = a.res_mode == 2 ? om[i][j] + (xv[i][j] > 0.f ? t[j] : t[j] * a.res_sign)
+                   : a.res_mode   ? (xv[i][j] > 0.f ? t[j] : t[j] * a.res_sign) * om[i][j]
+                                  : xv[i][j] + a.res_sign * (om[i][j] * t[j]);
           yg[f] = o;
         }
       }
@@ -617,7 +621,7 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
     S = conv2d_same_wreg_fits(cin, cout, H, W) ? conv_wreg_plan((int)cin, (int)cout, (int)H, (int)W, &a.cgs, &a.img_bytes, &lds) : 0;
   if (S == 0 || !aligned16(x) || !aligned16(y) || (in_mul && !aligned16(in_mul)) ||
       (res_x && ((!res_mul && !res_mode) || !aligned16(res_x) || (res_mul && !aligned16(res_mul)) || res_x == y))) return 0;
-  if (!specialised && res_x && (int64_t)S * cout * H * W / 4 > 4 * 512) return 0;
+  if (!specialised && res_x && ((int64_t)S * cout * H * W / 4 > 4 * 512 || res_mode == 2)) return 0;
   a.res_x = res_x; a.res_mul = res_mul; a.res_sign = res_sign; a.res_mode = res_mode;
   a.mSO = (unsigned)(0x100000000ULL / (uint64_t)(cout * H * W)) + 1u;
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;

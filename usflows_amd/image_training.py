@@ -96,6 +96,58 @@ class ConvSame(torch.autograd.Function):
         return dx, dW, db, None, None, None
 
 
+class ConvSameFork(torch.autograd.Function):
+    """(conv(in_act(x) * in_mul) + bias, x): the convolution of a layer whose INPUT forks -- GatedConv (the skip connection,
+    networks.py:108-122) and MaskedCoupling (the residual, transforms.py:277-306) use x a second time.  Returning x through the
+    same node lets the backward see both gradients and write their sum from ONE pass: the data-gradient convolution adds the
+    other branch's gradient in its output stream (usf_conv2d_same_gate_f32 with gate_add / usf_conv2d_same_res_f32) instead of
+    autograd's separate accumulation pass over the batch"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_mul, in_act):
+        x = x.contiguous()
+        w = weight.detach()
+        ks = w.shape[2]
+        ia = _act(in_act)
+        y = _ext.conv2d_same(x, _ext.conv2d_weight_planes(w), w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
+                             in_mul=in_mul, in_act=ia[0], in_slope=ia[1])
+        ctx.save_for_backward(x, w, in_mul)
+        ctx.cfg = (ks, in_act, bias is not None)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dxs):
+        x, w, in_mul = ctx.saved_tensors
+        ks, in_act, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        ia = _act(in_act)
+        dW = db = dx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+            if r is None:
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
+            dW, db = r
+        if ctx.needs_input_grad[0]:
+            planes_t = _ext.conv2d_weight_planes(w, transposed=True)
+            dxs = None if dxs is None else dxs.contiguous()
+            if dxs is not None and in_mul is not None and in_act is None:
+                # dx = dxs + mask * dgrad: the residual form of the convolution
+                dx = _ext.conv2d_same_res(dy, planes_t, w.shape[1], ks, dxs, in_mul, 1.0)
+            elif dxs is not None and in_mul is None:
+                dx = _ext.conv2d_same_gate(dy, planes_t, w.shape[1], ks, x, ia[1] if in_act is not None else 1.0, gate_add=dxs)
+            if dx is None:
+                if in_act is not None or in_mul is not None:
+                    dx = _ext.conv2d_same_gate(dy, planes_t, w.shape[1], ks, x, ia[1] if in_act is not None else 1.0, in_mul)
+                if dx is None:
+                    dx = _ext.conv2d_same(dy, planes_t, w.shape[1], ks)
+                    _gate_inplace(dx, x, in_act)
+                    if in_mul is not None:
+                        dx = _ext.masked_residual(None, dx, in_mul, 1.0)
+                if dxs is not None:
+                    dx = dx + dxs
+        return dx, dW, db, None, None
+
+
 class Pointwise(torch.autograd.Function):
     """bias + W in_act(x) per pixel on usf_pointwise_conv_f32 (W [cout, cin]: an nn.Conv2d weight with kernel 1)"""
 

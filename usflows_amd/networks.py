@@ -352,7 +352,8 @@ class GatedConv(nn.Module):
         from . import image_training as it
         n = self.net
         a0, a2 = _relu_kind(n[0]), _relu_kind(n[2])
-        h = it.ConvSame.apply(x, n[1].weight, n[1].bias, None, a0, None)
+        # (x forks into the convolution and the skip connection: one node returns both, its backward writes the summed gradient)
+        h, x = it.ConvSameFork.apply(x, n[1].weight, n[1].bias, None, a0)
         if it.pointwise_shape_ok(n[3], x.shape[0], x.shape[2], x.shape[3]):
             vg = it.Pointwise.apply(h, n[3].weight, n[3].bias, a2)
         else:
@@ -517,10 +518,13 @@ class ConvNet2D(nn.Module):
                 return False
         return True
 
-    def _forward_train_device(self, x, in_mul=None):
+    def _forward_train_device(self, x, in_mul=None, fork: bool = False):
+        """fork (a MaskedCoupling caller that uses x again for its residual): returns (net(x), x') where x' is x passed through
+        the first convolution's autograd node -- see image_training.ConvSameFork"""
         from . import image_training as it
         mods = list(self.nn)
         assert in_mul is None or isinstance(mods[0], nn.Conv2d)
+        x_fork = None
         k = 0
         while k < len(mods):
             m = mods[k]
@@ -530,6 +534,10 @@ class ConvNet2D(nn.Module):
                 after = mods[k + 2] if k + 2 < len(mods) else None
                 if fold is not None and isinstance(after, LayerNormChannels):
                     fold = None                                   # that ReLU belongs to the layer norm's pass
+                if fork and k == 0 and fold is None:
+                    x, x_fork = it.ConvSameFork.apply(x, m.weight, m.bias, in_mul, None)
+                    k += 1
+                    continue
                 x = it.ConvSame.apply(x, m.weight, m.bias, in_mul if k == 0 else None, None, fold)
                 k += 2 if fold is not None else 1
             elif isinstance(m, GatedConv):
@@ -544,7 +552,7 @@ class ConvNet2D(nn.Module):
             else:
                 x = m(x)
                 k += 1
-        return x
+        return (x, x_fork) if fork else x
 
     def first_conv_on_device(self, x) -> bool:
         """True when forward(x, in_mul=mask) may be used: the first module is a convolution the HIP kernel serves"""

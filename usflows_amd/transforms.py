@@ -218,8 +218,10 @@ class MaskedCoupling(BaseTransform):
         if not cond.train_on_device(x):
             return None
         from .image_training import MaskedResidual
-        t = cond(x, in_mul=self._mask_flat(x))
-        return MaskedResidual.apply(x, t, self._one_minus_mask(x), sign)
+        # (x forks into the conditioner and the residual: the conditioner's first convolution hands x back through its own
+        # autograd node, so the two gradients are summed inside its data-gradient pass)
+        t, xs = cond._forward_train_device(x, self._mask_flat(x), fork=True)
+        return MaskedResidual.apply(xs if xs is not None else x, t, self._one_minus_mask(x), sign)
 
     def _conditioner_masked(self, x, context, sign=None):
         """conditioner(x * mask); a ConvNet2D on the device takes x and the mask and multiplies inside its first
