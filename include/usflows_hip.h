@@ -246,6 +246,8 @@ int usf_masked_residual_f32(const float* x, const float* t, const float* one_min
  * Pointwise (1 x 1) convolution with few input channels on the vector ALUs, contiguous [B, cin, P] fp32 -> [B, cout, P]
  * (plain) or [B, cout / 2, P] (gated), P = H * W; W [cout, cin] row-major (nn.Conv2d weight [cout, cin, 1, 1]), bias [cout] or NULL:
  *   plain (gate_x == NULL): y[b, co, p] = out_act(bias[co] + sum_ci W[co, ci] * in_act(x[b, ci, p]))
+ *   plain with out_act == USF_ACT_GATE (a data gradient; gate_x [B, cout, P] = the forward layer's input):
+ *     y[b, co, p] = (bias[co] + W[co] . in_act(x)) * (gate_x[b, co, p] > 0 ? 1 : out_slope)
  *   gated (gate_x [B, C, P], cout = 2 C): y[b, c, p] = gate_x[b, c, p] + (bias[c] + W[c] . a) * sigmoid(bias[C + c] + W[C + c] . a)
  *     -- GatedConv.forward's second convolution with `x + val * sigmoid(gate)` (networks.py:108-122) in one pass.
  *   gated + layer norm (ln_gamma / ln_beta [C] non-NULL; needs cout == 2 cin, cin <= 32): the gated result r, then

@@ -208,6 +208,24 @@ def test_gated_data_gradient_convolution_is_conv_then_gate_then_mask(cin, cout, 
         assert torch.equal(got, ref), (slope, mul is not None, (got - ref).abs().max().item())
 
 
+@pytest.mark.gpu
+def test_pointwise_data_gradient_with_the_gate_in_its_pass():
+    """usf_pointwise_conv_f32 with out_act = USF_ACT_GATE == the plain pass followed by usf_act_grad_f32 on the gate tensor"""
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(11)
+    B, cin, cout, H, W = 301, 64, 32, 7, 7
+    dy = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, generator=g) * 0.1).to(DEV)
+    h = torch.randn(B, cout, H, W, generator=g).to(DEV)
+    h[0, 0, 0, 0] = 0.0
+    for slope in (0.0, 0.1):
+        got = _ext.pointwise_conv(dy, w, out_act=_ext.ACT_GATE, out_slope=slope, gate_x=h)
+        ref = _ext.pointwise_conv(dy, w)
+        n = ref.numel() // B
+        _ext.act_grad(ref, h, M=B, H=n, ldd=n, ldh=n, act=_ext.ACT_LEAKY_RELU, slope=slope)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+
+
 # ---- the autograd functions against fp64 torch autograd of the same module ------------------------------------------------
 def _grads_of(module_fn, params, x, dy):
     for p in params:

@@ -588,6 +588,9 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __rest
 #pragma unroll
           for (int ci = 0; ci < CIN; ++ci) acc = fmaf(wr[ci], v[ci], acc);
           if (bias) acc += bias[co];
+          // USF_ACT_GATE (a data gradient): times the derivative of the (Leaky)ReLU in front of the forward layer, read
+          // from that layer's input gate_x [B, cout, P]
+          if (out_act == USF_ACT_GATE) acc = gate_apply(acc, gate_x[(b * cout + co) * P + p], out_slope);
           yb[(int64_t)co * P] = act_apply(acc, out_act, out_slope);
         }
       }
@@ -604,7 +607,7 @@ int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cou
                    int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x,
                    const float* ln_gamma, const float* ln_beta, float ln_eps, hipStream_t stream) {
   if (B == 0 && P > 0 && cin > 0 && cout > 0) return 0;      // (an empty batch: its tensors have no storage to point to)
-  const int gated = gate_x != nullptr;
+  const int gated = gate_x != nullptr && out_act != USF_ACT_GATE;
   const bool lnorm = ln_gamma != nullptr;
   if (lnorm && (!ln_beta || !gated || cout != 2 * cin || cin > 32)) {
     set_error("usf_pointwise_conv_f32: the layer-norm form needs gamma and beta, the gated mode, cout == 2 cin and cin <= 32");
@@ -617,7 +620,8 @@ int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cou
   if (B == 0) return 0;
   if (!x || !y || !W) { set_error("usf_pointwise_conv_f32: null pointer"); return -1; }
   if (x == y || gate_x == y) { set_error("usf_pointwise_conv_f32: in-place operation is not supported"); return -2; }
-  if ((in_act != USF_ACT_NONE && in_act != USF_ACT_LEAKY_RELU) || (out_act != USF_ACT_NONE && out_act != USF_ACT_LEAKY_RELU)) {
+  if ((in_act != USF_ACT_NONE && in_act != USF_ACT_LEAKY_RELU) ||
+      (out_act != USF_ACT_NONE && out_act != USF_ACT_LEAKY_RELU && !(out_act == USF_ACT_GATE && gate_x && !lnorm))) {
     set_error("usf_pointwise_conv_f32: bad act");
     return -2;
   }

@@ -174,8 +174,11 @@ class Pointwise(torch.autograd.Function):
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r[0].reshape(wshape), r[1]
         if ctx.needs_input_grad[0]:
-            dx = _ext.pointwise_conv(dy, w2.t().contiguous())
-            _gate_inplace(dx, x, in_act)
+            if in_act is not None and ia[0] == _ext.ACT_LEAKY_RELU:
+                # the derivative of the input's (Leaky)ReLU rides in the data-gradient pass
+                dx = _ext.pointwise_conv(dy, w2.t().contiguous(), out_act=_ext.ACT_GATE, out_slope=ia[1], gate_x=x)
+            else:
+                dx = _ext.pointwise_conv(dy, w2.t().contiguous())
         return dx, dW, db, None
 
 
