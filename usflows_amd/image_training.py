@@ -15,8 +15,6 @@ inverse) stay torch ops on C x C tensors, as in the reference.
 """
 from __future__ import annotations
 
-import math
-
 import torch
 
 from . import _ext
@@ -80,7 +78,7 @@ class ConvSame(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
             if r is None:
-                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_train_ok was not consulted)")
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_shape_ok was not consulted)")
             dW, db = r
         if ctx.needs_input_grad[0]:
             planes_t = _ext.conv2d_weight_planes(w, transposed=True)
