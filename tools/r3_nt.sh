@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
-for v in 0 1 3; do
+for v in ${NTV:-0 1 3}; do
   lib=usflows_amd/csrc/libusflows_hip.so
   [ $v != 0 ] && lib=tools/libusflows_hip_nt$v.so
   export USFLOWS_AMD_LIB=$GRAFT_REPO_ROOT/$lib

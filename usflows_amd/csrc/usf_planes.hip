@@ -261,10 +261,18 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   vec8 fr[2][NPL], f2[2][NPL];                   // weight fragments: current tile pair / the pair being read
   f32x4 wst[NWV];
   const int nslab = p.nk;
-  issue_w(0, wst);
+  // K rotation (tuning build -DUSF_PL_ROT=1): column tile bn walks the K slabs starting at slab bn * nslab / nbn, so the
+  // column tiles of a row panel -- running side by side on one XCD -- do not ask the L2 for the same operand lines at
+  // the same moment (the order of the K sum inside a tile is free)
+#ifndef USF_PL_ROT
+#define USF_PL_ROT 0
+#endif
+  const int rot0 = USF_PL_ROT ? (bn * nslab) / max(p.nbn, 1) : 0;
+  auto ks = [&](int s_) { const int r = s_ + rot0; return r >= nslab ? r - nslab : r; };
+  issue_w(ks(0) * 32, wst);
   store_w(wring, wst);
-  issue_a(0, pa);
-  issue_w(min(1, nslab - 1) * 32, wst);         // staged at the middle of slab 0
+  issue_a(ks(0), pa);
+  issue_w(ks(min(1, nslab - 1)) * 32, wst);     // staged at the middle of slab 0
   __syncthreads();
   const float* const wl0 = wring + 4 * (lg * CS + (lj ^ (2 * lg)));
   auto read_pair = [&](const float* wl, int pr, vec8 (&f)[2][NPL]) {
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     const float* wl = wl0 + ring_s * STG;
     const float* wln = wl0 + ring_n * STG;
     float* wb = wring + ring_n * STG;
-    issue_a(min(s + 1, nslab - 1), nxt);
+    issue_a(ks(min(s + 1, nslab - 1)), nxt);
     // ---- pairs in front of the barrier; the last of them carries the stores that stage slab s + 1 ----
 #pragma unroll
     for (int pr = 0; pr <= MID; ++pr) {
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     // ---- pairs behind the barrier; the first carries the global loads of the weights of slab s + 2 (the staging
     // registers are free again: a full slab of latency cover until the middle of slab s + 1 stores them); the last
     // one reads the first pair of the NEXT slab (staged just now) ----
-    issue_w(min(s + 2, nslab - 1) * 32, wst);
+    issue_w(ks(min(s + 2, nslab - 1)) * 32, wst);
 #pragma unroll
     for (int pr = MID + 1; pr < NP; ++pr) {
       if (pr & 1) { if (pr + 1 < NP) read_pair(wl, pr + 1, fA); else read_pair(wln, 0, fA); mm_pair(pr, fB, cur); }
