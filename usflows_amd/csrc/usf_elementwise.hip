@@ -578,7 +578,11 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(const float* __rest
     }
   } else {
     float* yb = y + b * cout * P + p;
-    for (int c0 = 0; c0 < cout; c0 += 8) {
+    // (small batches: gridDim.y > 1 deals the groups of 8 output channels over blocks -- a handful of pixels per CU would
+    //  otherwise walk all cout dot products in one thread; large batches keep the loop: the inputs are loaded once)
+    const int c_lo = gridDim.y > 1 ? (int)blockIdx.y * 8 : 0;
+    const int c_hi = gridDim.y > 1 ? min(c_lo + 8, cout) : cout;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 8) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int co = c0 + j;
@@ -627,7 +631,9 @@ int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cou
   }
   const int64_t BP = B * P, blocks = (BP + 255) / 256;
   if (blocks > 0x7fffffffLL) { set_error("usf_pointwise_conv_f32: grid too large"); return -3; }
-  const dim3 g((unsigned)blocks), bl(256);
+  // plain mode at small batches: fewer than two blocks of pixels per CU -> the output channels are dealt over gridDim.y
+  const bool split_c = !gated && !lnorm && blocks < 2 * (int64_t)device_cu_count() && cout > 8;
+  const dim3 g((unsigned)blocks, split_c ? (unsigned)((cout + 7) / 8) : 1u), bl(256);
   const PwLn ln{ln_gamma, ln_beta, ln_eps};
 #define USF_PW(CI)                                                                                                      \
   do {                                                                                                                  \

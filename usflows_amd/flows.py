@@ -794,9 +794,10 @@ class Flow(torch.nn.Module):
             sc = noise.detach().clone() if noise is not None else None
 
             def body():
-                for p in params:
-                    if p.grad is not None:
-                        p.grad.zero_()          # (in place: the optimiser's pointer table and the graph keep their addresses)
+                # (in place: the optimiser's pointer table and the graph keep their addresses; one multi-tensor launch)
+                grads = [p.grad for p in params if p.grad is not None]
+                if grads:
+                    torch._foreach_zero_(grads)
                 with _unvalidated(self.base_distribution):
                     loss = -self.log_prob(sx, context=sc).mean() - self.log_prior()
                 loss.backward()

@@ -332,6 +332,21 @@ def current_prep(block_transform):
     return None if _PREP is None else _PREP.get(id(block_transform))
 
 
+_EYES = {}
+
+
+def _eye(C: int, device) -> torch.Tensor:
+    """the C x C identity on this device, made once (a constant: every call of the batched prep would otherwise spend two
+    launches on it)"""
+    key = (C, str(device))
+    e = _EYES.get(key)
+    if e is None:
+        if torch.cuda.is_available() and torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.eye(C, dtype=torch.float32, device=device)      # (never fill a cache inside a stream capture)
+        e = _EYES[key] = torch.eye(C, dtype=torch.float32, device=device)
+    return e
+
+
 def _parts(bt):
     from . import transforms as T
     parts = list(bt.transforms) if isinstance(bt, T.SequentialAffineTransform) else [bt]
@@ -348,7 +363,7 @@ def _parts(bt):
 
 def _prep_group(bts, parts_list, sig, device):
     n, C = len(bts), sig[0][1]
-    eye = torch.eye(C, dtype=torch.float32, device=device)
+    eye = _eye(C, device)
     M = Minv = b = None
     ladj = torch.zeros(n, dtype=torch.float32, device=device)
     for pos, kind in enumerate(sig):
