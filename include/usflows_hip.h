@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 25
+#define USF_ABI_VERSION 26
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -621,6 +621,26 @@ int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda,
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream);
 
+/* Many small weight / bias gradients in ONE launch.  At the reference's training batch (32 rows, tests/explib/mnist.yaml:34)
+ * Flow.fit's backward pass (flows.py:196-199) asks for one weight and one bias gradient per F.linear on the path -- some
+ * hundreds of launches of a few microseconds whose dispatch, not their work, bounds the step.  `jobs` is a DEVICE array;
+ * `block_job` a DEVICE array with the job index of every block of the launch (n_blocks entries; job j owns the blocks
+ * first_block .. first_block + its own count - 1, in order):
+ *   A != NULL: G[n,k] = alpha * sum_m Y[m,n] A[m,k] + beta * G[n,k], ceil(N/128) * ceil(K/128) blocks, exact-f32 MFMA over
+ *              one row range -- bit-identical to usf_wgrad_f32 (mode 0) on the same operands for M <= 256; the alignment
+ *              rules of usf_wgrad_f32 apply;
+ *   A == NULL: G[n] = alpha * sum_m Y[m,n] + beta * G[n], ceil(N/64) blocks (fixed summation order: reproducible).
+ * Meant for M <= 256; jobs of one launch must not write what another job of the same launch reads or writes. */
+typedef struct usf_grad_job {
+  const float* Y;
+  const float* A;
+  float* G;
+  int64_t ldy, lda, ldg;
+  int32_t M, N, K, first_block;
+  float alpha, beta;
+} usf_grad_job;
+int usf_grad_jobs_f32(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream);
+
 /*
  * SophiaG over all parameter tensors of a model in one launch (sophia.py:39-58 update_hessian, 151-199
  * _single_tensor_sophiag -- the optimiser Flow.fit defaults to, flows.py:116).  `chunks` is a DEVICE array; a chunk is
@@ -654,7 +674,8 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;
-                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc|usf_mt_chunk|usf_gated_norm_desc for 5|6|7|8|9:
+                                           usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc|usf_mt_chunk|usf_gated_norm_desc for 5|6|7|8|9,
+                                           usf_call_desc|usf_grad_job for 10|11:
                                            binding self-check */
 const char* usf_last_error(void);
 const char* usf_build_info(void);       /* "gfx950 ..." */

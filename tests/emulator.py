@@ -347,6 +347,25 @@ def _bf16_planes(w32):
 
 
 def _emu_pack_weight(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
+    if _ext._tls.jobs and n_out > 0 and n_in > 0:
+        # queued like the real call inside a batch_jobs block: runs at the flush, BEHIND the queued gradient jobs
+        _ext._tls.jobs[-1].jobs.append(lambda: _emu_pack_weight_now(src, out_idx, n_out, in_idx, n_in, W=W, ldw=ldw, planes=planes,
+                                                                  transpose=transpose, ld_src=ld_src))
+        return
+    _emu_pack_weight_now(src, out_idx, n_out, in_idx, n_in, W=W, ldw=ldw, planes=planes, transpose=transpose, ld_src=ld_src)
+
+
+def _emu_flush(self):
+    """batch_jobs.flush of the emulation: the queued gradient jobs first, then the queued pack jobs (the real order)"""
+    gj, self.grad_jobs = self.grad_jobs, []
+    for fn in gj:
+        fn()
+    jobs, self.jobs = self.jobs, []
+    for fn in jobs:
+        fn()
+
+
+def _emu_pack_weight_now(src, out_idx, n_out, in_idx, n_in, *, W=None, ldw=0, planes=None, transpose=False, ld_src=None):
     ld = ld_src if ld_src is not None else src.shape[-1]
     S = torch.as_strided(src.reshape(-1), (src.numel() // ld, ld), (ld, 1))
     if transpose:
@@ -410,14 +429,23 @@ def _emu_linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None,
     _view(C_out, c_off, M, N, ldc).copy_(v.to(torch.float32))
 
 
-def _emu_wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0):
+def _emu_wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0, defer=True):
+    bj = _ext._defer_grad_job(M) if defer else None
+    if bj is not None:         # as the real call: queued, reads its operands at the flush (usf_grad_jobs_f32)
+        bj.grad_jobs.append(lambda: _emu_wgrad(Y, A, G, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=ldg, y_off=y_off, a_off=a_off,
+                                               g_off=g_off, alpha=alpha, beta=beta, mode=mode, defer=False))
+        return
     y = _view(Y, y_off, M, N, ldy).double()
     a = _view(A, a_off, M, K, lda).double()
     g = _view(G, g_off, N, K, ldg)
     g.copy_((alpha * (y.t() @ a) + (beta * g.double() if beta != 0.0 else 0.0)).float())
 
 
-def _emu_colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):
+def _emu_colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0, defer=True):
+    bj = _ext._defer_grad_job(M) if defer else None
+    if bj is not None:
+        bj.grad_jobs.append(lambda: _emu_colsum(Y, out, M=M, N=N, ldy=ldy, y_off=y_off, alpha=alpha, beta=beta, defer=False))
+        return
     o = out.reshape(-1)[:N]
     o.copy_((alpha * _view(Y, y_off, M, N, ldy).double().sum(0) + (beta * o.double() if beta != 0.0 else 0.0)).float())
 
@@ -494,6 +522,7 @@ def install_prep_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "householder", _emu_householder)
     monkeypatch.setattr(_ext, "matmul_f64", _emu_matmul_f64)
     monkeypatch.setattr(_ext, "pack_weight", _emu_pack_weight)
+    monkeypatch.setattr(_ext.batch_jobs, "flush", _emu_flush)
     monkeypatch.setattr(_ext, "matvec_f64", _emu_matvec_f64)
     monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
 

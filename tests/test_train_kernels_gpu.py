@@ -112,3 +112,59 @@ def test_base_logprob_grad(base):
     got = out.cpu()
     assert (got[:, :D].double() - zz.grad).abs().max().item() <= 1e-6 * zz.grad.abs().max().item()
     assert got[:, D:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M", [1, 32, 48, 256])
+def test_grad_jobs_one_launch_equals_the_single_calls(M):
+    """usf_grad_jobs_f32: the weight and bias gradients of many layers as ONE launch (queued inside
+    ``batch_jobs(defer_grads=True)``) -- the weight gradients bit for bit what usf_wgrad_f32 writes for the same operands
+    (edge tiles, row / column offsets, alpha / beta), the column sums within fp32 rounding of fp64"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(M)
+    shapes = [(784, 784), (392, 256), (256, 256), (130, 36), (16, 4), (256, 392)]
+    jobs = []
+    for i, (N, K) in enumerate(shapes):
+        ldy, lda = ((N + 3) // 4) * 4 + 8, ((K + 3) // 4) * 4 + 4
+        Y = torch.randn(M, ldy, generator=g).to(DEV)
+        A = torch.randn(M, lda, generator=g).to(DEV)
+        G0 = torch.randn(N, K + 3, generator=g).to(DEV)
+        gs0 = torch.randn(N, generator=g).to(DEV)
+        jobs.append(dict(Y=Y, A=A, G0=G0, gs0=gs0, N=N, K=K, ldy=ldy, lda=lda, alpha=(-1.0 if i & 1 else 1.0),
+                         beta=(1.0 if i == 2 else 0.0), y_off=(4 if i == 3 else 0), a_off=(4 if i == 1 else 0)))
+    single, queued = [], []
+    for j in jobs:
+        Gs, ss = j["G0"].clone(), j["gs0"].clone()
+        n_eff, k_eff = j["N"] - j["y_off"], j["K"] - j["a_off"]
+        ext.wgrad(j["Y"], j["A"], Gs, M=M, N=n_eff, K=k_eff, ldy=j["ldy"], lda=j["lda"], ldg=Gs.shape[1], y_off=j["y_off"],
+                  a_off=j["a_off"], alpha=j["alpha"], beta=j["beta"])
+        ext.colsum(j["Y"], ss, M=M, N=n_eff, ldy=j["ldy"], y_off=j["y_off"], alpha=j["alpha"], beta=j["beta"])
+        single.append((Gs, ss))
+    with ext.batch_jobs(torch.device(DEV), defer_grads=True) as bj:
+        for j in jobs:
+            Gq, sq = j["G0"].clone(), j["gs0"].clone()
+            n_eff, k_eff = j["N"] - j["y_off"], j["K"] - j["a_off"]
+            ext.wgrad(j["Y"], j["A"], Gq, M=M, N=n_eff, K=k_eff, ldy=j["ldy"], lda=j["lda"], ldg=Gq.shape[1],
+                      y_off=j["y_off"], a_off=j["a_off"], alpha=j["alpha"], beta=j["beta"], mode=1)
+            ext.colsum(j["Y"], sq, M=M, N=n_eff, ldy=j["ldy"], y_off=j["y_off"], alpha=j["alpha"], beta=j["beta"])
+            queued.append((Gq, sq))
+        assert len(bj.grad_jobs) == 2 * len(jobs)
+        assert all(torch.equal(q[0], j["G0"]) for q, j in zip(queued, jobs))      # nothing ran yet
+    torch.cuda.synchronize()
+    for (Gs, ss), (Gq, sq), j in zip(single, queued, jobs):
+        assert torch.equal(Gs, Gq), (j["N"], j["K"])
+        n_eff = j["N"] - j["y_off"]
+        ref = j["alpha"] * j["Y"][:, j["y_off"]: j["y_off"] + n_eff].double().sum(0) + j["beta"] * j["gs0"][:n_eff].double()
+        scale = j["Y"].abs().max().item() * max(M, 1)
+        assert (sq[:n_eff].double() - ref).abs().max().item() <= 2e-6 * math.sqrt(max(M, 1)) * scale
+        assert torch.equal(sq[n_eff:], j["gs0"][n_eff:])                           # nothing written past N
+
+
+def test_grad_jobs_are_not_queued_above_the_row_limit():
+    ext = _ext()
+    M = ext.GRAD_JOB_MAX_ROWS + 1
+    Y, A = torch.randn(M, 16, device=DEV), torch.randn(M, 8, device=DEV)
+    G = torch.zeros(16, 8, device=DEV)
+    with ext.batch_jobs(torch.device(DEV), defer_grads=True) as bj:
+        ext.wgrad(Y, A, G, M=M, N=16, K=8, ldy=16, lda=8, ldg=8)
+        assert not bj.grad_jobs
+    assert torch.allclose(G, Y.t() @ A, rtol=1e-4, atol=1e-3)

@@ -159,3 +159,67 @@ def test_parameter_update_between_forward_and_backward_raises():
             p.mul_(1.001)
     with pytest.raises(RuntimeError, match="parameters were modified"):
         loss.backward()
+
+
+def _grads_of(flow, x, g_lp, ctx=None, defer=True):
+    from usflows_amd import training
+    path = TrainPath(flow)
+    path.defer_small_grads = defer
+    assert path.supported(x, ctx)
+    for p in flow.parameters():
+        p.grad = None
+    lp = training.log_prob_with_grad(path, x, ctx)
+    (lp * g_lp).sum().backward()
+    return lp.detach(), {n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None}, path
+
+
+@pytest.mark.parametrize("name", ["synth_d16_k3_densenn_relu", "synth_d16_k4_hh2_conj_laplace", "synth_d7_k3_soft_ctx"])
+def test_queued_gradient_jobs_equal_launching_each_in_place(name):
+    """the small-batch weight / bias gradients wait until the layer loop is over and leave as one launch
+    (usf_grad_jobs_f32; the emulation runs the queue at the flush, ahead of the queued scatter jobs, as the library does):
+    every layer's operands must still hold what they held when the job was queued -- same gradients, bit for bit, as with
+    each gradient launched at its place"""
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd)
+    x, ctx = a["x"], a.get("context")
+    if ctx is None and spec.soft_training:
+        ctx = torch.zeros(x.shape[0], 1)
+    g_lp = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(1))
+    lp_d, g_d, _ = _grads_of(flow, x, g_lp, ctx, defer=True)
+    lp_n, g_n, _ = _grads_of(flow, x, g_lp, ctx, defer=False)
+    assert torch.equal(lp_d, lp_n) and g_d.keys() == g_n.keys() and len(g_d) >= 6
+    for k in g_d:
+        assert torch.equal(g_d[k], g_n[k]), k
+
+
+@pytest.mark.parametrize("name", ["synth_d16_k3_densenn_relu", "synth_d7_k3_hh1_conj_normal"])
+def test_bound_flat_gradients_accumulate_like_autograd(name):
+    """TrainPath.bind_flat_grads: the parameters' .grad become views of one buffer and backward adds the whole arena at once
+    -- same values as autograd's per-parameter accumulation, accumulating over two backward passes, undone by grad = None"""
+    from usflows_amd import training
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd)
+    x, ctx = a["x"], a.get("context")
+    g_lp = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(2))
+    _lp, g1, path = _grads_of(flow, x, g_lp, ctx)
+    assert path.bind_flat_grads()
+    named = dict(flow.named_parameters())
+    ptrs = {n: named[n].grad.data_ptr() for n in g1}
+    for n in g1:
+        assert torch.equal(named[n].grad, g1[n])            # current values kept
+    path._gflat.zero_()
+    for rep in (1, 2):
+        lp = training.log_prob_with_grad(path, x, ctx)
+        (lp * g_lp).sum().backward()
+        for n in g1:
+            assert named[n].grad.data_ptr() == ptrs[n]       # still the views: nothing was handed to AccumulateGrad
+            assert torch.allclose(named[n].grad, rep * g1[n], rtol=1e-6, atol=1e-7 * float(g1[n].abs().max())), (n, rep)
+    some = next(iter(g1))
+    named[some].grad = None                                  # the binding is gone: autograd's own accumulation again
+    for p in flow.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    lp = training.log_prob_with_grad(path, x, ctx)
+    (lp * g_lp).sum().backward()
+    for n in g1:
+        assert torch.allclose(named[n].grad, g1[n], rtol=1e-6, atol=1e-7 * float(g1[n].abs().max())), n

@@ -274,5 +274,7 @@ def test_failed_capture_of_a_training_step_is_recoverable(monkeypatch):
     l_ref, lp_ref, _ = run(False)
     l_brk, lp_brk, failed = run(True)
     assert failed, "the capture was expected to fail"
+    # torch's generator of the device is usable again (a capture that breaks off leaves it in capture mode)
+    assert torch.isfinite(torch.normal(torch.zeros(8, device=DEV), torch.ones(8, device=DEV))).all()
     assert np.allclose(l_brk, l_ref, rtol=1e-6, atol=0), (l_brk, l_ref)
     assert torch.allclose(lp_brk, lp_ref, rtol=1e-6, atol=1e-5)

@@ -48,6 +48,9 @@ def run(graph: bool):
 
 
 ms_g, l_g, rep, failed = run(True)
+if os.environ.get("FIT_ONLY") == "graph":  # for kernel traces: the replayed step alone
+    print(f"Flow.fit cfg2 flat flow, batch {B}: graph replay {ms_g:.2f} ms/step ({rep} replays, capture failed: {failed})")
+    sys.exit(0)
 ms_e, l_e, _, _ = run(False)
 print(f"Flow.fit cfg2 flat flow, batch {B}, {STEPS} steps per epoch: graph replay {ms_g:.2f} ms/step ({rep} replays, capture failed: {failed}); "
       f"eager {ms_e:.2f} ms/step; epoch loss graph {l_g[-1]:.6f} vs eager {l_e[-1]:.6f}")

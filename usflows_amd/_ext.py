@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 25
+USF_ABI_VERSION = 26
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -135,6 +135,15 @@ class PackJob(C.Structure):
     ]
 
 
+class GradJob(C.Structure):
+    _fields_ = [
+        ("Y", _fp), ("A", _fp), ("G", _fp),
+        ("ldy", C.c_int64), ("lda", C.c_int64), ("ldg", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("first_block", C.c_int32),
+        ("alpha", C.c_float), ("beta", C.c_float),
+    ]
+
+
 # every symbol include/usflows_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "usf_abi_version": (C.c_int, []),
@@ -208,6 +217,7 @@ SYMBOLS = {
     "usf_base_logprob_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp,
                                             C.c_int64, C.c_void_p]),
     "usf_pack_weights_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_grad_jobs_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_void_p]),
     "usf_matvec_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_double, _fp, _fp, C.c_void_p]),
 }
 
@@ -237,7 +247,8 @@ def load() -> C.CDLL:
         raise RuntimeError(f"usflows_amd: ABI mismatch: library {lib.usf_abi_version()} != binding {USF_ABI_VERSION}")
     for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
                      (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc),
-                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk), (OP_GATED_NORM, GatedNormDesc), (OP_CALL, CallDesc)):
+                     (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk), (OP_GATED_NORM, GatedNormDesc), (OP_CALL, CallDesc),
+                     (11, GradJob)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -792,9 +803,14 @@ class batch_jobs:
     per size class at exit (or at an explicit ``flush``).  Only for calls whose sources are ready when the batch is
     flushed and whose outputs nobody reads before that."""
 
-    def __init__(self, device):
+    def __init__(self, device, defer_grads: bool = False):
         self.device = device
         self.jobs = []
+        # defer_grads: usf_wgrad_f32 / usf_colsum_f32 calls of at most GRAD_JOB_MAX_ROWS rows are queued as well and leave
+        # as ONE usf_grad_jobs_f32 launch ahead of the pack jobs (which may read their outputs).  The caller guarantees
+        # that their operands stay untouched until the flush.
+        self.defer_grads = bool(defer_grads)
+        self.grad_jobs = []
 
     def __enter__(self):
         _tls.jobs.append(self)
@@ -807,6 +823,7 @@ class batch_jobs:
         return False
 
     def flush(self):
+        self._flush_grads()
         jobs, self.jobs = self.jobs, []
         if not jobs:
             return
@@ -821,6 +838,33 @@ class batch_jobs:
             max_cols = max(max(j[0].n_in, j[0].ld_planes if j[0].planes else 0) for j in part)
             _launch("usf_pack_weights_f32", (table.data_ptr(), len(part), max_rows, max_cols,
                                              current_stream(self.device)), (table, [j[1] for j in part]))
+
+
+    def _flush_grads(self):
+        gj, self.grad_jobs = self.grad_jobs, []
+        if not gj:
+            return
+        block_job, first = [], 0
+        for i, (j, _keep) in enumerate(gj):
+            nb = ((j.N + 127) // 128) * ((j.K + 127) // 128) if j.A else (j.N + 63) // 64
+            j.first_block = first
+            block_job.extend([i] * nb)
+            first += nb
+        arr = (GradJob * len(gj))(*[j[0] for j in gj])
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        bj = torch.tensor(block_job, dtype=torch.int32).to(self.device)
+        _launch("usf_grad_jobs_f32", (table.data_ptr(), bj.data_ptr(), first, current_stream(self.device)),
+                (table, bj, [j[1] for j in gj]))
+
+
+GRAD_JOB_MAX_ROWS = 256      # usf_grad_jobs_f32 runs one row range per job (usf_wgrad_f32 splits the batch above this)
+
+
+def _defer_grad_job(M: int):
+    """the open batch that takes a weight / bias gradient of M rows as a queued job, or None"""
+    if _tls.jobs and _tls.jobs[-1].defer_grads and 0 < M <= GRAD_JOB_MAX_ROWS:
+        return _tls.jobs[-1]
+    return None
 
 
 def flush_jobs() -> None:
@@ -870,9 +914,16 @@ def _workspace(device, floats: int) -> torch.Tensor:
     return ws
 
 
-def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0):
-    """G[n,k] = alpha * sum_m Y[m,n] A[m,k] + beta * G (element offsets *_off into the fp32 tensors)"""
+def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0, defer=True):
+    """G[n,k] = alpha * sum_m Y[m,n] A[m,k] + beta * G (element offsets *_off into the fp32 tensors).  Inside a
+    ``batch_jobs(defer_grads=True)`` block a small-batch call is queued (same arithmetic: see usf_grad_jobs_f32)."""
     lib = load()
+    bj = _defer_grad_job(M) if defer else None
+    if bj is not None and ldy % 4 == 0 and lda % 4 == 0 and (Y.data_ptr() + 4 * y_off) % 16 == 0 \
+            and (A.data_ptr() + 4 * a_off) % 16 == 0:
+        bj.grad_jobs.append((GradJob(Y.data_ptr() + 4 * y_off, A.data_ptr() + 4 * a_off, G.data_ptr() + 4 * g_off, ldy, lda,
+                                     ldg, M, N, K, 0, float(alpha), float(beta)), (Y, A, G)))
+        return
     need = lib.usf_wgrad_workspace_floats(M, N, K)
     ws = _workspace(Y.device, need)
     _launch("usf_wgrad_f32", (Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
@@ -881,6 +932,11 @@ def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):
+    bj = _defer_grad_job(M)
+    if bj is not None:
+        bj.grad_jobs.append((GradJob(Y.data_ptr() + 4 * y_off, None, out.data_ptr(), ldy, 0, 0, M, N, 0, 0, float(alpha),
+                                     float(beta)), (Y, out)))
+        return
     ws = _workspace(Y.device, (M // 256 + M // 65536 + 4) * N)
     _launch("usf_colsum_f32", (Y.data_ptr() + 4 * y_off, ldy, M, N, out.data_ptr(), float(alpha), float(beta),
                                ws.data_ptr(), ws.numel(), current_stream(Y.device)), (Y, out, ws))

@@ -93,6 +93,7 @@ int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, f
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
           hipStream_t stream);
+int grad_jobs(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
 int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
@@ -118,6 +119,7 @@ int usf_sizeof_desc(int32_t kind) {
     case 8: return (int)sizeof(usf_mt_chunk);
     case USF_OP_GATED_NORM: return (int)sizeof(usf_gated_norm_desc);
     case USF_OP_CALL: return (int)sizeof(usf_call_desc);
+    case 11: return (int)sizeof(usf_grad_job);
     default: return -1;
   }
 }
@@ -300,6 +302,9 @@ int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K) {
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::colsum(Y, ldy, M, N, out, alpha, beta, workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_grad_jobs_f32(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream) {
+  return usf::grad_jobs(jobs, block_job, n_blocks, (hipStream_t)stream);
 }
 int usf_act_grad_f32(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
                      usf_stream_t stream) {

@@ -74,14 +74,13 @@ __device__ __forceinline__ void wg_load(const float* __restrict__ P, int64_t ld,
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+// one 128 x 128 output tile over one row range (the body of wgrad_kernel; grad_jobs_kernel runs it per queued job)
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, const int tile, const int split) {
   __shared__ __attribute__((aligned(16))) float Ys[2][WG_S][WG_LD];
   __shared__ __attribute__((aligned(16))) float As[2][WG_S][WG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int tilesK = (a.K + WG_T - 1) / WG_T;
-  int tile, split;
-  if (!wg_decode(a, tile, split)) return;
   const int n0 = (tile / tilesK) * WG_T, k0 = (tile % tilesK) * WG_T;
   const int m_begin = split * a.rows_per_split;
   const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
@@ -177,6 +176,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
           }
         }
       }
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  int tile, split;
+  if (!wg_decode(a, tile, split)) return;
+  wgrad_tile(a, tile, split);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Many small weight / bias gradients in ONE launch (usf_grad_jobs_f32).  At the reference's training batch of 32 rows
+// (tests/explib/mnist.yaml:34) a flow of 32 blocks asks for ~130 weight gradients and as many bias gradients of a few
+// microseconds each: the step is bound by their dispatch, not by their work.  Every block of this launch looks its job up
+// in `block_job` (block -> job index; the job names its first block) and runs
+//   A != NULL: one 128 x 128 tile of G = alpha Y^T A + beta G  -- wgrad_tile above, single row range, written directly
+//              (bit-identical to usf_wgrad_f32 mode 0 on the same operands at M <= 256),
+//   A == NULL: 64 columns of gsum = alpha colsum(Y) + beta gsum (4 row lanes, summed in a fixed order).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_jobs_kernel(const usf_grad_job* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const usf_grad_job jb = jobs[block_job[blockIdx.x]];
+  const int local = (int)blockIdx.x - jb.first_block;
+  if (jb.A) {
+    const int rows = (jb.M + 31) / 32 * 32;
+    const WgradArgs a{jb.Y, jb.ldy, jb.A, jb.lda, nullptr, jb.M, jb.N, jb.K, rows > 0 ? rows : 32, jb.G, jb.ldg, jb.alpha,
+                      jb.beta, 1, 0, 1, nullptr};
+    wgrad_tile(a, local, 0);
+    return;
+  }
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = local * 64 + cl;
+  float s = 0.f;
+  if (c < jb.N)
+    for (int m = rl; m < jb.M; m += 4) s += jb.Y[(int64_t)m * jb.ldy + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < jb.N) {
+    const float t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    jb.G[c] = jb.alpha * t + (jb.beta != 0.f ? jb.beta * jb.G[c] : 0.f);
+  }
 }
 
 
@@ -775,6 +813,16 @@ int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float 
     ld = N;
   }
   return check_launch("usf_colsum_f32");
+}
+
+int grad_jobs(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream) {
+  if (n_blocks < 0 || n_blocks > 0x7fffffff || (n_blocks > 0 && (!jobs || !block_job))) {
+    set_error("usf_grad_jobs_f32: bad arguments");
+    return -1;
+  }
+  if (n_blocks == 0) return 0;
+  grad_jobs_kernel<<<(unsigned)n_blocks, 256, 0, stream>>>(jobs, block_job);
+  return check_launch("usf_grad_jobs_f32");
 }
 
 // ---------------------------------------------------------------------------------------------------------

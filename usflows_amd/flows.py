@@ -765,7 +765,9 @@ class Flow(torch.nn.Module):
         # bases that build a fresh, argument-validating torch distribution on every log_prob (DistributionModule:
         # RadialDistribution with its norm distribution) read a flag back to the host inside the step, and a parameter
         # prior (prior_scale) is evaluated by host-side torch code: neither survives a stream capture -- eager steps
-        if isinstance(self.base_distribution, DistributionModule) or getattr(self, "prior_scale", None) is not None:
+        base = self.base_distribution
+        if isinstance(base, DistributionModule) or getattr(self, "prior_scale", None) is not None or \
+                (isinstance(base, torch.nn.Module) and any(isinstance(m_, DistributionModule) for m_ in base.modules())):
             return None
         with torch.enable_grad():
             if self._train_path(sample, noise) is not None:
@@ -792,10 +794,21 @@ class Flow(torch.nn.Module):
                 return None
             sx = sample.detach().clone()
             sc = noise.detach().clone() if noise is not None else None
+            gflat = None
+            with torch.enable_grad():
+                tp = self._train_path(sample, noise)
+            if tp is not None and tp.bind_flat_grads():
+                # flat flows: the gradients become views of one buffer -- zeroed and accumulated by one launch each
+                gflat = tp._gflat
+                if hasattr(optim, "prepare_tables"):
+                    optim.prepare_tables()
+            bound = set() if gflat is None else {id(e[0]) for e in tp._gflat_views.values()}
 
             def body():
                 # (in place: the optimiser's pointer table and the graph keep their addresses; one multi-tensor launch)
-                grads = [p.grad for p in params if p.grad is not None]
+                grads = [p.grad for p in params if p.grad is not None and id(p) not in bound]
+                if gflat is not None:
+                    gflat.zero_()
                 if grads:
                     torch._foreach_zero_(grads)
                 with _unvalidated(self.base_distribution):
@@ -814,8 +827,12 @@ class Flow(torch.nn.Module):
             except Exception as e:      # noqa: BLE001  (an op that cannot be captured: eager steps from now on)
                 self._train_graph_failed = True
                 self._recover_from_failed_capture(optim, params)
+                import traceback
+                where = " <- ".join(f"{f.name} ({os.path.basename(f.filename)}:{f.lineno})"
+                                    for f in reversed(traceback.extract_tb(e.__traceback__)[-4:]))
                 warnings.warn(f"usflows_amd: hipGraph capture of the training step failed ({type(e).__name__}: "
-                              f"{str(e).splitlines()[0] if str(e) else ''}); Flow.fit runs eager steps", RuntimeWarning)
+                              f"{str(e).splitlines()[0] if str(e) else ''}; at {where}); Flow.fit runs eager steps",
+                              RuntimeWarning)
                 return None
             # the graph holds raw addresses: keep what it writes to and reads from alive whatever happens to `p.grad` or to
             # the optimiser's pointer tables afterwards (an eager step in between -- the ragged last batch of an epoch --
@@ -850,6 +867,16 @@ class Flow(torch.nn.Module):
             fresh = torch.cuda.Stream(device=dev)
             torch.cuda.set_stream(fresh)
             self.__dict__["_fit_stream"] = fresh
+        if dev is not None and dev.type == "cuda":
+            # the broken capture never reached its epilogue: torch's default generator of the device still believes it is
+            # being captured ("Offset increment outside graph capture" at the next random draw).  An empty capture that
+            # does end runs prologue and epilogue and leaves the generator in its normal state.
+            try:
+                with torch.cuda.graph(torch.cuda.CUDAGraph()):
+                    torch.zeros(1, device=dev)
+                torch.cuda.synchronize(dev)
+            except Exception:           # noqa: BLE001
+                pass
         eng = getattr(self, "_engine_obj", None)
         if eng is not None:
             eng._pack, eng._pack_key = None, None

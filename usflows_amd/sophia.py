@@ -89,6 +89,19 @@ class SophiaG(Optimizer):
         self._tables[gi] = (key, dev, len(rows))
         return dev, len(rows)
 
+    def prepare_tables(self) -> None:
+        """(re)build the device chunk tables for the parameters' current gradient buffers now -- Flow.fit calls this
+        before it captures a step as a hipGraph: the upload of a table is a host-to-device copy, which a capture refuses"""
+        for gi, group in enumerate(self.param_groups):
+            if group["capturable"]:
+                continue
+            hip = [p for p in group["params"]
+                   if p.grad is not None and not p.grad.is_sparse and self._on_hip(p) and not torch.is_complex(p)]
+            if hip:
+                for p in hip:
+                    self._state_of(p)
+                self._table(gi, hip)
+
     @torch.no_grad()
     def update_hessian(self):
         """h = beta2 * h + (1 - beta2) * g * g   (sophia.py:39-58)"""

@@ -51,6 +51,8 @@ def _inverse_index(idx: torch.Tensor, D: int, device) -> torch.Tensor:
 class TrainPath:
     """forward / backward of ``Flow.log_prob`` for one flow (owned by the Flow; shares the FlowEngine)."""
 
+    defer_small_grads = True      # batches <= _ext.GRAD_JOB_MAX_ROWS: weight / bias gradients as one usf_grad_jobs_f32 launch
+
     def __init__(self, flow):
         self.flow = flow
         self.eng: FlowEngine = flow.engine()
@@ -209,7 +211,8 @@ class TrainPath:
                     W_split=planes, **kw)
 
     # ---- backward -------------------------------------------------------------------------------------
-    def backward(self, plan, x, g_lp: torch.Tensor, gsum: Optional[torch.Tensor] = None) -> Dict[int, torch.Tensor]:
+    def backward(self, plan, x, g_lp: torch.Tensor, gsum: Optional[torch.Tensor] = None,
+                 into_bound: bool = False) -> Dict[int, torch.Tensor]:
         """gradients of sum_m g_lp[m] * log_prob(x)[m] w.r.t. every trainable parameter: id(param) -> tensor.
 
         The launch sequence depends only on the plan: it is recorded on the first call (``_ext.Tape``) and replayed
@@ -233,11 +236,86 @@ class TrainPath:
                 if tape is not None:
                     tape.stream = _ext.current_stream(dev)
                 plan["bwd_tape"], plan["bwd_pk"] = tape, pk
+            self._last_arena = arena
+            if into_bound:
+                # the node was built over bound gradients (bind_flat_grads; _LogProbFn took no parameter inputs): what
+                # autograd's AccumulateGrad would do per parameter (~290 small adds) is one add over the flat buffer
+                gf = self._bound_grads(arena)
+                if gf is not None:
+                    gf.add_(arena["flat"])
+                else:               # the binding went away between forward and backward: per parameter, by hand
+                    params = self._arena_params()
+                    for pid in arena["touched"]:
+                        p, g = params[pid], arena["views"][pid]
+                        if p.grad is None:
+                            p.grad = g.clone()
+                        else:
+                            p.grad.add_(g)
+                return {}
             flat = arena["flat"].clone()          # autograd may keep what we return: never hand out the arena itself
             self.allreduce_gradients(flat, x.shape[0])
         # parameters the path never reaches (a context layer without context) get no gradient, as under autograd
         return {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items()
                 if pid in arena["touched"]}
+
+    # ---- gradients accumulated by one launch ----------------------------------------------------------------
+    def _arena_params(self) -> Dict[int, torch.nn.Parameter]:
+        ps = list(self.params())
+        b = self.flow.base_distribution
+        if hasattr(b, "loc") and isinstance(getattr(b, "loc", None), torch.nn.Parameter):
+            ps.append(b.loc)
+        return {id(p): p for p in ps}
+
+    def bind_flat_grads(self) -> bool:
+        """Make the ``.grad`` of every parameter this path produces a gradient for a VIEW of one flat fp32 buffer laid
+        out like the gradient arena (current values kept).  While the views stay in place (``optimizer.zero_grad(
+        set_to_none=True)`` or any reassignment undoes it), ``backward`` adds the whole arena with one launch instead of
+        handing ~9 tensors per block to autograd's per-parameter accumulation -- at the reference's batch of 32 rows those
+        adds are a tenth of the step.  Flow.fit calls this before it captures the step as a hipGraph.  Parameter hooks
+        on these parameters do not fire while bound (none are used by Flow.fit); data-parallel runs stay unbound."""
+        ar = self.__dict__.get("_last_arena")
+        if ar is None or self.grad_allreduce is not None:
+            return False
+        params = self._arena_params()
+        gf = torch.zeros_like(ar["flat"])
+        views = {}
+        for pid in ar["touched"]:
+            p = params.get(pid)
+            if p is None or p.dtype != torch.float32 or p.device != gf.device:
+                return False
+            o, n, shape = ar["slots"][pid]
+            views[pid] = (p, gf[o: o + n].view(shape))
+        with torch.no_grad():
+            for p, v in views.values():
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+        self._gflat = gf
+        # what the autograd node hangs on while the gradients are bound (its own gradient is a constant zero)
+        self._anchor = torch.zeros((), dtype=torch.float32, device=gf.device, requires_grad=True)
+        self._anchor_zero = torch.zeros((), dtype=torch.float32, device=gf.device)
+        self._gflat_views = {pid: (p, v.data_ptr(), ar["slots"][pid][0]) for pid, (p, v) in views.items()}
+        return True
+
+    def grads_bound(self) -> bool:
+        """are the parameters' .grad still the views bind_flat_grads made?  (checked when the autograd node is built)"""
+        views = self.__dict__.get("_gflat_views")
+        if not views or self.grad_allreduce is not None:
+            return False
+        return all(e[0].grad is not None and e[0].grad.data_ptr() == e[1] for e in views.values())
+
+    def _bound_grads(self, arena) -> Optional[torch.Tensor]:
+        gf = self.__dict__.get("_gflat")
+        if gf is None or self.grad_allreduce is not None or gf.shape != arena["flat"].shape:
+            return None
+        views = self._gflat_views
+        if len(views) != len(arena["touched"]):
+            return None
+        for pid in arena["touched"]:
+            e = views.get(pid)
+            if e is None or e[0].grad is None or e[0].grad.data_ptr() != e[1] or arena["slots"][pid][0] != e[2]:
+                return None
+        return gf
 
     def allreduce_gradients(self, flat: torch.Tensor, local_rows: int) -> None:
         """data-parallel training: ONE all-reduce over the flat gradient arena (its last element carries this rank's
@@ -340,13 +418,22 @@ class TrainPath:
         self._prepare_images(plan, first_meta)
         # gradient images -> parameter layout (scatter / un-permute): every layer has image buffers of its own, so all
         # of these copies wait in one batch and go out as one launch per size class behind the last layer
-        with _ext.batch_jobs(dev):
+        # Small batches (the reference trains on 32 rows: tests/explib/mnist.yaml:34): the ~260 weight / bias gradients of
+        # a step wait as well and leave as ONE usf_grad_jobs_f32 launch.  Their operands must then outlive the layer loop:
+        # every layer gets gradient / activation buffers of its own (a few hundred KB each at these batches) instead of
+        # the ping-pong pairs, and a coupling layer that would update, in place, columns a queued job of the coupling layer
+        # before it still has to read flushes the queue first (flows with an affine layer between couplings never do).
+        self._defer = bool(self.defer_small_grads) and 0 < B <= _ext.GRAD_JOB_MAX_ROWS
+        self._g_pending = False
+        with _ext.batch_jobs(dev, defer_grads=self._defer):
             for m in reversed(plan["meta"]):
                 if m["kind"] == "affine":
                     g_cur, g_other, g_ld = self._affine_backward(plan, m, g_cur, g_other, g_ld, aff, stacks,
                                                                  need_dgrad=(m is not first_meta))
+                    self._g_pending = False
                 else:
                     self._coupling_backward(plan, m, g_cur, g_ld, grads)
+                    self._g_pending = self._defer
         _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
 
     def _prepare_images(self, plan, first_meta):
@@ -422,7 +509,8 @@ class TrainPath:
         if m["in_buf"] == "user_in":
             # the caller's tensor changes from call to call: issued through the wrapper on every replay
             _ext.host_op(lambda g=g_cur, ld=g_ld: _ext.wgrad(g, self._cur["x"], Gp, M=B, N=n_out, K=n_in, ldy=ld,
-                                                            lda=self._cur["x"].shape[1], ldg=Gp.shape[1], mode=self._wmode))
+                                                            lda=self._cur["x"].shape[1], ldg=Gp.shape[1], mode=self._wmode,
+                                                            defer=False))
         else:
             _ext.wgrad(g_cur, ws[m["in_buf"]], Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=m["in_ld"], ldg=Gp.shape[1],
                        mode=self._wmode)
@@ -442,6 +530,10 @@ class TrainPath:
         rec["uses"].append(dict(which=which, G=G_nat, gsum=gs_nat, pre_scale=m["pre_scale"], row=k))
         if need_dgrad:
             Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
+            if self._defer:                       # g_cur waits for this layer's queued gradient jobs: never written again
+                dst = self._buf(ws, f"gD{m['op']}", B, wid)
+                self._linear(pk, g_cur, 0, g_ld, Wt, dst, 0, n_in, B, n_in, n_out)
+                return dst, g_other, n_in
             self._linear(pk, g_cur, 0, g_ld, Wt, g_other, 0, n_in, B, n_in, n_out)
             return g_other, g_cur, n_in
         return g_cur, g_other, g_ld
@@ -464,7 +556,8 @@ class TrainPath:
         nl = len(un["layers"])
         act, slope = cp["act"], cp["slope"]
         # 1. hidden activations again (the conditioning half of the saved buffer is what the forward saw)
-        hbufs = [self._buf(ws, f"Hs{j}", B, hmax) for j in range(nl)]
+        own = f"_{m['step']}" if self._defer else ""          # deferred gradient jobs read these after the layer loop
+        hbufs = [self._buf(ws, f"Hs{j}{own}", B, hmax) for j in range(nl)]
         src, src_off, src_ld, src_K = zbuf, cp["pass_off"], LD, cp["pass_n"]
         for j, (W, b) in enumerate(un["layers"]):
             kw = {}
@@ -491,9 +584,14 @@ class TrainPath:
         _ext.colsum(g_cur, gb, M=B, N=tr_n, ldy=g_ld, y_off=tr_off, alpha=sign)
         self._scatter_vec(grads, last_l.bias, gb, self._sel_inv(raw["tr_idx"], dev), eng.D)
         # d_h = d_out W_out  (sign is applied where the result leaves the MLP)
-        d_bufs = [self._buf(ws, "Dh0", B, hmax), self._buf(ws, "Dh1", B, hmax)]
+        if self._defer:
+            d_bufs = [self._buf(ws, f"Dh{j}{own}", B, hmax) for j in range(nl)]
+            d_of = lambda j: d_bufs[j]                            # noqa: E731  (gradient at hidden layer j's output)
+        else:
+            d_bufs = [self._buf(ws, "Dh0", B, hmax), self._buf(ws, "Dh1", B, hmax)]
+            d_of = lambda j: d_bufs[(nl - 1 - j) & 1]             # noqa: E731
         Wt = self._transposed(pk, W_out)                      # [hp_last, tr_n4]
-        d = d_bufs[0]
+        d = d_of(nl - 1)
         # (the (Leaky)ReLU backward from the saved layer output rides in the GEMM's epilogue: USF_ACT_GATE)
         gate = lambda hbuf: dict(act=_ext.ACT_GATE, slope=slope, addend=hbuf, ldadd=hmax) if act != _ext.ACT_NONE else {}
         self._linear(pk, g_cur, tr_off, g_ld, Wt, d, 0, hmax, B, hp[-1], Wt.shape[1], **gate(hbufs[-1]))
@@ -506,7 +604,7 @@ class TrainPath:
                        mode=self._wmode)
             self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
             self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
-            d_next = d_bufs[1] if d is d_bufs[0] else d_bufs[0]
+            d_next = d_of(j - 1)
             self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j], **gate(hbufs[j - 1]))
             d = d_next
         # 4. input layer
@@ -525,6 +623,8 @@ class TrainPath:
                 self._scatter_weight(grads, ctx_l.weight, gW, None, h[0], None, 1)
                 self._colsum_to(grads, ctx_l.bias, d, B, h[0], hmax, sign)
         # conditioning half of the gradient: g_P += s * d W_in   (in place)
+        if self._g_pending:
+            _ext.flush_jobs()          # the coupling layer before this one queued reads of columns this update rewrites
         self._linear(pk, d, 0, hmax, self._transposed(pk, W_in), g_cur, pass_off, g_ld, B, pass_n, hp[0],
                      residual=g_cur, r_off=pass_off, ldr=g_ld, res_sign=sign)
 
@@ -875,12 +975,18 @@ class _LogProbFn(torch.autograd.Function):
         lp, plan, xc, gen = path.forward(x, context)
         ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
         ctx.params = params
+        # bound gradients (TrainPath.bind_flat_grads): the only differentiable input is the path's anchor scalar; the
+        # parameters' gradients are added into their flat buffer by backward itself
+        ctx.bound = len(params) == 1 and params[0] is path.__dict__.get("_anchor")
         return lp
 
     @staticmethod
     def backward(ctx, g_lp):
         path: TrainPath = ctx.path
         path.revalidate(ctx)
+        if ctx.bound:
+            path.backward(ctx.plan, ctx.x, g_lp, into_bound=True)
+            return (None, None, None, path._anchor_zero)
         grads = path.backward(ctx.plan, ctx.x, g_lp)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (None, None, None) + out
@@ -942,4 +1048,6 @@ def log_prob_with_grad(path: TrainPath, x, context):
         base = path.flow.base_distribution
         r, logdet = _RadiusFn.apply(path, x, context, base.loc, *params)
         return base.log_prob_from_radius(r) + logdet
+    if path.grads_bound() and torch.is_grad_enabled():
+        return _LogProbFn.apply(path, x, context, path._anchor)
     return _LogProbFn.apply(path, x, context, *params)
