@@ -805,12 +805,15 @@ class Flow(torch.nn.Module):
             bound = set() if gflat is None else {id(e[0]) for e in tp._gflat_views.values()}
 
             def body():
-                # (in place: the optimiser's pointer table and the graph keep their addresses; one multi-tensor launch)
-                grads = [p.grad for p in params if p.grad is not None and id(p) not in bound]
+                # flat flows: the bound gradient buffer is zeroed in place (one launch).  Every other gradient is dropped:
+                # autograd then TAKES the tensors the backward pass produces as the new .grad (no zeroing launch, no
+                # per-parameter add); they are allocated inside the capture, i.e. at the same addresses in every replay,
+                # and the optimiser's pointer table is built for exactly those (uploaded after the capture).
                 if gflat is not None:
                     gflat.zero_()
-                if grads:
-                    torch._foreach_zero_(grads)
+                for p in params:
+                    if id(p) not in bound:
+                        p.grad = None
                 with _unvalidated(self.base_distribution):
                     loss = -self.log_prob(sx, context=sc).mean() - self.log_prior()
                 loss.backward()
@@ -822,8 +825,16 @@ class Flow(torch.nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 cur = torch.cuda.current_stream(sample.device)
                 on_own = cur == self.__dict__.get("_fit_stream")
-                with (torch.cuda.graph(graph, stream=cur) if on_own else torch.cuda.graph(graph)):
-                    sl = body()
+                if hasattr(optim, "defer_uploads"):
+                    optim.defer_uploads(True)
+                try:
+                    with (torch.cuda.graph(graph, stream=cur) if on_own else torch.cuda.graph(graph)):
+                        sl = body()
+                finally:
+                    if hasattr(optim, "defer_uploads"):
+                        optim.defer_uploads(False)
+                if hasattr(optim, "flush_uploads"):
+                    optim.flush_uploads()
             except Exception as e:      # noqa: BLE001  (an op that cannot be captured: eager steps from now on)
                 self._train_graph_failed = True
                 self._recover_from_failed_capture(optim, params)
@@ -884,6 +895,11 @@ class Flow(torch.nn.Module):
             eng._ws.clear()
         self._train_obj = None
         self.__dict__.pop("_train_graph_state", None)
+        if hasattr(optim, "_tables"):
+            # (a pointer table built during the broken capture was never uploaded, and a later allocation may land on the
+            # addresses it is keyed on)
+            optim._tables = {}
+            optim._pending_uploads = []
         for p in params:
             if p.grad is not None:
                 p.grad = None

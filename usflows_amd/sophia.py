@@ -84,10 +84,42 @@ class SophiaG(Optimizer):
                              min(_CHUNK, n - off), 0))
         dt = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("h", "<u8"), ("n", "<i4"), ("r", "<i4")])
         assert dt.itemsize == _ext.C.sizeof(_ext.MtChunk)
-        host = np.array(rows, dtype=dt)
-        dev = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(ps[0].device)
+        host = torch.from_numpy(np.array(rows, dtype=dt).view(np.uint8).reshape(-1).copy())
+        if getattr(self, "_defer_uploads", False) and torch.cuda.is_current_stream_capturing():
+            # Flow.fit captures a step whose gradients are allocated inside the capture (their addresses are known only
+            # now): a host-to-device copy is not capturable, and not needed -- nothing runs during a capture.  The table
+            # goes into a buffer allocated BEFORE the capture (memory allocated inside one is recycled between the graph's
+            # own kernels on every replay: a table uploaded once would be overwritten by whatever shared its block); its
+            # contents are uploaded by flush_uploads() before the first replay.
+            buf = self._capture_buffers.get(gi)
+            if buf is None or buf.numel() < host.numel():
+                raise RuntimeError("SophiaG: no pointer-table buffer prepared for this capture (defer_uploads)")
+            dev = buf[: host.numel()]
+            self._pending_uploads.append((dev, host))
+        else:
+            dev = host.to(ps[0].device)
         self._tables[gi] = (key, dev, len(rows))
         return dev, len(rows)
+
+    def defer_uploads(self, on: bool) -> None:
+        """Flow.fit, around the capture of a training step: table uploads wait for ``flush_uploads``; ``on`` allocates
+        one table buffer per group, large enough for all of the group's device parameters"""
+        from . import _ext
+        self._defer_uploads = bool(on)
+        if on:
+            self._pending_uploads = []
+            self._capture_buffers = {}
+            for gi, group in enumerate(self.param_groups):
+                ps = [p for p in group["params"] if p.is_cuda and p.dtype == torch.float32]
+                rows = sum((p.numel() + _CHUNK - 1) // _CHUNK for p in ps)
+                if rows:
+                    self._capture_buffers[gi] = torch.empty(rows * _ext.C.sizeof(_ext.MtChunk), dtype=torch.uint8,
+                                                            device=ps[0].device)
+
+    def flush_uploads(self) -> None:
+        for dev, host in getattr(self, "_pending_uploads", []):
+            dev.copy_(host)
+        self._pending_uploads = []
 
     def prepare_tables(self) -> None:
         """(re)build the device chunk tables for the parameters' current gradient buffers now -- Flow.fit calls this
