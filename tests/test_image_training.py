@@ -350,3 +350,69 @@ def test_image_flow_fit_on_device_matches_reference_run(monkeypatch):
         for k, v in sd_ref.items():
             s = max(v.abs().max().item(), 1e-3)
             assert (sd[k].cpu().double() - v.double()).abs().max().item() < 2e-3 * s, (graph, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,nvs,n", [(16, 1, 6), (48, 0, 5), (64, 2, 3), (7, 1, 2), (1, 0, 1), (32, 3, 2)])
+def test_affine_prep_kernels_match_the_torch_formulation(C, nvs, n, monkeypatch):
+    """usf_affine_prep_f32 / usf_affine_prep_bwd_f32 (one launch each for all blocks of a flow) against the batched torch
+    formulation of the same maps in fp64 on the CPU -- matrix, inverse, bias, log|det| and, from random cotangents on all
+    four, the gradients of L_raw, U_raw, bias_vector and the Householder vectors"""
+    import copy
+    from usflows_amd import image_training as it, transforms as T
+    g = torch.Generator().manual_seed(100 * C + nvs)
+    parts_list = []
+    for _ in range(n):
+        lu = T.LUTransform(C)
+        with torch.no_grad():
+            lu.L_raw.copy_(torch.eye(C) + 0.1 * torch.randn(C, C, generator=g).tril(-1))
+            sign = torch.where(torch.rand(C, generator=g) < 0.3, -1.0, 1.0)
+            lu.U_raw.copy_(torch.diag(sign * (0.75 + 0.5 * torch.rand(C, generator=g))) + 0.1 * torch.randn(C, C, generator=g).triu(1))
+            lu.bias_vector.copy_(torch.randn(C, generator=g))
+        parts = [lu]
+        if nvs:
+            hh = T.HouseholderTransform(C, nvs)
+            with torch.no_grad():
+                hh.vk_householder.copy_(torch.randn(nvs, C, generator=g))
+            parts.append(hh)
+        parts_list.append(parts)
+    sig = (("lu", C),) + ((("hh", C, nvs),) if nvs else ())
+    cot = [torch.randn(n, C, C, generator=g), torch.randn(n, C, C, generator=g), torch.randn(n, C, generator=g),
+           torch.randn(n, generator=g)]
+
+    def run(pl, device, dtype):
+        keys = [object() for _ in pl]
+        out = it._prep_group(keys, pl, sig, device)
+        loss = 0
+        for i, k in enumerate(keys):
+            M, Minv, b, ladj = out[id(k)]
+            loss = loss + (M * cot[0][i].to(device, dtype)).sum() + (Minv * cot[1][i].to(device, dtype)).sum() \
+                + (b * cot[2][i].to(device, dtype)).sum() + ladj * cot[3][i].to(device, dtype)
+        loss.backward()
+        return [tuple(t.detach().cpu().double() for t in out[id(k)]) for k in keys]
+
+    ref_pl = [[copy.deepcopy(m).double() for m in parts] for parts in parts_list]
+    monkeypatch.setattr(it, "affine_prep_kernels", False)
+    ref = run(ref_pl, torch.device("cpu"), torch.float64)
+    monkeypatch.setattr(it, "affine_prep_kernels", True)
+    dev_pl = [[copy.deepcopy(m).to(DEV) for m in parts] for parts in parts_list]
+    assert it._prep_group_device([object() for _ in dev_pl], dev_pl, sig, torch.device(DEV)) is not None
+    for parts in dev_pl:
+        for m in parts:
+            for p in m.parameters():
+                p.grad = None
+    got = run(dev_pl, torch.device(DEV), torch.float32)
+
+    def close(a, b, what, tol=2e-5):
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= tol * scale * max(C, 8) ** 0.5, (what, (a - b).abs().max().item(), scale)
+
+    for i in range(n):
+        for q, what in enumerate(("M", "Minv", "b", "ladj")):
+            close(got[i][q], ref[i][q], (what, i))
+        lu_d, lu_r = dev_pl[i][0], ref_pl[i][0]
+        close(lu_d.L_raw.grad.cpu().double(), lu_r.L_raw.grad, ("dL_raw", i), 1e-4)
+        close(lu_d.U_raw.grad.cpu().double(), lu_r.U_raw.grad, ("dU_raw", i), 1e-4)
+        close(lu_d.bias_vector.grad.cpu().double(), lu_r.bias_vector.grad, ("dbias", i), 1e-4)
+        if nvs:
+            close(dev_pl[i][1].vk_householder.grad.cpu().double(), ref_pl[i][1].vk_householder.grad, ("dvk", i), 1e-4)

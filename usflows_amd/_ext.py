@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 26
+USF_ABI_VERSION = 27
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -218,6 +218,10 @@ SYMBOLS = {
                                             C.c_int64, C.c_void_p]),
     "usf_pack_weights_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_grad_jobs_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_void_p]),
+    "usf_affine_prep_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp,
+                                      C.c_void_p]),
+    "usf_affine_prep_bwd_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp,
+                                          _fp, _fp, C.c_void_p]),
     "usf_matvec_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_double, _fp, _fp, C.c_void_p]),
 }
 
@@ -732,6 +736,39 @@ def gated_residual_bwd(dy, vg):
     dvg = torch.empty_like(vg)
     _direct("usf_gated_residual_bwd_f32", dy.data_ptr(), vg.data_ptr(), dvg.data_ptr(), B, CP, current_stream(dy.device))
     return dvg
+
+
+AFFINE_PREP_MAX_C = 64
+
+
+def affine_prep(Lr, Ur, bias, vk=None, w0=None):
+    """usf_affine_prep_f32 on stacked parameters -> (M, Minv [n,C,C], b [n,C], ladj [n], save [n,7,C,C])"""
+    n, Cc = int(Lr.shape[0]), int(Lr.shape[1])
+    nvs = 0 if vk is None else int(vk.shape[1])
+    dev = Lr.device
+    M = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
+    Minv = torch.empty_like(M)
+    b = torch.empty(n, Cc, dtype=torch.float32, device=dev)
+    ladj = torch.empty(n, dtype=torch.float32, device=dev)
+    save = torch.empty(n, 7, Cc, Cc, dtype=torch.float32, device=dev)
+    _direct("usf_affine_prep_f32", Lr.data_ptr(), Ur.data_ptr(), bias.data_ptr(), ptr(vk), ptr(w0), n, Cc, nvs, M.data_ptr(),
+            Minv.data_ptr(), b.data_ptr(), ladj.data_ptr(), save.data_ptr(), current_stream(dev))
+    return M, Minv, b, ladj, save
+
+
+def affine_prep_bwd(save, bias, vk, w0, dM, dMinv, db, dladj):
+    """usf_affine_prep_bwd_f32 -> (dL_raw, dU_raw [n,C,C], dbias [n,C], dvk [n,nvs,C] | None)"""
+    n, Cc = int(save.shape[0]), int(save.shape[2])
+    nvs = 0 if vk is None else int(vk.shape[1])
+    dev = save.device
+    dLr = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
+    dUr = torch.empty_like(dLr)
+    dbias = torch.empty(n, Cc, dtype=torch.float32, device=dev)
+    dvk = torch.empty(n, nvs, Cc, dtype=torch.float32, device=dev) if nvs else None
+    _direct("usf_affine_prep_bwd_f32", save.data_ptr(), bias.data_ptr(), ptr(vk), ptr(w0), dM.data_ptr(), dMinv.data_ptr(),
+            db.data_ptr(), dladj.data_ptr(), n, Cc, nvs, dLr.data_ptr(), dUr.data_ptr(), dbias.data_ptr(), ptr(dvk),
+            current_stream(dev))
+    return dLr, dUr, dbias, dvk
 
 
 def gather_cols(src, lds, dst, ldd, M, n, idx):

@@ -361,7 +361,92 @@ def _parts(bt):
     return parts, tuple(sig)
 
 
+class AffinePrep(torch.autograd.Function):
+    """(M, M^-1, b, log|det|) of n affine block transforms of equal structure -- LUTransform [+ HouseholderTransform] --
+    as ONE launch (usf_affine_prep_f32), and the gradients of their parameters as one more (usf_affine_prep_bwd_f32):
+    the formulas of ``_prep_group`` below and what autograd derives from them.  Inputs are the stacked parameters; the 4 n
+    outputs are handed out per block (views of the stacked results), so that the layers' gradients arrive per block and
+    are gathered by one ``stack`` per kind instead of a select-backward + add chain per use."""
+
+    @staticmethod
+    def forward(ctx, Lr, Ur, bias, vk, w0):
+        M, Minv, b, ladj, save = _ext.affine_prep(Lr, Ur, bias, vk, w0)
+        ctx.save_for_backward(save, bias, vk, w0)
+        n = Lr.shape[0]
+        ctx.n, ctx.C = n, Lr.shape[1]
+        return tuple(M.unbind(0)) + tuple(Minv.unbind(0)) + tuple(b.unbind(0)) + tuple(ladj.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        save, bias, vk, w0 = ctx.saved_tensors
+        n, C = ctx.n, ctx.C
+        dev = save.device
+
+        def gather(gs, shape):
+            if all(g is None for g in gs):
+                return _zeros((n,) + shape, dev)
+            z = _zeros(shape, dev)
+            return torch.stack([z if g is None else g for g in gs]).contiguous()
+
+        dM = gather(grads[0:n], (C, C))
+        dMinv = gather(grads[n:2 * n], (C, C))
+        db = gather(grads[2 * n:3 * n], (C,))
+        dl = gather(grads[3 * n:4 * n], ())
+        dLr, dUr, dbias, dvk = _ext.affine_prep_bwd(save, bias, vk, w0, dM, dMinv, db, dl)
+        return dLr, dUr, dbias, dvk, None
+
+
+_ZEROS = {}
+
+
+def _zeros(shape, device) -> torch.Tensor:
+    """a constant zero tensor of this shape (read-only: stands in for gradients that did not arrive)"""
+    key = (tuple(shape), str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.zeros(shape, dtype=torch.float32, device=device)      # (never fill a cache inside a stream capture)
+        z = _ZEROS[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return z
+
+
+affine_prep_kernels = True        # USFLOWS_AMD_AFFINE_PREP=0 / False: the batched torch formulation below
+
+
+def _prep_group_device(bts, parts_list, sig, device):
+    """the group's maps through usf_affine_prep_f32, or None when the structure is not the kernel's (one LUTransform,
+    optionally followed by one HouseholderTransform; C <= 64; fp32 parameters on a GPU)"""
+    import os
+    if not (affine_prep_kernels and os.environ.get("USFLOWS_AMD_AFFINE_PREP", "1") != "0"):
+        return None
+    if torch.device(device).type != "cuda" or tuple(k[0] for k in sig) not in (("lu",), ("lu", "hh")):
+        return None
+    C = sig[0][1]
+    if C > _ext.AFFINE_PREP_MAX_C or (len(sig) == 2 and (sig[1][1] != C or not 1 <= sig[1][2] <= 8)):
+        return None
+    lus = [p[0] for p in parts_list]
+    if any(t.dtype != torch.float32 for m in lus for t in (m.L_raw, m.U_raw, m.bias_vector)):
+        return None
+    _ext.load()
+    n = len(bts)
+    Lr = torch.stack([m.L_raw for m in lus])
+    Ur = torch.stack([m.U_raw for m in lus])
+    bias = torch.stack([m.bias_vector for m in lus])
+    vk = w0 = None
+    if len(sig) == 2:
+        hhs = [p[1] for p in parts_list]
+        if any(h.vk_householder.dtype != torch.float32 for h in hhs):
+            return None
+        vk = torch.stack([h.vk_householder for h in hhs])
+        w0 = torch.stack([h.w_0.detach() for h in hhs])
+    out = AffinePrep.apply(Lr, Ur, bias, vk, w0)
+    return {id(bt): (out[i], out[n + i], out[2 * n + i], out[3 * n + i]) for i, bt in enumerate(bts)}
+
+
 def _prep_group(bts, parts_list, sig, device):
+    dev_out = _prep_group_device(bts, parts_list, sig, device)
+    if dev_out is not None:
+        return dev_out
     n, C = len(bts), sig[0][1]
     eye = _eye(C, device)
     M = Minv = b = None
