@@ -677,19 +677,23 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
  * n transforms of equal structure: an LUTransform (transforms.py:1271-1320: L = tril(L_raw, -1) + I, U = triu(U_raw),
  * M_lu = L U, M_lu^-1 = U^-1 L^-1, log|det| = sum log|U_jj|), optionally followed by a HouseholderTransform of nvs vectors
  * (transforms.py:795-809: H = w_0 prod_k (I - 2 v_k v_k^T / v_k.v_k)) inside a SequentialAffineTransform (:1457-1476):
- *     M = M_lu H,   Minv = H^T M_lu^-1,   b = bias H          (nvs == 0: H = I; vk / w0 may be NULL)
- * All operands fp32, contiguous: L_raw, U_raw, w0, M, Minv [n, C, C]; bias, b [n, C]; vk [n, nvs, C]; ladj [n];
+ *     M = M_lu H,   Minv = H^T M_lu^-1,   b = bias H,   c = -Minv b   (nvs == 0: H = I; vk / w0 may be NULL)
+ * (c: the shift of the backward direction, x = Minv (y - b) = Minv y + c.)
+ * All operands fp32, contiguous: L_raw, U_raw, w0, M, Minv [n, C, C]; bias, b, c [n, C]; vk [n, nvs, C]; ladj [n];
  * save [n, 7, C, C] receives the factors the backward pass reads.  1 <= C <= 64, nvs <= 8.  One launch each.
- * usf_affine_prep_bwd_f32: from (dM, dMinv, db, dladj) -- zeros where an output was not used -- the gradients of the
+ * usf_affine_prep_bwd_f32: from the forward pass's Minv and b and (dM, dMinv, db, dc, dladj) -- zeros where an output was
+ * not used -- the gradients of the
  * parameters: dL_raw (strictly lower triangle, zeros elsewhere: the reference's gradient mask, transforms.py:1262-1268),
  * dU_raw (upper triangle), dbias [n, C], dvk [n, nvs, C].  What autograd derives from the reference's matrix() /
  * inverse_matrix() / bias() / log_abs_det_jacobian() chains, in two launches instead of some hundreds.
  */
 int usf_affine_prep_f32(const float* L_raw, const float* U_raw, const float* bias, const float* vk, const float* w0, int64_t n,
-                        int32_t C, int32_t nvs, float* M, float* Minv, float* b, float* ladj, float* save, usf_stream_t stream);
-int usf_affine_prep_bwd_f32(const float* save, const float* bias, const float* vk, const float* w0, const float* dM,
-                            const float* dMinv, const float* db, const float* dladj, int64_t n, int32_t C, int32_t nvs,
-                            float* dL_raw, float* dU_raw, float* dbias, float* dvk, usf_stream_t stream);
+                        int32_t C, int32_t nvs, float* M, float* Minv, float* b, float* c, float* ladj, float* save,
+                        usf_stream_t stream);
+int usf_affine_prep_bwd_f32(const float* save, const float* bias, const float* vk, const float* w0, const float* Minv,
+                            const float* b, const float* dM, const float* dMinv, const float* db, const float* dc,
+                            const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dL_raw, float* dU_raw, float* dbias,
+                            float* dvk, usf_stream_t stream);
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;

@@ -378,18 +378,30 @@ def test_affine_prep_kernels_match_the_torch_formulation(C, nvs, n, monkeypatch)
         parts_list.append(parts)
     sig = (("lu", C),) + ((("hh", C, nvs),) if nvs else ())
     cot = [torch.randn(n, C, C, generator=g), torch.randn(n, C, C, generator=g), torch.randn(n, C, generator=g),
-           torch.randn(n, generator=g)]
+           torch.randn(n, generator=g), torch.randn(n, C, generator=g)]
 
     def run(pl, device, dtype):
         keys = [object() for _ in pl]
         out = it._prep_group(keys, pl, sig, device)
         loss = 0
+        res = []
         for i, k in enumerate(keys):
-            M, Minv, b, ladj = out[id(k)]
+            o = out[id(k)]
+            M, Minv, b, ladj = o[0], o[1], o[2], o[3]
+            c = o[4] if len(o) > 4 else -(Minv @ b)              # the kernel also hands out c = -M^-1 b
             loss = loss + (M * cot[0][i].to(device, dtype)).sum() + (Minv * cot[1][i].to(device, dtype)).sum() \
-                + (b * cot[2][i].to(device, dtype)).sum() + ladj * cot[3][i].to(device, dtype)
+                + (b * cot[2][i].to(device, dtype)).sum() + ladj * cot[3][i].to(device, dtype) \
+                + (c * cot[4][i].to(device, dtype)).sum()
+            if len(o) <= 5:
+                loss = loss + ladj * cot[3][i].to(device, dtype)   # (the device path adds this through the stacked log|det|)
+            res.append(tuple(t.detach().cpu().double() for t in (M, Minv, b, ladj, c)))
+        o0 = out[id(keys[0])]
+        if len(o0) > 5:
+            stack = it.prep_stack(o0[5][0])
+            assert stack.shape == (len(keys),) and o0[5][1] == 0
+            loss = loss + (stack * cot[3].to(device, dtype)).sum()
         loss.backward()
-        return [tuple(t.detach().cpu().double() for t in out[id(k)]) for k in keys]
+        return res
 
     ref_pl = [[copy.deepcopy(m).double() for m in parts] for parts in parts_list]
     monkeypatch.setattr(it, "affine_prep_kernels", False)
@@ -408,7 +420,7 @@ def test_affine_prep_kernels_match_the_torch_formulation(C, nvs, n, monkeypatch)
         assert (a - b).abs().max().item() <= tol * scale * max(C, 8) ** 0.5, (what, (a - b).abs().max().item(), scale)
 
     for i in range(n):
-        for q, what in enumerate(("M", "Minv", "b", "ladj")):
+        for q, what in enumerate(("M", "Minv", "b", "ladj", "c")):
             close(got[i][q], ref[i][q], (what, i))
         lu_d, lu_r = dev_pl[i][0], ref_pl[i][0]
         close(lu_d.L_raw.grad.cpu().double(), lu_r.L_raw.grad, ("dL_raw", i), 1e-4)

@@ -218,10 +218,10 @@ SYMBOLS = {
                                             C.c_int64, C.c_void_p]),
     "usf_pack_weights_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_grad_jobs_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_void_p]),
-    "usf_affine_prep_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp,
+    "usf_affine_prep_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                       C.c_void_p]),
-    "usf_affine_prep_bwd_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp,
-                                          _fp, _fp, C.c_void_p]),
+    "usf_affine_prep_bwd_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32,
+                                          C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]),
     "usf_matvec_f64": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, _fp, C.c_double, _fp, _fp, C.c_void_p]),
 }
 
@@ -742,21 +742,22 @@ AFFINE_PREP_MAX_C = 64
 
 
 def affine_prep(Lr, Ur, bias, vk=None, w0=None):
-    """usf_affine_prep_f32 on stacked parameters -> (M, Minv [n,C,C], b [n,C], ladj [n], save [n,7,C,C])"""
+    """usf_affine_prep_f32 on stacked parameters -> (M, Minv [n,C,C], b, c [n,C], ladj [n], save [n,7,C,C])"""
     n, Cc = int(Lr.shape[0]), int(Lr.shape[1])
     nvs = 0 if vk is None else int(vk.shape[1])
     dev = Lr.device
     M = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
     Minv = torch.empty_like(M)
     b = torch.empty(n, Cc, dtype=torch.float32, device=dev)
+    c = torch.empty_like(b)
     ladj = torch.empty(n, dtype=torch.float32, device=dev)
     save = torch.empty(n, 7, Cc, Cc, dtype=torch.float32, device=dev)
     _direct("usf_affine_prep_f32", Lr.data_ptr(), Ur.data_ptr(), bias.data_ptr(), ptr(vk), ptr(w0), n, Cc, nvs, M.data_ptr(),
-            Minv.data_ptr(), b.data_ptr(), ladj.data_ptr(), save.data_ptr(), current_stream(dev))
-    return M, Minv, b, ladj, save
+            Minv.data_ptr(), b.data_ptr(), c.data_ptr(), ladj.data_ptr(), save.data_ptr(), current_stream(dev))
+    return M, Minv, b, c, ladj, save
 
 
-def affine_prep_bwd(save, bias, vk, w0, dM, dMinv, db, dladj):
+def affine_prep_bwd(save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dladj):
     """usf_affine_prep_bwd_f32 -> (dL_raw, dU_raw [n,C,C], dbias [n,C], dvk [n,nvs,C] | None)"""
     n, Cc = int(save.shape[0]), int(save.shape[2])
     nvs = 0 if vk is None else int(vk.shape[1])
@@ -765,9 +766,9 @@ def affine_prep_bwd(save, bias, vk, w0, dM, dMinv, db, dladj):
     dUr = torch.empty_like(dLr)
     dbias = torch.empty(n, Cc, dtype=torch.float32, device=dev)
     dvk = torch.empty(n, nvs, Cc, dtype=torch.float32, device=dev) if nvs else None
-    _direct("usf_affine_prep_bwd_f32", save.data_ptr(), bias.data_ptr(), ptr(vk), ptr(w0), dM.data_ptr(), dMinv.data_ptr(),
-            db.data_ptr(), dladj.data_ptr(), n, Cc, nvs, dLr.data_ptr(), dUr.data_ptr(), dbias.data_ptr(), ptr(dvk),
-            current_stream(dev))
+    _direct("usf_affine_prep_bwd_f32", save.data_ptr(), bias.data_ptr(), ptr(vk), ptr(w0), Minv.data_ptr(), b.data_ptr(),
+            dM.data_ptr(), dMinv.data_ptr(), db.data_ptr(), dc.data_ptr(), dladj.data_ptr(), n, Cc, nvs, dLr.data_ptr(),
+            dUr.data_ptr(), dbias.data_ptr(), ptr(dvk), current_stream(dev))
     return dLr, dUr, dbias, dvk
 
 

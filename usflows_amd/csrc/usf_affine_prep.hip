@@ -10,8 +10,9 @@
 // was ~340 launches of ~4 us of which ~200 were these parameter chains.  Here: ONE launch forward and ONE backward for all
 // blocks of equal structure -- a 256-thread block per transform, every matrix in LDS, fp32 (as the reference computes).
 //
-//   affine_prep_kernel      (L_raw, U_raw, bias, v, w_0) -> (M, M^-1, b, log|det|) + the factors the backward needs
-//   affine_prep_bwd_kernel  (dM, dM^-1, db, dlog|det|)   -> (dL_raw, dU_raw, dbias, dv):
+//   affine_prep_kernel      (L_raw, U_raw, bias, v, w_0) -> (M, M^-1, b, c = -M^-1 b, log|det|) + the factors the backward needs
+//   affine_prep_bwd_kernel  (dM, dM^-1, db, dc, dlog|det|) -> (dL_raw, dU_raw, dbias, dv):
+//       c = -M^-1 b:       dM^-1 -= dc (x) b,         db -= M^-T dc
 //       M = M_lu H:        dM_lu = dM H^T,            dH  = M_lu^T dM
 //       M^-1 = H^T M_lu^-1: dM_lu^-1 = H dM^-1,       dH += M_lu^-1 (dM^-1)^T
 //       b = b_lu H:        db_lu = H db,              dH += b_lu (x) db
@@ -31,13 +32,14 @@ constexpr int AP_SAVE = 7;       // matrices kept for the backward pass: L, U, L
 
 struct APArgs {
   const float* Lr; const float* Ur; const float* bias; const float* vk; const float* w0;
-  float* M; float* Minv; float* b; float* ladj; float* save;
+  float* M; float* Minv; float* b; float* cvec; float* ladj; float* save;
   int C, nvs;
 };
 
 struct APBArgs {
   const float* save; const float* bias; const float* vk; const float* w0;
-  const float* dM; const float* dMinv; const float* db; const float* dladj;
+  const float* Minv; const float* b;            // the forward pass's outputs (for the gradient through c = -Minv b)
+  const float* dM; const float* dMinv; const float* db; const float* dc; const float* dladj;
   float* dLr; float* dUr; float* dbias; float* dvk;
   int C, nvs;
 };
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_kernel(const APArgs a) {
       float s = 0.f;
       for (int i = 0; i < C; ++i) s = fmaf(a.bias[blk * C + i], sH[i * ld + tid], s);
       a.b[blk * C + tid] = s;
+      sv[tid] = s;
     }
   } else {
     for (int idx = tid; idx < C * C; idx += AP_NT) {
@@ -152,7 +155,24 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_kernel(const APArgs a) {
       Mi[idx] = sMilu[i * ld + j];
       sH[i * ld + j] = i == j ? 1.f : 0.f;
     }
-    if (tid < C) a.b[blk * C + tid] = a.bias[blk * C + tid];
+    if (tid < C) {
+      const float s = a.bias[blk * C + tid];
+      a.b[blk * C + tid] = s;
+      sv[tid] = s;
+    }
+  }
+  // c = -M^-1 b = -H^T (M_lu^-1 b): the shift of the backward direction y = M^-1 x + c (sH is the identity without a factor)
+  __syncthreads();
+  if (tid < C) {
+    float t = 0.f;
+    for (int j = 0; j < C; ++j) t = fmaf(sMilu[tid * ld + j], sv[j], t);
+    stmp[tid] = t;
+  }
+  __syncthreads();
+  if (tid < C) {
+    float t = 0.f;
+    for (int i = 0; i < C; ++i) t = fmaf(sH[i * ld + tid], stmp[i], t);
+    a.cvec[blk * C + tid] = -t;
   }
   float* sv_out = a.save + blk * AP_SAVE * C * C;
   for (int m = 0; m < AP_SAVE; ++m) {
@@ -183,18 +203,37 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
   const float* gMlu = sav + 4 * CC;
   const float* gMilu = sav + 5 * CC;
   const float* gH = sav + 6 * CC;
+  float* sdMi = stmp2 + AP_MAXC;   // [C][ld]  dM^-1 with the contribution of dc folded in
+  float* sdb = sdMi + msz;         // [C]      db likewise
   const float* dM = a.dM + blk * CC;
-  const float* dMi = a.dMinv + blk * CC;
-  const float* db = a.db + blk * C;
+  // c = -M^-1 b:  dM^-1 -= dc (x) b,  db -= (M^-1)^T dc
+  {
+    const float* gMi = a.Minv + blk * CC;
+    const float* gb = a.b + blk * C;
+    const float* dc = a.dc + blk * C;
+    for (int idx = tid; idx < CC; idx += AP_NT) {
+      const int i = idx / C, j = idx - i * C;
+      sdMi[i * ld + j] = a.dMinv[blk * CC + idx] - dc[i] * gb[j];
+    }
+    if (tid < C) {
+      float t = 0.f;
+      for (int i = 0; i < C; ++i) t = fmaf(gMi[i * C + tid], dc[i], t);
+      sdb[tid] = a.db[blk * C + tid] - t;
+    }
+  }
+  __syncthreads();
+  const float* dMi = sdMi;
+  const float* db = sdb;
+  const int ldi = ld;
   const float* pMlu = dM;          // dM_lu / dM_lu^-1: the incoming gradients themselves without a Householder factor
   const float* pMilu = dMi;
-  int ldg = C;
+  int ldg = C, ldgi = ldi;
   if (a.nvs > 0) {
     ap_mm<false, true, 0>(dM, C, gH, C, sdMlu, ld, C, 1.f);          // dM H^T
-    ap_mm<false, false, 0>(gH, C, dMi, C, sdMilu, ld, C, 1.f);       // H dM^-1
+    ap_mm<false, false, 0>(gH, C, dMi, ldi, sdMilu, ld, C, 1.f);     // H dM^-1
     ap_mm<true, false, 0>(gMlu, C, dM, C, sdH, ld, C, 1.f);          // M_lu^T dM
     __syncthreads();
-    ap_mm<false, true, 1>(gMilu, C, dMi, C, sdH, ld, C, 1.f);        // + M_lu^-1 (dM^-1)^T
+    ap_mm<false, true, 1>(gMilu, C, dMi, ldi, sdH, ld, C, 1.f);      // + M_lu^-1 (dM^-1)^T
     __syncthreads();
     for (int idx = tid; idx < CC; idx += AP_NT) {
       const int i = idx / C, j = idx - i * C;
@@ -205,7 +244,7 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
       for (int j = 0; j < C; ++j) s = fmaf(gH[tid * C + j], db[j], s);
       a.dbias[blk * C + tid] = s;                                    // H db
     }
-    pMlu = sdMlu; pMilu = sdMilu; ldg = ld;
+    pMlu = sdMlu; pMilu = sdMilu; ldg = ld; ldgi = ld;
   } else if (tid < C) {
     a.dbias[blk * C + tid] = db[tid];
   }
@@ -213,12 +252,12 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
   // ---- LU factors
   ap_mm<false, true, 0>(pMlu, ldg, gU, C, sdL, ld, C, 1.f);           // dL = dM_lu U^T
   ap_mm<true, false, 0>(gL, C, pMlu, ldg, sdU, ld, C, 1.f);           // dU = L^T dM_lu
-  ap_mm<false, true, 0>(pMilu, ldg, gLi, C, sT1, ld, C, 1.f);         // T1 = dM_lu^-1 L^-T          (= dU^-1)
+  ap_mm<false, true, 0>(pMilu, ldgi, gLi, C, sT1, ld, C, 1.f);        // T1 = dM_lu^-1 L^-T          (= dU^-1)
   __syncthreads();
   ap_mm<true, false, 0>(gUi, C, sT1, ld, sT2, ld, C, 1.f);            // T2 = U^-T T1
   __syncthreads();
   ap_mm<false, true, 1>(sT2, ld, gUi, C, sdU, ld, C, -1.f);           // dU -= T2 U^-T
-  ap_mm<true, false, 0>(gUi, C, pMilu, ldg, sT1, ld, C, 1.f);         // T1 = U^-T dM_lu^-1          (= dL^-1)
+  ap_mm<true, false, 0>(gUi, C, pMilu, ldgi, sT1, ld, C, 1.f);        // T1 = U^-T dM_lu^-1          (= dL^-1)
   __syncthreads();
   ap_mm<true, false, 0>(gLi, C, sT1, ld, sT2, ld, C, 1.f);            // T2 = L^-T T1
   __syncthreads();
@@ -270,7 +309,7 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
   }
 }
 
-static size_t ap_lds_bytes(int C) { return (size_t)(AP_SAVE * C * (C + 1) + 3 * AP_MAXC) * sizeof(float); }
+static size_t ap_lds_bytes(int C) { return (size_t)((AP_SAVE + 1) * C * (C + 1) + 4 * AP_MAXC) * sizeof(float); }
 
 static int ap_check(const char* what, int64_t n, int32_t C, int32_t nvs) {
   if (n < 0 || C < 1 || C > AP_MAXC || nvs < 0 || nvs > 8) {
@@ -281,10 +320,10 @@ static int ap_check(const char* what, int64_t n, int32_t C, int32_t nvs) {
 }
 
 int affine_prep(const float* Lr, const float* Ur, const float* bias, const float* vk, const float* w0, int64_t n, int32_t C,
-                int32_t nvs, float* M, float* Minv, float* b, float* ladj, float* save, hipStream_t stream) {
+                int32_t nvs, float* M, float* Minv, float* b, float* cvec, float* ladj, float* save, hipStream_t stream) {
   if (ap_check("usf_affine_prep_f32", n, C, nvs)) return -1;
   if (n == 0) return 0;
-  if (!Lr || !Ur || !bias || !M || !Minv || !b || !ladj || !save || (nvs > 0 && (!vk || !w0))) {
+  if (!Lr || !Ur || !bias || !M || !Minv || !b || !cvec || !ladj || !save || (nvs > 0 && (!vk || !w0))) {
     set_error("usf_affine_prep_f32: bad arguments");
     return -1;
   }
@@ -299,17 +338,17 @@ int affine_prep(const float* Lr, const float* Ur, const float* bias, const float
     }
     attr_done[dev] = true;
   }
-  const APArgs a{Lr, Ur, bias, vk, w0, M, Minv, b, ladj, save, C, nvs};
+  const APArgs a{Lr, Ur, bias, vk, w0, M, Minv, b, cvec, ladj, save, C, nvs};
   affine_prep_kernel<<<(unsigned)n, AP_NT, ap_lds_bytes(C), stream>>>(a);
   return check_launch("usf_affine_prep_f32");
 }
 
-int affine_prep_bwd(const float* save, const float* bias, const float* vk, const float* w0, const float* dM, const float* dMinv,
-                    const float* db, const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dLr, float* dUr, float* dbias,
+int affine_prep_bwd(const float* save, const float* bias, const float* vk, const float* w0, const float* Minv, const float* b,
+                    const float* dM, const float* dMinv, const float* db, const float* dc, const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dLr, float* dUr, float* dbias,
                     float* dvk, hipStream_t stream) {
   if (ap_check("usf_affine_prep_bwd_f32", n, C, nvs)) return -1;
   if (n == 0) return 0;
-  if (!save || !bias || !dM || !dMinv || !db || !dladj || !dLr || !dUr || !dbias || (nvs > 0 && (!vk || !w0 || !dvk))) {
+  if (!save || !bias || !Minv || !b || !dM || !dMinv || !db || !dc || !dladj || !dLr || !dUr || !dbias || (nvs > 0 && (!vk || !w0 || !dvk))) {
     set_error("usf_affine_prep_bwd_f32: bad arguments");
     return -1;
   }
@@ -324,7 +363,7 @@ int affine_prep_bwd(const float* save, const float* bias, const float* vk, const
     }
     attr_done[dev] = true;
   }
-  const APBArgs a{save, bias, vk, w0, dM, dMinv, db, dladj, dLr, dUr, dbias, dvk, C, nvs};
+  const APBArgs a{save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dladj, dLr, dUr, dbias, dvk, C, nvs};
   affine_prep_bwd_kernel<<<(unsigned)n, AP_NT, ap_lds_bytes(C), stream>>>(a);
   return check_launch("usf_affine_prep_bwd_f32");
 }

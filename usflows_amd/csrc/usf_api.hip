@@ -94,10 +94,10 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
           hipStream_t stream);
 int affine_prep(const float* Lr, const float* Ur, const float* bias, const float* vk, const float* w0, int64_t n, int32_t C,
-                int32_t nvs, float* M, float* Minv, float* b, float* ladj, float* save, hipStream_t stream);
-int affine_prep_bwd(const float* save, const float* bias, const float* vk, const float* w0, const float* dM, const float* dMinv,
-                    const float* db, const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dLr, float* dUr, float* dbias,
-                    float* dvk, hipStream_t stream);
+                int32_t nvs, float* M, float* Minv, float* b, float* cvec, float* ladj, float* save, hipStream_t stream);
+int affine_prep_bwd(const float* save, const float* bias, const float* vk, const float* w0, const float* Minv, const float* b,
+                    const float* dM, const float* dMinv, const float* db, const float* dc, const float* dladj, int64_t n,
+                    int32_t C, int32_t nvs, float* dLr, float* dUr, float* dbias, float* dvk, hipStream_t stream);
 int grad_jobs(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
@@ -309,13 +309,15 @@ int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out
   return usf::colsum(Y, ldy, M, N, out, alpha, beta, workspace, workspace_floats, (hipStream_t)stream);
 }
 int usf_affine_prep_f32(const float* L_raw, const float* U_raw, const float* bias, const float* vk, const float* w0, int64_t n,
-                        int32_t C, int32_t nvs, float* M, float* Minv, float* b, float* ladj, float* save, usf_stream_t stream) {
-  return usf::affine_prep(L_raw, U_raw, bias, vk, w0, n, C, nvs, M, Minv, b, ladj, save, (hipStream_t)stream);
+                        int32_t C, int32_t nvs, float* M, float* Minv, float* b, float* c, float* ladj, float* save,
+                        usf_stream_t stream) {
+  return usf::affine_prep(L_raw, U_raw, bias, vk, w0, n, C, nvs, M, Minv, b, c, ladj, save, (hipStream_t)stream);
 }
-int usf_affine_prep_bwd_f32(const float* save, const float* bias, const float* vk, const float* w0, const float* dM,
-                            const float* dMinv, const float* db, const float* dladj, int64_t n, int32_t C, int32_t nvs,
-                            float* dL_raw, float* dU_raw, float* dbias, float* dvk, usf_stream_t stream) {
-  return usf::affine_prep_bwd(save, bias, vk, w0, dM, dMinv, db, dladj, n, C, nvs, dL_raw, dU_raw, dbias, dvk,
+int usf_affine_prep_bwd_f32(const float* save, const float* bias, const float* vk, const float* w0, const float* Minv,
+                            const float* b, const float* dM, const float* dMinv, const float* db, const float* dc,
+                            const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dL_raw, float* dU_raw, float* dbias,
+                            float* dvk, usf_stream_t stream) {
+  return usf::affine_prep_bwd(save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dladj, n, C, nvs, dL_raw, dU_raw, dbias, dvk,
                               (hipStream_t)stream);
 }
 int usf_grad_jobs_f32(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream) {

@@ -276,12 +276,13 @@ class Flow(torch.nn.Module):
             from .image_training import batched_affine_prep
             prep = batched_affine_prep(self.layers, x.device)
         with prep:
-            log_det = torch.zeros(x.shape[0], device=x.device)     # (created on the device: a pageable host copy would synchronise)
+            ld = _LogDetSum()
             seq = list(reversed(self.layers))
+            batched = not isinstance(prep, contextlib.nullcontext)
             k = 0
             while k < len(seq):
                 layer = seq[k]
-                run = self._train_affine_run(seq, k, x) if not isinstance(prep, contextlib.nullcontext) else None
+                run = self._train_affine_run(seq, k, x) if batched else None
                 if run is not None:
                     # a run of consecutive 1 x 1-convolution affine layers in training: ONE differentiable channel-affine
                     # pass on the composed map (the C x C compositions are torch ops on the batched prep's tensors)
@@ -289,19 +290,21 @@ class Flow(torch.nn.Module):
                     from .image_training import ChannelAffine
                     y = ChannelAffine.apply(x, A, cvec, False)
                     for l2 in seq[k:k1]:
-                        log_det = log_det - l2.log_abs_det_jacobian(None, None)
+                        if not ld.take_affine(l2):
+                            ld.sub(l2.log_abs_det_jacobian(None, None))
                     x, k = y, k1
                     continue
                 if context is not None:
                     y = layer.backward(x, context=context)
-                    log_det = log_det - layer.log_abs_det_jacobian(y, x, context=context)
+                    ld.sub(layer.log_abs_det_jacobian(y, x, context=context))
                 else:
                     y = layer.backward(x)
-                    log_det = log_det - layer.log_abs_det_jacobian(y, x)
+                    if not (batched and ld.take_affine(layer)):
+                        ld.sub(layer.log_abs_det_jacobian(y, x))
                 x = y
                 k += 1
             lp = self._base_log_prob_layer_loop(y)
-            return (self.base_distribution.log_prob(y) if lp is None else lp) + log_det
+            return ld.add_to(self.base_distribution.log_prob(y) if lp is None else lp)
 
     def _train_affine_run(self, seq, k, x):
         """(end index, A, c) when seq[k:] starts with >= 2 affine layers whose backward is a device channel-affine pass in
@@ -321,8 +324,9 @@ class Flow(torch.nn.Module):
             pr = current_prep(blk.block_transform)
             if pr is None:
                 break
-            M, Minv, b, _ = pr
-            Ak, ck = (M, b) if inv else (Minv, -(Minv @ b))        # InverseTransform(block).backward == block.forward
+            M, Minv, b = pr[0], pr[1], pr[2]
+            c = pr[4] if len(pr) > 4 else None                     # -Minv b, from the prep kernel
+            Ak, ck = (M, b) if inv else (Minv, c if c is not None else -(Minv @ b))   # InverseTransform(block).backward == block.forward
             A, cvec = (Ak, ck) if A is None else (Ak @ A, Ak @ cvec + ck)
             j += 1
         return (j, A, cvec) if j - k >= 2 else None
@@ -986,6 +990,62 @@ def _ladj_is_parameter_only(layer) -> bool:
     if isinstance(layer, BlockAffineTransform):
         return isinstance(layer.block_transform, (LUTransform, HouseholderTransform, SequentialAffineTransform))
     return type(layer) in (ScaleTransform, MaskedCoupling)
+
+
+class _LogDetSum:
+    """log_det = - sum over the layers of log|det J| (flows.py:236-245), collected lazily in training.  The reference subtracts
+    every layer's term from a [B] tensor -- three launches per layer and as many in the backward pass, although most terms
+    are parameter-only scalars (additive couplings contribute the number 0.0).  Here numbers are summed on the host,
+    scalars (0-dim tensors) are stacked and reduced once, and the affine blocks covered by the batched prep kernel enter as ONE
+    weighted sum over its stacked log-determinants; only per-sample terms are added as tensors."""
+
+    def __init__(self):
+        self.const = 0.0
+        self.scalars = []        # (0-dim tensor, weight)
+        self.groups = {}         # prep group -> weights per row
+        self.vec = None
+
+    def sub(self, t) -> None:
+        if isinstance(t, (int, float)):
+            self.const -= float(t)
+        elif torch.is_tensor(t) and t.dim() == 0:
+            self.scalars.append((t, -1.0))
+        else:
+            self.vec = -t if self.vec is None else self.vec - t
+
+    def take_affine(self, layer) -> bool:
+        """a BlockAffineTransform (or its InverseTransform) whose maps come from the prep kernel: weight -/+ n_blocks on its
+        row of the stacked log-determinants (transforms.py:1017-1029: one C x C block per position)"""
+        from .transforms import BlockAffineTransform, InverseTransform
+        from .image_training import current_prep
+        inv = isinstance(layer, InverseTransform)
+        blk = layer.transform if inv else layer
+        if not isinstance(blk, BlockAffineTransform):
+            return False
+        pr = current_prep(blk.block_transform)
+        if pr is None or len(pr) < 6 or pr[5] is None:
+            return False
+        group, row = pr[5]
+        w = self.groups.setdefault(group, [0.0] * len(group[1]))
+        w[row] += float(blk.n_blocks) if inv else -float(blk.n_blocks)
+        return True
+
+    def add_to(self, lp: torch.Tensor) -> torch.Tensor:
+        from .image_training import coef_tensor, prep_stack
+        total = None
+        for group, w in self.groups.items():
+            term = (prep_stack(group) * coef_tensor(w, lp.device)).sum()
+            total = term if total is None else total + term
+        if self.scalars:
+            term = (torch.stack([t for t, _ in self.scalars]) * coef_tensor([w for _, w in self.scalars], lp.device)).sum()
+            total = term if total is None else total + term
+        if total is not None:
+            lp = lp + total
+        if self.vec is not None:
+            lp = lp + self.vec
+        if self.const != 0.0:
+            lp = lp + self.const
+        return lp
 
 
 class _unvalidated:

@@ -325,10 +325,12 @@ def needs_grad(module, *tensors) -> bool:
 # ``batched_affine_prep`` the same maps are evaluated ONCE per log_prob call for all blocks of equal structure as [n, C, C]
 # stacks (same formulas, torch autograd differentiates them); the layers pick their (M, M^-1, b, log|det|) from the stack.
 _PREP = None
+_PREP_STACKS = {}       # group -> stacked log|det| [n] of the current pass (device prep only)
 
 
 def current_prep(block_transform):
-    """(M, Minv, b, ladj) of this block transform inside ``batched_affine_prep``; None outside or when not covered"""
+    """(M, Minv, b, ladj[, c = -Minv b, (group, row)]) of this block transform inside ``batched_affine_prep``; None outside
+    or when not covered"""
     return None if _PREP is None else _PREP.get(id(block_transform))
 
 
@@ -370,15 +372,18 @@ class AffinePrep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Lr, Ur, bias, vk, w0):
-        M, Minv, b, ladj, save = _ext.affine_prep(Lr, Ur, bias, vk, w0)
-        ctx.save_for_backward(save, bias, vk, w0)
+        M, Minv, b, c, ladj, save = _ext.affine_prep(Lr, Ur, bias, vk, w0)
+        ctx.save_for_backward(save, bias, vk, w0, Minv, b)
         n = Lr.shape[0]
         ctx.n, ctx.C = n, Lr.shape[1]
-        return tuple(M.unbind(0)) + tuple(Minv.unbind(0)) + tuple(b.unbind(0)) + tuple(ladj.unbind(0))
+        # per block: M, M^-1, b, c = -M^-1 b, log|det|; and once more the stacked log|det| (the flow's total log-det is one
+        # weighted sum over it: Flow._layer_loop_log_prob)
+        return tuple(M.unbind(0)) + tuple(Minv.unbind(0)) + tuple(b.unbind(0)) + tuple(c.unbind(0)) + tuple(ladj.unbind(0)) \
+            + (ladj.view(n),)
 
     @staticmethod
     def backward(ctx, *grads):
-        save, bias, vk, w0 = ctx.saved_tensors
+        save, bias, vk, w0, Minv, b = ctx.saved_tensors
         n, C = ctx.n, ctx.C
         dev = save.device
 
@@ -391,8 +396,15 @@ class AffinePrep(torch.autograd.Function):
         dM = gather(grads[0:n], (C, C))
         dMinv = gather(grads[n:2 * n], (C, C))
         db = gather(grads[2 * n:3 * n], (C,))
-        dl = gather(grads[3 * n:4 * n], ())
-        dLr, dUr, dbias, dvk = _ext.affine_prep_bwd(save, bias, vk, w0, dM, dMinv, db, dl)
+        dc = gather(grads[3 * n:4 * n], (C,))
+        dl_each, dl_all = grads[4 * n:5 * n], grads[5 * n]
+        if dl_all is not None and all(g is None for g in dl_each):
+            dl = dl_all.contiguous()
+        else:
+            dl = gather(dl_each, ())
+            if dl_all is not None:
+                dl = dl + dl_all
+        dLr, dUr, dbias, dvk = _ext.affine_prep_bwd(save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dl)
         return dLr, dUr, dbias, dvk, None
 
 
@@ -408,6 +420,24 @@ def _zeros(shape, device) -> torch.Tensor:
             return torch.zeros(shape, dtype=torch.float32, device=device)      # (never fill a cache inside a stream capture)
         z = _ZEROS[key] = torch.zeros(shape, dtype=torch.float32, device=device)
     return z
+
+
+_COEFS = {}
+
+
+def coef_tensor(values, device) -> torch.Tensor:
+    """a constant fp32 vector with these values on the device, uploaded once (the log-det weights of a flow's layers)"""
+    key = (tuple(values), str(device))
+    t = _COEFS.get(key)
+    if t is None:
+        t = torch.tensor(list(values), dtype=torch.float32, device=device)
+        if not (torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _COEFS[key] = t
+    return t
+
+
+def prep_stack(group):
+    return _PREP_STACKS.get(group)
 
 
 affine_prep_kernels = True        # USFLOWS_AMD_AFFINE_PREP=0 / False: the batched torch formulation below
@@ -440,7 +470,10 @@ def _prep_group_device(bts, parts_list, sig, device):
         vk = torch.stack([h.vk_householder for h in hhs])
         w0 = torch.stack([h.w_0.detach() for h in hhs])
     out = AffinePrep.apply(Lr, Ur, bias, vk, w0)
-    return {id(bt): (out[i], out[n + i], out[2 * n + i], out[3 * n + i]) for i, bt in enumerate(bts)}
+    key = (sig, tuple(id(bt) for bt in bts))
+    _PREP_STACKS[key] = out[5 * n]
+    # (M, M^-1, b, log|det|, c = -M^-1 b, (group, row) of the block in the stacked log|det|)
+    return {id(bt): (out[i], out[n + i], out[2 * n + i], out[4 * n + i], out[3 * n + i], (key, i)) for i, bt in enumerate(bts)}
 
 
 def _prep_group(bts, parts_list, sig, device):
@@ -505,6 +538,8 @@ class batched_affine_prep:
                 g[0][id(bt)] = bt
                 g[1].append(parts)
         prep = {}
+        self.prev_stacks = dict(_PREP_STACKS)
+        _PREP_STACKS.clear()
         for sig, (bts, parts_list) in groups.items():
             prep.update(_prep_group(list(bts.values()), parts_list, sig, self.device))
         _PREP = prep
@@ -513,4 +548,6 @@ class batched_affine_prep:
     def __exit__(self, *exc):
         global _PREP
         _PREP = self.prev
+        _PREP_STACKS.clear()
+        _PREP_STACKS.update(self.prev_stacks)
         return False
