@@ -884,12 +884,11 @@ class Flow(torch.nn.Module):
             self.__dict__["_fit_stream"] = fresh
         if dev is not None and dev.type == "cuda":
             # the broken capture never reached its epilogue: torch's default generator of the device still believes it is
-            # being captured ("Offset increment outside graph capture" at the next random draw).  An empty capture that
-            # does end runs prologue and epilogue and leaves the generator in its normal state.
+            # being captured ("Offset increment outside graph capture" at the next random draw).  A clone of its state
+            # (same seed and offset) is a fresh state object that is not marked as capturing: the generator moves to it.
             try:
-                with torch.cuda.graph(torch.cuda.CUDAGraph()):
-                    torch.zeros(1, device=dev)
-                torch.cuda.synchronize(dev)
+                gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+                gen.graphsafe_set_state(gen.clone_state())
             except Exception:           # noqa: BLE001
                 pass
         eng = getattr(self, "_engine_obj", None)
