@@ -249,6 +249,11 @@ if want("train"):
             j["config"]["training_path"] = "composite torch ops (USFLOWS_AMD_TRAIN=composite)"
             lines.append(json.dumps(j))
     open(os.path.join(out, f"{tag}_train_bench.jsonl"), "w").write("\n".join(lines) + "\n")
+    # Flow.fit itself at the reference's batch sizes (the step replayed as a hipGraph): tools/fit_small_batch.py
+    with open(os.path.join(out, f"{tag}_train_small_batch.txt"), "w") as f:
+        for bsz, steps in (("32", "60"), ("256", "30")):
+            r = run(["python3", "tools/fit_small_batch.py", bsz, steps])
+            f.write("\n".join(l for l in r.stdout.splitlines() if l.startswith("Flow.fit")) + "\n")
     d = os.path.join(out, "ktrace_train")
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--mode",
          "train", "--steps", "5", "--warmup", "2"])
