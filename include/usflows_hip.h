@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 27
+#define USF_ABI_VERSION 28
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -588,6 +588,10 @@ typedef struct usf_pack_job {
 } usf_pack_job;
 int usf_pack_weights_f32(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols,
                          usf_stream_t stream);
+/* The same for jobs with the transpose bit set (the data-gradient images W^T of every layer): same results, the source read
+ * along its rows through a 32 x 32 LDS tile instead of one cache line per lane. */
+int usf_pack_weights_t_f32(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols,
+                           usf_stream_t stream);
 
 /* out[o] = alpha * sum_k src[idx[o], k] * b[k] (0 where idx[o] < 0; idx NULL = identity), fp64 accumulation; out32 and/or
  * out64 receive the result.  Bias folding c = -(Minv b) and SequentialAffineTransform.bias (transforms.py:1471-1476). */

@@ -171,6 +171,51 @@ def test_pack_weight_bit_exact(src_dtype, transpose):
     assert torch.equal(s[:, :n_in].cpu(), W_ref[:, :n_in])
 
 
+@pytest.mark.parametrize("planes_dtype", [None, torch.bfloat16, torch.float16])
+def test_batched_pack_jobs_transposed_through_tiles_bit_exact(planes_dtype):
+    """a batch of pack jobs (``batch_jobs``): the transposed ones leave through usf_pack_weights_t_f32 (32 x 32 LDS tiles),
+    the others through usf_pack_weights_f32 -- every image bit for bit the documented gather (emulator), with index
+    selections, holes (-1), ragged shapes that end inside a tile, fp32 and fp64 sources, W and / or planes"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(11)
+    jobs = []
+    for k, (R, Cc, n_out, n_in, tr, dt) in enumerate([(70, 91, 95, 64, True, torch.float64), (33, 33, 33, 33, True, torch.float32),
+                                                      (784, 784, 784, 800, True, torch.float64), (40, 57, 31, 40, False, torch.float32),
+                                                      (5, 130, 129, 4, True, torch.float32), (64, 64, 64, 64, True, torch.float64)]):
+        src = torch.randn(R, Cc, generator=g, dtype=torch.float64).to(dt)
+        rows_src, cols_src = (Cc, R) if tr else (R, Cc)
+        oi = torch.randint(-1, rows_src, (n_out,), generator=g).to(torch.int32) if k % 2 == 0 else None
+        ii = torch.randint(-1, cols_src, (n_in,), generator=g).to(torch.int32) if k % 3 != 1 else None
+        if oi is None:
+            n_out = min(n_out, rows_src)
+        if ii is None:
+            n_in = min(n_in, cols_src)
+        ldw, ldp = n_in + 3, (n_in + 31) // 32 * 32
+        W = torch.full((n_out, ldw), 7.0)
+        planes = None
+        if planes_dtype is not None:
+            planes = torch.ones(2 if planes_dtype == torch.float16 else 3, n_out, ldp, dtype=planes_dtype)
+        jobs.append(dict(src=src, oi=oi, n_out=n_out, ii=ii, n_in=n_in, W=W, ldw=ldw, planes=planes, tr=tr))
+    dev = lambda t: None if t is None else t.to(DEV)
+    got = []
+    with ext.batch_jobs(torch.device(DEV)) as bj:
+        for j in jobs:
+            Wd, Pd = dev(j["W"]), dev(j["planes"])
+            ext.pack_weight(dev(j["src"]), dev(j["oi"]), j["n_out"], dev(j["ii"]), j["n_in"], W=Wd, ldw=j["ldw"], planes=Pd,
+                            transpose=j["tr"])
+            got.append((Wd, Pd))
+        assert len(bj.jobs) == len(jobs)
+    torch.cuda.synchronize()
+    for j, (Wd, Pd) in zip(jobs, got):
+        W_ref = j["W"].clone()
+        P_ref = None if j["planes"] is None else j["planes"].clone()
+        emulator._emu_pack_weight_now(j["src"], j["oi"], j["n_out"], j["ii"], j["n_in"], W=W_ref, ldw=j["ldw"], planes=P_ref,
+                                      transpose=j["tr"])
+        assert torch.equal(Wd.cpu(), W_ref), (j["n_out"], j["n_in"], j["tr"])
+        if P_ref is not None:
+            assert torch.equal(Pd.cpu().view(torch.int16), P_ref.view(torch.int16)), (j["n_out"], j["n_in"], j["tr"])
+
+
 def test_matvec_f64():
     ext = _ext()
     g = torch.Generator().manual_seed(5)

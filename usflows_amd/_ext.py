@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 27
+USF_ABI_VERSION = 28
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -217,6 +217,7 @@ SYMBOLS = {
     "usf_base_logprob_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp,
                                             C.c_int64, C.c_void_p]),
     "usf_pack_weights_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_pack_weights_t_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_grad_jobs_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_void_p]),
     "usf_affine_prep_f32": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp,
                                       C.c_void_p]),
@@ -836,6 +837,9 @@ def householder(w_0, vk, out=None):
     return out
 
 
+TILED_TRANSPOSE = True      # transposed images of a batch through usf_pack_weights_t_f32 (False: the per-element kernel)
+
+
 class batch_jobs:
     """Defer the usf_pack_weight_f32 calls made inside the block and issue them as ONE usf_pack_weights_f32 launch
     per size class at exit (or at an explicit ``flush``).  Only for calls whose sources are ready when the batch is
@@ -865,17 +869,19 @@ class batch_jobs:
         jobs, self.jobs = self.jobs, []
         if not jobs:
             return
-        # two size classes: matrices and single rows (vectors) -- keeps the grid of empty blocks small
-        for cls in (True, False):
-            part = [j for j in jobs if (j[0].n_out > 1) == cls]
+        # size classes: transposed matrices (read through LDS tiles), other matrices, single rows (vectors) -- keeps the
+        # grid of empty blocks small
+        kind = lambda j: 2 if j.n_out <= 1 else (0 if (j.transpose & 1) and TILED_TRANSPOSE else 1)    # noqa: E731
+        for cls, entry in ((0, "usf_pack_weights_t_f32"), (1, "usf_pack_weights_f32"), (2, "usf_pack_weights_f32")):
+            part = [j for j in jobs if kind(j[0]) == cls]
             if not part:
                 continue
             arr = (PackJob * len(part))(*[j[0] for j in part])
             table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             max_rows = max(j[0].n_out for j in part)
             max_cols = max(max(j[0].n_in, j[0].ld_planes if j[0].planes else 0) for j in part)
-            _launch("usf_pack_weights_f32", (table.data_ptr(), len(part), max_rows, max_cols,
-                                             current_stream(self.device)), (table, [j[1] for j in part]))
+            _launch(entry, (table.data_ptr(), len(part), max_rows, max_cols, current_stream(self.device)),
+                    (table, [j[1] for j in part]))
 
 
     def _flush_grads(self):

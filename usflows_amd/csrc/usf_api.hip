@@ -51,6 +51,7 @@ int pack_weight(const void* src, int32_t src_is_f32, int64_t lds_, int32_t trans
                 const int32_t* in_idx, int64_t n_in, float* W, int64_t ldw, void* planes, int64_t ldp,
                 int64_t plane_stride, hipStream_t stream);
 int pack_jobs(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols, hipStream_t stream);
+int pack_jobs_t(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols, hipStream_t stream);
 int matvec_rows(const double* src, int64_t lds_, int64_t K, const int32_t* idx, int64_t n_out, const double* b,
                 double alpha, float* out32, double* out64, hipStream_t stream);
 
@@ -214,6 +215,9 @@ int usf_pack_weight_f32(const void* src, int32_t src_is_f32, int64_t ld_src, int
 int usf_pack_weights_f32(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols,
                          usf_stream_t stream) {
   return usf::pack_jobs(jobs, n_jobs, max_rows, max_cols, (hipStream_t)stream);
+}
+int usf_pack_weights_t_f32(const usf_pack_job* jobs, int64_t n_jobs, int64_t max_rows, int64_t max_cols, usf_stream_t stream) {
+  return usf::pack_jobs_t(jobs, n_jobs, max_rows, max_cols, (hipStream_t)stream);
 }
 
 int usf_matvec_f64(const double* src, int64_t ld_src, int64_t K, const int32_t* idx, int64_t n_out, const double* b,

@@ -32,8 +32,8 @@ struct SkArgs {
   int act, vec_ok;
 };
 
-constexpr int SK_G = 4;        // k-steps (of 16) fetched together
-
+// SK_G: k-steps (of 16) fetched together (4; 8 is a tuning instance: USF_SKINNY_G)
+template <int SK_G>
 __global__ __launch_bounds__(512) void linear_skinny_kernel(const SkArgs p) {
   __shared__ f32x4 red[8][2][64];              // [wave][batch tile][lane] partial accumulators
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,7 +171,10 @@ int linear_skinny_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (ks > nstep) ks = nstep;
   a.ks = ks;
   const dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)((a.M + 32 * a.mw - 1) / (32 * a.mw)));
-  hipLaunchKernelGGL(linear_skinny_kernel, grid, dim3(64 * a.mw * a.ks), 0, stream, a);
+  static int g8 = -1;
+  if (g8 < 0) { const char* e = getenv("USF_SKINNY_G"); g8 = (e && atoi(e) == 8) ? 1 : 0; }
+  if (g8) hipLaunchKernelGGL(linear_skinny_kernel<8>, grid, dim3(64 * a.mw * a.ks), 0, stream, a);
+  else hipLaunchKernelGGL(linear_skinny_kernel<4>, grid, dim3(64 * a.mw * a.ks), 0, stream, a);
   return check_launch("usf_linear_f32(skinny)");
 }
 
