@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 28
+#define USF_ABI_VERSION 29
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -280,9 +280,11 @@ int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int
  */
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks);
 /* The planes above from an fp32 nn.Conv2d weight w [cout, cin, ks, ks] on the device, one launch.  transposed == 0: planes of
- * this convolution (usf_conv2d_weight_elems(cin, cout, ks) bf16 elements).  transposed != 0: planes of the convolution that
+ * this convolution (usf_conv2d_weight_elems(cin, cout, ks) bf16 elements).  transposed == 1: planes of the convolution that
  * computes its DATA gradient -- cout -> cin channels with W'[ci, co, ky, kx] = w[co, ci, ks-1-ky, ks-1-kx]
- * (usf_conv2d_weight_elems(cout, cin, ks) elements).  Not for the gated row packing (the caller packs that on the host side). */
+ * (usf_conv2d_weight_elems(cout, cin, ks) elements).  transposed == 2: both, back to back in `planes` (the first set, then the
+ * second), in one launch -- what a training step needs of every convolution.  Not for the gated row packing (the caller
+ * packs that on the host side). */
 int usf_conv2d_weight_planes_f32(const float* w, void* planes, int64_t cin, int64_t cout, int64_t ks, int32_t transposed,
                                  usf_stream_t stream);
 /* > 0 (samples per LDS group) when usf_conv2d_same_f32 serves these sizes: weight planes + one padded sample must fit 158 KB of LDS */

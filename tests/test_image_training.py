@@ -181,6 +181,11 @@ def test_weight_planes_kernel_gives_the_bits_of_the_torch_split(cout, cin, ks):
         assert got.shape == ref.shape and got.dtype == torch.bfloat16
         assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
         assert torch.equal(ref.float().sum(0)[: (cin if transposed else cout)].double().abs().sum() > 0, torch.tensor(True))
+    # both orientations from ONE launch (transposed = 2): the same bits
+    pf, pt = _ext.conv2d_weight_planes_pair(w.to(DEV))
+    for got, transposed in ((pf, False), (pt, True)):
+        ref = _ext.conv2d_weight_planes(w, transposed=transposed)
+        assert got.shape == ref.shape and torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
 
 
 @pytest.mark.gpu

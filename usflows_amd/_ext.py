@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 28
+USF_ABI_VERSION = 29
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -543,6 +543,24 @@ def layernorm_channels(x, gamma, beta, eps, act=ACT_NONE, slope=0.0):
     _direct("usf_layernorm_channels_f32", x.data_ptr(), y.data_ptr(), B, Cc, P, gamma.data_ptr(), beta.data_ptr(), float(eps),
                                             int(act), float(slope), current_stream(x.device))
     return y
+
+
+def conv2d_weight_planes_pair(weight: torch.Tensor):
+    """(planes, planes_t) of a device fp32 Conv2d weight -- the convolution's own planes and those of its data-gradient
+    convolution -- from ONE usf_conv2d_weight_planes_f32 launch (transposed = 2); the same bits as two separate calls"""
+    cout, cin, k, _ = weight.shape
+    lib = load()
+    w = weight.detach().contiguous()
+    shapes = []
+    for rows, cols in ((cout, cin), (cin, cout)):
+        cp, coutp = (cols + 7) // 8 * 8, (rows + 15) // 16 * 16
+        shapes.append((3, coutp, (k * k * cp + 31) // 32 * 32))
+    n_f, n_t = math.prod(shapes[0]), math.prod(shapes[1])
+    assert n_f == lib.usf_conv2d_weight_elems(cin, cout, k) and n_t == lib.usf_conv2d_weight_elems(cout, cin, k)
+    buf = torch.empty(n_f + n_t, dtype=torch.bfloat16, device=weight.device)
+    check(lib.usf_conv2d_weight_planes_f32(w.data_ptr(), buf.data_ptr(), cin, cout, k, 2, current_stream(weight.device)),
+          "usf_conv2d_weight_planes_f32")
+    return buf[:n_f].view(shapes[0]), buf[n_f:].view(shapes[1])
 
 
 def conv2d_weight_planes(weight: torch.Tensor, gate_channels: int = 0, transposed: bool = False) -> torch.Tensor:

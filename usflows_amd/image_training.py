@@ -15,6 +15,8 @@ inverse) stay torch ops on C x C tensors, as in the reference.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _ext
@@ -50,6 +52,14 @@ def conv_shape_ok(conv, B: int, H: int, W: int) -> bool:
             and lib.usf_conv_wgrad_workspace(max(B, 1), cin, cout, H, W, k[0]) > 0)
 
 
+def _weight_planes(w, want_transposed: bool):
+    """(planes, planes_t | None) of a convolution weight: both from one launch when the data gradient will be asked for (the
+    weight does not change between a step's forward and backward pass)"""
+    if want_transposed and w.is_cuda and w.dtype == torch.float32:
+        return _ext.conv2d_weight_planes_pair(w)
+    return _ext.conv2d_weight_planes(w), None
+
+
 class ConvSame(torch.autograd.Function):
     """out_act(bias + conv(in_act(x) * in_mul)) on usf_conv2d_same_f32 (kernel 1 or 3, stride 1, "same")"""
 
@@ -59,7 +69,8 @@ class ConvSame(torch.autograd.Function):
         w = weight.detach()
         ks = w.shape[2]
         ia, oa = _act(in_act), _act(out_act)
-        y = _ext.conv2d_same(x, _ext.conv2d_weight_planes(w), w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
+        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0])
+        y = _ext.conv2d_same(x, planes, w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
                              in_mul=in_mul, in_act=ia[0], in_slope=ia[1], out_act=oa[0], out_slope=oa[1])
         ctx.save_for_backward(x, w, in_mul, y if out_act is not None else None)
         ctx.cfg = (ks, in_act, out_act, bias is not None)
@@ -81,7 +92,7 @@ class ConvSame(torch.autograd.Function):
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_shape_ok was not consulted)")
             dW, db = r
         if ctx.needs_input_grad[0]:
-            planes_t = _ext.conv2d_weight_planes(w, transposed=True)
+            planes_t = ctx.planes_t if ctx.planes_t is not None else _ext.conv2d_weight_planes(w, transposed=True)
             dx = None
             if in_act is not None or in_mul is not None:
                 # the input's (Leaky)ReLU and mask factors in the data-gradient convolution's output stream
@@ -107,7 +118,8 @@ class ConvSameFork(torch.autograd.Function):
         w = weight.detach()
         ks = w.shape[2]
         ia = _act(in_act)
-        y = _ext.conv2d_same(x, _ext.conv2d_weight_planes(w), w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
+        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0])
+        y = _ext.conv2d_same(x, planes, w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
                              in_mul=in_mul, in_act=ia[0], in_slope=ia[1])
         ctx.save_for_backward(x, w, in_mul)
         ctx.cfg = (ks, in_act, bias is not None)
@@ -126,7 +138,7 @@ class ConvSameFork(torch.autograd.Function):
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r
         if ctx.needs_input_grad[0]:
-            planes_t = _ext.conv2d_weight_planes(w, transposed=True)
+            planes_t = ctx.planes_t if ctx.planes_t is not None else _ext.conv2d_weight_planes(w, transposed=True)
             dxs = None if dxs is None else dxs.contiguous()
             if dxs is not None and in_mul is not None and in_act is None:
                 # dx = dxs + mask * dgrad: the residual form of the convolution
@@ -324,14 +336,21 @@ def needs_grad(module, *tensors) -> bool:
 # training step of the 2-block MNIST model is ~800 kernel launches of 3-4 us of which ~40 touch the batch.  Under
 # ``batched_affine_prep`` the same maps are evaluated ONCE per log_prob call for all blocks of equal structure as [n, C, C]
 # stacks (same formulas, torch autograd differentiates them); the layers pick their (M, M^-1, b, log|det|) from the stack.
-_PREP = None
-_PREP_STACKS = {}       # group -> stacked log|det| [n] of the current pass (device prep only)
+class _PrepState(threading.local):
+    """the current pass's prep, per thread (two threads training two flows must not see each other's maps)"""
+
+    def __init__(self):
+        self.prep = None       # id(block transform) -> (M, Minv, b, ladj[, c, (group, row)])
+        self.stacks = {}       # group -> stacked log|det| [n] of the current pass (device prep only)
+
+
+_STATE = _PrepState()
 
 
 def current_prep(block_transform):
     """(M, Minv, b, ladj[, c = -Minv b, (group, row)]) of this block transform inside ``batched_affine_prep``; None outside
     or when not covered"""
-    return None if _PREP is None else _PREP.get(id(block_transform))
+    return None if _STATE.prep is None else _STATE.prep.get(id(block_transform))
 
 
 _EYES = {}
@@ -437,7 +456,7 @@ def coef_tensor(values, device) -> torch.Tensor:
 
 
 def prep_stack(group):
-    return _PREP_STACKS.get(group)
+    return _STATE.stacks.get(group)
 
 
 affine_prep_kernels = True        # USFLOWS_AMD_AFFINE_PREP=0 / False: the batched torch formulation below
@@ -471,7 +490,7 @@ def _prep_group_device(bts, parts_list, sig, device):
         w0 = torch.stack([h.w_0.detach() for h in hhs])
     out = AffinePrep.apply(Lr, Ur, bias, vk, w0)
     key = (sig, tuple(id(bt) for bt in bts))
-    _PREP_STACKS[key] = out[5 * n]
+    _STATE.stacks[key] = out[5 * n]
     # (M, M^-1, b, log|det|, c = -M^-1 b, (group, row) of the block in the stacked log|det|)
     return {id(bt): (out[i], out[n + i], out[2 * n + i], out[4 * n + i], out[3 * n + i], (key, i)) for i, bt in enumerate(bts)}
 
@@ -521,9 +540,8 @@ class batched_affine_prep:
         self.layers, self.device, self.prev = layers, device, None
 
     def __enter__(self):
-        global _PREP
         from . import transforms as T
-        self.prev = _PREP
+        self.prev = _STATE.prep
         groups = {}
         for l in self.layers:
             blk = l.transform if isinstance(l, T.InverseTransform) else l
@@ -538,16 +556,14 @@ class batched_affine_prep:
                 g[0][id(bt)] = bt
                 g[1].append(parts)
         prep = {}
-        self.prev_stacks = dict(_PREP_STACKS)
-        _PREP_STACKS.clear()
+        self.prev_stacks = _STATE.stacks
+        _STATE.stacks = {}
         for sig, (bts, parts_list) in groups.items():
             prep.update(_prep_group(list(bts.values()), parts_list, sig, self.device))
-        _PREP = prep
+        _STATE.prep = prep
         return self
 
     def __exit__(self, *exc):
-        global _PREP
-        _PREP = self.prev
-        _PREP_STACKS.clear()
-        _PREP_STACKS.update(self.prev_stacks)
+        _STATE.prep = self.prev
+        _STATE.stacks = self.prev_stacks
         return False
