@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
-FIT_IMAGE_ONLY=device rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3/kt_fit32 -- python3 tools/fit_image.py mnist_image 32 > gpurun_out/r3/kt_fit32.log 2>&1
+FIT_IMAGE_ONLY=device rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3/kt_fit32 -- python3 tools/fit_image.py ${1:-mnist_image} 32 > gpurun_out/r3/kt_fit32.log 2>&1
 f=$(ls gpurun_out/r3/kt_fit32/*/*kernel_stats.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

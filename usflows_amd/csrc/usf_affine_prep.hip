@@ -41,7 +41,7 @@ struct APBArgs {
   const float* Minv; const float* b;            // the forward pass's outputs (for the gradient through c = -Minv b)
   const float* dM; const float* dMinv; const float* db; const float* dc; const float* dladj;
   float* dLr; float* dUr; float* dbias; float* dvk;
-  int C, nvs;
+  int C, nvs, stage;
 };
 
 // O[i][j] (op)= alpha * sum_k opA(A)[i][k] opB(B)[k][j];  ACC 0: set, 1: add.  All threads of the block; no barrier inside.
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
   const float* gH = sav + 6 * CC;
   float* sdMi = stmp2 + AP_MAXC;   // [C][ld]  dM^-1 with the contribution of dc folded in
   float* sdb = sdMi + msz;         // [C]      db likewise
-  const float* dM = a.dM + blk * CC;
+  const float* dM = a.dM + blk * CC;          // (re-pointed to the LDS copy below when staged)
   // c = -M^-1 b:  dM^-1 -= dc (x) b,  db -= (M^-1)^T dc
   {
     const float* gMi = a.Minv + blk * CC;
@@ -221,19 +221,32 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
       sdb[tid] = a.db[blk * C + tid] - t;
     }
   }
+  // C <= 48: the eight read-only matrices (the saved factors and dM) fit the LDS next to the temporaries -- every product
+  // below then reads LDS instead of global memory (21 blocks of C = 48: 232 -> ~60 us)
+  int lg = C;
+  if (a.stage) {
+    float* st = sdb + AP_MAXC;
+    for (int m = 0; m < AP_SAVE + 1; ++m) {
+      const float* src = m < AP_SAVE ? sav + m * CC : dM;
+      for (int idx = tid; idx < CC; idx += AP_NT) st[m * msz + (idx / C) * ld + idx % C] = src[idx];
+    }
+    gL = st; gU = st + msz; gLi = st + 2 * msz; gUi = st + 3 * msz; gMlu = st + 4 * msz; gMilu = st + 5 * msz; gH = st + 6 * msz;
+    dM = st + 7 * msz;
+    lg = ld;
+  }
   __syncthreads();
   const float* dMi = sdMi;
   const float* db = sdb;
   const int ldi = ld;
   const float* pMlu = dM;          // dM_lu / dM_lu^-1: the incoming gradients themselves without a Householder factor
   const float* pMilu = dMi;
-  int ldg = C, ldgi = ldi;
+  int ldg = lg, ldgi = ldi;
   if (a.nvs > 0) {
-    ap_mm<false, true, 0>(dM, C, gH, C, sdMlu, ld, C, 1.f);          // dM H^T
-    ap_mm<false, false, 0>(gH, C, dMi, ldi, sdMilu, ld, C, 1.f);     // H dM^-1
-    ap_mm<true, false, 0>(gMlu, C, dM, C, sdH, ld, C, 1.f);          // M_lu^T dM
+    ap_mm<false, true, 0>(dM, lg, gH, lg, sdMlu, ld, C, 1.f);          // dM H^T
+    ap_mm<false, false, 0>(gH, lg, dMi, ldi, sdMilu, ld, C, 1.f);     // H dM^-1
+    ap_mm<true, false, 0>(gMlu, lg, dM, lg, sdH, ld, C, 1.f);          // M_lu^T dM
     __syncthreads();
-    ap_mm<false, true, 1>(gMilu, C, dMi, ldi, sdH, ld, C, 1.f);      // + M_lu^-1 (dM^-1)^T
+    ap_mm<false, true, 1>(gMilu, lg, dMi, ldi, sdH, ld, C, 1.f);      // + M_lu^-1 (dM^-1)^T
     __syncthreads();
     for (int idx = tid; idx < CC; idx += AP_NT) {
       const int i = idx / C, j = idx - i * C;
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
     }
     if (tid < C) {
       float s = 0.f;
-      for (int j = 0; j < C; ++j) s = fmaf(gH[tid * C + j], db[j], s);
+      for (int j = 0; j < C; ++j) s = fmaf(gH[tid * lg + j], db[j], s);
       a.dbias[blk * C + tid] = s;                                    // H db
     }
     pMlu = sdMlu; pMilu = sdMilu; ldg = ld; ldgi = ld;
@@ -250,24 +263,24 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
   }
   __syncthreads();
   // ---- LU factors
-  ap_mm<false, true, 0>(pMlu, ldg, gU, C, sdL, ld, C, 1.f);           // dL = dM_lu U^T
-  ap_mm<true, false, 0>(gL, C, pMlu, ldg, sdU, ld, C, 1.f);           // dU = L^T dM_lu
-  ap_mm<false, true, 0>(pMilu, ldgi, gLi, C, sT1, ld, C, 1.f);        // T1 = dM_lu^-1 L^-T          (= dU^-1)
+  ap_mm<false, true, 0>(pMlu, ldg, gU, lg, sdL, ld, C, 1.f);           // dL = dM_lu U^T
+  ap_mm<true, false, 0>(gL, lg, pMlu, ldg, sdU, ld, C, 1.f);           // dU = L^T dM_lu
+  ap_mm<false, true, 0>(pMilu, ldgi, gLi, lg, sT1, ld, C, 1.f);        // T1 = dM_lu^-1 L^-T          (= dU^-1)
   __syncthreads();
-  ap_mm<true, false, 0>(gUi, C, sT1, ld, sT2, ld, C, 1.f);            // T2 = U^-T T1
+  ap_mm<true, false, 0>(gUi, lg, sT1, ld, sT2, ld, C, 1.f);            // T2 = U^-T T1
   __syncthreads();
-  ap_mm<false, true, 1>(sT2, ld, gUi, C, sdU, ld, C, -1.f);           // dU -= T2 U^-T
-  ap_mm<true, false, 0>(gUi, C, pMilu, ldgi, sT1, ld, C, 1.f);        // T1 = U^-T dM_lu^-1          (= dL^-1)
+  ap_mm<false, true, 1>(sT2, ld, gUi, lg, sdU, ld, C, -1.f);           // dU -= T2 U^-T
+  ap_mm<true, false, 0>(gUi, lg, pMilu, ldgi, sT1, ld, C, 1.f);        // T1 = U^-T dM_lu^-1          (= dL^-1)
   __syncthreads();
-  ap_mm<true, false, 0>(gLi, C, sT1, ld, sT2, ld, C, 1.f);            // T2 = L^-T T1
+  ap_mm<true, false, 0>(gLi, lg, sT1, ld, sT2, ld, C, 1.f);            // T2 = L^-T T1
   __syncthreads();
-  ap_mm<false, true, 1>(sT2, ld, gLi, C, sdL, ld, C, -1.f);           // dL -= T2 L^-T
+  ap_mm<false, true, 1>(sT2, ld, gLi, lg, sdL, ld, C, -1.f);           // dL -= T2 L^-T
   __syncthreads();
   const float dl = a.dladj[blk];
   for (int idx = tid; idx < CC; idx += AP_NT) {
     const int i = idx / C, j = idx - i * C;
     float du = sdU[i * ld + j];
-    if (i == j) du += dl / gU[idx];
+    if (i == j) du += dl / gU[i * lg + j];
     a.dLr[blk * CC + idx] = j < i ? sdL[i * ld + j] : 0.f;
     a.dUr[blk * CC + idx] = j >= i ? du : 0.f;
   }
@@ -310,6 +323,9 @@ __global__ __launch_bounds__(AP_NT) void affine_prep_bwd_kernel(const APBArgs a)
 }
 
 static size_t ap_lds_bytes(int C) { return (size_t)((AP_SAVE + 1) * C * (C + 1) + 4 * AP_MAXC) * sizeof(float); }
+// backward: the read-only matrices staged in LDS as well when 16 padded matrices fit 160 KB (C <= 48)
+static int ap_bwd_stage(int C) { return 2 * ap_lds_bytes(C) <= 160 * 1024 ? 1 : 0; }
+static size_t ap_bwd_lds_bytes(int C) { return ap_lds_bytes(C) + (ap_bwd_stage(C) ? (size_t)(AP_SAVE + 1) * C * (C + 1) * sizeof(float) : 0); }
 
 static int ap_check(const char* what, int64_t n, int32_t C, int32_t nvs) {
   if (n < 0 || C < 1 || C > AP_MAXC || nvs < 0 || nvs > 8) {
@@ -357,14 +373,15 @@ int affine_prep_bwd(const float* save, const float* bias, const float* vk, const
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
   if (!attr_done[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&affine_prep_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)ap_lds_bytes(AP_MAXC)) != hipSuccess) {
+                            160 * 1024) != hipSuccess) {
       set_error("usf_affine_prep_bwd_f32: cannot reserve LDS");
       return -5;
     }
     attr_done[dev] = true;
   }
-  const APBArgs a{save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dladj, dLr, dUr, dbias, dvk, C, nvs};
-  affine_prep_bwd_kernel<<<(unsigned)n, AP_NT, ap_lds_bytes(C), stream>>>(a);
+  const int stage = ap_bwd_stage(C);
+  const APBArgs a{save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dladj, dLr, dUr, dbias, dvk, C, nvs, stage};
+  affine_prep_bwd_kernel<<<(unsigned)n, AP_NT, ap_bwd_lds_bytes(C), stream>>>(a);
   return check_launch("usf_affine_prep_bwd_f32");
 }
 

@@ -427,10 +427,13 @@ template <int CMAX, bool FULL>
 __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
                                                              int64_t P, const float* __restrict__ W,
                                                              const float* __restrict__ pre_sub,
-                                                             const float* __restrict__ bias, int64_t BP) {
+                                                             const float* __restrict__ bias, int64_t BP, int co_per_block) {
   // pixels of all samples in one index space: with one block row per sample a 7 x 7 image left 207 of 256 threads idle
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= BP) return;
+  // few pixels (a training batch of 32 samples): the output channels are dealt over blockIdx.y -- a thread then walks
+  // co_per_block weight rows instead of all C (48 x 48 FMAs in one thread are 20 us whatever the batch); same sums
+  const int co0 = blockIdx.y * co_per_block, co1 = co0 + co_per_block;
   const int64_t b = i / P, p = i - b * P;
   const float* xb = x + b * C * P + p;
   const int Cn = FULL ? CMAX : C;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __rest
   float* yb = y + b * C * P + p;
 #pragma unroll
   for (int co = 0; co < CMAX; ++co) {
-    if (FULL || co < Cn) {
+    if ((FULL || co < Cn) && co >= co0 && co < co1) {          // (wave-uniform)
       const float* wr = W + co * Cn;
       float acc = 0.f;
 #pragma unroll
@@ -466,11 +469,13 @@ int channel_affine(const float* x, float* y, int64_t B, int64_t C, int64_t P, co
   if (x == y) { set_error("usf_channel_affine_f32: in-place operation is not supported"); return -2; }
   const int64_t BP = B * P, blocks = (BP + 255) / 256;
   if (blocks > 0x7fffffffLL) { set_error("usf_channel_affine_f32: grid too large"); return -3; }
-  const dim3 b(256), g((unsigned)blocks);
+  // up to 64 pixel blocks (16 384 pixels: a quarter of the chip): 8 output channels per block row
+  const int co_per_block = (blocks <= 64 && C > 8) ? 8 : 64;
+  const dim3 b(256), g((unsigned)blocks, (unsigned)((C + co_per_block - 1) / co_per_block));
 #define USF_CA(CM)                                                                                                       \
   do {                                                                                                                  \
-    if (C == CM) hipLaunchKernelGGL((channel_affine_kernel<CM, true>), g, b, 0, stream, x, y, (int)C, P, W, pre_sub, bias, BP);  \
-    else hipLaunchKernelGGL((channel_affine_kernel<CM, false>), g, b, 0, stream, x, y, (int)C, P, W, pre_sub, bias, BP);         \
+    if (C == CM) hipLaunchKernelGGL((channel_affine_kernel<CM, true>), g, b, 0, stream, x, y, (int)C, P, W, pre_sub, bias, BP, co_per_block);  \
+    else hipLaunchKernelGGL((channel_affine_kernel<CM, false>), g, b, 0, stream, x, y, (int)C, P, W, pre_sub, bias, BP, co_per_block);         \
   } while (0)
   if (C <= 8) USF_CA(8); else if (C <= 16) USF_CA(16); else if (C <= 24) USF_CA(24); else if (C <= 32) USF_CA(32);
   else if (C <= 48) USF_CA(48); else USF_CA(64);
