@@ -567,14 +567,19 @@ static int conv_wreg_plan(int cin, int cout, int H, int W, int* cgs, int* img_by
 
 // samples per group for the wave-specialised kernel (0: not served): 16 row tiles per group at most (dealt over the 4 / NCT
 // multiplying waves of an output tile), 4 staging units per service thread, image and output staging area double-buffered
-static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cgs, int* img_bytes, int64_t* lds) {
+// B / cus > 0: a launch of B samples on cus compute units.  When the groups of the best S would not even fill the chip once,
+// the SMALLEST servable S whose groups still fit one round of blocks is taken instead: at 100 samples a block then stages,
+// multiplies and stores one sample instead of five -- the launch is a dependent chain of those phases, not a throughput
+// problem (same sums per output element whatever S).
+static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cgs, int* img_bytes, int64_t* lds, int64_t B = 0,
+                         int cus = 0) {
   const int HW = H * W;
   if (!((cin == 16 || cin == 32 || cin == 48) && (cout == 16 || cout == 32 || cout == 48 || cout == 64)) || HW > 64 || HW < 1 ||
       ((cin * HW) & 3) || ((cout * HW) & 3)) return 0;
   const int nct_k = (cout + 15) / 16 == 3 ? 4 : (cout + 15) / 16;       // (48 channels: the four-tile instance, one multiplying wave idle)
   const int wpc = (nct_k == 1 ? 2 : 4) / nct_k;                         // (16 channels: two multiplying waves, six service waves)
   auto group_bytes = [&](int S) { return (int64_t)(((S * HW + 1) * 48 + 255) / 256 * 256); };   // three planes per position
-  int best = 0; double best_eff = 0.0;
+  int best = 0, small = 0; double best_eff = 0.0;
   for (int S = 1; S <= 16; ++S) {
     const int nrt = (S * HW + 15) / 16;
     if (nrt > 16) break;
@@ -585,8 +590,12 @@ static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cg
     if (with_res && (int64_t)S * cout * HW / 4 > 8 * 256) break;
     const double eff = (double)(S * HW) / (16.0 * wpc * ((nrt + wpc - 1) / wpc));
     if (eff >= best_eff - 1e-9) { best_eff = eff; best = S; }
+    if (small == 0 && eff >= 0.7 && B > 0 && cus > 0 && (B + S - 1) / S <= cus) small = S;
   }
   if (best == 0 || best_eff < 0.7) return 0;
+  static int small_on = -1;
+  if (small_on < 0) { const char* e = getenv("USF_CONV_SMALL_S"); small_on = e ? atoi(e) : 1; }    // tuning aid: 0 = always the best S
+  if (small_on && small > 0 && small < best && B > 0 && (B + best - 1) / best < cus) best = small;
   *cgs = (int)group_bytes(best);
   *img_bytes = (cin / 8) * (*cgs);                      // one image BUFFER (all three planes)
   *lds = 2LL * (*img_bytes) + 2LL * best * cout * HW * 4;
@@ -613,7 +622,7 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   int S = 0;
   bool specialised = false;
   if (wsp && cin <= 64 && cout <= 64 && H * W <= 64) {
-    S = conv_wsp_plan((int)cin, (int)cout, (int)H, (int)W, res_x != nullptr, &a.cgs, &a.img_bytes, &lds);
+    S = conv_wsp_plan((int)cin, (int)cout, (int)H, (int)W, res_x != nullptr, &a.cgs, &a.img_bytes, &lds, B, device_cu_count());
     specialised = S > 0;
   }
   if (!specialised && cin == 48) return 0;
