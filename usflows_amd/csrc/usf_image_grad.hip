@@ -36,6 +36,7 @@ struct WgArgs {
   const float* in_mul;     // [cin * HW] or NULL
   const float* pre_sub;    // [cin] or NULL
   int B, cin, cout, HW, W, S, base, CS, nch, q0, nex, ney, nacc;
+  int rsplit;                // kernel 3: waves per sample (1, 2 or 4): each takes a range of the position chunks (small batches)
   unsigned m_hw, m_w;      // ceil(2^32 / HW), ceil(2^32 / W)  (HW, W >= 2)
   float slope_eff;         // leaky slope of the input nonlinearity; 1 = none
   int toff[9];
@@ -125,15 +126,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     }
   };
 
-  int s = gw;
+  // rsplit waves share a sample (few samples: 32 of them would occupy 32 of the chip's 1024 wave slots for ~600 dependent
+  // MFMAs each): every wave stages the sample but multiplies only its range [c0, c1) of the position chunks -- partial sums
+  // like any other wave's.  4 * gridDim.x is a multiple of rsplit, so a wave keeps its part for the whole launch.
+  const int rs = a.rsplit, part = gw % rs;
+  const int c0 = part * a.nch / rs, c1 = (part + 1) * a.nch / rs;
+  const int nsw = nw / rs;                                     // samples in flight over the grid
+  int s = gw / rs;
   if (s < a.B) gload(s);
   const int loff = (lane & 15) * a.CS + a.q0 + (lane >> 4);
   constexpr int NR = COT + CIT * T, NM = COT * CIT * T;        // fragment reads / MFMAs per chunk
-  for (; s < a.B; s += nw) {
+  for (; s < a.B; s += nsw) {
     stage();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (s + nw < a.B) gload(s + nw);
+    if (s + nsw < a.B) gload(s + nsw);
     float av[2][COT], bv[2][CIT][T];
     auto frags = [&](int ch, int slot) {                       // (a chunk past the last one reads slack, never used)
       const int o = loff + 4 * ch;
@@ -162,8 +169,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
     };
-    frags(0, 0);
-    for (int ch = 0; ch + 1 < a.nch; ch += 2) {
+    frags(c0, 0);
+    for (int ch = c0; ch + 1 < c1; ch += 2) {
       frags(ch + 1, 1);
       mults(0);
       interleave();
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
       mults(1);
       interleave();
     }
-    if (a.nch & 1) mults(0);
+    if ((c1 - c0) & 1) mults(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -378,7 +385,7 @@ int wgrad_blocks_per_cu(int CIT, int COT, int T, int lds_bytes) {
 }
 
 struct WgPlan {
-  int CIT, COT, T, S, base, CS, nch, q0, nacc, lds_bytes, blocks, tab_floats;
+  int CIT, COT, T, S, base, CS, nch, q0, nacc, lds_bytes, blocks, tab_floats, rsplit;
   bool direct;               // kernel 1 without an input mask: conv_wgrad_k1_kernel
 };
 bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks, bool masked, WgPlan& pl) {
@@ -411,6 +418,7 @@ bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int6
   pl.CS = 2 * cs;
   pl.nacc = pl.COT * pl.CIT * pl.T * 256 + pl.COT * 16;
   pl.direct = (ks == 1 && !masked && H * W > 48);
+  pl.rsplit = 1;
   if (pl.direct) {
     pl.lds_bytes = 0;
     int per_cu = wgrad_k1_blocks_per_cu(pl.CIT, pl.COT);
@@ -427,8 +435,15 @@ bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int6
   int per_cu = wgrad_blocks_per_cu(pl.CIT, pl.COT, pl.T, pl.lds_bytes);
   if (per_cu <= 0) return false;
   if (per_cu > 4) per_cu = 4;                                    // (more partial slots than that buy nothing)
-  int64_t blocks = (B + 3) / 4;
   const int64_t cap = (int64_t)device_cu_count() * per_cu;
+  // few samples: 2 or 4 waves per sample (position chunks dealt over them) while that still fits one round of blocks
+  static int rs_on = -1;
+  if (rs_on < 0) { const char* e = getenv("USF_WGRAD_RSPLIT"); rs_on = e ? atoi(e) : 1; }     // tuning aid: 0 = one wave per sample
+  if (rs_on && pl.T == 9) {
+    if (B <= 64 && B <= cap && pl.nch >= 8) pl.rsplit = 4;          // (<= 256 partial slots: still one reduction round)
+    else if (B <= 128 && B <= 2 * cap && pl.nch >= 4) pl.rsplit = 2;
+  }
+  int64_t blocks = (B * pl.rsplit + 3) / 4;
   if (blocks > cap) blocks = cap;
   pl.blocks = (int)blocks;
   return true;
@@ -459,6 +474,7 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
   a.x = x; a.dy = dy; a.part = workspace; a.in_mul = in_mul; a.pre_sub = pre_sub;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.HW = (int)(H * W); a.W = (int)W; a.S = pl.S; a.base = pl.base;
   a.CS = pl.CS; a.nch = pl.nch; a.q0 = pl.q0; a.nex = (int)(cin * H * W); a.ney = (int)(cout * H * W); a.nacc = pl.nacc;
+  a.rsplit = pl.rsplit;
   a.m_hw = magic_div(a.HW); a.m_w = magic_div(a.W); a.slope_eff = (in_act == USF_ACT_LEAKY_RELU) ? in_slope : 1.f;
   a.tab_floats = pl.tab_floats;
   for (int t = 0; t < 9; ++t) a.toff[t] = (ks == 3) ? ((t / 3) - 1) * pl.S + ((t % 3) - 1) : 0;
