@@ -300,3 +300,33 @@ def test_round2_host_switches_are_inert_on_the_cpu():
     assert torch.equal(lu._tri_inverse(lu.L, False), torch.inverse(lu.L))
     from usflows_amd.flows import _ladj_is_parameter_only
     assert all(_ladj_is_parameter_only(l) for l in flow.layers)
+
+
+def test_lazy_log_det_sum_equals_the_layer_by_layer_subtraction():
+    """Flow._layer_loop_log_prob in training collects the layers' log-dets lazily (numbers on the host, scalars stacked once,
+    per-sample terms as tensors): same value and same gradients as the reference's `log_det = log_det - term` chain
+    (flows.py:236-245)"""
+    from usflows_amd.flows import _LogDetSum
+    g = torch.Generator().manual_seed(0)
+    B = 7
+    lp = torch.randn(B, generator=g)
+    a = torch.randn((), generator=g, requires_grad=True)
+    b = torch.randn((), generator=g, requires_grad=True)
+    v = torch.randn(B, generator=g, requires_grad=True)
+    terms = [0.0, a * 3.0, 1.25, v * 2.0, b.exp(), 0, v.sin()]
+    ld = _LogDetSum()
+    for t in terms:
+        ld.sub(t)
+    out = ld.add_to(lp)
+    ref = torch.zeros(B)
+    for t in terms:
+        ref = ref - t
+    ref = lp + ref
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    w = torch.randn(B, generator=g)
+    g1 = torch.autograd.grad((out * w).sum(), [a, b, v], retain_graph=True)
+    g2 = torch.autograd.grad((ref * w).sum(), [a, b, v])
+    for x, y in zip(g1, g2):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
+    # nothing collected: the density passes through unchanged
+    assert _LogDetSum().add_to(lp) is lp
