@@ -189,7 +189,10 @@ def test_queued_gradient_jobs_equal_launching_each_in_place(name):
     lp_n, g_n, _ = _grads_of(flow, x, g_lp, ctx, defer=False)
     assert torch.equal(lp_d, lp_n) and g_d.keys() == g_n.keys() and len(g_d) >= 6
     for k in g_d:
-        assert torch.equal(g_d[k], g_n[k]), k
+        # (the queued form also reads the hidden activations the forward pass saved instead of recomputing them: on the
+        # device the same kernel on the same operands; the emulation's forward runs in fp64 and its recomputation in fp32)
+        scale = float(g_n[k].abs().max())
+        assert torch.allclose(g_d[k], g_n[k], rtol=1e-5, atol=2e-6 * max(scale, 1e-12)), k
 
 
 @pytest.mark.parametrize("name", ["synth_d16_k3_densenn_relu", "synth_d7_k3_hh1_conj_normal"])

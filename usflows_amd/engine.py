@@ -1011,9 +1011,20 @@ class FlowEngine:
             else:
                 hbufs = ["H1", "H2"]
                 un = self._unfused_pack(pk, cp)
+                # training at small batches: every hidden layer of every coupling keeps a buffer of its own -- the backward
+                # pass reads the activations from there instead of running the conditioner a second time (2 launches per
+                # coupling of a step that is bound by the number of its launches; training.py names the same buffers)
+                save_h = train and 0 < B <= _ext.GRAD_JOB_MAX_ROWS
+                meta[-1]["hidden_saved"] = save_h
                 src_ptr, src_ld, src_K = zptr + 4 * cp["pass_off"], self.LD, cp["pass_n"]
                 for j, (W, b) in enumerate(un["layers"]):
-                    hb = ws[hbufs[j % 2]]
+                    if save_h:
+                        hname = f"Hs{j}_{i}"
+                        if hname not in ws or ws[hname].shape[0] != B or ws[hname].shape[1] < self.hmax:
+                            ws[hname] = torch.zeros(B, self.hmax, dtype=torch.float32, device=device)
+                        hb = ws[hname]
+                    else:
+                        hb = ws[hbufs[j % 2]]
                     kw = {}
                     if j == 0 and use_ctx:
                         # P = ctx * Wc + bc as a K=4 GEMM (context in column 0 of a zero-padded [B,4] operand);

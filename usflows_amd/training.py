@@ -559,7 +559,9 @@ class TrainPath:
         own = f"_{m['step']}" if self._defer else ""          # deferred gradient jobs read these after the layer loop
         hbufs = [self._buf(ws, f"Hs{j}{own}", B, hmax) for j in range(nl)]
         src, src_off, src_ld, src_K = zbuf, cp["pass_off"], LD, cp["pass_n"]
-        for j, (W, b) in enumerate(un["layers"]):
+        # (small batches: the forward plan left the hidden activations in exactly these buffers -- engine.py, `hidden_saved`)
+        recompute = not (self._defer and m.get("hidden_saved"))
+        for j, (W, b) in enumerate(un["layers"] if recompute else []):
             kw = {}
             if j == 0 and m["use_ctx"]:
                 self._linear(pk, ws["ctx4"], 0, 4, un["W_ctx4"], ws["P"], 0, hmax, B, hp[0], 4, bias=un["b_ctx"])
