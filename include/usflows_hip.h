@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 29
+#define USF_ABI_VERSION 30
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -185,6 +185,43 @@ int usf_base_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t bas
  */
 int usf_radial_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc, const float* r,
                           uint64_t seed, uint64_t offset, int64_t row_offset, usf_stream_t stream);
+
+/*
+ * RadialDistribution.log_prob in ONE launch (distributions.py:501-549 -- the base of every live image configuration:
+ * experiments/mnist/mnist.yaml:79-92, fashion/fashionclasses_veriflow.yaml:79-93, cifar/cifar.yaml), replacing
+ * usf_base_logprob_f32(LPNORM*) + the torch finishing formula on the [M] radius vector:
+ *     r[m]    = ||z[m,:] - loc||_p                       p_id = USF_BASE_LPNORM1 / LPNORM2 / LPNORMINF; D = prod(event shape)
+ *     logp[m] = log sum_k pi_k f_k(r[m]) - (logdv_const + (D - 1) log r[m]) + logdet_const (+ *logdet_dev)
+ * with the norm distribution a K-component mixture (1 <= K <= 64; K == 1: no mixture, logits may be NULL) of
+ *     USF_NORM_LOGNORMAL: f_k = torch LogNormal(par_a[k], softplus(par_b[k]))        (distributions.py:181-197, 822-834)
+ *     USF_NORM_GAMMA:     f_k = torch Gamma(softplus(par_a[k]), softplus(par_b[k]))  (distributions.py:162-179, 674-707)
+ * pi = softmax(logits) (MixtureSameFamily).  par_* are the modules' STORED parameters (positive ones through softplus, as
+ * DistributionModule._get_distribution_params applies it); OR-ing USF_NORM_RAW_PARAMS into `norm` takes them as they are
+ * (a plain torch distribution).  logdv_const = the r-independent part of log_delta_volume(p, r) (distributions.py:513-549),
+ * computed by the caller in fp64.  The O(K) finishing math runs in fp64 inside the kernel.  r_out (optional, [M]) receives the
+ * radii for the backward pass; sum_out as usf_base_logprob_f32.
+ *
+ * usf_radial_logprob_grad_f32: from g_lp [M] (gradient at logp) and the saved r:
+ *     g[m,d]   = g_lp[m] * dlogp/dr * dr/dz[m,d]   (0 for D <= d < ldg; ATen's norm backward: p = 1 sign(t), p = 2 t / r,
+ *                                                   p = inf sign(t) where |t| == r)
+ *     d_loc[d] = -sum_m g[m,d];   d_a / d_b / d_logits [K] = gradients of the STORED parameters (chain rule through softplus)
+ * each output pointer but g is optional.  z == NULL (both entry points): the radii are GIVEN -- the forward reads r_out as its
+ * input, the backward writes g [M] = the gradient at r (d_loc must be NULL): the finishing formula alone, for callers whose own
+ * tail kernel reduces the radius (the flat training path).  Partial sums are added in a fixed order (bit-reproducible).  workspace: at least
+ * usf_radial_logprob_grad_workspace(M, D) bytes, 8-byte aligned.
+ */
+#define USF_NORM_LOGNORMAL 0
+#define USF_NORM_GAMMA 1
+#define USF_NORM_RAW_PARAMS 0x100
+int usf_radial_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t p_id, const float* loc, int32_t norm,
+                           int32_t K, const float* par_a, const float* par_b, const float* logits, double logdv_const,
+                           float logdet_const, const double* logdet_dev, float* logp, float* r_out, double* sum_out,
+                           usf_stream_t stream);
+int64_t usf_radial_logprob_grad_workspace(int64_t M, int64_t D);
+int usf_radial_logprob_grad_f32(const float* z, int64_t ldz, const float* r, const float* g_lp, int64_t M, int64_t D, int32_t p_id,
+                                const float* loc, int32_t norm, int32_t K, const float* par_a, const float* par_b,
+                                const float* logits, float* g, int64_t ldg, float* d_loc, float* d_a, float* d_b, float* d_logits,
+                                void* workspace, int64_t workspace_bytes, usf_stream_t stream);
 
 /*
  * The random-word -> variate maps of the two head kernels above, applied to caller-supplied 32-bit words:
@@ -499,6 +536,7 @@ int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream);
 #define USF_FN_CONV2D_SAME 7
 #define USF_FN_CONV2D_SAME_RES 8
 #define USF_FN_BASE_LOGPROB 9
+#define USF_FN_RADIAL_LOGPROB 10
 #define USF_CALL_MAX_ARGS 20
 typedef struct usf_call_desc {
   int32_t fn;

@@ -30,7 +30,7 @@ from typing import Dict, List
 import torch
 import torch.nn.functional as F
 
-from .usflows_oracle import _AffineParams, layer_plan
+from .usflows_oracle import _AffineParams, gammamm_log_prob, layer_plan
 
 
 @dataclass
@@ -43,6 +43,9 @@ class ImageSpec:
     affine_conjugation: bool = True
     masktype: str = "checkerboard"
     negative_slope: float = 0.0                       # ConvNet2D's own nonlinearity: ReLU (0.0) or LeakyReLU(slope)
+    base: str = "laplace"                             # "laplace": Laplace(0, 1) | "radial": RadialDistribution, parameters in the state dict
+    radial_p: float = 1.0
+    radial_norm: str = "lognormal"                    # "lognormal" (LogNormal module, distributions.py:181-197) | "gammamm" (:674-707)
 
     @property
     def dim(self) -> int:                             # the affine blocks act on the channel axis (transforms.py:899-902)
@@ -151,10 +154,48 @@ def laplace_log_prob(z):
     return (-math.log(2.0) - z.abs()).flatten(1).sum(-1)
 
 
+def radial_log_prob(sd, spec: ImageSpec, z, prefix="base_distribution."):
+    """RadialDistribution.log_prob for an image-shaped loc (distributions.py:501-511): the p-norm runs over ALL event axes
+    (``event_dims = tuple(range(x.dim() - len(event_shape), x.dim()))``), then
+    ``norm_distribution.log_prob(r.unsqueeze(-1)).squeeze(-1) - log_delta_volume(p, r)`` (:513-549) with dim = C*H*W.
+    The norm distribution's parameters live in the state dict (they are trained: mnist.yaml:79-92)."""
+    dt = z.dtype
+    x = z - sd[prefix + "loc"].to(dt)
+    p = spec.radial_p
+    flat = x.flatten(1).abs()
+    if p == 1:
+        r = flat.sum(-1)
+    elif p == 2:
+        r = (flat * flat).sum(-1).sqrt()
+    elif p == math.inf:
+        r = flat.max(-1).values
+    else:
+        raise ValueError(p)
+    if spec.radial_norm == "lognormal":
+        # LogNormal module: torch LogNormal(loc, softplus(scale_unconstrained)) wrapped Independent(.., 1) (:127-139, 181-197);
+        # torch LogNormal.log_prob(r) = Normal(mu, sigma).log_prob(log r) - log r  (TransformedDistribution, ExpTransform)
+        mu = sd[prefix + "norm_distribution.loc"].to(dt)
+        sigma = F.softplus(sd[prefix + "norm_distribution.scale_unconstrained"].to(dt))
+        lr = torch.log(r).unsqueeze(-1)
+        lpn = (-((lr - mu) ** 2) / (2 * sigma ** 2) - sigma.log() - math.log(math.sqrt(2 * math.pi)) - lr).sum(-1)
+    elif spec.radial_norm == "gammamm":
+        lpn = gammamm_log_prob(sd, r, prefix + "norm_distribution.")
+    else:
+        raise ValueError(spec.radial_norm)
+    D = math.prod(spec.in_dims)
+    if p == 1:
+        log_dv = math.log(2) * D + torch.log(r) * (D - 1) - sum(math.log(i) for i in range(1, D))
+    elif p == 2:
+        log_dv = (math.log(D) + (D / 2) * math.log(math.pi) + (D - 1) * torch.log(r)) - math.lgamma(D / 2 + 1)
+    else:
+        log_dv = math.log(D) + D * math.log(2) + (D - 1) * torch.log(r)
+    return lpn - log_dv
+
+
 def flow_log_prob(sd, spec: ImageSpec, x):
-    """Flow.log_prob (flows.py:225-245) with the Laplace(0, 1) base of the golden cases"""
+    """Flow.log_prob (flows.py:225-245): Laplace(0, 1) base of the first golden cases, or the live configurations' radial base"""
     z, log_det = flow_backward(sd, spec, x, return_logdet=True)
-    return laplace_log_prob(z) + log_det
+    return (radial_log_prob(sd, spec, z) if spec.base == "radial" else laplace_log_prob(z)) + log_det
 
 
 def total_ladj(sd, spec: ImageSpec):

@@ -16,7 +16,7 @@ def case_names(small_only=False):
     # (the BASELINE cfg4 fixture -- 1.28 G parameters regenerated from the seed -- is loaded by name in
     # tests/test_configs_gpu.py only: far too big for the per-case loops)
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "fitsophia_", "sophia_")) and "cfg4" not in p)
+                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "imageradial_", "imageradialfit_", "fitsophia_", "sophia_")) and "cfg4" not in p)
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -131,3 +131,58 @@ def load_image_fit(name):
     z = np.load(os.path.join(GOLDEN_DIR, "imagefit_" + name[len("image_"):] + ".npz"), allow_pickle=False)
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
     return torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd
+
+
+def image_radial_case_names():
+    """the reference's LIVE image configurations (radial base with an image-shaped loc, prior_scale 1.0):
+    tests/golden/make_golden_image_radial.py"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "imageradial_*.npz")))
+
+
+def image_radial_fit_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "imageradialfit_*.npz")))
+
+
+def build_image_radial_flow(spec, base_sd, device="cpu"):
+    """the mirror's USFlow of a live-configuration case: constructor calls as the YAML makes them (mnist.yaml:44-92), layer
+    parameters from tests/image_synth.py, the base distribution's stored parameters loaded"""
+    from usflows_amd import distributions as D
+    from usflows_amd.flows import USFlow
+    from usflows_amd.networks import ConvNet2D
+    from image_synth import synth_image_params_
+    dims = spec["in_dims"]
+    torch.manual_seed(spec["seed"])
+    if spec["base"] == "lognormal":
+        nd = D.LogNormal(loc=torch.ones([1]) * 6, scale=torch.ones([1]) * .35, device="cpu")
+    else:
+        nd = D.GammaMM(concentration=torch.rand([20]) * 75, rate=torch.rand([20]), mixture_weights=torch.ones([20]) / 20, device="cpu")
+    base = D.RadialDistribution(device="cpu", p=float(spec["p"]), loc=torch.zeros(list(dims)), norm_distribution=nd)
+    flow = USFlow(base, list(dims), spec["coupling_blocks"], ConvNet2D, dict(spec["cond_args"], c_in=dims[0]),
+                  prior_scale=spec["prior_scale"], lu_transform=1, householder=0, affine_conjugation=True, nonlinearity=torch.nn.ReLU())
+    synth_image_params_(flow, spec["seed"])
+    res = flow.load_state_dict(base_sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    if device != "cpu":
+        flow = flow.to(device)
+    return flow
+
+
+def load_image_radial_case(name, device="cpu"):
+    """(mirror flow, arrays, {parameter name: fp64 gradient of -log_prob(x).mean() - log_prior()}, spec)"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    spec = json.loads(str(z["spec"]))
+    base_sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    flow = build_image_radial_flow(spec, base_sd, device)
+    arrays = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith(("sd/", "g/")) and k != "spec"}
+    grads = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}
+    return flow, arrays, grads, spec
+
+
+def load_image_radial_fit(name, device="cpu"):
+    """(mirror flow at the run's start, training rows, per-epoch losses, state dict after the reference's 6 SophiaG steps)"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    spec = json.loads(str(z["spec"]))
+    base_sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0/")}
+    flow = build_image_radial_flow(spec, base_sd, device)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return flow, torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd

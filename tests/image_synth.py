@@ -14,6 +14,8 @@ import torch
 def synth_image_params_(flow, seed: int, alpha: float = 0.3):
     with torch.no_grad():
         for i, (name, p) in enumerate(flow.named_parameters()):
+            if name.startswith("base_distribution."):
+                continue        # (a trainable base -- RadialDistribution and its norm distribution -- keeps its constructor values)
             g = torch.Generator().manual_seed(1_000_003 * seed + i)
             u = lambda *shape: torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1           # noqa: E731  U(-1, 1)
             leaf = name.rsplit(".", 1)[-1]

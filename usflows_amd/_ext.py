@@ -18,11 +18,13 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 29
+USF_ABI_VERSION = 30
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
 BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
+NORM_LOGNORMAL, NORM_GAMMA, NORM_RAW_PARAMS = 0, 1, 0x100
+RADIAL_MAX_K = 64
 OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES, OP_GATED_NORM, OP_CALL = 1, 2, 5, 6, 7, 9, 10
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -166,6 +168,11 @@ SYMBOLS = {
                                       C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_radial_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
                                         C.c_uint64, C.c_int64, C.c_void_p]),
+    "usf_radial_logprob_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int32, C.c_int32, _fp, _fp, _fp,
+                                         C.c_double, C.c_float, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "usf_radial_logprob_grad_workspace": (C.c_int64, [C.c_int64, C.c_int64]),
+    "usf_radial_logprob_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, C.c_int32, C.c_int32,
+                                              _fp, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_variates_from_bits_f32": (C.c_int, [_fp, C.c_int64, _fp, _fp, _fp, C.c_void_p]),
     "usf_scale_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_void_p]),
     "usf_affine_coupling_apply_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64,
@@ -262,6 +269,11 @@ def load() -> C.CDLL:
 
 
 def check(rc: int, what: str = "") -> None:
+    cl = getattr(_tls, "calls", None)
+    if cl is not None and what.startswith("usf_") and what not in CALL_FNS:
+        # a library call with no USF_OP_CALL form ran inside a pass that is being recorded as an op list: a replay of the
+        # list would skip it -- the pass is not replayable (Flow._layer_loop_listed keeps the eager loop)
+        cl.bad = cl.bad or what
     if rc != 0:
         msg = load().usf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"usflows_amd HIP call failed ({what}, rc={rc}): {msg}")
@@ -327,7 +339,7 @@ def _timed_call(fn, args, name):
 # ---- a layer loop's calls as ONE op list (USF_OP_CALL; flows.py: image-shaped flows) ------------------------------------
 CALL_FNS = {"usf_scale_f32": 1, "usf_channel_affine_f32": 2, "usf_layernorm_channels_f32": 3, "usf_gated_residual_f32": 4,
             "usf_masked_residual_f32": 5, "usf_pointwise_conv_f32": 6, "usf_conv2d_same_f32": 7, "usf_conv2d_same_res_f32": 8,
-            "usf_base_logprob_f32": 9}
+            "usf_base_logprob_f32": 9, "usf_radial_logprob_f32": 10}
 
 
 class CallList:
@@ -348,6 +360,9 @@ class CallList:
         for v, t in zip(args[:-1], types):
             if t is C.c_float:
                 words.append(struct.unpack("<I", struct.pack("<f", float(v)))[0])
+                is_ptr.append(False)
+            elif t is C.c_double:
+                words.append(struct.unpack("<Q", struct.pack("<d", float(v)))[0])
                 is_ptr.append(False)
             elif t in (C.c_void_p, _fp):
                 words.append(int(v) if v else 0)
@@ -498,6 +513,29 @@ def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None
     _launch("usf_base_logprob_f32", (z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), float(logdet_const),
                                      ptr(logdet_dev), out.data_ptr(), ptr(sum_out), current_stream(z.device)),
             keep=logdet_dev)
+
+
+def radial_logprob(z, ldz, M, D, p_id, loc, norm, K, par_a, par_b, logits, logdv_const, logdet_const, out, r_out=None, sum_out=None,
+                   logdet_dev=None):
+    """usf_radial_logprob_f32: RadialDistribution.log_prob of the rows of z in one launch (include/usflows_hip.h); z None:
+    the radii are given in r_out"""
+    _launch("usf_radial_logprob_f32", (ptr(z), ldz, M, D, int(p_id), ptr(loc), int(norm), int(K), par_a.data_ptr(),
+                                       par_b.data_ptr(), ptr(logits), float(logdv_const), float(logdet_const), ptr(logdet_dev),
+                                       out.data_ptr(), ptr(r_out), ptr(sum_out), current_stream(out.device)),
+            keep=(z, loc, par_a, par_b, logits, logdet_dev, out, r_out, sum_out))
+
+
+def radial_logprob_grad(z, ldz, r, g_lp, M, D, p_id, loc, norm, K, par_a, par_b, logits, g, ldg, d_loc=None, d_a=None, d_b=None,
+                        d_logits=None):
+    """usf_radial_logprob_grad_f32 (the workspace is allocated here and kept alive by the tape / the caller's stream order)"""
+    lib = load()
+    ws_n = max(8, lib.usf_radial_logprob_grad_workspace(max(M, 1), D))
+    ws = torch.empty((ws_n + 7) // 8, dtype=torch.float64, device=r.device)
+    _launch("usf_radial_logprob_grad_f32", (ptr(z), ldz, r.data_ptr(), g_lp.data_ptr(), M, D, int(p_id), ptr(loc),
+                                            int(norm), int(K), par_a.data_ptr(), par_b.data_ptr(), ptr(logits), g.data_ptr(), ldg,
+                                            ptr(d_loc), ptr(d_a), ptr(d_b), ptr(d_logits), ws.data_ptr(), ws.numel() * 8,
+                                            current_stream(r.device)),
+            keep=(z, r, g_lp, loc, par_a, par_b, logits, g, d_loc, d_a, d_b, d_logits, ws))
 
 
 def base_sample(z, ldz, M, D, base, loc, scale, seed, offset, row_offset=0):

@@ -106,6 +106,14 @@ int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int6
              hipStream_t stream);
 int base_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
               const float* scale, float* g, int64_t ldg, hipStream_t stream);
+int radial_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t p_id, const float* loc, int32_t norm, int32_t K,
+                   const float* par_a, const float* par_b, const float* logits, double logdv_const, float logdet_const,
+                   const double* logdet_dev, float* logp, float* r_out, double* sum_out, hipStream_t stream);
+int64_t radial_grad_workspace(int64_t M, int64_t D);
+int radial_grad(const float* z, int64_t ldz, const float* r, const float* g_lp, int64_t M, int64_t D, int32_t p_id,
+                const float* loc, int32_t norm, int32_t K, const float* par_a, const float* par_b, const float* logits, float* g,
+                int64_t ldg, float* d_loc, float* d_a, float* d_b, float* d_logits, void* workspace, int64_t workspace_bytes,
+                hipStream_t stream);
 
 }  // namespace usf
 
@@ -336,6 +344,22 @@ int usf_base_logprob_grad_f32(const float* z, int64_t ldz, const float* g_lp, in
   return usf::base_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg, (hipStream_t)stream);
 }
 
+int usf_radial_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t p_id, const float* loc, int32_t norm,
+                           int32_t K, const float* par_a, const float* par_b, const float* logits, double logdv_const,
+                           float logdet_const, const double* logdet_dev, float* logp, float* r_out, double* sum_out,
+                           usf_stream_t stream) {
+  return usf::radial_logprob(z, ldz, M, D, p_id, loc, norm, K, par_a, par_b, logits, logdv_const, logdet_const, logdet_dev, logp,
+                             r_out, sum_out, (hipStream_t)stream);
+}
+int64_t usf_radial_logprob_grad_workspace(int64_t M, int64_t D) { return usf::radial_grad_workspace(M, D); }
+int usf_radial_logprob_grad_f32(const float* z, int64_t ldz, const float* r, const float* g_lp, int64_t M, int64_t D, int32_t p_id,
+                                const float* loc, int32_t norm, int32_t K, const float* par_a, const float* par_b,
+                                const float* logits, float* g, int64_t ldg, float* d_loc, float* d_a, float* d_b, float* d_logits,
+                                void* workspace, int64_t workspace_bytes, usf_stream_t stream) {
+  return usf::radial_grad(z, ldz, r, g_lp, M, D, p_id, loc, norm, K, par_a, par_b, logits, g, ldg, d_loc, d_a, d_b, d_logits,
+                          workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // USF_OP_CALL: the recorded arguments back into the entry point's prototype
 static int run_call(const usf_call_desc* c, usf_stream_t stream) {
   const uint64_t* a = c->a;
@@ -344,8 +368,9 @@ static int run_call(const usf_call_desc* c, usf_stream_t stream) {
 #define I(i) ((int64_t)a[i])
 #define J(i) ((int32_t)a[i])
   auto F = [&](int i) { float f; uint32_t u = (uint32_t)a[i]; memcpy(&f, &u, 4); return f; };
-  static const int nargs[] = {0, 8, 8, 10, 5, 7, 16, 17, 16, 11};
-  if (c->fn < 1 || c->fn > USF_FN_BASE_LOGPROB || c->n_args != nargs[c->fn]) {
+  auto Dbl = [&](int i) { double d; uint64_t u = a[i]; memcpy(&d, &u, 8); return d; };
+  static const int nargs[] = {0, 8, 8, 10, 5, 7, 16, 17, 16, 11, 17};
+  if (c->fn < 1 || c->fn > USF_FN_RADIAL_LOGPROB || c->n_args != nargs[c->fn]) {
     usf::set_error("usf_run_ops: call op with unknown function %d or %d arguments", c->fn, c->n_args);
     return -2;
   }
@@ -369,6 +394,10 @@ static int run_call(const usf_call_desc* c, usf_stream_t stream) {
     case USF_FN_BASE_LOGPROB:
       return usf_base_logprob_f32(P(0), I(1), I(2), I(3), J(4), P(5), P(6), F(7), reinterpret_cast<const double*>((uintptr_t)a[8]), Q(9),
                                   reinterpret_cast<double*>((uintptr_t)a[10]), stream);
+    case USF_FN_RADIAL_LOGPROB:
+      return usf_radial_logprob_f32(P(0), I(1), I(2), I(3), J(4), P(5), J(6), J(7), P(8), P(9), P(10), Dbl(11), F(12),
+                                    reinterpret_cast<const double*>((uintptr_t)a[13]), Q(14), Q(15),
+                                    reinterpret_cast<double*>((uintptr_t)a[16]), stream);
   }
 #undef P
 #undef Q

@@ -564,7 +564,16 @@ class Flow(torch.nn.Module):
         train = torch.is_grad_enabled() and (y.requires_grad or _needs_grad(self, y, None))
         if train and (y.dim() < 3 or os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") == "0"):
             return None                                  # (flat flows train through training.py; image flows: below)
+        if train and logdet_dev is not None:
+            return None                                  # (the differentiable forms below do not add the constant: the caller subtracts it)
         d, n_ind = self.base_distribution, 0
+        if isinstance(d, RadialDistribution):
+            # the Lp-radial base of the live image configurations (mnist.yaml:79-92, fashionclasses_veriflow.yaml:79-93):
+            # radius, norm density, volume term -- and in training their gradients -- on usf_radial_logprob(_grad)_f32
+            if os.environ.get("USFLOWS_AMD_RADIAL", "1") == "0":
+                return None
+            from . import radial
+            return radial.log_prob(d, y, logdet_dev=logdet_dev)
         if isinstance(d, DistributionModule):
             return None
         while isinstance(d, tdist.Independent):
@@ -614,6 +623,12 @@ class Flow(torch.nn.Module):
             base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
             _ext.base_logprob(zbuf, ldz, B, eng.D, base, info[1], info[2], 0.0, out, sum_out, logdet_dev=logdet.neg_dev)
             return out
+        if os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0":
+            # radius + norm density + volume term + log-det constant (+ the data-parallel sums) in one launch
+            from . import radial
+            res = radial.log_prob(self.base_distribution, zbuf, logdet_dev=logdet.neg_dev, sum_out=sum_out, ldz=ldz)
+            if res is not None:
+                return res
         p = info[2]
         base = {1.0: _ext.BASE_LPNORM1, 2.0: _ext.BASE_LPNORM2}.get(p, _ext.BASE_LPNORMINF)
         _ext.base_logprob(zbuf, ldz, B, eng.D, base, info[1], None, 0.0, out, None)
@@ -655,12 +670,37 @@ class Flow(torch.nn.Module):
                 z = self.base_distribution.sample(shape).to(dev).reshape(n, eng.D).float()
             x = eng.transform(z, "forward")
             return x.reshape(*shape, eng.D)
-        if dev.type == "cuda" and not _needs_grad(self) and self.engine() is None:
-            self._warn_composite("Flow.sample")
-        y = self.base_distribution.sample(sample_shape)
+        y = None
+        if dev.type == "cuda" and context is None and not _needs_grad(self) and self.engine() is None:
+            y = self._radial_sample_image(tuple(sample_shape), dev, seed, row_offset)
+        if y is None:
+            if dev.type == "cuda" and not _needs_grad(self) and self.engine() is None:
+                self._warn_composite("Flow.sample")
+            y = self.base_distribution.sample(sample_shape)
         for layer in self.layers:
             y = layer.forward(y, context=context) if context is not None else layer.forward(y)
         return y
+
+    def _radial_sample_image(self, shape, dev, seed, row_offset):
+        """z ~ RadialDistribution with an image-shaped loc [C, H, W] (the live configurations' base: mnist.yaml:79-92) on
+        the Philox kernel: radii from the norm distribution (O(n) torch work), directions on the unit Lp sphere over the
+        FLATTENED event (distributions.py:474-499: u.reshape(*sample_shape, *loc.shape)) from usf_radial_sample_f32.
+        None: not this kind of base"""
+        b = self.base_distribution
+        if not (isinstance(b, RadialDistribution) and b.n_batch_dims == 0 and b.loc.is_cuda and b.loc.dtype == torch.float32
+                and float(b.p) in (1.0, 2.0, float("inf")) and os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0"):
+            return None
+        n = int(np.prod(shape)) if len(shape) else 1
+        D = int(b.loc.numel())
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        with torch.no_grad():
+            r = b.norm_distribution.sample((n,)).reshape(n).to(device=dev, dtype=torch.float32).contiguous()
+            z = torch.empty(n, D, dtype=torch.float32, device=dev)
+            if n > 0:
+                base = {1.0: _ext.BASE_LPNORM1, 2.0: _ext.BASE_LPNORM2}.get(float(b.p), _ext.BASE_LPNORMINF)
+                _ext.radial_sample(z, D, n, D, base, b.loc.detach().reshape(-1).contiguous(), r, seed, 0, row_offset)
+        return z.reshape(*shape, *b.loc.shape)
 
     def _param_device(self) -> torch.device:
         for p in self.parameters():
@@ -766,13 +806,19 @@ class Flow(torch.nn.Module):
             return None               # (optimisers whose step is known to be free of host synchronisation)
         if any(g_.get("capturable") for g_ in optim.param_groups if isinstance(optim, SophiaG)):
             return None
-        # bases that build a fresh, argument-validating torch distribution on every log_prob (DistributionModule:
-        # RadialDistribution with its norm distribution) read a flag back to the host inside the step, and a parameter
-        # prior (prior_scale) is evaluated by host-side torch code: neither survives a stream capture -- eager steps
+        # bases that build a fresh, argument-validating torch distribution on every log_prob (DistributionModule) read a
+        # flag back to the host inside the step: no stream capture -- unless the density runs on the radial kernels
+        # (radial.py: RadialDistribution over LogNormal / Gamma / GammaMM / LogNormalMM, every live configuration's base),
+        # which never build the distribution object.  (prior_scale: USFlow.log_prior() sums the LAYERS' priors and
+        # BlockAffineTransform inherits BaseTransform.log_prior == 0.0 -- transforms.py:62-64, 874-1029 -- so the term is
+        # the number 0.0 for every flow USFlow builds; a layer list with a tensor-valued prior is torch ops on parameters,
+        # which a capture records like any other.)
         base = self.base_distribution
-        if isinstance(base, DistributionModule) or getattr(self, "prior_scale", None) is not None or \
+        if isinstance(base, DistributionModule) or \
                 (isinstance(base, torch.nn.Module) and any(isinstance(m_, DistributionModule) for m_ in base.modules())):
-            return None
+            from . import radial
+            if os.environ.get("USFLOWS_AMD_RADIAL", "1") == "0" or radial.radial_spec(base, sample.device) is None:
+                return None
         with torch.enable_grad():
             if self._train_path(sample, noise) is not None:
                 # flat flows with a device backward (training.py): the step is ~850 dependent launches of a few microseconds

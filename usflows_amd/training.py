@@ -27,6 +27,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import _ext
@@ -1049,7 +1051,11 @@ def log_prob_with_grad(path: TrainPath, x, context):
     if info[0] == "radial":
         base = path.flow.base_distribution
         r, logdet = _RadiusFn.apply(path, x, context, base.loc, *params)
-        return base.log_prob_from_radius(r) + logdet
+        lp = None
+        if os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0":
+            from . import radial
+            lp = radial.log_prob_from_radius(base, r)      # (one launch each way, no validating distribution object)
+        return (base.log_prob_from_radius(r) if lp is None else lp) + logdet
     if path.grads_bound() and torch.is_grad_enabled():
         return _LogProbFn.apply(path, x, context, path._anchor)
     return _LogProbFn.apply(path, x, context, *params)
