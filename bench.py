@@ -14,6 +14,15 @@ blocks, LeakyReLU MLP conditioner [256,256], Laplace base) at batch 65536 per GP
                            ConvNet2D conditioner, 2 blocks), 65536 rows per GPU
     --config cifar_image   the reference's CIFAR experiment model (experiments/cifar/cifar.yaml:56-77: in_dims [48, 8, 8],
                            10 blocks), 16384 rows per GPU
+    --config mnist_live    the LIVE MNIST configuration (experiments/mnist/mnist.yaml:44-92: 15 blocks, 3 gated layers,
+                           RadialDistribution(zeros[16,7,7], p=1, LogNormal(6, .35)) base, prior_scale 1.0), 65536 rows per GPU
+    --config fashion_live  experiments/fashion/fashionclasses_veriflow.yaml:55-93 (10 blocks, GammaMM x 20 radial base)
+    (image configurations: --base radial|laplace, --radial-norm lognormal|gammamm, --prior-scale choose the base / prior;
+     mnist_image / cifar_image default to the Laplace base of rounds 2-3, the *_live ones to their YAML's radial base)
+
+With no flags at N = 1 the line also carries an "also" block: the other BASELINE configurations, the image models and the
+training steps measured in the same process after the headline (bounded steps each), so that every number DESIGN.md quotes
+has the driver's clock around it.
 
 One "step" = one full pass of the hot path over this rank's resident batch (inputs already in HBM)
 + the scalar mean-log_prob all-reduce.  Prints ONE JSON line (rank 0) with the whole-job
@@ -52,6 +61,13 @@ IMAGE_CONFIGS = {
                         cond=dict(c_in=16, c_hidden=32, num_layers=1, padding="same", kernel_size=3, normalize_layers=True, gating=True)),
     "cifar_image": dict(in_dims=[48, 8, 8], blocks=10, householder=0, rows=16384, ref="experiments/cifar/cifar.yaml:56-77",
                         cond=dict(c_in=48, c_hidden=32, num_layers=3, padding="same", kernel_size=3, normalize_layers=True, gating=True)),
+    # the live configurations as HyperoptExperiment._trial trains them: radial base, prior_scale 1.0, full depth
+    "mnist_live": dict(in_dims=[16, 7, 7], blocks=15, householder=0, rows=65536, ref="experiments/mnist/mnist.yaml:44-92",
+                       base="radial", radial_norm="lognormal", prior_scale=1.0,
+                       cond=dict(c_in=16, c_hidden=32, num_layers=3, padding="same", kernel_size=3, normalize_layers=True, gating=True)),
+    "fashion_live": dict(in_dims=[16, 7, 7], blocks=10, householder=0, rows=65536, ref="experiments/fashion/fashionclasses_veriflow.yaml:55-93",
+                         base="radial", radial_norm="gammamm", prior_scale=1.0,
+                         cond=dict(c_in=16, c_hidden=32, num_layers=3, padding="same", kernel_size=3, normalize_layers=True, gating=True)),
 }
 
 
@@ -82,9 +98,17 @@ def parse_args(argv=None):
     ap.add_argument("--no-merge-affine", action="store_true", help="never compose consecutive affine maps")
     ap.add_argument("--optim", choices=["sophia", "adam"], default="sophia",
                     help="--mode train: SophiaG (the reference's Flow.fit default) or torch's Adam")
-    ap.add_argument("--mode", choices=["log_prob", "sample", "train"], default=None,
+    ap.add_argument("--mode", choices=["log_prob", "sample", "train", "fit"], default=None,
                     help="sample: time Flow.sample (Philox head + forward pass); train: one optimiser step of Flow.fit's "
-                         "loss (-log_prob.mean(): device forward + backward + Adam)")
+                         "loss (-log_prob.mean(): device forward + backward + optimiser); fit (flat configurations): the same "
+                         "step as Flow.fit issues it on its own stream -- captured as a hipGraph and replayed at small batches")
+    ap.add_argument("--base", choices=["laplace", "radial"], default=None,
+                    help="image configurations: Laplace(0, 1) base or RadialDistribution(zeros[C,H,W], p=1, norm) -- the live YAMLs' base")
+    ap.add_argument("--radial-norm", choices=["lognormal", "gammamm"], default=None,
+                    help="--base radial: LogNormal(6, .35) (mnist.yaml:79-92) or GammaMM x 20 (fashionclasses_veriflow.yaml:79-93)")
+    ap.add_argument("--prior-scale", type=float, default=None, help="image configurations: USFlow(prior_scale=...) (live YAMLs: 1.0)")
+    ap.add_argument("--no-also", action="store_true", help="default invocation: skip the \"also\" block")
+    ap.add_argument("--seed", type=int, default=100, help="seed of the synthetic parameters")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the short CPU sample (second cpu_baseline figure)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--cpu-full-iters", type=int, default=3, help="full-batch iterations of the CPU baseline (median)")
@@ -118,9 +142,107 @@ def main():
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # started by torch.distributed.run
     if args.gpus > 1 and not under_launcher:
         sys.exit(launch_ranks(args))
+    out = run_config(args, under_launcher)
+    if out is None:                 # (a rank other than 0)
+        return
+    default_line = (len(sys.argv) == 1 or all(a.split("=")[0] in ("--gpus", "--steps", "--warmup") or a.lstrip("-").isdigit()
+                                             for a in sys.argv[1:]))
+    if default_line and args.gpus == 1 and not under_launcher and not args.no_also and args.device == "cuda":
+        out["also"] = run_also(args)
+    print(json.dumps(out), flush=True)
+
+
+ALSO = [
+    # (label, argv) -- measured in this process after the headline; bounded steps; the CPU legs on small samples
+    ("cfg4 log_prob (D=3072, 48 blocks, 32768 rows; golden rows of the real reference at head/middle/tail)",
+     ["--config", "cfg4", "--steps", "3", "--warmup", "1", "--no-fast-mode", "--no-cpu-baseline", "--seed", "102"]),
+    ("cfg5 per-rank share: sample() of 125000 draws (rank 0's Philox substream) + UDL check",
+     ["--config", "cfg5", "--batch", "125000", "--steps", "3", "--warmup", "1"]),
+    ("mnist_image log_prob, Laplace base (rounds 2-3 workload)",
+     ["--config", "mnist_image", "--steps", "10", "--warmup", "3", "--cpu-seconds", "2", "--cpu-rows", "2048"]),
+    ("mnist_live log_prob: the live MNIST configuration (15 blocks, 3 gated layers, radial LogNormal base)",
+     ["--config", "mnist_live", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "256"]),
+    ("cifar_image log_prob, live base (radial LogNormal, prior_scale 1)",
+     ["--config", "cifar_image", "--base", "radial", "--prior-scale", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "128"]),
+    ("cfg2 training step at 65536 rows (forward + backward + SophiaG)",
+     ["--config", "cfg2", "--mode", "train", "--steps", "5", "--warmup", "2"]),
+    ("cfg2 Flow.fit step at batch 32 (the reference's training batch), replayed hipGraph",
+     ["--config", "cfg2", "--mode", "fit", "--batch", "32", "--steps", "30", "--warmup", "6"]),
+    ("mnist_image training step at 65536 rows, live base (radial LogNormal, prior_scale 1)",
+     ["--config", "mnist_image", "--mode", "train", "--base", "radial", "--prior-scale", "1", "--steps", "5", "--warmup", "5",
+      "--cpu-seconds", "1", "--cpu-rows", "512"]),
+    ("mnist_image Flow.fit step at batch 32, live base, replayed hipGraph",
+     ["--config", "mnist_image", "--mode", "train", "--base", "radial", "--prior-scale", "1", "--batch", "32", "--steps", "50", "--warmup", "6",
+      "--cpu-seconds", "1"]),
+    ("mnist_live Flow.fit step at batch 32: what HyperoptExperiment._trial runs (mnist.yaml:30-92), replayed hipGraph",
+     ["--config", "mnist_live", "--mode", "train", "--batch", "32", "--steps", "30", "--warmup", "6", "--cpu-seconds", "1"]),
+]
+
+
+def run_also(args):
+    """the other workloads DESIGN.md quotes, each measured by run_config in this process (same contract: W warm-up steps,
+    K timed steps, device-synchronised), condensed to value / ms_per_step / dominant-kernel roofline / parity"""
+    import gc
+    out = []
+    t_all = time.perf_counter()
+    for label, argv in ALSO:
+        t0 = time.perf_counter()
+        rec = {"workload": label, "argv": " ".join(argv)}
+        try:
+            a = parse_args(argv)
+            if a.config == "cfg4":
+                a.probe_rows = _golden_probe("synth_d3072_k48_cfg4", a.seed)
+            o = run_config(a, False)
+            rl = o.get("roofline") or {}
+            cb = o.get("cpu_baseline") or {}
+            parity = {}
+            if cb.get("parity_max_rel_vs_cpu_fp32") is not None:
+                parity["max_rel_vs_cpu_fp32_oracle"] = cb["parity_max_rel_vs_cpu_fp32"]
+                parity["rows"] = cb.get("parity_rows")
+            for k in ("probe_parity", "train_parity", "udl_check"):
+                if o.get(k):
+                    parity[k] = o[k]
+            rec.update({"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                        "steps": o["steps"], "warmup": o["warmup"], "rows_per_gpu": o["config"]["rows_per_gpu"],
+                        "roofline": {k: rl.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                            "share_of_gpu_time", "kernel_ms_per_step")} if rl else None,
+                        "parity": parity or None, "train_step": o.get("train_step"),
+                        "cpu_baseline": ({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None),
+                        "mean_log_prob": o.get("mean_log_prob")})
+        except Exception as e:      # noqa: BLE001 -- one failing extra must not cost the headline its line
+            rec["error"] = f"{type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}"
+        rec["wall_s"] = round(time.perf_counter() - t0, 1)
+        out.append(rec)
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    return {"what": "measured in this process after the headline (bench.py run_also); every entry: W untimed warm-up steps, K timed "
+                    "steps between device synchronisations, inputs resident in HBM",
+            "wall_s": round(time.perf_counter() - t_all, 1), "entries": out}
+
+
+def _golden_probe(name, seed):
+    """(x rows, the real reference's fp64 log_prob of them) of a committed golden fixture whose parameters are this
+    generator's at `seed` (tests/golden/make_golden.py); None when the fixture is absent"""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.isfile(path):
+        return None
+    z = np.load(path, allow_pickle=False)
+    if int(z["seed"]) != int(seed) or abs(float(z["alpha"]) - 0.1) > 1e-12:
+        return None
+    return torch.from_numpy(z["x"]), torch.from_numpy(z["log_prob64"])
+
+
+def run_config(args, under_launcher):
+    """one configuration measured in this process; the JSON line's dict on rank 0, None on the other ranks"""
     if args.config in IMAGE_CONFIGS:
         return main_image(args, under_launcher)
+    return main_flat(args, under_launcher)
 
+
+def main_flat(args, under_launcher):
     cfg = CONFIGS[args.config]
     mode = args.mode or cfg["mode"]
     D = args.dim or cfg["dim"]
@@ -150,7 +272,7 @@ def main():
 
     spec = ModelSpec(D, blocks, hidden, householder=args.householder, affine_conjugation=args.conj,
                      negative_slope=0.01, conditioner="ConditionalDenseNN", base="laplace")
-    sd = synth_state_dict(spec, seed=100, alpha=0.1)         # same parameters on every rank
+    sd = synth_state_dict(spec, seed=args.seed, alpha=0.1)   # same parameters on every rank
     flow = build_usflow(spec, sd, device=str(dev))
     eng = flow.engine() if on_gpu else None
     if on_gpu:
@@ -181,16 +303,45 @@ def main():
         x = torch.rand(B, D, generator=g).to(dev)           # this rank's shard, resident in HBM
     acc = torch.zeros(2, dtype=torch.float64, device=dev)
 
+    # rows of the REAL reference's golden run placed at the head / middle / tail of the batch (the fixture's parameters are
+    # this generator's at the fixture's seed): parity of configurations whose oracle call would take minutes (cfg4)
+    probe = None
+    if getattr(args, "probe_rows", None) is not None and x is not None:
+        px, plp = args.probe_rows
+        n = px.shape[0]
+        a_, b_ = n // 3, 2 * (n // 3)
+        pidx = torch.cat([torch.arange(0, a_), torch.arange(B // 2 - (b_ - a_) // 2, B // 2 - (b_ - a_) // 2 + (b_ - a_)),
+                          torch.arange(B - (n - b_), B)])
+        x[pidx.to(dev)] = px.to(dev)
+        probe = (pidx.to(dev), plp)
+
     opt = None
-    if mode == "train":
+    if mode in ("train", "fit"):
         # the optimiser Flow.fit defaults to (flows.py:116): SophiaG -- one multi-tensor HIP launch per step on the GPU
         from usflows_amd.sophia import SophiaG
         opt = SophiaG(flow.parameters(), lr=1e-6) if args.optim == "sophia" else torch.optim.Adam(flow.parameters(), lr=1e-6)
-    if mode == "train" and under_launcher and world > 1:
+    if mode in ("train", "fit") and under_launcher and world > 1:
         from usflows_amd.parallel import data_parallel_training
         data_parallel_training(flow)                       # one all-reduce of the flat gradient arena per step
+    fit_replays = [0]
+
+    def fit_step():
+        # what Flow._fit_epochs does per batch (usflows_amd/flows.py): the replayed graph when there is one, else an eager step
+        loss = flow._train_graph_step(opt, x, None) if world == 1 else None
+        if loss is not None:
+            fit_replays[0] += 1
+            return torch.tensor(-loss, dtype=torch.float64), None
+        flow._zero_grad_for_step(opt)
+        lp_ = flow.log_prob(x)
+        loss = -lp_.mean() - flow.log_prior()
+        loss.backward()
+        opt.step()
+        return -loss.detach().double(), lp_.detach()
 
     def step():
+        if mode == "fit":
+            with flow.fit_stream(dev):                      # Flow.fit runs its loop on a stream of the flow's own
+                return fit_step()
         if mode == "train":
             opt.zero_grad(set_to_none=True)
             lp_ = flow.log_prob(x)
@@ -208,9 +359,10 @@ def main():
     mean, lp = step()                                        # includes the one-off parameter prep
     sync()
     prep_s = time.perf_counter() - t_prep0
-    for _ in range(max(args.warmup - 1, 0)):
+    for _ in range(max(args.warmup - 1, 4 if mode == "fit" else 0)):
         step()
-    if on_gpu and not args.no_kernel_timing and mode != "train":
+    fit_replays[0] = 0
+    if on_gpu and not args.no_kernel_timing and mode not in ("train", "fit"):
         eng.op_timing = []
     if on_gpu and not args.no_kernel_timing and mode == "train":
         from usflows_amd import _ext as _ext_t
@@ -274,7 +426,7 @@ def main():
     if rank != 0:
         if under_launcher:
             dist.destroy_process_group()
-        return
+        return None
 
     # ---- roofline of the dominant kernel (per-launch HIP-event durations from the timed region) ----
     roofline = None
@@ -440,19 +592,40 @@ def main():
         eng.pack(dev)
         sync()
         prep_warm_ms = (time.perf_counter() - t_w) * 1e3
+    # training modes: log_prob of head / middle / tail rows after the timed steps, device vs the CPU oracle at the CURRENT parameters
+    train_parity = None
+    if mode in ("train", "fit") and world == 1 and on_gpu and not args.no_cpu_baseline and D <= 1024:
+        from oracle import usflows_oracle as orc      # the CPU oracle: parity leg only
+        n3 = min(64, max(B // 3, 1))
+        tidx = torch.cat([torch.arange(0, n3), torch.arange(B // 2, min(B // 2 + n3, B)), torch.arange(B - n3, B)]).unique()
+        with torch.no_grad():
+            got = flow.log_prob(x)[tidx.to(dev)].double().cpu()
+            sd_now = {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()}
+            torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
+            ref_t = orc.flow_log_prob(sd_now, spec, x[tidx.to(dev)].cpu()).double()
+        train_parity = {"rows": int(tidx.numel()), "placed_at": "head / middle / tail of the batch",
+                        "max_rel_vs_cpu_fp32_oracle": float(((got - ref_t).abs() / ref_t.abs()).max().item()),
+                        "what": "log_prob of the trained-on rows after the timed steps, device vs oracle/usflows_oracle.py at the current parameters"}
+    probe_parity = None
+    if probe is not None and lp is not None and mode == "log_prob":
+        got = lp[probe[0]].double().cpu()
+        probe_parity = {"rows": int(got.numel()), "placed_at": "head / middle / tail of the batch",
+                        "max_rel_vs_reference_fp64": float(((got - probe[1].double()).abs() / probe[1].double().abs()).max().item()),
+                        "reference": "golden rows of the REAL reference's fp64 run (tests/golden, committed fixture)"}
     headline = (args.config == "cfg2" and args.batch is None and args.dim is None and args.blocks is None
                 and args.hidden is None and mode == "log_prob")
     metric = {"log_prob": "log_prob samples/sec (whole node), 32-layer 784-dim flow, batch 65536" if headline else
               f"log_prob samples/sec (whole node), {blocks}-layer {D}-dim flow, {args.config}",
               "sample": f"sample() samples/sec (whole node), {blocks}-layer {D}-dim flow",
-              "train": f"training-step samples/sec (forward + backward + {'SophiaG' if args.optim == 'sophia' else 'Adam'} step), {blocks}-layer {D}-dim flow"}[mode]
+              "train": f"training-step samples/sec (forward + backward + {'SophiaG' if args.optim == 'sophia' else 'Adam'} step), {blocks}-layer {D}-dim flow",
+              "fit": f"Flow.fit optimiser-step samples/sec (forward + backward + {'SophiaG' if args.optim == 'sophia' else 'Adam'} step as Flow.fit issues it), {blocks}-layer {D}-dim flow"}[mode]
     if not on_gpu:
         metric = "[CPU PLUMBING TEST -- not a measurement] " + metric
     if world == 1:
         par = "dp1 (single GPU: no collective)"
     elif mode == "sample":
         par = f"dp{world} (draws sharded by row range, disjoint Philox substreams, no collective)"
-    elif mode == "train":
+    elif mode in ("train", "fit"):
         par = f"dp{world} (batch sharded, one all-reduce of the flat gradient arena per step)"
     else:
         par = f"dp{world} (batch sharded, one all-reduce of 2 fp64 scalars [sum log_prob, count] per step)"
@@ -481,17 +654,21 @@ def main():
            "param_prep_first_call_s": round(prep_s, 3),
            "param_prep_warm_ms": None if prep_warm_ms is None else round(prep_warm_ms, 2),
            "mean_log_prob": float(mean.item()) if mode != "sample" else None,
-           "udl_check": udl,
+           "udl_check": udl, "probe_parity": probe_parity, "train_parity": train_parity,
            "roofline": roofline, "cpu_baseline": cpu, "fast_mode": fast}
-    print(json.dumps(out), flush=True)
+    if mode == "fit":
+        out["train_step"] = {"graph_replays": fit_replays[0], "of_steps": args.steps,
+                             "what": "Flow.fit's optimiser step (zero grads, log_prob, backward, SophiaG update) on its own stream; "
+                                     "captured as a hipGraph after three eager steps (batches <= 4096 rows)"}
     if under_launcher:
         dist.destroy_process_group()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # image-shaped flows
 # ----------------------------------------------------------------------------------------------------------------------
-_IMAGE_KERNELS = ("usf_conv2d_same_f32", "usf_conv2d_same_res_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
+_IMAGE_KERNELS = ("usf_radial_logprob_f32", "usf_radial_logprob_grad_f32", "usf_conv2d_same_f32", "usf_conv2d_same_res_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
                   "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32", "usf_conv_wgrad_f32", "usf_conv2d_same_gate_f32",
                   "usf_layernorm_channels_bwd_f32", "usf_gated_residual_bwd_f32")
 
@@ -529,6 +706,12 @@ def _image_launch_cost(name, a):
     if name == "usf_base_logprob_f32":       # (z, ldz, M, D, ...)
         M, D = int(a[2]), int(a[3])
         return ("base_logprob", D), 4.0 * M * D, 4.0 * M * D
+    if name == "usf_radial_logprob_f32":     # (z, ldz, M, D, ...): one read of the batch
+        M, D = int(a[2]), int(a[3])
+        return ("radial_logprob", D), 4.0 * M * D, 4.0 * M * D
+    if name == "usf_radial_logprob_grad_f32":   # (z, ldz, r, g_lp, M, D, ...): read z, write d/dz, read it once more for d/dloc
+        M, D = int(a[4]), int(a[5])
+        return ("radial_logprob_grad", D), 6.0 * M * D, 12.0 * M * D
     if name == "usf_conv_wgrad_f32":         # (x, dy, B, cin, cout, H, W, ks, ...): exact fp32 on the f32 MFMA
         B, cin, cout, H, W, ks = int(a[2]), int(a[3]), int(a[4]), int(a[5]), int(a[6]), int(a[7])
         return ("conv_wgrad", cin, cout, ks, H, W), 2.0 * B * H * W * cin * cout * ks * ks, 4.0 * B * H * W * (cin + cout)
@@ -566,13 +749,30 @@ def main_image(args, under_launcher):
     from usflows_amd.networks import ConvNet2D
     from usflows_amd.parallel import mean_log_prob
     dims = list(cfg["in_dims"])
-    torch.manual_seed(100)                                           # same parameters on every rank
-    host = USFlow(torch.distributions.Laplace(torch.zeros(dims), torch.ones(dims)), dims, cfg["blocks"], ConvNet2D, dict(cfg["cond"]),
+    base_kind = args.base or cfg.get("base", "laplace")
+    radial_norm = args.radial_norm or cfg.get("radial_norm", "lognormal")
+    prior_scale = args.prior_scale if args.prior_scale is not None else cfg.get("prior_scale")
+    n_blocks = args.blocks or cfg["blocks"]
+
+    def make_base(device):
+        if base_kind == "laplace":
+            return torch.distributions.Laplace(torch.zeros(dims, device=device), torch.ones(dims, device=device))
+        from usflows_amd import distributions as UD
+        # the YAMLs' constructor calls (mnist.yaml:79-92; fashionclasses_veriflow.yaml:79-93), on the CPU, then moved with the flow
+        if radial_norm == "lognormal":
+            nd = UD.LogNormal(loc=torch.ones([1]) * 6, scale=torch.ones([1]) * .35, device="cpu")
+        else:
+            nd = UD.GammaMM(concentration=torch.rand([20]) * 75, rate=torch.rand([20]), mixture_weights=torch.ones([20]) / 20, device="cpu")
+        return UD.RadialDistribution(device="cpu", p=float("1"), loc=torch.zeros(dims), norm_distribution=nd)
+
+    torch.manual_seed(args.seed)                                     # same parameters on every rank
+    host = USFlow(make_base("cpu"), dims, n_blocks, ConvNet2D, dict(cfg["cond"]), prior_scale=prior_scale,
                   householder=cfg["householder"], affine_conjugation=True)
-    _condition_image_flow(host, seed=100)
+    _condition_image_flow(host, seed=args.seed)
     sd_cpu = {k: v.detach().clone() for k, v in host.state_dict().items()}
-    flow = USFlow(torch.distributions.Laplace(torch.zeros(dims, device=dev), torch.ones(dims, device=dev)), dims, cfg["blocks"],
-                  ConvNet2D, dict(cfg["cond"]), householder=cfg["householder"], affine_conjugation=True)
+    torch.manual_seed(args.seed)
+    flow = USFlow(make_base(dev if base_kind == "laplace" else "cpu"), dims, n_blocks,
+                  ConvNet2D, dict(cfg["cond"]), prior_scale=prior_scale, householder=cfg["householder"], affine_conjugation=True)
     flow.load_state_dict(sd_cpu, strict=True)
     flow = flow.to(dev)
     del host
@@ -606,7 +806,7 @@ def main_image(args, under_launcher):
                 return torch.tensor(-loss, dtype=torch.float64), None
             flow._zero_grad_for_step(opt)
             lp_ = flow.log_prob(x)
-            loss = -lp_.mean()
+            loss = -lp_.mean() - flow.log_prior()              # Flow.fit's loss (flows.py:196-198)
             loss.backward()
             if world > 1:
                 from usflows_amd.parallel import allreduce_gradients
@@ -657,7 +857,7 @@ def main_image(args, under_launcher):
     if rank != 0:
         if under_launcher:
             dist.destroy_process_group()
-        return
+        return None
     ms_per_step = elapsed / args.steps * 1e3
     value = global_rows * args.steps / elapsed
 
@@ -704,14 +904,20 @@ def main_image(args, under_launcher):
     # ---- CPU baseline + parity: the image oracle (torch-CPU restatement of the reference's image path) on a bounded
     # sample of the same rows; rank 0 at N = 1 only ----
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and mode == "log_prob":
+    if world == 1 and not args.no_cpu_baseline and mode == "train":
+        with torch.no_grad():               # (outside the timed region) the trained-on rows' log_prob for the parity check
+            lp = flow.log_prob(x)
+    if world == 1 and not args.no_cpu_baseline and lp is not None:
         from oracle import usflows_image_oracle as iorc           # the CPU oracle: this leg only
-        spec = iorc.ImageSpec(in_dims=dims, coupling_blocks=cfg["blocks"], cond_args=dict(cfg["cond"]), householder=cfg["householder"],
-                              affine_conjugation=True)
+        spec = iorc.ImageSpec(in_dims=dims, coupling_blocks=n_blocks, cond_args=dict(cfg["cond"]), householder=cfg["householder"],
+                              affine_conjugation=True, base=base_kind, radial_p=1.0, radial_norm=radial_norm)
         torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
         rows = min(B, args.cpu_rows * 2)
         # head, middle and tail of the batch
-        idx = torch.cat([torch.arange(0, rows // 2), torch.arange(B // 2, B // 2 + rows // 4), torch.arange(B - rows // 4, B)])
+        idx = torch.cat([torch.arange(0, rows // 2), torch.arange(B // 2, B // 2 + rows // 4), torch.arange(B - rows // 4, B)]).unique()
+        if mode == "train":
+            # (a training step's parameters have moved by lr = 1e-6 per step since sd_cpu was taken: the oracle sees the current ones)
+            sd_cpu = {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()}
         xc = x[idx.to(dev)].cpu()
         with torch.no_grad():
             iorc.flow_log_prob(sd_cpu, spec, xc[:32])
@@ -726,20 +932,27 @@ def main_image(args, under_launcher):
         cpu = {"value": round(xc.shape[0] * n_it / cpu_s, 1), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{n_it} x log_prob of {xc.shape[0]} rows of the batch (head, middle, tail) through oracle/usflows_image_oracle.py, {cpu_s:.1f} s",
                "host_cpus": os.cpu_count(), "parity_rows": int(rel.numel()), "parity_max_rel_vs_cpu_fp32": float(rel.max().item())}
+        if mode == "train":
+            cpu["note"] = ("the CPU oracle restates log_prob only: value = the oracle's log_prob rate; parity = log_prob of the "
+                           "trained-on rows after the timed steps, device vs oracle with the current parameters")
 
     hw = dims[1] * dims[2]
     cnd = cfg["cond"]
     what = "log_prob" if mode == "log_prob" else "training-step (log_prob + backward + optimiser step)"
-    out = {"metric": f"{what} samples/sec (whole node), image flow {args.config}", "value": round(value, 1), "unit": "samples/s",
+    out = {"metric": f"{what} samples/sec (whole node), image flow {args.config}" + (f" ({base_kind} base)" if base_kind != "laplace" else ""), "value": round(value, 1), "unit": "samples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (3 x 3 convolutions as bf16x3 split on the bf16 MFMA: 24 significant bits, fp32 accumulate; everything else fp32 VALU)",
            "data": "synthetic", "world_size": world, "backend": backend, "device": str(dev),
-           "config": {"workload": f"{args.config}: USFlow in_dims={dims} ({cfg['ref']}), {cfg['blocks']} additive coupling blocks, "
+           "config": {"workload": f"{args.config}: USFlow in_dims={dims} ({cfg['ref']}), {n_blocks} additive coupling blocks, "
                                   f"ConvNet2D(c_hidden {cnd['c_hidden']}, {cnd['num_layers']} gated layer(s), layer norm, ReLU), lu_transform=1, "
-                                  f"householder={cfg['householder']}, affine_conjugation=True, Laplace(0,1) base (the goldens' base; the "
-                                  f"reference's config draws a radial base); {what} of {B} rows per GPU ({global_rows} over {world} GPU(s)) "
-                                  f"resident in HBM; conditioned synthetic parameters (seed 100)",
+                                  f"householder={cfg['householder']}, affine_conjugation=True, prior_scale={prior_scale}, "
+                                  + ("Laplace(0,1) base (the first goldens' base; the live YAMLs draw a radial base: --base radial)"
+                                     if base_kind == "laplace" else
+                                     f"RadialDistribution(zeros{dims}, p=1, {'LogNormal(6, .35)' if radial_norm == 'lognormal' else 'GammaMM x 20'}) base "
+                                     f"with trainable loc and norm parameters (the live YAMLs' base), density and gradients on usf_radial_logprob(_grad)_f32")
+                                  + f"; {what} of {B} rows per GPU ({global_rows} over {world} GPU(s)) "
+                                  f"resident in HBM; conditioned synthetic parameters (seed {args.seed})",
                       "rows_per_gpu": B, "global_rows": global_rows, "pixels": hw,
                       "parallelism": "dp1 (single GPU: no collective)" if world == 1 else
                                      f"dp{world} (batch sharded, one all-reduce of 2 fp64 scalars [sum log_prob, count] per step)"},
@@ -747,9 +960,9 @@ def main_image(args, under_launcher):
     if mode == "train":
         out["train_step"] = {"graph_replays": graph_steps[0], "of_steps": args.steps,
                              "what": "Flow.fit's optimiser step (zero grads, log_prob, backward, SophiaG update) on the resident batch"}
-    print(json.dumps(out), flush=True)
     if under_launcher:
         dist.destroy_process_group()
+    return out
 
 
 def _condition_image_flow(flow, seed, alpha=0.3):

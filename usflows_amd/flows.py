@@ -725,20 +725,28 @@ class Flow(torch.nn.Module):
         optim = optim(model.parameters(), **optim_params) if optim_params is not None else optim(model.parameters())
         N = len(data_train)
         epoch_losses = []
-        # On a GPU the whole loop runs on a stream of the flow's own (created once): the launch tapes of the device training
-        # path record the stream they were made on, and a training step can only be captured into a hipGraph on that very
-        # stream (a capture does not reach over to another one) -- never torch's legacy default stream.
+        with self.fit_stream(device):
+            self._fit_epochs(model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses)
+        return epoch_losses
+
+    @contextlib.contextmanager
+    def fit_stream(self, device):
+        """On a GPU the whole loop of ``fit`` runs on a stream of the flow's own (created once): the launch tapes of the device
+        training path record the stream they were made on, and a training step can only be captured into a hipGraph on that
+        very stream (a capture does not reach over to another one) -- never torch's legacy default stream.  Entering makes
+        that stream current (ordered behind the caller's), leaving orders the caller's stream behind it.  A caller that drives
+        ``_train_graph_step`` itself (bench.py) runs its steps inside this context."""
         side = None
-        if torch.device(device).type == "cuda" and self.use_train_graph and os.environ.get("USFLOWS_AMD_TRAIN_GRAPH", "1") != "0":
+        device = torch.device(device)
+        if device.type == "cuda" and self.use_train_graph and os.environ.get("USFLOWS_AMD_TRAIN_GRAPH", "1") != "0":
             side = self.__dict__.get("_fit_stream")
-            if side is None or side.device != torch.device(device):
+            if side is None or side.device != (device if device.index is not None else torch.device("cuda", torch.cuda.current_device())):
                 side = self.__dict__["_fit_stream"] = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream(device))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            self._fit_epochs(model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses)
+            yield side
         if side is not None:
             torch.cuda.current_stream(device).wait_stream(self.__dict__.get("_fit_stream", side))
-        return epoch_losses
 
     def _fit_epochs(self, model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses):
         for _ in range(epochs):
