@@ -107,6 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--radial-norm", choices=["lognormal", "gammamm"], default=None,
                     help="--base radial: LogNormal(6, .35) (mnist.yaml:79-92) or GammaMM x 20 (fashionclasses_veriflow.yaml:79-93)")
     ap.add_argument("--prior-scale", type=float, default=None, help="image configurations: USFlow(prior_scale=...) (live YAMLs: 1.0)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1: initialise a one-rank \"nccl\" (= RCCL) process group in this process and issue the step's collective "
+                         "anyway (the all-reduce of one rank is the identity): the RCCL path under the bench's clock on a single GPU")
     ap.add_argument("--no-also", action="store_true", help="default invocation: skip the \"also\" block")
     ap.add_argument("--seed", type=int, default=100, help="seed of the synthetic parameters")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the short CPU sample (second cpu_baseline figure)")
@@ -164,6 +167,8 @@ ALSO = [
      ["--config", "mnist_live", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "256"]),
     ("cifar_image log_prob, live base (radial LogNormal, prior_scale 1)",
      ["--config", "cifar_image", "--base", "radial", "--prior-scale", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "128"]),
+    ("cfg2 log_prob through a one-rank nccl (RCCL) group: communicator init + the scalar all-reduce on the compute stream",
+     ["--config", "cfg2", "--force-dist", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-fast-mode", "--no-kernel-timing"]),
     ("cfg2 training step at 65536 rows (forward + backward + SophiaG)",
      ["--config", "cfg2", "--mode", "train", "--steps", "5", "--warmup", "2"]),
     ("cfg2 Flow.fit step at batch 32 (the reference's training batch), replayed hipGraph",
@@ -208,7 +213,8 @@ def run_also(args):
                                                             "share_of_gpu_time", "kernel_ms_per_step")} if rl else None,
                         "parity": parity or None, "train_step": o.get("train_step"),
                         "cpu_baseline": ({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None),
-                        "mean_log_prob": o.get("mean_log_prob")})
+                        "mean_log_prob": o.get("mean_log_prob"), "backend": o.get("backend"),
+                        "parallelism": o["config"].get("parallelism")})
         except Exception as e:      # noqa: BLE001 -- one failing extra must not cost the headline its line
             rec["error"] = f"{type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}"
         rec["wall_s"] = round(time.perf_counter() - t0, 1)
@@ -254,6 +260,7 @@ def main_flat(args, under_launcher):
     on_gpu = args.device == "cuda"
     import torch.distributed as dist
     backend = None
+    own_group = False
     if under_launcher:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if on_gpu:
@@ -262,6 +269,15 @@ def main_flat(args, under_launcher):
         else:
             dist.init_process_group("gloo")
         backend = dist.get_backend()
+    elif args.force_dist:
+        # one rank, its own rendezvous: the collective path (communicator init, all-reduce on the compute stream) on ONE GPU
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if on_gpu:
+            torch.cuda.set_device(0)
+        dist.init_process_group("nccl" if on_gpu else "gloo", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                                **({"device_id": torch.device("cuda:0")} if on_gpu else {}))
+        backend = dist.get_backend()
+        own_group = under_launcher = True               # (barriers, the max over ranks and the teardown below run as under a launcher)
     dev = torch.device(f"cuda:{local_rank}") if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(dev)
@@ -320,14 +336,14 @@ def main_flat(args, under_launcher):
         # the optimiser Flow.fit defaults to (flows.py:116): SophiaG -- one multi-tensor HIP launch per step on the GPU
         from usflows_amd.sophia import SophiaG
         opt = SophiaG(flow.parameters(), lr=1e-6) if args.optim == "sophia" else torch.optim.Adam(flow.parameters(), lr=1e-6)
-    if mode in ("train", "fit") and under_launcher and world > 1:
+    if mode in ("train", "fit") and under_launcher and (world > 1 or args.force_dist):
         from usflows_amd.parallel import data_parallel_training
-        data_parallel_training(flow)                       # one all-reduce of the flat gradient arena per step
+        data_parallel_training(flow, force_collective=args.force_dist)      # one all-reduce of the flat gradient arena per step
     fit_replays = [0]
 
     def fit_step():
         # what Flow._fit_epochs does per batch (usflows_amd/flows.py): the replayed graph when there is one, else an eager step
-        loss = flow._train_graph_step(opt, x, None) if world == 1 else None
+        loss = flow._train_graph_step(opt, x, None) if (world == 1 and not args.force_dist) else None
         if loss is not None:
             fit_replays[0] += 1
             return torch.tensor(-loss, dtype=torch.float64), None
@@ -353,7 +369,7 @@ def main_flat(args, under_launcher):
             with torch.no_grad():
                 xs = flow.sample([B], seed=1234, row_offset=lo)       # rows [lo, lo+B) of the global draw
             return xs[0, 0].double(), xs
-        return mean_log_prob(flow, x, acc=acc)              # + ONE all-reduce of [sum log_prob, count] when world > 1
+        return mean_log_prob(flow, x, acc=acc, force_collective=args.force_dist)   # + ONE all-reduce of [sum log_prob, count] when world > 1
 
     t_prep0 = time.perf_counter()
     mean, lp = step()                                        # includes the one-off parameter prep
@@ -621,7 +637,9 @@ def main_flat(args, under_launcher):
               "fit": f"Flow.fit optimiser-step samples/sec (forward + backward + {'SophiaG' if args.optim == 'sophia' else 'Adam'} step as Flow.fit issues it), {blocks}-layer {D}-dim flow"}[mode]
     if not on_gpu:
         metric = "[CPU PLUMBING TEST -- not a measurement] " + metric
-    if world == 1:
+    if world == 1 and args.force_dist:
+        par = f"dp1 with the step's collective forced (one-rank {backend} group: the all-reduce is the identity, issued on the compute stream)"
+    elif world == 1:
         par = "dp1 (single GPU: no collective)"
     elif mode == "sample":
         par = f"dp{world} (draws sharded by row range, disjoint Philox substreams, no collective)"
@@ -741,6 +759,12 @@ def main_image(args, under_launcher):
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         backend = dist.get_backend()
+    elif args.force_dist:               # one-rank group of its own: the collective path on ONE GPU (see main_flat)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        backend = dist.get_backend()
+        under_launcher = True
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -800,7 +824,7 @@ def main_image(args, under_launcher):
             # the optimiser step as Flow.fit issues it (flows.py:196-210): after three eager steps the step is captured as a
             # hipGraph and replayed (Flow._train_graph_step); the eager form serves until then
             # (data-parallel: eager steps -- the gradient all-reduce sits between backward and the optimiser's update)
-            loss = flow._train_graph_step(opt, x, None) if not (args.eager_train or world > 1) else None
+            loss = flow._train_graph_step(opt, x, None) if not (args.eager_train or world > 1 or args.force_dist) else None
             if loss is not None:
                 graph_steps[0] += 1
                 return torch.tensor(-loss, dtype=torch.float64), None
@@ -808,16 +832,18 @@ def main_image(args, under_launcher):
             lp_ = flow.log_prob(x)
             loss = -lp_.mean() - flow.log_prior()              # Flow.fit's loss (flows.py:196-198)
             loss.backward()
-            if world > 1:
+            if world > 1 or args.force_dist:
                 from usflows_amd.parallel import allreduce_gradients
-                allreduce_gradients(flow, B)                   # ONE all-reduce of the flattened gradients, weighted by row counts
+                allreduce_gradients(flow, B)                   # ONE all-reduce of the flat gradient buffer, weighted by row counts
             opt.step()
             return -loss.detach().double(), lp_.detach()
-        return mean_log_prob(flow, x, acc=acc)
+        return mean_log_prob(flow, x, acc=acc, force_collective=args.force_dist)
 
+    if mode == "train" and (world > 1 or args.force_dist):
+        flow.__dict__["_grad_allreduce"] = (None, True)       # (Flow._zero_grad_for_step then zeroes the bound buffer in place)
     for _ in range(max(args.warmup, 5 if mode == "train" else 1)):
         mean, lp = step()
-    if not args.no_kernel_timing and mode == "train" and not args.eager_train and world == 1:
+    if not args.no_kernel_timing and mode == "train" and not args.eager_train and world == 1 and not args.force_dist:
         # per-kernel times of the step: three eager steps with HIP events around every launch (a replayed graph runs no
         # host code to put events around), before the timed region
         _ext.launch_timing = {n: [] for n in _IMAGE_KERNELS}

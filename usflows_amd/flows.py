@@ -973,6 +973,15 @@ class Flow(torch.nn.Module):
                         p.grad = g              # (someone set it to None or replaced it: back to the graph's buffer)
                     g.zero_()
             return
+        dpg = self.__dict__.get("_dp_grads")
+        if dpg is not None and self.__dict__.get("_grad_allreduce") is not None:
+            # data-parallel steps of a flow without the flat arena (parallel.bind_dp_grads): the gradients stay views of the
+            # one buffer the collective runs over -- zeroed in place by one launch
+            params = [p for p in self.parameters() if p.requires_grad]
+            if len(params) == len(dpg["views"]) and all(p.grad is v or (p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+                                                        for p, v in zip(params, dpg["views"])):
+                dpg["flat"].zero_()
+                return
         optim.zero_grad()
 
     def is_feasible(self) -> bool:

@@ -328,7 +328,8 @@ class TrainPath:
             return
         import torch.distributed as dist
         group, average = self.grad_allreduce
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        if not (dist.is_available() and dist.is_initialized() and
+                (dist.get_world_size(group) > 1 or getattr(self, "force_collective", False))):
             return
         if average:
             flat[:-1] *= float(local_rows)
