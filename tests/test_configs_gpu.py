@@ -114,6 +114,9 @@ def test_cfg2_model_at_cfg3_rank_shapes(cfg2, B, planes):
     flow.engine().use_planes = None
 
 
+_CFG5_REF = {}
+
+
 @pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
 def test_cfg5_per_rank_sample(cfg2, mode):
     """cfg5 per rank: rank 3's 125000 of the 10^6 draws.  (1) sample() == _forward of the head kernel's own noise;
@@ -137,7 +140,10 @@ def test_cfg5_per_rank_sample(cfg2, mode):
     assert xs.shape == (n, 784) and torch.isfinite(xs).all() and torch.isfinite(z).all()
     assert torch.equal(xs, xf)
     idx = torch.cat([torch.arange(0, 24), torch.arange(n // 2 - 12, n // 2 + 12), torch.arange(n - 24, n)])
-    ref = orc.flow_forward(orc.to_dtype(sd, torch.float64), spec, z[idx.to(DEV)].cpu().double())
+    zi = z[idx.to(DEV)].cpu().double()
+    if _CFG5_REF.get("z") is None or not torch.equal(_CFG5_REF["z"], zi):       # (the noise does not depend on the GEMM mode)
+        _CFG5_REF.update(z=zi, x=orc.flow_forward(orc.to_dtype(sd, torch.float64), spec, zi))
+    ref = _CFG5_REF["x"]
     s = max(1.0, ref.abs().max().item())
     assert (xs[idx.to(DEV)].cpu().double() - ref).abs().max().item() < 2e-5 * s
     base_lp = torch.distributions.Laplace(0.0, 1.0).log_prob(zb.double()).sum(-1)

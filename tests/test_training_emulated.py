@@ -211,6 +211,13 @@ def test_bound_flat_gradients_accumulate_like_autograd(name):
     for n in g1:
         assert torch.equal(named[n].grad, g1[n])            # current values kept
     path._gflat.zero_()
+    # outside the scope that asks for the bound node, log_prob is an ordinary autograd node over the parameters
+    lp = training.log_prob_with_grad(path, x, ctx)
+    gs = torch.autograd.grad((lp * g_lp).sum(), [named[n] for n in g1])
+    for n, g in zip(g1, gs):
+        assert torch.allclose(g, g1[n], rtol=1e-6, atol=1e-7 * float(g1[n].abs().max())), n
+        assert named[n].grad.data_ptr() == ptrs[n] and not named[n].grad.any()      # (autograd.grad has no side effect on .grad)
+    path.use_bound_node = True                               # what Flow.fit's captured step sets
     for rep in (1, 2):
         lp = training.log_prob_with_grad(path, x, ctx)
         (lp * g_lp).sum().backward()

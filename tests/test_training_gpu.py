@@ -103,7 +103,7 @@ def test_cfg2_training_step_ragged_batch(conj):
         from usflows_amd.synth import synth_state_dict
         spec = copy.copy(spec)
         spec.affine_conjugation = True           # (the layer numbering of the state dict changes with the variant)
-        spec.coupling_blocks = 16                # 33 affine applications as in cfg2; keeps the fp64 oracle's autograd ~30 s
+        spec.coupling_blocks = 8                 # 17 affine applications; keeps the fp64 oracle's autograd ~15 s
         sd = synth_state_dict(spec, seed=100, alpha=0.1)
     flow = build_flow(spec, sd, device=DEV)
     x = a["x"][:48]
@@ -118,7 +118,7 @@ def test_cfg2_training_step_ragged_batch(conj):
     (-lp1.mean()).backward()
     lp_ref, g_ref = oracle_grads(spec, sd, x, torch.full((48,), -1.0 / 48))
     assert ((lp1.detach().cpu().double() - lp_ref).abs() / lp_ref.abs()).max().item() < 1e-5
-    assert _compare(flow, g_ref, tol=5e-4, kink_frac=5e-3) >= (50 if conj else 100)
+    assert _compare(flow, g_ref, tol=5e-4, kink_frac=5e-3) >= (25 if conj else 100)
 
 
 def test_fit_runs_on_device_and_reduces_the_loss():

@@ -764,6 +764,9 @@ class FlowEngine:
         state = pk.setdefault("auto_merge", {})
         if direction in state:
             return state[direction]
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            return False          # (the probe reads a scalar back: never inside a caller's stream capture -- this call keeps
+            #                        the layer-by-layer plan, the next call outside a capture decides)
         has_run = any(a.startswith("affine") and b_.startswith("affine")
                       for (a, _), (b_, _) in zip(self._primitive_ops(direction)[:-1], self._primitive_ops(direction)[1:]))
         if not has_run or x.shape[0] == 0:

@@ -437,6 +437,8 @@ class Flow(torch.nn.Module):
     # per-layer ctypes call, no stream capture and none of its restrictions.  The list keeps the pass's intermediates
     # alive, so it serves batches whose intermediates stay under ``list_max_bytes``; a pass that is not pure (a shape one of
     # the kernels does not serve -> torch fallback inside a layer) is remembered as such and keeps the eager loop / graph.
+    # MEMORY: a list pins its pass's intermediates (that is what makes it replayable): at most ``list_max_bytes`` per list,
+    # 8 lists / 2 GB per flow, oldest out first; ``flow.list_max_bytes = 0`` (or USFLOWS_AMD_LOOP_LIST=0) keeps nothing.
     list_max_rows = 4096          # USFLOWS_AMD_LOOP_LIST=0: off (and graph_max_rows = 0 switches every replay form off)
     list_max_bytes = 1 << 30
 
@@ -872,9 +874,15 @@ class Flow(torch.nn.Module):
                 for p in params:
                     if id(p) not in bound:
                         p.grad = None
-                with _unvalidated(self.base_distribution):
-                    loss = -self.log_prob(sx, context=sc).mean() - self.log_prior()
-                loss.backward()
+                if gflat is not None:
+                    tp.use_bound_node = True        # (this scope only: training.log_prob_with_grad)
+                try:
+                    with _unvalidated(self.base_distribution):
+                        loss = -self.log_prob(sx, context=sc).mean() - self.log_prior()
+                    loss.backward()
+                finally:
+                    if gflat is not None:
+                        tp.use_bound_node = False
                 optim.step()
                 return loss.detach()
 

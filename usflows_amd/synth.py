@@ -5,8 +5,9 @@ Pure data generation -- no flow arithmetic: (1) ``ModelSpec``: the constructor a
 from the reference's init *distributions* followed by the documented conditioning transform of
 SURVEY.md section 7-H2 (the reference's default init explodes at depth: |z| ~ 7e22 at D=784, K=32);
 (3) ``build_usflow``: a ``usflows_amd.flows.USFlow`` built from a spec (+ state dict).
-The CPU oracle re-exports (1) and (2) so that oracle, reference fixtures and the device path all see
-the same parameters."""
+The CPU oracle has an independent twin of (1) and (2) (``oracle/synth.py``; ``tests/test_oracle.py`` holds the two
+against each other), so that oracle, reference fixtures and the device path all see the same parameters without the
+oracle importing the product."""
 from __future__ import annotations
 
 import math

@@ -273,8 +273,9 @@ class TrainPath:
         out like the gradient arena (current values kept).  While the views stay in place (``optimizer.zero_grad(
         set_to_none=True)`` or any reassignment undoes it), ``backward`` adds the whole arena with one launch instead of
         handing ~9 tensors per block to autograd's per-parameter accumulation -- at the reference's batch of 32 rows those
-        adds are a tenth of the step.  Flow.fit calls this before it captures the step as a hipGraph.  Parameter hooks
-        on these parameters do not fire while bound (none are used by Flow.fit); data-parallel runs stay unbound."""
+        adds are a tenth of the step.  Flow.fit calls this before it captures the step as a hipGraph and sets
+        ``use_bound_node`` for the duration of the captured step only: outside that scope ``log_prob`` stays an ordinary
+        autograd node over the parameters (which accumulates into the views in place).  Data-parallel runs stay unbound."""
         ar = self.__dict__.get("_last_arena")
         if ar is None or self.grad_allreduce is not None:
             return False
@@ -1057,6 +1058,10 @@ def log_prob_with_grad(path: TrainPath, x, context):
             from . import radial
             lp = radial.log_prob_from_radius(base, r)      # (one launch each way, no validating distribution object)
         return (base.log_prob_from_radius(r) if lp is None else lp) + logdet
-    if path.grads_bound() and torch.is_grad_enabled():
+    # (the bound node -- no parameter inputs, the whole arena added into the bound .grad views by one launch -- only inside
+    # the scope that asked for it: Flow.fit's captured step sets ``use_bound_node``; anywhere else a grad-enabled log_prob
+    # is an ordinary autograd node over the parameters, so torch.autograd.grad / hooks / backward(inputs=...) behave as usual
+    # even while the .grad views of an earlier fit are still in place)
+    if path.__dict__.get("use_bound_node", False) and path.grads_bound() and torch.is_grad_enabled():
         return _LogProbFn.apply(path, x, context, path._anchor)
     return _LogProbFn.apply(path, x, context, *params)
