@@ -722,3 +722,49 @@ def test_conv2d_with_masked_residual_equals_the_two_passes(B, cin, cout, H, W):
     # a 1 x 1 kernel: not served by the fused form
     w1 = torch.randn(cout, cin, 1, 1, generator=g).to("cuda:0")
     assert _ext.conv2d_same_res(x, _ext.conv2d_weight_planes(w1), cout, 1, rx, om, 1.0) is None
+
+
+@pytest.mark.gpu
+def test_convnet_spatial_conditioner_runs_on_the_image_kernels(monkeypatch):
+    """the reference's generic ``ConvNet`` with 2-D ``in_dims`` (networks.py:312-371) as a MaskedCoupling conditioner: the same
+    device passes as ConvNet2D in inference and training -- against the mirror's own torch formulation on the CPU in fp64 (which
+    tests/test_mirror_vs_live_reference.py holds bit for bit against the real reference)"""
+    import copy
+    from usflows_amd import _ext
+    from usflows_amd.flows import USFlow
+    from usflows_amd.networks import ConvNet
+    from image_synth import synth_image_params_
+    dims = [16, 7, 7]
+    flow = USFlow(torch.distributions.Laplace(torch.zeros(dims), torch.ones(dims)), dims, 2, ConvNet,
+                  dict(in_dims=dims, c_hidden=[32, 32]), householder=0, affine_conjugation=True)
+    synth_image_params_(flow, 71)
+    x = torch.rand(40, *dims, generator=torch.Generator().manual_seed(4))
+    f64 = copy.deepcopy(flow).double()
+    for l in f64.layers:
+        if torch.is_tensor(getattr(l, "mask", None)):
+            l.mask = l.mask.double()
+    f64.base_distribution = torch.distributions.Independent(torch.distributions.Laplace(torch.zeros(dims).double(), torch.ones(dims).double()), 3)
+    torch.set_default_dtype(torch.float64)
+    try:
+        lp64 = f64.log_prob(x.double())
+        (-lp64.mean()).backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    dev = flow.to(DEV)
+    convs, wg = [], []
+    real_c, real_w = _ext.conv2d_same, _ext.conv_wgrad
+    monkeypatch.setattr(_ext, "conv2d_same", lambda *a_, **k_: (convs.append(1), real_c(*a_, **k_))[1])
+    monkeypatch.setattr(_ext, "conv_wgrad", lambda *a_, **k_: (wg.append(1), real_w(*a_, **k_))[1])
+    with torch.no_grad():
+        lp = dev.log_prob(x.to(DEV))
+    assert len(convs) > 0, "the convolutions did not run on usf_conv2d_same_f32"
+    assert ((lp.double().cpu() - lp64.detach()).abs() / lp64.detach().abs()).max().item() < 1e-5
+    lpg = dev.log_prob(x.to(DEV))
+    (-lpg.mean()).backward()
+    assert len(wg) > 0, "the weight gradients did not come from usf_conv_wgrad_f32"
+    ref = dict(f64.named_parameters())
+    for k, p in dev.named_parameters():
+        if ref[k].grad is None:
+            continue
+        s = max(ref[k].grad.abs().max().item(), 1e-30)
+        assert (p.grad.double().cpu() - ref[k].grad).abs().max().item() <= 5e-5 * s, k

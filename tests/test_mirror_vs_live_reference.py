@@ -294,3 +294,25 @@ def test_image_shaped_usflow_side_by_side(masktype, gating, norm):
         torch.manual_seed(1)
         sm = mine.sample([3])
         assert sr.shape == sm.shape == (3, *dims) and torch.allclose(sr, sm, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("in_dims,c_hidden,kw", [
+    ([4, 6, 6], [8, 8], {}), ([3, 10], [6, 9], dict(gating=True)), ([4, 5, 5], [8, 12], dict(gating=False)),
+    ([2, 4, 4, 4], [6], dict(normalize_layers=False)), ([4, 6, 6], [8, 8], dict(padding=1, nonlinearity=torch.nn.LeakyReLU(0.1)))])
+def test_convnet_spatial_path_side_by_side(in_dims, c_hidden, kw):
+    """the SPATIAL branch of the reference's ConvNet (networks.py:312-371, 388-403: Conv1d / 2d / 3d, GatedConvND with and
+    without the residual projection, LayerNormChannelsND): same module tree, same state-dict keys, same bits on the CPU"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import ref_shim
+    _, _, networks, _ = ref_shim.install()
+    from usflows_amd.networks import ConvNet
+    torch.manual_seed(0)
+    ref = networks.ConvNet(in_dims, c_hidden, **kw)
+    mine = ConvNet(in_dims, c_hidden, **kw)
+    assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    x = torch.randn(5, *in_dims)
+    assert torch.equal(ref(x), mine(x))
+    if len(in_dims) == 2:                                   # (L, B, C) inputs are accepted as (B, C, L)
+        xl = torch.randn(in_dims[1], 7, in_dims[0])
+        assert torch.equal(ref(xl), mine(xl))

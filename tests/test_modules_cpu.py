@@ -221,8 +221,8 @@ def test_convnet_vector_path_layout_and_engine_view():
     assert blocks[0]["l1"] is default.nn[1].net1[1] and blocks[1]["proj"] is default.nn[3].proj
     assert blocks[1]["ln"] is default.nn[4].layernorm and "lin" not in blocks[0]
     assert not conditioner_supported(ConvNet([6], [8, 5], nonlinearity=torch.nn.Tanh()))
-    with pytest.raises(NotImplementedError):
-        ConvNet([3, 8, 8], [4])
+    spatial = ConvNet([3, 8, 8], [4])        # the spatial path: image-shaped flows (layer loop), not the flat engine
+    assert not spatial.is_vector and not conditioner_supported(spatial) and spatial(torch.randn(2, 3, 8, 8)).shape == (2, 3, 8, 8)
 
 
 # ---- Flow.fit against a golden run of the real reference (tests/golden/fit_*.npz) ---------------------------------

@@ -57,7 +57,7 @@ def conditioner_supported(cond: nn.Module) -> bool:
     if isinstance(cond, DenseNN):
         return cond.count_params == 1 and _activation_of(cond.f) is not None
     if isinstance(cond, ConvNet):        # vector path: plain chain of Linears, or GatedMLP / LayerNormVector blocks
-        return _activation_of(cond.f) is not None
+        return cond.is_vector and _activation_of(cond.f) is not None     # (spatial path: image-shaped flows, the layer loop)
     return False
 
 

@@ -118,8 +118,137 @@ def _as_batch_features(x):
     return x
 
 
-class ConvNet(nn.Module):
-    """Vector path of the reference's ``ConvNet`` (``len(in_dims) == 1``): ``self.nn`` =
+class _ConvStack(nn.Module):
+    """a ``self.nn`` sequence of Conv2d / GatedConv / nonlinearity / LayerNormChannels modules on [B, C, H, W] inputs run as
+    device passes (inference and training): shared by ``ConvNet2D`` and the 2-D spatial path of ``ConvNet``"""
+
+    def forward(self, x, context=None, in_mul=None, residual=None):
+        """in_mul (device path only, see ``first_conv_on_device``): a [C * H * W] mask the FIRST convolution multiplies
+        into its input -- MaskedCoupling hands over the unmasked x and its mask instead of a masked copy.
+        residual = (res_x, one_minus_mask, sign) (device path only): the caller is a MaskedCoupling that wants
+        res_x + sign * one_minus_mask * net(x); the return value is then (tensor, done) -- done: the LAST convolution
+        wrote the coupling's output itself (usf_conv2d_same_res_f32), otherwise tensor is net(x) as usual"""
+        mods = list(self.nn)
+        if not (x.is_cuda and x.dtype == torch.float32):
+            assert in_mul is None and residual is None
+            return self.nn(x)
+        if residual is None and self.train_on_device(x):
+            return self._forward_train_device(x, in_mul)
+        done = False
+        # the same module sequence on the device: convolutions on usf_conv2d_same_f32 (a nonlinearity behind a plain
+        # convolution rides in its epilogue), a (Leaky)ReLU in front of a LayerNormChannels joins that layer's pass
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            act = _relu_kind(m)
+            if isinstance(m, nn.Conv2d) and _conv_hip_ok(m, x):
+                fold = _relu_kind(nxt) if nxt is not None else None
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                if fold is not None and isinstance(after, LayerNormChannels):
+                    fold = None                                   # that ReLU belongs to the layer norm's pass
+                if residual is not None and k == len(mods) - 1 and fold is None:
+                    x, done = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, residual=residual)
+                else:
+                    x = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, out_act=fold)
+                k += 2 if fold is not None else 1
+            elif isinstance(m, GatedConv) and _relu_kind(nxt) is not None and k + 2 < len(mods) \
+                    and m.can_join_layernorm(x, mods[k + 2]):
+                x = m(x, post=(_relu_kind(nxt), mods[k + 2]))     # GatedConv + nonlinearity + layer norm: its last pass does all
+                k += 3
+            elif act is not None and isinstance(nxt, LayerNormChannels) and nxt._hip_ok(x):
+                x = nxt(x, pre_act=act)
+                k += 2
+            else:
+                assert not (k == 0 and in_mul is not None)
+                x = m(x)
+                k += 1
+        return (x, done) if residual is not None else x
+
+    # ---- training on the device (rows N2 x N4): the same module sequence as differentiable device passes ----------------
+    def train_on_device(self, x) -> bool:
+        """True when this call needs gradients and every module of the sequence has a device backward at this shape
+        (image_training.py); USFLOWS_AMD_IMAGE_TRAIN=0 keeps torch autograd"""
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
+                and torch.is_grad_enabled() and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0"):
+            return False
+        if not (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        from . import image_training as it
+        B, C, H, W = x.shape
+        mods = list(self.nn)
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            if isinstance(m, nn.Conv2d):
+                if m.in_channels != C or not it.conv_shape_ok(m, B, H, W):
+                    return False
+                C = m.out_channels
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                k += 2 if (_relu_kind(nxt) is not None and not isinstance(after, LayerNormChannels)) else 1
+            elif isinstance(m, GatedConv):
+                if not m.train_shape_ok(B, C, H, W):
+                    return False
+                k += 1
+            elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
+                if nxt.gamma.numel() != C or C > 64:
+                    return False
+                k += 2
+            elif isinstance(m, LayerNormChannels):
+                if m.gamma.numel() != C or C > 64:
+                    return False
+                k += 1
+            elif _relu_kind(m) is not None:
+                k += 1                                            # (a stand-alone nonlinearity: a torch elementwise op)
+            else:
+                return False
+        return True
+
+    def _forward_train_device(self, x, in_mul=None, fork: bool = False):
+        """fork (a MaskedCoupling caller that uses x again for its residual): returns (net(x), x') where x' is x passed through
+        the first convolution's autograd node -- see image_training.ConvSameFork"""
+        from . import image_training as it
+        mods = list(self.nn)
+        assert in_mul is None or isinstance(mods[0], nn.Conv2d)
+        x_fork = None
+        k = 0
+        while k < len(mods):
+            m = mods[k]
+            nxt = mods[k + 1] if k + 1 < len(mods) else None
+            if isinstance(m, nn.Conv2d):
+                fold = _relu_kind(nxt) if nxt is not None else None
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                if fold is not None and isinstance(after, LayerNormChannels):
+                    fold = None                                   # that ReLU belongs to the layer norm's pass
+                if fork and k == 0 and fold is None:
+                    x, x_fork = it.ConvSameFork.apply(x, m.weight, m.bias, in_mul, None)
+                    k += 1
+                    continue
+                x = it.ConvSame.apply(x, m.weight, m.bias, in_mul if k == 0 else None, None, fold)
+                k += 2 if fold is not None else 1
+            elif isinstance(m, GatedConv):
+                x = m.forward_train_device(x)
+                k += 1
+            elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
+                x = it.LayerNormCh.apply(x, nxt.gamma, nxt.beta, nxt.eps, _relu_kind(m))
+                k += 2
+            elif isinstance(m, LayerNormChannels):
+                x = it.LayerNormCh.apply(x, m.gamma, m.beta, m.eps, None)
+                k += 1
+            else:
+                x = m(x)
+                k += 1
+        return (x, x_fork) if fork else x
+
+    def first_conv_on_device(self, x) -> bool:
+        """True when forward(x, in_mul=mask) may be used: the first module is a convolution the HIP kernel serves"""
+        return len(self.nn) > 0 and _conv_hip_ok(self.nn[0], x)
+
+
+class ConvNet(_ConvStack):
+    """The reference's ``ConvNet`` (networks.py:247-403).  Spatial path (``len(in_dims) > 1``): see ``__init__``; on 2-D inputs it
+    runs on the device passes ``ConvNet2D`` uses.  Vector path (``len(in_dims) == 1``): ``self.nn`` =
     ``Linear(c_in, h0)``, one block per entry of ``c_hidden`` (block i maps ``c_hidden[i-1]`` (``h0`` for i = 0)
     to ``c_hidden[i]``: ``Sequential(f, Linear)`` or ``GatedMLP``, optionally followed by ``LayerNormVector``),
     ``Linear(c_hidden[-1], c_out)`` -- note: no activation in front of the final Linear.  Same constructor
@@ -134,14 +263,39 @@ class ConvNet(nn.Module):
             in_dims = [int(d) for d in in_dims]
         except TypeError:
             raise ValueError("in_dims must be an iterable like [C, H, W] or [C] for vector")
-        if len(in_dims) != 1:
-            raise NotImplementedError("usflows_amd.ConvNet: only the vector path (in_dims = [D]) is in scope")
+        if padding is None:
+            padding = kernel_size // 2
         if not c_hidden or any(h <= 0 for h in c_hidden):
             raise AssertionError("c_hidden must be non-empty list of positive ints")
         c_in = in_dims[0]
         c_out = c_out if c_out > 0 else c_in
         self.c_hidden = [int(h) for h in c_hidden]
         self.gating, self.normalize_layers, self.f = bool(gating), bool(normalize_layers), nonlinearity
+        if len(in_dims) != 1:
+            # spatial path (networks.py:312-371): Conv, one [GatedConvND | Conv, nonlinearity, (LayerNormChannelsND)] per entry of
+            # c_hidden, Conv -- the module tree and state-dict keys of the reference; for 2-D inputs the device passes of
+            # ConvNet2D (shared below: _ConvStack) serve it
+            rank = max(1, len(in_dims) - 1)
+            conv_map = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
+            if rank not in conv_map:
+                raise ValueError(f"Unsupported input rank {rank}")
+            Conv = conv_map[rank]
+            ckw = dict(kernel_size=kernel_size, padding=padding, stride=stride, dilation=dilation)
+            mods = [Conv(c_in, self.c_hidden[0], **ckw)]
+            width = self.c_hidden[0]
+            for h in self.c_hidden:
+                if gating:
+                    mods += [GatedConvND(width, h, nonlinearity=nonlinearity, input_rank=rank, **ckw), nonlinearity]
+                else:
+                    mods += [Conv(width, h, **ckw), nonlinearity]
+                if normalize_layers:
+                    mods.append(LayerNormChannelsND(h, num_spatial_dims=rank))
+                width = h
+            mods.append(Conv(width, c_out, **ckw))
+            self.nn = nn.Sequential(*mods)
+            self.is_vector = False
+            self._spatial_rank = rank
+            return
         mods = [nn.Linear(c_in, self.c_hidden[0])]
         width = self.c_hidden[0]
         for h in self.c_hidden:
@@ -154,7 +308,17 @@ class ConvNet(nn.Module):
         self.is_vector = True
         self._vector_in_features = c_in
 
-    def forward(self, x, context=None):
+    def forward(self, x, context=None, in_mul=None, residual=None):
+        if not self.is_vector:
+            # (L, B, C) / (1, B, C) inputs are accepted as (B, C, L) (networks.py:390-402)
+            if x.dim() == 3:
+                cin = self.nn[0].in_channels
+                if (x.shape[2] == cin and x.shape[0] != x.shape[1]) or (x.shape[0] == 1 and x.shape[2] == cin):
+                    x = x.permute(1, 2, 0).contiguous()
+            if self._spatial_rank == 2 and x.dim() == 4:
+                return _ConvStack.forward(self, x, context, in_mul, residual)
+            assert in_mul is None and residual is None
+            return self.nn(x)
         x = _as_batch_features(x)
         if x.dim() != 2:
             x = x.view(x.shape[0], -1)
@@ -409,7 +573,56 @@ class GatedConv(nn.Module):
         return ret
 
 
-class ConvNet2D(nn.Module):
+class LayerNormChannelsND(LayerNormChannels):
+    """channel-wise layer norm of (batch, channel, *spatial) tensors (networks.py:122-141): gamma / beta shaped
+    (1, C, 1, ..., 1) with ``num_spatial_dims`` trailing ones; the same arithmetic (and device pass) as LayerNormChannels"""
+
+    def __init__(self, c_in, num_spatial_dims: int = 2, eps=1e-5):
+        nn.Module.__init__(self)
+        shape = (1, c_in) + (1,) * num_spatial_dims
+        self.gamma = nn.Parameter(torch.ones(*shape))
+        self.beta = nn.Parameter(torch.zeros(*shape))
+        self.eps = eps
+
+
+class GatedConvND(GatedConv):
+    """gated residual block for 1 / 2 / 3-D convolutions (networks.py:144-203): ``x' + val * sigmoid(gate)``,
+    ``[val, gate] = Conv1x1(f(Conv(f(x))))``, ``x'`` = x or a 1 x 1 projection when the channel counts differ.  (Unlike the
+    2-D ``GatedConv`` the pointwise convolution has padding 0 and 2 * c_out outputs.)  With 2-D inputs and no projection it is
+    GatedConv's module sequence and takes its device passes."""
+
+    def __init__(self, c_in, c_out, kernel_size=3, padding=1, stride=1, dilation=1, nonlinearity=nn.ReLU(), input_rank: int = 2):
+        nn.Module.__init__(self)
+        assert stride == 1, "Stride > 1 cannot be used to skip connection."
+        conv_map = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
+        if input_rank not in conv_map:
+            raise ValueError(f"Unsupported input rank {input_rank}")
+        Conv = conv_map[input_rank]
+        self.net = nn.Sequential(
+            nonlinearity,
+            Conv(c_in, c_out, kernel_size=kernel_size, padding=padding, stride=stride, dilation=dilation),
+            nonlinearity,
+            Conv(c_out, 2 * c_out, kernel_size=1, padding=0, stride=1),
+        )
+        self.proj = Conv(c_in, c_out, kernel_size=1, padding=0) if c_in != c_out else None
+        self._plain2d = input_rank == 2 and self.proj is None
+
+    def can_join_layernorm(self, x, ln) -> bool:
+        return self._plain2d and super().can_join_layernorm(x, ln)
+
+    def train_shape_ok(self, B, C, H, W) -> bool:
+        return self._plain2d and super().train_shape_ok(B, C, H, W)
+
+    def forward(self, x, post=None):
+        if self._plain2d and x.dim() == 4:
+            return super().forward(x, post)
+        assert post is None
+        val, gate = self.net(x).chunk(2, dim=1)
+        skip = x if self.proj is None else self.proj(x)
+        return skip + val * torch.sigmoid(gate)
+
+
+class ConvNet2D(_ConvStack):
     """the CNN conditioner of the reference's image configs (networks.py:405-510): Conv2d(c_in, c_hidden), then
     ``num_layers`` x [GatedConv | Conv2d, nonlinearity, (LayerNormChannels)], then Conv2d(c_hidden, c_out).  Same
     module tree (``nn.{i}``) and state-dict keys; runs as torch ops (MIOpen convolutions on a ROCm device)."""
@@ -435,125 +648,3 @@ class ConvNet2D(nn.Module):
         layers += [conv(c_hidden, c_out)]
         self.nn = nn.Sequential(*layers)
 
-    def forward(self, x, context=None, in_mul=None, residual=None):
-        """in_mul (device path only, see ``first_conv_on_device``): a [C * H * W] mask the FIRST convolution multiplies
-        into its input -- MaskedCoupling hands over the unmasked x and its mask instead of a masked copy.
-        residual = (res_x, one_minus_mask, sign) (device path only): the caller is a MaskedCoupling that wants
-        res_x + sign * one_minus_mask * net(x); the return value is then (tensor, done) -- done: the LAST convolution
-        wrote the coupling's output itself (usf_conv2d_same_res_f32), otherwise tensor is net(x) as usual"""
-        mods = list(self.nn)
-        if not (x.is_cuda and x.dtype == torch.float32):
-            assert in_mul is None and residual is None
-            return self.nn(x)
-        if residual is None and self.train_on_device(x):
-            return self._forward_train_device(x, in_mul)
-        done = False
-        # the same module sequence on the device: convolutions on usf_conv2d_same_f32 (a nonlinearity behind a plain
-        # convolution rides in its epilogue), a (Leaky)ReLU in front of a LayerNormChannels joins that layer's pass
-        k = 0
-        while k < len(mods):
-            m = mods[k]
-            nxt = mods[k + 1] if k + 1 < len(mods) else None
-            act = _relu_kind(m)
-            if isinstance(m, nn.Conv2d) and _conv_hip_ok(m, x):
-                fold = _relu_kind(nxt) if nxt is not None else None
-                after = mods[k + 2] if k + 2 < len(mods) else None
-                if fold is not None and isinstance(after, LayerNormChannels):
-                    fold = None                                   # that ReLU belongs to the layer norm's pass
-                if residual is not None and k == len(mods) - 1 and fold is None:
-                    x, done = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, residual=residual)
-                else:
-                    x = _conv_hip(m, x, in_mul=in_mul if k == 0 else None, out_act=fold)
-                k += 2 if fold is not None else 1
-            elif isinstance(m, GatedConv) and _relu_kind(nxt) is not None and k + 2 < len(mods) \
-                    and m.can_join_layernorm(x, mods[k + 2]):
-                x = m(x, post=(_relu_kind(nxt), mods[k + 2]))     # GatedConv + nonlinearity + layer norm: its last pass does all
-                k += 3
-            elif act is not None and isinstance(nxt, LayerNormChannels) and nxt._hip_ok(x):
-                x = nxt(x, pre_act=act)
-                k += 2
-            else:
-                assert not (k == 0 and in_mul is not None)
-                x = m(x)
-                k += 1
-        return (x, done) if residual is not None else x
-
-    # ---- training on the device (rows N2 x N4): the same module sequence as differentiable device passes ----------------
-    def train_on_device(self, x) -> bool:
-        """True when this call needs gradients and every module of the sequence has a device backward at this shape
-        (image_training.py); USFLOWS_AMD_IMAGE_TRAIN=0 keeps torch autograd"""
-        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
-                and torch.is_grad_enabled() and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0"):
-            return False
-        if not (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return False
-        from . import image_training as it
-        B, C, H, W = x.shape
-        mods = list(self.nn)
-        k = 0
-        while k < len(mods):
-            m = mods[k]
-            nxt = mods[k + 1] if k + 1 < len(mods) else None
-            if isinstance(m, nn.Conv2d):
-                if m.in_channels != C or not it.conv_shape_ok(m, B, H, W):
-                    return False
-                C = m.out_channels
-                after = mods[k + 2] if k + 2 < len(mods) else None
-                k += 2 if (_relu_kind(nxt) is not None and not isinstance(after, LayerNormChannels)) else 1
-            elif isinstance(m, GatedConv):
-                if not m.train_shape_ok(B, C, H, W):
-                    return False
-                k += 1
-            elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
-                if nxt.gamma.numel() != C or C > 64:
-                    return False
-                k += 2
-            elif isinstance(m, LayerNormChannels):
-                if m.gamma.numel() != C or C > 64:
-                    return False
-                k += 1
-            elif _relu_kind(m) is not None:
-                k += 1                                            # (a stand-alone nonlinearity: a torch elementwise op)
-            else:
-                return False
-        return True
-
-    def _forward_train_device(self, x, in_mul=None, fork: bool = False):
-        """fork (a MaskedCoupling caller that uses x again for its residual): returns (net(x), x') where x' is x passed through
-        the first convolution's autograd node -- see image_training.ConvSameFork"""
-        from . import image_training as it
-        mods = list(self.nn)
-        assert in_mul is None or isinstance(mods[0], nn.Conv2d)
-        x_fork = None
-        k = 0
-        while k < len(mods):
-            m = mods[k]
-            nxt = mods[k + 1] if k + 1 < len(mods) else None
-            if isinstance(m, nn.Conv2d):
-                fold = _relu_kind(nxt) if nxt is not None else None
-                after = mods[k + 2] if k + 2 < len(mods) else None
-                if fold is not None and isinstance(after, LayerNormChannels):
-                    fold = None                                   # that ReLU belongs to the layer norm's pass
-                if fork and k == 0 and fold is None:
-                    x, x_fork = it.ConvSameFork.apply(x, m.weight, m.bias, in_mul, None)
-                    k += 1
-                    continue
-                x = it.ConvSame.apply(x, m.weight, m.bias, in_mul if k == 0 else None, None, fold)
-                k += 2 if fold is not None else 1
-            elif isinstance(m, GatedConv):
-                x = m.forward_train_device(x)
-                k += 1
-            elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
-                x = it.LayerNormCh.apply(x, nxt.gamma, nxt.beta, nxt.eps, _relu_kind(m))
-                k += 2
-            elif isinstance(m, LayerNormChannels):
-                x = it.LayerNormCh.apply(x, m.gamma, m.beta, m.eps, None)
-                k += 1
-            else:
-                x = m(x)
-                k += 1
-        return (x, x_fork) if fork else x
-
-    def first_conv_on_device(self, x) -> bool:
-        """True when forward(x, in_mul=mask) may be used: the first module is a convolution the HIP kernel serves"""
-        return len(self.nn) > 0 and _conv_hip_ok(self.nn[0], x)
