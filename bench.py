@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # same guide: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
+TIMING_EVERY = 4                    # flat log_prob / sample: per-launch HIP events on every 4th step of the timed region
 
 CONFIGS = {
     # name: (dim, blocks, hidden, rows, sharding)   rows: per GPU ("weak") or global ("strong")
@@ -378,8 +379,12 @@ def main_flat(args, under_launcher):
     for _ in range(max(args.warmup - 1, 4 if mode == "fit" else 0)):
         step()
     fit_replays[0] = 0
-    if on_gpu and not args.no_kernel_timing and mode not in ("train", "fit"):
-        eng.op_timing = []
+    # per-launch HIP events: on every TIMING_EVERY-th step of the timed region (first step included).  Two event records per
+    # launch on all 66 launches of every step cost the cfg2 step 2 % (18.55 vs 18.18 ms, same box): the headline would measure
+    # its own instrumentation; sampled, the events cost 0.5 % and still see >= 160 launches of the dominant kernel
+    timing_on = on_gpu and not args.no_kernel_timing and mode not in ("train", "fit")
+    timed_launch_steps = [0]
+    op_records = []
     if on_gpu and not args.no_kernel_timing and mode == "train":
         from usflows_amd import _ext as _ext_t
         _ext_t.launch_timing = {"usf_wgrad_f32": []}        # HIP events around every weight-gradient launch
@@ -387,8 +392,13 @@ def main_flat(args, under_launcher):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
+        if timing_on and i_step % TIMING_EVERY == 0:
+            eng.op_timing = op_records
+            timed_launch_steps[0] += 1
         mean, lp = step()
+        if timing_on:
+            eng.op_timing = None
     sync()
     if under_launcher:
         dist.barrier()
@@ -396,7 +406,8 @@ def main_flat(args, under_launcher):
     timing = None
     wg_timing = None
     if on_gpu:
-        timing, eng.op_timing = eng.op_timing, None
+        timing = op_records if timing_on else None
+        eng.op_timing = None
         if mode == "train" and not args.no_kernel_timing:
             from usflows_amd import _ext as _ext_t
             wg_timing, _ext_t.launch_timing = _ext_t.launch_timing["usf_wgrad_f32"], None
@@ -500,11 +511,14 @@ def main_flat(args, under_launcher):
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "mfma_pipe_util": mfma_util, "mfma_pipe_util_source": util_src, "kernel": name,
-                    "peak_is": peak_note, "measured_by": "HIP events around every launch of this run's timed region",
+                    "peak_is": peak_note,
+                    "measured_by": f"HIP events around every launch of every {TIMING_EVERY}th step of this run's timed region "
+                                   f"(events on all steps cost the step 2 %: bench.py TIMING_EVERY)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(classes[dom]),
                     "share_of_gpu_time": round(share, 3),
                     "algorithmic_flops_per_launch": flops,
-                    "all_kernels_ms_per_step": {f"{k[0]}:{k[2]}x{k[3]}": round(v / args.steps, 3) for k, v in tot.items()}}
+                    "all_kernels_ms_per_step": {f"{k[0]}:{k[2]}x{k[3]}": round(v / max(timed_launch_steps[0], 1), 3) for k, v in tot.items()},
+                    "instrumented_steps": timed_launch_steps[0]}
     if wg_timing:
         # training step: the weight gradients are the largest kernel class (usf_wgrad_f32 = the wgrad kernel + the
         # reduction of its row-range partials); the D x D launches of the affine layers are the dominant shape

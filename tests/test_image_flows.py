@@ -731,6 +731,7 @@ def test_convnet_spatial_conditioner_runs_on_the_image_kernels(monkeypatch):
     tests/test_mirror_vs_live_reference.py holds bit for bit against the real reference)"""
     import copy
     from usflows_amd import _ext
+    DEV = "cuda:0"
     from usflows_amd.flows import USFlow
     from usflows_amd.networks import ConvNet
     from image_synth import synth_image_params_
@@ -743,7 +744,8 @@ def test_convnet_spatial_conditioner_runs_on_the_image_kernels(monkeypatch):
     for l in f64.layers:
         if torch.is_tensor(getattr(l, "mask", None)):
             l.mask = l.mask.double()
-    f64.base_distribution = torch.distributions.Independent(torch.distributions.Laplace(torch.zeros(dims).double(), torch.ones(dims).double()), 3)
+    from usflows_amd.distributions import Independent
+    f64.base_distribution = Independent(torch.distributions.Laplace(torch.zeros(dims).double(), torch.ones(dims).double()), 3)
     torch.set_default_dtype(torch.float64)
     try:
         lp64 = f64.log_prob(x.double())

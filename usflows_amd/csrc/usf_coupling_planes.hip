@@ -86,6 +86,8 @@ struct CplPArgs {
 #define CSTAMP(v)
 #endif
 
+template <bool B> struct CpBoolT { static constexpr bool value = B; };
+
 template <int NPL, int NH>
 __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs p) {
   typedef CPlanes<NPL> PT;
@@ -287,6 +289,20 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
 
   CSTAMP(c2);
   // ================= phase 3: z_T[row][n] += sign * (b_out[n] + sum_h X[h][row] W_out[n][h']) on the transformed blocks =====
+  // The epilogue of output block nt (residual rebuilt from its planes, fma, three-way split, plane stores: ~80 vector
+  // instructions per lane) is deferred by one block: it sits in the instruction stream of block nt + 1 and is pinned, five
+  // instructions per MFMA group, into the issue slots the matrix instructions leave free (-DUSF_CP_PIPE_EPI=1; round 4: an
+  // experiment that did NOT pay in the flow and is off by default) -- otherwise both waves of a SIMD run it back to back
+  // behind their MFMAs.  The stores are raw buffer stores
+  // whose resource is empty for a wave beyond the last panel (dropped by the hardware): no branch inside the pinned region.
+  // (NH == 3 runs at the 256-register budget: it keeps the epilogue behind its own block.)
+#ifndef USF_CP_PIPE_EPI
+#define USF_CP_PIPE_EPI 0          // measured in the flow (profiles/r04_tuning_experiments.md): 6.53 ms of couplings per step with, 6.46 without
+#endif
+  constexpr bool PIPE = (USF_CP_PIPE_EPI != 0) && NH <= 2;
+  typedef unsigned cp_u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(
+      p.z, 0, live ? (int)((size_t)p.npanels * p.z_nkb * CHB) : 0, 0x00020000);
   auto output_layer = [&](f32x4 (&X)[T]) {
     vec8 xp[KS][NPL];
 #pragma unroll
@@ -301,8 +317,38 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
 #pragma unroll
       for (int u = 0; u < 2; ++u) bo[u] = *reinterpret_cast<const f32x4*>(p.b_out + nt * 32 + 16 * u + 4 * lg);
     };
+    // lane-local epilogue: the two tiles are the lane's 8 slots of its chunk line of block kb_t0 + nt
+    auto epilogue = [&](int nt, const auto& ac, const auto& rs) {
+      f32x4 v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float r = (float)rs[0][4 * u + e] + (float)rs[1][4 * u + e];
+          if (NPL == 3) r = r + (float)rs[NPL - 1][4 * u + e];
+          v[u][e] = __builtin_fmaf(p.sign, ac[u][e], r);       // (sign = +-1: the product is exact, one rounding either way)
+        }
+        guard(v[u]);
+      }
+      vec8 o[NPL];
+      PT::split(v[0], v[1], o);
+      if (PIPE) {
+        const unsigned off = (unsigned)(zbase + (size_t)(p.kb_t0 + nt) * CHB);
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_u32x4, o[q]), zrs, (int)(off + q * 1024u), 0, 0);
+      } else if (live) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q)
+          *reinterpret_cast<vec8*>(p.z + zbase + (size_t)(p.kb_t0 + nt) * CHB + q * 1024) = o[q];
+      }
+    };
     issue_res(0);
-    for (int nt = 0; nt < p.nk_t; ++nt, ++g) {
+    f32x4 accp[PIPE ? 2 : 1];
+    vec8 resp[PIPE ? NPL : 1];
+    // one output block: its MFMAs -- and, pipelined, the previous block's epilogue in their shadow
+    auto block = [&](int nt, auto with_prev) {
+      constexpr bool PREV = decltype(with_prev)::value;
       const int buf = g & 1;
       issue_n(p.Wout, p.ld_out, p.pl_out, min(nt + 1, p.nk_t - 1) * 32, st);
       f32x4 acc[2] = {bo[0], bo[1]};                         // the output bias is the accumulators' starting value
@@ -318,36 +364,35 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
           PT::mm(acc[u], w, xp[ks]);
         }
       }
+      if constexpr (PREV) epilogue(nt - 1, accp, resp);
       __builtin_amdgcn_sched_group_barrier(0x100, NPL * AHEAD, 0);
 #pragma unroll
       for (int i = 0; i < 2 * KS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, NPR, 0);
         if (i + AHEAD < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
         if (i < NST + NPL + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (PREV && i >= 1) __builtin_amdgcn_sched_group_barrier(0x002, (NPL == 3) ? 6 : 4, 0);
+        if (PREV && i >= 2 * KS - NPL) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       store_n(buf ^ 1, st);
-      // lane-local epilogue: the two tiles are the lane's 8 slots of its chunk line of block kb_t0 + nt
-      f32x4 v[2];
+      if constexpr (!PIPE) {
+        epilogue(nt, acc, res);
+      } else {
+        accp[0] = acc[0]; accp[1] = acc[1];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float r = (float)res[0][4 * u + e] + (float)res[1][4 * u + e];
-          if (NPL == 3) r = r + (float)res[NPL - 1][4 * u + e];
-          v[u][e] = __builtin_fmaf(p.sign, acc[u][e], r);      // (sign = +-1: the product is exact, one rounding either way)
-        }
-        guard(v[u]);
-      }
-      vec8 o[NPL];
-      PT::split(v[0], v[1], o);
-      if (live) {
-#pragma unroll
-        for (int q = 0; q < NPL; ++q)
-          *reinterpret_cast<vec8*>(p.z + zbase + (size_t)(p.kb_t0 + nt) * CHB + q * 1024) = o[q];
+        for (int q = 0; q < NPL; ++q) resp[q] = res[q];
       }
       issue_res(min(nt + 1, p.nk_t - 1));
       __syncthreads();
+      ++g;
+    };
+    if constexpr (PIPE) {
+      block(0, CpBoolT<false>());
+      for (int nt = 1; nt < p.nk_t; ++nt) block(nt, CpBoolT<true>());
+      epilogue(p.nk_t - 1, accp, resp);
+    } else {
+      for (int nt = 0; nt < p.nk_t; ++nt) block(nt, CpBoolT<false>());
     }
   };
   if (NH == 2) output_layer(X2); else output_layer(X1);

@@ -60,6 +60,84 @@ def _weight_planes(w, want_transposed: bool):
     return _ext.conv2d_weight_planes(w), None
 
 
+# ---- weight gradients beside the data-gradient chain (small batches): AN EXPERIMENT, OFF BY DEFAULT -------------------------
+# At the reference's training batch (32 rows, experiments/mnist/mnist.yaml:34) a step of the live MNIST configuration is ~1250
+# launches of ~5 us: bound by their dependent dispatch, not by their work.  The backward pass's critical path is the chain of
+# DATA gradients; a convolution's weight / bias gradient (usf_conv_wgrad_f32: the kernel and the sum of its per-sample partials)
+# is needed only by the optimiser.  With USFLOWS_AMD_SIDE_WGRAD=1 those launches (up to ``side_wgrad_max_rows`` rows) go to a
+# second stream that forks off the backward pass's stream in front of them and joins it once, when the pass ends (an autograd
+# engine callback): eagerly two streams, inside Flow.fit's captured step a parallel branch of the hipGraph.  MEASURED (round 4,
+# profiles/r04_tuning_experiments.md): the replayed step gets SLOWER -- live MNIST configuration at batch 32 6.25 -> 7.86 ms, the
+# 2-block model 0.67 -> 0.87 ms: every fork / join of a graph branch costs more than the ~5 us launch it takes off the chain.
+# Kept as a switch so that the measurement can be repeated; memory: operands read on the side stream are marked for it
+# (``record_stream``), results are allocated on it and used behind the join.
+side_wgrad_max_rows = 4096
+
+
+class _SideState(threading.local):
+    def __init__(self):
+        self.streams = {}        # device index -> side stream
+        self.pending = set()     # device indices with side work that the running backward pass has not joined yet
+        self.task = -1           # autograd graph task that queued the join callback
+
+
+_SIDE = _SideState()
+
+
+def _side_join():
+    """end of a backward pass (autograd engine callback): the pass's stream waits for the side work it forked"""
+    pend, _SIDE.pending = _SIDE.pending, set()
+    _SIDE.task = -1
+    for idx in pend:
+        torch.cuda.current_stream(idx).wait_stream(_SIDE.streams[idx])
+
+
+class side_wgrad:
+    """``with side_wgrad(x, dy, ...) as on:`` -- inside, launches go to the side stream when ``on`` (small batch, enabled)"""
+
+    def __init__(self, *operands, params=()):
+        """params: the Parameters whose gradients the block produces.  The autograd engine hands a gradient to its parameter as
+        soon as the node returns, on the pass's own stream: a parameter without a ``.grad`` simply TAKES the tensor (no read --
+        the case of every Flow.fit step), one with a ``.grad`` adds into it at once -- then the work stays on the pass's stream."""
+        self.ops = [t for t in operands if torch.is_tensor(t) and t.is_cuda]
+        import os
+        t0 = self.ops[0] if self.ops else None
+        self.on = (t0 is not None and 0 < t0.shape[0] <= side_wgrad_max_rows
+                   and os.environ.get("USFLOWS_AMD_SIDE_WGRAD", "0") == "1"
+                   and all(q is None or (q.grad is None and q.is_leaf and not q._backward_hooks) for q in params)
+                   and torch._C._current_graph_task_id() >= 0)
+        self.ctx = None
+
+    def __enter__(self):
+        if not self.on:
+            return False
+        dev = self.ops[0].device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        side = _SIDE.streams.get(idx)
+        if side is None:
+            side = _SIDE.streams[idx] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))           # fork: everything issued so far (x, dy) is ready
+        for t in self.ops:
+            t.record_stream(side)                                  # (their memory is not reused while the side work reads it)
+        task = torch._C._current_graph_task_id()
+        if task != _SIDE.task:
+            # a new backward pass (a pass that died of an exception never ran its callback: join what it left behind now)
+            if _SIDE.pending:
+                _side_join()
+                side.wait_stream(torch.cuda.current_stream(dev))
+            _SIDE.task = task
+            torch.autograd.Variable._execution_engine.queue_callback(_side_join)
+        _SIDE.pending.add(idx)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return True
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class ConvSame(torch.autograd.Function):
     """out_act(bias + conv(in_act(x) * in_mul)) on usf_conv2d_same_f32 (kernel 1 or 3, stride 1, "same")"""
 
@@ -74,6 +152,7 @@ class ConvSame(torch.autograd.Function):
                              in_mul=in_mul, in_act=ia[0], in_slope=ia[1], out_act=oa[0], out_slope=oa[1])
         ctx.save_for_backward(x, w, in_mul, y if out_act is not None else None)
         ctx.cfg = (ks, in_act, out_act, bias is not None)
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -87,7 +166,8 @@ class ConvSame(torch.autograd.Function):
         ia = _act(in_act)
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+            with side_wgrad(x, dy, in_mul, params=ctx.params):
+                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_shape_ok was not consulted)")
             dW, db = r
@@ -123,6 +203,7 @@ class ConvSameFork(torch.autograd.Function):
                              in_mul=in_mul, in_act=ia[0], in_slope=ia[1])
         ctx.save_for_backward(x, w, in_mul)
         ctx.cfg = (ks, in_act, bias is not None)
+        ctx.params = (weight, bias)
         return y, x.view_as(x)
 
     @staticmethod
@@ -133,7 +214,8 @@ class ConvSameFork(torch.autograd.Function):
         ia = _act(in_act)
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+            with side_wgrad(x, dy, in_mul, params=ctx.params):
+                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r
@@ -169,6 +251,7 @@ class Pointwise(torch.autograd.Function):
         y = _ext.pointwise_conv(x, w2, None if bias is None else bias.detach().contiguous(), in_act=ia[0], in_slope=ia[1])
         ctx.save_for_backward(x, w2)
         ctx.cfg = (in_act, bias is not None, tuple(weight.shape))
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -179,7 +262,8 @@ class Pointwise(torch.autograd.Function):
         ia = _act(in_act)
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+            with side_wgrad(x, dy, params=ctx.params):
+                r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r[0].reshape(wshape), r[1]
