@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 30
+#define USF_ABI_VERSION 31
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -358,6 +358,27 @@ int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, in
  * usf_gated_residual_bwd_f32: backward of usf_gated_residual_f32 with respect to vg: dvg [B, 2C, P] =
  *     (dy * sigmoid(gate), dy * val * sigmoid(gate) * (1 - sigmoid(gate))); the gradient with respect to x is dy itself.
  */
+/* Deferred sums of per-wave partial slots (the last stage of usf_conv_wgrad_f32) and many of them in ONE launch.
+ * usf_conv_wgrad_deferred_f32 = usf_conv_wgrad_f32 that stops in front of that stage: job[0 .. 1] (HOST memory, two entries)
+ * then describe what remains -- job[1] the final round that writes dW / db, job[0] the first round into the workspace's
+ * scratch rows when there are more than 64 slots (job[0].nparts == 0: a single round).  dW / db stay UNWRITTEN until
+ * usf_partial_sum_jobs_f32 launches containing first job[0] (if any), then job[1] have run in this stream order; the workspace
+ * must stay alive until then.
+ * usf_partial_sum_jobs_f32: jobs / block_job are DEVICE arrays: job j owns the blocks [first_block, first_block +
+ * ceil(n / 64) * rows) and block_job[b] names block b's job (n_blocks entries).  Row r of a job sums the slots
+ * [r * per, min((r + 1) * per, nparts)) in the order usf_conv_wgrad_f32's own rounds use: same bits.
+ * Why: at the reference's training batch (32 rows, experiments/mnist/mnist.yaml:34) a backward pass of the live MNIST
+ * configuration ends ~165 weight gradients with one or two such launches of a few microseconds each, all on the chain of
+ * dependent launches that bounds the step; queued, they are two launches behind the pass. */
+typedef struct usf_psum_job {
+  const float* part; float* out; float* out2;
+  int32_t nparts, n, mode, cin, cout, CIT, T, ntile;
+  int32_t first_block, per, rows, reserved;
+} usf_psum_job;
+int usf_conv_wgrad_deferred_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
+                                float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_stream_t stream);
+int usf_partial_sum_jobs_f32(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream);
 int64_t usf_conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int usf_conv_wgrad_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                        const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,

@@ -471,3 +471,40 @@ def test_weight_gradients_on_the_side_stream_are_the_same_bits(monkeypatch):
     assert not any(conv_used), "side stream used although the parameters already hold gradients"
     for k in g_off:
         assert torch.allclose(dict(flow.named_parameters())[k].grad, 2 * g_off[k], rtol=1e-5, atol=1e-6 * float(g_off[k].abs().max())), k
+
+
+@pytest.mark.gpu
+def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bits(monkeypatch):
+    """small batches: the last stage of every convolution weight gradient of a backward pass (the sum over per-wave partial
+    slots) is queued and leaves as ONE usf_partial_sum_jobs_f32 launch when the pass ends -- same additions in the same order
+    as usf_conv_wgrad_f32's own sum: same bits; a parameter that already holds a gradient keeps the undeferred call"""
+    from usflows_amd import _ext
+    flow, a = load_image_case("image_mnistcfg_c16_7x7_k2_gated_ln_hh1_conj", device=DEV)
+    x = a["x"].to(DEV)
+    launches = []
+    real = _ext._launch
+    monkeypatch.setattr(_ext, "_launch", lambda name, *a_, **k_: (launches.append(name), real(name, *a_, **k_))[1])
+
+    def grads(env):
+        monkeypatch.setenv("USFLOWS_AMD_PSUM_JOBS", env)
+        for p in flow.parameters():
+            p.grad = None
+        del launches[:]
+        (-flow.log_prob(x).mean()).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in flow.named_parameters() if p.grad is not None}, launches.count("usf_partial_sum_jobs_f32")
+
+    g_off, n_off = grads("0")
+    g_on, n_on = grads("1")
+    assert n_off == 0 and 1 <= n_on <= 2, (n_off, n_on)
+    assert set(g_on) == set(g_off)
+    for k in g_off:
+        assert torch.equal(g_on[k], g_off[k]), k
+    # gradients already in place: autograd adds the new ones at once -> nothing may be deferred
+    del launches[:]
+    (-flow.log_prob(x).mean()).backward()
+    torch.cuda.synchronize()
+    assert launches.count("usf_partial_sum_jobs_f32") == 0
+    named = dict(flow.named_parameters())
+    for k in g_off:
+        assert torch.allclose(named[k].grad, 2 * g_off[k], rtol=1e-5, atol=1e-6 * float(g_off[k].abs().max())), k

@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 30
+USF_ABI_VERSION = 31
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -137,6 +137,14 @@ class PackJob(C.Structure):
     ]
 
 
+class PsumJob(C.Structure):
+    """usf_psum_job: one deferred sum of per-wave partial slots (usf_conv_wgrad_deferred_f32 / usf_partial_sum_jobs_f32)"""
+    _fields_ = [("part", _fp), ("out", _fp), ("out2", _fp),
+                ("nparts", C.c_int32), ("n", C.c_int32), ("mode", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("CIT", C.c_int32), ("T", C.c_int32), ("ntile", C.c_int32), ("first_block", C.c_int32), ("per", C.c_int32),
+                ("rows", C.c_int32), ("reserved", C.c_int32)]
+
+
 class GradJob(C.Structure):
     _fields_ = [
         ("Y", _fp), ("A", _fp), ("G", _fp),
@@ -196,6 +204,9 @@ SYMBOLS = {
     "usf_conv_wgrad_workspace": (C.c_int64, [C.c_int64] * 6),
     "usf_conv_wgrad_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
                                      C.c_void_p]),
+    "usf_conv_wgrad_deferred_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
+                                              C.POINTER(PsumJob), C.c_void_p]),      # (job: two entries)
+    "usf_partial_sum_jobs_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_void_p]),
     "usf_layernorm_channels_bwd_workspace": (C.c_int64, [C.c_int64] * 3),
     "usf_layernorm_channels_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_int32, C.c_float,
                                                  _fp, _fp, C.c_int64, C.c_void_p]),
@@ -260,7 +271,7 @@ def load() -> C.CDLL:
     for kind, st in ((OP_LINEAR, LinearDesc), (OP_COUPLING, CouplingDesc), (0, Op), (3, LuPrepDesc), (4, PackJob),
                      (OP_PACK_PLANES, PackPlanesDesc), (OP_GEMM_PLANES, GemmPlanesDesc),
                      (OP_COUPLING_PLANES, CouplingPlanesDesc), (8, MtChunk), (OP_GATED_NORM, GatedNormDesc), (OP_CALL, CallDesc),
-                     (11, GradJob)):
+                     (11, GradJob), (12, PsumJob)):
         if lib.usf_sizeof_desc(kind) != C.sizeof(st):
             raise RuntimeError(f"usflows_amd: struct layout mismatch for {st.__name__}: "
                                f"C {lib.usf_sizeof_desc(kind)} vs ctypes {C.sizeof(st)}")
@@ -750,10 +761,115 @@ def masked_residual(x, t, one_minus_mask, sign):
     return y
 
 
-def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True):
+# ---- deferred sums of a backward pass (small batches): usf_conv_wgrad_deferred_f32 + ONE usf_partial_sum_jobs_f32 ------------
+# A weight gradient ends with a sum over per-wave partial slots -- at the reference's training batch a launch of a few
+# microseconds on the chain of dependent launches that bounds the step (live MNIST configuration: ~165 of ~1250 launches).  A
+# caller inside an autograd backward pass may ask ``conv_wgrad(..., defer=True)``: the sums of the pass are queued and leave as
+# ONE launch when the pass ends (an autograd engine callback).  dW / db are handed out UNWRITTEN until then, so the caller
+# vouches that nothing reads them before the pass ends (a parameter without a ``.grad`` takes the tensor as it is).
+# Inside a stream capture (Flow.fit's captured step) the job table cannot be uploaded (a host-to-device copy is not capturable)
+# and must not live in memory allocated inside the capture (recycled between the graph's kernels): ``capture_tables`` hands out
+# slices of a buffer allocated BEFORE the capture and uploads their contents after it, before the first replay.
+PSUM_DEFER_MAX_ROWS = 4096
+n_jobs_flushed = [0]             # (introspection for tests / tools: sums that left through usf_partial_sum_jobs_f32)
+
+
+class _PsumState:
+    """process-wide (under a lock), NOT thread-local: the autograd engine runs a device's backward nodes on a worker thread of
+    its own, while the end-of-pass callback runs on the thread that called backward()"""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.jobs = {}           # autograd graph task id -> [(PsumJob, tensors to keep alive until the launch)]
+        self.arena = None        # capture_tables: [buffer, bytes used, [(device slice, host tensor)]]
+
+
+_psum = _PsumState()
+
+
+class capture_tables:
+    """``with capture_tables(device, nbytes): <stream capture>`` -- device tables needed by launches inside the capture"""
+
+    def __init__(self, device, nbytes: int = 1 << 20):
+        self.device, self.nbytes, self.prev = device, nbytes, None
+
+    def __enter__(self):
+        self.prev = _psum.arena
+        _psum.arena = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device), 0, []]
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        arena, _psum.arena = _psum.arena, self.prev
+        self.pending = arena[2] if exc_type is None else []
+        self.keep = arena[0]
+        return False
+
+    def upload(self):
+        """after the capture has ended: the tables' contents (nothing of the graph has run yet)"""
+        for dev, host in self.pending:
+            dev.copy_(host)
+        self.pending = []
+
+
+def _device_table(host: torch.Tensor, device) -> Optional[torch.Tensor]:
+    """a uint8 host tensor on the device: an upload -- or, inside a capture, a slice of the capture's table buffer whose upload is
+    pending (None: capturing without such a buffer)"""
+    if torch.cuda.is_current_stream_capturing():
+        ar = _psum.arena
+        n = (host.numel() + 15) // 16 * 16
+        if ar is None or ar[0].device != torch.device(device) or ar[1] + n > ar[0].numel():
+            return None
+        dev = ar[0][ar[1]: ar[1] + host.numel()]
+        ar[1] += n
+        ar[2].append((dev, host))
+        return dev
+    return host.to(device)
+
+
+def psum_defer_ok(x) -> bool:
+    """may a weight gradient of this input queue its last sum?  (small batch, inside a backward pass, and -- inside a capture --
+    a table buffer at hand)"""
+    return (os.environ.get("USFLOWS_AMD_PSUM_JOBS", "1") != "0" and 0 < x.shape[0] <= PSUM_DEFER_MAX_ROWS
+            and torch._C._current_graph_task_id() >= 0
+            and (not torch.cuda.is_current_stream_capturing() or _psum.arena is not None))
+
+
+def flush_partial_sums(task: int) -> None:
+    """issue the sums backward pass `task` queued on the current stream (the pass's end-of-pass callback): ONE launch for all
+    first rounds, ONE for all final rounds"""
+    with _psum.lock:
+        jobs = _psum.jobs.pop(task, [])
+    if not jobs:
+        return
+    device = jobs[0][2][0].device
+    n_jobs_flushed[0] += len(jobs)
+    for stage in (0, 1):
+        part = [(j[stage], j[2]) for j in jobs if j[stage] is not None]
+        if not part:
+            continue
+        block_job, first = [], 0
+        for i, (j, _keep) in enumerate(part):
+            nb = ((j.n + 63) // 64) * j.rows
+            j.first_block = first
+            block_job.extend([i] * nb)
+            first += nb
+        arr = (PsumJob * len(part))(*[j for j, _ in part])
+        raw = bytearray(bytes(arr))
+        raw += b"\0" * ((-len(raw)) % 16)
+        off = len(raw)
+        raw += struct.pack(f"<{len(block_job)}i", *block_job)
+        host = torch.frombuffer(raw, dtype=torch.uint8)
+        table = _device_table(host, device)
+        if table is None:
+            raise RuntimeError("usflows_amd: deferred partial sums inside a stream capture without a capture_tables buffer")
+        _launch("usf_partial_sum_jobs_f32", (table.data_ptr(), table.data_ptr() + off, first, current_stream(device)),
+                (table, [k for _, k in part]))
+
+
+def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True, defer=False):
     """usf_conv_wgrad_f32: (dW [cout, cin, ks, ks], db [cout] | None) of a stride-1 "same" convolution from its input x
     [B, cin, H, W] (with the forward's input transforms) and the output gradient dy [B, cout, H, W]; None when the shape is
-    not served"""
+    not served.  defer (see above): the final sum may be queued -- dW / db are then complete when the backward pass ends"""
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     lib = load()
@@ -763,6 +879,29 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     dW = torch.empty(cout, cin, ks, ks, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    if defer and psum_defer_ok(x):
+        job2 = (PsumJob * 2)()
+        rc = lib.usf_conv_wgrad_deferred_f32(x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act),
+                                             float(in_slope), dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, job2, current_stream(x.device))
+        if rc == 1:
+            return None
+        check(rc, "usf_conv_wgrad_deferred_f32")
+        if job2[1].nparts > 0:
+            task = torch._C._current_graph_task_id()
+            with _psum.lock:
+                q = _psum.jobs.get(task)
+                if q is None:
+                    # (queues of passes that died of an exception are dropped here: their outputs are garbage anyway)
+                    _psum.jobs = {task: []}
+                    q = _psum.jobs[task]
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: flush_partial_sums(t))
+                # (only the partial slots are kept alive: an extra reference to dW / db would stop the autograd engine from
+                # TAKING them as the parameter's gradient -- it would copy them on the spot, before the sum has run)
+                j0 = None
+                if job2[0].nparts > 0:
+                    j0 = PsumJob.from_buffer_copy(job2[0])
+                q.append((j0, PsumJob.from_buffer_copy(job2[1]), (ws,)))
+        return dW, db
     args = (x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act), float(in_slope),
             dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, current_stream(x.device))
     rc = _timed_call(lib.usf_conv_wgrad_f32, args, "usf_conv_wgrad_f32")

@@ -81,7 +81,8 @@ int masked_residual(const float* x, const float* t, const float* om, float sign,
 int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
-               int64_t workspace_floats, hipStream_t stream);
+               int64_t workspace_floats, usf_psum_job* job, hipStream_t stream);
+int partial_sum_jobs(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
 int64_t layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P);
 int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma, float eps,
                            int32_t act, float slope, float* dgamma, float* dbeta, float* workspace, int64_t workspace_floats,
@@ -134,6 +135,7 @@ int usf_sizeof_desc(int32_t kind) {
     case USF_OP_GATED_NORM: return (int)sizeof(usf_gated_norm_desc);
     case USF_OP_CALL: return (int)sizeof(usf_call_desc);
     case 11: return (int)sizeof(usf_grad_job);
+    case 12: return (int)sizeof(usf_psum_job);
     default: return -1;
   }
 }
@@ -279,7 +281,17 @@ int usf_conv_wgrad_f32(const float* x, const float* dy, int64_t B, int64_t cin, 
                        const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
                        float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::conv_wgrad(x, dy, B, cin, cout, H, W, ks, in_mul, pre_sub, in_act, in_slope, dW, db, workspace, workspace_floats,
+                         nullptr, (hipStream_t)stream);
+}
+int usf_conv_wgrad_deferred_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
+                                float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_stream_t stream) {
+  if (!job) { usf::set_error("usf_conv_wgrad_deferred_f32: job is NULL"); return -1; }
+  return usf::conv_wgrad(x, dy, B, cin, cout, H, W, ks, in_mul, pre_sub, in_act, in_slope, dW, db, workspace, workspace_floats, job,
                          (hipStream_t)stream);
+}
+int usf_partial_sum_jobs_f32(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream) {
+  return usf::partial_sum_jobs(jobs, block_job, n_blocks, (hipStream_t)stream);
 }
 int64_t usf_layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P) { return usf::layernorm_channels_bwd_workspace(B, C, P); }
 int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma,

@@ -290,13 +290,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_k1_kernel(const WgArgs a) {
 // mode 0: out[j] for j < n.  mode 1 (weight gradient): slot layout of conv_wgrad_kernel -> dW [cout][cin][T], db [cout].
 // blockIdx.y selects a slice of `per` slots and (mode 0) its own output row: reduce_partials below adds many slots in two
 // rounds so that the sum over thousands of slots is not left to a handful of blocks.
-__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, int nparts, int per, int n,
-                                                          float* __restrict__ out, float* __restrict__ out2, int mode, int cin,
-                                                          int cout, int CIT, int T, int ntile) {
+__device__ __forceinline__ void partial_sum_block(const float* __restrict__ part, int nparts, int per, int n, float* __restrict__ out,
+                                                  float* __restrict__ out2, int mode, int cin, int cout, int CIT, int T, int ntile,
+                                                  int bx, int by) {
   __shared__ float red[4][64];
   const int jj = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + jj;
-  const int p0 = blockIdx.y * per, p1 = (p0 + per < nparts) ? p0 + per : nparts;
+  const int j = bx * 64 + jj;
+  const int p0 = by * per, p1 = (p0 + per < nparts) ? p0 + per : nparts;
   float s = 0.f;
   if (j < n)
     for (int p = p0 + g; p < p1; p += 4) s += part[(int64_t)p * n + j];
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
   if (g != 0 || j >= n) return;
   const float total = ((red[0][jj] + red[1][jj]) + red[2][jj]) + red[3][jj];
   if (mode == 0) {
-    out[(int64_t)blockIdx.y * n + j] = total;
+    out[(int64_t)by * n + j] = total;
     return;
   }
   if (j >= ntile * 256) {
@@ -317,6 +317,22 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restric
   const int cot = tile / (CIT * T), cit = (tile / T) % CIT, t = tile % T;
   const int co = cot * 16 + 4 * (ln >> 4) + r, ci = cit * 16 + (ln & 15);
   if (co < cout && ci < cin) out[((int64_t)co * cin + ci) * T + t] = total;
+}
+
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, int nparts, int per, int n,
+                                                          float* __restrict__ out, float* __restrict__ out2, int mode, int cin,
+                                                          int cout, int CIT, int T, int ntile) {
+  partial_sum_block(part, nparts, per, n, out, out2, mode, cin, cout, CIT, T, ntile, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// MANY single-round sums in one launch (usf_partial_sum_jobs_f32): block b serves job block_job[b], as block
+// b - first_block of partial_sum_kernel would -- same order of additions, same bits.  At the reference's training batch
+// (32 rows) a backward pass of the live MNIST configuration asks for ~165 of these sums of a few microseconds each; queued
+// (usf_conv_wgrad_deferred_f32) they leave the chain of dependent launches and run as ONE launch when the pass ends.
+__global__ __launch_bounds__(256) void partial_sum_jobs_kernel(const usf_psum_job* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const usf_psum_job j = jobs[block_job[blockIdx.x]];
+  const int local = (int)blockIdx.x - j.first_block, gx = (j.n + 63) / 64;
+  partial_sum_block(j.part, j.nparts, j.per, j.n, j.out, j.out2, j.mode, j.cin, j.cout, j.CIT, j.T, j.ntile, local % gx, local / gx);
 }
 
 constexpr int kReduceRows = 64;        // scratch rows of the two-round sum (workspace: kReduceRows * n floats behind the slots)
@@ -459,8 +475,9 @@ int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, in
 
 int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
-               int64_t workspace_floats, hipStream_t stream) {
+               int64_t workspace_floats, usf_psum_job* job, hipStream_t stream) {
   WgPlan pl;
+  if (job) job[0].nparts = job[1].nparts = 0;
   if (B < 0) { set_error("usf_conv_wgrad_f32: bad sizes"); return -2; }
   if (B == 0 || !wgrad_plan(B, cin, cout, H, W, ks, in_mul != nullptr, pl)) {
     if (B == 0) { set_error("usf_conv_wgrad_f32: empty batch"); return -2; }
@@ -501,8 +518,40 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
   int rc = check_launch("usf_conv_wgrad_f32");
   if (rc) return rc;
   const int ntile = pl.COT * pl.CIT * pl.T;
+  if (job) {
+    // the sums are handed to the caller as jobs of usf_partial_sum_jobs_f32 (the outputs stay unwritten until then): job[1] the
+    // final round, job[0] the first round into the scratch rows when there are more than 64 slots (reduce_partials' two rounds)
+    int nparts = pl.blocks * 4;
+    const float* src = workspace;
+    float* scratch = workspace + (int64_t)pl.blocks * 4 * pl.nacc;
+    job[0].nparts = 0;
+    if (nparts > 64) {
+      const int rows = nparts / 16 < kReduceRows ? (nparts + 15) / 16 : kReduceRows;
+      const int per = (nparts + rows - 1) / rows;
+      const int used = (nparts + per - 1) / per;
+      usf_psum_job& a0 = job[0];
+      a0.part = workspace; a0.out = scratch; a0.out2 = nullptr; a0.nparts = nparts; a0.n = pl.nacc; a0.mode = 0; a0.cin = a0.cout = 0;
+      a0.CIT = a0.T = a0.ntile = 0; a0.first_block = 0; a0.per = per; a0.rows = used;
+      src = scratch;
+      nparts = used;
+    }
+    usf_psum_job& a1 = job[1];
+    a1.part = src; a1.out = dW; a1.out2 = db; a1.nparts = nparts; a1.n = pl.nacc; a1.mode = 1; a1.cin = (int)cin; a1.cout = (int)cout;
+    a1.CIT = pl.CIT; a1.T = pl.T; a1.ntile = ntile; a1.first_block = 0; a1.per = nparts; a1.rows = 1;
+    return 0;
+  }
   return reduce_partials(workspace, pl.blocks * 4, pl.nacc, workspace + (int64_t)pl.blocks * 4 * pl.nacc, dW, db, 1, (int)cin, (int)cout,
                          pl.CIT, pl.T, ntile, stream, "usf_conv_wgrad_f32 (reduce)");
+}
+
+int partial_sum_jobs(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream) {
+  if (n_blocks < 0 || n_blocks > 0x7fffffff || (n_blocks > 0 && (!jobs || !block_job))) {
+    set_error("usf_partial_sum_jobs_f32: bad arguments");
+    return -1;
+  }
+  if (n_blocks == 0) return 0;
+  hipLaunchKernelGGL(partial_sum_jobs_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, jobs, block_job);
+  return check_launch("usf_partial_sum_jobs_f32");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -893,14 +893,16 @@ class Flow(torch.nn.Module):
                 on_own = cur == self.__dict__.get("_fit_stream")
                 if hasattr(optim, "defer_uploads"):
                     optim.defer_uploads(True)
+                tables = _ext.capture_tables(sample.device)          # (job tables of launches inside the capture: _ext.conv_wgrad)
                 try:
-                    with (torch.cuda.graph(graph, stream=cur) if on_own else torch.cuda.graph(graph)):
+                    with tables, (torch.cuda.graph(graph, stream=cur) if on_own else torch.cuda.graph(graph)):
                         sl = body()
                 finally:
                     if hasattr(optim, "defer_uploads"):
                         optim.defer_uploads(False)
                 if hasattr(optim, "flush_uploads"):
                     optim.flush_uploads()
+                tables.upload()
             except Exception as e:      # noqa: BLE001  (an op that cannot be captured: eager steps from now on)
                 self._train_graph_failed = True
                 self._recover_from_failed_capture(optim, params)
@@ -914,7 +916,7 @@ class Flow(torch.nn.Module):
             # the graph holds raw addresses: keep what it writes to and reads from alive whatever happens to `p.grad` or to
             # the optimiser's pointer tables afterwards (an eager step in between -- the ragged last batch of an epoch --
             # must not free them: a replay into freed gradient buffers is a GPU memory fault waiting for the allocator)
-            keep = ([p.grad for p in params], dict(getattr(optim, "_tables", {}) or {}))
+            keep = ([p.grad for p in params], dict(getattr(optim, "_tables", {}) or {}), tables.keep)
             st.update(graph=graph, x=sx, ctx=sc, loss=sl, params=params, keep=keep)
         st["x"].copy_(sample)
         if st["ctx"] is not None:

@@ -74,20 +74,31 @@ def _weight_planes(w, want_transposed: bool):
 side_wgrad_max_rows = 4096
 
 
-class _SideState(threading.local):
+def _takeable(params) -> bool:
+    """True when the autograd engine will TAKE the gradients of these Parameters as they are handed over (no ``.grad`` yet, no
+    hooks that would read them): a gradient whose last sum is still queued (_ext.conv_wgrad(defer=True)) or running on the side
+    stream must not be read before the backward pass ends"""
+    return all(q is None or (q.grad is None and q.is_leaf and not q._backward_hooks
+                             and not getattr(q, "_post_accumulate_grad_hooks", None)) for q in params)
+
+
+class _SideState:
+    """process-wide, not thread-local: backward nodes run on the autograd engine's device thread, the end-of-pass callback on
+    the thread that called backward()"""
+
     def __init__(self):
+        self.lock = threading.Lock()
         self.streams = {}        # device index -> side stream
-        self.pending = set()     # device indices with side work that the running backward pass has not joined yet
-        self.task = -1           # autograd graph task that queued the join callback
+        self.pending = {}        # autograd graph task id -> device indices with side work the pass has not joined yet
 
 
 _SIDE = _SideState()
 
 
-def _side_join():
+def _side_join(task):
     """end of a backward pass (autograd engine callback): the pass's stream waits for the side work it forked"""
-    pend, _SIDE.pending = _SIDE.pending, set()
-    _SIDE.task = -1
+    with _SIDE.lock:
+        pend = _SIDE.pending.pop(task, set())
     for idx in pend:
         torch.cuda.current_stream(idx).wait_stream(_SIDE.streams[idx])
 
@@ -104,8 +115,7 @@ class side_wgrad:
         t0 = self.ops[0] if self.ops else None
         self.on = (t0 is not None and 0 < t0.shape[0] <= side_wgrad_max_rows
                    and os.environ.get("USFLOWS_AMD_SIDE_WGRAD", "0") == "1"
-                   and all(q is None or (q.grad is None and q.is_leaf and not q._backward_hooks) for q in params)
-                   and torch._C._current_graph_task_id() >= 0)
+                   and _takeable(params) and torch._C._current_graph_task_id() >= 0)
         self.ctx = None
 
     def __enter__(self):
@@ -113,21 +123,20 @@ class side_wgrad:
             return False
         dev = self.ops[0].device
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        side = _SIDE.streams.get(idx)
-        if side is None:
-            side = _SIDE.streams[idx] = torch.cuda.Stream(device=dev)
+        with _SIDE.lock:
+            side = _SIDE.streams.get(idx)
+            if side is None:
+                side = _SIDE.streams[idx] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))           # fork: everything issued so far (x, dy) is ready
         for t in self.ops:
             t.record_stream(side)                                  # (their memory is not reused while the side work reads it)
         task = torch._C._current_graph_task_id()
-        if task != _SIDE.task:
-            # a new backward pass (a pass that died of an exception never ran its callback: join what it left behind now)
-            if _SIDE.pending:
-                _side_join()
-                side.wait_stream(torch.cuda.current_stream(dev))
-            _SIDE.task = task
-            torch.autograd.Variable._execution_engine.queue_callback(_side_join)
-        _SIDE.pending.add(idx)
+        with _SIDE.lock:
+            pend = _SIDE.pending.get(task)
+            if pend is None:
+                pend = _SIDE.pending[task] = set()
+                torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: _side_join(t))
+            pend.add(idx)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return True
@@ -167,7 +176,8 @@ class ConvSame(torch.autograd.Function):
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with side_wgrad(x, dy, in_mul, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
+                                    defer=_takeable(ctx.params))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_shape_ok was not consulted)")
             dW, db = r
@@ -215,7 +225,8 @@ class ConvSameFork(torch.autograd.Function):
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with side_wgrad(x, dy, in_mul, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
+                                    defer=_takeable(ctx.params))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r
@@ -263,7 +274,7 @@ class Pointwise(torch.autograd.Function):
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with side_wgrad(x, dy, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias)
+                r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable(ctx.params))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r[0].reshape(wshape), r[1]
