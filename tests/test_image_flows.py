@@ -516,7 +516,8 @@ def test_pointwise_conv_rejects_what_it_does_not_serve():
 def test_pointwise_conv_gated_layernorm_form_vs_torch(B, C, H, W):
     """usf_pointwise_conv_f32 with the layer norm joined to the gated pass: GatedConv's `x + val * sigmoid(gate)`, the ReLU
     and the LayerNormChannels behind it (networks.py:108-122, 480-493, 40-58) against the torch fp64 formulation, and
-    bit-equal to the two-pass device form (gated pointwise pass, then usf_layernorm_channels_f32 with the ReLU folded in)"""
+    bit-equal to the two-pass device form (gated pointwise pass, then usf_layernorm_channels_f32 with the ReLU folded in)
+    where that pass is the one-thread-per-pixel kernel (more than 16 384 pixels)"""
     from usflows_amd import _ext
     g = torch.Generator().manual_seed(B * 100 + C)
     dev = "cuda:0"
@@ -538,7 +539,12 @@ def test_pointwise_conv_gated_layernorm_form_vs_torch(B, C, H, W):
                                   relu[0], relu[1])
     torch.cuda.synchronize()
     assert (y.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
-    assert torch.equal(y, two)
+    if B * H * W > 16384 or C <= 8:
+        assert torch.equal(y, two)
+    else:
+        # few pixels: the stand-alone layer norm runs eight lanes per pixel (another order of additions): equal to rounding
+        assert (y - two).abs().max().item() < 4e-6 * max(1.0, ref.abs().max().item())
+        assert (two.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
     with pytest.raises(RuntimeError):
         _ext.pointwise_conv(x, w, b, ln=(gamma, beta, 1e-5))             # the layer-norm form needs the gated mode
 

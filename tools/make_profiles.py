@@ -45,7 +45,7 @@ def run(cmd, **kw):
 
 
 
-SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "image", "imagetrain"]
+SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "image", "imagetrain", "live"]
 
 
 B, D, H = 65536, 784, 256          # cfg2 shape (algorithmic byte counts of the traffic summaries)
@@ -90,21 +90,22 @@ def mfma_util(csv_path, out_path):
 
 
 if want("bench"):
-    # 1. plain bench
+    # 1. plain bench (the default line: headline + the "also" block)
     r = run(["python3", "bench.py"])
     open(os.path.join(out, f"{tag}_bench.json"), "w").write(last_json_line(r.stdout) + "\n")
 
     # 2. kernel trace + stats
     d = os.path.join(out, "ktrace")
-    r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py"])
+    r = run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--no-also"])
     open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w").write(last_json_line(r.stdout) + "\n")
     stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out, f"{tag}_bench_kernel_stats.csv"), "w") as f:
         f.write(open(stats[0]).read())
     with open(os.path.join(out, f"{tag}_bench_kernel_stats.md"), "w") as f:
-        f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py`\n\n"
-                "Command (GPU box): `rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py`\n"
+        f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --no-also`\n\n"
+                "Command (GPU box): `rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py --no-also`\n"
+                "(--no-also: the headline workload alone, without the other configurations the default line appends)\n"
                 "(defaults: --gpus 1 --steps 10 --warmup 3, gemm_mode bf16x3, planes pipeline; per pass 1 pack + 33 affine GEMMs on\n"
                 "planes (the last with fp32 output) + 32 fused couplings on planes + 1 tail; the same process then measures the\n"
                 "opt-in fp16x2 mode (the <2, ...> instantiations); the CPU-baseline leg and the first (parameter-prep) call add\n"
@@ -392,5 +393,64 @@ if want("imagetrain"):
          "mnist_image", "--mode", "train", "--eager-train", "--steps", "2", "--warmup", "1", "--no-kernel-timing"])
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         mfma_util(fn, os.path.join(out, f"{tag}_image_train_mfma_util.json"))
+
+# 7. the LIVE image configurations (round 4): radial base with an image-shaped loc, prior_scale 1.0, full depth
+#    (experiments/mnist/mnist.yaml:44-92, fashion/fashionclasses_veriflow.yaml:55-93, cifar/cifar.yaml)
+if want("live"):
+    with open(os.path.join(out, f"{tag}_live_bench.jsonl"), "w") as f:
+        for extra in (["--config", "mnist_live", "--steps", "5"], ["--config", "fashion_live", "--steps", "5"],
+                      ["--config", "cifar_image", "--base", "radial", "--prior-scale", "1", "--steps", "5"],
+                      ["--config", "mnist_image", "--base", "radial", "--prior-scale", "1", "--steps", "10"],
+                      ["--config", "mnist_live", "--mode", "train", "--batch", "32", "--steps", "40", "--warmup", "6"],
+                      ["--config", "fashion_live", "--mode", "train", "--batch", "32", "--steps", "40", "--warmup", "6"],
+                      ["--config", "mnist_image", "--base", "radial", "--prior-scale", "1", "--mode", "train", "--batch", "32", "--steps", "50", "--warmup", "6"],
+                      ["--config", "mnist_image", "--mode", "train", "--batch", "32", "--steps", "50", "--warmup", "6"],
+                      ["--config", "mnist_image", "--base", "radial", "--prior-scale", "1", "--mode", "train", "--steps", "5"],
+                      ["--config", "mnist_live", "--mode", "train", "--batch", "4096", "--steps", "5"]):
+            r = run(["python3", "bench.py", "--cpu-seconds", "2", "--cpu-rows", "256"] + extra)
+            f.write(last_json_line(r.stdout) + "\n")
+    d = os.path.join(out, "ktrace_live")
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--config", "mnist_live",
+         "--steps", "5", "--no-cpu-baseline"])
+    stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(out, f"{tag}_live_kernel_stats.md"), "w") as f:
+        f.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --config mnist_live --steps 5 --no-cpu-baseline`\n\n"
+                "(log_prob of 65 536 rows of the LIVE MNIST configuration, experiments/mnist/mnist.yaml:44-92: 15 coupling blocks x 3 gated\n"
+                "layers, RadialDistribution(zeros[16,7,7], p=1, LogNormal(6, .35)) base on usf_radial_logprob_f32; 6 calls in the trace)\n\n"
+                "| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|\n")
+        for row in rows[:14]:
+            name = row["Name"]
+            name = name if len(name) < 110 else name[:107] + "..."
+            f.write(f"| `{name}` | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |\n")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, "pmc_live_" + ctr)
+        run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--config", "mnist_image", "--base",
+             "radial", "--prior-scale", "1", "--mode", "train", "--eager-train", "--steps", "2", "--warmup", "1", "--no-kernel-timing",
+             "--no-cpu-baseline"])
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                k = row["Kernel_Name"]
+                if "usf::radial" not in k:
+                    continue
+                k = k[k.index("usf::") + 5:]
+                k = k[: k.index("(")] if "(" in k else k
+                agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    kern = {}
+    for k, dct in sorted(agg.items()):
+        f_ = sum(dct["FETCH_SIZE"]) / max(1, len(dct["FETCH_SIZE"]))
+        w_ = sum(dct["WRITE_SIZE"]) / max(1, len(dct["WRITE_SIZE"]))
+        kern[k] = {"FETCH_SIZE_KB": round(f_, 1), "WRITE_SIZE_KB": round(w_, 1), "dispatches": len(dct["FETCH_SIZE"]),
+                   "hbm_bytes_per_launch": int((2 * f_ + w_) * 1024)}
+    json.dump({
+        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --config mnist_image --base radial "
+                  "--prior-scale 1 --mode train --eager-train --steps 2 --warmup 1 --no-kernel-timing --no-cpu-baseline`, MI355X; "
+                  "tools/make_profiles.py",
+        "units": "the radial base's kernels at 65 536 rows x 784 features: hbm_bytes_per_launch = (2 FETCH_SIZE + WRITE_SIZE) KB (FETCH_SIZE "
+                 "doubled as MI355X_MICROARCH.md prescribes for gfx950).  Algorithmic bytes: usf_radial_logprob_f32 reads the batch once "
+                 "(4 D = 3136 B per sample: 205.5 MB) and writes 8 B per sample; usf_radial_logprob_grad_f32 reads it once and writes d/dz "
+                 "(411 MB), the column sum for d/dloc reads d/dz once more (205.5 MB, colsum_kernel).",
+        "kernels": kern}, open(os.path.join(out, f"{tag}_live_hbm_traffic.json"), "w"), indent=1)
 
 print("wrote", sorted(os.listdir(out)))

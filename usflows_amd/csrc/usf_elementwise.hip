@@ -713,6 +713,52 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(const float* __
     if (c < C) yb[(int64_t)c * P] = (v[c] - mean) / den * gamma[c] + beta[c];
 }
 
+// Few pixels (a training batch of 32 rows: 1 568 pixels): one thread per pixel fills seven blocks and every thread walks its
+// 32 channels alone -- 13.8 us per launch, three times the launch floor, on the chain of dependent launches that bounds such a
+// step.  Here EIGHT lanes share a pixel (lane = 8 * channel group + pixel of the wave's 8: channels cg, cg + 8, ...), the two
+// sums cross the 8 lanes by shuffles: 8 x the blocks, an eighth of the serial work per thread.  (Sums are added in another
+// order than in the one-thread kernel: the two kernels agree to rounding, not bit for bit; a launch uses one of them for all rows.)
+template <int CMAX>
+__global__ __launch_bounds__(256) void layernorm_channels_small_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t BP,
+                                                                       int C, int64_t P, const float* __restrict__ gamma,
+                                                                       const float* __restrict__ beta, float eps, int act,
+                                                                       float slope) {
+  constexpr int LP = 8, NC = CMAX / LP;
+  const int lane = threadIdx.x & 63;
+  const int pi = lane & 7, cg = lane >> 3;
+  const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + pi;
+  const bool on = i < BP;
+  const int64_t ic = on ? i : BP - 1;
+  const int64_t b = ic / P, p = ic - b * P;
+  const float* xb = x + b * C * P + p;
+  float v[NC];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = cg + LP * k;
+    v[k] = (c < C) ? act_apply(xb[(int64_t)c * P], act, slope) : 0.f;
+    sum += v[k];
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const float d = (cg + LP * k < C) ? v[k] - mean : 0.f;
+    sq += d * d;
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) sq += __shfl_xor(sq, o, 64);
+  const float den = sqrtf(sq / (float)C + eps);
+  float* yb = y + b * C * P + p;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = cg + LP * k;
+    if (on && c < C) yb[(int64_t)c * P] = (v[k] - mean) / den * gamma[c] + beta[c];
+  }
+}
+
 __global__ __launch_bounds__(256) void gated_residual_kernel(const float* __restrict__ x, const float* __restrict__ vg,
                                                              float* __restrict__ y, int64_t total, int64_t CP) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -737,6 +783,13 @@ int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P
   if (act != USF_ACT_NONE && act != USF_ACT_LEAKY_RELU) { set_error("usf_layernorm_channels_f32: bad act"); return -2; }
   const int64_t BP = B * P, blocks = (BP + 255) / 256;
   if (blocks > 0x7fffffffLL) { set_error("usf_layernorm_channels_f32: grid too large"); return -3; }
+  if (BP <= 16384 && C > 8) {                  // few pixels: eight lanes per pixel (see layernorm_channels_small_kernel)
+    const dim3 gs((unsigned)((BP + 31) / 32)), bs(256);
+    if (C <= 16) hipLaunchKernelGGL(layernorm_channels_small_kernel<16>, gs, bs, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+    else if (C <= 32) hipLaunchKernelGGL(layernorm_channels_small_kernel<32>, gs, bs, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+    else hipLaunchKernelGGL(layernorm_channels_small_kernel<64>, gs, bs, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
+    return check_launch("usf_layernorm_channels_f32");
+  }
   const dim3 g((unsigned)blocks), b(256);
   if (C <= 8) hipLaunchKernelGGL(layernorm_channels_kernel<8>, g, b, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
   else if (C <= 16) hipLaunchKernelGGL(layernorm_channels_kernel<16>, g, b, 0, stream, x, y, BP, (int)C, P, gamma, beta, eps, act, slope);
