@@ -770,7 +770,7 @@ def masked_residual(x, t, one_minus_mask, sign):
 # Inside a stream capture (Flow.fit's captured step) the job table cannot be uploaded (a host-to-device copy is not capturable)
 # and must not live in memory allocated inside the capture (recycled between the graph's kernels): ``capture_tables`` hands out
 # slices of a buffer allocated BEFORE the capture and uploads their contents after it, before the first replay.
-PSUM_DEFER_MAX_ROWS = 4096
+PSUM_DEFER_MAX_ROWS = 1024        # (launch-bound batches; above, the sums are a small part of kernels that take real time)
 n_jobs_flushed = [0]             # (introspection for tests / tools: sums that left through usf_partial_sum_jobs_f32)
 
 
@@ -790,7 +790,7 @@ _psum = _PsumState()
 class capture_tables:
     """``with capture_tables(device, nbytes): <stream capture>`` -- device tables needed by launches inside the capture"""
 
-    def __init__(self, device, nbytes: int = 1 << 20):
+    def __init__(self, device, nbytes: int = 8 << 20):
         self.device, self.nbytes, self.prev = device, nbytes, None
 
     def __enter__(self):
@@ -880,6 +880,13 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
     dW = torch.empty(cout, cin, ks, ks, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
     if defer and psum_defer_ok(x):
+        # (table bytes this pass has queued so far: inside a capture they must fit the pre-capture buffer)
+        with _psum.lock:
+            queued = _psum.jobs.get(torch._C._current_graph_task_id())
+            used = sum(q_[3] for q_ in queued) if queued else 0
+        if torch.cuda.is_current_stream_capturing() and used > _psum.arena[0].numel() // 2 - (1 << 16):
+            defer = False
+    if defer and psum_defer_ok(x):
         job2 = (PsumJob * 2)()
         rc = lib.usf_conv_wgrad_deferred_f32(x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act),
                                              float(in_slope), dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, job2, current_stream(x.device))
@@ -900,7 +907,8 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
                 j0 = None
                 if job2[0].nparts > 0:
                     j0 = PsumJob.from_buffer_copy(job2[0])
-                q.append((j0, PsumJob.from_buffer_copy(job2[1]), (ws,)))
+                nbytes = 2 * C.sizeof(PsumJob) + 4 * sum(((j_.n + 63) // 64) * j_.rows for j_ in job2 if j_.nparts > 0) + 64
+                q.append((j0, PsumJob.from_buffer_copy(job2[1]), (ws,), nbytes))
         return dW, db
     args = (x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act), float(in_slope),
             dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, current_stream(x.device))
