@@ -185,6 +185,9 @@ ALSO = [
 ]
 
 
+ALSO_BUDGET_S = 150.0            # (measured: 37 s for all entries on an idle box)
+
+
 def run_also(args):
     """the other workloads DESIGN.md quotes, each measured by run_config in this process (same contract: W warm-up steps,
     K timed steps, device-synchronised), condensed to value / ms_per_step / dominant-kernel roofline / parity"""
@@ -194,6 +197,11 @@ def run_also(args):
     for label, argv in ALSO:
         t0 = time.perf_counter()
         rec = {"workload": label, "argv": " ".join(argv)}
+        if t0 - t_all > ALSO_BUDGET_S:
+            # (a slow box: the default command must stay within a few minutes whatever happens; the entry can be run by hand)
+            rec["skipped"] = f"time budget of the also block ({ALSO_BUDGET_S} s) spent"
+            out.append(rec)
+            continue
         try:
             a = parse_args(argv)
             if a.config == "cfg4":

@@ -299,15 +299,19 @@ __global__ __launch_bounds__(64 * RAD_WPB) void radial_grad_kernel(
   }
 }
 
-// the blocks' partial sums added in block order; chain rule through softplus to the stored parameters
-__global__ __launch_bounds__(3 * RAD_MAXK) void radial_grad_finish_kernel(const double* __restrict__ part, int blocks, int norm, int K,
-                                                                          const float* __restrict__ par_a, const float* __restrict__ par_b,
-                                                                          float* __restrict__ d_a, float* __restrict__ d_b,
-                                                                          float* __restrict__ d_logits) {
-  const int q = threadIdx.x / RAD_MAXK, k = threadIdx.x % RAD_MAXK;
-  if (k >= K) return;
+// the blocks' partial sums added in a fixed order (one wave per output: lane l adds blocks l, l + 64, ..., then a shuffle tree);
+// chain rule through softplus to the stored parameters.  grid = 3 * K waves.  (A single thread per output walking up to 1024
+// partials one dependent load at a time took 0.25 ms at 4096 rows -- longer than the pass over the batch.)
+__global__ __launch_bounds__(64) void radial_grad_finish_kernel(const double* __restrict__ part, int blocks, int norm, int K,
+                                                                const float* __restrict__ par_a, const float* __restrict__ par_b,
+                                                                float* __restrict__ d_a, float* __restrict__ d_b,
+                                                                float* __restrict__ d_logits) {
+  const int q = blockIdx.x / K, k = blockIdx.x - q * K;
+  const int lane = threadIdx.x;
   double t = 0.0;
-  for (int b = 0; b < blocks; ++b) t += part[((int64_t)b * 3 + q) * RAD_MAXK + k];
+  for (int b = lane; b < blocks; b += 64) t += part[((int64_t)b * 3 + q) * RAD_MAXK + k];
+  t = wave_sum_d(t);
+  if (lane != 0) return;
   const bool raw = (norm & USF_NORM_RAW_PARAMS) != 0;
   const int kind = norm & 0xff;
   if (q == 0) {
@@ -369,7 +373,7 @@ int radial_grad(const float* z, int64_t ldz, const float* r, const float* g_lp, 
   int rc = check_launch("usf_radial_logprob_grad_f32");
   if (rc) return rc;
   if (d_a || d_b || d_logits) {
-    hipLaunchKernelGGL(radial_grad_finish_kernel, dim3(1), dim3(3 * RAD_MAXK), 0, stream, part, (int)blocks, (int)norm, (int)K,
+    hipLaunchKernelGGL(radial_grad_finish_kernel, dim3((unsigned)(3 * K)), dim3(64), 0, stream, part, (int)blocks, (int)norm, (int)K,
                        par_a, par_b, d_a, d_b, d_logits);
     rc = check_launch("usf_radial_logprob_grad_f32(finish)");
     if (rc) return rc;
