@@ -146,13 +146,24 @@ def main():
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # started by torch.distributed.run
     if args.gpus > 1 and not under_launcher:
         sys.exit(launch_ranks(args))
-    out = run_config(args, under_launcher)
+    # stdout carries exactly ONE line, the JSON: whatever a library prints to file descriptor 1 meanwhile (RCCL announces its
+    # version there when a communicator is created) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out = run_config(args, under_launcher)
+        if out is not None:
+            default_line = (len(sys.argv) == 1 or all(a.split("=")[0] in ("--gpus", "--steps", "--warmup") or a.lstrip("-").isdigit()
+                                                     for a in sys.argv[1:]))
+            if default_line and args.gpus == 1 and not under_launcher and not args.no_also and args.device == "cuda":
+                out["also"] = run_also(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     if out is None:                 # (a rank other than 0)
         return
-    default_line = (len(sys.argv) == 1 or all(a.split("=")[0] in ("--gpus", "--steps", "--warmup") or a.lstrip("-").isdigit()
-                                             for a in sys.argv[1:]))
-    if default_line and args.gpus == 1 and not under_launcher and not args.no_also and args.device == "cuda":
-        out["also"] = run_also(args)
     print(json.dumps(out), flush=True)
 
 
