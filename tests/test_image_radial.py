@@ -396,3 +396,40 @@ def test_radial_autograd_function_plumbing_cpu(monkeypatch):
         rr = torch.tensor([3.7], dtype=torch.float64)
         bb = D.RadialDistribution(loc=torch.zeros(d), norm_distribution=nd, p=p)
         assert abs(float(bb.log_delta_volume(p, rr)) - (radial.log_dv_const(p, d) + (d - 1) * math.log(3.7))) < 1e-9 * d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [0, 1, 3])
+def test_live_configuration_empty_and_tiny_batches(B):
+    """edge cases of the radial device path through the flow: an empty batch (empty log_prob; zero gradients for the base's
+    parameters), one and three rows (a ragged last batch of Flow.fit) -- values against the mirror on the CPU"""
+    import copy
+    name = "imageradial_fashionlive_c16_7x7_k2_l3_gammamm"
+    flow, a, _, spec = load_image_radial_case(name)
+    cpu = copy.deepcopy(flow)
+    flow = flow.to(DEV)
+    x = a["x"][:B]
+    with torch.no_grad():
+        lp = flow.log_prob(x.to(DEV))
+    assert lp.shape == (B,)
+    if B:
+        with torch.no_grad():
+            _close(lp, cpu.log_prob(x), 2e-6, "log_prob")
+    lpg = flow.log_prob(x.to(DEV))
+    lpg.sum().backward()
+    named, named_c = dict(flow.named_parameters()), dict(cpu.named_parameters())
+    if B:
+        # (an empty batch: torch's MixtureSameFamily -- the reference's own path -- raises on the empty reshape; the device path
+        # returns the empty tensor and zero gradients)
+        lpc = cpu.log_prob(x)
+        lpc.sum().backward()
+    for k in ("base_distribution.loc", "base_distribution.norm_distribution.concentration_unconstrained",
+              "base_distribution.norm_distribution.rate_unconstrained", "base_distribution.norm_distribution.mixture_logits"):
+        g = named[k].grad
+        assert g is not None and torch.isfinite(g).all(), k
+        if B == 0:
+            assert not g.any(), k
+        else:
+            gc = named_c[k].grad
+            s = max(gc.abs().max().item(), 1e-6)
+            assert (g.cpu() - gc).abs().max().item() <= 2e-4 * s + 1e-6 * lpc.abs().sum().item() / max(B, 1), k

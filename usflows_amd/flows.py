@@ -561,8 +561,10 @@ class Flow(torch.nn.Module):
         """Laplace / Normal base density of the layer loop's result through ``usf_base_logprob_f32`` (rows flattened) when
         nothing needs a gradient: one launch instead of the distribution object's op chain, whose argument validation
         (``_validate_sample``) synchronises the host with the device on every call.  None: not applicable."""
-        if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() >= 2 and y.shape[0] > 0):
+        if not (torch.is_tensor(y) and y.is_cuda and y.dtype == torch.float32 and y.dim() >= 2):
             return None
+        if y.shape[0] == 0 and not isinstance(self.base_distribution, RadialDistribution):
+            return None                                  # (the radial path serves an empty batch itself: empty result, zero gradients)
         train = torch.is_grad_enabled() and (y.requires_grad or _needs_grad(self, y, None))
         if train and (y.dim() < 3 or os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") == "0"):
             return None                                  # (flat flows train through training.py; image flows: below)
