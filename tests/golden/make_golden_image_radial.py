@@ -156,6 +156,13 @@ def main():
     run_case("imageradial_cifarlive_c48_8x8_k2_l3_lognormal", (48, 8, 8), 2, "lognormal", 44, n=6)
     # the live depth: 15 coupling blocks x 3 gated layers (mnist.yaml:56-72)
     run_case("imageradial_mnistlive_c16_7x7_k15_l3_lognormal", (16, 7, 7), 15, "lognormal", 45, n=8, grad_layers=(0, 1, 14, 15, 29, 30, 31))
+    # the other norms of the radial base (p = 2, inf: distributions.py:513-549) on an image-shaped event, and the Fashion / CIFAR
+    # configurations at their live depth of 10 blocks (gradients of the base and of the head / middle / tail layers)
+    run_case("imageradial_c16_7x7_k2_l3_lognormal_p2", (16, 7, 7), 2, "lognormal", 48, n=6, p=2.0, loc_noise=0.05, grad_layers=(0, 1, 4, 5))
+    run_case("imageradial_c16_7x7_k2_l3_gammamm_pinf", (16, 7, 7), 2, "gammamm", 49, n=6, p=float("inf"), loc_noise=0.05,
+             grad_layers=(0, 1, 4, 5))
+    run_case("imageradial_fashionlive_c16_7x7_k10_l3_gammamm", (16, 7, 7), 10, "gammamm", 50, n=6, grad_layers=(0, 1, 10, 19, 20, 21))
+    run_case("imageradial_cifarlive_c48_8x8_k10_l3_lognormal", (48, 8, 8), 10, "lognormal", 51, n=4, grad_layers=(0, 1, 10, 19, 20, 21))
     fit_case("imageradialfit_mnistlive_c16_7x7_k2_l3_lognormal", (16, 7, 7), 2, "lognormal", 46)
     fit_case("imageradialfit_fashionlive_c16_7x7_k2_l3_gammamm", (16, 7, 7), 2, "gammamm", 47)
 
