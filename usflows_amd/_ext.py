@@ -898,9 +898,11 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
             with _psum.lock:
                 q = _psum.jobs.get(task)
                 if q is None:
-                    # (queues of passes that died of an exception are dropped here: their outputs are garbage anyway)
-                    _psum.jobs = {task: []}
-                    q = _psum.jobs[task]
+                    # (queues of passes that died of an exception never met their callback: graph task ids only grow, so what is
+                    # far behind the current one is dropped -- NOT everything else: another thread's pass may be queueing too)
+                    for old in [t for t in _psum.jobs if t < task - 256]:
+                        del _psum.jobs[old]
+                    q = _psum.jobs[task] = []
                     torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: flush_partial_sums(t))
                 # (only the partial slots are kept alive: an extra reference to dW / db would stop the autograd engine from
                 # TAKING them as the parameter's gradient -- it would copy them on the spot, before the sum has run)
