@@ -1012,7 +1012,12 @@ class Flow(torch.nn.Module):
             raise TypeError("The base distribution of the flow must be of type RadialDistribution.")
         with torch.no_grad():
             latent = self.backward(calibration_dataset)
-            lp = self.base_distribution.log_prob(latent)
+            lp = None
+            if torch.is_tensor(latent) and latent.is_cuda and os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0":
+                from . import radial
+                lp = radial.log_prob(self.base_distribution, latent.float().contiguous())      # one launch (usf_radial_logprob_f32)
+            if lp is None:
+                lp = self.base_distribution.log_prob(latent)
         lp, _ = torch.sort(lp, descending=True)
         threshold = lp[int(len(lp) * q)]
         profile = self.base_distribution.radial_udl_profile(threshold=threshold, r_max=r_max, n_samples=n_samples)
