@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 31
+#define USF_ABI_VERSION 32
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -81,6 +81,14 @@ typedef struct usf_linear_desc {
    * W_split + p*split_plane_stride, each [N, ldw_split] bf16 with ldw_split >= ceil32(K), zero-padded.
    * Used when non-NULL and the op has no residual / addend and K % 8 == 0; W must still be given. */
   const void* W_split; int64_t ldw_split; int64_t split_plane_stride;
+  /* Optional side output (ABI 32): the three row-major bf16 planes of the INPUT A (A == p1 + p2 + p3 exactly, the
+   * split the bf16x3 kernel makes of its operand anyway), plane p at A_planes_out + p * planes_out_stride elements,
+   * each [ceil32(M), ldp_out] bf16 with ldp_out >= ceil32(K), ldp_out % 8 == 0; rows [M, ceil32(M)) are NOT written
+   * (the caller's buffer holds zeros there: usf_wgrad_planes_f32 sums over them), columns [K, ceil32(K)) receive finite
+   * padding.  This is the operand layout of usf_wgrad_planes_f32: the
+   * data-gradient / forward GEMM of a layer hands the weight gradient of the same layer its operand already split
+   * (flows.py:196-203: loss.backward() through every F.linear of the flow).  Not with pre_div / pre_sub. */
+  void* A_planes_out; int64_t ldp_out; int64_t planes_out_stride;
 } usf_linear_desc;
 
 int usf_linear_f32(const usf_linear_desc* d, usf_stream_t stream);
@@ -685,6 +693,31 @@ int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K);
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream);
+
+/*
+ * The weight gradient from PRE-SPLIT operands (ABI 32).  usf_wgrad_f32's loader waves split every fp32 operand value
+ * into its three bf16 planes again in each of the blocks that share its rows (seven times at 784 x 784); here Y and A
+ * arrive as the planes the layer's own GEMMs already made of them (usf_linear_desc::A_planes_out: the forward GEMM
+ * splits the layer input, the data-gradient GEMM the output gradient), or as usf_split_planes_f32 writes them:
+ *   plane p of an operand at base + p * plane_stride elements, each [ceil32(M), ld] bf16 row-major, ld % 8 == 0,
+ *   plane_stride % 8 == 0, plane_stride >= ceil32(M) * ld, 16-byte aligned base, rows [M, ceil32(M)) zero,
+ *   the three planes of one operand below 4 GiB; x == p0 + p1 + p2 exactly (round-to-nearest residual split).
+ * usf_wgrad_planes_f32: G[n,k] = alpha * sum_m Y[m, y_off + n] * A[m, a_off + k] + beta * G[n,k]  (y_off, a_off % 8 == 0)
+ *   -- the same six products per value pair in the same order as usf_wgrad_f32 mode 1, one block per CU over row ranges
+ *   of (nearly) equal duration, partial sums added in a fixed order (bitwise reproducible).  workspace: at least
+ *   usf_wgrad_planes_workspace_floats(M, N, K) floats.  usf_wgrad_planes_ok: 1 where the kernel pays (the loader-wave
+ *   kernel's cross-over: M >= 8192 and enough tiles), else 0 -- callers then keep usf_wgrad_f32.
+ * usf_split_planes_f32: P[p][m][c] for m < ceil32(M), c < ldp: the planes of X[m, c] (zeros for m >= M or c >= N).
+ * Replaces: the weight-gradient half of autograd's F.linear backward (flows.py:196-203, transforms.py:913-962,
+ * networks.py:739-751) at training batches of thousands of rows.
+ */
+int usf_wgrad_planes_f32(const void* Y_planes, int64_t ldyp, int64_t y_plane_stride, int64_t y_off, const void* A_planes,
+                         int64_t ldap, int64_t a_plane_stride, int64_t a_off, int64_t M, int64_t N, int64_t K, float* G,
+                         int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);
+int64_t usf_wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K);
+int usf_wgrad_planes_ok(int64_t M, int64_t N, int64_t K);
+int usf_split_planes_f32(const float* X, int64_t ldx, int64_t M, int64_t N, void* planes, int64_t ldp, int64_t plane_stride,
+                         usf_stream_t stream);
 
 /* Many small weight / bias gradients in ONE launch.  At the reference's training batch (32 rows, tests/explib/mnist.yaml:34)
  * Flow.fit's backward pass (flows.py:196-199) asks for one weight and one bias gradient per F.linear on the path -- some

@@ -168,3 +168,120 @@ def test_grad_jobs_are_not_queued_above_the_row_limit():
         ext.wgrad(Y, A, G, M=M, N=16, K=8, ldy=16, lda=8, ldg=8)
         assert not bj.grad_jobs
     assert torch.allclose(G, Y.t() @ A, rtol=1e-4, atol=1e-3)
+
+
+# ---- weight gradient from pre-split operand planes (usf_wgrad_planes_f32, usf_split_planes_f32, A_planes_out) ----
+def _planes_sum(P):
+    """fp32 value of [3, rows, cols] bf16 planes (the sum is exact in fp32: three 8-bit pieces of a 24-bit significand)"""
+    return (P[0].float() + P[1].float()) + P[2].float()
+
+
+@pytest.mark.parametrize("M,N,ld", [(1, 8, 8), (37, 20, 24), (1000, 392, 400), (8200, 784, 800)])
+def test_split_planes_is_an_exact_three_way_split(M, N, ld):
+    ext = _ext()
+    g = torch.Generator().manual_seed(M + N)
+    X = (torch.randn(M, ld, generator=g) * torch.exp(3 * torch.randn(M, ld, generator=g))).to(DEV)
+    P = ext.row_planes(M, N, DEV)
+    P.fill_(7.0)                                               # every element of the buffer is written
+    ext.split_planes(X, P, M=M, N=N, ldx=ld)
+    torch.cuda.synchronize()
+    S = _planes_sum(P)
+    assert torch.equal(S[:M, :N], X[:, :N])
+    assert not S[M:].any() and not S[:, N:].any()              # rows up to ceil32(M) and padding columns: zeros
+    hi = X[:, :N].bfloat16()
+    assert torch.equal(P[0, :M, :N], hi)                       # round-to-nearest residual split
+    assert torch.equal(P[1, :M, :N], (X[:, :N] - hi.float()).bfloat16())
+
+
+@pytest.mark.parametrize("M,N,K,y_off,a_off", [(8192, 784, 784, 0, 0), (8200, 784, 784, 0, 0), (33001, 130, 260, 8, 16),
+                                               (21000, 392, 256, 0, 8), (16384, 256, 392, 0, 0), (9000, 144, 128, 0, 0),
+                                               (40, 20, 36, 0, 0)])
+def test_wgrad_planes_matches_fp64_and_is_reproducible(M, N, K, y_off, a_off):
+    """every tile class of the balanced schedule (full, edge in k, edge in n, corner), ragged row counts, column offsets into
+    wider planes; the small shape runs where usf_wgrad_planes_ok says the kernel does not pay (it is still correct)"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(M + N + K)
+    Y = torch.randn(M, y_off + N + 8, generator=g)
+    A = torch.randn(M, a_off + K + 16, generator=g)
+    G0 = torch.randn(N, K + 4, generator=g)
+    ref = 0.5 * (Y[:, y_off:y_off + N].double().t() @ A[:, a_off:a_off + K].double()) - 1.5 * G0[:, :K].double()
+    Yp, Ap = ext.row_planes(M, Y.shape[1], DEV), ext.row_planes(M, A.shape[1], DEV)
+    ext.split_planes(Y.to(DEV), Yp, M=M, N=Y.shape[1], ldx=Y.shape[1])
+    ext.split_planes(A.to(DEV), Ap, M=M, N=A.shape[1], ldx=A.shape[1])
+    outs = []
+    for _ in range(2):
+        Gd = G0.to(DEV)
+        ext.wgrad_planes(Yp, Ap, Gd, M=M, N=N, K=K, ldg=K + 4, y_off=y_off, a_off=a_off, alpha=0.5, beta=-1.5)
+        torch.cuda.synchronize()
+        outs.append(Gd.cpu())
+    assert torch.equal(outs[0], outs[1])
+    tol = 2e-6 * math.sqrt(M) * max(1.0, ref.abs().max().item())
+    assert (outs[0][:, :K].double() - ref).abs().max().item() <= tol
+    assert torch.equal(outs[0][:, K:], G0[:, K:])
+    assert ext.wgrad_planes_ok(M, N, K) == (M >= 8192 and M * (-(-N // 128)) * (-(-K // 128)) >= 160000)
+
+
+def test_wgrad_planes_equals_the_loader_wave_kernel_on_the_plain_grid(monkeypatch):
+    """same products in the same order: with the balanced schedule switched off the gradient has the bits of usf_wgrad_f32"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import torch
+        from usflows_amd import _ext as ext
+        ext.load()
+        g = torch.Generator().manual_seed(5)
+        M, N, K = 32768, 392, 256
+        assert ext.load().usf_wgrad_variant(M, N, K, N, K, 1) == 2
+        Y, A = torch.randn(M, N, generator=g).cuda(), torch.randn(M, K, generator=g).cuda()
+        G1, G2 = torch.empty(N, K, device="cuda"), torch.empty(N, K, device="cuda")
+        ext.wgrad(Y, A, G1, M=M, N=N, K=K, ldy=N, lda=K, ldg=K, mode=1)
+        Yp, Ap = ext.row_planes(M, N, "cuda"), ext.row_planes(M, K, "cuda")
+        ext.split_planes(Y, Yp, M=M, N=N, ldx=N); ext.split_planes(A, Ap, M=M, N=K, ldx=K)
+        ext.wgrad_planes(Yp, Ap, G2, M=M, N=N, K=K, ldg=K)
+        torch.cuda.synchronize()
+        assert torch.equal(G1, G2), (G1 - G2).abs().max().item()
+        print("same bits")
+    ''')
+    import os
+    env = dict(os.environ, USF_WGRAD_SCHED="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "same bits" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 784, 784), (8200, 784, 800), (300, 256, 392), (70, 96, 40), (4096, 160, 256)])
+def test_linear_writes_the_planes_of_its_input(M, N, K):
+    """usf_linear_desc::A_planes_out: the bf16x3 instantiations write the planes they split (column block 0's blocks), the
+    kernels that do not split get them from a pass of their own; the GEMM's result does not change by a bit"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(M + N + K)
+    lda = K + 8
+    A = torch.randn(M, lda, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    Kp = -(-K // 32) * 32
+    Wp = torch.zeros(3, N, Kp, dtype=torch.bfloat16, device=DEV)
+    ext.split_planes(W, Wp, M=N, N=K, ldx=K) if N % 32 == 0 else None
+    if N % 32:                                                  # weight planes [3, N, ceil32(K)]: rows as they are
+        hi = W.bfloat16(); r = W - hi.float(); mid = r.bfloat16(); lo = (r - mid.float()).bfloat16()
+        Wp[0, :, :K], Wp[1, :, :K], Wp[2, :, :K] = hi, mid, lo
+    C0, C1 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ext.linear(A, W, C0, M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, bias=bias, W_split=Wp)
+    P = ext.row_planes(M, K, DEV)                               # zeros; rows [M, ceil32(M)) stay as the caller left them
+    P[:, :M].fill_(3.0)
+    ext.linear(A, W, C1, M=M, N=N, K=K, lda=lda, ldw=K, ldc=N, bias=bias, W_split=Wp, planes_out=P)
+    torch.cuda.synchronize()
+    assert torch.equal(C0, C1)
+    S = _planes_sum(P)
+    assert torch.equal(S[:M, :K], A[:, :K])
+    assert not S[M:].any()                                      # rows [M, ceil32(M)) zero: the weight gradient sums over them
+    Q = ext.row_planes(M, K, DEV)
+    ext.split_planes(A, Q, M=M, N=K, ldx=lda)
+    assert torch.equal(P[:, :M, :K], Q[:, :M, :K])             # the same split as usf_split_planes_f32
+
+
+def test_linear_planes_out_rejects_a_prologue():
+    ext = _ext()
+    A, W, Cc = torch.randn(128, 64, device=DEV), torch.randn(96, 64, device=DEV), torch.empty(128, 96, device=DEV)
+    with pytest.raises(RuntimeError, match="pre_div"):
+        ext.linear(A, W, Cc, M=128, N=96, K=64, lda=64, ldw=64, ldc=96, pre_sub=torch.zeros(64, device=DEV),
+                   planes_out=ext.row_planes(128, 64, DEV))

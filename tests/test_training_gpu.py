@@ -278,3 +278,32 @@ def test_failed_capture_of_a_training_step_is_recoverable(monkeypatch):
     assert torch.isfinite(torch.normal(torch.zeros(8, device=DEV), torch.ones(8, device=DEV))).all()
     assert np.allclose(l_brk, l_ref, rtol=1e-6, atol=0), (l_brk, l_ref)
     assert torch.allclose(lp_brk, lp_ref, rtol=1e-6, atol=1e-5)
+
+
+def test_weight_gradients_from_operand_planes_equal_the_fp32_operand_path(monkeypatch):
+    """From 8192 rows the affine layers' GEMMs leave the bf16 planes of their operands (usf_linear_desc::A_planes_out) and the
+    weight gradients multiply those (usf_wgrad_planes_f32) instead of splitting fp32 rows again: same products, another
+    order of the partial sums -- every parameter gradient within 1e-5 of the path with USFLOWS_AMD_WGRAD_PLANES=0, which the
+    tests above pin against the oracle and the reference's goldens."""
+    from usflows_amd import _ext
+    spec, sd, _a = load_case("synth_d784_k32_cfg2")
+    x = torch.rand(8200, 784, generator=torch.Generator().manual_seed(3)).to(DEV)        # ragged: 8200 = 256 x 32 + 8
+    grads, calls = [], []
+    real = _ext.wgrad_planes
+    monkeypatch.setattr(_ext, "wgrad_planes", lambda *a, **k: (calls.append(k["N"]), real(*a, **k))[1])
+    for planes in ("0", "1"):
+        monkeypatch.setenv("USFLOWS_AMD_WGRAD_PLANES", planes)
+        flow = build_flow(spec, sd, device=DEV)
+        n0 = len(calls)
+        for _ in range(2):                                      # the second pass replays the recorded launches
+            for p in flow.parameters():
+                p.grad = None
+            (-flow.log_prob(x).mean()).backward()
+        torch.cuda.synchronize()
+        assert (len(calls) > n0) == (planes == "1")
+        grads.append({n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None})
+    assert len(calls) >= 31 and set(calls) == {784}             # every affine layer behind the first one
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    for n in grads[0]:
+        big = grads[0][n].abs().max().item()
+        assert (grads[0][n] - grads[1][n]).abs().max().item() <= 1e-5 * big + 1e-12, n

@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 31
+USF_ABI_VERSION = 32
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -43,6 +43,7 @@ class LinearDesc(C.Structure):
         ("res_sign", C.c_float), ("slope", C.c_float),
         ("act", C.c_int32), ("reserved", C.c_int32),
         ("W_split", _fp), ("ldw_split", C.c_int64), ("split_plane_stride", C.c_int64),
+        ("A_planes_out", _fp), ("ldp_out", C.c_int64), ("planes_out_stride", C.c_int64),
     ]
 
 
@@ -224,6 +225,11 @@ SYMBOLS = {
     "usf_wgrad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
                                 C.c_float, C.c_float, C.c_int32, _fp, C.c_int64, C.c_void_p]),
     "usf_wgrad_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_wgrad_planes_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                       C.c_int64, C.c_int64, _fp, C.c_int64, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
+    "usf_wgrad_planes_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_wgrad_planes_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_split_planes_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, _fp]),
     "usf_wgrad_variant": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "usf_sophiag_step_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                        C.c_void_p]),
@@ -460,8 +466,9 @@ def current_stream(device=None) -> int:
 # ---- thin typed wrappers (each enqueues on torch's current stream) ---------------------------
 def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_sub=None, residual=None,
            ldr=0, post_mul=None, res_sign=1.0, act=ACT_NONE, slope=0.0, a_off=0, c_off=0, r_off=0,
-           addend=None, ldadd=0, W_split=None):
-    """usf_linear_f32 on raw tensors; *_off are element offsets into A/C/residual."""
+           addend=None, ldadd=0, W_split=None, planes_out=None):
+    """usf_linear_f32 on raw tensors; *_off are element offsets into A/C/residual.  planes_out: a ``row_planes`` buffer
+    [3, ceil32(M), ld] that receives the bf16 planes of the input A (usf_linear_desc::A_planes_out)."""
     d = LinearDesc()
     d.A = A.data_ptr() + 4 * a_off
     d.lda = lda
@@ -483,6 +490,8 @@ def linear(A, W, C_out, *, M, N, K, lda, ldw, ldc, bias=None, pre_div=None, pre_
     d.ldc = ldc
     d.M, d.N, d.K = M, N, K
     d.res_sign, d.slope, d.act = res_sign, slope, act
+    if planes_out is not None:
+        d.A_planes_out, d.ldp_out, d.planes_out_stride = planes_out.data_ptr(), planes_out.shape[2], planes_out.shape[1] * planes_out.shape[2]
     _launch("usf_linear_f32", (C.byref(d), current_stream(A.device)), d)
 
 
@@ -1178,6 +1187,31 @@ def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1
     _launch("usf_wgrad_f32", (Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
                               G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), int(mode), ws.data_ptr(),
                               ws.numel(), current_stream(Y.device)), (Y, A, G, ws))
+
+
+def row_planes(M: int, cols: int, device) -> torch.Tensor:
+    """[3, ceil32(M), ceil32(cols)] bf16: the row-major operand planes of usf_wgrad_planes_f32 (include/usflows_hip.h)"""
+    return torch.zeros(3, -(-M // 32) * 32, -(-cols // 32) * 32, dtype=torch.bfloat16, device=device)
+
+
+def split_planes(X, planes, *, M, N, ldx, x_off=0):
+    """usf_split_planes_f32: planes[p, m, c] = plane p of X[m, c] (zeros beyond M / N)"""
+    _launch("usf_split_planes_f32", (X.data_ptr() + 4 * x_off, ldx, M, N, planes.data_ptr(), planes.shape[2],
+                                     planes.shape[1] * planes.shape[2], current_stream(X.device)), (X, planes))
+
+
+def wgrad_planes_ok(M: int, N: int, K: int) -> bool:
+    return bool(load().usf_wgrad_planes_ok(M, N, K))
+
+
+def wgrad_planes(Yp, Ap, G, *, M, N, K, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0):
+    """usf_wgrad_planes_f32: G[n,k] = alpha * sum_m Y[m, y_off+n] A[m, a_off+k] + beta * G from ``row_planes`` operands"""
+    lib = load()
+    need = lib.usf_wgrad_planes_workspace_floats(M, N, K)
+    ws = _workspace(Yp.device, need)
+    _launch("usf_wgrad_planes_f32", (Yp.data_ptr(), Yp.shape[2], Yp.shape[1] * Yp.shape[2], y_off, Ap.data_ptr(), Ap.shape[2],
+                                     Ap.shape[1] * Ap.shape[2], a_off, M, N, K, G.data_ptr() + 4 * g_off, ldg, float(alpha),
+                                     float(beta), ws.data_ptr(), ws.numel(), current_stream(Yp.device)), (Yp, Ap, G, ws))
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):

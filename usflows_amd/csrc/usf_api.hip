@@ -101,6 +101,12 @@ int affine_prep_bwd(const float* save, const float* bias, const float* vk, const
                     const float* dM, const float* dMinv, const float* db, const float* dc, const float* dladj, int64_t n,
                     int32_t C, int32_t nvs, float* dLr, float* dUr, float* dbias, float* dvk, hipStream_t stream);
 int grad_jobs(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
+int split_planes(const float* X, int64_t ldx, int64_t M, int64_t N, void* P, int64_t ldp, int64_t plane_stride, hipStream_t stream);
+int wgrad_planes_ok(int64_t M, int64_t N, int64_t K);
+int64_t wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K);
+int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, const void* Ap, int64_t ldap, int64_t astride,
+                 int64_t a_off, int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* workspace,
+                 int64_t workspace_floats, hipStream_t stream);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
 int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
@@ -327,6 +333,18 @@ int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda,
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K) {
   int64_t out = 0;
   return usf::wgrad_workspace_floats(M, N, K, &out) == 0 ? out : -1;
+}
+int usf_wgrad_planes_f32(const void* Y_planes, int64_t ldyp, int64_t y_plane_stride, int64_t y_off, const void* A_planes,
+                         int64_t ldap, int64_t a_plane_stride, int64_t a_off, int64_t M, int64_t N, int64_t K, float* G,
+                         int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+  return usf::wgrad_planes(Y_planes, ldyp, y_plane_stride, y_off, A_planes, ldap, a_plane_stride, a_off, M, N, K, G, ldg, alpha, beta,
+                           workspace, workspace_floats, (hipStream_t)stream);
+}
+int64_t usf_wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_workspace_floats(M, N, K); }
+int usf_wgrad_planes_ok(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_ok(M, N, K); }
+int usf_split_planes_f32(const float* X, int64_t ldx, int64_t M, int64_t N, void* planes, int64_t ldp, int64_t plane_stride,
+                         usf_stream_t stream) {
+  return usf::split_planes(X, ldx, M, N, planes, ldp, plane_stride, (hipStream_t)stream);
 }
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream) {

@@ -320,6 +320,7 @@ static int launch_linear(const LinArgs& a0, hipStream_t stream) {
   return check_launch("usf_linear_f32");
 }
 
+int split_planes(const float* X, int64_t ldx, int64_t M, int64_t N, void* P, int64_t ldp, int64_t plane_stride, hipStream_t stream);
 bool linear_bf16x3_eligible(const usf_linear_desc* d);
 int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream);
 bool linear_skinny_eligible(const usf_linear_desc* d);
@@ -362,6 +363,21 @@ int linear_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU && d->act != USF_ACT_GATE) { set_error("usf_linear_f32: bad act"); return -2; }
   if (d->act == USF_ACT_GATE && (!d->addend || d->residual)) { set_error("usf_linear_f32: USF_ACT_GATE reads the gate from `addend` (required) and takes no residual"); return -2; }
   if (d->residual && d->addend) { set_error("usf_linear_f32: residual and addend are mutually exclusive"); return -2; }
+  if (d->A_planes_out) {
+    const int64_t rows_pad = (d->M + 31) / 32 * 32, kp = (d->K + 31) / 32 * 32;
+    if (d->pre_div || d->pre_sub) { set_error("usf_linear_f32: A_planes_out takes no pre_div / pre_sub"); return -2; }
+    if (d->ldp_out < kp || (d->ldp_out & 7) || (d->planes_out_stride & 7) || d->planes_out_stride < rows_pad * d->ldp_out ||
+        !aligned16(d->A_planes_out) || 3 * d->planes_out_stride * 2 >= (1LL << 31)) {
+      set_error("usf_linear_f32: A_planes_out needs ldp_out >= ceil32(K), a multiple of 8, planes_out_stride >= ceil32(M) * ldp_out "
+                "and planes below 2 GiB");
+      return -2;
+    }
+    if (linear_skinny_eligible(d) || !linear_bf16x3_eligible(d)) {
+      // the kernels that do not split their operand: the planes come from a pass of their own
+      const int rc = split_planes(d->A, d->lda, d->M, d->K, d->A_planes_out, d->ldp_out, d->planes_out_stride, stream);
+      if (rc) return rc;
+    }
+  }
   if (linear_skinny_eligible(d)) return linear_skinny_dispatch(d, stream);     // small batches: latency, not FLOPs
   if (linear_bf16x3_eligible(d)) return linear_bf16x3_dispatch(d, stream);
   LinArgs a;

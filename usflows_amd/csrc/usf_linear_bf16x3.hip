@@ -32,6 +32,7 @@ struct Lin3Args {
   float slope; int act;
   int bias_vec;
   unsigned long long* dbg;              // tuning builds only (USF_STAMP)
+  __bf16* Apl; unsigned ldpl, plstride, plbytes;   // side output: planes of A (usf_linear_desc::A_planes_out), or NULL
 };
 
 __device__ __forceinline__ void split3(const f32x4 x0, const f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -46,7 +47,7 @@ __device__ __forceinline__ void split3(const f32x4 x0, const f32x4 x1, bf16x8& p
   }
 }
 
-template <int TN, int WM, bool PRO, int NB>
+template <int TN, int WM, bool PRO, int NB, bool SIDE = false>
 __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Args p) {
   constexpr int NT = WM * 64;
   constexpr int BM = WM * 32;
@@ -194,6 +195,34 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   // activation lines of slab s+2 are fetched during step 1 of slab s, right after the lines of slab s+1 went
   // through the scratch -- a full slab of latency cover; slab s+1's operand planes are split (VALU) in the
   // shadow of step 1's MFMAs.
+  // SIDE: the blocks also write the operand planes they split -- every column block of a row panel sees the whole operand,
+  // so block bn writes the slabs s with s % nbn == bn (a wave-uniform branch around six 16-byte stores per owned slab).
+  // Rows >= M are not written (an offset beyond the buffer: dropped): the caller's buffer holds zeros there.
+  // Measured on the 784 x 784 GEMM of the training step (65 536 rows, 404 us without the side output): all stores through
+  // column block 0 + 53 us; dealt out, every block issuing every store (foreign slabs dropped by the bounds check) + 42 us;
+  // this form: see r04_tuning_experiments.md section 7.
+  typedef unsigned side_u32x4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t side_rs = __builtin_amdgcn_make_buffer_rsrc(SIDE ? p.Apl : nullptr, 0, SIDE ? (int)p.plbytes : 0, 0x00020000);
+  unsigned side_vo[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int row = row0 + 16 * b + lj;
+    side_vo[b] = (SIDE && row < p.M) ? ((unsigned)row * p.ldpl + 8u * (unsigned)lg) * 2u : 0x80000000u;
+  }
+  auto side_store = [&](int k0, const bf16x8 (&pl)[2][3]) {
+    if (!SIDE) return;
+    if ((k0 >> 5) % p.nbn != bn) return;                                     // scalar
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        // (the whole offset in the vector register, soffset 0: with a scalar-register soffset the compiler's hazard model
+        // sees no "store data overwritten right behind a 16-byte store" hazard and gfx950 has it -- measured: the last
+        // dword of a store replaced by the next store's data in some lanes)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(side_u32x4, pl[b][q]), side_rs,
+                                               (int)(side_vo[b] + ((unsigned)k0 + (unsigned)q * p.plstride) * 2u), 0, 0);
+      }
+  };
   bf16x8 pc[2][3], pn[2][3];
   f32x4 a_nxt[4], af[4];
   f32x4 wst[NWV];
@@ -209,6 +238,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
   issue_a(BK, a_nxt);
   split3(af[0], af[1], pc[0][0], pc[0][1], pc[0][2]);
   split3(af[2], af[3], pc[1][0], pc[1][1], pc[1][2]);
+  side_store(0, pc);
   __syncthreads();
 
   // half h of the slab's feature tiles: per tile 3 weight-plane fragments (lane (j, g): row 16 ft + j, k-chunk g)
@@ -310,6 +340,7 @@ __global__ __launch_bounds__(WM * 64, 2) void linear_bf16x3_kernel(const Lin3Arg
     __builtin_amdgcn_sched_barrier(0);
     LSTAMP(l3);
     store_w(wb, wst);
+    side_store(k1, pn);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -397,7 +428,8 @@ static int launch3(Lin3Args a, hipStream_t stream) {
   a.nbn = (a.N + BN - 1) / BN;
   const int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
   if (grid > 0x7fffffffLL) { set_error("usf_linear_f32(bf16x3): grid too large"); return -3; }
-  if (pro) hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, true, NB>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  if (a.Apl) hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, false, NB, true>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
+  else if (pro) hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, true, NB>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
   else hipLaunchKernelGGL((linear_bf16x3_kernel<TN, WM, false, NB>), dim3((unsigned)grid), dim3(WM * 64), 0, stream, a);
   return check_launch("usf_linear_f32(bf16x3)");
 }
@@ -454,6 +486,12 @@ int linear_bf16x3_dispatch(const usf_linear_desc* d, hipStream_t stream) {
 #ifdef USF_STAMP
   a.dbg = g_bdbg;
 #endif
+  a.Apl = nullptr; a.ldpl = a.plstride = a.plbytes = 0;
+  if (d->A_planes_out) {                 // (linear_dispatch checked the geometry and that there is no prologue)
+    a.Apl = reinterpret_cast<__bf16*>(d->A_planes_out);
+    a.ldpl = (unsigned)d->ldp_out; a.plstride = (unsigned)d->planes_out_stride;
+    a.plbytes = (unsigned)(3 * d->planes_out_stride * 2);
+  }
   switch (linear_bf16x3_variant(a.M, a.N)) {
     case 3244: return launch3<2, 4, 4>(a, stream);
     case 3584: return launch3<5, 8, 4>(a, stream);

@@ -974,9 +974,20 @@ class FlowEngine:
                     patch_in.append(len(ops))
                 if dst == "user_out":
                     patch_out.append(len(ops))
+                # training at thousands of rows: the GEMM also writes the bf16 planes it makes of its input -- the operand
+                # of this layer's weight gradient, already split (usf_wgrad_planes_f32; 3 x B x LD x 2 bytes per layer)
+                in_planes = None
+                if (train and cur[0] != "user_in" and "pre_div" not in kw and "pre_sub" not in kw
+                        and self.wgrad_from_planes(B, Ndim, Kdim)):
+                    in_planes = f"apl{len(ops)}"
+                    t = ws.get(in_planes)
+                    if t is None or t.shape[1] != -(-B // 32) * 32 or t.shape[2] != -(-Kdim // 32) * 32:
+                        t = ws[in_planes] = _ext.row_planes(B, Kdim, device)
+                    kw.update(A_planes_out=t.data_ptr(), ldp_out=t.shape[2], planes_out_stride=t.shape[1] * t.shape[2])
                 meta.append(dict(kind="affine", op=len(ops), prim=prim, blk=blk, in_buf=cur[0], in_layout=in_layout,
                                  in_ld=cur[2], out_buf=dst, out_layout=out_layout, out_ld=ldc, N=Ndim, K=Kdim,
-                                 pre_scale=scale_mod, post_scale=(self._step(nxt[1]).module if fuse_post else None)))
+                                 pre_scale=scale_mod, post_scale=(self._step(nxt[1]).module if fuse_post else None),
+                                 in_planes=in_planes))
                 ops.append(lin_op(A=(0 if cur[0] == "user_in" else ws[cur[0]].data_ptr()), lda=cur[2],
                                   W=W.data_ptr(), ldw=W.shape[1], C=cptr, ldc=ldc, M=B, N=Ndim, K=Kdim,
                                   res_sign=1.0, slope=0.0, act=_ext.ACT_NONE, **kw))
@@ -1060,6 +1071,12 @@ class FlowEngine:
         return dict(arr=arr, n=len(ops), patch_in=[(i_, "linear", "A") for i_ in patch_in],
                     patch_out=[(i_, "linear", "C") for i_ in patch_out], side=side,
                     final_gather=final_gather, out_buf=cur, ws=ws, pk=pk, meta=meta)
+
+    def wgrad_from_planes(self, B: int, N: int, K: int) -> bool:
+        """weight gradients of the training step from pre-split operand planes (usf_wgrad_planes_f32): in the bf16x3 mode,
+        where the kernel pays (its own cross-over), unless USFLOWS_AMD_WGRAD_PLANES=0"""
+        return (self.gemm_mode == "bf16x3" and os.environ.get("USFLOWS_AMD_WGRAD_PLANES", "1") != "0"
+                and _ext.wgrad_planes_ok(B, N, K))
 
     def _general_coupling_ops(self, ops, lin_op, pk, cp, ws, zptr, B, sign, device):
         """the vector ConvNet conditioner with GatedMLP / LayerNormVector blocks (networks.py:206-245, 287-308) as a chain

@@ -510,7 +510,18 @@ class TrainPath:
         # weight gradient in the image layout, then back to the natural [D, D] layout of the block's matrix
         wid = max(eng.LD, eng.LDn)
         Gp = self._buf(ws, f"Gp{m['op']}", wid, wid)           # own image per layer: its un-permute job runs later
-        if m["in_buf"] == "user_in":
+        # large batches: the data-gradient GEMM runs first and leaves the planes it makes of g; the weight gradient then
+        # multiplies them with the planes the forward GEMM left of the layer input (no operand split in its loaders)
+        from_planes = (need_dgrad and not self._defer and self._wmode == 1 and m.get("in_planes") is not None
+                       and m["in_planes"] in ws and eng.wgrad_from_planes(B, n_out, n_in))
+        if from_planes:
+            gpl = ws.get("gpl")
+            if gpl is None or gpl.shape[1] != -(-B // 32) * 32 or gpl.shape[2] < -(-n_out // 32) * 32:
+                gpl = ws["gpl"] = _ext.row_planes(B, max(n_out, eng.LD, eng.LDn), dev)
+            Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
+            self._linear(pk, g_cur, 0, g_ld, Wt, g_other, 0, n_in, B, n_in, n_out, planes_out=gpl)
+            _ext.wgrad_planes(gpl, ws[m["in_planes"]], Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1])
+        elif m["in_buf"] == "user_in":
             # the caller's tensor changes from call to call: issued through the wrapper on every replay
             _ext.host_op(lambda g=g_cur, ld=g_ld: _ext.wgrad(g, self._cur["x"], Gp, M=B, N=n_out, K=n_in, ldy=ld,
                                                             lda=self._cur["x"].shape[1], ldg=Gp.shape[1], mode=self._wmode,
@@ -532,6 +543,8 @@ class TrainPath:
         _ext.pack_weight(gs, None, 1, self._inv_idx(m["out_layout"], dev), D, W=gs_nat, ldw=D, ld_src=gs.shape[1])
         rec = aff.setdefault(id(blk), dict(blk=blk, uses=[]))
         rec["uses"].append(dict(which=which, G=G_nat, gsum=gs_nat, pre_scale=m["pre_scale"], row=k))
+        if from_planes:
+            return g_other, g_cur, n_in
         if need_dgrad:
             Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
             if self._defer:                       # g_cur waits for this layer's queued gradient jobs: never written again
