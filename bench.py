@@ -406,7 +406,7 @@ def main_flat(args, under_launcher):
     op_records = []
     if on_gpu and not args.no_kernel_timing and mode == "train":
         from usflows_amd import _ext as _ext_t
-        _ext_t.launch_timing = {"usf_wgrad_f32": []}        # HIP events around every weight-gradient launch
+        _ext_t.launch_timing = {"usf_wgrad_f32": [], "usf_wgrad_bias_f32": [], "usf_wgrad_planes_f32": []}     # HIP events around every weight-gradient launch
     if under_launcher:
         dist.barrier()
     sync()
@@ -429,7 +429,8 @@ def main_flat(args, under_launcher):
         eng.op_timing = None
         if mode == "train" and not args.no_kernel_timing:
             from usflows_amd import _ext as _ext_t
-            wg_timing, _ext_t.launch_timing = _ext_t.launch_timing["usf_wgrad_f32"], None
+            wg_timing = [(e0, e1, a, fn) for fn in ("usf_wgrad_f32", "usf_wgrad_bias_f32", "usf_wgrad_planes_f32") for e0, e1, a in _ext_t.launch_timing[fn]]
+            _ext_t.launch_timing = None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if under_launcher:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -543,26 +544,34 @@ def main_flat(args, under_launcher):
         # reduction of its row-range partials); the D x D launches of the affine layers are the dominant shape
         from usflows_amd import _ext as _ext_t
         shapes = {}
-        for e0, e1, a in wg_timing:
-            shapes.setdefault((int(a[4]), int(a[5]), int(a[6])), []).append(e0.elapsed_time(e1))
+        for e0, e1, a, fn in wg_timing:
+            mnk = (int(a[8]), int(a[9]), int(a[10])) if fn == "usf_wgrad_planes_f32" else (int(a[4]), int(a[5]), int(a[6]))
+            shapes.setdefault(("usf_wgrad_f32" if fn == "usf_wgrad_bias_f32" else fn,) + mnk, []).append(e0.elapsed_time(e1))
         tot = {k: sum(v) for k, v in shapes.items()}
         dom = max(tot, key=tot.get)
-        M_, N_, K_ = dom
+        fn_, M_, N_, K_ = dom
         avg_ms = tot[dom] / len(shapes[dom])
         flops = 2.0 * M_ * N_ * K_
-        variant = _ext_t.load().usf_wgrad_variant(M_, N_, K_, (N_ + 3) // 4 * 4, (K_ + 3) // 4 * 4, 1 if eng.gemm_mode != "f32" else 0)
-        bf = variant != 0
+        if fn_ == "usf_wgrad_planes_f32":
+            bf = True
+            kname = ("wgrad_planes_kernel (bf16x3 from the operand planes the layer's GEMMs wrote; one block per CU) + "
+                     f"reduce_partials_cls_kernel: usf_wgrad_planes_f32 N={N_} K={K_} over {M_} rows")
+        else:
+            variant = _ext_t.load().usf_wgrad_variant(M_, N_, K_, (N_ + 3) // 4 * 4, (K_ + 3) // 4 * 4, 1 if eng.gemm_mode != "f32" else 0)
+            bf = variant != 0
+            kname = ({0: "wgrad_kernel (exact f32)", 1: "wgrad_bf16x3_kernel", 2: "wgrad_lw_kernel (bf16x3, loader waves)"}[variant]
+                     + f" + reduce_partials_kernel: usf_wgrad_f32 N={N_} K={K_} over {M_} rows")
         peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1) if bf else F32_MFMA_PEAK_TFLOPS
         ach = flops / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": None, "traffic_source": None,
-                    "kernel": {0: "wgrad_kernel (exact f32)", 1: "wgrad_bf16x3_kernel", 2: "wgrad_lw_kernel (bf16x3, loader waves)"}[variant]
-                              + f" + reduce_partials_kernel: usf_wgrad_f32 N={N_} K={K_} over {M_} rows",
+                    "kernel": kname,
                     "peak_is": "dense bf16 MFMA peak (2500) / 6 products per fp32 product" if bf else "dense f32 MFMA",
-                    "measured_by": "HIP events around every usf_wgrad_f32 launch of this run's timed region",
+                    "measured_by": f"HIP events around every {fn_} launch of this run's timed region",
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(shapes[dom]),
                     "algorithmic_flops_per_launch": flops,
-                    "wgrad_ms_per_step": {f"{k[1]}x{k[2]}": round(v / args.steps, 3) for k, v in tot.items()},
+                    "wgrad_ms_per_step": {f"{k[2]}x{k[3]}" + (" (planes)" if k[0] == "usf_wgrad_planes_f32" else ""): round(v / args.steps, 3)
+                                          for k, v in tot.items()},
                     "wgrad_share_of_step": round(sum(tot.values()) / args.steps / ms_per_step, 3)}
     # whole-flow algorithmic FLOP rate (mask-aware count)
     hs = list(hidden)

@@ -691,6 +691,14 @@ int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int6
                   usf_stream_t stream);
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K);
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
+/* usf_wgrad_f32 and the layer's bias gradient in one pass (ABI 32): colsum_out[n] = cs_alpha * sum_m Y[m,n] + cs_beta *
+ * colsum_out[n] (what usf_colsum_f32 computes), from the operand fragments the loader-wave kernel holds anyway -- three more
+ * MFMAs per fragment row against an operand of ones in the blocks of tile column 0; partial sums in a fixed order.  Only
+ * where usf_wgrad_bias_ok says 1 (usf_wgrad_variant == 2 and K >= 64); the same workspace as usf_wgrad_f32. */
+int usf_wgrad_bias_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
+                       int64_t ldg, float alpha, float beta, int32_t mode, float* colsum_out, float cs_alpha, float cs_beta,
+                       float* workspace, int64_t workspace_floats, usf_stream_t stream);
+int usf_wgrad_bias_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta,
                    float* workspace, int64_t workspace_floats, usf_stream_t stream);
 
@@ -704,18 +712,23 @@ int usf_colsum_f32(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out
  *   the three planes of one operand below 4 GiB; x == p0 + p1 + p2 exactly (round-to-nearest residual split).
  * usf_wgrad_planes_f32: G[n,k] = alpha * sum_m Y[m, y_off + n] * A[m, a_off + k] + beta * G[n,k]  (y_off, a_off % 8 == 0)
  *   -- the same six products per value pair in the same order as usf_wgrad_f32 mode 1, one block per CU over row ranges
- *   of (nearly) equal duration, partial sums added in a fixed order (bitwise reproducible).  workspace: at least
+ *   of equal length, partial sums added in a fixed order (bitwise reproducible).  workspace: at least
  *   usf_wgrad_planes_workspace_floats(M, N, K) floats.  usf_wgrad_planes_ok: 1 where the kernel pays (the loader-wave
  *   kernel's cross-over: M >= 8192 and enough tiles), else 0 -- callers then keep usf_wgrad_f32.
+ *   colsum_out (may be NULL; needs usf_wgrad_planes_colsum_ok = K >= 64): colsum_out[n] = cs_alpha * sum_m Y[m, y_off + n]
+ *   + cs_beta * colsum_out[n] -- the layer's bias gradient (usf_colsum_f32) from the fragments the kernel holds anyway:
+ *   three more MFMAs per fragment row against an operand of ones in the blocks of tile column 0.
  * usf_split_planes_f32: P[p][m][c] for m < ceil32(M), c < ldp: the planes of X[m, c] (zeros for m >= M or c >= N).
  * Replaces: the weight-gradient half of autograd's F.linear backward (flows.py:196-203, transforms.py:913-962,
  * networks.py:739-751) at training batches of thousands of rows.
  */
 int usf_wgrad_planes_f32(const void* Y_planes, int64_t ldyp, int64_t y_plane_stride, int64_t y_off, const void* A_planes,
                          int64_t ldap, int64_t a_plane_stride, int64_t a_off, int64_t M, int64_t N, int64_t K, float* G,
-                         int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);
+                         int64_t ldg, float alpha, float beta, float* colsum_out, float cs_alpha, float cs_beta, float* workspace,
+                         int64_t workspace_floats, usf_stream_t stream);
 int64_t usf_wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K);
 int usf_wgrad_planes_ok(int64_t M, int64_t N, int64_t K);
+int usf_wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K);
 int usf_split_planes_f32(const float* X, int64_t ldx, int64_t M, int64_t N, void* planes, int64_t ldp, int64_t plane_stride,
                          usf_stream_t stream);
 

@@ -45,6 +45,27 @@ def test_wgrad_matches_fp64(M, N, K, mode):
     assert torch.equal(got[:, K:], G0[:, K:])                 # padding columns of G untouched
 
 
+@pytest.mark.parametrize("M,N,K", [(8200, 784, 784), (33001, 130, 260), (21000, 392, 256), (65536, 256, 392)])
+def test_wgrad_bias_adds_the_column_sums_without_changing_the_gradient(M, N, K):
+    """usf_wgrad_bias_f32: the weight gradient has the bits of usf_wgrad_f32, the column sums are those of usf_colsum_f32
+    within fp32 summation-order noise, both reproducible"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(M + N)
+    ldy, lda = (N + 3) // 4 * 4 + 4, (K + 3) // 4 * 4 + 8
+    Y, A = torch.randn(M, ldy, generator=g).to(DEV), torch.randn(M, lda, generator=g).to(DEV)
+    assert ext.wgrad_bias_ok(M, N, K, ldy, lda, 1) and not ext.wgrad_bias_ok(M, N, K, ldy, lda, 0)
+    assert not ext.wgrad_bias_ok(4096, N, K, ldy, lda, 1)
+    G0, G1, G2 = (torch.empty(N, K, device=DEV) for _ in range(3))
+    ext.wgrad(Y, A, G0, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=K, alpha=0.5, mode=1)
+    cs1, cs2 = torch.full((N,), 2.0, device=DEV), torch.full((N,), 2.0, device=DEV)
+    ext.wgrad(Y, A, G1, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=K, alpha=0.5, mode=1, colsum=cs1, cs_alpha=-1.0, cs_beta=3.0)
+    ext.wgrad(Y, A, G2, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=K, alpha=0.5, mode=1, colsum=cs2, cs_alpha=-1.0, cs_beta=3.0)
+    torch.cuda.synchronize()
+    assert torch.equal(G0, G1) and torch.equal(G1, G2) and torch.equal(cs1, cs2)
+    ref = 6.0 - Y[:, :N].double().sum(0)
+    assert (cs1.double() - ref).abs().max().item() <= 2e-6 * math.sqrt(M) * max(1.0, ref.abs().max().item())
+
+
 def test_wgrad_is_the_autograd_weight_gradient_and_reproducible():
     ext = _ext()
     g = torch.Generator().manual_seed(1)
@@ -208,13 +229,22 @@ def test_wgrad_planes_matches_fp64_and_is_reproducible(M, N, K, y_off, a_off):
     Yp, Ap = ext.row_planes(M, Y.shape[1], DEV), ext.row_planes(M, A.shape[1], DEV)
     ext.split_planes(Y.to(DEV), Yp, M=M, N=Y.shape[1], ldx=Y.shape[1])
     ext.split_planes(A.to(DEV), Ap, M=M, N=A.shape[1], ldx=A.shape[1])
-    outs = []
+    outs, sums = [], []
+    cs_ok = bool(ext.load().usf_wgrad_planes_colsum_ok(M, N, K))
+    assert cs_ok == (K >= 64)
     for _ in range(2):
         Gd = G0.to(DEV)
-        ext.wgrad_planes(Yp, Ap, Gd, M=M, N=N, K=K, ldg=K + 4, y_off=y_off, a_off=a_off, alpha=0.5, beta=-1.5)
+        cs = torch.full((N,), 2.0, device=DEV) if cs_ok else None
+        ext.wgrad_planes(Yp, Ap, Gd, M=M, N=N, K=K, ldg=K + 4, y_off=y_off, a_off=a_off, alpha=0.5, beta=-1.5, colsum=cs,
+                         cs_alpha=-1.0, cs_beta=3.0)
         torch.cuda.synchronize()
         outs.append(Gd.cpu())
+        sums.append(cs.cpu() if cs_ok else None)
     assert torch.equal(outs[0], outs[1])
+    if cs_ok:                                                   # the bias gradient from the same pass: -colsum(Y) + 3 * 2
+        assert torch.equal(sums[0], sums[1])
+        ref_cs = 6.0 - Y[:, y_off:y_off + N].double().sum(0)
+        assert (sums[0].double() - ref_cs).abs().max().item() <= 2e-6 * math.sqrt(M) * max(1.0, ref_cs.abs().max().item())
     tol = 2e-6 * math.sqrt(M) * max(1.0, ref.abs().max().item())
     assert (outs[0][:, :K].double() - ref).abs().max().item() <= tol
     assert torch.equal(outs[0][:, K:], G0[:, K:])

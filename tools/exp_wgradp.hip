@@ -3,6 +3,7 @@
 //   (-DUSF_STAMP: per-slab work / barrier-wait cycles of the planes kernel's MFMA and loader waves -> tools/exp_wgradp_s)
 //   tools/exp_wgradp [M] [N] [K]      -- times usf_wgrad_f32 (loader waves) and usf_wgrad_planes_f32 and compares their bits
 #include "../usflows_amd/csrc/usf_train.hip"
+#include "../usflows_amd/csrc/usf_wgrad_planes.hip"
 #include <stdarg.h>
 #include <vector>
 #include <string.h>
@@ -16,8 +17,10 @@ int main(int argc, char** argv) {
   for (auto& v : ha) v = rnd() * 3.f;
   float *Y, *A, *G, *G2, *ws; int64_t wsf = 0;
   usf::wgrad_workspace_floats(M, N, K, &wsf);
+  { const int64_t w2 = usf::wgrad_planes_workspace_floats(M, N, K); if (w2 > wsf) wsf = w2; }
   const int64_t Mp = (M + 31) / 32 * 32, ldy = (N + 31) / 32 * 32, lda = (K + 31) / 32 * 32;
   void *Yp, *Ap;
+  float* CS = nullptr; if (getenv("EXP_COLSUM")) hipMalloc(&CS, N * 4);
   hipMalloc(&Y, M * N * 4); hipMalloc(&A, M * K * 4); hipMalloc(&G, N * K * 4); hipMalloc(&G2, N * K * 4); hipMalloc(&ws, wsf * 4);
   hipMalloc(&Yp, 3 * Mp * ldy * 2); hipMalloc(&Ap, 3 * Mp * lda * 2);
   hipMemcpy(Y, hy.data(), M * N * 4, hipMemcpyHostToDevice); hipMemcpy(A, ha.data(), M * K * 4, hipMemcpyHostToDevice);
@@ -37,12 +40,12 @@ int main(int argc, char** argv) {
   hipEventElapsedTime(&ms, e0, e1); ms /= it;
   printf("split_planes %lld x %lld: %.3f ms  (%.2f TB/s)\n", (long long)M, (long long)N, ms, 10.0 * M * N / ms / 1e9);
 #ifdef USF_STAMP
-  unsigned long long* dbg; hipMalloc(&dbg, 1024 * 12 * 4 * 8); hipMemset(dbg, 0, 1024 * 12 * 4 * 8); usf::g_wdbg = dbg;
+  unsigned long long* dbg; hipMalloc(&dbg, 1024 * 12 * 4 * 8); hipMemset(dbg, 0, 1024 * 12 * 4 * 8); usf::g_wpdbg = dbg;
 #endif
-  for (int i = 0; i < 3; ++i) if (usf::wgrad_planes(Yp, ldy, Mp * ldy, 0, Ap, lda, Mp * lda, 0, M, N, K, G2, K, 1.f, 0.f, ws, wsf, 0)) return 1;
+  for (int i = 0; i < 3; ++i) if (usf::wgrad_planes(Yp, ldy, Mp * ldy, 0, Ap, lda, Mp * lda, 0, M, N, K, G2, K, 1.f, 0.f, CS, 1.f, 0.f, ws, wsf, 0)) return 1;
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 2; }
   hipEventRecord(e0);
-  for (int i = 0; i < it; ++i) usf::wgrad_planes(Yp, ldy, Mp * ldy, 0, Ap, lda, Mp * lda, 0, M, N, K, G2, K, 1.f, 0.f, ws, wsf, 0);
+  for (int i = 0; i < it; ++i) usf::wgrad_planes(Yp, ldy, Mp * ldy, 0, Ap, lda, Mp * lda, 0, M, N, K, G2, K, 1.f, 0.f, CS, 1.f, 0.f, ws, wsf, 0);
   hipEventRecord(e1); hipEventSynchronize(e1);
   hipEventElapsedTime(&ms, e0, e1); ms /= it;
   printf("wgrad (planes)         M=%lld N=%lld K=%lld: %.3f ms  %.1f TF/s fp32-equivalent\n", (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);
@@ -50,7 +53,7 @@ int main(int argc, char** argv) {
   {
     std::vector<unsigned long long> h(1024 * 12 * 4); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
     double w[2] = {0, 0}, b[2] = {0, 0}, sl[2] = {0, 0}; int n[2] = {0, 0};
-    for (int i = 0; i < 1024 * 12; ++i) if (h[4 * i + 3]) { const int r = (i % 12) >= 4; w[r] += h[4 * i]; b[r] += h[4 * i + 1]; sl[r] += h[4 * i + 2]; ++n[r]; }
+    for (int i = 0; i < 1024 * 8; ++i) if (h[4 * i + 3]) { const int r = (i % 8) >= 4; w[r] += h[4 * i]; b[r] += h[4 * i + 1]; sl[r] += h[4 * i + 2]; ++n[r]; }
     for (int r = 0; r < 2; ++r) if (n[r]) printf("  %s waves (%d): per slab: work %.0f cycles, barrier wait %.0f cycles\n", r ? "loader" : "MFMA  ", n[r], w[r] / sl[r], b[r] / sl[r]);
   }
 #endif
@@ -60,12 +63,6 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < g.size(); ++i) { if (memcmp(&g[i], &g2[i], 4)) ++diff; const double d = fabs((double)g[i] - g2[i]); if (d > mx) mx = d; }
   double gm = 0; for (float v : g) gm = fmax(gm, fabs((double)v));
   printf("bits differ in %zu of %zu entries, max |diff| %.3g (max |g| %.3g)\n", diff, g.size(), mx, gm);
-  for (int pl = 0; pl < 2; ++pl) {
-    usf::WgSched sc;
-    if (usf::wg_schedule(M, N, K, usf::wg_env_pct(pl ? "USF_WGRADP_EDGE_PCT" : "USF_WGRAD_EDGE_PCT", pl ? 100 : 40),
-                         usf::wg_env_pct(pl ? "USF_WGRADP_CORNER_PCT" : "USF_WGRAD_CORNER_PCT", pl ? 100 : 35), sc))
-      printf("  schedule (%s): items %d; row ranges per tile full %d, edge-k %d, edge-n %d, corner %d; rows %d / %d / %d / %d\n", pl ? "planes" : "fp32",
-             sc.items, sc.nseg[0], sc.nseg[1], sc.nseg[2], sc.nseg[3], sc.rows[0], sc.rows[1], sc.rows[2], sc.rows[3]);
-  }
+  { char buf[1024]; usf::wgrad_planes_describe(M, N, K, buf, sizeof(buf)); printf("  schedule: %s\n", buf); }
   return mx > 1e-4 * gm ? 3 : 0;
 }

@@ -225,8 +225,13 @@ SYMBOLS = {
     "usf_wgrad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
                                 C.c_float, C.c_float, C.c_int32, _fp, C.c_int64, C.c_void_p]),
     "usf_wgrad_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "usf_wgrad_bias_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
+                                     C.c_float, C.c_float, C.c_int32, _fp, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
+    "usf_wgrad_bias_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
     "usf_wgrad_planes_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                       C.c_int64, C.c_int64, _fp, C.c_int64, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
+                                       C.c_int64, C.c_int64, _fp, C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float,
+                                       _fp, C.c_int64, _fp]),
+    "usf_wgrad_planes_colsum_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_split_planes_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, _fp]),
@@ -1172,10 +1177,23 @@ def _workspace(device, floats: int) -> torch.Tensor:
     return ws
 
 
-def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0, defer=True):
+def wgrad_bias_ok(M, N, K, ldy, lda, mode) -> bool:
+    return bool(load().usf_wgrad_bias_ok(M, N, K, ldy, lda, mode))
+
+
+def wgrad(Y, A, G, *, M, N, K, ldy, lda, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, mode=0, defer=True, colsum=None,
+          cs_alpha=1.0, cs_beta=0.0):
     """G[n,k] = alpha * sum_m Y[m,n] A[m,k] + beta * G (element offsets *_off into the fp32 tensors).  Inside a
-    ``batch_jobs(defer_grads=True)`` block a small-batch call is queued (same arithmetic: see usf_grad_jobs_f32)."""
+    ``batch_jobs(defer_grads=True)`` block a small-batch call is queued (same arithmetic: see usf_grad_jobs_f32).
+    colsum [N] (only where ``wgrad_bias_ok``): cs_alpha * sum_m Y[m,n] + cs_beta * colsum from the same pass (usf_wgrad_bias_f32)"""
     lib = load()
+    if colsum is not None:
+        ws = _workspace(Y.device, lib.usf_wgrad_workspace_floats(M, N, K))
+        _launch("usf_wgrad_bias_f32", (Y.data_ptr() + 4 * y_off, ldy, A.data_ptr() + 4 * a_off, lda, M, N, K,
+                                       G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), int(mode), colsum.data_ptr(),
+                                       float(cs_alpha), float(cs_beta), ws.data_ptr(), ws.numel(), current_stream(Y.device)),
+                (Y, A, G, ws, colsum))
+        return
     bj = _defer_grad_job(M) if defer else None
     if bj is not None and ldy % 4 == 0 and lda % 4 == 0 and (Y.data_ptr() + 4 * y_off) % 16 == 0 \
             and (A.data_ptr() + 4 * a_off) % 16 == 0:
@@ -1204,14 +1222,17 @@ def wgrad_planes_ok(M: int, N: int, K: int) -> bool:
     return bool(load().usf_wgrad_planes_ok(M, N, K))
 
 
-def wgrad_planes(Yp, Ap, G, *, M, N, K, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0):
-    """usf_wgrad_planes_f32: G[n,k] = alpha * sum_m Y[m, y_off+n] A[m, a_off+k] + beta * G from ``row_planes`` operands"""
+def wgrad_planes(Yp, Ap, G, *, M, N, K, ldg, y_off=0, a_off=0, g_off=0, alpha=1.0, beta=0.0, colsum=None, cs_alpha=1.0,
+                 cs_beta=0.0):
+    """usf_wgrad_planes_f32: G[n,k] = alpha * sum_m Y[m, y_off+n] A[m, a_off+k] + beta * G from ``row_planes`` operands;
+    colsum [N] (optional, K >= 64): cs_alpha * sum_m Y[m, y_off+n] + cs_beta * colsum -- the bias gradient from the same pass"""
     lib = load()
     need = lib.usf_wgrad_planes_workspace_floats(M, N, K)
     ws = _workspace(Yp.device, need)
     _launch("usf_wgrad_planes_f32", (Yp.data_ptr(), Yp.shape[2], Yp.shape[1] * Yp.shape[2], y_off, Ap.data_ptr(), Ap.shape[2],
                                      Ap.shape[1] * Ap.shape[2], a_off, M, N, K, G.data_ptr() + 4 * g_off, ldg, float(alpha),
-                                     float(beta), ws.data_ptr(), ws.numel(), current_stream(Yp.device)), (Yp, Ap, G, ws))
+                                     float(beta), ptr(colsum), float(cs_alpha), float(cs_beta), ws.data_ptr(), ws.numel(),
+                                     current_stream(Yp.device)), (Yp, Ap, G, ws, colsum))
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):

@@ -94,7 +94,8 @@ int sophiag_step(const usf_mt_chunk* chunks, int64_t n_chunks, float decay, floa
 int sophiag_hessian(const usf_mt_chunk* chunks, int64_t n_chunks, float beta2, float one_minus_beta2, hipStream_t stream);
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
-          hipStream_t stream);
+          hipStream_t stream, float* colsum_out = nullptr, float cs_alpha = 0.f, float cs_beta = 0.f);
+int wgrad_bias_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 int affine_prep(const float* Lr, const float* Ur, const float* bias, const float* vk, const float* w0, int64_t n, int32_t C,
                 int32_t nvs, float* M, float* Minv, float* b, float* cvec, float* ladj, float* save, hipStream_t stream);
 int affine_prep_bwd(const float* save, const float* bias, const float* vk, const float* w0, const float* Minv, const float* b,
@@ -105,8 +106,9 @@ int split_planes(const float* X, int64_t ldx, int64_t M, int64_t N, void* P, int
 int wgrad_planes_ok(int64_t M, int64_t N, int64_t K);
 int64_t wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K);
 int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, const void* Ap, int64_t ldap, int64_t astride,
-                 int64_t a_off, int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* workspace,
-                 int64_t workspace_floats, hipStream_t stream);
+                 int64_t a_off, int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out,
+                 float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, hipStream_t stream);
+int wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
 int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
@@ -327,6 +329,16 @@ int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, in
   return usf::conv2d_same_res(x, y, B, cin, cout, H, W, ks, w_planes, bias, in_mul, in_act, in_slope, res_x, res_mul, res_sign,
                               (hipStream_t)stream);
 }
+int usf_wgrad_bias_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
+                       int64_t ldg, float alpha, float beta, int32_t mode, float* colsum_out, float cs_alpha, float cs_beta,
+                       float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+  if (!colsum_out) { usf::set_error("usf_wgrad_bias_f32: colsum_out is NULL (usf_wgrad_f32 is the call without it)"); return -1; }
+  return usf::wgrad(Y, ldy, A, lda, M, N, K, G, ldg, alpha, beta, mode, workspace, workspace_floats, (hipStream_t)stream, colsum_out,
+                    cs_alpha, cs_beta);
+}
+int usf_wgrad_bias_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
+  return usf::wgrad_bias_ok(M, N, K, ldy, lda, mode);
+}
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   return usf::wgrad_variant(M, N, K, ldy, lda, mode);
 }
@@ -336,10 +348,12 @@ int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K) {
 }
 int usf_wgrad_planes_f32(const void* Y_planes, int64_t ldyp, int64_t y_plane_stride, int64_t y_off, const void* A_planes,
                          int64_t ldap, int64_t a_plane_stride, int64_t a_off, int64_t M, int64_t N, int64_t K, float* G,
-                         int64_t ldg, float alpha, float beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+                         int64_t ldg, float alpha, float beta, float* colsum_out, float cs_alpha, float cs_beta, float* workspace,
+                         int64_t workspace_floats, usf_stream_t stream) {
   return usf::wgrad_planes(Y_planes, ldyp, y_plane_stride, y_off, A_planes, ldap, a_plane_stride, a_off, M, N, K, G, ldg, alpha, beta,
-                           workspace, workspace_floats, (hipStream_t)stream);
+                           colsum_out, cs_alpha, cs_beta, workspace, workspace_floats, (hipStream_t)stream);
 }
+int usf_wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_colsum_ok(M, N, K); }
 int64_t usf_wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_workspace_floats(M, N, K); }
 int usf_wgrad_planes_ok(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_ok(M, N, K); }
 int usf_split_planes_f32(const float* X, int64_t ldx, int64_t M, int64_t N, void* planes, int64_t ldp, int64_t plane_stride,

@@ -13,8 +13,6 @@
 // Data gradients (dgrad) are usf_linear_f32 launches with the transposed weight image (usf_pack_weight_f32,
 // transpose = 1); the parameter-sized chain rule through M^-1 = U^-1 L^-1 is usf_gemm_f64.
 #include "usf_common.h"
-#include <stdlib.h>
-#include <string.h>
 #include <type_traits>
 
 namespace usf {
@@ -22,53 +20,6 @@ namespace usf {
 constexpr int WG_T = 128;      // output tile (n and k)
 constexpr int WG_S = 16;       // batch rows per slab
 constexpr int WG_LD = 144;     // LDS row stride (floats): 4 consecutive rows start 16 banks apart
-
-// ---- balanced schedule of the loader-wave kernels (round 4) ----------------------------------------------------------
-// 784 = 6 x 128 + 16: 13 of the 49 output tiles of a 784 x 784 weight gradient are edge tiles whose blocks take a
-// fraction of a full block's time, and 49 tiles x 16 row ranges = 784 blocks are 3.06 rounds on 256 CUs -- with the plain
-// (tile, row range) grid the last blocks run beside idle CUs (measured makespan 3.7 full-block times against 2.6 of
-// work per CU).  Here the grid is ONE block per CU and every block gets one item of (nearly) equal duration: the tiles
-// fall into four classes (full, edge in k, edge in n, corner), a tile of class c is cut into nseg[c] row ranges with
-// nseg proportional to the class's cost per slab (greedy min-max on the host), items are numbered class by class and,
-// inside a class, row range by row range (so the 32 blocks of an XCD -- consecutive items -- work on the same rows and
-// share them in its L2).  Partial s of a tile lives in part[s]; the reduction knows how many each class wrote.
-struct WgSched {
-  int items;                   // 0: the plain grid (wg_decode)
-  int per_xcd;                 // blocks per XCD (grid / 8)
-  int fN, fK;                  // full 128-wide tile rows / columns
-  int T[4];                    // tiles per class: full, edge in k, edge in n, corner
-  int off[5];                  // first item of each class
-  int nseg[4], rows[4];        // row ranges per tile, rows per range (multiples of 32)
-  short start[4][8], cnt[4][8]; // items of class c on XCD x: start[c][x] .. + cnt[c][x] (numbered inside the class)
-};
-
-__device__ __forceinline__ bool wg_item(const WgSched& sc, int M, int& n0, int& k0, int& m_begin, int& m_end, int& seg) {
-  // XCD x takes an eighth of EVERY class's items (an XCD with nothing but edge tiles, which share no operand columns
-  // with each other, is bound by its own memory-side bandwidth: measured 0.75 of a full tile's time per slab)
-  const int b = blockIdx.x;
-  const int x = b & 7;
-  int slot = b >> 3, cls = 0, le = -1;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int n = sc.cnt[c][x];
-    if (le < 0) {
-      if (slot < n) { le = sc.start[c][x] + slot; cls = c; }
-      else slot -= n;
-    }
-  }
-  if (le < 0) return false;
-  seg = le / sc.T[cls];
-  const int t = le - seg * sc.T[cls];
-  int tn, tk;
-  if (cls == 0) { tn = t / sc.fK; tk = t - tn * sc.fK; }
-  else if (cls == 1) { tn = t; tk = sc.fK; }
-  else if (cls == 2) { tn = sc.fN; tk = t; }
-  else { tn = sc.fN; tk = sc.fK; }
-  n0 = tn * WG_T; k0 = tk * WG_T;
-  m_begin = seg * sc.rows[cls];
-  m_end = (m_begin + sc.rows[cls] < M) ? m_begin + sc.rows[cls] : M;
-  return m_begin < m_end;
-}
 
 struct WgradArgs {
   const float* Y; int64_t ldy;
@@ -81,7 +32,7 @@ struct WgradArgs {
   int direct;
   int tiles, splits;           // 1-D grid, XCD-aware: see wg_decode
   unsigned long long* dbg;     // tuning builds (-DUSF_STAMP) only
-  WgSched sched;               // loader-wave kernel only
+  float* cs_part;              // loader-wave kernel: [splits][N] partial column sums of Y, or NULL (usf_wgrad_bias_f32)
 };
 #ifdef USF_STAMP
 #define WSTAMP() __builtin_amdgcn_s_memtime()
@@ -249,7 +200,7 @@ __global__ __launch_bounds__(256) void grad_jobs_kernel(const usf_grad_job* __re
   if (jb.A) {
     const int rows = (jb.M + 31) / 32 * 32;
     const WgradArgs a{jb.Y, jb.ldy, jb.A, jb.lda, nullptr, jb.M, jb.N, jb.K, rows > 0 ? rows : 32, jb.G, jb.ldg, jb.alpha,
-                      jb.beta, 1, 0, 1, nullptr};
+                      jb.beta, 1, 0, 1, nullptr, nullptr};
     wgrad_tile(a, local, 0);
     return;
   }
@@ -456,15 +407,20 @@ __device__ __forceinline__ void wl_split(const float (&x)[8], bf16x8_t& p1, bf16
 
 // the MFMA waves' main loop for a patch of NI x NJ live 16 x 16 sub-tiles (rounded up to a power of two; columns
 // beyond N / K produce values that are not stored)
-template <int NI, int NJ>
+// CS: the wave also sums its Y fragments over the batch (the layer's bias gradient): three more MFMAs per fragment row and
+// slab against a B operand of ones -- every column of the 16 x 16 result is the column sum of Y
+template <int NI, int NJ, bool CS = false>
 __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], int nslab, int nslab4, int wn, int wk, int li, int lg,
-                                             unsigned long long* dbg_slot) {
+                                             unsigned long long* dbg_slot, f32x4 (&cs)[4]) {
   int ycol[NI], acol[NJ];
 #pragma unroll
   for (int t = 0; t < NI; ++t) ycol[t] = wl_swz(wn * 64 + t * 16 + li);
 #pragma unroll
   for (int t = 0; t < NJ; ++t) acol[t] = wl_swz(wk * 64 + t * 16 + li);
   bf16x8_t yp[NI][3], ap[2][3];
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   auto read_y1 = [&](int ring, int t) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) yp[t][pl] = sh.Yp[ring][pl][lg][ycol[t]];
@@ -489,6 +445,10 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         USF_WL(2, 0); USF_WL(1, 1); USF_WL(0, 2); USF_WL(1, 0); USF_WL(0, 1); USF_WL(0, 0);   // smallest terms first
+        if (CS && j == 0) {
+#pragma unroll
+          for (int pl = 2; pl >= 0; --pl) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][pl], ones, cs[i], 0, 0, 0);
+        }
         if (j + 1 == NJ) read_y1(ring_next, i);
       }
     }
@@ -496,16 +456,19 @@ __device__ __forceinline__ void wl_mfma_loop(WlShared& sh, f32x4 (&acc)[4][4], i
     // per A fragment: the next fragment's reads, then its MFMAs (the last column also carries the next slab's Y reads)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      constexpr int XC = CS ? 3 : 0;            // column 0's extra MFMAs per fragment row
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       if (j + 1 == NJ) {
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          if (j == 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 + XC, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         }
       } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI, 0);
+        if (j == 0) __builtin_amdgcn_sched_group_barrier(0x008, (4 + XC) * NI, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI, 0);
       }
     }
   };
@@ -544,16 +507,11 @@ __global__ __launch_bounds__(768) void wgrad_lw_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tilesK = (a.K + WG_T - 1) / WG_T;
-  int n0, k0, m_begin, m_end, split;
-  if (a.sched.items) {
-    if (!wg_item(a.sched, a.M, n0, k0, m_begin, m_end, split)) return;
-  } else {
-    int tile;
-    if (!wg_decode(a, tile, split)) return;
-    n0 = (tile / tilesK) * WG_T; k0 = (tile % tilesK) * WG_T;
-    m_begin = split * a.rows_per_split;
-    m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
-  }
+  int tile, split;
+  if (!wg_decode(a, tile, split)) return;
+  const int n0 = (tile / tilesK) * WG_T, k0 = (tile % tilesK) * WG_T;
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
   const int nslab = (m_end - m_begin + WB_S - 1) / WB_S;
   const int nslab4 = (nslab + 3) & ~3;        // iterations every wave runs (barrier count): see the loader loop
   unsigned long long* dbg_slot = nullptr;
@@ -650,282 +608,35 @@ __global__ __launch_bounds__(768) void wgrad_lw_kernel(WgradArgs a) {
   const int rem_n = a.N - (n0 + wn * 64), rem_k = a.K - (k0 + wk * 64);
   const int ni = rem_n <= 0 ? 0 : (rem_n >= 64 ? 4 : (rem_n + 15) / 16);
   const int nj = rem_k <= 0 ? 0 : (rem_k >= 64 ? 4 : (rem_k + 15) / 16);
+  const bool do_cs = a.cs_part != nullptr && k0 == 0 && wk == 0;      // wave-uniform
+  f32x4 cs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   // wave-uniform choice of the patch size: live sub-tiles rounded up to {1, 2, 4} x {1, 2, 4}; a wave whose patch lies
   // outside the matrix only keeps the barriers
   if (ni == 0 || nj == 0) {
     for (int s = 0; s < nslab4; ++s) __syncthreads();
   } else {
-#define WL_GO(NI_, NJ_) wl_mfma_loop<NI_, NJ_>(sh, acc, nslab, nslab4, wn, wk, li, lg, dbg_slot)
+#define WL_GO(NI_, NJ_) wl_mfma_loop<NI_, NJ_>(sh, acc, nslab, nslab4, wn, wk, li, lg, dbg_slot, cs)
 #define WL_ROW(NI_) do { if (nj > 2) WL_GO(NI_, 4); else if (nj > 1) WL_GO(NI_, 2); else WL_GO(NI_, 1); } while (0)
-    if (ni > 2) WL_ROW(4); else if (ni > 1) WL_ROW(2); else WL_ROW(1);
+#define WL_CS(NI_) wl_mfma_loop<NI_, 4, true>(sh, acc, nslab, nslab4, wn, wk, li, lg, dbg_slot, cs)
+    if (do_cs && nj == 4) {                     // (the host asks for column sums only where K >= 64: nj == 4 in wave column 0)
+      if (ni > 2) WL_CS(4); else if (ni > 1) WL_CS(2); else WL_CS(1);
+    } else if (ni > 2) WL_ROW(4); else if (ni > 1) WL_ROW(2); else WL_ROW(1);
+#undef WL_CS
 #undef WL_ROW
 #undef WL_GO
   }
-  float* out = a.part + (int64_t)split * a.N * a.K;
+  if (do_cs && (lane & 15) == 0) {
+    float* co = a.cs_part + (int64_t)split * a.N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
-        const int k = k0 + wk * 64 + j * 16 + (lane & 15);
-        if (n < a.N && k < a.K) {
-          if (a.direct) {
-            float* dst = a.G + (int64_t)n * a.ldg + k;
-            float vv = a.alpha * acc[i][j][r];
-            if (a.beta != 0.f) vv += a.beta * *dst;
-            *dst = vv;
-          } else {
-            out[(int64_t)n * a.K + k] = acc[i][j][r];
-          }
-        }
+        if (n < a.N && i < ni) co[n] = cs[i][r];
       }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// bf16x3 wgrad from PRE-SPLIT operands (round 4): Y and A arrive as three row-major bf16 planes each (the side output
-// of the GEMM that consumed them -- usf_linear_f32's a_planes_out --, or usf_split_planes_f32).  Same block shape, ring,
-// barrier scheme, product order and output path as wgrad_lw_kernel (bit-identical gradients), but
-//   * the loader waves only COPY: six 16-byte buffer loads and six ds_write_b128 per thread and slab -- no conversion
-//     (the operand split the seven blocks of a row slab each repeated, 5.25 vector instructions per value, was what
-//     bound wgrad_lw_kernel: r02_tuning_experiments.md section 4);
-//   * the LDS image keeps the rows as they are in HBM: [32 batch rows][128 columns] bf16 per plane, 16-byte chunk ch of
-//     row r at position ch ^ (((r & 3) << 2) | ((r >> 2) & 3)), and the MFMA waves read their operand fragments (8
-//     consecutive batch rows of one column per lane) with the transposing read ds_read_b64_tr_b16, two per fragment.
-// Rows [M, ceil32(M)) of the planes must be zero (both producers write them so); columns beyond N / K read whatever
-// follows (padding, the next row, zeros beyond the buffer) and only reach outputs that are not stored.
-// ---------------------------------------------------------------------------------------------------------
-struct WpArgs {
-  const __bf16* Yp; int64_t ldyp, ystride;     // planes [3][rows][ld]: plane stride in elements
-  const __bf16* Ap; int64_t ldap, astride;
-  int y_col0, a_col0;                          // first column of the operands inside their planes (multiples of 8)
-  unsigned ybytes, abytes;                     // readable bytes from Yp / Ap (buffer bounds: beyond reads as zeros)
-  float* part;
-  int M, N, K;
-  int rows_per_split;
-  float* G; int64_t ldg;
-  float alpha, beta;
-  int direct;
-  int tiles, splits;
-  unsigned long long* dbg;                     // tuning builds (-DUSF_STAMP) only
-  WgSched sched;
-  int trim;                                    // both operands' planes end below 2 GiB: dead chunks of edge tiles are skipped
-};
-
-struct WpShared {
-  uint4 img[3][2][3][512];                     // [ring][Y / A][plane][32 rows x 16 chunks, swizzled]
-};
-
-typedef short wp_s16x4 __attribute__((ext_vector_type(4)));
-typedef short wp_s16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ int wp_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
-__device__ __forceinline__ bf16x8_t wp_frag(const char* tile, int o0, int o1) {
-  typedef __attribute__((address_space(3))) wp_s16x4 lds_v;
-  const wp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + o0));
-  const wp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + o1));
-  const wp_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8_t, v);
-}
-
-template <int NI, int NJ>
-__device__ __forceinline__ void wp_mfma_loop(WpShared& sh, f32x4 (&acc)[4][4], int nslab, int nslab4, int wn, int wk, int lane,
-                                             unsigned long long* dbg_slot) {
-  // lane 16 g + 4 q + p supplies row 8 g + 4 hh + q, columns 16 t + 4 p .. + 3 of the sub-tile (hh = 0, 1: the two reads)
-  const int lg = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  int yo[NI][2], ao[NJ][2];
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    const int r = 8 * lg + 4 * hh + q;
-#pragma unroll
-    for (int t = 0; t < NI; ++t) yo[t][hh] = 256 * r + 16 * ((8 * wn + 2 * t + (pp >> 1)) ^ wp_swz(r)) + 8 * (pp & 1);
-#pragma unroll
-    for (int t = 0; t < NJ; ++t) ao[t][hh] = 256 * r + 16 * ((8 * wk + 2 * t + (pp >> 1)) ^ wp_swz(r)) + 8 * (pp & 1);
-  }
-  bf16x8_t yp[NI][3], ap[2][3];
-  auto read_y1 = [&](int ring, int t) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) yp[t][pl] = wp_frag(reinterpret_cast<const char*>(&sh.img[ring][0][pl][0]), yo[t][0], yo[t][1]);
-  };
-  auto read_a = [&](int ring, int j, bf16x8_t (&f)[3]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) f[pl] = wp_frag(reinterpret_cast<const char*>(&sh.img[ring][1][pl][0]), ao[j][0], ao[j][1]);
-  };
-  auto slab = [&](int ring, int ring_next, auto b0) {
-    constexpr int B0 = decltype(b0)::value;
-#define USF_WP(P, Q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[i][P], ap[(j + B0) & 1][Q], acc[i][j], 0, 0, 0)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      if (j + 1 < NJ) {
-        read_a(ring, j + 1, ap[(j + 1 + B0) & 1]);
-      } else {
-        read_a(ring_next, 0, ap[(j + 1 + B0) & 1]);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        USF_WP(2, 0); USF_WP(1, 1); USF_WP(0, 2); USF_WP(1, 0); USF_WP(0, 1); USF_WP(0, 0);   // the order of wgrad_lw_kernel
-        if (j + 1 == NJ) read_y1(ring_next, i);
-      }
-    }
-#undef USF_WP
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NI, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-      if (j + 1 == NJ) {
-#pragma unroll
-        for (int t = 0; t < NI; ++t) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        }
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI, 0);
-      }
-    }
-  };
-  typedef std::integral_constant<int, 0> C0;
-  typedef std::integral_constant<int, NJ & 1> C1;
-#pragma unroll
-  for (int t = 0; t < NI; ++t) read_y1(0, t);
-  read_a(0, 0, ap[0]);
-#ifdef USF_STAMP
-  unsigned long long tw = 0, tb = 0;
-#endif
-  int s = 0, ring = 0;
-  auto nxt = [](int r) { return r == 2 ? 0 : r + 1; };
-  for (; s < nslab4; s += 2) {
-    WL_Q(q0);
-    if (s < nslab) slab(ring, nxt(ring), C0());
-    WL_Q(q1);
-    __syncthreads();
-    WL_Q(q2);
-    ring = nxt(ring);
-    if (s + 1 < nslab) slab(ring, nxt(ring), C1());
-    WL_Q(q3);
-    __syncthreads();
-    ring = nxt(ring);
-#ifdef USF_STAMP
-    tw += (q1 - q0) + (q3 - q2); tb += (q2 - q1) + (WSTAMP() - q3);
-#endif
-  }
-#ifdef USF_STAMP
-  if (dbg_slot) { dbg_slot[0] = tw; dbg_slot[1] = tb; dbg_slot[2] = nslab; dbg_slot[3] = 1; }
-#endif
-}
-
-__global__ __launch_bounds__(768) void wgrad_planes_kernel(WpArgs a) {
-  __shared__ __attribute__((aligned(16))) WpShared sh;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tilesK = (a.K + WG_T - 1) / WG_T;
-  int n0, k0, m_begin, m_end, split;
-  if (a.sched.items) {
-    if (!wg_item(a.sched, a.M, n0, k0, m_begin, m_end, split)) return;
-  } else {
-    const int b = blockIdx.x;
-    const int tile = (b >> 3) % a.tiles;                                                 // wg_decode's map
-    split = ((b >> 3) / a.tiles) * 8 + (b & 7);
-    if (split >= a.splits) return;
-    n0 = (tile / tilesK) * WG_T; k0 = (tile % tilesK) * WG_T;
-    m_begin = split * a.rows_per_split;
-    m_end = (m_begin + a.rows_per_split < a.M) ? m_begin + a.rows_per_split : a.M;
-  }
-  const int nslab = (m_end - m_begin + WB_S - 1) / WB_S;
-  const int nslab4 = (nslab + 3) & ~3;
-  unsigned long long* dbg_slot = nullptr;
-#ifdef USF_STAMP
-  if (a.dbg && lane == 0) dbg_slot = a.dbg + (size_t)((blockIdx.x % 1024) * 12 + wave) * 4;
-#endif
-
-  if (wave >= 4) {
-    // ------------------------------- loader waves: waves 4 .. 7 copy Y, waves 8 .. 11 copy A -------------------------------
-    const bool isA = wave >= 8;                 // wave-uniform
-    const int u = (tid - 256) & 255;
-    const unsigned ld = (unsigned)(isA ? a.ldap : a.ldyp);
-    const unsigned pstride = (unsigned)(isA ? a.astride : a.ystride) * 2u;           // bytes
-    const unsigned c0 = (unsigned)(isA ? k0 + a.a_col0 : n0 + a.y_col0);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(isA ? a.Ap : a.Yp), 0, (int)(isA ? a.abytes : a.ybytes), 0x00020000);
-    // chunks beyond the tile's live columns (edge tiles: 784 = 6 x 128 + 16) are not fetched: their lanes ask for an offset
-    // beyond the buffer (answered with zeros, no memory access); the MFMA waves never read those columns
-    const int live = (isA ? a.K - k0 : a.N - n0);
-    const int live_ch = a.trim ? 2 * ((live + 15) >> 4) : 16;
-    unsigned vo[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = u + 256 * h, r = c >> 4, ch = (c & 15) ^ wp_swz(r);
-      vo[h] = ch < live_ch ? (((unsigned)m_begin + (unsigned)r) * ld + c0 + 8u * (unsigned)ch) * 2u : 0x80000000u;
-    }
-    typedef unsigned wp_u32x4 __attribute__((ext_vector_type(4)));
-    auto fetch = [&](int sl, wp_u32x4 (&v)[6]) {
-      const unsigned adv = (unsigned)sl * (WB_S * 2u) * ld;
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          v[2 * pl + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo[h] + adv), (int)((unsigned)pl * pstride), 0);
-    };
-    auto store = [&](int ring, const wp_u32x4 (&v)[6]) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          sh.img[ring][isA ? 1 : 0][pl][u + 256 * h] = __builtin_bit_cast(uint4, v[2 * pl + h]);
-    };
-#ifndef USF_WP_DEPTH
-#define USF_WP_DEPTH 2
-#endif
-    constexpr int DEPTH = USF_WP_DEPTH;         // slabs in flight per thread (2 or 4: the slab count is rounded up to a multiple of four)
-    wp_u32x4 vs[DEPTH][6];
-#pragma unroll
-    for (int t = 0; t < DEPTH; ++t) fetch(t, vs[t]);
-    store(0, vs[0]); fetch(DEPTH, vs[0]);
-    store(1, vs[1 % DEPTH]); fetch(DEPTH + 1, vs[1 % DEPTH]);
-    __syncthreads();
-    int ring2 = 2;
-#ifdef USF_STAMP
-    unsigned long long tw = 0, tb = 0;
-#endif
-    for (int s0 = 0; s0 < nslab4; s0 += DEPTH) {
-#pragma unroll
-      for (int k = 0; k < DEPTH; ++k) {
-        WL_Q(q0);
-        store(ring2, vs[(k + 2) % DEPTH]);
-        fetch(s0 + k + 2 + DEPTH, vs[(k + 2) % DEPTH]);
-        WL_Q(q1);
-        __syncthreads();
-        ring2 = ring2 == 2 ? 0 : ring2 + 1;
-#ifdef USF_STAMP
-        tw += q1 - q0; tb += WSTAMP() - q1;
-#endif
-      }
-    }
-#ifdef USF_STAMP
-    if (dbg_slot) { dbg_slot[0] = tw; dbg_slot[1] = tb; dbg_slot[2] = nslab; dbg_slot[3] = 1; }
-#endif
-    return;
-  }
-
-  // ------------------------------- MFMA waves -------------------------------
-  const int wn = wave >> 1, wk = wave & 1;
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int rem_n = a.N - (n0 + wn * 64), rem_k = a.K - (k0 + wk * 64);
-  const int ni = rem_n <= 0 ? 0 : (rem_n >= 64 ? 4 : (rem_n + 15) / 16);
-  const int nj = rem_k <= 0 ? 0 : (rem_k >= 64 ? 4 : (rem_k + 15) / 16);
-  __syncthreads();
-  if (ni == 0 || nj == 0) {
-    for (int s = 0; s < nslab4; ++s) __syncthreads();
-  } else {
-#define WP_GO(NI_, NJ_) wp_mfma_loop<NI_, NJ_>(sh, acc, nslab, nslab4, wn, wk, lane, dbg_slot)
-#define WP_ROW(NI_) do { if (nj > 2) WP_GO(NI_, 4); else if (nj > 1) WP_GO(NI_, 2); else WP_GO(NI_, 1); } while (0)
-    if (ni > 2) WP_ROW(4); else if (ni > 1) WP_ROW(2); else WP_ROW(1);
-#undef WP_ROW
-#undef WP_GO
   }
   float* out = a.part + (int64_t)split * a.N * a.K;
 #pragma unroll
@@ -948,64 +659,29 @@ __global__ __launch_bounds__(768) void wgrad_planes_kernel(WpArgs a) {
         }
       }
 }
-
 #undef WL_Q
-
-// fp32 rows -> three row-major bf16 planes (round-to-nearest residual split, x = p1 + p2 + p3 exactly): P[pl][m][c] for
-// m < rows_pad, c < ldp; zeros for m >= M or c >= N.  One thread = 8 columns of a row.
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, __bf16* __restrict__ P,
-                                                           int64_t ldp, int64_t pstride, int rows_pad, int vec) {
-  const int cpr = (int)(ldp >> 3);
-  const int64_t total = (int64_t)rows_pad * cpr;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int m = (int)(e / cpr), c = (int)(e - (int64_t)m * cpr) * 8;
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = 0.f;
-    if (m < M) {
-      if (c + 8 <= N && vec) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(X + (int64_t)m * ldx + c), v1 = *reinterpret_cast<const f32x4*>(X + (int64_t)m * ldx + c + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { x[j] = v0[j]; x[4 + j] = v1[j]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (c + j < N) x[j] = X[(int64_t)m * ldx + c + j];
-      }
-    }
-    bf16x8_t p1, p2, p3;
-    wl_split(x, p1, p2, p3);
-    __bf16* d = P + (int64_t)m * ldp + c;
-    *reinterpret_cast<bf16x8_t*>(d) = p1;
-    *reinterpret_cast<bf16x8_t*>(d + pstride) = p2;
-    *reinterpret_cast<bf16x8_t*>(d + 2 * pstride) = p3;
-  }
-}
 
 // out[r*ldo + c] = alpha * sum_s part[s][r][c] + beta * out[...]   (rows x cols elements per partial)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int splits, int64_t rows,
                                                               int64_t cols, float* __restrict__ out, int64_t ldo,
-                                                              float alpha, float beta) {
+                                                              float alpha, float beta, const float* __restrict__ cs_part = nullptr,
+                                                              float* __restrict__ cs_out = nullptr, float cs_alpha = 0.f,
+                                                              float cs_beta = 0.f) {
   const int64_t total = rows * cols;
+  if (cs_out)                                   // the column sums of Y (usf_wgrad_bias_f32): a loop of its own, the main one as it was
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+      float s = 0.f;
+      // (16 loads in flight, added in order: one wave walks all the row ranges here -- a load per iteration would cost its latency each time)
+#pragma unroll 16
+      for (int p = 0; p < splits; ++p) s += cs_part[(int64_t)p * rows + r];
+      float v = cs_alpha * s;
+      if (cs_beta != 0.f) v += cs_beta * cs_out[r];
+      cs_out[r] = v;
+    }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     float s = 0.f;
     for (int p = 0; p < splits; ++p) s += part[(int64_t)p * total + e];
     const int64_t r = e / cols, c = e - r * cols;
-    float v = alpha * s;
-    if (beta != 0.f) v += beta * out[r * ldo + c];
-    out[r * ldo + c] = v;
-  }
-}
-
-// the same for the balanced schedule: element (r, c) sums the nseg[class of its tile] partials its tile wrote
-__global__ __launch_bounds__(256) void reduce_partials_cls_kernel(const float* __restrict__ part, WgSched sc, int64_t rows, int64_t cols,
-                                                                  float* __restrict__ out, int64_t ldo, float alpha, float beta) {
-  const int64_t total = rows * cols;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t r = e / cols, c = e - r * cols;
-    const int cls = (r >= (int64_t)sc.fN * WG_T ? 2 : 0) + (c >= (int64_t)sc.fK * WG_T ? 1 : 0);
-    const int n = sc.nseg[cls];
-    float s = 0.f;
-    for (int p = 0; p < n; ++p) s += part[(int64_t)p * total + e];
     float v = alpha * s;
     if (beta != 0.f) v += beta * out[r * ldo + c];
     out[r * ldo + c] = v;
@@ -1097,89 +773,10 @@ static bool use_lw(int64_t M, int32_t mode, int64_t tiles, int64_t ldy, int64_t 
 
 static int64_t wg_tiles(int64_t N, int64_t K) { return ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T); }
 
-// One item per CU (see WgSched).  edge_cost: time of an edge tile's slab relative to a full tile's, in percent.
-static int wg_cus() {
-  static int n = -1;
-  if (n < 0) {
-    int dev = 0; hipDeviceProp_t pr;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
-    const char* e = getenv("USF_WGRAD_CUS");
-    if (e && atoi(e) > 0) n = atoi(e);
-    n &= ~7;
-    if (n < 8) n = 8;
-  }
-  return n;
-}
-static bool wg_schedule(int64_t M, int64_t N, int64_t K, int edge_pct, int corner_pct, WgSched& sc) {
-  memset(&sc, 0, sizeof(sc));
-  const int cus = wg_cus();
-  const int S = (int)((M + WB_S - 1) / WB_S);                  // slabs
-  sc.per_xcd = cus / 8;
-  sc.fN = (int)(N / WG_T); sc.fK = (int)(K / WG_T);
-  const int eN = (N % WG_T) ? 1 : 0, eK = (K % WG_T) ? 1 : 0;
-  sc.T[0] = sc.fN * sc.fK; sc.T[1] = sc.fN * eK; sc.T[2] = eN * sc.fK; sc.T[3] = eN * eK;
-  const int cost[4] = {100, edge_pct, edge_pct, corner_pct};
-  int tiles = 0;
-  for (int c = 0; c < 4; ++c) { sc.nseg[c] = sc.T[c] ? 1 : 0; tiles += sc.T[c]; }
-  if (tiles > cus || S < 4) return false;
-  int used = tiles;
-  while (true) {                                               // greedy min-max: one more row range for the class whose items run longest
-    int best = -1; int64_t bt = -1;
-    for (int c = 0; c < 4; ++c) {
-      if (!sc.T[c] || sc.nseg[c] >= S || sc.nseg[c] >= 256) continue;
-      const int64_t t = (int64_t)((S + sc.nseg[c] - 1) / sc.nseg[c]) * cost[c];
-      if (t > bt) { bt = t; best = c; }
-    }
-    if (best < 0 || used + sc.T[best] > cus) break;
-    ++sc.nseg[best]; used += sc.T[best];
-  }
-  sc.items = 0;
-  for (int c = 0; c < 4; ++c) {
-    sc.off[c] = sc.items;
-    if (sc.T[c]) {
-      const int slabs = (S + sc.nseg[c] - 1) / sc.nseg[c];
-      sc.rows[c] = slabs * WB_S;
-      sc.nseg[c] = (S + slabs - 1) / slabs;
-    }
-    sc.items += sc.T[c] * sc.nseg[c];
-  }
-  sc.off[4] = sc.items;
-  // class by class, an eighth to every XCD; the remainders go to the XCDs with the fewest items so far
-  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int c = 0; c < 4; ++c) {
-    const int n = sc.T[c] * sc.nseg[c];
-    int cn[8];
-    for (int x = 0; x < 8; ++x) cn[x] = n / 8;
-    for (int r = 0; r < n % 8; ++r) {
-      int bx = 0;
-      for (int x = 1; x < 8; ++x) if (load[x] + cn[x] < load[bx] + cn[bx]) bx = x;
-      ++cn[bx];
-    }
-    int st = 0;
-    for (int x = 0; x < 8; ++x) { sc.start[c][x] = (short)st; sc.cnt[c][x] = (short)cn[x]; st += cn[x]; load[x] += cn[x]; }
-  }
-  for (int x = 0; x < 8; ++x) if (load[x] > sc.per_xcd) return false;
-  return true;
-}
-static int wg_sched_max_parts(const WgSched& sc) {
-  int m = 1;
-  for (int c = 0; c < 4; ++c) if (sc.nseg[c] > m) m = sc.nseg[c];
-  return m;
-}
-static int wg_env_pct(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && atoi(e) > 0) ? atoi(e) : dflt;
-}
-
 int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out) {
   if (M < 0 || N <= 0 || K <= 0) return -1;
   const int sa = pick_splits(M, wg_tiles(N, K), false), sb = pick_splits(M, wg_tiles(N, K), true);      // either kernel may be chosen
-  int sc_parts = 0;
-  WgSched sc;
-  if (wg_schedule(M, N, K, 20, 20, sc)) sc_parts = wg_sched_max_parts(sc);    // the cheapest edge cost any kernel uses: most row ranges
-  int m = sa > sb ? sa : sb;
-  if (sc_parts > m) m = sc_parts;
-  *out = (int64_t)m * N * K;
+  *out = (int64_t)(sa > sb ? sa : sb) * N * (K + 1);            // + the partial column sums of usf_wgrad_bias_f32
   return 0;
 }
 
@@ -1192,9 +789,18 @@ int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int
   return (mode == 1 && M >= 2048) ? 1 : 0;
 }
 
+// usf_wgrad_bias_f32: where the loader-wave kernel runs and K >= 64 the column sums of Y ride along
+int wgrad_bias_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
+  return (wgrad_variant(M, N, K, ldy, lda, mode) == 2 && K >= 64) ? 1 : 0;
+}
+
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
-          hipStream_t stream) {
+          hipStream_t stream, float* colsum_out, float cs_alpha, float cs_beta) {
+  if (colsum_out && !wgrad_bias_ok(M, N, K, ldy, lda, mode)) {
+    set_error("usf_wgrad_bias_f32: the column sums need the loader-wave kernel and K >= 64 (usf_wgrad_bias_ok)");
+    return -2;
+  }
   if (((!Y || !A) && M > 0) || !G || !workspace || M < 0 || N <= 0 || K <= 0 || ldg < K || ldy < N || lda < K) {
     set_error("usf_wgrad_f32: bad arguments");
     return -1;
@@ -1210,126 +816,30 @@ int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, i
   const int variant = wgrad_variant(M, N, K, ldy, lda, mode);
   const bool lw = variant == 2;
   const int splits = pick_splits(M, tiles, lw);
-  if (workspace_floats < (int64_t)splits * N * K) {
+  if (workspace_floats < (int64_t)splits * N * (K + (colsum_out ? 1 : 0))) {
     set_error("usf_wgrad_f32: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
-              (long long)splits * N * K);
+              (long long)splits * N * (K + 1));
     return -4;
   }
   int rows = (int)((M + splits - 1) / splits);
   rows = (rows + WB_S - 1) / WB_S * WB_S;
   WgradArgs a{Y, ldy, A, lda, workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S, G, ldg, alpha, beta,
-              splits == 1 ? 1 : 0, (int)tiles, splits, nullptr};
-  memset(&a.sched, 0, sizeof(a.sched));
+              (splits == 1 && !colsum_out) ? 1 : 0, (int)tiles, splits, nullptr, nullptr};
+  if (colsum_out) a.cs_part = workspace + (int64_t)splits * N * K;
 #ifdef USF_STAMP
   a.dbg = g_wdbg;
 #endif
-  static int use_sched = -1;                  // USF_WGRAD_SCHED=0: the plain (tile, row range) grid (tuning aid)
-  if (use_sched < 0) { const char* e = getenv("USF_WGRAD_SCHED_F32"); use_sched = e ? atoi(e) : 0; }
-  if (lw && use_sched && wg_schedule(M, N, K, wg_env_pct("USF_WGRAD_EDGE_PCT", 40), wg_env_pct("USF_WGRAD_CORNER_PCT", 35), a.sched) &&
-      (int64_t)wg_sched_max_parts(a.sched) * N * K <= workspace_floats) {
-    a.direct = 0;
-    wgrad_lw_kernel<<<(unsigned)(a.sched.per_xcd * 8), 768, 0, stream>>>(a);
-    int64_t rb = (N * K + 255) / 256;
-    if (rb > 4096) rb = 4096;
-    reduce_partials_cls_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, a.sched, N, K, G, ldg, alpha, beta);
-    return check_launch("usf_wgrad_f32");
-  }
-  a.sched.items = 0;
   const unsigned grid = (unsigned)(tiles * ((splits + 7) / 8) * 8);
   if (lw) wgrad_lw_kernel<<<grid, 768, 0, stream>>>(a);
   else if (variant == 1) wgrad_bf16x3_kernel<<<grid, 256, 0, stream>>>(a);
   else wgrad_kernel<<<grid, 256, 0, stream>>>(a);
-  if (splits > 1) {
+  if (splits > 1 || colsum_out) {
     int64_t rb = (N * K + 255) / 256;
     if (rb > 4096) rb = 4096;
-    reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta);
+    reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta, a.cs_part, colsum_out,
+                                                              cs_alpha, cs_beta);
   }
   return check_launch("usf_wgrad_f32");
-}
-
-// usf_split_planes_f32 / usf_wgrad_planes_f32: see include/usflows_hip.h
-int split_planes(const float* X, int64_t ldx, int64_t M, int64_t N, void* P, int64_t ldp, int64_t plane_stride, hipStream_t stream) {
-  if ((!X && M > 0) || !P || M < 0 || N <= 0 || ldx < N || ldp < N || (ldp & 7) || !aligned16(P) || (plane_stride & 7)) {
-    set_error("usf_split_planes_f32: bad arguments (ldp and plane_stride multiples of 8, 16-byte aligned planes)");
-    return -1;
-  }
-  const int64_t rows_pad = (M + WB_S - 1) / WB_S * WB_S;
-  if (M > 0x7fffffff - WB_S || plane_stride < rows_pad * ldp) { set_error("usf_split_planes_f32: plane_stride < ceil32(M) * ldp"); return -2; }
-  if (rows_pad == 0) return 0;
-  int64_t nb = (rows_pad * (ldp >> 3) + 255) / 256;
-  if (nb > 65536) nb = 65536;
-  split_planes_kernel<<<(unsigned)nb, 256, 0, stream>>>(X, ldx, (int)M, (int)N, (__bf16*)P, ldp, plane_stride, (int)rows_pad,
-                                                      (aligned16(X) && !(ldx & 3)) ? 1 : 0);
-  return check_launch("usf_split_planes_f32");
-}
-
-int64_t wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K) {
-  if (M < 0 || N <= 0 || K <= 0) return -1;
-  int m = pick_splits(M, wg_tiles(N, K), true);
-  WgSched sc;
-  if (wg_schedule(M, N, K, 20, 20, sc) && wg_sched_max_parts(sc) > m) m = wg_sched_max_parts(sc);
-  return (int64_t)m * N * K;
-}
-
-int wgrad_planes_ok(int64_t M, int64_t N, int64_t K) {
-  // the copying kernel pays where the loader-wave kernel is chosen (its cross-over, the same block shape)
-  return M >= 8192 && M * wg_tiles(N, K) >= 160000;
-}
-
-int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, const void* Ap, int64_t ldap, int64_t astride,
-                 int64_t a_off, int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* workspace,
-                 int64_t workspace_floats, hipStream_t stream) {
-  if (!Yp || !Ap || !G || !workspace || M <= 0 || N <= 0 || K <= 0 || ldg < K || y_off < 0 || a_off < 0 || ldyp < y_off + N ||
-      ldap < a_off + K) {
-    set_error("usf_wgrad_planes_f32: bad arguments");
-    return -1;
-  }
-  if ((ldyp & 7) || (ldap & 7) || (y_off & 7) || (a_off & 7) || (ystride & 7) || (astride & 7) || !aligned16(Yp) || !aligned16(Ap)) {
-    set_error("usf_wgrad_planes_f32: row strides, plane strides and column offsets must be multiples of 8 elements, planes 16-byte aligned");
-    return -3;
-  }
-  const int64_t rows_pad = (M + WB_S - 1) / WB_S * WB_S;
-  if (ystride < rows_pad * ldyp || astride < rows_pad * ldap) { set_error("usf_wgrad_planes_f32: plane stride < ceil32(M) * ld"); return -2; }
-  const int64_t yb = (2 * ystride + rows_pad * ldyp) * 2, ab = (2 * astride + rows_pad * ldap) * 2;
-  if (M > 0x7fffffff - 4096 || N > (1 << 20) || K > (1 << 20) || yb >= (1LL << 32) || ab >= (1LL << 32)) {
-    set_error("usf_wgrad_planes_f32: size out of range (planes of one operand must stay below 4 GiB)");
-    return -2;
-  }
-  const int64_t tiles = wg_tiles(N, K);
-  const int splits = pick_splits(M, tiles, true);
-  int rows = (int)((M + splits - 1) / splits);
-  rows = (rows + WB_S - 1) / WB_S * WB_S;
-  WpArgs a{(const __bf16*)Yp, ldyp, ystride, (const __bf16*)Ap, ldap, astride, (int)y_off, (int)a_off, (unsigned)yb, (unsigned)ab,
-           workspace, (int)M, (int)N, (int)K, rows > 0 ? rows : WB_S, G, ldg, alpha, beta, splits == 1 ? 1 : 0, (int)tiles, splits, nullptr};
-  memset(&a.sched, 0, sizeof(a.sched));
-  a.trim = (yb < (1LL << 31) && ab < (1LL << 31) && wg_env_pct("USF_WGRADP_TRIM", 1) == 1) ? 1 : 0;
-#ifdef USF_STAMP
-  a.dbg = g_wdbg;
-#endif
-  static int use_sched = -1;
-  if (use_sched < 0) { const char* e = getenv("USF_WGRAD_SCHED"); use_sched = e ? atoi(e) : 1; }
-  if (use_sched && wg_schedule(M, N, K, wg_env_pct("USF_WGRADP_EDGE_PCT", 100), wg_env_pct("USF_WGRADP_CORNER_PCT", 100), a.sched) &&
-      (int64_t)wg_sched_max_parts(a.sched) * N * K <= workspace_floats) {
-    a.direct = 0;
-    wgrad_planes_kernel<<<(unsigned)(a.sched.per_xcd * 8), 768, 0, stream>>>(a);
-    int64_t rb = (N * K + 255) / 256;
-    if (rb > 4096) rb = 4096;
-    reduce_partials_cls_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, a.sched, N, K, G, ldg, alpha, beta);
-    return check_launch("usf_wgrad_planes_f32");
-  }
-  a.sched.items = 0;
-  if (workspace_floats < (int64_t)splits * N * K) {
-    set_error("usf_wgrad_planes_f32: workspace too small (%lld < %lld floats)", (long long)workspace_floats, (long long)splits * N * K);
-    return -4;
-  }
-  const unsigned grid = (unsigned)(tiles * ((splits + 7) / 8) * 8);
-  wgrad_planes_kernel<<<grid, 768, 0, stream>>>(a);
-  if (splits > 1) {
-    int64_t rb = (N * K + 255) / 256;
-    if (rb > 4096) rb = 4096;
-    reduce_partials_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, splits, N, K, G, ldg, alpha, beta);
-  }
-  return check_launch("usf_wgrad_planes_f32");
 }
 
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,

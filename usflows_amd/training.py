@@ -520,7 +520,12 @@ class TrainPath:
                 gpl = ws["gpl"] = _ext.row_planes(B, max(n_out, eng.LD, eng.LDn), dev)
             Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
             self._linear(pk, g_cur, 0, g_ld, Wt, g_other, 0, n_in, B, n_in, n_out, planes_out=gpl)
-            _ext.wgrad_planes(gpl, ws[m["in_planes"]], Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1])
+            gs = self._buf(ws, f"gs{m['op']}", 1, wid)
+            cs_fused = (os.environ.get("USFLOWS_AMD_FUSED_BIAS", "1") != "0"              # the bias gradient from the same pass
+                        and bool(_ext.load().usf_wgrad_planes_colsum_ok(B, n_out, n_in)))
+            _ext.wgrad_planes(gpl, ws[m["in_planes"]], Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1], colsum=gs if cs_fused else None)
+            if not cs_fused:
+                _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
         elif m["in_buf"] == "user_in":
             # the caller's tensor changes from call to call: issued through the wrapper on every replay
             _ext.host_op(lambda g=g_cur, ld=g_ld: _ext.wgrad(g, self._cur["x"], Gp, M=B, N=n_out, K=n_in, ldy=ld,
@@ -529,8 +534,9 @@ class TrainPath:
         else:
             _ext.wgrad(g_cur, ws[m["in_buf"]], Gp, M=B, N=n_out, K=n_in, ldy=g_ld, lda=m["in_ld"], ldg=Gp.shape[1],
                        mode=self._wmode)
-        gs = self._buf(ws, f"gs{m['op']}", 1, wid)
-        _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
+        if not from_planes:
+            gs = self._buf(ws, f"gs{m['op']}", 1, wid)
+            _ext.colsum(g_cur, gs, M=B, N=n_out, ldy=g_ld)
         D = eng.D
         k = self._lu_slot[id(blk)] if self._lu_slot is not None else stacks["next"]
         stacks["next"] += 1
@@ -595,12 +601,17 @@ class TrainPath:
         W_out = un["W_out"]                                   # [tr_n, hp_last]
         gimg = lambda tag: self._buf(ws, f"gW{m['step']}_{tag}", max(hmax, LD), max(hmax, LD))
         gW = gimg("out")
+        gb = self._buf(ws, f"gb{m['step']}", 1, max(hmax, LD))
+        # large batches: the bias gradient (column sums of the same Y) rides in the weight-gradient pass (usf_wgrad_bias_f32)
+        fuse = lambda n, k, ldy, lda: (not self._defer and os.environ.get("USFLOWS_AMD_FUSED_BIAS", "1") != "0"  # noqa: E731
+                                       and _ext.wgrad_bias_ok(B, n, k, ldy, lda, self._wmode))
+        fused_out = fuse(tr_n, hp[-1], g_ld, hmax)
         _ext.wgrad(g_cur, hbufs[-1], gW, M=B, N=tr_n, K=hp[-1], ldy=g_ld, lda=hmax, ldg=gW.shape[1], y_off=tr_off,
-                   alpha=sign, mode=self._wmode)
+                   alpha=sign, mode=self._wmode, **(dict(colsum=gb, cs_alpha=sign) if fused_out else {}))
         self._scatter_weight(grads, last_l.weight, gW, rows_sel=self._sel_inv(raw["tr_idx"], dev), n_rows=eng.D,
                              cols_sel=None, n_cols=h[-1])
-        gb = self._buf(ws, f"gb{m['step']}", 1, max(hmax, LD))
-        _ext.colsum(g_cur, gb, M=B, N=tr_n, ldy=g_ld, y_off=tr_off, alpha=sign)
+        if not fused_out:
+            _ext.colsum(g_cur, gb, M=B, N=tr_n, ldy=g_ld, y_off=tr_off, alpha=sign)
         self._scatter_vec(grads, last_l.bias, gb, self._sel_inv(raw["tr_idx"], dev), eng.D)
         # d_h = d_out W_out  (sign is applied where the result leaves the MLP)
         if self._defer:
@@ -619,10 +630,12 @@ class TrainPath:
             W, _b = un["layers"][j]                           # [hp_j, hp_{j-1}]
             l = hidden_l[j - 1]
             gW = gimg(f"h{j}")
+            gbias = self._grad_slot(grads, l.bias) if (hp[j] == h[j] and fuse(hp[j], hp[j - 1], hmax, hmax)) else None
             _ext.wgrad(d, hbufs[j - 1], gW, M=B, N=hp[j], K=hp[j - 1], ldy=hmax, lda=hmax, ldg=gW.shape[1], alpha=sign,
-                       mode=self._wmode)
+                       mode=self._wmode, **(dict(colsum=gbias, cs_alpha=sign) if gbias is not None else {}))
             self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
-            self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
+            if gbias is None:
+                self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
             d_next = d_of(j - 1)
             self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j], **gate(hbufs[j - 1]))
             d = d_next
@@ -630,10 +643,12 @@ class TrainPath:
         W_in, _b = un["layers"][0]                            # [hp0, pass_n]
         pass_n, pass_off = cp["pass_n"], cp["pass_off"]
         gW = gimg("in")
+        gbias = self._grad_slot(grads, first_l.bias) if (hp[0] == h[0] and fuse(hp[0], pass_n, hmax, LD)) else None
         _ext.wgrad(d, zbuf, gW, M=B, N=hp[0], K=pass_n, ldy=hmax, lda=LD, ldg=gW.shape[1], a_off=pass_off, alpha=sign,
-                   mode=self._wmode)
+                   mode=self._wmode, **(dict(colsum=gbias, cs_alpha=sign) if gbias is not None else {}))
         self._scatter_weight(grads, first_l.weight, gW, None, h[0], self._sel_inv(raw["pass_idx"], dev), eng.D)
-        self._colsum_to(grads, first_l.bias, d, B, h[0], hmax, sign)
+        if gbias is None:
+            self._colsum_to(grads, first_l.bias, d, B, h[0], hmax, sign)
         if has_ctx:
             ctx_l = lin[1]
             if m["use_ctx"]:
