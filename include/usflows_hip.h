@@ -153,6 +153,12 @@ typedef struct usf_coupling_desc {
   const void* split_in;  int64_t split_in_ld,  split_in_plane;
   const void* split_hid[USF_MAX_HIDDEN]; int64_t split_hid_ld, split_hid_plane;
   const void* split_out; int64_t split_out_ld, split_out_plane;
+  /* Optional (ABI 32): hidden_out[l] [M, ld_hidden_out] receives the activations of hidden layer l (after the
+   * nonlinearity; the padded width, zeros in the padding) -- what the backward pass of the training step otherwise computes a
+   * second time (two GEMMs per coupling layer; flows.py:196-203).  Only the bf16x3 kernel stores them (its eligibility rule
+   * above): a descriptor that sets hidden_out and is served by another kernel is rejected.  ld_hidden_out % 4 == 0,
+   * 16-byte aligned bases. */
+  float* hidden_out[USF_MAX_HIDDEN]; int64_t ld_hidden_out;
 } usf_coupling_desc;
 
 int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream);

@@ -65,6 +65,7 @@ class CouplingDesc(C.Structure):
         ("split_in", _fp), ("split_in_ld", C.c_int64), ("split_in_plane", C.c_int64),
         ("split_hid", _fp * USF_MAX_HIDDEN), ("split_hid_ld", C.c_int64), ("split_hid_plane", C.c_int64),
         ("split_out", _fp), ("split_out_ld", C.c_int64), ("split_out_plane", C.c_int64),
+        ("hidden_out", _fp * USF_MAX_HIDDEN), ("ld_hidden_out", C.c_int64),
     ]
 
 

@@ -34,6 +34,7 @@ struct Cpl3Args {
   const float* ctx; const float* W_ctx; const float* b_ctx;
   float sign, slope; int act;
   unsigned long long* dbg;              // tuning builds only (USF_STAMP)
+  float* hsave[3]; int64_t ld_hs;       // usf_coupling_desc::hidden_out, or NULLs
 };
 
 __device__ __forceinline__ void c3_split3(const f32x4 x0, const f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -272,6 +273,14 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
     }
   };
   ctx_act(X1, p.ctx != nullptr);
+  // training: the hidden activations go to HBM for the backward pass (lane (j, g) holds units 16 ht + 4 g .. + 3 of row j)
+  auto save_hidden = [&](const f32x4 (&X)[T], float* H) {
+    if (H == nullptr || wrow0 + lj >= p.M) return;
+    float* d = H + (int64_t)(wrow0 + lj) * p.ld_hs + 4 * lg;
+#pragma unroll
+    for (int ht = 0; ht < T; ++ht) *reinterpret_cast<f32x4*>(d + 16 * ht) = X[ht];
+  };
+  save_hidden(X1, p.hsave[0]);
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1'] * Xin[h1'][row] ====================
   auto hidden_layer = [&](f32x4 (&Xin)[T], f32x4 (&Xout)[T], int l) {
@@ -303,11 +312,13 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
 #pragma unroll
     for (int t = 0; t < T; ++t) X2[t] = *reinterpret_cast<const f32x4*>(p.b_hid[0] + t * 16 + 4 * lg);
     hidden_layer(X1, X2, 0);
+    save_hidden(X2, p.hsave[1]);
   }
   if (NH >= 3) {
 #pragma unroll
     for (int t = 0; t < T; ++t) X1[t] = *reinterpret_cast<const f32x4*>(p.b_hid[1] + t * 16 + 4 * lg);
     hidden_layer(X2, X1, 1);
+    save_hidden(X1, p.hsave[2]);
   }
 
   C3STAMP(t2);
@@ -422,6 +433,12 @@ int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
 #ifdef USF_STAMP
   a.dbg = g_c3dbg;
 #endif
+  for (int i = 0; i < 3; ++i) a.hsave[i] = (i < d->n_hidden) ? d->hidden_out[i] : nullptr;
+  a.ld_hs = d->ld_hidden_out;
+  if (d->hidden_out[0] && (d->ld_hidden_out < C3_HMAX || (d->ld_hidden_out & 3) || !aligned16(d->hidden_out[0]))) {
+    set_error("usf_coupling_additive_f32(bf16x3): hidden_out needs ld_hidden_out >= 256, a multiple of 4, 16-byte aligned bases");
+    return -2;
+  }
   const int64_t kp = ((d->n_pass + 31) / 32) * 32;
   if (d->split_in_ld < kp || d->split_hid_ld < C3_HMAX * (d->n_hidden > 1) || d->split_out_ld < C3_HMAX || (d->split_in_ld & 7) ||
       (d->split_out_ld & 7) || !aligned16(d->split_in) || !aligned16(d->split_out)) {

@@ -1021,7 +1021,18 @@ class FlowEngine:
             if cp.get("general"):
                 self._general_coupling_ops(ops, lin_op, pk, cp, ws, zptr, B, sign, device)
             elif self.use_fused_coupling and self._fused_ok(cp) and B >= self.fused_min_rows:
-                ops.append(self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None))
+                op = self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None)
+                # training: the fused kernel also stores the hidden activations (buffers of the layer's own; 2 x B x 256 x 4
+                # bytes per coupling) -- the backward pass reads them instead of running the conditioner a second time
+                if train and self.save_fused_hidden(cp, B) and op.u.coupling.split_in:
+                    for j in range(len(cp["hidden"])):
+                        hname = f"Hs{j}_{i}"
+                        if hname not in ws or ws[hname].shape[0] != B or ws[hname].shape[1] < self.hmax:
+                            ws[hname] = torch.zeros(B, self.hmax, dtype=torch.float32, device=device)
+                        op.u.coupling.hidden_out[j] = ws[hname].data_ptr()
+                    op.u.coupling.ld_hidden_out = self.hmax
+                    meta[-1]["hidden_saved_fused"] = True
+                ops.append(op)
             else:
                 hbufs = ["H1", "H2"]
                 un = self._unfused_pack(pk, cp)
@@ -1071,6 +1082,13 @@ class FlowEngine:
         return dict(arr=arr, n=len(ops), patch_in=[(i_, "linear", "A") for i_ in patch_in],
                     patch_out=[(i_, "linear", "C") for i_ in patch_out], side=side,
                     final_gather=final_gather, out_buf=cur, ws=ws, pk=pk, meta=meta)
+
+    def save_fused_hidden(self, cp, B: int) -> bool:
+        """training: the fused bf16x3 coupling kernel stores its hidden activations (usf_coupling_desc::hidden_out) -- where
+        that kernel serves the layer (hidden width in (128, 256], >= 1024 rows), unless USFLOWS_AMD_SAVE_HIDDEN=0"""
+        hm = max(cp["hidden"])
+        return (self.gemm_mode == "bf16x3" and os.environ.get("USFLOWS_AMD_SAVE_HIDDEN", "1") != "0" and 128 < hm <= 256
+                and B >= 1024 and self.hmax >= 256 and self.hmax % 4 == 0)
 
     def wgrad_from_planes(self, B: int, N: int, K: int) -> bool:
         """weight gradients of the training step from pre-split operand planes (usf_wgrad_planes_f32): in the bf16x3 mode,

@@ -579,11 +579,12 @@ class TrainPath:
         nl = len(un["layers"])
         act, slope = cp["act"], cp["slope"]
         # 1. hidden activations again (the conditioning half of the saved buffer is what the forward saw)
-        own = f"_{m['step']}" if self._defer else ""          # deferred gradient jobs read these after the layer loop
+        saved_fused = bool(m.get("hidden_saved_fused"))       # large batches: the fused forward kernel left them (engine.py)
+        own = f"_{m['step']}" if (self._defer or saved_fused) else ""   # deferred gradient jobs read these after the layer loop
         hbufs = [self._buf(ws, f"Hs{j}{own}", B, hmax) for j in range(nl)]
         src, src_off, src_ld, src_K = zbuf, cp["pass_off"], LD, cp["pass_n"]
         # (small batches: the forward plan left the hidden activations in exactly these buffers -- engine.py, `hidden_saved`)
-        recompute = not (self._defer and m.get("hidden_saved"))
+        recompute = not ((self._defer and m.get("hidden_saved")) or saved_fused)
         for j, (W, b) in enumerate(un["layers"] if recompute else []):
             kw = {}
             if j == 0 and m["use_ctx"]:
