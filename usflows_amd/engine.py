@@ -1093,7 +1093,9 @@ class FlowEngine:
     def wgrad_from_planes(self, B: int, N: int, K: int) -> bool:
         """weight gradients of the training step from pre-split operand planes (usf_wgrad_planes_f32): in the bf16x3 mode,
         where the kernel pays (its own cross-over), unless USFLOWS_AMD_WGRAD_PLANES=0"""
+        rows, wid = -(-B // 32) * 32, -(-max(N, K, self.LD, self.LDn) // 32) * 32
         return (self.gemm_mode == "bf16x3" and os.environ.get("USFLOWS_AMD_WGRAD_PLANES", "1") != "0"
+                and 3 * rows * wid * 2 < (1 << 31)          # the three planes of an operand stay below 2 GiB (32-bit offsets)
                 and _ext.wgrad_planes_ok(B, N, K))
 
     def _general_coupling_ops(self, ops, lin_op, pk, cp, ws, zptr, B, sign, device):
