@@ -159,6 +159,14 @@ typedef struct usf_coupling_desc {
    * above): a descriptor that sets hidden_out and is served by another kernel is rejected.  ld_hidden_out % 4 == 0,
    * 16-byte aligned bases. */
   float* hidden_out[USF_MAX_HIDDEN]; int64_t ld_hidden_out;
+  /* act == USF_ACT_GATE (ABI 32; bf16x3 kernel only, no context): hidden layer l's pre-activation is not passed through
+   * the nonlinearity but multiplied by (gate[l][m, j] > 0 ? 1 : slope), gate[l] [M, ld_gate] -- the conditioner's BACKWARD
+   * pass on the same kernel: with the transposed weights (W_in = W_out^T, W_hid reversed and transposed, W_out = W_in^T),
+   * zero biases, the column segments swapped (pass <-> trans) and gate[l] = the forward's saved activation of hidden layer
+   * n_hidden - 1 - l, the launch computes  g[:, pass] += sign * d_h1 W_in  from g[:, trans]  and hidden_out receives the
+   * gradients at the hidden activations (d_h of the last hidden layer first): what autograd derives for the MLP of
+   * MaskedCoupling (transforms.py:277-306, networks.py:739-751) in three GEMM launches + gates. */
+  const float* gate[USF_MAX_HIDDEN]; int64_t ld_gate;
 } usf_coupling_desc;
 
 int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream);

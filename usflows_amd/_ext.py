@@ -66,6 +66,7 @@ class CouplingDesc(C.Structure):
         ("split_hid", _fp * USF_MAX_HIDDEN), ("split_hid_ld", C.c_int64), ("split_hid_plane", C.c_int64),
         ("split_out", _fp), ("split_out_ld", C.c_int64), ("split_out_plane", C.c_int64),
         ("hidden_out", _fp * USF_MAX_HIDDEN), ("ld_hidden_out", C.c_int64),
+        ("gate", _fp * USF_MAX_HIDDEN), ("ld_gate", C.c_int64),
     ]
 
 
@@ -996,6 +997,11 @@ def affine_prep_bwd(save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dladj):
 def gather_cols(src, lds, dst, ldd, M, n, idx):
     check(load().usf_gather_cols_f32(src.data_ptr(), lds, dst.data_ptr(), ldd, M, n, idx.data_ptr(),
                                      current_stream(src.device)), "usf_gather_cols_f32")
+
+
+def coupling_op(op, device):
+    """one usf_coupling_additive_f32 launch from an Op built by the engine (its descriptor; taped like every launch)"""
+    _launch("usf_coupling_additive_f32", (C.byref(op.u.coupling), current_stream(device)), op)
 
 
 def run_ops(ops_array, n, device=None):

@@ -35,6 +35,7 @@ struct Cpl3Args {
   float sign, slope; int act;
   unsigned long long* dbg;              // tuning builds only (USF_STAMP)
   float* hsave[3]; int64_t ld_hs;       // usf_coupling_desc::hidden_out, or NULLs
+  const float* gate[3]; int64_t ld_gate; // act == USF_ACT_GATE: usf_coupling_desc::gate
 };
 
 __device__ __forceinline__ void c3_split3(const f32x4 x0, const f32x4 x1, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -255,7 +256,19 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
 
   C3STAMP(t1);
   const int rowc = min(wrow0 + lj, p.M - 1);
-  auto ctx_act = [&](f32x4 (&X)[T], bool with_ctx) {
+  auto ctx_act = [&](f32x4 (&X)[T], bool with_ctx, int layer) {
+    if (p.act == USF_ACT_GATE) {
+      // the conditioner's backward pass: the (Leaky)ReLU backward from the forward's saved output of the layer this
+      // gradient belongs to (lane (j, g): units 16 ht + 4 g .. + 3 of row j -- the layout save_hidden writes)
+      const float* G = p.gate[layer] + (int64_t)rowc * p.ld_gate + 4 * lg;
+#pragma unroll
+      for (int ht = 0; ht < T; ++ht) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(G + 16 * ht);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) X[ht][t] = gate_apply(X[ht][t], hv[t], p.slope);
+      }
+      return;
+    }
     const float cv = with_ctx ? p.ctx[rowc] : 0.f;
 #pragma unroll
     for (int ht = 0; ht < T; ++ht) {
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
       }
     }
   };
-  ctx_act(X1, p.ctx != nullptr);
+  ctx_act(X1, p.ctx != nullptr, 0);
   // training: the hidden activations go to HBM for the backward pass (lane (j, g) holds units 16 ht + 4 g .. + 3 of row j)
   auto save_hidden = [&](const f32x4 (&X)[T], float* H) {
     if (H == nullptr || wrow0 + lj >= p.M) return;
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(C3_NT, 2) void coupling_bf16x3_kernel(const Cpl3Arg
       __syncthreads();
       ++g;
     }
-    ctx_act(Xout, false);
+    ctx_act(Xout, false, l + 1);
   };
   if (NH >= 2) {
 #pragma unroll
@@ -434,6 +447,16 @@ int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   a.dbg = g_c3dbg;
 #endif
   for (int i = 0; i < 3; ++i) a.hsave[i] = (i < d->n_hidden) ? d->hidden_out[i] : nullptr;
+  for (int i = 0; i < 3; ++i) a.gate[i] = (i < d->n_hidden) ? d->gate[i] : nullptr;
+  a.ld_gate = d->ld_gate;
+  if (d->act == USF_ACT_GATE) {
+    for (int i = 0; i < d->n_hidden; ++i)
+      if (!d->gate[i] || !aligned16(d->gate[i])) { set_error("usf_coupling_additive_f32(bf16x3): USF_ACT_GATE needs gate[l] for every hidden layer (16-byte aligned)"); return -2; }
+    if (d->ld_gate < C3_HMAX || (d->ld_gate & 3) || d->context) {
+      set_error("usf_coupling_additive_f32(bf16x3): USF_ACT_GATE needs ld_gate >= 256, a multiple of 4, and no context");
+      return -2;
+    }
+  }
   a.ld_hs = d->ld_hidden_out;
   if (d->hidden_out[0] && (d->ld_hidden_out < C3_HMAX || (d->ld_hidden_out & 3) || !aligned16(d->hidden_out[0]))) {
     set_error("usf_coupling_additive_f32(bf16x3): hidden_out needs ld_hidden_out >= 256, a multiple of 4, 16-byte aligned bases");

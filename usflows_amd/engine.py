@@ -536,17 +536,19 @@ class FlowEngine:
         t[: idx.numel()] = idx
         return t.to(device)
 
-    def _packed(self, src, out_sel, n_out, in_sel, n_in, planes_sel=None, planes_ld=0, want_w=True):
-        """(W [n_out, n_in] fp32 | None, planes [3, n_out, planes_ld] bf16 | None) from a raw parameter"""
+    def _packed(self, src, out_sel, n_out, in_sel, n_in, planes_sel=None, planes_ld=0, want_w=True, transpose=False):
+        """(W [n_out, n_in] fp32 | None, planes [3, n_out, planes_ld] bf16 | None) from a raw parameter; transpose: the
+        image of src^T (out_sel picks columns of src, in_sel rows)"""
         dev = src.device
         W = torch.empty(n_out, n_in, dtype=torch.float32, device=dev) if want_w else None
+        kw = dict(transpose=True) if transpose else {}
         if W is not None:
-            _ext.pack_weight(src, out_sel, n_out, in_sel, n_in, W=W, ldw=n_in)
+            _ext.pack_weight(src, out_sel, n_out, in_sel, n_in, W=W, ldw=n_in, **kw)
         planes = None
         if planes_ld:
             planes = torch.empty(3, n_out, planes_ld, dtype=torch.bfloat16, device=dev)
             _ext.pack_weight(src, out_sel, n_out, in_sel if planes_sel is None else planes_sel,
-                             min(n_in, planes_ld) if planes_sel is None else int(planes_sel.numel()), planes=planes)
+                             min(n_in, planes_ld) if planes_sel is None else int(planes_sel.numel()), planes=planes, **kw)
         return W, planes
 
     def _packed_vec(self, src, sel, n) -> torch.Tensor:
@@ -1088,7 +1090,8 @@ class FlowEngine:
         that kernel serves the layer (hidden width in (128, 256], >= 1024 rows), unless USFLOWS_AMD_SAVE_HIDDEN=0"""
         hm = max(cp["hidden"])
         return (self.gemm_mode == "bf16x3" and os.environ.get("USFLOWS_AMD_SAVE_HIDDEN", "1") != "0" and 128 < hm <= 256
-                and B >= 1024 and self.hmax >= 256 and self.hmax % 4 == 0)
+                and B >= 1024 and self.hmax >= 256 and self.hmax % 4 == 0
+                and cp["tr_n"] % 4 == 0 and cp["tr_off"] % 4 == 0)      # (the backward launch reads the transformed half as its input)
 
     def wgrad_from_planes(self, B: int, N: int, K: int) -> bool:
         """weight gradients of the training step from pre-split operand planes (usf_wgrad_planes_f32): in the bf16x3 mode,
@@ -1490,6 +1493,75 @@ class FlowEngine:
             f["b_ctx"] = self._packed_vec(bc, rows0, Hp)
         cp["fused"] = f
         return f
+
+    def _fused_pack_bwd(self, pk, cp) -> dict:
+        """the conditioner's weights transposed and re-laid out for the fused kernel run BACKWARDS (usf_coupling_desc::gate):
+        W_in = W_last^T [hidden, trans], hidden matrices reversed and transposed, W_out = W_first^T [pass, hidden], zero biases"""
+        if "fused_bwd" in cp:
+            return cp["fused_bwd"]
+        lib = _ext.load()
+        raw = cp["raw"]
+        dev, h = raw["device"], raw["h"]
+        Hp = lib.usf_coupling_padded_width(max(cp["hidden"]))
+        Kp, Np = _round_up(cp["tr_n"], 32), _round_up(cp["pass_n"], 32)      # the roles of the column segments swap
+        tr_sel, pass_sel = self._sel(raw["tr_idx"], Kp, dev), self._sel(raw["pass_idx"], Np, dev)
+
+        def kperm(n_valid):
+            g, j = torch.arange(4)[:, None], torch.arange(8)[None, :]
+            within = torch.where(j < 4, 4 * g + j, 16 + 4 * g + (j - 4)).reshape(-1)
+            perm = (torch.arange(0, Hp, 32)[:, None] + within[None, :]).reshape(-1)
+            return torch.where(perm < n_valid, perm, torch.full_like(perm, -1)).to(device=dev, dtype=torch.int32)
+
+        with self._pk_record(pk):
+            zeros = torch.zeros(max(Hp, Np), dtype=torch.float32, device=dev)
+            W, _b = raw["last"]                                   # [features, h_last]
+            W_in, P_in = self._packed(W, self._iarange(h[-1], Hp, dev), Hp, tr_sel, Kp, planes_ld=Kp, transpose=True)
+            f = dict(Hp=Hp, W_in=W_in, zeros=zeros, hid=[], split=dict(hid=[]))
+            f["split"]["in"] = P_in
+            for j in range(len(raw["hidden"]) - 1, -1, -1):       # hidden matrix j maps layer j -> j + 1: backwards j + 1 -> j
+                W, _b = raw["hidden"][j]                          # [h_{j+1}, h_j]
+                Wp, P = self._packed(W, self._iarange(h[j], Hp, dev), Hp, self._iarange(h[j + 1], Hp, dev), Hp,
+                                     planes_sel=kperm(h[j + 1]), planes_ld=Hp, transpose=True)
+                f["hid"].append(Wp)
+                f["split"]["hid"].append(P)
+            W, _b = raw["first"]                                  # [h_0, features]
+            f["W_out"], f["split"]["out"] = self._packed(W, pass_sel, Np, self._iarange(h[0], Hp, dev), Hp,
+                                                         planes_sel=kperm(h[0]), planes_ld=Hp, transpose=True)
+        cp["fused_bwd"] = f
+        return f
+
+    def coupling_backward_op(self, pk, cp, gptr, ld, B, sign, gates, d_out, act=_ext.ACT_GATE) -> _ext.Op:
+        """ONE launch for the data-gradient chain of a coupling layer's conditioner: g[:, pass] += sign * MLP^T(g[:, trans]) with
+        the (Leaky)ReLU backward from the saved activations `gates` (layer order of the forward); d_out[l] receives the gradient
+        at hidden activation l (forward order)"""
+        f = self._fused_pack_bwd(pk, cp)
+        nl = len(cp["hidden"])
+        op = _ext.Op()
+        op.kind = _ext.OP_COUPLING
+        d = op.u.coupling
+        d.z, d.ldz, d.out, d.ldo, d.M = gptr, ld, gptr, ld, B
+        d.off_pass, d.n_pass, d.off_trans, d.n_trans = cp["tr_off"], cp["tr_n"], cp["pass_off"], cp["pass_n"]
+        d.n_hidden = nl
+        for j in range(nl):
+            d.hidden[j] = cp["hidden"][nl - 1 - j]
+            d.gate[j] = gates[nl - 1 - j].data_ptr()
+            d.hidden_out[j] = d_out[nl - 1 - j].data_ptr()
+        d.ld_gate = gates[0].shape[1]
+        d.ld_hidden_out = d_out[0].shape[1]
+        z = f["zeros"].data_ptr()
+        d.W_in, d.ldw_in, d.b_in = f["W_in"].data_ptr(), f["W_in"].shape[1], z
+        for j, W in enumerate(f["hid"]):
+            d.W_hid[j], d.b_hid[j], d.ldw_hid[j] = W.data_ptr(), z, W.shape[1]
+        d.W_out, d.ldw_out, d.b_out = f["W_out"].data_ptr(), f["W_out"].shape[1], z
+        d.sign, d.slope, d.act = sign, cp["slope"], act
+        s3 = f["split"]
+        d.split_in, d.split_in_ld, d.split_in_plane = s3["in"].data_ptr(), s3["in"].shape[2], s3["in"].shape[1] * s3["in"].shape[2]
+        for j, P in enumerate(s3["hid"]):
+            d.split_hid[j] = P.data_ptr()
+        if s3["hid"]:
+            d.split_hid_ld, d.split_hid_plane = s3["hid"][0].shape[2], s3["hid"][0].shape[1] * s3["hid"][0].shape[2]
+        d.split_out, d.split_out_ld, d.split_out_plane = s3["out"].data_ptr(), s3["out"].shape[2], s3["out"].shape[1] * s3["out"].shape[2]
+        return op
 
     def _coupling_op(self, cp, zptr, B, sign, ws_ctx) -> _ext.Op:
         f = self._fused_pack(cp)

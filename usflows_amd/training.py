@@ -454,6 +454,9 @@ class TrainPath:
             with _ext.batch_jobs(dev):
                 for m in plan["meta"]:
                     if m["kind"] == "coupling":
+                        if self._fused_cbwd(m, plan["ws"]["zA"].shape[0]):
+                            eng._fused_pack_bwd(pk, pk["coupling"][m["step"]])      # the transposed set of the fused kernel
+                            continue
                         un = eng._unfused_pack(pk, pk["coupling"][m["step"]])
                         for W, _b in un["layers"]:
                             self._transposed(pk, W)
@@ -461,6 +464,12 @@ class TrainPath:
                     elif m is not first_meta:
                         which = "Minv" if m["prim"] == "affine_bwd" else "M"
                         self._mat_t(pk, m["blk"], which, m["out_layout"], m["in_layout"])
+
+    def _fused_cbwd(self, m, B) -> bool:
+        """the data-gradient chain of this coupling layer's conditioner as ONE launch of the fused kernel (engine.
+        coupling_backward_op): where the forward ran fused and left its hidden activations, unless USFLOWS_AMD_FUSED_CBWD=0"""
+        return (bool(m.get("hidden_saved_fused")) and not (bool(self.defer_small_grads) and 0 < B <= _ext.GRAD_JOB_MAX_ROWS)
+                and os.environ.get("USFLOWS_AMD_FUSED_CBWD", "1") != "0")
 
     def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
         """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every affine
@@ -597,6 +606,14 @@ class TrainPath:
         has_ctx = isinstance(cond, ConditionalDenseNN)
         first_l, last_l = lin[0], lin[-1]
         hidden_l = lin[2:-1] if has_ctx else lin[1:-1]
+        fused_bwd = self._fused_cbwd(m, B)
+        if fused_bwd:
+            # ONE launch: g_P += s * MLP^T(g_T) with the (Leaky)ReLU backward from the saved activations; the gradients at the
+            # hidden activations land in Dh{j} for the weight gradients below
+            dh = [self._buf(ws, f"DhF{j}", B, hmax) for j in range(nl)]
+            op = eng.coupling_backward_op(pk, cp, g_cur.data_ptr(), g_ld, B, sign, hbufs, dh,
+                                          act=_ext.ACT_GATE if act != _ext.ACT_NONE else _ext.ACT_NONE)
+            _ext.coupling_op(op, dev)
         # 2. output layer: d_out = gradient at the transformed half (unchanged by the layer: out_T = z_T + s MLP)
         tr_n, tr_off = cp["tr_n"], cp["tr_off"]
         W_out = un["W_out"]                                   # [tr_n, hp_last]
@@ -621,11 +638,14 @@ class TrainPath:
         else:
             d_bufs = [self._buf(ws, "Dh0", B, hmax), self._buf(ws, "Dh1", B, hmax)]
             d_of = lambda j: d_bufs[(nl - 1 - j) & 1]             # noqa: E731
-        Wt = self._transposed(pk, W_out)                      # [hp_last, tr_n4]
+        if fused_bwd:
+            d_of = lambda j: dh[j]                                # noqa: E731
         d = d_of(nl - 1)
         # (the (Leaky)ReLU backward from the saved layer output rides in the GEMM's epilogue: USF_ACT_GATE)
         gate = lambda hbuf: dict(act=_ext.ACT_GATE, slope=slope, addend=hbuf, ldadd=hmax) if act != _ext.ACT_NONE else {}
-        self._linear(pk, g_cur, tr_off, g_ld, Wt, d, 0, hmax, B, hp[-1], Wt.shape[1], **gate(hbufs[-1]))
+        if not fused_bwd:
+            Wt = self._transposed(pk, W_out)                  # [hp_last, tr_n4]
+            self._linear(pk, g_cur, tr_off, g_ld, Wt, d, 0, hmax, B, hp[-1], Wt.shape[1], **gate(hbufs[-1]))
         # 3. hidden layers, last to first
         for j in range(nl - 1, 0, -1):
             W, _b = un["layers"][j]                           # [hp_j, hp_{j-1}]
@@ -638,7 +658,8 @@ class TrainPath:
             if gbias is None:
                 self._colsum_to(grads, l.bias, d, B, h[j], hmax, sign)
             d_next = d_of(j - 1)
-            self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j], **gate(hbufs[j - 1]))
+            if not fused_bwd:
+                self._linear(pk, d, 0, hmax, self._transposed(pk, W), d_next, 0, hmax, B, hp[j - 1], hp[j], **gate(hbufs[j - 1]))
             d = d_next
         # 4. input layer
         W_in, _b = un["layers"][0]                            # [hp0, pass_n]
@@ -658,6 +679,8 @@ class TrainPath:
                 self._scatter_weight(grads, ctx_l.weight, gW, None, h[0], None, 1)
                 self._colsum_to(grads, ctx_l.bias, d, B, h[0], hmax, sign)
         # conditioning half of the gradient: g_P += s * d W_in   (in place)
+        if fused_bwd:
+            return                     # (the fused launch above already updated the conditioning half)
         if self._g_pending:
             _ext.flush_jobs()          # the coupling layer before this one queued reads of columns this update rewrites
         self._linear(pk, d, 0, hmax, self._transposed(pk, W_in), g_cur, pass_off, g_ld, B, pass_n, hp[0],
