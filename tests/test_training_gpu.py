@@ -280,16 +280,25 @@ def test_failed_capture_of_a_training_step_is_recoverable(monkeypatch):
     assert torch.allclose(lp_brk, lp_ref, rtol=1e-6, atol=1e-5)
 
 
-def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch):
+@pytest.mark.parametrize("variant", ["plain", "conj8", "ctx"])
+def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch, variant):
     """From 8192 rows the affine layers' GEMMs leave the bf16 planes of their operands (usf_linear_desc::A_planes_out) and the
     weight gradients multiply those (usf_wgrad_planes_f32); bias gradients ride in the weight-gradient passes; from 1024 rows
     the fused coupling kernel stores its hidden activations (hidden_out) and the conditioner's data-gradient chain is ONE
     launch of the same kernel run backwards (USF_ACT_GATE).  Same products, other orders of summation: every parameter
-    gradient within 1e-5 of the path with all four switched off, which the tests above pin against the oracle and the
+    gradient within 1e-4 of its largest entry of the path with all four switched off, which the tests above pin against the oracle and the
     reference's goldens -- each switch on its own, then all together."""
     from usflows_amd import _ext
     spec, sd, _a = load_case("synth_d784_k32_cfg2")
+    n_cpl = 32
+    if variant == "conj8":                                      # affine_conjugation: every block also in its M form (what the live configs use)
+        import copy
+        from usflows_amd.synth import synth_state_dict
+        spec = copy.copy(spec)
+        spec.affine_conjugation, spec.coupling_blocks, n_cpl = True, 8, 8
+        sd = synth_state_dict(spec, seed=100, alpha=0.1)
     x = torch.rand(16400, 784, generator=torch.Generator().manual_seed(3)).to(DEV)       # ragged (16400 = 512 x 32 + 16), above the fused coupling kernel's cross-over
+    ctx = torch.rand(16400, 1, generator=torch.Generator().manual_seed(4)).to(DEV) if variant == "ctx" else None   # soft-training context branch
     calls = []
     real = _ext.wgrad_planes
     monkeypatch.setattr(_ext, "wgrad_planes", lambda *a, **k: (calls.append(k["N"]), real(*a, **k))[1])
@@ -305,17 +314,17 @@ def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch):
         for _ in range(2):                                      # the second pass replays the recorded launches
             for p in flow.parameters():
                 p.grad = None
-            lp = flow.log_prob(x)
+            lp = flow.log_prob(x, ctx)
             (-lp.mean()).backward()
         torch.cuda.synchronize()
         return {n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None}, calls[n0:], lp.detach()
 
     base, c0, lp0 = grads_with(())
-    assert not c0 and len(base) > 100
-    for on in (switches[:1], switches[1:2], switches[2:3], switches[2:], switches):
+    assert not c0 and len(base) > (100 if variant != "conj8" else 25)
+    for on in ((switches[:1], switches[1:2], switches[2:3], switches[2:], switches) if variant == "plain" else (switches,)):
         got, c, lp = grads_with(on)
-        assert (c.count(784) >= 31) == (switches[0] in on)      # every affine layer behind the first one
-        assert (c.count("cbwd") == 32) == (switches[3] in on)   # one backward launch per coupling layer
+        assert (c.count(784) >= (31 if variant != "conj8" else 15)) == (switches[0] in on)   # every affine layer behind the first one
+        assert (c.count("cbwd") == n_cpl) == (switches[3] in on)                              # one backward launch per coupling layer
         assert torch.equal(lp, lp0)                             # the forward values do not depend on any of them
         assert got.keys() == base.keys()
         for n in base:
@@ -324,6 +333,6 @@ def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch):
             # changing one sample's contribution to a few entries; see _compare's kink_frac)
             big = base[n].abs().max().item()
             diff = (base[n] - got[n]).abs()
-            n_bad = int((diff > 1e-5 * big + 1e-12).sum().item())
+            n_bad = int((diff > 1e-4 * big + 1e-12).sum().item())       # (other orders of summation over 16 400 rows: fp32 noise of cancelling sums)
             assert n_bad <= max(2, int(1e-3 * diff.numel())), (on, n, n_bad, diff.numel())
             assert diff.max().item() <= 1e-3 * big + 1e-12, (on, n, diff.max().item(), big)
