@@ -425,3 +425,30 @@ def test_gated_norm_rows_rejects_bad_args():
         ext.gated_norm_rows(x, M=4, C_cols=8, ld_skip=8, out=x, ld_out=8, gamma=x)          # gamma without beta
     with pytest.raises(RuntimeError):
         ext.gated_norm_rows(x, M=4, C_cols=5000, c_pad=5000, ld_skip=5000, out=x, ld_out=5000)
+
+
+def test_coupling_hidden_out_and_gate_need_the_bf16x3_kernel():
+    DEV = "cuda:0"
+    """usf_coupling_desc::hidden_out / USF_ACT_GATE: served by the split-precision kernel only -- a descriptor that another
+    kernel would serve is rejected, not silently run without the side output"""
+    from usflows_amd import _ext
+    lib = _ext.load()
+    d = _ext.CouplingDesc()
+    M, n = 2048, 64
+    z = torch.zeros(M, 2 * n, device=DEV)
+    W = torch.zeros(256, 256, device=DEV)
+    b = torch.zeros(256, device=DEV)
+    H = torch.zeros(M, 256, device=DEV)
+    d.z = d.out = z.data_ptr(); d.ldz = d.ldo = 2 * n; d.M = M
+    d.off_pass, d.n_pass, d.off_trans, d.n_trans = 0, n, n, n
+    d.n_hidden = 1; d.hidden[0] = 256
+    d.W_in, d.ldw_in, d.b_in = W.data_ptr(), 256, b.data_ptr()
+    d.W_out, d.ldw_out, d.b_out = W.data_ptr(), 256, b.data_ptr()
+    d.sign, d.slope, d.act = 1.0, 0.01, _ext.ACT_LEAKY_RELU
+    d.hidden_out[0], d.ld_hidden_out = H.data_ptr(), 256          # no split planes given: the exact-f32 kernel would serve it
+    import ctypes as C
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.usf_coupling_additive_f32(C.byref(d), st) == -2 and b"bf16x3 kernel only" in lib.usf_last_error()
+    d.hidden_out[0] = None
+    d.act = _ext.ACT_GATE
+    assert lib.usf_coupling_additive_f32(C.byref(d), st) == -2 and b"bf16x3 kernel only" in lib.usf_last_error()

@@ -315,3 +315,25 @@ def test_linear_planes_out_rejects_a_prologue():
     with pytest.raises(RuntimeError, match="pre_div"):
         ext.linear(A, W, Cc, M=128, N=96, K=64, lda=64, ldw=64, ldc=96, pre_sub=torch.zeros(64, device=DEV),
                    planes_out=ext.row_planes(128, 64, DEV))
+
+
+def test_planes_entry_points_reject_what_they_cannot_serve():
+    """loud errors, no silent fall-backs: misaligned planes, a workspace that is too small, column sums where no
+    instantiation carries them, the bias-fused call where the loader-wave kernel is not chosen"""
+    ext = _ext()
+    lib = ext.load()
+    M, N, K = 8192, 256, 256
+    Yp, Ap = ext.row_planes(M, N, DEV), ext.row_planes(M, K, DEV)
+    G = torch.empty(N, K, device=DEV)
+    ws = torch.empty(16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    args = lambda yp=Yp, y_off=0, wsf=ws.numel(), cs=None, k=K: (
+        yp.data_ptr(), yp.shape[2], yp.shape[1] * yp.shape[2], y_off, Ap.data_ptr(), Ap.shape[2], Ap.shape[1] * Ap.shape[2], 0,
+        M, N, k, G.data_ptr(), K, 1.0, 0.0, cs, 1.0, 0.0, ws.data_ptr(), wsf, st)
+    assert lib.usf_wgrad_planes_f32(*args()) == -4 and b"workspace" in lib.usf_last_error()
+    assert lib.usf_wgrad_planes_f32(*args(yp=ext.row_planes(M, N + 32, DEV), y_off=4, wsf=1 << 30)) == -3   # column offsets in units of 8
+    assert lib.usf_wgrad_planes_f32(*args(cs=G.data_ptr(), k=40)) == -2 and b"colsum_out" in lib.usf_last_error()
+    A32, Y32 = torch.empty(4096, K, device=DEV), torch.empty(4096, N, device=DEV)
+    with pytest.raises(RuntimeError, match="usf_wgrad_bias_ok"):            # 4096 rows: not the loader-wave kernel
+        ext.wgrad(Y32, A32, G, M=4096, N=N, K=K, ldy=N, lda=K, ldg=K, mode=1, colsum=torch.empty(N, device=DEV))
+    assert lib.usf_split_planes_f32(Y32.data_ptr(), N, 4096, N, Yp.data_ptr() + 2, Yp.shape[2], Yp.shape[1] * Yp.shape[2], st) == -1
