@@ -19,12 +19,12 @@ int main(int argc, char** argv) {
 #ifdef USF_STAMP
   unsigned long long* dbg; hipMalloc(&dbg, 1024 * 12 * 4 * 8); hipMemset(dbg, 0, 1024 * 12 * 4 * 8); usf::g_wdbg = dbg;
 #endif
-  for (int i = 0; i < 3; ++i) if (usf::wgrad(Y, N, A, K, M, N, K, G, K, 1.f, 0.f, 1, ws, wsf, 0)) return 1;
+  for (int i = 0; i < 3; ++i) if (usf::wgrad(Y, N, A, K, M, N, K, G, K, 1.f, 0.f, 1, ws, wsf, 0, nullptr, 0.f, 0.f)) return 1;
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel fault\n"); return 2; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
   const int it = 20;
-  for (int i = 0; i < it; ++i) usf::wgrad(Y, N, A, K, M, N, K, G, K, 1.f, 0.f, 1, ws, wsf, 0);
+  for (int i = 0; i < it; ++i) usf::wgrad(Y, N, A, K, M, N, K, G, K, 1.f, 0.f, 1, ws, wsf, 0, nullptr, 0.f, 0.f);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
   printf("wgrad M=%lld N=%lld K=%lld: %.3f ms  %.1f TF/s fp32-equivalent\n", (long long)M, (long long)N, (long long)K, ms, 2.0 * M * N * K / ms / 1e9);

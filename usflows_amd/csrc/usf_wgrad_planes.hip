@@ -174,6 +174,9 @@ __device__ __forceinline__ void wp_mfma_loop(WpShared& sh, f32x4 (&acc)[5][5], i
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
+#ifdef USF_WP_X_SKIP5                           // tuning build (wrong results): the wide tiles without their fifth fragment's products
+        if (i == 4 || j == 4) continue;
+#endif
         USF_WP(2, 0); USF_WP(1, 1); USF_WP(0, 2); USF_WP(1, 0); USF_WP(0, 1); USF_WP(0, 0);   // smallest terms first (wgrad_lw_kernel's order)
         if (CS && j == 0) {
 #pragma unroll
