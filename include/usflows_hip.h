@@ -706,9 +706,10 @@ int usf_wgrad_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int6
 int64_t usf_wgrad_workspace_floats(int64_t M, int64_t N, int64_t K);
 int usf_wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode);
 /* usf_wgrad_f32 and the layer's bias gradient in one pass (ABI 32): colsum_out[n] = cs_alpha * sum_m Y[m,n] + cs_beta *
- * colsum_out[n] (what usf_colsum_f32 computes), from the operand fragments the loader-wave kernel holds anyway -- three more
+ * colsum_out[n] (what usf_colsum_f32 computes), from the operand fragments the bf16x3 kernels hold anyway -- three more
  * MFMAs per fragment row against an operand of ones in the blocks of tile column 0; partial sums in a fixed order.  Only
- * where usf_wgrad_bias_ok says 1 (usf_wgrad_variant == 2 and K >= 64); the same workspace as usf_wgrad_f32. */
+ * where usf_wgrad_bias_ok says 1 (usf_wgrad_variant >= 1, i.e. mode 1 from 2048 rows, and K >= 64); the same workspace
+ * as usf_wgrad_f32. */
 int usf_wgrad_bias_f32(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
                        int64_t ldg, float alpha, float beta, int32_t mode, float* colsum_out, float cs_alpha, float cs_beta,
                        float* workspace, int64_t workspace_floats, usf_stream_t stream);

@@ -45,7 +45,7 @@ def test_wgrad_matches_fp64(M, N, K, mode):
     assert torch.equal(got[:, K:], G0[:, K:])                 # padding columns of G untouched
 
 
-@pytest.mark.parametrize("M,N,K", [(8200, 784, 784), (33001, 130, 260), (21000, 392, 256), (65536, 256, 392)])
+@pytest.mark.parametrize("M,N,K", [(8200, 784, 784), (33001, 130, 260), (21000, 392, 256), (65536, 256, 392), (4096, 784, 784), (2500, 392, 256)])
 def test_wgrad_bias_adds_the_column_sums_without_changing_the_gradient(M, N, K):
     """usf_wgrad_bias_f32: the weight gradient has the bits of usf_wgrad_f32, the column sums are those of usf_colsum_f32
     within fp32 summation-order noise, both reproducible"""
@@ -54,7 +54,7 @@ def test_wgrad_bias_adds_the_column_sums_without_changing_the_gradient(M, N, K):
     ldy, lda = (N + 3) // 4 * 4 + 4, (K + 3) // 4 * 4 + 8
     Y, A = torch.randn(M, ldy, generator=g).to(DEV), torch.randn(M, lda, generator=g).to(DEV)
     assert ext.wgrad_bias_ok(M, N, K, ldy, lda, 1) and not ext.wgrad_bias_ok(M, N, K, ldy, lda, 0)
-    assert not ext.wgrad_bias_ok(4096, N, K, ldy, lda, 1)
+    assert not ext.wgrad_bias_ok(1000, N, K, ldy, lda, 1)             # below 2048 rows mode 1 runs the exact-f32 kernel
     G0, G1, G2 = (torch.empty(N, K, device=DEV) for _ in range(3))
     ext.wgrad(Y, A, G0, M=M, N=N, K=K, ldy=ldy, lda=lda, ldg=K, alpha=0.5, mode=1)
     cs1, cs2 = torch.full((N,), 2.0, device=DEV), torch.full((N,), 2.0, device=DEV)
@@ -319,7 +319,7 @@ def test_linear_planes_out_rejects_a_prologue():
 
 def test_planes_entry_points_reject_what_they_cannot_serve():
     """loud errors, no silent fall-backs: misaligned planes, a workspace that is too small, column sums where no
-    instantiation carries them, the bias-fused call where the loader-wave kernel is not chosen"""
+    instantiation carries them, the bias-fused call where no bf16x3 kernel is chosen"""
     ext = _ext()
     lib = ext.load()
     M, N, K = 8192, 256, 256
@@ -334,6 +334,6 @@ def test_planes_entry_points_reject_what_they_cannot_serve():
     assert lib.usf_wgrad_planes_f32(*args(yp=ext.row_planes(M, N + 32, DEV), y_off=4, wsf=1 << 30)) == -3   # column offsets in units of 8
     assert lib.usf_wgrad_planes_f32(*args(cs=G.data_ptr(), k=40)) == -2 and b"colsum_out" in lib.usf_last_error()
     A32, Y32 = torch.empty(4096, K, device=DEV), torch.empty(4096, N, device=DEV)
-    with pytest.raises(RuntimeError, match="usf_wgrad_bias_ok"):            # 4096 rows: not the loader-wave kernel
-        ext.wgrad(Y32, A32, G, M=4096, N=N, K=K, ldy=N, lda=K, ldg=K, mode=1, colsum=torch.empty(N, device=DEV))
+    with pytest.raises(RuntimeError, match="usf_wgrad_bias_ok"):            # 1024 rows: the exact-f32 kernel carries no column sums
+        ext.wgrad(Y32, A32, G, M=1024, N=N, K=K, ldy=N, lda=K, ldg=K, mode=1, colsum=torch.empty(N, device=DEV))
     assert lib.usf_split_planes_f32(Y32.data_ptr(), N, 4096, N, Yp.data_ptr() + 2, Yp.shape[2], Yp.shape[1] * Yp.shape[2], st) == -1

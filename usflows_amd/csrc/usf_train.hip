@@ -304,6 +304,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
       dstp[2][rg][4 * cg + q] = p3;
     }
   };
+  // usf_wgrad_bias_f32: the waves of tile column 0 also sum their Y fragments over the batch (three MFMAs per fragment row
+  // against an operand of ones: every column of the 16 x 16 result is the column sum)
+  const bool do_cs = a.cs_part != nullptr && k0 == 0 && wk == 0;      // wave-uniform
+  f32x4 cs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   if (m_begin < m_end) fetch(m_begin);
   for (int m0 = m_begin; m0 < m_end; m0 += WB_S) {
     __syncthreads();                       // the previous slab's fragment reads are done
@@ -315,6 +324,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) yp[t][pl] = Yp[pl][lg][wn * 64 + t * 16 + li];
+    if (do_cs) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < ni) {
+#pragma unroll
+          for (int pl = 2; pl >= 0; --pl) cs[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yp[t][pl], ones, cs[t], 0, 0, 0);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (j >= nj) break;
@@ -350,6 +367,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgradArgs a) {
           }
         }
       }
+  if (do_cs && (lane & 15) == 0) {
+    float* co = a.cs_part + (int64_t)split * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (n < a.N && i < ni) co[n] = cs[i][r];
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -789,16 +816,16 @@ int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int
   return (mode == 1 && M >= 2048) ? 1 : 0;
 }
 
-// usf_wgrad_bias_f32: where the loader-wave kernel runs and K >= 64 the column sums of Y ride along
+// usf_wgrad_bias_f32: where a bf16x3 kernel runs (mode 1 from 2048 rows) and K >= 64 the column sums of Y ride along
 int wgrad_bias_ok(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
-  return (wgrad_variant(M, N, K, ldy, lda, mode) == 2 && K >= 64) ? 1 : 0;
+  return (wgrad_variant(M, N, K, ldy, lda, mode) >= 1 && K >= 64) ? 1 : 0;     // either bf16x3 kernel
 }
 
 int wgrad(const float* Y, int64_t ldy, const float* A, int64_t lda, int64_t M, int64_t N, int64_t K, float* G,
           int64_t ldg, float alpha, float beta, int32_t mode, float* workspace, int64_t workspace_floats,
           hipStream_t stream, float* colsum_out, float cs_alpha, float cs_beta) {
   if (colsum_out && !wgrad_bias_ok(M, N, K, ldy, lda, mode)) {
-    set_error("usf_wgrad_bias_f32: the column sums need the loader-wave kernel and K >= 64 (usf_wgrad_bias_ok)");
+    set_error("usf_wgrad_bias_f32: the column sums need a bf16x3 kernel (mode 1, M >= 2048) and K >= 64 (usf_wgrad_bias_ok)");
     return -2;
   }
   if (((!Y || !A) && M > 0) || !G || !workspace || M < 0 || N <= 0 || K <= 0 || ldg < K || ldy < N || lda < K) {
