@@ -1041,7 +1041,9 @@ class FlowEngine:
                 # training at small batches: every hidden layer of every coupling keeps a buffer of its own -- the backward
                 # pass reads the activations from there instead of running the conditioner a second time (2 launches per
                 # coupling of a step that is bound by the number of its launches; training.py names the same buffers)
-                save_h = train and 0 < B <= _ext.GRAD_JOB_MAX_ROWS
+                # (round 4: at every training batch, not only the small ones -- the activations land in per-layer buffers instead of
+                # the shared pair at no cost to the forward; USFLOWS_AMD_SAVE_HIDDEN=0: only up to GRAD_JOB_MAX_ROWS rows as before)
+                save_h = train and B > 0 and (B <= _ext.GRAD_JOB_MAX_ROWS or os.environ.get("USFLOWS_AMD_SAVE_HIDDEN", "1") != "0")
                 meta[-1]["hidden_saved"] = save_h
                 src_ptr, src_ld, src_K = zptr + 4 * cp["pass_off"], self.LD, cp["pass_n"]
                 for j, (W, b) in enumerate(un["layers"]):

@@ -589,11 +589,12 @@ class TrainPath:
         act, slope = cp["act"], cp["slope"]
         # 1. hidden activations again (the conditioning half of the saved buffer is what the forward saw)
         saved_fused = bool(m.get("hidden_saved_fused"))       # large batches: the fused forward kernel left them (engine.py)
-        own = f"_{m['step']}" if (self._defer or saved_fused) else ""   # deferred gradient jobs read these after the layer loop
+        saved = saved_fused or bool(m.get("hidden_saved"))    # ... or the unfused forward's GEMMs wrote them into the layer's own buffers
+        own = f"_{m['step']}" if (self._defer or saved) else ""         # deferred gradient jobs read these after the layer loop
         hbufs = [self._buf(ws, f"Hs{j}{own}", B, hmax) for j in range(nl)]
         src, src_off, src_ld, src_K = zbuf, cp["pass_off"], LD, cp["pass_n"]
         # (small batches: the forward plan left the hidden activations in exactly these buffers -- engine.py, `hidden_saved`)
-        recompute = not ((self._defer and m.get("hidden_saved")) or saved_fused)
+        recompute = not saved
         for j, (W, b) in enumerate(un["layers"] if recompute else []):
             kw = {}
             if j == 0 and m["use_ctx"]:
