@@ -196,7 +196,9 @@ def test_cfg4_full_size(cfg4, mode):
     got = lp[idx.to(DEV)]
     assert _rel(got, a["log_prob64"]) < RTOL
     assert _rel(got, a["log_prob32"]) < 2 * RTOL        # (the reference's own fp32-vs-fp64 gap at this depth: see fixture log)
-    z = _properties(flow, xd, lp, ladj, rt_tol=4e-3 if mode == "f16x2" else 1e-3)
+    # (round trip through 97 fp32 layers of 3072 columns: 8.8e-4 in the runs this was written on, 1.1e-3 once on another
+    # box of the pool -- a property of the fp32 chain, not a parity bound: parity is the golden rows above and below)
+    z = _properties(flow, xd, lp, ladj, rt_tol=4e-3 if mode == "f16x2" else 2e-3)
     s = max(1.0, a["backward64"].abs().max().item())
     assert (z[idx.to(DEV)].cpu().double() - a["backward64"]).abs().max().item() < 2e-5 * s
     with torch.no_grad():
