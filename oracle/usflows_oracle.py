@@ -176,8 +176,13 @@ class _AffineParams:
         return b
 
     def ladj(self):
-        parts = self._parts()
-        return sum(p[3] for p in parts)                          # transforms.py:1444-1446
+        # transforms.py:1444-1446: the sum of the sub-transforms' log-dets -- LUTransform: lu_ladj(U) (:1303-1320), Householder: 0
+        # (:760).  (Not through _parts(): the matrices and their inverses are not needed for it -- 49 fp64 inverses of 3072 x 3072
+        # at cfg4 size.)
+        sd, p, spec = self.sd, self.prefix, self.spec
+        if not self.sequential:
+            return lu_ladj(sd[p + "U_raw"])
+        return sum(lu_ladj(sd[f"{p}transforms.{j}.U_raw"]) for j in range(spec.lu_transform))
 
     # BlockAffineTransform for rank-1 in_dims: F.linear (transforms.py:904-934, 936-962)
     def forward(self, x):
