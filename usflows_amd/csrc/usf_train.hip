@@ -5,13 +5,17 @@
 //                (BlockAffineTransform transforms.py:913-962, conditioner Linear layers networks.py:739-751):
 //                a GEMM whose reduction runs over the BATCH, exact-f32 MFMA (v_mfma_f32_16x16x4_f32), split over
 //                row ranges into partials + a deterministic reduction (no atomics: bitwise reproducible gradients)
-//   colsum       g_bias[n] = sum_m Y[m,n]               bias gradient, same two-stage scheme
+//   colsum       g_bias[n] = sum_m Y[m,n]               bias gradient, same two-stage scheme; in the bf16x3 kernels the
+//                column sums of Y can ride in the weight-gradient pass itself (usf_wgrad_bias_f32, round 4: three more MFMAs
+//                per fragment row against an operand of ones).  The weight gradient from PRE-SPLIT operands (the planes the
+//                layer's own GEMMs write) is usf_wgrad_planes.hip.
 //   act_grad     d[m,j] *= (h[m,j] > 0 ? 1 : slope)     LeakyReLU / ReLU backward from the saved OUTPUT h
 //                (slope >= 0: sign(h) == sign(pre-activation); ATen leaky_relu_backward uses x > 0 ? 1 : slope)
 //   base_grad    g[m,d] = g_lp[m] * d/dz base_d(z[m,d])  Laplace / Normal (torch Laplace.log_prob, Normal.log_prob)
 //
 // Data gradients (dgrad) are usf_linear_f32 launches with the transposed weight image (usf_pack_weight_f32,
-// transpose = 1); the parameter-sized chain rule through M^-1 = U^-1 L^-1 is usf_gemm_f64.
+// transpose = 1) -- for the fused coupling layers one launch of the coupling kernel itself on the transposed weight set
+// (USF_ACT_GATE, usf_coupling_bf16x3.hip); the parameter-sized chain rule through M^-1 = U^-1 L^-1 is usf_gemm_f64.
 #include "usf_common.h"
 #include <type_traits>
 
