@@ -336,3 +336,36 @@ def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch, variant)
             n_bad = int((diff > 1e-4 * big + 1e-12).sum().item())       # (other orders of summation over 16 400 rows: fp32 noise of cancelling sums)
             assert n_bad <= max(2, int(1e-3 * diff.numel())), (on, n, n_bad, diff.numel())
             assert diff.max().item() <= 1e-3 * big + 1e-12, (on, n, diff.max().item(), big)
+
+
+def test_fit_hands_large_host_batches_over_under_the_running_step(monkeypatch):
+    """Flow.fit on a HOST data set with batches of >= 16 MB: the next batch is staged in pinned memory and uploaded on a copy
+    stream while the current step runs (flows._BatchFeed).  Same batches in the same order: the loss curve equals, value for
+    value, the one of the reference's hand-over (a pageable .to(device) in front of every step), ragged last batch included."""
+    import numpy as np
+    from usflows_amd import flows as F_
+    from usflows_amd.sophia import SophiaG
+    spec, sd, _a = load_case("synth_d64_k6_hh0_laplace")
+    B, N = 70000, 3 * 70000 + 1234                              # 70000 x 64 x 4 = 17.9 MB per batch
+    data = torch.rand(N, 64, generator=torch.Generator().manual_seed(11))
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return data[i], 0
+
+    made = []
+    real = F_._BatchFeed.make
+    monkeypatch.setattr(F_._BatchFeed, "make", staticmethod(lambda *a: (made.append(real(*a)), made[-1])[1]))
+    curves = []
+    for prefetch in ("0", "1"):
+        monkeypatch.setenv("USFLOWS_AMD_FIT_PREFETCH", prefetch)
+        flow = build_flow(spec, sd, device=DEV)
+        np.random.seed(5)
+        curves.append(flow.fit(DS(), optim=SophiaG, optim_params=dict(lr=1e-4), batch_size=B, shuffle=True,
+                               device=torch.device(DEV), epochs=2))
+        torch.cuda.synchronize()
+    assert made[0] is None and made[1] is None and made[2] is not None and made[3] is not None     # off twice, on twice (one per epoch)
+    assert curves[0] == curves[1] and len(curves[0]) == 2

@@ -45,6 +45,58 @@ class TransformedDistribution(tdist.TransformedDistribution):
                 t._cached_x_y = None, None
 
 
+
+class _BatchFeed:
+    """Hand-over of large batches of a HOST data set to ``Flow.fit``'s step (the reference slices the permuted data set and
+    the model's ``log_prob`` pulls each slice to the device, flows.py:157-166: a pageable, synchronous copy in front of every
+    step -- 205 MB at 65 536 x 784).  Two pinned staging buffers and two device buffers: while step i runs, batch i + 1 is
+    copied into pinned memory and uploaded on a copy stream; step i + 1 waits for that upload's event only.  Same batches,
+    same order, same values.  Used from 16 MB per batch on a CUDA device with a float32 CPU tensor; USFLOWS_AMD_FIT_PREFETCH=0:
+    off.  (Buffer reuse is safe without further events: a buffer is overwritten two batches after its use, and ``fit`` reads
+    every step's loss back before it goes on.)"""
+
+    MIN_BYTES = 16 << 20
+
+    @staticmethod
+    def make(data, N, batch_size, device):
+        device = torch.device(device)
+        if (device.type != "cuda" or not torch.is_tensor(data) or data.is_cuda or data.dtype != torch.float32 or data.dim() < 2
+                or os.environ.get("USFLOWS_AMD_FIT_PREFETCH", "1") == "0" or N <= batch_size):
+            return None
+        if min(batch_size, N) * data[0].numel() * 4 < _BatchFeed.MIN_BYTES:
+            return None
+        return _BatchFeed(data, N, batch_size, device)
+
+    def __init__(self, data, N, batch_size, device):
+        self.data, self.N, self.bs, self.device = data, N, batch_size, device
+        shape = (min(batch_size, N),) + tuple(data.shape[1:])
+        self.pin = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.dev = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
+        self.up = [torch.cuda.Event() for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.staged = -1
+        self.stage(0)
+
+    def stage(self, idx):
+        """start the hand-over of the batch that begins at row idx (no-op beyond the data set or when already staged)"""
+        if idx >= self.N or idx <= self.staged:
+            return
+        j = (idx // self.bs) & 1
+        n = min(self.bs, self.N - idx)
+        self.up[j].synchronize()                                  # (the upload that last read this pinned buffer: two batches ago)
+        self.pin[j][:n].copy_(self.data[idx: idx + n])
+        with torch.cuda.stream(self.copy_stream):
+            self.dev[j][:n].copy_(self.pin[j][:n], non_blocking=True)
+            self.up[j].record(self.copy_stream)
+        self.staged = idx
+
+    def take(self, idx):
+        self.stage(idx)                                           # (normally staged during the previous step)
+        j = (idx // self.bs) & 1
+        torch.cuda.current_stream(self.device).wait_event(self.up[j])
+        return self.dev[j][: min(self.bs, self.N - idx)]
+
+
 class Flow(torch.nn.Module):
     """Base flow: a list of bijective layers over a base distribution (flows.py:22-378)."""
 
@@ -760,11 +812,15 @@ class Flow(torch.nn.Module):
                 data = data_train[perm][0]
             else:
                 data = data_train[np.arange(N)][0]
+            feed = _BatchFeed.make(data, N, batch_size, device)     # large host batches: the next one crosses PCIe under this step
             for idx in range(0, N, batch_size):
-                sample = data[idx: min(idx + batch_size, N)]
-                if not isinstance(sample, torch.Tensor):
-                    sample = torch.Tensor(sample)
-                sample = sample.to(device)
+                if feed is not None:
+                    sample = feed.take(idx)
+                else:
+                    sample = data[idx: min(idx + batch_size, N)]
+                    if not isinstance(sample, torch.Tensor):
+                        sample = torch.Tensor(sample)
+                    sample = sample.to(device)
                 noise = None
                 if self.soft_training:
                     noise = self.training_noise_prior.sample([sample.shape[0]]).to(device)
@@ -780,6 +836,8 @@ class Flow(torch.nn.Module):
                     model._zero_grad_for_step(optim)
                     loss = -model.log_prob(sample, context=noise).mean() - model.log_prior()
                     loss.backward()
+                    if feed is not None:
+                        feed.stage(idx + batch_size)       # host copy + asynchronous upload of the next batch, before the read-back below waits
                     losses.append(float(loss.detach()))
                     if dp is not None:
                         from .parallel import allreduce_gradients
