@@ -118,7 +118,23 @@ __device__ __forceinline__ void gemm_tile_f64(const double* __restrict__ A, int6
   if (kHi > K) kHi = K;
 
   double ra[4], rb[4];
+  // tiles that lie inside the matrices with 16-byte aligned rows (all but the last tile row / column at D = 784) fetch their
+  // four consecutive values as two 16-byte loads without per-element bounds checks
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const bool inner = r0 + 64 <= M && c0 + 64 <= N && !(lda & 1) && !(ldb & 1) &&
+                     !(reinterpret_cast<uintptr_t>(A) & 15) && !(reinterpret_cast<uintptr_t>(B) & 15);
+  auto load4 = [&](const double* __restrict__ p, double (&r)[4]) {
+    const f64x2 v0 = *reinterpret_cast<const f64x2*>(p), v1 = *reinterpret_cast<const f64x2*>(p + 2);
+    r[0] = v0[0]; r[1] = v0[1]; r[2] = v1[0]; r[3] = v1[1];
+  };
   auto load = [&](int k0) {
+    if (inner && k0 + 16 <= K) {                // block-uniform
+      if (!TA) load4(A + (int64_t)(r0 + (tid >> 2)) * lda + k0 + (tid & 3) * 4, ra);
+      else load4(A + (int64_t)(k0 + (tid >> 4)) * lda + r0 + (tid & 15) * 4, ra);
+      if (!TB) load4(B + (int64_t)(k0 + (tid >> 4)) * ldb + c0 + (tid & 15) * 4, rb);
+      else load4(B + (int64_t)(c0 + (tid >> 2)) * ldb + k0 + (tid & 3) * 4, rb);
+      return;
+    }
     if (!TA) {
       const int row = tid >> 2, kq = (tid & 3) * 4;
       const int gr = r0 + row;
