@@ -82,6 +82,10 @@ __device__ __forceinline__ int wp_swz(int r) { return ((r & 3) << 2) | ((r >> 2)
 __device__ __forceinline__ int wp_ext_row(int r) { return r ^ (((r >> 3) & 1) << 2); }
 
 __device__ __forceinline__ wp_bf16x8 wp_frag(const char* tile, int o0, int o1) {
+#ifdef USF_WP_X_B128                            // tuning build (wrong results): ONE 16-byte read per fragment instead of two transposing reads
+  (void)o1;
+  return *reinterpret_cast<const wp_bf16x8*>(tile + (o0 & ~15));
+#endif
   typedef __attribute__((address_space(3))) wp_s16x4 lds_v;
   const wp_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + o0));
   const wp_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(tile + o1));
