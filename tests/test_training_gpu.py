@@ -369,3 +369,41 @@ def test_fit_hands_large_host_batches_over_under_the_running_step(monkeypatch):
         torch.cuda.synchronize()
     assert made[0] is None and made[1] is None and made[2] is not None and made[3] is not None     # off twice, on twice (one per epoch)
     assert curves[0] == curves[1] and len(curves[0]) == 2
+
+
+@pytest.mark.parametrize("hidden,soft", [([256], False), ([256, 192, 256], False), ([200, 256], True)])
+def test_fused_coupling_backward_for_one_to_three_hidden_layers(monkeypatch, hidden, soft):
+    """the conditioner's backward pass on the fused kernel (USF_ACT_GATE) for 1 / 2 / 3 hidden layers, ragged widths and the
+    soft-training context branch: gradients of -mean log_prob against the fp64 oracle's autograd, and against the path with
+    the saved activations and the fused backward switched off"""
+    from oracle import usflows_oracle as orc_
+    from usflows_amd import _ext
+    spec = orc_.FlowSpec(72, 2, hidden, householder=0, soft_training=soft)
+    sd = orc_.synth_state_dict(spec, seed=21)
+    B = 2048
+    x = torch.rand(B, 72, generator=torch.Generator().manual_seed(6))
+    ctx = torch.rand(B, 1, generator=torch.Generator().manual_seed(7)) if soft else None
+    n_launch = []
+    real_c = _ext.coupling_op
+    monkeypatch.setattr(_ext, "coupling_op", lambda *a, **k: (n_launch.append(1), real_c(*a, **k))[1])
+    grads = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("USFLOWS_AMD_SAVE_HIDDEN", on)
+        monkeypatch.setenv("USFLOWS_AMD_FUSED_CBWD", on)
+        flow = build_flow(spec, sd, device=DEV)
+        flow.engine().fused_min_rows = 0                        # the fused kernel from 1024 rows on
+        n0 = len(n_launch)
+        lp = flow.log_prob(x.to(DEV), ctx.to(DEV) if soft else None)
+        (-lp.mean()).backward()
+        torch.cuda.synchronize()
+        assert (len(n_launch) - n0 == 2) == (on == "1")         # one backward launch per coupling layer
+        grads.append({n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None})
+        if on == "1":
+            lp_ref, g_ref = oracle_grads(spec, sd, x, torch.full((B,), -1.0 / B), ctx)
+            assert ((lp.detach().cpu().double() - lp_ref).abs() / lp_ref.abs()).max().item() < 1e-5
+            assert _compare(flow, g_ref, tol=5e-4, kink_frac=5e-3) >= 5
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        big = grads[1][n].abs().max().item()
+        diff = (grads[0][n] - grads[1][n]).abs()
+        assert int((diff > 1e-4 * big + 1e-12).sum().item()) <= max(2, int(1e-3 * diff.numel())), n
