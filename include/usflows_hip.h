@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 32
+#define USF_ABI_VERSION 33
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -523,6 +523,19 @@ typedef struct usf_coupling_planes_desc {
   float sign, slope;
   int32_t act, format;
   int32_t* range_flag;
+  /* Training (ABI 33; USF_PLANES_BF16X3, n_hidden <= 2).  Planes buffers with 8 blocks per panel (hidden width 256):
+   *   hidden_out[l] (optional, all n_hidden or none): receives the activations of hidden layer l -- the lane-local splits
+   *     the kernel makes anyway, i.e. the operands of the conditioner's weight gradients (usf_wgrad_blocked_f32) and the
+   *     gates of the backward launch.
+   *   act == USF_ACT_GATE (needs hidden_out and gate[l] for every layer): the launch runs the conditioner's data-gradient
+   *     chain -- the caller passes the transposed weight images in reverse order, zero biases and swaps the block ranges:
+   *     z = the gradient buffer, g[:, pass] += sign * MLP^T(g[:, trans]); layer l's nonlinearity is leaky_relu_backward
+   *     from the saved activations gate[l] (v * (h > 0 ? 1 : slope); only plane 0 of gate[l] is read) and hidden_out[l]
+   *     receives the gated values (the gradients at the pre-activations of forward hidden layer n_hidden - 1 - l).
+   * Replaces autograd's backward of MaskedCoupling + its conditioner (transforms.py:277-306, networks.py:739-751) under
+   * Flow.fit (flows.py:196-203) at batches of thousands of rows. */
+  void* hidden_out[2];
+  const void* gate[2];
 } usf_coupling_planes_desc;
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream);
 /* Which kernel serves usf_coupling_planes: 0 = 16 batch rows per wave, two waves per SIMD (the default); 1 = 32 rows per
@@ -746,6 +759,18 @@ int usf_wgrad_planes_ok(int64_t M, int64_t N, int64_t K);
 int usf_wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K);
 int usf_split_planes_f32(const float* X, int64_t ldx, int64_t M, int64_t N, void* planes, int64_t ldp, int64_t plane_stride,
                          usf_stream_t stream);
+/* The same weight gradient with both operands in the BLOCKED planes format of the planes pipeline (ABI 33) -- the buffers the
+ * training forward's usf_gemm_planes_bf16x3 / usf_coupling_planes launches leave behind and the backward's launches write:
+ *   G[n,k] = alpha * sum_m Y[m, 32 y_kb0 + n] * A[m, 32 a_kb0 + k] + beta * G[n,k],   n < N, k < K  (LOGICAL positions),
+ * Y / A planes buffers of ceil(M/16) panels with y_nkb / a_nkb blocks per panel (USF_PLANES_BF16X3), N <= 32 (y_nkb - y_kb0),
+ * K <= 32 (a_nkb - a_kb0).  Rows [M, 16 ceil(M/16)) of Y must hold zeros (they do in every buffer whose producer chain
+ * starts at usf_pack_planes_f32 and has no bias); those of A must be finite.  Same kernel, schedule, order of products,
+ * workspace (usf_wgrad_planes_workspace_floats) and colsum_out semantics as usf_wgrad_planes_f32; a buffer must stay below
+ * 2 GiB.  Loader waves copy whole 1-KiB chunks; the MFMA waves' transposing reads un-do the slot order, so G comes out in
+ * logical order. */
+int usf_wgrad_blocked_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, const void* A_planes, int64_t a_nkb, int64_t a_kb0,
+                          int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out,
+                          float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);
 
 /* Many small weight / bias gradients in ONE launch.  At the reference's training batch (32 rows, tests/explib/mnist.yaml:34)
  * Flow.fit's backward pass (flows.py:196-199) asks for one weight and one bias gradient per F.linear on the path -- some

@@ -18,7 +18,7 @@ import torch  # noqa: F401  -- must be imported first: the .so binds to torch's 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
 
-USF_ABI_VERSION = 32
+USF_ABI_VERSION = 33
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -92,7 +92,7 @@ class CouplingPlanesDesc(C.Structure):
                 ("W_hid", _fp * 2), ("b_hid", _fp * 2), ("ldw_hid", C.c_int64), ("w_hid_plane", C.c_int64),
                 ("W_out", _fp), ("ldw_out", C.c_int64), ("w_out_plane", C.c_int64), ("b_out", _fp),
                 ("sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("format", C.c_int32),
-                ("range_flag", _fp)]
+                ("range_flag", _fp), ("hidden_out", _fp * 2), ("gate", _fp * 2)]
 
 
 class MtChunk(C.Structure):
@@ -233,6 +233,8 @@ SYMBOLS = {
     "usf_wgrad_planes_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int64, C.c_int64, _fp, C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float,
                                        _fp, C.c_int64, _fp]),
+    "usf_wgrad_blocked_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp,
+                                        C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
     "usf_wgrad_planes_colsum_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
@@ -1240,6 +1242,19 @@ def wgrad_planes(Yp, Ap, G, *, M, N, K, ldg, y_off=0, a_off=0, g_off=0, alpha=1.
                                      Ap.shape[1] * Ap.shape[2], a_off, M, N, K, G.data_ptr() + 4 * g_off, ldg, float(alpha),
                                      float(beta), ptr(colsum), float(cs_alpha), float(cs_beta), ws.data_ptr(), ws.numel(),
                                      current_stream(Yp.device)), (Yp, Ap, G, ws, colsum))
+
+
+def wgrad_blocked(Yp, y_nkb, y_kb0, Ap, a_nkb, a_kb0, G, *, M, N, K, ldg, g_off=0, alpha=1.0, beta=0.0, colsum=None,
+                  cs_alpha=1.0, cs_beta=0.0):
+    """usf_wgrad_blocked_f32: G[n,k] = alpha * sum_m Y[m, 32 y_kb0 + n] A[m, 32 a_kb0 + k] + beta * G with both operands
+    planes buffers of the planes pipeline (uint8 tensors; logical positions); colsum as for ``wgrad_planes``"""
+    lib = load()
+    need = lib.usf_wgrad_planes_workspace_floats(M, N, K)
+    ws = _workspace(Yp.device, need)
+    _launch("usf_wgrad_blocked_f32", (Yp.data_ptr(), y_nkb, y_kb0, Ap.data_ptr(), a_nkb, a_kb0, M, N, K,
+                                      G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ptr(colsum), float(cs_alpha),
+                                      float(cs_beta), ws.data_ptr(), ws.numel(), current_stream(Yp.device)),
+            (Yp, Ap, G, ws, colsum))
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):

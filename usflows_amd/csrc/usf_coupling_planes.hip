@@ -78,6 +78,10 @@ struct CplPArgs {
   float sign, slope; int act;
   int32_t* range_flag;
   unsigned long long* dbg;               // tuning builds (-DUSF_STAMP) only
+  // training (ABI 33; bf16x3 only): planes buffers of 8 blocks per panel (hidden width 256).  hout[l]: receives hidden
+  // layer l's activations (MODE 1) resp. the gradients at its pre-activations (MODE 2); gate[l]: MODE 2, the saved
+  // activations whose sign gates layer l (leaky_relu_backward from the saved output; only plane 0 is read)
+  char* hout[2]; const char* gate[2];
 };
 
 #ifdef USF_STAMP
@@ -88,7 +92,12 @@ struct CplPArgs {
 
 template <bool B> struct CpBoolT { static constexpr bool value = B; };
 
-template <int NPL, int NH>
+// MODE 0: inference.  MODE 1 (training forward): the lane-local splits of the hidden activations -- the next layer's B
+// operands -- are also stored as planes (hout[l]: the operands of the conditioner's weight gradients and the gates of the
+// backward launch).  MODE 2 (training backward: the launch runs the conditioner's transposed chain on the gradient
+// buffer, usf_coupling_planes_desc::gate): the activation is leaky_relu_backward from the saved activations gate[l], and
+// hout[l] receives the gated values (the gradients at the pre-activations).
+template <int NPL, int NH, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs p) {
   typedef CPlanes<NPL> PT;
   typedef typename PT::vec vec8;
@@ -239,7 +248,21 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     __syncthreads();
     ++g;
   }
-  auto activate = [&](f32x4 (&X)[T]) {
+  const size_t hbase = (size_t)panc * 8 * CHB + (size_t)lane * 16;      // this lane's line in block 0 of a hidden planes buffer
+  auto activate = [&](f32x4 (&X)[T], int l) {
+    if (MODE == 2) {
+      // lane (j, g)'s line of block ks holds slots 8 g .. 8 g + 7 = registers 0..3 of tiles 2 ks and 2 ks + 1
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const vec8 hv = *reinterpret_cast<const vec8*>(p.gate[l] + hbase + (size_t)ks * CHB);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          X[2 * ks][t] = gate_apply(X[2 * ks][t], (float)hv[t], p.slope);
+          X[2 * ks + 1][t] = gate_apply(X[2 * ks + 1][t], (float)hv[4 + t], p.slope);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int ht = 0; ht < T; ++ht) {
 #pragma unroll
@@ -247,7 +270,13 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
       guard(X[ht]);
     }
   };
-  activate(X1);
+  auto save_hidden = [&](int l, int ks, const vec8 (&x)[NPL]) {
+    if (MODE != 0 && live) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<vec8*>(p.hout[l] + hbase + (size_t)ks * CHB + q * 1024) = x[q];
+    }
+  };
+  activate(X1, 0);
   CSTAMP(c1);
 
   // ================= phase 2: Xout[h2][row] += W_h[h2][h1'] * Xin[h1'][row] ====================
@@ -256,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
     PT::split(Xin[0], Xin[1], xc);               // slot order {4g.., 16+4g..}: the weights' K order
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      save_hidden(l, ks, xc);
       const int buf = g & 1;
       const bool last = (ks + 1 == KS);
       const bool next_is_hidden = (l + 2 < NH);
@@ -274,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
       __syncthreads();
       ++g;
     }
-    activate(Xout);
+    activate(Xout, l + 1);
   };
   if (NH >= 2) {
 #pragma unroll
@@ -306,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void coupling_planes_kernel(const CplPArgs 
   auto output_layer = [&](f32x4 (&X)[T]) {
     vec8 xp[KS][NPL];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) PT::split(X[2 * ks], X[2 * ks + 1], xp[ks]);
+    for (int ks = 0; ks < KS; ++ks) { PT::split(X[2 * ks], X[2 * ks + 1], xp[ks]); save_hidden(NH - 1, ks, xp[ks]); }
     // residual of output block nt (the lane's own chunk line) and its slice of the output bias, one block ahead
     vec8 res[NPL];
     f32x4 bo[2];
@@ -913,6 +943,29 @@ int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream) {
   a.dbg = g_cdbg;
 #endif
   const dim3 grid((unsigned)((npanels + 7) / 8));
+  // ---- training forms (ABI 33): hidden_out / gate ----
+  const bool want_h = d->hidden_out[0] != nullptr || d->hidden_out[1] != nullptr;
+  const bool gated = d->act == USF_ACT_GATE;
+  if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU && !gated) { set_error("usf_coupling_planes: bad act %d", d->act); return -2; }
+  for (int i = 0; i < 2; ++i) { a.hout[i] = nullptr; a.gate[i] = nullptr; }
+  if (want_h || gated) {
+    if (npl != 3 || d->n_hidden > 2) { set_error("usf_coupling_planes: hidden_out / USF_ACT_GATE need the bf16x3 format and n_hidden <= 2"); return -2; }
+    if (gated && !want_h) { set_error("usf_coupling_planes: USF_ACT_GATE needs hidden_out (the gradients at the hidden pre-activations)"); return -2; }
+    for (int i = 0; i < d->n_hidden; ++i) {
+      if (!d->hidden_out[i] || !aligned16(d->hidden_out[i]) || (gated && (!d->gate[i] || !aligned16(d->gate[i])))) {
+        set_error("usf_coupling_planes: hidden_out[l] (and gate[l] with USF_ACT_GATE) must be set for every hidden layer, 16-byte aligned");
+        return -2;
+      }
+      a.hout[i] = reinterpret_cast<char*>(d->hidden_out[i]);
+      a.gate[i] = reinterpret_cast<const char*>(gated ? d->gate[i] : nullptr);
+    }
+    const dim3 block(512);
+#define USF_CPT(NH_, MODE_) hipLaunchKernelGGL((coupling_planes_kernel<3, NH_, MODE_>), grid, block, 0, stream, a)
+    if (gated) { if (d->n_hidden == 1) USF_CPT(1, 2); else USF_CPT(2, 2); }
+    else { if (d->n_hidden == 1) USF_CPT(1, 1); else USF_CPT(2, 1); }
+#undef USF_CPT
+    return check_launch("usf_coupling_planes");
+  }
   static int w32_env = -1;
   if (w32_env < 0) { const char* e = getenv("USF_CP_W32"); w32_env = e ? atoi(e) : 0; }   // 1: the 32-row-wave kernel (usf_coupling_planes_select)
   const int w32 = g_cp_w32 >= 0 ? g_cp_w32 : w32_env;

@@ -68,6 +68,7 @@ struct WpArgs {
   int M, N, K;
   unsigned long long* dbg;                     // tuning builds (-DUSF_STAMP) only
   float* cs_part;                              // [row ranges][N] partial column sums of Y, or NULL (see wgrad_planes)
+  int y_nkb, y_kb0, a_nkb, a_kb0;              // BLOCKED operands (usf_wgrad_blocked_f32): blocks per panel, first block
   WpSched sched;
 };
 
@@ -80,6 +81,22 @@ __device__ __forceinline__ int wp_swz(int r) { return ((r & 3) << 2) | ((r >> 2)
 // extension image: row r (32 bytes) at position r ^ 4 where bit 3 of r is set -- the two 4-row blocks a 32-lane half
 // reads (rows 8 g + 4 hh .., g = 0, 1) land in different halves of the 64 banks
 __device__ __forceinline__ int wp_ext_row(int r) { return r ^ (((r >> 3) & 1) << 2); }
+
+// ---- BLOCKED operands: the planes buffers of the planes pipeline (include/usflows_hip.h: chunk(panel, block, plane) = 1 KiB,
+// line 16 g' + j = row j of the panel, slots 8 g' .. 8 g' + 7; slot 8 g' + u = position 16 (u >> 2) + 4 g' + (u & 3) of the
+// block).  A slab's image per plane = 2 panels x 4 blocks x 64 lines, the chunks copied as they are except that line
+// 16 g' + j of a chunk sits at 16 g' + (j ^ 4 (g' >> 1)).  A transposing read wants, per 16-lane group, 4 rows x 4 pieces of
+// 4 consecutive columns; here piece p of sub-tile tt (0 / 1) of a block is the half (p & 1) ^ tt of group g' = p's line: the
+// pieces of a 32-lane half land in 32 different (16-byte bank group, half) places -- conflict-free -- and the sub-tile's
+// column c = 4 p + e is position wp_blk_pos(c, tt) of the block.
+__device__ __forceinline__ int wp_blk_line(int ph, int blk, int L) {
+  const int gq = L >> 4, j = L & 15;
+  return (ph * 4 + blk) * 64 + 16 * gq + (j ^ ((gq >> 1) << 2));
+}
+__device__ __forceinline__ int wp_blk_off(int r, int blk, int pp, int tt) {
+  return 16 * wp_blk_line(r >> 4, blk, 16 * pp + (r & 15)) + 8 * ((pp & 1) ^ tt);
+}
+__host__ __device__ __forceinline__ int wp_blk_pos(int c, int tt) { return 16 * (((c >> 2) & 1) ^ tt) + 4 * (c >> 2) + (c & 3); }
 
 __device__ __forceinline__ wp_bf16x8 wp_frag(const char* tile, int o0, int o1) {
 #ifdef USF_WP_X_B128                            // tuning build (wrong results): ONE 16-byte read per fragment instead of two transposing reads
@@ -133,7 +150,9 @@ __device__ __forceinline__ bool wp_item(const WpSched& sc, int M, int& n0, int& 
 // extension image's (columns 128 .. 143 of a wide tile)
 // CS: the wave also sums its Y fragments over the batch -- three more MFMAs per fragment row and slab against a B operand of
 // ones (every column of the 16 x 16 result is the column sum of Y: the bias gradient of the layer, for free)
-template <int NI, int NJ, bool CS = false>
+// BLK: the image holds the operands in the BLOCKED planes format (see wgrad_planes_kernel); sub-tile t of a wave's patch is
+// then one half of block t >> 1 whose 16 columns come out in the order wp_blk_pos gives.
+template <int NI, int NJ, bool CS = false, bool BLK = false>
 __device__ __forceinline__ void wp_mfma_loop(WpShared& sh, f32x4 (&acc)[5][5], int nslab, int nslab4, int wvn, int wvk, int lane,
                                              unsigned long long* dbg_slot, f32x4 (&cs)[5]) {
   static_assert(!(NI == 5 && NJ == 5), "a 144 x 144 tile does not fit the LDS ring");
@@ -145,9 +164,13 @@ __device__ __forceinline__ void wp_mfma_loop(WpShared& sh, f32x4 (&acc)[5][5], i
     const int r = 8 * lg + 4 * hh + q;
     const int eo = 32 * wp_ext_row(r) + 16 * (pp >> 1) + 8 * (pp & 1);
 #pragma unroll
-    for (int t = 0; t < NI; ++t) yo[t][hh] = t == 4 ? eo : 256 * r + 16 * ((8 * wvn + 2 * t + (pp >> 1)) ^ wp_swz(r)) + 8 * (pp & 1);
+    for (int t = 0; t < NI; ++t)
+      yo[t][hh] = t == 4 ? eo : (BLK ? wp_blk_off(r, 2 * wvn + (t >> 1), pp, t & 1)
+                                     : 256 * r + 16 * ((8 * wvn + 2 * t + (pp >> 1)) ^ wp_swz(r)) + 8 * (pp & 1));
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) ao[t][hh] = t == 4 ? eo : 256 * r + 16 * ((8 * wvk + 2 * t + (pp >> 1)) ^ wp_swz(r)) + 8 * (pp & 1);
+    for (int t = 0; t < NJ; ++t)
+      ao[t][hh] = t == 4 ? eo : (BLK ? wp_blk_off(r, 2 * wvk + (t >> 1), pp, t & 1)
+                                     : 256 * r + 16 * ((8 * wvk + 2 * t + (pp >> 1)) ^ wp_swz(r)) + 8 * (pp & 1));
   }
   wp_bf16x8 yp[NI][3], ap[2][3];
   wp_bf16x8 ones;
@@ -239,6 +262,9 @@ __device__ __forceinline__ void wp_mfma_loop(WpShared& sh, f32x4 (&acc)[5][5], i
 }
 
 // 512 threads: waves 0 .. 3 (one per SIMD) multiply a (64 | 80) x (64 | 80) patch each, waves 4, 5 copy Y, waves 6, 7 copy A
+// BLK: both operands in the BLOCKED planes format (usf_wgrad_blocked_f32); tiles are 4 blocks wide, the folded remainder is
+// the first 16 positions of a fifth block.
+template <bool BLK>
 __global__ __launch_bounds__(512) void wgrad_planes_kernel(WpArgs a) {
   __shared__ __attribute__((aligned(16))) WpShared sh;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -267,36 +293,66 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WpArgs a) {
     const int live_ch = 2 * (((live < WP_T ? live : WP_T) + 15) >> 4);
     const bool wide = live > WP_T;
     unsigned vo[4], eo;                        // thread = chunks u, u + 128, u + 256, u + 384 of the 32 x 16 image; one of the extension
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int c = u + 128 * h, r = c >> 4, ch = (c & 15) ^ wp_swz(r);
-      vo[h] = ch < live_ch ? (((unsigned)m_begin + (unsigned)r) * ld + c0 + 8u * (unsigned)ch) * 2u : 0x80000000u;
-    }
+    int vdst[4];                               // ... and where they go in the image
     // extension: 64 chunks per plane; the operand's first loader wave copies planes 0 and 1, its second wave plane 2
     const bool second = (wave & 1) != 0;        // scalar
     const int er = (u & 63) >> 1, eh = u & 1;
-    eo = wide ? (((unsigned)m_begin + (unsigned)er) * ld + c0 + (unsigned)WP_T + 8u * (unsigned)eh) * 2u : 0x80000000u;
     const int epos = 2 * wp_ext_row(er) + eh;
+    // BLOCKED: bytes per panel / between the slabs' panels, the tile's first block
+    const unsigned nkb = (unsigned)(isA ? a.a_nkb : a.y_nkb);
+    const unsigned kb_t = (unsigned)(isA ? a.a_kb0 + (k0 >> 5) : a.y_kb0 + (n0 >> 5));
+    if (BLK) {
+      const int live_blk = ((live < WP_T ? live : WP_T) + 31) >> 5;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int c = u + 128 * h, ph = c >> 8, blk = (c >> 6) & 3, L = c & 63;
+        vo[h] = blk < live_blk ? ((((unsigned)(m_begin >> 4) + (unsigned)ph) * nkb + kb_t + (unsigned)blk) * 3072u + 16u * (unsigned)L) : 0x80000000u;
+        vdst[h] = wp_blk_line(ph, blk, L);
+      }
+      // extension chunk (er, eh): pieces p = 2 eh, 2 eh + 1 = the first 8 bytes of lines 16 p + (er & 15) of the fifth block
+      eo = wide ? ((((unsigned)(m_begin >> 4) + (unsigned)(er >> 4)) * nkb + kb_t + 4u) * 3072u + 16u * (unsigned)(32 * eh + (er & 15))) : 0x80000000u;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int c = u + 128 * h, r = c >> 4, ch = (c & 15) ^ wp_swz(r);
+        vo[h] = ch < live_ch ? (((unsigned)m_begin + (unsigned)r) * ld + c0 + 8u * (unsigned)ch) * 2u : 0x80000000u;
+        vdst[h] = c;
+      }
+      eo = wide ? (((unsigned)m_begin + (unsigned)er) * ld + c0 + (unsigned)WP_T + 8u * (unsigned)eh) * 2u : 0x80000000u;
+    }
     // per slab and thread: 12 loads of the main image + 2 of the extension
     auto fetch = [&](int sl, wp_u32x4 (&v)[14]) {
 #ifdef USF_WP_X_NOLOAD
       if (sl > 8) return;                      // tuning build: what the kernel takes without its operand traffic (wrong results)
 #endif
-      const unsigned adv = (unsigned)sl * (WP_S * 2u) * ld;
+      const unsigned adv = BLK ? (unsigned)sl * 2u * nkb * 3072u : (unsigned)sl * (WP_S * 2u) * ld;
+      const unsigned pst = BLK ? 1024u : pstride;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-          v[4 * pl + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo[h] + adv), (int)((unsigned)pl * pstride), 0);
-      v[12] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eo + adv), (int)((second ? 2u : 0u) * pstride), 0);
-      v[13] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(second ? 0x80000000u : eo + adv), (int)pstride, 0);
+          v[4 * pl + h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo[h] + adv), (int)((unsigned)pl * pst), 0);
+      if (BLK) {
+        // two 8-byte pieces per extension chunk (lines 16 apart = 256 bytes)
+        typedef unsigned wp_u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned e1 = eo + adv, e2 = second ? 0x80000000u : eo + adv;
+        const wp_u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)e1, (int)((second ? 2u : 0u) * pst), 0);
+        const wp_u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(e1 + 256u), (int)((second ? 2u : 0u) * pst), 0);
+        const wp_u32x2 b0 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)e2, (int)pst, 0);
+        const wp_u32x2 b1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(e2 + 256u), (int)pst, 0);
+        v[12] = (wp_u32x4){a0[0], a0[1], a1[0], a1[1]};
+        v[13] = (wp_u32x4){b0[0], b0[1], b1[0], b1[1]};
+      } else {
+        v[12] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eo + adv), (int)((second ? 2u : 0u) * pstride), 0);
+        v[13] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(second ? 0x80000000u : eo + adv), (int)pstride, 0);
+      }
     };
     auto store = [&](int ring, const wp_u32x4 (&v)[14]) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
         for (int h = 0; h < 4; ++h)
-          sh.img[ring][isA ? 1 : 0][pl][u + 128 * h] = __builtin_bit_cast(uint4, v[4 * pl + h]);
+          sh.img[ring][isA ? 1 : 0][pl][vdst[h]] = __builtin_bit_cast(uint4, v[4 * pl + h]);
       if (wide) {                               // wave-uniform
         sh.ext[ring][second ? 2 : 0][epos] = __builtin_bit_cast(uint4, v[12]);
         if (!second) sh.ext[ring][1][epos] = __builtin_bit_cast(uint4, v[13]);
@@ -347,8 +403,12 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WpArgs a) {
     for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // live 16-wide sub-tiles of this wave's patch (wave-uniform): 64 columns each, the second wave also the extension
   const int rem_n = wn - wvn * 64, rem_k = wk - wvk * 64;
-  const int ni = rem_n <= 0 ? 0 : (wvn == 0 ? (rem_n >= 64 ? 4 : (rem_n + 15) / 16) : (rem_n + 15) / 16);
-  const int nj = rem_k <= 0 ? 0 : (wvk == 0 ? (rem_k >= 64 ? 4 : (rem_k + 15) / 16) : (rem_k + 15) / 16);
+  int ni = rem_n <= 0 ? 0 : (wvn == 0 ? (rem_n >= 64 ? 4 : (rem_n + 15) / 16) : (rem_n + 15) / 16);
+  int nj = rem_k <= 0 ? 0 : (wvk == 0 ? (rem_k >= 64 ? 4 : (rem_k + 15) / 16) : (rem_k + 15) / 16);
+  if (BLK) {                                    // a block's two sub-tiles interleave its positions: whole blocks are live
+    if (ni > 0 && ni < 4) ni = (ni + 1) & ~1;
+    if (nj > 0 && nj < 4) nj = (nj + 1) & ~1;
+  }
   const bool do_cs = a.cs_part != nullptr && k0 == 0 && wvk == 0;      // wave-uniform
   f32x4 cs[5];
 #pragma unroll
@@ -358,10 +418,10 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WpArgs a) {
   if (ni == 0 || nj == 0) {
     for (int s = 0; s < nslab4; ++s) __syncthreads();
   } else {
-#define WP_GO(NI_, NJ_) wp_mfma_loop<NI_, NJ_>(sh, acc, nslab, nslab4, wvn, wvk, lane, dbg_slot, cs)
+#define WP_GO(NI_, NJ_) wp_mfma_loop<NI_, NJ_, false, BLK>(sh, acc, nslab, nslab4, wvn, wvk, lane, dbg_slot, cs)
 #define WP_ROW(NI_) do { if (nj > 4) WP_GO(NI_, 5); else if (nj > 2) WP_GO(NI_, 4); else if (nj > 1) WP_GO(NI_, 2); else WP_GO(NI_, 1); } while (0)
 #define WP_ROW4(NI_) do { if (nj > 2) WP_GO(NI_, 4); else if (nj > 1) WP_GO(NI_, 2); else WP_GO(NI_, 1); } while (0)
-#define WP_CS(NI_) wp_mfma_loop<NI_, 4, true>(sh, acc, nslab, nslab4, wvn, wvk, lane, dbg_slot, cs)
+#define WP_CS(NI_) wp_mfma_loop<NI_, 4, true, BLK>(sh, acc, nslab, nslab4, wvn, wvk, lane, dbg_slot, cs)
     if (do_cs && nj == 4) {                     // (the host asks for column sums only where K >= 64: nj == 4 in wave column 0)
       if (ni > 4) WP_CS(5); else if (ni > 2) WP_CS(4); else if (ni > 1) WP_CS(2); else WP_CS(1);
     } else if (ni > 4) WP_ROW4(5); else if (ni > 2) WP_ROW(4); else if (ni > 1) WP_ROW(2); else WP_ROW(1);
@@ -377,8 +437,12 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WpArgs a) {
     for (int j = 0; j < 5; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int tn = wvn * 64 + i * 16 + 4 * (lane >> 4) + r;
-        const int tk = wvk * 64 + j * 16 + (lane & 15);
+        int tn = wvn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        int tk = wvk * 64 + j * 16 + (lane & 15);
+        if (BLK) {                              // (the extension sub-tile, index 4 of the second wave, is in position order)
+          if (i < 4) tn = wvn * 64 + (i >> 1) * 32 + wp_blk_pos(4 * (lane >> 4) + r, i & 1);
+          if (j < 4) tk = wvk * 64 + (j >> 1) * 32 + wp_blk_pos(lane & 15, j & 1);
+        }
         if (tn < wn && tk < wk && i < ni && j < nj) out[(int64_t)(n0 + tn) * a.K + k0 + tk] = acc[i][j][r];
       }
   if (do_cs && (lane & 15) == 0) {
@@ -387,7 +451,8 @@ __global__ __launch_bounds__(512) void wgrad_planes_kernel(WpArgs a) {
     for (int i = 0; i < 5; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int tn = wvn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        int tn = wvn * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (BLK && i < 4) tn = wvn * 64 + (i >> 1) * 32 + wp_blk_pos(4 * (lane >> 4) + r, i & 1);
         if (tn < wn && i < ni) co[n0 + tn] = cs[i][r];
       }
   }
@@ -638,7 +703,7 @@ int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, c
     return -2;
   }
   WpArgs a{(const __bf16*)Yp, ldyp, ystride, (const __bf16*)Ap, ldap, astride, (int)y_off, (int)a_off, (unsigned)yb, (unsigned)ab,
-           workspace, (int)M, (int)N, (int)K, nullptr, nullptr};
+           workspace, (int)M, (int)N, (int)K, nullptr, nullptr, 0, 0, 0, 0};
 #ifdef USF_STAMP
   a.dbg = g_wpdbg;
 #endif
@@ -654,12 +719,51 @@ int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, c
     return -4;
   }
   if (colsum_out) a.cs_part = workspace + (int64_t)wp_max_parts(a.sched) * N * K;
-  wgrad_planes_kernel<<<(unsigned)(a.sched.per_xcd * 8), 512, 0, stream>>>(a);
+  wgrad_planes_kernel<false><<<(unsigned)(a.sched.per_xcd * 8), 512, 0, stream>>>(a);
   int64_t rb = (N * K + 255) / 256;
   if (rb > 4096) rb = 4096;
   reduce_partials_cls_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, a.sched, N, K, G, ldg, alpha, beta, a.cs_part, colsum_out,
                                                                 cs_alpha, cs_beta);
   return check_launch("usf_wgrad_planes_f32");
+}
+
+// usf_wgrad_blocked_f32: see include/usflows_hip.h
+int wgrad_blocked(const void* Yp, int64_t y_nkb, int64_t y_kb0, const void* Ap, int64_t a_nkb, int64_t a_kb0, int64_t M, int64_t N,
+                  int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out, float cs_alpha, float cs_beta,
+                  float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  if (colsum_out && !wgrad_planes_colsum_ok(M, N, K)) { set_error("usf_wgrad_blocked_f32: colsum_out needs K >= 64"); return -2; }
+  if (!Yp || !Ap || !G || !workspace || M <= 0 || N <= 0 || K <= 0 || ldg < K || y_kb0 < 0 || a_kb0 < 0 || y_nkb <= 0 || a_nkb <= 0 ||
+      y_kb0 * 32 + N > y_nkb * 32 || a_kb0 * 32 + K > a_nkb * 32 || !aligned16(Yp) || !aligned16(Ap)) {
+    set_error("usf_wgrad_blocked_f32: bad arguments (block ranges inside the buffers, 16-byte aligned planes)");
+    return -1;
+  }
+  const int64_t npanels = (M + 15) / 16;
+  const int64_t yb = npanels * y_nkb * 3072, ab = npanels * a_nkb * 3072;
+  if (M > 0x7fffffff - 4096 || N > (1 << 20) || K > (1 << 20) || yb >= (1LL << 31) || ab >= (1LL << 31)) {
+    set_error("usf_wgrad_blocked_f32: size out of range (a planes buffer must stay below 2 GiB)");
+    return -2;
+  }
+  WpArgs a{(const __bf16*)Yp, 0, 0, (const __bf16*)Ap, 0, 0, 0, 0, (unsigned)yb, (unsigned)ab,
+           workspace, (int)M, (int)N, (int)K, nullptr, nullptr, (int)y_nkb, (int)y_kb0, (int)a_nkb, (int)a_kb0};
+  // the same schedules as usf_wgrad_planes_f32 (one block per CU where the tiles allow it, else the plain grid)
+  const bool balanced = wp_env("USF_WGRAD_SCHED", 1) != 0 && wp_schedule(M, N, K, true, 0, a.sched) &&
+                        (int64_t)wp_max_parts(a.sched) * N * (K + 1) <= workspace_floats;
+  if (!balanced && !wp_schedule(M, N, K, false, wp_plain_splits(M, N, K), a.sched)) {
+    set_error("usf_wgrad_blocked_f32: no schedule for M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+    return -2;
+  }
+  if ((int64_t)wp_max_parts(a.sched) * N * (K + (colsum_out ? 1 : 0)) > workspace_floats) {
+    set_error("usf_wgrad_blocked_f32: workspace too small (%lld < %lld floats)", (long long)workspace_floats,
+              (long long)wp_max_parts(a.sched) * N * (K + 1));
+    return -4;
+  }
+  if (colsum_out) a.cs_part = workspace + (int64_t)wp_max_parts(a.sched) * N * K;
+  wgrad_planes_kernel<true><<<(unsigned)(a.sched.per_xcd * 8), 512, 0, stream>>>(a);
+  int64_t rb = (N * K + 255) / 256;
+  if (rb > 4096) rb = 4096;
+  reduce_partials_cls_kernel<<<(unsigned)rb, 256, 0, stream>>>(workspace, a.sched, N, K, G, ldg, alpha, beta, a.cs_part, colsum_out,
+                                                                cs_alpha, cs_beta);
+  return check_launch("usf_wgrad_blocked_f32");
 }
 
 // tuning aid (tools/exp_wgradp.hip): the schedule in words

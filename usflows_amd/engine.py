@@ -302,6 +302,11 @@ class FlowEngine:
         self.use_planes = None if env_planes == "auto" else env_planes != "0"
         self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
         self.planes_min_rows_bf16x3 = 24576
+        # training on the planes pipeline (round 5): the forward keeps every layer's planes buffer and the conditioners' hidden
+        # activations as planes, the backward runs on usf_gemm_planes_bf16x3 / usf_coupling_planes (gate mode) /
+        # usf_wgrad_blocked_f32.  USFLOWS_AMD_TRAIN_PLANES=0 keeps the fp32-row path of rounds 3 / 4.
+        self.use_train_planes = os.environ.get("USFLOWS_AMD_TRAIN_PLANES", "1") != "0"
+        self.train_planes_min_rows = 16384
         self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
         self.graph_max_rows = 1024
         self._layout_from_masks()
@@ -865,7 +870,7 @@ class FlowEngine:
         pk = self.pack(device)
         with self._pk_record(pk), _ext.batch_jobs(device):
             if self._planes_ok(direction, B, has_ctx, train):
-                return self._build_plan_planes(direction, B, device, final)
+                return self._build_plan_planes(direction, B, device, final, train)
             return self._build_plan_body(direction, B, device, has_ctx, final, train)
 
     def _build_plan_body(self, direction: str, B: int, device, has_ctx: bool, final: str, train: bool = False) -> dict:
@@ -1182,7 +1187,14 @@ class FlowEngine:
             use = self.gemm_mode == "f16x2" or B >= self.planes_min_rows_bf16x3 or self._has_wide_conditioner()
         else:
             use = bool(self.use_planes)
-        if (train or has_ctx or not use or self._general_cond or self.gemm_mode not in ("bf16x3", "f16x2")
+        if train:
+            # the training step on the planes pipeline (round 5; training.py `_backward_planes`): log_prob plans in the bf16x3
+            # format whose couplings all run as ONE fused launch (conditioners of <= 2 hidden layers up to 256 wide), from
+            # train_planes_min_rows rows; every planes buffer below 2 GiB (usf_wgrad_blocked_f32's offsets)
+            use = (self.use_train_planes and direction == "backward" and self.gemm_mode == "bf16x3" and self.use_fused_coupling
+                   and B >= max(self.train_planes_min_rows, self.fused_min_rows)
+                   and (-(-B // 16)) * (self.LDp // 32) * 3072 < 2 ** 31 and self._train_planes_conditioners_ok())
+        if (has_ctx or not use or self._general_cond or self.gemm_mode not in ("bf16x3", "f16x2")
                 or B < self.planes_min_rows or (-(-B // 16)) * (self.LDp // 32) * 3072 >= 2 ** 32):
             return False
         # (the structure check does not depend on which runs are merged: a merged run is an affine step like its parts)
@@ -1196,6 +1208,17 @@ class FlowEngine:
         body = [k_ for k_ in kinds if not k_.startswith("scale")]
         # the last layer must be an affine (it writes the fp32 result) and the chain needs at least two GEMM-sized ops
         return len(body) >= 2 and body[-1].startswith("affine")
+
+    def _train_planes_conditioners_ok(self) -> bool:
+        for s_ in self.steps:
+            if s_.kind == "coupling":
+                cond = s_.module.conditioner
+                if not isinstance(cond, (ConditionalDenseNN, DenseNN)):
+                    return False
+                widths = [int(w) for w in cond.hidden_dims]
+                if len(widths) > 2 or max(widths) > 256:
+                    return False
+        return True
 
     def _has_wide_conditioner(self) -> bool:
         """a conditioner wider than 256 or deeper than 3 hidden layers: no fused coupling kernel serves it"""
@@ -1241,7 +1264,7 @@ class FlowEngine:
                                        lambda o, src=src, sel=sel_dev: o.copy_(self._perm_vec(src.double(), sel, pad)))
         return vecs[key]
 
-    def _build_plan_planes(self, direction: str, B: int, device, final: str) -> dict:
+    def _build_plan_planes(self, direction: str, B: int, device, final: str, train: bool = False) -> dict:
         """Launch list of the planes pipeline: pack -> (GEMM on planes)* -> GEMM with fp32 output.
 
         Every layer is the same kernel: an affine block one GEMM, an additive coupling the chain of its conditioner's
@@ -1252,7 +1275,7 @@ class FlowEngine:
         that hold its transformed features (zero rows elsewhere: those values are rewritten unchanged)."""
         pk = self.pack(device)
         ws = self._workspace(B, device)
-        prims = self._primitive_ops(direction, merge=True)
+        prims = self._primitive_ops(direction, merge=not train)     # (the training backward needs every block's own launch)
         npan = -(-B // 16)
         nkb = self.LDp // 32
         segp, natp = self.segp_idx, self.natp_idx
@@ -1269,10 +1292,16 @@ class FlowEngine:
                 ws[name] = torch.empty(npan * blocks * 3072, dtype=torch.uint8, device=device)     # (sized for either format)
             return ws[name]
 
-        zbufs = [planes_buf("pzA", nkb), planes_buf("pzB", nkb)]
+        # training: every affine output keeps a planes buffer of its own (the saved activations of the backward pass,
+        # already in operand form: (K + 1) x B x LDp x 6 bytes -- cfg2 at 65536 rows: 10.4 GB of the 288 GB), couplings update
+        # theirs in place (their conditioning half -- all the backward needs of them -- is untouched)
+        zbufs = [planes_buf("pzA", nkb), planes_buf("pzB", nkb)] if not train else [planes_buf("pz0", nkb), None]
+        znames = ["pzA", "pzB"] if not train else ["pz0", None]
+        n_z = [1]
         cur = 0
         ops: List[_ext.Op] = []
         patch_in, patch_out = [], []
+        meta: List[dict] = []
 
         def gemm_op(**kw) -> _ext.Op:
             op = _ext.Op()
@@ -1305,6 +1334,8 @@ class FlowEngine:
             k = 1
         patch_in.append((len(ops), "pack_planes", "src"))
         ops.append(pack)
+        head_scale = self._step(prims[0][1]).module if prims[0][0] == "scale_div" else None
+        head_bias_folded = first_bias_in_prologue
 
         while k < n:
             prim, i = prims[k]
@@ -1315,6 +1346,12 @@ class FlowEngine:
                 a = self._affine_entry(pk, blk)
                 fuse_post = prim == "affine_fwd" and nxt is not None and nxt[0] == "scale_mul"
                 is_last = (k == n - 1) or (fuse_post and k == n - 2)
+                if train:
+                    is_head = not any(m_["kind"] == "affine" for m_ in meta) and not any(m_["kind"] == "coupling" for m_ in meta)
+                    meta.append(dict(kind="affine", op=len(ops), prim=prim, blk=blk, in_buf=znames[cur], in_layout="segp",
+                                     out_layout="natp" if is_last else "segp", N=self.D if is_last else self.LD, K=self.LD,
+                                     pre_scale=head_scale if is_head else None, post_scale=None,
+                                     pre_sub_folded=bool(is_head and head_bias_folded), is_last=is_last))
                 out_sel = natp if is_last else segp
                 which = "Minv" if prim == "affine_bwd" else "M"
                 W = self._planes_image(pk, ("pl_aff", id(blk), which, is_last), a[which], out_sel, seg_phys, fmt)
@@ -1349,8 +1386,14 @@ class FlowEngine:
                         kw.update(C_f32=ws["nat2"].data_ptr(), ldc=self.LDn, N=self.D)
                         out_buf = ("nat2", "nat", self.LDn)
                 else:
+                    if train:
+                        znames[1 - cur] = f"pz{n_z[0]}"
+                        zbufs[1 - cur] = planes_buf(znames[1 - cur], nkb)
+                        n_z[0] += 1
                     kw.update(C_planes=zbufs[1 - cur].data_ptr(), c_nkb=nkb, c_kb0=0, c_kbn=nkb)
                     cur = 1 - cur
+                if train:
+                    meta[-1]["out_buf"] = out_buf[0] if is_last else znames[cur]
                 ops.append(gemm_op(**kw))
                 k += 1
                 continue
@@ -1394,9 +1437,20 @@ class FlowEngine:
                 c.W_out, c.ldw_out, c.w_out_plane = Wo.data_ptr(), Wo.shape[2], Wo.shape[1] * Wo.shape[2]
                 c.b_out = self._planes_vec(pk, ("pl_coutb", i), layers[-1][1], out_sel).data_ptr()
                 c.sign, c.slope, c.act, c.format, c.range_flag = sign, cp["slope"], cp["act"], fmt, flag
+                if train:
+                    # the lane-local splits of the hidden activations also go to planes buffers of the layer's own (8 blocks:
+                    # 2 x B x 256 x 6 bytes per coupling): operands of the conditioner's weight gradients, gates of its backward
+                    hnames = [f"pHs{j}_{i}" for j in range(len(h))]
+                    for j, hn in enumerate(hnames):
+                        c.hidden_out[j] = planes_buf(hn, 8).data_ptr()
+                    meta.append(dict(kind="coupling", op=len(ops), step=i, buf=znames[cur], sign=sign, use_ctx=False,
+                                     kb_p0=kb_p0, nk_p=kb_p1 - kb_p0, kb_t0=kb_t0, nk_t=kb_t1 - kb_t0, hidden_planes=hnames,
+                                     feat_p=feat_p, feat_t=feat_t))
                 ops.append(op)
                 k += 1
                 continue
+            if train:
+                raise EngineUnsupported("training on the planes pipeline needs the fused coupling launch")
             hbufs = [planes_buf("pH1", Hp // 32), planes_buf("pH2", Hp // 32)]
             src_buf, src_nkb, src_kb0, src_nk = z, nkb, kb_p0, kb_p1 - kb_p0
             in_sel = self._phys(feat_p[32 * kb_p0: 32 * kb_p1])
@@ -1429,7 +1483,7 @@ class FlowEngine:
 
         arr = (_ext.Op * len(ops))(*ops)
         return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=[], final_gather=None,
-                    out_buf=out_buf, ws=ws, pk=pk, meta=[], planes=True, planes_fmt=fmt)
+                    out_buf=out_buf, ws=ws, pk=pk, meta=meta, planes=True, planes_fmt=fmt, planes_train=bool(train))
 
     # fused coupling kernel availability (filled in when the kernel is present)
     def _fused_ok(self, cp) -> bool:
@@ -1598,7 +1652,7 @@ class FlowEngine:
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
                train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3,
-               (not train) and self._merge_on(direction))
+               (not train) and self._merge_on(direction), train and self.use_train_planes, train and self.train_planes_min_rows)
         plan = self._plans.get(key)
         if plan is None:
             plan = self._build_plan(direction, B, device, has_ctx, final, train)
