@@ -196,6 +196,9 @@ ALSO = [
 ]
 
 
+_TRAIN_WGRADS = ("usf_wgrad_f32", "usf_wgrad_bias_f32", "usf_wgrad_planes_f32", "usf_wgrad_blocked_f32")
+_TRAIN_TIMED = _TRAIN_WGRADS + ("usf_gemm_planes_bf16x3", "usf_coupling_planes", "usf_coupling_additive_f32", "usf_linear_f32",
+                                "usf_pack_planes_f32", "usf_run_ops", "usf_gemm_f64", "usf_pack_weights_f32", "usf_pack_weights_t_f32")
 ALSO_BUDGET_S = 150.0            # (measured: 37 s for all entries on an idle box)
 
 
@@ -406,7 +409,7 @@ def main_flat(args, under_launcher):
     op_records = []
     if on_gpu and not args.no_kernel_timing and mode == "train":
         from usflows_amd import _ext as _ext_t
-        _ext_t.launch_timing = {"usf_wgrad_f32": [], "usf_wgrad_bias_f32": [], "usf_wgrad_planes_f32": []}     # HIP events around every weight-gradient launch
+        _ext_t.launch_timing = {n_: [] for n_ in _TRAIN_TIMED}     # HIP events around every weight-gradient launch (+ the planes step's other classes)
     if under_launcher:
         dist.barrier()
     sync()
@@ -429,7 +432,8 @@ def main_flat(args, under_launcher):
         eng.op_timing = None
         if mode == "train" and not args.no_kernel_timing:
             from usflows_amd import _ext as _ext_t
-            wg_timing = [(e0, e1, a, fn) for fn in ("usf_wgrad_f32", "usf_wgrad_bias_f32", "usf_wgrad_planes_f32") for e0, e1, a in _ext_t.launch_timing[fn]]
+            wg_timing = [(e0, e1, a, fn) for fn in _TRAIN_WGRADS for e0, e1, a in _ext_t.launch_timing[fn]]
+            train_classes = {fn: (len(v), sum(e0.elapsed_time(e1) for e0, e1, _a in v)) for fn, v in _ext_t.launch_timing.items() if v}
             _ext_t.launch_timing = None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if under_launcher:
@@ -545,14 +549,19 @@ def main_flat(args, under_launcher):
         from usflows_amd import _ext as _ext_t
         shapes = {}
         for e0, e1, a, fn in wg_timing:
-            mnk = (int(a[8]), int(a[9]), int(a[10])) if fn == "usf_wgrad_planes_f32" else (int(a[4]), int(a[5]), int(a[6]))
+            mnk = ((int(a[8]), int(a[9]), int(a[10])) if fn == "usf_wgrad_planes_f32" else
+                   (int(a[6]), int(a[7]), int(a[8])) if fn == "usf_wgrad_blocked_f32" else (int(a[4]), int(a[5]), int(a[6])))
             shapes.setdefault(("usf_wgrad_f32" if fn == "usf_wgrad_bias_f32" else fn,) + mnk, []).append(e0.elapsed_time(e1))
         tot = {k: sum(v) for k, v in shapes.items()}
         dom = max(tot, key=tot.get)
         fn_, M_, N_, K_ = dom
         avg_ms = tot[dom] / len(shapes[dom])
         flops = 2.0 * M_ * N_ * K_
-        if fn_ == "usf_wgrad_planes_f32":
+        if fn_ == "usf_wgrad_blocked_f32":
+            bf = True
+            kname = ("wgrad_planes_kernel<blocked> (bf16x3, both operands the planes buffers of the planes pipeline; one block per CU) + "
+                     f"reduce_partials_cls_kernel: usf_wgrad_blocked_f32 N={N_} K={K_} over {M_} rows")
+        elif fn_ == "usf_wgrad_planes_f32":
             bf = True
             kname = ("wgrad_planes_kernel (bf16x3 from the operand planes the layer's GEMMs wrote; one block per CU) + "
                      f"reduce_partials_cls_kernel: usf_wgrad_planes_f32 N={N_} K={K_} over {M_} rows")
@@ -570,9 +579,24 @@ def main_flat(args, under_launcher):
                     "measured_by": f"HIP events around every {fn_} launch of this run's timed region",
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(shapes[dom]),
                     "algorithmic_flops_per_launch": flops,
-                    "wgrad_ms_per_step": {f"{k[2]}x{k[3]}" + (" (planes)" if k[0] == "usf_wgrad_planes_f32" else ""): round(v / args.steps, 3)
+                    "wgrad_ms_per_step": {f"{k[2]}x{k[3]}" + (" (planes)" if k[0] == "usf_wgrad_planes_f32" else
+                                                               " (blocked planes)" if k[0] == "usf_wgrad_blocked_f32" else ""): round(v / args.steps, 3)
                                           for k, v in tot.items()},
+                    "wgrad_frac_by_shape": {f"{k[2]}x{k[3]}": round(2.0 * k[1] * k[2] * k[3] / (v / len(shapes[k]) * 1e-3) / 1e12 / peak, 3)
+                                            for k, v in tot.items()},
+                    "launch_classes_ms_per_step": {fn: round(ms_ / args.steps, 3) for fn, (_n, ms_) in train_classes.items()},
                     "wgrad_share_of_step": round(sum(tot.values()) / args.steps / ms_per_step, 3)}
+    if roofline is not None and on_gpu and roofline.get("bound") == "mfma" and "bf16" in str(roofline.get("peak_is", "")):
+        # the ceiling this part SUSTAINS for the kernels' matrix-core instruction mix, measured in THIS run right behind the timed
+        # region (usf_mfma_probe: a register-only loop of v_mfma_f32_16x16x32_bf16 at the GEMM's occupancy and tiling; under
+        # dense MFMA load the chip is power-bound and its clock sits below the 2.4 GHz the nominal 2.5 PFLOP/s assume)
+        from usflows_amd import _ext as _ext_p
+        pr = _ext_p.mfma_probe(dev, iters=400, repeats=5)
+        roofline["sustained_peak"] = round(pr["tflops_f32_equiv"], 1)
+        roofline["frac_of_sustained"] = round(roofline["achieved"] / pr["tflops_f32_equiv"], 4)
+        roofline["sustained_peak_is"] = (f"usf_mfma_probe in this run: register-only loop of the planes GEMM's MFMA mix, {pr['tflops_bf16']:.0f} TFLOP/s "
+                                         f"bf16 = {pr['tflops_bf16'] / BF16_MFMA_PEAK_TFLOPS:.2f} of nominal, / 6 products per fp32 product; "
+                                         f"median of {pr['launches']} launches of {pr['ms']:.2f} ms")
     # whole-flow algorithmic FLOP rate (mask-aware count)
     hs = list(hidden)
     flop_per_sample = (blocks * (2 if args.conj else 1) + 1) * 2.0 * D * D + blocks * 2.0 * (

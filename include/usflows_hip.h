@@ -846,6 +846,13 @@ int usf_affine_prep_bwd_f32(const float* save, const float* bias, const float* v
                             const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dL_raw, float* dU_raw, float* dbias,
                             float* dvk, usf_stream_t stream);
 
+/* Measurement aid (bench.py: roofline.sustained_peak): ONE launch of a register-only loop of the planes GEMM's matrix-core
+ * instruction mix (v_mfma_f32_16x16x32_bf16, 10 x 2 accumulator tiles, six products per fp32-equivalent product; 512 threads,
+ * two waves per SIMD; no LDS, no memory traffic in the loop) -- `iters` slabs of 120 MFMAs per wave on `blocks` blocks
+ * (0: two per CU).  src1024: 1024 finite floats (device); sink: one float (device, never written); *flops_out (host, may be
+ * NULL): the bf16 MFMA flops of the launch (fp32-equivalent: / 6).  The caller times the launch with events on `stream`. */
+int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, usf_stream_t stream);
+
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;
                                            usf_pack_planes_desc|usf_gemm_planes_desc|usf_coupling_planes_desc|usf_mt_chunk|usf_gated_norm_desc for 5|6|7|8|9,

@@ -213,16 +213,96 @@ def emulate_coupling_planes(d, pm: PtrMap, dtype=torch.float32):
         slot = torch.tensor([32 * (c // 32) + _SLOT_OF_FEATURE[c % 32] for c in range(K)])
         return W[:, :K][:, slot]
 
-    act = (lambda v: torch.where(v > 0, v, v * d.slope)) if d.act == _ext.ACT_LEAKY_RELU else (lambda v: v)
+    gated = d.act == _ext.ACT_GATE
+
+    def act(v, l):
+        if gated:      # leaky_relu_backward from the saved activations (only plane 0 of gate[l] is read)
+            hv = planes_view(pm, d.gate[l], npan, 8, fmt)[:, :, :1]
+            h0 = planes_decode(torch.cat([hv, torch.zeros_like(hv)], dim=2), M)
+            v = torch.where(h0.to(dtype) > 0, v, v * d.slope)
+        elif d.act == _ext.ACT_LEAKY_RELU:
+            v = torch.where(v > 0, v, v * d.slope)
+        if d.hidden_out[l]:
+            planes_encode(planes_view(pm, d.hidden_out[l], npan, 8, fmt), v.to(torch.float32), 0)
+        return v
+
     A = Z[:, 32 * d.kb_p0: 32 * (d.kb_p0 + d.nk_p)].to(dtype)
-    h = act(A @ weights(d.W_in, 256, d.ldw_in, d.w_in_plane, 32 * d.nk_p).to(dtype).t() + pm.vec(d.b_in, 256).to(dtype))
+    h = act(A @ weights(d.W_in, 256, d.ldw_in, d.w_in_plane, 32 * d.nk_p).to(dtype).t() + pm.vec(d.b_in, 256).to(dtype), 0)
     for j in range(d.n_hidden - 1):
-        h = act(h @ weights(d.W_hid[j], 256, d.ldw_hid, d.w_hid_plane, 256).to(dtype).t() + pm.vec(d.b_hid[j], 256).to(dtype))
+        h = act(h @ weights(d.W_hid[j], 256, d.ldw_hid, d.w_hid_plane, 256).to(dtype).t() + pm.vec(d.b_hid[j], 256).to(dtype), j + 1)
     out = h @ weights(d.W_out, 32 * d.nk_t, d.ldw_out, d.w_out_plane, 256).to(dtype).t() + pm.vec(d.b_out, 32 * d.nk_t).to(dtype)
     v = Z[:, 32 * d.kb_t0: 32 * (d.kb_t0 + d.nk_t)].to(dtype) + d.sign * out
     if fmt == 1 and d.range_flag and not bool((v.abs() < 65000.0).all() and (h.abs() < 65000.0).all()):
         pm.view(d.range_flag, 1, 1, 1, dtype=torch.int32)[0, 0] = 1
     planes_encode(zv, v.to(torch.float32), d.kb_t0)
+
+
+# ---- direct calls of the planes entry points (the training backward on the planes pipeline, training.py) ----------------
+def _tensor_planes_view(t, M, nkb):
+    npan = -(-M // 16)
+    return t.view(-1)[: npan * nkb * 3072].view(torch.bfloat16).view(npan, nkb, 3, 64, 8)
+
+
+def _emu_pack_planes_call(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None, fmt=0, range_flag=None):
+    ld = src.stride(0) if ld is None else ld
+    idx = idx.long()
+    rows = torch.as_strided(src, (M, int(idx.max()) + 1), (ld, 1), src.storage_offset())
+    X = torch.zeros(M, 32 * nkb)
+    ok = idx >= 0
+    X[:, ok] = rows[:, idx[ok]]
+    if pre_div is not None:
+        X[:, ok] = X[:, ok] / pre_div[ok]
+    if pre_sub is not None:
+        X[:, ok] = X[:, ok] - pre_sub[ok]
+    planes_encode(_tensor_planes_view(planes, M, nkb), X, 0)
+
+
+def _planes_weight(W_planes, K):
+    W = W_planes[0].float() + W_planes[1].float() + W_planes[2].float()
+    slot = torch.tensor([32 * (c // 32) + _SLOT_OF_FEATURE[c % 32] for c in range(K)])
+    return W[:, :K][:, slot]
+
+
+def _emu_gemm_planes_call(A, W_planes, *, M, a_nkb, nk, a_kb0=0, bias=None, post_mul=None, residual=None, C_planes=None, c_nkb=0,
+                          c_kb0=0, c_kbn=0, C_f32=None, ldc=0, N=0, res_sign=1.0, act=0, slope=0.0, fmt=0, range_flag=None):
+    assert fmt == 0 and residual is None and C_f32 is None and post_mul is None
+    Am = planes_decode(_tensor_planes_view(A, M, a_nkb), M)[:, 32 * a_kb0: 32 * (a_kb0 + nk)].double()
+    v = Am @ _planes_weight(W_planes, 32 * nk).double().t()
+    if bias is not None:
+        v = v + bias.double()
+    if act == _ext.ACT_LEAKY_RELU:
+        v = torch.where(v > 0, v, v * slope)
+    planes_encode(_tensor_planes_view(C_planes, M, c_nkb), v[:, : 32 * c_kbn].float(), c_kb0)
+
+
+def _emu_wgrad_blocked(Yp, y_nkb, y_kb0, Ap, a_nkb, a_kb0, G, *, M, N, K, ldg, g_off=0, alpha=1.0, beta=0.0, colsum=None,
+                       cs_alpha=1.0, cs_beta=0.0):
+    Y = planes_decode(_tensor_planes_view(Yp, M, y_nkb), M)[:, 32 * y_kb0: 32 * y_kb0 + N].double()
+    A = planes_decode(_tensor_planes_view(Ap, M, a_nkb), M)[:, 32 * a_kb0: 32 * a_kb0 + K].double()
+    g = _view(G, g_off, N, K, ldg)
+    r = alpha * (Y.t() @ A)
+    g.copy_((r + beta * g.double() if beta != 0.0 else r).float())
+    if colsum is not None:
+        c = cs_alpha * Y.sum(0)
+        cv = colsum.view(-1)[:N]
+        cv.copy_((c + cs_beta * cv.double() if cs_beta != 0.0 else c).float())
+
+
+_LAST_RUN = {}
+
+
+def _emu_coupling_planes_op(op, device):
+    eng, plan = _LAST_RUN["eng"], _LAST_RUN["plan"]
+    pm = PtrMap()
+    for t in plan["ws"].values():
+        pm.add(t)
+    for group in ("mats", "vecs"):
+        for t in plan["pk"][group].values():
+            pm.add(t)
+    for cp in plan["pk"]["coupling"].values():
+        if "planes_bwd" in cp:
+            pm.add(cp["planes_bwd"]["zeros"])
+    emulate_coupling_planes(op.u.coupling_planes, pm, torch.float64)
 
 
 def _gather(src, dst, idx):
@@ -234,6 +314,7 @@ def _gather(src, dst, idx):
 
 def run_plan(eng, plan, x, out, context=None, dtype=torch.float32):
     """CPU stand-in for FlowEngine._execute."""
+    _LAST_RUN.update(eng=eng, plan=plan)
     ws, pk = plan["ws"], plan["pk"]
     pm = PtrMap()
     for t in ws.values():
@@ -508,6 +589,10 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "base_logprob", _emu_base_logprob)
     monkeypatch.setattr(_ext, "base_logprob_grad", _emu_base_logprob_grad)
     monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
+    monkeypatch.setattr(_ext, "pack_planes", _emu_pack_planes_call)
+    monkeypatch.setattr(_ext, "gemm_planes", _emu_gemm_planes_call)
+    monkeypatch.setattr(_ext, "wgrad_blocked", _emu_wgrad_blocked)
+    monkeypatch.setattr(_ext, "coupling_planes_op", _emu_coupling_planes_op)
     monkeypatch.setattr(FlowEngine, "_check_input", lambda self, x: x.contiguous().float())
     monkeypatch.setattr(FlowEngine, "_execute_plain",
                         lambda self, plan, x, out, context: run_plan(self, plan, x, out, context, dtype=torch.float64))

@@ -289,6 +289,7 @@ def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch, variant)
     gradient within 1e-4 of its largest entry of the path with all four switched off, which the tests above pin against the oracle and the
     reference's goldens -- the operand planes and the saved activations also on their own."""
     from usflows_amd import _ext
+    monkeypatch.setenv("USFLOWS_AMD_TRAIN_PLANES", "0")       # (this test: the fp32-row path, which still serves context / f32 mode / wide conditioners)
     spec, sd, _a = load_case("synth_d784_k32_cfg2")
     n_cpl = 32
     if variant in ("conj8", "hh8"):                             # affine_conjugation: every block also in its M form (what the live configs
@@ -411,3 +412,111 @@ def test_fused_coupling_backward_for_one_to_three_hidden_layers(monkeypatch, hid
         big = grads[1][n].abs().max().item()
         diff = (grads[0][n] - grads[1][n]).abs()
         assert int((diff > 1e-4 * big + 1e-12).sum().item()) <= max(2, int(1e-3 * diff.numel())), n
+
+
+# ---- round 5: the training step on the planes pipeline -----------------------------------------------------------------------
+def _cfg2_like(blocks, seed=5, **kw):
+    import copy
+    from usflows_amd.synth import synth_state_dict
+    spec, _sd, _a = load_case("synth_d784_k32_cfg2")
+    spec = copy.copy(spec)
+    spec.coupling_blocks = blocks
+    for k_, v_ in kw.items():
+        setattr(spec, k_, v_)
+    return spec, synth_state_dict(spec, seed=seed, alpha=0.1)
+
+
+def _compare_large(flow, g_ref, linear):
+    """every parameter gradient against the oracle's.  linear (negative_slope = 1: the conditioners have no kink): 2e-4 of each
+    tensor's largest entry, no exception.  Otherwise a hidden unit whose pre-activation is within fp32 noise of zero sits on
+    the other LeakyReLU branch than in fp64 -- ~1e-6 of the units, i.e. a few per conditioner layer at these batches -- and
+    moves that sample's contribution (~1 / sqrt(B) of an entry's sum) in a whole row of the layer's weight gradient and, diluted,
+    in the layers in front: entries may miss 5e-4 in up to 2 % of a tensor, none by more than 5 % of its largest entry, and the
+    tensor as a whole agrees to 3e-3 in the Frobenius norm (a wrong index map / sign / missing term gives O(1) there)."""
+    n = 0
+    for pname, p in flow.named_parameters():
+        ref = g_ref.get(pname)
+        if not p.requires_grad or ref is None or ref.abs().max().item() == 0.0:
+            continue
+        assert p.grad is not None, f"no gradient for {pname}"
+        got = p.grad.cpu().double()
+        diff = (got - ref.reshape(p.shape)).abs()
+        big = ref.abs().max().item()
+        if linear:
+            assert diff.max().item() <= 2e-4 * big, (pname, diff.max().item(), big)
+        else:
+            n_bad = int((diff > 5e-4 * big).sum().item())
+            assert n_bad <= max(2, int(2e-2 * diff.numel())), (pname, n_bad, diff.numel())
+            assert diff.max().item() <= 0.05 * big, (pname, diff.max().item(), big)
+            assert (diff.norm() / ref.norm()).item() <= 3e-3, (pname, (diff.norm() / ref.norm()).item())
+        n += 1
+    return n
+
+
+@pytest.mark.parametrize("B,force,kw", [(8192, True, {}), (8192, True, dict(negative_slope=1.0)), (16400, False, {}),
+                                        (16400, False, dict(negative_slope=1.0)),
+                                        (8200, True, dict(affine_conjugation=True, householder=1, negative_slope=1.0)),
+                                        (8200, True, dict(affine_conjugation=True, householder=1)),
+                                        (8192, True, dict(hidden_dims=[200]))])
+def test_planes_training_backward_matches_oracle_autograd_at_d784(B, force, kw):
+    """D = 784, K = 4 (the BASELINE cfg2 layer shapes), >= 8192 rows: ONE backward pass of the planes training path
+    (usf_gemm_planes_bf16x3 / usf_coupling_planes gate mode / usf_wgrad_blocked_f32) held DIRECTLY against fp64 autograd through
+    the oracle's restatement of Flow.log_prob (flows.py:196-203) -- no link through another device path.  Also with
+    affine_conjugation + Householder blocks (the constructor's defaults / the live configurations) and a one-layer conditioner;
+    with negative_slope = 1 (no kinks: every launch's linear algebra, index map and the chain rule at the tight tolerance) and
+    with the BASELINE's LeakyReLU(0.01) (the gates; tolerance for branch flips at fp32 noise, see _compare_large)."""
+    spec, sd = _cfg2_like(4, **kw)
+    flow = build_flow(spec, sd, device=DEV)
+    eng = flow.engine()
+    if force:
+        eng.train_planes_min_rows = eng.fused_min_rows = 0
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 784, generator=g)
+    g_lp = torch.randn(B, generator=g) / B
+    before = eng.launch_count
+    lp = flow.log_prob(x.to(DEV))
+    assert lp.requires_grad and eng.launch_count > before
+    plan = eng._plan("backward", B, torch.device(DEV), False, "nat", train=True)
+    assert plan.get("planes_train"), "the planes training plan was not chosen"
+    (lp * g_lp.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    lp_ref, g_ref = oracle_grads(spec, sd, x, g_lp)
+    assert ((lp.detach().cpu().double() - lp_ref).abs() / lp_ref.abs()).max().item() < 1e-5
+    assert _compare_large(flow, g_ref, linear=kw.get("negative_slope") == 1.0) >= 20
+    # the replayed pass (recorded launches) gives the same bits
+    first = {n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None}
+    for p in flow.parameters():
+        p.grad = None
+    lp2 = flow.log_prob(x.to(DEV))
+    (lp2 * g_lp.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(lp2.detach(), lp.detach())
+    for n, p in flow.named_parameters():
+        if n in first:
+            assert torch.equal(p.grad, first[n]), n
+
+
+def test_planes_training_path_equals_the_fp32_row_path(monkeypatch):
+    """the planes training path against the round-4 path (pinned above and in the tests before) on the full 32-block cfg2
+    model at 16400 rows: the same gradients up to summation order / a handful of LeakyReLU kink flips"""
+    spec, sd, _a = load_case("synth_d784_k32_cfg2")
+    x = torch.rand(16400, 784, generator=torch.Generator().manual_seed(3)).to(DEV)
+    res = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("USFLOWS_AMD_TRAIN_PLANES", on)
+        flow = build_flow(spec, sd, device=DEV)
+        lp = flow.log_prob(x)
+        plan = flow.engine()._plan("backward", 16400, torch.device(DEV), False, "nat", train=True)
+        assert bool(plan.get("planes_train")) == (on == "1")
+        (-lp.mean()).backward()
+        torch.cuda.synchronize()
+        res.append(({n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None}, lp.detach()))
+    (g0, lp0), (g1, lp1) = res
+    assert ((lp0 - lp1).abs() / lp0.abs()).max().item() < 2e-6
+    assert g0.keys() == g1.keys() and len(g0) > 100
+    for n in g0:
+        big = g0[n].abs().max().item()
+        diff = (g0[n] - g1[n]).abs()
+        n_bad = int((diff > 1e-4 * big + 1e-12).sum().item())
+        assert n_bad <= max(2, int(1e-3 * diff.numel())), (n, n_bad, diff.numel())
+        assert diff.max().item() <= 1e-3 * big + 1e-12, (n, diff.max().item(), big)

@@ -235,6 +235,7 @@ SYMBOLS = {
                                        _fp, C.c_int64, _fp]),
     "usf_wgrad_blocked_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp,
                                         C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
+    "usf_mfma_probe": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
     "usf_wgrad_planes_colsum_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
@@ -1004,6 +1005,33 @@ def gather_cols(src, lds, dst, ldd, M, n, idx):
 def coupling_op(op, device):
     """one usf_coupling_additive_f32 launch from an Op built by the engine (its descriptor; taped like every launch)"""
     _launch("usf_coupling_additive_f32", (C.byref(op.u.coupling), current_stream(device)), op)
+
+
+def mfma_probe(device, iters: int = 400, repeats: int = 5) -> dict:
+    """usf_mfma_probe timed with HIP events on torch's current stream: what the part sustains on the bf16 matrix cores for
+    the planes GEMM's instruction mix (register-only loop).  Returns TFLOP/s of bf16 MFMA work and the fp32-equivalent (/ 6);
+    the median of `repeats` launches after one warm-up."""
+    src = torch.rand(1024, device=device) + 0.5
+    sink = torch.zeros(1, device=device)
+    flops = C.c_double(0.0)
+    times = []
+    for i in range(repeats + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(load().usf_mfma_probe(src.data_ptr(), sink.data_ptr(), iters, 0, C.byref(flops), current_stream(device)), "usf_mfma_probe")
+        e1.record()
+        e1.synchronize()
+        if i:
+            times.append(e0.elapsed_time(e1))
+    times.sort()
+    ms = times[len(times) // 2]
+    tf = flops.value / (ms * 1e-3) / 1e12
+    return dict(ms=ms, tflops_bf16=tf, tflops_f32_equiv=tf / 6.0, iters=iters, launches=repeats)
+
+
+def coupling_planes_op(op, device):
+    """one usf_coupling_planes launch from an Op built by the engine (taped like every launch)"""
+    _launch("usf_coupling_planes", (C.byref(op.u.coupling_planes), current_stream(device)), op)
 
 
 def run_ops(ops_array, n, device=None):

@@ -112,6 +112,7 @@ int wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K);
 int wgrad_blocked(const void* Yp, int64_t y_nkb, int64_t y_kb0, const void* Ap, int64_t a_nkb, int64_t a_kb0, int64_t M, int64_t N,
                   int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out, float cs_alpha, float cs_beta,
                   float* workspace, int64_t workspace_floats, hipStream_t stream);
+int mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, hipStream_t stream);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
 int act_grad(float* d, int64_t ldd, const float* h, int64_t ldh, int64_t M, int64_t H, int32_t act, float slope,
@@ -361,6 +362,9 @@ int usf_wgrad_blocked_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, co
                           float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::wgrad_blocked(Y_planes, y_nkb, y_kb0, A_planes, a_nkb, a_kb0, M, N, K, G, ldg, alpha, beta, colsum_out, cs_alpha,
                             cs_beta, workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, usf_stream_t stream) {
+  return usf::mfma_probe(src1024, sink, iters, blocks, flops_out, (hipStream_t)stream);
 }
 int usf_wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_colsum_ok(M, N, K); }
 int64_t usf_wgrad_planes_workspace_floats(int64_t M, int64_t N, int64_t K) { return usf::wgrad_planes_workspace_floats(M, N, K); }

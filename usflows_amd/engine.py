@@ -1230,11 +1230,11 @@ class FlowEngine:
                     return True
         return False
 
-    def _planes_image(self, pk, key, src, out_sel: torch.Tensor, in_sel: torch.Tensor, fmt: int = 0):
-        """cached weight planes of src[out_sel][:, in_sel] (-1: zero), one queued launch: [3, rows, cols] bf16
-        (bf16x3) or [2, rows, cols] fp16 (fp16x2)"""
+    def _planes_image(self, pk, key, src, out_sel: torch.Tensor, in_sel: torch.Tensor, fmt: int = 0, transpose: bool = False):
+        """cached weight planes of src[out_sel][:, in_sel] (-1: zero; transpose: of src[in_sel][:, out_sel]^T), one queued
+        launch: [3, rows, cols] bf16 (bf16x3) or [2, rows, cols] fp16 (fp16x2)"""
         mats = pk["mats"]
-        key = key + (fmt,)
+        key = key + (fmt,) + (("T",) if transpose else ())
         if key not in mats:
             dev = src.device
             n_out, n_in = int(out_sel.numel()), int(in_sel.numel())
@@ -1243,9 +1243,75 @@ class FlowEngine:
             else:
                 P = torch.empty(3, n_out, n_in, dtype=torch.bfloat16, device=dev)
             _ext.pack_weight(src, out_sel.to(device=dev, dtype=torch.int32), n_out,
-                             in_sel.to(device=dev, dtype=torch.int32), n_in, planes=P)
+                             in_sel.to(device=dev, dtype=torch.int32), n_in, planes=P, transpose=transpose)
             mats[key] = P
         return mats[key]
+
+    # ---- training on the planes pipeline: the backward launches' weight images (training.py `_backward_body_planes`) ----
+    def planes_dgrad_image(self, pk, m) -> torch.Tensor:
+        """weight planes of an affine layer's data gradient g_in = g_out W as a usf_gemm_planes_bf16x3 operand: rows = the
+        positions of the layer's INPUT layout (segp), K axis = the slots of its OUTPUT layout"""
+        blk = m["blk"]
+        which = "Minv" if m["prim"] == "affine_bwd" else "M"
+        out_phys = self._phys(self.natp_idx if m["out_layout"] == "natp" else self.segp_idx)
+        return self._planes_image(pk, ("pl_aff_t", id(blk), which, m["out_layout"]), self._affine_entry(pk, blk)[which],
+                                  self.segp_idx, out_phys, _ext.PLANES_BF16X3, transpose=True)
+
+    def planes_coupling_bwd(self, pk, m) -> dict:
+        """the conditioner's weights for usf_coupling_planes run BACKWARDS (USF_ACT_GATE): W_in = W_last^T [256, slots of the
+        transformed blocks], hidden matrices reversed and transposed, W_out = W_first^T [positions of the conditioning blocks,
+        256], zero biases"""
+        i = m["step"]
+        cp = pk["coupling"][i]
+        if "planes_bwd" in cp:
+            return cp["planes_bwd"]
+        raw = cp["raw"]
+        h = list(raw["h"])
+        layers = [raw["first"]] + list(raw["hidden"]) + [raw["last"]]
+        fmt = _ext.PLANES_BF16X3
+
+        def pad256(n_valid):
+            t = torch.full((256,), -1, dtype=torch.long)
+            t[:n_valid] = torch.arange(n_valid)
+            return t
+        ft = m["feat_t"][32 * m["kb_t0"]: 32 * (m["kb_t0"] + m["nk_t"])]
+        fp = m["feat_p"][32 * m["kb_p0"]: 32 * (m["kb_p0"] + m["nk_p"])]
+        dev = raw["device"]
+        f = dict(zeros=torch.zeros(max(256, int(fp.numel())), dtype=torch.float32, device=dev), hid=[])
+        f["W_in"] = self._planes_image(pk, ("pl_cin_t", i), layers[-1][0], pad256(h[-1]), self._phys(ft), fmt, transpose=True)
+        for j in range(len(h) - 1, 0, -1):        # forward hidden matrix j maps layer j - 1 -> j: backwards j -> j - 1
+            f["hid"].append(self._planes_image(pk, ("pl_chid_t", i, j), layers[j][0], pad256(h[j - 1]), self._phys(pad256(h[j])),
+                                               fmt, transpose=True))
+        f["W_out"] = self._planes_image(pk, ("pl_cout_t", i), layers[0][0], fp, self._phys(pad256(h[0])), fmt, transpose=True)
+        cp["planes_bwd"] = f
+        return f
+
+    def planes_coupling_bwd_op(self, pk, m, g, g_nkb: int, B: int, gates, d_out) -> _ext.Op:
+        """ONE launch for the data-gradient chain of a coupling layer's conditioner on the gradient planes buffer g:
+        g[:, conditioning blocks] += sign * MLP^T(g[:, transformed blocks]); gates / d_out: planes buffers (8 blocks per panel)
+        in the FORWARD's layer order -- the saved activations resp. the gradients at the pre-activations"""
+        cp = pk["coupling"][m["step"]]
+        f = self.planes_coupling_bwd(pk, m)
+        nl = len(cp["hidden"])
+        op = _ext.Op()
+        op.kind = _ext.OP_COUPLING_PLANES
+        c = op.u.coupling_planes
+        c.z, c.z_nkb, c.M = g.data_ptr(), g_nkb, B
+        c.kb_p0, c.nk_p, c.kb_t0, c.nk_t = m["kb_t0"], m["nk_t"], m["kb_p0"], m["nk_p"]      # the roles of the block ranges swap
+        c.n_hidden, c.hidden_padded = nl, 256
+        z = f["zeros"].data_ptr()
+        Wi = f["W_in"]
+        c.W_in, c.ldw_in, c.w_in_plane, c.b_in = Wi.data_ptr(), Wi.shape[2], Wi.shape[1] * Wi.shape[2], z
+        for j, Wh in enumerate(f["hid"]):
+            c.W_hid[j], c.b_hid[j] = Wh.data_ptr(), z
+            c.ldw_hid, c.w_hid_plane = Wh.shape[2], Wh.shape[1] * Wh.shape[2]
+        Wo = f["W_out"]
+        c.W_out, c.ldw_out, c.w_out_plane, c.b_out = Wo.data_ptr(), Wo.shape[2], Wo.shape[1] * Wo.shape[2], z
+        c.sign, c.slope, c.act, c.format, c.range_flag = m["sign"], cp["slope"], _ext.ACT_GATE, _ext.PLANES_BF16X3, 0
+        for l in range(nl):
+            c.gate[l] = gates[nl - 1 - l].data_ptr()
+            c.hidden_out[l] = d_out[nl - 1 - l].data_ptr()
+        return op
 
     def _planes_vec(self, pk, key, src, sel: torch.Tensor, pad: float = 0.0) -> torch.Tensor:
         """cached fp32 vector src[sel] (-1: pad) of length len(sel)"""

@@ -386,6 +386,8 @@ class TrainPath:
         return ar
 
     def _backward_body(self, plan, arena):
+        if plan.get("planes_train"):
+            return self._backward_body_planes(plan, arena)
         eng = self.eng
         ws, pk = plan["ws"], plan["pk"]
         dev = ws["zA"].device
@@ -439,6 +441,170 @@ class TrainPath:
                     self._coupling_backward(plan, m, g_cur, g_ld, grads)
                     self._g_pending = self._defer
         _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
+
+    # ---- the backward pass on the planes pipeline (round 5) -----------------------------------------------------------
+    # The forward ran as the inference pipeline does -- usf_pack_planes_f32, usf_gemm_planes_bf16x3, usf_coupling_planes --
+    # with every affine output in a planes buffer of its own and the conditioners' hidden activations saved as planes
+    # (engine._build_plan_planes(train=True)).  Backwards, layer by layer on a pair of gradient planes buffers:
+    #   affine    usf_wgrad_blocked_f32 (gradient planes x saved input planes; the bias gradient from the same pass), then the
+    #             data gradient = usf_gemm_planes_bf16x3 on the transposed weight planes
+    #   coupling  ONE usf_coupling_planes launch in gate mode (the conditioner's transposed chain with leaky_relu_backward
+    #             from the saved activations; it leaves the gradients at the pre-activations as planes), then the three
+    #             weight gradients on usf_wgrad_blocked_f32
+    # No fp32 row buffer and no operand split anywhere in the loop; the parameter-sized chain rule is the one above.
+    def _planes_buf(self, ws, name, B, blocks):
+        n = (-(-B // 16)) * blocks * 3072
+        t = ws.get(name)
+        if t is None or t.numel() < n:
+            t = ws[name] = torch.zeros(n, dtype=torch.uint8, device=ws["zA"].device)
+        return t
+
+    def _backward_body_planes(self, plan, arena):
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        dev = ws["zA"].device
+        B = ws["zA"].shape[0]
+        D = eng.D
+        nkb = eng.LDp // 32
+        nkb_g = max(eng.LDp, eng.LDnp) // 32
+        wid = max(eng.LD, eng.LDn)
+        gA = self._buf(ws, "gA", B, wid)
+        glp = self._buf(ws, "g_lp", 1, B)[0, :B]
+        _ext.host_op(lambda: (arena["flat"].zero_(), glp.copy_(self._cur["g_lp"])))
+        info = self.flow._base_info(dev)
+        base, loc, scale = self._base_ids(info)
+        zname, _, ldn = plan["out_buf"]
+        grads = arena["views"]
+        self._touched = arena["touched"]
+        if info[0] == "radial":
+            scale = self._buf(ws, "radius", 1, B)[0, :B]
+        _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, loc, scale, gA, ldn)
+        if info[0] == "radial":
+            g_loc = self._grad_slot(grads, self.flow.base_distribution.loc)
+            if g_loc is not None:
+                _ext.colsum(gA, g_loc, M=B, N=D, ldy=ldn, alpha=-1.0)
+        gp = [self._planes_buf(ws, "pgA", B, nkb_g), self._planes_buf(ws, "pgB", B, nkb_g)]
+        key = ("natp_g", nkb_g, str(dev))
+        if key not in self._inv:
+            t = torch.full((32 * nkb_g,), -1, dtype=torch.int32)
+            t[:D] = torch.arange(D, dtype=torch.int32)
+            self._inv[key] = t.to(dev)
+        _ext.pack_planes(gA, gp[0], M=B, nkb=nkb_g, idx=self._inv[key], ld=ldn)
+        cur = 0
+        aff: Dict[int, dict] = {}
+        n_aff = sum(1 for m in plan["meta"] if m["kind"] == "affine")
+        stacks = dict(G=torch.zeros(max(n_aff, 1), D, D, dtype=torch.float32, device=dev),
+                      gs=torch.zeros(max(n_aff, 1), D, dtype=torch.float32, device=dev), next=0)
+        self._lu_slot = self._lu_slots(plan)
+        if self._lu_slot is not None and any(m["kind"] == "affine" and m["prim"] == "affine_fwd" for m in plan["meta"]):
+            stacks["GM"] = torch.zeros_like(stacks["G"])
+            stacks["gsM"] = torch.zeros_like(stacks["gs"])
+        first_meta = plan["meta"][0] if plan["meta"] else None
+        with eng._pk_record(pk), _ext.batch_jobs(dev):      # every weight image of the backward, one batched launch
+            for m in plan["meta"]:
+                if m["kind"] == "coupling":
+                    eng.planes_coupling_bwd(pk, m)
+                elif m is not first_meta:
+                    eng.planes_dgrad_image(pk, m)
+        self._defer = False
+        with _ext.batch_jobs(dev):
+            for m in reversed(plan["meta"]):
+                if m["kind"] == "affine":
+                    cur = self._affine_backward_planes(plan, m, gp, cur, nkb, nkb_g, aff, stacks, need_dgrad=(m is not first_meta))
+                else:
+                    self._coupling_backward_planes(plan, m, gp[cur], nkb, nkb_g, grads)
+        _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
+
+    def _affine_backward_planes(self, plan, m, gp, cur, nkb, nkb_g, aff, stacks, need_dgrad):
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        dev = ws["zA"].device
+        B = ws["zA"].shape[0]
+        D = eng.D
+        blk = m["blk"]
+        which = "Minv" if m["prim"] == "affine_bwd" else "M"
+        n_out, n_in = m["N"], m["K"]
+        wid = max(eng.LD, eng.LDn)
+        Gp = self._buf(ws, f"Gp{m['op']}", wid, wid)
+        gs = self._buf(ws, f"gs{m['op']}", 1, wid)
+        _ext.wgrad_blocked(gp[cur], nkb_g, 0, ws[m["in_buf"]], nkb, 0, Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1], colsum=gs)
+        k = self._lu_slot[id(blk)] if self._lu_slot is not None else stacks["next"]
+        stacks["next"] += 1
+        if self._lu_slot is not None and which == "M":
+            G_nat, gs_nat = stacks["GM"][k], stacks["gsM"][k]
+        else:
+            G_nat, gs_nat = stacks["G"][k], stacks["gs"][k]
+        _ext.pack_weight(Gp, self._inv_idx(m["out_layout"], dev), D, self._inv_idx(m["in_layout"], dev), D,
+                         W=G_nat, ldw=D, ld_src=Gp.shape[1])
+        _ext.pack_weight(gs, None, 1, self._inv_idx(m["out_layout"], dev), D, W=gs_nat, ldw=D, ld_src=gs.shape[1])
+        rec = aff.setdefault(id(blk), dict(blk=blk, uses=[]))
+        rec["uses"].append(dict(which=which, G=G_nat, gsum=gs_nat, pre_scale=m["pre_scale"], row=k,
+                                pre_sub_folded=bool(m.get("pre_sub_folded"))))
+        if not need_dgrad:
+            return cur
+        Wt = eng.planes_dgrad_image(pk, m)
+        nk = (eng.LDnp if m["out_layout"] == "natp" else eng.LDp) // 32
+        _ext.gemm_planes(gp[cur], Wt, M=B, a_nkb=nkb_g, nk=nk, C_planes=gp[1 - cur], c_nkb=nkb_g, c_kb0=0, c_kbn=nkb)
+        return 1 - cur
+
+    def _seg_sel(self, m, which: str, device) -> torch.Tensor:
+        """int32 [D]: feature -> position relative to the first block of the coupling's conditioning ('p') / transformed ('t')
+        block range (-1: the feature is not in that set)"""
+        key = ("segsel", m["step"], which, str(device))
+        if key not in self._inv:
+            feat = m["feat_p"] if which == "p" else m["feat_t"]
+            kb0 = m["kb_p0"] if which == "p" else m["kb_t0"]
+            sel = torch.full((self.eng.D,), -1, dtype=torch.int32)
+            for pos, f in enumerate(feat.tolist()):
+                if f >= 0:
+                    sel[f] = pos - 32 * kb0
+            self._inv[key] = sel.to(device)
+        return self._inv[key]
+
+    def _coupling_backward_planes(self, plan, m, g, nkb, nkb_g, grads):
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        cp = pk["coupling"][m["step"]]
+        cond = eng.steps[m["step"]].module.conditioner
+        raw = cp["raw"]
+        dev = raw["device"]
+        B = ws["zA"].shape[0]
+        h = list(raw["h"])
+        nl = len(h)
+        sign = m["sign"]
+        hs = [ws[n_] for n_ in m["hidden_planes"]]
+        dh = [self._planes_buf(ws, f"pD{j}", B, 8) for j in range(nl)]
+        _ext.coupling_planes_op(eng.planes_coupling_bwd_op(pk, m, g, nkb_g, B, hs, dh), dev)
+        lin = list(cond.layers)
+        has_ctx = isinstance(cond, ConditionalDenseNN)
+        first_l, last_l = lin[0], lin[-1]
+        hidden_l = lin[2:-1] if has_ctx else lin[1:-1]
+        wmax = max(eng.LDp, 256)
+        gimg = lambda tag: self._buf(ws, f"gW{m['step']}_{tag}", wmax, wmax)      # noqa: E731
+        gvec = lambda tag: self._buf(ws, f"gb{m['step']}_{tag}", 1, wmax)          # noqa: E731
+        # output layer: Y = the gradient at the transformed blocks (unchanged by the launch above), A = the last hidden activations
+        n_t = int((m["feat_t"] >= 0).nonzero().max().item()) + 1 - 32 * m["kb_t0"]
+        gW, gb = gimg("out"), gvec("out")
+        _ext.wgrad_blocked(g, nkb_g, m["kb_t0"], hs[nl - 1], 8, 0, gW, M=B, N=n_t, K=256, ldg=gW.shape[1], alpha=sign,
+                           colsum=gb, cs_alpha=sign)
+        tsel = self._seg_sel(m, "t", dev)
+        self._scatter_weight(grads, last_l.weight, gW, rows_sel=tsel, n_rows=eng.D, cols_sel=None, n_cols=h[-1])
+        self._scatter_vec(grads, last_l.bias, gb, tsel, eng.D)
+        # hidden layers, last to first: Y = the gradient at layer j's pre-activation, A = layer j - 1's activations
+        for j in range(nl - 1, 0, -1):
+            l = hidden_l[j - 1]
+            gW, gb = gimg(f"h{j}"), gvec(f"h{j}")
+            _ext.wgrad_blocked(dh[j], 8, 0, hs[j - 1], 8, 0, gW, M=B, N=h[j], K=256, ldg=gW.shape[1], alpha=sign,
+                               colsum=gb, cs_alpha=sign)
+            self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
+            self._scatter_vec(grads, l.bias, gb, None, h[j])
+        # input layer: A = the conditioning blocks of the layer's own z buffer (what the forward's conditioner saw)
+        n_p = int((m["feat_p"] >= 0).nonzero().max().item()) + 1 - 32 * m["kb_p0"]
+        gW, gb = gimg("in"), gvec("in")
+        _ext.wgrad_blocked(dh[0], 8, 0, ws[m["buf"]], nkb, m["kb_p0"], gW, M=B, N=h[0], K=n_p, ldg=gW.shape[1], alpha=sign,
+                           colsum=gb, cs_alpha=sign)
+        self._scatter_weight(grads, first_l.weight, gW, None, h[0], self._seg_sel(m, "p", dev), eng.D)
+        self._scatter_vec(grads, first_l.bias, gb, None, h[0])
 
     def _prepare_images(self, plan, first_meta):
         """every weight image the backward reads (unfused conditioner layers, transposed images of the data-gradient
@@ -772,6 +938,8 @@ class TrainPath:
                 gs = u["gsum"].double()
                 if u["which"] == "Minv":
                     if u["pre_scale"] is not None:
+                        if u.get("pre_sub_folded"):
+                            G = self._unfold_head(u["pre_scale"], G, gs, prep["b"])
                         G = self._scale_grad(u["pre_scale"], prep["Minv"], G, Gsum, grads)
                     # y = (a - b) Minv^T:  dMinv = g^T a - gsum (x) b ,  db = -Minv^T gsum
                     G = G - torch.outer(gs, prep["b"])
@@ -783,6 +951,13 @@ class TrainPath:
                     db = db + gs
             self._to_leaves(blk, prep, dMinv, dM, db, coef.get(id(blk), 0.0) * Gsum, lu_acc, grads, pk)
         self._lu_param_grads(pk, lu_acc, grads)
+
+    @staticmethod
+    def _unfold_head(scale_mod, G3, gs, b):
+        """planes pipeline: the head packs a' = x / s - b, so the first layer's weight gradient arrives as G3 = g^T a';
+        g^T x = (G3 + gsum (x) b) diag(s) is what _scale_grad takes (fp64, parameter-sized)"""
+        s64 = scale_mod.scale.detach().double()
+        return (G3 + torch.outer(gs, b)) * s64[None, :]
 
     def _scale_grad(self, scale_mod, Minv, G2, Gsum, grads):
         """first layer: a = x / s.  G2 = g^T x; returns g^T a = G2 diag(1/s) and writes
@@ -831,6 +1006,8 @@ class TrainPath:
         for rec in aff.values():
             for u in rec["uses"]:
                 if u["pre_scale"] is not None:
+                    if u.get("pre_sub_folded"):
+                        G[u["row"]] = self._unfold_head(u["pre_scale"], G[u["row"]], gs[u["row"]], b_t[u["row"]])
                     G[u["row"]] = self._scale_grad(u["pre_scale"], Minv_t[u["row"]], G[u["row"]], Gsum, grads)
         dMinv_t = G - gs[:, :, None] * b_t[:, None, :]
         db_t = -torch.bmm(Minv_t.transpose(1, 2), gs.unsqueeze(2)).squeeze(2)
