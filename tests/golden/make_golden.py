@@ -241,6 +241,15 @@ def main():
     run_case("synth_d784_k32_cfg2", S(784, 32, [256, 256], householder=0), "synth", 100, n=64, store_sd=False)
     run_case("synth_d784_k4_hh1_conj", S(784, 4, [256, 256], householder=1, affine_conjugation=True),
              "synth", 101, n=32, store_sd=False)
+    # --- the two variants SURVEY section 8 wants parity-tested AND reported beside the headline, at the cfg2 depth, and the
+    # secondary base of section 8d (Radial p = 1, LogNormal(6, .35): tests/explib/mnist.yaml:79-92) on the flat cfg2 model;
+    # bench.py places these rows at the head / middle / tail of its 65536-row batches (--golden <name>)
+    run_case("synth_d784_k32_conj", S(784, 32, [256, 256], householder=0, affine_conjugation=True),
+             "synth", 103, n=32, store_sd=False)
+    run_case("synth_d784_k32_hh1_conj", S(784, 32, [256, 256], householder=1, affine_conjugation=True),
+             "synth", 104, n=32, store_sd=False)
+    run_case("synth_d784_k32_radial1", S(784, 32, [256, 256], householder=0, base="radial", radial_p=1.0,
+                                         radial_norm_loc=6.0, radial_norm_scale=0.35), "synth", 105, n=32, store_sd=False)
     # --- BASELINE cfg4 model (D=3072, K=48, h=[1024,1024]; 1.28 G parameters): 16 rows, outputs only -------------
     # (each pass of the reference re-inverts 49 x 2 triangular 3072 x 3072 factors: ~10 min and ~25 GB here)
     run_case("synth_d3072_k48_cfg4", S(3072, 48, [1024, 1024], householder=0), "synth", 102, n=16, store_sd=False)

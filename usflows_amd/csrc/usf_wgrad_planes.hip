@@ -583,7 +583,21 @@ bool wp_schedule(int64_t M, int64_t N, int64_t K, bool balanced, int plain_split
   int ns;
   if (balanced) {
     if (tiles > cus || S < 4) return false;
-    ns = cus / tiles;                                          // one item per CU at most
+    // SEVERAL items per CU where that fills the chip better: with one (37 tiles x 6 row ranges at 784 x 784 = 222 items) 34 of
+    // the 256 CUs idle and every row range is walked by two XCDs; with three (37 x 20 = 740 items for 768 slots) the grid is a
+    // plain one the hardware deals out block by block -- block b runs on XCD b & 7, its items numbered so that the blocks an
+    // XCD runs side by side are the tiles of ONE row range -- at the price of 20 instead of 6 partial images to sum.  The
+    // number of row ranges minimises rounds x (slabs per item + ~6 slabs' worth of ring prologue / partial-image store).
+    const int max_rounds = wp_env("USF_WGRAD_ROUNDS", 3);
+    const int ns_max = (max_rounds > 1 ? max_rounds : 1) * cus / tiles;
+    ns = cus / tiles < 1 ? 1 : cus / tiles;
+    long best = -1;
+    for (int c = 1; c <= ns_max && c <= S && c <= 256; ++c) {
+      const int slabs = (S + c - 1) / c, nseg = (S + slabs - 1) / slabs;
+      const long items = (long)tiles * nseg, rounds = (items + cus - 1) / cus;
+      const long cost = rounds * (slabs + 6);
+      if (best < 0 || cost < best) { best = cost; ns = c; }
+    }
   } else {
     ns = plain_splits < 1 ? 1 : plain_splits;
   }
@@ -618,8 +632,7 @@ bool wp_schedule(int64_t M, int64_t N, int64_t K, bool balanced, int plain_split
   }
   int mx = 0;
   for (int x = 0; x < 8; ++x) if (load[x] > mx) mx = load[x];
-  if (balanced && mx > sc.per_xcd) return false;
-  sc.per_xcd = balanced ? sc.per_xcd : mx;                     // plain grid: as many blocks per XCD as its share of the items
+  sc.per_xcd = mx;                                             // as many blocks per XCD as its share of the items
   return true;
 }
 int wp_max_parts(const WpSched& sc) {
