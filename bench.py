@@ -111,6 +111,10 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1: initialise a one-rank \"nccl\" (= RCCL) process group in this process and issue the step's collective "
                          "anyway (the all-reduce of one rank is the identity): the RCCL path under the bench's clock on a single GPU")
+    ap.add_argument("--golden", default=None,
+                    help="flat log_prob: name of a committed fixture of the REAL reference (tests/golden/<name>.npz, its parameters this "
+                         "generator's at the fixture's seed): its rows are placed at the head / middle / tail of the batch and the "
+                         "device log_prob of them is compared with the reference's fp64 run (probe_parity)")
     ap.add_argument("--no-also", action="store_true", help="default invocation: skip the \"also\" block")
     ap.add_argument("--seed", type=int, default=100, help="seed of the synthetic parameters")
     ap.add_argument("--cpu-rows", type=int, default=4096, help="rows of the short CPU sample (second cpu_baseline figure)")
@@ -181,6 +185,17 @@ ALSO = [
      ["--config", "cifar_image", "--base", "radial", "--prior-scale", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "128"]),
     ("cfg2 log_prob through a one-rank nccl (RCCL) group: communicator init + the scalar all-reduce on the compute stream",
      ["--config", "cfg2", "--force-dist", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-fast-mode", "--no-kernel-timing"]),
+    # SURVEY section 8's two mandatory variants and section 8d's secondary base, at the headline's depth and batch, golden rows of the
+    # real reference at head / middle / tail
+    ("cfg2 log_prob with affine_conjugation=True, householder=0 (what every live configuration uses)",
+     ["--config", "cfg2", "--conj", "--seed", "103", "--golden", "synth_d784_k32_conj", "--steps", "5", "--warmup", "2", "--no-fast-mode",
+      "--no-cpu-baseline"]),
+    ("cfg2 log_prob with affine_conjugation=True, householder=1 (the USFlow constructor's default, flows.py:402)",
+     ["--config", "cfg2", "--conj", "--householder", "1", "--seed", "104", "--golden", "synth_d784_k32_hh1_conj", "--steps", "5", "--warmup", "2",
+      "--no-fast-mode", "--no-cpu-baseline"]),
+    ("cfg2 log_prob with the secondary base RadialDistribution(p=1, LogNormal(6, .35)) (tests/explib/mnist.yaml:79-92)",
+     ["--config", "cfg2", "--base", "radial", "--seed", "105", "--golden", "synth_d784_k32_radial1", "--steps", "5", "--warmup", "2", "--no-fast-mode",
+      "--no-cpu-baseline"]),
     ("cfg2 training step at 65536 rows (forward + backward + SophiaG)",
      ["--config", "cfg2", "--mode", "train", "--steps", "5", "--warmup", "2"]),
     ("cfg2 Flow.fit step at batch 32 (the reference's training batch), replayed hipGraph",
@@ -220,6 +235,8 @@ def run_also(args):
             a = parse_args(argv)
             if a.config == "cfg4":
                 a.probe_rows = _golden_probe("synth_d3072_k48_cfg4", a.seed)
+            elif a.golden:
+                a.probe_rows = _golden_probe(a.golden, a.seed)
             o = run_config(a, False)
             rl = o.get("roofline") or {}
             cb = o.get("cpu_baseline") or {}
@@ -309,8 +326,15 @@ def main_flat(args, under_launcher):
     from usflows_amd.synth import ModelSpec, synth_state_dict, build_usflow
     from usflows_amd.parallel import mean_log_prob, sample_sharded, shard_rows
 
+    if getattr(args, "probe_rows", None) is None and getattr(args, "golden", None):
+        args.probe_rows = _golden_probe(args.golden, args.seed)
+    # --base radial: the secondary base of SURVEY section 8d on the flat model -- RadialDistribution(p = 1, LogNormal(6, .35))
+    # (tests/explib/mnist.yaml:79-92); density on usf_radial_logprob_f32
+    base_kw = dict(base="laplace")
+    if args.base == "radial":
+        base_kw = dict(base="radial", radial_p=1.0, radial_norm="lognormal", radial_norm_loc=6.0, radial_norm_scale=0.35)
     spec = ModelSpec(D, blocks, hidden, householder=args.householder, affine_conjugation=args.conj,
-                     negative_slope=0.01, conditioner="ConditionalDenseNN", base="laplace")
+                     negative_slope=0.01, conditioner="ConditionalDenseNN", **base_kw)
     sd = synth_state_dict(spec, seed=args.seed, alpha=0.1)   # same parameters on every rank
     flow = build_usflow(spec, sd, device=str(dev))
     eng = flow.engine() if on_gpu else None
@@ -725,7 +749,9 @@ def main_flat(args, under_launcher):
            "world_size": world, "backend": backend, "device": str(dev),
            "config": {"workload": f"BASELINE {args.config}: USFlow in_dims=[{D}], {blocks} additive coupling blocks, "
                                   f"ConditionalDenseNN{hidden}+LeakyReLU(0.01), lu_transform=1, householder={args.householder}, "
-                                  f"affine_conjugation={args.conj}, Laplace(0,1) base; {mode} of {B} rows per GPU "
+                                  f"affine_conjugation={args.conj}, "
+                                  + ("RadialDistribution(p=1, LogNormal(6, .35)) base" if args.base == "radial" else "Laplace(0,1) base")
+                                  + f"; {mode} of {B} rows per GPU "
                                   f"({global_rows} over {world} GPU(s)) resident in HBM; conditioned synthetic parameters "
                                   f"(seed 100, alpha 0.1)",
                       "rows_per_gpu": B, "global_rows": global_rows, "parallelism": par,

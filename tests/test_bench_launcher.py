@@ -43,3 +43,25 @@ def test_cfg3_strong_sharding_and_cfg5_sampling_modes():
     c5 = _run(["--gpus", "2", "--config", "cfg5", "--no-kernel-timing"] + SMALL)
     assert c5["scaling"] == "strong" and c5["config"]["global_rows"] == 1000000 and c5["config"]["rows_per_gpu"] == 500000
     assert "no collective" in c5["config"]["parallelism"] and c5["metric"].count("sample()") == 1
+
+
+def test_eight_ranks_shard_cfg3_and_cfg5_as_the_node_will():
+    """the 8-GPU node's launch (--gpus 8; here 8 gloo ranks on the CPU): the process group sees 8 ranks, cfg3 / cfg5 shard
+    their totals into 32768 / 125000 rows per rank, the weak-scaling default keeps the per-rank batch"""
+    env_threads = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "1"
+    try:
+        w = _run(["--gpus", "8", "--batch", "32"] + SMALL)
+        assert w["n_gpus"] == 8 and w["world_size"] == 8 and w["backend"] == "gloo" and w["scaling"] == "weak"
+        assert w["config"]["rows_per_gpu"] == 32 and w["config"]["global_rows"] == 256
+        assert "dp8" in w["config"]["parallelism"]
+        c3 = _run(["--gpus", "8", "--config", "cfg3"] + SMALL)
+        assert c3["world_size"] == 8 and c3["scaling"] == "strong"
+        assert c3["config"]["global_rows"] == 262144 and c3["config"]["rows_per_gpu"] == 32768
+        c5 = _run(["--gpus", "8", "--config", "cfg5", "--no-kernel-timing"] + SMALL)
+        assert c5["world_size"] == 8 and c5["config"]["global_rows"] == 1000000 and c5["config"]["rows_per_gpu"] == 125000
+    finally:
+        if env_threads is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = env_threads

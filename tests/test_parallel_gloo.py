@@ -63,6 +63,57 @@ def test_mean_log_prob_allreduce_world2():
     assert abs(sum(r[2] for r in res) / n - expect) < 1e-5 * abs(expect)
 
 
+def _worker8(rank, world, port, q, n_rows):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from golden_util import load_case
+        from model_util import build_flow
+        from usflows_amd.parallel import mean_log_prob, shard_rows
+        spec, sd, _a = load_case("synth_d16_k4_hh2_conj_laplace")
+        flow = build_flow(spec, sd)
+        x = torch.rand(n_rows, 16, generator=torch.Generator().manual_seed(9))      # the same global batch on every rank
+        lo, hi = shard_rows(n_rows, rank, world)
+        mean, lp = mean_log_prob(flow, x[lo:hi])
+        q.put((rank, float(mean), lp.double().sum().item(), hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [1003, 5])
+def test_mean_log_prob_allreduce_world8_uneven_total(n_rows):
+    """8 ranks (the node's world size), a total that does not divide (1003 = 3 x 126 + 5 x 125) and one smaller than the world
+    (5 rows: three ranks hold an empty shard and still join the collective): every rank ends with the same global mean"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import load_case
+    from model_util import build_flow
+    from usflows_amd.parallel import shard_rows
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q, n_rows)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(8))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[3] for r in res] == [b - a for a, b in (shard_rows(n_rows, r, 8) for r in range(8))] and sum(r[3] for r in res) == n_rows
+    spec, sd, _a = load_case("synth_d16_k4_hh2_conj_laplace")
+    with torch.no_grad():
+        expect = build_flow(spec, sd).log_prob(torch.rand(n_rows, 16, generator=torch.Generator().manual_seed(9))).double().mean().item()
+    means = [r[1] for r in res]
+    assert max(means) - min(means) <= 1e-9 * abs(expect)                   # every rank's line agrees
+    assert abs(means[0] - expect) < 1e-5 * abs(expect)
+    # the shares the 8-GPU configurations get
+    assert [b - a for a, b in (shard_rows(262144, r, 8) for r in range(8))] == [32768] * 8
+    assert [b - a for a, b in (shard_rows(10 ** 6, r, 8) for r in range(8))] == [125000] * 8
+
+
 def test_shard_rows_partition():
     from usflows_amd.parallel import shard_rows
     for n in (0, 1, 7, 8, 65536, 1000003):
