@@ -33,7 +33,11 @@ def mean_log_prob(flow, x_shard: torch.Tensor, context: Optional[torch.Tensor] =
     else:
         acc.zero_()
     with torch.no_grad():
-        if x_shard.is_cuda and flow._on_device_fast_path(x_shard, context):
+        if x_shard.shape[0] == 0:
+            # an empty shard (fewer rows than ranks): nothing to evaluate -- torch's Independent cannot even reshape an empty
+            # event batch --, but the rank still joins the collective below with [0, 0]: the others would hang without it
+            lp = torch.empty(0, dtype=torch.float32, device=dev)
+        elif x_shard.is_cuda and flow._on_device_fast_path(x_shard, context):
             lp = flow._log_prob_device(x_shard, context, sum_out=acc)
         else:
             lp = flow.log_prob(x_shard, context) if context is not None else flow.log_prob(x_shard)
