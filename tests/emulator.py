@@ -243,10 +243,16 @@ def _tensor_planes_view(t, M, nkb):
     return t.view(-1)[: npan * nkb * 3072].view(torch.bfloat16).view(npan, nkb, 3, 64, 8)
 
 
-def _emu_pack_planes_call(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None, fmt=0, range_flag=None):
+def _emu_pack_planes_call(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None, fmt=0, range_flag=None, src_cols=0,
+                          grad=None):
     ld = src.stride(0) if ld is None else ld
     idx = idx.long()
     rows = torch.as_strided(src, (M, int(idx.max()) + 1), (ld, 1), src.storage_offset())
+    if grad is not None:          # g = row_weight * d/dz base(z) (usf_base_logprob_grad_f32's Laplace / Normal formulas)
+        base, w, loc, scale = grad
+        n = rows.shape[1]
+        t = rows - loc[:n]
+        rows = (-torch.sign(t) / scale[:n] if base == _ext.BASE_LAPLACE else -t / (scale[:n] * scale[:n])) * w[:M, None]
     X = torch.zeros(M, 32 * nkb)
     ok = idx >= 0
     X[:, ok] = rows[:, idx[ok]]

@@ -45,9 +45,11 @@ def _weight_planes(W, n_rows_pad, fmt=0):
     return torch.stack([p1, p2, p3]).contiguous()
 
 
+@pytest.mark.parametrize("rows", [False, True])
 @pytest.mark.parametrize("fmt", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("M,D,nkb", [(1, 5, 1), (37, 50, 2), (1000, 784, 25), (4099, 96, 3)])
-def test_pack_planes_is_the_exact_three_way_split(M, D, nkb, fmt):
+def test_pack_planes_is_the_exact_three_way_split(M, D, nkb, fmt, rows):
+    """rows: with the promise src_cols (every index below it) the kernel stages whole rows in LDS -- the same planes, bit for bit"""
     ext = _ext()
     fmt = FMT[fmt]
     g = torch.Generator().manual_seed(M + D)
@@ -61,7 +63,7 @@ def test_pack_planes_is_the_exact_three_way_split(M, D, nkb, fmt):
     buf = torch.zeros(ext.planes_bytes(M, nkb, fmt), dtype=torch.uint8, device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     ext.pack_planes(x.to(DEV), buf, M=M, nkb=nkb, idx=idx.to(DEV), pre_div=pdiv.to(DEV), pre_sub=psub.to(DEV), fmt=fmt,
-                    range_flag=flag)
+                    range_flag=flag, src_cols=(D + 3) if rows else 0)
     torch.cuda.synchronize()
     Mp = -(-M // 16) * 16
     got = emulator.planes_decode(_view(buf, M, nkb, fmt), Mp)
@@ -77,6 +79,35 @@ def test_pack_planes_is_the_exact_three_way_split(M, D, nkb, fmt):
         assert torch.equal(got[:M], hi.float() + (ref - hi.float()).to(torch.float16).float())
         assert int(flag.item()) == 0
     assert (got[M:] == 0).all()             # padding rows of the last panel: zeros
+
+
+@pytest.mark.parametrize("base", ["laplace", "normal"])
+@pytest.mark.parametrize("M,D", [(33, 40), (5000, 784)])
+def test_pack_planes_with_the_base_gradient_on_the_way_in(M, D, base):
+    """grad mode (the head of the training backward): planes of g = row_weight * d/dz base(z), bit for bit what
+    usf_base_logprob_grad_f32 followed by a plain pack gives"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(M)
+    z = (torch.randn(M, D + 4, generator=g) * 3).to(DEV)
+    z[3, 5] = 0.25                                                      # on the Laplace kink: loc[5] = 0.25 below
+    w = (torch.randn(M, generator=g)).to(DEV)
+    loc = (torch.randn(D, generator=g)).to(DEV)
+    loc[5] = 0.25
+    scale = (torch.rand(D, generator=g) + 0.5).to(DEV)
+    bid = ext.BASE_LAPLACE if base == "laplace" else ext.BASE_NORMAL
+    nkb = -(-D // 32)
+    idx = torch.full((32 * nkb,), -1, dtype=torch.int32)
+    idx[:D] = torch.arange(D, dtype=torch.int32)
+    idx = idx.to(DEV)
+    b1 = torch.zeros(ext.planes_bytes(M, nkb), dtype=torch.uint8, device=DEV)
+    b2 = torch.zeros_like(b1)
+    ext.pack_planes(z, b1, M=M, nkb=nkb, idx=idx, ld=D + 4, src_cols=D, grad=(bid, w, loc, scale))
+    gbuf = torch.zeros(M, D, device=DEV)
+    ext.base_logprob_grad(z, D + 4, w, M, D, bid, loc, scale, gbuf, D)
+    ext.pack_planes(gbuf, b2, M=M, nkb=nkb, idx=idx)
+    torch.cuda.synchronize()
+    assert torch.equal(b1, b2)
+    assert emulator.planes_decode(_view(b1, M, nkb), M)[3, 5].item() == 0.0 or base == "normal"
 
 
 CASES = [

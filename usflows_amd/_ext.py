@@ -72,7 +72,9 @@ class CouplingDesc(C.Structure):
 
 class PackPlanesDesc(C.Structure):
     _fields_ = [("src", _fp), ("ld", C.c_int64), ("M", C.c_int64), ("nkb", C.c_int64), ("idx", _fp),
-                ("pre_div", _fp), ("pre_sub", _fp), ("planes", _fp), ("format", C.c_int32), ("reserved", C.c_int32), ("range_flag", _fp)]
+                ("pre_div", _fp), ("pre_sub", _fp), ("planes", _fp), ("format", C.c_int32), ("reserved", C.c_int32), ("range_flag", _fp),
+                ("src_cols", C.c_int64), ("row_weight", _fp), ("loc", _fp), ("scale", _fp), ("grad_base", C.c_int32),
+                ("reserved2", C.c_int32)]
 
 
 class GemmPlanesDesc(C.Structure):
@@ -513,12 +515,22 @@ def planes_bytes(M: int, nkb: int, fmt: int = 0) -> int:
 PLANES_BF16X3, PLANES_F16X2 = 0, 1
 
 
-def pack_planes(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None, fmt=PLANES_BF16X3, range_flag=None):
+def pack_planes(src, planes, *, M, nkb, idx, ld=None, pre_div=None, pre_sub=None, fmt=PLANES_BF16X3, range_flag=None, src_cols=0,
+                grad=None):
+    """usf_pack_planes_f32.  src_cols > 0: a promise that every idx[l] < src_cols (rows are then read coalesced and gathered out
+    of LDS).  grad = (base id, row_weight [M], loc [src_cols], scale [src_cols]): the planes receive the gradient of the base
+    density at src = z, weighted per row (the head of the training backward pass; Laplace / Normal)."""
     d = PackPlanesDesc()
     d.format, d.range_flag = fmt, ptr(range_flag)
     d.src, d.ld, d.M, d.nkb = src.data_ptr(), (src.stride(0) if ld is None else ld), M, nkb
     d.idx, d.pre_div, d.pre_sub, d.planes = idx.data_ptr(), ptr(pre_div), ptr(pre_sub), planes.data_ptr()
-    _launch("usf_pack_planes_f32", (C.byref(d), current_stream(src.device)), (d, src, planes, idx, pre_div, pre_sub))
+    d.src_cols = src_cols
+    keep = (d, src, planes, idx, pre_div, pre_sub)
+    if grad is not None:
+        base, w, loc, scale = grad
+        d.grad_base, d.row_weight, d.loc, d.scale = 1 + base, w.data_ptr(), loc.data_ptr(), scale.data_ptr()
+        keep = keep + (w, loc, scale)
+    _launch("usf_pack_planes_f32", (C.byref(d), current_stream(src.device)), keep)
 
 
 def gemm_planes(A, W_planes, *, M, a_nkb, nk, a_kb0=0, bias=None, post_mul=None, residual=None, C_planes=None, c_nkb=0,

@@ -123,6 +123,89 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
   for (int q = 0; q < NPL; ++q) *reinterpret_cast<typename PT::vec*>(out + q * 1024) = o[q];
 }
 
+// The same with whole rows read once, coalesced: one block per panel stages its 16 source rows in LDS (row stride src_cols + 1
+// floats) and its four waves gather the panel's chunks from there.  The per-element gather above asks the memory system for
+// 16 different rows per wave instruction and, with a checkerboard layout index, for every other float of a line: 2.6 TB/s of
+// the 8 (profiles/r04_hbm_traffic.json); here the HBM sees 16-byte loads along rows and 1-KiB plane stores only.
+// GRAD: the staged value is g = row_weight[m] * d/dz base_c(z) (base_grad_kernel's Laplace / Normal formulas) instead of the
+// source value -- the training backward's head in one pass instead of usf_base_logprob_grad_f32 + usf_pack_planes_f32.
+template <int NPL, bool GRAD>
+__global__ __launch_bounds__(256) void pack_planes_rows_kernel(const float* __restrict__ src, int64_t ld, int M, int nkb, int src_cols,
+                                                               const int32_t* __restrict__ idx, const float* __restrict__ pre_div,
+                                                               const float* __restrict__ pre_sub, char* __restrict__ dst,
+                                                               int32_t* __restrict__ range_flag, const float* __restrict__ row_weight,
+                                                               const float* __restrict__ loc, const float* __restrict__ scale, int grad_base,
+                                                               int vec) {
+  typedef Planes<NPL> PT;
+  extern __shared__ float tile[];                 // [16][S]
+  const int S = src_cols + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = blockIdx.x;
+  auto xform = [&](float v, int c, float w) {
+    if (!GRAD) return v;
+    const float t = v - loc[c];
+    const float sg = (float)((t > 0.f) - (t < 0.f));
+    const float g = (grad_base == 1 + USF_BASE_LAPLACE) ? -sg / scale[c] : -t / (scale[c] * scale[c]);
+    return g * w;
+  };
+  if (vec) {
+    const int c4n = src_cols >> 2;
+    for (int e = tid; e < 16 * c4n; e += 256) {
+      const int r = e / c4n, c = 4 * (e - r * c4n);
+      const int row = 16 * p + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      float w = 0.f;
+      if (row < M) {
+        v = *reinterpret_cast<const f32x4*>(src + (int64_t)row * ld + c);
+        if (GRAD) w = row_weight[row];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tile[r * S + c + q] = (row < M) ? xform(v[q], c + q, w) : 0.f;
+    }
+    for (int e = tid; e < 16 * (src_cols & 3); e += 256) {      // (a column remainder: scalar)
+      const int r = e / (src_cols & 3), c = (src_cols & ~3) + e % (src_cols & 3);
+      const int row = 16 * p + r;
+      tile[r * S + c] = (row < M) ? xform(src[(int64_t)row * ld + c], c, GRAD ? row_weight[row] : 0.f) : 0.f;
+    }
+  } else {
+    for (int e = tid; e < 16 * src_cols; e += 256) {
+      const int r = e / src_cols, c = e - r * src_cols;
+      const int row = 16 * p + r;
+      tile[r * S + c] = (row < M) ? xform(src[(int64_t)row * ld + c], c, GRAD ? row_weight[row] : 0.f) : 0.f;
+    }
+  }
+  __syncthreads();
+  const int lj = lane & 15, lg = lane >> 4;
+  bool bad = false;
+  for (int kb = wave; kb < nkb; kb += 4) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int l = 32 * kb + 16 * (u >> 2) + 4 * lg + (u & 3);
+      const int c = idx[l];
+      float v = 0.f;
+      if (c >= 0) {                                  // (rows beyond M hold zeros in the tile; pre_div / pre_sub must not touch them)
+        v = tile[lj * S + c];
+        if (16 * p + lj < M) {
+          if (pre_div) v = v / pre_div[l];
+          if (pre_sub) v = v - pre_sub[l];
+        }
+      }
+      x[u] = v;
+    }
+    if (NPL == 2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bad = bad || !(fabsf(x[u]) < USF_F16_GUARD);
+    }
+    typename PT::vec o[NPL];
+    PT::split(x, o);
+    char* out = dst + ((int64_t)((int64_t)p * nkb + kb) * NPL) * 1024 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) *reinterpret_cast<typename PT::vec*>(out + q * 1024) = o[q];
+  }
+  if (NPL == 2 && range_flag && bad) atomicOr(range_flag, 1);
+}
+
 int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_pack_planes_f32: null descriptor"); return -1; }
   if (d->M < 0 || d->nkb <= 0 || d->M > 0x7fffffff || d->nkb > 0x7fffff || d->ld < 1) { set_error("usf_pack_planes_f32: bad sizes"); return -2; }
@@ -134,6 +217,29 @@ int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
   const int64_t chunks = npanels * d->nkb;
   const int64_t blocks = (chunks + 3) / 4;
   if (blocks > 0x7fffffffLL) { set_error("usf_pack_planes_f32: grid too large"); return -3; }
+  if (d->grad_base != 0) {
+    if (d->src_cols <= 0 || !d->row_weight || !d->loc || !d->scale || d->format != USF_PLANES_BF16X3 ||
+        (d->grad_base != 1 + USF_BASE_LAPLACE && d->grad_base != 1 + USF_BASE_NORMAL)) {
+      set_error("usf_pack_planes_f32: grad_base needs src_cols, row_weight, loc, scale, the bf16x3 format and a Laplace / Normal base");
+      return -2;
+    }
+  }
+  static int rows_env = -1;
+  if (rows_env < 0) { const char* e = getenv("USF_PACK_ROWS"); rows_env = e ? atoi(e) : 1; }      // tuning aid: 0 = the per-element gather
+  const size_t lds = (size_t)16 * (size_t)(d->src_cols + 1) * sizeof(float);
+  if (d->src_cols > 0 && d->src_cols <= d->ld && lds <= 65536 && (rows_env || d->grad_base != 0)) {
+    const int vec = (aligned16(d->src) && (d->ld & 3) == 0) ? 1 : 0;
+    char* out = reinterpret_cast<char*>(d->planes);
+#define USF_PPR(NPL_, GRAD_) hipLaunchKernelGGL((pack_planes_rows_kernel<NPL_, GRAD_>), dim3((unsigned)npanels), dim3(256), lds, stream, d->src, \
+                             d->ld, (int)d->M, (int)d->nkb, (int)d->src_cols, d->idx, d->pre_div, d->pre_sub, out, d->range_flag,      \
+                             d->row_weight, d->loc, d->scale, (int)d->grad_base, vec)
+    if (d->grad_base != 0) USF_PPR(3, true);
+    else if (d->format == USF_PLANES_F16X2) USF_PPR(2, false);
+    else USF_PPR(3, false);
+#undef USF_PPR
+    return check_launch("usf_pack_planes_f32");
+  }
+  if (d->grad_base != 0) { set_error("usf_pack_planes_f32: grad_base needs 16 (src_cols + 1) floats to fit 64 KB of LDS"); return -2; }
   if (d->format == USF_PLANES_F16X2)
     hipLaunchKernelGGL(pack_planes_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, d->src, d->ld, (int)d->M, (int)npanels,
                        (int)d->nkb, d->idx, d->pre_div, d->pre_sub, reinterpret_cast<char*>(d->planes), d->range_flag);

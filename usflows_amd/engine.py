@@ -1386,6 +1386,7 @@ class FlowEngine:
         pack.kind = _ext.OP_PACK_PLANES
         d = pack.u.pack_planes
         d.src, d.ld, d.M, d.nkb = 0, self.D, B, nkb
+        d.src_cols = self.D                    # (every index of the layout is a feature number: rows are read whole, coalesced)
         d.format, d.range_flag = fmt, flag
         d.idx = self._idx_dev("segp", device).data_ptr()
         d.planes = zbufs[cur].data_ptr()

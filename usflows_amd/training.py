@@ -476,20 +476,25 @@ class TrainPath:
         zname, _, ldn = plan["out_buf"]
         grads = arena["views"]
         self._touched = arena["touched"]
-        if info[0] == "radial":
-            scale = self._buf(ws, "radius", 1, B)[0, :B]
-        _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, loc, scale, gA, ldn)
-        if info[0] == "radial":
-            g_loc = self._grad_slot(grads, self.flow.base_distribution.loc)
-            if g_loc is not None:
-                _ext.colsum(gA, g_loc, M=B, N=D, ldy=ldn, alpha=-1.0)
         gp = [self._planes_buf(ws, "pgA", B, nkb_g), self._planes_buf(ws, "pgB", B, nkb_g)]
         key = ("natp_g", nkb_g, str(dev))
         if key not in self._inv:
             t = torch.full((32 * nkb_g,), -1, dtype=torch.int32)
             t[:D] = torch.arange(D, dtype=torch.int32)
             self._inv[key] = t.to(dev)
-        _ext.pack_planes(gA, gp[0], M=B, nkb=nkb_g, idx=self._inv[key], ld=ldn)
+        if info[0] != "radial" and 16 * (D + 1) * 4 <= 65536:
+            # Laplace / Normal base: the gradient at the latent goes straight into the planes (one pass over z instead of
+            # usf_base_logprob_grad_f32's fp32 rows + their repack)
+            _ext.pack_planes(ws[zname], gp[0], M=B, nkb=nkb_g, idx=self._inv[key], ld=ldn, src_cols=D, grad=(base, glp, loc, scale))
+        else:
+            if info[0] == "radial":
+                scale = self._buf(ws, "radius", 1, B)[0, :B]
+            _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, loc, scale, gA, ldn)
+            if info[0] == "radial":
+                g_loc = self._grad_slot(grads, self.flow.base_distribution.loc)
+                if g_loc is not None:
+                    _ext.colsum(gA, g_loc, M=B, N=D, ldy=ldn, alpha=-1.0)
+            _ext.pack_planes(gA, gp[0], M=B, nkb=nkb_g, idx=self._inv[key], ld=ldn, src_cols=D)
         cur = 0
         aff: Dict[int, dict] = {}
         n_aff = sum(1 for m in plan["meta"] if m["kind"] == "affine")
