@@ -53,6 +53,12 @@ CONFIGS = {
     "cfg3": dict(dim=784, blocks=32, hidden=[256, 256], rows=262144, scaling="strong", mode="log_prob"),
     "cfg4": dict(dim=3072, blocks=48, hidden=[1024, 1024], rows=32768, scaling="weak", mode="log_prob"),
     "cfg5": dict(dim=784, blocks=32, hidden=[256, 256], rows=1000000, scaling="strong", mode="sample"),
+    # the reference's LIVE FLAT configuration as HyperoptExperiment._trial trains it (experiments/synthetic/gaussian_mixture.yaml:
+    # 40-93, the 10-D overwrite): pyro.nn.DenseNN[32, 32] + ReLU, 10 blocks, affine_conjugation, RadialDistribution(p = 1,
+    # GammaMM x 20) base, prior_scale 1.0, SophiaG, batch 32
+    "gm_live": dict(dim=10, blocks=10, hidden=[32, 32], rows=32, scaling="weak", mode="fit", conj=True, conditioner="DenseNN",
+                    negative_slope=0.0, base=dict(base="radial", radial_p=1.0, radial_norm="gammamm"),
+                    extra={"gammamm_k": 20, "prior_scale": 1.0}),
 }
 
 
@@ -200,6 +206,9 @@ ALSO = [
      ["--config", "cfg2", "--mode", "train", "--steps", "5", "--warmup", "2"]),
     ("cfg2 Flow.fit step at batch 32 (the reference's training batch), replayed hipGraph",
      ["--config", "cfg2", "--mode", "fit", "--batch", "32", "--steps", "30", "--warmup", "6"]),
+    ("gm_live Flow.fit step at batch 32: the live FLAT configuration (gaussian_mixture.yaml:40-93, 10-D: DenseNN[32,32]+ReLU, 10 blocks, "
+     "conj, GammaMM x 20 radial base, prior_scale 1, SophiaG), replayed hipGraph",
+     ["--config", "gm_live", "--steps", "30", "--warmup", "6"]),
     ("mnist_image training step at 65536 rows, live base (radial LogNormal, prior_scale 1)",
      ["--config", "mnist_image", "--mode", "train", "--base", "radial", "--prior-scale", "1", "--steps", "5", "--warmup", "5",
       "--cpu-seconds", "1", "--cpu-rows", "512"]),
@@ -333,8 +342,13 @@ def main_flat(args, under_launcher):
     base_kw = dict(base="laplace")
     if args.base == "radial":
         base_kw = dict(base="radial", radial_p=1.0, radial_norm="lognormal", radial_norm_loc=6.0, radial_norm_scale=0.35)
+    if cfg.get("base"):
+        base_kw = dict(cfg["base"])
+    if cfg.get("conj"):
+        args.conj = True
     spec = ModelSpec(D, blocks, hidden, householder=args.householder, affine_conjugation=args.conj,
-                     negative_slope=0.01, conditioner="ConditionalDenseNN", **base_kw)
+                     negative_slope=cfg.get("negative_slope", 0.01), conditioner=cfg.get("conditioner", "ConditionalDenseNN"),
+                     extra=dict(cfg.get("extra", {})), **base_kw)
     sd = synth_state_dict(spec, seed=args.seed, alpha=0.1)   # same parameters on every rank
     flow = build_usflow(spec, sd, device=str(dev))
     eng = flow.engine() if on_gpu else None
@@ -747,13 +761,16 @@ def main_flat(args, under_launcher):
                      "f32 (GEMMs as bf16x3 split on the bf16 MFMA: 24 significant bits, fp32 accumulate)"),
            "data": "synthetic",
            "world_size": world, "backend": backend, "device": str(dev),
-           "config": {"workload": f"BASELINE {args.config}: USFlow in_dims=[{D}], {blocks} additive coupling blocks, "
-                                  f"ConditionalDenseNN{hidden}+LeakyReLU(0.01), lu_transform=1, householder={args.householder}, "
-                                  f"affine_conjugation={args.conj}, "
-                                  + ("RadialDistribution(p=1, LogNormal(6, .35)) base" if args.base == "radial" else "Laplace(0,1) base")
+           "config": {"workload": (f"{args.config} (experiments/synthetic/gaussian_mixture.yaml:40-93)" if args.config == "gm_live" else f"BASELINE {args.config}")
+                                  + f": USFlow in_dims=[{D}], {blocks} additive coupling blocks, "
+                                  f"{spec.conditioner}{hidden}+{'ReLU' if spec.negative_slope == 0 else f'LeakyReLU({spec.negative_slope})'}, "
+                                  f"lu_transform=1, householder={args.householder}, affine_conjugation={args.conj}, "
+                                  + (f"RadialDistribution(p=1, {'GammaMM x ' + str(spec.extra.get('gammamm_k')) if spec.radial_norm == 'gammamm' else 'LogNormal(6, .35)'}) base"
+                                     if spec.base == "radial" else "Laplace(0,1) base")
+                                  + (f", prior_scale={spec.extra['prior_scale']}" if spec.extra.get("prior_scale") is not None else "")
                                   + f"; {mode} of {B} rows per GPU "
                                   f"({global_rows} over {world} GPU(s)) resident in HBM; conditioned synthetic parameters "
-                                  f"(seed 100, alpha 0.1)",
+                                  f"(seed {args.seed}, alpha 0.1)",
                       "rows_per_gpu": B, "global_rows": global_rows, "parallelism": par,
                       "fused_coupling": not args.unfused, "gemm_mode": eng.gemm_mode if on_gpu else "torch-cpu",
                       "merge_affine": (eng.merge_affine if eng.merge_affine != "auto" else

@@ -16,7 +16,7 @@ def case_names(small_only=False):
     # (the BASELINE cfg4 fixture -- 1.28 G parameters regenerated from the seed -- is loaded by name in
     # tests/test_configs_gpu.py only: far too big for the per-case loops)
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "imageradial_", "imageradialfit_", "fitsophia_", "sophia_")) and "cfg4" not in p)
+                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "imageradial_", "imageradialfit_", "fitsophia_", "sophia_", "gmfit_")) and "cfg4" not in p)
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -45,6 +45,34 @@ def load_case(name):
     if "base_scale" in arrays:
         spec.base_scale = arrays["base_scale"]
     return spec, sd, arrays
+
+
+def gm_live_case_names():
+    """the reference's LIVE FLAT configuration (experiments/synthetic/gaussian_mixture.yaml:50-93) for D = 2, 10, 100:
+    tests/golden/make_golden_gaussian_mixture.py"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "init_d*_k10_gmlive.npz")))
+
+
+def load_gm_live_grads(name):
+    """(loss, log_prior, {parameter: d(-log_prob(x).mean() - log_prior()) / d parameter}) of the reference's fp64 run -- EVERY
+    parameter, the GammaMM's and the radial loc included"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    return float(z["loss64"]), float(z["log_prior64"]), {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}
+
+
+def gm_live_fit_case_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "gmfit_d*_k10_gmlive.npz")))
+
+
+def load_gm_live_fit(name):
+    """(spec, training rows, per-epoch losses, state dict before, state dict after) of the reference's Flow.fit with SophiaG at
+    the live hyper-parameters (lr 1e-3, weight_decay 0, batch 32, 2 epochs x 96 rows, shuffle under numpy seed 5)"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    d = json.loads(str(z["spec"]))
+    spec = orc.FlowSpec(**d)
+    sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0/")}
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    return spec, torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd0, sd
 
 
 def grad_case_names():

@@ -1,0 +1,119 @@
+"""The reference's LIVE FLAT configuration -- experiments/synthetic/gaussian_mixture.yaml:50-93: pyro.nn.DenseNN[32, 32] + ReLU,
+10 coupling blocks, affine_conjugation, lu_transform 1, householder 0, RadialDistribution(p = 1, GammaMM x 20) base with a
+trainable loc, prior_scale 1.0, SophiaG lr 1e-3 at batch 32 -- for D = 2, 10, 100, against goldens of the REAL reference
+(tests/golden/make_golden_gaussian_mixture.py): log_prob / backward / _forward (also through the generic golden loops of
+test_oracle.py / test_flow_gpu.py), EVERY gradient of Flow.fit's loss -- GammaMM parameters and loc included --, and the
+reference's own 6-step SophiaG Flow.fit run.  CPU: the mirror's torch formulation; GPU: the device path, eager and replayed."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import gm_live_case_names, gm_live_fit_case_names, load_case, load_gm_live_fit, load_gm_live_grads
+from model_util import build_flow
+
+DEV = "cuda:0"
+
+
+def _close(got, ref, tol, what):
+    ref = ref.double()
+    big = max(ref.abs().max().item(), 1e-30)
+    d = (got.detach().cpu().double().reshape(ref.shape) - ref).abs().max().item()
+    assert d <= tol * big, (what, d, big)
+
+
+def _loss(flow, x):
+    return -flow.log_prob(x).mean() - flow.log_prior()
+
+
+@pytest.mark.parametrize("name", gm_live_case_names())
+def test_mirror_reproduces_every_gradient_of_the_fit_loss_cpu(name):
+    """the mirror's own torch formulation in fp64: values to 1e-11, every gradient (layers, GammaMM concentration / rate /
+    mixture weights, radial loc) to 1e-8"""
+    spec, sd, a = load_case(name)
+    loss_ref, prior_ref, g_ref = load_gm_live_grads(name)
+    torch.set_default_dtype(torch.float64)
+    try:
+        flow = build_flow(spec, sd).double()
+        for l in flow.layers:
+            if hasattr(l, "mask") and torch.is_tensor(l.mask):
+                l.mask = l.mask.double()
+        x = a["x"].double()
+        loss = _loss(flow, x)
+        assert abs(float(flow.log_prior()) - prior_ref) <= 1e-12 and abs(float(loss) - loss_ref) <= 1e-10 * abs(loss_ref)
+        loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    named = dict(flow.named_parameters())
+    assert set(g_ref) <= set(named), sorted(set(g_ref) - set(named))
+    assert any("norm_distribution" in k for k in g_ref) and "base_distribution.loc" in g_ref
+    for k, g in g_ref.items():
+        assert named[k].grad is not None, k
+        _close(named[k].grad, g, 1e-8, k)
+
+
+def _fit(flow, data, device):
+    ds = torch.utils.data.TensorDataset(data, torch.zeros(data.shape[0]))
+    np.random.seed(5)
+    return flow.fit(ds, optim_params=dict(lr=1e-3, weight_decay=0.0), batch_size=32, shuffle=True, device=torch.device(device), epochs=2)
+
+
+def _check_fit(flow, losses, losses_ref, sd_ref, loss_tol, exact):
+    for l, r in zip(losses, losses_ref):
+        assert abs(float(l) - r) < loss_tol * abs(r), (losses, losses_ref)
+    sd = flow.state_dict()
+    for k, v in sd_ref.items():
+        d = (sd[k].cpu().double() - v.double()).abs()
+        s = max(v.abs().max().item(), 1e-3)
+        if exact:
+            assert d.max().item() <= 2e-5 * s + 1e-7, (k, d.max().item())
+        else:
+            # SophiaG with a zero Hessian estimate moves every entry by lr * sign(momentum) per step: 6e-3 after 6 steps; a sign
+            # flip of a near-zero gradient moves an entry by 2 lr
+            assert d.max().item() <= 2.1e-3 + 2e-3 * s, (k, d.max().item())
+            assert (d > 1e-4 * s + 1e-6).double().mean().item() < 0.02, (k, "more than 2 % of the entries took another sign")
+
+
+@pytest.mark.parametrize("name", gm_live_fit_case_names())
+def test_mirror_fit_reproduces_the_reference_run_cpu(name):
+    spec, data, losses_ref, sd0, sd_ref = load_gm_live_fit(name)
+    flow = build_flow(spec, sd0)
+    losses = _fit(flow, data, "cpu")
+    _check_fit(flow, losses, losses_ref, sd_ref, 2e-5, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", gm_live_case_names())
+def test_device_gradients_of_the_fit_loss_match_the_reference(name):
+    """Flow.fit's loss on the device: log_prob to 1e-5 of the reference's fp64 run, EVERY gradient -- no parameter skipped --
+    to 5e-5 of its tensor's largest entry; the flow's own training path ran (no composite fallback)"""
+    spec, sd, a = load_case(name)
+    loss_ref, _prior_ref, g_ref = load_gm_live_grads(name)
+    flow = build_flow(spec, sd, device=DEV)
+    x = a["x"].to(DEV)
+    before = flow.engine().launch_count
+    lp = flow.log_prob(x)
+    assert lp.requires_grad and flow.engine().launch_count > before, "the device training path did not run"
+    _close(lp, a["log_prob64"], 1e-5, "log_prob")
+    loss = -lp.mean() - flow.log_prior()
+    assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref)
+    loss.backward()
+    named = dict(flow.named_parameters())
+    for k, g in g_ref.items():
+        assert named[k].grad is not None, k
+        _close(named[k].grad, g, 5e-5 if g.abs().max().item() > 0 else 1e-30, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", gm_live_fit_case_names())
+def test_device_fit_reproduces_the_reference_run(name, monkeypatch):
+    """Flow.fit with SophiaG at the live hyper-parameters on the device: the reference's own 6 steps, eagerly and with the step
+    captured as a hipGraph and replayed"""
+    for graph in ("0", "1"):
+        monkeypatch.setenv("USFLOWS_AMD_TRAIN_GRAPH", graph)
+        spec, data, losses_ref, sd0, sd_ref = load_gm_live_fit(name)
+        flow = build_flow(spec, sd0, device=DEV)
+        losses = _fit(flow, data, DEV)
+        st = flow.__dict__.get("_train_graph_state")
+        if graph == "1":
+            assert st is not None and st["graph"] is not None and st["replays"] >= 1, (st and st.get("replays"))
+        _check_fit(flow, losses, losses_ref, sd_ref, 2e-4, exact=False)

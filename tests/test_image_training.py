@@ -485,12 +485,17 @@ def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bi
     real = _ext._launch
     monkeypatch.setattr(_ext, "_launch", lambda name, *a_, **k_: (launches.append(name), real(name, *a_, **k_))[1])
 
-    def grads(env):
+    def grads(env, scope=True, twice=False):
         monkeypatch.setenv("USFLOWS_AMD_PSUM_JOBS", env)
         for p in flow.parameters():
             p.grad = None
         del launches[:]
-        (-flow.log_prob(x).mean()).backward()
+        loss = -flow.log_prob(x).mean()
+        if twice:                                   # the same weights feed two nodes of ONE backward graph
+            loss = loss - flow.log_prob(x.flip(0)).mean()
+        import contextlib
+        with (_ext.deferred_sums_scope() if scope else contextlib.nullcontext()):      # (Flow.fit opens this scope around its own steps)
+            loss.backward()
         torch.cuda.synchronize()
         return {k: p.grad.clone() for k, p in flow.named_parameters() if p.grad is not None}, launches.count("usf_partial_sum_jobs_f32")
 
@@ -500,9 +505,21 @@ def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bi
     assert set(g_on) == set(g_off)
     for k in g_off:
         assert torch.equal(g_on[k], g_off[k]), k
+    # outside a scope (any loss.backward() that is not Flow.fit's own: hooks / DistributedDataParallel may read gradients mid-pass)
+    g_out, n_out = grads("1", scope=False)
+    assert n_out == 0 and all(torch.equal(g_out[k], g_off[k]) for k in g_off)
+    # two log_prob calls in one loss -- autograd adds the two gradients of a weight as soon as the second arrives: the
+    # queue is flushed in front of that and the second producer is not deferred; same bits as without any deferral
+    g2_off, _ = grads("0", twice=True)
+    g2_on, _n2 = grads("1", twice=True)
+    assert set(g2_on) == set(g2_off)
+    for k in g2_off:
+        assert torch.equal(g2_on[k], g2_off[k]), k
     # gradients already in place: autograd adds the new ones at once -> nothing may be deferred
+    g_on, n_on = grads("1")
     del launches[:]
-    (-flow.log_prob(x).mean()).backward()
+    with _ext.deferred_sums_scope():
+        (-flow.log_prob(x).mean()).backward()
     torch.cuda.synchronize()
     assert launches.count("usf_partial_sum_jobs_f32") == 0
     named = dict(flow.named_parameters())

@@ -458,9 +458,8 @@ def _compare_large(flow, g_ref, linear):
 _SMOOTH = dict(negative_slope=1.0, base="normal")
 
 
-@pytest.mark.parametrize("B,force,kw", [(8192, True, {}), (8192, True, _SMOOTH), (16400, False, {}), (16400, False, _SMOOTH),
+@pytest.mark.parametrize("B,force,kw", [(8192, True, {}), (8192, True, _SMOOTH), (16400, False, _SMOOTH),
                                         (8200, True, dict(affine_conjugation=True, householder=1, **_SMOOTH)),
-                                        (8200, True, dict(affine_conjugation=True, householder=1)),
                                         (8192, True, dict(hidden_dims=[200]))])
 def test_planes_training_backward_matches_oracle_autograd_at_d784(B, force, kw):
     """D = 784, K = 4 (the BASELINE cfg2 layer shapes), >= 8192 rows: ONE backward pass of the planes training path

@@ -813,9 +813,33 @@ class _PsumState:
         self.lock = threading.Lock()
         self.jobs = {}           # autograd graph task id -> [(PsumJob, tensors to keep alive until the launch)]
         self.arena = None        # capture_tables: [buffer, bytes used, [(device slice, host tensor)]]
+        self.scope = 0           # > 0: inside deferred_sums_scope (a backward pass whose caller vouches for its parameters)
+        self.owners = {}         # autograd graph task id -> ids of the Parameters that already have a queued gradient
 
 
 _psum = _PsumState()
+
+
+class deferred_sums_scope:
+    """``with deferred_sums_scope(): loss.backward()`` -- only inside such a scope may a weight gradient's last sum be queued
+    until the backward pass ends.  A queued gradient is handed to autograd UNWRITTEN, so whoever opens the scope vouches that
+    nothing reads a parameter's gradient before the pass ends: no hooks on the parameters' gradient accumulators (torch's
+    DistributedDataParallel registers such hooks from C++, invisible to Python -- hence a scope, not a per-parameter check) and
+    no optimiser / user code between the node and the end of the pass.  Flow.fit opens it around its own steps' backward
+    passes; a ``loss.backward()`` anywhere else never defers.  What the scope cannot know is checked per call: a parameter that
+    already holds a ``.grad`` or has tensor hooks (image_training._takeable), and a SECOND producer for the same parameter in
+    one pass (``conv_wgrad(owners=...)``: autograd adds the two gradients as soon as the second arrives -- the queue is flushed
+    first and that call stays undeferred)."""
+
+    def __enter__(self):
+        with _psum.lock:
+            _psum.scope += 1
+        return self
+
+    def __exit__(self, *exc):
+        with _psum.lock:
+            _psum.scope -= 1
+        return False
 
 
 class capture_tables:
@@ -860,7 +884,7 @@ def _device_table(host: torch.Tensor, device) -> Optional[torch.Tensor]:
 def psum_defer_ok(x) -> bool:
     """may a weight gradient of this input queue its last sum?  (small batch, inside a backward pass, and -- inside a capture --
     a table buffer at hand)"""
-    return (os.environ.get("USFLOWS_AMD_PSUM_JOBS", "1") != "0" and 0 < x.shape[0] <= PSUM_DEFER_MAX_ROWS
+    return (_psum.scope > 0 and os.environ.get("USFLOWS_AMD_PSUM_JOBS", "1") != "0" and 0 < x.shape[0] <= PSUM_DEFER_MAX_ROWS
             and torch._C._current_graph_task_id() >= 0
             and (not torch.cuda.is_current_stream_capturing() or _psum.arena is not None))
 
@@ -870,6 +894,7 @@ def flush_partial_sums(task: int) -> None:
     first rounds, ONE for all final rounds"""
     with _psum.lock:
         jobs = _psum.jobs.pop(task, [])
+        _psum.owners.pop(task, None)
     if not jobs:
         return
     device = jobs[0][2][0].device
@@ -897,10 +922,12 @@ def flush_partial_sums(task: int) -> None:
                 (table, [k for _, k in part]))
 
 
-def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True, defer=False):
+def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True, defer=False, owners=()):
     """usf_conv_wgrad_f32: (dW [cout, cin, ks, ks], db [cout] | None) of a stride-1 "same" convolution from its input x
     [B, cin, H, W] (with the forward's input transforms) and the output gradient dy [B, cout, H, W]; None when the shape is
-    not served.  defer (see above): the final sum may be queued -- dW / db are then complete when the backward pass ends"""
+    not served.  defer (see above): the final sum may be queued -- dW / db are then complete when the backward pass ends.
+    owners: ids of the Parameters the gradients are for -- a second call for the same parameter inside one backward pass
+    flushes the queue and is not deferred (autograd sums the two gradients when the second one arrives)"""
     B, cin, H, W = x.shape
     cout = dy.shape[1]
     lib = load()
@@ -910,6 +937,15 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     dW = torch.empty(cout, cin, ks, ks, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    if defer and psum_defer_ok(x) and owners:
+        task = torch._C._current_graph_task_id()
+        with _psum.lock:
+            seen = _psum.owners.setdefault(task, set())
+            dup = any(o in seen for o in owners)
+            seen.update(owners)
+        if dup:
+            flush_partial_sums(task)          # the earlier producer's sums run now, in stream order before autograd's add
+            defer = False
     if defer and psum_defer_ok(x):
         # (table bytes this pass has queued so far: inside a capture they must fit the pre-capture buffer)
         with _psum.lock:

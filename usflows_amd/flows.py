@@ -835,7 +835,8 @@ class Flow(torch.nn.Module):
                 else:
                     model._zero_grad_for_step(optim)
                     loss = -model.log_prob(sample, context=noise).mean() - model.log_prior()
-                    loss.backward()
+                    with model._fit_backward_scope():
+                        loss.backward()
                     if feed is not None:
                         feed.stage(idx + batch_size)       # host copy + asynchronous upload of the next batch, before the read-back below waits
                     losses.append(float(loss.detach()))
@@ -939,7 +940,8 @@ class Flow(torch.nn.Module):
                 try:
                     with _unvalidated(self.base_distribution):
                         loss = -self.log_prob(sx, context=sc).mean() - self.log_prior()
-                    loss.backward()
+                    with self._fit_backward_scope():
+                        loss.backward()
                 finally:
                     if gflat is not None:
                         tp.use_bound_node = False
@@ -1030,6 +1032,16 @@ class Flow(torch.nn.Module):
         for p in params:
             if p.grad is not None:
                 p.grad = None
+
+    def _fit_backward_scope(self):
+        """the scope of a backward pass Flow.fit itself drives: the last sums of its convolution weight gradients may be queued
+        until the pass ends (_ext.deferred_sums_scope explains what the opener vouches for).  Not when a process group is up
+        without this flow's own data-parallel path in charge of it: a DistributedDataParallel wrapper would hook the
+        parameters' gradient accumulators and read the gradients mid-pass."""
+        import torch.distributed as dist
+        foreign_dp = (dist.is_available() and dist.is_initialized() and self.__dict__.get("_grad_allreduce") is None
+                      and getattr(self.__dict__.get("_train_obj"), "grad_allreduce", None) is None)
+        return contextlib.nullcontext() if foreign_dp else _ext.deferred_sums_scope()
 
     def _zero_grad_for_step(self, optim) -> None:
         """``optim.zero_grad()`` of an eager step -- but once a training step of this optimiser has been captured, the

@@ -177,7 +177,7 @@ class ConvSame(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with side_wgrad(x, dy, in_mul, params=ctx.params):
                 r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
-                                    defer=_takeable(ctx.params))
+                                    defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_shape_ok was not consulted)")
             dW, db = r
@@ -226,7 +226,7 @@ class ConvSameFork(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with side_wgrad(x, dy, in_mul, params=ctx.params):
                 r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
-                                    defer=_takeable(ctx.params))
+                                    defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r
@@ -274,7 +274,7 @@ class Pointwise(torch.autograd.Function):
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             with side_wgrad(x, dy, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable(ctx.params))
+                r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r[0].reshape(wshape), r[1]
