@@ -725,6 +725,8 @@ def main_flat(args, under_launcher):
             ref_t = orc.flow_log_prob(sd_now, spec, x[tidx.to(dev)].cpu()).double()
         train_parity = {"rows": int(tidx.numel()), "placed_at": "head / middle / tail of the batch",
                         "max_rel_vs_cpu_fp32_oracle": float(((got - ref_t).abs() / ref_t.abs()).max().item()),
+                        # (low-dimensional flows: a row's log_prob can sit near zero, where the row-wise relative figure says nothing)
+                        "max_abs_err_over_max_abs_log_prob": float(((got - ref_t).abs().max() / ref_t.abs().max()).item()),
                         "what": "log_prob of the trained-on rows after the timed steps, device vs oracle/usflows_oracle.py at the current parameters"}
     probe_parity = None
     if probe is not None and lp is not None and mode == "log_prob":

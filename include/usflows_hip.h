@@ -854,6 +854,16 @@ int usf_affine_prep_bwd_f32(const float* save, const float* bias, const float* v
                             const float* dladj, int64_t n, int32_t C, int32_t nvs, float* dL_raw, float* dU_raw, float* dbias,
                             float* dvk, usf_stream_t stream);
 
+/* Trainable Laplace / Normal base (the reference's distributions.Laplace / Normal modules, distributions.py:199-238, as a flow's
+ * base distribution under Flow.fit, flows.py:196-203) -- ABI 33:
+ *   d_loc_scale[d]     = sum_m g_lp[m] * d/dloc_d   base_d(z[m,d]; loc_d, scale_d)
+ *   d_loc_scale[D + d] = sum_m g_lp[m] * d/dscale_d base_d(...)          (scale = the CONSTRAINED scale the density uses;
+ * the caller applies softplus' for the modules' scale_unconstrained).  Laplace: sign(t)/b, |t|/b^2 - 1/b; Normal: t/s^2,
+ * t^2/s^3 - 1/s (t = z - loc).  Row ranges of 256 summed in a fixed order (bit-reproducible).  workspace: at least
+ * (ceil(M/256) + ceil(M/65536) + 4) * 2 D floats. */
+int usf_base_param_grad_f32(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
+                            const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, usf_stream_t stream);
+
 /* Measurement aid (bench.py: roofline.sustained_peak): ONE launch of a register-only loop of the planes GEMM's matrix-core
  * instruction mix (v_mfma_f32_16x16x32_bf16, 10 x 2 accumulator tiles, six products per fp32-equivalent product; 512 threads,
  * two waves per SIMD; no LDS, no memory traffic in the loop) -- `iters` slabs of 120 MFMAs per wave on `blocks` blocks

@@ -573,6 +573,19 @@ def _emu_base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
     gv[:, :D] = (v * g_lp.double()[:, None]).float()
 
 
+def _emu_base_param_grad(z, ldz, g_lp, M, D, base, loc, scale, out):
+    zz = _view(z, 0, M, D, ldz).double()
+    t = zz - loc.double()
+    b = scale.double()
+    w = g_lp.double()[:M, None]
+    if base == _ext.BASE_LAPLACE:
+        dl, ds = torch.sign(t) / b, t.abs() / (b * b) - 1.0 / b
+    else:
+        dl, ds = t / (b * b), t * t / (b * b * b) - 1.0 / b
+    out[0, :D].copy_((w * dl).sum(0).float())
+    out[1, :D].copy_((w * ds).sum(0).float())
+
+
 def _emu_gemm_f64(A, B, Cout, *, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=1, strideA=0, strideB=0,
                   strideC=0, alpha=1.0, beta=0.0, tri=0, a_off=0, b_off=0, c_off=0):
     for i in range(batch):
@@ -594,6 +607,7 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "act_grad", _emu_act_grad)
     monkeypatch.setattr(_ext, "base_logprob", _emu_base_logprob)
     monkeypatch.setattr(_ext, "base_logprob_grad", _emu_base_logprob_grad)
+    monkeypatch.setattr(_ext, "base_param_grad", _emu_base_param_grad)
     monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
     monkeypatch.setattr(_ext, "pack_planes", _emu_pack_planes_call)
     monkeypatch.setattr(_ext, "gemm_planes", _emu_gemm_planes_call)

@@ -16,7 +16,7 @@ def case_names(small_only=False):
     # (the BASELINE cfg4 fixture -- 1.28 G parameters regenerated from the seed -- is loaded by name in
     # tests/test_configs_gpu.py only: far too big for the per-case loops)
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "imageradial_", "imageradialfit_", "fitsophia_", "sophia_", "gmfit_")) and "cfg4" not in p)
+                   if not os.path.basename(p).startswith(("grads_", "fit_", "udl_", "image_", "imagegrads_", "imagefit_", "imageradial_", "imageradialfit_", "fitsophia_", "sophia_", "gmfit_", "tbase_")) and "cfg4" not in p)
     if small_only:
         names = [n for n in names if "d784" not in n]
     return names
@@ -73,6 +73,24 @@ def load_gm_live_fit(name):
     sd0 = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0/")}
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
     return spec, torch.from_numpy(z["data"]), [float(v) for v in z["losses"]], sd0, sd
+
+
+def trainable_base_case_names():
+    """flows over the reference's TRAINABLE Laplace / Normal base modules: tests/golden/make_golden_trainable_base.py"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "tbase_*.npz")))
+
+
+def load_trainable_base_case(name):
+    """(spec, state dict incl. base_distribution.*, x, log_prob64, loss, {parameter: gradient of -log_prob(x).mean()})"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    d = json.loads(str(z["spec"]))
+    spec = orc.FlowSpec(**d)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    spec.base_loc = sd["base_distribution.loc"].clone()
+    sc = torch.nn.functional.softplus(sd["base_distribution.scale_unconstrained"])
+    spec.base_scale = sc.expand(spec.dim).clone() if sc.dim() == 0 else sc.clone()
+    return (spec, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["log_prob64"]), float(z["loss64"]),
+            {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")})
 
 
 def grad_case_names():

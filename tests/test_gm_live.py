@@ -98,9 +98,13 @@ def test_device_gradients_of_the_fit_loss_match_the_reference(name):
     assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref)
     loss.backward()
     named = dict(flow.named_parameters())
+    gmax = max(g.abs().max().item() for g in g_ref.values())
     for k, g in g_ref.items():
         assert named[k].grad is not None, k
-        _close(named[k].grad, g, 5e-5 if g.abs().max().item() > 0 else 1e-30, k)
+        # (a tensor whose reference gradient cancels to ~1e-15 -- L_raw's one entry at D = 2, where the block's M and M^-1 usages
+        # meet -- is held to the noise floor of the pass: 1e-5 of the largest gradient entry of the flow)
+        d = (named[k].grad.detach().cpu().double().reshape(g.shape) - g.double()).abs().max().item()
+        assert d <= 5e-5 * g.abs().max().item() + 1e-5 * gmax, (k, d, g.abs().max().item())
 
 
 @pytest.mark.gpu

@@ -237,6 +237,7 @@ SYMBOLS = {
                                        _fp, C.c_int64, _fp]),
     "usf_wgrad_blocked_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp,
                                         C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
+    "usf_base_param_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_mfma_probe": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
     "usf_wgrad_planes_colsum_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
@@ -1353,6 +1354,13 @@ def base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
     _launch("usf_base_logprob_grad_f32", (z.data_ptr(), ldz, g_lp.data_ptr(), M, D, base, loc.data_ptr(),
                                           scale.data_ptr(), g.data_ptr(), ldg, current_stream(z.device)),
             (z, g_lp, loc, scale, g))
+
+
+def base_param_grad(z, ldz, g_lp, M, D, base, loc, scale, out):
+    """usf_base_param_grad_f32: out [2, D] = (sum_m g_lp[m] d/dloc, sum_m g_lp[m] d/dscale) of a Laplace / Normal base at z"""
+    ws = _workspace(z.device, (M // 256 + M // 65536 + 6) * 2 * D)
+    _launch("usf_base_param_grad_f32", (z.data_ptr(), ldz, g_lp.data_ptr(), M, D, base, loc.data_ptr(), scale.data_ptr(), out.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), current_stream(z.device)), (z, g_lp, loc, scale, out, ws))
 
 
 def sophiag_step(chunks_dev: torch.Tensor, n_chunks: int, *, decay, beta1, rho_bs, lr, maximize=False) -> None:

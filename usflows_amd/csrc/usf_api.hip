@@ -112,6 +112,8 @@ int wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K);
 int wgrad_blocked(const void* Yp, int64_t y_nkb, int64_t y_kb0, const void* Ap, int64_t a_nkb, int64_t a_kb0, int64_t M, int64_t N,
                   int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out, float cs_alpha, float cs_beta,
                   float* workspace, int64_t workspace_floats, hipStream_t stream);
+int base_param_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
+                    const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, hipStream_t stream);
 int mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, hipStream_t stream);
 int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float alpha, float beta, float* workspace,
            int64_t workspace_floats, hipStream_t stream);
@@ -362,6 +364,10 @@ int usf_wgrad_blocked_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, co
                           float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::wgrad_blocked(Y_planes, y_nkb, y_kb0, A_planes, a_nkb, a_kb0, M, N, K, G, ldg, alpha, beta, colsum_out, cs_alpha,
                             cs_beta, workspace, workspace_floats, (hipStream_t)stream);
+}
+int usf_base_param_grad_f32(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
+                            const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
+  return usf::base_param_grad(z, ldz, g_lp, M, D, base, loc, scale, d_loc_scale, workspace, workspace_floats, (hipStream_t)stream);
 }
 int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, usf_stream_t stream) {
   return usf::mfma_probe(src1024, sink, iters, blocks, flops_out, (hipStream_t)stream);

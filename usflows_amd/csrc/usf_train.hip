@@ -743,6 +743,47 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   }
 }
 
+// Gradients of sum_m g_lp[m] * sum_d base_d(z[m,d]; loc_d, scale_d) w.r.t. loc and scale, over a range of 256 rows (colsum_kernel's
+// block shape): part[split][0][d] = sum_m g_lp[m] * d/dloc,  part[split][1][d] = sum_m g_lp[m] * d/dscale
+//   Laplace (torch.distributions.Laplace.log_prob): d/dloc = sign(t) / b,  d/db = |t| / b^2 - 1 / b      (t = z - loc)
+//   Normal:                                         d/dloc = t / s^2,      d/ds = t^2 / s^3 - 1 / s
+__global__ __launch_bounds__(1024) void base_param_grad_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ g_lp,
+                                                               int M, int D, int base, const float* __restrict__ loc,
+                                                               const float* __restrict__ scale, float* __restrict__ part) {
+  __shared__ float red[2][16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int m_begin = blockIdx.y * 256;
+  const int m_end = (m_begin + 256 < M) ? m_begin + 256 : M;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < D) {
+    const float mu = loc[c], b = scale[c];
+    const float ib = 1.0f / b;
+#pragma unroll 4
+    for (int m = m_begin + rl; m < m_end; m += 16) {
+      const float t = z[(int64_t)m * ldz + c] - mu;
+      const float w = g_lp[m];
+      if (base == USF_BASE_LAPLACE) {
+        const float sg = (float)((t > 0.f) - (t < 0.f));
+        s0 += w * (sg * ib);
+        s1 += w * (fabsf(t) * ib * ib - ib);
+      } else {
+        s0 += w * (t * ib * ib);
+        s1 += w * (t * t * ib * ib * ib - ib);
+      }
+    }
+  }
+  red[0][rl][cl] = s0;
+  red[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl < 2 && c < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[rl][r][cl];
+    part[((int64_t)blockIdx.y * 2 + rl) * D + c] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_grad_kernel(float* __restrict__ d, int64_t ldd, const float* __restrict__ h,
                                                        int64_t ldh, int64_t M, int64_t H, float slope) {
   const int64_t total = M * H;
@@ -898,6 +939,23 @@ int colsum(const float* Y, int64_t ldy, int64_t M, int64_t N, float* out, float 
     ld = N;
   }
   return check_launch("usf_colsum_f32");
+}
+
+// usf_base_param_grad_f32: see include/usflows_hip.h
+int base_param_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
+                    const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, hipStream_t stream) {
+  if (M < 0 || D <= 0 || ldz < D || (M > 0 && (!z || !g_lp)) || !loc || !scale || !d_loc_scale || M > 0x7fffffff || D > 0x3fffffff) {
+    set_error("usf_base_param_grad_f32: bad arguments");
+    return -1;
+  }
+  if (base != USF_BASE_LAPLACE && base != USF_BASE_NORMAL) { set_error("usf_base_param_grad_f32: Laplace / Normal only"); return -2; }
+  const int64_t splits = M > 0 ? (M + 255) / 256 : 0;
+  if (splits == 0) return hipMemsetAsync(d_loc_scale, 0, (size_t)(2 * D) * sizeof(float), stream) == hipSuccess ? 0 : -5;
+  if (!workspace || splits * 2 * D > workspace_floats) { set_error("usf_base_param_grad_f32: workspace too small"); return -4; }
+  base_param_grad_kernel<<<dim3((unsigned)((D + 63) / 64), (unsigned)splits), 1024, 0, stream>>>(z, ldz, g_lp, (int)M, (int)D, base, loc,
+                                                                                              scale, workspace);
+  // the partials' rows [split][2 D] summed in colsum's fixed order (bit-reproducible)
+  return colsum(workspace, 2 * D, splits, 2 * D, d_loc_scale, 1.f, 0.f, workspace + splits * 2 * D, workspace_floats - splits * 2 * D, stream);
 }
 
 int grad_jobs(const usf_grad_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream) {

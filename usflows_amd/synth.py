@@ -167,6 +167,12 @@ def make_base(spec: ModelSpec, device="cpu"):
     if spec.base in ("laplace", "normal"):
         loc = (spec.base_loc if spec.base_loc is not None else torch.zeros(n)).to(device)
         sc = (spec.base_scale if spec.base_scale is not None else torch.ones(n)).to(device)
+        if spec.extra.get("trainable_base"):
+            # the reference's TRAINABLE base modules (distributions.py:199-238): loc / softplus-constrained scale as nn.Parameters
+            # (their values travel in the state dict); "scalar_scale": a 0-dim scale (Normal's expand path, distributions.py:231-234)
+            if spec.extra.get("trainable_base") == "scalar_scale":
+                sc = sc.flatten()[0].clone()
+            return (D.Laplace if spec.base == "laplace" else D.Normal)(loc.clone(), sc.clone(), device=device)
         cls = torch.distributions.Laplace if spec.base == "laplace" else torch.distributions.Normal
         return cls(loc, sc)
     if spec.radial_norm == "gammamm":

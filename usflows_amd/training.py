@@ -76,7 +76,7 @@ class TrainPath:
             # returns the Lp radius and the finishing formula stays in torch (O(B), differentiable)
             if getattr(self.flow.base_distribution, "n_batch_dims", 1) != 0:
                 return False
-        elif any(p.requires_grad for p in self._base_params()):
+        elif any(p.requires_grad for p in self._base_params()) and self._locscale_base() is None:
             return False
         for s in eng.steps:
             if s.kind == "coupling" and not isinstance(s.module.conditioner, (ConditionalDenseNN, DenseNN)):
@@ -88,6 +88,37 @@ class TrainPath:
     def _base_params(self):
         b = self.flow.base_distribution
         return list(b.parameters()) if isinstance(b, torch.nn.Module) else []
+
+    def _locscale_base(self):
+        """the base distribution when it is one of the reference's TRAINABLE Laplace / Normal modules (distributions.py:199-238:
+        ``loc`` and a softplus-constrained ``scale_unconstrained`` as nn.Parameters, [D] or broadcast over the features): their
+        gradients come from usf_base_param_grad_f32"""
+        from .distributions import Laplace, Normal
+        b = self.flow.base_distribution
+        if not isinstance(b, (Laplace, Normal)) or getattr(b, "n_batch_dims", 0) != 0:
+            return None
+        D = self.eng.D
+        for p in (b.loc, b.scale_unconstrained):
+            if p.dim() > 1 or (p.dim() == 1 and p.shape[0] not in (1, D)) or p.dtype != torch.float32:
+                return None
+        return b
+
+    def base_extra_params(self, device=None) -> List[torch.nn.Parameter]:
+        """trainable parameters of the base distribution whose gradients the node itself produces (besides the layers')"""
+        b = self._locscale_base()
+        if b is None:
+            return []
+        return [p for p in (b.loc, b.scale_unconstrained) if p.requires_grad]
+
+    def _base_tensors(self, ws, info):
+        """(base id, loc, scale) for the tail / gradient kernels.  A trainable Laplace / Normal module: persistent [D] buffers
+        of the workspace, refilled by every forward pass (the recorded backward launches keep reading the same addresses)"""
+        base, loc, scale = self._base_ids(info)
+        if info[0] != "radial" and self.base_extra_params():
+            D = self.eng.D
+            lb, sb = self._buf(ws, "base_loc", 1, D)[0, :D], self._buf(ws, "base_scale", 1, D)[0, :D]
+            return base, lb, sb
+        return base, loc, scale
 
     def params(self) -> List[torch.nn.Parameter]:
         return self.eng._params()
@@ -105,6 +136,11 @@ class TrainPath:
         zname, _, ldn = plan["out_buf"]
         info = self.flow._base_info(dev)
         base, loc, scale = self._base_ids(info)
+        if info[0] != "radial" and self.base_extra_params():
+            _b, lb, sb = self._base_tensors(plan["ws"], info)
+            lb.copy_(loc)
+            sb.copy_(scale)
+            loc, scale = lb, sb
         # what the backward must find unchanged: the workspace's pass counter (ANY later pass over the same (B, device)
         # workspace -- a training forward or a no_grad log_prob / backward / sample -- overwrites the saved
         # activations, the staged input and the context columns) and the parameter versions
@@ -266,6 +302,7 @@ class TrainPath:
         b = self.flow.base_distribution
         if hasattr(b, "loc") and isinstance(getattr(b, "loc", None), torch.nn.Parameter):
             ps.append(b.loc)
+        ps += self.base_extra_params()
         return {id(p): p for p in ps}
 
     def bind_flat_grads(self) -> bool:
@@ -375,6 +412,7 @@ class TrainPath:
         info = self.flow._base_info(dev)
         if info is not None and info[0] == "radial":
             extra.append(self.flow.base_distribution.loc)
+        extra += self.base_extra_params()
         for p in list(self.params()) + extra:
             if id(p) not in slots and p.requires_grad:
                 slots[id(p)] = (off, p.numel(), tuple(p.shape))
@@ -398,12 +436,13 @@ class TrainPath:
         glp = self._buf(ws, "g_lp", 1, B)[0, :B]
         _ext.host_op(lambda: (arena["flat"].zero_(), glp.copy_(self._cur["g_lp"])))
         info = self.flow._base_info(dev)
-        base, loc, scale = self._base_ids(info)
+        base, loc, scale = self._base_tensors(ws, info)
         zname, _, ldn = plan["out_buf"]
         grads = arena["views"]
         self._touched = arena["touched"]
         if info[0] == "radial":
             scale = self._buf(ws, "radius", 1, B)[0, :B]              # the forward left r = ||z - loc||_p here
+        self._base_param_grads(ws, ws[zname], ldn, glp, B, base, loc, scale, grads)
         _ext.base_logprob_grad(ws[zname], ldn, glp, B, D, base, loc, scale, gA, ldn)
         if info[0] == "radial":
             g_loc = self._grad_slot(grads, self.flow.base_distribution.loc)
@@ -442,6 +481,29 @@ class TrainPath:
                     self._g_pending = self._defer
         _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
 
+    def _base_param_grads(self, ws, z, ldz, glp, B, base, loc, scale, grads):
+        """a trainable Laplace / Normal base: d/dloc, d/dscale_unconstrained of sum_m g_lp[m] log_prob[m] -- one pass over the
+        latent (usf_base_param_grad_f32), then the softplus chain rule / the reduction of broadcast parameters on [D] tensors"""
+        extra = self.base_extra_params()
+        if not extra:
+            return
+        bm = self._locscale_base()
+        D = self.eng.D
+        tmp = self._buf(ws, "base_pg", 2, D)
+        _ext.base_param_grad(z, ldz, glp, B, D, base, loc, scale, tmp)
+
+        def finish():
+            def to_shape(v, p):
+                return v.reshape(p.shape) if p.numel() == D and p.dim() == 1 else v.sum().reshape(p.shape)
+            g = self._grad_slot(grads, bm.loc)
+            if g is not None:
+                g.copy_(to_shape(tmp[0, :D], bm.loc))
+            g = self._grad_slot(grads, bm.scale_unconstrained)
+            if g is not None:
+                raw = bm.scale_unconstrained.detach()
+                g.copy_(to_shape(tmp[1, :D] * torch.sigmoid(raw).expand(D), bm.scale_unconstrained))
+        _ext.host_op(finish)
+
     # ---- the backward pass on the planes pipeline (round 5) -----------------------------------------------------------
     # The forward ran as the inference pipeline does -- usf_pack_planes_f32, usf_gemm_planes_bf16x3, usf_coupling_planes --
     # with every affine output in a planes buffer of its own and the conditioners' hidden activations saved as planes
@@ -472,10 +534,11 @@ class TrainPath:
         glp = self._buf(ws, "g_lp", 1, B)[0, :B]
         _ext.host_op(lambda: (arena["flat"].zero_(), glp.copy_(self._cur["g_lp"])))
         info = self.flow._base_info(dev)
-        base, loc, scale = self._base_ids(info)
+        base, loc, scale = self._base_tensors(ws, info)
         zname, _, ldn = plan["out_buf"]
         grads = arena["views"]
         self._touched = arena["touched"]
+        self._base_param_grads(ws, ws[zname], ldn, glp, B, base, loc, scale, grads)
         gp = [self._planes_buf(ws, "pgA", B, nkb_g), self._planes_buf(ws, "pgB", B, nkb_g)]
         key = ("natp_g", nkb_g, str(dev))
         if key not in self._inv:
@@ -1299,4 +1362,4 @@ def log_prob_with_grad(path: TrainPath, x, context):
     # even while the .grad views of an earlier fit are still in place)
     if path.__dict__.get("use_bound_node", False) and path.grads_bound() and torch.is_grad_enabled():
         return _LogProbFn.apply(path, x, context, path._anchor)
-    return _LogProbFn.apply(path, x, context, *params)
+    return _LogProbFn.apply(path, x, context, *(params + path.base_extra_params()))
