@@ -546,12 +546,6 @@ typedef struct usf_coupling_planes_desc {
   const void* gate[2];
 } usf_coupling_planes_desc;
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream);
-/* Which kernel serves usf_coupling_planes: 0 = 16 batch rows per wave, two waves per SIMD (the default); 1 = 32 rows per
- * wave on the 512-register budget, one wave per SIMD (n_hidden <= 2, nk_p >= 2; other layers keep the 16-row kernel);
- * -1 = back to the environment's choice (USF_CP_W32, default 0).  The two kernels sum every accumulator in the same order:
- * bit-identical results in the bf16x3 format.  Returns the previous setting.  (A tuning knob: process-wide, not
- * thread-safe against concurrent launches.) */
-int usf_coupling_planes_select(int w32);
 
 /*
  * Row pass of the vector ConvNet conditioner's blocks (networks.py:222-245 GatedMLP, :206-219 LayerNormVector, vector
@@ -870,6 +864,11 @@ int usf_base_param_grad_f32(const float* z, int64_t ldz, const float* g_lp, int6
  * (0: two per CU).  src1024: 1024 finite floats (device); sink: one float (device, never written); *flops_out (host, may be
  * NULL): the bf16 MFMA flops of the launch (fp32-equivalent: / 6).  The caller times the launch with events on `stream`. */
 int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, usf_stream_t stream);
+
+/* Tuning knobs of the kernels' host code (A/B switches, cross-overs): named integers, preset on first use from the environment
+ * variable USFLOWS_AMD_TUNE ("name=value,..."), changed at run time here.  usf_get_tuning(name, dflt): the value in force. */
+int usf_set_tuning(const char* name, int64_t value);
+int64_t usf_get_tuning(const char* name, int64_t dflt);
 
 int usf_abi_version(void);
 int usf_sizeof_desc(int32_t kind);      /* sizeof(usf_linear_desc|usf_coupling_desc|usf_op|usf_lu_prep_desc|usf_pack_job) for kind 1|2|0|3|4;

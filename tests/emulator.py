@@ -222,7 +222,7 @@ def emulate_coupling_planes(d, pm: PtrMap, dtype=torch.float32):
             v = torch.where(h0.to(dtype) > 0, v, v * d.slope)
         elif d.act == _ext.ACT_LEAKY_RELU:
             v = torch.where(v > 0, v, v * d.slope)
-        if d.hidden_out[l]:
+        if l < 2 and d.hidden_out[l]:
             planes_encode(planes_view(pm, d.hidden_out[l], npan, 8, fmt), v.to(torch.float32), 0)
         return v
 

@@ -67,10 +67,13 @@ def _check_fit(flow, losses, losses_ref, sd_ref, loss_tol, exact):
         if exact:
             assert d.max().item() <= 2e-5 * s + 1e-7, (k, d.max().item())
         else:
-            # SophiaG with a zero Hessian estimate moves every entry by lr * sign(momentum) per step: 6e-3 after 6 steps; a sign
-            # flip of a near-zero gradient moves an entry by 2 lr
-            assert d.max().item() <= 2.1e-3 + 2e-3 * s, (k, d.max().item())
-            assert (d > 1e-4 * s + 1e-6).double().mean().item() < 0.02, (k, "more than 2 % of the entries took another sign")
+            # SophiaG with a zero Hessian estimate moves every entry by lr * sign(momentum) per step, WHATEVER the gradient's size:
+            # an entry whose gradient cancels to fp32 noise (the bias of a conjugated block: its M and M^-1 usages meet) walks on the
+            # noise's sign, 2 lr apart per step between two correct implementations -- at most 12e-3 after the 6 steps.  Entries
+            # with a real gradient agree; in a tensor of hundreds of entries the noise-driven ones are a small minority.
+            assert d.max().item() <= 12.1e-3 + 2e-3 * s, (k, d.max().item())
+            if d.numel() >= 256:
+                assert (d > 1e-4 * s + 1e-6).double().mean().item() < 0.02, (k, "more than 2 % of the entries took another sign")
 
 
 @pytest.mark.parametrize("name", gm_live_fit_case_names())

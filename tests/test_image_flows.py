@@ -552,7 +552,7 @@ def test_pointwise_conv_gated_layernorm_form_vs_torch(B, C, H, W):
 @pytest.mark.gpu
 def test_convnet2d_joins_gated_conv_relu_and_layernorm_into_one_pass(monkeypatch):
     """ConvNet2D on the device: [GatedConv, ReLU, LayerNormChannels] runs as conv 3x3 + ONE pointwise pass (no separate layer
-    norm launch); same values as with USF_POINTWISE=0 (matrix-core 1 x 1 convolution + layer-norm pass) to rounding and as the
+    norm launch); same values as with config.pointwise = False (matrix-core 1 x 1 convolution + layer-norm pass) to rounding and as the
     torch modules on the CPU"""
     from usflows_amd import _ext
     from usflows_amd.networks import ConvNet2D
@@ -568,7 +568,8 @@ def test_convnet2d_joins_gated_conv_relu_and_layernorm_into_one_pass(monkeypatch
         monkeypatch.setattr(_ext, "layernorm_channels", lambda *a_, **k_: (ln_calls.append(1), real(*a_, **k_))[1])
         y = dnet(x.to("cuda:0"))
         assert not ln_calls, "the layer norm ran as a pass of its own"
-        monkeypatch.setenv("USF_POINTWISE", "0")
+        from usflows_amd.config import config
+        monkeypatch.setattr(config, "pointwise", False)
         y0 = dnet(x.to("cuda:0"))
         assert len(ln_calls) == 2
     assert (y.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

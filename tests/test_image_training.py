@@ -436,44 +436,6 @@ def test_affine_prep_kernels_match_the_torch_formulation(C, nvs, n, monkeypatch)
 
 
 @pytest.mark.gpu
-def test_weight_gradients_on_the_side_stream_are_the_same_bits(monkeypatch):
-    """small batches: the convolutions' weight / bias gradients run on a second stream beside the data-gradient chain and join
-    it when the backward pass ends (image_training.side_wgrad) -- same bits as on one stream, used only while a parameter's
-    .grad is empty (the engine then takes the tensor without reading it), joined before anything reads the gradients"""
-    from usflows_amd import image_training as it
-    flow, a = load_image_case("image_mnistcfg_c16_7x7_k2_gated_ln_hh1_conj", device=DEV)
-    x = a["x"].to(DEV)
-    used = []
-    real_enter = it.side_wgrad.__enter__
-    monkeypatch.setattr(it.side_wgrad, "__enter__", lambda self: (used.append(self.on), real_enter(self))[1])
-
-    def grads(env):
-        monkeypatch.setenv("USFLOWS_AMD_SIDE_WGRAD", env)
-        for p in flow.parameters():
-            p.grad = None
-        (-flow.log_prob(x).mean()).backward()
-        torch.cuda.synchronize()
-        return {k: p.grad.clone() for k, p in flow.named_parameters() if p.grad is not None}
-
-    g_off = grads("0")
-    assert used and not any(used)
-    del used[:]
-    g_on = grads("1")
-    assert any(used), "the side stream was not used"
-    assert set(g_on) == set(g_off)
-    for k in g_off:
-        assert torch.equal(g_on[k], g_off[k]), k
-    # a second pass WITHOUT emptying the gradients accumulates in place: the work stays on the pass's own stream
-    del used[:]
-    (-flow.log_prob(x).mean()).backward()
-    torch.cuda.synchronize()
-    conv_used = [u for u in used]
-    assert not any(conv_used), "side stream used although the parameters already hold gradients"
-    for k in g_off:
-        assert torch.allclose(dict(flow.named_parameters())[k].grad, 2 * g_off[k], rtol=1e-5, atol=1e-6 * float(g_off[k].abs().max())), k
-
-
-@pytest.mark.gpu
 def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bits(monkeypatch):
     """small batches: the last stage of every convolution weight gradient of a backward pass (the sum over per-wave partial
     slots) is queued and leaves as ONE usf_partial_sum_jobs_f32 launch when the pass ends -- same additions in the same order
@@ -486,7 +448,8 @@ def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bi
     monkeypatch.setattr(_ext, "_launch", lambda name, *a_, **k_: (launches.append(name), real(name, *a_, **k_))[1])
 
     def grads(env, scope=True, twice=False):
-        monkeypatch.setenv("USFLOWS_AMD_PSUM_JOBS", env)
+        from usflows_amd.config import config
+        monkeypatch.setattr(config, "psum_jobs", env == "1")
         for p in flow.parameters():
             p.grad = None
         del launches[:]

@@ -272,7 +272,7 @@ def test_wgrad_planes_equals_the_loader_wave_kernel_on_the_plain_grid(monkeypatc
         print("same bits")
     ''')
     import os
-    env = dict(os.environ, USF_WGRAD_SCHED="0")
+    env = dict(os.environ, USFLOWS_AMD_TUNE="wgrad_sched=0")      # (the library's tuning table: the plain grid of row ranges)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "same bits" in r.stdout, r.stdout + r.stderr

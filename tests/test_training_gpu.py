@@ -309,11 +309,12 @@ def test_large_batch_training_paths_equal_the_round_3_path(monkeypatch, variant)
     monkeypatch.setattr(_ext, "wgrad_planes", lambda *a, **k: (calls.append(k["N"]), real(*a, **k))[1])
     real_c = _ext.coupling_op
     monkeypatch.setattr(_ext, "coupling_op", lambda *a, **k: (calls.append("cbwd"), real_c(*a, **k))[1])
-    switches = ("USFLOWS_AMD_WGRAD_PLANES", "USFLOWS_AMD_FUSED_BIAS", "USFLOWS_AMD_SAVE_HIDDEN", "USFLOWS_AMD_FUSED_CBWD")
+    from usflows_amd.config import config
+    switches = ("wgrad_planes", "fused_bias", "save_hidden", "fused_cbwd")          # (usflows_amd.config's knobs of the fp32-row path)
 
     def grads_with(on):
         for sw in switches:
-            monkeypatch.setenv(sw, "1" if sw in on else "0")
+            monkeypatch.setattr(config, sw, sw in on)
         flow = build_flow(spec, sd, device=DEV)
         n0 = len(calls)
         for _ in range(2):                                      # the second pass replays the recorded launches
@@ -366,7 +367,8 @@ def test_fit_hands_large_host_batches_over_under_the_running_step(monkeypatch):
     monkeypatch.setattr(F_._BatchFeed, "make", staticmethod(lambda *a: (made.append(real(*a)), made[-1])[1]))
     curves = []
     for prefetch in ("0", "1"):
-        monkeypatch.setenv("USFLOWS_AMD_FIT_PREFETCH", prefetch)
+        from usflows_amd.config import config
+        monkeypatch.setattr(config, "fit_prefetch", prefetch == "1")
         flow = build_flow(spec, sd, device=DEV)
         np.random.seed(5)
         curves.append(flow.fit(DS(), optim=SophiaG, optim_params=dict(lr=1e-4), batch_size=B, shuffle=True,
@@ -393,8 +395,9 @@ def test_fused_coupling_backward_for_one_to_three_hidden_layers(monkeypatch, hid
     monkeypatch.setattr(_ext, "coupling_op", lambda *a, **k: (n_launch.append(1), real_c(*a, **k))[1])
     grads = []
     for on in ("1", "0"):
-        monkeypatch.setenv("USFLOWS_AMD_SAVE_HIDDEN", on)
-        monkeypatch.setenv("USFLOWS_AMD_FUSED_CBWD", on)
+        from usflows_amd.config import config
+        monkeypatch.setattr(config, "save_hidden", on == "1")
+        monkeypatch.setattr(config, "fused_cbwd", on == "1")
         flow = build_flow(spec, sd, device=DEV)
         flow.engine().fused_min_rows = 0                        # the fused kernel from 1024 rows on
         n0 = len(n_launch)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """usf_conv2d_same_f32 at the conditioner shapes of the MNIST image configuration: register-weight kernel vs first kernel
-(USF_CONV_WREG=0) -- run once per setting of USF_CONVW_DBG (phase ablations; tuning aid)."""
+(USFLOWS_AMD_TUNE=conv_wreg=0) -- run once per setting of USFLOWS_AMD_TUNE=convw_dbg=... (phase ablations; tuning aid)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ from usflows_amd import _ext
 _ext.load()
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-tag = f"WREG={os.environ.get('USF_CONV_WREG', '1')} DBG={os.environ.get('USF_CONVW_DBG', '0')}"
+tag = f"WREG={os.environ.get('USFLOWS_AMD_TUNE', '')} DBG={'see USFLOWS_AMD_TUNE (conv_wreg, convw_dbg)'}"
 out = []
 for cin, cout, H, W in [(32, 32, 7, 7), (16, 32, 7, 7), (32, 16, 7, 7), (32, 32, 8, 8), (48, 32, 8, 8), (32, 48, 8, 8)]:
     b_ = B if H * W < 60 else B // 4

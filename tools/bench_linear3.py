@@ -1,5 +1,5 @@
 """usf_linear_f32 on the bf16x3 kernel (W_split given) at the GEMM shapes of the cfg2 training step (dev tool, GPU box only):
-   python tools/bench_linear3.py [rows]        USF_BF16X3_WM=4 / 8 forces the 4- / 8-wave tile"""
+   python tools/bench_linear3.py [rows]        USFLOWS_AMD_TUNE=bf16x3_wm=4 / 8 forces the 4- / 8-wave tile"""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

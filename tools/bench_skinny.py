@@ -2,7 +2,7 @@
 """usf_linear_f32 at small batches as the flow runs it: a chain of LAYERS dependent launches, every layer with weights of its
 own (cold in the L2), replayed as a hipGraph -- microseconds per layer.  tools/bench_skinny.py [rows] [layers]
 Variants by environment (read once per process): USF_SKINNY_KS_SMALL=4|8 (K ranges per block up to 32 rows),
-USF_SKINNY_G=4|8 (k-steps fetched together)."""
+USFLOWS_AMD_TUNE=skinny_g=4|8 (k-steps fetched together)."""
 import math
 import os
 import sys
@@ -42,4 +42,4 @@ for N, K in ((784, 784), (256, 392), (256, 256), (392, 256)):
         e1.record()
         e1.synchronize()
     print(f"rows {M}  {N} x {K}: {e0.elapsed_time(e1) / 20 / LAYERS * 1e3:.2f} us per layer "
-          f"(KS_SMALL={os.environ.get('USF_SKINNY_KS_SMALL', '4')} G={os.environ.get('USF_SKINNY_G', '4')})", flush=True)
+          f"(KS_SMALL={os.environ.get('USFLOWS_AMD_TUNE', '')} G={'(skinny_ks_small / skinny_g)'})", flush=True)

@@ -2,7 +2,7 @@
 """Flow.fit of the reference's MNIST / CIFAR image models (tests/explib/mnist.yaml:44-77, experiments/cifar/cifar.yaml:56-77):
 GPU time of one optimiser step (zero grads, log_prob, backward, SophiaG update) as Flow.fit replays it (the captured
 hipGraph, timed over N replays) -- the device training path (usflows_amd/image_training.py) against torch autograd + MIOpen
-(USFLOWS_AMD_IMAGE_TRAIN=0) on the same flow, same data; the two runs' epoch losses side by side.
+(usflows_amd.config.image_train = False) on the same flow, same data; the two runs' epoch losses side by side.
 
     python3 tools/fit_image.py [mnist_image|cifar_image] [batch ...]"""
 import os
@@ -37,7 +37,8 @@ def build():
 
 
 def run(B, device_path):
-    os.environ["USFLOWS_AMD_IMAGE_TRAIN"] = "1" if device_path else "0"
+    from usflows_amd.config import config
+    config.image_train = bool(device_path)
     flow = build()
     x = torch.rand(B * 6, *dims, generator=torch.Generator().manual_seed(5))
     ds = torch.utils.data.TensorDataset(x, torch.zeros(x.shape[0]))

@@ -334,14 +334,14 @@ if want("imagetrain"):
                            ("cifar_image", "32")):
             r = run(["python3", "bench.py", "--config", cfg, "--mode", "train", "--batch", batch, "--steps", "10"])
             f.write(last_json_line(r.stdout) + "\n")
-        # the same flow through torch autograd + MIOpen (what round 2 replayed): USFLOWS_AMD_IMAGE_TRAIN=0
-        env_t = dict(env, USFLOWS_AMD_IMAGE_TRAIN="0")
+        # the same flow through torch autograd + MIOpen (what round 2 replayed): USFLOWS_AMD_TUNE=image_train=0
+        env_t = dict(env, USFLOWS_AMD_TUNE="image_train=0")
         for cfg, batch in (("mnist_image", "65536"), ("mnist_image", "32")):
-            print("+ USFLOWS_AMD_IMAGE_TRAIN=0 python3 bench.py --config", cfg, "--mode train --batch", batch, flush=True)
+            print("+ USFLOWS_AMD_TUNE=image_train=0 python3 bench.py --config", cfg, "--mode train --batch", batch, flush=True)
             r = subprocess.run(["python3", "bench.py", "--config", cfg, "--mode", "train", "--batch", batch, "--steps", "10"], cwd=ROOT,
                                env=env_t, capture_output=True, text=True)
             line = json.loads(last_json_line(r.stdout))
-            line["config"]["workload"] += " [USFLOWS_AMD_IMAGE_TRAIN=0: torch autograd + MIOpen backward]"
+            line["config"]["workload"] += " [USFLOWS_AMD_TUNE=image_train=0: torch autograd + MIOpen backward]"
             f.write(json.dumps(line) + "\n")
     d = os.path.join(out, "ktrace_image_train")
     run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--config",

@@ -16,7 +16,9 @@ from typing import Optional
 import torch  # noqa: F401  -- must be imported first: the .so binds to torch's HIP runtime instance
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("USFLOWS_AMD_LIB", os.path.join(_HERE, "csrc", "libusflows_hip.so"))  # env: A/B tuning aid
+from .config import config  # noqa: E402
+
+LIB_PATH = config.lib_path     # (USFLOWS_AMD_LIB: A/B builds)
 
 USF_ABI_VERSION = 33
 USF_MAX_HIDDEN = 4
@@ -162,6 +164,8 @@ class GradJob(C.Structure):
 # every symbol include/usflows_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "usf_abi_version": (C.c_int, []),
+    "usf_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
+    "usf_get_tuning": (C.c_int64, [C.c_char_p, C.c_int64]),
     "usf_sizeof_desc": (C.c_int, [C.c_int32]),
     "usf_last_error": (C.c_char_p, []),
     "usf_build_info": (C.c_char_p, []),
@@ -171,7 +175,6 @@ SYMBOLS = {
     "usf_gemm_planes_bf16x3": (C.c_int, [C.POINTER(GemmPlanesDesc), C.c_void_p]),
     "usf_gemm_planes_variant": (C.c_int, [C.POINTER(GemmPlanesDesc)]),
     "usf_coupling_planes": (C.c_int, [C.POINTER(CouplingPlanesDesc), C.c_void_p]),
-    "usf_coupling_planes_select": (C.c_int, [C.c_int]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
@@ -885,7 +888,7 @@ def _device_table(host: torch.Tensor, device) -> Optional[torch.Tensor]:
 def psum_defer_ok(x) -> bool:
     """may a weight gradient of this input queue its last sum?  (small batch, inside a backward pass, and -- inside a capture --
     a table buffer at hand)"""
-    return (_psum.scope > 0 and os.environ.get("USFLOWS_AMD_PSUM_JOBS", "1") != "0" and 0 < x.shape[0] <= PSUM_DEFER_MAX_ROWS
+    return (_psum.scope > 0 and config.psum_jobs and 0 < x.shape[0] <= PSUM_DEFER_MAX_ROWS
             and torch._C._current_graph_task_id() >= 0
             and (not torch.cuda.is_current_stream_capturing() or _psum.arena is not None))
 

@@ -1,5 +1,6 @@
 // extern "C" surface of libusflows_hip.so (declared in include/usflows_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "usf_common.h"
@@ -7,6 +8,46 @@
 namespace usf {
 
 static thread_local char g_err[512] = "";
+
+// ---- the ONE table of tuning knobs (usf_common.h: usf::tuning) ------------------------------------------------------------
+// Every A/B switch of the kernels' host code is a named integer read through tuning(name, default); the table is preset, on
+// first use, from the environment variable USFLOWS_AMD_TUNE ("name=value,name=value": the same variable usflows_amd/config.py
+// parses for the Python side's knobs; names nobody asks for are ignored) and changed at run time with usf_set_tuning.  The
+// only getenv of the library lives here.  Not synchronised against concurrent usf_set_tuning calls (a tuning aid).
+struct TuneEntry { char name[40]; long long value; };
+static TuneEntry g_tune[96];
+static int g_ntune = 0;
+static bool g_tune_init = false;
+
+static void tune_store(const char* name, size_t len, long long value) {
+  if (len == 0 || len >= sizeof(g_tune[0].name)) return;
+  for (int i = 0; i < g_ntune; ++i)
+    if (strlen(g_tune[i].name) == len && strncmp(g_tune[i].name, name, len) == 0) { g_tune[i].value = value; return; }
+  if (g_ntune < (int)(sizeof(g_tune) / sizeof(g_tune[0]))) {
+    memcpy(g_tune[g_ntune].name, name, len);
+    g_tune[g_ntune].name[len] = 0;
+    g_tune[g_ntune].value = value;
+    ++g_ntune;
+  }
+}
+static void tune_init() {
+  if (g_tune_init) return;
+  g_tune_init = true;
+  const char* e = getenv("USFLOWS_AMD_TUNE");
+  while (e && *e) {
+    const char* end = strchr(e, ',');
+    const size_t n = end ? (size_t)(end - e) : strlen(e);
+    const char* eq = (const char*)memchr(e, '=', n);
+    if (eq) tune_store(e, (size_t)(eq - e), atoll(eq + 1));
+    e = end ? end + 1 : nullptr;
+  }
+}
+long long tuning(const char* name, long long dflt) {
+  tune_init();
+  for (int i = 0; i < g_ntune; ++i)
+    if (strcmp(g_tune[i].name, name) == 0) return g_tune[i].value;
+  return dflt;
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -41,7 +82,6 @@ int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream);
 int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream);
 int gemm_planes_variant(const usf_gemm_planes_desc* d);
 int coupling_planes(const usf_coupling_planes_desc* d, hipStream_t stream);
-extern int g_cp_w32;
 int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream);
 int gemm_f64(const double* A, int64_t lda, int64_t sA, int transA, const double* B, int64_t ldb, int64_t sB, int transB,
              double* C, int64_t ldc, int64_t sC, int64_t M, int64_t N, int64_t K, int64_t batch, double alpha,
@@ -135,6 +175,13 @@ int radial_grad(const float* z, int64_t ldz, const float* r, const float* g_lp, 
 extern "C" {
 
 int usf_abi_version(void) { return USF_ABI_VERSION; }
+int usf_set_tuning(const char* name, int64_t value) {
+  if (!name || !*name || strlen(name) >= sizeof(usf::g_tune[0].name)) { usf::set_error("usf_set_tuning: bad name"); return -1; }
+  usf::tune_init();
+  usf::tune_store(name, strlen(name), (long long)value);
+  return 0;
+}
+int64_t usf_get_tuning(const char* name, int64_t dflt) { return name ? (int64_t)usf::tuning(name, (long long)dflt) : dflt; }
 int usf_sizeof_desc(int32_t kind) {
   switch (kind) {
     case USF_OP_LINEAR: return (int)sizeof(usf_linear_desc);
@@ -170,7 +217,6 @@ int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream) { re
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream) { return usf::gemm_planes(d, (hipStream_t)stream); }
 
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream) { return usf::coupling_planes(d, (hipStream_t)stream); }
-int usf_coupling_planes_select(int w32) { const int old = usf::g_cp_w32; usf::g_cp_w32 = w32 < 0 ? -1 : (w32 ? 1 : 0); return old; }
 int usf_gemm_planes_variant(const usf_gemm_planes_desc* d) { return usf::gemm_planes_variant(d); }
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }

@@ -14,6 +14,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace usf {
 
 void set_error(const char* fmt, ...);
+// a named tuning knob (usf_api.hip: the one table, preset from USFLOWS_AMD_TUNE, changed with usf_set_tuning)
+long long tuning(const char* name, long long dflt);
 
 static inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

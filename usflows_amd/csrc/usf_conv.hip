@@ -323,9 +323,7 @@ int conv2d_same(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, 
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W; a.ks = (int)ks;
   a.in_act = in_act; a.out_act = out_act; a.in_slope = in_slope; a.out_slope = out_slope;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("USF_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-  a.dbg = dbg;
+  a.dbg = (int)tuning("conv_dbg", 0);
   a.gate_x = gate_x; a.gateC = (int)gate_channels;
   // samples per group: as many as fit 158 KB of LDS (at most 8; at least one has to fit)
   int S = 8;

@@ -593,8 +593,7 @@ static int conv_wsp_plan(int cin, int cout, int H, int W, bool with_res, int* cg
     if (small == 0 && eff >= 0.7 && B > 0 && cus > 0 && (B + S - 1) / S <= cus) small = S;
   }
   if (best == 0 || best_eff < 0.7) return 0;
-  static int small_on = -1;
-  if (small_on < 0) { const char* e = getenv("USF_CONV_SMALL_S"); small_on = e ? atoi(e) : 1; }    // tuning aid: 0 = always the best S
+  const int small_on = (int)tuning("conv_small_s", 1);     // tuning aid: 0 = always the best S
   if (small_on && small > 0 && small < best && B > 0 && (B + best - 1) / best < cus) best = small;
   *cgs = (int)group_bytes(best);
   *img_bytes = (cin / 8) * (*cgs);                      // one image BUFFER (all three planes)
@@ -612,13 +611,10 @@ int conv2d_same_wreg_fits(int64_t cin, int64_t cout, int64_t H, int64_t W) {
 int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, const void* wplanes,
                      const float* bias, const float* in_mul, int32_t in_act, float in_slope, int32_t out_act, float out_slope,
                      const float* res_x, const float* res_mul, float res_sign, int res_mode, hipStream_t stream) {
-  static int enabled = -1;
-  if (enabled < 0) { const char* e = getenv("USF_CONV_WREG"); enabled = e ? atoi(e) : 1; }     // tuning aid: 0 = first kernel only
-  if (!enabled) return 0;
+  if (!tuning("conv_wreg", 1)) return 0;                   // tuning aid: 0 = first kernel only
   ConvWArgs a;
   int64_t lds = 0;
-  static int wsp = -1;
-  if (wsp < 0) { const char* e = getenv("USF_CONV_WSP"); wsp = e ? atoi(e) : 1; }            // tuning aid: 0 = the unspecialised kernel
+  const int wsp = (int)tuning("conv_wsp", 1);              // tuning aid: 0 = the unspecialised kernel
   int S = 0;
   bool specialised = false;
   if (wsp && cin <= 64 && cout <= 64 && H * W <= 64) {
@@ -636,9 +632,7 @@ int conv2d_same_wreg(const float* x, float* y, int64_t B, int64_t cin, int64_t c
   a.x = x; a.y = y; a.wp = reinterpret_cast<const __bf16*>(wplanes); a.bias = bias; a.in_mul = in_mul;
   a.B = (int)B; a.cin = (int)cin; a.cout = (int)cout; a.H = (int)H; a.W = (int)W;
   a.coutp = (int)((cout + 15) / 16 * 16); a.kp = (int)((9 * cin + 31) / 32 * 32);
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("USF_CONVW_DBG"); dbg = e ? atoi(e) : 0; }
-  a.dbg = dbg;
+  a.dbg = (int)tuning("convw_dbg", 0);
   a.S = S; a.in_act = in_act; a.out_act = out_act; a.in_slope = in_slope; a.out_slope = out_slope;
   a.mHW = (unsigned)(0x100000000ULL / (uint64_t)(H * W)) + 1u; a.mW = (unsigned)(0x100000000ULL / (uint64_t)W) + 1u;
   a.mSE = (unsigned)(0x100000000ULL / (uint64_t)(cin * H * W)) + 1u;

@@ -453,8 +453,7 @@ bool wgrad_plan(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int6
   if (per_cu > 4) per_cu = 4;                                    // (more partial slots than that buy nothing)
   const int64_t cap = (int64_t)device_cu_count() * per_cu;
   // few samples: 2 or 4 waves per sample (position chunks dealt over them) while that still fits one round of blocks
-  static int rs_on = -1;
-  if (rs_on < 0) { const char* e = getenv("USF_WGRAD_RSPLIT"); rs_on = e ? atoi(e) : 1; }     // tuning aid: 0 = one wave per sample
+  const int rs_on = (int)tuning("conv_wgrad_rsplit", 1);   // tuning aid: 0 = one wave per sample
   if (rs_on && pl.T == 9) {
     if (B <= 64 && B <= cap && pl.nch >= 8) pl.rsplit = 4;          // (<= 256 partial slots: still one reduction round)
     else if (B <= 128 && B <= 2 * cap && pl.nch >= 4) pl.rsplit = 2;

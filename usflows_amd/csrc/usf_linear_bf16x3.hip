@@ -451,9 +451,9 @@ int linear_bf16x3_variant(int M, int N) {
   const int pad160 = ((N + 159) / 160) * 160 - N;
   const int pad128 = ((N + 127) / 128) * 128 - N;
   // 8-wave blocks (256 rows) stage each weight slab once per 256 rows: 2 % faster in the flow than 4-wave
-  // blocks at M = 65536; USF_BF16X3_WM=4 / 8 forces the 4- / 8-wave tile (tuning aid)
-  static int wm4 = -1;
-  if (wm4 < 0) { const char* e = getenv("USF_BF16X3_WM"); wm4 = (e && atoi(e) == 4) ? 1 : ((e && atoi(e) == 8) ? 2 : 0); }
+  // blocks at M = 65536; USFLOWS_AMD_TUNE=bf16x3_wm=4 / 8 forces the 4- / 8-wave tile (tuning aid)
+  const long long wm_ = tuning("bf16x3_wm", 0);
+  const int wm4 = wm_ == 4 ? 1 : (wm_ == 8 ? 2 : 0);
   // small batches are latency-bound by one block's serial K loop: narrow column blocks (64 wide) shorten the
   // per-slab MFMA chain 2.5x and put 2.5x more blocks on the chip
   if ((int64_t)((M + 127) / 128) * ((N + 159) / 160) < 256) return 3244;

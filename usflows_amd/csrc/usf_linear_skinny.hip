@@ -148,9 +148,7 @@ __global__ __launch_bounds__(512) void linear_skinny_kernel(const SkArgs p) {
 }
 
 bool linear_skinny_eligible(const usf_linear_desc* d) {
-  static int64_t max_rows = -1;                 // USF_SKINNY_MAX: tuning aid (cross-over against the tiled kernels)
-  if (max_rows < 0) { const char* e = getenv("USF_SKINNY_MAX"); max_rows = e ? atoll(e) : 768; }
-  return d->M <= max_rows;
+  return d->M <= tuning("skinny_max", 768);     // tuning aid (cross-over against the tiled kernels)
 }
 
 int linear_skinny_dispatch(const usf_linear_desc* d, hipStream_t stream) {
@@ -165,14 +163,13 @@ int linear_skinny_dispatch(const usf_linear_desc* d, hipStream_t stream) {
   const int nstep = (a.K + 15) / 16;
   // waves per block <= 8.  (Cutting K in 8 for batches of <= 32 rows -- one fetch round per wave instead of three --
   // measured no faster: 8.8 vs 8.2 us per launch in Flow.fit at batch 32; USF_SKINNY_KS_SMALL: tuning aid)
-  static int ks_small = -1;
-  if (ks_small < 0) { const char* e = getenv("USF_SKINNY_KS_SMALL"); ks_small = e ? atoi(e) : 4; if (ks_small < 1 || ks_small > 8) ks_small = 4; }
+  int ks_small = (int)tuning("skinny_ks_small", 4);
+  if (ks_small < 1 || ks_small > 8) ks_small = 4;
   int ks = a.mw == 1 ? ks_small : 4;
   if (ks > nstep) ks = nstep;
   a.ks = ks;
   const dim3 grid((unsigned)((a.N + 15) / 16), (unsigned)((a.M + 32 * a.mw - 1) / (32 * a.mw)));
-  static int g8 = -1;
-  if (g8 < 0) { const char* e = getenv("USF_SKINNY_G"); g8 = (e && atoi(e) == 8) ? 1 : 0; }
+  const int g8 = tuning("skinny_g", 4) == 8 ? 1 : 0;
   if (g8) hipLaunchKernelGGL(linear_skinny_kernel<8>, grid, dim3(64 * a.mw * a.ks), 0, stream, a);
   else hipLaunchKernelGGL(linear_skinny_kernel<4>, grid, dim3(64 * a.mw * a.ks), 0, stream, a);
   return check_launch("usf_linear_f32(skinny)");

@@ -30,21 +30,10 @@ namespace usf {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define USF_F16_GUARD 65000.0f
-// cache policy of the activation stream (tuning: -DUSF_PL_NT=1 marks the operand loads / 2 the plane stores / 3 both
-// non-temporal, so that the streamed panels do not push the layer's weight planes out of the XCD's 4 MiB L2)
-#ifndef USF_PL_NT
-#define USF_PL_NT 0
-#endif
-#if USF_PL_NT & 1
-#define USF_PL_LOAD_A(ptr) __builtin_nontemporal_load(ptr)
-#else
 #define USF_PL_LOAD_A(ptr) (*(ptr))
-#endif
-#if USF_PL_NT & 2
-#define USF_PL_STORE_C(v, ptr) __builtin_nontemporal_store(v, ptr)
-#else
 #define USF_PL_STORE_C(v, ptr) (*(ptr) = (v))
-#endif      // |x| at or above this (or NaN) cannot travel as fp16 planes (fp16 max = 65504)
+// (non-temporal loads / stores of the activation stream and a rotated K walk per column tile were measured in rounds 3 / 4 --
+// within noise, profiles/r03_tuning_experiments.md section 2 -- and are gone)
 
 // NPL = 3: bf16 planes, six products per fp32 product (24 significant bits per operand, fp32's exponent range);
 // NPL = 2: fp16 planes, three products a1 w1 + (a1 w2 + a2 w1) (22 significant bits per operand; half the matrix
@@ -224,8 +213,7 @@ int pack_planes(const usf_pack_planes_desc* d, hipStream_t stream) {
       return -2;
     }
   }
-  static int rows_env = -1;
-  if (rows_env < 0) { const char* e = getenv("USF_PACK_ROWS"); rows_env = e ? atoi(e) : 1; }      // tuning aid: 0 = the per-element gather
+  const int rows_env = (int)tuning("pack_rows", 1);        // tuning aid: 0 = the per-element gather
   const size_t lds = (size_t)16 * (size_t)(d->src_cols + 1) * sizeof(float);
   if (d->src_cols > 0 && d->src_cols <= d->ld && lds <= 65536 && (rows_env || d->grad_base != 0)) {
     const int vec = (aligned16(d->src) && (d->ld & 3) == 0) ? 1 : 0;
@@ -367,14 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   vec8 fr[2][NPL], f2[2][NPL];                   // weight fragments: current tile pair / the pair being read
   f32x4 wst[NWV];
   const int nslab = p.nk;
-  // K rotation (tuning build -DUSF_PL_ROT=1): column tile bn walks the K slabs starting at slab bn * nslab / nbn, so the
-  // column tiles of a row panel -- running side by side on one XCD -- do not ask the L2 for the same operand lines at
-  // the same moment (the order of the K sum inside a tile is free)
-#ifndef USF_PL_ROT
-#define USF_PL_ROT 0
-#endif
-  const int rot0 = USF_PL_ROT ? (bn * nslab) / max(p.nbn, 1) : 0;
-  auto ks = [&](int s_) { const int r = s_ + rot0; return r >= nslab ? r - nslab : r; };
+  auto ks = [&](int s_) { return s_; };
   issue_w(ks(0) * 32, wst);
   store_w(wring, wst);
   issue_a(ks(0), pa);
@@ -606,8 +587,7 @@ static int launch_planes(PlArgs a, bool f32out, hipStream_t stream) {
   int64_t grid = (((int64_t)a.nbm + 7) / 8) * 8 * a.nbn;
   if (grid > 0x7fffffffLL) { set_error("usf_gemm_planes: grid too large"); return -3; }
   a.nvb = (int)grid;
-  static int persist = -1;
-  if (persist < 0) { const char* e = getenv("USF_PLANES_PERSIST"); persist = e ? atoi(e) : 1; }      // tuning aid: 0 = one block per tile
+  const int persist = (int)tuning("planes_persist", 1);    // tuning aid: 0 = one block per tile
   int cus = device_cu_count();
   cus = (cus / 8) * 8 > 0 ? (cus / 8) * 8 : 8;
   if (persist && grid > cus) grid = cus;
@@ -685,8 +665,7 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
     if (npanels * d->c_nkb * npl * 1024 >= (1LL << 40)) { set_error("usf_gemm_planes_bf16x3: output too large"); return -3; }
     nblk = d->c_kbn;
   }
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("USF_PLANES_TN"); force = e ? atoi(e) : 0; }
+  const int force = (int)tuning("planes_tn", 0);
   const int tn = (force == 4 || force == 5) ? force : gemm_planes_tn(nblk);
   if (npl == 2) return tn == 4 ? launch_planes<2, 4>(a, f32out, stream) : launch_planes<2, 5>(a, f32out, stream);
   return tn == 4 ? launch_planes<3, 4>(a, f32out, stream) : launch_planes<3, 5>(a, f32out, stream);

@@ -824,8 +824,8 @@ static int pick_splits(int64_t M, int64_t tiles, bool lw) {
   // row ranges of at least 256 rows.  256-thread kernels (two blocks per CU): enough to give every CU ~2 blocks.
   // Loader-wave kernel (one 512-thread block per CU): ~3 rounds of blocks, so that the short edge tiles (784 = 6 x 128
   // + 16) and the full ones even out over the CUs, at >= 64 slabs per block.
-  static int lw_blocks = -1;
-  if (lw_blocks < 0) { const char* e = getenv("USF_WGRAD_BLOCKS"); lw_blocks = e ? atoi(e) : 768; if (lw_blocks < 1) lw_blocks = 768; }
+  int lw_blocks = (int)tuning("wgrad_blocks", 768);
+  if (lw_blocks < 1) lw_blocks = 768;
   const int64_t target = lw ? lw_blocks : 640;
   int64_t s = (target + tiles - 1) / tiles;
   const int64_t smax = lw ? (M + 1023) / 1024 : (M + 255) / 256;
@@ -836,10 +836,9 @@ static int pick_splits(int64_t M, int64_t tiles, bool lw) {
 }
 // The loader-wave kernel: from the measured cross-over against the 256-thread kernel (at least 8192 rows and enough
 // work to fill its one block per CU; 4096 x 784 x 784 and 8192 x 256 x 392 are still faster on the old one), and
-// while its 32-bit byte offsets hold (prefetch distance included).  USF_WGRAD_LW_MIN: tuning aid.
+// while its 32-bit byte offsets hold (prefetch distance included).  wgrad_lw_min: tuning knob.
 static bool use_lw(int64_t M, int32_t mode, int64_t tiles, int64_t ldy, int64_t lda) {
-  static int64_t lw_min = -1;
-  if (lw_min < 0) { const char* e = getenv("USF_WGRAD_LW_MIN"); lw_min = e ? atoll(e) : 8192; }
+  const int64_t lw_min = tuning("wgrad_lw_min", 8192);
   return mode == 1 && M >= lw_min && M * tiles >= 160000 && (M + 448) * (ldy > lda ? ldy : lda) * 4 < (1LL << 32);
 }
 
@@ -855,8 +854,7 @@ int wgrad_workspace_floats(int64_t M, int64_t N, int64_t K, int64_t* out) {
 // which kernel usf_wgrad_f32 launches: 0 exact-f32 MFMA, 1 bf16x3 (256 threads), 2 bf16x3 with loader waves
 int wgrad_variant(int64_t M, int64_t N, int64_t K, int64_t ldy, int64_t lda, int32_t mode) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  static int old_kernel = -1;                 // tuning aid: USF_WGRAD_OLD=1 keeps the round-1 bf16x3 kernel
-  if (old_kernel < 0) { const char* e = getenv("USF_WGRAD_OLD"); old_kernel = e ? atoi(e) : 0; }
+  const int old_kernel = (int)tuning("wgrad_old", 0);      // tuning aid: 1 keeps the round-1 bf16x3 kernel
   if (use_lw(M, mode, wg_tiles(N, K), ldy, lda) && !old_kernel) return 2;
   return (mode == 1 && M >= 2048) ? 1 : 0;
 }

@@ -543,17 +543,14 @@ int wp_cus() {
   if (n < 0) {
     int dev = 0; hipDeviceProp_t pr;
     n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
-    const char* e = getenv("USF_WGRAD_CUS");
-    if (e && atoi(e) > 0) n = atoi(e);
+    const long long e = tuning("wgrad_cus", 0);
+    if (e > 0) n = (int)e;
     n &= ~7;
     if (n < 8) n = 8;
   }
   return n;
 }
-int wp_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
+int wp_env(const char* name, int dflt) { return (int)tuning(name, dflt); }
 
 // balanced = false: the plain grid -- no folding, every tile cut into the same `plain_splits` row ranges (the partial sums
 // are then those of usf_wgrad_f32's loader-wave kernel, bit for bit)
@@ -564,7 +561,7 @@ bool wp_schedule(int64_t M, int64_t N, int64_t K, bool balanced, int plain_split
   sc.per_xcd = cus / 8;
   sc.fN = (int)(N / WP_T); sc.fK = (int)(K / WP_T);
   sc.rN = (int)(N % WP_T); sc.rK = (int)(K % WP_T);
-  const bool fold = balanced && wp_env("USF_WGRADP_FOLD", 1) != 0;
+  const bool fold = balanced && wp_env("wgrad_fold", 1) != 0;
   sc.foldN = (fold && sc.fN >= 1 && sc.rN > 0 && sc.rN <= WP_FOLD) ? 1 : 0;
   sc.foldK = (fold && sc.fK >= 1 && sc.rK > 0 && sc.rK <= WP_FOLD) ? 1 : 0;
   // tile counts per type in n; in k they depend on the row's type (the wide row keeps its edge)
@@ -588,7 +585,7 @@ bool wp_schedule(int64_t M, int64_t N, int64_t K, bool balanced, int plain_split
     // plain one the hardware deals out block by block -- block b runs on XCD b & 7, its items numbered so that the blocks an
     // XCD runs side by side are the tiles of ONE row range -- at the price of 20 instead of 6 partial images to sum.  The
     // number of row ranges minimises rounds x (slabs per item + ~6 slabs' worth of ring prologue / partial-image store).
-    const int max_rounds = wp_env("USF_WGRAD_ROUNDS", 3);
+    const int max_rounds = wp_env("wgrad_rounds", 3);
     const int ns_max = (max_rounds > 1 ? max_rounds : 1) * cus / tiles;
     ns = cus / tiles < 1 ? 1 : cus / tiles;
     long best = -1;
@@ -643,7 +640,7 @@ int wp_max_parts(const WpSched& sc) {
 // the loader-wave kernel's number of row ranges (usf_train.hip: pick_splits(lw = true))
 int wp_plain_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((N + WP_T - 1) / WP_T) * ((K + WP_T - 1) / WP_T);
-  int blocks = wp_env("USF_WGRAD_BLOCKS", 768);
+  int blocks = wp_env("wgrad_blocks", 768);
   if (blocks < 1) blocks = 768;
   int64_t s = (blocks + tiles - 1) / tiles;
   const int64_t smax = (M + 1023) / 1024;
@@ -720,7 +717,7 @@ int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, c
 #ifdef USF_STAMP
   a.dbg = g_wpdbg;
 #endif
-  const bool balanced = wp_env("USF_WGRAD_SCHED", 1) != 0 && wp_schedule(M, N, K, true, 0, a.sched) &&
+  const bool balanced = wp_env("wgrad_sched", 1) != 0 && wp_schedule(M, N, K, true, 0, a.sched) &&
                         (int64_t)wp_max_parts(a.sched) * N * (K + 1) <= workspace_floats;
   if (!balanced && !wp_schedule(M, N, K, false, wp_plain_splits(M, N, K), a.sched)) {
     set_error("usf_wgrad_planes_f32: no schedule for M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -759,7 +756,7 @@ int wgrad_blocked(const void* Yp, int64_t y_nkb, int64_t y_kb0, const void* Ap, 
   WpArgs a{(const __bf16*)Yp, 0, 0, (const __bf16*)Ap, 0, 0, 0, 0, (unsigned)yb, (unsigned)ab,
            workspace, (int)M, (int)N, (int)K, nullptr, nullptr, (int)y_nkb, (int)y_kb0, (int)a_nkb, (int)a_kb0};
   // the same schedules as usf_wgrad_planes_f32 (one block per CU where the tiles allow it, else the plain grid)
-  const bool balanced = wp_env("USF_WGRAD_SCHED", 1) != 0 && wp_schedule(M, N, K, true, 0, a.sched) &&
+  const bool balanced = wp_env("wgrad_sched", 1) != 0 && wp_schedule(M, N, K, true, 0, a.sched) &&
                         (int64_t)wp_max_parts(a.sched) * N * (K + 1) <= workspace_floats;
   if (!balanced && !wp_schedule(M, N, K, false, wp_plain_splits(M, N, K), a.sched)) {
     set_error("usf_wgrad_blocked_f32: no schedule for M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -782,7 +779,7 @@ int wgrad_blocked(const void* Yp, int64_t y_nkb, int64_t y_kb0, const void* Ap, 
 // tuning aid (tools/exp_wgradp.hip): the schedule in words
 void wgrad_planes_describe(int64_t M, int64_t N, int64_t K, char* buf, size_t n) {
   WpSched sc;
-  const bool ok = wp_env("USF_WGRAD_SCHED", 1) != 0 && wp_schedule(M, N, K, true, 0, sc);
+  const bool ok = wp_env("wgrad_sched", 1) != 0 && wp_schedule(M, N, K, true, 0, sc);
   if (!ok) wp_schedule(M, N, K, false, wp_plain_splits(M, N, K), sc);
   size_t o = (size_t)snprintf(buf, n, "%s, %d items on %d blocks, fold n/k %d/%d;", ok ? "balanced" : "plain grid", sc.items, sc.per_xcd * 8, sc.foldN, sc.foldK);
   static const char* nm[3] = {"n", "w", "e"};

@@ -32,6 +32,7 @@ from torch import nn
 
 from . import _ext
 from . import transforms as T
+from .config import config
 from .networks import ConditionalDenseNN, ConvNet, DenseNN
 
 
@@ -268,8 +269,7 @@ class FlowEngine:
         # flows: unchanged, 5e-8 .. 1.5e-7).  merge_affine = "auto" (default): every run of layers is composed only if a
         # pack-time probe says the composite is as accurate as the run applied layer by layer (_merge_guard); True
         # (USFLOWS_AMD_MERGE_AFFINE=1): always; False (=0): never.
-        _m = os.environ.get("USFLOWS_AMD_MERGE_AFFINE", "auto")
-        self.merge_affine = True if _m == "1" else (False if _m == "0" else "auto")
+        self.merge_affine = config.merge_affine
         self.merge_guard_log: List[tuple] = []   # (accepted, element-wise deviation, L1-norm deviation) of composed vs layer-by-layer, per probe
         self._virtual: List[_Step] = []          # merged steps, addressed as step index len(self.steps) + n
         self._virtual_ix: Dict[tuple, int] = {}
@@ -282,7 +282,7 @@ class FlowEngine:
         # bits, six MFMAs per product); "f16x2": the planes pipeline uses two fp16 planes per operand
         # (22 significant bits, three MFMAs per product, range-guarded with a bf16x3 redo; everything outside the planes
         # pipeline as "bf16x3"); "f32": exact-f32 MFMA everywhere (USFLOWS_AMD_GEMM=... or engine.gemm_mode = ...)
-        self.gemm_mode = os.environ.get("USFLOWS_AMD_GEMM", "bf16x3")
+        self.gemm_mode = config.gemm_mode
         # True: the pack also keeps L, U^T, L^-1, U^-T of every LU block (fp64) -- the training backward's operands
         self.keep_factors = False
         # USFLOWS_AMD_GRAPH=1: batches up to graph_max_rows replay their launch list as one hipGraph.  Off by default:
@@ -298,16 +298,15 @@ class FlowEngine:
         # -- the per-rank shard of the 8-GPU configuration cfg3 --, 40960 14.05 / 14.30, 65536 18.8 / 19.2),
         # or from planes_min_rows when a conditioner is too wide / deep for the fused coupling kernels (cfg4, hidden 1024:
         # 176.6 vs 215.8 ms at 32768 rows)
-        env_planes = os.environ.get("USFLOWS_AMD_PLANES", "auto")
-        self.use_planes = None if env_planes == "auto" else env_planes != "0"
-        self.planes_min_rows = int(os.environ.get("USFLOWS_AMD_PLANES_MIN_ROWS", "8192"))
+        self.use_planes = config.planes
+        self.planes_min_rows = int(config.planes_min_rows)
         self.planes_min_rows_bf16x3 = 24576
         # training on the planes pipeline (round 5): the forward keeps every layer's planes buffer and the conditioners' hidden
         # activations as planes, the backward runs on usf_gemm_planes_bf16x3 / usf_coupling_planes (gate mode) /
         # usf_wgrad_blocked_f32.  USFLOWS_AMD_TRAIN_PLANES=0 keeps the fp32-row path of rounds 3 / 4.
-        self.use_train_planes = os.environ.get("USFLOWS_AMD_TRAIN_PLANES", "1") != "0"
+        self.use_train_planes = config.train_planes
         self.train_planes_min_rows = 16384
-        self.use_graphs = os.environ.get("USFLOWS_AMD_GRAPH", "0") == "1"
+        self.use_graphs = bool(config.engine_graph)
         self.graph_max_rows = 1024
         self._layout_from_masks()
 
@@ -1048,7 +1047,7 @@ class FlowEngine:
                 # coupling of a step that is bound by the number of its launches; training.py names the same buffers)
                 # (round 4: at every training batch, not only the small ones -- the activations land in per-layer buffers instead of
                 # the shared pair at no cost to the forward; USFLOWS_AMD_SAVE_HIDDEN=0: only up to GRAD_JOB_MAX_ROWS rows as before)
-                save_h = train and B > 0 and (B <= _ext.GRAD_JOB_MAX_ROWS or os.environ.get("USFLOWS_AMD_SAVE_HIDDEN", "1") != "0")
+                save_h = train and B > 0 and (B <= _ext.GRAD_JOB_MAX_ROWS or config.save_hidden)
                 meta[-1]["hidden_saved"] = save_h
                 src_ptr, src_ld, src_K = zptr + 4 * cp["pass_off"], self.LD, cp["pass_n"]
                 for j, (W, b) in enumerate(un["layers"]):
@@ -1096,7 +1095,7 @@ class FlowEngine:
         """training: the fused bf16x3 coupling kernel stores its hidden activations (usf_coupling_desc::hidden_out) -- where
         that kernel serves the layer (hidden width in (128, 256], >= 1024 rows), unless USFLOWS_AMD_SAVE_HIDDEN=0"""
         hm = max(cp["hidden"])
-        return (self.gemm_mode == "bf16x3" and os.environ.get("USFLOWS_AMD_SAVE_HIDDEN", "1") != "0" and 128 < hm <= 256
+        return (self.gemm_mode == "bf16x3" and config.save_hidden and 128 < hm <= 256
                 and B >= 1024 and self.hmax >= 256 and self.hmax % 4 == 0
                 and cp["tr_n"] % 4 == 0 and cp["tr_off"] % 4 == 0)      # (the backward launch reads the transformed half as its input)
 
@@ -1104,7 +1103,7 @@ class FlowEngine:
         """weight gradients of the training step from pre-split operand planes (usf_wgrad_planes_f32): in the bf16x3 mode,
         where the kernel pays (its own cross-over), unless USFLOWS_AMD_WGRAD_PLANES=0"""
         rows, wid = -(-B // 32) * 32, -(-max(N, K, self.LD, self.LDn) // 32) * 32
-        return (self.gemm_mode == "bf16x3" and os.environ.get("USFLOWS_AMD_WGRAD_PLANES", "1") != "0"
+        return (self.gemm_mode == "bf16x3" and config.wgrad_planes
                 and 3 * rows * wid * 2 < (1 << 31)          # the three planes of an operand stay below 2 GiB (32-bit offsets)
                 and _ext.wgrad_planes_ok(B, N, K))
 

@@ -22,6 +22,7 @@ import torch
 from torch import distributions as tdist
 
 from . import _ext
+from .config import config
 from .distributions import Independent, RadialDistribution, DistributionModule
 from .engine import EngineUnsupported, FlowEngine
 from .transforms import (BaseTransform, BlockAffineTransform, HouseholderTransform, InverseTransform,
@@ -61,7 +62,7 @@ class _BatchFeed:
     def make(data, N, batch_size, device):
         device = torch.device(device)
         if (device.type != "cuda" or not torch.is_tensor(data) or data.is_cuda or data.dtype != torch.float32 or data.dim() < 2
-                or os.environ.get("USFLOWS_AMD_FIT_PREFETCH", "1") == "0" or N <= batch_size):
+                or not config.fit_prefetch or N <= batch_size):
             return None
         if min(batch_size, N) * data[0].numel() * 4 < _BatchFeed.MIN_BYTES:
             return None
@@ -119,7 +120,7 @@ class Flow(torch.nn.Module):
         self._train_obj = None
         # True: log_prob under autograd runs forward AND backward on the HIP kernels (training.py); False: the
         # differentiable composite formulation in torch ops (USFLOWS_AMD_TRAIN=composite)
-        self.use_device_training = os.environ.get("USFLOWS_AMD_TRAIN", "device") != "composite"
+        self.use_device_training = config.train_on_device
         self.to(device)
         self.device = device
         # batch dims of the base become event dims (flows.py:94-101)
@@ -323,7 +324,7 @@ class Flow(torch.nn.Module):
             return (self.base_distribution.log_prob(y) if lp is None else lp) - ladj_total
         prep = contextlib.nullcontext()
         if torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and torch.is_grad_enabled() \
-                and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0":
+                and config.image_train:
             # an image-shaped flow in training: the affine blocks' parameter maps once per pass, batched over the blocks
             from .image_training import batched_affine_prep
             prep = batched_affine_prep(self.layers, x.device)
@@ -363,7 +364,7 @@ class Flow(torch.nn.Module):
         training and whose parameter maps come from the batched prep: y = A x + c for the whole run; else None"""
         from .transforms import BlockAffineTransform, InverseTransform
         from .image_training import current_prep
-        if os.environ.get("USFLOWS_AMD_MERGE_AFFINE") == "0" or self.merge_image_affine is False:
+        if config.merge_affine is False or self.merge_image_affine is False:
             return None
         A = cvec = None
         j = k
@@ -396,8 +397,7 @@ class Flow(torch.nn.Module):
         """the reversed layer loop of an image-shaped flow as a list of callables, runs of channel-affine layers composed;
         None: use the plain loop"""
         from .transforms import BlockAffineTransform, InverseTransform
-        env = os.environ.get("USFLOWS_AMD_MERGE_AFFINE")
-        mode = self.merge_image_affine if env is None else (env != "0")
+        mode = self.merge_image_affine if config.merge_affine == "auto" else config.merge_affine
         if mode is False or not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 0) \
                 or (torch.is_grad_enabled() and _needs_grad(self, x)):
             return None
@@ -497,7 +497,7 @@ class Flow(torch.nn.Module):
     def _layer_loop_list_ok(self, x, context) -> bool:
         return (context is None and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
                 and 0 < x.shape[0] <= self.list_max_rows and self.graph_max_rows > 0 and x.is_contiguous()
-                and os.environ.get("USFLOWS_AMD_LOOP_LIST", "1") != "0" and not _needs_grad(self, x)
+                and config.loop_list and not _needs_grad(self, x)
                 and not torch.cuda.is_current_stream_capturing())
 
     def _loop_versions(self):
@@ -561,7 +561,7 @@ class Flow(torch.nn.Module):
     def _layer_loop_graph_ok(self, x, context) -> bool:
         return (context is None and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3
                 and 0 < x.shape[0] <= self.graph_max_rows and not getattr(self, "_loop_graph_off", False)
-                and os.environ.get("USFLOWS_AMD_LOOP_GRAPH", "1") != "0" and not _needs_grad(self, x)
+                and config.loop_graph and not _needs_grad(self, x)
                 and not torch.cuda.is_current_stream_capturing())
 
     def _layer_loop_graphed(self, x):
@@ -618,7 +618,7 @@ class Flow(torch.nn.Module):
         if y.shape[0] == 0 and not isinstance(self.base_distribution, RadialDistribution):
             return None                                  # (the radial path serves an empty batch itself: empty result, zero gradients)
         train = torch.is_grad_enabled() and (y.requires_grad or _needs_grad(self, y, None))
-        if train and (y.dim() < 3 or os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") == "0"):
+        if train and (y.dim() < 3 or not config.image_train):
             return None                                  # (flat flows train through training.py; image flows: below)
         if train and logdet_dev is not None:
             return None                                  # (the differentiable forms below do not add the constant: the caller subtracts it)
@@ -626,7 +626,7 @@ class Flow(torch.nn.Module):
         if isinstance(d, RadialDistribution):
             # the Lp-radial base of the live image configurations (mnist.yaml:79-92, fashionclasses_veriflow.yaml:79-93):
             # radius, norm density, volume term -- and in training their gradients -- on usf_radial_logprob(_grad)_f32
-            if os.environ.get("USFLOWS_AMD_RADIAL", "1") == "0":
+            if not config.radial:
                 return None
             from . import radial
             return radial.log_prob(d, y, logdet_dev=logdet_dev)
@@ -679,7 +679,7 @@ class Flow(torch.nn.Module):
             base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
             _ext.base_logprob(zbuf, ldz, B, eng.D, base, info[1], info[2], 0.0, out, sum_out, logdet_dev=logdet.neg_dev)
             return out
-        if os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0":
+        if config.radial:
             # radius + norm density + volume term + log-det constant (+ the data-parallel sums) in one launch
             from . import radial
             res = radial.log_prob(self.base_distribution, zbuf, logdet_dev=logdet.neg_dev, sum_out=sum_out, ldz=ldz)
@@ -744,7 +744,7 @@ class Flow(torch.nn.Module):
         None: not this kind of base"""
         b = self.base_distribution
         if not (isinstance(b, RadialDistribution) and b.n_batch_dims == 0 and b.loc.is_cuda and b.loc.dtype == torch.float32
-                and float(b.p) in (1.0, 2.0, float("inf")) and os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0"):
+                and float(b.p) in (1.0, 2.0, float("inf")) and config.radial):
             return None
         n = int(np.prod(shape)) if len(shape) else 1
         D = int(b.loc.numel())
@@ -794,7 +794,7 @@ class Flow(torch.nn.Module):
         ``_train_graph_step`` itself (bench.py) runs its steps inside this context."""
         side = None
         device = torch.device(device)
-        if device.type == "cuda" and self.use_train_graph and os.environ.get("USFLOWS_AMD_TRAIN_GRAPH", "1") != "0":
+        if device.type == "cuda" and self.use_train_graph and config.train_graph:
             side = self.__dict__.get("_fit_stream")
             if side is None or side.device != (device if device.index is not None else torch.device("cuda", torch.cuda.current_device())):
                 side = self.__dict__["_fit_stream"] = torch.cuda.Stream(device=device)
@@ -868,7 +868,7 @@ class Flow(torch.nn.Module):
         must not hold the loss tensor (or anything else with a grad_fn over the parameters) of an earlier eager step: the
         parameters' gradient-accumulation nodes stay bound to the eager stream through it, and a capture that reaches over
         to that stream does not survive hipStreamEndCapture."""
-        if not (self.use_train_graph and os.environ.get("USFLOWS_AMD_TRAIN_GRAPH", "1") != "0"
+        if not (self.use_train_graph and config.train_graph
                 and torch.is_tensor(sample) and sample.is_cuda and sample.dtype == torch.float32 and sample.shape[0] > 0
                 and not getattr(self, "_train_graph_failed", False) and not torch.cuda.is_current_stream_capturing()):
             return None
@@ -888,7 +888,7 @@ class Flow(torch.nn.Module):
         if isinstance(base, DistributionModule) or \
                 (isinstance(base, torch.nn.Module) and any(isinstance(m_, DistributionModule) for m_ in base.modules())):
             from . import radial
-            if os.environ.get("USFLOWS_AMD_RADIAL", "1") == "0" or radial.radial_spec(base, sample.device) is None:
+            if not config.radial or radial.radial_spec(base, sample.device) is None:
                 return None
         with torch.enable_grad():
             if self._train_path(sample, noise) is not None:
@@ -1083,7 +1083,7 @@ class Flow(torch.nn.Module):
         with torch.no_grad():
             latent = self.backward(calibration_dataset)
             lp = None
-            if torch.is_tensor(latent) and latent.is_cuda and os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0":
+            if torch.is_tensor(latent) and latent.is_cuda and config.radial:
                 from . import radial
                 lp = radial.log_prob(self.base_distribution, latent.float().contiguous())      # one launch (usf_radial_logprob_f32)
             if lp is None:

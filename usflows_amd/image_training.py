@@ -20,6 +20,7 @@ import threading
 import torch
 
 from . import _ext
+from .config import config
 
 
 def _act(a):
@@ -60,91 +61,17 @@ def _weight_planes(w, want_transposed: bool):
     return _ext.conv2d_weight_planes(w), None
 
 
-# ---- weight gradients beside the data-gradient chain (small batches): AN EXPERIMENT, OFF BY DEFAULT -------------------------
-# At the reference's training batch (32 rows, experiments/mnist/mnist.yaml:34) a step of the live MNIST configuration is ~1250
-# launches of ~5 us: bound by their dependent dispatch, not by their work.  The backward pass's critical path is the chain of
-# DATA gradients; a convolution's weight / bias gradient (usf_conv_wgrad_f32: the kernel and the sum of its per-sample partials)
-# is needed only by the optimiser.  With USFLOWS_AMD_SIDE_WGRAD=1 those launches (up to ``side_wgrad_max_rows`` rows) go to a
-# second stream that forks off the backward pass's stream in front of them and joins it once, when the pass ends (an autograd
-# engine callback): eagerly two streams, inside Flow.fit's captured step a parallel branch of the hipGraph.  MEASURED (round 4,
-# profiles/r04_tuning_experiments.md): the replayed step gets SLOWER -- live MNIST configuration at batch 32 6.25 -> 7.86 ms, the
-# 2-block model 0.67 -> 0.87 ms: every fork / join of a graph branch costs more than the ~5 us launch it takes off the chain.
-# Kept as a switch so that the measurement can be repeated; memory: operands read on the side stream are marked for it
-# (``record_stream``), results are allocated on it and used behind the join.
-side_wgrad_max_rows = 4096
+# (Round 4 also tried the weight gradients of a small-batch backward pass on a second stream / a parallel hipGraph branch:
+# live MNIST configuration at batch 32 6.25 -> 7.86 ms per replayed step -- every fork / join costs more than the ~5 us launch it
+# takes off the chain; profiles/r04_tuning_experiments.md section 3.  The switch and its code are gone.)
 
 
 def _takeable(params) -> bool:
     """True when the autograd engine will TAKE the gradients of these Parameters as they are handed over (no ``.grad`` yet, no
-    hooks that would read them): a gradient whose last sum is still queued (_ext.conv_wgrad(defer=True)) or running on the side
-    stream must not be read before the backward pass ends"""
+    hooks that would read them): a gradient whose last sum is still queued (_ext.conv_wgrad(defer=True)) must not be read
+    before the backward pass ends"""
     return all(q is None or (q.grad is None and q.is_leaf and not q._backward_hooks
                              and not getattr(q, "_post_accumulate_grad_hooks", None)) for q in params)
-
-
-class _SideState:
-    """process-wide, not thread-local: backward nodes run on the autograd engine's device thread, the end-of-pass callback on
-    the thread that called backward()"""
-
-    def __init__(self):
-        self.lock = threading.Lock()
-        self.streams = {}        # device index -> side stream
-        self.pending = {}        # autograd graph task id -> device indices with side work the pass has not joined yet
-
-
-_SIDE = _SideState()
-
-
-def _side_join(task):
-    """end of a backward pass (autograd engine callback): the pass's stream waits for the side work it forked"""
-    with _SIDE.lock:
-        pend = _SIDE.pending.pop(task, set())
-    for idx in pend:
-        torch.cuda.current_stream(idx).wait_stream(_SIDE.streams[idx])
-
-
-class side_wgrad:
-    """``with side_wgrad(x, dy, ...) as on:`` -- inside, launches go to the side stream when ``on`` (small batch, enabled)"""
-
-    def __init__(self, *operands, params=()):
-        """params: the Parameters whose gradients the block produces.  The autograd engine hands a gradient to its parameter as
-        soon as the node returns, on the pass's own stream: a parameter without a ``.grad`` simply TAKES the tensor (no read --
-        the case of every Flow.fit step), one with a ``.grad`` adds into it at once -- then the work stays on the pass's stream."""
-        self.ops = [t for t in operands if torch.is_tensor(t) and t.is_cuda]
-        import os
-        t0 = self.ops[0] if self.ops else None
-        self.on = (t0 is not None and 0 < t0.shape[0] <= side_wgrad_max_rows
-                   and os.environ.get("USFLOWS_AMD_SIDE_WGRAD", "0") == "1"
-                   and _takeable(params) and torch._C._current_graph_task_id() >= 0)
-        self.ctx = None
-
-    def __enter__(self):
-        if not self.on:
-            return False
-        dev = self.ops[0].device
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        with _SIDE.lock:
-            side = _SIDE.streams.get(idx)
-            if side is None:
-                side = _SIDE.streams[idx] = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))           # fork: everything issued so far (x, dy) is ready
-        for t in self.ops:
-            t.record_stream(side)                                  # (their memory is not reused while the side work reads it)
-        task = torch._C._current_graph_task_id()
-        with _SIDE.lock:
-            pend = _SIDE.pending.get(task)
-            if pend is None:
-                pend = _SIDE.pending[task] = set()
-                torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: _side_join(t))
-            pend.add(idx)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return True
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
 
 
 class ConvSame(torch.autograd.Function):
@@ -175,9 +102,8 @@ class ConvSame(torch.autograd.Function):
         ia = _act(in_act)
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            with side_wgrad(x, dy, in_mul, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
-                                    defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
+            r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
+                                defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (conv_shape_ok was not consulted)")
             dW, db = r
@@ -224,9 +150,8 @@ class ConvSameFork(torch.autograd.Function):
         ia = _act(in_act)
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            with side_wgrad(x, dy, in_mul, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
-                                    defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
+            r = _ext.conv_wgrad(x, dy, ks, in_mul=in_mul, in_act=ia[0], in_slope=ia[1], want_bias=has_bias,
+                                defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r
@@ -273,8 +198,7 @@ class Pointwise(torch.autograd.Function):
         ia = _act(in_act)
         dW = db = dx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            with side_wgrad(x, dy, params=ctx.params):
-                r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
+            r = _ext.conv_wgrad(x, dy, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable(ctx.params), owners=tuple(id(q) for q in ctx.params if q is not None))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
             dW, db = r[0].reshape(wshape), r[1]
@@ -561,7 +485,7 @@ def _prep_group_device(bts, parts_list, sig, device):
     """the group's maps through usf_affine_prep_f32, or None when the structure is not the kernel's (one LUTransform,
     optionally followed by one HouseholderTransform; C <= 64; fp32 parameters on a GPU)"""
     import os
-    if not (affine_prep_kernels and os.environ.get("USFLOWS_AMD_AFFINE_PREP", "1") != "0"):
+    if not (affine_prep_kernels and config.affine_prep):
         return None
     if torch.device(device).type != "cuda" or tuple(k[0] for k in sig) not in (("lu",), ("lu", "hh")):
         return None

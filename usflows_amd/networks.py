@@ -20,6 +20,8 @@ import os
 from typing import List, Optional, Sequence
 
 import torch
+
+from .config import config  # noqa: E402
 from torch import nn
 
 
@@ -170,7 +172,7 @@ class _ConvStack(nn.Module):
         """True when this call needs gradients and every module of the sequence has a device backward at this shape
         (image_training.py); USFLOWS_AMD_IMAGE_TRAIN=0 keeps torch autograd"""
         if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
-                and torch.is_grad_enabled() and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0"):
+                and torch.is_grad_enabled() and config.image_train):
             return False
         if not (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
@@ -437,7 +439,7 @@ def _conv_hip(conv, x, in_act=None, in_mul=None, out_act=None, residual=None):
     ia, isl = in_act if in_act is not None else (_ext.ACT_NONE, 0.0)
     oa, osl = out_act if out_act is not None else (_ext.ACT_NONE, 0.0)
     bias = None if conv.bias is None else conv.bias.detach().to(torch.float32).contiguous()
-    if residual is not None and out_act is None and os.environ.get("USF_CONV_RES", "1") != "0":
+    if residual is not None and out_act is None and config.conv_res:
         rx, om, sign = residual
         y = _ext.conv2d_same_res(x.contiguous(), cache[1], conv.out_channels, conv.kernel_size[0], rx.contiguous(), om, sign,
                                  bias=bias, in_mul=in_mul, in_act=ia, in_slope=isl)
@@ -494,7 +496,7 @@ class GatedConv(nn.Module):
         n = self.net
         C = x.shape[1]
         if not (x.is_cuda and x.dim() == 4 and isinstance(ln, LayerNormChannels) and ln._hip_ok(x) and ln.gamma.numel() == C
-                and os.environ.get("USF_POINTWISE", "1") != "0" and _relu_kind(n[0]) is not None and _relu_kind(n[2]) is not None):
+                and config.pointwise and _relu_kind(n[0]) is not None and _relu_kind(n[2]) is not None):
             return False
         from . import _ext
         c2 = n[3]
@@ -538,7 +540,7 @@ class GatedConv(nn.Module):
             from . import _ext
             h = _conv_hip(n[1], x, in_act=a0)
             C = x.shape[1]
-            if n[3].out_channels == 2 * C and os.environ.get("USF_POINTWISE", "1") != "0":
+            if n[3].out_channels == 2 * C and config.pointwise:
                 out = _pointwise_hip(n[3], h, in_act=a2, gate_x=x)      # second convolution + gate: one pass on the vector ALUs
                 if out is not None:
                     return out

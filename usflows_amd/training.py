@@ -33,6 +33,7 @@ import torch
 
 from . import _ext
 from . import transforms as T
+from .config import config
 from .engine import FlowEngine, _round_up
 from .networks import ConditionalDenseNN, DenseNN
 
@@ -703,7 +704,7 @@ class TrainPath:
         """the data-gradient chain of this coupling layer's conditioner as ONE launch of the fused kernel (engine.
         coupling_backward_op): where the forward ran fused and left its hidden activations, unless USFLOWS_AMD_FUSED_CBWD=0"""
         return (bool(m.get("hidden_saved_fused")) and not (bool(self.defer_small_grads) and 0 < B <= _ext.GRAD_JOB_MAX_ROWS)
-                and os.environ.get("USFLOWS_AMD_FUSED_CBWD", "1") != "0")
+                and config.fused_cbwd)
 
     def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
         """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every affine
@@ -764,7 +765,7 @@ class TrainPath:
             Wt = self._mat_t(pk, blk, which, m["out_layout"], m["in_layout"])
             self._linear(pk, g_cur, 0, g_ld, Wt, g_other, 0, n_in, B, n_in, n_out, planes_out=gpl)
             gs = self._buf(ws, f"gs{m['op']}", 1, wid)
-            cs_fused = (os.environ.get("USFLOWS_AMD_FUSED_BIAS", "1") != "0"              # the bias gradient from the same pass
+            cs_fused = (config.fused_bias                                                  # the bias gradient from the same pass
                         and bool(_ext.load().usf_wgrad_planes_colsum_ok(B, n_out, n_in)))
             _ext.wgrad_planes(gpl, ws[m["in_planes"]], Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1], colsum=gs if cs_fused else None)
             if not cs_fused:
@@ -856,7 +857,7 @@ class TrainPath:
         gW = gimg("out")
         gb = self._buf(ws, f"gb{m['step']}", 1, max(hmax, LD))
         # large batches: the bias gradient (column sums of the same Y) rides in the weight-gradient pass (usf_wgrad_bias_f32)
-        fuse = lambda n, k, ldy, lda: (not self._defer and os.environ.get("USFLOWS_AMD_FUSED_BIAS", "1") != "0"  # noqa: E731
+        fuse = lambda n, k, ldy, lda: (not self._defer and config.fused_bias  # noqa: E731
                                        and _ext.wgrad_bias_ok(B, n, k, ldy, lda, self._wmode))
         fused_out = fuse(tr_n, hp[-1], g_ld, hmax)
         _ext.wgrad(g_cur, hbufs[-1], gW, M=B, N=tr_n, K=hp[-1], ldy=g_ld, lda=hmax, ldg=gW.shape[1], y_off=tr_off,
@@ -1352,7 +1353,7 @@ def log_prob_with_grad(path: TrainPath, x, context):
         base = path.flow.base_distribution
         r, logdet = _RadiusFn.apply(path, x, context, base.loc, *params)
         lp = None
-        if os.environ.get("USFLOWS_AMD_RADIAL", "1") != "0":
+        if config.radial:
             from . import radial
             lp = radial.log_prob_from_radius(base, r)      # (one launch each way, no validating distribution object)
         return (base.log_prob_from_radius(r) if lp is None else lp) + logdet

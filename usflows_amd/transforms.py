@@ -22,6 +22,8 @@ import os
 from typing import Any, Iterable, List, Optional
 
 import torch
+
+from .config import config  # noqa: E402
 from torch import nn
 from torch.distributions import constraints
 from torch.nn import functional as F
@@ -759,7 +761,7 @@ class BlockAffineTransform(BaseTransform):
         """a call that needs gradients on NCHW data: the 1 x 1 convolution, its data gradient and the C x C weight gradient
         on the HIP kernels (image_training.ChannelAffine); the parameter maps stay torch ops on C x C tensors"""
         if not (self.input_rank == 2 and torch.is_tensor(x) and x.dim() == 4 and x.shape[0] > 0 and torch.is_grad_enabled()
-                and os.environ.get("USFLOWS_AMD_IMAGE_TRAIN", "1") != "0"):
+                and config.image_train):
             return False
         from .image_training import channel_affine_train_ok
         return channel_affine_train_ok(x, self.block_size) and _needs_grad(self, x)
