@@ -447,7 +447,10 @@ def main_flat(args, under_launcher):
     op_records = []
     if on_gpu and not args.no_kernel_timing and mode == "train":
         from usflows_amd import _ext as _ext_t
-        _ext_t.launch_timing = {n_: [] for n_ in _TRAIN_TIMED}     # HIP events around every weight-gradient launch (+ the planes step's other classes)
+        # HIP events around the launches of the training step's kernel classes -- on every TIMING_EVERY-th step only (two event records
+        # around each of the ~430 launches cost the 68 ms step 3.5 ms)
+        train_events = {n_: [] for n_ in _TRAIN_TIMED}
+        train_timed_steps = 0
     if under_launcher:
         dist.barrier()
     sync()
@@ -456,6 +459,9 @@ def main_flat(args, under_launcher):
         if timing_on and i_step % TIMING_EVERY == 0:
             eng.op_timing = op_records
             timed_launch_steps[0] += 1
+        if on_gpu and not args.no_kernel_timing and mode == "train":
+            _ext_t.launch_timing = train_events if i_step % TIMING_EVERY == 0 else None
+            train_timed_steps += 1 if i_step % TIMING_EVERY == 0 else 0
         mean, lp = step()
         if timing_on:
             eng.op_timing = None
@@ -470,9 +476,9 @@ def main_flat(args, under_launcher):
         eng.op_timing = None
         if mode == "train" and not args.no_kernel_timing:
             from usflows_amd import _ext as _ext_t
-            wg_timing = [(e0, e1, a, fn) for fn in _TRAIN_WGRADS for e0, e1, a in _ext_t.launch_timing[fn]]
-            train_classes = {fn: (len(v), sum(e0.elapsed_time(e1) for e0, e1, _a in v)) for fn, v in _ext_t.launch_timing.items() if v}
             _ext_t.launch_timing = None
+            wg_timing = [(e0, e1, a, fn) for fn in _TRAIN_WGRADS for e0, e1, a in train_events[fn]]
+            train_classes = {fn: (len(v), sum(e0.elapsed_time(e1) for e0, e1, _a in v)) for fn, v in train_events.items() if v}
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if under_launcher:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -614,16 +620,17 @@ def main_flat(args, under_launcher):
                     "traffic": None, "traffic_source": None,
                     "kernel": kname,
                     "peak_is": "dense bf16 MFMA peak (2500) / 6 products per fp32 product" if bf else "dense f32 MFMA",
-                    "measured_by": f"HIP events around every {fn_} launch of this run's timed region",
+                    "measured_by": f"HIP events around every {fn_} launch of every {TIMING_EVERY}th step of this run's timed region",
                     "avg_launch_ms": round(avg_ms, 4), "launches": len(shapes[dom]),
                     "algorithmic_flops_per_launch": flops,
                     "wgrad_ms_per_step": {f"{k[2]}x{k[3]}" + (" (planes)" if k[0] == "usf_wgrad_planes_f32" else
-                                                               " (blocked planes)" if k[0] == "usf_wgrad_blocked_f32" else ""): round(v / args.steps, 3)
+                                                               " (blocked planes)" if k[0] == "usf_wgrad_blocked_f32" else ""): round(v / max(train_timed_steps, 1), 3)
                                           for k, v in tot.items()},
+                    "instrumented_steps": train_timed_steps,
                     "wgrad_frac_by_shape": {f"{k[2]}x{k[3]}": round(2.0 * k[1] * k[2] * k[3] / (v / len(shapes[k]) * 1e-3) / 1e12 / peak, 3)
                                             for k, v in tot.items()},
-                    "launch_classes_ms_per_step": {fn: round(ms_ / args.steps, 3) for fn, (_n, ms_) in train_classes.items()},
-                    "wgrad_share_of_step": round(sum(tot.values()) / args.steps / ms_per_step, 3)}
+                    "launch_classes_ms_per_step": {fn: round(ms_ / max(train_timed_steps, 1), 3) for fn, (_n, ms_) in train_classes.items()},
+                    "wgrad_share_of_step": round(sum(tot.values()) / max(train_timed_steps, 1) / ms_per_step, 3)}
     if roofline is not None and on_gpu and roofline.get("bound") == "mfma" and "bf16" in str(roofline.get("peak_is", "")):
         # the ceiling this part SUSTAINS for the kernels' matrix-core instruction mix, measured in THIS run right behind the timed
         # region (usf_mfma_probe: a register-only loop of v_mfma_f32_16x16x32_bf16 at the GEMM's occupancy and tiling; under

@@ -1,7 +1,7 @@
 """Regenerate the committed profile summaries (run on the GPU box from the repo root):
 
     python3 tools/make_profiles.py r03 [sections]   # writes gpurun_out/profiles_r03/*, copy them into profiles/
-    sections (default all): bench pmc f16 peak other train image imagetrain -- several calls fit gpurun's 20-minute limit
+    sections (default all): bench pmc f16 peak other train trainpmc image imagetrain live -- several calls fit gpurun's 20-minute limit
 
 1. `python3 bench.py` (defaults)                                   -> <tag>_bench.json
 2. `rocprofv3 --kernel-trace --stats -- python3 bench.py`          -> <tag>_bench_kernel_stats.{csv,md}, <tag>_bench_under_rocprof.json
@@ -45,7 +45,7 @@ def run(cmd, **kw):
 
 
 
-SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "image", "imagetrain", "live"]
+SECTIONS = sys.argv[2:] or ["bench", "pmc", "f16", "peak", "other", "train", "trainpmc", "image", "imagetrain", "live"]
 
 
 B, D, H = 65536, 784, 256          # cfg2 shape (algorithmic byte counts of the traffic summaries)
@@ -270,6 +270,37 @@ if want("train"):
             name = row["Name"]
             name = name if len(name) < 110 else name[:107] + "..."
             f.write(f"| `{name}` | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |\n")
+
+if want("trainpmc"):
+    # 4b. HBM traffic of the training step's kernels (round 5: the planes training path), each counter in its own pass
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(out, "pmc_train_" + ctr)
+        run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--mode", "train", "--steps", "2",
+             "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing"])
+        for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(fn)):
+                k = row["Kernel_Name"]
+                if "usf::" not in k:
+                    continue
+                k = k[k.index("usf::") + 5:]
+                k = k[: k.index("(")] if "(" in k else k
+                # (the weight-gradient kernel serves four shapes: keyed by its grid as well)
+                agg[k + " grid " + row.get("Grid_Size", "?")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    kern = {}
+    for k, dct in sorted(agg.items()):
+        f = sum(dct["FETCH_SIZE"]) / max(1, len(dct["FETCH_SIZE"]))
+        w = sum(dct["WRITE_SIZE"]) / max(1, len(dct["WRITE_SIZE"]))
+        kern[k] = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1), "dispatches": len(dct["FETCH_SIZE"]),
+                   "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    json.dump({
+        "source": "rocprofv3 --pmc FETCH_SIZE and (separate pass) --pmc WRITE_SIZE on `python3 bench.py --mode train --steps 2 --warmup 1 "
+                  "--no-cpu-baseline --no-kernel-timing` (cfg2 model, 65536 rows, planes training path), MI355X; tools/make_profiles.py",
+        "units": "KB per dispatch (mean); hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE doubled as "
+                 "MI355X_MICROARCH.md prescribes for gfx950)",
+        "algorithmic_bytes": {"wgrad 784 x 784 (usf_wgrad_blocked_f32)": 2 * B * 800 * 6, "gemm_planes 784 x 784": 2 * B * 800 * 6 + 3 * 800 * 800 * 2,
+                              "conditioner wgrads of one coupling": (392 + 256 + 256 + 256 + 256 + 400) * B * 6},
+        "kernels": kern}, open(os.path.join(out, f"{tag}_train_hbm_traffic.json"), "w"), indent=1)
 
 # 5. image-shaped flows: bench lines of the reference's MNIST / CIFAR experiment models, kernel trace and the
 #    PMC passes (FETCH_SIZE / WRITE_SIZE and the matrix-pipe counters, each in its own run) of the MNIST configuration
