@@ -893,12 +893,13 @@ def psum_defer_ok(x) -> bool:
             and (not torch.cuda.is_current_stream_capturing() or _psum.arena is not None))
 
 
-def flush_partial_sums(task: int) -> None:
+def flush_partial_sums(task: int, final: bool = True) -> None:
     """issue the sums backward pass `task` queued on the current stream (the pass's end-of-pass callback): ONE launch for all
     first rounds, ONE for all final rounds"""
     with _psum.lock:
         jobs = _psum.jobs.pop(task, [])
-        _psum.owners.pop(task, None)
+        if final:          # (a flush in the middle of the pass keeps the record of which parameters already have a gradient)
+            _psum.owners.pop(task, None)
     if not jobs:
         return
     device = jobs[0][2][0].device
@@ -944,11 +945,14 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
     if defer and psum_defer_ok(x) and owners:
         task = torch._C._current_graph_task_id()
         with _psum.lock:
+            if task not in _psum.owners:
+                for old in [t for t in _psum.owners if t < task - 256]:      # (passes that never met their end-of-pass callback)
+                    del _psum.owners[old]
             seen = _psum.owners.setdefault(task, set())
             dup = any(o in seen for o in owners)
             seen.update(owners)
         if dup:
-            flush_partial_sums(task)          # the earlier producer's sums run now, in stream order before autograd's add
+            flush_partial_sums(task, final=False)      # the earlier producer's sums run now, in stream order before autograd's add
             defer = False
     if defer and psum_defer_ok(x):
         # (table bytes this pass has queued so far: inside a capture they must fit the pre-capture buffer)
@@ -974,7 +978,7 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
                     for old in [t for t in _psum.jobs if t < task - 256]:
                         del _psum.jobs[old]
                     q = _psum.jobs[task] = []
-                    torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: flush_partial_sums(t))
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: flush_partial_sums(t, final=True))
                 # (only the partial slots are kept alive: an extra reference to dW / db would stop the autograd engine from
                 # TAKING them as the parameter's gradient -- it would copy them on the spot, before the sum has run)
                 j0 = None
