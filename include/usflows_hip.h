@@ -463,7 +463,7 @@ typedef struct usf_pack_planes_desc {
                                            travel as fp16): the caller must then redo the pass in BF16X3 */
   /* ABI 33 */
   int64_t src_cols;                     /* > 0: every idx[l] < src_cols -- lets the kernel read whole rows coalesced and gather out
-                                           of LDS (16 (src_cols + 1) floats must fit 64 KB); 0: unknown (one gather per element) */
+                                           of LDS (16 (src_cols + 1) + 96 nkb floats must fit 64 KB); 0: unknown (one gather per element) */
   /* optional, src_cols > 0 only: the source is transformed on the way in -- the head of the TRAINING backward pass,
    * src = the latent z and the planes receive  g[m, c] = row_weight[m] * d/dz base_c(z[m, c])  (usf_base_logprob_grad_f32's
    * formulas for USF_BASE_LAPLACE / USF_BASE_NORMAL with loc / scale [src_cols]; grad_base = 1 + base id, 0 = plain copy) */

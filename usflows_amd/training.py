@@ -546,7 +546,7 @@ class TrainPath:
             t = torch.full((32 * nkb_g,), -1, dtype=torch.int32)
             t[:D] = torch.arange(D, dtype=torch.int32)
             self._inv[key] = t.to(dev)
-        if info[0] != "radial" and 16 * (D + 1) * 4 <= 65536:
+        if info[0] != "radial" and (16 * (D + 1) + 96 * nkb_g) * 4 <= 65536:      # (the rows kernel's LDS: 16 rows + the layout tables)
             # Laplace / Normal base: the gradient at the latent goes straight into the planes (one pass over z instead of
             # usf_base_logprob_grad_f32's fp32 rows + their repack)
             _ext.pack_planes(ws[zname], gp[0], M=B, nkb=nkb_g, idx=self._inv[key], ld=ldn, src_cols=D, grad=(base, glp, loc, scale))
