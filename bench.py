@@ -1154,7 +1154,7 @@ def _from_profile(kind, base, field, args, B, D, hidden):
     if not (B == 65536 and D == 784 and list(hidden) == [256, 256] and args.config == "cfg2"):
         return None, None
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json")), reverse=True):
         try:
             prof = json.load(open(path))
             cand = [(v.get("dispatches", 0), v) for k, v in prof["kernels"].items() if k.split("<")[0] == base]
