@@ -296,12 +296,32 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   // Persistent blocks: the grid is one block per CU (a multiple of 8); block b works through the virtual blocks
   // b, b + grid, b + 2 grid, ... -- the order in which the hardware would have dispatched a grid of that size.
   // XCD-aware map of a virtual block: the column blocks of one 256-row panel group run back to back on one XCD.
-  // Round 5: the FIRST loads of the next tile (weight slab 0 -> staging registers, operand slab 0 -> pa) are issued in front of
-  // the current tile's epilogue, so their latency runs under its ~500 vector instructions instead of in front of an idle matrix
-  // pipe (the pro- / epilogue was 12.4 % of a tile: profiles/r02_tuning_experiments.md).
-  int n0 = 0, bn = 0;
-  int pw[2] = {0, 0};                           // this wave's two panels (unclamped: >= npanels means "no rows")
-  unsigned aoff[2] = {0u, 0u};
+  for (int bid = blockIdx.x; bid < p.nvb; bid += gridDim.x) {
+  const int xcd = bid & 7;
+  const int seq = bid >> 3;
+  const int pg = (seq / p.nbn) * 8 + xcd;       // group of 16 panels (256 rows)
+  const int bn = seq % p.nbn;
+  if (pg >= p.nbm) continue;
+  if (bid != (int)blockIdx.x) __syncthreads();  // the previous tile's last reads of the weight ring are done
+  const int n0 = bn * BN;
+  int pw[2];                                    // this wave's two panels (unclamped: >= npanels means "no rows")
+  pw[0] = pg * 16 + wave * 2;
+  pw[1] = pw[0] + 1;
+
+  // ---- activations: one 16-byte load per lane, plane and batch tile, straight into the MFMA B operand ----
+  unsigned aoff[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+    aoff[b] = ((unsigned)min(pw[b], p.npanels - 1) * (unsigned)p.a_nkb + (unsigned)p.a_kb0) * CHB + (unsigned)lane * 16u;
+  auto issue_a = [&](int kb, vec8 (&dst)[2][NPL]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        dst[b][q] = USF_PL_LOAD_A(reinterpret_cast<const vec8*>(p.A + (aoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u)));
+  };
+
+  // ---- weights: register-staged into the LDS ring (2-byte elements; offsets in bytes) ----
   unsigned wsrc[NWV];
   int wdst[NWV];
 #pragma unroll
@@ -310,47 +330,9 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     const int idc = (idx < NSLOT) ? idx : idx - NSLOT;
     const int pl = idc / (4 * BN), rem = idc % (4 * BN);
     const int r = rem >> 2, ch = rem & 3;
+    wsrc[i] = (unsigned)(2 * (pl * p.plane_stride + (int64_t)min(n0 + r, p.wrows - 1) * p.ldwp + 8 * ch));
     wdst[i] = 4 * ((pl * 4 + ch) * CS + (r ^ (2 * ch)));
-    wsrc[i] = 0u;
   }
-  // virtual block -> (group of 16 panels, column tile); false for the padding blocks of the last XCD round
-  auto decode = [&](int bid_, int& pg_, int& bn_) {
-    const int xcd = bid_ & 7;
-    const int seq = bid_ >> 3;
-    pg_ = (seq / p.nbn) * 8 + xcd;
-    bn_ = seq % p.nbn;
-    return pg_ < p.nbm;
-  };
-  auto next_valid = [&](int bid_, int& pg_, int& bn_) {
-    while (bid_ < p.nvb && !decode(bid_, pg_, bn_)) bid_ += (int)gridDim.x;
-    return bid_;
-  };
-  // addresses of a tile: activations -- one 16-byte load per lane, plane and batch tile, straight into the MFMA B operand --
-  // and weights -- register-staged into the LDS ring (2-byte elements; offsets in bytes)
-  auto setup = [&](int pg_, int bn_) {
-    bn = bn_;
-    n0 = bn_ * BN;
-    pw[0] = pg_ * 16 + wave * 2;
-    pw[1] = pw[0] + 1;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-      aoff[b] = ((unsigned)min(pw[b], p.npanels - 1) * (unsigned)p.a_nkb + (unsigned)p.a_kb0) * CHB + (unsigned)lane * 16u;
-#pragma unroll
-    for (int i = 0; i < NWV; ++i) {
-      const int idx = tid + NT * i;
-      const int idc = (idx < NSLOT) ? idx : idx - NSLOT;
-      const int pl = idc / (4 * BN), rem = idc % (4 * BN);
-      const int r = rem >> 2, ch = rem & 3;
-      wsrc[i] = (unsigned)(2 * (pl * p.plane_stride + (int64_t)min(n0 + r, p.wrows - 1) * p.ldwp + 8 * ch));
-    }
-  };
-  auto issue_a = [&](int kb, vec8 (&dst)[2][NPL]) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < NPL; ++q)
-        dst[b][q] = USF_PL_LOAD_A(reinterpret_cast<const vec8*>(p.A + (aoff[b] + (unsigned)kb * CHB + (unsigned)q * 1024u)));
-  };
   auto issue_w = [&](int k0, f32x4 (&dst)[NWV]) {
 #pragma unroll
     for (int i = 0; i < NWV; ++i) dst[i] = *reinterpret_cast<const f32x4*>(p.Wp + (wsrc[i] + 2u * (unsigned)k0));
@@ -359,26 +341,6 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #pragma unroll
     for (int i = 0; i < NWV; ++i) *reinterpret_cast<f32x4*>(wb + wdst[i]) = src[i];
   };
-  vec8 pa[2][NPL], pb[2][NPL];
-  vec8 fr[2][NPL], f2[2][NPL];                   // weight fragments: current tile pair / the pair being read
-  f32x4 wst[NWV];
-  const int nslab = p.nk;
-  auto ks = [&](int s_) { return s_; };
-
-  // Persistent blocks: the grid is one block per CU (a multiple of 8); block b works through the virtual blocks
-  // b, b + grid, b + 2 grid, ... -- the order in which the hardware would have dispatched a grid of that size.
-  // XCD-aware map of a virtual block: the column blocks of one 256-row panel group run back to back on one XCD.
-  int pg_first = 0, bn_first = 0;
-  int bid = next_valid((int)blockIdx.x, pg_first, bn_first);
-  if (bid < p.nvb) {
-    setup(pg_first, bn_first);
-    issue_w(ks(0) * 32, wst);
-    issue_a(ks(0), pa);
-  }
-  bool first_tile = true;
-  while (bid < p.nvb) {
-  if (!first_tile) __syncthreads();             // the previous tile's last reads of the weight ring are done
-  first_tile = false;
 
   // accumulators (C^T: batch row on the lane, 4 consecutive output features per register group) start at the bias
   f32x4 acc[FT][2];
@@ -400,7 +362,14 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #ifdef USF_STAMP
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  store_w(wring, wst);                          // (slab 0: loaded in front of the previous tile's epilogue / the loop)
+  vec8 pa[2][NPL], pb[2][NPL];
+  vec8 fr[2][NPL], f2[2][NPL];                   // weight fragments: current tile pair / the pair being read
+  f32x4 wst[NWV];
+  const int nslab = p.nk;
+  auto ks = [&](int s_) { return s_; };
+  issue_w(ks(0) * 32, wst);
+  store_w(wring, wst);
+  issue_a(ks(0), pa);
   issue_w(ks(min(1, nslab - 1)) * 32, wst);     // staged at the middle of slab 0
   __syncthreads();
   const float* const wl0 = wring + 4 * (lg * CS + (lj ^ (2 * lg)));
@@ -518,18 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #undef USF_MM
   PSTAMP(t2);
 
-  // ---- the next tile's first loads, then the epilogue of this one (on copies of its identity) ----
-  const int n0_c = n0, bn_c = bn, pw_c0 = pw[0], pw_c1 = pw[1];
-  int pg_n = 0, bn_n = 0;
-  const int bid_next = next_valid(bid + (int)gridDim.x, pg_n, bn_n);
-  if (!F32OUT && bid_next < p.nvb) {           // (the fp32-output epilogue keeps all its registers: its prefetch follows it)
-    setup(pg_n, bn_n);
-    issue_w(ks(0) * 32, wst);
-    issue_a(ks(0), pa);
-  }
-  {
-  const int n0 = n0_c, bn = bn_c;
-  const int pw[2] = {pw_c0, pw_c1};
+  // ---- epilogue ----
   bool bad = false;                            // fp16 planes only: range guard (see usf_gemm_planes_desc.range_flag)
   if (p.act == USF_ACT_LEAKY_RELU) {           // wave-uniform branch: the affine layers (no activation) skip the selects
 #pragma unroll
@@ -609,12 +567,6 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
     }
   }
   if (NPL == 2 && p.range_flag && bad) atomicOr(p.range_flag, 1);
-  }
-  if (F32OUT && bid_next < p.nvb) {
-    setup(pg_n, bn_n);
-    issue_w(ks(0) * 32, wst);
-    issue_a(ks(0), pa);
-  }
 #ifdef USF_STAMP
   PSTAMP(t3);
   if (p.dbg && lane == 0) {
@@ -627,7 +579,6 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #endif
   }
 #endif
-  bid = bid_next;
   }  // virtual blocks
 #ifdef USF_STAMP
   if (p.span && tid == 0) atomicMax(p.span + 1, __builtin_amdgcn_s_memrealtime());
