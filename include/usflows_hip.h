@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 33
+#define USF_ABI_VERSION 34
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -410,6 +410,28 @@ int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, i
                                    float eps, int32_t act, float slope, float* dgamma_dbeta, float* workspace,
                                    int64_t workspace_floats, usf_stream_t stream);
 int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream);
+
+/* The tail of a GatedConv layer of ConvNet2D (reference networks.py:108-122 with the nonlinearity and LayerNormChannels that
+ * follow it, networks.py:40-58, 480-493) at training batches, forward and backward ONE launch each:
+ *     a = in_act(h); [val, gate] = W a + bias (W [2 C, C], bias [2 C] or NULL); r = x + val * sigmoid(gate);
+ *     y = LayerNormChannels(post_act(r); gamma, beta, eps)    (ln_gamma == NULL: y = r, post_act must be USF_ACT_NONE)
+ * on contiguous [B, C, P] fp32 tensors, C in {8, 16, 24, 32} (usf_gated_tail_supported).  It replaces the chain
+ * usf_pointwise_conv_f32 -> usf_gated_residual_f32 -> usf_layernorm_channels_f32 and, backward, usf_layernorm_channels_bwd_f32
+ * -> usf_gated_residual_bwd_f32 -> usf_pointwise_conv_f32 on a transposed copy of W: the backward recomputes val / gate / r
+ * from (h, x) and writes dx [B, C, P] (the skip branch), dh [B, C, P], dvg [B, 2 C, P] = d[val, gate] (the weight gradient
+ * of W is usf_conv_wgrad_f32(h, dvg, ks = 1, in_act)) and dgamma_dbeta [2 C].  workspace >= usf_gated_tail_workspace floats.
+ * job == NULL: dgamma_dbeta is complete when the call's launches have run; else job[0 .. 1] (HOST memory) describe its last
+ * sum for usf_partial_sum_jobs_f32 as usf_conv_wgrad_deferred_f32 does (nparts == 0: nothing to do).
+ * Eight lanes share a pixel: made for few pixels (a 32-row training batch); HBM traffic 4 C (3 + 4) bytes per pixel backward. */
+int usf_gated_tail_supported(int64_t C);
+int64_t usf_gated_tail_workspace(int64_t B, int64_t C, int64_t P);
+int usf_gated_tail_f32(const float* h, const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* bias,
+                       int32_t in_act, float in_slope, int32_t post_act, float post_slope, const float* ln_gamma,
+                       const float* ln_beta, float ln_eps, usf_stream_t stream);
+int usf_gated_tail_bwd_f32(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C,
+                           int64_t P, const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act,
+                           float post_slope, const float* ln_gamma, const float* ln_beta, float ln_eps, float* dgamma_dbeta,
+                           float* workspace, int64_t workspace_floats, struct usf_psum_job* job, usf_stream_t stream);
 
 /* A data-gradient convolution with the factors of the layer's INPUT transforms in its output stream:
  *   y = conv(x) * (gate_h > 0 ? 1 : gate_slope) * gate_mul          (gate_add == NULL)

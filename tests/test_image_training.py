@@ -231,6 +231,65 @@ def test_pointwise_data_gradient_with_the_gate_in_its_pass():
         assert got.shape == ref.shape and torch.equal(got, ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,P,B,ln,in_act,post_act,bias", [
+    (32, 49, 32, True, (1, 0.0), (1, 0.0), True),        # the live MNIST configuration's layer at its training batch
+    (32, 49, 300, True, (1, 0.1), (1, 0.2), True),       # > 64 blocks: two rounds of the parameter sums
+    (16, 20, 7, True, (1, 0.0), None, False),            # ragged: 140 pixels, no bias, layer norm without a nonlinearity
+    (24, 64, 3, False, (1, 0.0), None, True),            # no layer norm: y = x + val * sigmoid(gate)
+    (8, 6, 1, True, None, (1, 0.0), True),
+])
+def test_gated_tail_forward_and_backward_vs_fp64(C, P, B, ln, in_act, post_act, bias):
+    """usf_gated_tail_f32 / usf_gated_tail_bwd_f32 against fp64 autograd of the chain they replace (reference networks.py:108-122,
+    40-58: 1 x 1 convolution, gate, skip connection, nonlinearity, LayerNormChannels)"""
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(C + P + B)
+    h = torch.randn(B, C, P, generator=g).to(DEV)
+    x = torch.randn(B, C, P, generator=g).to(DEV)
+    dy = torch.randn(B, C, P, generator=g).to(DEV)
+    W = (torch.randn(2 * C, C, generator=g) / C ** 0.5).to(DEV)
+    bvec = (0.3 * torch.randn(2 * C, generator=g)).to(DEV) if bias else None
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.2 * torch.randn(C, generator=g)).to(DEV)
+    eps = 1e-5
+    ia = in_act if in_act is not None else (_ext.ACT_NONE, 0.0)
+    pa = post_act if post_act is not None else (_ext.ACT_NONE, 0.0)
+    lnp = (gamma, beta, eps) if ln else None
+    y = _ext.gated_tail(h, x, W, bvec, ia[0], ia[1], pa[0], pa[1], lnp)
+    dx, dh, dvg, dg, dbt = _ext.gated_tail_bwd(h, x, dy, W, bvec, ia[0], ia[1], pa[0], pa[1], lnp)
+    h64, x64 = h.double().requires_grad_(True), x.double().requires_grad_(True)
+    W64 = W.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.leaky_relu(h64, in_act[1]) if in_act is not None else h64
+    vg = torch.einsum("oc,bcp->bop", W64, a)
+    if bias:
+        vg = vg + bvec.double().view(1, -1, 1)
+    vg.retain_grad()
+    val, gate = vg.chunk(2, dim=1)
+    r = x64 + val * torch.sigmoid(gate)
+    if ln:
+        v = F.leaky_relu(r, post_act[1]) if post_act is not None else r
+        mean = v.mean(dim=1, keepdim=True)
+        var = v.var(dim=1, unbiased=False, keepdim=True)
+        r = (v - mean) / torch.sqrt(var + eps) * g64.view(1, C, 1) + b64.view(1, C, 1)
+    r.backward(dy.double())
+    _close(y, r.detach(), 1e-5, "y")
+    _close(dx, x64.grad, 1e-5, "dx")
+    _close(dh, h64.grad, 1e-5, "dh")
+    _close(dvg, vg.grad, 1e-5, "dvg")
+    if ln:
+        _close(dg, g64.grad, 1e-5, "dgamma")
+        _close(dbt, b64.grad, 1e-5, "dbeta")
+    else:
+        assert dg is None and dbt is None
+    # the weight gradient of W from d[val, gate]: the kernel-1 form of usf_conv_wgrad_f32 on (h, dvg) with the input nonlinearity
+    if C % 16 == 0:
+        Hs = {49: (7, 7), 20: (5, 4), 64: (8, 8)}[P]
+        r2 = _ext.conv_wgrad(h.view(B, C, *Hs), dvg.view(B, 2 * C, *Hs), 1, in_act=ia[0], in_slope=ia[1], want_bias=True)
+        if r2 is not None:
+            _close(r2[0].view(2 * C, C), W64.grad, 1e-5, "dW")
+
+
 # ---- the autograd functions against fp64 torch autograd of the same module ------------------------------------------------
 def _grads_of(module_fn, params, x, dy):
     for p in params:

@@ -20,7 +20,7 @@ from .config import config  # noqa: E402
 
 LIB_PATH = config.lib_path     # (USFLOWS_AMD_LIB: A/B builds)
 
-USF_ABI_VERSION = 33
+USF_ABI_VERSION = 34
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
@@ -219,6 +219,12 @@ SYMBOLS = {
     "usf_layernorm_channels_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_int32, C.c_float,
                                                  _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_gated_residual_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_gated_tail_supported": (C.c_int, [C.c_int64]),
+    "usf_gated_tail_workspace": (C.c_int64, [C.c_int64] * 3),
+    "usf_gated_tail_f32": (C.c_int, [_fp, _fp, _fp] + [C.c_int64] * 3 + [_fp, _fp, C.c_int32, C.c_float, C.c_int32, C.c_float, _fp, _fp,
+                                     C.c_float, C.c_void_p]),
+    "usf_gated_tail_bwd_f32": (C.c_int, [_fp] * 6 + [C.c_int64] * 3 + [_fp, _fp, C.c_int32, C.c_float, C.c_int32, C.c_float, _fp, _fp,
+                                         C.c_float, _fp, _fp, C.c_int64, C.c_void_p, C.c_void_p]),
     "usf_conv2d_weight_planes_f32": (C.c_int, [_fp, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "usf_gather_cols_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_void_p]),
     "usf_run_ops": (C.c_int, [C.POINTER(Op), C.c_int32, C.c_void_p]),
@@ -927,6 +933,53 @@ def flush_partial_sums(task: int, final: bool = True) -> None:
                 (table, [k for _, k in part]))
 
 
+def _psum_may_defer(x, owners) -> bool:
+    """may the producer of gradients for the Parameters `owners` (ids) queue its last sum in the current backward pass?  A second
+    producer for the same parameter flushes the queue first and is not deferred (autograd adds the two gradients when the second
+    one arrives: the first must be complete by then)"""
+    if not (psum_defer_ok(x) and owners):
+        return False
+    task = torch._C._current_graph_task_id()
+    with _psum.lock:
+        if task not in _psum.owners:
+            for old in [t for t in _psum.owners if t < task - 256]:      # (passes that never met their end-of-pass callback)
+                del _psum.owners[old]
+        seen = _psum.owners.setdefault(task, set())
+        dup = any(o in seen for o in owners)
+        seen.update(owners)
+    if dup:
+        flush_partial_sums(task, final=False)      # the earlier producer's sums run now, in stream order before autograd's add
+        return False
+    # (table bytes this pass has queued so far: inside a capture they must fit the pre-capture buffer)
+    with _psum.lock:
+        queued = _psum.jobs.get(task)
+        used = sum(q_[3] for q_ in queued) if queued else 0
+    if torch.cuda.is_current_stream_capturing() and used > _psum.arena[0].numel() // 2 - (1 << 16):
+        return False
+    return True
+
+
+def _psum_queue(job2, keep) -> None:
+    """queue the (first round | none, last round) jobs an entry point returned; `keep` = the tensors holding the partial slots"""
+    if job2[1].nparts <= 0:
+        return
+    task = torch._C._current_graph_task_id()
+    with _psum.lock:
+        q = _psum.jobs.get(task)
+        if q is None:
+            # (queues of passes that died of an exception never met their callback: graph task ids only grow, so what is
+            # far behind the current one is dropped -- NOT everything else: another thread's pass may be queueing too)
+            for old in [t for t in _psum.jobs if t < task - 256]:
+                del _psum.jobs[old]
+            q = _psum.jobs[task] = []
+            torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: flush_partial_sums(t, final=True))
+        # (only the partial slots are kept alive: an extra reference to the outputs would stop the autograd engine from
+        # TAKING them as the parameter's gradient -- it would copy them on the spot, before the sum has run)
+        j0 = PsumJob.from_buffer_copy(job2[0]) if job2[0].nparts > 0 else None
+        nbytes = 2 * C.sizeof(PsumJob) + 4 * sum(((j_.n + 63) // 64) * j_.rows for j_ in job2 if j_.nparts > 0) + 64
+        q.append((j0, PsumJob.from_buffer_copy(job2[1]), tuple(keep), nbytes))
+
+
 def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True, defer=False, owners=()):
     """usf_conv_wgrad_f32: (dW [cout, cin, ks, ks], db [cout] | None) of a stride-1 "same" convolution from its input x
     [B, cin, H, W] (with the forward's input transforms) and the output gradient dy [B, cout, H, W]; None when the shape is
@@ -942,50 +995,14 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
     ws = torch.empty(ws_n, dtype=torch.float32, device=x.device)
     dW = torch.empty(cout, cin, ks, ks, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
-    if defer and psum_defer_ok(x) and owners:
-        task = torch._C._current_graph_task_id()
-        with _psum.lock:
-            if task not in _psum.owners:
-                for old in [t for t in _psum.owners if t < task - 256]:      # (passes that never met their end-of-pass callback)
-                    del _psum.owners[old]
-            seen = _psum.owners.setdefault(task, set())
-            dup = any(o in seen for o in owners)
-            seen.update(owners)
-        if dup:
-            flush_partial_sums(task, final=False)      # the earlier producer's sums run now, in stream order before autograd's add
-            defer = False
-    if defer and psum_defer_ok(x):
-        # (table bytes this pass has queued so far: inside a capture they must fit the pre-capture buffer)
-        with _psum.lock:
-            queued = _psum.jobs.get(torch._C._current_graph_task_id())
-            used = sum(q_[3] for q_ in queued) if queued else 0
-        if torch.cuda.is_current_stream_capturing() and used > _psum.arena[0].numel() // 2 - (1 << 16):
-            defer = False
-    if defer and psum_defer_ok(x):
+    if defer and _psum_may_defer(x, owners):
         job2 = (PsumJob * 2)()
         rc = lib.usf_conv_wgrad_deferred_f32(x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act),
                                              float(in_slope), dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, job2, current_stream(x.device))
         if rc == 1:
             return None
         check(rc, "usf_conv_wgrad_deferred_f32")
-        if job2[1].nparts > 0:
-            task = torch._C._current_graph_task_id()
-            with _psum.lock:
-                q = _psum.jobs.get(task)
-                if q is None:
-                    # (queues of passes that died of an exception never met their callback: graph task ids only grow, so what is
-                    # far behind the current one is dropped -- NOT everything else: another thread's pass may be queueing too)
-                    for old in [t for t in _psum.jobs if t < task - 256]:
-                        del _psum.jobs[old]
-                    q = _psum.jobs[task] = []
-                    torch.autograd.Variable._execution_engine.queue_callback(lambda t=task: flush_partial_sums(t, final=True))
-                # (only the partial slots are kept alive: an extra reference to dW / db would stop the autograd engine from
-                # TAKING them as the parameter's gradient -- it would copy them on the spot, before the sum has run)
-                j0 = None
-                if job2[0].nparts > 0:
-                    j0 = PsumJob.from_buffer_copy(job2[0])
-                nbytes = 2 * C.sizeof(PsumJob) + 4 * sum(((j_.n + 63) // 64) * j_.rows for j_ in job2 if j_.nparts > 0) + 64
-                q.append((j0, PsumJob.from_buffer_copy(job2[1]), (ws,), nbytes))
+        _psum_queue(job2, (ws,))
         return dW, db
     args = (x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act), float(in_slope),
             dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, current_stream(x.device))
@@ -1017,6 +1034,50 @@ def gated_residual_bwd(dy, vg):
     dvg = torch.empty_like(vg)
     _direct("usf_gated_residual_bwd_f32", dy.data_ptr(), vg.data_ptr(), dvg.data_ptr(), B, CP, current_stream(dy.device))
     return dvg
+
+
+def gated_tail_supported(C_: int) -> bool:
+    return bool(load().usf_gated_tail_supported(int(C_)))
+
+
+def gated_tail(h, x, W, bias, in_act=ACT_NONE, in_slope=0.0, post_act=ACT_NONE, post_slope=0.0, ln=None):
+    """usf_gated_tail_f32: GatedConv's 1 x 1 convolution + gate + skip [+ nonlinearity + LayerNormChannels, ln = (gamma, beta, eps)]
+    of contiguous [B, C, *spatial] tensors h (the 3 x 3 convolution's output) and x (the layer's input) in one launch"""
+    B, Cc = x.shape[0], x.shape[1]
+    P = math.prod(x.shape[2:])
+    y = torch.empty_like(x)
+    g, bt, eps = ln if ln is not None else (None, None, 0.0)
+    _direct("usf_gated_tail_f32", h.data_ptr(), x.data_ptr(), y.data_ptr(), B, Cc, P, W.data_ptr(), ptr(bias), int(in_act),
+            float(in_slope), int(post_act), float(post_slope), ptr(g), ptr(bt), float(eps), current_stream(x.device))
+    return y
+
+
+def gated_tail_bwd(h, x, dy, W, bias, in_act=ACT_NONE, in_slope=0.0, post_act=ACT_NONE, post_slope=0.0, ln=None, defer=False,
+                   owners=()):
+    """usf_gated_tail_bwd_f32 -> (dx, dh, dvg [B, 2C, *spatial], dgamma [C] | None, dbeta [C] | None); defer / owners as in
+    conv_wgrad (the layer norm's parameter sums may be queued until the backward pass ends)"""
+    B, Cc = x.shape[0], x.shape[1]
+    P = math.prod(x.shape[2:])
+    lib = load()
+    dx, dh = torch.empty_like(x), torch.empty_like(x)
+    dvg = torch.empty((B, 2 * Cc) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    g, bt, eps = ln if ln is not None else (None, None, 0.0)
+    dgb = ws = None
+    ws_n = 0
+    if ln is not None:
+        ws_n = lib.usf_gated_tail_workspace(B, Cc, P)
+        ws = torch.empty(max(1, ws_n), dtype=torch.float32, device=x.device)
+        dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+    job2 = (PsumJob * 2)() if (ln is not None and defer and _psum_may_defer(x, owners)) else None
+    args = (h.data_ptr(), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dh.data_ptr(), dvg.data_ptr(), B, Cc, P, W.data_ptr(), ptr(bias),
+            int(in_act), float(in_slope), int(post_act), float(post_slope), ptr(g), ptr(bt), float(eps), ptr(dgb), ptr(ws), ws_n,
+            C.cast(job2, C.c_void_p) if job2 is not None else None, current_stream(x.device))
+    check(_timed_call(lib.usf_gated_tail_bwd_f32, args, "usf_gated_tail_bwd_f32"), "usf_gated_tail_bwd_f32")
+    if job2 is not None:
+        _psum_queue(job2, (ws,))
+    if dgb is None:
+        return dx, dh, dvg, None, None
+    return dx, dh, dvg, dgb[:Cc], dgb[Cc:]
 
 
 AFFINE_PREP_MAX_C = 64

@@ -123,6 +123,15 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
                int64_t workspace_floats, usf_psum_job* job, hipStream_t stream);
 int partial_sum_jobs(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
+int gated_tail_supported(int64_t C);
+int64_t gated_tail_workspace(int64_t B, int64_t C, int64_t P);
+int gated_tail_fwd(const float* h, const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* bias,
+                   int32_t in_act, float in_slope, int32_t post_act, float post_slope, const float* gamma, const float* beta,
+                   float eps, hipStream_t stream);
+int gated_tail_bwd(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C, int64_t P,
+                   const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act, float post_slope,
+                   const float* gamma, const float* beta, float eps, float* dgamma_dbeta, float* workspace, int64_t workspace_floats,
+                   usf_psum_job* job, hipStream_t stream);
 int64_t layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P);
 int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma, float eps,
                            int32_t act, float slope, float* dgamma, float* dbeta, float* workspace, int64_t workspace_floats,
@@ -366,6 +375,21 @@ int usf_conv2d_weight_planes_f32(const float* w, void* planes, int64_t cin, int6
 }
 int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream) {
   return usf::gated_residual_bwd(dy, vg, dvg, B, CP, (hipStream_t)stream);
+}
+int usf_gated_tail_supported(int64_t C) { return usf::gated_tail_supported(C); }
+int64_t usf_gated_tail_workspace(int64_t B, int64_t C, int64_t P) { return usf::gated_tail_workspace(B, C, P); }
+int usf_gated_tail_f32(const float* h, const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* bias,
+                       int32_t in_act, float in_slope, int32_t post_act, float post_slope, const float* ln_gamma,
+                       const float* ln_beta, float ln_eps, usf_stream_t stream) {
+  return usf::gated_tail_fwd(h, x, y, B, C, P, W, bias, in_act, in_slope, post_act, post_slope, ln_gamma, ln_beta, ln_eps,
+                             (hipStream_t)stream);
+}
+int usf_gated_tail_bwd_f32(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C,
+                           int64_t P, const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act,
+                           float post_slope, const float* ln_gamma, const float* ln_beta, float ln_eps, float* dgamma_dbeta,
+                           float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_stream_t stream) {
+  return usf::gated_tail_bwd(h, x, dy, dx, dh, dvg, B, C, P, W, bias, in_act, in_slope, post_act, post_slope, ln_gamma, ln_beta,
+                             ln_eps, dgamma_dbeta, workspace, workspace_floats, job, (hipStream_t)stream);
 }
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks) { return usf::conv2d_weight_elems(cin, cout, ks); }
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) { return usf::conv2d_same_fits(cin, cout, H, W, ks); }

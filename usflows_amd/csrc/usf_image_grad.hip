@@ -354,6 +354,28 @@ static int reduce_partials(const float* part, int nparts, int n, float* scratch,
   return check_launch(what);
 }
 
+// the same sum for other kernels' per-block slots (usf_gated_tail.hip), mode 0: at once (job == NULL), or handed to the caller as
+// jobs of usf_partial_sum_jobs_f32 -- job[0] the first round (nparts == 0: none), job[1] the last
+int64_t sum_slots_scratch(int64_t n) { return (int64_t)kReduceRows * n; }
+
+int sum_slots(const float* part, int nparts, int n, float* scratch, float* out, usf_psum_job* job, hipStream_t stream, const char* what) {
+  if (!job) return reduce_partials(part, nparts, n, scratch, out, nullptr, 0, 0, 0, 0, 0, 0, stream, what);
+  job[0] = usf_psum_job{};
+  job[1] = usf_psum_job{};
+  if (nparts > 64) {
+    const int rows = nparts / 16 < kReduceRows ? (nparts + 15) / 16 : kReduceRows;
+    const int per = (nparts + rows - 1) / rows;
+    const int used = (nparts + per - 1) / per;
+    usf_psum_job& a0 = job[0];
+    a0.part = part; a0.out = scratch; a0.nparts = nparts; a0.n = n; a0.per = per; a0.rows = used;
+    part = scratch;
+    nparts = used;
+  }
+  usf_psum_job& a1 = job[1];
+  a1.part = part; a1.out = out; a1.nparts = nparts; a1.n = n; a1.per = nparts; a1.rows = 1;
+  return 0;
+}
+
 // ceil(2^32 / d), d >= 2: floor(n / d) == umulhi(n, magic) for n * d < 2^32
 static unsigned magic_div(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 

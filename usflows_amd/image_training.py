@@ -239,6 +239,71 @@ class GatedResidual(torch.autograd.Function):
         return dy, _ext.gated_residual_bwd(dy, vg)
 
 
+GATED_TAIL_MAX_PIXELS = 1 << 16     # (eight lanes per pixel: made for the few pixels of a training batch; larger ones keep the chain)
+
+
+def gated_tail_ok(conv2, x, ln=None) -> bool:
+    """GatedConv's 1 x 1 convolution `conv2` (C -> 2 C) with the gate, the skip connection [and the (Leaky)ReLU + LayerNormChannels
+    that follow] as ONE differentiable launch each way (usf_gated_tail_f32 / usf_gated_tail_bwd_f32) at this input"""
+    if not (config.gated_tail and isinstance(conv2, torch.nn.Conv2d) and conv2.kernel_size == (1, 1) and conv2.stride == (1, 1)
+            and conv2.groups == 1 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    pad = conv2.padding
+    if not (pad == "same" or (not isinstance(pad, str) and tuple(pad) == (0, 0))):
+        return False
+    B, Cc, H, W = x.shape
+    if not (conv2.in_channels == Cc and conv2.out_channels == 2 * Cc and 0 < B * H * W <= GATED_TAIL_MAX_PIXELS
+            and _ext.gated_tail_supported(Cc)):
+        return False
+    if ln is not None and not (ln.gamma.numel() == Cc and ln.gamma.dtype == torch.float32):
+        return False
+    return _ext.load().usf_conv_wgrad_workspace(max(B, 1), Cc, 2 * Cc, H, W, 1) > 0
+
+
+class GatedTail(torch.autograd.Function):
+    """LayerNormChannels(post_act(x + val * sigmoid(gate))), [val, gate] = W in_act(h) + bias -- the tail of a GatedConv layer
+    of ConvNet2D (networks.py:108-122, 40-58, 480-493) on usf_gated_tail_f32; gamma None: no layer norm, y = x + val * sigmoid(gate).
+    The backward recomputes val / gate from (h, x): one launch for dx, dh, d[val, gate] and the layer norm's parameter sums, one
+    (usf_conv_wgrad_f32, kernel 1) for dW / dbias."""
+
+    @staticmethod
+    def forward(ctx, h, x, weight, bias, gamma, beta, in_act, post_act, eps):
+        h, x = h.contiguous(), x.contiguous()
+        w2 = weight.detach().reshape(weight.shape[0], weight.shape[1]).contiguous()
+        b2 = None if bias is None else bias.detach().contiguous()
+        ia, pa = _act(in_act), _act(post_act)
+        ln = None
+        if gamma is not None:
+            ln = (gamma.detach().reshape(-1).contiguous(), beta.detach().reshape(-1).contiguous(), float(eps))
+        y = _ext.gated_tail(h, x, w2, b2, ia[0], ia[1], pa[0], pa[1], ln)
+        ctx.save_for_backward(h, x, w2, b2, *(ln[:2] if ln is not None else ()))
+        ctx.cfg = (in_act, post_act, float(eps), tuple(weight.shape), bias is not None, None if gamma is None else tuple(gamma.shape))
+        ctx.params = (weight, bias, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        in_act, post_act, eps, wshape, has_bias, pshape = ctx.cfg
+        saved = ctx.saved_tensors
+        h, x, w2, b2 = saved[:4]
+        ln = (saved[4], saved[5], eps) if pshape is not None else None
+        ia, pa = _act(in_act), _act(post_act)
+        weight, bias, gamma, beta = ctx.params
+        dx, dh, dvg, dg, dbt = _ext.gated_tail_bwd(h, x, dy.contiguous(), w2, b2, ia[0], ia[1], pa[0], pa[1], ln,
+                                                   defer=_takeable((gamma, beta)),
+                                                   owners=tuple(id(q) for q in (gamma, beta) if q is not None))
+        dW = db = None
+        if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
+            r = _ext.conv_wgrad(h, dvg, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable((weight, bias)),
+                                owners=tuple(id(q) for q in (weight, bias) if q is not None))
+            if r is None:
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (gated_tail_ok was not consulted)")
+            dW, db = r[0].reshape(wshape), r[1]
+        if pshape is not None:
+            dg, dbt = dg.reshape(pshape), dbt.reshape(pshape)
+        return dh, dx, dW, db, dg, dbt, None, None, None
+
+
 class LayerNormCh(torch.autograd.Function):
     """LayerNormChannels (networks.py:40-58) with the (Leaky)ReLU ConvNet2D puts in front of it"""
 

@@ -230,8 +230,18 @@ class _ConvStack(nn.Module):
                 x = it.ConvSame.apply(x, m.weight, m.bias, in_mul if k == 0 else None, None, fold)
                 k += 2 if fold is not None else 1
             elif isinstance(m, GatedConv):
-                x = m.forward_train_device(x)
-                k += 1
+                # (few pixels: the nonlinearity and layer norm behind the block join its tail's launch, each way)
+                after = mods[k + 2] if k + 2 < len(mods) else None
+                if isinstance(nxt, LayerNormChannels) and it.gated_tail_ok(m.net[3], x, nxt):
+                    x = m.forward_train_device(x, post=(None, nxt))
+                    k += 2
+                elif nxt is not None and _relu_kind(nxt) is not None and isinstance(after, LayerNormChannels) \
+                        and it.gated_tail_ok(m.net[3], x, after):
+                    x = m.forward_train_device(x, post=(_relu_kind(nxt), after))
+                    k += 3
+                else:
+                    x = m.forward_train_device(x)
+                    k += 1
             elif _relu_kind(m) is not None and isinstance(nxt, LayerNormChannels):
                 x = it.LayerNormCh.apply(x, nxt.gamma, nxt.beta, nxt.eps, _relu_kind(m))
                 k += 2
@@ -513,13 +523,19 @@ class GatedConv(nn.Module):
                 and n[3].in_channels == n[1].out_channels and it.conv_shape_ok(n[1], B, H, W)
                 and (it.pointwise_shape_ok(n[3], B, H, W) or it.conv_shape_ok(n[3], B, H, W)))
 
-    def forward_train_device(self, x):
-        """the block as three differentiable device passes: 3 x 3 convolution, 1 x 1 convolution, gate"""
+    def forward_train_device(self, x, post=None):
+        """the block as differentiable device passes: 3 x 3 convolution, then -- few pixels (image_training.gated_tail_ok) -- ONE
+        pass for the 1 x 1 convolution, the gate, the skip connection and ``post`` = ((act id, slope) | None, LayerNormChannels)
+        behind the block; else 1 x 1 convolution and gate as two passes (post must be None)"""
         from . import image_training as it
         n = self.net
         a0, a2 = _relu_kind(n[0]), _relu_kind(n[2])
         # (x forks into the convolution and the skip connection: one node returns both, its backward writes the summed gradient)
         h, x = it.ConvSameFork.apply(x, n[1].weight, n[1].bias, None, a0)
+        if post is not None or it.gated_tail_ok(n[3], x):
+            pa, lnm = post if post is not None else (None, None)
+            return it.GatedTail.apply(h, x, n[3].weight, n[3].bias, None if lnm is None else lnm.gamma,
+                                      None if lnm is None else lnm.beta, a2, pa, 0.0 if lnm is None else lnm.eps)
         if it.pointwise_shape_ok(n[3], x.shape[0], x.shape[2], x.shape[3]):
             vg = it.Pointwise.apply(h, n[3].weight, n[3].bias, a2)
         else:
