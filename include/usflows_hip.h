@@ -411,6 +411,18 @@ int usf_layernorm_channels_bwd_f32(const float* x, const float* dy, float* dx, i
                                    int64_t workspace_floats, usf_stream_t stream);
 int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream);
 
+/* usf_conv2d_weight_planes_f32(transposed = 2) for MANY weights in one launch.  jobs / block_job are DEVICE arrays (as for
+ * usf_partial_sum_jobs_f32): job j splits the fp32 weight w [cout, cin, ks, ks] into its planes followed by the planes of its
+ * data-gradient convolution, at planes_base + out_off (bf16 elements; usf_conv2d_weight_elems(cin, cout, ks) +
+ * usf_conv2d_weight_elems(cout, cin, ks) of them), and owns the blocks [first_block, first_block + ceil(max of the two
+ * [rows x K] sizes / 256)); block_job[b] names block b's job.  Same bits as the single launches. */
+typedef struct usf_wplanes_job {
+  const float* w; int64_t out_off;
+  int32_t cin, cout, ks, first_block;
+} usf_wplanes_job;
+int usf_conv2d_weight_planes_batch_f32(const usf_wplanes_job* jobs, const int32_t* block_job, int64_t n_blocks, void* planes_base,
+                                       usf_stream_t stream);
+
 /* The tail of a GatedConv layer of ConvNet2D (reference networks.py:108-122 with the nonlinearity and LayerNormChannels that
  * follow it, networks.py:40-58, 480-493) at training batches, forward and backward ONE launch each:
  *     a = in_act(h); [val, gate] = W a + bias (W [2 C, C], bias [2 C] or NULL); r = x + val * sigmoid(gate);

@@ -69,15 +69,47 @@ def base_state(flow):
     return {k: v.detach().clone() for k, v in flow.state_dict().items() if k.startswith("base_distribution.")}
 
 
-def run_case(name, in_dims, K, base, seed, n=12, p=1.0, loc_noise=0.0, grad_layers=None):
+def relu_margin(flow, x):
+    """smallest |input| of any (Leaky)ReLU of the flow on this batch, relative to that input tensor's largest entry: the
+    derivative of a ReLU whose input lies within fp32 rounding of zero (~1e-6) is either one-sided value, depending on the
+    order of evaluation -- a gradient fixture must stay clear of that"""
+    worst = [float("inf")]
+
+    def hook(_m, inp, _out):
+        t = inp[0].detach()
+        worst[0] = min(worst[0], (t.abs().min() / t.abs().max().clamp_min(1e-30)).item())
+
+    hs = [m.register_forward_hook(hook) for m in flow.modules() if isinstance(m, (torch.nn.ReLU, torch.nn.LeakyReLU))]
+    try:
+        with torch.no_grad():
+            flow.log_prob(x)
+    finally:
+        for h in hs:
+            h.remove()
+    return worst[0]
+
+
+def run_case(name, in_dims, K, base, seed, n=12, p=1.0, loc_noise=0.0, grad_layers=None, kink_margin=None):
+    """kink_margin: draw the inputs from the first generator seed 1000 + seed + 100 j (j = 0, 1, ...) for which every ReLU
+    input of the fp32 reference stays at least that far (relative) from zero (round 5: the seed-51 inputs of the CIFAR
+    k10 case held a pre-activation of 1.4e-7 -- the device's gradient then depends on its order of additions)"""
     if len(sys.argv) > 1 and name not in sys.argv[1:]:
         return
     spec = dict(in_dims=list(in_dims), coupling_blocks=K, base=base, seed=seed, p=p, loc_noise=loc_noise, cond_args=LIVE_COND,
                 prior_scale=1.0)
     flow = build(spec)
     bsd = base_state(flow)
-    g = torch.Generator().manual_seed(1000 + seed)
-    x = torch.rand(n, *in_dims, generator=g)
+    x_seed = 1000 + seed
+    while True:
+        g = torch.Generator().manual_seed(x_seed)
+        x = torch.rand(n, *in_dims, generator=g)
+        margin = relu_margin(flow, x)
+        if kink_margin is None or margin >= kink_margin:
+            break
+        print(f"{name}: input seed {x_seed}: smallest relative |ReLU input| {margin:.2e} < {kink_margin:.0e}; next seed")
+        x_seed += 100
+    print(f"{name}: input seed {x_seed}, smallest relative |ReLU input| {margin:.2e}")
+    spec["x_seed"] = x_seed
     # (latents for _forward: the reference's RadialDistribution.sample raises a shape error for an image-shaped loc --
     # distributions.py:482-494 repeats the [n, 1] radii along the wrong axes -- so they are drawn here directly)
     zin = 0.5 * torch.randn(n, *in_dims, generator=g)
@@ -162,7 +194,8 @@ def main():
     run_case("imageradial_c16_7x7_k2_l3_gammamm_pinf", (16, 7, 7), 2, "gammamm", 49, n=6, p=float("inf"), loc_noise=0.05,
              grad_layers=(0, 1, 4, 5))
     run_case("imageradial_fashionlive_c16_7x7_k10_l3_gammamm", (16, 7, 7), 10, "gammamm", 50, n=6, grad_layers=(0, 1, 10, 19, 20, 21))
-    run_case("imageradial_cifarlive_c48_8x8_k10_l3_lognormal", (48, 8, 8), 10, "lognormal", 51, n=4, grad_layers=(0, 1, 10, 19, 20, 21))
+    run_case("imageradial_cifarlive_c48_8x8_k10_l3_lognormal", (48, 8, 8), 10, "lognormal", 51, n=4, grad_layers=(0, 1, 10, 19, 20, 21),
+             kink_margin=2e-6)
     fit_case("imageradialfit_mnistlive_c16_7x7_k2_l3_lognormal", (16, 7, 7), 2, "lognormal", 46)
     fit_case("imageradialfit_fashionlive_c16_7x7_k2_l3_gammamm", (16, 7, 7), 2, "gammamm", 47)
 

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from golden_util import image_grad_case_names, load_image_case, load_image_fit, load_image_grads
+from golden_util import grads_close, image_grad_case_names, load_image_case, load_image_fit, load_image_grads
 
 DEV = "cuda:0"
 
@@ -186,6 +186,23 @@ def test_weight_planes_kernel_gives_the_bits_of_the_torch_split(cout, cin, ks):
     for got, transposed in ((pf, False), (pt, True)):
         ref = _ext.conv2d_weight_planes(w, transposed=transposed)
         assert got.shape == ref.shape and torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.gpu
+def test_weight_planes_batch_gives_the_bits_of_the_single_launches():
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(11)
+    ws = [torch.randn(co, ci, k, k, generator=g).to(DEV) for co, ci, k in [(32, 16, 3), (32, 32, 3), (16, 32, 3), (64, 32, 1), (5, 3, 3),
+                                                                          (48, 7, 3)]]
+    batch = _ext.WeightPlanesBatch(ws)
+    for _ in range(2):                                          # (the second run reuses the device table)
+        out = batch.run()
+        assert len(out) == len(ws)
+        for w, (pf, pt) in zip(ws, out):
+            rf, rt = _ext.conv2d_weight_planes_pair(w)
+            assert pf.shape == rf.shape and pt.shape == rt.shape
+            assert torch.equal(pf.view(torch.int16), rf.view(torch.int16)) and torch.equal(pt.view(torch.int16), rt.view(torch.int16))
+        ws[0].mul_(1.5)                                         # the table names addresses: new values, same table
 
 
 @pytest.mark.gpu
@@ -383,9 +400,7 @@ def test_image_flow_device_gradients_match_the_real_reference(name, monkeypatch)
     n_aff_runs = (n_aff - 1) // 2 + 1 if conj else n_aff
     assert len(wg) == n_convs + n_aff_runs, f"{len(wg)} weight-gradient launches for {n_convs} convolutions + {n_aff} affine layers"
     named = dict(flow.named_parameters())
-    for k, g in g_ref.items():
-        assert named[k].grad is not None, k
-        _close(named[k].grad, g, 5e-5, k)
+    grads_close(named, g_ref)
 
 
 @pytest.mark.gpu
@@ -541,13 +556,17 @@ def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bi
         assert torch.allclose(g2_on[k], g2_off[k], rtol=2e-5, atol=2e-6 * float(g2_off[k].abs().max())), k
         if "conditioner" in k:
             assert torch.equal(g2_on[k], g2_off[k]), k
-    # gradients already in place: autograd adds the new ones at once -> nothing may be deferred
+    # gradients already in place: autograd adds the new ones at once -> no PARAMETER's gradient may be deferred (what may still be
+    # queued: the C x C gradients of the composed affine runs, whose consumer -- image_training.RunsOut / AffinePrep -- issues the
+    # queue before it reads them: at most one per affine layer)
     g_on, n_on = grads("1")
     del launches[:]
+    flushed0 = _ext.n_jobs_flushed[0]
     with _ext.deferred_sums_scope():
         (-flow.log_prob(x).mean()).backward()
     torch.cuda.synchronize()
-    assert launches.count("usf_partial_sum_jobs_f32") == 0
+    n_aff = sum(1 for l in flow.layers if type(l).__name__ in ("BlockAffineTransform", "InverseTransform"))
+    assert launches.count("usf_partial_sum_jobs_f32") <= 2 and _ext.n_jobs_flushed[0] - flushed0 <= n_aff
     named = dict(flow.named_parameters())
     for k in g_off:
         assert torch.allclose(named[k].grad, 2 * g_off[k], rtol=1e-5, atol=1e-6 * float(g_off[k].abs().max())), k

@@ -219,6 +219,7 @@ SYMBOLS = {
     "usf_layernorm_channels_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_int32, C.c_float,
                                                  _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_gated_residual_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
+    "usf_conv2d_weight_planes_batch_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "usf_gated_tail_supported": (C.c_int, [C.c_int64]),
     "usf_gated_tail_workspace": (C.c_int64, [C.c_int64] * 3),
     "usf_gated_tail_f32": (C.c_int, [_fp, _fp, _fp] + [C.c_int64] * 3 + [_fp, _fp, C.c_int32, C.c_float, C.c_int32, C.c_float, _fp, _fp,
@@ -651,6 +652,57 @@ def conv2d_weight_planes_pair(weight: torch.Tensor):
     check(lib.usf_conv2d_weight_planes_f32(w.data_ptr(), buf.data_ptr(), cin, cout, k, 2, current_stream(weight.device)),
           "usf_conv2d_weight_planes_f32")
     return buf[:n_f].view(shapes[0]), buf[n_f:].view(shapes[1])
+
+
+class WPlanesJob(C.Structure):
+    """usf_wplanes_job"""
+    _fields_ = [("w", C.c_void_p), ("out_off", C.c_int64), ("cin", C.c_int32), ("cout", C.c_int32), ("ks", C.c_int32),
+                ("first_block", C.c_int32)]
+
+
+class WeightPlanesBatch:
+    """the plane pairs of MANY device fp32 Conv2d weights from ONE launch (usf_conv2d_weight_planes_batch_f32): the job table is
+    built once for a set of weights (it names their addresses) and stays on the device; every ``run()`` splits the weights'
+    CURRENT values into a fresh buffer and returns [(planes, planes_t)] -- the same bits as conv2d_weight_planes_pair"""
+
+    def __init__(self, weights):
+        self.key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+        self.device = weights[0].device
+        jobs, block_job, self.views, off, first = [], [], [], 0, 0
+        for i, w in enumerate(weights):
+            cout, cin, k, _ = w.shape
+            shapes = []
+            for rows, cols in ((cout, cin), (cin, cout)):
+                cp, coutp = (cols + 7) // 8 * 8, (rows + 15) // 16 * 16
+                shapes.append((3, coutp, (k * k * cp + 31) // 32 * 32))
+            n_f, n_t = math.prod(shapes[0]), math.prod(shapes[1])
+            nb = (max(n_f, n_t) // 3 + 255) // 256
+            jobs.append(WPlanesJob(w.data_ptr(), off, cin, cout, k, first))
+            block_job.extend([i] * nb)
+            self.views.append((off, n_f, shapes[0], n_t, shapes[1]))
+            off += n_f + n_t
+            first += nb
+        self.total, self.n_blocks = off, first
+        raw = bytearray(bytes((WPlanesJob * len(jobs))(*jobs)))
+        raw += b"\0" * ((-len(raw)) % 16)
+        self.off_blocks = len(raw)
+        raw += struct.pack(f"<{len(block_job)}i", *block_job)
+        self.host = torch.frombuffer(raw, dtype=torch.uint8)
+        self.table = None
+
+    def run(self):
+        """None: inside a stream capture without a table buffer (the caller splits weight by weight)"""
+        table = self.table
+        if table is None:
+            table = _device_table(self.host, self.device)
+            if table is None:
+                return None
+            if not torch.cuda.is_current_stream_capturing():
+                self.table = table
+        buf = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+        _launch("usf_conv2d_weight_planes_batch_f32", (table.data_ptr(), table.data_ptr() + self.off_blocks, self.n_blocks, buf.data_ptr(),
+                                                       current_stream(self.device)), (table, buf))
+        return [(buf[o: o + n_f].view(sf), buf[o + n_f: o + n_f + n_t].view(st)) for o, n_f, sf, n_t, st in self.views]
 
 
 def conv2d_weight_planes(weight: torch.Tensor, gate_channels: int = 0, transposed: bool = False) -> torch.Tensor:
@@ -1088,10 +1140,10 @@ def affine_prep(Lr, Ur, bias, vk=None, w0=None):
     n, Cc = int(Lr.shape[0]), int(Lr.shape[1])
     nvs = 0 if vk is None else int(vk.shape[1])
     dev = Lr.device
-    M = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
-    Minv = torch.empty_like(M)
-    b = torch.empty(n, Cc, dtype=torch.float32, device=dev)
-    c = torch.empty_like(b)
+    # (M | Minv and b | c share a buffer each: image_training.compose_runs gathers rows of either kind with one index_select)
+    MM = torch.empty(2 * n, Cc, Cc, dtype=torch.float32, device=dev)
+    bc = torch.empty(2 * n, Cc, dtype=torch.float32, device=dev)
+    M, Minv, b, c = MM[:n], MM[n:], bc[:n], bc[n:]
     ladj = torch.empty(n, dtype=torch.float32, device=dev)
     save = torch.empty(n, 7, Cc, Cc, dtype=torch.float32, device=dev)
     _direct("usf_affine_prep_f32", Lr.data_ptr(), Ur.data_ptr(), bias.data_ptr(), ptr(vk), ptr(w0), n, Cc, nvs, M.data_ptr(),

@@ -54,6 +54,7 @@ class Config:
         affine_prep=True,          # image flows: the affine blocks' parameter maps in one launch
         conv_res=True,             # conv kernel with MaskedCoupling's residual in its output stream
         pointwise=True,            # 1x1 convolutions on usf_pointwise_conv_f32
+        batch_wplanes=True,        # image training, launch-bound batches: all convolution weights' planes from one launch per pass
         gated_tail=True,           # image training, few pixels: GatedConv's 1x1 conv + gate + ReLU + layer norm as one launch each way
     )
 

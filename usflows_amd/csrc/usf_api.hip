@@ -123,6 +123,8 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
                int64_t workspace_floats, usf_psum_job* job, hipStream_t stream);
 int partial_sum_jobs(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
+int conv2d_weight_planes_batch(const usf_wplanes_job* jobs, const int32_t* block_job, int64_t n_blocks, void* planes_base,
+                               hipStream_t stream);
 int gated_tail_supported(int64_t C);
 int64_t gated_tail_workspace(int64_t B, int64_t C, int64_t P);
 int gated_tail_fwd(const float* h, const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* bias,
@@ -375,6 +377,10 @@ int usf_conv2d_weight_planes_f32(const float* w, void* planes, int64_t cin, int6
 }
 int usf_gated_residual_bwd_f32(const float* dy, const float* vg, float* dvg, int64_t B, int64_t CP, usf_stream_t stream) {
   return usf::gated_residual_bwd(dy, vg, dvg, B, CP, (hipStream_t)stream);
+}
+int usf_conv2d_weight_planes_batch_f32(const usf_wplanes_job* jobs, const int32_t* block_job, int64_t n_blocks, void* planes_base,
+                                       usf_stream_t stream) {
+  return usf::conv2d_weight_planes_batch(jobs, block_job, n_blocks, planes_base, (hipStream_t)stream);
 }
 int usf_gated_tail_supported(int64_t C) { return usf::gated_tail_supported(C); }
 int64_t usf_gated_tail_workspace(int64_t B, int64_t C, int64_t P) { return usf::gated_tail_workspace(B, C, P); }

@@ -855,6 +855,35 @@ int conv2d_weight_planes(const float* w, void* planes, int64_t cin, int64_t cout
   return check_launch("usf_conv2d_weight_planes_f32");
 }
 
+// MANY weights' plane pairs in ONE launch (usf_conv2d_weight_planes_batch_f32): block b serves job block_job[b] as block
+// b - first_block of conv_weight_planes_pair_kernel would (same bits); job j's pair lands at planes_base + out_off elements.
+// A training step of the live MNIST configuration at batch 32 splits 75 convolution weights: 75 launches of ~5 us on the
+// chain of dependent launches that bounds the step -> 1.
+__global__ __launch_bounds__(256) void conv_weight_planes_batch_kernel(const usf_wplanes_job* __restrict__ jobs,
+                                                                       const int32_t* __restrict__ block_job,
+                                                                       unsigned short* __restrict__ planes_base) {
+  const usf_wplanes_job j = jobs[block_job[blockIdx.x]];
+  const int i = ((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  const int ks2 = j.ks * j.ks;
+  const int cp_f = (j.cin + 7) / 8 * 8, kp_f = (ks2 * cp_f + 31) / 32 * 32, coutp_f = (j.cout + 15) / 16 * 16;
+  const int cp_t = (j.cout + 7) / 8 * 8, kp_t = (ks2 * cp_t + 31) / 32 * 32, coutp_t = (j.cin + 15) / 16 * 16;
+  unsigned short* planes = planes_base + j.out_off;
+  if (i < coutp_f * kp_f) conv_weight_planes_elem(j.w, planes, i, j.cout, j.cin, ks2, cp_f, kp_f, coutp_f, 0);
+  if (i < coutp_t * kp_t) conv_weight_planes_elem(j.w, planes + 3 * (int64_t)coutp_f * kp_f, i, j.cin, j.cout, ks2, cp_t, kp_t, coutp_t, 1);
+}
+
+int conv2d_weight_planes_batch(const usf_wplanes_job* jobs, const int32_t* block_job, int64_t n_blocks, void* planes_base,
+                               hipStream_t stream) {
+  if (n_blocks < 0 || n_blocks > 0x7fffffff || (n_blocks > 0 && (!jobs || !block_job || !planes_base))) {
+    set_error("usf_conv2d_weight_planes_batch_f32: bad arguments");
+    return -1;
+  }
+  if (n_blocks == 0) return 0;
+  hipLaunchKernelGGL(conv_weight_planes_batch_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, jobs, block_job,
+                     reinterpret_cast<unsigned short*>(planes_base));
+  return check_launch("usf_conv2d_weight_planes_batch_f32");
+}
+
 // d(vg) of y = x + val * sigmoid(gate): d val = dy * s, d gate = dy * val * s * (1 - s); dx = dy (no kernel)
 __global__ __launch_bounds__(256) void gated_residual_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ vg,
                                                                  float* __restrict__ dvg, int64_t total, int64_t CP) {

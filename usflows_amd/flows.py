@@ -322,13 +322,16 @@ class Flow(torch.nn.Module):
                 return lp
             lp = self._base_log_prob_layer_loop(y)
             return (self.base_distribution.log_prob(y) if lp is None else lp) - ladj_total
-        prep = contextlib.nullcontext()
+        prep = wpl = contextlib.nullcontext()
         if torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and torch.is_grad_enabled() \
                 and config.image_train:
             # an image-shaped flow in training: the affine blocks' parameter maps once per pass, batched over the blocks
-            from .image_training import batched_affine_prep
+            from .image_training import batched_affine_prep, batched_weight_planes
             prep = batched_affine_prep(self.layers, x.device)
-        with prep:
+            if x.shape[0] <= _ext.PSUM_DEFER_MAX_ROWS and config.batch_wplanes:
+                # (a launch-bound batch: the convolutions' weight planes from ONE launch per pass)
+                wpl = batched_weight_planes(self, self.layers, x.device)
+        with prep, wpl:
             ld = _LogDetSum()
             seq = list(reversed(self.layers))
             batched = not isinstance(prep, contextlib.nullcontext)
@@ -339,9 +342,9 @@ class Flow(torch.nn.Module):
                 if run is not None:
                     # a run of consecutive 1 x 1-convolution affine layers in training: ONE differentiable channel-affine
                     # pass on the composed map (the C x C compositions are torch ops on the batched prep's tensors)
-                    k1, A, cvec = run
+                    k1, A, cvec, At = run
                     from .image_training import ChannelAffine
-                    y = ChannelAffine.apply(x, A, cvec, False)
+                    y = ChannelAffine.apply(x, A, cvec, False, At, At is not None)
                     for l2 in seq[k:k1]:
                         if not ld.take_affine(l2):
                             ld.sub(l2.log_abs_det_jacobian(None, None))
@@ -360,29 +363,57 @@ class Flow(torch.nn.Module):
             return ld.add_to(self.base_distribution.log_prob(y) if lp is None else lp)
 
     def _train_affine_run(self, seq, k, x):
-        """(end index, A, c) when seq[k:] starts with >= 2 affine layers whose backward is a device channel-affine pass in
-        training and whose parameter maps come from the batched prep: y = A x + c for the whole run; else None"""
-        from .transforms import BlockAffineTransform, InverseTransform
-        from .image_training import current_prep
+        """(end index, A, c, A^T | None) when seq[k:] starts with >= 2 affine layers whose backward is a device channel-affine
+        pass in training and whose parameter maps come from the batched prep: y = A x + c for the whole run; else None.  The runs
+        of the whole sequence are composed together on first use in a pass (image_training.compose_runs)."""
+        from . import image_training as it
         if config.merge_affine is False or self.merge_image_affine is False:
             return None
-        A = cvec = None
-        j = k
+        runs = it._STATE.runs
+        if runs is None:
+            runs = it._STATE.runs = self._compose_affine_runs(seq, x)
+        return runs.get(k)
+
+    def _compose_affine_runs(self, seq, x) -> dict:
+        from .transforms import BlockAffineTransform, InverseTransform
+        from . import image_training as it
+        found, j = [], 0
         while j < len(seq):
-            layer = seq[j]
-            inv = isinstance(layer, InverseTransform)
-            blk = layer.transform if inv else layer
-            if not (isinstance(blk, BlockAffineTransform) and blk._channel_train(x)):
-                break
-            pr = current_prep(blk.block_transform)
-            if pr is None:
-                break
-            M, Minv, b = pr[0], pr[1], pr[2]
-            c = pr[4] if len(pr) > 4 else None                     # -Minv b, from the prep kernel
-            Ak, ck = (M, b) if inv else (Minv, c if c is not None else -(Minv @ b))   # InverseTransform(block).backward == block.forward
-            A, cvec = (Ak, ck) if A is None else (Ak @ A, Ak @ cvec + ck)
-            j += 1
-        return (j, A, cvec) if j - k >= 2 else None
+            k, rows, group = j, [], None
+            while j < len(seq):
+                layer = seq[j]
+                inv = isinstance(layer, InverseTransform)
+                blk = layer.transform if inv else layer
+                if not (isinstance(blk, BlockAffineTransform) and blk._channel_train(x)):
+                    break
+                pr = it.current_prep(blk.block_transform)
+                if pr is None:
+                    break
+                g = pr[5] if len(pr) > 5 else None                     # (group, row) in the prep kernel's stacks; None: torch prep
+                kind = g[0] if g is not None else "torch"
+                group = kind if not rows or kind == group else "torch"   # (a run over two stacks: composed on its own, below)
+                rows.append((g[1] if g is not None else None, inv, pr))
+                j += 1
+            if j - k >= 2:
+                found.append((k, j, group, rows))
+            j = max(j, k + 1)
+        out = {}
+        dev_runs = [f for f in found if f[2] != "torch"]
+        if dev_runs:
+            specs = [(g, [(row, inv) for row, inv, _ in rows]) for _, _, g, rows in dev_runs]
+            for (k, j, _, _), (A, cvec, At) in zip(dev_runs, it.compose_runs(specs)):
+                out[k] = (j, A, cvec, At)
+        for k, j, group, rows in found:
+            if group != "torch":
+                continue
+            A = cvec = None                                          # (the torch formulation of the prep: composed run by run)
+            for _, inv, pr in rows:
+                M, Minv, b = pr[0], pr[1], pr[2]
+                c = pr[4] if len(pr) > 4 else None                     # -Minv b, from the prep kernel
+                Ak, ck = (M, b) if inv else (Minv, c if c is not None else -(Minv @ b))   # InverseTransform(block).backward == block.forward
+                A, cvec = (Ak, ck) if A is None else (Ak @ A, Ak @ cvec + ck)
+            out[k] = (j, A, cvec, None)
+        return out
 
     # ---- runs of consecutive 1 x 1-convolution affine layers composed (image-shaped flows, inference) -------------------
     # With ``affine_conjugation=True`` a coupling is followed by ``block_i^-1`` and ``block_(i+1)`` (flows.py:452-470): two

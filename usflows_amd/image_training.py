@@ -53,12 +53,61 @@ def conv_shape_ok(conv, B: int, H: int, W: int) -> bool:
             and lib.usf_conv_wgrad_workspace(max(B, 1), cin, cout, H, W, k[0]) > 0)
 
 
-def _weight_planes(w, want_transposed: bool):
+def _weight_planes(w, want_transposed: bool, param=None):
     """(planes, planes_t | None) of a convolution weight: both from one launch when the data gradient will be asked for (the
-    weight does not change between a step's forward and backward pass)"""
+    weight does not change between a step's forward and backward pass); inside ``batched_weight_planes`` from the pass's ONE
+    launch for all weights"""
+    batch = _WSTATE.planes
+    if batch is not None and param is not None:
+        hit = batch.get(id(param))
+        if hit is not None:
+            return hit
     if want_transposed and w.is_cuda and w.dtype == torch.float32:
         return _ext.conv2d_weight_planes_pair(w)
     return _ext.conv2d_weight_planes(w), None
+
+
+class _WPlanesState(threading.local):
+    def __init__(self):
+        self.planes = None     # id(weight Parameter) -> (planes, planes_t) of the current pass
+
+
+_WSTATE = _WPlanesState()
+
+
+class batched_weight_planes:
+    """context manager around one training pass of an image-shaped flow at a launch-bound batch: the bf16x3 plane pairs of ALL
+    3 x 3 convolution weights under ``layers`` from one launch (``_ext.WeightPlanesBatch``; the job table is kept on ``owner``
+    while the weights keep their addresses) instead of one per convolution and pass"""
+
+    def __init__(self, owner, layers, device):
+        self.owner, self.layers, self.device, self.prev = owner, layers, device, None
+
+    def __enter__(self):
+        self.prev = _WSTATE.planes
+        ws = []
+        for l in self.layers:
+            for m in l.modules():
+                if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.weight.device == self.device \
+                        and m.weight.dtype == torch.float32 and m.weight.is_contiguous():
+                    ws.append(m.weight)
+        planes = None
+        if ws:
+            key = tuple((w.data_ptr(), tuple(w.shape)) for w in ws)
+            batch = self.owner.__dict__.get("_wplanes_batch")
+            if batch is None or batch.key != key:
+                batch = _ext.WeightPlanesBatch([w.detach() for w in ws])
+                if not torch.cuda.is_current_stream_capturing():
+                    self.owner.__dict__["_wplanes_batch"] = batch
+            out = batch.run()
+            if out is not None:
+                planes = {id(w): pr for w, pr in zip(ws, out)}
+        _WSTATE.planes = planes
+        return self
+
+    def __exit__(self, *exc):
+        _WSTATE.planes = self.prev
+        return False
 
 
 # (Round 4 also tried the weight gradients of a small-batch backward pass on a second stream / a parallel hipGraph branch:
@@ -83,7 +132,7 @@ class ConvSame(torch.autograd.Function):
         w = weight.detach()
         ks = w.shape[2]
         ia, oa = _act(in_act), _act(out_act)
-        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0])
+        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0], weight)
         y = _ext.conv2d_same(x, planes, w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
                              in_mul=in_mul, in_act=ia[0], in_slope=ia[1], out_act=oa[0], out_slope=oa[1])
         ctx.save_for_backward(x, w, in_mul, y if out_act is not None else None)
@@ -134,7 +183,7 @@ class ConvSameFork(torch.autograd.Function):
         w = weight.detach()
         ks = w.shape[2]
         ia = _act(in_act)
-        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0])
+        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0], weight)
         y = _ext.conv2d_same(x, planes, w.shape[0], ks, bias=None if bias is None else bias.detach().contiguous(),
                              in_mul=in_mul, in_act=ia[0], in_slope=ia[1])
         ctx.save_for_backward(x, w, in_mul)
@@ -348,7 +397,9 @@ class ChannelAffine(torch.autograd.Function):
     pre_sub True: y = W (x - b) (backward direction, W = M^-1); W [C, C], b [C] are tiny differentiable torch tensors"""
 
     @staticmethod
-    def forward(ctx, x, W, b, pre_sub):
+    def forward(ctx, x, W, b, pre_sub, Wt=None, defer=False):
+        """Wt: W^T, contiguous (the data gradient's map; made here when not given).  defer: the consumer of dW / db is a node
+        that issues queued sums before it reads them (RunsOut / AffinePrep) -- the weight gradient's last sum may be queued"""
         x = x.contiguous()
         Wd, bd = W.detach().contiguous(), b.detach().contiguous()
         y = torch.empty_like(x)
@@ -356,25 +407,26 @@ class ChannelAffine(torch.autograd.Function):
             _ext.channel_affine(x, y, Wd, pre_sub=bd)
         else:
             _ext.channel_affine(x, y, Wd, bias=bd)
-        ctx.save_for_backward(x, Wd, bd)
+        ctx.save_for_backward(x, Wd, bd, Wt)
         ctx.pre_sub = pre_sub
+        ctx.defer = bool(defer) and not pre_sub
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, Wd, bd = ctx.saved_tensors
+        x, Wd, bd, Wt = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dW = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            r = _ext.conv_wgrad(x, dy, 1, pre_sub=bd if ctx.pre_sub else None, want_bias=True)
+            r = _ext.conv_wgrad(x, dy, 1, pre_sub=bd if ctx.pre_sub else None, want_bias=True, defer=ctx.defer, owners=(id(ctx),))
             if r is None:
                 raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this channel count")
             dW = r[0].reshape(Wd.shape)
             db = -(Wd.t() @ r[1]) if ctx.pre_sub else r[1]
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(dy)
-            _ext.channel_affine(dy, dx, Wd.t().contiguous())
-        return dx, dW, db, None
+            _ext.channel_affine(dy, dx, Wt if Wt is not None else Wd.t().contiguous())
+        return dx, dW, db, None, None, None
 
 
 def channel_affine_train_ok(x, C) -> bool:
@@ -426,6 +478,8 @@ class _PrepState(threading.local):
     def __init__(self):
         self.prep = None       # id(block transform) -> (M, Minv, b, ladj[, c, (group, row)])
         self.stacks = {}       # group -> stacked log|det| [n] of the current pass (device prep only)
+        self.maps = {}         # group -> ([M | M^-1] [2n, C, C], [b | c] [2n, C], n) of the current pass (device prep only)
+        self.runs = None       # flows.Flow._train_affine_run: the composed runs of the current pass
 
 
 _STATE = _PrepState()
@@ -481,14 +535,17 @@ class AffinePrep(torch.autograd.Function):
         ctx.n, ctx.C = n, Lr.shape[1]
         # per block: M, M^-1, b, c = -M^-1 b, log|det|; and once more the stacked log|det| (the flow's total log-det is one
         # weighted sum over it: Flow._layer_loop_log_prob)
+        # ... and the stacked [M | M^-1] and [b | c] (compose_runs gathers the maps of a run's layers from them)
         return tuple(M.unbind(0)) + tuple(Minv.unbind(0)) + tuple(b.unbind(0)) + tuple(c.unbind(0)) + tuple(ladj.unbind(0)) \
-            + (ladj.view(n),)
+            + (ladj.view(n), M._base.view(2 * n, ctx.C, ctx.C), b._base.view(2 * n, ctx.C))
 
     @staticmethod
     def backward(ctx, *grads):
         save, bias, vk, w0, Minv, b = ctx.saved_tensors
         n, C = ctx.n, ctx.C
         dev = save.device
+        # (gradients of single affine layers may still be waiting for their last sum: image_training.ChannelAffine)
+        _ext.flush_partial_sums(torch._C._current_graph_task_id(), final=False)
 
         def gather(gs, shape):
             if all(g is None for g in gs):
@@ -501,6 +558,11 @@ class AffinePrep(torch.autograd.Function):
         db = gather(grads[2 * n:3 * n], (C,))
         dc = gather(grads[3 * n:4 * n], (C,))
         dl_each, dl_all = grads[4 * n:5 * n], grads[5 * n]
+        gMM, gbc = grads[5 * n + 1], grads[5 * n + 2]
+        if gMM is not None:
+            dM, dMinv = dM + gMM[:n], dMinv + gMM[n:]
+        if gbc is not None:
+            db, dc = db + gbc[:n], dc + gbc[n:]
         if dl_all is not None and all(g is None for g in dl_each):
             dl = dl_all.contiguous()
         else:
@@ -575,6 +637,7 @@ def _prep_group_device(bts, parts_list, sig, device):
     out = AffinePrep.apply(Lr, Ur, bias, vk, w0)
     key = (sig, tuple(id(bt) for bt in bts))
     _STATE.stacks[key] = out[5 * n]
+    _STATE.maps[key] = (out[5 * n + 1], out[5 * n + 2], n)
     # (M, M^-1, b, log|det|, c = -M^-1 b, (group, row) of the block in the stacked log|det|)
     return {id(bt): (out[i], out[n + i], out[2 * n + i], out[4 * n + i], out[3 * n + i], (key, i)) for i, bt in enumerate(bts)}
 
@@ -640,8 +703,8 @@ class batched_affine_prep:
                 g[0][id(bt)] = bt
                 g[1].append(parts)
         prep = {}
-        self.prev_stacks = _STATE.stacks
-        _STATE.stacks = {}
+        self.prev_stacks = (_STATE.stacks, _STATE.maps, _STATE.runs)
+        _STATE.stacks, _STATE.maps, _STATE.runs = {}, {}, None
         for sig, (bts, parts_list) in groups.items():
             prep.update(_prep_group(list(bts.values()), parts_list, sig, self.device))
         _STATE.prep = prep
@@ -649,5 +712,76 @@ class batched_affine_prep:
 
     def __exit__(self, *exc):
         _STATE.prep = self.prev
-        _STATE.stacks = self.prev_stacks
+        _STATE.stacks, _STATE.maps, _STATE.runs = self.prev_stacks
         return False
+
+
+# ---- runs of consecutive affine layers, composed for ALL runs of a pass at once -------------------------------------------------
+# With affine_conjugation a coupling is followed by block_i^-1 and block_(i+1) (flows.py:452-470): y = A2 (A1 x + c1) + c2 is one
+# channel-affine pass on A = A2 A1, c = A2 c1 + c2.  Composing run by run is three tiny torch launches per run and six in the
+# backward pass (14 runs in the live MNIST configuration: ~125 of the ~1 000 launches of its training step at batch 32); here
+# the runs of equal length and direction pattern are composed together: one index_select per position from the prep kernel's
+# stacked maps and one batched product per position -- a dozen launches per pass, whatever the number of runs.
+_IDX = {}
+
+
+def _idx_tensor(values, device) -> torch.Tensor:
+    key = (tuple(values), str(device))
+    t = _IDX.get(key)
+    if t is None:
+        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        if not (torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _IDX[key] = t
+    return t
+
+
+class RunsOut(torch.autograd.Function):
+    """the composed maps handed out per run; the backward first issues the sums the runs' weight gradients queued
+    (ChannelAffine with defer=True), then gathers the gradients with one ``stack`` per kind"""
+
+    @staticmethod
+    def forward(ctx, A, cv):
+        ctx.R, ctx.C = A.shape[0], A.shape[1]
+        return tuple(A.unbind(0)) + tuple(cv.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        R, C = ctx.R, ctx.C
+        _ext.flush_partial_sums(torch._C._current_graph_task_id(), final=False)
+        dev = next(g.device for g in grads if g is not None)
+
+        def gather(gs, shape):
+            if all(g is None for g in gs):
+                return None
+            z = _zeros(shape, dev)
+            return torch.stack([z if g is None else g for g in gs])
+
+        return gather(grads[:R], (C, C)), gather(grads[R:], (C,))
+
+
+def compose_runs(specs):
+    """specs: [(group, [(row, inv), ...])] -- runs of >= 2 affine layers whose maps are rows of the group's prep stacks (inv: the
+    layer is an InverseTransform, i.e. its backward is the block's forward map M, b; else M^-1, c = -M^-1 b).  Returns
+    [(A, c, A^T)] per run: y = A x + c for the run applied in order, A^T a contiguous copy for the data gradient."""
+    out = [None] * len(specs)
+    classes = {}
+    for r, (group, rows) in enumerate(specs):
+        classes.setdefault((group, len(rows), tuple(inv for _, inv in rows)), []).append(r)
+    for (group, L, pattern), members in classes.items():
+        MM, bc, n = _STATE.maps[group]
+        dev = MM.device
+        A = cv = None
+        for j in range(L):
+            idx = _idx_tensor([specs[r][1][j][0] + (0 if pattern[j] else n) for r in members], dev)
+            Aj, cj = MM.index_select(0, idx), bc.index_select(0, idx)
+            if A is None:
+                A, cv = Aj, cj
+            else:
+                cv = torch.baddbmm(cj.unsqueeze(2), Aj, cv.unsqueeze(2)).squeeze(2)
+                A = torch.bmm(Aj, A)
+        At = A.detach().transpose(1, 2).contiguous()
+        outs = RunsOut.apply(A, cv)
+        R = len(members)
+        for i, r in enumerate(members):
+            out[r] = (outs[i], outs[R + i], At[i])
+    return out

@@ -781,7 +781,7 @@ class BlockAffineTransform(BaseTransform):
             from .image_training import ChannelAffine, current_prep
             prep = current_prep(self.block_transform)
             if prep is not None:
-                return ChannelAffine.apply(x, prep[0], prep[2], False)
+                return ChannelAffine.apply(x, prep[0], prep[2], False, None, len(prep) > 5)      # (device prep: its backward issues queued sums)
             return ChannelAffine.apply(x, self.block_transform.matrix().to(x.device), self.block_transform.bias().to(x.device), False)
         w = self.block_transform.matrix().view(self.block_size, self.block_size, *([1] * self.input_rank)).to(x.device)
         return self.global_transform(x, w, self.block_transform.bias().to(x.device))
