@@ -429,12 +429,13 @@ int usf_conv2d_weight_planes_batch_f32(const usf_wplanes_job* jobs, const int32_
  *     y = LayerNormChannels(post_act(r); gamma, beta, eps)    (ln_gamma == NULL: y = r, post_act must be USF_ACT_NONE)
  * on contiguous [B, C, P] fp32 tensors, C in {8, 16, 24, 32} (usf_gated_tail_supported).  It replaces the chain
  * usf_pointwise_conv_f32 -> usf_gated_residual_f32 -> usf_layernorm_channels_f32 and, backward, usf_layernorm_channels_bwd_f32
- * -> usf_gated_residual_bwd_f32 -> usf_pointwise_conv_f32 on a transposed copy of W: the backward recomputes val / gate / r
- * from (h, x) and writes dx [B, C, P] (the skip branch), dh [B, C, P], dvg [B, 2 C, P] = d[val, gate] (the weight gradient
- * of W is usf_conv_wgrad_f32(h, dvg, ks = 1, in_act)) and dgamma_dbeta [2 C].  workspace >= usf_gated_tail_workspace floats.
- * job == NULL: dgamma_dbeta is complete when the call's launches have run; else job[0 .. 1] (HOST memory) describe its last
+ * -> usf_gated_residual_bwd_f32 -> usf_pointwise_conv_f32 on a transposed copy of W -> usf_conv_wgrad_f32 (kernel 1): the
+ * backward recomputes val / gate / r from (h, x) and writes dx [B, C, P] (the skip branch), dh [B, C, P] and
+ * dparams = [dW (2 C C) | dbias (2 C) | dgamma (C) | dbeta (C)] (the last two only with a layer norm); dvg [B, 2 C, P] =
+ * d[val, gate] is written when the pointer is not NULL.  workspace >= usf_gated_tail_workspace floats.
+ * job == NULL: dparams is complete when the call's launches have run; else job[0 .. 1] (HOST memory) describe its last
  * sum for usf_partial_sum_jobs_f32 as usf_conv_wgrad_deferred_f32 does (nparts == 0: nothing to do).
- * Eight lanes share a pixel: made for few pixels (a 32-row training batch); HBM traffic 4 C (3 + 4) bytes per pixel backward. */
+ * Eight lanes share a pixel: made for few pixels (a 32-row training batch); HBM traffic 4 C (3 + 2) bytes per pixel backward. */
 int usf_gated_tail_supported(int64_t C);
 int64_t usf_gated_tail_workspace(int64_t B, int64_t C, int64_t P);
 int usf_gated_tail_f32(const float* h, const float* x, float* y, int64_t B, int64_t C, int64_t P, const float* W, const float* bias,
@@ -442,7 +443,7 @@ int usf_gated_tail_f32(const float* h, const float* x, float* y, int64_t B, int6
                        const float* ln_beta, float ln_eps, usf_stream_t stream);
 int usf_gated_tail_bwd_f32(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C,
                            int64_t P, const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act,
-                           float post_slope, const float* ln_gamma, const float* ln_beta, float ln_eps, float* dgamma_dbeta,
+                           float post_slope, const float* ln_gamma, const float* ln_beta, float ln_eps, float* dparams,
                            float* workspace, int64_t workspace_floats, struct usf_psum_job* job, usf_stream_t stream);
 
 /* A data-gradient convolution with the factors of the layer's INPUT transforms in its output stream:

@@ -273,7 +273,8 @@ def test_gated_tail_forward_and_backward_vs_fp64(C, P, B, ln, in_act, post_act, 
     pa = post_act if post_act is not None else (_ext.ACT_NONE, 0.0)
     lnp = (gamma, beta, eps) if ln else None
     y = _ext.gated_tail(h, x, W, bvec, ia[0], ia[1], pa[0], pa[1], lnp)
-    dx, dh, dvg, dg, dbt = _ext.gated_tail_bwd(h, x, dy, W, bvec, ia[0], ia[1], pa[0], pa[1], lnp)
+    dx, dh, dW, db, dg, dbt, dvg = _ext.gated_tail_bwd(h, x, dy, W, bvec, ia[0], ia[1], pa[0], pa[1], lnp, want_dvg=True)
+    assert _ext.gated_tail_bwd(h, x, dy, W, bvec, ia[0], ia[1], pa[0], pa[1], lnp)[6] is None
     h64, x64 = h.double().requires_grad_(True), x.double().requires_grad_(True)
     W64 = W.double().requires_grad_(True)
     g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
@@ -299,12 +300,8 @@ def test_gated_tail_forward_and_backward_vs_fp64(C, P, B, ln, in_act, post_act, 
         _close(dbt, b64.grad, 1e-5, "dbeta")
     else:
         assert dg is None and dbt is None
-    # the weight gradient of W from d[val, gate]: the kernel-1 form of usf_conv_wgrad_f32 on (h, dvg) with the input nonlinearity
-    if C % 16 == 0:
-        Hs = {49: (7, 7), 20: (5, 4), 64: (8, 8)}[P]
-        r2 = _ext.conv_wgrad(h.view(B, C, *Hs), dvg.view(B, 2 * C, *Hs), 1, in_act=ia[0], in_slope=ia[1], want_bias=True)
-        if r2 is not None:
-            _close(r2[0].view(2 * C, C), W64.grad, 1e-5, "dW")
+    _close(dW, W64.grad, 1e-5, "dW")
+    _close(db, vg.grad.sum(dim=(0, 2)), 1e-5, "dbias")
 
 
 # ---- the autograd functions against fp64 torch autograd of the same module ------------------------------------------------
@@ -344,10 +341,12 @@ def test_convnet2d_trains_on_device_like_fp64_autograd(cfg, monkeypatch):
     wg = []
     real = _ext.conv_wgrad
     monkeypatch.setattr(_ext, "conv_wgrad", lambda *a_, **k_: (wg.append(1), real(*a_, **k_))[1])
+    real_gt = _ext.gated_tail_bwd       # (a GatedConv's 1 x 1 convolution: its weight gradient comes from the fused tail's backward)
+    monkeypatch.setattr(_ext, "gated_tail_bwd", lambda *a_, **k_: (wg.append(1), real_gt(*a_, **k_))[1])
     assert net.train_on_device(x.to(DEV).requires_grad_(True))
     y, dx, gp = _grads_of(lambda t: net(t, in_mul=mask.to(DEV)), list(net.parameters()), x.to(DEV), dy.to(DEV))
     n_convs = sum(1 for m in net.modules() if isinstance(m, torch.nn.Conv2d))
-    assert len(wg) == n_convs, "a convolution's weight gradient did not come from usf_conv_wgrad_f32"
+    assert len(wg) == n_convs, "a convolution's weight gradient did not come from usf_conv_wgrad_f32 / usf_gated_tail_bwd_f32"
     y64, dx64, gp64 = _grads_of(lambda t: ref(t * mask.double().view(1, cfg["c_in"], H, W)), list(ref.parameters()), x.double(), dy.double())
     _close(y, y64, 2e-5, "y")
     _close(dx, dx64, 2e-5, "dx")
@@ -388,6 +387,8 @@ def test_image_flow_device_gradients_match_the_real_reference(name, monkeypatch)
     wg = []
     real = _ext.conv_wgrad
     monkeypatch.setattr(_ext, "conv_wgrad", lambda *a_, **k_: (wg.append(1), real(*a_, **k_))[1])
+    real_gt = _ext.gated_tail_bwd       # (a GatedConv's 1 x 1 convolution: its weight gradient comes from the fused tail's backward)
+    monkeypatch.setattr(_ext, "gated_tail_bwd", lambda *a_, **k_: (wg.append(1), real_gt(*a_, **k_))[1])
     lp = flow.log_prob(a["x"].to(DEV))
     _close(lp.detach(), a["log_prob64"], 1e-5, "log_prob under autograd")
     loss = -lp.mean()

@@ -1105,31 +1105,31 @@ def gated_tail(h, x, W, bias, in_act=ACT_NONE, in_slope=0.0, post_act=ACT_NONE, 
 
 
 def gated_tail_bwd(h, x, dy, W, bias, in_act=ACT_NONE, in_slope=0.0, post_act=ACT_NONE, post_slope=0.0, ln=None, defer=False,
-                   owners=()):
-    """usf_gated_tail_bwd_f32 -> (dx, dh, dvg [B, 2C, *spatial], dgamma [C] | None, dbeta [C] | None); defer / owners as in
-    conv_wgrad (the layer norm's parameter sums may be queued until the backward pass ends)"""
+                   owners=(), want_dvg=False):
+    """usf_gated_tail_bwd_f32 -> (dx, dh, dW [2C, C], dbias [2C], dgamma [C] | None, dbeta [C] | None, dvg | None); the parameter
+    gradients are views of one buffer; defer / owners as in conv_wgrad (their last sum may be queued until the backward pass
+    ends); want_dvg: also d[val, gate] [B, 2C, *spatial] (tests)"""
     B, Cc = x.shape[0], x.shape[1]
     P = math.prod(x.shape[2:])
     lib = load()
     dx, dh = torch.empty_like(x), torch.empty_like(x)
-    dvg = torch.empty((B, 2 * Cc) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    dvg = torch.empty((B, 2 * Cc) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device) if want_dvg else None
     g, bt, eps = ln if ln is not None else (None, None, 0.0)
-    dgb = ws = None
-    ws_n = 0
-    if ln is not None:
-        ws_n = lib.usf_gated_tail_workspace(B, Cc, P)
-        ws = torch.empty(max(1, ws_n), dtype=torch.float32, device=x.device)
-        dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
-    job2 = (PsumJob * 2)() if (ln is not None and defer and _psum_may_defer(x, owners)) else None
-    args = (h.data_ptr(), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dh.data_ptr(), dvg.data_ptr(), B, Cc, P, W.data_ptr(), ptr(bias),
-            int(in_act), float(in_slope), int(post_act), float(post_slope), ptr(g), ptr(bt), float(eps), ptr(dgb), ptr(ws), ws_n,
-            C.cast(job2, C.c_void_p) if job2 is not None else None, current_stream(x.device))
+    ws_n = lib.usf_gated_tail_workspace(B, Cc, P)
+    ws = torch.empty(max(1, ws_n), dtype=torch.float32, device=x.device)
+    nW = 2 * Cc * Cc
+    dpar = torch.empty(nW + 2 * Cc + (2 * Cc if ln is not None else 0), dtype=torch.float32, device=x.device)
+    job2 = (PsumJob * 2)() if (defer and _psum_may_defer(x, owners)) else None
+    args = (h.data_ptr(), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dh.data_ptr(), ptr(dvg), B, Cc, P, W.data_ptr(), ptr(bias),
+            int(in_act), float(in_slope), int(post_act), float(post_slope), ptr(g), ptr(bt), float(eps), dpar.data_ptr(), ws.data_ptr(),
+            ws_n, C.cast(job2, C.c_void_p) if job2 is not None else None, current_stream(x.device))
     check(_timed_call(lib.usf_gated_tail_bwd_f32, args, "usf_gated_tail_bwd_f32"), "usf_gated_tail_bwd_f32")
     if job2 is not None:
         _psum_queue(job2, (ws,))
-    if dgb is None:
-        return dx, dh, dvg, None, None
-    return dx, dh, dvg, dgb[:Cc], dgb[Cc:]
+    dW, db = dpar[:nW].view(2 * Cc, Cc), dpar[nW: nW + 2 * Cc]
+    if ln is None:
+        return dx, dh, dW, db, None, None, dvg
+    return dx, dh, dW, db, dpar[nW + 2 * Cc: nW + 3 * Cc], dpar[nW + 3 * Cc:], dvg
 
 
 AFFINE_PREP_MAX_C = 64

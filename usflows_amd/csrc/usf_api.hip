@@ -132,7 +132,7 @@ int gated_tail_fwd(const float* h, const float* x, float* y, int64_t B, int64_t 
                    float eps, hipStream_t stream);
 int gated_tail_bwd(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C, int64_t P,
                    const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act, float post_slope,
-                   const float* gamma, const float* beta, float eps, float* dgamma_dbeta, float* workspace, int64_t workspace_floats,
+                   const float* gamma, const float* beta, float eps, float* dparams, float* workspace, int64_t workspace_floats,
                    usf_psum_job* job, hipStream_t stream);
 int64_t layernorm_channels_bwd_workspace(int64_t B, int64_t C, int64_t P);
 int layernorm_channels_bwd(const float* x, const float* dy, float* dx, int64_t B, int64_t C, int64_t P, const float* gamma, float eps,
@@ -392,10 +392,10 @@ int usf_gated_tail_f32(const float* h, const float* x, float* y, int64_t B, int6
 }
 int usf_gated_tail_bwd_f32(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C,
                            int64_t P, const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act,
-                           float post_slope, const float* ln_gamma, const float* ln_beta, float ln_eps, float* dgamma_dbeta,
+                           float post_slope, const float* ln_gamma, const float* ln_beta, float ln_eps, float* dparams,
                            float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_stream_t stream) {
   return usf::gated_tail_bwd(h, x, dy, dx, dh, dvg, B, C, P, W, bias, in_act, in_slope, post_act, post_slope, ln_gamma, ln_beta,
-                             ln_eps, dgamma_dbeta, workspace, workspace_floats, job, (hipStream_t)stream);
+                             ln_eps, dparams, workspace, workspace_floats, job, (hipStream_t)stream);
 }
 int64_t usf_conv2d_weight_elems(int64_t cin, int64_t cout, int64_t ks) { return usf::conv2d_weight_elems(cin, cout, ks); }
 int usf_conv2d_same_fits(int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks) { return usf::conv2d_same_fits(cin, cout, H, W, ks); }

@@ -11,8 +11,10 @@
 // of round 4 spent 3 launches on this tail in the forward pass (pointwise convolution, gated residual, layer norm) and 5 in the
 // backward pass (layer norm, its parameter sums, gated residual, a transposed copy of W, pointwise data gradient).  The backward
 // kernel here recomputes the forward from (h, x) -- val / gate / r are never stored -- and writes dx (skip branch), dh
-// (through W^T and in_act'), d[val, gate] (for the weight gradient of W: usf_conv_wgrad_f32, kernel 1) and per-block partial
-// sums of dgamma / dbeta (last sum: usf_partial_sum_jobs_f32 or at once).
+// (through W^T and in_act') and per-block partial sums of ALL parameter gradients: dW = sum over pixels of d[val, gate] (x) a
+// (the block's 32 pixels meet in LDS: thread t owns the entries e = t, t + 256, ... of dW and adds the pixels in ascending
+// order), dbias, dgamma, dbeta -- one slot of 2 C C + 4 C floats per block (last sum: usf_partial_sum_jobs_f32 or at once).
+// d[val, gate] itself is written only on request (tests).
 //
 // Few pixels, so EIGHT lanes share a pixel (lane = 8 * channel group + pixel of the wave's 8): channel group cg owns channels
 // cg, cg + 8, ...; each lane holds all C values of a (the same loads in the 8 lanes of a pixel hit L1), walks its 2 C / 8 rows
@@ -32,6 +34,7 @@ struct GtArgs {
   float* y; float* dx; float* dh; float* dvg; float* part;
   int64_t BP, P;
   float eps, in_slope, post_slope;      // slope 1 = no nonlinearity
+  int slot_floats;                      // backward: 2 C C + 2 C (+ 2 C with a layer norm) floats per block in part
 };
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -41,6 +44,12 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
   constexpr int NC = C / 8, WS = C + 4;
   __shared__ __attribute__((aligned(16))) float wl[2 * C * WS];
   __shared__ float red[BWD && LN ? 4 * 2 * C : 1];
+  __shared__ float sa[BWD ? 32 * C : 1];                       // a of the block's 32 pixels
+  __shared__ float sd[BWD ? 32 * 2 * C : 1];                   // d[val, gate] of the block's 32 pixels
+  constexpr int NE = (2 * C * C + 255) / 256;                  // entries of dW per thread
+  float dwacc[BWD ? NE : 1], dbacc = 0.f;
+#pragma unroll
+  for (int i = 0; i < (BWD ? NE : 1); ++i) dwacc[i] = 0.f;
   for (int i = threadIdx.x; i < 2 * C * C; i += 256) {
     const int r = i / C, c = i - r * C;
     wl[r * WS + c] = a.W[i];
@@ -59,9 +68,10 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
     dgam[k] = dbet[k] = 0.f;
   }
   const float inv_c = 1.f / (float)C;
-  const int64_t nwv = (int64_t)gridDim.x * 4;
-  for (int64_t wv = (int64_t)blockIdx.x * 4 + wave; wv * 8 < a.BP; wv += nwv) {      // wave-uniform trip count
-    const int64_t i0 = wv * 8 + pi;
+  // block-uniform trip count (the backward's waves meet at barriers): a wave whose 8 pixels lie past the end works on a
+  // clamped pixel with zero gradients and stores nothing
+  for (int64_t blk = blockIdx.x; blk * 32 < a.BP; blk += gridDim.x) {
+    const int64_t i0 = (blk * 4 + wave) * 8 + pi;
     const bool on = i0 < a.BP;
     const int64_t i = on ? i0 : a.BP - 1;
     const int64_t b = i / a.P, p = i - b * a.P;
@@ -170,11 +180,43 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
         if (on) {
           const int64_t off = (int64_t)(cg + 8 * k) * a.P;
           dxb[off] = dr[k];
-          dvb[off] = dv[k];
-          dvb[off + (int64_t)C * a.P] = dgt[k];
+          if (a.dvg) {
+            dvb[off] = dv[k];
+            dvb[off + (int64_t)C * a.P] = dgt[k];
+          }
+        }
+        const int px = wave * 8 + pi;
+        sa[px * C + cg + 8 * k] = leaky(ho[k], a.in_slope);
+        sd[px * 2 * C + cg + 8 * k] = dv[k];                   // (zero for a pixel past the end: d == 0)
+        sd[px * 2 * C + C + cg + 8 * k] = dgt[k];
+      }
+    }
+    __syncthreads();
+    // dW[co][ci] += d[val, gate][px][co] * a[px][ci], pixels in ascending order
+    if constexpr (256 % C == 0) {
+      const int ci = threadIdx.x % C, co0 = threadIdx.x / C;   // entry e = t + 256 i: ci fixed, co = co0 + (256 / C) i
+#pragma unroll 4
+      for (int px = 0; px < 32; ++px) {
+        const float av_ = sa[px * C + ci];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          const int co = co0 + (256 / C) * i;
+          if (co < 2 * C) dwacc[i] = fmaf(sd[px * 2 * C + co], av_, dwacc[i]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < 2 * C * C) {
+          const int co = e / C, ci = e - co * C;
+          for (int px = 0; px < 32; ++px) dwacc[i] = fmaf(sd[px * 2 * C + co], sa[px * C + ci], dwacc[i]);
         }
       }
     }
+    if (threadIdx.x < 2 * C)
+      for (int px = 0; px < 32; ++px) dbacc += sd[px * 2 * C + threadIdx.x];
+    __syncthreads();                                            // (the next round's pixels overwrite sa / sd)
     // da[ci] = sum over the 2 C rows of W[row][ci] * d[val, gate][row]: this lane's 2 NC rows, then a reduce-scatter over
     // the 8 channel groups (fixed order: deterministic); av is reused for the partial sums
 #pragma unroll
@@ -218,8 +260,17 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
     for (int k = 0; k < NC; ++k)
       if (on) dhb[(int64_t)(cg + 8 * k) * a.P] = ho[k] > 0.f ? da[k] : da[k] * a.in_slope;
   }
+  if (BWD) {
+    float* slot = a.part + (int64_t)blockIdx.x * a.slot_floats;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < 2 * C * C) slot[e] = dwacc[i];
+    }
+    if (threadIdx.x < 2 * C) slot[2 * C * C + threadIdx.x] = dbacc;
+  }
   if (BWD && LN) {
-    // dgamma / dbeta: over the wave's 8 pixels, then over the block's 4 waves -> one slot per block
+    // dgamma / dbeta: over the wave's 8 pixels, then over the block's 4 waves
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       float g = dgam[k], bt = dbet[k];
@@ -236,7 +287,7 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
     __syncthreads();
     if (threadIdx.x < 2 * C) {
       const int j = threadIdx.x;
-      a.part[(int64_t)blockIdx.x * 2 * C + j] = ((red[j] + red[2 * C + j]) + red[4 * C + j]) + red[6 * C + j];
+      a.part[(int64_t)blockIdx.x * a.slot_floats + 2 * C * C + 2 * C + j] = ((red[j] + red[2 * C + j]) + red[4 * C + j]) + red[6 * C + j];
     }
   }
 }
@@ -251,9 +302,13 @@ static int gated_tail_blocks(int64_t BP) {
 
 int gated_tail_supported(int64_t C) { return gated_tail_c_ok(C) ? 1 : 0; }
 
+// floats of the parameter gradients [dW (2 C C) | dbias (2 C) | dgamma (C) | dbeta (C)] (the last two with a layer norm)
+static int64_t gated_tail_nparams(int64_t C, bool ln) { return 2 * C * C + 2 * C + (ln ? 2 * C : 0); }
+
 int64_t gated_tail_workspace(int64_t B, int64_t C, int64_t P) {
   if (B <= 0 || P <= 0 || !gated_tail_c_ok(C)) return 0;
-  return (int64_t)gated_tail_blocks(B * P) * 2 * C + sum_slots_scratch(2 * C);
+  const int64_t n = gated_tail_nparams(C, true);
+  return (int64_t)gated_tail_blocks(B * P) * n + sum_slots_scratch(n);
 }
 
 static int gated_tail_check(const char* what, int64_t B, int64_t C, int64_t P, const float* h, const float* x, const float* W,
@@ -299,14 +354,14 @@ int gated_tail_fwd(const float* h, const float* x, float* y, int64_t B, int64_t 
 
 int gated_tail_bwd(const float* h, const float* x, const float* dy, float* dx, float* dh, float* dvg, int64_t B, int64_t C, int64_t P,
                    const float* W, const float* bias, int32_t in_act, float in_slope, int32_t post_act, float post_slope,
-                   const float* gamma, const float* beta, float eps, float* dgamma_dbeta, float* workspace, int64_t workspace_floats,
+                   const float* gamma, const float* beta, float eps, float* dparams, float* workspace, int64_t workspace_floats,
                    usf_psum_job* job, hipStream_t stream) {
   const int rc = gated_tail_check("usf_gated_tail_bwd_f32", B, C, P, h, x, W, in_act, post_act, gamma, beta);
   if (job) job[0].nparts = job[1].nparts = 0;
   if (rc) return rc < 0 ? rc : 0;
-  if (!dy || !dx || !dh || !dvg) { set_error("usf_gated_tail_bwd_f32: null pointer"); return -1; }
-  if (gamma && (!dgamma_dbeta || !workspace || workspace_floats < gated_tail_workspace(B, C, P))) {
-    set_error("usf_gated_tail_bwd_f32: dgamma_dbeta [2 C] and a workspace of usf_gated_tail_workspace floats are needed");
+  if (!dy || !dx || !dh) { set_error("usf_gated_tail_bwd_f32: null pointer"); return -1; }
+  if (!dparams || !workspace || workspace_floats < gated_tail_workspace(B, C, P)) {
+    set_error("usf_gated_tail_bwd_f32: dparams [2 C C + 2 C (+ 2 C)] and a workspace of usf_gated_tail_workspace floats are needed");
     return -2;
   }
   GtArgs a{};
@@ -314,13 +369,14 @@ int gated_tail_bwd(const float* h, const float* x, const float* dy, float* dx, f
   a.part = workspace; a.BP = B * P; a.P = P; a.eps = eps;
   a.in_slope = in_act == USF_ACT_LEAKY_RELU ? in_slope : 1.f;
   a.post_slope = post_act == USF_ACT_LEAKY_RELU ? post_slope : 1.f;
+  const int n = (int)gated_tail_nparams(C, gamma != nullptr);
+  a.slot_floats = n;
   const int blocks = gated_tail_blocks(a.BP);
   const dim3 g((unsigned)blocks), bl(256);
   if (gamma) { USF_GT_DISPATCH(true, true) } else { USF_GT_DISPATCH(false, true) }
   const int rc2 = check_launch("usf_gated_tail_bwd_f32");
-  if (rc2 || !gamma) return rc2;
-  const int n = (int)(2 * C);
-  return sum_slots(workspace, blocks, n, workspace + (int64_t)blocks * n, dgamma_dbeta, job, stream, "usf_gated_tail_bwd_f32 (sums)");
+  if (rc2) return rc2;
+  return sum_slots(workspace, blocks, n, workspace + (int64_t)blocks * n, dparams, job, stream, "usf_gated_tail_bwd_f32 (sums)");
 }
 #undef USF_GT_DISPATCH
 

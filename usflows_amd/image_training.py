@@ -312,8 +312,7 @@ def gated_tail_ok(conv2, x, ln=None) -> bool:
 class GatedTail(torch.autograd.Function):
     """LayerNormChannels(post_act(x + val * sigmoid(gate))), [val, gate] = W in_act(h) + bias -- the tail of a GatedConv layer
     of ConvNet2D (networks.py:108-122, 40-58, 480-493) on usf_gated_tail_f32; gamma None: no layer norm, y = x + val * sigmoid(gate).
-    The backward recomputes val / gate from (h, x): one launch for dx, dh, d[val, gate] and the layer norm's parameter sums, one
-    (usf_conv_wgrad_f32, kernel 1) for dW / dbias."""
+    The backward recomputes val / gate from (h, x): ONE launch for dx, dh and the partial sums of dW, dbias, dgamma, dbeta."""
 
     @staticmethod
     def forward(ctx, h, x, weight, bias, gamma, beta, in_act, post_act, eps):
@@ -338,18 +337,14 @@ class GatedTail(torch.autograd.Function):
         ln = (saved[4], saved[5], eps) if pshape is not None else None
         ia, pa = _act(in_act), _act(post_act)
         weight, bias, gamma, beta = ctx.params
-        dx, dh, dvg, dg, dbt = _ext.gated_tail_bwd(h, x, dy.contiguous(), w2, b2, ia[0], ia[1], pa[0], pa[1], ln,
-                                                   defer=_takeable((gamma, beta)),
-                                                   owners=tuple(id(q) for q in (gamma, beta) if q is not None))
-        dW = db = None
-        if ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3]):
-            r = _ext.conv_wgrad(h, dvg, 1, in_act=ia[0], in_slope=ia[1], want_bias=has_bias, defer=_takeable((weight, bias)),
-                                owners=tuple(id(q) for q in (weight, bias) if q is not None))
-            if r is None:
-                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape (gated_tail_ok was not consulted)")
-            dW, db = r[0].reshape(wshape), r[1]
+        params = (weight, bias, gamma, beta)
+        dx, dh, dW, db, dg, dbt, _ = _ext.gated_tail_bwd(h, x, dy.contiguous(), w2, b2, ia[0], ia[1], pa[0], pa[1], ln,
+                                                         defer=_takeable(params), owners=tuple(id(q) for q in params if q is not None))
+        dW = dW.view(wshape)
+        if not has_bias:
+            db = None
         if pshape is not None:
-            dg, dbt = dg.reshape(pshape), dbt.reshape(pshape)
+            dg, dbt = dg.view(pshape), dbt.view(pshape)
         return dh, dx, dW, db, dg, dbt, None, None, None
 
 
@@ -531,6 +526,8 @@ class AffinePrep(torch.autograd.Function):
     def forward(ctx, Lr, Ur, bias, vk, w0):
         M, Minv, b, c, ladj, save = _ext.affine_prep(Lr, Ur, bias, vk, w0)
         ctx.save_for_backward(save, bias, vk, w0, Minv, b)
+        # (5 n + 3 outputs, most of them unused in a given pass: no zero tensors -- a fill launch each -- for those)
+        ctx.set_materialize_grads(False)
         n = Lr.shape[0]
         ctx.n, ctx.C = n, Lr.shape[1]
         # per block: M, M^-1, b, c = -M^-1 b, log|det|; and once more the stacked log|det| (the flow's total log-det is one
@@ -558,6 +555,8 @@ class AffinePrep(torch.autograd.Function):
         db = gather(grads[2 * n:3 * n], (C,))
         dc = gather(grads[3 * n:4 * n], (C,))
         dl_each, dl_all = grads[4 * n:5 * n], grads[5 * n]
+        if dl_all is None and all(g is None for g in dl_each):
+            dl_all = _zeros((n,), dev)
         gMM, gbc = grads[5 * n + 1], grads[5 * n + 2]
         if gMM is not None:
             dM, dMinv = dM + gMM[:n], dMinv + gMM[n:]
@@ -570,7 +569,44 @@ class AffinePrep(torch.autograd.Function):
             if dl_all is not None:
                 dl = dl + dl_all
         dLr, dUr, dbias, dvk = _ext.affine_prep_bwd(save, bias, vk, w0, Minv, b, dM, dMinv, db, dc, dl)
+        # (the kernel writes zeros outside L's / U's triangle: LUTransform's gradient hooks need not multiply by their masks)
+        mark_masked(dLr)
+        mark_masked(dUr)
         return dLr, dUr, dbias, dvk, None
+
+
+# ---- gradients that already carry LUTransform's structural zeros ------------------------------------------------------------------
+# LUTransform masks the gradients of L_raw / U_raw with a tensor hook each (transforms.py:563-564 here, the reference's
+# LUTransform likewise): 2 launches per block and pass.  usf_affine_prep_bwd_f32 writes exact zeros outside the triangles, so
+# for ITS rows the product changes nothing; AffinePrep.backward registers the rows it is about to hand to autograd (address +
+# shape, per backward pass), the hook asks ``take_masked(grad)`` and skips the product for exactly those tensors, once each.
+_masked_lock = threading.Lock()
+_masked = {}          # autograd graph task id -> {(data_ptr, shape)}
+
+
+def mark_masked(stack: torch.Tensor) -> None:
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return
+    with _masked_lock:
+        for old in [t for t in _masked if t < task - 256]:
+            del _masked[old]
+        s = _masked.setdefault(task, set())
+        for row in stack.unbind(0):
+            s.add((row.data_ptr(), tuple(row.shape)))
+
+
+def take_masked(grad: torch.Tensor) -> bool:
+    task = torch._C._current_graph_task_id()
+    if task < 0 or not _masked:
+        return False
+    key = (grad.data_ptr(), tuple(grad.shape))
+    with _masked_lock:
+        s = _masked.get(task)
+        if s is not None and key in s and grad.is_contiguous():
+            s.discard(key)
+            return True
+    return False
 
 
 _ZEROS = {}
@@ -725,11 +761,14 @@ class batched_affine_prep:
 _IDX = {}
 
 
-def _idx_tensor(values, device) -> torch.Tensor:
-    key = (tuple(values), str(device))
+def _onehot(rows, width, device) -> torch.Tensor:
+    """the constant [len(rows), width] fp32 matrix with a one at (i, rows[i]), uploaded once"""
+    key = (tuple(rows), width, str(device))
     t = _IDX.get(key)
     if t is None:
-        t = torch.tensor(list(values), dtype=torch.int64, device=device)
+        host = torch.zeros(len(rows), width, dtype=torch.float32)
+        host[torch.arange(len(rows)), torch.tensor(list(rows))] = 1.0
+        t = host.to(device)
         if not (torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
             _IDX[key] = t
     return t
@@ -771,9 +810,12 @@ def compose_runs(specs):
         MM, bc, n = _STATE.maps[group]
         dev = MM.device
         A = cv = None
+        C = MM.shape[1]
         for j in range(L):
-            idx = _idx_tensor([specs[r][1][j][0] + (0 if pattern[j] else n) for r in members], dev)
-            Aj, cj = MM.index_select(0, idx), bc.index_select(0, idx)
+            # (rows picked by a constant one-hot matrix: exact -- 1.0 * x plus zeros -- and its backward is one small product
+            # instead of index_select's zero-fill + index_add, 40 us per stack at these sizes)
+            S = _onehot([specs[r][1][j][0] + (0 if pattern[j] else n) for r in members], 2 * n, dev)
+            Aj, cj = torch.mm(S, MM.view(2 * n, C * C)).view(len(members), C, C), torch.mm(S, bc)
             if A is None:
                 A, cv = Aj, cj
             else:

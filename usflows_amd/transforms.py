@@ -543,6 +543,11 @@ class HouseholderTransform(AffineTransform):
         return torch.zeros(self.dim, device=self.vk_householder.device)
 
 
+def _grad_is_masked(grad) -> bool:
+    from .image_training import take_masked
+    return grad.is_cuda and take_masked(grad)
+
+
 class LUTransform(AffineTransform):
     """y = (L U) x + b with unit-lower L and upper U (transforms.py:1178-1379)."""
 
@@ -560,8 +565,9 @@ class LUTransform(AffineTransform):
         self.L_mask = torch.tril(torch.ones(dim, dim), diagonal=-1)
         self.U_mask = torch.triu(torch.ones(dim, dim), diagonal=0)
         # keep the structural zeros: gradients outside the triangles are masked
-        self.L_raw.register_hook(lambda grad: grad * self.L_mask)
-        self.U_raw.register_hook(lambda grad: grad * self.U_mask)
+        # (a gradient that comes from usf_affine_prep_bwd_f32 already holds exact zeros there: image_training.take_masked)
+        self.L_raw.register_hook(lambda grad: None if _grad_is_masked(grad) else grad * self.L_mask)
+        self.U_raw.register_hook(lambda grad: None if _grad_is_masked(grad) else grad * self.U_mask)
 
     def init_params(self):
         d = self.dim
