@@ -387,7 +387,8 @@ int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, in
  * usf_partial_sum_jobs_f32 launches containing first job[0] (if any), then job[1] have run in this stream order; the workspace
  * must stay alive until then.
  * usf_partial_sum_jobs_f32: jobs / block_job are DEVICE arrays: job j owns the blocks [first_block, first_block +
- * ceil(n / 64) * rows) and block_job[b] names block b's job (n_blocks entries).  Row r of a job sums the slots
+ * ceil(n / 64) * rows) -- ceil(n / 256) * rows when vec4 != 0 (mode 0, n a multiple of 4, 16-byte aligned part / out: four
+ * columns per thread) -- and block_job[b] names block b's job (n_blocks entries).  Row r of a job sums the slots
  * [r * per, min((r + 1) * per, nparts)) in the order usf_conv_wgrad_f32's own rounds use: same bits.
  * Why: at the reference's training batch (32 rows, experiments/mnist/mnist.yaml:34) a backward pass of the live MNIST
  * configuration ends ~165 weight gradients with one or two such launches of a few microseconds each, all on the chain of
@@ -395,7 +396,7 @@ int usf_conv2d_same_res_f32(const float* x, float* y, int64_t B, int64_t cin, in
 typedef struct usf_psum_job {
   const float* part; float* out; float* out2;
   int32_t nparts, n, mode, cin, cout, CIT, T, ntile;
-  int32_t first_block, per, rows, reserved;
+  int32_t first_block, per, rows, vec4;
 } usf_psum_job;
 int usf_conv_wgrad_deferred_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                                 const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,

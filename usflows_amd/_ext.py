@@ -149,7 +149,7 @@ class PsumJob(C.Structure):
     _fields_ = [("part", _fp), ("out", _fp), ("out2", _fp),
                 ("nparts", C.c_int32), ("n", C.c_int32), ("mode", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("CIT", C.c_int32), ("T", C.c_int32), ("ntile", C.c_int32), ("first_block", C.c_int32), ("per", C.c_int32),
-                ("rows", C.c_int32), ("reserved", C.c_int32)]
+                ("rows", C.c_int32), ("vec4", C.c_int32)]
 
 
 class GradJob(C.Structure):
@@ -968,7 +968,7 @@ def flush_partial_sums(task: int, final: bool = True) -> None:
             continue
         block_job, first = [], 0
         for i, (j, _keep) in enumerate(part):
-            nb = ((j.n + 63) // 64) * j.rows
+            nb = ((j.n + 255) // 256 if j.vec4 else (j.n + 63) // 64) * j.rows
             j.first_block = first
             block_job.extend([i] * nb)
             first += nb

@@ -12,8 +12,8 @@
 // backward pass (layer norm, its parameter sums, gated residual, a transposed copy of W, pointwise data gradient).  The backward
 // kernel here recomputes the forward from (h, x) -- val / gate / r are never stored -- and writes dx (skip branch), dh
 // (through W^T and in_act') and per-block partial sums of ALL parameter gradients: dW = sum over pixels of d[val, gate] (x) a
-// (the block's 32 pixels meet in LDS: thread t owns the entries e = t, t + 256, ... of dW and adds the pixels in ascending
-// order), dbias, dgamma, dbeta -- one slot of 2 C C + 4 C floats per block (last sum: usf_partial_sum_jobs_f32 or at once).
+// (the block's 32 pixels meet in LDS; C a multiple of 16: 16 x 16 tiles on v_mfma_f32_16x16x4_f32, else thread t owns the
+// entries e = t, t + 256, ... and adds the pixels in ascending order), dbias, dgamma, dbeta -- one slot of 2 C C + 4 C floats per block (last sum: usf_partial_sum_jobs_f32 or at once).
 // d[val, gate] itself is written only on request (tests).
 //
 // Few pixels, so EIGHT lanes share a pixel (lane = 8 * channel group + pixel of the wave's 8): channel group cg owns channels
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
   __shared__ float red[BWD && LN ? 4 * 2 * C : 1];
   __shared__ float sa[BWD ? 32 * C : 1];                       // a of the block's 32 pixels
   __shared__ float sd[BWD ? 32 * 2 * C : 1];                   // d[val, gate] of the block's 32 pixels
-  constexpr int NE = (2 * C * C + 255) / 256;                  // entries of dW per thread
+  // entries of dW per thread: C % 16 == 0: the 4 accumulators of each 16 x 16 tile its wave owns; else e = t, t + 256, ...
+  constexpr int NE = C % 16 == 0 ? 4 * (((2 * C / 16) * (C / 16) + 3) / 4) : (2 * C * C + 255) / 256;
   float dwacc[BWD ? NE : 1], dbacc = 0.f;
 #pragma unroll
   for (int i = 0; i < (BWD ? NE : 1); ++i) dwacc[i] = 0.f;
@@ -192,16 +193,25 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
       }
     }
     __syncthreads();
-    // dW[co][ci] += d[val, gate][px][co] * a[px][ci], pixels in ascending order
-    if constexpr (256 % C == 0) {
-      const int ci = threadIdx.x % C, co0 = threadIdx.x / C;   // entry e = t + 256 i: ci fixed, co = co0 + (256 / C) i
-#pragma unroll 4
-      for (int px = 0; px < 32; ++px) {
-        const float av_ = sa[px * C + ci];
+    // dW[co][ci] += d[val, gate][px][co] * a[px][ci] over the block's 32 pixels
+    if constexpr (C % 16 == 0) {
+      // on the fp32 matrix instruction (exact fp32 products and sums): tile (cot, cit) = 16 rows of d[val, gate] x 16 channels
+      // of a, K = the pixels four at a time; wave w owns the tiles w, w + 4, ...
+      constexpr int NT = (2 * C / 16) * (C / 16);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-          const int co = co0 + (256 / C) * i;
-          if (co < 2 * C) dwacc[i] = fmaf(sd[px * 2 * C + co], av_, dwacc[i]);
+      for (int ti = 0; ti < (NT + 3) / 4; ++ti) {
+        const int t = wave + 4 * ti;
+        if (t < NT) {
+          const int cot = t / (C / 16), cit = t - cot * (C / 16);
+          f32x4 acc = {dwacc[4 * ti], dwacc[4 * ti + 1], dwacc[4 * ti + 2], dwacc[4 * ti + 3]};
+#pragma unroll
+          for (int k0 = 0; k0 < 32; k0 += 4) {
+            const int px = k0 + (lane >> 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sd[px * 2 * C + cot * 16 + (lane & 15)], sa[px * C + cit * 16 + (lane & 15)],
+                                                       acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dwacc[4 * ti + r] = acc[r];
         }
       }
     } else {
@@ -262,10 +272,23 @@ __global__ __launch_bounds__(256) void gated_tail_kernel(const GtArgs a) {
   }
   if (BWD) {
     float* slot = a.part + (int64_t)blockIdx.x * a.slot_floats;
+    if constexpr (C % 16 == 0) {
+      constexpr int NT = (2 * C / 16) * (C / 16);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = threadIdx.x + 256 * i;
-      if (e < 2 * C * C) slot[e] = dwacc[i];
+      for (int ti = 0; ti < (NT + 3) / 4; ++ti) {
+        const int t = wave + 4 * ti;
+        if (t < NT) {
+          const int cot = t / (C / 16), cit = t - cot * (C / 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slot[(cot * 16 + 4 * (lane >> 4) + r) * C + cit * 16 + (lane & 15)] = dwacc[4 * ti + r];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < 2 * C * C) slot[e] = dwacc[i];
+      }
     }
     if (threadIdx.x < 2 * C) slot[2 * C * C + threadIdx.x] = dbacc;
   }

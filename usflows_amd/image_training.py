@@ -170,6 +170,51 @@ class ConvSame(torch.autograd.Function):
         return dx, dW, db, None, None, None
 
 
+class ConvSameRes(torch.autograd.Function):
+    """rx + sign * om * (conv(x) + bias): a conditioner's LAST convolution with MaskedCoupling's residual in its output stream
+    (usf_conv2d_same_res_f32; transforms.py:277-306) -- one launch for what ConvSame + MaskedResidual do in two; the backward is
+    theirs (d conv = sign * om * dy, d rx = dy).  ``ConvSameRes.served`` tells whether the kernel takes the shape."""
+
+    @staticmethod
+    def served(conv, x) -> bool:
+        """the shapes of the fused form (include/usflows_hip.h); a launch that still declines falls back to the two passes"""
+        return (config.conv_res and conv.kernel_size == (3, 3) and conv.in_channels in (16, 32) and conv.out_channels in (16, 32, 64)
+                and x.shape[2] * x.shape[3] <= 64 and conv_shape_ok(conv, x.shape[0], x.shape[2], x.shape[3]))
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rx, om, sign):
+        x, rx = x.contiguous(), rx.contiguous()
+        w = weight.detach()
+        ks = w.shape[2]
+        planes, ctx.planes_t = _weight_planes(w, ctx.needs_input_grad[0], weight)
+        b = None if bias is None else bias.detach().contiguous()
+        y = _ext.conv2d_same_res(x, planes, w.shape[0], ks, rx, om, sign, bias=b)
+        if y is None:
+            y = _ext.masked_residual(rx, _ext.conv2d_same(x, planes, w.shape[0], ks, bias=b), om, sign)
+        ctx.save_for_backward(x, w, om)
+        ctx.cfg = (ks, bias is not None, sign)
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, om = ctx.saved_tensors
+        ks, has_bias, sign = ctx.cfg
+        dy = dy.contiguous()
+        dt = _ext.masked_residual(None, dy, om, sign)
+        dW = db = dx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            r = _ext.conv_wgrad(x, dt, ks, want_bias=has_bias, defer=_takeable(ctx.params),
+                                owners=tuple(id(q) for q in ctx.params if q is not None))
+            if r is None:
+                raise RuntimeError("usflows_amd: usf_conv_wgrad_f32 does not serve this shape")
+            dW, db = r
+        if ctx.needs_input_grad[0]:
+            planes_t = ctx.planes_t if ctx.planes_t is not None else _ext.conv2d_weight_planes(w, transposed=True)
+            dx = _ext.conv2d_same(dt, planes_t, w.shape[1], ks)
+        return dx, dW, db, dy, None, None
+
+
 class ConvSameFork(torch.autograd.Function):
     """(conv(in_act(x) * in_mul) + bias, x): the convolution of a layer whose INPUT forks -- GatedConv (the skip connection,
     networks.py:108-122) and MaskedCoupling (the residual, transforms.py:277-306) use x a second time.  Returning x through the

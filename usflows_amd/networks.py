@@ -207,12 +207,15 @@ class _ConvStack(nn.Module):
                 return False
         return True
 
-    def _forward_train_device(self, x, in_mul=None, fork: bool = False):
+    def _forward_train_device(self, x, in_mul=None, fork: bool = False, residual=None):
         """fork (a MaskedCoupling caller that uses x again for its residual): returns (net(x), x') where x' is x passed through
-        the first convolution's autograd node -- see image_training.ConvSameFork"""
+        the first convolution's autograd node -- see image_training.ConvSameFork.  residual = (one_minus_mask, sign) with fork:
+        the coupling's output x' + sign * (1 - mask) * net(x) may leave the LAST convolution's launch
+        (image_training.ConvSameRes); returns (output, x', done)"""
         from . import image_training as it
         mods = list(self.nn)
         assert in_mul is None or isinstance(mods[0], nn.Conv2d)
+        x_in = x
         x_fork = None
         k = 0
         while k < len(mods):
@@ -227,6 +230,10 @@ class _ConvStack(nn.Module):
                     x, x_fork = it.ConvSameFork.apply(x, m.weight, m.bias, in_mul, None)
                     k += 1
                     continue
+                if residual is not None and k > 0 and k == len(mods) - 1 and m.out_channels == x_in.shape[1] \
+                        and it.ConvSameRes.served(m, x):
+                    y = it.ConvSameRes.apply(x, m.weight, m.bias, x_fork if x_fork is not None else x_in, residual[0], residual[1])
+                    return y, x_fork, True
                 x = it.ConvSame.apply(x, m.weight, m.bias, in_mul if k == 0 else None, None, fold)
                 k += 2 if fold is not None else 1
             elif isinstance(m, GatedConv):
@@ -251,6 +258,8 @@ class _ConvStack(nn.Module):
             else:
                 x = m(x)
                 k += 1
+        if residual is not None:
+            return x, x_fork, False
         return (x, x_fork) if fork else x
 
     def first_conv_on_device(self, x) -> bool:

@@ -222,7 +222,10 @@ class MaskedCoupling(BaseTransform):
         from .image_training import MaskedResidual
         # (x forks into the conditioner and the residual: the conditioner's first convolution hands x back through its own
         # autograd node, so the two gradients are summed inside its data-gradient pass)
-        t, xs = cond._forward_train_device(x, self._mask_flat(x), fork=True)
+        # (... and the residual leaves the last convolution's launch where its kernel has that form)
+        t, xs, done = cond._forward_train_device(x, self._mask_flat(x), fork=True, residual=(self._one_minus_mask(x), sign))
+        if done:
+            return t
         return MaskedResidual.apply(xs if xs is not None else x, t, self._one_minus_mask(x), sign)
 
     def _conditioner_masked(self, x, context, sign=None):
