@@ -402,6 +402,22 @@ int usf_conv_wgrad_deferred_f32(const float* x, const float* dy, int64_t B, int6
                                 const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
                                 float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_stream_t stream);
 int usf_partial_sum_jobs_f32(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream);
+/* The weight-gradient kernel itself queued as well (small batches: one weight gradient occupies an eighth of the chip).
+ * usf_conv_wgrad_plan_f32 = usf_conv_wgrad_deferred_f32 that launches NOTHING when the shape runs on the LDS-staged kernel: it
+ * fills *wjob (HOST memory; blocks > 0) with that kernel's arguments -- the caller later runs all queued jobs of equal
+ * (CIT, COT, T) with ONE usf_conv_wgrad_jobs_f32 launch (jobs / block_job DEVICE arrays as for usf_partial_sum_jobs_f32: job j
+ * owns the blocks [first_block, first_block + blocks), first_block set by the caller; lds_bytes = the largest of the jobs')
+ * and then the sums job[0 .. 1] describe.  x, dy, in_mul, pre_sub and the workspace must stay alive and unchanged until then.
+ * wjob->blocks == 0 on return: the shape runs on the direct kernel-1 form, which HAS been launched (only the sums remain). */
+typedef struct usf_wgrad_job {
+  unsigned char args[192];                      /* the kernel's arguments (opaque) */
+  int32_t CIT, COT, T, blocks, lds_bytes, first_block;
+} usf_wgrad_job;
+int usf_conv_wgrad_plan_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                            const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
+                            float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_wgrad_job* wjob, usf_stream_t stream);
+int usf_conv_wgrad_jobs_f32(const usf_wgrad_job* jobs, const int32_t* block_job, int64_t n_blocks, int32_t CIT, int32_t COT, int32_t T,
+                            int32_t lds_bytes, usf_stream_t stream);
 int64_t usf_conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int usf_conv_wgrad_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                        const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,

@@ -538,8 +538,12 @@ def test_deferred_partial_sums_of_a_backward_pass_are_one_launch_and_the_same_bi
         return {k: p.grad.clone() for k, p in flow.named_parameters() if p.grad is not None}, launches.count("usf_partial_sum_jobs_f32")
 
     g_off, n_off = grads("0")
+    w0 = _ext.n_wgrad_jobs_flushed[0]
     g_on, n_on = grads("1")
     assert n_off == 0 and 1 <= n_on <= 2, (n_off, n_on)
+    # ... and the 3 x 3 weight-gradient kernels themselves left as one usf_conv_wgrad_jobs_f32 launch per tile shape
+    n_conv3 = sum(1 for m in flow.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3))
+    assert _ext.n_wgrad_jobs_flushed[0] - w0 == n_conv3 and 1 <= launches.count("usf_conv_wgrad_jobs_f32") <= 4
     assert set(g_on) == set(g_off)
     for k in g_off:
         assert torch.equal(g_on[k], g_off[k]), k

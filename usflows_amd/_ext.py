@@ -152,6 +152,12 @@ class PsumJob(C.Structure):
                 ("rows", C.c_int32), ("vec4", C.c_int32)]
 
 
+class WgradJob(C.Structure):
+    """usf_wgrad_job: one queued weight-gradient launch (usf_conv_wgrad_plan_f32 / usf_conv_wgrad_jobs_f32)"""
+    _fields_ = [("args", C.c_ubyte * 192), ("CIT", C.c_int32), ("COT", C.c_int32), ("T", C.c_int32), ("blocks", C.c_int32),
+                ("lds_bytes", C.c_int32), ("first_block", C.c_int32)]
+
+
 class GradJob(C.Structure):
     _fields_ = [
         ("Y", _fp), ("A", _fp), ("G", _fp),
@@ -213,7 +219,10 @@ SYMBOLS = {
     "usf_conv_wgrad_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
                                      C.c_void_p]),
     "usf_conv_wgrad_deferred_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
-                                              C.POINTER(PsumJob), C.c_void_p]),      # (job: two entries)
+                                              C.POINTER(PsumJob), C.c_void_p]),
+    "usf_conv_wgrad_plan_f32": (C.c_int, [_fp, _fp] + [C.c_int64] * 6 + [_fp, _fp, C.c_int32, C.c_float, _fp, _fp, _fp, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "usf_conv_wgrad_jobs_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),      # (job: two entries)
     "usf_partial_sum_jobs_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_void_p]),
     "usf_layernorm_channels_bwd_workspace": (C.c_int64, [C.c_int64] * 3),
     "usf_layernorm_channels_bwd_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_float, C.c_int32, C.c_float,
@@ -865,6 +874,7 @@ def masked_residual(x, t, one_minus_mask, sign):
 # slices of a buffer allocated BEFORE the capture and uploads their contents after it, before the first replay.
 PSUM_DEFER_MAX_ROWS = 1024        # (launch-bound batches; above, the sums are a small part of kernels that take real time)
 n_jobs_flushed = [0]             # (introspection for tests / tools: sums that left through usf_partial_sum_jobs_f32)
+n_wgrad_jobs_flushed = [0]       # (... and weight-gradient launches that left through usf_conv_wgrad_jobs_f32)
 
 
 class _PsumState:
@@ -962,6 +972,29 @@ def flush_partial_sums(task: int, final: bool = True) -> None:
         return
     device = jobs[0][2][0].device
     n_jobs_flushed[0] += len(jobs)
+    # the queued weight-gradient launches first: one per tile shape, all its jobs' blocks side by side
+    groups = {}
+    for j in jobs:
+        w = j[4]
+        if w is not None:
+            groups.setdefault((w.CIT, w.COT, w.T), []).append((w, j[2]))
+    for (cit, cot, t_), members in groups.items():
+        block_job, first = [], 0
+        for i, (w, _keep) in enumerate(members):
+            w.first_block = first
+            block_job.extend([i] * w.blocks)
+            first += w.blocks
+        raw = bytearray(bytes((WgradJob * len(members))(*[w for w, _ in members])))
+        raw += b"\0" * ((-len(raw)) % 16)
+        off = len(raw)
+        raw += struct.pack(f"<{len(block_job)}i", *block_job)
+        table = _device_table(torch.frombuffer(raw, dtype=torch.uint8), device)
+        if table is None:
+            raise RuntimeError("usflows_amd: deferred weight gradients inside a stream capture without a capture_tables buffer")
+        n_wgrad_jobs_flushed[0] += len(members)
+        _launch("usf_conv_wgrad_jobs_f32", (table.data_ptr(), table.data_ptr() + off, first, cit, cot, t_,
+                                            max(w.lds_bytes for w, _ in members), current_stream(device)),
+                (table, [k for _, k in members]))
     for stage in (0, 1):
         part = [(j[stage], j[2]) for j in jobs if j[stage] is not None]
         if not part:
@@ -1011,8 +1044,9 @@ def _psum_may_defer(x, owners) -> bool:
     return True
 
 
-def _psum_queue(job2, keep) -> None:
-    """queue the (first round | none, last round) jobs an entry point returned; `keep` = the tensors holding the partial slots"""
+def _psum_queue(job2, keep, wjob=None) -> None:
+    """queue the (first round | none, last round) jobs an entry point returned; `keep` = the tensors holding the partial slots
+    (and, with a queued weight-gradient launch `wjob`, its operands)"""
     if job2[1].nparts <= 0:
         return
     task = torch._C._current_graph_task_id()
@@ -1029,7 +1063,9 @@ def _psum_queue(job2, keep) -> None:
         # TAKING them as the parameter's gradient -- it would copy them on the spot, before the sum has run)
         j0 = PsumJob.from_buffer_copy(job2[0]) if job2[0].nparts > 0 else None
         nbytes = 2 * C.sizeof(PsumJob) + 4 * sum(((j_.n + 63) // 64) * j_.rows for j_ in job2 if j_.nparts > 0) + 64
-        q.append((j0, PsumJob.from_buffer_copy(job2[1]), tuple(keep), nbytes))
+        if wjob is not None:
+            nbytes += C.sizeof(WgradJob) + 4 * wjob.blocks + 32
+        q.append((j0, PsumJob.from_buffer_copy(job2[1]), tuple(keep), nbytes, wjob))
 
 
 def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0.0, want_bias=True, defer=False, owners=()):
@@ -1049,6 +1085,21 @@ def conv_wgrad(x, dy, ks, in_mul=None, pre_sub=None, in_act=ACT_NONE, in_slope=0
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
     if defer and _psum_may_defer(x, owners):
         job2 = (PsumJob * 2)()
+        if config.wgrad_jobs:
+            # the weight-gradient launch itself is queued too (one launch per tile shape when the pass ends); the direct kernel-1
+            # form is launched here (wjob.blocks == 0) and only its sums wait
+            wjob = WgradJob()
+            rc = lib.usf_conv_wgrad_plan_f32(x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act),
+                                             float(in_slope), dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, C.addressof(job2),
+                                             C.addressof(wjob), current_stream(x.device))
+            if rc == 1:
+                return None
+            check(rc, "usf_conv_wgrad_plan_f32")
+            if wjob.blocks > 0:
+                _psum_queue(job2, (ws, x, dy, in_mul, pre_sub), wjob)
+            else:
+                _psum_queue(job2, (ws,))
+            return dW, db
         rc = lib.usf_conv_wgrad_deferred_f32(x.data_ptr(), dy.data_ptr(), B, cin, cout, H, W, ks, ptr(in_mul), ptr(pre_sub), int(in_act),
                                              float(in_slope), dW.data_ptr(), ptr(db), ws.data_ptr(), ws_n, job2, current_stream(x.device))
         if rc == 1:

@@ -51,6 +51,7 @@ class Config:
         loop_graph=True,           # ... or replayed as a hipGraph
         radial=True,               # RadialDistribution on usf_radial_logprob(_grad)_f32
         psum_jobs=True,            # small-batch conv weight gradients: last sums queued until the pass ends
+        wgrad_jobs=True,           # ... and the weight-gradient launches themselves (one launch per tile shape when the pass ends)
         affine_prep=True,          # image flows: the affine blocks' parameter maps in one launch
         conv_res=True,             # conv kernel with MaskedCoupling's residual in its output stream
         pointwise=True,            # 1x1 convolutions on usf_pointwise_conv_f32

@@ -121,7 +121,9 @@ int masked_residual(const float* x, const float* t, const float* om, float sign,
 int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks);
 int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
-               int64_t workspace_floats, usf_psum_job* job, hipStream_t stream);
+               int64_t workspace_floats, usf_psum_job* job, usf_wgrad_job* wjob, hipStream_t stream);
+int conv_wgrad_jobs(const usf_wgrad_job* jobs, const int32_t* block_job, int64_t n_blocks, int32_t CIT, int32_t COT, int32_t T,
+                    int32_t lds_bytes, hipStream_t stream);
 int partial_sum_jobs(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
 int conv2d_weight_planes_batch(const usf_wplanes_job* jobs, const int32_t* block_job, int64_t n_blocks, void* planes_base,
                                hipStream_t stream);
@@ -352,14 +354,25 @@ int usf_conv_wgrad_f32(const float* x, const float* dy, int64_t B, int64_t cin, 
                        const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
                        float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::conv_wgrad(x, dy, B, cin, cout, H, W, ks, in_mul, pre_sub, in_act, in_slope, dW, db, workspace, workspace_floats,
-                         nullptr, (hipStream_t)stream);
+                         nullptr, nullptr, (hipStream_t)stream);
 }
 int usf_conv_wgrad_deferred_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                                 const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
                                 float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_stream_t stream) {
   if (!job) { usf::set_error("usf_conv_wgrad_deferred_f32: job is NULL"); return -1; }
   return usf::conv_wgrad(x, dy, B, cin, cout, H, W, ks, in_mul, pre_sub, in_act, in_slope, dW, db, workspace, workspace_floats, job,
-                         (hipStream_t)stream);
+                         nullptr, (hipStream_t)stream);
+}
+int usf_conv_wgrad_plan_f32(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
+                            const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db,
+                            float* workspace, int64_t workspace_floats, usf_psum_job* job, usf_wgrad_job* wjob, usf_stream_t stream) {
+  if (!job || !wjob) { usf::set_error("usf_conv_wgrad_plan_f32: job / wjob is NULL"); return -1; }
+  return usf::conv_wgrad(x, dy, B, cin, cout, H, W, ks, in_mul, pre_sub, in_act, in_slope, dW, db, workspace, workspace_floats, job,
+                         wjob, (hipStream_t)stream);
+}
+int usf_conv_wgrad_jobs_f32(const usf_wgrad_job* jobs, const int32_t* block_job, int64_t n_blocks, int32_t CIT, int32_t COT, int32_t T,
+                            int32_t lds_bytes, usf_stream_t stream) {
+  return usf::conv_wgrad_jobs(jobs, block_job, n_blocks, CIT, COT, T, lds_bytes, (hipStream_t)stream);
 }
 int usf_partial_sum_jobs_f32(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream) {
   return usf::partial_sum_jobs(jobs, block_job, n_blocks, (hipStream_t)stream);

@@ -13,6 +13,7 @@
 // more launch adds the slots in a fixed order.
 #include "usf_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace usf {
 
@@ -43,11 +44,13 @@ struct WgArgs {
   int tab_floats;          // LDS floats in front of the waves' images: index tables (u16), mask, pre_sub
 };
 
+// (bx of nblk: the block's place in ITS launch -- blockIdx.x of gridDim.x, or its place among the blocks of its job when many
+// weight gradients share one launch: conv_wgrad_jobs_kernel below)
 template <int CIT, int COT, int T>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const WgArgs& a, const int bx, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float wg_lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+  const int gw = bx * 4 + wave, nw = nblk * 4;
   const int nex = a.nex, ney = a.ney;                          // elements per sample
   // ---- tables (once per block), one entry per (lane, register) slot of the staging below: the LDS index of the slot's
   // element (slots past the sample's end point at a scratch word behind the wave's image), the input mask, pre_sub
@@ -202,6 +205,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     v += __shfl_xor(v, 32, 64);
     if (lane < 16) pw[COT * CIT * T * 256 + i * 16 + lane] = v;
   }
+}
+
+template <int CIT, int COT, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
+  conv_wgrad_body<CIT, COT, T>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// MANY weight gradients of one tile shape in ONE launch (usf_conv_wgrad_jobs_f32): block b works on job block_job[b] as block
+// b - first_block of that job's own launch would -- same partial slots, same bits.  At the reference's training batch (32
+// rows) one weight gradient is 128 waves (an eighth of the chip) for 10-14 us, and the 75 of a backward pass of the live MNIST
+// configuration follow each other in stream order although nothing but the parameter update waits for them: queued
+// (usf_conv_wgrad_plan_f32) they leave the chain of dependent launches and fill the chip together when the pass ends.
+static_assert(sizeof(WgArgs) <= sizeof(((usf_wgrad_job*)nullptr)->args), "usf_wgrad_job.args too small for the kernel's arguments");
+
+template <int CIT, int COT, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_jobs_kernel(const usf_wgrad_job* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+  const usf_wgrad_job* j = jobs + block_job[blockIdx.x];
+  const WgArgs a = *reinterpret_cast<const WgArgs*>(j->args);
+  conv_wgrad_body<CIT, COT, T>(a, (int)blockIdx.x - j->first_block, j->blocks);
 }
 
 // Kernel 1 (the pointwise convolution of GatedConv, the 1 x 1 convolution of BlockAffineTransform) without an input mask,
@@ -523,9 +545,10 @@ int64_t conv_wgrad_workspace(int64_t B, int64_t cin, int64_t cout, int64_t H, in
 
 int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t cout, int64_t H, int64_t W, int64_t ks,
                const float* in_mul, const float* pre_sub, int32_t in_act, float in_slope, float* dW, float* db, float* workspace,
-               int64_t workspace_floats, usf_psum_job* job, hipStream_t stream) {
+               int64_t workspace_floats, usf_psum_job* job, usf_wgrad_job* wjob, hipStream_t stream) {
   WgPlan pl;
   if (job) job[0].nparts = job[1].nparts = 0;
+  if (wjob) wjob->blocks = 0;
   if (B < 0) { set_error("usf_conv_wgrad_f32: bad sizes"); return -2; }
   if (B == 0 || !wgrad_plan(B, cin, cout, H, W, ks, in_mul != nullptr, pl)) {
     if (B == 0) { set_error("usf_conv_wgrad_f32: empty batch"); return -2; }
@@ -550,7 +573,13 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
     launched = true;                                                                                                       \
   }
   bool launched = false;
-  if (pl.direct) {
+  if (wjob && !pl.direct) {
+    // not launched: the caller queues the job for usf_conv_wgrad_jobs_f32 (the sums below follow it)
+    memset(wjob, 0, sizeof(*wjob));
+    memcpy(wjob->args, &a, sizeof(a));
+    wjob->CIT = pl.CIT; wjob->COT = pl.COT; wjob->T = pl.T; wjob->blocks = pl.blocks; wjob->lds_bytes = pl.lds_bytes;
+    launched = true;
+  } else if (pl.direct) {
 #define USF_WG1(CIT_, COT_)                                                                                                \
   if (pl.CIT == CIT_ && pl.COT == COT_) {                                                                                  \
     hipLaunchKernelGGL((conv_wgrad_k1_kernel<CIT_, COT_>), g, b, 0, stream, a);                                            \
@@ -591,6 +620,36 @@ int conv_wgrad(const float* x, const float* dy, int64_t B, int64_t cin, int64_t 
   }
   return reduce_partials(workspace, pl.blocks * 4, pl.nacc, workspace + (int64_t)pl.blocks * 4 * pl.nacc, dW, db, 1, (int)cin, (int)cout,
                          pl.CIT, pl.T, ntile, stream, "usf_conv_wgrad_f32 (reduce)");
+}
+
+int conv_wgrad_jobs(const usf_wgrad_job* jobs, const int32_t* block_job, int64_t n_blocks, int32_t CIT, int32_t COT, int32_t T,
+                    int32_t lds_bytes, hipStream_t stream) {
+  if (n_blocks < 0 || n_blocks > 0x7fffffff || (n_blocks > 0 && (!jobs || !block_job)) || lds_bytes < 0 || lds_bytes > 160 * 1024) {
+    set_error("usf_conv_wgrad_jobs_f32: bad arguments");
+    return -1;
+  }
+  if (n_blocks == 0) return 0;
+  static bool attr_done[USF_MAX_DEVICES][5][5][2];
+  const int dev = current_device_slot();
+  bool launched = false;
+#define USF_WGJ(CIT_, COT_, T_)                                                                                            \
+  if (CIT == CIT_ && COT == COT_ && T == T_) {                                                                             \
+    const void* fn = reinterpret_cast<const void*>(&conv_wgrad_jobs_kernel<CIT_, COT_, T_>);                               \
+    if (!attr_done[dev][CIT_][COT_][T_ == 9]) {                                                                            \
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {                 \
+        set_error("usf_conv_wgrad_jobs_f32: cannot raise the kernel's LDS limit");                                        \
+        return -3;                                                                                                         \
+      }                                                                                                                    \
+      attr_done[dev][CIT_][COT_][T_ == 9] = true;                                                                          \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((conv_wgrad_jobs_kernel<CIT_, COT_, T_>), dim3((unsigned)n_blocks), dim3(256), (size_t)lds_bytes, stream, jobs,  \
+                       block_job);                                                                                         \
+    launched = true;                                                                                                       \
+  }
+  USF_WG_INSTANCES(USF_WGJ)
+#undef USF_WGJ
+  if (!launched) { set_error("usf_conv_wgrad_jobs_f32: no kernel instance for tiles (%d, %d, %d)", CIT, COT, T); return -2; }
+  return check_launch("usf_conv_wgrad_jobs_f32");
 }
 
 int partial_sum_jobs(const usf_psum_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream) {
