@@ -1209,6 +1209,10 @@ class FlowEngine:
         return len(body) >= 2 and body[-1].startswith("affine")
 
     def _train_planes_conditioners_ok(self) -> bool:
+        # (the weight-gradient kernel carries the bias sums along only for operands of >= 64 columns -- usf_wgrad_planes_colsum_ok --:
+        # flows whose halves are narrower keep the fp32-row training path, which is made for them)
+        if min(self.n0a, self.n1a) < 64:
+            return False
         for s_ in self.steps:
             if s_.kind == "coupling":
                 cond = s_.module.conditioner

@@ -333,7 +333,6 @@ class GatedResidual(torch.autograd.Function):
         return dy, _ext.gated_residual_bwd(dy, vg)
 
 
-GATED_TAIL_MAX_PIXELS = 1 << 16     # (eight lanes per pixel: made for the few pixels of a training batch; larger ones keep the chain)
 
 
 def gated_tail_ok(conv2, x, ln=None) -> bool:
@@ -346,7 +345,7 @@ def gated_tail_ok(conv2, x, ln=None) -> bool:
     if not (pad == "same" or (not isinstance(pad, str) and tuple(pad) == (0, 0))):
         return False
     B, Cc, H, W = x.shape
-    if not (conv2.in_channels == Cc and conv2.out_channels == 2 * Cc and 0 < B * H * W <= GATED_TAIL_MAX_PIXELS
+    if not (conv2.in_channels == Cc and conv2.out_channels == 2 * Cc and 0 < B * H * W <= config.gated_tail_max_pixels
             and _ext.gated_tail_supported(Cc)):
         return False
     if ln is not None and not (ln.gamma.numel() == Cc and ln.gamma.dtype == torch.float32):
