@@ -225,7 +225,11 @@ int usf_radial_sample_f32(float* z, int64_t ldz, int64_t M, int64_t D, int32_t b
  *
  * usf_radial_logprob_grad_f32: from g_lp [M] (gradient at logp) and the saved r:
  *     g[m,d]   = g_lp[m] * dlogp/dr * dr/dz[m,d]   (0 for D <= d < ldg; ATen's norm backward: p = 1 sign(t), p = 2 t / r,
- *                                                   p = inf sign(t) where |t| == r)
+ *                                                   p = inf sign(t) / (number of d with |t| == r) where |t| == r: tied
+ *                                                   maxima share the gradient evenly, as x.norm(p=inf) does)
+ *     r == 0 (z == loc exactly): log r = -inf and (D - 1) / r = inf enter the row as they do in the reference
+ *     (distributions.py:506-549): logp is +-inf or NaN depending on the norm distribution and the row of g is NaN (p = 2: t / r
+ *     is taken as 0) -- nothing is clamped.
  *     d_loc[d] = -sum_m g[m,d];   d_a / d_b / d_logits [K] = gradients of the STORED parameters (chain rule through softplus)
  * each output pointer but g is optional.  z == NULL (both entry points): the radii are GIVEN -- the forward reads r_out as its
  * input, the backward writes g [M] = the gradient at r (d_loc must be NULL): the finishing formula alone, for callers whose own

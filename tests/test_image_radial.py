@@ -37,7 +37,8 @@ def ref_radial_logprob(z, loc, p, kind, a, b, logits, raw=False):
     components (torch's log_prob formulas), every tensor fp64"""
     x = (z - loc).flatten(1)
     D = x.shape[1]
-    r = x.abs().sum(-1) if p == 1 else (x * x).sum(-1).sqrt() if p == 2 else x.abs().max(-1).values
+    # (p = inf: the reference's ``x.norm(p=inf)`` -- distributions.py:506 -- whose backward shares the gradient among tied maxima)
+    r = x.abs().sum(-1) if p == 1 else (x * x).sum(-1).sqrt() if p == 2 else torch.linalg.vector_norm(x, ord=math.inf, dim=-1)
     lr = torch.log(r).unsqueeze(-1)
     if kind == "lognormal":
         mu, sigma = a, (b if raw else F.softplus(b))
@@ -123,6 +124,34 @@ def test_radial_kernels_vs_fp64(case, B):
     again = run()
     for u, v in zip(got, again):
         assert (u is None and v is None) or torch.equal(u, v), "not bit-reproducible"
+
+
+@pytest.mark.gpu
+def test_radial_gradient_with_tied_maxima_p_inf():
+    """quantised / clamped latents tie the maximum of |z - loc|: ``x.norm(p=inf)`` (distributions.py:506) divides the
+    gradient among the tied coordinates (ATen's norm backward) -- so does usf_radial_logprob_grad_f32"""
+    from usflows_amd import _ext, radial
+    ev, D, B = (3, 5, 2), 30, 7
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, *ev, generator=g) * 40.0
+    loc = torch.zeros(*ev)
+    zf = z.view(B, D)
+    for m in range(B):                                          # row m: m + 1 coordinates share the maximum (signs mixed)
+        top = zf[m].abs().max() * 1.5
+        for j in range(m + 1):
+            zf[m, (3 * j + m) % D] = top if j % 2 == 0 else -top
+    a, b, logits = _norm_params("lognormal", 5, g)
+    glp = torch.randn(B, generator=g)
+    zd = z.to(DEV).requires_grad_(True)
+    lp = radial.RadialLogProb.apply(zd, loc.to(DEV), a.to(DEV), b.to(DEV), logits.to(DEV), radial.p_id_of(math.inf), _ext.NORM_LOGNORMAL, 5,
+                                    radial.log_dv_const(math.inf, D))
+    lp.backward(glp.to(DEV))
+    z6 = z.double().requires_grad_(True)
+    lp6, _ = ref_radial_logprob(z6, loc.double(), math.inf, "lognormal", a.double(), b.double(), logits.double())
+    lp6.backward(glp.double())
+    _close(lp.detach(), lp6.detach(), 2e-6, "logp")
+    _close(zd.grad, z6.grad, 2e-5, "dz with ties")
+    assert int((zd.grad[B - 1] != 0).sum()) == B                # the last row's gradient sits on its B tied coordinates
 
 
 @pytest.mark.gpu

@@ -375,6 +375,7 @@ def test_fit_hands_large_host_batches_over_under_the_running_step(monkeypatch):
                                device=torch.device(DEV), epochs=2))
         torch.cuda.synchronize()
     assert made[0] is None and made[1] is None and made[2] is not None and made[3] is not None     # off twice, on twice (one per epoch)
+    assert made[2] is made[3]                                   # ... ONE feed (buffers, copy stream, events) for both epochs
     assert curves[0] == curves[1] and len(curves[0]) == 2
 
 

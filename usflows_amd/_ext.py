@@ -883,6 +883,7 @@ class _PsumState:
 
     def __init__(self):
         self.lock = threading.Lock()
+        self.capture_lock = threading.RLock()    # held for the whole of a capture_tables block (re-entrant: nested blocks of one thread)
         self.jobs = {}           # autograd graph task id -> [(PsumJob, tensors to keep alive until the launch)]
         self.arena = None        # capture_tables: [buffer, bytes used, [(device slice, host tensor)]]
         self.scope = 0           # > 0: inside deferred_sums_scope (a backward pass whose caller vouches for its parameters)
@@ -921,12 +922,20 @@ class capture_tables:
         self.device, self.nbytes, self.prev = device, nbytes, None
 
     def __enter__(self):
-        self.prev = _psum.arena
-        _psum.arena = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device), 0, []]
+        # ONE capture with tables at a time per process: the buffer is read by the autograd engine's worker threads (not the
+        # thread that captures), so it cannot be thread-local; a second thread that wants to capture waits here until the first
+        # capture has ended (its tables would otherwise land in the wrong buffer)
+        _psum.capture_lock.acquire()
+        buf = torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
+        with _psum.lock:
+            self.prev = _psum.arena
+            _psum.arena = [buf, 0, []]
         return self
 
     def __exit__(self, exc_type, *exc):
-        arena, _psum.arena = _psum.arena, self.prev
+        with _psum.lock:
+            arena, _psum.arena = _psum.arena, self.prev
+        _psum.capture_lock.release()
         self.pending = arena[2] if exc_type is None else []
         self.keep = arena[0]
         return False
@@ -942,13 +951,14 @@ def _device_table(host: torch.Tensor, device) -> Optional[torch.Tensor]:
     """a uint8 host tensor on the device: an upload -- or, inside a capture, a slice of the capture's table buffer whose upload is
     pending (None: capturing without such a buffer)"""
     if torch.cuda.is_current_stream_capturing():
-        ar = _psum.arena
         n = (host.numel() + 15) // 16 * 16
-        if ar is None or ar[0].device != torch.device(device) or ar[1] + n > ar[0].numel():
-            return None
-        dev = ar[0][ar[1]: ar[1] + host.numel()]
-        ar[1] += n
-        ar[2].append((dev, host))
+        with _psum.lock:
+            ar = _psum.arena
+            if ar is None or ar[0].device != torch.device(device) or ar[1] + n > ar[0].numel():
+                return None
+            dev = ar[0][ar[1]: ar[1] + host.numel()]
+            ar[1] += n
+            ar[2].append((dev, host))
         return dev
     return host.to(device)
 
@@ -1039,8 +1049,11 @@ def _psum_may_defer(x, owners) -> bool:
     with _psum.lock:
         queued = _psum.jobs.get(task)
         used = sum(q_[3] for q_ in queued) if queued else 0
-    if torch.cuda.is_current_stream_capturing() and used > _psum.arena[0].numel() // 2 - (1 << 16):
-        return False
+    if torch.cuda.is_current_stream_capturing():
+        with _psum.lock:
+            ar = _psum.arena
+        if ar is None or used > ar[0].numel() // 2 - (1 << 16):
+            return False
     return True
 
 

@@ -458,9 +458,23 @@ int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
     }
   }
   a.ld_hs = d->ld_hidden_out;
-  if (d->hidden_out[0] && (d->ld_hidden_out < C3_HMAX || (d->ld_hidden_out & 3) || !aligned16(d->hidden_out[0]))) {
-    set_error("usf_coupling_additive_f32(bf16x3): hidden_out needs ld_hidden_out >= 256, a multiple of 4, 16-byte aligned bases");
-    return -2;
+  {
+    // all n_hidden slots or none (a NULL slot would be skipped silently and the caller would train on stale activations)
+    int set = 0;
+    for (int i = 0; i < d->n_hidden; ++i) set += d->hidden_out[i] != nullptr;
+    if (set != 0 && set != d->n_hidden) {
+      set_error("usf_coupling_additive_f32(bf16x3): hidden_out: either all n_hidden pointers or none");
+      return -2;
+    }
+    if (set && (d->ld_hidden_out < C3_HMAX || (d->ld_hidden_out & 3))) {
+      set_error("usf_coupling_additive_f32(bf16x3): hidden_out needs ld_hidden_out >= 256, a multiple of 4");
+      return -2;
+    }
+    for (int i = 0; i < d->n_hidden; ++i)
+      if (d->hidden_out[i] && !aligned16(d->hidden_out[i])) {
+        set_error("usf_coupling_additive_f32(bf16x3): hidden_out[%d] must be 16-byte aligned", i);
+        return -2;
+      }
   }
   const int64_t kp = ((d->n_pass + 31) / 32) * 32;
   if (d->split_in_ld < kp || d->split_hid_ld < C3_HMAX * (d->n_hidden > 1) || d->split_out_ld < C3_HMAX || (d->split_in_ld & 7) ||

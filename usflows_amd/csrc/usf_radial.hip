@@ -263,6 +263,16 @@ __global__ __launch_bounds__(64 * RAD_WPB) void radial_grad_kernel(
     const float inv_r = rf > 0.f ? 1.0f / rf : 0.f;
     const float* zr = z + row * ldz;
     float* gr = g + row * ldg;
+    float coef_inf = coef;
+    if (P_ID == USF_BASE_LPNORMINF) {
+      // x.norm(p=inf) (distributions.py:506) shares the gradient EVENLY among tied maxima (ATen's norm backward divides by their
+      // number): one more pass over the row counts them (quantised or clamped latents; a row of distinct values counts 1)
+      int cnt = 0;
+      for (int d = lane; d < D; d += 64) cnt += fabsf(zr[d] - loc[d]) == rf ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+      coef_inf = coef / (float)(cnt > 0 ? cnt : 1);
+    }
     for (int d = lane * 4; d < D4; d += 256) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(zr + d);
       const f32x4 l = *reinterpret_cast<const f32x4*>(loc + d);
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(64 * RAD_WPB) void radial_grad_kernel(
         const float sg = (float)((t > 0.f) - (t < 0.f));
         if (P_ID == USF_BASE_LPNORM1) o[j] = coef * sg;
         else if (P_ID == USF_BASE_LPNORM2) o[j] = coef * (t * inv_r);
-        else o[j] = (fabsf(t) == rf) ? coef * sg : 0.f;
+        else o[j] = (fabsf(t) == rf) ? coef_inf * sg : 0.f;
       }
       *reinterpret_cast<f32x4*>(gr + d) = o;
     }
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(64 * RAD_WPB) void radial_grad_kernel(
         const float sg = (float)((t > 0.f) - (t < 0.f));
         if (P_ID == USF_BASE_LPNORM1) o = coef * sg;
         else if (P_ID == USF_BASE_LPNORM2) o = coef * (t * inv_r);
-        else o = (fabsf(t) == rf) ? coef * sg : 0.f;
+        else o = (fabsf(t) == rf) ? coef_inf * sg : 0.f;
       }
       gr[d] = o;
     }

@@ -53,19 +53,23 @@ class _BatchFeed:
     step -- 205 MB at 65 536 x 784).  Two pinned staging buffers and two device buffers: while step i runs, batch i + 1 is
     copied into pinned memory and uploaded on a copy stream; step i + 1 waits for that upload's event only.  Same batches,
     same order, same values.  Used from 16 MB per batch on a CUDA device with a float32 CPU tensor; USFLOWS_AMD_FIT_PREFETCH=0:
-    off.  (Buffer reuse is safe without further events: a buffer is overwritten two batches after its use, and ``fit`` reads
-    every step's loss back before it goes on.)"""
+    off.  One feed serves all epochs of a ``fit`` (``make(..., reuse=feed)`` re-points it at the epoch's permuted data).  A device
+    buffer is overwritten two batches after its use: the upload waits for the event ``done`` recorded on the compute stream behind
+    the step that consumed it -- the order does not rest on the host reading every step's loss back."""
 
     MIN_BYTES = 16 << 20
 
     @staticmethod
-    def make(data, N, batch_size, device):
+    def make(data, N, batch_size, device, reuse=None):
         device = torch.device(device)
         if (device.type != "cuda" or not torch.is_tensor(data) or data.is_cuda or data.dtype != torch.float32 or data.dim() < 2
                 or not config.fit_prefetch or N <= batch_size):
             return None
         if min(batch_size, N) * data[0].numel() * 4 < _BatchFeed.MIN_BYTES:
             return None
+        if reuse is not None and reuse.fits(data, N, batch_size, device):
+            reuse.rebind(data)
+            return reuse
         return _BatchFeed(data, N, batch_size, device)
 
     def __init__(self, data, N, batch_size, device):
@@ -74,9 +78,27 @@ class _BatchFeed:
         self.pin = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
         self.dev = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
         self.up = [torch.cuda.Event() for _ in range(2)]
+        self.used = [None, None]                                  # recorded behind the last step that read dev[j]
         self.copy_stream = torch.cuda.Stream(device=device)
         self.staged = -1
         self.stage(0)
+
+    def fits(self, data, N, batch_size, device) -> bool:
+        return (self.N == N and self.bs == batch_size and self.device == device
+                and tuple(self.pin[0].shape[1:]) == tuple(data.shape[1:]))
+
+    def rebind(self, data) -> None:
+        """the next epoch's (permuted) data set through the same buffers, stream and events"""
+        self.data, self.staged = data, -1
+        self.stage(0)
+
+    def done(self, idx) -> None:
+        """the step on the batch that begins at row idx has been issued: its device buffer may be overwritten once the compute
+        stream gets here"""
+        j = (idx // self.bs) & 1
+        if self.used[j] is None:
+            self.used[j] = torch.cuda.Event()
+        self.used[j].record(torch.cuda.current_stream(self.device))
 
     def stage(self, idx):
         """start the hand-over of the batch that begins at row idx (no-op beyond the data set or when already staged)"""
@@ -87,6 +109,8 @@ class _BatchFeed:
         self.up[j].synchronize()                                  # (the upload that last read this pinned buffer: two batches ago)
         self.pin[j][:n].copy_(self.data[idx: idx + n])
         with torch.cuda.stream(self.copy_stream):
+            if self.used[j] is not None:
+                self.copy_stream.wait_event(self.used[j])        # (the last step that read dev[j])
             self.dev[j][:n].copy_(self.pin[j][:n], non_blocking=True)
             self.up[j].record(self.copy_stream)
         self.staged = idx
@@ -836,6 +860,7 @@ class Flow(torch.nn.Module):
             torch.cuda.current_stream(device).wait_stream(self.__dict__.get("_fit_stream", side))
 
     def _fit_epochs(self, model, optim, data_train, N, epochs, batch_size, shuffle, gradient_clip, device, epoch_losses):
+        feed = None
         for _ in range(epochs):
             losses = []
             if shuffle:
@@ -843,7 +868,8 @@ class Flow(torch.nn.Module):
                 data = data_train[perm][0]
             else:
                 data = data_train[np.arange(N)][0]
-            feed = _BatchFeed.make(data, N, batch_size, device)     # large host batches: the next one crosses PCIe under this step
+            # large host batches: the next one crosses PCIe under this step (one feed for all epochs)
+            feed = _BatchFeed.make(data, N, batch_size, device, feed)
             for idx in range(0, N, batch_size):
                 if feed is not None:
                     sample = feed.take(idx)
@@ -880,6 +906,8 @@ class Flow(torch.nn.Module):
                     # (drop the step's autograd graph now: it keeps the parameters' AccumulateGrad nodes alive, and those are
                     # bound to the stream they were created on -- a later capture of the step must create its own)
                     del loss
+                if feed is not None:
+                    feed.done(idx)
                 if not self.is_feasible():
                     raise RuntimeError("Model is not invertible")
                 model.transform.clear_cache()
