@@ -259,7 +259,7 @@ def run_also(args):
             rec.update({"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
                         "steps": o["steps"], "warmup": o["warmup"], "rows_per_gpu": o["config"]["rows_per_gpu"],
                         "roofline": {k: rl.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
-                                                            "share_of_gpu_time", "kernel_ms_per_step")} if rl else None,
+                                                            "share_of_gpu_time", "kernel_ms_per_step", "launch_bound")} if rl else None,
                         "parity": parity or None, "train_step": o.get("train_step"),
                         "cpu_baseline": ({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None),
                         "mean_log_prob": o.get("mean_log_prob"), "backend": o.get("backend"),
@@ -631,6 +631,10 @@ def main_flat(args, under_launcher):
                                             for k, v in tot.items()},
                     "launch_classes_ms_per_step": {fn: round(ms_ / max(train_timed_steps, 1), 3) for fn, (_n, ms_) in train_classes.items()},
                     "wgrad_share_of_step": round(sum(tot.values()) / max(train_timed_steps, 1) / ms_per_step, 3)}
+    if mode == "fit" and roofline is not None:
+        #  Flow.fit at the reference's batch is a chain of dependent launches: no kernel roofline applies
+        roofline.update({"bound": "launch", "frac": None, "achieved": None, "peak": None, "unit": None,
+                         "peak_is": "no kernel roofline applies: the replayed step is bound by the number of dependent launches"})
     if roofline is not None and on_gpu and roofline.get("bound") == "mfma" and "bf16" in str(roofline.get("peak_is", "")):
         # the ceiling this part SUSTAINS for the kernels' matrix-core instruction mix, measured in THIS run right behind the timed
         # region (usf_mfma_probe: a register-only loop of v_mfma_f32_16x16x32_bf16 at the GEMM's occupancy and tiling; under
@@ -806,7 +810,10 @@ def main_flat(args, under_launcher):
 # ----------------------------------------------------------------------------------------------------------------------
 _IMAGE_KERNELS = ("usf_radial_logprob_f32", "usf_radial_logprob_grad_f32", "usf_conv2d_same_f32", "usf_conv2d_same_res_f32", "usf_channel_affine_f32", "usf_pointwise_conv_f32", "usf_layernorm_channels_f32",
                   "usf_gated_residual_f32", "usf_masked_residual_f32", "usf_base_logprob_f32", "usf_conv_wgrad_f32", "usf_conv2d_same_gate_f32",
-                  "usf_layernorm_channels_bwd_f32", "usf_gated_residual_bwd_f32")
+                  "usf_layernorm_channels_bwd_f32", "usf_gated_residual_bwd_f32", "usf_gated_tail_f32", "usf_gated_tail_bwd_f32",
+                  "usf_conv_wgrad_jobs_f32", "usf_partial_sum_jobs_f32", "usf_conv2d_weight_planes_batch_f32")
+LAUNCH_BOUND_ROWS = 1024      # image training at or below this batch is a chain of dependent ~5 us launches: no kernel roofline applies
+LAUNCH_FLOOR_US = 4.7         # a dependent launch inside the replayed graph (ordered kernel trace, profiles/r05_live_fit32_trace_after.txt)
 
 
 def _image_launch_cost(name, a):
@@ -857,6 +864,12 @@ def _image_launch_cost(name, a):
     if name == "usf_gated_residual_bwd_f32":       # (dy, vg, dvg, B, CP, stream)
         B, CP = int(a[3]), int(a[4])
         return ("gated_residual_bwd", CP), 8.0 * B * CP, 20.0 * B * CP
+    if name == "usf_gated_tail_f32":               # (h, x, y, B, C, P, W, ...): 1 x 1 convolution C -> 2 C + gate + skip + layer norm
+        B, C, P = int(a[3]), int(a[4]), int(a[5])
+        return ("gated_tail", C, P), 2.0 * B * P * C * 2 * C, 12.0 * B * C * P
+    if name == "usf_gated_tail_bwd_f32":           # (h, x, dy, dx, dh, dvg, B, C, P, ...): forward again + W^T product + dW
+        B, C, P = int(a[6]), int(a[7]), int(a[8])
+        return ("gated_tail_bwd", C, P), 3 * 2.0 * B * P * C * 2 * C, 20.0 * B * C * P
     return (name,), 0.0, 0.0
 
 
@@ -1044,6 +1057,16 @@ def main_image(args, under_launcher):
         if eager_timing is not None:
             roofline["measured_by"] = ("HIP events around every launch of three eager steps of this run, before the timed region "
                                        "(the timed steps are hipGraph replays, as in Flow.fit)")
+        if mode == "train" and B <= LAUNCH_BOUND_ROWS:
+            # a kernel roofline fraction says nothing about a step that is a chain of dependent launches of a
+            # few microseconds each -- what bounds it is their NUMBER times the launch floor
+            n_usf = sum(v["n"] for v in classes.values()) // n_timed
+            roofline.update({"bound": "launch", "frac": None, "achieved": None, "peak": None, "unit": None,
+                             "peak_is": "no kernel roofline applies: the step is bound by the number of dependent launches",
+                             "launch_bound": {"library_launches_per_step": n_usf, "floor_us_per_launch": LAUNCH_FLOOR_US,
+                                              "floor_ms": round(n_usf * LAUNCH_FLOOR_US * 1e-3, 3), "ms_per_step": round(ms_per_step, 3),
+                                              "note": "torch's own launches of the loss / log-det / optimiser glue (~50 per step) are not "
+                                                      "counted; ordered trace of one replayed step: profiles/r05_live_fit32_trace_after.txt"}})
 
     # ---- CPU baseline + parity: the image oracle (torch-CPU restatement of the reference's image path) on a bounded
     # sample of the same rows; rank 0 at N = 1 only ----
