@@ -623,6 +623,24 @@ typedef struct usf_gated_norm_desc {
   int32_t act, reserved;
 } usf_gated_norm_desc;
 int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream);
+/* The backward twin (ABI 34): what torch.autograd derives from GatedMLP's gate (networks.py:222-245) and LayerNormVector
+ * (:206-219) in Flow.fit, rows of [M, C] fp32, r / mean / variance recomputed from (skip, vg) as the forward computes them:
+ *     g = dy * gamma;  dr = (g - mean_c g - xh * mean_c(g xh)) / sqrt(var r + eps)        (gamma == NULL: dr = dy)
+ *     d_skip = dr;  d_vg[:, :C] = dr * sigmoid(gate);  d_vg[:, gate_off:] = dr * val * sigmoid(gate) (1 - sigmoid(gate))
+ *     dy_xh = dy * xh  (optional, needs gamma: dgamma = its column sums, dbeta = the column sums of dy -- usf_colsum_f32)
+ * Columns [C, c_pad) of every output are written as zeros (operand padding of the GEMMs that follow); gate_off >= c_pad. */
+typedef struct usf_gated_norm_bwd_desc {
+  const float* skip;   int64_t ld_skip;
+  const float* vg;     int64_t ld_vg;    int64_t gate_off;
+  const float* gamma;
+  const float* dy;     int64_t ld_dy;
+  float*       d_skip; int64_t ld_d_skip;
+  float*       d_vg;   int64_t ld_d_vg;
+  float*       dy_xh;  int64_t ld_dy_xh;
+  int64_t M, C, c_pad;
+  float eps, reserved;
+} usf_gated_norm_bwd_desc;
+int usf_gated_norm_rows_bwd_f32(const usf_gated_norm_bwd_desc* d, usf_stream_t stream);
 
 /*
  * Run a prebuilt list of ops with ONE call (the whole flow: ~2K+2 launches). op.kind selects the

@@ -537,6 +537,62 @@ def _emu_colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0, defer=True):
     o.copy_((alpha * _view(Y, y_off, M, N, ldy).double().sum(0) + (beta * o.double() if beta != 0.0 else 0.0)).float())
 
 
+def _emu_gated_norm_rows(skip, *, M, C_cols, c_pad=None, ld_skip=None, vg=None, ld_vg=0, gate_off=0, gamma=None, beta=None, eps=1e-5,
+                         out=None, ld_out=0, out_act=None, ld_act=0, act=_ext.ACT_NONE, slope=0.0, dtype=torch.float64):
+    """usf_gated_norm_rows_f32 (include/usflows_hip.h) on raw buffers"""
+    Cn, Cp = C_cols, c_pad if c_pad is not None else C_cols
+    r = _view(skip, 0, M, Cn, ld_skip if ld_skip is not None else Cn).to(dtype)
+    if vg is not None:
+        r = r + _view(vg, 0, M, Cn, ld_vg).to(dtype) * torch.sigmoid(_view(vg, gate_off, M, Cn, ld_vg).to(dtype))
+    if gamma is not None:
+        mean = r.mean(dim=1, keepdim=True)
+        var = ((r - mean) ** 2).mean(dim=1, keepdim=True)
+        r = (r - mean) / torch.sqrt(var + eps) * gamma[:Cn].to(dtype) + beta[:Cn].to(dtype)
+    full = torch.zeros(M, Cp, dtype=dtype)
+    full[:, :Cn] = r
+    if out is not None:
+        _view(out, 0, M, Cp, ld_out).copy_(full.float())
+    if out_act is not None:
+        a = torch.where(full > 0, full, full * slope) if act == _ext.ACT_LEAKY_RELU else full
+        _view(out_act, 0, M, Cp, ld_act).copy_(a.float())
+
+
+def _emu_gated_norm_rows_bwd(skip, dy, d_skip, *, M, C_cols, c_pad, ld_skip, ld_dy, ld_d_skip, vg=None, ld_vg=0, gate_off=0, d_vg=None,
+                             ld_d_vg=0, gamma=None, eps=1e-5, dy_xh=None, ld_dy_xh=0, dtype=torch.float64):
+    """usf_gated_norm_rows_bwd_f32 (include/usflows_hip.h): the formulas of the header, not autograd"""
+    Cn, Cp = C_cols, c_pad
+    r = _view(skip, 0, M, Cn, ld_skip).to(dtype)
+    val = sg = None
+    if vg is not None:
+        val = _view(vg, 0, M, Cn, ld_vg).to(dtype)
+        sg = torch.sigmoid(_view(vg, gate_off, M, Cn, ld_vg).to(dtype))
+        r = r + val * sg
+    g = _view(dy, 0, M, Cn, ld_dy).to(dtype)
+    if gamma is not None:
+        mean = r.mean(dim=1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((r - mean) ** 2).mean(dim=1, keepdim=True) + eps)
+        xh = (r - mean) * rstd
+        if dy_xh is not None:
+            full = torch.zeros(M, Cp, dtype=dtype)
+            full[:, :Cn] = g * xh
+            _view(dy_xh, 0, M, Cp, ld_dy_xh).copy_(full.float())
+        g = g * gamma[:Cn].to(dtype)
+        g = (g - g.mean(dim=1, keepdim=True) - xh * (g * xh).mean(dim=1, keepdim=True)) * rstd
+    full = torch.zeros(M, Cp, dtype=dtype)
+    full[:, :Cn] = g
+    _view(d_skip, 0, M, Cp, ld_d_skip).copy_(full.float())
+    if d_vg is not None:
+        a, b = torch.zeros(M, Cp, dtype=dtype), torch.zeros(M, Cp, dtype=dtype)
+        a[:, :Cn] = g * sg
+        b[:, :Cn] = g * val * sg * (1 - sg)
+        _view(d_vg, 0, M, Cp, ld_d_vg).copy_(a.float())
+        _view(d_vg, gate_off, M, Cp, ld_d_vg).copy_(b.float())
+
+
+def _emu_add_rows(x, t, ones):
+    x.add_(t)
+
+
 def _emu_act_grad(d, h, *, M, H, ldd, ldh, act, slope):
     if act == _ext.ACT_NONE:
         return
@@ -605,6 +661,9 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "wgrad", _emu_wgrad)
     monkeypatch.setattr(_ext, "colsum", _emu_colsum)
     monkeypatch.setattr(_ext, "act_grad", _emu_act_grad)
+    monkeypatch.setattr(_ext, "gated_norm_rows", _emu_gated_norm_rows)
+    monkeypatch.setattr(_ext, "gated_norm_rows_bwd", _emu_gated_norm_rows_bwd)
+    monkeypatch.setattr(_ext, "add_rows", _emu_add_rows)
     monkeypatch.setattr(_ext, "base_logprob", _emu_base_logprob)
     monkeypatch.setattr(_ext, "base_logprob_grad", _emu_base_logprob_grad)
     monkeypatch.setattr(_ext, "base_param_grad", _emu_base_param_grad)

@@ -21,12 +21,15 @@ import make_golden as mg  # noqa: E402
 from golden_util import load_case  # noqa: E402
 
 # (case, prior_scale): with a prior scale the loss carries -log_prior() (LUTransform.log_prior, transforms.py:1371-1379)
-CASES = [("synth_d7_k3_hh0_laplace", None), ("synth_d16_k3_hh1_radial2", None), ("synth_d7_k3_hh1_conj_normal", 0.5)]
+CASES = [("synth_d7_k3_hh0_laplace", None), ("synth_d16_k3_hh1_radial2", None), ("synth_d7_k3_hh1_conj_normal", 0.5),
+         ("synth_d16_k3_convnet_gated_ln", None)]      # (round 5: the vector ConvNet conditioner with GatedMLP / LayerNormVector blocks)
 LR, NP_SEED, N_ROWS, BATCH, EPOCHS = 1e-3, 5, 96, 32, 2
 
 
 def main():
     for name, prior_scale in CASES:
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         spec, sd, a = load_case(name)
         seed = int(np.load(os.path.join(HERE, name + ".npz"))["seed"])
         flow = mg.build_reference(spec, seed)

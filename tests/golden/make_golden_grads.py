@@ -23,11 +23,15 @@ from golden_util import load_case  # noqa: E402
 
 CASES = ["synth_d7_k3_hh0_laplace", "synth_d7_k3_hh1_conj_normal", "synth_d16_k4_hh2_conj_laplace",
          "synth_d16_k3_hh1_radial2", "synth_d16_k4_hh0_conj_radial1", "synth_d16_k3_hh0_radialinf",
-         "synth_d7_k3_soft_ctx", "synth_d16_k3_densenn_relu", "synth_d33_k3_lu2_hh1"]
+         "synth_d7_k3_soft_ctx", "synth_d16_k3_densenn_relu", "synth_d33_k3_lu2_hh1",
+         # round 5: the vector ConvNet conditioner (GatedMLP / LayerNormVector blocks, networks.py:206-245, 287-308) under autograd
+         "synth_d16_k3_convnet_gated_ln", "synth_d33_k2_convnet_gated_conj", "synth_d64_k3_convnet_ln", "init_d4_k2_convnet_default"]
 
 
 def main():
     for name in CASES:
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         spec, sd, a = load_case(name)
         seed = int(np.load(os.path.join(HERE, name + ".npz"))["seed"])
         flow = mg.build_reference(spec, seed)

@@ -337,3 +337,52 @@ def test_planes_entry_points_reject_what_they_cannot_serve():
     with pytest.raises(RuntimeError, match="usf_wgrad_bias_ok"):            # 1024 rows: the exact-f32 kernel carries no column sums
         ext.wgrad(Y32, A32, G, M=1024, N=N, K=K, ldy=N, lda=K, ldg=K, mode=1, colsum=torch.empty(N, device=DEV))
     assert lib.usf_split_planes_f32(Y32.data_ptr(), N, 4096, N, Yp.data_ptr() + 2, Yp.shape[2], Yp.shape[1] * Yp.shape[2], st) == -1
+
+
+@pytest.mark.parametrize("C,gated,ln,M", [(40, True, True, 37), (130, True, False, 5), (33, False, True, 300), (256, True, True, 2049),
+                                          (7, False, True, 1)])
+def test_gated_norm_rows_backward_vs_fp64_autograd(C, gated, ln, M):
+    """usf_gated_norm_rows_bwd_f32 (the backward twin of the vector ConvNet's row pass: GatedMLP's gate + LayerNormVector,
+    reference networks.py:206-245) against fp64 autograd of the same formulas; padding columns written as zeros"""
+    from usflows_amd import _ext
+    g = torch.Generator().manual_seed(C + M)
+    cp = (C + 3) // 4 * 4
+    ld, ldv = cp + 8, 2 * cp + 12
+    skip = torch.randn(M, ld, generator=g).to(DEV)
+    vg = torch.randn(M, ldv, generator=g).to(DEV) if gated else None
+    dy = torch.randn(M, ld, generator=g).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).to(DEV) if ln else None
+    d_skip = torch.full((M, ld), 7.0, device=DEV)
+    d_vg = torch.full((M, ldv), 7.0, device=DEV) if gated else None
+    dy_xh = torch.full((M, ld), 7.0, device=DEV) if ln else None
+    _ext.gated_norm_rows_bwd(skip, dy, d_skip, M=M, C_cols=C, c_pad=cp, ld_skip=ld, ld_dy=ld, ld_d_skip=ld, vg=vg, ld_vg=ldv, gate_off=cp,
+                             d_vg=d_vg, ld_d_vg=ldv, gamma=gamma, eps=1e-5, dy_xh=dy_xh, ld_dy_xh=ld)
+    s6 = skip[:, :C].double().requires_grad_(True)
+    r = s6
+    if gated:
+        v6 = vg.double().requires_grad_(True)
+        r = r + v6[:, :C] * torch.sigmoid(v6[:, cp: cp + C])
+    if ln:
+        g6 = gamma.double().requires_grad_(True)
+        mean = r.mean(dim=1, keepdim=True)
+        var = ((r - mean) ** 2).mean(dim=1, keepdim=True)
+        xh = (r - mean) / torch.sqrt(var + 1e-5)
+        r = xh * g6
+    r.backward(dy[:, :C].double())
+    close = lambda a_, b_, what: _assert_close(a_, b_, what)      # noqa: E731
+    close(d_skip[:, :C], s6.grad, "d_skip")
+    assert (d_skip[:, C:cp] == 0).all() and (d_skip[:, cp:] == 7.0).all()
+    if gated:
+        close(d_vg[:, :C], v6.grad[:, :C], "d_val")
+        close(d_vg[:, cp: cp + C], v6.grad[:, cp: cp + C], "d_gate")
+        assert (d_vg[:, C:cp] == 0).all() and (d_vg[:, cp + C: 2 * cp] == 0).all() and (d_vg[:, 2 * cp:] == 7.0).all()
+    if ln:
+        close(dy_xh[:, :C].sum(0), g6.grad, "dgamma = colsum(dy * xh)")
+        assert (dy_xh[:, C:cp] == 0).all()
+
+
+def _assert_close(got, want, what, tol=2e-5):
+    got, want = got.double().cpu(), want.double().cpu()
+    s_ = max(want.abs().max().item(), 1e-30)
+    err = (got - want).abs().max().item()
+    assert err <= tol * s_, f"{what}: max abs err {err:.3e} vs scale {s_:.3e}"

@@ -13,7 +13,9 @@ import emulator
 CASES = ["synth_d7_k3_hh0_laplace", "synth_d16_k3_densenn_relu", "synth_d7_k3_hh1_conj_normal",
          "synth_d16_k4_hh2_conj_laplace", "synth_d33_k3_lu2_hh1", "synth_d7_k3_soft_ctx", "synth_d64_k6_hh0_laplace",
          "init_d2_k4_hh0_laplace", "synth_d16_k3_hh0_radialinf", "synth_d16_k3_hh1_radial2",
-         "synth_d16_k4_hh0_conj_radial1"]
+         "synth_d16_k4_hh0_conj_radial1",
+         # the vector ConvNet conditioner with GatedMLP / LayerNormVector blocks (training.py: _coupling_backward_general)
+         "synth_d16_k3_convnet_gated_ln", "synth_d33_k2_convnet_gated_conj", "synth_d64_k3_convnet_ln", "init_d4_k2_convnet_default"]
 
 
 @pytest.fixture(autouse=True)

@@ -199,6 +199,8 @@ def test_device_gradients_match_the_real_reference(name):
     loss = -flow.log_prob(a["x"].to(DEV), ctx.to(DEV) if ctx is not None else None).mean()
     loss.backward()
     assert flow.engine().launch_count > before
+    # (the device training path took the call -- not the torch composite formulation: vector ConvNet conditioners included)
+    assert flow._train_obj is not None and not getattr(flow, "_train_failed", False)
     assert abs(loss.item() - loss_ref) <= 1e-5 * abs(loss_ref)
     checked = 0
     for pname, p in flow.named_parameters():

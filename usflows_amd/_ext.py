@@ -112,6 +112,14 @@ class GatedNormDesc(C.Structure):
                 ("act", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GatedNormBwdDesc(C.Structure):
+    """usf_gated_norm_bwd_desc: the backward twin of the row pass"""
+    _fields_ = [("skip", _fp), ("ld_skip", C.c_int64), ("vg", _fp), ("ld_vg", C.c_int64), ("gate_off", C.c_int64),
+                ("gamma", _fp), ("dy", _fp), ("ld_dy", C.c_int64), ("d_skip", _fp), ("ld_d_skip", C.c_int64),
+                ("d_vg", _fp), ("ld_d_vg", C.c_int64), ("dy_xh", _fp), ("ld_dy_xh", C.c_int64),
+                ("M", C.c_int64), ("C", C.c_int64), ("c_pad", C.c_int64), ("eps", C.c_float), ("reserved", C.c_float)]
+
+
 class CallDesc(C.Structure):
     """usf_call_desc: one entry-point call inside an op list, arguments as 64-bit words"""
     _fields_ = [("fn", C.c_int32), ("n_args", C.c_int32), ("a", C.c_uint64 * 20)]
@@ -204,6 +212,7 @@ SYMBOLS = {
                                              C.c_float, C.c_void_p]),
     "usf_gated_residual_f32": (C.c_int, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_gated_norm_rows_f32": (C.c_int, [C.POINTER(GatedNormDesc), C.c_void_p]),
+    "usf_gated_norm_rows_bwd_f32": (C.c_int, [C.POINTER(GatedNormBwdDesc), C.c_void_p]),
     "usf_pointwise_conv_supported": (C.c_int, [C.c_int64, C.c_int64, C.c_int32]),
     "usf_pointwise_conv_f32": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, _fp, C.c_int32, C.c_float,
                                          C.c_int32, C.c_float, _fp, _fp, _fp, C.c_float, C.c_void_p]),
@@ -851,6 +860,22 @@ def gated_norm_rows(skip, *, M, C_cols, c_pad=None, ld_skip=None, vg=None, ld_vg
                       gate_off=gate_off, gamma=ptr(gamma), beta=ptr(beta), out=ptr(out), ld_out=ld_out, out_act=ptr(out_act),
                       ld_act=ld_act, M=M, C=C_cols, c_pad=c_pad if c_pad is not None else C_cols, eps=eps, slope=slope, act=act)
     _launch("usf_gated_norm_rows_f32", (C.byref(d), current_stream(skip.device)), (d, skip, vg, gamma, beta, out, out_act))
+
+
+def gated_norm_rows_bwd(skip, dy, d_skip, *, M, C_cols, c_pad, ld_skip, ld_dy, ld_d_skip, vg=None, ld_vg=0, gate_off=0, d_vg=None,
+                        ld_d_vg=0, gamma=None, eps=1e-5, dy_xh=None, ld_dy_xh=0):
+    """usf_gated_norm_rows_bwd_f32 on raw [M, ld] fp32 buffers (see include/usflows_hip.h)"""
+    d = GatedNormBwdDesc(skip=skip.data_ptr(), ld_skip=ld_skip, vg=ptr(vg), ld_vg=ld_vg, gate_off=gate_off, gamma=ptr(gamma),
+                         dy=dy.data_ptr(), ld_dy=ld_dy, d_skip=d_skip.data_ptr(), ld_d_skip=ld_d_skip, d_vg=ptr(d_vg), ld_d_vg=ld_d_vg,
+                         dy_xh=ptr(dy_xh), ld_dy_xh=ld_dy_xh, M=M, C=C_cols, c_pad=c_pad, eps=eps)
+    _launch("usf_gated_norm_rows_bwd_f32", (C.byref(d), current_stream(skip.device)), (d, skip, vg, gamma, dy, d_skip, d_vg, dy_xh))
+
+
+def add_rows(x, t, ones) -> None:
+    """x += t for two [M, ld] fp32 buffers of equal row stride (usf_masked_residual_f32 with a mask of ones [ld]; taped)"""
+    M, ld = x.shape[0], x.shape[1]
+    _launch("usf_masked_residual_f32", (x.data_ptr(), t.data_ptr(), ones.data_ptr(), 1.0, x.data_ptr(), M, ld, current_stream(x.device)),
+            (x, t, ones))
 
 
 def masked_residual(x, t, one_minus_mask, sign):

@@ -112,6 +112,7 @@ int layernorm_channels(const float* x, float* y, int64_t B, int64_t C, int64_t P
                        float eps, int32_t act, float slope, hipStream_t stream);
 int gated_residual(const float* x, const float* vg, float* y, int64_t B, int64_t CP, hipStream_t stream);
 int gated_norm_rows(const usf_gated_norm_desc* d, hipStream_t stream);
+int gated_norm_rows_bwd(const usf_gated_norm_bwd_desc* d, hipStream_t stream);
 int pointwise_conv_supported(int64_t cin, int64_t cout, int32_t gated);
 int pointwise_conv(const float* x, float* y, int64_t B, int64_t cin, int64_t cout, int64_t P, const float* W, const float* bias,
                    int32_t in_act, float in_slope, int32_t out_act, float out_slope, const float* gate_x,
@@ -337,6 +338,9 @@ int usf_pointwise_conv_f32(const float* x, float* y, int64_t B, int64_t cin, int
 }
 int usf_gated_norm_rows_f32(const usf_gated_norm_desc* d, usf_stream_t stream) {
   return usf::gated_norm_rows(d, (hipStream_t)stream);
+}
+int usf_gated_norm_rows_bwd_f32(const usf_gated_norm_bwd_desc* d, usf_stream_t stream) {
+  return usf::gated_norm_rows_bwd(d, (hipStream_t)stream);
 }
 int usf_masked_residual_f32(const float* x, const float* t, const float* one_minus_mask, float sign, float* y, int64_t B,
                             int64_t CP, usf_stream_t stream) {

@@ -904,5 +904,109 @@ int gated_norm_rows(const usf_gated_norm_desc* d, hipStream_t stream) {
   return check_launch("usf_gated_norm_rows_f32");
 }
 
+// ------------------------------------------------------------------------------------------
+// usf_gated_norm_rows_bwd_f32: the backward twin.  With r, mean, rstd, xh = (r - mean) rstd recomputed from (skip, vg):
+//   g  = dy * gamma                                         (no layer norm: dr = dy)
+//   dr = (g - mean_c g - xh * mean_c (g xh)) * rstd         torch.nn.LayerNorm's backward over the C real columns
+//   d_skip = dr;   d_val = dr * s,  d_gate = dr * val * s (1 - s),  s = sigmoid(gate)
+//   dy_xh  = dy * xh    (optional: its column sums are dgamma; dbeta = the column sums of dy)
+// Padding columns [C, c_pad) of d_skip / d_vg (both halves) / dy_xh are written as zeros: they are operands of the
+// weight-gradient and data-gradient GEMMs.  One wave per row, the row in registers.
+// ------------------------------------------------------------------------------------------
+template <int NIT>
+__global__ __launch_bounds__(256) void gated_norm_rows_bwd_kernel(usf_gated_norm_bwd_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.M) return;
+  const int C = (int)d.C, CP = (int)d.c_pad;
+  const float* sk = d.skip + row * d.ld_skip;
+  const float* vg = d.vg ? d.vg + row * d.ld_vg : nullptr;
+  const float* dy = d.dy + row * d.ld_dy;
+  float r[NIT], val[NIT], sg[NIT], g[NIT];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    float v = 0.f;
+    val[it] = 0.f;
+    sg[it] = 0.f;
+    g[it] = 0.f;
+    if (c < C) {
+      v = sk[c];
+      if (vg) {
+        val[it] = vg[c];
+        sg[it] = 1.f / (1.f + expf(-vg[d.gate_off + c]));
+        v += val[it] * sg[it];
+      }
+      g[it] = dy[c];
+    }
+    r[it] = v;
+    sum += v;
+  }
+  float* dyx = d.dy_xh ? d.dy_xh + row * d.ld_dy_xh : nullptr;
+  if (d.gamma) {
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const float dv = (it * 64 + lane < C) ? r[it] - mean : 0.f;
+      r[it] = dv;
+      sq += dv * dv;
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) / (float)C + d.eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = it * 64 + lane;
+      r[it] *= rstd;                                            // xh
+      if (dyx && c < CP) dyx[c] = g[it] * r[it];
+      g[it] = (c < C) ? g[it] * d.gamma[c] : 0.f;
+      m1 += g[it];
+      m2 += g[it] * r[it];
+    }
+    m1 = wave_sum(m1) / (float)C;
+    m2 = wave_sum(m2) / (float)C;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) g[it] = (it * 64 + lane < C) ? (g[it] - m1 - r[it] * m2) * rstd : 0.f;   // dr
+  }
+  float* ds = d.d_skip + row * d.ld_d_skip;
+  float* dv = d.d_vg ? d.d_vg + row * d.ld_d_vg : nullptr;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 64 + lane;
+    if (c < CP) {
+      ds[c] = g[it];
+      if (dv) {
+        dv[c] = g[it] * sg[it];
+        dv[d.gate_off + c] = g[it] * val[it] * (sg[it] * (1.f - sg[it]));
+      }
+    }
+  }
+}
+
+int gated_norm_rows_bwd(const usf_gated_norm_bwd_desc* d, hipStream_t stream) {
+  if (!d) { set_error("usf_gated_norm_rows_bwd_f32: null descriptor"); return -1; }
+  if (d->M < 0 || d->C <= 0 || d->c_pad < d->C || d->c_pad > 4096) {
+    set_error("usf_gated_norm_rows_bwd_f32: bad sizes (1 <= C <= c_pad <= 4096)");
+    return -2;
+  }
+  if (d->M == 0) return 0;
+  if (!d->skip || !d->dy || !d->d_skip || ((d->vg == nullptr) != (d->d_vg == nullptr)) || (d->dy_xh && !d->gamma)) {
+    set_error("usf_gated_norm_rows_bwd_f32: null pointer (skip, dy, d_skip; vg and d_vg together; dy_xh only with gamma)");
+    return -1;
+  }
+  if (d->ld_skip < d->C || d->ld_dy < d->C || d->ld_d_skip < d->c_pad || (d->dy_xh && d->ld_dy_xh < d->c_pad) ||
+      (d->vg && (d->gate_off < d->c_pad || d->ld_vg < d->gate_off + d->C || d->ld_d_vg < d->gate_off + d->c_pad))) {
+    set_error("usf_gated_norm_rows_bwd_f32: row stride shorter than the row (gate_off >= c_pad)");
+    return -2;
+  }
+  const int64_t blocks = (d->M + 3) / 4;
+  if (blocks > 0x7fffffffLL) { set_error("usf_gated_norm_rows_bwd_f32: grid too large"); return -3; }
+  const dim3 g((unsigned)blocks), b(256);
+  if (d->c_pad <= 256) hipLaunchKernelGGL(gated_norm_rows_bwd_kernel<4>, g, b, 0, stream, *d);
+  else if (d->c_pad <= 1024) hipLaunchKernelGGL(gated_norm_rows_bwd_kernel<16>, g, b, 0, stream, *d);
+  else hipLaunchKernelGGL(gated_norm_rows_bwd_kernel<64>, g, b, 0, stream, *d);
+  return check_launch("usf_gated_norm_rows_bwd_f32");
+}
 
 }  // namespace usf

@@ -457,7 +457,10 @@ class FlowEngine:
                     pk["ladj_terms"].append((-1.0 if s.inverted else 1.0, la))
                 elif s.kind == "coupling":
                     pk["coupling"][i] = self._pack_coupling(i, s.module, device)
-                    convnet = convnet or isinstance(s.module.conditioner, ConvNet)
+                    # (a PLAIN-MLP ConvNet folds its last two Linears on the torch side: the pack cannot be replayed; the general
+                    # form -- GatedMLP / LayerNormVector blocks -- packs from the parameters' own storage like a DenseNN)
+                    cond_ = s.module.conditioner
+                    convnet = convnet or (isinstance(cond_, ConvNet) and (not cond_.is_vector or cond_.is_plain_mlp()))
             pk["ladj_total"] = self._ladj_total(pk)
         # replay needs every source to be the parameter's own storage (no staging copies) and no torch-side folding
         pk["replayable"] = (_copied_params[0] == copies0) and not convnet

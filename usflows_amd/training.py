@@ -35,7 +35,7 @@ from . import _ext
 from . import transforms as T
 from .config import config
 from .engine import FlowEngine, _round_up
-from .networks import ConditionalDenseNN, DenseNN
+from .networks import ConditionalDenseNN, ConvNet, DenseNN
 
 
 class TrainUnsupported(Exception):
@@ -81,7 +81,11 @@ class TrainPath:
             return False
         for s in eng.steps:
             if s.kind == "coupling" and not isinstance(s.module.conditioner, (ConditionalDenseNN, DenseNN)):
-                return False
+                # the vector ConvNet with GatedMLP / LayerNormVector blocks (networks.py:206-245, 287-308): chain of linear launches
+                # + row passes, backward in _coupling_backward_general
+                cond = s.module.conditioner
+                if not (isinstance(cond, ConvNet) and cond.is_vector and not cond.is_plain_mlp() and context is None):
+                    return False
             if s.kind == "scale" and s.inverted:
                 return False
         return True
@@ -197,6 +201,10 @@ class TrainPath:
                     raise TrainUnsupported(f"affine part {[type(t).__name__ for t in parts]}")
             elif m["kind"] == "coupling":
                 cond = self.eng.steps[m["step"]].module.conditioner
+                if isinstance(cond, ConvNet):
+                    if not plan["pk"]["coupling"][m["step"]].get("general"):
+                        raise TrainUnsupported("ConvNet conditioner without the general (block-wise) pack")
+                    continue
                 lin = [l for l in cond.layers]
                 has_ctx = isinstance(cond, ConditionalDenseNN)
                 h = [int(v) for v in cond.hidden_dims]
@@ -693,6 +701,10 @@ class TrainPath:
                             eng._fused_pack_bwd(pk, pk["coupling"][m["step"]])      # the transposed set of the fused kernel
                             continue
                         un = eng._unfused_pack(pk, pk["coupling"][m["step"]])
+                        if un.get("general"):
+                            for W in self._general_weights(un):
+                                self._transposed(pk, W)
+                            continue
                         for W, _b in un["layers"]:
                             self._transposed(pk, W)
                         self._transposed(pk, un["W_out"])
@@ -806,10 +818,178 @@ class TrainPath:
         return g_cur, g_other, g_ld
 
     # ---- coupling layers ------------------------------------------------------------------------------
+    @staticmethod
+    def _general_weights(un):
+        ws_ = [un["first"][0], un["W_out"]]
+        for e in un["blocks"]:
+            ws_ += [e[k][0] for k in ("lin", "l1", "l2", "proj") if k in e]
+        return ws_
+
+    def _coupling_backward_general(self, plan, m, g_cur, g_ld, grads):
+        """backward of a coupling layer whose conditioner is the vector ConvNet with GatedMLP / LayerNormVector blocks
+        (reference networks.py:206-245, 287-308; forward: engine._general_coupling_ops).  The conditioner runs once more from the
+        layer's saved input with every intermediate kept (x_j, f(x_j), the hidden activations, [val, gate], the projected skip),
+        then block by block backwards: usf_gated_norm_rows_bwd_f32 (layer norm + gate), usf_wgrad_f32 / usf_colsum_f32 for the
+        parameters, usf_linear_f32 on the transposed images for the data gradients (the (Leaky)ReLU derivative in its epilogue:
+        USF_ACT_GATE) -- what torch.autograd derives from the module under Flow.fit."""
+        eng = self.eng
+        ws, pk = plan["ws"], plan["pk"]
+        cp = pk["coupling"][m["step"]]
+        cond = eng.steps[m["step"]].module.conditioner
+        un = eng._unfused_pack(pk, cp)
+        raw = cp["raw"]
+        dev = raw["device"]
+        zbuf = ws[m["buf"]]
+        B = zbuf.shape[0]
+        LD, hm = eng.LD, eng.hmax
+        sign = m["sign"]
+        act, slope = cp["act"], cp["slope"]
+        r4 = lambda n: _round_up(n, 4)                                 # noqa: E731
+        own = f"_{m['step']}" if self._defer else ""                   # (queued gradient jobs read these after the layer loop)
+        buf = lambda tag, j, w=hm: self._buf(ws, f"GC{tag}{j}{own}", B, w)   # noqa: E731
+        first_m, blocks_m, final_m = cond.block_view()
+        nb = len(un["blocks"])
+        h0 = raw["h"][0]
+        pass_n, pass_off, tr_n, tr_off = cp["pass_n"], cp["pass_off"], cp["tr_n"], cp["tr_off"]
+        gate = lambda hbuf: dict(act=_ext.ACT_GATE, slope=slope, addend=hbuf, ldadd=hm) if act != _ext.ACT_NONE else {}   # noqa: E731
+        # ---- 1. forward again, everything kept ----
+        X = [buf("X", j) for j in range(nb + 1)]
+        A = [buf("A", j) for j in range(nb)]
+        Wf, bf = un["first"]
+        self._linear(pk, zbuf, pass_off, LD, Wf, X[0], 0, hm, B, Wf.shape[0], pass_n, bias=bf)
+        _ext.gated_norm_rows(X[0], M=B, C_cols=h0, c_pad=r4(h0), ld_skip=hm, out_act=A[0], ld_act=hm, act=act, slope=slope)
+        Tb, VG, S = {}, {}, {}
+        for j, e in enumerate(un["blocks"]):
+            wi, wo = e["w_in"], e["w_out"]
+            nxt = A[j + 1] if j + 1 < nb else None
+            ln = e.get("ln")
+            kw_ln = dict(gamma=ln[0], beta=ln[1], eps=e["eps"]) if ln is not None else {}
+            kw_act = dict(out_act=nxt, ld_act=hm, act=act, slope=slope) if nxt is not None else {}
+            Tb[j] = buf("T", j)
+            if "lin" in e:
+                W, b = e["lin"]
+                self._linear(pk, A[j], 0, hm, W, Tb[j], 0, hm, B, W.shape[0], W.shape[1], bias=b)
+                _ext.gated_norm_rows(Tb[j], M=B, C_cols=wo, c_pad=r4(wo), ld_skip=hm, out=X[j + 1], ld_out=hm, **kw_ln, **kw_act)
+            else:
+                W1, b1 = e["l1"]
+                W2, b2 = e["l2"]
+                self._linear(pk, A[j], 0, hm, W1, Tb[j], 0, hm, B, W1.shape[0], W1.shape[1], bias=b1, act=act, slope=slope)
+                VG[j] = buf("VG", j, 2 * hm)
+                self._linear(pk, Tb[j], 0, hm, W2, VG[j], 0, 2 * hm, B, W2.shape[0], W2.shape[1], bias=b2)
+                skip = X[j]
+                if "proj" in e:
+                    Wp, bp = e["proj"]
+                    S[j] = buf("S", j)
+                    self._linear(pk, X[j], 0, hm, Wp, S[j], 0, hm, B, Wp.shape[0], Wp.shape[1], bias=bp)
+                    skip = S[j]
+                _ext.gated_norm_rows(skip, M=B, C_cols=wo, c_pad=r4(wo), ld_skip=hm, vg=VG[j], ld_vg=2 * hm, gate_off=r4(wo),
+                                     out=X[j + 1], ld_out=hm, **kw_ln, **kw_act)
+        # ---- 2. the output Linear: Y = the gradient at the transformed half, A = x_nb ----
+        gimg = lambda tag: self._buf(ws, f"gWG{m['step']}_{tag}", max(2 * hm, LD), max(hm, LD))     # noqa: E731
+        gvec = lambda tag: self._buf(ws, f"gbG{m['step']}_{tag}", 1, max(2 * hm, LD))              # noqa: E731
+        W_out = un["W_out"]
+        w_last = un["blocks"][-1]["w_out"]
+        gW, gb = gimg("out"), gvec("out")
+        _ext.wgrad(g_cur, X[nb], gW, M=B, N=tr_n, K=W_out.shape[1], ldy=g_ld, lda=hm, ldg=gW.shape[1], y_off=tr_off, alpha=sign,
+                   mode=self._wmode)
+        tsel = self._sel_inv(raw["tr_idx"], dev)
+        self._scatter_weight(grads, final_m.weight, gW, rows_sel=tsel, n_rows=eng.D, cols_sel=None, n_cols=w_last)
+        _ext.colsum(g_cur, gb, M=B, N=tr_n, ldy=g_ld, y_off=tr_off, alpha=sign)
+        self._scatter_vec(grads, final_m.bias, gb, tsel, eng.D)
+        DX = [buf("DX", j) for j in range(nb + 1)]
+        Wt = self._transposed(pk, W_out)
+        self._linear(pk, g_cur, tr_off, g_ld, Wt, DX[nb], 0, hm, B, Wt.shape[0], Wt.shape[1])
+        # ---- 3. the blocks, last to first ----
+        for j in range(nb - 1, -1, -1):
+            e, bm = un["blocks"][j], blocks_m[j]
+            wi, wo = e["w_in"], e["w_out"]
+            ln = e.get("ln")
+            gated = "lin" not in e
+            skip = Tb[j] if not gated else (S[j] if "proj" in e else X[j])
+            DR = buf("DR", j)
+            DVG = buf("DVG", j, 2 * hm) if gated else None
+            DYX = buf("DYX", j) if ln is not None else None
+            _ext.gated_norm_rows_bwd(skip, DX[j + 1], DR, M=B, C_cols=wo, c_pad=r4(wo), ld_skip=hm, ld_dy=hm, ld_d_skip=hm,
+                                     vg=VG.get(j), ld_vg=2 * hm, gate_off=r4(wo), d_vg=DVG, ld_d_vg=2 * hm,
+                                     gamma=None if ln is None else ln[0], eps=e["eps"], dy_xh=DYX, ld_dy_xh=hm)
+            if ln is not None:
+                self._colsum_to(grads, bm["ln"].weight, DYX, B, wo, hm, sign)
+                self._colsum_to(grads, bm["ln"].bias, DX[j + 1], B, wo, hm, sign)
+            if not gated:
+                W, _b = e["lin"]
+                gW = gimg(f"l{j}")
+                _ext.wgrad(DR, A[j], gW, M=B, N=W.shape[0], K=W.shape[1], ldy=hm, lda=hm, ldg=gW.shape[1], alpha=sign, mode=self._wmode)
+                self._scatter_weight(grads, bm["lin"].weight, gW, None, wo, None, wi)
+                self._colsum_to(grads, bm["lin"].bias, DR, B, wo, hm, sign)
+                Wt = self._transposed(pk, W)
+                self._linear(pk, DR, 0, hm, Wt, DX[j], 0, hm, B, Wt.shape[0], Wt.shape[1], **gate(X[j]))
+                continue
+            W1, _b1 = e["l1"]
+            W2, _b2 = e["l2"]
+            # second Linear: Y = d[val, gate] (value rows [0, wp), gate rows [wp, 2 wp)), A = the hidden activations
+            gW = gimg(f"b{j}")
+            _ext.wgrad(DVG, Tb[j], gW, M=B, N=W2.shape[0], K=W2.shape[1], ldy=2 * hm, lda=hm, ldg=gW.shape[1], alpha=sign, mode=self._wmode)
+            self._scatter_weight(grads, bm["l2"].weight, gW, self._two_sel(wo, dev), 2 * wo, None, wo)
+            g2 = self._grad_slot(grads, bm["l2"].bias)
+            if g2 is not None:
+                _ext.colsum(DVG, g2[:wo], M=B, N=wo, ldy=2 * hm, alpha=sign)
+                _ext.colsum(DVG, g2[wo:], M=B, N=wo, ldy=2 * hm, y_off=r4(wo), alpha=sign)
+            DT = buf("DT", j)
+            Wt2 = self._transposed(pk, W2)
+            self._linear(pk, DVG, 0, 2 * hm, Wt2, DT, 0, hm, B, Wt2.shape[0], Wt2.shape[1], **gate(Tb[j]))
+            gW = gimg(f"a{j}")
+            _ext.wgrad(DT, A[j], gW, M=B, N=W1.shape[0], K=W1.shape[1], ldy=hm, lda=hm, ldg=gW.shape[1], alpha=sign, mode=self._wmode)
+            self._scatter_weight(grads, bm["l1"].weight, gW, None, wo, None, wi)
+            self._colsum_to(grads, bm["l1"].bias, DT, B, wo, hm, sign)
+            Wt1 = self._transposed(pk, W1)
+            if "proj" in e:
+                Wp, _bp = e["proj"]
+                gW = gimg(f"p{j}")
+                _ext.wgrad(DR, X[j], gW, M=B, N=Wp.shape[0], K=Wp.shape[1], ldy=hm, lda=hm, ldg=gW.shape[1], alpha=sign, mode=self._wmode)
+                self._scatter_weight(grads, bm["proj"].weight, gW, None, wo, None, wi)
+                self._colsum_to(grads, bm["proj"].bias, DR, B, wo, hm, sign)
+                # d x_j = f'(x_j) (dT W1) + dr Wp
+                self._linear(pk, DT, 0, hm, Wt1, DX[j], 0, hm, B, Wt1.shape[0], Wt1.shape[1], **gate(X[j]))
+                Wtp = self._transposed(pk, Wp)
+                self._linear(pk, DR, 0, hm, Wtp, DX[j], 0, hm, B, Wtp.shape[0], Wtp.shape[1], residual=DX[j], ldr=hm)
+            else:
+                # d x_j = f'(x_j) (dT W1) + dr (the skip connection; USF_ACT_GATE takes no residual: one elementwise launch more)
+                self._linear(pk, DT, 0, hm, Wt1, DX[j], 0, hm, B, Wt1.shape[0], Wt1.shape[1], **gate(X[j]))
+                _ext.add_rows(DX[j], DR, self._ones(hm, dev))
+        # ---- 4. the first Linear and the conditioning half of the gradient ----
+        gW = gimg("in")
+        _ext.wgrad(DX[0], zbuf, gW, M=B, N=Wf.shape[0], K=pass_n, ldy=hm, lda=LD, ldg=gW.shape[1], a_off=pass_off, alpha=sign,
+                   mode=self._wmode)
+        self._scatter_weight(grads, first_m.weight, gW, None, h0, self._sel_inv(raw["pass_idx"], dev), eng.D)
+        self._colsum_to(grads, first_m.bias, DX[0], B, h0, hm, sign)
+        if self._g_pending:
+            _ext.flush_jobs()          # the coupling layer before this one queued reads of columns this update rewrites
+        Wtf = self._transposed(pk, Wf)
+        self._linear(pk, DX[0], 0, hm, Wtf, g_cur, pass_off, g_ld, B, pass_n, Wtf.shape[1],
+                     residual=g_cur, r_off=pass_off, ldr=g_ld, res_sign=sign)
+
+    def _ones(self, n: int, device) -> torch.Tensor:
+        key = ("ones", n, str(device))
+        if key not in self._inv:
+            self._inv[key] = torch.ones(n, dtype=torch.float32, device=device)
+        return self._inv[key]
+
+    def _two_sel(self, wo: int, device) -> torch.Tensor:
+        """row selector of a GatedMLP's second Linear: parameter row i -> image row (value rows [0, wo) stay, gate rows
+        [wo, 2 wo) sit at [wp, wp + wo), wp = wo rounded up to 4)"""
+        key = ("twosel", wo, str(device))
+        if key not in self._inv:
+            t = torch.arange(2 * wo, dtype=torch.int32)
+            t[wo:] += _round_up(wo, 4) - wo
+            self._inv[key] = t.to(device)
+        return self._inv[key]
+
     def _coupling_backward(self, plan, m, g_cur, g_ld, grads):
         eng = self.eng
         ws, pk = plan["ws"], plan["pk"]
         cp = pk["coupling"][m["step"]]
+        if cp.get("general"):
+            return self._coupling_backward_general(plan, m, g_cur, g_ld, grads)
         layer = eng.steps[m["step"]].module
         cond = layer.conditioner
         un = eng._unfused_pack(pk, cp)
