@@ -278,3 +278,30 @@ def test_planes_training_path_gradients_match_oracle_autograd(D, K, hidden, conj
         assert err <= 2e-4 * ref.abs().max().item(), (pname, err, ref.abs().max().item())
         checked += 1
     assert checked >= 5
+
+
+@pytest.mark.parametrize("name", ["synth_d7_k3_hh0_laplace", "synth_d16_k4_hh2_conj_laplace", "synth_d16_k4_hh0_conj_radial1",
+                                  "synth_d16_k3_convnet_gated_ln"])
+def test_input_gradient_from_the_training_path(name):
+    """an input that requires grad (round 5): the node also returns d log_prob / dx -- the first layer's data gradient, divided
+    by the ScaleTransform's scale folded in front of it -- against autograd through the oracle; parameter gradients unchanged"""
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd)
+    x = a["x"].clone().requires_grad_(True)
+    g_lp = torch.randn(x.shape[0], generator=torch.Generator().manual_seed(2))
+    path = TrainPath(flow)
+    assert path.supported(x, None)
+    from usflows_amd import training
+    lp = training.log_prob_with_grad(path, x, None)
+    (lp * g_lp).sum().backward()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    x6 = a["x"].double().requires_grad_(True)
+    lp6 = orc.flow_log_prob(sd64, spec, x6, None)
+    (lp6 * g_lp.double()).sum().backward()
+    assert x.grad is not None and x.grad.shape == x.shape
+    s_ = x6.grad.abs().max().item()
+    assert (x.grad.double() - x6.grad).abs().max().item() <= 2e-5 * s_, name
+    # ... and once more (the recorded tape replays): same values
+    x2 = a["x"].clone().requires_grad_(True)
+    (training.log_prob_with_grad(path, x2, None) * g_lp).sum().backward()
+    assert torch.allclose(x2.grad, x.grad, rtol=1e-6, atol=1e-7 * s_)

@@ -214,6 +214,38 @@ def test_device_gradients_match_the_real_reference(name):
     assert checked >= 20
 
 
+@pytest.mark.parametrize("name", ["synth_d7_k3_hh1_conj_normal", "synth_d16_k4_hh0_conj_radial1", "synth_d64_k6_hh0_laplace",
+                                  "synth_d16_k3_convnet_gated_ln"])
+def test_input_gradient_on_the_device_path(name):
+    """``Flow.log_prob`` of an input that requires grad (it used to take the torch composite formulation):
+    the device training path returns d log_prob / dx as well -- against autograd through the fp64 oracle -- and the parameters'
+    gradients are the ones of a call whose input does not require grad"""
+    from oracle import usflows_oracle as orc_
+    spec, sd, a = load_case(name)
+    flow = build_flow(spec, sd, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(a["x"].shape[0], generator=g)
+    x = a["x"].to(DEV).requires_grad_(True)
+    before = flow.engine().launch_count
+    lp = flow.log_prob(x)
+    (lp * w.to(DEV)).sum().backward()
+    assert flow.engine().launch_count > before and flow._train_obj is not None and not getattr(flow, "_train_failed", False)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    x6 = a["x"].double().requires_grad_(True)
+    lp6 = orc_.flow_log_prob(sd64, spec, x6, None)
+    (lp6 * w.double()).sum().backward()
+    assert ((lp.detach().cpu().double() - lp6.detach()).abs() / lp6.detach().abs()).max().item() < 2e-5
+    s_ = x6.grad.abs().max().item()
+    assert (x.grad.cpu().double() - x6.grad).abs().max().item() <= 5e-5 * s_
+    grads_x = {k: p.grad.clone() for k, p in flow.named_parameters() if p.grad is not None}
+    for p in flow.parameters():
+        p.grad = None
+    (flow.log_prob(a["x"].to(DEV)) * w.to(DEV)).sum().backward()
+    for k, p in flow.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(grads_x[k], p.grad, rtol=1e-4, atol=1e-5 * float(p.grad.abs().max()) + 1e-12), k
+
+
 def test_fit_on_device_matches_reference_run():
     """Flow.fit on the MI355X (HIP forward + backward, launch tapes replayed from step 2, pack refreshed in place
     after every SGD step) against the golden run of the REAL reference's Flow.fit: per-epoch losses and every

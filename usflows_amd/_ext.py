@@ -346,11 +346,12 @@ TAPES_ENABLED = True
 
 
 class Tape:
-    __slots__ = ("entries", "stream")
+    __slots__ = ("entries", "stream", "dx")
 
     def __init__(self):
         self.entries = []
         self.stream = None
+        self.dx = None          # training.TrainPath: (buffer, row stride) the recorded backward leaves the input's gradient in
 
 
 class _ThreadState(threading.local):

@@ -286,10 +286,11 @@ class Flow(torch.nn.Module):
             from .training import TrainUnsupported, log_prob_with_grad
             try:
                 return log_prob_with_grad(path, x, context)
-            except TrainUnsupported:
+            except TrainUnsupported as e:
                 if dp:
                     raise RuntimeError("usflows_amd: data_parallel_training: this layer list has no device backward")
-                self._train_failed = True          # this layer list has no device backward: composite from now on
+                if not getattr(e, "input_grad_only", False):
+                    self._train_failed = True      # this layer list has no device backward: composite from now on
         if self._layer_loop_list_ok(x, context):
             out = self._layer_loop_listed(x)
             if out is not None:

@@ -67,8 +67,9 @@ class TrainPath:
     # ---- eligibility ----------------------------------------------------------------------------------
     def supported(self, x: torch.Tensor, context) -> bool:
         eng = self.eng
-        if eng is None or x.requires_grad or (context is not None and context.requires_grad):
+        if eng is None or (context is not None and context.requires_grad):
             return False
+        # (an input that requires grad -- round 5: the backward also returns d log_prob / dx, see ``_input_grad``)
         info = self.flow._base_info(x.device)
         if info is None:
             return False
@@ -129,14 +130,25 @@ class TrainPath:
         return self.eng._params()
 
     # ---- forward --------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, context):
+    def forward(self, x: torch.Tensor, context, want_dx: bool = False):
         eng = self.eng
         x = eng._check_input(x)
         B = x.shape[0]
         dev = x.device
         eng.keep_factors = True
-        plan = eng._plan("backward", B, dev, context is not None, "nat", train=True)
+        if want_dx:
+            # the input's gradient leaves the fp32-row backward (the planes backward ends in planes of the first layer's weight
+            # gradient operand, not in rows)
+            keep, eng.use_train_planes = eng.use_train_planes, False
+            try:
+                plan = eng._plan("backward", B, dev, context is not None, "nat", train=True)
+            finally:
+                eng.use_train_planes = keep
+        else:
+            plan = eng._plan("backward", B, dev, context is not None, "nat", train=True)
         self._check_plan(plan)
+        if want_dx:
+            self._check_input_grad(plan)
         eng._run(plan, x, None, context)
         zname, _, ldn = plan["out_buf"]
         info = self.flow._base_info(dev)
@@ -171,7 +183,7 @@ class TrainPath:
                                "(optimiser step or load_state_dict in between); the device training path keeps "
                                "activations, not parameter copies -- call backward() before changing parameters")
         if ctx.plan["ws"].get("_gen") != ws_gen:
-            _, ctx.plan, ctx.x, ctx.gen = self.forward(ctx.x, ctx.context)
+            _, ctx.plan, ctx.x, ctx.gen = self.forward(ctx.x, ctx.context, want_dx=getattr(ctx, "want_dx", False))
 
     @staticmethod
     def _base_ids(info):
@@ -258,8 +270,29 @@ class TrainPath:
                     W_split=planes, **kw)
 
     # ---- backward -------------------------------------------------------------------------------------
+    def _check_input_grad(self, plan) -> None:
+        """d log_prob / dx is served when the first layer of the plan is an affine block that reads the caller's tensor in its
+        natural order (what every USFlow layer list gives: [ScaleTransform folded,] BlockAffineTransform first)"""
+        first = plan["meta"][0] if plan["meta"] else None
+        # ("nat": a zero-padded copy of the caller's rows when D is not a multiple of 4 -- same order)
+        if first is None or first["kind"] != "affine" or first["in_buf"] not in ("user_in", "nat") or first["in_layout"] != "nat" \
+                or plan.get("planes_train"):
+            e = TrainUnsupported("input gradient: the layer list does not start with an affine block on the caller's tensor")
+            e.input_grad_only = True            # (parameter-only calls of this flow keep the device path: flows.Flow.log_prob)
+            raise e
+
+    def _input_grad(self, plan) -> torch.Tensor:
+        """d sum_m g_lp[m] log_prob[m] / dx [B, D] from the gradient the last backward pass left at the first layer's input"""
+        g, ld = self._dx
+        D = self.eng.D
+        dx = g[:, :D]
+        sm = plan["meta"][0]["pre_scale"]
+        if sm is not None:                                             # x' = x / scale in front of the block (ScaleTransform.backward)
+            dx = dx / sm.scale.detach().to(dx.device, torch.float32).reshape(1, D)
+        return dx.contiguous() if sm is None else dx
+
     def backward(self, plan, x, g_lp: torch.Tensor, gsum: Optional[torch.Tensor] = None,
-                 into_bound: bool = False) -> Dict[int, torch.Tensor]:
+                 into_bound: bool = False, want_dx: bool = False) -> Dict[int, torch.Tensor]:
         """gradients of sum_m g_lp[m] * log_prob(x)[m] w.r.t. every trainable parameter: id(param) -> tensor.
 
         The launch sequence depends only on the plan: it is recorded on the first call (``_ext.Tape``) and replayed
@@ -271,10 +304,12 @@ class TrainPath:
                          gsum=None if gsum is None else gsum.detach())
         pk = plan["pk"]
         arena = self._arena(plan)
-        tape = plan.get("bwd_tape")
+        self._want_dx = bool(want_dx)
+        tkey = "bwd_tape_dx" if want_dx else "bwd_tape"              # (the launch sequence differs: the first layer's data gradient)
+        tape = plan.get(tkey)
         usable = _ext.TAPES_ENABLED and pk.get("replayable", False)
         with torch.no_grad():
-            if usable and tape is not None and tape.stream == _ext.current_stream(dev) and plan.get("bwd_pk") is pk:
+            if usable and tape is not None and tape.stream == _ext.current_stream(dev) and plan.get(tkey + "_pk") is pk:
                 _ext.replay(tape)
             else:
                 tape = _ext.Tape() if usable else None
@@ -282,7 +317,10 @@ class TrainPath:
                     self._backward_body(plan, arena)
                 if tape is not None:
                     tape.stream = _ext.current_stream(dev)
-                plan["bwd_tape"], plan["bwd_pk"] = tape, pk
+                    tape.dx = getattr(self, "_dx", None)
+                plan[tkey], plan[tkey + "_pk"] = tape, pk
+            if want_dx and tape is not None:
+                self._dx = tape.dx                                     # (a replay writes the same buffer)
             self._last_arena = arena
             if into_bound:
                 # the node was built over bound gradients (bind_flat_grads; _LogProbFn took no parameter inputs): what
@@ -483,11 +521,12 @@ class TrainPath:
             for m in reversed(plan["meta"]):
                 if m["kind"] == "affine":
                     g_cur, g_other, g_ld = self._affine_backward(plan, m, g_cur, g_other, g_ld, aff, stacks,
-                                                                 need_dgrad=(m is not first_meta))
+                                                                 need_dgrad=(m is not first_meta) or self._want_dx)
                     self._g_pending = False
                 else:
                     self._coupling_backward(plan, m, g_cur, g_ld, grads)
                     self._g_pending = self._defer
+        self._dx = (g_cur, g_ld) if self._want_dx else None          # the gradient at the first layer's input (natural order)
         _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
 
     def _base_param_grads(self, ws, z, ldz, glp, B, base, loc, scale, grads):
@@ -708,7 +747,7 @@ class TrainPath:
                         for W, _b in un["layers"]:
                             self._transposed(pk, W)
                         self._transposed(pk, un["W_out"])
-                    elif m is not first_meta:
+                    elif m is not first_meta or getattr(self, "_want_dx", False):
                         which = "Minv" if m["prim"] == "affine_bwd" else "M"
                         self._mat_t(pk, m["blk"], which, m["out_layout"], m["in_layout"])
 
@@ -1457,7 +1496,8 @@ class _LogProbFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, path: TrainPath, x, context, *params):
-        lp, plan, xc, gen = path.forward(x, context)
+        ctx.want_dx = bool(ctx.needs_input_grad[1])
+        lp, plan, xc, gen = path.forward(x, context, want_dx=ctx.want_dx)
         ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
         ctx.params = params
         # bound gradients (TrainPath.bind_flat_grads): the only differentiable input is the path's anchor scalar; the
@@ -1472,9 +1512,9 @@ class _LogProbFn(torch.autograd.Function):
         if ctx.bound:
             path.backward(ctx.plan, ctx.x, g_lp, into_bound=True)
             return (None, None, None, path._anchor_zero)
-        grads = path.backward(ctx.plan, ctx.x, g_lp)
+        grads = path.backward(ctx.plan, ctx.x, g_lp, want_dx=ctx.want_dx)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
-        return (None, None, None) + out
+        return (None, path._input_grad(ctx.plan).reshape(ctx.x.shape) if ctx.want_dx else None, None) + out
 
 
 class _RadiusFn(torch.autograd.Function):
@@ -1484,7 +1524,8 @@ class _RadiusFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, path: TrainPath, x, context, *params):
-        r, plan, xc, gen = path.forward(x, context)
+        ctx.want_dx = bool(ctx.needs_input_grad[1])
+        r, plan, xc, gen = path.forward(x, context, want_dx=ctx.want_dx)
         ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
         ctx.params = params
         logdet = plan["pk"]["ladj_total"].neg32(r.device)
@@ -1498,9 +1539,9 @@ class _RadiusFn(torch.autograd.Function):
             g_r = torch.zeros(ctx.x.shape[0], dtype=torch.float32, device=ctx.x.device)
         if g_logdet is None:
             g_logdet = torch.zeros((), dtype=torch.float32, device=ctx.x.device)
-        grads = path.backward(ctx.plan, ctx.x, g_r, gsum=g_logdet)
+        grads = path.backward(ctx.plan, ctx.x, g_r, gsum=g_logdet, want_dx=ctx.want_dx)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
-        return (None, None, None) + out
+        return (None, path._input_grad(ctx.plan).reshape(ctx.x.shape) if ctx.want_dx else None, None) + out
 
 
 class _EmptyShardFn(torch.autograd.Function):
