@@ -1510,8 +1510,8 @@ class _LogProbFn(torch.autograd.Function):
         path: TrainPath = ctx.path
         path.revalidate(ctx)
         if ctx.bound:
-            path.backward(ctx.plan, ctx.x, g_lp, into_bound=True)
-            return (None, None, None, path._anchor_zero)
+            path.backward(ctx.plan, ctx.x, g_lp, into_bound=True, want_dx=ctx.want_dx)
+            return (None, path._input_grad(ctx.plan).reshape(ctx.x.shape) if ctx.want_dx else None, None, path._anchor_zero)
         grads = path.backward(ctx.plan, ctx.x, g_lp, want_dx=ctx.want_dx)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (None, path._input_grad(ctx.plan).reshape(ctx.x.shape) if ctx.want_dx else None, None) + out
@@ -1528,6 +1528,9 @@ class _RadiusFn(torch.autograd.Function):
         r, plan, xc, gen = path.forward(x, context, want_dx=ctx.want_dx)
         ctx.path, ctx.plan, ctx.x, ctx.context, ctx.gen = path, plan, xc, context, gen
         ctx.params = params
+        # bound gradients (as _LogProbFn): the only differentiable input is the path's anchor; backward adds the whole arena -- the
+        # base's loc included -- into the bound .grad views with one launch
+        ctx.bound = len(params) == 1 and params[0] is path.__dict__.get("_anchor")
         logdet = plan["pk"]["ladj_total"].neg32(r.device)
         return r, logdet
 
@@ -1539,6 +1542,9 @@ class _RadiusFn(torch.autograd.Function):
             g_r = torch.zeros(ctx.x.shape[0], dtype=torch.float32, device=ctx.x.device)
         if g_logdet is None:
             g_logdet = torch.zeros((), dtype=torch.float32, device=ctx.x.device)
+        if ctx.bound:
+            path.backward(ctx.plan, ctx.x, g_r, gsum=g_logdet, into_bound=True, want_dx=ctx.want_dx)
+            return (None, path._input_grad(ctx.plan).reshape(ctx.x.shape) if ctx.want_dx else None, None, path._anchor_zero)
         grads = path.backward(ctx.plan, ctx.x, g_r, gsum=g_logdet, want_dx=ctx.want_dx)
         out = tuple(grads.get(id(p)) if p.requires_grad else None for p in ctx.params)
         return (None, path._input_grad(ctx.plan).reshape(ctx.x.shape) if ctx.want_dx else None, None) + out
@@ -1572,7 +1578,10 @@ def log_prob_with_grad(path: TrainPath, x, context):
     info = path.flow._base_info(x.device)
     if info[0] == "radial":
         base = path.flow.base_distribution
-        r, logdet = _RadiusFn.apply(path, x, context, base.loc, *params)
+        if path.__dict__.get("use_bound_node", False) and path.grads_bound() and torch.is_grad_enabled():
+            r, logdet = _RadiusFn.apply(path, x, context, path._anchor)     # (Flow.fit's captured step: see below)
+        else:
+            r, logdet = _RadiusFn.apply(path, x, context, base.loc, *params)
         lp = None
         if config.radial:
             from . import radial
