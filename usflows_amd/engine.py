@@ -190,7 +190,7 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
             dev = out["ladj"].device
             bias = [_param(l.bias_vector, device) for l in part]
             b64 = _refreshed((len(part), D), torch.float64, dev,
-                             lambda o, bias=bias: torch.stack([v.double() for v in bias], out=o))
+                             lambda o, bias=bias: o.copy_(torch.stack(bias)))       # (one gather + one converting copy, not one per block)
             chunks.append(dict(lus=part, out=out, b=b64))
             for j, l in enumerate(part):
                 r = dict(M=out["M"][j], Minv=out["Minv"][j], b=b64[j], ladj=out["ladj"][j])
