@@ -182,6 +182,8 @@ int usf_coupling_padded_width(int h);   /* Hp of the padding contract for hidden
  *                             on the [M] vector: distributions.py:506-511)
  * loc/scale: [D] (scale unused for LPNORM*). If sum_out != NULL, sum_out[0] += sum_m logp[m] and
  * sum_out[1] += M (fp64 accumulators, for the data-parallel mean: one RCCL all-reduce of 2 scalars).
+ * The per-feature tables (loc; for LAPLACE / NORMAL also scale and the density's constant) live in LDS: D <= 8192 for
+ * LAPLACE / NORMAL, D <= 24576 for LPNORM*.
  */
 int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base,
                          const float* loc, const float* scale, float logdet_const, const double* logdet_dev,

@@ -35,31 +35,41 @@ __global__ __launch_bounds__(256) void base_logprob_kernel(const float* __restri
                                                            const double* __restrict__ logdet_dev,
                                                            float* __restrict__ logp, double* __restrict__ sum_out) {
   if (logdet_dev) logdet_const += (float)*logdet_dev;      // the constant as a device scalar: no host round trip
-  extern __shared__ __attribute__((aligned(16))) float cst_tab[];      // [D4 rounded] per-feature constants (or empty)
+  // per-feature tables in LDS, built once per block: loc | scale | the density's constant (the last two: Laplace / Normal only).
+  // Only the rows of z come from HBM in the row loop (round 5: with loc / scale re-read from global memory next to every 16 bytes
+  // of z the kernel streamed 2.9 TB/s)
+  extern __shared__ __attribute__((aligned(16))) float base_tab[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int waves_per_block = blockDim.x >> 6;
   double block_sum = 0.0;
   constexpr bool HAS_CST = (BASE == USF_BASE_LAPLACE || BASE == USF_BASE_NORMAL);
-  const bool vec = ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15u) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(loc) & 15u) == 0) &&
-                   (scale == nullptr || (reinterpret_cast<uintptr_t>(scale) & 15u) == 0);
+  const int Dp = (D + 3) & ~3;
+  float* const loc_t = base_tab;
+  float* const scale_t = base_tab + Dp;
+  float* const cst_t = base_tab + 2 * Dp;
+  const bool vec = ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(z) & 15u) == 0);
   const int D4 = vec ? (D & ~3) : 0;
-  if (HAS_CST) {
-    for (int d = threadIdx.x; d < D; d += blockDim.x) cst_tab[d] = base_const(scale[d], BASE);
-    __syncthreads();
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    loc_t[d] = loc[d];
+    if (HAS_CST) {
+      scale_t[d] = scale[d];
+      cst_t[d] = base_const(scale[d], BASE);
+    }
   }
+  __syncthreads();
   for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave_in_block; row < M;
        row += (int64_t)gridDim.x * waves_per_block) {
     const float* zr = z + row * ldz;
     float acc = 0.f;
+#pragma unroll 4
     for (int d = lane * 4; d < D4; d += 256) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(zr + d);
-      const f32x4 l = *reinterpret_cast<const f32x4*>(loc + d);
+      const f32x4 l = *reinterpret_cast<const f32x4*>(loc_t + d);
       f32x4 s = {1.f, 1.f, 1.f, 1.f}, c = {0.f, 0.f, 0.f, 0.f};
       if (HAS_CST) {
-        s = *reinterpret_cast<const f32x4*>(scale + d);
-        c = *reinterpret_cast<const f32x4*>(cst_tab + d);
+        s = *reinterpret_cast<const f32x4*>(scale_t + d);
+        c = *reinterpret_cast<const f32x4*>(cst_t + d);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -68,8 +78,8 @@ __global__ __launch_bounds__(256) void base_logprob_kernel(const float* __restri
       }
     }
     for (int d = D4 + lane; d < D; d += 64) {
-      const float s = HAS_CST ? scale[d] : 1.f;
-      const float t = base_term(zr[d], loc[d], s, HAS_CST ? cst_tab[d] : 0.f, BASE);
+      const float s = HAS_CST ? scale_t[d] : 1.f;
+      const float t = base_term(zr[d], loc_t[d], s, HAS_CST ? cst_t[d] : 0.f, BASE);
       acc = (BASE == USF_BASE_LPNORMINF) ? fmaxf(acc, t) : acc + t;
     }
     acc = (BASE == USF_BASE_LPNORMINF) ? wave_max(acc) : wave_sum(acc);
@@ -107,8 +117,8 @@ int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base
   int64_t blocks = (M + wpb - 1) / wpb;
   if (blocks > 256 * 8) blocks = 256 * 8;        // grid-stride: the per-feature constant table is built once per block
   dim3 g((unsigned)blocks), b(256);
-  const size_t tab = (base == USF_BASE_LAPLACE || base == USF_BASE_NORMAL) ? (size_t)((D + 3) / 4 * 4) * sizeof(float) : 0;
-  if (tab > 96 * 1024) { set_error("usf_base_logprob_f32: D = %lld too large for the constant table", (long long)D); return -2; }
+  const size_t tab = (size_t)((D + 3) / 4 * 4) * sizeof(float) * ((base == USF_BASE_LAPLACE || base == USF_BASE_NORMAL) ? 3 : 1);
+  if (tab > 96 * 1024) { set_error("usf_base_logprob_f32: D = %lld too large for the per-feature tables", (long long)D); return -2; }
   // (dynamic LDS above HIP's 64 KB default needs the kernel's limit raised -- once per instantiation)
 #define USF_LAUNCH_BASE(B)                                                                                            \
   do {                                                                                                                \
