@@ -187,6 +187,8 @@ ALSO = [
      ["--config", "mnist_image", "--steps", "10", "--warmup", "3", "--cpu-seconds", "2", "--cpu-rows", "2048"]),
     ("mnist_live log_prob: the live MNIST configuration (15 blocks, 3 gated layers, radial LogNormal base)",
      ["--config", "mnist_live", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "256"]),
+    ("mnist_live log_prob at 100 rows: the reference's evaluation chunk (hyperopt.py:273-278), the recorded op list replayed",
+     ["--config", "mnist_live", "--batch", "100", "--steps", "50", "--warmup", "10", "--cpu-seconds", "1", "--cpu-rows", "100", "--no-kernel-timing"]),
     ("cifar_image log_prob, live base (radial LogNormal, prior_scale 1)",
      ["--config", "cifar_image", "--base", "radial", "--prior-scale", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2", "--cpu-rows", "128"]),
     ("cfg2 log_prob through a one-rank nccl (RCCL) group: communicator init + the scalar all-reduce on the compute stream",

@@ -671,6 +671,7 @@ int usf_gated_norm_rows_bwd_f32(const usf_gated_norm_bwd_desc* d, usf_stream_t s
 #define USF_FN_CONV2D_SAME_RES 8
 #define USF_FN_BASE_LOGPROB 9
 #define USF_FN_RADIAL_LOGPROB 10
+#define USF_FN_GATED_TAIL 11
 #define USF_CALL_MAX_ARGS 20
 typedef struct usf_call_desc {
   int32_t fn;

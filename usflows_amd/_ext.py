@@ -398,7 +398,7 @@ def _timed_call(fn, args, name):
 # ---- a layer loop's calls as ONE op list (USF_OP_CALL; flows.py: image-shaped flows) ------------------------------------
 CALL_FNS = {"usf_scale_f32": 1, "usf_channel_affine_f32": 2, "usf_layernorm_channels_f32": 3, "usf_gated_residual_f32": 4,
             "usf_masked_residual_f32": 5, "usf_pointwise_conv_f32": 6, "usf_conv2d_same_f32": 7, "usf_conv2d_same_res_f32": 8,
-            "usf_base_logprob_f32": 9, "usf_radial_logprob_f32": 10}
+            "usf_base_logprob_f32": 9, "usf_radial_logprob_f32": 10, "usf_gated_tail_f32": 11}
 
 
 class CallList:

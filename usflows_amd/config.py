@@ -56,6 +56,7 @@ class Config:
         conv_res=True,             # conv kernel with MaskedCoupling's residual in its output stream
         pointwise=True,            # 1x1 convolutions on usf_pointwise_conv_f32
         batch_wplanes=True,        # image training, launch-bound batches: all convolution weights' planes from one launch per pass
+        gated_tail_infer_max_pixels=1 << 14,   # inference: the same kernel instead of the one-thread-per-pixel pass up to this many pixels
         gated_tail_max_pixels=1 << 16,   # ... up to this many pixels (eight lanes share a pixel: made for few pixels)
         gated_tail=True,           # image training, few pixels: GatedConv's 1x1 conv + gate + ReLU + layer norm as one launch each way
     )

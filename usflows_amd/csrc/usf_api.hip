@@ -525,8 +525,8 @@ static int run_call(const usf_call_desc* c, usf_stream_t stream) {
 #define J(i) ((int32_t)a[i])
   auto F = [&](int i) { float f; uint32_t u = (uint32_t)a[i]; memcpy(&f, &u, 4); return f; };
   auto Dbl = [&](int i) { double d; uint64_t u = a[i]; memcpy(&d, &u, 8); return d; };
-  static const int nargs[] = {0, 8, 8, 10, 5, 7, 16, 17, 16, 11, 17};
-  if (c->fn < 1 || c->fn > USF_FN_RADIAL_LOGPROB || c->n_args != nargs[c->fn]) {
+  static const int nargs[] = {0, 8, 8, 10, 5, 7, 16, 17, 16, 11, 17, 15};
+  if (c->fn < 1 || c->fn > USF_FN_GATED_TAIL || c->n_args != nargs[c->fn]) {
     usf::set_error("usf_run_ops: call op with unknown function %d or %d arguments", c->fn, c->n_args);
     return -2;
   }
@@ -538,6 +538,8 @@ static int run_call(const usf_call_desc* c, usf_stream_t stream) {
     case USF_FN_MASKED_RESIDUAL: return usf_masked_residual_f32(P(0), P(1), P(2), F(3), Q(4), I(5), I(6), stream);
     case USF_FN_POINTWISE_CONV:
       return usf_pointwise_conv_f32(P(0), Q(1), I(2), I(3), I(4), I(5), P(6), P(7), J(8), F(9), J(10), F(11), P(12), P(13), P(14), F(15), stream);
+    case USF_FN_GATED_TAIL:
+      return usf_gated_tail_f32(P(0), P(1), Q(2), I(3), I(4), I(5), P(6), P(7), J(8), F(9), J(10), F(11), P(12), P(13), F(14), stream);
     case USF_FN_CONV2D_SAME:
       return usf_conv2d_same_f32(P(0), Q(1), I(2), I(3), I(4), I(5), I(6), I(7), (const void*)(uintptr_t)a[8], P(9), P(10), J(11), F(12),
                                  J(13), F(14), P(15), I(16), stream);

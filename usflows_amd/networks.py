@@ -440,6 +440,12 @@ def _pointwise_hip(conv, x, in_act=None, gate_x=None, post=None):
     if post is not None:
         (oa, osl), lnm = post
         ln = (lnm.gamma.detach().reshape(-1).contiguous(), lnm.beta.detach().reshape(-1).contiguous(), lnm.eps)
+    if gate_x is not None and config.gated_tail and conv.out_channels == 2 * conv.in_channels and x.dim() == 4 \
+            and 0 < x.shape[0] * x.shape[2] * x.shape[3] <= config.gated_tail_infer_max_pixels and _ext.gated_tail_supported(conv.in_channels):
+        # few pixels (the reference evaluates in chunks of 100 rows, hyperopt.py:273-278): eight lanes per pixel instead of one
+        # thread walking all 2 C dot products -- usf_gated_tail_f32, the training path's forward (live MNIST configuration, 100
+        # rows: 19 -> 7 us per launch, 45 launches per log_prob)
+        return _ext.gated_tail(x.contiguous(), gate_x.contiguous(), cache[1], cache[2], ia, isl, oa, osl, ln)
     return _ext.pointwise_conv(x.contiguous(), cache[1], cache[2], in_act=ia, in_slope=isl, out_act=oa, out_slope=osl,
                                gate_x=None if gate_x is None else gate_x.contiguous(), ln=ln)
 
