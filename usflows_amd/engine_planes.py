@@ -291,7 +291,8 @@ class PlanesPlanMixin:
                         # (y - b) @ Minv^T == y @ Minv^T + c, c = -(Minv b) formed in fp64 at pack time ("bias folding")
                         if "c" not in a:
                             a["c"] = torch.empty(a["b"].shape, dtype=torch.float64, device=a["b"].device)
-                            _ext.flush_jobs()
+                            # (launched now, in front of the queued image jobs: it reads the prepared M^-1 and b only, and the job that
+                            # packs c runs with the batch behind the layout loop -- no flush: the images of ALL layers stay one batch)
                             _ext.matvec_f64(a["Minv"], a["b"].contiguous(), alpha=-1.0, out64=a["c"])
                         kw["bias"] = self._planes_vec(pk, ("pl_c", id(blk), lay), a["c"], out_sel).data_ptr()
                 else:
