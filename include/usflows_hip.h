@@ -850,6 +850,23 @@ int usf_split_planes_f32(const float* X, int64_t ldx, int64_t M, int64_t N, void
 int usf_wgrad_blocked_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, const void* A_planes, int64_t a_nkb, int64_t a_kb0,
                           int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out,
                           float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_stream_t stream);
+/* The reduction of usf_wgrad_blocked_f32 queued (round 5; large-batch training: 129 weight gradients per step end with a reduction of
+ * ~18 us each, one after the other although only the parameter update waits for them).  usf_wgrad_blocked_plan_f32 = the same call
+ * that launches the multiply kernel only and fills *job (HOST memory): G / colsum_out stay unwritten and the workspace stays in use
+ * until a usf_wgrad_reduce_jobs_f32 launch containing the job has run (jobs / block_job DEVICE arrays as for
+ * usf_partial_sum_jobs_f32: job j owns the blocks [first_block, first_block + blocks), first_block set by the caller).  Same
+ * additions in the same order as the undeferred call: same bits. */
+typedef struct usf_wreduce_job {
+  const float* part; float* out; const float* cs_part; float* cs_out;
+  int64_t rows, cols, ldo;
+  float alpha, beta, cs_alpha, cs_beta;
+  int32_t first_block, blocks;
+  unsigned char sched[64];                      /* the schedule's tile classes (opaque) */
+} usf_wreduce_job;
+int usf_wgrad_blocked_plan_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, const void* A_planes, int64_t a_nkb, int64_t a_kb0,
+                          int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out,
+                          float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_wreduce_job* job, usf_stream_t stream);
+int usf_wgrad_reduce_jobs_f32(const usf_wreduce_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream);
 
 /* Many small weight / bias gradients in ONE launch.  At the reference's training batch (32 rows, tests/explib/mnist.yaml:34)
  * Flow.fit's backward pass (flows.py:196-199) asks for one weight and one bias gradient per F.linear on the path -- some

@@ -282,7 +282,7 @@ def _emu_gemm_planes_call(A, W_planes, *, M, a_nkb, nk, a_kb0=0, bias=None, post
 
 
 def _emu_wgrad_blocked(Yp, y_nkb, y_kb0, Ap, a_nkb, a_kb0, G, *, M, N, K, ldg, g_off=0, alpha=1.0, beta=0.0, colsum=None,
-                       cs_alpha=1.0, cs_beta=0.0):
+                       cs_alpha=1.0, cs_beta=0.0, queue=None, ws=None):
     Y = planes_decode(_tensor_planes_view(Yp, M, y_nkb), M)[:, 32 * y_kb0: 32 * y_kb0 + N].double()
     A = planes_decode(_tensor_planes_view(Ap, M, a_nkb), M)[:, 32 * a_kb0: 32 * a_kb0 + K].double()
     g = _view(G, g_off, N, K, ldg)

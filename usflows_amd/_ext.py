@@ -166,6 +166,13 @@ class WgradJob(C.Structure):
                 ("lds_bytes", C.c_int32), ("first_block", C.c_int32)]
 
 
+class WReduceJob(C.Structure):
+    """usf_wreduce_job: one queued reduction of usf_wgrad_blocked_plan_f32 (usf_wgrad_reduce_jobs_f32)"""
+    _fields_ = [("part", _fp), ("out", _fp), ("cs_part", _fp), ("cs_out", _fp), ("rows", C.c_int64), ("cols", C.c_int64),
+                ("ldo", C.c_int64), ("alpha", C.c_float), ("beta", C.c_float), ("cs_alpha", C.c_float), ("cs_beta", C.c_float),
+                ("first_block", C.c_int32), ("blocks", C.c_int32), ("sched", C.c_ubyte * 64)]
+
+
 class GradJob(C.Structure):
     _fields_ = [
         ("Y", _fp), ("A", _fp), ("G", _fp),
@@ -265,6 +272,9 @@ SYMBOLS = {
                                        _fp, C.c_int64, _fp]),
     "usf_wgrad_blocked_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp,
                                         C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float, _fp, C.c_int64, _fp]),
+    "usf_wgrad_blocked_plan_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp,
+                                             C.c_int64, C.c_float, C.c_float, _fp, C.c_float, C.c_float, _fp, C.c_int64, C.c_void_p, _fp]),
+    "usf_wgrad_reduce_jobs_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "usf_base_param_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_mfma_probe": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
     "usf_wgrad_planes_colsum_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
@@ -1532,16 +1542,50 @@ def wgrad_planes(Yp, Ap, G, *, M, N, K, ldg, y_off=0, a_off=0, g_off=0, alpha=1.
 
 
 def wgrad_blocked(Yp, y_nkb, y_kb0, Ap, a_nkb, a_kb0, G, *, M, N, K, ldg, g_off=0, alpha=1.0, beta=0.0, colsum=None,
-                  cs_alpha=1.0, cs_beta=0.0):
+                  cs_alpha=1.0, cs_beta=0.0, queue=None, ws=None):
     """usf_wgrad_blocked_f32: G[n,k] = alpha * sum_m Y[m, 32 y_kb0 + n] A[m, 32 a_kb0 + k] + beta * G with both operands
-    planes buffers of the planes pipeline (uint8 tensors; logical positions); colsum as for ``wgrad_planes``"""
+    planes buffers of the planes pipeline (uint8 tensors; logical positions); colsum as for ``wgrad_planes``.
+    queue (a list) + ws (a workspace of this call's own, >= wgrad_blocked_workspace floats): the multiply kernel is launched, the
+    reduction is appended to the queue -- G / colsum are complete after ``wgrad_reduce_flush(queue, device)``"""
     lib = load()
+    if queue is not None:
+        job = WReduceJob()
+        _launch("usf_wgrad_blocked_plan_f32", (Yp.data_ptr(), y_nkb, y_kb0, Ap.data_ptr(), a_nkb, a_kb0, M, N, K,
+                                               G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ptr(colsum), float(cs_alpha),
+                                               float(cs_beta), ws.data_ptr(), ws.numel(), C.addressof(job), current_stream(Yp.device)),
+                (Yp, Ap, G, ws, colsum, job))
+        queue.append((job, (G, ws, colsum)))
+        return
     need = lib.usf_wgrad_planes_workspace_floats(M, N, K)
     ws = _workspace(Yp.device, need)
     _launch("usf_wgrad_blocked_f32", (Yp.data_ptr(), y_nkb, y_kb0, Ap.data_ptr(), a_nkb, a_kb0, M, N, K,
                                       G.data_ptr() + 4 * g_off, ldg, float(alpha), float(beta), ptr(colsum), float(cs_alpha),
                                       float(cs_beta), ws.data_ptr(), ws.numel(), current_stream(Yp.device)),
             (Yp, Ap, G, ws, colsum))
+
+
+def wgrad_blocked_workspace(M: int, N: int, K: int) -> int:
+    return int(load().usf_wgrad_planes_workspace_floats(M, N, K))
+
+
+def wgrad_reduce_flush(queue, device) -> None:
+    """ONE usf_wgrad_reduce_jobs_f32 launch for the queued reductions (taped like every launch: the job table is a device tensor
+    built once -- the queued pointers are plan-owned buffers, the same on every replay)"""
+    if not queue:
+        return
+    block_job, first = [], 0
+    for i, (j, _keep) in enumerate(queue):
+        j.first_block = first
+        block_job.extend([i] * j.blocks)
+        first += j.blocks
+    raw = bytearray(bytes((WReduceJob * len(queue))(*[j for j, _ in queue])))
+    raw += b"\0" * ((-len(raw)) % 16)
+    off = len(raw)
+    raw += struct.pack(f"<{len(block_job)}i", *block_job)
+    table = torch.frombuffer(raw, dtype=torch.uint8).to(device)
+    _launch("usf_wgrad_reduce_jobs_f32", (table.data_ptr(), table.data_ptr() + off, first, current_stream(device)),
+            (table, [k for _, k in queue]))
+    del queue[:]
 
 
 def colsum(Y, out, *, M, N, ldy, y_off=0, alpha=1.0, beta=0.0):

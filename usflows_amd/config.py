@@ -43,6 +43,7 @@ class Config:
         engine_graph=False,        # engine: replay small inference batches as a hipGraph (measured no faster than usf_run_ops)
         save_hidden=True,          # training: conditioners' hidden activations kept by the forward instead of recomputed
         wgrad_planes=True,         # fp32-row training path: weight gradients from operand planes (usf_wgrad_planes_f32)
+        wreduce_jobs=True,         # planes training: the weight gradients' reductions as one launch behind the layer loop
         fused_cbwd=True,           # fp32-row training path: the conditioner's backward as ONE fused launch
         fused_bias=True,           # bias gradients from the weight-gradient pass
         fit_prefetch=True,         # Flow.fit: next batch staged in pinned memory / uploaded under the running step

@@ -165,7 +165,8 @@ int wgrad_planes(const void* Yp, int64_t ldyp, int64_t ystride, int64_t y_off, c
 int wgrad_planes_colsum_ok(int64_t M, int64_t N, int64_t K);
 int wgrad_blocked(const void* Yp, int64_t y_nkb, int64_t y_kb0, const void* Ap, int64_t a_nkb, int64_t a_kb0, int64_t M, int64_t N,
                   int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out, float cs_alpha, float cs_beta,
-                  float* workspace, int64_t workspace_floats, hipStream_t stream);
+                  float* workspace, int64_t workspace_floats, usf_wreduce_job* job, hipStream_t stream);
+int wgrad_reduce_jobs(const usf_wreduce_job* jobs, const int32_t* block_job, int64_t n_blocks, hipStream_t stream);
 int base_param_grad(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
                     const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, hipStream_t stream);
 int mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, hipStream_t stream);
@@ -456,7 +457,18 @@ int usf_wgrad_blocked_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, co
                           int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out,
                           float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::wgrad_blocked(Y_planes, y_nkb, y_kb0, A_planes, a_nkb, a_kb0, M, N, K, G, ldg, alpha, beta, colsum_out, cs_alpha,
-                            cs_beta, workspace, workspace_floats, (hipStream_t)stream);
+                            cs_beta, workspace, workspace_floats, nullptr, (hipStream_t)stream);
+}
+int usf_wgrad_blocked_plan_f32(const void* Y_planes, int64_t y_nkb, int64_t y_kb0, const void* A_planes, int64_t a_nkb, int64_t a_kb0,
+                               int64_t M, int64_t N, int64_t K, float* G, int64_t ldg, float alpha, float beta, float* colsum_out,
+                               float cs_alpha, float cs_beta, float* workspace, int64_t workspace_floats, usf_wreduce_job* job,
+                               usf_stream_t stream) {
+  if (!job) { usf::set_error("usf_wgrad_blocked_plan_f32: job is NULL"); return -1; }
+  return usf::wgrad_blocked(Y_planes, y_nkb, y_kb0, A_planes, a_nkb, a_kb0, M, N, K, G, ldg, alpha, beta, colsum_out, cs_alpha,
+                            cs_beta, workspace, workspace_floats, job, (hipStream_t)stream);
+}
+int usf_wgrad_reduce_jobs_f32(const usf_wreduce_job* jobs, const int32_t* block_job, int64_t n_blocks, usf_stream_t stream) {
+  return usf::wgrad_reduce_jobs(jobs, block_job, n_blocks, (hipStream_t)stream);
 }
 int usf_base_param_grad_f32(const float* z, int64_t ldz, const float* g_lp, int64_t M, int64_t D, int32_t base, const float* loc,
                             const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, usf_stream_t stream) {

@@ -623,13 +623,24 @@ class TrainPath:
                 elif m is not first_meta:
                     eng.planes_dgrad_image(pk, m)
         self._defer = False
+        # the reductions that end the weight gradients are queued (each with a workspace of its own) and leave as ONE launch behind
+        # the layer loop, in front of the batched un-permute jobs that read their outputs (config.wreduce_jobs)
+        self._wred = [] if config.wreduce_jobs else None
         with _ext.batch_jobs(dev):
             for m in reversed(plan["meta"]):
                 if m["kind"] == "affine":
                     cur = self._affine_backward_planes(plan, m, gp, cur, nkb, nkb_g, aff, stacks, need_dgrad=(m is not first_meta))
                 else:
                     self._coupling_backward_planes(plan, m, gp[cur], nkb, nkb_g, grads)
+            if self._wred:
+                _ext.wgrad_reduce_flush(self._wred, dev)
         _ext.host_op(lambda: self._affine_param_grads(plan, aff, stacks, glp, grads, arena))
+
+    def _wq(self, ws, tag, B, N, K) -> dict:
+        """queue + a workspace of this call's own for usf_wgrad_blocked_plan_f32 (empty: the undeferred call)"""
+        if getattr(self, "_wred", None) is None:
+            return {}
+        return dict(queue=self._wred, ws=self._buf(ws, f"WGws{tag}", 1, _ext.wgrad_blocked_workspace(B, N, K)))
 
     def _affine_backward_planes(self, plan, m, gp, cur, nkb, nkb_g, aff, stacks, need_dgrad):
         eng = self.eng
@@ -643,7 +654,8 @@ class TrainPath:
         wid = max(eng.LD, eng.LDn)
         Gp = self._buf(ws, f"Gp{m['op']}", wid, wid)
         gs = self._buf(ws, f"gs{m['op']}", 1, wid)
-        _ext.wgrad_blocked(gp[cur], nkb_g, 0, ws[m["in_buf"]], nkb, 0, Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1], colsum=gs)
+        _ext.wgrad_blocked(gp[cur], nkb_g, 0, ws[m["in_buf"]], nkb, 0, Gp, M=B, N=n_out, K=n_in, ldg=Gp.shape[1], colsum=gs,
+                           **self._wq(ws, f"a{m['op']}", B, n_out, n_in))
         k = self._lu_slot[id(blk)] if self._lu_slot is not None else stacks["next"]
         stacks["next"] += 1
         if self._lu_slot is not None and which == "M":
@@ -702,7 +714,7 @@ class TrainPath:
         n_t = int((m["feat_t"] >= 0).nonzero().max().item()) + 1 - 32 * m["kb_t0"]
         gW, gb = gimg("out"), gvec("out")
         _ext.wgrad_blocked(g, nkb_g, m["kb_t0"], hs[nl - 1], 8, 0, gW, M=B, N=n_t, K=256, ldg=gW.shape[1], alpha=sign,
-                           colsum=gb, cs_alpha=sign)
+                           colsum=gb, cs_alpha=sign, **self._wq(ws, f"c{m['step']}o", B, n_t, 256))
         tsel = self._seg_sel(m, "t", dev)
         self._scatter_weight(grads, last_l.weight, gW, rows_sel=tsel, n_rows=eng.D, cols_sel=None, n_cols=h[-1])
         self._scatter_vec(grads, last_l.bias, gb, tsel, eng.D)
@@ -711,14 +723,14 @@ class TrainPath:
             l = hidden_l[j - 1]
             gW, gb = gimg(f"h{j}"), gvec(f"h{j}")
             _ext.wgrad_blocked(dh[j], 8, 0, hs[j - 1], 8, 0, gW, M=B, N=h[j], K=256, ldg=gW.shape[1], alpha=sign,
-                               colsum=gb, cs_alpha=sign)
+                               colsum=gb, cs_alpha=sign, **self._wq(ws, f"c{m['step']}h{j}", B, h[j], 256))
             self._scatter_weight(grads, l.weight, gW, None, h[j], None, h[j - 1])
             self._scatter_vec(grads, l.bias, gb, None, h[j])
         # input layer: A = the conditioning blocks of the layer's own z buffer (what the forward's conditioner saw)
         n_p = int((m["feat_p"] >= 0).nonzero().max().item()) + 1 - 32 * m["kb_p0"]
         gW, gb = gimg("in"), gvec("in")
         _ext.wgrad_blocked(dh[0], 8, 0, ws[m["buf"]], nkb, m["kb_p0"], gW, M=B, N=h[0], K=n_p, ldg=gW.shape[1], alpha=sign,
-                           colsum=gb, cs_alpha=sign)
+                           colsum=gb, cs_alpha=sign, **self._wq(ws, f"c{m['step']}i", B, h[0], n_p))
         self._scatter_weight(grads, first_l.weight, gW, None, h[0], self._seg_sel(m, "p", dev), eng.D)
         self._scatter_vec(grads, first_l.bias, gb, None, h[0])
 
