@@ -628,7 +628,8 @@ _masked_lock = threading.Lock()
 _masked = {}          # autograd graph task id -> {(data_ptr, shape)}
 
 
-def mark_masked(stack: torch.Tensor) -> None:
+def mark_masked(stack) -> None:
+    """stack: a [n, D, D] tensor (its rows are registered) or a list of tensors"""
     task = torch._C._current_graph_task_id()
     if task < 0:
         return
@@ -636,7 +637,7 @@ def mark_masked(stack: torch.Tensor) -> None:
         for old in [t for t in _masked if t < task - 256]:
             del _masked[old]
         s = _masked.setdefault(task, set())
-        for row in stack.unbind(0):
+        for row in (stack.unbind(0) if torch.is_tensor(stack) else stack):
             s.add((row.data_ptr(), tuple(row.shape)))
 
 

@@ -340,8 +340,15 @@ class TrainPath:
             flat = arena["flat"].clone()          # autograd may keep what we return: never hand out the arena itself
             self.allreduce_gradients(flat, x.shape[0])
         # parameters the path never reaches (a context layer without context) get no gradient, as under autograd
-        return {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items()
-                if pid in arena["touched"]}
+        out = {pid: flat[o: o + n].view(shape) for pid, (o, n, shape) in arena["slots"].items() if pid in arena["touched"]}
+        # the LU factors' gradients leave the chain rule with exact zeros outside their triangles (triu / tril in fp64): LUTransform's
+        # mask hooks (transforms.py: one product per factor and pass -- 66 launches of the cfg2 model) skip exactly these tensors
+        lu_ids = [id(getattr(lu, nm)) for ch in pk["affine_parts"]["__chunks__"] for lu in ch["lus"] for nm in ("L_raw", "U_raw")]
+        masked = [out[i] for i in lu_ids if i in out]
+        if masked:
+            from .image_training import mark_masked
+            mark_masked(masked)
+        return out
 
     # ---- gradients accumulated by one launch ----------------------------------------------------------------
     def _arena_params(self) -> Dict[int, torch.nn.Parameter]:
