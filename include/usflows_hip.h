@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* usf_stream_t; /* hipStream_t */
 
-#define USF_ABI_VERSION 34
+#define USF_ABI_VERSION 35
 
 /* activation ids (conditioner nonlinearity, networks.py:717,737) */
 #define USF_ACT_NONE 0
@@ -40,6 +40,8 @@ typedef void* usf_stream_t; /* hipStream_t */
 #define USF_BASE_LPNORM1 2 /* r = ||z-loc||_1  (RadialDistribution.log_prob, distributions.py:501-505) */
 #define USF_BASE_LPNORM2 3 /* r = ||z-loc||_2 */
 #define USF_BASE_LPNORMINF 4 /* r = ||z-loc||_inf */
+#define USF_BASE_ROWSUM 5  /* usf_base_logprob_f32 only: logp[m] = sum_d z[m,d] + logdet (z = the partial sums a fused
+                              epilogue left, usf_gemm_planes_desc.base_part; loc / scale unused, D <= 8) */
 
 /*
  * Fused dense layer:   C = epilogue( prologue(A) @ W^T )        (row-major, fp32, exact-f32 MFMA)
@@ -188,6 +190,11 @@ int usf_coupling_padded_width(int h);   /* Hp of the padding contract for hidden
 int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base,
                          const float* loc, const float* scale, float logdet_const, const double* logdet_dev,
                          float* logp, double* sum_out, usf_stream_t stream);
+/* per-feature tables of a Laplace / Normal base for usf_gemm_planes_desc.base_tab: tab[d] = loc[d],
+ * tab[stride + d] = 1 / scale[d], tab[2 stride + d] = the density's constant (-log(2 b) resp. -log(sigma) - log sqrt(2 pi)),
+ * zeros for D <= d < stride (stride: a multiple of 4, >= D). */
+int usf_base_tables_f32(int32_t base, const float* loc, const float* scale, int64_t D, float* tab, int64_t stride,
+                        usf_stream_t stream);
 
 /*
  * Head of Flow.sample (flows.py:258): z ~ base, counter-based Philox4x32-10 RNG.
@@ -544,6 +551,12 @@ int usf_pack_planes_f32(const usf_pack_planes_desc* d, usf_stream_t stream);
  *            blocks per panel, for n < 32 c_kbn;  v = act(acc + bias);  with residual (a planes buffer of C's
  *            geometry, may alias C_planes): v = residual + res_sign * v
  *   fp32 output (C_f32 != NULL): C_f32[m, n] = act(acc + bias) * post_mul, n < N, row-major with stride ldc
+ *   base density in the epilogue (base_part != NULL; fp32-output form, C_f32 may then be NULL: the rows are not stored):
+ *            the layer is the LAST of Flow.log_prob (flows.py:225-234) and its result z only feeds
+ *            base_distribution.log_prob: base_part[m, j] = sum over the columns n of column block j (32 TN columns, TN as
+ *            usf_gemm_planes_variant reports; at most 8 blocks: N <= 1024) of the Laplace / Normal terms of
+ *            usf_base_logprob_f32 at z[m, n], with 1 / scale and the per-feature constant taken from base_tab
+ *            (usf_base_tables_f32).  base_part is [M, 8] fp32; usf_base_logprob_f32(USF_BASE_ROWSUM) finishes the rows.
  */
 typedef struct usf_gemm_planes_desc {
   const void* A; int64_t a_nkb, a_kb0, nk;
@@ -560,6 +573,10 @@ typedef struct usf_gemm_planes_desc {
   int32_t* range_flag;                  /* F16X2 only, may be NULL: set to 1 when an output that has to travel as fp16
                                            planes is NaN or |x| >= 65000, or an fp32 output is not finite (an overflowed
                                            plane upstream) -- the results of the pass are void, redo it in BF16X3 */
+  /* ABI 35 (appended): base density in the epilogue, see above; all zero = off */
+  const float* base_tab; int64_t base_tab_stride;
+  float* base_part;
+  int32_t base, reserved;
 } usf_gemm_planes_desc;
 int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream);
 /* which instantiation serves the descriptor (nothing is launched): 5000 + 10 TN + (1: fp32 output, 0: planes output),

@@ -181,12 +181,22 @@ def emulate_gemm_planes(d, pm: PtrMap, dtype=torch.float32):
         v = v + pm.vec(d.bias, d.w_rows).to(dtype)
     if d.act == _ext.ACT_LEAKY_RELU:
         v = torch.where(v > 0, v, v * d.slope)
-    if d.C_f32:
+    if d.C_f32 or d.base_part:
         if d.post_mul:
             v = v * pm.vec(d.post_mul, d.w_rows).to(dtype)
         if fmt == 1 and d.range_flag and not bool(torch.isfinite(v[:, : d.N]).all()):
             pm.view(d.range_flag, 1, 1, 1, dtype=torch.int32)[0, 0] = 1
-        pm.view(d.C_f32, M, d.N, d.ldc).copy_(v[:, : d.N].to(torch.float32))
+        if d.base_part:        # base density in the epilogue: one partial sum per (row, column block of 32 TN columns)
+            tab = pm.view(d.base_tab, 3, d.N, d.base_tab_stride).to(dtype)
+            t = (v[:, : d.N] - tab[0]) * tab[1]
+            term = tab[2] - (t.abs() if d.base == _ext.BASE_LAPLACE else 0.5 * t * t)
+            bn = 32 * ((_ext.load().usf_gemm_planes_variant(d) - 5000) // 10)
+            part = pm.view(d.base_part, M, 8, 8)
+            part.fill_(float("nan"))                     # (slots beyond the column blocks are never written by the kernel)
+            for j in range(-(-d.N // bn)):
+                part[:, j] = term[:, j * bn: (j + 1) * bn].sum(1).to(torch.float32)
+        if d.C_f32:
+            pm.view(d.C_f32, M, d.N, d.ldc).copy_(v[:, : d.N].to(torch.float32))
         return
     v = v[:, : 32 * d.c_kbn]
     Cv = planes_view(pm, d.C_planes, npan, d.c_nkb, fmt)
@@ -604,12 +614,26 @@ def _emu_base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out
     if logdet_dev is not None:
         logdet_const = float(logdet_const) + float(logdet_dev.float())
     zz = _view(z, 0, M, D, ldz).double()
+    if base == _ext.BASE_ROWSUM:
+        out.copy_((zz.sum(-1) + logdet_const).float())
+        if sum_out is not None:
+            sum_out[0] += out.double().sum()
+            sum_out[1] += M
+        return
     if base in (_ext.BASE_LPNORM1, _ext.BASE_LPNORM2, _ext.BASE_LPNORMINF):
         p = {_ext.BASE_LPNORM1: 1.0, _ext.BASE_LPNORM2: 2.0}.get(base, float("inf"))
         out.copy_((zz - loc.double()).norm(p=p, dim=1).float())
         return
     dist = (torch.distributions.Laplace if base == _ext.BASE_LAPLACE else torch.distributions.Normal)(loc.double(), scale.double())
     out.copy_((dist.log_prob(zz).sum(-1) + logdet_const).float())
+
+
+def _emu_base_tables(base, loc, scale, D, tab, stride):
+    t = tab.view(3, stride)
+    t.zero_()
+    t[0, :D] = loc
+    t[1, :D] = 1.0 / scale
+    t[2, :D] = -(2.0 * scale).log() if base == _ext.BASE_LAPLACE else -scale.log() - 0.91893853320467274178
 
 
 def _emu_base_logprob_grad(z, ldz, g_lp, M, D, base, loc, scale, g, ldg):
@@ -665,6 +689,7 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "gated_norm_rows_bwd", _emu_gated_norm_rows_bwd)
     monkeypatch.setattr(_ext, "add_rows", _emu_add_rows)
     monkeypatch.setattr(_ext, "base_logprob", _emu_base_logprob)
+    monkeypatch.setattr(_ext, "base_tables", _emu_base_tables)
     monkeypatch.setattr(_ext, "base_logprob_grad", _emu_base_logprob_grad)
     monkeypatch.setattr(_ext, "base_param_grad", _emu_base_param_grad)
     monkeypatch.setattr(_ext, "gemm_f64", _emu_gemm_f64)
@@ -718,3 +743,20 @@ def engine_latent(eng, x, context=None, fused=False, planes=False):
     run_plan(eng, plan, x.contiguous(), None, context)
     buf = plan["ws"][plan["out_buf"][0]]
     return buf[:, : eng.D].clone(), -float(plan["pk"]["ladj_total"])
+
+
+def engine_base_log_prob(eng, x, base, loc, scale, fused=False, planes="bf16x3"):
+    """Flow.log_prob's planes plan with the base density in the last GEMM's epilogue (Engine.latent_base_sums + the row-sum tail)"""
+    eng.use_fused_coupling = fused
+    eng.fused_min_rows = 0
+    eng.use_planes, eng.planes_min_rows, eng.gemm_mode = True, 0, planes
+    if fused:
+        eng._fused_ok = lambda cp: len(cp["hidden"]) <= 3
+    B = x.shape[0]
+    plan = eng._plan("backward", B, x.device, False, f"base{base}")
+    ws = plan["ws"]
+    _emu_base_tables(base, loc, scale, eng.D, ws["btab"], ws["btab"].numel() // 3)
+    run_plan(eng, plan, x.contiguous(), None, None)
+    out = torch.empty(B)
+    _emu_base_logprob(ws["bpart"], 8, B, plan["n_part"], _ext.BASE_ROWSUM, None, None, -float(plan["pk"]["ladj_total"]), out)
+    return out

@@ -137,6 +137,14 @@ def test_planes_pipeline_ops_reproduce_golden(name, fmt, fused):
     lp = orc.base_log_prob(spec, zl.double(), orc.to_dtype(sd, torch.float64)) + logdet
     rel = ((lp - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
     assert rel < 2e-5, rel
+    info = flow._base_info(torch.device("cpu"))
+    if info is not None and info[0] in ("laplace", "normal"):
+        # the same plan with the base density reduced in the last GEMM's epilogue (partial sums per column block, no rows stored)
+        from usflows_amd import _ext
+        base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
+        lpf = emulator.engine_base_log_prob(eng, a["x"], base, info[1], info[2], fused, fmt)
+        rel = ((lpf.double() - a["log_prob64"]).abs() / a["log_prob64"].abs()).max().item()
+        assert rel < 2e-5, rel
 
 
 def test_single_layer_engines():

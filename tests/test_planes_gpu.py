@@ -252,6 +252,8 @@ def test_golden_parity_through_the_planes_plan(name, fmt, fused):
         z = flow.backward(a["x"].to(DEV))
         xf = flow._forward(a["zin"].to(DEV))
     assert any(p.get("planes") and p["planes_fmt"] == FMT[fmt] for p in eng._plans.values()), "planes plan was not built"
+    if spec.base in ("laplace", "normal"):
+        assert any(p.get("n_part", 0) >= 1 for p in eng._plans.values()), "base density was not reduced in the last GEMM's epilogue"
     from usflows_amd import _ext as E
     has_fused = any(p["arr"][j].kind == E.OP_COUPLING_PLANES for p in eng._plans.values() if p.get("planes")
                     for j in range(p["n"]))
@@ -288,6 +290,41 @@ def test_planes_plan_ragged_rows_vs_fp32_plan(B):
     assert (z1 - z2).abs().max().item() < 1e-4 * max(1.0, z2.abs().max().item())
     ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x[:64].cpu().double())
     assert ((lp1[:64].cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("base", ["laplace", "normal"])
+@pytest.mark.parametrize("D,B", [(72, 1), (70, 17), (72, 8200), (784, 4099), (1000, 300)])
+def test_base_density_in_the_last_gemms_epilogue(D, B, base, monkeypatch):
+    """Flow.log_prob on a planes plan: the Laplace / Normal base density reduced by the last GEMM's epilogue (one partial sum
+    per row and column block + the row-sum tail, z never stored) against the fp64 oracle and against the plan that stores z
+    and runs usf_base_logprob_f32 over it; per-feature loc / scale, ragged row counts, D not a multiple of 4, 1 .. 8 column
+    blocks, and the data-parallel sums"""
+    from oracle import usflows_oracle as orc
+    from usflows_amd.config import config
+    g = torch.Generator().manual_seed(D + B)
+    spec = orc.FlowSpec(D, 2, [40, 24], householder=0, affine_conjugation=True, base=base,
+                        base_loc=torch.randn(D, generator=g) * 0.3, base_scale=0.5 + torch.rand(D, generator=g))
+    sd = orc.synth_state_dict(spec, seed=5)
+    flow = build_flow(spec, sd, device=DEV)
+    eng = flow.engine()
+    eng.use_planes, eng.planes_min_rows = True, 0
+    x = torch.rand(B, D, generator=g).to(DEV)
+    sums = torch.zeros(2, dtype=torch.float64, device=DEV)
+    with torch.no_grad():
+        lp1 = flow._log_prob_device(x, None, sums)
+        assert any(p.get("n_part", 0) >= 1 for p in eng._plans.values()), "the fused tail was not taken"
+        n_part = max(p.get("n_part", 0) for p in eng._plans.values())
+        assert n_part == {72: 1, 70: 1, 784: 5, 1000: 8}[D]
+        monkeypatch.setattr(config, "base_in_epilogue", False)
+        eng._plans.clear()
+        lp2 = flow.log_prob(x)
+        assert not any(p.get("n_part", 0) >= 1 for p in eng._plans.values())
+    assert torch.isfinite(lp1).all()
+    assert ((lp1 - lp2).abs() / lp2.abs()).max().item() < 2e-6
+    assert abs(sums[0].item() - lp1.double().sum().item()) < 1e-9 * abs(sums[0].item()) + 1e-9 and sums[1].item() == B
+    n = min(B, 64)
+    ref = orc.flow_log_prob(orc.to_dtype(sd, torch.float64), spec, x[:n].cpu().double())
+    assert ((lp1[:n].cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5
 
 
 def test_fp16_overflow_falls_back_to_bf16x3_planes():

@@ -20,11 +20,11 @@ from .config import config  # noqa: E402
 
 LIB_PATH = config.lib_path     # (USFLOWS_AMD_LIB: A/B builds)
 
-USF_ABI_VERSION = 34
+USF_ABI_VERSION = 35
 USF_MAX_HIDDEN = 4
 
 ACT_NONE, ACT_LEAKY_RELU, ACT_GATE = 0, 1, 2
-BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF = 0, 1, 2, 3, 4
+BASE_LAPLACE, BASE_NORMAL, BASE_LPNORM1, BASE_LPNORM2, BASE_LPNORMINF, BASE_ROWSUM = 0, 1, 2, 3, 4, 5
 NORM_LOGNORMAL, NORM_GAMMA, NORM_RAW_PARAMS = 0, 1, 0x100
 RADIAL_MAX_K = 64
 OP_LINEAR, OP_COUPLING, OP_PACK_PLANES, OP_GEMM_PLANES, OP_COUPLING_PLANES, OP_GATED_NORM, OP_CALL = 1, 2, 5, 6, 7, 9, 10
@@ -85,7 +85,8 @@ class GemmPlanesDesc(C.Structure):
                 ("bias", _fp), ("post_mul", _fp), ("residual", _fp),
                 ("C_planes", _fp), ("c_nkb", C.c_int64), ("c_kb0", C.c_int64), ("c_kbn", C.c_int64),
                 ("C_f32", _fp), ("ldc", C.c_int64), ("N", C.c_int64), ("M", C.c_int64),
-                ("res_sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("format", C.c_int32), ("range_flag", _fp)]
+                ("res_sign", C.c_float), ("slope", C.c_float), ("act", C.c_int32), ("format", C.c_int32), ("range_flag", _fp),
+                ("base_tab", _fp), ("base_tab_stride", C.c_int64), ("base_part", _fp), ("base", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CouplingPlanesDesc(C.Structure):
@@ -201,6 +202,7 @@ SYMBOLS = {
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
     "usf_base_logprob_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_float,
                                        _fp, _fp, _fp, C.c_void_p]),
+    "usf_base_tables_f32": (C.c_int, [C.c_int32, _fp, _fp, C.c_int64, _fp, C.c_int64, C.c_void_p]),
     "usf_base_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
                                       C.c_uint64, C.c_int64, C.c_void_p]),
     "usf_radial_sample_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64,
@@ -595,6 +597,11 @@ def base_logprob(z, ldz, M, D, base, loc, scale, logdet_const, out, sum_out=None
     _launch("usf_base_logprob_f32", (z.data_ptr(), ldz, M, D, base, ptr(loc), ptr(scale), float(logdet_const),
                                      ptr(logdet_dev), out.data_ptr(), ptr(sum_out), current_stream(z.device)),
             keep=logdet_dev)
+
+
+def base_tables(base, loc, scale, D, tab, stride):
+    """loc | 1 / scale | constant of a Laplace / Normal base, [3, stride] fp32: the tables of the last GEMM's fused tail"""
+    _launch("usf_base_tables_f32", (base, loc.data_ptr(), scale.data_ptr(), D, tab.data_ptr(), stride, current_stream(tab.device)))
 
 
 def radial_logprob(z, ldz, M, D, p_id, loc, norm, K, par_a, par_b, logits, logdv_const, logdet_const, out, r_out=None, sum_out=None,

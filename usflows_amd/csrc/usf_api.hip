@@ -61,6 +61,7 @@ int linear_variant(const usf_linear_desc* d);
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 int coupling_max_width();
 int coupling_padded_width(int h);
+int base_tables(int32_t base, const float* loc, const float* scale, int64_t D, float* tab, int64_t stride, hipStream_t stream);
 int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                  const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
                  hipStream_t stream);
@@ -236,6 +237,9 @@ int usf_gemm_planes_variant(const usf_gemm_planes_desc* d) { return usf::gemm_pl
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }
 
+int usf_base_tables_f32(int32_t base, const float* loc, const float* scale, int64_t D, float* tab, int64_t stride, usf_stream_t stream) {
+  return usf::base_tables(base, loc, scale, D, tab, stride, (hipStream_t)stream);
+}
 int usf_base_logprob_f32(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                          const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
                          usf_stream_t stream) {

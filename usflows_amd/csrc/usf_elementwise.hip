@@ -106,11 +106,70 @@ __global__ __launch_bounds__(256) void base_logprob_kernel(const float* __restri
 
 __global__ void add_count_kernel(double* sum_out, double n) { sum_out[1] += n; }
 
+// USF_BASE_ROWSUM: the row's partial sums (one per column block of the last GEMM, usf_planes.hip) -> logp; one thread per row
+__global__ __launch_bounds__(256) void base_rowsum_kernel(const float* __restrict__ z, int64_t ldz, int M, int D, float logdet_const,
+                                                          const double* __restrict__ logdet_dev, float* __restrict__ logp,
+                                                          double* __restrict__ sum_out) {
+  if (logdet_dev) logdet_const += (float)*logdet_dev;
+  double mine = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < M; row += (int64_t)gridDim.x * blockDim.x) {
+    const float* zr = z + row * ldz;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += zr[d];
+    const float out = acc + logdet_const;
+    logp[row] = out;
+    mine += (double)out;
+  }
+  if (sum_out != nullptr) {
+    __shared__ double part[4];
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double t = part[0] + part[1] + part[2] + part[3];
+      if (t != 0.0) atomicAdd(&sum_out[0], t);
+    }
+  }
+}
+
+__global__ void base_tables_kernel(int base, const float* __restrict__ loc, const float* __restrict__ scale, int D, float* __restrict__ tab,
+                                   int stride) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= stride) return;
+  const bool in = d < D;
+  tab[d] = in ? loc[d] : 0.f;
+  tab[stride + d] = in ? 1.0f / scale[d] : 0.f;
+  tab[2 * stride + d] = in ? base_const(scale[d], base) : 0.f;
+}
+
+int base_tables(int32_t base, const float* loc, const float* scale, int64_t D, float* tab, int64_t stride, hipStream_t stream) {
+  if (D <= 0 || stride < D || (stride & 3) || stride > 0x7fffffff) { set_error("usf_base_tables_f32: bad sizes"); return -2; }
+  if (!loc || !scale || !tab) { set_error("usf_base_tables_f32: null pointer"); return -1; }
+  if (base != USF_BASE_LAPLACE && base != USF_BASE_NORMAL) { set_error("usf_base_tables_f32: base %d has no tables", base); return -2; }
+  hipLaunchKernelGGL(base_tables_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, stream, (int)base, loc, scale, (int)D,
+                     tab, (int)stride);
+  return check_launch("usf_base_tables_f32");
+}
+
 int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                  const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
                  hipStream_t stream) {
   if (M < 0 || D <= 0 || M > 0x7fffffff || D > 0x7fffffff || ldz < D) { set_error("usf_base_logprob_f32: bad sizes"); return -2; }
   if (M == 0) return 0;
+  if (base == USF_BASE_ROWSUM) {
+    if (!z || !logp) { set_error("usf_base_logprob_f32: null pointer"); return -1; }
+    if (D > 8) { set_error("usf_base_logprob_f32: USF_BASE_ROWSUM sums at most 8 partial sums per row"); return -2; }
+    int64_t blocks = (M + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(base_rowsum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, z, ldz, (int)M, (int)D, logdet_const,
+                       logdet_dev, logp, sum_out);
+    int rc = check_launch("usf_base_logprob_f32(rowsum)");
+    if (rc == 0 && sum_out) {
+      hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, stream, sum_out, (double)M);
+      rc = check_launch("usf_base_logprob_f32(count)");
+    }
+    return rc;
+  }
   if (!z || !loc || !logp) { set_error("usf_base_logprob_f32: null pointer"); return -1; }
   if ((base == USF_BASE_LAPLACE || base == USF_BASE_NORMAL) && !scale) { set_error("usf_base_logprob_f32: scale required"); return -1; }
   const int wpb = 4;

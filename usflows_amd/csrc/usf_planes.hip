@@ -262,6 +262,8 @@ struct PlArgs {
   int N, nbm, nbn, nvb;
   float res_sign, slope; int act;
   int32_t* range_flag;
+  // base density in the fp32-output epilogue (b_part == nullptr: off): tables loc | 1 / scale | constant, stride b_stride
+  const float* b_tab; float* b_part; int b_stride; int b_base;
   unsigned long long* dbg;
   unsigned long long* span;             // tuning builds only: [first wave start, last wave end] in s_memrealtime ticks
 };
@@ -503,17 +505,32 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int row = 16 * pw[b] + lj;
+      float bsum = 0.f;                          // this lane's share of sum_d log p(z[row, d]) over the block's columns
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft) {
         const int col = n0 + 16 * ft + 4 * lg;
         f32x4 v = acc[ft][b];
         if (p.post_mul) v = v * *reinterpret_cast<const f32x4*>(p.post_mul + min(col, p.wrows - 4));
+        if (p.b_part) {
+          // the flow's last layer: the base density of the row (usf_base_logprob_f32's terms, 1 / scale from the table) is
+          // reduced here instead of by a pass over the stored rows
+          const float* t = p.b_tab + min(col, p.b_stride - 4);
+          const f32x4 bl = *reinterpret_cast<const f32x4*>(t);
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(t + p.b_stride);
+          const f32x4 bc = *reinterpret_cast<const f32x4*>(t + 2 * p.b_stride);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = (v[j] - bl[j]) * bi[j];
+            const float term = (p.b_base == USF_BASE_LAPLACE) ? bc[j] - fabsf(d) : bc[j] - 0.5f * d * d;
+            bsum += (col + j < p.N) ? term : 0.f;
+          }
+        }
         if (NPL == 2 && row < p.M && col < p.N) {
           // (an overflowed weight or activation plane upstream shows up here as inf / NaN)
 #pragma unroll
           for (int j = 0; j < 4; ++j) bad = bad || (col + j < p.N && !(fabsf(v[j]) < 3.0e38f));
         }
-        if (row < p.M && col < p.N) {
+        if (p.Cf != nullptr && row < p.M && col < p.N) {      // (Cf == nullptr: only the base density is wanted of this layer)
           float* dst = p.Cf + (int64_t)row * p.ldc + col;
           if (vec_ok && col + 3 < p.N) {
             *reinterpret_cast<f32x4*>(dst) = v;
@@ -523,6 +540,12 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
               if (col + j < p.N) dst[j] = v[j];
           }
         }
+      }
+      if (p.b_part) {
+        // the four lanes (j, g = 0..3) of a row hold its 16-column tiles' quarters: one partial sum per (row, column block)
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (lg == 0 && row < p.M) p.b_part[(int64_t)row * 8 + bn] = bsum;
       }
     }
   } else {
@@ -616,7 +639,7 @@ int gemm_planes_tn(int64_t nblk) {
 // which instantiation usf_gemm_planes_bf16x3 launches for this descriptor: 5000 + 10 TN + (1: fp32 output, 0: planes)
 int gemm_planes_variant(const usf_gemm_planes_desc* d) {
   if (!d || d->M <= 0) return 0;
-  const bool f32out = d->C_f32 != nullptr;
+  const bool f32out = d->C_f32 != nullptr || d->base_part != nullptr;
   const int64_t nblk = f32out ? (d->N + 31) / 32 : d->c_kbn;
   if (nblk <= 0) return 0;
   return 5000 + 10 * gemm_planes_tn(nblk) + (f32out ? 1 : 0);
@@ -631,7 +654,7 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
     return -2;
   }
   if (d->M == 0) return 0;
-  const bool f32out = d->C_f32 != nullptr;
+  const bool f32out = d->C_f32 != nullptr || d->base_part != nullptr;
   if (!d->A || !d->W_planes || (!f32out && !d->C_planes)) { set_error("usf_gemm_planes_bf16x3: null A / W / C"); return -1; }
   if (f32out && d->C_planes) { set_error("usf_gemm_planes_bf16x3: give C_planes or C_f32, not both"); return -2; }
   if (!aligned16(d->A) || !aligned16(d->W_planes) || (d->C_planes && !aligned16(d->C_planes)) ||
@@ -657,6 +680,7 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
   a.c_nkb = (int)d->c_nkb; a.c_kb0 = (int)d->c_kb0; a.c_kbn = (int)d->c_kbn; a.N = (int)d->N;
   a.res_sign = d->res_sign; a.slope = d->slope; a.act = d->act; a.nbm = a.nbn = a.nvb = 0;
   a.range_flag = d->range_flag;
+  a.b_tab = d->base_tab; a.b_part = d->base_part; a.b_stride = (int)d->base_tab_stride; a.b_base = d->base;
   a.dbg = nullptr; a.span = nullptr;
 #ifdef USF_STAMP
   a.dbg = g_pdbg; a.span = g_pspan;
@@ -667,7 +691,16 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
     if (d->N <= 0 || d->N > d->w_rows || d->ldc < d->N) { set_error("usf_gemm_planes_bf16x3: bad N / ldc for fp32 output"); return -2; }
     if (d->residual) { set_error("usf_gemm_planes_bf16x3: residual needs planes output"); return -2; }
     nblk = (d->N + 31) / 32;
+    if (d->base_part) {
+      if (!d->base_tab || !aligned16(d->base_tab) || (d->base_tab_stride & 3) || d->base_tab_stride < ((d->N + 3) & ~(int64_t)3) ||
+          d->base_tab_stride > 0x7fffffff || (d->base != USF_BASE_LAPLACE && d->base != USF_BASE_NORMAL)) {
+        set_error("usf_gemm_planes_bf16x3: base density in the epilogue needs the tables of usf_base_tables_f32 (16-byte aligned, "
+                  "stride a multiple of 4 and >= N) and base = USF_BASE_LAPLACE / USF_BASE_NORMAL");
+        return -2;
+      }
+    }
   } else {
+    if (d->base_part) { set_error("usf_gemm_planes_bf16x3: base_part needs the fp32-output form"); return -2; }
     if (d->c_kbn <= 0 || d->c_kb0 < 0 || d->c_kb0 + d->c_kbn > d->c_nkb || d->c_kbn * 32 > d->w_rows) {
       set_error("usf_gemm_planes_bf16x3: bad output block range (c_kb0=%lld c_kbn=%lld c_nkb=%lld w_rows=%lld)",
                 (long long)d->c_kb0, (long long)d->c_kbn, (long long)d->c_nkb, (long long)d->w_rows);
@@ -678,6 +711,10 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
   }
   const int force = (int)tuning("planes_tn", 0);
   const int tn = (force == 4 || force == 5) ? force : gemm_planes_tn(nblk);
+  if (d->base_part && (d->N + 32 * tn - 1) / (32 * tn) > 8) {
+    set_error("usf_gemm_planes_bf16x3: base_part holds 8 column blocks per row (N <= 1024)");
+    return -2;
+  }
   if (npl == 2) return tn == 4 ? launch_planes<2, 4>(a, f32out, stream) : launch_planes<2, 5>(a, f32out, stream);
   return tn == 4 ? launch_planes<3, 4>(a, f32out, stream) : launch_planes<3, 5>(a, f32out, stream);
 }

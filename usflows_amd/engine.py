@@ -1532,5 +1532,25 @@ class FlowEngine(PlanesPlanMixin):
         buf = plan["ws"][plan["out_buf"][0]]
         return buf, plan["out_buf"][2], plan["pk"]["ladj_total"]
 
+    def latent_base_sums(self, x: torch.Tensor, base: int, loc: torch.Tensor, scale: torch.Tensor):
+        """backward pass with the Laplace / Normal base density reduced by the last GEMM's epilogue (planes plans, D <= 1024):
+        (partial sums [B, 8], how many of the 8 are used, the flow's LogDet) -- ``usf_base_logprob_f32(USF_BASE_ROWSUM)`` finishes
+        the rows; None when this batch does not take a planes plan (the caller runs ``latent`` + the density pass)."""
+        from .config import config
+        x = self._check_input(x)
+        B = x.shape[0]
+        if not (config.base_in_epilogue and self.D <= 1024 and self._planes_ok("backward", B, False, False)):
+            return None
+        if self.merge_affine == "auto":
+            self.resolve_merge("backward", x)
+        final = f"base{int(base)}"
+        plan = self._plan("backward", B, x.device, False, final)
+        if plan.get("n_part", 0) < 1:
+            return None
+        ws = plan["ws"]
+        _ext.base_tables(base, loc, scale, self.D, ws["btab"], ws["btab"].numel() // 3)
+        plan = self._run_guarded("backward", x, None, None, final)
+        return plan["ws"]["bpart"], plan["n_part"], plan["pk"]["ladj_total"]
+
     def ladj_total(self, device) -> float:
         return float(self.pack(device)["ladj_total"])

@@ -307,6 +307,16 @@ class PlanesPlanMixin:
                         kw.update(C_f32=0, ldc=self.D, N=self.D)
                         patch_out.append((len(ops), "gemm_planes", "C_f32"))
                         out_buf = ("user_out", "nat", self.D)
+                    elif final.startswith("base"):
+                        # Flow.log_prob: z only feeds the base density -- the epilogue reduces the row's Laplace / Normal terms per
+                        # column block ([B, 8] partial sums; tables refreshed per call by Engine.latent) and stores no rows
+                        stride = _round_up(self.D, 4)
+                        if "btab" not in ws:
+                            ws["btab"] = torch.zeros(3 * stride, dtype=torch.float32, device=device)
+                            ws["bpart"] = torch.zeros(B, 8, dtype=torch.float32, device=device)
+                        kw.update(C_f32=0, ldc=self.D, N=self.D, base_tab=ws["btab"].data_ptr(), base_tab_stride=stride,
+                                  base_part=ws["bpart"].data_ptr(), base=int(final[4:]))
+                        out_buf = ("bpart", "part", 8)
                     else:
                         if "nat2" not in ws:
                             ws["nat2"] = torch.zeros(B, self.LDn, dtype=torch.float32, device=device)
@@ -410,5 +420,9 @@ class PlanesPlanMixin:
             k += 1
 
         arr = (_ext.Op * len(ops))(*ops)
-        return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=[], final_gather=None,
+        n_part = 0
+        if out_buf[1] == "part":
+            tn = (_ext.load().usf_gemm_planes_variant(arr[len(ops) - 1].u.gemm_planes) - 5000) // 10
+            n_part = -(-self.D // (32 * tn))
+        return dict(arr=arr, n=len(ops), patch_in=patch_in, patch_out=patch_out, side=[], final_gather=None, n_part=n_part,
                     out_buf=out_buf, ws=ws, pk=pk, meta=meta, planes=True, planes_fmt=fmt, planes_train=bool(train))

@@ -232,8 +232,16 @@ class Flow(LayerLoopMixin, FitMixin, torch.nn.Module):
         out = torch.empty(B, dtype=torch.float32, device=x.device)
         if B == 0:
             return out
-        zbuf, ldz, logdet = eng.latent(x, context)
         info = self._base_info(x.device)
+        if info is not None and info[0] in ("laplace", "normal") and context is None:
+            # large batches on the planes pipeline: the base density is reduced in the last layer's epilogue (z is never stored)
+            base = _ext.BASE_LAPLACE if info[0] == "laplace" else _ext.BASE_NORMAL
+            fused = eng.latent_base_sums(x, base, info[1], info[2])
+            if fused is not None:
+                part, n_part, logdet = fused
+                _ext.base_logprob(part, 8, B, n_part, _ext.BASE_ROWSUM, None, None, 0.0, out, sum_out, logdet_dev=logdet.neg_dev)
+                return out
+        zbuf, ldz, logdet = eng.latent(x, context)
         if info is None:
             # arbitrary torch base distribution: density evaluated by the distribution object itself
             z = zbuf[:, : eng.D]
