@@ -191,8 +191,13 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
             b64 = _refreshed((len(part), D), torch.float64, dev,
                              lambda o, bias=bias: o.copy_(torch.stack(bias)))       # (one gather + one converting copy, not one per block)
             chunks.append(dict(lus=part, out=out, b=b64))
+            # bias folding, (y - b) Minv^T == y Minv^T + c: c = -(Minv b) of ALL blocks in one batched launch (it was one
+            # usf_matvec_f64 per block on the pack's tape: 32 launches of every small-batch training step)
+            c64 = torch.empty(len(part), D, dtype=torch.float64, device=dev)
+            _ext.gemm_f64(b64, out["Minv"], c64, batch=len(part), M=1, N=D, K=D, lda=D, ldb=D, ldc=D, strideA=D, strideB=D * D,
+                          strideC=D, transB=True, alpha=-1.0)
             for j, l in enumerate(part):
-                r = dict(M=out["M"][j], Minv=out["Minv"][j], b=b64[j], ladj=out["ladj"][j])
+                r = dict(M=out["M"][j], Minv=out["Minv"][j], b=b64[j], c=c64[j], ladj=out["ladj"][j])
                 if keep_factors:
                     r.update(L=out["tri"][2 * j], Ut=out["tri"][2 * j + 1], Linv=out["tri_inv"][2 * j],
                              Uinv_t=out["tri_inv"][2 * j + 1])
@@ -230,8 +235,11 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
             _ext.gemm_f64(Hs, out["Minv"], Mit, transA=True, b_off=r0 * DD, **bat)         # H^T M_lu^-1
             _ext.gemm_f64(chunks[0]["b"], Hs, bt, batch=m, M=1, N=D, K=D, lda=D, ldb=D, ldc=D, strideA=D, strideB=DD,
                           strideC=D, a_off=r0 * D)                                         # b_lu H
+            ct = f64(m, D)
+            _ext.gemm_f64(bt, Mit, ct, batch=m, M=1, N=D, K=D, lda=D, ldb=D, ldc=D, strideA=D, strideB=DD, strideC=D, transB=True,
+                          alpha=-1.0)                                                      # c = -(Minv b), as for the LU blocks
             for i, b in enumerate(seq):
-                res[id(b)] = dict(M=Mt[i], Minv=Mit[i], b=bt[i], ladj=out["ladj"][r0 + i])  # (Householder: ladj 0)
+                res[id(b)] = dict(M=Mt[i], Minv=Mit[i], b=bt[i], c=ct[i], ladj=out["ladj"][r0 + i])  # (Householder: ladj 0)
             batched = True
     for b in (seq if not batched else []):
         if True:                                                                  # general composition, block by block
