@@ -648,6 +648,22 @@ def main_flat(args, under_launcher):
         roofline["sustained_peak_is"] = (f"usf_mfma_probe in this run: register-only loop of the planes GEMM's MFMA mix, {pr['tflops_bf16']:.0f} TFLOP/s "
                                          f"bf16 = {pr['tflops_bf16'] / BF16_MFMA_PEAK_TFLOPS:.2f} of nominal, / 6 products per fp32 product; "
                                          f"median of {pr['launches']} launches of {pr['ms']:.2f} ms")
+        if mode == "log_prob":
+            # the clock the matrix cores actually run at (usf_set_clock_buffer: every block's lifetime in shader cycles over the same
+            # in ticks of the constant 100 MHz counter) under the step's planes GEMMs and under the probe: the nominal peak assumes
+            # 2400 MHz, the part holds less under dense MFMA load -- `frac_at_own_clock` prices the GEMM against the roof AT THE CLOCK
+            # IT RAN AT (what is left is issue slots the kernel does not fill; the clock itself is what its data movement costs)
+            with _ext_p.clock_meter(dev) as cm:
+                for _ in range(3):
+                    step()
+                sync()
+            with _ext_p.clock_meter(dev) as cm2:
+                _ext_p.mfma_probe(dev, iters=400, repeats=3)
+            g_mhz, p_mhz = cm.mhz(), cm2.mhz()
+            if g_mhz and p_mhz:
+                roofline["clock_mhz"] = {"under_gemm_planes": round(g_mhz), "under_mfma_probe": round(p_mhz), "nominal": 2400,
+                                         "how": "s_memtime / s_memrealtime over every block's lifetime, 3 steps / 4 probe launches behind the timed region"}
+                roofline["frac_at_own_clock"] = round(roofline["achieved"] / (roofline["peak"] * g_mhz / 2400.0), 4)
     # whole-flow algorithmic FLOP rate (mask-aware count)
     hs = list(hidden)
     flop_per_sample = (blocks * (2 if args.conj else 1) + 1) * 2.0 * D * D + blocks * 2.0 * (

@@ -975,6 +975,11 @@ int usf_base_param_grad_f32(const float* z, int64_t ldz, const float* g_lp, int6
  * (0: two per CU).  src1024: 1024 finite floats (device); sink: one float (device, never written); *flops_out (host, may be
  * NULL): the bf16 MFMA flops of the launch (fp32-equivalent: / 6).  The caller times the launch with events on `stream`. */
 int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, usf_stream_t stream);
+/* Measurement aid (bench.py: roofline.clock_mhz): while dev_buf2 (device memory, two 64-bit counters, zeroed by the caller) is
+ * set, every block of usf_gemm_planes_bf16x3's kernel and of usf_mfma_probe adds its lifetime to it -- [0] in shader-clock cycles
+ * (s_memtime), [1] in ticks of the constant 100 MHz counter (s_memrealtime): 100 MHz x [0] / [1] is the clock the matrix cores ran
+ * at under that kernel (the nominal peaks assume 2400 MHz).  NULL: off (the default; the kernels then read no counter). */
+int usf_set_clock_buffer(unsigned long long* dev_buf2);
 
 /* Tuning knobs of the kernels' host code (A/B switches, cross-overs): named integers, preset on first use from the environment
  * variable USFLOWS_AMD_TUNE ("name=value,..."), changed at run time here.  usf_get_tuning(name, dflt): the value in force. */

@@ -327,6 +327,29 @@ def test_base_density_in_the_last_gemms_epilogue(D, B, base, monkeypatch):
     assert ((lp1[:n].cpu().double() - ref).abs() / ref.abs()).max().item() < 1e-5
 
 
+def test_clock_meter_counts_the_gemm_blocks_lifetimes():
+    """usf_set_clock_buffer (bench.py: roofline.clock_mhz): set -> the planes GEMM and the MFMA probe add shader cycles and
+    100 MHz ticks of their blocks; unset -> the counters stay untouched"""
+    ext = _ext()
+    M, nkb = 8192, 25
+    A = torch.zeros(ext.planes_bytes(M, nkb), dtype=torch.uint8, device=DEV)
+    W = torch.zeros(3, 800, 800, dtype=torch.bfloat16, device=DEV)
+    C_ = torch.zeros_like(A)
+    with ext.clock_meter(DEV) as cm:
+        for _ in range(3):
+            ext.gemm_planes(A, W, M=M, a_nkb=nkb, nk=nkb, C_planes=C_, c_nkb=nkb, c_kbn=nkb)
+        torch.cuda.synchronize()
+    mhz = cm.mhz()
+    assert mhz is not None and 300.0 < mhz < 2600.0, mhz
+    before = cm.buf.clone()
+    ext.gemm_planes(A, W, M=M, a_nkb=nkb, nk=nkb, C_planes=C_, c_nkb=nkb, c_kbn=nkb)
+    torch.cuda.synchronize()
+    assert torch.equal(cm.buf, before)
+    with ext.clock_meter(DEV) as cm2:
+        ext.mfma_probe(DEV, iters=50, repeats=1)
+    assert 300.0 < cm2.mhz() < 2600.0
+
+
 def test_fp16_overflow_falls_back_to_bf16x3_planes():
     """a flow whose activations leave fp16's range (inputs ~1e6): the fp16x2 pass raises its range flag, the engine
     redoes it with bf16x3 planes -- same result as the bf16x3 mode, never an inf / NaN from the plane format"""

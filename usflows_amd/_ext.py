@@ -279,6 +279,7 @@ SYMBOLS = {
     "usf_wgrad_reduce_jobs_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "usf_base_param_grad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, C.c_int64, C.c_void_p]),
     "usf_mfma_probe": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_void_p]),
+    "usf_set_clock_buffer": (C.c_int, [_fp]),
     "usf_wgrad_planes_colsum_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "usf_wgrad_planes_ok": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
@@ -1303,6 +1304,26 @@ def mfma_probe(device, iters: int = 400, repeats: int = 5) -> dict:
     ms = times[len(times) // 2]
     tf = flops.value / (ms * 1e-3) / 1e12
     return dict(ms=ms, tflops_bf16=tf, tflops_f32_equiv=tf / 6.0, iters=iters, launches=repeats)
+
+
+class clock_meter:
+    """``with clock_meter(device) as m: ...launches...`` then ``m.mhz()``: the shader clock under the planes GEMM / the MFMA probe
+    launched inside the block (usf_set_clock_buffer: block lifetimes in shader cycles over the same in 100 MHz ticks)"""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        check(load().usf_set_clock_buffer(self.buf.data_ptr()), "usf_set_clock_buffer")
+        return self
+
+    def __exit__(self, *exc):
+        check(load().usf_set_clock_buffer(0), "usf_set_clock_buffer")
+        return False
+
+    def mhz(self):
+        c, t = (int(v) for v in self.buf.cpu().tolist())
+        return 100.0 * c / t if t > 0 else None
 
 
 def coupling_planes_op(op, device):

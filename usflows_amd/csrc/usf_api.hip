@@ -42,6 +42,8 @@ static void tune_init() {
     e = end ? end + 1 : nullptr;
   }
 }
+unsigned long long* g_clock_buffer = nullptr;
+unsigned long long* clock_buffer() { return g_clock_buffer; }
 long long tuning(const char* name, long long dflt) {
   tune_init();
   for (int i = 0; i < g_ntune; ++i)
@@ -478,6 +480,7 @@ int usf_base_param_grad_f32(const float* z, int64_t ldz, const float* g_lp, int6
                             const float* scale, float* d_loc_scale, float* workspace, int64_t workspace_floats, usf_stream_t stream) {
   return usf::base_param_grad(z, ldz, g_lp, M, D, base, loc, scale, d_loc_scale, workspace, workspace_floats, (hipStream_t)stream);
 }
+int usf_set_clock_buffer(unsigned long long* dev_buf2) { usf::g_clock_buffer = dev_buf2; return 0; }
 int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, usf_stream_t stream) {
   return usf::mfma_probe(src1024, sink, iters, blocks, flops_out, (hipStream_t)stream);
 }

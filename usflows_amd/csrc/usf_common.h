@@ -16,6 +16,9 @@ namespace usf {
 void set_error(const char* fmt, ...);
 // a named tuning knob (usf_api.hip: the one table, preset from USFLOWS_AMD_TUNE, changed with usf_set_tuning)
 long long tuning(const char* name, long long dflt);
+// measurement aid (usf_set_clock_buffer): device buffer [2] that the planes GEMM and the MFMA probe add their blocks' lifetimes
+// to -- [0] shader-clock cycles (s_memtime), [1] ticks of the constant 100 MHz counter (s_memrealtime); nullptr: off
+unsigned long long* clock_buffer();
 
 static inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

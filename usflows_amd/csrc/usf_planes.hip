@@ -264,6 +264,7 @@ struct PlArgs {
   int32_t* range_flag;
   // base density in the fp32-output epilogue (b_part == nullptr: off): tables loc | 1 / scale | constant, stride b_stride
   const float* b_tab; float* b_part; int b_stride; int b_base;
+  unsigned long long* clk;              // usf_set_clock_buffer: [shader cycles, 100 MHz ticks] summed over the blocks' lifetimes
   unsigned long long* dbg;
   unsigned long long* span;             // tuning builds only: [first wave start, last wave end] in s_memrealtime ticks
 };
@@ -293,6 +294,10 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
   const int lj = lane & 15, lg = lane >> 4;
 #ifdef USF_STAMP
   if (p.span && tid == 0) atomicMin(p.span, __builtin_amdgcn_s_memrealtime());
+#endif
+  unsigned long long clk_c0 = 0, clk_r0 = 0;    // (scalar registers; block-uniform branch)
+#ifndef USF_NO_CLOCK                             // (A/B builds: the kernel without the two counter reads)
+  if (p.clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
   // Persistent blocks: the grid is one block per CU (a multiple of 8); block b works through the virtual blocks
@@ -606,6 +611,12 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_kernel(const PlArgs p) {
 #ifdef USF_STAMP
   if (p.span && tid == 0) atomicMax(p.span + 1, __builtin_amdgcn_s_memrealtime());
 #endif
+#ifndef USF_NO_CLOCK
+  if (p.clk && tid == 0) {
+    atomicAdd(p.clk, __builtin_amdgcn_s_memtime() - clk_c0);
+    atomicAdd(p.clk + 1, __builtin_amdgcn_s_memrealtime() - clk_r0);
+  }
+#endif
 }
 
 #ifdef USF_STAMP
@@ -682,6 +693,7 @@ int gemm_planes(const usf_gemm_planes_desc* d, hipStream_t stream) {
   a.range_flag = d->range_flag;
   a.b_tab = d->base_tab; a.b_part = d->base_part; a.b_stride = (int)d->base_tab_stride; a.b_base = d->base;
   a.dbg = nullptr; a.span = nullptr;
+  a.clk = clock_buffer();
 #ifdef USF_STAMP
   a.dbg = g_pdbg; a.span = g_pspan;
   if (g_pspan) g_pspan += 2;            // one [start, end] pair per launch

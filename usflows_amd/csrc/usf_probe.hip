@@ -11,8 +11,11 @@ namespace usf {
 
 typedef __bf16 pb_bf16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(512, 2) void mfma_probe_kernel(const float* __restrict__ src, float* __restrict__ sink, int iters) {
+__global__ __launch_bounds__(512, 2) void mfma_probe_kernel(const float* __restrict__ src, float* __restrict__ sink, int iters,
+                                                            unsigned long long* __restrict__ clk) {
   const int tid = threadIdx.x;
+  unsigned long long clk_c0 = 0, clk_r0 = 0;
+  if (clk) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
   pb_bf16x8 a[2][3], w[2][3];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -45,13 +48,17 @@ __global__ __launch_bounds__(512, 2) void mfma_probe_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < 2; ++b) s += acc[t][b][0] + acc[t][b][1] + acc[t][b][2] + acc[t][b][3];
   if (s == 12345.678f) sink[0] = s;             // (never true: keeps the loop alive)
+  if (clk && tid == 0) {                         // usf_set_clock_buffer: the clock this loop runs at
+    atomicAdd(clk, __builtin_amdgcn_s_memtime() - clk_c0);
+    atomicAdd(clk + 1, __builtin_amdgcn_s_memrealtime() - clk_r0);
+  }
 }
 
 // one launch of `blocks` blocks (0: two per CU); returns the bf16 MFMA flops it performs through *flops_out
 int mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blocks, double* flops_out, hipStream_t stream) {
   if (!src1024 || !sink || iters <= 0 || iters > (1 << 24) || blocks < 0 || blocks > (1 << 20)) { set_error("usf_mfma_probe: bad arguments"); return -1; }
   if (blocks == 0) blocks = 2 * (int64_t)device_cu_count();
-  mfma_probe_kernel<<<(unsigned)blocks, 512, 0, stream>>>(src1024, sink, (int)iters);
+  mfma_probe_kernel<<<(unsigned)blocks, 512, 0, stream>>>(src1024, sink, (int)iters, clock_buffer());
   if (flops_out) *flops_out = (double)blocks * 8.0 * (double)iters * 120.0 * (2.0 * 16 * 16 * 32);
   return check_launch("usf_mfma_probe");
 }
