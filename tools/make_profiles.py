@@ -139,7 +139,8 @@ if want("pmc"):
            "coupling_planes_kernel": 3 * 13 * 32 * B * 6 + 3 * 2 * (H * 416 + H * H + 416 * H),
            "linear_bf16x3_kernel": 2 * B * D * 4 + 3 * D * 800 * 2,
            "coupling_bf16x3_kernel": (B * D + B * (D // 2)) * 4 + 3 * 2 * (H * 416 + H * H + 416 * H),
-           "base_logprob_kernel": B * D * 4 + B * 4}
+           "base_logprob_kernel": B * D * 4 + B * 4,
+           "pack_planes_rows_kernel": B * D * 4 + B * 800 * 6}                # fp32 rows in, bf16x3 planes out
     kern = {}
     for k, dct in sorted(agg.items()):
         f = sum(dct["FETCH_SIZE"]) / max(1, len(dct["FETCH_SIZE"]))
@@ -153,8 +154,10 @@ if want("pmc"):
                   "--no-cpu-baseline --no-kernel-timing` (default gemm_mode bf16x3), MI355X; tools/make_profiles.py",
         "units": "counter values are KB per dispatch (mean over dispatches). hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                  "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B); calibration inside "
-                 "the same run: base_logprob_kernel streams 205.5 MB with 16-B coalesced lane loads (its FETCH_SIZE should read 0.50x of "
-                 "that). algorithmic_bytes_per_launch: activations in + out once, weights once.",
+                 "the same run: pack_planes_rows_kernel<3, false> reads its 205.5 MB of fp32 rows once, coalesced (its FETCH_SIZE should read "
+                 "0.50x of that), and writes 314.6 MB of planes (its WRITE_SIZE should read 1.00x of that). "
+                 "algorithmic_bytes_per_launch: activations in + out once, weights once (the last GEMM, <3, 5, true>, stores [B, 8] "
+                 "partial sums of the base density instead of rows since round 5).",
         "kernels": kern}, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
     d = os.path.join(out, "pmc_mfma")
