@@ -2,9 +2,9 @@
 # --batch 32): launches per step and GPU time by kernel (gpurun_out/flat_fit32_stats.md) + the ordered trace of the last step
 cd "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}" || exit 1
 export TMPDIR=/tmp
-STEPS=${FIT_STEPS:-30}
+STEPS=${FIT_STEPS:-30}; CFG=${FIT_CFG:-cfg2}; MODE=${FIT_MODE:-fit}
 rm -rf gpurun_out/flat_ktrace
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/flat_ktrace -- python3 bench.py --config cfg2 --mode fit --batch 32 \
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/flat_ktrace -- python3 bench.py --config $CFG --mode $MODE --batch 32 \
     --steps $STEPS --warmup 6 --no-cpu-baseline --no-kernel-timing --no-also > gpurun_out/flat_rocprof.log 2>&1
 f=$(find gpurun_out/flat_ktrace -name "*kernel_stats.csv" | head -1)
 t=$(find gpurun_out/flat_ktrace -name "*kernel_trace.csv" | head -1)

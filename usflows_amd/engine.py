@@ -255,6 +255,8 @@ def prepare_affine_blocks(blocks: Sequence[nn.Module], device=None, keep_factors
                 ladj = _refreshed((), torch.float64, bm.device,
                                   lambda o, a=ladj, c=p_["ladj"]: torch.add(a, c, out=o))
             res[id(b)] = dict(M=M, Minv=Minv, b=bias, ladj=ladj)
+            if len(parts) == 1 and "c" in parts[0]:
+                res[id(b)]["c"] = parts[0]["c"]          # Sequential([LU]): the block IS its LU factor, folded bias included
     res["__chunks__"] = chunks
     return res
 
