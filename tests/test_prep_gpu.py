@@ -179,9 +179,13 @@ def test_batched_pack_jobs_transposed_through_tiles_bit_exact(planes_dtype):
     ext = _ext()
     g = torch.Generator().manual_seed(11)
     jobs = []
-    for k, (R, Cc, n_out, n_in, tr, dt) in enumerate([(70, 91, 95, 64, True, torch.float64), (33, 33, 33, 33, True, torch.float32),
-                                                      (784, 784, 784, 800, True, torch.float64), (40, 57, 31, 40, False, torch.float32),
-                                                      (5, 130, 129, 4, True, torch.float32), (64, 64, 64, 64, True, torch.float64)]):
+    # (the last field: ldw - n_in; the non-transposed jobs with 16-byte-aligned image rows take usf_pack_weights_f32's 4-column form)
+    for k, (R, Cc, n_out, n_in, tr, dt, pad) in enumerate([(70, 91, 95, 64, True, torch.float64, 3), (33, 33, 33, 33, True, torch.float32, 3),
+                                                           (784, 784, 784, 800, True, torch.float64, 3), (40, 57, 31, 40, False, torch.float32, 3),
+                                                           (5, 130, 129, 4, True, torch.float32, 3), (64, 64, 64, 64, True, torch.float64, 3),
+                                                           (784, 784, 784, 784, False, torch.float64, 0), (100, 300, 77, 260, False, torch.float32, 0),
+                                                           (20, 2100, 9, 2100, False, torch.float64, 4), (50, 61, 50, 61, False, torch.float64, 3),
+                                                           (128, 96, 128, 90, False, torch.float32, 2)]):
         src = torch.randn(R, Cc, generator=g, dtype=torch.float64).to(dt)
         rows_src, cols_src = (Cc, R) if tr else (R, Cc)
         oi = torch.randint(-1, rows_src, (n_out,), generator=g).to(torch.int32) if k % 2 == 0 else None
@@ -190,7 +194,7 @@ def test_batched_pack_jobs_transposed_through_tiles_bit_exact(planes_dtype):
             n_out = min(n_out, rows_src)
         if ii is None:
             n_in = min(n_in, cols_src)
-        ldw, ldp = n_in + 3, (n_in + 31) // 32 * 32
+        ldw, ldp = n_in + pad, (n_in + 31) // 32 * 32
         W = torch.full((n_out, ldw), 7.0)
         planes = None
         if planes_dtype is not None:
