@@ -239,10 +239,27 @@ struct GemmArgs {
   double alpha, beta;
 };
 
-// grid (tilesN, tilesM, batch)
+// XCD-aware block map of a batched launch, grid (gx, gy, nz rounded up to a multiple of 8): the hardware deals consecutive
+// blocks (x fastest) round-robin over the 8 XCDs, so in the plain map the tiles of ONE matrix are spread over all eight L2s and
+// every L2 streams every matrix.  Here block L = 8 slot + xcd works on matrix 8 (slot / tiles) + xcd, tile slot % tiles: all
+// tiles of a matrix share one XCD's L2 (its operands are re-read by the tiles of its row / column).  false: padding block.
+__device__ __forceinline__ bool xcd_batch_map(int nz, int& bx, int& by, int& bz) {
+  const int gx = gridDim.x, per = gridDim.x * gridDim.y;
+  const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int xcd = L & 7, slot = L >> 3;
+  const int grp = slot / per, t = slot - grp * per;
+  bz = grp * 8 + xcd;
+  by = t / gx;
+  bx = t - by * gx;
+  return bz < nz;
+}
+
+// grid (tilesN, tilesM, batch).  (The XCD-aware maps of tri_level_kernel were measured here too: whole matrices per XCD leave 33
+// matrices unevenly over 8 XCDs, 10-15 % slower; one row of tiles per XCD: no different from the plain map.)
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int r0 = by * 64, c0 = bx * 64;
   const int kmode = g.tri & 7, omask = g.tri >> 3;
   if (omask == 1 && r0 >= c0 + 64) return;       // tile strictly below the diagonal: not wanted, left untouched
   if (omask == 2 && c0 >= r0 + 64) return;       // ... strictly above
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   if (kmode == 2) kLo = (r0 > c0 ? r0 : c0);
   if (kmode == 3) kHi = r0 + 64;
   if (kmode == 4) kHi = c0 + 64;
-  const int64_t b = blockIdx.z;
+  const int64_t b = bz;
   gemm_tile_f64<TA, TB>(g.A + b * g.sA, g.lda, g.B + b * g.sB, g.ldb, g.C + b * g.sC, g.ldc, g.M, g.N, g.K, r0, c0,
                         kLo, kHi, g.alpha, g.beta);
 }
@@ -261,15 +278,17 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 //   PHASE 1: work[C block] = C A^-1          PHASE 2: inv[C block] = -B^-1 work[C block]
 template <int PHASE>
 __global__ __launch_bounds__(256) void tri_level_kernel(const double* __restrict__ tri, double* __restrict__ inv,
-                                                        double* __restrict__ work, int64_t D, int s) {
-  const int64_t p0 = 2 * (int64_t)blockIdx.y * s;
+                                                        double* __restrict__ work, int64_t D, int s, int nmat) {
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (nmat >= 8 && !xcd_batch_map(nmat, bx, by, bz)) return;       // (grid z: nmat rounded up to a multiple of 8)
+  const int64_t p0 = 2 * (int64_t)by * s;
   const int sa = s;
   const int64_t rest = D - p0 - s;
   const int sb = (int)(rest < s ? rest : s);
   const int tilesN = (sa + 63) / 64;
-  const int r0 = (blockIdx.x / tilesN) * 64, c0 = (blockIdx.x % tilesN) * 64;
+  const int r0 = (bx / tilesN) * 64, c0 = (bx % tilesN) * 64;
   if (r0 >= sb) return;
-  const int64_t mo = (int64_t)blockIdx.z * D * D;
+  const int64_t mo = (int64_t)bz * D * D;
   const int64_t offC = (p0 + s) * D + p0;
   if (PHASE == 1) {
     // (C A^-1)[i][j] = sum_{k >= j} C[i][k] A^-1[k][j]
@@ -614,9 +633,10 @@ int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream) {
   for (int64_t s = NB; s < D; s *= 2) {
     const int pairs = (int)((D - s + 2 * s - 1) / (2 * s));
     const int tiles = (int)(((s + 63) / 64) * ((s + 63) / 64));
-    dim3 grid(tiles, pairs, (unsigned)(2 * n));
-    tri_level_kernel<1><<<grid, 256, 0, stream>>>(d->tri, d->tri_inv, d->work, D, (int)s);
-    tri_level_kernel<2><<<grid, 256, 0, stream>>>(d->tri, d->tri_inv, d->work, D, (int)s);
+    const int nmat = (int)(2 * n);
+    dim3 grid(tiles, pairs, (unsigned)(nmat >= 8 ? (nmat + 7) / 8 * 8 : nmat));
+    tri_level_kernel<1><<<grid, 256, 0, stream>>>(d->tri, d->tri_inv, d->work, D, (int)s, nmat);
+    tri_level_kernel<2><<<grid, 256, 0, stream>>>(d->tri, d->tri_inv, d->work, D, (int)s, nmat);
   }
   rc = check_launch("tri_level");
   if (rc) return rc;
