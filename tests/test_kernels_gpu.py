@@ -448,7 +448,88 @@ def test_coupling_hidden_out_and_gate_need_the_bf16x3_kernel():
     d.hidden_out[0], d.ld_hidden_out = H.data_ptr(), 256          # no split planes given: the exact-f32 kernel would serve it
     import ctypes as C
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.usf_coupling_additive_f32(C.byref(d), st) == -2 and b"bf16x3 kernel only" in lib.usf_last_error()
+    assert lib.usf_coupling_additive_f32(C.byref(d), st) == -2 and b"hidden_out / USF_ACT_GATE are served by" in lib.usf_last_error()
     d.hidden_out[0] = None
     d.act = _ext.ACT_GATE
-    assert lib.usf_coupling_additive_f32(C.byref(d), st) == -2 and b"bf16x3 kernel only" in lib.usf_last_error()
+    assert lib.usf_coupling_additive_f32(C.byref(d), st) == -2 and b"hidden_out / USF_ACT_GATE are served by" in lib.usf_last_error()
+
+
+@pytest.mark.parametrize("mode", ["plain", "hidden_out", "gate", "ctx"])
+@pytest.mark.parametrize("M,n_pass,n_trans,hidden", [(1, 4, 4, [32]), (32, 8, 12, [32, 32]), (33, 52, 48, [32, 20]), (200, 48, 40, [64, 32, 40]),
+                                                      (256, 4, 8, [7, 5])])
+def test_tiny_layer_coupling_kernel(M, n_pass, n_trans, hidden, mode):
+    """usf_coupling_additive_f32 at launch-bound batches with tiny layers (usf_coupling_tiny.hip: the reference's live flat
+    configuration, gaussian_mixture.yaml): forward, the saved hidden activations, the backward chain in gate mode and the context
+    branch against the fp64 formulation (transforms.py:277-306, networks.py:739-751)"""
+    import ctypes as C
+    DEV = "cuda:0"
+    from usflows_amd import _ext
+    lib = _ext.load()
+    g = torch.Generator().manual_seed(M + n_pass)
+    nh = len(hidden)
+    ldz = n_pass + (n_trans + 3) // 4 * 4 + 4
+    off_trans = n_pass
+    z = torch.randn(M, ldz, generator=g)
+    dims = [n_pass] + hidden + [n_trans]
+    Ws = [torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5 for i in range(nh + 1)]
+    bs = [torch.randn(dims[i + 1], generator=g) * 0.1 for i in range(nh + 1)]
+    lds_ = [(dims[i] + 3) // 4 * 4 + 4 for i in range(nh + 1)]                       # row strides with slack, multiples of 4
+    Wp = [torch.zeros(dims[i + 1], lds_[i]) for i in range(nh + 1)]
+    for i in range(nh + 1):
+        Wp[i][:, : dims[i]] = Ws[i]
+    hmax = (max(hidden) + 3) // 4 * 4
+    gates = [torch.randn(M, hmax, generator=g) for _ in range(nh)]
+    ctx, Wc, bc = torch.randn(M, generator=g), torch.randn(hidden[0], generator=g), torch.randn(hidden[0], generator=g)
+    slope, sign = 0.01, -1.0
+    dev = lambda t: t.to(DEV).contiguous()
+    zd, Wd, bd, gd = dev(z), [dev(w) for w in Wp], [dev(b) for b in bs], [dev(t) for t in gates]
+    houts = [torch.full((M, hmax), 9.0, device=DEV) for _ in range(nh)]
+    ctxd, Wcd, bcd = dev(ctx), dev(Wc), dev(bc)
+    d = _ext.CouplingDesc()
+    d.z = d.out = zd.data_ptr(); d.ldz = d.ldo = ldz; d.M = M
+    d.off_pass, d.n_pass, d.off_trans, d.n_trans = 0, n_pass, off_trans, n_trans
+    d.n_hidden = nh
+    for i, h in enumerate(hidden):
+        d.hidden[i] = h
+    d.W_in, d.ldw_in, d.b_in = Wd[0].data_ptr(), lds_[0], bd[0].data_ptr()
+    for i in range(1, nh):
+        d.W_hid[i - 1], d.ldw_hid[i - 1], d.b_hid[i - 1] = Wd[i].data_ptr(), lds_[i], bd[i].data_ptr()
+    d.W_out, d.ldw_out, d.b_out = Wd[nh].data_ptr(), lds_[nh], bd[nh].data_ptr()
+    d.sign, d.slope, d.act = sign, slope, _ext.ACT_GATE if mode == "gate" else _ext.ACT_LEAKY_RELU
+    if mode in ("hidden_out", "gate"):
+        for i in range(nh):
+            d.hidden_out[i] = houts[i].data_ptr()
+        d.ld_hidden_out = hmax
+    if mode == "gate":
+        for i in range(nh):
+            d.gate[i] = gd[i].data_ptr()
+        d.ld_gate = hmax
+    if mode == "ctx":
+        d.context, d.W_ctx, d.b_ctx = ctxd.data_ptr(), Wcd.data_ptr(), bcd.data_ptr()
+    rc = lib.usf_coupling_additive_f32(C.byref(d), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.usf_last_error()
+    torch.cuda.synchronize()
+    # fp64 formulation
+    h = z[:, :n_pass].double()
+    hs = []
+    for i in range(nh):
+        v = h @ Ws[i].double().t() + bs[i].double()
+        if mode == "gate":
+            v = v * torch.where(gates[i][:, : hidden[i]].double() > 0, 1.0, slope)
+        else:
+            if i == 0 and mode == "ctx":
+                v = v + (ctx.double()[:, None] * Wc.double()[None, :] + bc.double()[None, :])
+            v = torch.where(v > 0, v, v * slope)
+        hs.append(v)
+        h = v
+    t = h @ Ws[nh].double().t() + bs[nh].double()
+    ref = z.double().clone()
+    ref[:, off_trans: off_trans + n_trans] += sign * t
+    got = zd.cpu().double()
+    s = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 2e-6 * s                                   # everything else of z untouched, too
+    if mode in ("hidden_out", "gate"):
+        for i in range(nh):
+            hv = houts[i].cpu().double()
+            assert (hv[:, : hidden[i]] - hs[i]).abs().max().item() < 2e-6 * max(1.0, hs[i].abs().max().item())
+            assert (hv[:, hidden[i]:] == 9.0).all()                                    # columns beyond the layer's width are not written

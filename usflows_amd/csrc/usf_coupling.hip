@@ -348,6 +348,8 @@ int coupling_max_width() { return CPL_HMAX; }
 
 bool coupling_bf16x3_eligible(const usf_coupling_desc* d);
 int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream);
+bool coupling_tiny_eligible(const usf_coupling_desc* d);       // usf_coupling_tiny.hip
+int coupling_tiny_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_additive_f32: null descriptor"); return -1; }
@@ -366,7 +368,8 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU && d->act != USF_ACT_GATE) { set_error("usf_coupling_additive_f32: bad act"); return -2; }
   if (coupling_bf16x3_eligible(d)) return coupling_bf16x3_dispatch(d, stream);
-  if (d->hidden_out[0] || d->act == USF_ACT_GATE) { set_error("usf_coupling_additive_f32: hidden_out / USF_ACT_GATE are served by the bf16x3 kernel only (split planes, hidden width in (128, 256], M >= 1024)"); return -2; }
+  if (coupling_tiny_eligible(d)) return coupling_tiny_dispatch(d, stream);
+  if (d->hidden_out[0] || d->act == USF_ACT_GATE) { set_error("usf_coupling_additive_f32: hidden_out / USF_ACT_GATE are served by the bf16x3 kernel (split planes, hidden width in (128, 256], M >= 1024) and by the tiny-layer kernel (M <= 256, segments <= 128, hidden <= 64) only"); return -2; }
   CplArgs a;
   a.z = d->z; a.out = d->out; a.ldz = d->ldz;
   a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans; a.n_trans4 = (int)((d->n_trans + 3) / 4 * 4);
