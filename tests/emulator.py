@@ -79,16 +79,28 @@ def emulate_gated_norm(d, pm: PtrMap, dtype=torch.float32):
 
 def emulate_coupling(d, pm: PtrMap, dtype=torch.float32):
     M = d.M
+    gated = d.act == _ext.ACT_GATE
+
+    def finish(v, l):
+        """layer l's nonlinearity -- or, in gate mode, leaky_relu_backward from the saved activation -- and the optional side output"""
+        if gated:
+            gt = pm.view(d.gate[l], M, d.hidden[l], d.ld_gate).to(dtype)
+            v = v * torch.where(gt > 0, torch.ones_like(v), torch.full_like(v, d.slope))
+        elif d.act == _ext.ACT_LEAKY_RELU:
+            v = torch.where(v > 0, v, v * d.slope)
+        if d.hidden_out[l]:
+            pm.view(d.hidden_out[l], M, d.hidden[l], d.ld_hidden_out).copy_(v.to(torch.float32))
+        return v
+
     zp = pm.view(d.z + 4 * d.off_pass, M, d.n_pass, d.ldz).to(dtype)
     h = zp @ pm.view(d.W_in, d.hidden[0], d.n_pass, d.ldw_in).to(dtype).t() + pm.vec(d.b_in, d.hidden[0]).to(dtype)
-    if d.context:
+    if d.context and not gated:
         ctx = pm.vec(d.context, M).to(dtype)
         h = h + (ctx[:, None] * pm.vec(d.W_ctx, d.hidden[0]).to(dtype)[None, :] + pm.vec(d.b_ctx, d.hidden[0]).to(dtype))
-    act = lambda v: torch.where(v > 0, v, v * d.slope) if d.act == _ext.ACT_LEAKY_RELU else v
-    h = act(h)
+    h = finish(h, 0)
     for j in range(d.n_hidden - 1):
         W = pm.view(d.W_hid[j], d.hidden[j + 1], d.hidden[j], d.ldw_hid[j]).to(dtype)
-        h = act(h @ W.t() + pm.vec(d.b_hid[j], d.hidden[j + 1]).to(dtype))
+        h = finish(h @ W.t() + pm.vec(d.b_hid[j], d.hidden[j + 1]).to(dtype), j + 1)
     Wo = pm.view(d.W_out, d.n_trans, d.hidden[d.n_hidden - 1], d.ldw_out).to(dtype)
     t = h @ Wo.t() + pm.vec(d.b_out, d.n_trans).to(dtype)
     zt = pm.view(d.z + 4 * d.off_trans, M, d.n_trans, d.ldz).to(dtype)
@@ -305,6 +317,25 @@ def _emu_wgrad_blocked(Yp, y_nkb, y_kb0, Ap, a_nkb, a_kb0, G, *, M, N, K, ldg, g
 
 
 _LAST_RUN = {}
+
+
+def _emu_coupling_op(op, device):
+    """_ext.coupling_op of the training backward (the fused / tiny-layer kernel in gate mode): every tensor the descriptor can
+    point into -- workspace, packed weights of the forward and backward images"""
+    eng, plan = _LAST_RUN["eng"], _LAST_RUN["plan"]
+    pm = PtrMap()
+    for t in plan["ws"].values():
+        pm.add(t)
+    for cp in plan["pk"]["coupling"].values():
+        for key in ("fused", "fused_bwd"):
+            f = cp.get(key)
+            if f:
+                for t in [f.get("W_in"), f.get("b_in"), f.get("W_out"), f.get("b_out"), f.get("zeros"), f.get("W_ctx"), f.get("b_ctx")]:
+                    pm.add(t)
+                for hv in f.get("hid", []):
+                    for t in (hv if isinstance(hv, (tuple, list)) else (hv,)):
+                        pm.add(t)
+    emulate_coupling(op.u.coupling, pm, torch.float64)
 
 
 def _emu_coupling_planes_op(op, device):
@@ -697,6 +728,7 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "gemm_planes", _emu_gemm_planes_call)
     monkeypatch.setattr(_ext, "wgrad_blocked", _emu_wgrad_blocked)
     monkeypatch.setattr(_ext, "coupling_planes_op", _emu_coupling_planes_op)
+    monkeypatch.setattr(_ext, "coupling_op", _emu_coupling_op)
     monkeypatch.setattr(FlowEngine, "_check_input", lambda self, x: x.contiguous().float())
     monkeypatch.setattr(FlowEngine, "_execute_plain",
                         lambda self, plan, x, out, context: run_plan(self, plan, x, out, context, dtype=torch.float64))

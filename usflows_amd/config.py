@@ -41,6 +41,7 @@ class Config:
     _KNOBS = dict(
         planes_min_rows=8192,      # engine: smallest batch of a planes plan
         base_in_epilogue=True,     # planes plans of Flow.log_prob: Laplace / Normal base density reduced by the last GEMM's epilogue
+        tiny_coupling=True,        # launch-bound batches, tiny conditioners (the live flat configuration): a coupling layer as ONE launch each way
         engine_graph=False,        # engine: replay small inference batches as a hipGraph (measured no faster than usf_run_ops)
         save_hidden=True,          # training: conditioners' hidden activations kept by the forward instead of recomputed
         wgrad_planes=True,         # fp32-row training path: weight gradients from operand planes (usf_wgrad_planes_f32)

@@ -361,6 +361,9 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (d->M == 0) return 0;
   if (!d->z || !d->out || !d->W_in || !d->b_in || !d->W_out || !d->b_out) { set_error("usf_coupling_additive_f32: null pointer"); return -1; }
   if (d->out != d->z || d->ldo != d->ldz) { set_error("usf_coupling_additive_f32: this version works in place (out == z)"); return -2; }
+  if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU && d->act != USF_ACT_GATE) { set_error("usf_coupling_additive_f32: bad act"); return -2; }
+  // tiny layers at launch-bound batches (M <= 256: disjoint from the bf16x3 kernel's M >= 1024): scalar accesses, no alignment rules
+  if (coupling_tiny_eligible(d)) return coupling_tiny_dispatch(d, stream);
   if ((d->n_pass & 3) || (d->off_pass & 3) || (d->off_trans & 3) || (d->ldz & 3) || d->off_trans + ((d->n_trans + 3) / 4) * 4 > d->ldz || (d->ldw_in & 3) || (d->ldw_out & 3) || !aligned16(d->z) ||
       !aligned16(d->W_in) || !aligned16(d->W_out) || !aligned16(d->b_in)) {
     set_error("usf_coupling_additive_f32: n_pass/off_pass/ldz/ldw must be multiples of 4 and pointers 16-byte aligned");
@@ -368,7 +371,6 @@ int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   }
   if (d->act != USF_ACT_NONE && d->act != USF_ACT_LEAKY_RELU && d->act != USF_ACT_GATE) { set_error("usf_coupling_additive_f32: bad act"); return -2; }
   if (coupling_bf16x3_eligible(d)) return coupling_bf16x3_dispatch(d, stream);
-  if (coupling_tiny_eligible(d)) return coupling_tiny_dispatch(d, stream);
   if (d->hidden_out[0] || d->act == USF_ACT_GATE) { set_error("usf_coupling_additive_f32: hidden_out / USF_ACT_GATE are served by the bf16x3 kernel (split planes, hidden width in (128, 256], M >= 1024) and by the tiny-layer kernel (M <= 256, segments <= 128, hidden <= 64) only"); return -2; }
   CplArgs a;
   a.z = d->z; a.out = d->out; a.ldz = d->ldz;

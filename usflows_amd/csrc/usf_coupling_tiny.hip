@@ -111,6 +111,10 @@ bool coupling_tiny_eligible(const usf_coupling_desc* d) {
 }
 
 int coupling_tiny_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
+  if (d->off_pass < 0 || d->off_trans < 0 || d->off_pass + d->n_pass > d->ldz || d->off_trans + d->n_trans > d->ldz) {
+    set_error("usf_coupling_additive_f32: column segments outside the rows (ldz %lld)", (long long)d->ldz);
+    return -2;
+  }
   TinyArgs a;
   a.z = d->z; a.out = d->out; a.ldz = d->ldz;
   a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans;

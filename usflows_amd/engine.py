@@ -1038,11 +1038,14 @@ class FlowEngine(PlanesPlanMixin):
             # its latency is one wave's serial MFMA chain; small batches run the MLP as 3 short linear launches
             if cp.get("general"):
                 self._general_coupling_ops(ops, lin_op, pk, cp, ws, zptr, B, sign, device)
-            elif self.use_fused_coupling and self._fused_ok(cp) and B >= self.fused_min_rows:
+            elif self.use_fused_coupling and self._fused_ok(cp) and (B >= self.fused_min_rows or self.tiny_coupling(cp, B)):
+                tiny = B < self.fused_min_rows
                 op = self._coupling_op(cp, zptr, B, sign, ws if use_ctx else None)
                 # training: the fused kernel also stores the hidden activations (buffers of the layer's own; 2 x B x 256 x 4
                 # bytes per coupling) -- the backward pass reads them instead of running the conditioner a second time
-                if train and self.save_fused_hidden(cp, B) and op.u.coupling.split_in:
+                # (tiny layers at launch-bound batches: usf_coupling_tiny.hip does the same, and the backward chain in one launch)
+                meta[-1]["tiny"] = tiny
+                if train and (tiny or (self.save_fused_hidden(cp, B) and op.u.coupling.split_in)):
                     for j in range(len(cp["hidden"])):
                         hname = f"Hs{j}_{i}"
                         if hname not in ws or ws[hname].shape[0] != B or ws[hname].shape[1] < self.hmax:
@@ -1102,6 +1105,23 @@ class FlowEngine(PlanesPlanMixin):
         return dict(arr=arr, n=len(ops), patch_in=[(i_, "linear", "A") for i_ in patch_in],
                     patch_out=[(i_, "linear", "C") for i_ in patch_out], side=side,
                     final_gather=final_gather, out_buf=cur, ws=ws, pk=pk, meta=meta)
+
+    def tiny_coupling(self, cp, B: int) -> bool:
+        """launch-bound batches with tiny conditioners (the reference's live flat configuration, gaussian_mixture.yaml: D <= 100,
+        DenseNN [32, 32], batch 32): the whole coupling layer is one launch of the tiny-layer kernel (usf_coupling_tiny.hip's
+        eligibility rule, restated: <= 256 rows, segments <= 128, hidden <= 64, every weight matrix + the rows in 64 KB of LDS)"""
+        from .config import config
+        if not config.tiny_coupling or not (0 < B <= 256) or cp.get("general"):
+            return False
+        hid = list(cp["hidden"])
+        if len(hid) > 3 or max(hid) > 64 or cp["pass_n"] > 128 or cp["tr_n"] > 128:
+            return False
+        floats, k = 0, cp["pass_n"]
+        for h_ in hid:
+            floats += h_ * (k + 1)
+            k = h_
+        floats += cp["tr_n"] * (k + 1) + 32 * (cp["pass_n"] + 1) + 2 * 32 * 65
+        return floats * 4 <= 64 * 1024
 
     def save_fused_hidden(self, cp, B: int) -> bool:
         """training: the fused bf16x3 coupling kernel stores its hidden activations (usf_coupling_desc::hidden_out) -- where
@@ -1342,7 +1362,7 @@ class FlowEngine(PlanesPlanMixin):
     def _plan(self, direction, B, device, has_ctx, final, train: bool = False):
         pk = self.pack(device)   # may invalidate plans
         key = (direction, B, str(device), has_ctx, final, self.use_fused_coupling, self.gemm_mode, self.fused_min_rows,
-               train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3,
+               config.tiny_coupling, train, self.use_planes, self.planes_min_rows, self._planes_fmt(), self.planes_min_rows_bf16x3,
                (not train) and self._merge_on(direction), train and self.use_train_planes, train and self.train_planes_min_rows)
         plan = self._plans.get(key)
         if plan is None:

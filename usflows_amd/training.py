@@ -773,8 +773,9 @@ class TrainPath:
     def _fused_cbwd(self, m, B) -> bool:
         """the data-gradient chain of this coupling layer's conditioner as ONE launch of the fused kernel (engine.
         coupling_backward_op): where the forward ran fused and left its hidden activations, unless USFLOWS_AMD_FUSED_CBWD=0"""
-        return (bool(m.get("hidden_saved_fused")) and not (bool(self.defer_small_grads) and 0 < B <= _ext.GRAD_JOB_MAX_ROWS)
-                and config.fused_cbwd)
+        # (queued gradient jobs read the d_h buffers after the layer loop: the tiny-layer form gives every layer buffers of its own)
+        return (bool(m.get("hidden_saved_fused")) and config.fused_cbwd
+                and (bool(m.get("tiny")) or not (bool(self.defer_small_grads) and 0 < B <= _ext.GRAD_JOB_MAX_ROWS)))
 
     def _lu_slots(self, plan) -> Optional[Dict[int, int]]:
         """id(affine block) -> row of the batched gradient stacks, when the batched chain rule applies: every affine
@@ -1084,9 +1085,11 @@ class TrainPath:
         if fused_bwd:
             # ONE launch: g_P += s * MLP^T(g_T) with the (Leaky)ReLU backward from the saved activations; the gradients at the
             # hidden activations land in Dh{j} for the weight gradients below
-            dh = [self._buf(ws, f"DhF{j}", B, hmax) for j in range(nl)]
+            dh = [self._buf(ws, f"DhF{j}{own if self._defer else ''}", B, hmax) for j in range(nl)]
             op = eng.coupling_backward_op(pk, cp, g_cur.data_ptr(), g_ld, B, sign, hbufs, dh,
                                           act=_ext.ACT_GATE if act != _ext.ACT_NONE else _ext.ACT_NONE)
+            if self._g_pending:
+                _ext.flush_jobs()      # the coupling layer before this one queued reads of columns this launch rewrites
             _ext.coupling_op(op, dev)
         # 2. output layer: d_out = gradient at the transformed half (unchanged by the layer: out_T = z_T + s MLP)
         tr_n, tr_off = cp["tr_n"], cp["tr_off"]
