@@ -455,7 +455,7 @@ def test_coupling_hidden_out_and_gate_need_the_bf16x3_kernel():
 
 
 @pytest.mark.parametrize("mode", ["plain", "hidden_out", "gate", "ctx"])
-@pytest.mark.parametrize("M,n_pass,n_trans,hidden", [(1, 4, 4, [32]), (32, 8, 12, [32, 32]), (33, 52, 48, [32, 20]), (200, 48, 40, [64, 32, 40]),
+@pytest.mark.parametrize("M,n_pass,n_trans,hidden", [(1, 4, 4, [32]), (32, 8, 12, [32, 32]), (33, 52, 48, [32, 20]), (200, 24, 20, [32, 32, 24]), (70, 32, 32, [64]),
                                                       (256, 4, 8, [7, 5])])
 def test_tiny_layer_coupling_kernel(M, n_pass, n_trans, hidden, mode):
     """usf_coupling_additive_f32 at launch-bound batches with tiny layers (usf_coupling_tiny.hip: the reference's live flat

@@ -1,113 +1,219 @@
 // usf_coupling_additive_f32 for TINY layers at launch-bound batches: the live flat configuration of the reference
 // (experiments/synthetic/gaussian_mixture.yaml:50-93: D = 2 .. 100, DenseNN [32, 32], Flow.fit at batch 32) spends a replayed
 // training step on ~200 dependent launches of a few microseconds each, three of them per coupling layer and direction.  Here the
-// whole layer -- conditioner MLP, (Leaky)ReLU or the backward gates, residual -- is ONE launch whose duration is one global-memory
-// round trip: every weight matrix of the layer is staged into LDS up front (they fit: <= 64 KB together), the rows' activations
-// stay in LDS between the layers, plain fp32 FMAs (a 32 x 32 layer is 1024 dot products of 32 terms: not matrix-core work).
-// Serves the training forms of the descriptor too: hidden_out (the saved activations) and USF_ACT_GATE (the conditioner's
-// data-gradient chain on transposed weights), which the fp32 MFMA kernel (usf_coupling.hip) does not.
+// whole layer -- conditioner MLP, (Leaky)ReLU or the backward gates, residual -- is ONE launch built around a single exposed
+// global-memory round trip: everything the layer reads -- every weight image, bias, the rows' conditioning half and residual, the
+// backward gates -- is fetched in ONE batch of loads and parked in LDS (<= 64 KB); the rows' activations stay in LDS between the
+// layers, which run on v_mfma_f32_16x16x4_f32.  Serves the training forms of the descriptor too: hidden_out (the saved
+// activations) and USF_ACT_GATE (the conditioner's data-gradient chain on transposed weights), which the fp32 MFMA kernel
+// (usf_coupling.hip) does not.
 #include "usf_common.h"
 
 namespace usf {
 
 constexpr int TINY_ROWS = 32;          // batch rows per block
-constexpr int TINY_MAXW = 128;         // widest column segment
-constexpr int TINY_MAXH = 64;          // widest hidden layer
+constexpr int TINY_MAXW = 64;          // widest column segment / hidden layer
 constexpr int TINY_MAX_M = 256;        // above this the MFMA kernels fill the chip
+constexpr int TINY_HS = TINY_MAXW + 4; // row stride of the activation buffers
+constexpr int TINY_NV4 = 4;            // 16-byte groups per thread of the largest weight image (64 x 64 floats)
 
-struct TinyArgs {
-  const float* z; float* out; int64_t ldz;
-  int M, off_pass, n_pass, off_trans, n_trans, nh;
-  int rows[4], K[4];                   // layer l = 0 .. nh (nh: the output layer): W[l] is [rows[l], K[l]]
-  const float* W[4]; int64_t ldw[4]; const float* b[4];
-  const float* ctx; const float* W_ctx; const float* b_ctx;
-  float* hout[3]; int64_t ld_hout;
-  const float* gate[3]; int64_t ld_gate;
-  float sign, slope; int act;
-  int woff[4];                         // float offsets of the layers' weight images in LDS (row stride K + 1)
-  int xoff, haoff, hboff;              // ... of the input rows [32, n_pass + 1] and the two activation buffers [32, 65]
+struct TinySeg {                       // a [rows, cols] piece of global memory and where it goes in LDS
+  const float* src; int64_t ld;
+  int n, cols;                         // n = rows * cols elements
+  float inv_cols;                      // 1 / cols (row of element e = floor((e + 0.5) * inv_cols))
+  int dst, dld;                        // LDS float offset and row stride
+  int batch;                           // rows are batch rows (offset by the block's first row, zero beyond M)
 };
 
-__global__ __launch_bounds__(256) void coupling_tiny_kernel(const TinyArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float tiny_lds[];
-  const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * TINY_ROWS;
-  // ---- everything the layer reads, in one wave of loads: the weight images and the rows' conditioning half ----
-#pragma unroll 1
-  for (int l = 0; l <= p.nh; ++l) {
-    const int R = p.rows[l], K = p.K[l];
-    float* dst = tiny_lds + p.woff[l];
-    for (int idx = tid; idx < R * K; idx += 256) {
-      const int r = idx / K, k = idx - r * K;
-      dst[r * (K + 1) + k] = p.W[l][(int64_t)r * p.ldw[l] + k];
-    }
-  }
-  float* x0 = tiny_lds + p.xoff;
-  for (int idx = tid; idx < TINY_ROWS * p.n_pass; idx += 256) {
-    const int r = idx / p.n_pass, k = idx - r * p.n_pass;
-    x0[r * (p.n_pass + 1) + k] = (row0 + r < p.M) ? p.z[(int64_t)(row0 + r) * p.ldz + p.off_pass + k] : 0.f;
-  }
-  __syncthreads();
-  float* hin = x0;
-  int ldin = p.n_pass + 1;
-  float* hbuf[2] = {tiny_lds + p.haoff, tiny_lds + p.hboff};
-  // ---- hidden layers: h = act(W h_prev + b [+ context branch]); gate mode: (W h_prev) * leaky_relu'(saved activation) ----
-#pragma unroll 1
-  for (int l = 0; l < p.nh; ++l) {
-    const int H = p.rows[l], K = p.K[l];
-    const float* Wl = tiny_lds + p.woff[l];
-    float* hout = hbuf[l & 1];
-    for (int idx = tid; idx < TINY_ROWS * H; idx += 256) {
-      const int r = idx / H, u = idx - r * H;
-      const int row = row0 + r;
-      float acc = p.b[l][u];                                   // (accumulators start at the bias, as in usf_coupling.hip)
-      const float* w = Wl + u * (K + 1);
-      const float* x = hin + r * ldin;
-      for (int k = 0; k < K; ++k) acc = fmaf(w[k], x[k], acc);
-      float v;
-      if (p.act == USF_ACT_GATE) {
-        const float gt = (row < p.M) ? p.gate[l][(int64_t)row * p.ld_gate + u] : 0.f;
-        v = acc * (gt > 0.f ? 1.f : p.slope);
-      } else {
-        if (l == 0 && p.ctx != nullptr && row < p.M) acc = acc + (p.ctx[row] * p.W_ctx[u] + p.b_ctx[u]);   // networks.py:741-743
-        v = act_apply(acc, p.act, p.slope);
+struct TinyArgs {
+  float* out; const float* z; int64_t ldz;
+  int M, off_trans, n_trans, nh;
+  int rows[4], K4[4];                  // layer l = 0 .. nh (nh: the output layer): rows[l] outputs, K4[l] = K rounded up to 4
+  int woff[4], wld[4], boff[4], goff[3];
+  TinySeg w[4], b[4], g[3], x0, zres, ctx, wctx, bctx;
+  int xoff, xld, haoff, hboff, zoff, coff, wcoff, bcoff;
+  float* hout[3]; int64_t ld_hout;
+  float sign, slope; int act, has_ctx;
+};
+
+// element e of a segment -> (row, column): floor((e + 0.5) / cols) through the reciprocal (exact for these sizes)
+template <int NV>
+__device__ __forceinline__ void tiny_load(const TinySeg& s, int row0, int M, float (&v)[NV]) {
+  const int cnt = (s.n + 255) >> 8;                       // block-uniform: iterations beyond it are skipped by a scalar branch
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = 0.f;
+    if (i < cnt) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < s.n) {
+        const int r = (int)(((float)e + 0.5f) * s.inv_cols);
+        const int c = e - r * s.cols;
+        const int gr = s.batch ? row0 + r : r;
+        if (!s.batch || gr < M) v[i] = s.src[(int64_t)gr * s.ld + c];
       }
-      hout[r * (TINY_MAXH + 1) + u] = v;
-      if (p.hout[l] != nullptr && row < p.M) p.hout[l][(int64_t)row * p.ld_hout + u] = v;
     }
-    __syncthreads();
-    hin = hout;
-    ldin = TINY_MAXH + 1;
   }
-  // ---- output layer + residual: out[:, trans] = z[:, trans] + sign * (W_out h + b_out) ----
-  {
-    const int N = p.rows[p.nh], K = p.K[p.nh];
-    const float* Wl = tiny_lds + p.woff[p.nh];
-    for (int idx = tid; idx < TINY_ROWS * N; idx += 256) {
-      const int r = idx / N, n = idx - r * N;
-      const int row = row0 + r;
-      if (row >= p.M) continue;
-      float acc = 0.f;
-      const float* w = Wl + n * (K + 1);
-      const float* x = hin + r * ldin;
-      for (int k = 0; k < K; ++k) acc = fmaf(w[k], x[k], acc);
-      const int64_t o = (int64_t)row * p.ldz + p.off_trans + n;
-      p.out[o] = p.z[o] + p.sign * (acc + p.b[p.nh][n]);
+}
+template <int NV>
+__device__ __forceinline__ void tiny_store(const TinySeg& s, float* lds, const float (&v)[NV]) {
+  const int cnt = (s.n + 255) >> 8;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < cnt) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < s.n) {
+        const int r = (int)(((float)e + 0.5f) * s.inv_cols);
+        lds[s.dst + r * s.dld + (e - r * s.cols)] = v[i];
+      }
+    }
+  }
+}
+// weight images: whole 16-byte groups (the source rows are 16-byte aligned and zero beyond K up to the next multiple of 4)
+template <int NV>
+__device__ __forceinline__ void tiny_load4(const TinySeg& s, f32x4 (&v)[NV]) {
+  const int cnt = (s.n + 255) >> 8;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < cnt) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < s.n) {
+        const int r = (int)(((float)e + 0.5f) * s.inv_cols);
+        v[i] = *reinterpret_cast<const f32x4*>(s.src + (int64_t)r * s.ld + 4 * (e - r * s.cols));
+      }
+    }
+  }
+}
+template <int NV>
+__device__ __forceinline__ void tiny_store4(const TinySeg& s, float* lds, const f32x4 (&v)[NV]) {
+  const int cnt = (s.n + 255) >> 8;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (i < cnt) {
+      const int e = threadIdx.x + 256 * i;
+      if (e < s.n) {
+        const int r = (int)(((float)e + 0.5f) * s.inv_cols);
+        *reinterpret_cast<f32x4*>(lds + s.dst + r * s.dld + 4 * (e - r * s.cols)) = v[i];
+      }
     }
   }
 }
 
-// the descriptor has passed coupling_dispatch's checks (usf_coupling.hip)
+// One wave per SIMD and nothing to hide behind: the kernel's time is its instruction count.  The layers run on
+// v_mfma_f32_16x16x4_f32 (a 32-row x 16-unit tile per wave: K / 4 matrix instructions and two LDS words per lane each), the weight
+// images are staged as 16-byte groups, and every staging loop runs only the iterations its segment has.
+__global__ __launch_bounds__(256) void coupling_tiny_kernel(const TinyArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lj = lane & 15, lg = lane >> 4;
+  const int row0 = blockIdx.x * TINY_ROWS;
+  const bool gated = p.act == USF_ACT_GATE;
+  // ---- everything the layer reads, ONE batch of loads: the arithmetic of a layer is far too short to hide a second round trip ----
+  f32x4 vw[4][TINY_NV4];
+  float vx[8], vz[8], vb[4][1], vg[3][8], vc[1], vwc[1], vbc[1];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l <= p.nh) { tiny_load4<TINY_NV4>(p.w[l], vw[l]); tiny_load<1>(p.b[l], row0, p.M, vb[l]); }
+  tiny_load<8>(p.x0, row0, p.M, vx);
+  tiny_load<8>(p.zres, row0, p.M, vz);
+  if (gated) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+      if (l < p.nh) tiny_load<8>(p.g[l], row0, p.M, vg[l]);
+  }
+  if (p.has_ctx) { tiny_load<1>(p.ctx, row0, p.M, vc); tiny_load<1>(p.wctx, row0, p.M, vwc); tiny_load<1>(p.bctx, row0, p.M, vbc); }
+  // zero the padded images while the loads fly (weight rows beyond the layer's width, inputs beyond K, activations beyond the widths)
+  for (int e = tid; e < (p.zoff >> 2); e += 256) reinterpret_cast<f32x4*>(tl)[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l <= p.nh) { tiny_store4<TINY_NV4>(p.w[l], tl, vw[l]); tiny_store<1>(p.b[l], tl, vb[l]); }
+  tiny_store<8>(p.x0, tl, vx);
+  tiny_store<8>(p.zres, tl, vz);
+  if (gated) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+      if (l < p.nh) tiny_store<8>(p.g[l], tl, vg[l]);
+  }
+  if (p.has_ctx) { tiny_store<1>(p.ctx, tl, vc); tiny_store<1>(p.wctx, tl, vwc); tiny_store<1>(p.bctx, tl, vbc); }
+  __syncthreads();
+  const float* hin = tl + p.xoff;
+  int ldin = p.xld;
+#pragma unroll 1
+  for (int l = 0; l <= p.nh; ++l) {
+    const bool last = l == p.nh;
+    const int H = p.rows[l], K4 = p.K4[l];
+    const int wld = p.wld[l];
+    const float* bl = tl + p.boff[l];
+    float* hout = tl + ((l & 1) ? p.hboff : p.haoff);
+    const int ntile = 2 * ((H + 15) >> 4);                      // (row tile, unit tile) pairs: tile t = 2 ut + rt
+    for (int t = wave; t < ntile; t += 4) {                     // wave-uniform
+      const int rt = t & 1, ut = t >> 1;
+      // D[unit, row] += W[unit, k] x[row, k]: A lane (unit lj, k lg), B lane (k lg, row lj); D lane: row lj, units 4 lg + i
+      const float* wa = tl + p.woff[l] + (ut * 16 + lj) * wld + lg;
+      const float* xb = hin + (rt * 16 + lj) * ldin + lg;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < K4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 * k], xb[4 * k], acc, 0, 0, 0);
+      const int r = rt * 16 + lj, row = row0 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = ut * 16 + 4 * lg + i;
+        if (u >= H) {                                             // the next layer reads whole groups of four: zeros, never leftovers
+          if (!last && u < ((H + 3) & ~3)) hout[r * TINY_HS + u] = 0.f;
+          continue;
+        }
+        if (!last) {
+          float v = acc[i] + bl[u];
+          if (gated) {
+            v = v * (tl[p.goff[l] + r * H + u] > 0.f ? 1.f : p.slope);
+          } else {
+            if (l == 0 && p.has_ctx) v = v + (tl[p.coff + r] * tl[p.wcoff + u] + tl[p.bcoff + u]);          // networks.py:741-743
+            v = act_apply(v, p.act, p.slope);
+          }
+          hout[r * TINY_HS + u] = v;
+          if (p.hout[l] != nullptr && row < p.M) p.hout[l][(int64_t)row * p.ld_hout + u] = v;
+        } else if (row < p.M) {
+          p.out[(int64_t)row * p.ldz + p.off_trans + u] = tl[p.zoff + r * p.n_trans + u] + p.sign * (acc[i] + bl[u]);
+        }
+      }
+    }
+    if (last) break;
+    __syncthreads();
+    hin = hout;
+    ldin = TINY_HS;
+  }
+}
+
+static inline int r4(int64_t v) { return (int)((v + 3) / 4 * 4); }
+
+// LDS floats of a descriptor's layout (see coupling_tiny_dispatch); the engine restates it (FlowEngine.tiny_coupling)
+static int64_t tiny_lds_floats(const usf_coupling_desc* d) {
+  int64_t f = 0, k = d->n_pass, rows_sum = 0, gate_sum = 0;
+  for (int i = 0; i <= d->n_hidden; ++i) {
+    const int64_t rows = i == d->n_hidden ? d->n_trans : d->hidden[i];
+    f += ((rows + 15) / 16 * 16) * (r4(k) + 4);
+    rows_sum += rows;
+    if (i < d->n_hidden) gate_sum += TINY_ROWS * rows;
+    k = rows;
+  }
+  return f + TINY_ROWS * (r4(d->n_pass) + 4) + 2 * TINY_ROWS * TINY_HS + rows_sum + TINY_ROWS * d->n_trans + gate_sum + TINY_ROWS + 2 * TINY_MAXW;
+}
+
+// the descriptor has passed coupling_dispatch's basic checks (usf_coupling.hip)
 bool coupling_tiny_eligible(const usf_coupling_desc* d) {
   if (!tuning("coupling_tiny", 1) || d->M > TINY_MAX_M || d->n_pass > TINY_MAXW || d->n_trans > TINY_MAXW) return false;
-  int64_t floats = 0, k = d->n_pass;
-  for (int i = 0; i < d->n_hidden; ++i) {
-    if (d->hidden[i] < 1 || d->hidden[i] > TINY_MAXH) return false;
-    floats += (int64_t)d->hidden[i] * (k + 1);
-    k = d->hidden[i];
+  for (int i = 0; i < d->n_hidden; ++i)
+    if (d->hidden[i] < 1 || d->hidden[i] > TINY_MAXW) return false;
+  // the weight images are staged as 16-byte groups: aligned rows, and (the padding contract of the header) zeros beyond K up to
+  // the next multiple of 4
+  int64_t k = d->n_pass;
+  for (int i = 0; i <= d->n_hidden; ++i) {
+    const float* W = i == d->n_hidden ? d->W_out : (i == 0 ? d->W_in : d->W_hid[i - 1]);
+    const int64_t ldw = i == d->n_hidden ? d->ldw_out : (i == 0 ? d->ldw_in : d->ldw_hid[i - 1]);
+    if (!W || !aligned16(W) || (ldw & 3) || ldw < r4(k)) return false;
+    k = i == d->n_hidden ? d->n_trans : d->hidden[i];
   }
-  floats += d->n_trans * (k + 1) + TINY_ROWS * (d->n_pass + 1) + 2 * TINY_ROWS * (TINY_MAXH + 1);
-  return floats * 4 <= 64 * 1024;
+  return tiny_lds_floats(d) * 4 <= 64 * 1024;
 }
 
 int coupling_tiny_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
@@ -116,40 +222,64 @@ int coupling_tiny_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
     return -2;
   }
   TinyArgs a;
-  a.z = d->z; a.out = d->out; a.ldz = d->ldz;
-  a.M = (int)d->M; a.off_pass = (int)d->off_pass; a.n_pass = (int)d->n_pass; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans;
-  a.nh = d->n_hidden;
+  a.out = d->out; a.z = d->z; a.ldz = d->ldz;
+  a.M = (int)d->M; a.off_trans = (int)d->off_trans; a.n_trans = (int)d->n_trans; a.nh = d->n_hidden;
   const bool want_h = d->hidden_out[0] != nullptr, gated = d->act == USF_ACT_GATE;
+  auto seg = [](const float* src, int64_t ld, int rows, int cols, int dst, int dld, int batch) {
+    TinySeg s;
+    s.src = src; s.ld = ld; s.n = src ? rows * cols : 0; s.cols = cols > 0 ? cols : 1; s.inv_cols = 1.0f / (float)s.cols;
+    s.dst = dst; s.dld = dld; s.batch = batch;
+    return s;
+  };
+  // LDS layout: [weight images | input rows | two activation buffers]  (zero-filled: p.zoff floats)  | residual | biases | gates | ctx
   int k = (int)d->n_pass, off = 0;
   for (int l = 0; l <= a.nh; ++l) {
     const bool last = l == a.nh;
-    a.rows[l] = last ? (int)d->n_trans : d->hidden[l];
-    a.K[l] = k;
-    a.W[l] = last ? d->W_out : (l == 0 ? d->W_in : d->W_hid[l - 1]);
-    a.ldw[l] = last ? d->ldw_out : (l == 0 ? d->ldw_in : d->ldw_hid[l - 1]);
-    a.b[l] = last ? d->b_out : (l == 0 ? d->b_in : d->b_hid[l - 1]);
-    if (!a.W[l] || !a.b[l] || a.ldw[l] < k) { set_error("usf_coupling_additive_f32: bad layer %d (null pointer or ld < K)", l); return -2; }
-    a.woff[l] = off;
-    off += a.rows[l] * (k + 1);
-    k = a.rows[l];
+    const int rows = last ? (int)d->n_trans : d->hidden[l];
+    const float* W = last ? d->W_out : (l == 0 ? d->W_in : d->W_hid[l - 1]);
+    const int64_t ldw = last ? d->ldw_out : (l == 0 ? d->ldw_in : d->ldw_hid[l - 1]);
+    const float* b = last ? d->b_out : (l == 0 ? d->b_in : d->b_hid[l - 1]);
+    if (!W || !b || ldw < k) { set_error("usf_coupling_additive_f32: bad layer %d (null pointer or ld < K)", l); return -2; }
+    a.rows[l] = rows; a.K4[l] = r4(k) / 4; a.woff[l] = off; a.wld[l] = r4(k) + 4;
+    a.w[l] = seg(W, ldw, rows, r4(k) / 4, off, a.wld[l], 0);        // (cols = 16-byte groups per row)
+    off += ((rows + 15) / 16 * 16) * a.wld[l];
+    k = rows;
   }
-  for (int l = a.nh + 1; l < 4; ++l) { a.rows[l] = a.K[l] = a.woff[l] = 0; a.W[l] = nullptr; a.b[l] = nullptr; a.ldw[l] = 0; }
-  a.xoff = off; off += TINY_ROWS * (a.n_pass + 1);
-  a.haoff = off; off += TINY_ROWS * (TINY_MAXH + 1);
-  a.hboff = off; off += TINY_ROWS * (TINY_MAXH + 1);
-  for (int l = 0; l < 3; ++l) {
-    a.hout[l] = (want_h && l < a.nh) ? d->hidden_out[l] : nullptr;
-    a.gate[l] = (gated && l < a.nh) ? d->gate[l] : nullptr;
-    if (want_h && l < a.nh && !d->hidden_out[l]) { set_error("usf_coupling_additive_f32: hidden_out needs a buffer for every hidden layer"); return -1; }
-    if (gated && l < a.nh && !d->gate[l]) { set_error("usf_coupling_additive_f32: USF_ACT_GATE needs gate[l] for every hidden layer"); return -1; }
+  for (int l = a.nh + 1; l < 4; ++l) { a.rows[l] = a.K4[l] = a.woff[l] = a.wld[l] = a.boff[l] = 0; a.w[l] = seg(nullptr, 0, 0, 1, 0, 0, 0); a.b[l] = a.w[l]; }
+  a.xoff = off; a.xld = r4(d->n_pass) + 4;
+  a.x0 = seg(d->z + d->off_pass, d->ldz, TINY_ROWS, (int)d->n_pass, off, a.xld, 1);
+  off += TINY_ROWS * a.xld;
+  a.haoff = off; off += TINY_ROWS * TINY_HS;
+  a.hboff = off; off += TINY_ROWS * TINY_HS;
+  a.zoff = off;
+  a.zres = seg(d->z + d->off_trans, d->ldz, TINY_ROWS, (int)d->n_trans, off, (int)d->n_trans, 1);
+  off += TINY_ROWS * (int)d->n_trans;
+  for (int l = 0; l <= a.nh; ++l) {
+    const float* b = l == a.nh ? d->b_out : (l == 0 ? d->b_in : d->b_hid[l - 1]);
+    a.boff[l] = off;
+    a.b[l] = seg(b, 0, 1, a.rows[l], off, a.rows[l], 0);
+    off += a.rows[l];
   }
-  a.ld_hout = d->ld_hidden_out; a.ld_gate = d->ld_gate;
   int hmax = 0;
-  for (int l = 0; l < a.nh; ++l) hmax = d->hidden[l] > hmax ? d->hidden[l] : hmax;
-  if ((want_h && a.ld_hout < hmax) || (gated && a.ld_gate < hmax)) { set_error("usf_coupling_additive_f32: ld_hidden_out / ld_gate below the hidden width"); return -2; }
-  a.ctx = gated ? nullptr : d->context; a.W_ctx = d->W_ctx; a.b_ctx = d->b_ctx;
-  if (a.ctx && (!a.W_ctx || !a.b_ctx)) { set_error("usf_coupling_additive_f32: context needs W_ctx and b_ctx"); return -1; }
+  for (int l = 0; l < 3; ++l) {
+    const bool used = l < a.nh;
+    a.hout[l] = (want_h && used) ? d->hidden_out[l] : nullptr;
+    if (want_h && used && !d->hidden_out[l]) { set_error("usf_coupling_additive_f32: hidden_out needs a buffer for every hidden layer"); return -1; }
+    if (gated && used && !d->gate[l]) { set_error("usf_coupling_additive_f32: USF_ACT_GATE needs gate[l] for every hidden layer"); return -1; }
+    a.goff[l] = off;
+    a.g[l] = seg((gated && used) ? d->gate[l] : nullptr, d->ld_gate, TINY_ROWS, used ? d->hidden[l] : 1, off, used ? d->hidden[l] : 1, 1);
+    if (gated && used) off += TINY_ROWS * d->hidden[l];
+    if (used && d->hidden[l] > hmax) hmax = d->hidden[l];
+  }
+  a.ld_hout = d->ld_hidden_out;
+  if ((want_h && a.ld_hout < hmax) || (gated && d->ld_gate < hmax)) { set_error("usf_coupling_additive_f32: ld_hidden_out / ld_gate below the hidden width"); return -2; }
+  a.has_ctx = (!gated && d->context != nullptr) ? 1 : 0;
+  if (a.has_ctx && (!d->W_ctx || !d->b_ctx)) { set_error("usf_coupling_additive_f32: context needs W_ctx and b_ctx"); return -1; }
+  a.coff = off; a.ctx = seg(a.has_ctx ? d->context : nullptr, 1, TINY_ROWS, 1, off, 1, 1); off += TINY_ROWS;
+  a.wcoff = off; a.wctx = seg(a.has_ctx ? d->W_ctx : nullptr, 0, 1, d->hidden[0], off, d->hidden[0], 0); off += TINY_MAXW;
+  a.bcoff = off; a.bctx = seg(a.has_ctx ? d->b_ctx : nullptr, 0, 1, d->hidden[0], off, d->hidden[0], 0); off += TINY_MAXW;
   a.sign = d->sign; a.slope = d->slope; a.act = d->act;
+  if ((int64_t)off * 4 > 64 * 1024) { set_error("usf_coupling_additive_f32: tiny-layer layout exceeds 64 KB of LDS"); return -3; }
   const dim3 grid((unsigned)((d->M + TINY_ROWS - 1) / TINY_ROWS)), block(256);
   hipLaunchKernelGGL(coupling_tiny_kernel, grid, block, (size_t)off * sizeof(float), stream, a);
   return check_launch("usf_coupling_additive_f32(tiny)");

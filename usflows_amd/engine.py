@@ -1108,20 +1108,26 @@ class FlowEngine(PlanesPlanMixin):
 
     def tiny_coupling(self, cp, B: int) -> bool:
         """launch-bound batches with tiny conditioners (the reference's live flat configuration, gaussian_mixture.yaml: D <= 100,
-        DenseNN [32, 32], batch 32): the whole coupling layer is one launch of the tiny-layer kernel (usf_coupling_tiny.hip's
-        eligibility rule, restated: <= 256 rows, segments <= 128, hidden <= 64, every weight matrix + the rows in 64 KB of LDS)"""
+        DenseNN [32, 32], batch 32): the whole coupling layer is one launch of the tiny-layer kernel each way
+        (usf_coupling_tiny.hip's eligibility rule, restated for the forward AND the backward descriptor: <= 256 rows, segments
+        and hidden widths <= 64, the layer's weight images + rows + side inputs in 64 KB of LDS)"""
         from .config import config
         if not config.tiny_coupling or not (0 < B <= 256) or cp.get("general"):
             return False
-        hid = list(cp["hidden"])
-        if len(hid) > 3 or max(hid) > 64 or cp["pass_n"] > 128 or cp["tr_n"] > 128:
+        hid = [int(h_) for h_ in cp["hidden"]]
+        if len(hid) > 3 or max(hid) > 64 or cp["pass_n"] > 64 or cp["tr_n"] > 64:
             return False
-        floats, k = 0, cp["pass_n"]
-        for h_ in hid:
-            floats += h_ * (k + 1)
-            k = h_
-        floats += cp["tr_n"] * (k + 1) + 32 * (cp["pass_n"] + 1) + 2 * 32 * 65
-        return floats * 4 <= 64 * 1024
+
+        def lds_floats(n_pass, hidden, n_trans):
+            r4 = lambda v: (v + 3) // 4 * 4
+            f, k, rows_sum = 0, n_pass, 0
+            for rows in list(hidden) + [n_trans]:
+                f += (rows + 15) // 16 * 16 * (r4(k) + 4)
+                rows_sum += rows
+                k = rows
+            return f + 32 * (r4(n_pass) + 4) + 2 * 32 * 68 + rows_sum + 32 * n_trans + 32 * sum(hidden) + 32 + 128
+
+        return max(lds_floats(cp["pass_n"], hid, cp["tr_n"]), lds_floats(cp["tr_n"], hid[::-1], cp["pass_n"])) * 4 <= 64 * 1024
 
     def save_fused_hidden(self, cp, B: int) -> bool:
         """training: the fused bf16x3 coupling kernel stores its hidden activations (usf_coupling_desc::hidden_out) -- where
