@@ -751,6 +751,15 @@ int usf_gemm_f64(const double* A, int64_t lda, int64_t strideA, int32_t transA, 
                  int64_t strideB, int32_t transB, double* C, int64_t ldc, int64_t strideC, int64_t M, int64_t N,
                  int64_t K, int64_t batch, double alpha, double beta, int32_t tri, usf_stream_t stream);
 
+/* The last step of LUTransform's parameter gradients under Flow.fit (what autograd derives through transforms.py:1271-1320's
+ * tril(L_raw, -1) + I and triu(U_raw), and the log-det term sum log|diag U|), for n blocks at once, fp64 in / fp32 out:
+ *     dL_out[i] = tril(dL[i] (+ TL[i]), -1)                     dU_out[i] = triu(dU[i] (+ TU[i])) + diag(c[i] / diag(U_i))
+ * dL / dU [n, D, D]: the chain-rule products (only the wanted triangle has to be valid); TL / TU: the products of the M = L U
+ * usages, or NULL; c [n]: coefficient of the log-det term; tri [2n, D, D] as usf_lu_prepare_f64 leaves it (U_i^T at 2i + 1).
+ * One pass instead of triu / tril / diagonal add / sums / converting copies over [n, D, D] tensors. */
+int usf_lu_grad_finish_f64(const double* dL, const double* dU, const double* TL, const double* TU, const double* c,
+                           const double* tri, int64_t n, int64_t D, float* dL_out, float* dU_out, usf_stream_t stream);
+
 /* HouseholderTransform._construct_householder_permutation (transforms.py:795-809) as row-local rank-1 updates:
  * out = w_0 prod_k (I - 2 v_k v_k^T / v_k.v_k); w_0 [D,D] fp32, vk [nvs,D] fp32, out [D,D] fp64. */
 int usf_householder_f64(const float* w_0, const float* vk, int64_t nvs, int64_t D, double* out, usf_stream_t stream);

@@ -707,6 +707,16 @@ def _emu_gemm_f64(A, B, Cout, *, M, N, K, lda, ldb, ldc, transA=False, transB=Fa
         c.copy_(r + beta * c if beta != 0.0 else r)
 
 
+def _emu_lu_grad_finish(dL, dU, TL, TU, c, tri, n, D, out_L, out_U):
+    l = dL[:n].double() + (TL[:n].double() if TL is not None else 0.0)
+    u = dU[:n].double().triu()
+    u = u + torch.diag_embed(c[:n, None].double() / tri[1:2 * n:2].double().diagonal(dim1=1, dim2=2))
+    if TU is not None:
+        u = u + TU[:n].double().triu()
+    out_L.view(n, D, D).copy_(l.tril(-1).float())
+    out_U.view(n, D, D).copy_(u.float())
+
+
 def install_training_emulation(monkeypatch):
     """parameter prep + every batch-sized entry point of the training path on torch-CPU; FlowEngine runs its op
     lists through run_plan.  Exercises engine.py / training.py (layouts, index maps, chain rule) without a GPU."""
@@ -729,6 +739,7 @@ def install_training_emulation(monkeypatch):
     monkeypatch.setattr(_ext, "wgrad_blocked", _emu_wgrad_blocked)
     monkeypatch.setattr(_ext, "coupling_planes_op", _emu_coupling_planes_op)
     monkeypatch.setattr(_ext, "coupling_op", _emu_coupling_op)
+    monkeypatch.setattr(_ext, "lu_grad_finish", _emu_lu_grad_finish)
     monkeypatch.setattr(FlowEngine, "_check_input", lambda self, x: x.contiguous().float())
     monkeypatch.setattr(FlowEngine, "_execute_plain",
                         lambda self, plan, x, out, context: run_plan(self, plan, x, out, context, dtype=torch.float64))

@@ -276,3 +276,27 @@ def test_engine_prep_matches_oracle(case):
         assert (r["M"].cpu() - M_ref).abs().max().item() <= 1e-11 * max(1.0, M_ref.abs().max().item())
         assert (r["Minv"].cpu() - Minv_ref).abs().max().item() <= 1e-9 * max(1.0, Minv_ref.abs().max().item())
         assert (r["b"].cpu() - b_ref).abs().max().item() <= 1e-12 * max(1.0, b_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("with_m", [False, True])
+@pytest.mark.parametrize("n,D", [(1, 5), (3, 33), (4, 784)])
+def test_lu_grad_finish_is_the_torch_formulation(n, D, with_m):
+    """usf_lu_grad_finish_f64 == tril(dL + TL, -1), triu(dU) + diag(c / U_jj) + triu(TU) rounded once to fp32
+    (what Flow.fit's autograd derives through transforms.py:1271-1320), garbage in the unwanted triangles included"""
+    ext = _ext()
+    g = torch.Generator().manual_seed(n * D)
+    r = lambda *shape: torch.randn(*shape, generator=g, dtype=torch.float64)
+    dL, dU, TL, TU, c, tri = r(n, D, D), r(n, D, D), r(n, D, D), r(n, D, D), r(n), r(2 * n, D, D)
+    dL = dL + torch.full_like(dL, 1e30).triu()                 # never read: the upper triangle (diagonal included) of dL
+    dU = dU + torch.full_like(dU, 1e30).tril(-1)               # ... the strictly lower triangle of dU
+    oL = torch.full((n * D * D,), 7.0, device=DEV)
+    oU = torch.full((n * D * D,), 7.0, device=DEV)
+    dev = lambda t: t.to(DEV)
+    ext.lu_grad_finish(dev(dL), dev(dU), dev(TL) if with_m else None, dev(TU) if with_m else None, dev(c), dev(tri), n, D, oL, oU)
+    torch.cuda.synchronize()
+    rl = dL.tril(-1) + (TL.tril(-1) if with_m else 0.0)
+    ru = dU.triu() + torch.diag_embed(c[:, None] / tri[1::2].diagonal(dim1=1, dim2=2))
+    if with_m:
+        ru = ru + TU.triu()
+    assert torch.equal(oL.cpu().view(n, D, D), rl.float())
+    assert torch.equal(oU.cpu().view(n, D, D), ru.float())

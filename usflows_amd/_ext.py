@@ -261,6 +261,7 @@ SYMBOLS = {
                                _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                C.c_double, C.c_double, C.c_int32, C.c_void_p]),
     "usf_householder_f64": (C.c_int, [_fp, _fp, C.c_int64, C.c_int64, _fp, C.c_void_p]),
+    "usf_lu_grad_finish_f64": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int64, _fp, _fp, C.c_void_p]),
     "usf_pack_weight_f32": (C.c_int, [_fp, C.c_int32, C.c_int64, C.c_int32, _fp, C.c_int64, _fp, C.c_int64,
                                       _fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_void_p]),
     "usf_wgrad_f32": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _fp, C.c_int64,
@@ -1379,6 +1380,12 @@ def matmul_f64(A: torch.Tensor, B: torch.Tensor, transA=False, transB=False, tri
     out = torch.empty(M, N, dtype=torch.float64, device=A.device)
     gemm_f64(A, B, out, M=M, N=N, K=K, lda=A.shape[1], ldb=B.shape[1], ldc=N, transA=transA, transB=transB, tri=tri)
     return out
+
+
+def lu_grad_finish(dL, dU, TL, TU, c, tri, n, D, out_L, out_U):
+    """tril(dL + TL, -1) and triu(dU + TU) + diag(c / diag U) of n blocks, fp64 -> the fp32 gradient arena, one launch"""
+    _launch("usf_lu_grad_finish_f64", (dL.data_ptr(), dU.data_ptr(), ptr(TL), ptr(TU), c.data_ptr(), tri.data_ptr(), n, D,
+                                       out_L.data_ptr(), out_U.data_ptr(), current_stream(dL.device)), (dL, dU, TL, TU, c, tri, out_L, out_U))
 
 
 def householder(w_0, vk, out=None):

@@ -63,6 +63,8 @@ int linear_variant(const usf_linear_desc* d);
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 int coupling_max_width();
 int coupling_padded_width(int h);
+int lu_grad_finish(const double* dL, const double* dU, const double* TL, const double* TU, const double* c, const double* tri,
+                   int64_t n, int64_t D, float* oL, float* oU, hipStream_t stream);
 int base_tables(int32_t base, const float* loc, const float* scale, int64_t D, float* tab, int64_t stride, hipStream_t stream);
 int base_logprob(const float* z, int64_t ldz, int64_t M, int64_t D, int32_t base, const float* loc,
                  const float* scale, float logdet_const, const double* logdet_dev, float* logp, double* sum_out,
@@ -292,6 +294,10 @@ int usf_gemm_f64(const double* A, int64_t lda, int64_t strideA, int32_t transA, 
                        tri, (hipStream_t)stream);
 }
 
+int usf_lu_grad_finish_f64(const double* dL, const double* dU, const double* TL, const double* TU, const double* c,
+                           const double* tri, int64_t n, int64_t D, float* dL_out, float* dU_out, usf_stream_t stream) {
+  return usf::lu_grad_finish(dL, dU, TL, TU, c, tri, n, D, dL_out, dU_out, (hipStream_t)stream);
+}
 int usf_householder_f64(const float* w_0, const float* vk, int64_t nvs, int64_t D, double* out, usf_stream_t stream) {
   return usf::householder(w_0, vk, nvs, D, out, (hipStream_t)stream);
 }

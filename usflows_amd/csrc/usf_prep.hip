@@ -655,6 +655,43 @@ int lu_prepare(const usf_lu_prep_desc* d, hipStream_t stream) {
   return 0;
 }
 
+// dL_out = tril(dL + TL, -1), dU_out = triu(dU + TU) + diag(c / diag U): one thread per element pair (usf_lu_grad_finish_f64)
+__global__ __launch_bounds__(256) void lu_grad_finish_kernel(const double* __restrict__ dL, const double* __restrict__ dU,
+                                                            const double* __restrict__ TL, const double* __restrict__ TU,
+                                                            const double* __restrict__ c, const double* __restrict__ tri, int64_t D,
+                                                            float* __restrict__ oL, float* __restrict__ oU) {
+  const int64_t i = blockIdx.y;
+  const int64_t DD = D * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < DD; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / D, cn = e - r * D;
+    const int64_t o = i * DD + e;
+    float vl = 0.f, vu = 0.f;
+    if (r > cn) {
+      double v = dL[o];
+      if (TL) v += TL[o];
+      vl = (float)v;
+    } else {
+      double v = dU[o];
+      if (r == cn) v += c[i] / tri[(2 * i + 1) * DD + e];       // (the addition order of the torch formulation: triu, + diagonal term, + TU)
+      if (TU) v += TU[o];
+      vu = (float)v;
+    }
+    oL[o] = vl;
+    oU[o] = vu;
+  }
+}
+
+int lu_grad_finish(const double* dL, const double* dU, const double* TL, const double* TU, const double* c, const double* tri,
+                   int64_t n, int64_t D, float* oL, float* oU, hipStream_t stream) {
+  if (n < 0 || D <= 0 || n > 65535 || D > 46340) { set_error("usf_lu_grad_finish_f64: bad sizes"); return -2; }
+  if (n == 0) return 0;
+  if (!dL || !dU || !c || !tri || !oL || !oU || (!TL) != (!TU)) { set_error("usf_lu_grad_finish_f64: null pointer (TL and TU: both or neither)"); return -1; }
+  int64_t bx = (D * D + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  lu_grad_finish_kernel<<<dim3((unsigned)bx, (unsigned)n), 256, 0, stream>>>(dL, dU, TL, TU, c, tri, D, oL, oU);
+  return check_launch("usf_lu_grad_finish_f64");
+}
+
 int householder(const float* w0, const float* vk, int64_t nvs, int64_t D, double* out, hipStream_t stream) {
   if (!w0 || !out || D <= 0 || nvs < 0 || (nvs > 0 && !vk) || D > 8000) {
     set_error("usf_householder_f64: bad arguments");

@@ -1354,22 +1354,19 @@ class TrainPath:
         if "coef" not in stacks:        # built once: a host-to-device copy here would drain the stream every step
             stacks["coef"] = torch.tensor([coef.get(id(b_), 0.0) for b_ in blocks], dtype=torch.float64, device=dev)
         c = stacks["coef"] * Gsum
-        Udiag = out["tri"][1::2].diagonal(dim1=1, dim2=2)                                        # U_jj (of U^T)
-        dU = dU.triu()
-        dU.diagonal(dim1=1, dim2=2).add_(c[:, None] / Udiag)                                     # transforms.py:1303-1320
-        dL = dL.tril(-1)
+        TL = TU = None
         if dM_lu is not None:
             # the M = L U usages:  dL += tril(G U^T, -1),  dU += triu(L^T G)
             tri = out["tri"]                                    # [2n, D, D]: L at even, U^T at odd rows
             TL, TU = tmp[0], stacks.setdefault("T2", f64())
             _ext.gemm_f64(dM_lu, tri, TL, strideA=DD, strideB=2 * DD, b_off=DD, tri=16, **bat)    # tril(G U^T)
             _ext.gemm_f64(tri, dM_lu, TU, transA=True, strideA=2 * DD, strideB=DD, tri=8, **bat)  # triu(L^T G)
-            dL = dL + TL.tril(-1)
-            dU = dU + TU.triu()
+        # tril(dL + TL, -1), triu(dU + TU) + diag(c / U_jj) (transforms.py:1303-1320) and the converting copies into the fp32
+        # gradient arena: one pass (usf_lu_grad_finish_f64) instead of eight over [n, D, D] tensors
         base, _n = arena["lu_views"][0]
         flat = arena["flat"]
-        flat[base: base + n * DD].view(n, D, D).copy_(dL)
-        flat[base + n * DD: base + 2 * n * DD].view(n, D, D).copy_(dU)
+        _ext.lu_grad_finish(dL, dU, TL, TU, c.contiguous(), out["tri"], n, D, flat[base: base + n * DD],
+                            flat[base + n * DD: base + 2 * n * DD])
         flat[base + 2 * n * DD: base + 2 * n * DD + n * D].view(n, D).copy_(db_lu)
         for lu in ch["lus"]:
             for name in ("L_raw", "U_raw", "bias_vector"):
