@@ -1320,7 +1320,10 @@ class TrainPath:
                         G[u["row"]] = self._unfold_head(u["pre_scale"], G[u["row"]], gs[u["row"]], b_t[u["row"]])
                     G[u["row"]] = self._scale_grad(u["pre_scale"], Minv_t[u["row"]], G[u["row"]], Gsum, grads)
         dMinv_t = G - gs[:, :, None] * b_t[:, None, :]
-        db_t = -torch.bmm(Minv_t.transpose(1, 2), gs.unsqueeze(2)).squeeze(2)
+        # db_t = -M_t^-T gsum, one row-vector product per block on the library's batched fp64 kernel (no BLAS call on the path)
+        db_t = torch.empty(n, D, dtype=torch.float64, device=dev)
+        _ext.gemm_f64(gs.contiguous(), Minv_t.contiguous(), db_t, batch=n, M=1, N=D, K=D, lda=D, ldb=D, ldc=D, strideA=D, strideB=DD,
+                      strideC=D, alpha=-1.0)
         dM_t = None
         if "GM" in stacks:
             dM_t = stacks["GM"][:n].double()
