@@ -102,6 +102,10 @@ __device__ __forceinline__ void tiny_store4(const TinySeg& s, float* lds, const 
 // One wave per SIMD and nothing to hide behind: the kernel's time is its instruction count.  The layers run on
 // v_mfma_f32_16x16x4_f32 (a 32-row x 16-unit tile per wave: K / 4 matrix instructions and two LDS words per lane each), the weight
 // images are staged as 16-byte groups, and every staging loop runs only the iterations its segment has.
+// NW: 16-byte groups per thread of the largest weight image, NS: elements per thread of the largest row segment (inputs, residual,
+// gates) -- the staging code is straight-line and runs once per launch, cold: the small instantiation (<= 32 x 32 layers, the
+// live flat configuration) is a third of the large one's code
+template <int NW, int NS>
 __global__ __launch_bounds__(256) void coupling_tiny_kernel(const TinyArgs p) {
   extern __shared__ __attribute__((aligned(16))) float tl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,17 +113,17 @@ __global__ __launch_bounds__(256) void coupling_tiny_kernel(const TinyArgs p) {
   const int row0 = blockIdx.x * TINY_ROWS;
   const bool gated = p.act == USF_ACT_GATE;
   // ---- everything the layer reads, ONE batch of loads: the arithmetic of a layer is far too short to hide a second round trip ----
-  f32x4 vw[4][TINY_NV4];
-  float vx[8], vz[8], vb[4][1], vg[3][8], vc[1], vwc[1], vbc[1];
+  f32x4 vw[4][NW];
+  float vx[NS], vz[NS], vb[4][1], vg[3][NS], vc[1], vwc[1], vbc[1];
 #pragma unroll
   for (int l = 0; l < 4; ++l)
-    if (l <= p.nh) { tiny_load4<TINY_NV4>(p.w[l], vw[l]); tiny_load<1>(p.b[l], row0, p.M, vb[l]); }
-  tiny_load<8>(p.x0, row0, p.M, vx);
-  tiny_load<8>(p.zres, row0, p.M, vz);
+    if (l <= p.nh) { tiny_load4<NW>(p.w[l], vw[l]); tiny_load<1>(p.b[l], row0, p.M, vb[l]); }
+  tiny_load<NS>(p.x0, row0, p.M, vx);
+  tiny_load<NS>(p.zres, row0, p.M, vz);
   if (gated) {
 #pragma unroll
     for (int l = 0; l < 3; ++l)
-      if (l < p.nh) tiny_load<8>(p.g[l], row0, p.M, vg[l]);
+      if (l < p.nh) tiny_load<NS>(p.g[l], row0, p.M, vg[l]);
   }
   if (p.has_ctx) { tiny_load<1>(p.ctx, row0, p.M, vc); tiny_load<1>(p.wctx, row0, p.M, vwc); tiny_load<1>(p.bctx, row0, p.M, vbc); }
   // zero the padded images while the loads fly (weight rows beyond the layer's width, inputs beyond K, activations beyond the widths)
@@ -127,13 +131,13 @@ __global__ __launch_bounds__(256) void coupling_tiny_kernel(const TinyArgs p) {
   __syncthreads();
 #pragma unroll
   for (int l = 0; l < 4; ++l)
-    if (l <= p.nh) { tiny_store4<TINY_NV4>(p.w[l], tl, vw[l]); tiny_store<1>(p.b[l], tl, vb[l]); }
-  tiny_store<8>(p.x0, tl, vx);
-  tiny_store<8>(p.zres, tl, vz);
+    if (l <= p.nh) { tiny_store4<NW>(p.w[l], tl, vw[l]); tiny_store<1>(p.b[l], tl, vb[l]); }
+  tiny_store<NS>(p.x0, tl, vx);
+  tiny_store<NS>(p.zres, tl, vz);
   if (gated) {
 #pragma unroll
     for (int l = 0; l < 3; ++l)
-      if (l < p.nh) tiny_store<8>(p.g[l], tl, vg[l]);
+      if (l < p.nh) tiny_store<NS>(p.g[l], tl, vg[l]);
   }
   if (p.has_ctx) { tiny_store<1>(p.ctx, tl, vc); tiny_store<1>(p.wctx, tl, vwc); tiny_store<1>(p.bctx, tl, vbc); }
   __syncthreads();
@@ -281,7 +285,11 @@ int coupling_tiny_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   a.sign = d->sign; a.slope = d->slope; a.act = d->act;
   if ((int64_t)off * 4 > 64 * 1024) { set_error("usf_coupling_additive_f32: tiny-layer layout exceeds 64 KB of LDS"); return -3; }
   const dim3 grid((unsigned)((d->M + TINY_ROWS - 1) / TINY_ROWS)), block(256);
-  hipLaunchKernelGGL(coupling_tiny_kernel, grid, block, (size_t)off * sizeof(float), stream, a);
+  bool small = a.x0.n <= 1024 && a.zres.n <= 1024;
+  for (int l = 0; l <= a.nh; ++l) small = small && a.w[l].n <= 256;
+  for (int l = 0; l < a.nh; ++l) small = small && a.g[l].n <= 1024;
+  if (small) hipLaunchKernelGGL((coupling_tiny_kernel<1, 4>), grid, block, (size_t)off * sizeof(float), stream, a);
+  else hipLaunchKernelGGL((coupling_tiny_kernel<TINY_NV4, 8>), grid, block, (size_t)off * sizeof(float), stream, a);
   return check_launch("usf_coupling_additive_f32(tiny)");
 }
 
