@@ -172,6 +172,10 @@ typedef struct usf_coupling_desc {
 } usf_coupling_desc;
 
 int usf_coupling_additive_f32(const usf_coupling_desc* d, usf_stream_t stream);
+/* which kernel usf_coupling_additive_f32 launches for this descriptor (nothing is launched, no pointer is dereferenced):
+ * 3 the tiny-layer kernel (M <= 256, segments and hidden widths <= 64, the layer's images in 64 KB of LDS: usf_coupling_tiny.hip),
+ * 2 the bf16x3 kernel, 1 the exact-f32 MFMA kernel, 0 for a NULL descriptor */
+int usf_coupling_variant(const usf_coupling_desc* d);
 int usf_coupling_max_width(void);       /* widest hidden layer the fused kernel accepts */
 int usf_coupling_padded_width(int h);   /* Hp of the padding contract for hidden width h (-1 if unsupported) */
 

@@ -73,3 +73,42 @@ def test_integration_md_ctypes_stub_matches_the_c_structs():
     exec(code, ns)
     assert ctypes.sizeof(ns["LinearDesc"]) == ctypes.sizeof(_ext.LinearDesc)
     assert [f[0] for f in ns["LinearDesc"]._fields_] == [f[0] for f in _ext.LinearDesc._fields_]
+
+
+def test_tiny_coupling_rule_of_the_engine_is_the_librarys():
+    """FlowEngine.tiny_coupling restates usf_coupling_tiny.hip's eligibility rule (a plan that sets hidden_out on a descriptor the
+    library then serves with another kernel is rejected at run time): the two agree over a sweep of shapes, for the forward
+    descriptor and for the backward one (segments swapped, hidden layers reversed).  Host-only: usf_coupling_variant launches
+    nothing and reads no pointer."""
+    import itertools
+    from usflows_amd import _ext
+    from usflows_amd.engine import FlowEngine
+    lib = _ext.load()
+
+    def variant(B, n_pass, hidden, n_trans):
+        d = _ext.CouplingDesc()
+        d.z = d.out = 0x10000
+        d.ldz = d.ldo = 512
+        d.M, d.off_pass, d.n_pass, d.off_trans, d.n_trans = B, 0, n_pass, 256, n_trans
+        d.n_hidden = len(hidden)
+        k = n_pass
+        r32 = lambda v: (v + 31) // 32 * 32
+        for i, h in enumerate(hidden):
+            d.hidden[i] = h
+        d.W_in, d.ldw_in, d.b_in = 0x20000, r32(n_pass), 0x30000
+        for i in range(1, len(hidden)):
+            d.W_hid[i - 1], d.ldw_hid[i - 1], d.b_hid[i - 1] = 0x40000 + 0x10000 * i, 64, 0x30000
+        d.W_out, d.ldw_out, d.b_out = 0x80000, 64, 0x30000
+        d.sign, d.slope, d.act = 1.0, 0.01, _ext.ACT_LEAKY_RELU
+        return lib.usf_coupling_variant(d)
+
+    n_checked = n_tiny = 0
+    for B, n_pass, n_trans, hidden in itertools.product([1, 32, 256, 257, 4096], [4, 8, 52, 64, 68], [4, 5, 48, 64, 100],
+                                                        [[32], [32, 32], [64, 64], [64, 64, 64], [7, 5], [65], [48, 32, 40]]):
+        cp = dict(hidden=hidden, pass_n=n_pass, tr_n=n_trans)
+        py = FlowEngine.tiny_coupling(None, cp, B)
+        both = variant(B, n_pass, hidden, n_trans) == 3 and variant(B, n_trans, hidden[::-1], n_pass) == 3
+        assert py == both, (B, n_pass, n_trans, hidden, py, both)
+        n_checked += 1
+        n_tiny += int(py)
+    assert n_checked > 800 and 20 < n_tiny < n_checked

@@ -198,6 +198,7 @@ SYMBOLS = {
     "usf_gemm_planes_variant": (C.c_int, [C.POINTER(GemmPlanesDesc)]),
     "usf_coupling_planes": (C.c_int, [C.POINTER(CouplingPlanesDesc), C.c_void_p]),
     "usf_coupling_additive_f32": (C.c_int, [C.POINTER(CouplingDesc), C.c_void_p]),
+    "usf_coupling_variant": (C.c_int, [C.POINTER(CouplingDesc)]),
     "usf_coupling_max_width": (C.c_int, []),
     "usf_coupling_padded_width": (C.c_int, [C.c_int]),
     "usf_base_logprob_f32": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, C.c_float,

@@ -61,6 +61,7 @@ void set_error(const char* fmt, ...) {
 int linear_dispatch(const usf_linear_desc* d, hipStream_t stream);
 int linear_variant(const usf_linear_desc* d);
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream);
+int coupling_variant(const usf_coupling_desc* d);
 int coupling_max_width();
 int coupling_padded_width(int h);
 int lu_grad_finish(const double* dL, const double* dU, const double* TL, const double* TU, const double* c, const double* tri,
@@ -238,6 +239,7 @@ int usf_gemm_planes_bf16x3(const usf_gemm_planes_desc* d, usf_stream_t stream) {
 
 int usf_coupling_planes(const usf_coupling_planes_desc* d, usf_stream_t stream) { return usf::coupling_planes(d, (hipStream_t)stream); }
 int usf_gemm_planes_variant(const usf_gemm_planes_desc* d) { return usf::gemm_planes_variant(d); }
+int usf_coupling_variant(const usf_coupling_desc* d) { return usf::coupling_variant(d); }
 int usf_coupling_max_width(void) { return usf::coupling_max_width(); }
 int usf_coupling_padded_width(int h) { return usf::coupling_padded_width(h); }
 

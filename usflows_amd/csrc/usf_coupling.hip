@@ -351,6 +351,12 @@ int coupling_bf16x3_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 bool coupling_tiny_eligible(const usf_coupling_desc* d);       // usf_coupling_tiny.hip
 int coupling_tiny_dispatch(const usf_coupling_desc* d, hipStream_t stream);
 
+int coupling_variant(const usf_coupling_desc* d) {
+  if (!d) return 0;
+  if (d->M >= 0 && d->n_pass > 0 && d->n_trans > 0 && d->n_hidden >= 1 && d->n_hidden <= 3 && coupling_tiny_eligible(d)) return 3;
+  return coupling_bf16x3_eligible(d) ? 2 : 1;
+}
+
 int coupling_dispatch(const usf_coupling_desc* d, hipStream_t stream) {
   if (!d) { set_error("usf_coupling_additive_f32: null descriptor"); return -1; }
   if (d->M < 0 || d->M > 0x7fffffff || d->n_pass <= 0 || d->n_trans <= 0 || d->n_hidden < 1 || d->n_hidden > 3) {
