@@ -991,7 +991,8 @@ int usf_mfma_probe(const float* src1024, float* sink, int64_t iters, int64_t blo
 /* Measurement aid (bench.py: roofline.clock_mhz): while dev_buf2 (device memory, two 64-bit counters, zeroed by the caller) is
  * set, every block of usf_gemm_planes_bf16x3's kernel and of usf_mfma_probe adds its lifetime to it -- [0] in shader-clock cycles
  * (s_memtime), [1] in ticks of the constant 100 MHz counter (s_memrealtime): 100 MHz x [0] / [1] is the clock the matrix cores ran
- * at under that kernel (the nominal peaks assume 2400 MHz).  NULL: off (the default; the kernels then read no counter). */
+ * at under that kernel (the nominal peaks assume 2400 MHz).  NULL: off (the default; the kernels then read no counter).
+ * One process-wide setting (not per device, not synchronised with launches in flight): set it, launch, synchronise, clear it. */
 int usf_set_clock_buffer(unsigned long long* dev_buf2);
 
 /* Tuning knobs of the kernels' host code (A/B switches, cross-overs): named integers, preset on first use from the environment
